@@ -1,0 +1,354 @@
+"""oracle/salience_ref.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU (PyTorch fp32/fp64) restatement of the Salience-DETR encoder hot path as
+plain functions over a ``state_dict`` (same key names as the reference's
+``SalienceTransformer``).  Each function cites the reference lines it follows.
+It is the parity checker for the HIP product path and the timed ``cpu_baseline``
+("port") of bench.py; the product package never imports it.
+
+Pinned against tests/golden/*.npz, which were produced by running the IMPORTED
+reference (tests/golden/make_golden.py): tests/test_oracle_golden.py asserts
+this file reproduces every captured intermediate (score maps, token budgets,
+selected indices, per-layer outputs, final memory) to ~1e-5.
+
+Tie rule (the reference leaves it to torch.topk/torch.sort, unspecified):
+equal scores are ordered lower-index-first (stable descending sort).
+"""
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import msda_c
+
+SD = Dict[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------- F0 helpers
+def flatten_levels(xs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """models/bricks/base_transformer.py:22-27 -- [B,(C),H,W] x L -> [B,S,(C)]."""
+    out = torch.cat([x.flatten(-2) for x in xs], -1)
+    return out.transpose(1, 2).contiguous() if out.ndim == 3 else out
+
+
+def level_pos_embed(sd: SD, pos: Sequence[torch.Tensor]) -> torch.Tensor:
+    """base_transformer.py:29-33."""
+    le = sd["level_embeds"]
+    return flatten_levels([p + le[l].view(1, -1, 1, 1) for l, p in enumerate(pos)])
+
+
+def valid_ratio(mask: torch.Tensor) -> torch.Tensor:
+    """base_transformer.py:48-56 -- (w, h) fraction of valid pixels along row 0 / column 0."""
+    _, h, w = mask.shape
+    vh = (~mask[:, :, 0]).sum(1).float() / h
+    vw = (~mask[:, 0, :]).sum(1).float() / w
+    return torch.stack([vw, vh], -1)
+
+
+def level_misc(masks: Sequence[torch.Tensor]):
+    """base_transformer.py:35-46."""
+    shapes = torch.tensor([tuple(m.shape[-2:]) for m in masks], dtype=torch.int64)
+    sizes = shapes.prod(1)
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    vr = torch.stack([valid_ratio(m) for m in masks], 1)
+    return shapes, lsi, vr
+
+
+def sine_position_embedding(mask: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
+                            scale: float = 2 * math.pi, eps: float = 1e-6, offset: float = -0.5):
+    """models/bricks/position_encoding.py:48-67 with normalize=True (config: resnet50_800_1333.py:32)."""
+    not_mask = (~mask).to(torch.float32)
+    y = not_mask.cumsum(1)
+    x = not_mask.cumsum(2)
+    y = (y + offset) / (y[:, -1:, :] + eps) * scale
+    x = (x + offset) / (x[:, :, -1:] + eps) * scale
+    i = torch.arange(num_pos_feats)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_pos_feats)
+    px = x[..., None] / dim_t
+    py = y[..., None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).permute(0, 3, 1, 2).contiguous()
+
+
+def linear(sd: SD, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def layer_norm(sd: SD, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+
+def backbone_output_memory(sd: SD, memory: torch.Tensor, mask_flat: torch.Tensor, shapes: torch.Tensor):
+    """base_transformer.py:74-112, first return value only (salience_transformer.py:112-114).
+
+    A token survives iff it is not padding and its proposal (cx, cy, w, h) lies in (0.01, 0.99).
+    """
+    n = memory.shape[0]
+    valid = []
+    cur = 0
+    for lvl, (h, w) in enumerate(shapes.tolist()):
+        m = mask_flat[:, cur:cur + h * w].view(n, h, w)
+        vh = (~m[:, :, 0]).sum(1).view(n, 1, 1).float()
+        vw = (~m[:, 0, :]).sum(1).view(n, 1, 1).float()
+        gy = torch.arange(h, dtype=torch.float32).view(1, h, 1)
+        gx = torch.arange(w, dtype=torch.float32).view(1, 1, w)
+        cx = ((gx + 0.5) / vw).expand(n, h, w)
+        cy = ((gy + 0.5) / vh).expand(n, h, w)
+        wh = 0.05 * 2.0 ** lvl
+        ok = (cx > 0.01) & (cx < 0.99) & (cy > 0.01) & (cy < 0.99) & (0.01 < wh < 0.99)
+        valid.append(ok.reshape(n, h * w))
+        cur += h * w
+    valid = torch.cat(valid, 1)
+    keep = (~mask_flat) & valid
+    x = memory * keep[..., None].to(memory.dtype)
+    return layer_norm(sd, "enc_output_norm", linear(sd, "enc_output", x))
+
+
+# ----------------------------------------------------------------------------- F1 mask predictor
+def mask_predictor(sd: SD, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """salience_transformer.py:16-47.  The global half is the mean over ALL tokens of the level."""
+    z = F.gelu(linear(sd, prefix + ".layer1.1", layer_norm(sd, prefix + ".layer1.0", x)))
+    h = z.shape[-1] // 2
+    z_local, z_global = z[..., :h], z[..., h:]
+    z_global = z_global.mean(1, keepdim=True).expand(-1, z.shape[1], -1)
+    z = torch.cat([z_local, z_global], -1)
+    z = F.gelu(linear(sd, prefix + ".layer2.0", z))
+    z = F.gelu(linear(sd, prefix + ".layer2.2", z))
+    return linear(sd, prefix + ".layer2.4", z)
+
+
+# ----------------------------------------------------------------------------- F2 / F3 filtering
+def token_budgets(masks: Sequence[torch.Tensor], level_filter_ratio: torch.Tensor):
+    """salience_transformer.py:116-121 (fp32 product truncated by .int())."""
+    valid = torch.stack([(~m).sum((1, 2)) for m in masks], -1)
+    focus = (valid * level_filter_ratio.to(torch.float32)).int()
+    level_token_nums = focus.max(0)[0]
+    return focus.sum(-1), level_token_nums, valid
+
+
+def topk_desc_stable(score: torch.Tensor, k: int):
+    s, i = torch.sort(score, dim=1, descending=True, stable=True)
+    return s[:, :k], i[:, :k]
+
+
+def level_filtering(sd: SD, bom: torch.Tensor, mask_flat: torch.Tensor, shapes: torch.Tensor,
+                    lsi: torch.Tensor, level_token_nums: torch.Tensor, predictor_prefix="enc_mask_predictor"):
+    """salience_transformer.py:123-154 -- high level -> low level score prediction + per-level top-k."""
+    B = bom.shape[0]
+    L = shapes.shape[0]
+    alpha = sd["alpha"]
+    score_maps: List[Optional[torch.Tensor]] = [None] * L
+    level_inds: List[Optional[torch.Tensor]] = [None] * L
+    level_score: List[Optional[torch.Tensor]] = [None] * L
+    score = None
+    for lvl in range(L - 1, -1, -1):
+        h, w = shapes[lvl].tolist()
+        s0 = int(lsi[lvl])
+        mem = bom[:, s0:s0 + h * w]
+        m = mask_flat[:, s0:s0 + h * w]
+        if lvl != L - 1:
+            up = F.interpolate(score, size=(h, w), mode="bilinear", align_corners=True)
+            up = up.view(B, 1, h * w).transpose(1, 2)
+            mem = mem + mem * up * alpha[lvl]
+        sc = mask_predictor(sd, predictor_prefix, mem)  # [B, hw, 1]
+        valid_score = sc.squeeze(-1).masked_fill(m, sc.min())
+        score = sc.transpose(1, 2).reshape(B, 1, h, w)
+        ls, li = topk_desc_stable(valid_score, int(level_token_nums[lvl]))
+        score_maps[lvl] = score
+        level_inds[lvl] = li + s0
+        level_score[lvl] = ls
+    return score_maps, level_inds, level_score
+
+
+def salience_filtering(score_maps, level_inds, level_score, mask_flat, layer_filter_ratio: torch.Tensor):
+    """salience_transformer.py:156-168 -- global sort + per-layer prefixes + foreground score."""
+    sel_score = torch.cat(level_score, 1)
+    order = torch.sort(sel_score, dim=1, descending=True, stable=True)[1]
+    sel_inds = torch.cat(level_inds, 1).gather(1, order)
+    n = sel_inds.shape[1]
+    counts = (n * layer_filter_ratio.to(torch.float32)).to(torch.int64)
+    foreground_inds = [sel_inds[:, :int(r)] for r in counts]
+    fg = flatten_levels(score_maps).squeeze(-1)
+    fg = fg.masked_fill(mask_flat, fg.min())
+    return foreground_inds, fg
+
+
+# ----------------------------------------------------------------------------- M2 / M4 MSDA
+def msda_core_c(value, shapes, lsi, loc, aw):
+    """Closed-form op via the plain-C oracle (forward only)."""
+    out = msda_c.msda_forward(value.detach().numpy(), shapes.numpy(), lsi.numpy(),
+                              loc.detach().numpy(), aw.detach().numpy())
+    return torch.from_numpy(out)
+
+
+def msda_core_torch(value, shapes, lsi, loc, aw):
+    """Differentiable closed-form restatement (ms_deform_im2col_cuda.cuh:22-73, 226-288)
+    used where autograd is needed (backward oracle for the module-level path)."""
+    B, Nv, M, D = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    out = value.new_zeros(B, Nq, M, D)
+    bidx = torch.arange(B).view(B, 1, 1, 1)
+    midx = torch.arange(M).view(1, 1, M, 1)
+    for l in range(L):
+        H, W = shapes[l].tolist()
+        x = loc[:, :, :, l, :, 0] * W - 0.5
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        inside = (y > -1) & (x > -1) & (y < H) & (x < W)
+        x0 = torch.floor(x)
+        y0 = torch.floor(y)
+        lx, ly = x - x0, y - y0
+        x0, y0 = x0.long(), y0.long()
+        acc = 0
+        for dy, dx, wgt in ((0, 0, (1 - ly) * (1 - lx)), (0, 1, (1 - ly) * lx),
+                            (1, 0, ly * (1 - lx)), (1, 1, ly * lx)):
+            yy, xx = y0 + dy, x0 + dx
+            ok = inside & (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+            idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)) + int(lsi[l])
+            v = value[bidx, idx, midx]  # [B,Nq,M,P,D]
+            acc = acc + v * (wgt * ok.to(value.dtype))[..., None]
+        out = out + (acc * aw[:, :, :, l, :, None]).sum(3)
+    return out.reshape(B, Nq, M * D)
+
+
+def sampling_locations(ref, offsets, shapes, num_points):
+    """ms_deform_attn.py:339-355."""
+    if ref.shape[-1] == 2:
+        norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(offsets.dtype)
+        return ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    if ref.shape[-1] == 4:
+        return ref[:, :, None, :, None, :2] + offsets / num_points * ref[:, :, None, :, None, 2:] * 0.5
+    raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(ref.shape[-1]))
+
+
+def msda_module(sd: SD, prefix: str, query, ref, value, shapes, lsi, pad_mask, heads: int, levels: int,
+                points: int, core=msda_core_c):
+    """ms_deform_attn.py:286-377."""
+    B, Nq, E = query.shape
+    Nv = value.shape[1]
+    v = linear(sd, prefix + ".value_proj", value)
+    if pad_mask is not None:
+        v = v.masked_fill(pad_mask[..., None], 0.0)
+    v = v.view(B, Nv, heads, E // heads)
+    off = linear(sd, prefix + ".sampling_offsets", query).view(B, Nq, heads, levels, points, 2)
+    aw = linear(sd, prefix + ".attention_weights", query).view(B, Nq, heads, levels * points)
+    aw = aw.softmax(-1).view(B, Nq, heads, levels, points)
+    loc = sampling_locations(ref, off, shapes, points)
+    out = core(v.contiguous(), shapes, lsi, loc.contiguous(), aw.contiguous())
+    return linear(sd, prefix + ".output_proj", out)
+
+
+# ----------------------------------------------------------------------------- E1-E4 encoder
+def mha_self(sd: SD, prefix: str, qk: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True) forward, q = k = qk, value = v
+    (salience_transformer.py:371-376), restated."""
+    B, N, E = qk.shape
+    hd = E // heads
+    w, b = sd[prefix + ".in_proj_weight"], sd[prefix + ".in_proj_bias"]
+    q = F.linear(qk, w[:E], b[:E]).view(B, N, heads, hd).transpose(1, 2)
+    k = F.linear(qk, w[E:2 * E], b[E:2 * E]).view(B, N, heads, hd).transpose(1, 2)
+    vv = F.linear(v, w[2 * E:], b[2 * E:]).view(B, N, heads, hd).transpose(1, 2)
+    att = (q * (1.0 / math.sqrt(hd))) @ k.transpose(-1, -2)
+    o = att.softmax(-1) @ vv
+    o = o.transpose(1, 2).reshape(B, N, E)
+    return linear(sd, prefix + ".out_proj", o)
+
+
+def encoder_reference_points(shapes: torch.Tensor, valid_ratios: torch.Tensor) -> torch.Tensor:
+    """salience_transformer.py:418-432 -> [B, S, L, 2]."""
+    refs = []
+    for lvl, (h, w) in enumerate(shapes.tolist()):
+        ry = (torch.arange(h, dtype=torch.float32) + 0.5).view(h, 1).expand(h, w).reshape(-1)
+        rx = (torch.arange(w, dtype=torch.float32) + 0.5).view(1, w).expand(h, w).reshape(-1)
+        ry = ry[None] / (valid_ratios[:, None, lvl, 1] * h)
+        rx = rx[None] / (valid_ratios[:, None, lvl, 0] * w)
+        refs.append(torch.stack((rx, ry), -1))
+    ref = torch.cat(refs, 1)
+    return ref[:, :, None] * valid_ratios[:, None]
+
+
+def encoder_layer(sd: SD, prefix: str, query, query_pos, value, ref, shapes, lsi, pad_mask, score_tgt,
+                  fg_pre, heads, levels, points, topk_sa, core=msda_core_c):
+    """salience_transformer.py:353-396 (dropout = 0)."""
+    E = query.shape[-1]
+    mc = score_tgt.max(-1)[0] * fg_pre
+    sel = topk_desc_stable(mc, topk_sa)[1]
+    sel_e = sel.unsqueeze(-1).expand(-1, -1, E)
+    tgt = torch.gather(query, 1, sel_e)
+    pos = torch.gather(query_pos, 1, sel_e)
+    tgt = layer_norm(sd, prefix + ".pre_norm", tgt + mha_self(sd, prefix + ".pre_attention", tgt + pos, tgt, heads))
+    query = query.scatter(1, sel_e, tgt)
+    src2 = msda_module(sd, prefix + ".self_attn", query + query_pos, ref, value, shapes, lsi, pad_mask,
+                       heads, levels, points, core)
+    query = layer_norm(sd, prefix + ".norm1", query + src2)
+    ffn = linear(sd, prefix + ".linear2", F.relu(linear(sd, prefix + ".linear1", query)))
+    return layer_norm(sd, prefix + ".norm2", query + ffn)
+
+
+def learned_background(sd: SD, prefix: str, masks: Sequence[torch.Tensor]) -> torch.Tensor:
+    """position_encoding.py:70-99 applied per level and flattened (salience_transformer.py:488-492)."""
+    outs = []
+    for m in masks:
+        B, h, w = m.shape
+        xe = sd[prefix + ".col_embed.weight"][:w]  # [w, E/2]
+        ye = sd[prefix + ".row_embed.weight"][:h]  # [h, E/2]
+        pos = torch.cat([xe[None].expand(h, w, -1), ye[:, None].expand(h, w, -1)], -1)  # [h,w,E]
+        outs.append(pos.reshape(1, h * w, -1).expand(B, -1, -1))
+    return torch.cat(outs, 1)
+
+
+def encoder(sd: SD, query, shapes, lsi, valid_ratios, query_pos, pad_mask, foreground_score,
+            focus_token_nums, foreground_inds, masks, heads, levels, points, topk_sa, num_layers,
+            prefix="encoder", core=msda_core_c, collect=None):
+    """salience_transformer.py:434-497."""
+    ref_all = encoder_reference_points(shapes, valid_ratios)
+    B, S, Lr, two = ref_all.shape
+    E = query.shape[-1]
+    value = output = query
+    inds_e = None
+    for k in range(num_layers):
+        inds = foreground_inds[k]
+        inds_e = inds.unsqueeze(-1).expand(-1, -1, E)
+        q = torch.gather(output, 1, inds_e)
+        qp = torch.gather(query_pos, 1, inds_e)
+        fg = torch.gather(foreground_score, 1, inds)
+        ref = torch.gather(ref_all.view(B, S, -1), 1, inds.unsqueeze(-1).expand(-1, -1, Lr * two)).view(B, -1, Lr, two)
+        score_tgt = linear(sd, prefix + ".enhance_mcsp", q)
+        q = encoder_layer(sd, f"{prefix}.layers.{k}", q, qp, value, ref, shapes, lsi, pad_mask, score_tgt, fg,
+                          heads, levels, points, topk_sa, core)
+        if collect is not None:
+            collect.append(q)
+        new = []
+        for i in range(B):
+            n = int(focus_token_nums[i])
+            new.append(output[i].scatter(0, inds[i, :n].unsqueeze(-1).expand(-1, E), q[i, :n]))
+        output = torch.stack(new)
+    bg = learned_background(sd, prefix + ".background_embedding", masks).clone()
+    bg.scatter_(1, inds_e, 0)
+    bg = bg * (~pad_mask).unsqueeze(-1)
+    return output + bg
+
+
+# ----------------------------------------------------------------------------- whole hot path
+def hot_path(sd: SD, feats, masks, pos, heads=8, points=4, topk_sa=300, num_layers=6, core=msda_core_c):
+    """SalienceTransformer.forward up to ``memory`` (salience_transformer.py:97-183)."""
+    L = len(feats)
+    feat_flat = flatten_levels(feats)
+    mask_flat = flatten_levels(masks)
+    pos_flat = level_pos_embed(sd, pos)
+    shapes, lsi, vr = level_misc(masks)
+    bom = backbone_output_memory(sd, feat_flat + pos_flat, mask_flat, shapes)
+    focus, level_token_nums, _ = token_budgets(masks, sd["level_filter_ratio"])
+    score_maps, level_inds, level_score = level_filtering(sd, bom, mask_flat, shapes, lsi, level_token_nums)
+    fg_inds, fg_score = salience_filtering(score_maps, level_inds, level_score, mask_flat,
+                                           sd["layer_filter_ratio"])
+    layer_out = []
+    memory = encoder(sd, feat_flat, shapes, lsi, vr, pos_flat, mask_flat, fg_score, focus, fg_inds, masks,
+                     heads, L, points, topk_sa, num_layers, core=core, collect=layer_out)
+    return dict(feat_flatten=feat_flat, mask_flatten=mask_flat, lvl_pos_embed_flatten=pos_flat,
+                spatial_shapes=shapes, level_start_index=lsi, valid_ratios=vr, backbone_output_memory=bom,
+                focus_token_nums=focus, level_token_nums=level_token_nums, score_maps=score_maps,
+                level_inds=level_inds, level_score=level_score, foreground_inds=fg_inds,
+                foreground_score=fg_score, layer_out=layer_out, memory=memory)

@@ -1,0 +1,292 @@
+"""Generate the golden vectors under tests/golden/ from the IMPORTED upstream reference.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's own modules (CPU / pure-PyTorch path; the CUDA
+extension cannot be built here, so the reference itself selects
+``multi_scale_deformable_attn_pytorch``, models/bricks/ms_deform_attn.py:367-370),
+feeds them the deterministic synthetic inputs/weights of
+``salience_detr_amd.synthetic`` and stores inputs + expected outputs as .npz.
+The fixtures are data only; no reference source is copied.
+
+Fixtures:
+  msda_op_cases.npz        M4 core op outputs (fp32 + fp64) and autograd gradients
+  msda_module_cases.npz    M2 module forward, 2-d and 4-d reference points
+  hotpath_small_*.npz      reduced-size SalienceTransformer: filtering + encoder intermediates
+  hotpath_full_digest.npz  full-size (800x1333 & 800x1066, E=256) digests / sub-samples
+"""
+import os
+import sys
+import warnings
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+warnings.filterwarnings("ignore")
+
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+
+from models.bricks.ms_deform_attn import (  # noqa: E402
+    MultiScaleDeformableAttention,
+    multi_scale_deformable_attn_pytorch,
+)
+from models.bricks.position_encoding import PositionEmbeddingSine  # noqa: E402
+from models.bricks.salience_transformer import (  # noqa: E402
+    SalienceTransformer,
+    SalienceTransformerEncoder,
+    SalienceTransformerEncoderLayer,
+)
+
+from salience_detr_amd import synthetic as syn  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------------- op level
+def op_case(name, B, M, D, level_shapes, P, Nq, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    L = len(level_shapes)
+    shapes = torch.tensor(level_shapes, dtype=torch.int64)
+    sizes = shapes.prod(1)
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    Nv = int(sizes.sum())
+    # inputs are drawn in fp32 (and stored as fp32) so the fp64 run sees exactly the same numbers
+    value = torch.randn(B, Nv, M, D, generator=g, dtype=torch.float32).double()
+    loc = (torch.rand(B, Nq, M, L, P, 2, generator=g, dtype=torch.float32) * (hi - lo) + lo).double()
+    aw = torch.randn(B, Nq, M, L * P, generator=g, dtype=torch.float32).softmax(-1).view(B, Nq, M, L, P).double()
+    gout = torch.randn(B, Nq, M * D, generator=g, dtype=torch.float32).double()
+    out = {}
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        v = value.detach().clone().to(dt).requires_grad_(True)
+        lc = loc.detach().clone().to(dt).requires_grad_(True)
+        a = aw.detach().clone().to(dt).requires_grad_(True)
+        o = multi_scale_deformable_attn_pytorch(v, shapes, lc, a)
+        o.backward(gout.to(dt))
+        out[f"{name}.out_{tag}"] = np_(o)
+        out[f"{name}.gv_{tag}"] = np_(v.grad)
+        out[f"{name}.gl_{tag}"] = np_(lc.grad)
+        out[f"{name}.ga_{tag}"] = np_(a.grad)
+    out[f"{name}.value"] = np_(value.float())
+    out[f"{name}.loc"] = np_(loc.float())
+    out[f"{name}.aw"] = np_(aw.float())
+    out[f"{name}.gout"] = np_(gout.float())
+    out[f"{name}.shapes"] = np_(shapes)
+    out[f"{name}.lsi"] = np_(lsi)
+    return out
+
+
+def make_op_cases():
+    data = {}
+    data.update(op_case("tiny", 2, 2, 4, [(5, 7), (3, 4), (2, 2)], 2, 9, -0.3, 1.3, 11))
+    data.update(op_case("degenerate", 1, 3, 8, [(1, 2), (2, 2), (1, 1)], 3, 5, -0.6, 1.6, 12))
+    data.update(op_case("hotlike", 2, 8, 32, [(6, 8), (3, 4), (2, 2), (1, 1)], 4, 24, -0.1, 1.1, 13))
+    data.update(op_case("odd_d", 1, 2, 5, [(4, 3), (2, 2)], 3, 7, -0.2, 1.2, 14))
+    data["names"] = np.array(["tiny", "degenerate", "hotlike", "odd_d"])
+    np.savez_compressed(os.path.join(HERE, "msda_op_cases.npz"), **data)
+    print("msda_op_cases.npz", len(data))
+
+
+# --------------------------------------------------------------------------- module level
+def make_module_cases():
+    E, Lv, H, P = 32, 3, 4, 2
+    level_shapes = [(6, 9), (3, 5), (2, 3)]
+    shapes = torch.tensor(level_shapes, dtype=torch.int64)
+    sizes = shapes.prod(1)
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    Nv = int(sizes.sum())
+    mod = MultiScaleDeformableAttention(E, Lv, H, P)
+    sd = syn.det_state_dict(mod.state_dict(), num_heads=H, num_levels=Lv, num_points=P)
+    mod.load_state_dict(sd)
+    mod.eval()
+    B, Nq = 2, 11
+    data = {"shapes": np_(shapes), "lsi": np_(lsi), "dims": np.array([E, Lv, H, P])}
+    for k, v in sd.items():
+        data["sd." + k] = np_(v)
+    query = syn.det_randn("mod.query", (B, Nq, E))
+    value = syn.det_randn("mod.value", (B, Nv, E))
+    mask = torch.zeros(B, Nv, dtype=torch.bool)
+    mask[1, -7:] = True
+    mask[1, 5:9] = True
+    ref2 = syn.det_rand("mod.ref2", (B, Nq, Lv, 2)) * 1.1 - 0.05
+    ref4 = torch.cat([syn.det_rand("mod.ref4xy", (B, Nq, Lv, 2)),
+                      syn.det_rand("mod.ref4wh", (B, Nq, Lv, 2)) * 0.5 + 0.02], -1)
+    with torch.no_grad():
+        out2 = mod(query, ref2, value, shapes, lsi, mask)
+        out4 = mod(query, ref4, value, shapes, lsi, mask)
+        out2_nomask = mod(query, ref2, value, shapes, lsi, None)
+    data.update(query=np_(query), value=np_(value), mask=np_(mask), ref2=np_(ref2), ref4=np_(ref4),
+                out2=np_(out2), out4=np_(out4), out2_nomask=np_(out2_nomask))
+    np.savez_compressed(os.path.join(HERE, "msda_module_cases.npz"), **data)
+    print("msda_module_cases.npz", len(data))
+
+
+# --------------------------------------------------------------------------- hot path
+class _StopAfterEncoder(Exception):
+    pass
+
+
+class _DummyDecoder(torch.nn.Module):
+    def forward(self, *a, **k):  # never reached
+        raise RuntimeError("decoder must not run")
+
+
+def build_reference_transformer(E, heads, d_ffn, layers, classes, topk_sa, max_emb, level_ratio, layer_ratio,
+                                points=4, levels=4):
+    enc_layer = SalienceTransformerEncoderLayer(
+        embed_dim=E, d_ffn=d_ffn, dropout=0.0, n_heads=heads, activation=torch.nn.ReLU(inplace=True),
+        n_levels=levels, n_points=points, topk_sa=topk_sa)
+    enc = SalienceTransformerEncoder(enc_layer, num_layers=layers, max_num_embedding=max_emb)
+    tr = SalienceTransformer(encoder=enc, neck=None, decoder=_DummyDecoder(), num_classes=classes,
+                             num_feature_levels=levels, two_stage_num_proposals=10,
+                             level_filter_ratio=level_ratio, layer_filter_ratio=layer_ratio)
+    sd = syn.det_state_dict(tr.state_dict(), num_heads=heads, num_levels=levels, num_points=points)
+    tr.load_state_dict(sd)
+    tr.eval()
+    return tr, sd
+
+
+def run_reference_hotpath(tr, feats, masks, pos):
+    cap = {"score_maps": [], "layer_out": []}
+
+    def enc_hook(mod, args, kwargs, output):
+        cap["enc_kwargs"] = kwargs
+        cap["memory"] = output
+        raise _StopAfterEncoder()
+
+    def mp_hook(mod, args, output):
+        cap["score_maps"].append(output)  # [B, N_l, 1], called for level L-1 ... 0
+
+    def norm_hook(mod, args, output):
+        cap.setdefault("backbone_output_memory", output)
+
+    def layer_hook(mod, args, output):
+        cap["layer_out"].append(output)
+
+    hs = [tr.encoder.register_forward_hook(enc_hook, with_kwargs=True),
+          tr.enc_mask_predictor.register_forward_hook(mp_hook),
+          tr.enc_output_norm.register_forward_hook(norm_hook)]
+    hs += [l.register_forward_hook(layer_hook) for l in tr.encoder.layers]
+    try:
+        with torch.no_grad():
+            tr(feats, masks, pos, None, None, None)
+    except _StopAfterEncoder:
+        pass
+    finally:
+        for h in hs:
+            h.remove()
+    return cap
+
+
+def hotpath_inputs(image_sizes, E, seed):
+    img_mask, level_masks = syn.make_masks(image_sizes)
+    level_shapes = [tuple(m.shape[-2:]) for m in level_masks]
+    feats = syn.make_feats(len(image_sizes), level_shapes, E, seed)
+    pe = PositionEmbeddingSine(E // 2, temperature=10000, normalize=True, offset=-0.5)
+    pos = [pe(m) for m in level_masks]
+    return feats, level_masks, pos, level_shapes
+
+
+def make_hotpath_small(tag, image_sizes, seed):
+    E, heads, d_ffn, layers, classes, topk_sa, max_emb = 32, 4, 64, 3, 7, 6, 20
+    level_ratio, layer_ratio = (0.4, 0.8, 1.0, 1.0), (1.0, 0.8, 0.4)
+    tr, sd = build_reference_transformer(E, heads, d_ffn, layers, classes, topk_sa, max_emb,
+                                         level_ratio, layer_ratio)
+    feats, masks, pos, level_shapes = hotpath_inputs(image_sizes, E, seed)
+    cap = run_reference_hotpath(tr, feats, masks, pos)
+    kw = cap["enc_kwargs"]
+    data = {"hyper": np.array([E, heads, d_ffn, layers, classes, topk_sa, max_emb]),
+            "image_sizes": np.array(image_sizes), "level_shapes": np.array(level_shapes),
+            "seed": np.array(seed)}
+    for k, v in sd.items():
+        data["sd." + k] = np_(v)
+    for l in range(4):
+        data[f"feat{l}"] = np_(feats[l])
+        data[f"mask{l}"] = np_(masks[l])
+        data[f"pos{l}"] = np_(pos[l])
+        data[f"score_map{l}"] = np_(cap["score_maps"][3 - l])  # [B, N_l, 1]
+    data["backbone_output_memory"] = np_(cap["backbone_output_memory"])
+    data["spatial_shapes"] = np_(kw["spatial_shapes"])
+    data["level_start_index"] = np_(kw["level_start_index"])
+    data["valid_ratios"] = np_(kw["valid_ratios"])
+    data["feat_flatten"] = np_(kw["query"])
+    data["lvl_pos_embed_flatten"] = np_(kw["query_pos"])
+    data["mask_flatten"] = np_(kw["query_key_padding_mask"])
+    data["foreground_score"] = np_(kw["foreground_score"])
+    data["focus_token_nums"] = np_(kw["focus_token_nums"])
+    for i, inds in enumerate(kw["foreground_inds"]):
+        data[f"foreground_inds{i}"] = np_(inds)
+    for i, lo in enumerate(cap["layer_out"]):
+        data[f"layer_out{i}"] = np_(lo)
+    data["memory"] = np_(cap["memory"])
+    np.savez_compressed(os.path.join(HERE, f"hotpath_small_{tag}.npz"), **data)
+    print(f"hotpath_small_{tag}.npz", len(data), "focus", kw["focus_token_nums"].tolist(),
+          "nq", [int(i.shape[1]) for i in kw["foreground_inds"]])
+
+
+def make_hotpath_full_digest():
+    E, heads, d_ffn, layers, classes, topk_sa, max_emb = 256, 8, 2048, 6, 91, 300, 200
+    level_ratio, layer_ratio = (0.4, 0.8, 1.0, 1.0), (1.0, 0.8, 0.6, 0.6, 0.4, 0.2)
+    tr, sd = build_reference_transformer(E, heads, d_ffn, layers, classes, topk_sa, max_emb,
+                                         level_ratio, layer_ratio)
+    data = {}
+    for tag, image_sizes in (("single", [(800, 1333)]), ("mixed", [(800, 1333), (800, 1066)])):
+        feats, masks, pos, level_shapes = hotpath_inputs(image_sizes, E, seed=0)
+        cap = run_reference_hotpath(tr, feats, masks, pos)
+        kw = cap["enc_kwargs"]
+        data[f"{tag}.image_sizes"] = np.array(image_sizes)
+        data[f"{tag}.level_shapes"] = np.array(level_shapes)
+        data[f"{tag}.focus_token_nums"] = np_(kw["focus_token_nums"])
+        data[f"{tag}.valid_ratios"] = np_(kw["valid_ratios"])
+        data[f"{tag}.nq"] = np.array([int(i.shape[1]) for i in kw["foreground_inds"]])
+        fs = kw["foreground_score"]
+        data[f"{tag}.foreground_score_sub"] = np_(fs[:, ::37])
+        data[f"{tag}.foreground_score_stats"] = np.array([float(fs.mean()), float(fs.abs().max()), float(fs.min())])
+        inds0 = kw["foreground_inds"][0]
+        data[f"{tag}.inds0_head"] = np_(inds0[:, :256])
+        data[f"{tag}.inds0_crc"] = np.array([zlib.crc32(np_(inds0[b]).astype(np.int64).tobytes())
+                                             for b in range(inds0.shape[0])], dtype=np.int64)
+        # sorted set digest per layer (order-independent), valid prefix only
+        for k, inds in enumerate(kw["foreground_inds"]):
+            data[f"{tag}.inds{k}_set_crc"] = np.array(
+                [zlib.crc32(np.sort(np_(inds[b])).astype(np.int64).tobytes()) for b in range(inds.shape[0])],
+                dtype=np.int64)
+        bom = cap["backbone_output_memory"]
+        data[f"{tag}.backbone_output_memory_sub"] = np_(bom[:, ::101, ::7])
+        for l in range(4):
+            sm = cap["score_maps"][3 - l]
+            data[f"{tag}.score_map{l}_sub"] = np_(sm[:, ::13, 0])
+        for i, lo in enumerate(cap["layer_out"]):
+            data[f"{tag}.layer_out{i}_sub"] = np_(lo[:, ::53, ::5])
+            data[f"{tag}.layer_out{i}_stats"] = np.array([float(lo.mean()), float(lo.abs().mean()),
+                                                          float(lo.abs().max())])
+        mem = cap["memory"]
+        data[f"{tag}.memory_sub"] = np_(mem[:, ::41, ::3])
+        data[f"{tag}.memory_stats"] = np.array([float(mem.mean()), float(mem.abs().mean()), float(mem.abs().max())])
+        print(tag, "focus", kw["focus_token_nums"].tolist(), "nq", data[f"{tag}.nq"].tolist())
+    np.savez_compressed(os.path.join(HERE, "hotpath_full_digest.npz"), **data)
+    print("hotpath_full_digest.npz", len(data))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["op", "module", "small", "full"]
+    if "op" in which:
+        make_op_cases()
+    if "module" in which:
+        make_module_cases()
+    if "small" in which:
+        make_hotpath_small("single", [(64, 96)], seed=3)
+        make_hotpath_small("mixed", [(64, 96), (48, 80)], seed=4)
+    if "full" in which:
+        make_hotpath_full_digest()
