@@ -1,0 +1,157 @@
+/*
+ * include/salience_hip.h -- C ABI of libsalience_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for the Salience-DETR encoder hot path (hierarchical
+ * salience filtering + multi-scale deformable attention).  Plain pointers and
+ * sizes only: every pointer is a DEVICE pointer unless stated otherwise, every
+ * launch is enqueued on `stream` and returns without synchronising (same
+ * contract as the reference launchers, which enqueue on the current stream).
+ *
+ * Return value: 0 on success; SDETR_EINVAL (-1) for a rejected argument
+ * (nothing was launched); a positive hipError_t if the launch itself failed
+ * (the reference only printf()s launch errors --
+ * models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:937-941,1310-1314 -- this
+ * library reports them).  sdetr_last_error() returns a thread-local message.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the upstream repository root).
+ */
+#ifndef SALIENCE_HIP_H_
+#define SALIENCE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t *sdetr_stream_t; /* == hipStream_t */
+
+#define SDETR_ABI_VERSION 1
+#define SDETR_EINVAL (-1)
+
+/* element types for the native (non drop-in) entry points */
+#define SDETR_F32 0
+#define SDETR_BF16 1
+
+int sdetr_abi_version(void);
+const char *sdetr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) MSDA forward, reference layout -- replaces
+ *     ms_deformable_im2col_cuda<scalar_t>(stream, data_value, data_spatial_shapes,
+ *         data_level_start_index, data_sampling_loc, data_attn_weight, batch_size, spatial_size,
+ *         num_heads, channels, num_levels, num_query, num_point, data_col)
+ *     models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:912-943 (kernel :226-288),
+ *     called from ms_deform_attn_cuda_forward, models/bricks/ops/cuda/ms_deform_attn_cuda.cu:12-72.
+ *   value [B,Nv,M,D]  shapes [L,2] int64 (H,W)  level_start_index [L] int64
+ *   loc [B,Nq,M,L,P,2] (x,y in [0,1])  aw [B,Nq,M,L,P]  ->  data_col [B,Nq,M*D] (fully overwritten)
+ * ------------------------------------------------------------------------------------------- */
+int sdetr_msda_im2col_f32(sdetr_stream_t stream, const float *data_value,
+                          const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
+                          const float *data_sampling_loc, const float *data_attn_weight,
+                          int batch_size, int spatial_size, int num_heads, int channels,
+                          int num_levels, int num_query, int num_point, float *data_col);
+int sdetr_msda_im2col_f64(sdetr_stream_t stream, const double *data_value,
+                          const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
+                          const double *data_sampling_loc, const double *data_attn_weight,
+                          int batch_size, int spatial_size, int num_heads, int channels,
+                          int num_levels, int num_query, int num_point, double *data_col);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) MSDA backward, reference layout -- replaces
+ *     ms_deformable_col2im_cuda<scalar_t>(stream, grad_col, data_value, ..., grad_value,
+ *         grad_sampling_loc, grad_attn_weight)
+ *     models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:945-1316 (kernels :290-909),
+ *     called from ms_deform_attn_cuda_backward, ms_deform_attn_cuda.cu:75-145.
+ *   grad_value must be zero on entry (the op accumulates with float atomics, as the reference
+ *   does); grad_sampling_loc / grad_attn_weight are fully overwritten.
+ * ------------------------------------------------------------------------------------------- */
+int sdetr_msda_col2im_f32(sdetr_stream_t stream, const float *grad_col, const float *data_value,
+                          const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
+                          const float *data_sampling_loc, const float *data_attn_weight,
+                          int batch_size, int spatial_size, int num_heads, int channels,
+                          int num_levels, int num_query, int num_point, float *grad_value,
+                          float *grad_sampling_loc, float *grad_attn_weight);
+int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const double *data_value,
+                          const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
+                          const double *data_sampling_loc, const double *data_attn_weight,
+                          int batch_size, int spatial_size, int num_heads, int channels,
+                          int num_levels, int num_query, int num_point, double *grad_value,
+                          double *grad_sampling_loc, double *grad_attn_weight);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) Native MI355X path behind MultiScaleDeformableAttention.forward
+ *     (models/bricks/ms_deform_attn.py:286-377).
+ *
+ * sdetr_value_to_head_major: the tail of `value_proj` (ms_deform_attn.py:316-321): zero the
+ *   padded tokens (masked_fill) and re-lay the projected value out head-major,
+ *   src [B,Nv,M*D] (row stride `src_row_stride` elements) -> dst [B,M,Nv,D], optional dtype cast.
+ *   pad_mask [B,Nv] bytes (1 = padding) or NULL.
+ *
+ * sdetr_msda_fused_forward: softmax over the L*P logits, sampling-location arithmetic
+ *   (ms_deform_attn.py:322-355, 2-d or 4-d reference points) and the gather-reduce, in one launch.
+ *   value_hm  [B,M,Nv,D] (value_dtype)        ref_points [B,Nq,L,ref_dim] f32, ref_dim in {2,4}
+ *   proj      [B,Nq,row_stride] (proj_dtype): row = [ M*L*P*2 offsets | M*L*P logits | ... ]
+ *             i.e. the concatenated output of sampling_offsets and attention_weights Linear.
+ *   order     [B,Nq] int32 processing order (slot i handles query order[b][i]) or NULL
+ *   out       [B,Nq,M*D] (out_dtype)
+ * ------------------------------------------------------------------------------------------- */
+int sdetr_value_to_head_major(sdetr_stream_t stream, const void *src, int src_dtype,
+                              int64_t src_row_stride, const uint8_t *pad_mask, int batch_size,
+                              int spatial_size, int num_heads, int channels, void *dst, int dst_dtype);
+
+int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                             const int64_t *data_spatial_shapes,
+                             const int64_t *data_level_start_index, const float *ref_points,
+                             int ref_dim, const void *proj, int proj_dtype, int64_t proj_row_stride,
+                             const int32_t *order, int batch_size, int spatial_size, int num_heads,
+                             int channels, int num_levels, int num_query, int num_point, void *out,
+                             int out_dtype);
+
+/* Same gather on a head-major value with explicit sampling locations / weights (the reference
+ * op's math on the native layout); loc/aw as in (1), fp32. */
+int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                  const int64_t *data_spatial_shapes,
+                                  const int64_t *data_level_start_index, const float *data_sampling_loc,
+                                  const float *data_attn_weight, int batch_size, int spatial_size,
+                                  int num_heads, int channels, int num_levels, int num_query,
+                                  int num_point, void *out, int out_dtype);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) Salience filtering: masked top-k, sorted descending, ties -> lower index first.
+ *     Replaces the torch.topk / torch.sort calls of the inline filtering code
+ *     models/bricks/salience_transformer.py:146-150 (per-level top-k with
+ *     masked_fill(mask, score.min())), :156-158 (global sort + index gather) and :366-367
+ *     (per-layer top-300).
+ *   score [B,N] f32; mask [B,N] bytes or NULL.  fill_mode 0: masked scores are left alone (mask
+ *   must be NULL); 1: masked scores are replaced by min(score) over the WHOLE [B,N] array
+ *   (computed in-kernel, masked entries included -- reference :146).
+ *   payload [B,N] int64 or NULL: out_index[b][j] = payload[b][pos] if given, else pos+index_offset.
+ *   out_score [B,k] f32 (may be NULL), out_index [B,k] int64.
+ *   workspace: device scratch of at least sdetr_topk_workspace_bytes(B,N,k) bytes (may be NULL
+ *   when that returns 0, i.e. whenever the problem fits the in-LDS path).
+ * ------------------------------------------------------------------------------------------- */
+size_t sdetr_topk_workspace_bytes(int batch_size, int n, int k);
+int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                               int fill_mode, const int64_t *payload, int batch_size, int n, int k,
+                               int64_t index_offset, float *out_score, int64_t *out_index,
+                               void *workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5) Token row movement of the encoder loop (models/bricks/salience_transformer.py:454-461
+ *     torch.gather by foreground_inds; :474-485 per-image scatter of the first
+ *     focus_token_nums[b] rows).  Rows are `row_bytes` bytes (multiple of 4).
+ *   gather : dst[b][i] = src[b][idx[b][i]]  (+ addend[b][idx[b][i]] if addend != NULL, f32 only)
+ *   scatter: dst[b][idx[b][i]] = src[b][i] for i < (count ? count[b] : n)    (in place)
+ * ------------------------------------------------------------------------------------------- */
+int sdetr_gather_rows(sdetr_stream_t stream, const void *src, const int64_t *idx, int batch_size,
+                      int src_rows, int n, int row_bytes, void *dst);
+int sdetr_scatter_rows(sdetr_stream_t stream, void *dst, const int64_t *idx, const void *src,
+                       const int64_t *count, int batch_size, int dst_rows, int n, int row_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALIENCE_HIP_H_ */

@@ -1,0 +1,99 @@
+"""ctypes binding of libsalience_hip.so (the C ABI declared in include/salience_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or an operator is handed a
+tensor that is not on a HIP device, the call raises.  PyTorch is used here only as the owner
+of device memory and streams (``tensor.data_ptr()``, ``torch.cuda.current_stream()``).
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsalience_hip.so")
+
+F32, BF16 = 0, 1
+EINVAL = -1
+
+_lib = None
+
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must match include/salience_hip.h
+SIGNATURES = {
+    "sdetr_abi_version": (_i, []),
+    "sdetr_last_error": (ctypes.c_char_p, []),
+    "sdetr_msda_im2col_f32": (_i, [_p] * 6 + [_i] * 7 + [_p]),
+    "sdetr_msda_im2col_f64": (_i, [_p] * 6 + [_i] * 7 + [_p]),
+    "sdetr_msda_col2im_f32": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
+    "sdetr_msda_col2im_f64": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
+    "sdetr_value_to_head_major": (_i, [_p, _p, _i, _i64, _p, _i, _i, _i, _i, _p, _i]),
+    "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _i64, _p] + [_i] * 7 + [_p, _i]),
+    "sdetr_msda_forward_head_major": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 7 + [_p, _i]),
+    "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i64, _p, _p, _p, _sz]),
+    "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
+}
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load the shared library once; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f"{LIB_PATH} is missing: build it with `python -m salience_detr_amd.csrc.build` "
+                "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)  # AttributeError -> the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if cdll.sdetr_abi_version() != 1:
+            raise HipExtensionError("libsalience_hip.so ABI version mismatch")
+        _lib = cdll
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().sdetr_last_error().decode(errors="replace")
+        if code == EINVAL:
+            raise RuntimeError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: HIP launch error {code}: {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_device(what: str, **tensors) -> None:
+    """The reference asserts `.is_cuda` + contiguity (ms_deform_attn_cuda.cu:20-30); so do we."""
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(f"{what}: {name} must be a HIP (cuda) tensor; the hot path has no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{what}: {name} tensor has to be contiguous")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"unsupported dtype {dt} (float32 / bfloat16 only)")

@@ -1,0 +1,13 @@
+// ABI bookkeeping of libsalience_hip.so: version + thread-local error text.
+#include "common.h"
+
+namespace sdetr {
+char *error_buffer()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace sdetr
+
+extern "C" int sdetr_abi_version(void) { return SDETR_ABI_VERSION; }
+extern "C" const char *sdetr_last_error(void) { return sdetr::error_buffer(); }

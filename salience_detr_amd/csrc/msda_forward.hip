@@ -1,0 +1,436 @@
+// Multi-scale deformable attention, forward gather-reduce, for gfx950 (MI355X).
+//
+// Semantics follow the reference op (models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:22-73,
+// 226-288 and models/bricks/ms_deform_attn.py:159-212, 322-355); the kernel structure does not:
+//
+//  * A "group" of G = D*sizeof(value)/16 adjacent lanes owns one (batch, query, head) output row
+//    and every lane moves 16 bytes per corner (global_load_dwordx4): a 64-lane wavefront serves
+//    64/G rows, so a head's D channels of one pixel are exactly one 64/128-byte segment.
+//  * A workgroup serves ONE head of ONE image: blockIdx % num_heads is the head, and because the
+//    dispatcher places block b on XCD b % 8, with 8 heads each XCD's private 4 MiB L2 only ever
+//    holds "its" head's slice of the value map (2.9 MB for the 800x1333 pyramid, batch 2, bf16
+//    head-major) instead of thrashing on the whole 23-46 MB tensor.
+//  * Sampling set-up (softmax over the L*P logits, location arithmetic, bounds tests, the four
+//    corner byte offsets and the four bilinear*attention weights) is done ONCE per sample by one
+//    lane and broadcast to the group through LDS (two ds_read_b128 per sample), instead of being
+//    recomputed by every channel thread as in the reference (32x redundant there).
+//  * The fused entry point consumes the raw sampling_offsets / attention_weights projections and
+//    the reference points directly, so sampling_locations [B,Nq,M,L,P,2] and the softmaxed weights
+//    are never written to HBM.
+#include "common.h"
+
+namespace sdetr {
+
+constexpr int kChunk = 16;  // samples staged per LDS round
+
+template <typename VT>
+struct ValTraits;
+template <>
+struct ValTraits<float> {
+    static constexpr int kCpl = 4;  // channels per 16-byte lane load
+    __device__ static __forceinline__ void fma4(float *acc, const uint4 &v, float w)
+    {
+        acc[0] = fmaf(w, __uint_as_float(v.x), acc[0]);
+        acc[1] = fmaf(w, __uint_as_float(v.y), acc[1]);
+        acc[2] = fmaf(w, __uint_as_float(v.z), acc[2]);
+        acc[3] = fmaf(w, __uint_as_float(v.w), acc[3]);
+    }
+};
+template <>
+struct ValTraits<bf16_t> {
+    static constexpr int kCpl = 8;
+    __device__ static __forceinline__ void fma4(float *acc, const uint4 &v, float w)
+    {
+        acc[0] = fmaf(w, bf16_lo(v.x), acc[0]);
+        acc[1] = fmaf(w, bf16_hi(v.x), acc[1]);
+        acc[2] = fmaf(w, bf16_lo(v.y), acc[2]);
+        acc[3] = fmaf(w, bf16_hi(v.y), acc[3]);
+        acc[4] = fmaf(w, bf16_lo(v.z), acc[4]);
+        acc[5] = fmaf(w, bf16_hi(v.z), acc[5]);
+        acc[6] = fmaf(w, bf16_lo(v.w), acc[6]);
+        acc[7] = fmaf(w, bf16_hi(v.w), acc[7]);
+    }
+};
+
+struct GatherArgs {
+    const char *value;
+    const int64_t *shapes;
+    const int64_t *lsi;
+    // explicit mode
+    const float *loc;
+    const float *aw;
+    // fused mode
+    const float *ref;
+    int ref_dim;
+    const void *proj;
+    int proj_bf16;
+    int64_t proj_stride;
+    const int32_t *order;
+    void *out;
+    int out_bf16;
+    int B, Nv, M, L, Nq, P;
+    int nchunk;  // query chunks per image
+};
+
+__device__ __forceinline__ float load_proj(const void *proj, int is_bf16, int64_t idx)
+{
+    if (is_bf16) return __uint_as_float((uint32_t) reinterpret_cast<const bf16_t *>(proj)[idx] << 16);
+    return reinterpret_cast<const float *>(proj)[idx];
+}
+
+// One sample's descriptor: 4 corner byte offsets (relative to the block's value base, lane
+// offset excluded) and 4 weights = bilinear weight * attention weight (0 for an out-of-range
+// corner, whose offset is clamped into the map so the load stays legal).
+__device__ __forceinline__ void make_descriptor(float x, float y, float a, int H, int W, int level_start,
+                                                uint32_t pixel_bytes, uint32_t *d)
+{
+    const float h_im = y * (float)H - 0.5f;
+    const float w_im = x * (float)W - 0.5f;
+    const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    const float fy = floorf(h_im), fx = floorf(w_im);
+    int y0 = (int)fy, x0 = (int)fx;
+    const float ly = h_im - fy, lx = w_im - fx;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    if (!inside) {
+        y0 = 0;
+        x0 = 0;
+        a = 0.f;
+    }
+    const int y1 = y0 + 1, x1 = x0 + 1;
+    const bool y0ok = y0 >= 0, x0ok = x0 >= 0, y1ok = y1 <= H - 1, x1ok = x1 <= W - 1;
+    const int y0c = y0ok ? y0 : 0, x0c = x0ok ? x0 : 0;
+    const int y1c = y1ok ? y1 : H - 1, x1c = x1ok ? x1 : W - 1;
+    const uint32_t r0 = (uint32_t)(level_start + y0c * W), r1 = (uint32_t)(level_start + y1c * W);
+    d[0] = (r0 + x0c) * pixel_bytes;
+    d[1] = (r0 + x1c) * pixel_bytes;
+    d[2] = (r1 + x0c) * pixel_bytes;
+    d[3] = (r1 + x1c) * pixel_bytes;
+    d[4] = __float_as_uint((y0ok && x0ok) ? hy * hx * a : 0.f);
+    d[5] = __float_as_uint((y0ok && x1ok) ? hy * lx * a : 0.f);
+    d[6] = __float_as_uint((y1ok && x0ok) ? ly * hx * a : 0.f);
+    d[7] = __float_as_uint((y1ok && x1ok) ? ly * lx * a : 0.f);
+}
+
+template <typename VT, int D, bool HEAD_MAJOR, bool FUSED>
+__global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
+{
+    using T = ValTraits<VT>;
+    constexpr int CPL = T::kCpl;
+    constexpr int G = D / CPL;            // lanes per (b,q,m) row
+    constexpr int GPB = kBlock / G;       // rows per workgroup
+    constexpr int DSTRIDE = kChunk * 8 + 4;  // descriptor dwords per row (+4: bank spread)
+    static_assert(D % CPL == 0 && (G & (G - 1)) == 0 && G <= kWave, "unsupported head dim");
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *desc = smem;                                  // [GPB][DSTRIDE]
+    int *lvl_tab = reinterpret_cast<int *>(smem + GPB * DSTRIDE);  // [L][3] = H, W, start
+
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x % p.M;
+    const int chunk_global = blockIdx.x / p.M;
+    const int b = chunk_global / p.nchunk;
+    const int chunk = chunk_global - b * p.nchunk;
+    const int g = tid / G;        // row within the block
+    const int j = tid - g * G;    // lane within the row
+    const int slot = chunk * GPB + g;
+    const bool active = slot < p.Nq;
+    int q = 0;
+    if (active) q = p.order ? p.order[(int64_t)b * p.Nq + slot] : slot;
+
+    if (tid < p.L) {
+        lvl_tab[tid * 3 + 0] = (int)p.shapes[2 * tid];
+        lvl_tab[tid * 3 + 1] = (int)p.shapes[2 * tid + 1];
+        lvl_tab[tid * 3 + 2] = (int)p.lsi[tid];
+    }
+    __syncthreads();
+
+    const int LP = p.L * p.P;
+    const int64_t row = ((int64_t)b * p.Nq + q) * p.M + m;  // (b,q,m) row index
+    constexpr uint32_t kPixelBytesHM = D * sizeof(VT);
+    const uint32_t pixel_bytes = HEAD_MAJOR ? kPixelBytesHM : (uint32_t)(p.M * D * sizeof(VT));
+    // block-uniform base of this image (and head, when head-major)
+    const char *base = p.value + (HEAD_MAJOR ? ((int64_t)b * p.M + m) * p.Nv * (int64_t)kPixelBytesHM
+                                             : (int64_t)b * p.Nv * (int64_t)pixel_bytes);
+    const uint32_t lane_off = (HEAD_MAJOR ? 0u : (uint32_t)(m * D * sizeof(VT))) + (uint32_t)(j * 16);
+
+    // ---- fused mode: softmax statistics over this row's L*P logits, spread over the G lanes ----
+    float sm_max = 0.f, sm_inv = 1.f;
+    int64_t proj_row = 0;
+    if (FUSED && active) {
+        proj_row = ((int64_t)b * p.Nq + q) * p.proj_stride;
+        const int64_t lg = proj_row + (int64_t)p.M * LP * 2 + (int64_t)m * LP;
+        float mx = -INFINITY;
+        for (int s = j; s < LP; s += G) mx = fmaxf(mx, load_proj(p.proj, p.proj_bf16, lg + s));
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, G));
+        float sum = 0.f;
+        for (int s = j; s < LP; s += G) sum += __expf(load_proj(p.proj, p.proj_bf16, lg + s) - mx);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, G);
+        sm_max = mx;
+        sm_inv = 1.f / sum;
+    }
+
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+
+    uint32_t *my_desc = desc + g * DSTRIDE;
+    for (int c0 = 0; c0 < LP; c0 += kChunk) {
+        const int ns = min(kChunk, LP - c0);
+        if (c0 > 0) __syncthreads();  // previous chunk fully consumed
+        if (active) {
+            for (int t = j; t < ns; t += G) {
+                const int s = c0 + t;
+                const int l = s / p.P;
+                const int H = lvl_tab[l * 3], W = lvl_tab[l * 3 + 1], start = lvl_tab[l * 3 + 2];
+                float x, y, a;
+                if (FUSED) {
+                    const int64_t oi = proj_row + ((int64_t)m * LP + s) * 2;
+                    const float ox = load_proj(p.proj, p.proj_bf16, oi);
+                    const float oy = load_proj(p.proj, p.proj_bf16, oi + 1);
+                    const float lgt = load_proj(p.proj, p.proj_bf16,
+                                                proj_row + (int64_t)p.M * LP * 2 + (int64_t)m * LP + s);
+                    a = __expf(lgt - sm_max) * sm_inv;
+                    const float *r = p.ref + (((int64_t)b * p.Nq + q) * p.L + l) * p.ref_dim;
+                    if (p.ref_dim == 2) {
+                        x = r[0] + ox / (float)W;
+                        y = r[1] + oy / (float)H;
+                    } else {
+                        x = r[0] + ox / (float)p.P * r[2] * 0.5f;
+                        y = r[1] + oy / (float)p.P * r[3] * 0.5f;
+                    }
+                } else {
+                    const float2 xy = reinterpret_cast<const float2 *>(p.loc)[row * LP + s];
+                    x = xy.x;
+                    y = xy.y;
+                    a = p.aw[row * LP + s];
+                }
+                uint32_t d[8];
+                make_descriptor(x, y, a, H, W, start, pixel_bytes, d);
+                *reinterpret_cast<uint4 *>(my_desc + t * 8) = make_uint4(d[0], d[1], d[2], d[3]);
+                *reinterpret_cast<uint4 *>(my_desc + t * 8 + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const char *lane_base = base + lane_off;
+            int t = 0;
+            for (; t + 4 <= ns; t += 4) {
+                uint4 o[4], w[4], v[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    o[u] = *reinterpret_cast<const uint4 *>(my_desc + (t + u) * 8);
+                    w[u] = *reinterpret_cast<const uint4 *>(my_desc + (t + u) * 8 + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u][0] = *reinterpret_cast<const uint4 *>(lane_base + o[u].x);
+                    v[u][1] = *reinterpret_cast<const uint4 *>(lane_base + o[u].y);
+                    v[u][2] = *reinterpret_cast<const uint4 *>(lane_base + o[u].z);
+                    v[u][3] = *reinterpret_cast<const uint4 *>(lane_base + o[u].w);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    T::fma4(acc, v[u][0], __uint_as_float(w[u].x));
+                    T::fma4(acc, v[u][1], __uint_as_float(w[u].y));
+                    T::fma4(acc, v[u][2], __uint_as_float(w[u].z));
+                    T::fma4(acc, v[u][3], __uint_as_float(w[u].w));
+                }
+            }
+            for (; t < ns; ++t) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(my_desc + t * 8);
+                const uint4 w = *reinterpret_cast<const uint4 *>(my_desc + t * 8 + 4);
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(lane_base + o.x);
+                const uint4 v1 = *reinterpret_cast<const uint4 *>(lane_base + o.y);
+                const uint4 v2 = *reinterpret_cast<const uint4 *>(lane_base + o.z);
+                const uint4 v3 = *reinterpret_cast<const uint4 *>(lane_base + o.w);
+                T::fma4(acc, v0, __uint_as_float(w.x));
+                T::fma4(acc, v1, __uint_as_float(w.y));
+                T::fma4(acc, v2, __uint_as_float(w.z));
+                T::fma4(acc, v3, __uint_as_float(w.w));
+            }
+        }
+    }
+
+    if (active) {
+        const int64_t o = row * D + j * CPL;
+        if (p.out_bf16) {
+            bf16_t *out = reinterpret_cast<bf16_t *>(p.out) + o;
+            if (CPL == 8) {
+                *reinterpret_cast<uint4 *>(out) =
+                    make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                               pack_bf16x2(acc[4 % CPL], acc[5 % CPL]), pack_bf16x2(acc[6 % CPL], acc[7 % CPL]));
+            } else {
+                *reinterpret_cast<uint2 *>(out) = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+            }
+        } else {
+            float *out = reinterpret_cast<float *>(p.out) + o;
+#pragma unroll
+            for (int c = 0; c < CPL; c += 4)
+                *reinterpret_cast<float4 *>(out + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+        }
+    }
+}
+
+// Generic fallback: any head dim, fp32/fp64, reference layout.  One thread per (b,q,m,c).
+template <typename S>
+__global__ void __launch_bounds__(kBlock) msda_generic_kernel(int64_t n, const S *value, const int64_t *shapes,
+                                                              const int64_t *lsi, const S *loc, const S *aw, int Nv,
+                                                              int M, int D, int L, int Nq, int P, S *out)
+{
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % D);
+        const int64_t row = idx / D;
+        const int m = (int)(row % M);
+        const int64_t bq = row / M;
+        const int b = (int)(bq / Nq);
+        S col = 0;
+        const int LP = L * P;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const S *vl = value + ((int64_t)b * Nv + lsi[l]) * M * D + (int64_t)m * D + c;
+            for (int pp = 0; pp < P; ++pp) {
+                const int s = l * P + pp;
+                const S x = loc[(row * LP + s) * 2] * (S)W - (S)0.5;
+                const S y = loc[(row * LP + s) * 2 + 1] * (S)H - (S)0.5;
+                const S a = aw[row * LP + s];
+                if (!(y > (S)-1 && x > (S)-1 && y < (S)H && x < (S)W)) continue;
+                const S fy = floor(y), fx = floor(x);
+                const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+                const S ly = y - fy, lx = x - fx, hy = (S)1 - ly, hx = (S)1 - lx;
+                const int64_t sp = (int64_t)M * D;
+                S v = 0;
+                if (y0 >= 0 && x0 >= 0) v += hy * hx * vl[((int64_t)y0 * W + x0) * sp];
+                if (y0 >= 0 && x1 <= W - 1) v += hy * lx * vl[((int64_t)y0 * W + x1) * sp];
+                if (y1 <= H - 1 && x0 >= 0) v += ly * hx * vl[((int64_t)y1 * W + x0) * sp];
+                if (y1 <= H - 1 && x1 <= W - 1) v += ly * lx * vl[((int64_t)y1 * W + x1) * sp];
+                col += v * a;
+            }
+        }
+        out[idx] = col;
+    }
+}
+
+template <typename VT, int D, bool HM, bool FUSED>
+static int launch_gather(hipStream_t stream, GatherArgs &a)
+{
+    constexpr int G = D / ValTraits<VT>::kCpl;
+    constexpr int GPB = kBlock / G;
+    a.nchunk = (a.Nq + GPB - 1) / GPB;
+    const int64_t blocks = (int64_t)a.B * a.nchunk * a.M;
+    if (blocks == 0) return 0;
+    if (blocks > 0x7fffffffLL) return fail("msda: grid too large");
+    const size_t lds = (size_t)(GPB * (kChunk * 8 + 4) + kMaxLevels * 3) * 4;
+    hipLaunchKernelGGL((msda_gather_kernel<VT, D, HM, FUSED>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    return check_launch("msda_gather");
+}
+
+template <typename VT, bool HM, bool FUSED>
+static int dispatch_d(hipStream_t stream, GatherArgs &a, int D)
+{
+    constexpr int CPL = ValTraits<VT>::kCpl;
+    switch (D) {
+        case 4: if (CPL == 4) return launch_gather<VT, (CPL == 4 ? 4 : 8), HM, FUSED>(stream, a); break;
+        case 8: return launch_gather<VT, 8, HM, FUSED>(stream, a);
+        case 16: return launch_gather<VT, 16, HM, FUSED>(stream, a);
+        case 32: return launch_gather<VT, 32, HM, FUSED>(stream, a);
+        case 64: return launch_gather<VT, 64, HM, FUSED>(stream, a);
+        case 128: return launch_gather<VT, 128, HM, FUSED>(stream, a);
+        default: break;
+    }
+    return fail("msda: head dim %d not supported by the tiled kernel for this value type", D);
+}
+
+static bool offsets_fit_32bit(int64_t Nv, int64_t pixel_bytes) { return Nv * pixel_bytes < 0xffffffffLL; }
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+static int check_dims(int B, int Nv, int M, int D, int L, int Nq, int P)
+{
+    if (B < 0 || Nv < 0 || M <= 0 || D <= 0 || L <= 0 || Nq < 0 || P <= 0)
+        return fail("msda: bad dims B=%d Nv=%d M=%d D=%d L=%d Nq=%d P=%d", B, Nv, M, D, L, Nq, P);
+    return 0;
+}
+
+extern "C" int sdetr_msda_im2col_f32(sdetr_stream_t stream, const float *value, const int64_t *shapes,
+                                     const int64_t *lsi, const float *loc, const float *aw, int B, int Nv, int M,
+                                     int D, int L, int Nq, int P, float *out)
+{
+    if (int e = check_dims(B, Nv, M, D, L, Nq, P)) return e;
+    if (!value || !shapes || !lsi || !loc || !aw || !out) return fail("msda_im2col_f32: null pointer");
+    if ((int64_t)B * Nq == 0) return 0;
+    const bool tiled = (D == 4 || D == 8 || D == 16 || D == 32 || D == 64 || D == 128) && L <= kMaxLevels &&
+                       offsets_fit_32bit(Nv, (int64_t)M * D * 4);
+    if (tiled) {
+        GatherArgs a{};
+        a.value = reinterpret_cast<const char *>(value);
+        a.shapes = shapes; a.lsi = lsi; a.loc = loc; a.aw = aw; a.out = out; a.out_bf16 = 0;
+        a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
+        return dispatch_d<float, false, false>(stream, a, D);
+    }
+    const int64_t n = (int64_t)B * Nq * M * D;
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(msda_generic_kernel<float>, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)),
+                       dim3(kBlock), 0, stream, n, value, shapes, lsi, loc, aw, Nv, M, D, L, Nq, P, out);
+    return check_launch("msda_generic_f32");
+}
+
+extern "C" int sdetr_msda_im2col_f64(sdetr_stream_t stream, const double *value, const int64_t *shapes,
+                                     const int64_t *lsi, const double *loc, const double *aw, int B, int Nv, int M,
+                                     int D, int L, int Nq, int P, double *out)
+{
+    if (int e = check_dims(B, Nv, M, D, L, Nq, P)) return e;
+    if (!value || !shapes || !lsi || !loc || !aw || !out) return fail("msda_im2col_f64: null pointer");
+    const int64_t n = (int64_t)B * Nq * M * D;
+    if (n == 0) return 0;
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(msda_generic_kernel<double>, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)),
+                       dim3(kBlock), 0, stream, n, value, shapes, lsi, loc, aw, Nv, M, D, L, Nq, P, out);
+    return check_launch("msda_generic_f64");
+}
+
+extern "C" int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                             const int64_t *shapes, const int64_t *lsi, const float *loc,
+                                             const float *aw, int B, int Nv, int M, int D, int L, int Nq, int P,
+                                             void *out, int out_dtype)
+{
+    if (int e = check_dims(B, Nv, M, D, L, Nq, P)) return e;
+    if (!value_hm || !shapes || !lsi || !loc || !aw || !out) return fail("msda_forward_head_major: null pointer");
+    if (L > kMaxLevels) return fail("msda_forward_head_major: at most %d levels", kMaxLevels);
+    if ((int64_t)B * Nq == 0) return 0;
+    GatherArgs a{};
+    a.value = reinterpret_cast<const char *>(value_hm);
+    a.shapes = shapes; a.lsi = lsi; a.loc = loc; a.aw = aw; a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
+    if (value_dtype == SDETR_F32) return dispatch_d<float, true, false>(stream, a, D);
+    if (value_dtype == SDETR_BF16) return dispatch_d<bf16_t, true, false>(stream, a, D);
+    return fail("msda_forward_head_major: bad value dtype %d", value_dtype);
+}
+
+extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                        const int64_t *shapes, const int64_t *lsi, const float *ref, int ref_dim,
+                                        const void *proj, int proj_dtype, int64_t proj_row_stride,
+                                        const int32_t *order, int B, int Nv, int M, int D, int L, int Nq, int P,
+                                        void *out, int out_dtype)
+{
+    if (int e = check_dims(B, Nv, M, D, L, Nq, P)) return e;
+    if (!value_hm || !shapes || !lsi || !ref || !proj || !out) return fail("msda_fused_forward: null pointer");
+    if (ref_dim != 2 && ref_dim != 4)
+        return fail("Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+    if (L > kMaxLevels) return fail("msda_fused_forward: at most %d levels", kMaxLevels);
+    if (proj_row_stride < (int64_t)M * L * P * 3) return fail("msda_fused_forward: proj row stride too small");
+    if ((int64_t)B * Nq == 0) return 0;
+    GatherArgs a{};
+    a.value = reinterpret_cast<const char *>(value_hm);
+    a.shapes = shapes; a.lsi = lsi; a.ref = ref; a.ref_dim = ref_dim; a.proj = proj;
+    a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;
+    a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
+    if (value_dtype == SDETR_F32) return dispatch_d<float, true, true>(stream, a, D);
+    if (value_dtype == SDETR_BF16) return dispatch_d<bf16_t, true, true>(stream, a, D);
+    return fail("msda_fused_forward: bad value dtype %d", value_dtype);
+}

@@ -1,0 +1,325 @@
+"""Multi-scale deformable attention on MI355X behind the reference's operator signatures.
+
+Mirrors (names, argument meaning, error behaviour) of the reference's
+``models/bricks/ms_deform_attn.py``:
+
+* B1  ``ms_deform_attn_forward`` / ``ms_deform_attn_backward`` -- the two functions the
+  reference's pybind module ``_C`` exports (``models/bricks/ops/cuda/ms_deform_attn_cuda.cu:12-18,
+  75-82, 148-151``), here thin host wrappers over the C ABI ``sdetr_msda_im2col_f32`` /
+  ``sdetr_msda_col2im_f32`` of libsalience_hip.so.
+* B2  ``MultiScaleDeformableAttnFunction`` (``ms_deform_attn.py:35-84``).
+* B3  ``MultiScaleDeformableAttention`` (``ms_deform_attn.py:215-377``): same constructor, same
+  parameter names (``sampling_offsets``, ``attention_weights``, ``value_proj``, ``output_proj`` --
+  released checkpoints and ``optimizer/param_dict.py:79-81`` depend on them), same ``forward``
+  signature.  Without autograd it runs the native path: value re-laid head-major (optionally
+  bf16) and ONE fused kernel for softmax + sampling locations + gather.
+
+There is no CPU fallback (the reference's ``multi_scale_deformable_attn_pytorch`` lives, restated,
+in ``oracle/`` as the parity checker only).
+"""
+import math
+import warnings
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn import functional as F
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import _hip
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+def _op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, what):
+    _hip.require_device(what, value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                        sampling_loc=sampling_loc, attn_weight=attn_weight)
+    if value.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"{what}: only float32 / float64 are supported by the reference-layout op "
+                           f"(got {value.dtype})")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError(f"{what}: value, sampling_loc and attn_weight must share one dtype")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError(f"{what}: spatial_shapes / level_start_index must be int64")
+    B, Nv, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Nq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (B, Nq, M, L, P, 2) or tuple(attn_weight.shape) != (B, Nq, M, L, P):
+        raise RuntimeError(f"{what}: inconsistent shapes value{tuple(value.shape)} "
+                           f"loc{tuple(sampling_loc.shape)} aw{tuple(attn_weight.shape)}")
+    step = min(B, int(im2col_step)) if B > 0 else 1
+    if step <= 0 or B % step != 0:
+        # reference: AT_ASSERTM(batch % im2col_step_ == 0, ...)  ms_deform_attn_cuda.cu:42-44
+        raise RuntimeError(f"{what}: batch({B}) must divide im2col_step({step})")
+    return B, Nv, M, D, L, Nq, P
+
+
+def ms_deform_attn_forward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                           sampling_loc: Tensor, attn_weight: Tensor, im2col_step: int) -> Tensor:
+    """``_C.ms_deform_attn_forward`` (ms_deform_attn_cuda.cu:12-72).  Returns ``[B, Nq, M*D]``.
+
+    The reference chunks the batch by ``im2col_step`` only to bound its int32 thread index; the
+    HIP launcher covers the whole batch in one launch, so the step is validated and otherwise unused.
+    """
+    B, Nv, M, D, L, Nq, P = _op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                     im2col_step, "ms_deform_attn_forward")
+    out = torch.empty((B, Nq, M * D), dtype=value.dtype, device=value.device)
+    fn = _hip.lib().sdetr_msda_im2col_f32 if value.dtype == torch.float32 else _hip.lib().sdetr_msda_im2col_f64
+    with torch.cuda.device(value.device):
+        code = fn(_hip.stream_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                  sampling_loc.data_ptr(), attn_weight.data_ptr(), B, Nv, M, D, L, Nq, P, out.data_ptr())
+    _hip.check(code, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                            sampling_loc: Tensor, attn_weight: Tensor, grad_output: Tensor, im2col_step: int):
+    """``_C.ms_deform_attn_backward`` (ms_deform_attn_cuda.cu:75-145).
+    Returns ``[grad_value, grad_sampling_loc, grad_attn_weight]``."""
+    B, Nv, M, D, L, Nq, P = _op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                     im2col_step, "ms_deform_attn_backward")
+    _hip.require_device("ms_deform_attn_backward", grad_output=grad_output)
+    if grad_output.dtype != value.dtype or grad_output.numel() != B * Nq * M * D:
+        raise RuntimeError("ms_deform_attn_backward: grad_output must be [B, Nq, M*D] of value's dtype")
+    grad_value = torch.zeros_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_aw = torch.empty_like(attn_weight)
+    fn = _hip.lib().sdetr_msda_col2im_f32 if value.dtype == torch.float32 else _hip.lib().sdetr_msda_col2im_f64
+    with torch.cuda.device(value.device):
+        code = fn(_hip.stream_ptr(), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+                  level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                  B, Nv, M, D, L, Nq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr())
+    _hip.check(code, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_aw]
+
+
+class MultiScaleDeformableAttnFunction(Function):
+    """Autograd wrapper with the reference's argument order (ms_deform_attn.py:35-84)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                        sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        grad_value, grad_loc, grad_aw = ms_deform_attn_backward(
+            value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step)
+        return grad_value, None, None, grad_loc, grad_aw, None
+
+
+# ------------------------------------------------------------------------------------------------
+# native-layout helpers (no reference symbol; the inside of MultiScaleDeformableAttention.forward)
+# ------------------------------------------------------------------------------------------------
+def value_to_head_major(value_proj_out: Tensor, key_padding_mask: Optional[Tensor], num_heads: int,
+                        out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """masked_fill(padding, 0) + head split of ms_deform_attn.py:318-321, written ``[B, M, Nv, D]``.
+
+    ``value_proj_out`` is ``[B, Nv, M*D]`` and may be a column slice of a wider GEMM output
+    (row stride > M*D), e.g. one layer of a batched all-layers value projection.
+    """
+    B, Nv, E = value_proj_out.shape
+    if not value_proj_out.is_cuda:
+        raise RuntimeError("value_to_head_major: value must be a HIP (cuda) tensor; no CPU fallback")
+    if value_proj_out.stride(2) != 1 or value_proj_out.stride(0) != Nv * value_proj_out.stride(1):
+        value_proj_out = value_proj_out.contiguous()
+    D = E // num_heads
+    out_dtype = out_dtype or value_proj_out.dtype
+    dst = torch.empty((B, num_heads, Nv, D), dtype=out_dtype, device=value_proj_out.device)
+    mask_u8 = None
+    if key_padding_mask is not None:
+        _hip.require_device("value_to_head_major", key_padding_mask=key_padding_mask)
+        mask_u8 = key_padding_mask.view(torch.uint8) if key_padding_mask.dtype == torch.bool else key_padding_mask
+    with torch.cuda.device(dst.device):
+        code = _hip.lib().sdetr_value_to_head_major(
+            _hip.stream_ptr(), value_proj_out.data_ptr(), _hip.dtype_code(value_proj_out.dtype),
+            value_proj_out.stride(1), _hip.ptr(mask_u8), B, Nv, num_heads, D, dst.data_ptr(),
+            _hip.dtype_code(out_dtype))
+    _hip.check(code, "value_to_head_major")
+    return dst
+
+
+def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                       reference_points: Tensor, proj: Tensor, num_levels: int, num_points: int,
+                       order: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """softmax + sampling locations + gather-reduce in one launch (ms_deform_attn.py:322-372).
+
+    ``proj`` is the concatenated ``[sampling_offsets | attention_weights]`` projection of the query,
+    ``[B, Nq, >= 3*M*L*P]``; ``reference_points`` is ``[B, Nq, L, 2|4]`` fp32.
+    """
+    _hip.require_device("msda_fused_forward", value_hm=value_hm, spatial_shapes=spatial_shapes,
+                        level_start_index=level_start_index, reference_points=reference_points, order=order)
+    if reference_points.shape[-1] not in (2, 4):
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+            reference_points.shape[-1]))
+    B, M, Nv, D = value_hm.shape
+    Nq = proj.shape[1]
+    if proj.stride(2) != 1 or proj.stride(0) != Nq * proj.stride(1):
+        proj = proj.contiguous()
+    if reference_points.dtype != torch.float32:
+        reference_points = reference_points.float()
+    out_dtype = out_dtype or proj.dtype
+    out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
+    with torch.cuda.device(out.device):
+        code = _hip.lib().sdetr_msda_fused_forward(
+            _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), reference_points.data_ptr(), reference_points.shape[-1],
+            proj.data_ptr(), _hip.dtype_code(proj.dtype), proj.stride(1), _hip.ptr(order),
+            B, Nv, M, D, num_levels, Nq, num_points, out.data_ptr(), _hip.dtype_code(out_dtype))
+    _hip.check(code, "msda_fused_forward")
+    return out
+
+
+def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
+                            sampling_loc: Tensor, attn_weight: Tensor,
+                            out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """The reference op's math on the head-major value layout (explicit fp32 locations / weights)."""
+    _hip.require_device("msda_forward_head_major", value_hm=value_hm, spatial_shapes=spatial_shapes,
+                        level_start_index=level_start_index, sampling_loc=sampling_loc, attn_weight=attn_weight)
+    B, M, Nv, D = value_hm.shape
+    _, Nq, _, L, P, _ = sampling_loc.shape
+    out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
+    with torch.cuda.device(out.device):
+        code = _hip.lib().sdetr_msda_forward_head_major(
+            _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            B, Nv, M, D, L, Nq, P, out.data_ptr(), _hip.dtype_code(out_dtype))
+    _hip.check(code, "msda_forward_head_major")
+    return out
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    """Multi-Scale Deformable Attention Module (Deformable-DETR), MI355X-native inside.
+
+    Constructor / parameters / ``forward`` signature as the reference class
+    (``models/bricks/ms_deform_attn.py:215-294``).  ``value_dtype`` selects the storage type of the
+    head-major value map on the no-grad path (``None`` = the activation dtype).
+    """
+
+    def __init__(self, embed_dim: int = 256, num_levels: int = 4, num_heads: int = 8, num_points: int = 4,
+                 img2col_step: int = 64, value_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        if embed_dim % num_heads != 0:
+            raise ValueError(
+                "embed_dim must be divisible by num_heads, but got {} and {}".format(embed_dim, num_heads))
+        head_dim = embed_dim // num_heads
+        if not _is_power_of_2(head_dim):
+            warnings.warn("You'd better set embed_dim in MSDeformAttn to make sure that each dim of the "
+                          "attention head a power of 2, which is more efficient.")
+        self.im2col_step = img2col_step
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.num_levels = num_levels
+        self.num_points = num_points
+        self.value_dtype = value_dtype
+        self.sampling_offsets = nn.Linear(embed_dim, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dim, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dim, embed_dim)
+        self.output_proj = nn.Linear(embed_dim, embed_dim)
+        self._fused_cache = None
+        self.init_weights()
+
+    def init_weights(self):
+        """Default initialisation (ms_deform_attn.py:262-284): zero offset weights, 8-direction ring
+        bias scaled by the point index, uniform attention, xavier value/output projections."""
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2)
+        grid = grid.repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.view(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    # -- native path pieces --------------------------------------------------------------------
+    def _fused_query_projection(self):
+        """[sampling_offsets ; attention_weights] as one (384 x 256) GEMM operand, cached per
+        parameter version so eval-mode forwards do not re-concatenate."""
+        ps = (self.sampling_offsets.weight, self.sampling_offsets.bias,
+              self.attention_weights.weight, self.attention_weights.bias)
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        if self._fused_cache is None or self._fused_cache[0] != key:
+            w = torch.cat([ps[0].detach(), ps[2].detach()], 0).contiguous()
+            b = torch.cat([ps[1].detach(), ps[3].detach()], 0).contiguous()
+            self._fused_cache = (key, w, b)
+        return self._fused_cache[1], self._fused_cache[2]
+
+    def project_value(self, value: Tensor, key_padding_mask: Optional[Tensor]) -> Tensor:
+        """value_proj + padding zero-fill + head-major re-layout -> ``[B, M, Nv, D]``."""
+        v = F.linear(value, self.value_proj.weight, self.value_proj.bias)
+        return value_to_head_major(v, key_padding_mask, self.num_heads, self.value_dtype or v.dtype)
+
+    def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
+                       level_start_index: Tensor, order: Optional[Tensor] = None) -> Tensor:
+        w, b = self._fused_query_projection()
+        proj = F.linear(query, w, b)
+        out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
+                                 self.num_levels, self.num_points, order=order, out_dtype=query.dtype)
+        return F.linear(out, self.output_proj.weight, self.output_proj.bias)
+
+    # -- reference signature -------------------------------------------------------------------
+    def forward(self, query: Tensor, reference_points: Tensor, value: Tensor, spatial_shapes: Tensor,
+                level_start_index: Tensor, key_padding_mask: Tensor) -> Tensor:
+        """Same contract as the reference ``forward`` (ms_deform_attn.py:286-377):
+        query ``[B,Nq,E]``, reference_points ``[B,Nq,L,2|4]`` in [0,1], value ``[B,Nv,E]``,
+        spatial_shapes ``[L,2]`` (h,w), level_start_index ``[L]``, key_padding_mask ``[B,Nv]`` or None."""
+        batch_size, num_query, _ = query.shape
+        batch_size, num_value, _ = value.shape
+        if not query.is_cuda:
+            raise RuntimeError("MultiScaleDeformableAttention: the HIP extension path needs device tensors; "
+                               "there is no CPU fallback (the CPU restatement lives in oracle/)")
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        needs_grad = torch.is_grad_enabled() and (
+            query.requires_grad or value.requires_grad or reference_points.requires_grad
+            or any(p.requires_grad for p in self.parameters()))
+        if not needs_grad:
+            value_hm = self.project_value(value, key_padding_mask)
+            return self.forward_native(query, reference_points, value_hm, spatial_shapes, level_start_index)
+
+        # autograd path: reference layout, fp32 op with the HIP forward/backward kernels
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], float(0))
+        value = value.view(batch_size, num_value, self.num_heads, self.embed_dim // self.num_heads)
+        sampling_offsets = self.sampling_offsets(query).view(
+            batch_size, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        attention_weights = self.attention_weights(query).view(
+            batch_size, num_query, self.num_heads, self.num_levels * self.num_points)
+        attention_weights = attention_weights.softmax(-1).view(
+            batch_size, num_query, self.num_heads, self.num_levels, self.num_points)
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            sampling_locations = (reference_points[:, :, None, :, None, :]
+                                  + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
+        else:
+            sampling_locations = (reference_points[:, :, None, :, None, :2]
+                                  + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5)
+        output = MultiScaleDeformableAttnFunction.apply(
+            value.to(torch.float32).contiguous(), spatial_shapes, level_start_index,
+            sampling_locations.to(torch.float32).contiguous(), attention_weights.to(torch.float32).contiguous(),
+            self.im2col_step)
+        if value.dtype != torch.float32:
+            output = output.to(value.dtype)
+        return self.output_proj(output)

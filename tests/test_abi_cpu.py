@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol the header declares; the product
+path refuses to run without a device (no CPU fallback); host-side argument checks."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from salience_detr_amd.csrc import build
+    return build.build()
+
+
+def test_header_symbols_exported(libpath):
+    header = open(os.path.join(ROOT, "include", "salience_hip.h")).read()
+    declared = set(re.findall(r"\b(sdetr_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 12
+    cdll = ctypes.CDLL(libpath)
+    for name in declared:
+        assert hasattr(cdll, name), name
+    from salience_detr_amd import _hip
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    assert _hip.lib().sdetr_abi_version() == 1
+
+
+def test_argument_rejection_without_gpu(libpath):
+    """Invalid arguments are rejected on the host before any launch (safe without a GPU)."""
+    from salience_detr_amd import _hip
+    lib = _hip.lib()
+    assert lib.sdetr_masked_topk_desc_f32(None, None, None, 0, None, 2, 10, 11, 0, None, None, None, 0) == _hip.EINVAL
+    assert b"out of range" in lib.sdetr_last_error()
+    assert lib.sdetr_msda_im2col_f32(None, None, None, None, None, None, 1, 1, 0, 32, 4, 1, 4, None) == _hip.EINVAL
+    assert lib.sdetr_msda_fused_forward(None, 1, 0, 1, 1, 1, 3, 1, 0, 384, None, 1, 1, 8, 32, 4, 1, 4, 1, 0) == _hip.EINVAL
+    assert b"must be 2 or 4" in lib.sdetr_last_error()
+    assert lib.sdetr_topk_workspace_bytes(2, 16800, 6680) == 0
+    assert lib.sdetr_topk_workspace_bytes(1, 67200, 26880) == 32768 * 8
+
+
+def test_no_cpu_fallback():
+    from salience_detr_amd import filter_ops, ms_deform_attn as M
+    from salience_detr_amd import synthetic as syn
+    value, shapes, lsi, loc, aw = syn.make_msda_inputs(1, 5, [(4, 4), (2, 2)], 2, 8, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)
+    with pytest.raises(RuntimeError):
+        filter_ops.masked_topk_desc(torch.zeros(1, 4), 2)
+    mod = M.MultiScaleDeformableAttention(32, 2, 4, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mod(torch.zeros(1, 5, 32), torch.zeros(1, 5, 2, 2), torch.zeros(1, 20, 32), shapes, lsi, None)
+
+
+def test_module_boundary_contract():
+    """B3: constructor errors, parameter names, default initialisation (reference ms_deform_attn.py:221-284)."""
+    from salience_detr_amd.ms_deform_attn import MultiScaleDeformableAttention
+    with pytest.raises(ValueError):
+        MultiScaleDeformableAttention(embed_dim=30, num_heads=8)
+    m = MultiScaleDeformableAttention(256, 4, 8, 4)
+    assert sorted(m.state_dict()) == sorted(
+        f"{n}.{p}" for n in ("sampling_offsets", "attention_weights", "value_proj", "output_proj")
+        for p in ("weight", "bias"))
+    assert m.sampling_offsets.weight.abs().max() == 0 and m.attention_weights.bias.abs().max() == 0
+    bias = m.sampling_offsets.bias.view(8, 4, 4, 2)
+    assert torch.allclose(bias[0, :, :, 0], torch.arange(1.0, 5.0).expand(4, 4))  # head 0 points along +x
+    assert torch.allclose(bias[:, :, 3].abs().max(-1)[0], torch.full((8, 4), 4.0))
+    assert sum(p.numel() for p in m.parameters()) == 230272
