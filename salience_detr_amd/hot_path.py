@@ -1,0 +1,141 @@
+"""The Salience-DETR encoder hot path as one module: ``SalienceTransformer.forward`` from the
+multi-level features down to ``memory`` (reference ``models/bricks/salience_transformer.py:97-183``).
+
+``SalienceEncoderHotPath`` owns exactly the parameters of the reference ``SalienceTransformer`` that the
+path touches, under the SAME state_dict keys (``level_embeds``, ``enc_output*``, ``alpha``,
+``level_filter_ratio`` / ``layer_filter_ratio`` buffers, ``enc_mask_predictor.*``,
+``encoder_class_head.*`` shared with ``encoder.enhance_mcsp.*``, ``encoder.*``), so a released
+checkpoint loads with ``load_state_dict(strict=False)``; the neck, two-stage proposal head and decoder
+(everything after ``memory``) are out of scope.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _hip, pyramid
+from .salience_encoder import SalienceTransformerEncoder, SalienceTransformerEncoderLayer
+from .salience_filtering import MaskPredictor, level_filtering, salience_filtering, token_budgets
+
+
+class SalienceEncoderHotPath(nn.Module):
+    def __init__(self, encoder: SalienceTransformerEncoder, num_classes: int, num_feature_levels: int = 4,
+                 level_filter_ratio: Tuple = (0.25, 0.5, 1.0, 1.0),
+                 layer_filter_ratio: Tuple = (1.0, 0.8, 0.6, 0.6, 0.4, 0.2)):
+        super().__init__()
+        _hip.lib()  # fail loudly at construction if the HIP extension is not built
+        self.embed_dim = encoder.embed_dim
+        self.num_feature_levels = num_feature_levels
+        self.num_classes = num_classes
+        # DETRBaseTransformer / TwostageTransformer parts (base_transformer.py:11-72)
+        self.level_embeds = nn.Parameter(torch.Tensor(num_feature_levels, self.embed_dim))
+        self.enc_output = nn.Linear(self.embed_dim, self.embed_dim)
+        self.enc_output_norm = nn.LayerNorm(self.embed_dim)
+        # salience parameters (salience_transformer.py:68-70)
+        self.register_buffer("level_filter_ratio", torch.Tensor(level_filter_ratio))
+        self.register_buffer("layer_filter_ratio", torch.Tensor(layer_filter_ratio))
+        self.alpha = nn.Parameter(torch.Tensor(3), requires_grad=True)
+        self.encoder = encoder
+        self.encoder_class_head = nn.Linear(self.embed_dim, num_classes)
+        self.encoder.enhance_mcsp = self.encoder_class_head
+        self.enc_mask_predictor = MaskPredictor(self.embed_dim, self.embed_dim)
+        self._ratio_host = (tuple(float(r) for r in level_filter_ratio), tuple(float(r) for r in layer_filter_ratio))
+        self.init_weights()
+
+    def init_weights(self):
+        import math
+        nn.init.normal_(self.level_embeds)
+        nn.init.xavier_uniform_(self.enc_output.weight)
+        nn.init.constant_(self.enc_output.bias, 0.0)
+        nn.init.constant_(self.encoder_class_head.bias, -math.log((1 - 0.01) / 0.01))
+        self.alpha.data.uniform_(-0.3, 0.3)
+
+    def set_encoder_dtype(self, dtype: torch.dtype) -> "SalienceEncoderHotPath":
+        """Run the six encoder layers (and the shared class head) in ``dtype`` (bf16 for the inference
+        benchmark).  The filtering stage -- token selection -- always stays fp32 so that the selected
+        index sets do not depend on the encoder precision."""
+        self.encoder.to(dtype)
+        for layer in self.encoder.layers:
+            layer.self_attn.value_dtype = dtype
+        return self
+
+    @property
+    def encoder_dtype(self) -> torch.dtype:
+        return self.encoder.layers[0].linear1.weight.dtype
+
+    def _ratios(self):
+        """Filter ratios as host floats (float32 values of the registered buffers; refreshed after a
+        checkpoint load changed them -- one tiny D2H copy, then cached)."""
+        key = (self.level_filter_ratio._version, self.layer_filter_ratio._version,
+               self.level_filter_ratio.data_ptr())
+        if getattr(self, "_ratio_key", None) != key:
+            self._ratio_host = (tuple(self.level_filter_ratio.detach().cpu().tolist()),
+                                tuple(self.layer_filter_ratio.detach().cpu().tolist()))
+            self._ratio_key = key
+        return self._ratio_host
+
+    def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
+                multi_level_pos_embeds: Sequence[Tensor],
+                image_sizes: Optional[Sequence[Tuple[int, int]]] = None,
+                canvas: Optional[Tuple[int, int]] = None, return_aux: bool = False):
+        """``(memory [B,S,E], salience_score list[L] of [B,1,H_l,W_l])`` (+ aux dict).
+
+        With ``image_sizes`` (+ the padded ``canvas`` size) the token budgets are computed on the host and
+        the whole forward issues no device->host synchronisation; otherwise one sync reads them back.
+        """
+        level_ratio, layer_ratio = self._ratios()
+        feat_flatten = pyramid.flatten_multi_level(multi_level_feats)
+        mask_flatten = pyramid.flatten_multi_level(multi_level_masks)
+        lvl_pos_embed_flatten = pyramid.get_lvl_pos_embed(self.level_embeds.to(multi_level_pos_embeds[0].dtype),
+                                                          multi_level_pos_embeds)
+        spatial_shapes, level_start_index, valid_ratios = pyramid.multi_level_misc(multi_level_masks)
+        level_shapes = pyramid.level_shapes_of(multi_level_masks)
+        starts = [0]
+        for h, w in level_shapes[:-1]:
+            starts.append(starts[-1] + h * w)
+
+        backbone_output_memory = pyramid.encoder_output_memory(
+            self.enc_output, self.enc_output_norm, feat_flatten + lvl_pos_embed_flatten, mask_flatten, level_shapes)
+
+        if image_sizes is not None:
+            if canvas is None:
+                raise ValueError("image_sizes needs the padded canvas size as well")
+            focus_host, level_host, _ = pyramid.host_token_budgets(image_sizes, canvas, level_shapes, level_ratio)
+            focus_token_nums = torch.as_tensor(focus_host, dtype=torch.int64).to(feat_flatten.device, non_blocking=True)
+            level_token_nums = [int(v) for v in level_host]
+        else:
+            focus_token_nums, level_dev, _ = token_budgets(multi_level_masks, self.level_filter_ratio.float())
+            level_token_nums = level_dev.tolist()  # the stage's single host sync
+            focus_token_nums = focus_token_nums.to(torch.int64)
+
+        salience_score, level_inds, level_score = level_filtering(
+            backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
+            self.alpha)
+        foreground_inds, foreground_score = salience_filtering(salience_score, level_inds, level_score, mask_flatten,
+                                                               layer_ratio)
+        edt = self.encoder_dtype
+        memory = self.encoder(
+            query=feat_flatten.to(edt), query_pos=lvl_pos_embed_flatten.to(edt), query_key_padding_mask=mask_flatten,
+            spatial_shapes=spatial_shapes, level_start_index=level_start_index, valid_ratios=valid_ratios,
+            foreground_score=foreground_score, focus_token_nums=focus_token_nums, foreground_inds=foreground_inds,
+            multi_level_masks=multi_level_masks)
+        if not return_aux:
+            return memory, salience_score
+        aux = dict(feat_flatten=feat_flatten, mask_flatten=mask_flatten, lvl_pos_embed_flatten=lvl_pos_embed_flatten,
+                   spatial_shapes=spatial_shapes, level_start_index=level_start_index, valid_ratios=valid_ratios,
+                   backbone_output_memory=backbone_output_memory, focus_token_nums=focus_token_nums,
+                   level_token_nums=level_token_nums, level_inds=level_inds, level_score=level_score,
+                   foreground_inds=foreground_inds, foreground_score=foreground_score)
+        return memory, salience_score, aux
+
+
+def build_hot_path(embed_dim=256, num_heads=8, d_ffn=2048, num_layers=6, num_classes=91, num_levels=4, num_points=4,
+                   topk_sa=300, max_num_embedding=200, level_filter_ratio=(0.4, 0.8, 1.0, 1.0),
+                   layer_filter_ratio=(1.0, 0.8, 0.6, 0.6, 0.4, 0.2)) -> SalienceEncoderHotPath:
+    """The configuration of ``configs/salience_detr/salience_detr_resnet50_800_1333.py:22-82`` by default."""
+    layer = SalienceTransformerEncoderLayer(embed_dim=embed_dim, d_ffn=d_ffn, dropout=0.0, n_heads=num_heads,
+                                            activation=nn.ReLU(inplace=True), n_levels=num_levels,
+                                            n_points=num_points, topk_sa=topk_sa)
+    encoder = SalienceTransformerEncoder(layer, num_layers=num_layers, max_num_embedding=max_num_embedding)
+    return SalienceEncoderHotPath(encoder, num_classes=num_classes, num_feature_levels=num_levels,
+                                  level_filter_ratio=level_filter_ratio, layer_filter_ratio=layer_filter_ratio)

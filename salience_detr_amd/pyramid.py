@@ -1,0 +1,168 @@
+"""Pyramid plumbing that feeds the filtering stage and the two position
+embeddings the hot path needs.  Device-side torch glue only; no arithmetic kernels live here.
+
+Reference: ``models/bricks/base_transformer.py:22-56, 74-112`` and
+``models/bricks/position_encoding.py:10-99``.
+"""
+import math
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+
+def flatten_multi_level(multi_level_elements: Sequence[Tensor]) -> Tensor:
+    """``[B,(C),H_l,W_l]`` per level -> token-major ``[B,S,(C)]`` (base_transformer.py:22-27)."""
+    flat = torch.cat([e.flatten(-2) for e in multi_level_elements], -1)
+    if flat.ndim == 3:
+        flat = flat.transpose(1, 2).contiguous()
+    return flat
+
+
+def get_lvl_pos_embed(level_embeds: Tensor, multi_level_pos_embeds: Sequence[Tensor]) -> Tensor:
+    """pos + level embedding, flattened (base_transformer.py:29-33)."""
+    return flatten_multi_level([p + level_embeds[l].view(1, -1, 1, 1) for l, p in enumerate(multi_level_pos_embeds)])
+
+
+def get_valid_ratios(mask: Tensor) -> Tensor:
+    """(w, h) valid fraction read off row 0 / column 0 (base_transformer.py:48-56)."""
+    _, h, w = mask.shape
+    valid_h = torch.sum(~mask[:, :, 0], 1)
+    valid_w = torch.sum(~mask[:, 0, :], 1)
+    return torch.stack([valid_w.float() / w, valid_h.float() / h], -1)
+
+
+def multi_level_misc(multi_level_masks: Sequence[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """spatial_shapes [L,2] int64, level_start_index [L] int64 (both on the masks' device, as the
+    reference op reads them from device memory) and valid_ratios [B,L,2] (base_transformer.py:35-46)."""
+    device = multi_level_masks[0].device
+    shapes = torch.as_tensor([tuple(m.shape[-2:]) for m in multi_level_masks], dtype=torch.int64)
+    sizes = shapes.prod(1)
+    lsi = torch.cat((sizes.new_zeros((1,)), sizes.cumsum(0)[:-1]))
+    valid_ratios = torch.stack([get_valid_ratios(m) for m in multi_level_masks], 1)
+    return shapes.to(device), lsi.to(device), valid_ratios
+
+
+def level_shapes_of(multi_level_masks: Sequence[Tensor]) -> List[Tuple[int, int]]:
+    return [tuple(int(s) for s in m.shape[-2:]) for m in multi_level_masks]
+
+
+def encoder_output_memory(enc_output: nn.Linear, enc_output_norm: nn.LayerNorm, memory: Tensor,
+                          memory_padding_mask: Tensor, level_shapes: Sequence[Tuple[int, int]]) -> Tensor:
+    """First return value of ``gen_encoder_output_proposals`` (base_transformer.py:74-112): tokens that
+    are padding, or whose proposal box (cx, cy, w, h) leaves (0.01, 0.99), are zeroed before
+    ``LayerNorm(Linear(.))``.  The proposal geometry only depends on the masks, so the keep-mask is
+    built with a handful of small ops and no host sync."""
+    n = memory.shape[0]
+    keep = []
+    cur = 0
+    for lvl, (h, w) in enumerate(level_shapes):
+        m = memory_padding_mask[:, cur:cur + h * w].view(n, h, w)
+        valid_h = torch.sum(~m[:, :, 0], 1).view(n, 1, 1).float()
+        valid_w = torch.sum(~m[:, 0, :], 1).view(n, 1, 1).float()
+        cy = (torch.arange(h, dtype=torch.float32, device=memory.device).view(1, h, 1) + 0.5) / valid_h
+        cx = (torch.arange(w, dtype=torch.float32, device=memory.device).view(1, 1, w) + 0.5) / valid_w
+        wh = 0.05 * 2.0 ** lvl
+        ok = (cx > 0.01) & (cx < 0.99) & (cy > 0.01) & (cy < 0.99)
+        if not (0.01 < wh < 0.99):
+            ok = torch.zeros_like(ok)
+        keep.append(ok.expand(n, h, w).reshape(n, h * w))
+        cur += h * w
+    keep = torch.cat(keep, 1) & ~memory_padding_mask
+    return enc_output_norm(enc_output(memory * keep.unsqueeze(-1).to(memory.dtype)))
+
+
+class PositionEmbeddingSine(nn.Module):
+    """DETR sine embedding of a padding mask (position_encoding.py:10-67); same constructor."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6,
+                 offset=0.0):
+        super().__init__()
+        dim_t = 2 * torch.arange(num_pos_feats).div(2, rounding_mode="floor") / num_pos_feats
+        if isinstance(temperature, int):
+            dim_tx = dim_ty = temperature ** dim_t
+        else:
+            assert len(temperature) == 2, "Only support two elements as (t_x, t_y) in temperature"
+            dim_tx, dim_ty = [t ** dim_t for t in temperature]
+        self.register_buffer("dim_tx", dim_tx)
+        self.register_buffer("dim_ty", dim_ty)
+        self.normalize, self.scale, self.eps, self.offset = normalize, scale, eps, offset
+
+    def forward(self, mask: Tensor) -> Tensor:
+        not_mask = 1 - mask.to(torch.int)
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+        else:
+            y_embed = y_embed + self.offset
+            x_embed = x_embed + self.offset
+        pos_x = x_embed[:, :, :, None] / self.dim_tx
+        pos_y = y_embed[:, :, :, None] / self.dim_ty
+        pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
+        pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """Learned row/column embedding (position_encoding.py:70-99); used as the encoder's background
+    embedding.  ``flat(level_shapes)`` returns the batch-independent ``[S, 2*num_pos_feats]`` table."""
+
+    def __init__(self, num_embeddings: int = 50, num_pos_feats: int = 256):
+        super().__init__()
+        self.row_embed = nn.Embedding(num_embeddings, num_pos_feats)
+        self.col_embed = nn.Embedding(num_embeddings, num_pos_feats)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def level_table(self, h: int, w: int) -> Tensor:
+        if h > self.row_embed.num_embeddings or w > self.col_embed.num_embeddings:
+            raise IndexError(f"feature map {h}x{w} exceeds max_num_embedding={self.row_embed.num_embeddings}")
+        x_emb = self.col_embed.weight[:w]
+        y_emb = self.row_embed.weight[:h]
+        return torch.cat([x_emb.unsqueeze(0).expand(h, w, -1), y_emb.unsqueeze(1).expand(h, w, -1)], dim=-1)
+
+    def flat(self, level_shapes: Sequence[Tuple[int, int]]) -> Tensor:
+        return torch.cat([self.level_table(h, w).reshape(h * w, -1) for h, w in level_shapes], 0)
+
+    def forward(self, mask: Tensor) -> Tensor:
+        h, w = mask.shape[-2:]
+        return self.level_table(h, w).permute(2, 0, 1).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side token budgets (no device sync): the data-dependent sizes of the filtering stage
+# ------------------------------------------------------------------------------------------------
+def _nearest_valid_extent(valid: int, size_in: int, size_out: int) -> int:
+    """Number of output rows/cols of F.interpolate(mode='nearest') that map to a valid input index
+    (< ``valid``); same float32 index arithmetic as ATen (src = floor(dst * in/out))."""
+    scale = np.float32(size_in) / np.float32(size_out)
+    src = np.minimum(np.floor(np.arange(size_out, dtype=np.float32) * scale).astype(np.int64), size_in - 1)
+    return int((src < valid).sum())
+
+
+def host_token_budgets(image_sizes: Sequence[Tuple[int, int]], canvas: Tuple[int, int],
+                       level_shapes: Sequence[Tuple[int, int]], level_filter_ratio: Sequence[float]):
+    """``focus_token_nums`` [B], ``level_token_nums`` [L] and valid tokens [B,L] computed on the HOST from
+    the image sizes, reproducing salience_transformer.py:116-121 including the float32 product that is
+    truncated by ``.int()``.  Lets a caller that knows its image sizes (the detector does) run the
+    filtering stage without any device->host synchronisation."""
+    ratio = np.asarray(level_filter_ratio, dtype=np.float32)
+    valid = np.zeros((len(image_sizes), len(level_shapes)), dtype=np.int64)
+    for b, (h, w) in enumerate(image_sizes):
+        for l, (hl, wl) in enumerate(level_shapes):
+            valid[b, l] = _nearest_valid_extent(h, canvas[0], hl) * _nearest_valid_extent(w, canvas[1], wl)
+    focus = (valid.astype(np.float32) * ratio[None]).astype(np.int32)  # trunc toward zero like .int()
+    return focus.sum(-1).astype(np.int64), focus.max(0).astype(np.int64), valid
+
+
+def layer_token_counts(num_inds: int, layer_filter_ratio: Sequence[float]) -> List[int]:
+    """``(num_inds * layer_filter_ratio).to(int64)`` in float32 (salience_transformer.py:161-165)."""
+    r = np.asarray(layer_filter_ratio, dtype=np.float32)
+    return [int(v) for v in (np.float32(num_inds) * r).astype(np.int64)]

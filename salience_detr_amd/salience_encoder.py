@@ -1,0 +1,240 @@
+"""Salience-DETR transformer encoder on MI355X (boundary B5).
+
+Same classes, constructor arguments, parameter names and ``forward`` signatures as the reference
+(``models/bricks/salience_transformer.py:298-497``) so ``SalienceTransformer`` can hold this encoder
+unchanged; inside, the no-grad path is re-organised for the hardware:
+
+* the six layers sample the SAME, never-updated feature map (``value = output = query``, :452), so all
+  six ``value_proj`` GEMMs run as ONE [Nv,256]x[256,1536] GEMM and each layer's slice is re-laid
+  head-major (optionally bf16) by ``value_to_head_major``;
+* query / position / reference-point rows move with 16-byte-lane gather/scatter kernels (no expanded
+  int64 index tensors), the per-image ``focus_token_nums`` prefix is applied on the device (no host
+  sync, no python loop over images);
+* the per-layer top-300 selection uses the single-workgroup top-k kernel;
+* softmax + sampling locations + bilinear gather are one launch (``msda_fused_forward``).
+
+With autograd enabled the layers fall back to differentiable torch indexing around the HIP
+forward/backward op (``MultiScaleDeformableAttnFunction``).
+"""
+import copy
+import math
+from typing import List, Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+from . import pyramid
+from .filter_ops import gather_rows, masked_topk_desc, scatter_rows_
+from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
+from .pyramid import PositionEmbeddingLearned
+
+
+def _needs_grad(module: nn.Module, *tensors) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters())
+
+
+class SalienceTransformerEncoderLayer(nn.Module):
+    """One encoder layer (salience_transformer.py:298-396): top-``topk_sa`` dense self-attention,
+    multi-scale deformable self-attention over the filtered queries, FFN."""
+
+    def __init__(self, embed_dim=256, d_ffn=1024, dropout=0.1, n_heads=8, activation=nn.ReLU(inplace=True),
+                 n_levels=4, n_points=4, topk_sa=300):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.topk_sa = topk_sa
+        self.n_heads = n_heads
+        # pre attention
+        self.pre_attention = nn.MultiheadAttention(embed_dim, n_heads, dropout, batch_first=True)
+        self.pre_dropout = nn.Dropout(dropout)
+        self.pre_norm = nn.LayerNorm(embed_dim)
+        # self attention
+        self.self_attn = MultiScaleDeformableAttention(embed_dim, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        # ffn
+        self.linear1 = nn.Linear(embed_dim, d_ffn)
+        self.activation = activation
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, embed_dim)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.xavier_uniform_(self.pre_attention.in_proj_weight)
+        nn.init.xavier_uniform_(self.pre_attention.out_proj.weight)
+        nn.init.xavier_uniform_(self.linear1.weight)
+        nn.init.xavier_uniform_(self.linear2.weight)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, query):
+        src2 = self.linear2(self.dropout2(self.activation(self.linear1(query))))
+        return self.norm2(query + self.dropout3(src2))
+
+    def _pre_attention(self, qk: Tensor, v: Tensor) -> Tensor:
+        """nn.MultiheadAttention(q=k=qk, value=v) with the module's own parameters, as three GEMMs and
+        one batched softmax(QK^T)V over the 300 selected tokens (salience_transformer.py:371-376)."""
+        mha = self.pre_attention
+        B, N, E = qk.shape
+        H = mha.num_heads
+        hd = E // H
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        q_k = F.linear(qk, w[:2 * E], b[:2 * E]).view(B, N, 2, H, hd)
+        q = q_k[:, :, 0].transpose(1, 2)
+        k = q_k[:, :, 1].transpose(1, 2)
+        vv = F.linear(v, w[2 * E:], b[2 * E:]).view(B, N, H, hd).transpose(1, 2)
+        att = torch.matmul(q * (1.0 / math.sqrt(hd)), k.transpose(-1, -2)).softmax(-1)
+        if self.training and mha.dropout > 0:
+            att = F.dropout(att, mha.dropout)
+        o = torch.matmul(att, vv).transpose(1, 2).reshape(B, N, E)
+        return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+
+    def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
+                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None):
+        """Reference signature (salience_transformer.py:353-364) plus an optional pre-projected
+        head-major ``value_hm`` (``[B,M,Nv,D]``) supplied by the encoder's batched value projection."""
+        native = not _needs_grad(self, query, value)
+        mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
+        if native:
+            select_tgt_index = masked_topk_desc(mc_score.float().contiguous(), self.topk_sa, want_scores=False)[1]
+            select_tgt = gather_rows(query, select_tgt_index)
+            select_pos = gather_rows(query_pos, select_tgt_index)
+        else:
+            select_tgt_index = torch.sort(mc_score, dim=1, descending=True, stable=True)[1][:, :self.topk_sa]
+            index_e = select_tgt_index.unsqueeze(-1).expand(-1, -1, self.embed_dim)
+            select_tgt = torch.gather(query, 1, index_e)
+            select_pos = torch.gather(query_pos, 1, index_e)
+        tgt2 = self._pre_attention(self.with_pos_embed(select_tgt, select_pos), select_tgt)
+        select_tgt = self.pre_norm(select_tgt + self.pre_dropout(tgt2))
+        if native:
+            query = scatter_rows_(query, select_tgt_index, select_tgt)  # query is the layer's own gathered copy
+        else:
+            query = query.scatter(1, index_e, select_tgt)
+
+        # multi-scale deformable self attention
+        if native:
+            if value_hm is None:
+                value_hm = self.self_attn.project_value(value, query_key_padding_mask)
+            src2 = self.self_attn.forward_native(self.with_pos_embed(query, query_pos), reference_points, value_hm,
+                                                 spatial_shapes, level_start_index)
+        else:
+            src2 = self.self_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
+                                  value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                  key_padding_mask=query_key_padding_mask)
+        query = self.norm1(query + self.dropout1(src2))
+        return self.forward_ffn(query)
+
+
+class SalienceTransformerEncoder(nn.Module):
+    """Encoder over salience-filtered queries (salience_transformer.py:399-497)."""
+
+    def __init__(self, encoder_layer: nn.Module, num_layers: int = 6, max_num_embedding=200):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.embed_dim = encoder_layer.embed_dim
+        # learnt background embed for prediction
+        self.background_embedding = PositionEmbeddingLearned(max_num_embedding, num_pos_feats=self.embed_dim // 2)
+        self._value_proj_cache = None
+        self.init_weights()
+
+    def init_weights(self):
+        for layer in self.layers:
+            if hasattr(layer, "init_weights"):
+                layer.init_weights()
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel-centre reference points scaled by the valid ratios -> ``[B,S,L,2]``
+        (salience_transformer.py:418-432).  ``spatial_shapes`` may be a tensor or a list of (h, w)."""
+        shapes = spatial_shapes.tolist() if isinstance(spatial_shapes, Tensor) else list(spatial_shapes)
+        xs, ys, lv, sz = [], [], [], []
+        for lvl, (h, w) in enumerate(shapes):
+            ys.append((torch.arange(h, dtype=torch.float32, device=device) + 0.5).view(h, 1).expand(h, w).reshape(-1))
+            xs.append((torch.arange(w, dtype=torch.float32, device=device) + 0.5).view(1, w).expand(h, w).reshape(-1))
+            lv.append(torch.full((h * w,), lvl, dtype=torch.int64, device=device))
+            sz.append(torch.tensor([float(w), float(h)], device=device).expand(h * w, 2))
+        pix = torch.stack([torch.cat(xs), torch.cat(ys)], -1)            # [S,2] pixel centres (x+0.5, y+0.5)
+        own = valid_ratios[:, torch.cat(lv)]                              # [B,S,2] the token's own level ratio
+        centre = pix[None] / (own * torch.cat(sz)[None])                  # (idx + 0.5) / (valid_ratio * size)
+        return centre[:, :, None] * valid_ratios[:, None]
+
+    def _all_value_projections(self):
+        """[6*E, E] weight / [6*E] bias of every layer's value_proj, cached per parameter version."""
+        ps = [p for l in self.layers for p in (l.self_attn.value_proj.weight, l.self_attn.value_proj.bias)]
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+        if self._value_proj_cache is None or self._value_proj_cache[0] != key:
+            w = torch.cat([l.self_attn.value_proj.weight.detach() for l in self.layers], 0).contiguous()
+            b = torch.cat([l.self_attn.value_proj.bias.detach() for l in self.layers], 0).contiguous()
+            self._value_proj_cache = (key, w, b)
+        return self._value_proj_cache[1], self._value_proj_cache[2]
+
+    def forward(self, query, spatial_shapes, level_start_index, valid_ratios, query_pos=None,
+                query_key_padding_mask=None, foreground_score=None, focus_token_nums=None, foreground_inds=None,
+                multi_level_masks=None):
+        """Reference signature (salience_transformer.py:434-447).  ``foreground_inds`` is the list of
+        per-layer ``[B,Nq_k]`` index tensors, ``focus_token_nums`` ``[B]`` the per-image valid prefix."""
+        if not query.is_cuda:
+            raise RuntimeError("SalienceTransformerEncoder: HIP device tensors required; there is no CPU fallback")
+        native = not _needs_grad(self, query, query_pos)
+        E = self.embed_dim
+        level_shapes = pyramid.level_shapes_of(multi_level_masks) if multi_level_masks is not None \
+            else [tuple(s) for s in spatial_shapes.tolist()]
+        reference_points = self.get_reference_points(level_shapes, valid_ratios, device=query.device)
+        b, n, s, p = reference_points.shape
+        ori_reference_points = reference_points.reshape(b, n, s * p).contiguous()
+        ori_pos = query_pos
+        value = query
+        output = query.clone() if native else query
+        focus64 = focus_token_nums.to(torch.int64).contiguous()
+
+        value_hm_all = None
+        if native:
+            heads = self.layers[0].self_attn.num_heads
+            w_all, b_all = self._all_value_projections()
+            v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
+            vdt = self.layers[0].self_attn.value_dtype or v_all.dtype
+            value_hm_all = [value_to_head_major(v_all[:, :, k * E:(k + 1) * E], query_key_padding_mask, heads, vdt)
+                            for k in range(self.num_layers)]
+
+        inds = None
+        for layer_id, layer in enumerate(self.layers):
+            inds = foreground_inds[layer_id]
+            if native:
+                inds = inds.contiguous()
+                q = gather_rows(output, inds)
+                q_pos = gather_rows(ori_pos, inds)
+                fg = torch.gather(foreground_score, 1, inds)
+                ref = gather_rows(ori_reference_points, inds).view(b, -1, s, p)
+            else:
+                inds_e = inds.unsqueeze(-1).expand(-1, -1, E)
+                q = torch.gather(output, 1, inds_e)
+                q_pos = torch.gather(ori_pos, 1, inds_e)
+                fg = torch.gather(foreground_score, 1, inds)
+                ref = torch.gather(ori_reference_points, 1, inds.unsqueeze(-1).repeat(1, 1, s * p)).view(b, -1, s, p)
+            score_tgt = self.enhance_mcsp(q)
+            q = layer(q, q_pos, value, ref, spatial_shapes, level_start_index, query_key_padding_mask, score_tgt, fg,
+                      value_hm=value_hm_all[layer_id] if native else None)
+            if native:
+                scatter_rows_(output, inds, q, count=focus64)
+            else:
+                rows = torch.arange(inds.shape[1], device=inds.device)[None] < focus64[:, None]   # [B,Nq]
+                keep_old = torch.gather(output, 1, inds.unsqueeze(-1).expand(-1, -1, E))
+                output = output.scatter(1, inds.unsqueeze(-1).expand(-1, -1, E),
+                                        torch.where(rows[..., None], q, keep_old))
+
+        # learnt embedding for background tokens: every token that is neither padding nor in the LAST
+        # layer's index set (salience_transformer.py:487-495)
+        if multi_level_masks is not None:
+            bg = self.background_embedding.flat(level_shapes).to(output.dtype)        # [S, E]
+            keep = torch.ones(b, n, dtype=output.dtype, device=output.device)
+            keep.scatter_(1, inds, 0.0)
+            keep = keep * (~query_key_padding_mask).to(output.dtype)
+            output = torch.addcmul(output, bg.unsqueeze(0), keep.unsqueeze(-1))
+        return output

@@ -1,0 +1,111 @@
+"""Hierarchical salience filtering (boundary B4).
+
+The reference keeps this logic inline in ``SalienceTransformer.forward``
+(``models/bricks/salience_transformer.py:116-168``); here it is two operators with pinned
+inputs/outputs:
+
+* ``level_filtering``   == lines 123-154: coarse-to-fine salience prediction and the per-level
+  masked top-k, whose sort/selection runs in the single-workgroup HIP kernel of ``csrc/topk.hip``.
+* ``salience_filtering`` == lines 116-121 + 156-168: token budgets, global sort of the selected
+  scores, per-layer prefixes and the flattened foreground score.
+
+Index outputs are bit-identical to the reference on tie-free inputs; equal scores are ordered
+lower-index-first (torch leaves tie order unspecified).  ``salience_score`` stays differentiable
+w.r.t. the mask predictor and ``alpha`` because only the index selection goes through the kernel.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+from . import pyramid
+from .filter_ops import masked_topk_desc
+
+
+class MaskPredictor(nn.Module):
+    """Salience head (salience_transformer.py:16-47); identical parameter names
+    (``layer1.0`` LayerNorm, ``layer1.1`` Linear, ``layer2.{0,2,4}`` Linear)."""
+
+    def __init__(self, in_dim: int, h_dim: int):
+        super().__init__()
+        self.h_dim = h_dim
+        self.layer1 = nn.Sequential(nn.LayerNorm(in_dim), nn.Linear(in_dim, h_dim), nn.GELU())
+        self.layer2 = nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.GELU(), nn.Linear(h_dim // 2, h_dim // 4),
+                                    nn.GELU(), nn.Linear(h_dim // 4, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x: Tensor) -> Tensor:
+        z = self.layer1(x)
+        half = self.h_dim // 2
+        # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
+        z = torch.cat([z[..., :half], z[..., half:].mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
+        return self.layer2(z)
+
+
+def token_budgets(multi_level_masks: Sequence[Tensor], level_filter_ratio: Tensor):
+    """Device-side budgets (salience_transformer.py:116-121).  Returns
+    ``(focus_token_nums [B] int64, level_token_nums [L] int32, valid_token_nums [B,L])`` as device tensors;
+    turning ``level_token_nums`` into python ints costs the one host sync this stage needs -- callers that
+    know their image sizes use ``pyramid.host_token_budgets`` instead and never synchronise."""
+    valid = torch.stack([(~m).sum((1, 2)) for m in multi_level_masks], -1)
+    focus = (valid * level_filter_ratio).int()
+    return focus.sum(-1), focus.max(0)[0], valid
+
+
+def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_shapes: Sequence[Tuple[int, int]],
+                    level_start_index: Sequence[int], level_token_nums: Sequence[int], mask_predictor: nn.Module,
+                    alpha: Tensor):
+    """Coarse-to-fine salience scores + per-level top-k (salience_transformer.py:123-154).
+
+    ``level_shapes`` / ``level_start_index`` / ``level_token_nums`` are python ints (shapes come from the
+    tensors' own sizes; budgets from ``token_budgets``/``host_token_budgets``).
+    Returns ``(salience_score: list[L] of [B,1,H_l,W_l], level_inds: list[L] of [B,k_l] int64 (global token
+    index), level_score: list[L] of [B,k_l])`` ordered low level -> high level.
+    """
+    B = backbone_output_memory.shape[0]
+    L = len(level_shapes)
+    salience_score: List[Optional[Tensor]] = [None] * L
+    level_inds: List[Optional[Tensor]] = [None] * L
+    level_score: List[Optional[Tensor]] = [None] * L
+    score = None
+    for lvl in range(L - 1, -1, -1):
+        h, w = level_shapes[lvl]
+        start = int(level_start_index[lvl])
+        level_memory = backbone_output_memory[:, start:start + h * w, :]
+        mask = mask_flatten[:, start:start + h * w].contiguous()
+        if lvl != L - 1:
+            up = F.interpolate(score, size=(h, w), mode="bilinear", align_corners=True)
+            up = up.view(B, -1, h * w).transpose(1, 2)
+            level_memory = level_memory + level_memory * up * alpha[lvl]
+        token_score = mask_predictor(level_memory)                      # [B, hw, 1]
+        score = token_score.transpose(1, 2).reshape(B, -1, h, w)
+        # masked_fill(mask, score.min()) + topk, fused in one launch; fp32 keys
+        s32 = token_score.detach().squeeze(-1).float().contiguous()
+        ls, li = masked_topk_desc(s32, int(level_token_nums[lvl]), mask=mask, fill_with_global_min=True,
+                                  index_offset=start)
+        salience_score[lvl] = score
+        level_inds[lvl] = li
+        level_score[lvl] = ls
+    return salience_score, level_inds, level_score
+
+
+def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Tensor], level_score: Sequence[Tensor],
+                       mask_flatten: Tensor, layer_filter_ratio: Sequence[float]):
+    """Global sort, per-layer prefixes and foreground score (salience_transformer.py:156-168).
+
+    Returns ``(foreground_inds: list[num_layers] of [B,Nq_k] int64, foreground_score [B,S])`` -- exactly the
+    ``foreground_inds`` / ``foreground_score`` keyword arguments of ``SalienceTransformerEncoder.forward``.
+    """
+    selected_score = torch.cat(list(level_score), 1)
+    selected_inds = torch.cat(list(level_inds), 1)
+    n = selected_inds.shape[1]
+    _, sorted_inds = masked_topk_desc(selected_score, n, payload=selected_inds, want_scores=False)
+    counts = pyramid.layer_token_counts(n, layer_filter_ratio)
+    foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c].contiguous() for c in counts]
+    fg = pyramid.flatten_multi_level(salience_score).squeeze(-1)
+    fg = torch.where(mask_flatten, fg.min(), fg)
+    return foreground_inds, fg

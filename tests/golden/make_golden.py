@@ -268,7 +268,12 @@ def make_hotpath_full_digest():
             sm = cap["score_maps"][3 - l]
             data[f"{tag}.score_map{l}_sub"] = np_(sm[:, ::13, 0])
         for i, lo in enumerate(cap["layer_out"]):
-            data[f"{tag}.layer_out{i}_sub"] = np_(lo[:, ::53, ::5])
+            # rows of a layer output follow the salience ORDER, which is tie-order dependent at this size
+            # (all border tokens tie); store it scattered into token space, which is not.
+            inds = kw["foreground_inds"][i]
+            tok = torch.zeros(lo.shape[0], kw["query"].shape[1], lo.shape[2])
+            tok.scatter_(1, inds.unsqueeze(-1).expand(-1, -1, lo.shape[2]), lo)
+            data[f"{tag}.layer_out{i}_sub"] = np_(tok[:, ::53, ::5])
             data[f"{tag}.layer_out{i}_stats"] = np.array([float(lo.mean()), float(lo.abs().mean()),
                                                           float(lo.abs().max())])
         mem = cap["memory"]

@@ -1,0 +1,86 @@
+"""CPU: host-side logic of the product package that needs no device -- pyramid plumbing, position
+embeddings, token budgets (host arithmetic == the reference's float32 truncation), checkpoint keys."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import salience_ref as R
+from salience_detr_amd import pyramid
+from salience_detr_amd import synthetic as syn
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("tag", ["single", "mixed"])
+def test_pyramid_plumbing_matches_golden(tag):
+    d = np.load(os.path.join(G, f"hotpath_small_{tag}.npz"))
+    masks = [_t(d[f"mask{l}"]) for l in range(4)]
+    feats = [_t(d[f"feat{l}"]) for l in range(4)]
+    pos = [_t(d[f"pos{l}"]) for l in range(4)]
+    shapes, lsi, vr = pyramid.multi_level_misc(masks)
+    assert torch.equal(shapes, _t(d["spatial_shapes"])) and torch.equal(lsi, _t(d["level_start_index"]))
+    assert (vr - _t(d["valid_ratios"])).abs().max() < 1e-7
+    assert torch.equal(pyramid.flatten_multi_level(feats), _t(d["feat_flatten"]))
+    assert torch.equal(pyramid.flatten_multi_level(masks), _t(d["mask_flatten"]))
+    lp = pyramid.get_lvl_pos_embed(_t(d["sd.level_embeds"]), pos)
+    assert (lp - _t(d["lvl_pos_embed_flatten"])).abs().max() < 1e-6
+    E = int(d["hyper"][0])
+    pe = pyramid.PositionEmbeddingSine(E // 2, temperature=10000, normalize=True, offset=-0.5)
+    for l in range(4):
+        assert (pe(masks[l]) - pos[l]).abs().max() < 2e-6
+    lin = torch.nn.Linear(E, E)
+    ln = torch.nn.LayerNorm(E)
+    lin.load_state_dict({"weight": _t(d["sd.enc_output.weight"]), "bias": _t(d["sd.enc_output.bias"])})
+    ln.load_state_dict({"weight": _t(d["sd.enc_output_norm.weight"]), "bias": _t(d["sd.enc_output_norm.bias"])})
+    with torch.no_grad():
+        bom = pyramid.encoder_output_memory(lin, ln, _t(d["feat_flatten"]) + _t(d["lvl_pos_embed_flatten"]),
+                                            _t(d["mask_flatten"]), pyramid.level_shapes_of(masks))
+    assert (bom - _t(d["backbone_output_memory"])).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("sizes", [[(800, 1333)], [(800, 1333), (800, 1066)], [(640, 480), (333, 500), (512, 512)],
+                                   [(64, 96), (48, 80)], [(1, 1)], [(37, 41), (800, 1201)]])
+def test_host_budgets_equal_device_rule(sizes):
+    canvas = syn.pad_to_32(max(s[0] for s in sizes), max(s[1] for s in sizes))
+    _, masks = syn.make_masks(sizes)
+    ratio = torch.tensor([0.4, 0.8, 1.0, 1.0])
+    focus_ref, level_ref, valid_ref = R.token_budgets(masks, ratio)
+    focus, level, valid = pyramid.host_token_budgets(sizes, canvas, pyramid.level_shapes_of(masks), ratio.tolist())
+    assert valid.tolist() == valid_ref.tolist()
+    assert focus.tolist() == focus_ref.tolist()
+    assert level.tolist() == level_ref.tolist()
+
+
+def test_benchmark_shape_constants():
+    """800x1333 -> levels, Nv, per-level top-k, per-layer query counts."""
+    _, masks = syn.make_masks([(800, 1333)])
+    shapes = pyramid.level_shapes_of(masks)
+    assert shapes == [(100, 168), (50, 84), (25, 42), (13, 21)]
+    focus, level, valid = pyramid.host_token_budgets([(800, 1333)], (800, 1344), shapes, (0.4, 0.8, 1.0, 1.0))
+    assert valid.tolist() == [[16700, 4200, 1050, 273]] and level.tolist() == [6680, 3360, 1050, 273]
+    assert focus.tolist() == [11363]
+    assert pyramid.layer_token_counts(11363, (1.0, 0.8, 0.6, 0.6, 0.4, 0.2)) == [11363, 9090, 6817, 6817, 4545, 2272]
+
+
+def test_reference_points_match_oracle():
+    from salience_detr_amd.salience_encoder import SalienceTransformerEncoder
+    _, masks = syn.make_masks([(64, 96), (48, 80)])
+    shapes, lsi, vr = pyramid.multi_level_misc(masks)
+    got = SalienceTransformerEncoder.get_reference_points(shapes, vr, device="cpu")
+    assert (got - R.encoder_reference_points(shapes, vr)).abs().max() < 1e-6
+
+
+def test_learned_embedding_table_and_limits():
+    pe = pyramid.PositionEmbeddingLearned(20, 16)
+    m = torch.zeros(2, 5, 7, dtype=torch.bool)
+    full = pe(m)
+    assert full.shape == (2, 32, 5, 7)
+    assert torch.equal(full[0].flatten(1).t(), pe.flat([(5, 7)]))
+    with pytest.raises(IndexError):
+        pe.flat([(21, 3)])

@@ -76,7 +76,12 @@ def test_forward_backward_vs_c_oracle(B, Nq, levels, M_, D, P):
     gv, gl, ga = M.ms_deform_attn_backward(dv, shapes.to(DEV), lsi.to(DEV), dloc, daw, go.to(DEV), 64)
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
     assert np.abs(gv.cpu().numpy() - rgv).max() < 2e-4 * max(1.0, np.abs(rgv).max())
-    assert np.abs(gl.cpu().numpy() - rgl).max() < 2e-4 * max(1.0, np.abs(rgl).max())
+    # d(out)/d(loc) jumps where a sampling point sits exactly on a pixel boundary; a 1-ulp difference
+    # in loc*size-0.5 (fma contraction on the GPU) flips floor() there.  Exclude those samples.
+    px = loc * torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()[None, None, None, :, None, :] - 0.5
+    smooth = ((px - px.round()).abs() > 1e-3).all(-1, keepdim=True).expand_as(loc).numpy()
+    assert smooth.mean() > 0.99
+    assert np.abs((gl.cpu().numpy() - rgl) * smooth).max() < 2e-4 * max(1.0, np.abs(rgl).max())
     assert np.abs(ga.cpu().numpy() - rga).max() < 2e-4 * max(1.0, np.abs(rga).max())
 
 
