@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Benchmark of the Salience-DETR encoder hot path on MI355X (contract: see task / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path (F0 pyramid plumbing -> F1-F3 hierarchical salience filtering ->
+6-layer salience encoder, i.e. reference SalienceTransformer.forward lines 97-183) over ONE batch of
+synthetic 800x1333 4-level pyramids resident in HBM, batch-per-GPU = 2, bf16 encoder
+(BASELINE.json configs[1]).  Images are independent, so N GPUs run N replicas of the path on their own
+batches with no data-path collective (weak scaling); the timed region is bracketed by
+barrier + synchronize on both sides and the MAX over ranks is reported.
+
+Rank 0 prints ONE JSON line: whole-job images/s, ms per encoder layer, the `roofline` object of the
+dominant kernel (the fused MSDA gather, measured live with stream events around every launch of an
+instrumented pass) and, at N=1, the `cpu_baseline` (the oracle's CPU port of the same path, timed on the
+host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from salience_detr_amd import ms_deform_attn as msda_mod  # noqa: E402
+from salience_detr_amd import pyramid, synthetic as syn  # noqa: E402
+from salience_detr_amd.hot_path import build_hot_path  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--instrumented-steps", type=int, default=10)
+    return ap.parse_args()
+
+
+def make_inputs(batch, h, w, device, seed):
+    sizes = [(h, w)] * batch
+    canvas = syn.pad_to_32(h, w)
+    _, masks = syn.make_masks(sizes)
+    shapes = pyramid.level_shapes_of(masks)
+    feats = syn.make_feats(batch, shapes, 256, seed=seed)
+    pe = pyramid.PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5)
+    pos = [pe(m) for m in masks]
+    cpu = (feats, masks, pos)
+    dev = tuple([t.to(device) for t in ts] for ts in cpu)
+    return sizes, canvas, shapes, cpu, dev
+
+
+def algorithmic_bytes(B, Nv, Nq, M, D, L, P, value_bytes, proj_bytes, out_bytes, ref_dim=2):
+    """Each input and output of the fused MSDA launch touched exactly once (SURVEY.md 8(d) formula with the
+    fused kernel's actual operands: 3 projection values per sample instead of loc(2)+weight(1), plus the
+    fp32 reference points)."""
+    return B * (Nv * M * D * value_bytes + Nq * M * L * P * 3 * proj_bytes + Nq * L * ref_dim * 4
+                + Nq * M * D * out_bytes)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    model = build_hot_path()
+    model.load_state_dict(syn.det_state_dict(model.state_dict()))
+    model = model.to(device).eval()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.set_encoder_dtype(dtype)
+
+    sizes, canvas, level_shapes, cpu_inputs, (feats, masks, pos) = make_inputs(
+        args.batch, args.height, args.width, device, seed=rank)
+
+    def step():
+        with torch.no_grad():
+            return model(feats, masks, pos, image_sizes=sizes, canvas=canvas)[0]
+
+    for _ in range(max(args.warmup, 3)):
+        out = step()
+    torch.cuda.synchronize()
+
+    graphed = False
+    run = step
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = step()
+            g.replay()
+            torch.cuda.synchronize()
+            run = g.replay
+            graphed = True
+        except Exception as e:  # keep the eager path measurable if capture is unavailable
+            sys.stderr.write(f"[bench] hipGraph capture failed, timing eager launches: {e}\n")
+            torch.cuda.synchronize()
+    for _ in range(3):
+        run()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    images_per_s = world * args.batch * args.steps / elapsed
+
+    # ---- instrumented eager pass: events around every fused-MSDA launch and every layer boundary ----
+    msda_events, layer_events, launches = [], [], []
+    real_fused = msda_mod.msda_fused_forward
+
+    def timed_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
+                    order=None, out_dtype=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o = real_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
+                       order=order, out_dtype=out_dtype)
+        e1.record()
+        msda_events.append((e0, e1))
+        B, M, Nv, D = value_hm.shape
+        launches.append(algorithmic_bytes(B, Nv, proj.shape[1], M, D, num_levels, num_points,
+                                          value_hm.element_size(), proj.element_size(), o.element_size(),
+                                          reference_points.shape[-1]))
+        return o
+
+    def marker(layer_id):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        layer_events.append((layer_id, e))
+
+    msda_mod.msda_fused_forward = timed_fused
+    model.encoder.layer_marker = marker
+    for _ in range(args.instrumented_steps):
+        step()
+    torch.cuda.synchronize()
+    msda_mod.msda_fused_forward = real_fused
+    model.encoder.layer_marker = None
+
+    nl = model.encoder.num_layers
+    msda_us = [0.0] * nl
+    for i, (e0, e1) in enumerate(msda_events):
+        msda_us[i % nl] += e0.elapsed_time(e1) * 1e3 / args.instrumented_steps
+    layer_ms = [0.0] * nl
+    for (l0, e0), (l1, e1) in zip(layer_events[:-1], layer_events[1:]):
+        if l1 == l0 + 1:
+            layer_ms[l0] += e0.elapsed_time(e1) / args.instrumented_steps
+    bytes_per_layer = launches[:nl]
+    total_bytes, total_us = sum(bytes_per_layer), sum(msda_us)
+    achieved = total_bytes / total_us / 1e3  # GB/s
+    roofline = {
+        "kernel": "sdetr::msda_gather_kernel (fused softmax + sampling locations + bilinear gather)",
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "launches_per_step": nl, "avg_launch_us": round(total_us / nl, 2),
+        "per_layer_us": [round(u, 2) for u in msda_us],
+        "per_layer_algorithmic_MB": [round(b / 1e6, 2) for b in bytes_per_layer],
+    }
+
+    result = {
+        "metric": "images/s (whole node) + ms/encoder-layer, ResNet50 800x1333",
+        "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "salience_detr_resnet50_800_1333 %s inference, batch=%d per MI355X: pyramid flatten + "
+                               "hierarchical salience filtering + 6-layer salience encoder (MSDA)" % (args.dtype, args.batch),
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "image": [args.height, args.width], "levels": [list(s) for s in level_shapes],
+                   "parallelism": "replicas, images sharded across GPUs, no data-path collective",
+                   "hipgraph": graphed},
+        "ms_per_encoder_layer": {"mean": round(sum(layer_ms) / nl, 4), "per_layer": [round(x, 4) for x in layer_ms],
+                                 "note": "eager instrumented pass (stream events at layer boundaries)"},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle's port of the same path on the host cores (rank 0, N=1 only) ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import salience_ref as R  # checker / baseline only; never on the product path
+        from oracle import msda_c
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        cf, cm, cp = cpu_inputs
+        cores = torch.get_num_threads()
+        times = []
+        t_start = time.perf_counter()
+        with torch.no_grad():
+            R.hot_path(sd, cf, cm, cp)  # warm-up
+            while len(times) < 5 and time.perf_counter() - t_start < 20.0:
+                t1 = time.perf_counter()
+                ref = R.hot_path(sd, cf, cm, cp)
+                times.append(time.perf_counter() - t1)
+        times.sort()
+        med = times[len(times) // 2]
+        err = (out.float().cpu() - ref["memory"]).abs()
+        result["cpu_baseline"] = {
+            "value": round(args.batch / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d timed passes of the same batch-%d 800x1333 hot path (oracle/salience_ref.py, fp32, "
+                      "torch CPU ops + OpenMP C gather on %d threads), median" % (len(times), args.batch,
+                                                                                  msda_c.num_threads()),
+            "ms_per_pass": round(med * 1e3, 1),
+        }
+        result["parity_vs_cpu"] = {"max_abs": round(float(err.max()), 5), "mean_abs": round(float(err.mean()), 6),
+                                   "note": "GPU %s output vs fp32 CPU oracle on the same batch" % args.dtype}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,9 +100,13 @@ class SalienceEncoderHotPath(nn.Module):
         if image_sizes is not None:
             if canvas is None:
                 raise ValueError("image_sizes needs the padded canvas size as well")
-            focus_host, level_host, _ = pyramid.host_token_budgets(image_sizes, canvas, level_shapes, level_ratio)
-            focus_token_nums = torch.as_tensor(focus_host, dtype=torch.int64).to(feat_flatten.device, non_blocking=True)
-            level_token_nums = [int(v) for v in level_host]
+            def build():
+                focus_host, level_host, _ = pyramid.host_token_budgets(image_sizes, canvas, level_shapes, level_ratio)
+                return (torch.as_tensor(focus_host, dtype=torch.int64).to(feat_flatten.device),
+                        [int(v) for v in level_host])
+            focus_token_nums, level_token_nums = pyramid.static_tensor(
+                ("budgets", tuple(map(tuple, image_sizes)), tuple(canvas), tuple(level_shapes), level_ratio,
+                 str(feat_flatten.device)), build)
         else:
             focus_token_nums, level_dev, _ = token_budgets(multi_level_masks, self.level_filter_ratio.float())
             level_token_nums = level_dev.tolist()  # the stage's single host sync

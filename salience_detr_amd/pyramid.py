@@ -34,15 +34,38 @@ def get_valid_ratios(mask: Tensor) -> Tensor:
     return torch.stack([valid_w.float() / w, valid_h.float() / h], -1)
 
 
+# Small tensors whose content only depends on the pyramid geometry (spatial shapes, level starts,
+# pixel-centre grids, host-computed budgets).  They originate on the host; caching them per
+# (geometry, device) removes the per-forward H2D copies, which also keeps the forward capturable
+# in a hipGraph (no host-memory copies inside the captured region).
+_STATIC = {}
+
+
+def static_tensor(key, build):
+    t = _STATIC.get(key)
+    if t is None:
+        if len(_STATIC) > 256:
+            _STATIC.clear()
+        t = _STATIC[key] = build()
+    return t
+
+
+def shape_tensors(level_shapes: Sequence[Tuple[int, int]], device) -> Tuple[Tensor, Tensor]:
+    """spatial_shapes [L,2] / level_start_index [L], int64, on ``device`` (cached per geometry)."""
+    def build():
+        shapes = torch.as_tensor([tuple(s) for s in level_shapes], dtype=torch.int64)
+        sizes = shapes.prod(1)
+        lsi = torch.cat((sizes.new_zeros((1,)), sizes.cumsum(0)[:-1]))
+        return shapes.to(device), lsi.to(device)
+    return static_tensor(("shapes", tuple(map(tuple, level_shapes)), str(device)), build)
+
+
 def multi_level_misc(multi_level_masks: Sequence[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
     """spatial_shapes [L,2] int64, level_start_index [L] int64 (both on the masks' device, as the
     reference op reads them from device memory) and valid_ratios [B,L,2] (base_transformer.py:35-46)."""
-    device = multi_level_masks[0].device
-    shapes = torch.as_tensor([tuple(m.shape[-2:]) for m in multi_level_masks], dtype=torch.int64)
-    sizes = shapes.prod(1)
-    lsi = torch.cat((sizes.new_zeros((1,)), sizes.cumsum(0)[:-1]))
+    shapes, lsi = shape_tensors(level_shapes_of(multi_level_masks), multi_level_masks[0].device)
     valid_ratios = torch.stack([get_valid_ratios(m) for m in multi_level_masks], 1)
-    return shapes.to(device), lsi.to(device), valid_ratios
+    return shapes, lsi, valid_ratios
 
 
 def level_shapes_of(multi_level_masks: Sequence[Tensor]) -> List[Tuple[int, int]]:

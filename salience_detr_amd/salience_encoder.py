@@ -142,6 +142,9 @@ class SalienceTransformerEncoder(nn.Module):
         # learnt background embed for prediction
         self.background_embedding = PositionEmbeddingLearned(max_num_embedding, num_pos_feats=self.embed_dim // 2)
         self._value_proj_cache = None
+        # optional instrumentation: a callable(tag) invoked at every layer boundary of the loop
+        # (bench.py records a stream event there to report ms per encoder layer)
+        self.layer_marker = None
         self.init_weights()
 
     def init_weights(self):
@@ -154,15 +157,20 @@ class SalienceTransformerEncoder(nn.Module):
         """Pixel-centre reference points scaled by the valid ratios -> ``[B,S,L,2]``
         (salience_transformer.py:418-432).  ``spatial_shapes`` may be a tensor or a list of (h, w)."""
         shapes = spatial_shapes.tolist() if isinstance(spatial_shapes, Tensor) else list(spatial_shapes)
-        xs, ys, lv, sz = [], [], [], []
-        for lvl, (h, w) in enumerate(shapes):
-            ys.append((torch.arange(h, dtype=torch.float32, device=device) + 0.5).view(h, 1).expand(h, w).reshape(-1))
-            xs.append((torch.arange(w, dtype=torch.float32, device=device) + 0.5).view(1, w).expand(h, w).reshape(-1))
-            lv.append(torch.full((h * w,), lvl, dtype=torch.int64, device=device))
-            sz.append(torch.tensor([float(w), float(h)], device=device).expand(h * w, 2))
-        pix = torch.stack([torch.cat(xs), torch.cat(ys)], -1)            # [S,2] pixel centres (x+0.5, y+0.5)
-        own = valid_ratios[:, torch.cat(lv)]                              # [B,S,2] the token's own level ratio
-        centre = pix[None] / (own * torch.cat(sz)[None])                  # (idx + 0.5) / (valid_ratio * size)
+
+        def build():
+            xs, ys, lv, sz = [], [], [], []
+            for lvl, (h, w) in enumerate(shapes):
+                ys.append((torch.arange(h, dtype=torch.float32) + 0.5).view(h, 1).expand(h, w).reshape(-1))
+                xs.append((torch.arange(w, dtype=torch.float32) + 0.5).view(1, w).expand(h, w).reshape(-1))
+                lv.append(torch.full((h * w,), lvl, dtype=torch.int64))
+                sz.append(torch.tensor([float(w), float(h)]).expand(h * w, 2))
+            pix = torch.stack([torch.cat(xs), torch.cat(ys)], -1)   # [S,2] pixel centres (x+0.5, y+0.5)
+            return pix.to(device), torch.cat(lv).to(device), torch.cat(sz).to(device)
+
+        pix, lv, sz = pyramid.static_tensor(("refgrid", tuple(map(tuple, shapes)), str(device)), build)
+        own = valid_ratios[:, lv]                                         # [B,S,2] the token's own level ratio
+        centre = pix[None] / (own * sz[None])                             # (idx + 0.5) / (valid_ratio * size)
         return centre[:, :, None] * valid_ratios[:, None]
 
     def _all_value_projections(self):
@@ -205,6 +213,8 @@ class SalienceTransformerEncoder(nn.Module):
 
         inds = None
         for layer_id, layer in enumerate(self.layers):
+            if self.layer_marker is not None:
+                self.layer_marker(layer_id)
             inds = foreground_inds[layer_id]
             if native:
                 inds = inds.contiguous()
@@ -229,6 +239,8 @@ class SalienceTransformerEncoder(nn.Module):
                 output = output.scatter(1, inds.unsqueeze(-1).expand(-1, -1, E),
                                         torch.where(rows[..., None], q, keep_old))
 
+        if self.layer_marker is not None:
+            self.layer_marker(self.num_layers)
         # learnt embedding for background tokens: every token that is neither padding nor in the LAST
         # layer's index set (salience_transformer.py:487-495)
         if multi_level_masks is not None:

@@ -161,7 +161,7 @@ def test_full_size_properties():
     o12 = M.ms_deform_attn_forward(v1 + 2.0 * v2, sh, ls, dl, da, 64)
     assert (o12 - (o1 + 2.0 * o2)).abs().max() < 1e-4
     # constant value map + all sampling points strictly inside -> output == constant (weights sum to 1)
-    inner = loc.clamp(0.02, 0.98).to(DEV)
+    inner = loc.clamp(0.04, 0.96).to(DEV)  # 0.04*13-0.5 >= 0 on the coarsest (13x21) level
     oc = M.ms_deform_attn_forward(torch.full_like(v1, 3.0), sh, ls, inner, da, 64)
     assert (oc - 3.0).abs().max() < 1e-5
     # head-major bf16 fused path agrees with the reference-layout op on the same (bf16-rounded) value
