@@ -75,6 +75,17 @@ def main():
             t = timeit(lambda: M.msda_fused_forward(hm, sh, ls, refp, pj, L, P, out_dtype=pdt))
             res.append(dict(case=f"fused_bf16value_proj{str(pdt)[6:]}", Nq=Nq, order="random", us=t,
                             GBps=B * (Nv * 256 * 2 + Nq * (384 + 256) * pj.element_size() + Nq * 32) / t / 1e3))
+    # encoder-like dense query sets: direct fused kernel vs LDS-staged kernel
+    for Nq in args.nq:
+        for off in (1.5, 3.0):
+            tok, ref, proj, shapes, lsi = syn.make_encoder_like_queries(B, Nq, LEVELS, 8, 4, seed=1, offset_px=off)
+            hm = M.value_to_head_major(torch.randn(B, 22323, 256, device=DEV), None, 8, torch.bfloat16)
+            sh, ls, rf, pj = shapes.to(DEV), lsi.to(DEV), ref.to(DEV), proj.to(torch.bfloat16).to(DEV)
+            alg = B * (22323 * 256 * 2 + Nq * 384 * 2 + Nq * 32 + Nq * 256 * 2)
+            t = timeit(lambda: M.msda_fused_forward(hm, sh, ls, rf, pj, 4, 4, out_dtype=torch.bfloat16))
+            res.append(dict(case="enc_direct_bf16", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
+            t = timeit(lambda: M.msda_tiled_forward(hm, sh, ls, rf, pj, LEVELS[0], 4, 4, out_dtype=torch.bfloat16))
+            res.append(dict(case="enc_tiled_bf16(+bucket)", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
     value = torch.randn(B, 22323, 256, device=DEV)
     for sdt in (torch.float32, torch.bfloat16):
         for ddt in (torch.float32, torch.bfloat16):

@@ -110,6 +110,26 @@ int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int va
                              int channels, int num_levels, int num_query, int num_point, void *out,
                              int out_dtype);
 
+/* LDS-staged variant of sdetr_msda_fused_forward for dense query sets (the encoder): queries are first
+ * bucketed by the level-0 region of their reference point (sdetr_region_bucket), then one workgroup per
+ * (image, head, region) stages that region's window of every level in LDS and gathers from there; samples
+ * outside the window fall back to global loads inside the kernel, so results equal the direct kernel's.
+ * Shape support: bf16 head-major value, head_dim 32, 4 levels, 4 points (all Salience-DETR configs).
+ *   sdetr_tiled_config : compile-time region size (level-0 pixels) and window halo
+ *   sdetr_region_bucket: order [B,Nq] int32 (query slots grouped by region), region_start [B,R+1] int32,
+ *                        R = ceil(level0_w/region_w) * ceil(level0_h/region_h)
+ */
+void sdetr_tiled_config(int *region_w, int *region_h, int *halo);
+int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_points, int ref_dim, int batch_size,
+                        int num_query, int num_levels, int level0_h, int level0_w, int32_t *order,
+                        int32_t *region_start);
+int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm_bf16,
+                             const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
+                             const float *ref_points, int ref_dim, const void *proj, int proj_dtype,
+                             int64_t proj_row_stride, const int32_t *order, const int32_t *region_start,
+                             int num_regions, int batch_size, int spatial_size, int num_heads, int channels,
+                             int num_levels, int num_query, int num_point, void *out, int out_dtype);
+
 /* Same gather on a head-major value with explicit sampling locations / weights (the reference
  * op's math on the native layout); loc/aw as in (1), fp32. */
 int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, int value_dtype,

@@ -96,7 +96,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
-                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None):
+                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None,
+                level0_hw=None):
         """Reference signature (salience_transformer.py:353-364) plus an optional pre-projected
         head-major ``value_hm`` (``[B,M,Nv,D]``) supplied by the encoder's batched value projection."""
         native = not _needs_grad(self, query, value)
@@ -122,7 +123,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
             if value_hm is None:
                 value_hm = self.self_attn.project_value(value, query_key_padding_mask)
             src2 = self.self_attn.forward_native(self.with_pos_embed(query, query_pos), reference_points, value_hm,
-                                                 spatial_shapes, level_start_index)
+                                                 spatial_shapes, level_start_index, level0_hw=level0_hw)
         else:
             src2 = self.self_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
                                   value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -230,7 +231,7 @@ class SalienceTransformerEncoder(nn.Module):
                 ref = torch.gather(ori_reference_points, 1, inds.unsqueeze(-1).repeat(1, 1, s * p)).view(b, -1, s, p)
             score_tgt = self.enhance_mcsp(q)
             q = layer(q, q_pos, value, ref, spatial_shapes, level_start_index, query_key_padding_mask, score_tgt, fg,
-                      value_hm=value_hm_all[layer_id] if native else None)
+                      value_hm=value_hm_all[layer_id] if native else None, level0_hw=level_shapes[0])
             if native:
                 scatter_rows_(output, inds, q, count=focus64)
             else:

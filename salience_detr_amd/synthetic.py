@@ -152,3 +152,25 @@ def make_msda_inputs(B: int, Nq: int, level_shapes: Sequence[Tuple[int, int]], M
     loc = centre[:, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
     aw = torch.randn(B, Nq, M, L * P, generator=g).softmax(-1).view(B, Nq, M, L, P)
     return (value.to(dtype), shapes, lsi, loc.to(dtype).contiguous(), aw.to(dtype).contiguous())
+
+
+def make_encoder_like_queries(B: int, Nq: int, level_shapes: Sequence[Tuple[int, int]], M: int = 8, P: int = 4,
+                              seed: int = 0, offset_px: float = 2.0, dtype=torch.float32):
+    """Fused-MSDA inputs shaped like an encoder layer's: ``Nq`` distinct tokens of the pyramid per image,
+    reference points = that token's centre on every level (``[B,Nq,L,2]``), projection rows
+    ``[M*L*P*2 offsets ~ N(0, offset_px) | M*L*P logits ~ N(0,1)]``."""
+    L = len(level_shapes)
+    shapes = torch.tensor(level_shapes, dtype=torch.int64)
+    sizes = shapes.prod(1)
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    Nv = int(sizes.sum())
+    g = _gen("encoder_like", seed)
+    tok = torch.stack([torch.randperm(Nv, generator=g)[:Nq] for _ in range(B)])
+    lvl = (tok[..., None] >= lsi[None, None]).sum(-1) - 1
+    rel = tok - lsi[lvl]
+    cx = ((rel % shapes[lvl, 1]).float() + 0.5) / shapes[lvl, 1].float()
+    cy = (torch.div(rel, shapes[lvl, 1], rounding_mode="floor").float() + 0.5) / shapes[lvl, 0].float()
+    ref = torch.stack([cx, cy], -1)[:, :, None, :].expand(B, Nq, L, 2).contiguous()
+    proj = torch.cat([torch.randn(B, Nq, M * L * P * 2, generator=g) * offset_px,
+                      torch.randn(B, Nq, M * L * P, generator=g)], -1)
+    return tok, ref, proj.to(dtype), shapes, lsi
