@@ -120,14 +120,14 @@ int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int va
  *                        R = ceil(level0_w/region_w) * ceil(level0_h/region_h)
  */
 void sdetr_tiled_config(int *region_w, int *region_h, int *halo);
-int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_points, int ref_dim, int batch_size,
-                        int num_query, int num_levels, int level0_h, int level0_w, int32_t *order,
-                        int32_t *region_start);
+int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_points, const int64_t *data_spatial_shapes,
+                        int ref_dim, int batch_size, int num_query, int num_levels, int level0_h, int level0_w,
+                        int32_t *order, int32_t *region_start, int32_t *region_box /* [B,R,4 levels,4] */);
 int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm_bf16,
                              const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
                              const float *ref_points, int ref_dim, const void *proj, int proj_dtype,
                              int64_t proj_row_stride, const int32_t *order, const int32_t *region_start,
-                             int num_regions, int batch_size, int spatial_size, int num_heads, int channels,
+                             const int32_t *region_box, int num_regions, int batch_size, int spatial_size, int num_heads, int channels,
                              int num_levels, int num_query, int num_point, void *out, int out_dtype);
 
 /* Same gather on a head-major value with explicit sampling locations / weights (the reference

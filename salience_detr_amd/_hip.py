@@ -35,8 +35,8 @@ SIGNATURES = {
     "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _i64, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_msda_forward_head_major": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_tiled_config": (None, [_p, _p, _p]),
-    "sdetr_region_bucket": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
-    "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _i] + [_i] * 7 + [_p, _i]),
+    "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i64, _p, _p, _p, _sz]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

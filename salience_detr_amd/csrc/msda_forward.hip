@@ -72,10 +72,17 @@ struct GatherArgs {
     int nchunk;  // query chunks per image
 };
 
-__device__ __forceinline__ float load_proj(const void *proj, int is_bf16, int64_t idx)
+template <typename PT>
+__device__ __forceinline__ float proj_elem(const void *proj, int64_t idx);
+template <>
+__device__ __forceinline__ float proj_elem<float>(const void *proj, int64_t idx)
 {
-    if (is_bf16) return __uint_as_float((uint32_t) reinterpret_cast<const bf16_t *>(proj)[idx] << 16);
     return reinterpret_cast<const float *>(proj)[idx];
+}
+template <>
+__device__ __forceinline__ float proj_elem<bf16_t>(const void *proj, int64_t idx)
+{
+    return __uint_as_float((uint32_t) reinterpret_cast<const bf16_t *>(proj)[idx] << 16);
 }
 
 // One sample's descriptor: 4 corner byte offsets (relative to the block's value base, lane
@@ -154,19 +161,39 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     const uint32_t lane_off = (HEAD_MAJOR ? 0u : (uint32_t)(m * D * sizeof(VT))) + (uint32_t)(j * 16);
 
     // ---- fused mode: softmax statistics over this row's L*P logits, spread over the G lanes ----
+    // All of a lane's logits are loaded in ONE batch (clamped indices, no per-sample branch) so the set-up
+    // costs one memory round trip instead of one per sample.
+    constexpr int TMAX = (kChunk + G - 1) / G;  // samples a lane owns per LDS round
     float sm_max = 0.f, sm_inv = 1.f;
-    int64_t proj_row = 0;
-    if (FUSED && active) {
-        proj_row = ((int64_t)b * p.Nq + q) * p.proj_stride;
-        const int64_t lg = proj_row + (int64_t)p.M * LP * 2 + (int64_t)m * LP;
-        float mx = -INFINITY;
-        for (int s = j; s < LP; s += G) mx = fmaxf(mx, load_proj(p.proj, p.proj_bf16, lg + s));
+    const int64_t proj_row = FUSED ? ((int64_t)b * p.Nq + q) * p.proj_stride : 0;
+    const int64_t logit0 = proj_row + (int64_t)p.M * LP * 2 + (int64_t)m * LP;
+    if (FUSED) {
+        float mx = -INFINITY, sum = 0.f;
+        for (int s0 = 0; s0 < LP; s0 += kChunk) {  // one trip when L*P <= 16
+            float lg[TMAX];
+            if (p.proj_bf16) {  // dtype branch OUTSIDE the batch so the loads issue back to back
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, G));
-        float sum = 0.f;
-        for (int s = j; s < LP; s += G) sum += __expf(load_proj(p.proj, p.proj_bf16, lg + s) - mx);
+                for (int t = 0; t < TMAX; ++t) lg[t] = proj_elem<bf16_t>(p.proj, logit0 + min(s0 + j + t * G, LP - 1));
+            } else {
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, G);
+                for (int t = 0; t < TMAX; ++t) lg[t] = proj_elem<float>(p.proj, logit0 + min(s0 + j + t * G, LP - 1));
+            }
+            float cmx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (s0 + j + t * G < min(LP, s0 + kChunk)) cmx = fmaxf(cmx, lg[t]);
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o, G));
+            const float nmx = fmaxf(mx, cmx);
+            float csum = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (s0 + j + t * G < min(LP, s0 + kChunk)) csum += __expf(lg[t] - nmx);
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) csum += __shfl_xor(csum, o, G);
+            sum = sum * __expf(mx - nmx) + csum;  // online softmax across rounds (mx = -inf first: factor 0)
+            mx = nmx;
+        }
         sm_max = mx;
         sm_inv = 1.f / sum;
     }
@@ -179,76 +206,120 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     for (int c0 = 0; c0 < LP; c0 += kChunk) {
         const int ns = min(kChunk, LP - c0);
         if (c0 > 0) __syncthreads();  // previous chunk fully consumed
-        if (active) {
-            for (int t = j; t < ns; t += G) {
-                const int s = c0 + t;
-                const int l = s / p.P;
-                const int H = lvl_tab[l * 3], W = lvl_tab[l * 3 + 1], start = lvl_tab[l * 3 + 2];
-                float x, y, a;
-                if (FUSED) {
-                    const int64_t oi = proj_row + ((int64_t)m * LP + s) * 2;
-                    const float ox = load_proj(p.proj, p.proj_bf16, oi);
-                    const float oy = load_proj(p.proj, p.proj_bf16, oi + 1);
-                    const float lgt = load_proj(p.proj, p.proj_bf16,
-                                                proj_row + (int64_t)p.M * LP * 2 + (int64_t)m * LP + s);
-                    a = __expf(lgt - sm_max) * sm_inv;
-                    const float *r = p.ref + (((int64_t)b * p.Nq + q) * p.L + l) * p.ref_dim;
-                    if (p.ref_dim == 2) {
-                        x = r[0] + ox / (float)W;
-                        y = r[1] + oy / (float)H;
-                    } else {
-                        x = r[0] + ox / (float)p.P * r[2] * 0.5f;
-                        y = r[1] + oy / (float)p.P * r[3] * 0.5f;
+        {
+            // raw per-sample inputs of this lane, all loads first
+            float rx[TMAX], ry[TMAX], ra[TMAX], rr[TMAX][4];
+            int lv[TMAX];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) lv[t] = min(c0 + j + t * G, LP - 1) / p.P;
+            if (FUSED) {
+                if (p.proj_bf16) {
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+                        const int s = min(c0 + j + t * G, LP - 1);
+                        const uint32_t xy = *reinterpret_cast<const uint32_t *>(
+                            reinterpret_cast<const bf16_t *>(p.proj) + proj_row + ((int64_t)m * LP + s) * 2);
+                        rx[t] = bf16_lo(xy);
+                        ry[t] = bf16_hi(xy);
+                        ra[t] = proj_elem<bf16_t>(p.proj, logit0 + s);
                     }
                 } else {
-                    const float2 xy = reinterpret_cast<const float2 *>(p.loc)[row * LP + s];
-                    x = xy.x;
-                    y = xy.y;
-                    a = p.aw[row * LP + s];
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+                        const int s = min(c0 + j + t * G, LP - 1);
+                        const float2 xy = *reinterpret_cast<const float2 *>(
+                            reinterpret_cast<const float *>(p.proj) + proj_row + ((int64_t)m * LP + s) * 2);
+                        rx[t] = xy.x;
+                        ry[t] = xy.y;
+                        ra[t] = proj_elem<float>(p.proj, logit0 + s);
+                    }
                 }
-                uint32_t d[8];
-                make_descriptor(x, y, a, H, W, start, pixel_bytes, d);
-                *reinterpret_cast<uint4 *>(my_desc + t * 8) = make_uint4(d[0], d[1], d[2], d[3]);
-                *reinterpret_cast<uint4 *>(my_desc + t * 8 + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+                if (p.ref_dim == 4) {
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+                        const float4 r = *reinterpret_cast<const float4 *>(p.ref + (((int64_t)b * p.Nq + q) * p.L + lv[t]) * 4);
+                        rr[t][0] = r.x; rr[t][1] = r.y; rr[t][2] = r.z; rr[t][3] = r.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+                        const float2 r = *reinterpret_cast<const float2 *>(p.ref + (((int64_t)b * p.Nq + q) * p.L + lv[t]) * 2);
+                        rr[t][0] = r.x; rr[t][1] = r.y; rr[t][2] = 0.f; rr[t][3] = 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t) {
+                    const int s = min(c0 + j + t * G, LP - 1);
+                    const float2 xy = reinterpret_cast<const float2 *>(p.loc)[row * LP + s];
+                    rx[t] = xy.x;
+                    ry[t] = xy.y;
+                    ra[t] = p.aw[row * LP + s];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                const int ts = j + t * G;  // slot within this round
+                if (ts < ns && active) {
+                    const int l = lv[t];
+                    const int H = lvl_tab[l * 3], W = lvl_tab[l * 3 + 1], start = lvl_tab[l * 3 + 2];
+                    float x, y, a;
+                    if (FUSED) {
+                        a = __expf(ra[t] - sm_max) * sm_inv;
+                        if (p.ref_dim == 2) {
+                            x = rr[t][0] + rx[t] / (float)W;
+                            y = rr[t][1] + ry[t] / (float)H;
+                        } else {
+                            x = rr[t][0] + rx[t] / (float)p.P * rr[t][2] * 0.5f;
+                            y = rr[t][1] + ry[t] / (float)p.P * rr[t][3] * 0.5f;
+                        }
+                    } else {
+                        x = rx[t];
+                        y = ry[t];
+                        a = ra[t];
+                    }
+                    uint32_t d[8];
+                    make_descriptor(x, y, a, H, W, start, pixel_bytes, d);
+                    *reinterpret_cast<uint4 *>(my_desc + ts * 8) = make_uint4(d[0], d[1], d[2], d[3]);
+                    *reinterpret_cast<uint4 *>(my_desc + ts * 8 + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+                }
             }
         }
         __syncthreads();
         if (active) {
+            // Software-pipelined gather: batches of 2 samples (8 x 16-byte loads), two register buffers; the
+            // loads of batch k+1 are issued BEFORE batch k is accumulated, so the memory pipe never drains
+            // while the wave does its unpack/FMA work (the loop was latency-bound with load -> wait -> math).
             const char *lane_base = base + lane_off;
-            int t = 0;
-            for (; t + 4 <= ns; t += 4) {
-                uint4 o[4], w[4], v[4][4];
+            auto issue = [&](uint4 (&v)[2][4], int t) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    o[u] = *reinterpret_cast<const uint4 *>(my_desc + (t + u) * 8);
-                    w[u] = *reinterpret_cast<const uint4 *>(my_desc + (t + u) * 8 + 4);
+                for (int u = 0; u < 2; ++u) {
+                    const int tt = min(t + u, ns - 1);  // clamped: a tail slot re-reads a valid sample
+                    const uint4 o = *reinterpret_cast<const uint4 *>(my_desc + tt * 8);
+                    v[u][0] = *reinterpret_cast<const uint4 *>(lane_base + o.x);
+                    v[u][1] = *reinterpret_cast<const uint4 *>(lane_base + o.y);
+                    v[u][2] = *reinterpret_cast<const uint4 *>(lane_base + o.z);
+                    v[u][3] = *reinterpret_cast<const uint4 *>(lane_base + o.w);
                 }
+            };
+            auto accumulate = [&](const uint4 (&v)[2][4], int t) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[u][0] = *reinterpret_cast<const uint4 *>(lane_base + o[u].x);
-                    v[u][1] = *reinterpret_cast<const uint4 *>(lane_base + o[u].y);
-                    v[u][2] = *reinterpret_cast<const uint4 *>(lane_base + o[u].z);
-                    v[u][3] = *reinterpret_cast<const uint4 *>(lane_base + o[u].w);
+                for (int u = 0; u < 2; ++u) {
+                    uint4 w = *reinterpret_cast<const uint4 *>(my_desc + min(t + u, ns - 1) * 8 + 4);
+                    if (t + u >= ns) w = make_uint4(0u, 0u, 0u, 0u);  // tail slot contributes nothing
+                    T::fma4(acc, v[u][0], __uint_as_float(w.x));
+                    T::fma4(acc, v[u][1], __uint_as_float(w.y));
+                    T::fma4(acc, v[u][2], __uint_as_float(w.z));
+                    T::fma4(acc, v[u][3], __uint_as_float(w.w));
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    T::fma4(acc, v[u][0], __uint_as_float(w[u].x));
-                    T::fma4(acc, v[u][1], __uint_as_float(w[u].y));
-                    T::fma4(acc, v[u][2], __uint_as_float(w[u].z));
-                    T::fma4(acc, v[u][3], __uint_as_float(w[u].w));
-                }
-            }
-            for (; t < ns; ++t) {
-                const uint4 o = *reinterpret_cast<const uint4 *>(my_desc + t * 8);
-                const uint4 w = *reinterpret_cast<const uint4 *>(my_desc + t * 8 + 4);
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(lane_base + o.x);
-                const uint4 v1 = *reinterpret_cast<const uint4 *>(lane_base + o.y);
-                const uint4 v2 = *reinterpret_cast<const uint4 *>(lane_base + o.z);
-                const uint4 v3 = *reinterpret_cast<const uint4 *>(lane_base + o.w);
-                T::fma4(acc, v0, __uint_as_float(w.x));
-                T::fma4(acc, v1, __uint_as_float(w.y));
-                T::fma4(acc, v2, __uint_as_float(w.z));
-                T::fma4(acc, v3, __uint_as_float(w.w));
+            };
+            uint4 va[2][4], vb[2][4];
+            issue(va, 0);
+            for (int t = 0; t < ns; t += 4) {
+                if (t + 2 < ns) issue(vb, t + 2);
+                accumulate(va, t);
+                if (t + 4 < ns) issue(va, t + 4);
+                if (t + 2 < ns) accumulate(vb, t + 2);
             }
         }
     }

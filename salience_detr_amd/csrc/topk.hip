@@ -4,33 +4,27 @@
 // (per-level top-k under masked_fill(mask, score.min())), :156-158 (global sort of the selected
 // scores + index gather) and :366-367 (per-layer top-300).
 //
-// A sorting network confined to one CU is LDS-bandwidth bound (a 16 K-key bitonic sort is 105
-// passes over 128 KiB of LDS; measured 190-350 us), so the sort is split into two launches that
-// use the whole chip and contain no sorting network at all:
+// A sorting network confined to one CU is LDS-bandwidth bound (a 16 K-key bitonic sort is 105 passes over
+// 128 KiB of LDS: measured 190-350 us), and a radix/bitwise SELECT confined to one CU is instruction
+// bound (measured 25-60 us for 4 K-22 K keys).  The sizes here (273 ... 22 323 keys per row) are small
+// enough that brute-force RANK BY COUNTING spread over the whole chip beats both:
 //
-//  1. topk_select (one 1024-thread workgroup per row): every thread keeps a CONTIGUOUS chunk of
-//     the row's keys in registers (key = descending-orderable score bits, masked entries replaced
-//     by the whole-array minimum as the reference does).  A 32-step bitwise search finds the k-th
-//     key (one block-wide count per bit, no LDS atomics), then a stable block scan compacts the k
-//     survivors -- in index order, ties at the threshold resolved to the lowest indices -- into a
-//     global scratch list (u32 key, u32 position).
-//  2. topk_rank (ceil(k/64) workgroups per row): rank by counting.  Workgroup w owns survivors
-//     [64w, 64w+64); its four wavefronts stream the survivor key list (staged in LDS, read as
-//     broadcast ds_read_b128) and count, per owned key, the keys that sort before it.  Because
-//     the list is in index order the tie rule is positional: "<=" for keys listed before the
-//     owned block, "<" after it, exact only inside it -- two VALU ops per comparison.  The rank
-//     IS the output slot, so results are written directly, no merge step.
-//     Work is k^2 comparisons (45 M for k = 6 680) spread over k/64 workgroups: ~3 us of VALU
-//     per wavefront instead of a 91-pass single-CU sort.
+//   topk_min  (fill_mode 1 only, one workgroup): min over the whole [B,N] score array -> workspace[0],
+//             the value the reference substitutes for masked scores (score.min(), masked entries included).
+//   topk_rank (ceil(N/64) workgroups per row): workgroup w owns keys [64w, 64w+64) of its row.  All keys
+//             of the row (key = descending-orderable score bits, masked -> fill) are staged in LDS in
+//             12 K-key tiles; the four wavefronts stream them as broadcast ds_read_b128 and count, per owned
+//             key, the keys that sort before it.  The list is in index order, so the tie rule is positional:
+//             "<=" for keys before the owned block, "<" after it, exact only inside it (two VALU ops per
+//             comparison, branch-free loops, 8 LDS reads in flight).  rank < k  =>  out[rank] = (score, index):
+//             the rank IS the output slot -- no select pass, no sorting network, no merge.
+//   N^2 comparisons (282 M for the largest level, 16 800 keys) over 1024 SIMDs is ~10-20 us.
 #include "common.h"
 
 namespace sdetr {
 
-constexpr int kSelThreads = 1024;
-constexpr int kSelWaves = kSelThreads / 64;
-constexpr int kMaxKeysPerThread = 24;    // register-resident rows up to 24 576 scores
 constexpr int kRankThreads = 256;
-constexpr int kRankTile = 12288;         // survivor keys staged per LDS round (48 KiB)
+constexpr int kRankTile = 12288;  // keys staged per LDS round (48 KiB)
 
 __device__ __forceinline__ uint32_t desc_bits(float s)
 {
@@ -46,188 +40,32 @@ __device__ __forceinline__ float undesc_bits(uint32_t d)
     return __uint_as_float(u);
 }
 
-struct SelectArgs {
-    const float *score;
-    const uint8_t *mask;
-    int fill_mode;
-    int B, N, k;
-    uint32_t *cand_key;  // [B][k]
-    uint32_t *cand_pos;  // [B][k]
-};
-
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *buf /*[kSelWaves]*/, int tid)
+__global__ void __launch_bounds__(1024) topk_min_kernel(const float *score, int64_t total, float *out)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((tid & 63) == 0) buf[tid >> 6] = v;
-    __syncthreads();
-    uint32_t t = 0;
-#pragma unroll
-    for (int w = 0; w < kSelWaves; ++w) t += buf[w];
-    return t;
-}
-
-// exclusive prefix over the block's threads (thread order) + grand total
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *buf /*[kSelWaves]*/, int tid,
-                                                         uint32_t &total)
-{
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t n = __shfl_up(incl, o, 64);
-        if ((tid & 63) >= o) incl += n;
-    }
-    if ((tid & 63) == 63) buf[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t before = 0, t = 0;
-#pragma unroll
-    for (int w = 0; w < kSelWaves; ++w) {
-        const uint32_t c = buf[w];
-        if (w < (tid >> 6)) before += c;
-        t += c;
-    }
-    total = t;
-    return before + incl - v;
-}
-
-// KPT = keys held in registers per thread (0: row too long, re-read it from global every pass)
-template <int KPT>
-__global__ void __launch_bounds__(kSelThreads) topk_select_kernel(SelectArgs p)
-{
-    constexpr bool IN_REGS = KPT > 0;
-    constexpr int kKeysPerThread = KPT > 0 ? KPT : 1;
-    __shared__ uint32_t bufA[kSelWaves], bufB[kSelWaves];
-    __shared__ float redf[kSelWaves];
+    __shared__ float red[16];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const float *srow = p.score + (int64_t)b * p.N;
-    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.N : nullptr;
-
-    float fill = 0.f;
-    if (p.fill_mode == 1) {
-        float mn = INFINITY;
-        const int64_t total = (int64_t)p.B * p.N;
-        for (int64_t i = tid; i < total; i += kSelThreads) mn = fminf(mn, p.score[i]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-        if ((tid & 63) == 0) redf[tid >> 6] = mn;
-        __syncthreads();
-        mn = redf[0];
-#pragma unroll
-        for (int w = 1; w < kSelWaves; ++w) mn = fminf(mn, redf[w]);
-        fill = mn;
+    float mn = INFINITY;
+    int64_t i = tid;
+    for (; i + 3 * 1024 < total; i += 4 * 1024) {
+        const float a0 = score[i], a1 = score[i + 1024], a2 = score[i + 2048], a3 = score[i + 3072];
+        mn = fminf(fminf(mn, a0), fminf(fminf(a1, a2), a3));
     }
-
-    // contiguous chunk per thread => compaction in thread order is compaction in index order
-    const int chunk = (p.N + kSelThreads - 1) / kSelThreads;
-    const int lo = tid * chunk;
-    const int hi = min(p.N, lo + chunk);
-    auto load_key = [&](int i) -> uint32_t {
-        float s = srow[i];
-        if (mrow && mrow[i]) s = fill;
-        return desc_bits(s);
-    };
-    uint32_t keys[kKeysPerThread];
-    if (IN_REGS) {
+    for (; i < total; i += 1024) mn = fminf(mn, score[i]);
 #pragma unroll
-        for (int c = 0; c < kKeysPerThread; ++c) keys[c] = (lo + c < hi) ? load_key(lo + c) : 0xffffffffu;
-    }
-
-    uint32_t threshold = 0xffffffffu, need_eq = 0;
-    if (p.k < p.N) {
-        uint32_t prefix = 0, rem = p.k;
-        for (int bit = 31; bit >= 0; --bit) {
-            // keys matching the decided prefix whose current bit is 0  <=>  (key >> bit) == (prefix >> bit)
-            // (prefix has bit `bit` and everything below still clear).  Out-of-range slots hold 0xffffffff and
-            // can only match an all-ones prefix, which is excluded by the range test.
-            const uint32_t want = prefix >> bit;
-            // wave-wide count without any cross-lane data movement: the compare mask IS the ballot
-            // (v_cmp -> SGPR pair), popcounted on the scalar unit
-            uint32_t cnt = 0;
-            if (IN_REGS) {
-#pragma unroll
-                for (int c = 0; c < kKeysPerThread; ++c)
-                    cnt += (uint32_t)__popcll(__ballot(((keys[c] >> bit) == want) && (lo + c < hi)));
-            } else {
-                const int steps = chunk;  // uniform trip count so every lane reaches the ballot
-                for (int c = 0; c < steps; ++c) {
-                    const int i = lo + c;
-                    cnt += (uint32_t)__popcll(__ballot(i < hi && (load_key(min(i, p.N - 1)) >> bit) == want));
-                }
-            }
-            uint32_t *buf = (bit & 1) ? bufA : bufB;  // alternate buffers: one barrier per bit
-            if ((tid & 63) == 0) buf[tid >> 6] = cnt;
-            __syncthreads();
-            uint32_t zeros = 0;
-#pragma unroll
-            for (int w = 0; w < kSelWaves; ++w) zeros += buf[w];
-            if (rem > zeros) {
-                prefix |= 1u << bit;
-                rem -= zeros;
-            }
-        }
-        threshold = prefix;  // the k-th key in sorted order (with multiplicity)
-        need_eq = rem;       // how many keys == threshold belong to the top k (lowest indices first)
-    }
-
-    // stable compaction: all keys < threshold, plus the first need_eq keys == threshold
-    uint32_t n_lt = 0, n_eq = 0;
-    if (p.k < p.N) {
-        if (IN_REGS) {
-#pragma unroll
-            for (int c = 0; c < kKeysPerThread; ++c) {
-                if (lo + c < hi) {
-                    n_lt += keys[c] < threshold;
-                    n_eq += keys[c] == threshold;
-                }
-            }
-        } else {
-            for (int i = lo; i < hi; ++i) {
-                const uint32_t key = load_key(i);
-                n_lt += key < threshold;
-                n_eq += key == threshold;
-            }
-        }
-    }
+    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mn;
     __syncthreads();
-    uint32_t tot_eq, tot_sel;
-    const uint32_t eq_before = (p.k < p.N) ? block_exclusive_scan(n_eq, bufA, tid, tot_eq) : 0u;
-    uint32_t my_sel;
-    if (p.k < p.N) {
-        const uint32_t eq_take = eq_before >= need_eq ? 0u : min(n_eq, need_eq - eq_before);
-        my_sel = n_lt + eq_take;
-    } else {
-        my_sel = (uint32_t)max(0, hi - lo);
-    }
-    __syncthreads();
-    uint32_t out = block_exclusive_scan(my_sel, bufB, tid, tot_sel);
-    uint32_t eq_seen = eq_before;
-    uint32_t *ck = p.cand_key + (int64_t)b * p.k;
-    uint32_t *cp = p.cand_pos + (int64_t)b * p.k;
-    auto emit = [&](uint32_t key, int i) {
-        bool take = true;
-        if (p.k < p.N) {
-            take = key < threshold;
-            if (key == threshold) take = (eq_seen++ < need_eq);
-        }
-        if (take) {
-            ck[out] = key;
-            cp[out] = (uint32_t)i;
-            ++out;
-        }
-    };
-    if (IN_REGS) {
-#pragma unroll
-        for (int c = 0; c < kKeysPerThread; ++c)
-            if (lo + c < hi) emit(keys[c], lo + c);
-    } else {
-        for (int i = lo; i < hi; ++i) emit(load_key(i), i);
+    if (tid == 0) {
+        mn = red[0];
+        for (int w = 1; w < 16; ++w) mn = fminf(mn, red[w]);
+        *out = mn;
     }
 }
 
 struct RankArgs {
-    const uint32_t *cand_key;
-    const uint32_t *cand_pos;
+    const float *score;
+    const uint8_t *mask;
+    const float *fill;  // device scalar or NULL
     const int64_t *payload;
     int N, k;
     int64_t index_offset;
@@ -241,55 +79,83 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
     __shared__ uint32_t partial[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const int base = blockIdx.x * 64;  // owned survivors [base, base+64)
-    const uint32_t *ck = p.cand_key + (int64_t)b * p.k;
+    const int base = blockIdx.x * 64;  // owned keys [base, base+64)
+    const float *srow = p.score + (int64_t)b * p.N;
+    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.N : nullptr;
+    const float fill = p.fill ? *p.fill : 0.f;
+    auto key_at = [&](int i) -> uint32_t {  // i < N
+        float s = srow[i];
+        if (mrow && mrow[i]) s = fill;
+        return desc_bits(s);
+    };
     const int mypos = base + lane;
-    const uint32_t mine = mypos < p.k ? ck[mypos] : 0u;
+    const uint32_t mine = mypos < p.N ? key_at(mypos) : 0u;
     uint32_t rank = 0;
 
-    for (int t0 = 0; t0 < p.k; t0 += kRankTile) {
-        const int tn = min(kRankTile, p.k - t0);
+    for (int t0 = 0; t0 < p.N; t0 += kRankTile) {
+        const int tn = min(kRankTile, p.N - t0);
         if (t0 > 0) __syncthreads();
-        for (int i = tid; i < (tn + 3) / 4; i += kRankThreads) {
-            uint4 v;
-            const int j = t0 + i * 4;
-            if (j + 3 < p.k && ((reinterpret_cast<uintptr_t>(ck + j) & 15) == 0)) {
-                v = *reinterpret_cast<const uint4 *>(ck + j);
-            } else {  // pad with the worst key: never counted by "<" or "<=" against a real key ... except
-                      // equal 0xffffffff keys, which the position test below excludes (j >= k)
-                v.x = j + 0 < p.k ? ck[j + 0] : 0xffffffffu;
-                v.y = j + 1 < p.k ? ck[j + 1] : 0xffffffffu;
-                v.z = j + 2 < p.k ? ck[j + 2] : 0xffffffffu;
-                v.w = j + 3 < p.k ? ck[j + 3] : 0xffffffffu;
+        // stage: all global loads of this thread first (<= 48 scalars), then the LDS stores; padding keys
+        // (positions >= N) are 0xffffffff, which no "<" test counts and whose positions fail the tie rule
+        constexpr int kPer = kRankTile / kRankThreads;  // 48
+        for (int c0 = 0; c0 < kPer; c0 += 12) {
+            float sv[12];
+            uint8_t mk[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const int i = t0 + (c0 + c) * kRankThreads + tid;
+                sv[c] = srow[min(i, p.N - 1)];
             }
-            reinterpret_cast<uint4 *>(tile)[i] = v;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const int i = t0 + (c0 + c) * kRankThreads + tid;
+                mk[c] = mrow ? mrow[min(i, p.N - 1)] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const int li = (c0 + c) * kRankThreads + tid;
+                if (li < ((tn + 3) & ~3)) tile[li] = (t0 + li < p.N) ? desc_bits(mk[c] ? fill : sv[c]) : 0xffffffffu;
+            }
+            if ((c0 + 12) * kRankThreads >= tn) break;
         }
         __syncthreads();
-        // groups of 4 keys, round-robin over the 4 wavefronts
+        // groups of 4 keys, round-robin over the 4 wavefronts; the list splits into three ranges relative to
+        // the owned block so every loop body is branch-free and the LDS reads pipeline (8 in flight)
         const int ngroups = (tn + 3) / 4;
-        for (int g = wave; g < ngroups; g += 4) {
-            const uint4 c = reinterpret_cast<const uint4 *>(tile)[g];  // same address in all lanes: broadcast
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tile);
+        const int g_own0 = min(ngroups, max(0, (base - t0) / 4));           // first group inside the owned block
+        const int g_own1 = min(ngroups, max(0, (base + 64 - t0 + 3) / 4));  // first group after it
+        auto first_at_or_after = [&](int g0) { return g0 + ((wave - g0) % 4 + 4) % 4; };
+        int g = wave;
+#pragma unroll 8
+        for (; g < g_own0; g += 4) {  // before: ties sort before us
+            const uint4 c = t4[g];
+            rank += (c.x <= mine) + (c.y <= mine) + (c.z <= mine) + (c.w <= mine);
+        }
+        for (g = first_at_or_after(g_own0); g < g_own1; g += 4) {  // inside: exact positional tie rule
+            const uint4 c = t4[g];
             const int j = t0 + g * 4;
-            if (j + 3 < base) {  // entirely before the owned block: ties sort before us
-                rank += (c.x <= mine) + (c.y <= mine) + (c.z <= mine) + (c.w <= mine);
-            } else if (j >= base + 64) {  // entirely after: ties sort after us (padding keys are > or == -> excluded)
-                rank += (c.x < mine) + (c.y < mine) + (c.z < mine) + (c.w < mine);
-            } else {  // inside the owned block: exact positional tie rule
-                rank += (c.x < mine || (c.x == mine && j + 0 < mypos)) ? 1u : 0u;
-                rank += (c.y < mine || (c.y == mine && j + 1 < mypos)) ? 1u : 0u;
-                rank += (c.z < mine || (c.z == mine && j + 2 < mypos)) ? 1u : 0u;
-                rank += (c.w < mine || (c.w == mine && j + 3 < mypos)) ? 1u : 0u;
-            }
+            rank += (c.x < mine || (c.x == mine && j + 0 < mypos)) ? 1u : 0u;
+            rank += (c.y < mine || (c.y == mine && j + 1 < mypos)) ? 1u : 0u;
+            rank += (c.z < mine || (c.z == mine && j + 2 < mypos)) ? 1u : 0u;
+            rank += (c.w < mine || (c.w == mine && j + 3 < mypos)) ? 1u : 0u;
+        }
+        g = first_at_or_after(g_own1);
+#pragma unroll 8
+        for (; g < ngroups; g += 4) {  // after: ties sort after us (padding keys 0xffffffff are never "<")
+            const uint4 c = t4[g];
+            rank += (c.x < mine) + (c.y < mine) + (c.z < mine) + (c.w < mine);
         }
     }
     partial[wave][lane] = rank;
     __syncthreads();
-    if (wave == 0 && mypos < p.k) {
+    if (wave == 0 && mypos < p.N) {
         const uint32_t r = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
-        const uint32_t pos = p.cand_pos[(int64_t)b * p.k + mypos];
-        if (p.out_score) p.out_score[(int64_t)b * p.k + r] = undesc_bits(mine);
-        p.out_index[(int64_t)b * p.k + r] =
-            p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
+        if (r < (uint32_t)p.k) {
+            if (p.out_score) p.out_score[(int64_t)b * p.k + r] = undesc_bits(mine);
+            p.out_index[(int64_t)b * p.k + r] =
+                p.payload ? p.payload[(int64_t)b * p.N + mypos] : (int64_t)mypos + p.index_offset;
+        }
     }
 }
 
@@ -300,7 +166,7 @@ using namespace sdetr;
 extern "C" size_t sdetr_topk_workspace_bytes(int B, int n, int k)
 {
     if (B <= 0 || n <= 0 || k <= 0) return 0;
-    return (size_t)B * k * 2 * sizeof(uint32_t);
+    return 16;  // one float: the masked-fill value
 }
 
 extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
@@ -315,28 +181,17 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
     if (B == 0 || k == 0) return 0;
     if (!score || !out_index) return fail("masked_topk: null pointer");
     if (n >= (1 << 30) || B > 65535) return fail("masked_topk: row too long / too many rows");
-    const size_t need = sdetr_topk_workspace_bytes(B, n, k);
-    if (!workspace || workspace_bytes < need)
-        return fail("masked_topk: needs %zu bytes of workspace, got %zu", need, workspace_bytes);
-    // padding keys of the rank kernel (0xffffffff) tie with a real key only for score == -NaN patterns;
-    // the "<"/position rules keep them out of every count because their positions are >= k.
-    SelectArgs s{};
-    s.score = score; s.mask = mask; s.fill_mode = fill_mode; s.B = B; s.N = n; s.k = k;
-    s.cand_key = reinterpret_cast<uint32_t *>(workspace);
-    s.cand_pos = s.cand_key + (size_t)B * k;
-    const int chunk = (n + kSelThreads - 1) / kSelThreads;
-#define SDETR_SEL(KPT) hipLaunchKernelGGL(topk_select_kernel<KPT>, dim3((unsigned)B), dim3(kSelThreads), 0, stream, s)
-    if (chunk <= 2) SDETR_SEL(2);
-    else if (chunk <= 5) SDETR_SEL(5);
-    else if (chunk <= 12) SDETR_SEL(12);
-    else if (chunk <= 17) SDETR_SEL(17);
-    else if (chunk <= kMaxKeysPerThread) SDETR_SEL(kMaxKeysPerThread);
-    else SDETR_SEL(0);
-#undef SDETR_SEL
-    if (int e = check_launch("topk_select")) return e;
     RankArgs r{};
-    r.cand_key = s.cand_key; r.cand_pos = s.cand_pos; r.payload = payload; r.N = n; r.k = k;
+    r.score = score; r.mask = mask; r.payload = payload; r.N = n; r.k = k;
     r.index_offset = index_offset; r.out_score = out_score; r.out_index = out_index;
-    hipLaunchKernelGGL(topk_rank_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)B), dim3(kRankThreads), 0, stream, r);
+    if (fill_mode == 1) {
+        if (!workspace || workspace_bytes < sizeof(float))
+            return fail("masked_topk: needs %zu bytes of workspace, got %zu", sizeof(float), workspace_bytes);
+        hipLaunchKernelGGL(topk_min_kernel, dim3(1), dim3(1024), 0, stream, score, (int64_t)B * n,
+                           reinterpret_cast<float *>(workspace));
+        if (int e = check_launch("topk_min")) return e;
+        r.fill = reinterpret_cast<const float *>(workspace);
+    }
+    hipLaunchKernelGGL(topk_rank_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)B), dim3(kRankThreads), 0, stream, r);
     return check_launch("topk_rank");
 }

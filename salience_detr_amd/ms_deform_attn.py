@@ -201,6 +201,29 @@ def tiled_supported(value_hm: Tensor, num_levels: int, num_points: int) -> bool:
     return value_hm.dtype == torch.bfloat16 and value_hm.shape[-1] == 32 and num_levels == 4 and num_points == 4
 
 
+def region_bucket(reference_points: Tensor, spatial_shapes: Tensor, level0_hw, num_levels: int = 4):
+    """Group query slots by the level-0 region of their reference point.  Returns
+    ``(order [B,Nq] int32, region_start [B,R+1] int32, region_box [B,R,4,4] int32, R)``."""
+    _hip.require_device("region_bucket", reference_points=reference_points, spatial_shapes=spatial_shapes)
+    if reference_points.dtype != torch.float32:
+        reference_points = reference_points.float()
+    B, Nq = reference_points.shape[:2]
+    rw, rh, _ = tiled_config()
+    H0, W0 = int(level0_hw[0]), int(level0_hw[1])
+    R = ((W0 + rw - 1) // rw) * ((H0 + rh - 1) // rh)
+    dev = reference_points.device
+    order = torch.empty((B, Nq), dtype=torch.int32, device=dev)
+    region_start = torch.empty((B, R + 1), dtype=torch.int32, device=dev)
+    region_box = torch.empty((B, R, 4, 4), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        code = _hip.lib().sdetr_region_bucket(_hip.stream_ptr(), reference_points.data_ptr(),
+                                              spatial_shapes.data_ptr(), reference_points.shape[-1], B, Nq,
+                                              num_levels, H0, W0, order.data_ptr(), region_start.data_ptr(),
+                                              region_box.data_ptr())
+    _hip.check(code, "region_bucket")
+    return order, region_start, region_box, R
+
+
 def msda_tiled_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                        reference_points: Tensor, proj: Tensor, level0_hw, num_levels: int = 4, num_points: int = 4,
                        out_dtype: Optional[torch.dtype] = None) -> Tensor:
@@ -226,16 +249,19 @@ def msda_tiled_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
     dev = value_hm.device
     order = torch.empty((B, Nq), dtype=torch.int32, device=dev)
     region_start = torch.empty((B, R + 1), dtype=torch.int32, device=dev)
+    region_box = torch.empty((B, R, 4, 4), dtype=torch.int32, device=dev)
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=dev)
     lib = _hip.lib()
     with torch.cuda.device(dev):
-        code = lib.sdetr_region_bucket(_hip.stream_ptr(), reference_points.data_ptr(), reference_points.shape[-1],
-                                       B, Nq, num_levels, H0, W0, order.data_ptr(), region_start.data_ptr())
+        code = lib.sdetr_region_bucket(_hip.stream_ptr(), reference_points.data_ptr(), spatial_shapes.data_ptr(),
+                                       reference_points.shape[-1], B, Nq, num_levels, H0, W0, order.data_ptr(),
+                                       region_start.data_ptr(), region_box.data_ptr())
         _hip.check(code, "region_bucket")
         code = lib.sdetr_msda_tiled_forward(
             _hip.stream_ptr(), value_hm.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             reference_points.data_ptr(), reference_points.shape[-1], proj.data_ptr(), _hip.dtype_code(proj.dtype),
-            proj.stride(1), order.data_ptr(), region_start.data_ptr(), R, B, Nv, M, D, num_levels, Nq, num_points,
+            proj.stride(1), order.data_ptr(), region_start.data_ptr(), region_box.data_ptr(), R, B, Nv, M, D,
+            num_levels, Nq, num_points,
             out.data_ptr(), _hip.dtype_code(out_dtype))
     _hip.check(code, "msda_tiled_forward")
     return out
@@ -327,9 +353,11 @@ class MultiScaleDeformableAttention(nn.Module):
         v = F.linear(value, self.value_proj.weight, self.value_proj.bias)
         return value_to_head_major(v, key_padding_mask, self.num_heads, self.value_dtype or v.dtype)
 
-    # queries per level-0 region above which the LDS-staged kernel is used (below it the window loads
-    # cost more than the gathers they replace); None disables it
-    tiled_min_queries_per_region = 12.0
+    # queries per level-0 region above which the LDS-staged kernel is used; None disables it.  Round-1
+    # measurement (profiles/r01_msda_pmc.md): the staged kernel is correct but ~1.5x SLOWER than the direct
+    # gather at every encoder density (per-workgroup serial latency with only 2 workgroups/CU resident), so
+    # it stays opt-in until it is restructured as a persistent double-buffered pipeline.
+    tiled_min_queries_per_region = None
 
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
                        level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None) -> Tensor:
