@@ -87,8 +87,9 @@ int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const d
  *
  * sdetr_value_to_head_major: the tail of `value_proj` (ms_deform_attn.py:316-321): zero the
  *   padded tokens (masked_fill) and re-lay the projected value out head-major,
- *   src [B,Nv,M*D] (row stride `src_row_stride` elements) -> dst [B,M,Nv,D], optional dtype cast.
- *   pad_mask [B,Nv] bytes (1 = padding) or NULL.
+ *   src [B,Nv,G*M*D] (row stride `src_row_stride` elements) -> dst [G,B,M,Nv,D], optional dtype cast;
+ *   G = num_groups lets one launch split the batched value projection of all encoder layers
+ *   (the six layers sample the same, never-updated feature map).  pad_mask [B,Nv] bytes or NULL.
  *
  * sdetr_msda_fused_forward: softmax over the L*P logits, sampling-location arithmetic
  *   (ms_deform_attn.py:322-355, 2-d or 4-d reference points) and the gather-reduce, in one launch.
@@ -100,7 +101,8 @@ int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const d
  * ------------------------------------------------------------------------------------------- */
 int sdetr_value_to_head_major(sdetr_stream_t stream, const void *src, int src_dtype,
                               int64_t src_row_stride, const uint8_t *pad_mask, int batch_size,
-                              int spatial_size, int num_heads, int channels, void *dst, int dst_dtype);
+                              int spatial_size, int num_heads, int channels, int num_groups, void *dst,
+                              int dst_dtype);
 
 int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
                              const int64_t *data_spatial_shapes,
@@ -170,6 +172,24 @@ int sdetr_gather_rows(sdetr_stream_t stream, const void *src, const int64_t *idx
                       int src_rows, int n, int row_bytes, void *dst);
 int sdetr_scatter_rows(sdetr_stream_t stream, void *dst, const int64_t *idx, const void *src,
                        const int64_t *count, int batch_size, int dst_rows, int n, int row_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * (6) Plumbing that feeds / surrounds the path.
+ *   sdetr_pyramid_flatten_level: one level of flatten_multi_level + get_lvl_pos_embed
+ *     (models/bricks/base_transformer.py:22-33) and the token validity of gen_encoder_output_proposals
+ *     (:74-112): NCHW feat/pos -> token-major feat_out, pos_out (= pos + level_embed),
+ *     sum_out = (feat + pos_out) * keep (the input of enc_output), mask_out (flattened padding mask),
+ *     optional bf16 copies.  mask [B,H,W] bytes (1 = padding); outputs are [B,S,C] / [B,S], this level
+ *     occupying tokens [level_start, level_start + H*W).
+ *   sdetr_class_max_times: out[r] = max_c score[r,c] * scale[r]  (mc_score of
+ *     models/bricks/salience_transformer.py:366), score [rows,num_classes] f32|bf16, out f32.
+ * ------------------------------------------------------------------------------------------- */
+int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const float *pos, const uint8_t *mask,
+                                const float *level_embed, int batch_size, int channels, int height, int width,
+                                int level, int level_start, int spatial_size, float *feat_out, float *pos_out,
+                                float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16);
+int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
+                          int64_t rows, int num_classes, float *out);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ SIGNATURES = {
     "sdetr_msda_im2col_f64": (_i, [_p] * 6 + [_i] * 7 + [_p]),
     "sdetr_msda_col2im_f32": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
     "sdetr_msda_col2im_f64": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
-    "sdetr_value_to_head_major": (_i, [_p, _p, _i, _i64, _p, _i, _i, _i, _i, _p, _i]),
+    "sdetr_value_to_head_major": (_i, [_p, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _i64, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_msda_forward_head_major": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_tiled_config": (None, [_p, _p, _p]),
@@ -39,6 +39,8 @@ SIGNATURES = {
     "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i64, _p, _p, _p, _sz]),
+    "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _p]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
 }

@@ -1,0 +1,157 @@
+// HBM-bound plumbing kernels of the hot path that replace long chains of tiny framework launches.
+//
+//  * pyramid_flatten_kernel: F0 of the path (reference models/bricks/base_transformer.py:22-33
+//    flatten_multi_level / get_lvl_pos_embed and :74-112 the validity geometry of
+//    gen_encoder_output_proposals).  One launch per level turns the NCHW feature and position maps into
+//    the token-major tensors the transformer consumes -- feat_flatten, pos + level_embed, the masked
+//    sum (feat + pos) * keep that feeds enc_output, the flattened padding mask, and (optionally) bf16
+//    copies of the first two for the bf16 encoder -- with a 32x32 LDS transpose so both the NCHW reads
+//    and the token-major writes are coalesced.  The reference does this with ~110 launches
+//    (cat / transpose / arange / compare chains); the keep flag (token not padding AND its proposal box
+//    inside (0.01, 0.99)) is evaluated per token from the valid extents, which each block recounts from
+//    row 0 / column 0 of the mask exactly like the reference.
+//  * class_max_times_kernel: mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
+//    (models/bricks/salience_transformer.py:366): one pass over the [B*Nq, num_classes] logits.
+#include "common.h"
+
+namespace sdetr {
+
+struct FlattenArgs {
+    const float *feat;   // [B,C,H,W]
+    const float *pos;    // [B,C,H,W]
+    const uint8_t *mask; // [B,H,W]
+    const float *level_embed;  // [C]
+    int B, C, H, W, S, start;
+    float box_wh;  // 0.05 * 2^level
+    float *feat_out;     // [B,S,C]
+    float *pos_out;      // [B,S,C]
+    float *sum_out;      // [B,S,C]  (feat + pos) * keep
+    uint8_t *mask_out;   // [B,S]
+    bf16_t *feat_bf16;   // [B,S,C] or NULL
+    bf16_t *pos_bf16;    // [B,S,C] or NULL
+};
+
+// block (32, 8): tile of 32 tokens x 32 channels
+__global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
+{
+    __shared__ float tf[32][33], tp[32][33];
+    __shared__ int valid_hw[2];
+    const int HW = p.H * p.W;
+    const int b = blockIdx.z;
+    const int tok0 = blockIdx.x * 32, ch0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * 32 + tx;
+    const uint8_t *mb = p.mask + (int64_t)b * HW;
+
+    // valid extents: number of unmasked entries in column 0 (height) and row 0 (width)
+    if (tid < 64) {
+        int cnt = 0;
+        if (tid < 32) { for (int i = tid; i < p.H; i += 32) cnt += mb[(int64_t)i * p.W] == 0; }
+        else          { for (int i = tid - 32; i < p.W; i += 32) cnt += mb[i] == 0; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 32);
+        if ((tid & 31) == 0) valid_hw[tid >> 5] = cnt;
+    }
+    // load: threads along tokens (contiguous in NCHW)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = ch0 + ty + 8 * r, t = tok0 + tx;
+        float f = 0.f, q = 0.f;
+        if (c < p.C && t < HW) {
+            const int64_t i = ((int64_t)b * p.C + c) * HW + t;
+            f = p.feat[i];
+            q = p.pos[i] + p.level_embed[c];
+        }
+        tf[ty + 8 * r][tx] = f;
+        tp[ty + 8 * r][tx] = q;
+    }
+    __syncthreads();
+    const float vh = (float)valid_hw[0], vw = (float)valid_hw[1];
+    // store: threads along channels (contiguous in token-major)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = tok0 + ty + 8 * r, c = ch0 + tx;
+        if (t < HW && c < p.C) {
+            const int y = t / p.W, x = t - y * p.W;
+            const bool pad = mb[t] != 0;
+            const float cx = ((float)x + 0.5f) / vw, cy = ((float)y + 0.5f) / vh;
+            const bool keep = !pad && cx > 0.01f && cx < 0.99f && cy > 0.01f && cy < 0.99f &&
+                              p.box_wh > 0.01f && p.box_wh < 0.99f;
+            const float f = tf[tx][ty + 8 * r], q = tp[tx][ty + 8 * r];
+            const int64_t o = ((int64_t)b * p.S + p.start + t) * p.C + c;
+            p.feat_out[o] = f;
+            p.pos_out[o] = q;
+            p.sum_out[o] = keep ? f + q : 0.f;
+            if (p.feat_bf16) p.feat_bf16[o] = (bf16_t)f32_to_bf16_bits(f);
+            if (p.pos_bf16) p.pos_bf16[o] = (bf16_t)f32_to_bf16_bits(q);
+            if (c == 0) p.mask_out[(int64_t)b * p.S + p.start + t] = pad ? 1 : 0;
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+
+// 16 lanes per row; rows = B*Nq
+template <typename T>
+__global__ void __launch_bounds__(256) class_max_times_kernel(const T *score, const float *fg, int64_t rows, int C,
+                                                              float *out)
+{
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    float mx = -INFINITY;
+    if (row < rows) {
+        const T *s = score + row * C;
+        for (int c = l; c < C; c += 16) mx = fmaxf(mx, to_f32<T>(s[c]));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    if (row < rows && l == 0) out[row] = mx * fg[row];
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const float *pos,
+                                           const uint8_t *mask, const float *level_embed, int B, int C, int H, int W,
+                                           int level, int level_start, int S, float *feat_out, float *pos_out,
+                                           float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16)
+{
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level_start < 0 || S < level_start + H * W)
+        return fail("pyramid_flatten_level: bad dims");
+    if (!feat || !pos || !mask || !level_embed || !feat_out || !pos_out || !sum_out || !mask_out)
+        return fail("pyramid_flatten_level: null pointer");
+    if (B == 0) return 0;
+    FlattenArgs a{};
+    a.feat = feat; a.pos = pos; a.mask = mask; a.level_embed = level_embed;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.S = S; a.start = level_start;
+    a.box_wh = 0.05f * (float)(1u << level);
+    a.feat_out = feat_out; a.pos_out = pos_out; a.sum_out = sum_out; a.mask_out = mask_out;
+    a.feat_bf16 = reinterpret_cast<bf16_t *>(feat_bf16); a.pos_bf16 = reinterpret_cast<bf16_t *>(pos_bf16);
+    const dim3 grid((unsigned)((H * W + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(pyramid_flatten_kernel, grid, dim3(32, 8), 0, stream, a);
+    return check_launch("pyramid_flatten_level");
+}
+
+extern "C" int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
+                                     int64_t rows, int num_classes, float *out)
+{
+    if (rows < 0 || num_classes <= 0) return fail("class_max_times: bad dims");
+    if (rows == 0) return 0;
+    if (!score || !scale || !out) return fail("class_max_times: null pointer");
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    if (score_dtype == SDETR_F32)
+        hipLaunchKernelGGL(class_max_times_kernel<float>, grid, block, 0, stream, (const float *)score, scale, rows,
+                           num_classes, out);
+    else if (score_dtype == SDETR_BF16)
+        hipLaunchKernelGGL(class_max_times_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t *)score, scale, rows,
+                           num_classes, out);
+    else
+        return fail("class_max_times: bad dtype %d", score_dtype);
+    return check_launch("class_max_times");
+}

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(kBlock) scatter_rows_kernel(V *dst, const int6
 // wavefront writes 64/(D/8) consecutive pixels of ONE head: a contiguous run in the destination.
 template <typename ST, typename DT>
 __global__ void __launch_bounds__(kBlock) head_major_kernel(const ST *src, int64_t src_stride, const uint8_t *pad,
-                                                            int64_t total, int Nv, int M, int D, DT *dst)
+                                                            int64_t total, int B, int Nv, int M_all, int M, int D, DT *dst)
 {
     const int cpr = D / 8;           // 8-channel chunks per head row
     const int ppw = kWave / cpr;     // pixels per wavefront
@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(kBlock) head_major_kernel(const ST *src, int64
          t += (int64_t)gridDim.x * blockDim.x) {
         const int lane = (int)(t & (kWave - 1));
         const int64_t wave = t >> 6;  // global wave id: (b, pixel block, head)
-        const int m = (int)(wave % M);
-        const int64_t pb = wave / M;  // b * nblk + pixel block
+        const int m = (int)(wave % M_all);  // head index over all groups (group = m / M)
+        const int64_t pb = wave / M_all;    // b * nblk + pixel block
         const int nblk = (Nv + ppw - 1) / ppw;
         const int b = (int)(pb / nblk);
         const int pix = (int)(pb - (int64_t)b * nblk) * ppw + lane / cpr;
@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(kBlock) head_major_kernel(const ST *src, int64
             v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
             v[4] = bf16_lo(a.z); v[5] = bf16_hi(a.z); v[6] = bf16_lo(a.w); v[7] = bf16_hi(a.w);
         }
-        DT *d = dst + (((int64_t)b * M + m) * Nv + pix) * D + ch;
+        // destination [group][B][M][Nv][D]
+        DT *d = dst + ((((int64_t)(m / M) * B + b) * M + (m % M)) * Nv + pix) * D + ch;
         if (sizeof(DT) == 4) {
             reinterpret_cast<float4 *>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
             reinterpret_cast<float4 *>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -139,22 +140,24 @@ extern "C" int sdetr_scatter_rows(sdetr_stream_t stream, void *dst, const int64_
 }
 
 extern "C" int sdetr_value_to_head_major(sdetr_stream_t stream, const void *src, int src_dtype, int64_t src_row_stride,
-                                         const uint8_t *pad_mask, int B, int Nv, int M, int D, void *dst, int dst_dtype)
+                                         const uint8_t *pad_mask, int B, int Nv, int M, int D, int num_groups, void *dst,
+                                         int dst_dtype)
 {
-    if (B < 0 || Nv < 0 || M <= 0 || D <= 0) return fail("value_to_head_major: bad dims");
+    if (B < 0 || Nv < 0 || M <= 0 || D <= 0 || num_groups <= 0) return fail("value_to_head_major: bad dims");
+    const int M_all = M * num_groups;
     if (D % 8 != 0 || D > 512 || (kWave % (D / 8)) != 0)
         return fail("value_to_head_major: head dim %d must be a multiple of 8 dividing 512", D);
-    if (src_row_stride < (int64_t)M * D) return fail("value_to_head_major: source row stride too small");
+    if (src_row_stride < (int64_t)M_all * D) return fail("value_to_head_major: source row stride too small");
     if ((src_row_stride % 8) != 0) return fail("value_to_head_major: source row stride must be a multiple of 8");
     if ((int64_t)B * Nv == 0) return 0;
     if (!src || !dst) return fail("value_to_head_major: null pointer");
     const int ppw = kWave / (D / 8);
     const int64_t nblk = (Nv + ppw - 1) / ppw;
-    const int64_t total = (int64_t)B * nblk * M * kWave;
+    const int64_t total = (int64_t)B * nblk * M_all * kWave;
     const dim3 grid(grid_for(total)), block(kBlock);
 #define SDETR_HM(ST, DT)                                                                                     \
     hipLaunchKernelGGL((head_major_kernel<ST, DT>), grid, block, 0, stream, (const ST *)src, src_row_stride, \
-                       pad_mask, total, Nv, M, D, (DT *)dst)
+                       pad_mask, total, B, Nv, M_all, M, D, (DT *)dst)
     if (src_dtype == SDETR_F32 && dst_dtype == SDETR_F32) SDETR_HM(float, float);
     else if (src_dtype == SDETR_F32 && dst_dtype == SDETR_BF16) SDETR_HM(float, bf16_t);
     else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_BF16) SDETR_HM(bf16_t, bf16_t);

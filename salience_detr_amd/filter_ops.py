@@ -85,3 +85,57 @@ def scatter_rows_(dst: Tensor, idx: Tensor, src: Tensor, count: Optional[Tensor]
                                              _hip.ptr(count), B, S, n, row_bytes)
     _hip.check(code, "scatter_rows_")
     return dst
+
+
+def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks, level_embeds: Tensor,
+                    want_bf16: bool = False):
+    """F0 in one launch per level: ``flatten_multi_level`` + ``get_lvl_pos_embed``
+    (base_transformer.py:22-33) + the token validity of ``gen_encoder_output_proposals`` (:74-112).
+
+    Returns ``(feat_flatten [B,S,C], lvl_pos_embed_flatten [B,S,C], enc_output_input [B,S,C] =
+    (feat + pos) * keep, mask_flatten [B,S] bool, feat_bf16 | None, pos_bf16 | None)``.
+    """
+    feats = [f.contiguous() for f in multi_level_feats]
+    pos = [p.contiguous() for p in multi_level_pos_embeds]
+    masks = [m.contiguous() for m in multi_level_masks]
+    _hip.require_device("pyramid_flatten", level_embeds=level_embeds, **{f"feat{i}": f for i, f in enumerate(feats)})
+    if feats[0].dtype != torch.float32 or pos[0].dtype != torch.float32:
+        raise RuntimeError("pyramid_flatten: float32 feature / position maps expected")
+    B, C = feats[0].shape[:2]
+    S = sum(int(f.shape[2]) * int(f.shape[3]) for f in feats)
+    dev = feats[0].device
+    feat_out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
+    pos_out = torch.empty_like(feat_out)
+    sum_out = torch.empty_like(feat_out)
+    mask_out = torch.empty((B, S), dtype=torch.bool, device=dev)
+    feat_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    pos_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    le = level_embeds.detach().float().contiguous()
+    lib = _hip.lib()
+    start = 0
+    with torch.cuda.device(dev):
+        for lvl, (f, p, m) in enumerate(zip(feats, pos, masks)):
+            H, W = int(f.shape[2]), int(f.shape[3])
+            mu8 = m.view(torch.uint8) if m.dtype == torch.bool else m
+            code = lib.sdetr_pyramid_flatten_level(
+                _hip.stream_ptr(), f.data_ptr(), p.data_ptr(), mu8.data_ptr(), le[lvl].data_ptr(), B, C, H, W, lvl,
+                start, S, feat_out.data_ptr(), pos_out.data_ptr(), sum_out.data_ptr(), mask_out.data_ptr(),
+                _hip.ptr(feat_bf16), _hip.ptr(pos_bf16))
+            _hip.check(code, "pyramid_flatten_level")
+            start += H * W
+    return feat_out, pos_out, sum_out, mask_out, feat_bf16, pos_bf16
+
+
+def class_max_times(score: Tensor, scale: Tensor) -> Tensor:
+    """``score.max(-1)[0] * scale`` in one pass: score ``[B,Nq,num_classes]`` (fp32 | bf16), scale ``[B,Nq]``
+    fp32 -> fp32 ``[B,Nq]`` (mc_score of salience_transformer.py:366)."""
+    _hip.require_device("class_max_times", score=score, scale=scale)
+    if scale.dtype != torch.float32:
+        scale = scale.float()
+    B, Nq, C = score.shape
+    out = torch.empty((B, Nq), dtype=torch.float32, device=score.device)
+    with torch.cuda.device(score.device):
+        code = _hip.lib().sdetr_class_max_times(_hip.stream_ptr(), score.data_ptr(), _hip.dtype_code(score.dtype),
+                                                scale.data_ptr(), B * Nq, C, out.data_ptr())
+    _hip.check(code, "class_max_times")
+    return out

@@ -84,18 +84,34 @@ class SalienceEncoderHotPath(nn.Module):
         the whole forward issues no device->host synchronisation; otherwise one sync reads them back.
         """
         level_ratio, layer_ratio = self._ratios()
-        feat_flatten = pyramid.flatten_multi_level(multi_level_feats)
-        mask_flatten = pyramid.flatten_multi_level(multi_level_masks)
-        lvl_pos_embed_flatten = pyramid.get_lvl_pos_embed(self.level_embeds.to(multi_level_pos_embeds[0].dtype),
-                                                          multi_level_pos_embeds)
+        edt = self.encoder_dtype
+        native = not (torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                   or any(f.requires_grad for f in multi_level_feats)))
+        feat_enc = pos_enc = None
+        if native and multi_level_feats[0].dtype == torch.float32:
+            # F0 in one launch per level (flatten + level embedding + validity mask [+ bf16 copies])
+            from .filter_ops import pyramid_flatten
+            feat_flatten, lvl_pos_embed_flatten, enc_in, mask_flatten, feat_enc, pos_enc = pyramid_flatten(
+                multi_level_feats, multi_level_pos_embeds, multi_level_masks, self.level_embeds,
+                want_bf16=(edt == torch.bfloat16))
+        else:
+            enc_in = None
+            feat_flatten = pyramid.flatten_multi_level(multi_level_feats)
+            mask_flatten = pyramid.flatten_multi_level(multi_level_masks)
+            lvl_pos_embed_flatten = pyramid.get_lvl_pos_embed(self.level_embeds.to(multi_level_pos_embeds[0].dtype),
+                                                              multi_level_pos_embeds)
         spatial_shapes, level_start_index, valid_ratios = pyramid.multi_level_misc(multi_level_masks)
         level_shapes = pyramid.level_shapes_of(multi_level_masks)
         starts = [0]
         for h, w in level_shapes[:-1]:
             starts.append(starts[-1] + h * w)
 
-        backbone_output_memory = pyramid.encoder_output_memory(
-            self.enc_output, self.enc_output_norm, feat_flatten + lvl_pos_embed_flatten, mask_flatten, level_shapes)
+        if enc_in is not None:
+            backbone_output_memory = self.enc_output_norm(self.enc_output(enc_in))
+        else:
+            backbone_output_memory = pyramid.encoder_output_memory(
+                self.enc_output, self.enc_output_norm, feat_flatten + lvl_pos_embed_flatten, mask_flatten,
+                level_shapes)
 
         if image_sizes is not None:
             if canvas is None:
@@ -117,9 +133,10 @@ class SalienceEncoderHotPath(nn.Module):
             self.alpha)
         foreground_inds, foreground_score = salience_filtering(salience_score, level_inds, level_score, mask_flatten,
                                                                layer_ratio)
-        edt = self.encoder_dtype
+        if feat_enc is None:
+            feat_enc, pos_enc = feat_flatten.to(edt), lvl_pos_embed_flatten.to(edt)
         memory = self.encoder(
-            query=feat_flatten.to(edt), query_pos=lvl_pos_embed_flatten.to(edt), query_key_padding_mask=mask_flatten,
+            query=feat_enc, query_pos=pos_enc, query_key_padding_mask=mask_flatten,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index, valid_ratios=valid_ratios,
             foreground_score=foreground_score, focus_token_nums=focus_token_nums, foreground_inds=foreground_inds,
             multi_level_masks=multi_level_masks)

