@@ -187,9 +187,26 @@ int sdetr_scatter_rows(sdetr_stream_t stream, void *dst, const int64_t *idx, con
 int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const float *pos, const uint8_t *mask,
                                 const float *level_embed, int batch_size, int channels, int height, int width,
                                 int level, int level_start, int spatial_size, float *feat_out, float *pos_out,
-                                float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16);
+                                float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16,
+                                float *valid_ratio /* this level's (w,h) of image 0, or NULL */,
+                                int valid_ratio_stride /* floats between images */);
 int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
                           int64_t rows, int num_classes, float *out);
+
+/*   sdetr_layernorm: out = LayerNorm((x [+ residual]) * (1 + row_scale[row] * *alpha)) * gamma + beta, eps as
+ *     nn.LayerNorm.  Covers the encoder's residual LayerNorms (models/bricks/salience_transformer.py:347-351,
+ *     377-378, 390-391), the level modulation + MaskPredictor LayerNorm (:143, :20) and enc_output_norm
+ *     (models/bricks/base_transformer.py:111).  x / residual are [batch_size, rows_per_batch, channels] with the
+ *     given element strides (last dim contiguous); residual, row_scale ([batch*rows] f32) and alpha (device
+ *     scalar) may be NULL; out is contiguous.  dtypes: SDETR_F32 | SDETR_BF16 (x and residual share x_dtype).
+ *   sdetr_column_mean_f32: out[b,c] = mean_i x[b,i,c]   (global half of the salience head, :43-45). */
+int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void *residual, int x_dtype,
+                    int64_t x_batch_stride, int64_t x_row_stride, int64_t res_batch_stride, int64_t res_row_stride,
+                    const float *row_scale, const float *alpha, const void *gamma, const void *beta,
+                    int param_dtype, float eps, int batch_size, int rows_per_batch, int channels, void *out,
+                    int out_dtype);
+int sdetr_column_mean_f32(sdetr_stream_t stream, const float *x, int64_t batch_stride, int64_t row_stride,
+                          int batch_size, int rows, int channels, float *out);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ struct FlattenArgs {
     uint8_t *mask_out;   // [B,S]
     bf16_t *feat_bf16;   // [B,S,C] or NULL
     bf16_t *pos_bf16;    // [B,S,C] or NULL
+    float *valid_ratio;  // this level's (w, h) pair of image 0; stride between images below
+    int valid_ratio_stride;
 };
 
 // block (32, 8): tile of 32 tokens x 32 channels
@@ -67,6 +69,10 @@ __global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
     }
     __syncthreads();
     const float vh = (float)valid_hw[0], vw = (float)valid_hw[1];
+    if (p.valid_ratio && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // get_valid_ratios: (w, h)
+        p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 0] = vw / (float)p.W;
+        p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 1] = vh / (float)p.H;
+    }
     // store: threads along channels (contiguous in token-major)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -120,7 +126,8 @@ using namespace sdetr;
 extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const float *pos,
                                            const uint8_t *mask, const float *level_embed, int B, int C, int H, int W,
                                            int level, int level_start, int S, float *feat_out, float *pos_out,
-                                           float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16)
+                                           float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16,
+                                           float *valid_ratio, int valid_ratio_stride)
 {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level_start < 0 || S < level_start + H * W)
         return fail("pyramid_flatten_level: bad dims");
@@ -133,6 +140,7 @@ extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *f
     a.box_wh = 0.05f * (float)(1u << level);
     a.feat_out = feat_out; a.pos_out = pos_out; a.sum_out = sum_out; a.mask_out = mask_out;
     a.feat_bf16 = reinterpret_cast<bf16_t *>(feat_bf16); a.pos_bf16 = reinterpret_cast<bf16_t *>(pos_bf16);
+    a.valid_ratio = valid_ratio; a.valid_ratio_stride = valid_ratio_stride;
     const dim3 grid((unsigned)((H * W + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
     hipLaunchKernelGGL(pyramid_flatten_kernel, grid, dim3(32, 8), 0, stream, a);
     return check_launch("pyramid_flatten_level");

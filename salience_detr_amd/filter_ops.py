@@ -93,7 +93,9 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
     (base_transformer.py:22-33) + the token validity of ``gen_encoder_output_proposals`` (:74-112).
 
     Returns ``(feat_flatten [B,S,C], lvl_pos_embed_flatten [B,S,C], enc_output_input [B,S,C] =
-    (feat + pos) * keep, mask_flatten [B,S] bool, feat_bf16 | None, pos_bf16 | None)``.
+    (feat + pos) * keep, mask_flatten [B,S] bool, feat_bf16 | None, pos_bf16 | None, valid_ratios [B,L,2])``;
+    ``valid_ratios`` is ``get_valid_ratios`` of every level (base_transformer.py:48-56), a by-product of the
+    extents the kernel counts anyway.
     """
     feats = [f.contiguous() for f in multi_level_feats]
     pos = [p.contiguous() for p in multi_level_pos_embeds]
@@ -111,6 +113,7 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
     feat_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     pos_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     le = level_embeds.detach().float().contiguous()
+    valid_ratios = torch.empty((B, len(feats), 2), dtype=torch.float32, device=dev)
     lib = _hip.lib()
     start = 0
     with torch.cuda.device(dev):
@@ -120,10 +123,10 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
             code = lib.sdetr_pyramid_flatten_level(
                 _hip.stream_ptr(), f.data_ptr(), p.data_ptr(), mu8.data_ptr(), le[lvl].data_ptr(), B, C, H, W, lvl,
                 start, S, feat_out.data_ptr(), pos_out.data_ptr(), sum_out.data_ptr(), mask_out.data_ptr(),
-                _hip.ptr(feat_bf16), _hip.ptr(pos_bf16))
+                _hip.ptr(feat_bf16), _hip.ptr(pos_bf16), valid_ratios.data_ptr() + lvl * 8, len(feats) * 2)
             _hip.check(code, "pyramid_flatten_level")
             start += H * W
-    return feat_out, pos_out, sum_out, mask_out, feat_bf16, pos_bf16
+    return feat_out, pos_out, sum_out, mask_out, feat_bf16, pos_bf16, valid_ratios
 
 
 def class_max_times(score: Tensor, scale: Tensor) -> Tensor:
@@ -138,4 +141,61 @@ def class_max_times(score: Tensor, scale: Tensor) -> Tensor:
         code = _hip.lib().sdetr_class_max_times(_hip.stream_ptr(), score.data_ptr(), _hip.dtype_code(score.dtype),
                                                 scale.data_ptr(), B * Nq, C, out.data_ptr())
     _hip.check(code, "class_max_times")
+    return out
+
+
+def _bn_view(t: Tensor):
+    """(tensor viewed as [B, n, C] with a contiguous last dim, batch stride, row stride)."""
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3:
+        t = t.reshape(-1, t.shape[-2], t.shape[-1])
+    if t.stride(2) != 1:
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(1)
+
+
+def fused_layer_norm(x: Tensor, norm: torch.nn.LayerNorm, residual: Optional[Tensor] = None,
+                     row_scale: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
+                     out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """``norm((x [+ residual]) * (1 + row_scale * alpha))`` in one launch (see include/salience_hip.h (6)).
+    ``x`` may be a batch-strided view (e.g. one level's slice of ``[B,S,C]``); the result is contiguous."""
+    if not x.is_cuda:
+        raise RuntimeError("fused_layer_norm: HIP device tensors required; there is no CPU fallback")
+    shape = x.shape
+    xv, xbs, xrs = _bn_view(x)
+    B, n, C = xv.shape
+    rv, rbs, rrs = (None, 0, 0)
+    if residual is not None:
+        if residual.dtype != x.dtype or residual.shape != x.shape:
+            raise RuntimeError("fused_layer_norm: residual must match x")
+        rv, rbs, rrs = _bn_view(residual)
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1)
+        if row_scale.dtype != torch.float32 or row_scale.numel() != B * n or not row_scale.is_contiguous():
+            row_scale = row_scale.float().contiguous()
+    w, b = norm.weight.detach(), norm.bias.detach()
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty((B, n, C), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib().sdetr_layernorm(
+            _hip.stream_ptr(), xv.data_ptr(), _hip.ptr(rv), _hip.dtype_code(x.dtype), xbs, xrs, rbs, rrs,
+            _hip.ptr(row_scale), _hip.ptr(alpha), w.data_ptr(), b.data_ptr(), _hip.dtype_code(w.dtype),
+            float(norm.eps), B, n, C, out.data_ptr(), _hip.dtype_code(out_dtype))
+    _hip.check(code, "fused_layer_norm")
+    return out.view(shape)
+
+
+def column_mean(x: Tensor) -> Tensor:
+    """Mean over dim 1 of a ``[B,n,C]`` fp32 tensor (may be a strided column slice) -> ``[B,1,C]``."""
+    if not x.is_cuda:
+        raise RuntimeError("column_mean: HIP device tensors required; there is no CPU fallback")
+    if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
+        raise RuntimeError("column_mean: fp32 [B,n,C] with a contiguous last dim expected")
+    B, n, C = x.shape
+    out = torch.empty((B, 1, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib().sdetr_column_mean_f32(_hip.stream_ptr(), x.data_ptr(), x.stride(0), x.stride(1), B, n, C,
+                                                out.data_ptr())
+    _hip.check(code, "column_mean")
     return out

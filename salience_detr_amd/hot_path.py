@@ -91,23 +91,28 @@ class SalienceEncoderHotPath(nn.Module):
         if native and multi_level_feats[0].dtype == torch.float32:
             # F0 in one launch per level (flatten + level embedding + validity mask [+ bf16 copies])
             from .filter_ops import pyramid_flatten
-            feat_flatten, lvl_pos_embed_flatten, enc_in, mask_flatten, feat_enc, pos_enc = pyramid_flatten(
+            feat_flatten, lvl_pos_embed_flatten, enc_in, mask_flatten, feat_enc, pos_enc, valid_ratios_k = pyramid_flatten(
                 multi_level_feats, multi_level_pos_embeds, multi_level_masks, self.level_embeds,
                 want_bf16=(edt == torch.bfloat16))
         else:
-            enc_in = None
+            enc_in = valid_ratios_k = None
             feat_flatten = pyramid.flatten_multi_level(multi_level_feats)
             mask_flatten = pyramid.flatten_multi_level(multi_level_masks)
             lvl_pos_embed_flatten = pyramid.get_lvl_pos_embed(self.level_embeds.to(multi_level_pos_embeds[0].dtype),
                                                               multi_level_pos_embeds)
-        spatial_shapes, level_start_index, valid_ratios = pyramid.multi_level_misc(multi_level_masks)
         level_shapes = pyramid.level_shapes_of(multi_level_masks)
+        if valid_ratios_k is not None:
+            spatial_shapes, level_start_index = pyramid.shape_tensors(level_shapes, feat_flatten.device)
+            valid_ratios = valid_ratios_k
+        else:
+            spatial_shapes, level_start_index, valid_ratios = pyramid.multi_level_misc(multi_level_masks)
         starts = [0]
         for h, w in level_shapes[:-1]:
             starts.append(starts[-1] + h * w)
 
         if enc_in is not None:
-            backbone_output_memory = self.enc_output_norm(self.enc_output(enc_in))
+            from .filter_ops import fused_layer_norm
+            backbone_output_memory = fused_layer_norm(self.enc_output(enc_in), self.enc_output_norm)
         else:
             backbone_output_memory = pyramid.encoder_output_memory(
                 self.enc_output, self.enc_output_norm, feat_flatten + lvl_pos_embed_flatten, mask_flatten,

@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import class_max_times, gather_rows, masked_topk_desc, scatter_rows_
+from .filter_ops import class_max_times, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -77,6 +77,20 @@ class SalienceTransformerEncoderLayer(nn.Module):
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(query))))
         return self.norm2(query + self.dropout3(src2))
 
+    def _forward_ffn_native(self, query):
+        """No-grad FFN: ReLU in the first GEMM's epilogue when the activation is ReLU, residual + LayerNorm in
+        one launch."""
+        if isinstance(self.activation, nn.ReLU):
+            x2d = query.reshape(-1, query.shape[-1])
+            try:
+                hidden = torch._addmm_activation(self.linear1.bias, x2d, self.linear1.weight.t(), use_gelu=False)
+            except (RuntimeError, AttributeError):
+                hidden = F.relu(F.linear(x2d, self.linear1.weight, self.linear1.bias))
+        else:
+            hidden = self.activation(self.linear1(query))
+        src2 = F.linear(hidden, self.linear2.weight, self.linear2.bias).view(query.shape)
+        return fused_layer_norm(query, self.norm2, residual=src2)
+
     def _pre_attention(self, qk: Tensor, v: Tensor) -> Tensor:
         """nn.MultiheadAttention(q=k=qk, value=v) with the module's own parameters, as three GEMMs and
         one batched softmax(QK^T)V over the 300 selected tokens (salience_transformer.py:371-376)."""
@@ -113,7 +127,10 @@ class SalienceTransformerEncoderLayer(nn.Module):
             select_tgt = torch.gather(query, 1, index_e)
             select_pos = torch.gather(query_pos, 1, index_e)
         tgt2 = self._pre_attention(self.with_pos_embed(select_tgt, select_pos), select_tgt)
-        select_tgt = self.pre_norm(select_tgt + self.pre_dropout(tgt2))
+        if native:
+            select_tgt = fused_layer_norm(select_tgt, self.pre_norm, residual=tgt2)
+        else:
+            select_tgt = self.pre_norm(select_tgt + self.pre_dropout(tgt2))
         if native:
             query = scatter_rows_(query, select_tgt_index, select_tgt)  # query is the layer's own gathered copy
         else:
@@ -129,6 +146,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
             src2 = self.self_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
                                   value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                   key_padding_mask=query_key_padding_mask)
+        if native:
+            return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2))
         query = self.norm1(query + self.dropout1(src2))
         return self.forward_ffn(query)
 

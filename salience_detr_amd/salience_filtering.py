@@ -20,7 +20,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import masked_topk_desc
+from .filter_ops import column_mean, fused_layer_norm, masked_topk_desc
 
 
 class MaskPredictor(nn.Module):
@@ -38,17 +38,31 @@ class MaskPredictor(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, x: Tensor) -> Tensor:
-        z = self.layer1(x)
+    def forward(self, x: Tensor, row_scale: Optional[Tensor] = None, alpha: Optional[Tensor] = None) -> Tensor:
+        """``x`` [B,N,C].  With ``row_scale`` [B,N] (+ ``alpha``, one element) the input is first modulated as
+        ``x + x * row_scale * alpha`` (the coarse-to-fine update of salience_transformer.py:143)."""
         half = self.h_dim // 2
-        # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included.
-        # The mean over tokens is a [1 x N] x [N x h/2] product: as a batched GEMM it is one fast, deterministic
-        # launch where the framework's strided reduction takes up to 90 us at N = 16 800.
-        n = z.shape[1]
-        mean_row = z.new_full((z.shape[0], 1, n), 1.0 / n)
-        z_global = torch.bmm(mean_row, z[..., half:])
-        z = torch.cat([z[..., :half], z_global.expand(-1, n, -1)], dim=-1)
-        return self.layer2(z)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad or not x.is_cuda:
+            if row_scale is not None:
+                x = x + x * row_scale.unsqueeze(-1) * alpha
+            z = self.layer1(x)
+            # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
+            z = torch.cat([z[..., :half], z[..., half:].mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
+            return self.layer2(z)
+        # native path: modulation + LayerNorm in one launch; the global half enters layer2[0] as a per-image
+        # constant  W[:, half:] @ mean + b  (no [B,N,h] concat, half the GEMM), its token mean from a
+        # deterministic column-mean kernel
+        B, N, _ = x.shape
+        z = fused_layer_norm(x, self.layer1[0], row_scale=row_scale, alpha=alpha)
+        z = F.gelu(self.layer1[1](z))                                     # [B,N,h]
+        lin = self.layer2[0]
+        const = F.linear(column_mean(z[..., half:]), lin.weight[:, half:], lin.bias)   # [B,1,h/2]
+        w_local_t = lin.weight[:, :half].t()
+        h = torch.stack([torch.addmm(const[b], z[b, :, :half], w_local_t) for b in range(B)])
+        h = F.gelu(h)
+        h = F.gelu(self.layer2[2](h))
+        return self.layer2[4](h)
 
 
 def token_budgets(multi_level_masks: Sequence[Tensor], level_filter_ratio: Tensor):
@@ -84,9 +98,9 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
         mask = mask_flatten[:, start:start + h * w].contiguous()
         if lvl != L - 1:
             up = F.interpolate(score, size=(h, w), mode="bilinear", align_corners=True)
-            up = up.view(B, -1, h * w).transpose(1, 2)
-            level_memory = level_memory + level_memory * up * alpha[lvl]
-        token_score = mask_predictor(level_memory)                      # [B, hw, 1]
+            token_score = mask_predictor(level_memory, row_scale=up.reshape(B, h * w), alpha=alpha[lvl:lvl + 1])
+        else:
+            token_score = mask_predictor(level_memory)                  # [B, hw, 1]
         score = token_score.transpose(1, 2).reshape(B, -1, h, w)
         # masked_fill(mask, score.min()) + topk, fused in one launch; fp32 keys
         s32 = token_score.detach().squeeze(-1).float().contiguous()

@@ -125,3 +125,39 @@ def test_pyramid_flatten_matches_reference_plumbing(sizes, bf16):
         assert torch.equal(fb.cpu(), ref_feat.to(torch.bfloat16)) and torch.equal(pb.cpu(), ref_pos.to(torch.bfloat16))
     else:
         assert fb is None and pb is None
+
+
+@pytest.mark.parametrize("xdt,pdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                     (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("C", [256, 32, 64])
+def test_fused_layer_norm(xdt, pdt, C):
+    B, N = 2, 777
+    big = syn.det_randn("ln.x", (B, N + 50, C)).to(xdt)
+    x = big[:, 20:20 + N]                        # batch-strided view, like one level of [B,S,C]
+    res = syn.det_randn("ln.r", (B, N, C)).to(xdt)
+    scale = syn.det_randn("ln.s", (B, N))
+    alpha = torch.tensor([0.3])
+    ln = torch.nn.LayerNorm(C)
+    ln.weight.data = 1 + 0.1 * syn.det_randn("ln.w", (C,))
+    ln.bias.data = 0.1 * syn.det_randn("ln.b", (C,))
+    ln_d = torch.nn.LayerNorm(C).to(DEV).to(pdt)
+    ln_d.load_state_dict({k: v.to(pdt) for k, v in ln.state_dict().items()})
+    lw, lb = ln_d.weight.float().cpu(), ln_d.bias.float().cpu()
+    tol = 1e-5 if xdt == torch.float32 else 2e-2
+    ref = lambda t: torch.nn.functional.layer_norm(t, (C,), lw, lb, ln.eps)
+    got = F.fused_layer_norm(x.to(DEV), ln_d)
+    assert (got.float().cpu() - ref(x.float())).abs().max() < tol
+    got = F.fused_layer_norm(x.to(DEV), ln_d, residual=res.to(DEV))
+    assert (got.float().cpu() - ref(x.float() + res.float())).abs().max() < tol
+    got = F.fused_layer_norm(x.to(DEV), ln_d, row_scale=scale.to(DEV), alpha=alpha.to(DEV), out_dtype=torch.float32)
+    xm = x.float() + x.float() * scale[..., None] * alpha
+    assert (got.cpu() - ref(xm)).abs().max() < (1e-5 if xdt == torch.float32 else 1e-4)
+
+
+def test_column_mean_strided():
+    z = syn.det_randn("cm", (2, 16800, 256)).to(DEV)
+    got = F.column_mean(z[..., 128:])
+    assert got.shape == (2, 1, 128)
+    assert (got.cpu() - z[..., 128:].cpu().double().mean(1, keepdim=True).float()).abs().max() < 1e-6
+    again = F.column_mean(z[..., 128:])
+    assert torch.equal(got, again)  # deterministic
