@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer (default, BASELINE.json configs[1]) or train: fp32 forward+backward of the hot path, "
+                         "flat RCCL gradient all-reduce, AdamW step (configs[2])")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
@@ -69,6 +72,99 @@ def algorithmic_bytes(B, Nv, Nq, M, D, L, P, value_bytes, proj_bytes, out_bytes,
                 + Nq * M * D * out_bytes)
 
 
+def train_main(args, model, device, rank, world, dist):
+    """configs[2]: one training step of the hot-path modules per batch of 2 images per GPU -- fp32 forward
+    through the autograd path (HIP MSDA forward/backward op), a synthetic loss on `memory` and the salience
+    maps, backward, ONE flat all-reduce of the ~38 MB of gradients over RCCL, AdamW."""
+    from salience_detr_amd.data_parallel import FlatGradAllReducer, broadcast_parameters
+    sizes, canvas, level_shapes, _, (feats, masks, pos) = make_inputs(args.batch, args.height, args.width, device,
+                                                                      seed=rank)
+    model.train()
+    if dist is not None:
+        broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    reducer = FlatGradAllReducer(params) if dist is not None else None
+    w = None
+
+    def step():
+        nonlocal w
+        opt.zero_grad(set_to_none=True)
+        memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
+        if w is None:
+            w = torch.randn_like(memory)
+        loss = (memory * w).mean() + sum((s.float() ** 2).mean() for s in score_maps)
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce(average=True)
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # dominant kernel of the training step: the MSDA backward scatter; timed with stream events
+    evs, nbytes = [], []
+    real_bwd = msda_mod.ms_deform_attn_backward
+
+    def timed_bwd(value, shapes, lsi, loc, aw, grad_out, step_):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real_bwd(value, shapes, lsi, loc, aw, grad_out, step_)
+        e1.record()
+        evs.append((e0, e1))
+        B, Nv, M, D = value.shape
+        Nq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        nbytes.append(4 * B * (2 * Nv * M * D + 2 * Nq * M * L * P * 3 + Nq * M * D))  # SURVEY.md 8(d) backward
+        return r
+
+    msda_mod.ms_deform_attn_backward = timed_bwd
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    msda_mod.ms_deform_attn_backward = real_bwd
+    tot_us = sum(e0.elapsed_time(e1) for e0, e1 in evs) * 1e3
+    achieved = sum(nbytes) / tot_us / 1e3
+    result = {
+        "metric": "images/s (whole node) + ms/encoder-layer, ResNet50 800x1333",
+        "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": "salience_detr_resnet50_800_1333 training step of the hot path (filtering + 6-layer "
+                               "encoder fwd+bwd, synthetic loss, AdamW), batch=%d per MI355X" % args.batch,
+                   "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "parallelism": "data parallel, one flat gradient all-reduce per step over RCCL"
+                                  if world > 1 else "single GPU",
+                   "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params)},
+        "roofline": {"kernel": "sdetr::msda_col2im_kernel (MSDA backward scatter, fp32 atomics)", "bound": "hbm",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "avg_launch_us": round(tot_us / max(1, len(evs)), 1)},
+        "loss": float(loss),
+    }
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -86,6 +182,8 @@ def main():
     model = build_hot_path()
     model.load_state_dict(syn.det_state_dict(model.state_dict()))
     model = model.to(device).eval()
+    if args.mode == "train":
+        return train_main(args, model, device, rank, world, dist)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_encoder_dtype(dtype)
 

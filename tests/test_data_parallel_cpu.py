@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the N > 1 path (image sharding + flat gradient all-reduce) that the driver
+runs at 2/4/8 GPUs over RCCL.  Gradients of a 2-rank data-parallel step must equal the single-process
+gradients of the full batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from salience_detr_amd import synthetic as syn
+from salience_detr_amd.data_parallel import FlatGradAllReducer, broadcast_parameters, shard_range
+from salience_detr_amd.salience_filtering import MaskPredictor
+
+
+def test_shard_range_covers_everything_once():
+    for n in (0, 1, 2, 7, 16, 17):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                a, b = shard_range(n, r, world)
+                assert 0 <= a <= b <= n
+                seen += list(range(a, b))
+            assert seen == list(range(n))
+            sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _model():
+    torch.manual_seed(0)
+    m = MaskPredictor(32, 32)
+    m.load_state_dict(syn.det_state_dict(m.state_dict()))
+    return m
+
+
+def _loss(model, x):
+    return (model(x) ** 2).mean()
+
+
+def _worker(rank, world, port, bucket_bytes, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        if rank == 1:  # replicas start different; broadcast must fix that
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        broadcast_parameters(model, src=0)
+        x = syn.det_randn("dp.x", (4, 50, 32))
+        a, b = shard_range(x.shape[0], rank, world)
+        # mean over the global batch = average of per-rank means when shards are equal
+        _loss(model, x[a:b]).backward()
+        if rank == 1:  # a parameter that only one rank touched
+            model.layer2[4].bias.grad = None
+        red = FlatGradAllReducer(model.parameters(), bucket_bytes=bucket_bytes)
+        red.all_reduce(average=True)
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"g{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [None, 4096])
+def test_two_rank_gradients_match_single_process(tmp_path, bucket_bytes):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, bucket_bytes, str(tmp_path)), nprocs=2, join=True)
+    g0 = torch.load(os.path.join(tmp_path, "g0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "g1.pt"))
+    model = _model()
+    x = syn.det_randn("dp.x", (4, 50, 32))
+    # reference: average of the two half-batch losses.  NOTE the MaskPredictor couples the tokens of ONE
+    # image batch through its global mean over dim 1 only, so per-rank half batches are exactly the two terms.
+    (0.5 * (_loss(model, x[:2]) + _loss(model, x[2:]))).backward()
+    for name, p in model.named_parameters():
+        expect = p.grad
+        if name == "layer2.4.bias":  # rank 1 contributed zeros for it
+            m2 = _model()
+            (0.5 * _loss(m2, x[:2])).backward()
+            expect = dict(m2.named_parameters())[name].grad
+        assert torch.allclose(g0[name], expect, atol=1e-6), name
+        assert torch.equal(g0[name], g1[name]), name
