@@ -19,6 +19,14 @@
 //             comparison, branch-free loops, 8 LDS reads in flight).  rank < k  =>  out[rank] = (score, index):
 //             the rank IS the output slot -- no select pass, no sorting network, no merge.
 //   N^2 comparisons (282 M for the largest level, 16 800 keys) over 1024 SIMDs is ~10-20 us.
+//
+//   When k is well below N (the per-layer top-300 of 11 363, the 40 % budget of the finest level) a
+//   PREFILTER shrinks the ranked set first: topk_prefilter (one 1024-thread workgroup per row) ranks a
+//   1024-key strided sample in LDS, takes the sample key whose rank is k*S/N plus five standard deviations
+//   as a conservative threshold, counts the row's keys passing it and -- only if at least k pass, otherwise
+//   it lets everything pass -- compacts them STABLY (index order, block scan) into a scratch list.  The
+//   rank kernel then counts among those ~1.2 k candidates only (any key that fails the threshold sorts
+//   after every candidate, so candidate ranks are global ranks).  Exactness never depends on the sample.
 #include "common.h"
 
 namespace sdetr {
@@ -62,11 +70,123 @@ __global__ void __launch_bounds__(1024) topk_min_kernel(const float *score, int6
     }
 }
 
+constexpr int kPreThreads = 1024;
+constexpr int kPreWaves = kPreThreads / 64;
+
+struct PrefilterArgs {
+    const float *score;
+    const uint8_t *mask;
+    const float *fill;
+    int N, k;
+    uint32_t *cand_key;   // [B][N]
+    uint32_t *cand_pos;   // [B][N]
+    int32_t *cand_count;  // [B]
+};
+
+// exclusive prefix over the block's threads (thread order) + grand total
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *buf /*[kPreWaves]*/, int tid,
+                                                         uint32_t &total)
+{
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += n;
+    }
+    if ((tid & 63) == 63) buf[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < kPreWaves; ++w) {
+        const uint32_t c = buf[w];
+        if (w < (tid >> 6)) before += c;
+        t += c;
+    }
+    total = t;
+    return before + incl - v;
+}
+
+template <int KPT>
+__global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterArgs p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t samp[kPreThreads];
+    __shared__ uint32_t scan_buf[kPreWaves];
+    __shared__ uint32_t thr_s;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float *srow = p.score + (int64_t)b * p.N;
+    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.N : nullptr;
+    const float fill = p.fill ? *p.fill : 0.f;
+    const int chunk = (p.N + kPreThreads - 1) / kPreThreads;  // <= KPT
+    const int lo = tid * chunk, hi = min(p.N, lo + chunk);
+    uint32_t keys[KPT];
+    {
+        float sv[KPT];
+        uint8_t mk[KPT];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) sv[c] = srow[min(lo + c, p.N - 1)];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) mk[c] = mrow ? mrow[min(lo + c, p.N - 1)] : (uint8_t)0;
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) keys[c] = (lo + c < hi) ? desc_bits(mk[c] ? fill : sv[c]) : 0xffffffffu;
+    }
+    // strided sample: the first key of every thread's chunk (0xffffffff = no key: sorts last)
+    samp[tid] = keys[0];
+    if (tid == 0) thr_s = 0xffffffffu;
+    __syncthreads();
+    const int S = (p.N + chunk - 1) / chunk;  // threads that own at least one key
+    // target sample rank: k*S/N plus five standard deviations of the binomial sample count
+    const float frac = (float)p.k / (float)p.N;
+    const int target = min(S - 1, (int)(frac * S + 5.f * sqrtf(fmaxf(frac * (1.f - frac) * S, 1.f)) + 1.f));
+    {
+        const uint32_t mine = keys[0];
+        uint32_t rank = 0;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(samp);
+#pragma unroll 8
+        for (int g = 0; g < kPreThreads / 4; ++g) {
+            const uint4 c = s4[g];
+            const int j = g * 4;
+            rank += (c.x < mine || (c.x == mine && j + 0 < tid)) ? 1u : 0u;
+            rank += (c.y < mine || (c.y == mine && j + 1 < tid)) ? 1u : 0u;
+            rank += (c.z < mine || (c.z == mine && j + 2 < tid)) ? 1u : 0u;
+            rank += (c.w < mine || (c.w == mine && j + 3 < tid)) ? 1u : 0u;
+        }
+        if ((int)rank == target) thr_s = mine;  // ranks are a permutation: exactly one writer
+    }
+    __syncthreads();
+    uint32_t thr = thr_s;
+    uint32_t n_pass = 0;
+#pragma unroll
+    for (int c = 0; c < KPT; ++c) n_pass += (lo + c < hi && keys[c] <= thr) ? 1u : 0u;
+    uint32_t total;
+    uint32_t out = block_exclusive_scan(n_pass, scan_buf, tid, total);
+    if (total < (uint32_t)p.k) {  // the sample was unlucky: let every key pass (still exact, just slower)
+        thr = 0xffffffffu;
+        n_pass = (uint32_t)max(0, hi - lo);
+        __syncthreads();
+        out = block_exclusive_scan(n_pass, scan_buf, tid, total);
+    }
+    uint32_t *ck = p.cand_key + (int64_t)b * p.N;
+    uint32_t *cp = p.cand_pos + (int64_t)b * p.N;
+#pragma unroll
+    for (int c = 0; c < KPT; ++c) {
+        if (lo + c < hi && keys[c] <= thr) {
+            ck[out] = keys[c];
+            cp[out] = (uint32_t)(lo + c);
+            ++out;
+        }
+    }
+    if (tid == 0) p.cand_count[b] = (int)total;
+}
+
 struct RankArgs {
     const float *score;
     const uint8_t *mask;
     const float *fill;  // device scalar or NULL
     const int64_t *payload;
+    // candidate mode (after topk_prefilter): keys / positions / count per row instead of raw scores
+    const uint32_t *cand_key;
+    const uint32_t *cand_pos;
+    const int32_t *cand_count;
     int N, k;
     int64_t index_offset;
     float *out_score;
@@ -80,41 +200,49 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int base = blockIdx.x * 64;  // owned keys [base, base+64)
+    const bool cand = p.cand_key != nullptr;
+    const int n_keys = cand ? p.cand_count[b] : p.N;  // length of the ranked list
+    if (base >= n_keys) return;                        // uniform per workgroup
     const float *srow = p.score + (int64_t)b * p.N;
     const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.N : nullptr;
+    const uint32_t *ckey = cand ? p.cand_key + (int64_t)b * p.N : nullptr;
     const float fill = p.fill ? *p.fill : 0.f;
-    auto key_at = [&](int i) -> uint32_t {  // i < N
+    auto key_at = [&](int i) -> uint32_t {  // i < n_keys
+        if (cand) return ckey[i];
         float s = srow[i];
         if (mrow && mrow[i]) s = fill;
         return desc_bits(s);
     };
     const int mypos = base + lane;
-    const uint32_t mine = mypos < p.N ? key_at(mypos) : 0u;
+    const uint32_t mine = mypos < n_keys ? key_at(mypos) : 0u;
     uint32_t rank = 0;
 
-    for (int t0 = 0; t0 < p.N; t0 += kRankTile) {
-        const int tn = min(kRankTile, p.N - t0);
+    for (int t0 = 0; t0 < n_keys; t0 += kRankTile) {
+        const int tn = min(kRankTile, n_keys - t0);
         if (t0 > 0) __syncthreads();
         // stage: all global loads of this thread first (<= 48 scalars), then the LDS stores; padding keys
         // (positions >= N) are 0xffffffff, which no "<" test counts and whose positions fail the tie rule
         constexpr int kPer = kRankTile / kRankThreads;  // 48
         for (int c0 = 0; c0 < kPer; c0 += 12) {
-            float sv[12];
-            uint8_t mk[12];
+            uint32_t kv[12];
+            if (cand) {
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const int i = t0 + (c0 + c) * kRankThreads + tid;
-                sv[c] = srow[min(i, p.N - 1)];
-            }
+                for (int c = 0; c < 12; ++c) kv[c] = ckey[min(t0 + (c0 + c) * kRankThreads + tid, n_keys - 1)];
+            } else {
+                float sv[12];
+                uint8_t mk[12];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const int i = t0 + (c0 + c) * kRankThreads + tid;
-                mk[c] = mrow ? mrow[min(i, p.N - 1)] : (uint8_t)0;
+                for (int c = 0; c < 12; ++c) sv[c] = srow[min(t0 + (c0 + c) * kRankThreads + tid, n_keys - 1)];
+#pragma unroll
+                for (int c = 0; c < 12; ++c)
+                    mk[c] = mrow ? mrow[min(t0 + (c0 + c) * kRankThreads + tid, n_keys - 1)] : (uint8_t)0;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) kv[c] = desc_bits(mk[c] ? fill : sv[c]);
             }
 #pragma unroll
             for (int c = 0; c < 12; ++c) {
                 const int li = (c0 + c) * kRankThreads + tid;
-                if (li < ((tn + 3) & ~3)) tile[li] = (t0 + li < p.N) ? desc_bits(mk[c] ? fill : sv[c]) : 0xffffffffu;
+                if (li < ((tn + 3) & ~3)) tile[li] = (t0 + li < n_keys) ? kv[c] : 0xffffffffu;
             }
             if ((c0 + 12) * kRankThreads >= tn) break;
         }
@@ -149,12 +277,13 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
     }
     partial[wave][lane] = rank;
     __syncthreads();
-    if (wave == 0 && mypos < p.N) {
+    if (wave == 0 && mypos < n_keys) {
         const uint32_t r = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
         if (r < (uint32_t)p.k) {
+            const int pos = cand ? (int)p.cand_pos[(int64_t)b * p.N + mypos] : mypos;
             if (p.out_score) p.out_score[(int64_t)b * p.k + r] = undesc_bits(mine);
             p.out_index[(int64_t)b * p.k + r] =
-                p.payload ? p.payload[(int64_t)b * p.N + mypos] : (int64_t)mypos + p.index_offset;
+                p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
         }
     }
 }
@@ -163,10 +292,18 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
 
 using namespace sdetr;
 
+static bool use_prefilter(int n, int k)
+{
+    // worth it when the ranked set shrinks at least ~2x and the row fits the register-resident prefilter
+    return n >= 2048 && n <= kPreThreads * 24 && (int64_t)k * 5 <= (int64_t)n * 2;
+}
+
 extern "C" size_t sdetr_topk_workspace_bytes(int B, int n, int k)
 {
     if (B <= 0 || n <= 0 || k <= 0) return 0;
-    return 16;  // one float: the masked-fill value
+    size_t bytes = 16;  // one float: the masked-fill value
+    if (use_prefilter(n, k)) bytes += (size_t)B * n * 8 + (size_t)B * 4 + 16;  // candidate keys, positions, counts
+    return bytes;
 }
 
 extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
@@ -192,6 +329,29 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
         if (int e = check_launch("topk_min")) return e;
         r.fill = reinterpret_cast<const float *>(workspace);
     }
-    hipLaunchKernelGGL(topk_rank_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)B), dim3(kRankThreads), 0, stream, r);
+    int ranked = n;
+    if (use_prefilter(n, k)) {
+        const size_t need = sdetr_topk_workspace_bytes(B, n, k);
+        if (!workspace || workspace_bytes < need)
+            return fail("masked_topk: needs %zu bytes of workspace, got %zu", need, workspace_bytes);
+        PrefilterArgs f{};
+        f.score = score; f.mask = mask; f.fill = r.fill; f.N = n; f.k = k;
+        f.cand_key = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(workspace) + 16);
+        f.cand_pos = f.cand_key + (size_t)B * n;
+        f.cand_count = reinterpret_cast<int32_t *>(f.cand_pos + (size_t)B * n);
+        const int chunk = (n + kPreThreads - 1) / kPreThreads;
+#define SDETR_PRE(KPT) hipLaunchKernelGGL(topk_prefilter_kernel<KPT>, dim3((unsigned)B), dim3(kPreThreads), 0, stream, f)
+        if (chunk <= 5) SDETR_PRE(5);
+        else if (chunk <= 12) SDETR_PRE(12);
+        else if (chunk <= 17) SDETR_PRE(17);
+        else SDETR_PRE(24);
+#undef SDETR_PRE
+        if (int e = check_launch("topk_prefilter")) return e;
+        r.cand_key = f.cand_key; r.cand_pos = f.cand_pos; r.cand_count = f.cand_count;
+        // expected candidates ~ k + 5 sigma (+ one sample stride); the grid covers the worst case (n) and
+        // surplus workgroups exit on their first instruction
+        ranked = n;
+    }
+    hipLaunchKernelGGL(topk_rank_kernel, dim3((unsigned)((ranked + 63) / 64), (unsigned)B), dim3(kRankThreads), 0, stream, r);
     return check_launch("topk_rank");
 }
