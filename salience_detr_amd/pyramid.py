@@ -127,7 +127,8 @@ class PositionEmbeddingSine(nn.Module):
         pos_y = y_embed[:, :, :, None] / self.dim_ty
         pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
         pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
-        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+        # contiguous NCHW: the flatten kernel downstream then reads it without a per-forward re-layout copy
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2).contiguous()
 
 
 class PositionEmbeddingLearned(nn.Module):

@@ -92,21 +92,31 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return fused_layer_norm(query, self.norm2, residual=src2)
 
     def _pre_attention(self, qk: Tensor, v: Tensor) -> Tensor:
-        """nn.MultiheadAttention(q=k=qk, value=v) with the module's own parameters, as three GEMMs and
-        one batched softmax(QK^T)V over the 300 selected tokens (salience_transformer.py:371-376)."""
+        """nn.MultiheadAttention(q=k=qk, value=v) with the module's own parameters
+        (salience_transformer.py:371-376).  The 300-token problem is launch-latency bound, so it is arranged as
+        few launches: ONE in-projection GEMM over the stacked [qk ; v] rows (q,k are read from the first half,
+        v from the second), one fused scaled-dot-product attention, one out-projection."""
         mha = self.pre_attention
         B, N, E = qk.shape
         H = mha.num_heads
         hd = E // H
-        w, b = mha.in_proj_weight, mha.in_proj_bias
-        q_k = F.linear(qk, w[:2 * E], b[:2 * E]).view(B, N, 2, H, hd)
-        q = q_k[:, :, 0].transpose(1, 2)
-        k = q_k[:, :, 1].transpose(1, 2)
-        vv = F.linear(v, w[2 * E:], b[2 * E:]).view(B, N, H, hd).transpose(1, 2)
-        att = torch.matmul(q * (1.0 / math.sqrt(hd)), k.transpose(-1, -2)).softmax(-1)
-        if self.training and mha.dropout > 0:
-            att = F.dropout(att, mha.dropout)
-        o = torch.matmul(att, vv).transpose(1, 2).reshape(B, N, E)
+        proj = F.linear(torch.cat([qk, v], 1), mha.in_proj_weight, mha.in_proj_bias)   # [B, 2N, 3E]
+        q = proj[:, :N, :E].view(B, N, H, hd).transpose(1, 2)
+        k = proj[:, :N, E:2 * E].view(B, N, H, hd).transpose(1, 2)
+        vv = proj[:, N:, 2 * E:].view(B, N, H, hd).transpose(1, 2)
+        drop = mha.dropout if self.training else 0.0
+        o = None
+        if not (torch.is_grad_enabled() and qk.requires_grad):
+            try:
+                o = F.scaled_dot_product_attention(q, k, vv, dropout_p=drop)
+            except RuntimeError:
+                o = None
+        if o is None:
+            att = torch.matmul(q * (1.0 / math.sqrt(hd)), k.transpose(-1, -2)).softmax(-1)
+            if drop > 0:
+                att = F.dropout(att, drop)
+            o = torch.matmul(att, vv)
+        o = o.transpose(1, 2).reshape(B, N, E)
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
