@@ -46,6 +46,9 @@ def parse():
                          "flat RCCL gradient all-reduce, AdamW step (configs[2])")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--value-dtype", choices=["same", "fp16"], default="fp16",
+                    help="storage type of the head-major value maps sampled by the MSDA kernel in bf16 mode: fp16 "
+                         "(default; 11-bit mantissa, gather via v_fma_mix_f32) or the activation dtype (bf16)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--instrumented-steps", type=int, default=10)
@@ -186,7 +189,7 @@ def main():
     if args.mode == "train":
         return train_main(args, model, device, rank, world, dist)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model.set_encoder_dtype(dtype)
+    model.set_encoder_dtype(dtype, torch.float16 if (args.dtype == "bf16" and args.value_dtype == "fp16") else None)
 
     sizes, canvas, level_shapes, cpu_inputs, (feats, masks, pos) = make_inputs(
         args.batch, args.height, args.width, device, seed=rank)
@@ -294,7 +297,8 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_traffic.json")))
         nqs = [int(round((b_ / args.batch - 22323 * 256 * 2) / (384 * 2 + 32 + 512))) for b_ in bytes_per_layer]
-        if args.dtype == "bf16" and args.batch == tj["batch"] and all(str(n) in tj["per_num_query"] for n in nqs):
+        if (args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same") and args.batch == tj["batch"]
+                and all(str(n) in tj["per_num_query"] for n in nqs)):
             traffic = int(sum(tj["per_num_query"][str(n)]["hbm_bytes"] for n in nqs) / nl)
             traffic_src = "profiles/r01_msda_traffic.json"
     except (OSError, ValueError, KeyError):
@@ -318,6 +322,7 @@ def main():
                                "hierarchical salience filtering + 6-layer salience encoder (MSDA)" % (args.dtype, args.batch),
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "image": [args.height, args.width], "levels": [list(s) for s in level_shapes],
+                   "value_map_storage": ("fp16" if (args.dtype == "bf16" and args.value_dtype == "fp16") else args.dtype),
                    "parallelism": "replicas, images sharded across GPUs, no data-path collective",
                    "hipgraph": graphed},
         "ms_per_encoder_layer": {"mean": round(sum(layer_ms) / nl, 4), "per_layer": [round(x, 4) for x in layer_ms],

@@ -84,6 +84,9 @@ def main():
             alg = B * (22323 * 256 * 2 + Nq * 384 * 2 + Nq * 32 + Nq * 256 * 2)
             t = timeit(lambda: M.msda_fused_forward(hm, sh, ls, rf, pj, 4, 4, out_dtype=torch.bfloat16))
             res.append(dict(case="enc_direct_bf16", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
+            hm16 = hm.float().to(torch.float16)
+            t = timeit(lambda: M.msda_fused_forward(hm16, sh, ls, rf, pj, 4, 4, out_dtype=torch.bfloat16))
+            res.append(dict(case="enc_direct_f16value", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
             order = M.region_bucket(rf, sh, LEVELS[0])[0]
             t = timeit(lambda: M.msda_fused_forward(hm, sh, ls, rf, pj, 4, 4, order=order, out_dtype=torch.bfloat16))
             res.append(dict(case="enc_direct_bf16_region_order", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))

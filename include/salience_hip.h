@@ -34,6 +34,7 @@ typedef struct ihipStream_t *sdetr_stream_t; /* == hipStream_t */
 /* element types for the native (non drop-in) entry points */
 #define SDETR_F32 0
 #define SDETR_BF16 1
+#define SDETR_F16 2 /* IEEE half: accepted as the storage type of the head-major value map only */
 
 int sdetr_abi_version(void);
 const char *sdetr_last_error(void);

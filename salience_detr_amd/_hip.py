@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsalience_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EINVAL = -1
 
 _lib = None
@@ -103,4 +103,6 @@ def dtype_code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
-    raise RuntimeError(f"unsupported dtype {dt} (float32 / bfloat16 only)")
+    if dt == torch.float16:
+        return F16  # storage type of the head-major value map only
+    raise RuntimeError(f"unsupported dtype {dt} (float32 / bfloat16, float16 value maps only)")

@@ -56,4 +56,30 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
 }
 
+// ---- IEEE fp16 storage (distinct C++ type so templates can tell it from bf16) -----------------
+struct half_t {
+    uint16_t bits;
+};
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)
+{
+    // round-to-nearest-even, saturating at +-65504 so a large activation never becomes inf in storage
+    const _Float16 a = (_Float16)fminf(fmaxf(lo, -65504.f), 65504.f);
+    const _Float16 b = (_Float16)fminf(fmaxf(hi, -65504.f), 65504.f);
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+__device__ __forceinline__ float f16_lo(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed & 0xffffu)); }
+__device__ __forceinline__ float f16_hi(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed >> 16)); }
+// acc += f32(half of `packed`) * w as ONE instruction (v_fma_mix_f32: f16 source converted exactly, single
+// rounding) -- no separate unpack, which is a third of the bf16 gather's instruction stream
+__device__ __forceinline__ float fma_f16lo(uint32_t packed, float w, float acc)
+{
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ float fma_f16hi(uint32_t packed, float w, float acc)
+{
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
+    return acc;
+}
+
 }  // namespace sdetr

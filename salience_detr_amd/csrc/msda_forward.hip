@@ -52,6 +52,22 @@ struct ValTraits<bf16_t> {
     }
 };
 
+template <>
+struct ValTraits<half_t> {
+    static constexpr int kCpl = 8;
+    __device__ static __forceinline__ void fma4(float *acc, const uint4 &v, float w)
+    {
+        acc[0] = fma_f16lo(v.x, w, acc[0]);
+        acc[1] = fma_f16hi(v.x, w, acc[1]);
+        acc[2] = fma_f16lo(v.y, w, acc[2]);
+        acc[3] = fma_f16hi(v.y, w, acc[3]);
+        acc[4] = fma_f16lo(v.z, w, acc[4]);
+        acc[5] = fma_f16hi(v.z, w, acc[5]);
+        acc[6] = fma_f16lo(v.w, w, acc[6]);
+        acc[7] = fma_f16hi(v.w, w, acc[7]);
+    }
+};
+
 struct GatherArgs {
     const char *value;
     const int64_t *shapes;
@@ -85,37 +101,37 @@ __device__ __forceinline__ float proj_elem<bf16_t>(const void *proj, int64_t idx
     return __uint_as_float((uint32_t) reinterpret_cast<const bf16_t *>(proj)[idx] << 16);
 }
 
-// One sample's descriptor: 4 corner byte offsets (relative to the block's value base, lane
-// offset excluded) and 4 weights = bilinear weight * attention weight (0 for an out-of-range
-// corner, whose offset is clamped into the map so the load stays legal).
+// One sample's descriptor: 4 corner byte offsets (relative to the block's value base, lane offset excluded)
+// and 4 weights = bilinear weight * attention weight (0 for an out-of-range corner, whose offset is clamped
+// into the map so the load stays legal).  Written for instruction count -- the set-up is ~40 % of the
+// kernel's VALU work: separable validity (row / column) folded into the 1-d weights, clamps as v_med3,
+// no division, no branches.
 __device__ __forceinline__ void make_descriptor(float x, float y, float a, int H, int W, int level_start,
                                                 uint32_t pixel_bytes, uint32_t *d)
 {
-    const float h_im = y * (float)H - 0.5f;
-    const float w_im = x * (float)W - 0.5f;
-    const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    const float fH = (float)H, fW = (float)W;
+    const float h_im = fmaf(y, fH, -0.5f);
+    const float w_im = fmaf(x, fW, -0.5f);
+    const bool inside = (h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW);
     const float fy = floorf(h_im), fx = floorf(w_im);
-    int y0 = (int)fy, x0 = (int)fx;
     const float ly = h_im - fy, lx = w_im - fx;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    if (!inside) {
-        y0 = 0;
-        x0 = 0;
-        a = 0.f;
-    }
-    const int y1 = y0 + 1, x1 = x0 + 1;
-    const bool y0ok = y0 >= 0, x0ok = x0 >= 0, y1ok = y1 <= H - 1, x1ok = x1 <= W - 1;
-    const int y0c = y0ok ? y0 : 0, x0c = x0ok ? x0 : 0;
-    const int y1c = y1ok ? y1 : H - 1, x1c = x1ok ? x1 : W - 1;
+    const int y0 = (int)fy, x0 = (int)fx;  // (int) saturates for wild values; weights are zero then
+    a = inside ? a : 0.f;
+    const float wy0 = (y0 >= 0) ? (1.f - ly) * a : 0.f;
+    const float wy1 = (y0 + 1 <= H - 1) ? ly * a : 0.f;
+    const float wx0 = (x0 >= 0) ? (1.f - lx) : 0.f;
+    const float wx1 = (x0 + 1 <= W - 1) ? lx : 0.f;
+    const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x0 + 1, 0), W - 1);
     const uint32_t r0 = (uint32_t)(level_start + y0c * W), r1 = (uint32_t)(level_start + y1c * W);
     d[0] = (r0 + x0c) * pixel_bytes;
     d[1] = (r0 + x1c) * pixel_bytes;
     d[2] = (r1 + x0c) * pixel_bytes;
     d[3] = (r1 + x1c) * pixel_bytes;
-    d[4] = __float_as_uint((y0ok && x0ok) ? hy * hx * a : 0.f);
-    d[5] = __float_as_uint((y0ok && x1ok) ? hy * lx * a : 0.f);
-    d[6] = __float_as_uint((y1ok && x0ok) ? ly * hx * a : 0.f);
-    d[7] = __float_as_uint((y1ok && x1ok) ? ly * lx * a : 0.f);
+    d[4] = __float_as_uint(wy0 * wx0);
+    d[5] = __float_as_uint(wy0 * wx1);
+    d[6] = __float_as_uint(wy1 * wx0);
+    d[7] = __float_as_uint(wy1 * wx1);
 }
 
 template <typename VT, int D, bool HEAD_MAJOR, bool FUSED>
@@ -150,6 +166,7 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
         lvl_tab[tid * 3 + 2] = (int)p.lsi[tid];
     }
     __syncthreads();
+    const float inv_P = 0.5f / (float)p.P;  // offsets / num_points * wh * 0.5 (4-d reference boxes)
 
     const int LP = p.L * p.P;
     const int64_t row = ((int64_t)b * p.Nq + q) * p.M + m;  // (b,q,m) row index
@@ -266,12 +283,12 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
                     float x, y, a;
                     if (FUSED) {
                         a = __expf(ra[t] - sm_max) * sm_inv;
-                        if (p.ref_dim == 2) {
-                            x = rr[t][0] + rx[t] / (float)W;
-                            y = rr[t][1] + ry[t] / (float)H;
+                        if (p.ref_dim == 2) {  // ref + offset / (W, H): reciprocal + fma (<= 1 ulp from a true division)
+                            x = fmaf(rx[t], __frcp_rn((float)W), rr[t][0]);
+                            y = fmaf(ry[t], __frcp_rn((float)H), rr[t][1]);
                         } else {
-                            x = rr[t][0] + rx[t] / (float)p.P * rr[t][2] * 0.5f;
-                            y = rr[t][1] + ry[t] / (float)p.P * rr[t][3] * 0.5f;
+                            x = fmaf(rx[t] * inv_P, rr[t][2], rr[t][0]);
+                            y = fmaf(ry[t] * inv_P, rr[t][3], rr[t][1]);
                         }
                     } else {
                         x = rx[t];
@@ -479,6 +496,7 @@ extern "C" int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
     if (value_dtype == SDETR_F32) return dispatch_d<float, true, false>(stream, a, D);
     if (value_dtype == SDETR_BF16) return dispatch_d<bf16_t, true, false>(stream, a, D);
+    if (value_dtype == SDETR_F16) return dispatch_d<half_t, true, false>(stream, a, D);
     return fail("msda_forward_head_major: bad value dtype %d", value_dtype);
 }
 
@@ -503,5 +521,6 @@ extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
     if (value_dtype == SDETR_F32) return dispatch_d<float, true, true>(stream, a, D);
     if (value_dtype == SDETR_BF16) return dispatch_d<bf16_t, true, true>(stream, a, D);
+    if (value_dtype == SDETR_F16) return dispatch_d<half_t, true, true>(stream, a, D);
     return fail("msda_fused_forward: bad value dtype %d", value_dtype);
 }

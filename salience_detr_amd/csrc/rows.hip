@@ -9,6 +9,8 @@
 //    (models/bricks/ms_deform_attn.py:316-321): masked_fill(padding, 0) + view as heads, written
 //    head-major [B,M,Nv,D] (optionally bf16) so that one head of one pixel is one contiguous
 //    64/128-byte segment and one head's map is one contiguous slab (XCD-private in L2).
+#include <type_traits>
+
 #include "common.h"
 
 namespace sdetr {
@@ -81,6 +83,9 @@ __global__ void __launch_bounds__(kBlock) head_major_kernel(const ST *src, int64
         if (sizeof(DT) == 4) {
             reinterpret_cast<float4 *>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
             reinterpret_cast<float4 *>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (std::is_same<DT, half_t>::value) {
+            *reinterpret_cast<uint4 *>(d) = make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]),
+                                                      pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
         } else {
             *reinterpret_cast<uint4 *>(d) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
@@ -162,6 +167,8 @@ extern "C" int sdetr_value_to_head_major(sdetr_stream_t stream, const void *src,
     else if (src_dtype == SDETR_F32 && dst_dtype == SDETR_BF16) SDETR_HM(float, bf16_t);
     else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_BF16) SDETR_HM(bf16_t, bf16_t);
     else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_F32) SDETR_HM(bf16_t, float);
+    else if (src_dtype == SDETR_F32 && dst_dtype == SDETR_F16) SDETR_HM(float, half_t);
+    else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_F16) SDETR_HM(bf16_t, half_t);
     else return fail("value_to_head_major: bad dtypes %d -> %d", src_dtype, dst_dtype);
 #undef SDETR_HM
     return check_launch("value_to_head_major");

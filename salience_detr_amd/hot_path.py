@@ -50,13 +50,15 @@ class SalienceEncoderHotPath(nn.Module):
         nn.init.constant_(self.encoder_class_head.bias, -math.log((1 - 0.01) / 0.01))
         self.alpha.data.uniform_(-0.3, 0.3)
 
-    def set_encoder_dtype(self, dtype: torch.dtype) -> "SalienceEncoderHotPath":
+    def set_encoder_dtype(self, dtype: torch.dtype, value_dtype: Optional[torch.dtype] = None):
         """Run the six encoder layers (and the shared class head) in ``dtype`` (bf16 for the inference
         benchmark).  The filtering stage -- token selection -- always stays fp32 so that the selected
-        index sets do not depend on the encoder precision."""
+        index sets do not depend on the encoder precision.  ``value_dtype`` is the storage type of the
+        head-major value maps the MSDA kernel samples (default ``dtype``); ``torch.float16`` keeps 3 more
+        mantissa bits than bf16 at the same size and lets the gather use ``v_fma_mix_f32`` (no unpack)."""
         self.encoder.to(dtype)
         for layer in self.encoder.layers:
-            layer.self_attn.value_dtype = dtype
+            layer.self_attn.value_dtype = value_dtype or dtype
         return self
 
     @property

@@ -85,7 +85,7 @@ def test_forward_backward_vs_c_oracle(B, Nq, levels, M_, D, P):
     assert np.abs(ga.cpu().numpy() - rga).max() < 2e-4 * max(1.0, np.abs(rga).max())
 
 
-@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("vdt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Nq,levels,M_,D,P", [(2, 301, LEVELS_SMALL, 8, 32, 4), (1, 65, LEVELS_SMALL, 4, 16, 2)])
 def test_head_major_explicit_vs_oracle(vdt, B, Nq, levels, M_, D, P):
     value, shapes, lsi, loc, aw = syn.make_msda_inputs(B, Nq, levels, M_, D, P, seed=2, spread_px=5.0)
@@ -114,7 +114,7 @@ def _fused_reference(value_q, shapes, lsi, ref_pts, proj, M_, L, P):
 
 @pytest.mark.parametrize("ref_dim", [2, 4])
 @pytest.mark.parametrize("vdt,pdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
-                                     (torch.bfloat16, torch.bfloat16)])
+                                     (torch.bfloat16, torch.bfloat16), (torch.float16, torch.bfloat16)])
 def test_fused_forward_vs_oracle(ref_dim, vdt, pdt):
     B, Nq, M_, D, P, levels = 2, 257, 8, 32, 4, LEVELS_SMALL
     L = len(levels)
@@ -147,6 +147,13 @@ def test_value_to_head_major_mask_and_stride():
     hm = M.value_to_head_major(sl, mask.to(DEV), M_, torch.bfloat16)
     expect = sl.cpu().masked_fill(mask[..., None], 0.0).view(B, Nv, M_, D).permute(0, 2, 1, 3).to(torch.bfloat16)
     assert torch.equal(hm.cpu(), expect)
+    # grouped (all encoder layers in one launch) + fp16 storage with saturation
+    big = wide.clone()
+    big[0, 0, 0] = 1e6
+    hm3 = M.value_to_head_major(big, mask.to(DEV), M_, torch.float16, num_groups=3)
+    assert hm3.shape == (3, B, M_, Nv, D) and hm3.dtype == torch.float16
+    ref3 = big.cpu().masked_fill(mask[..., None], 0.0).clamp(-65504, 65504).view(B, Nv, 3, M_, D).permute(2, 0, 3, 1, 4)
+    assert torch.equal(hm3.cpu(), ref3.to(torch.float16))
 
 
 def test_full_size_properties():
