@@ -68,6 +68,24 @@ struct ValTraits<half_t> {
     }
 };
 
+// 16-byte load through a buffer resource: the block-uniform base lives in the (SGPR) descriptor, the lane
+// supplies a 32-bit byte offset -- one v_add_u32 per corner instead of a 64-bit VALU address
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_uniform_rsrc(const char *base, uint32_t num_bytes)
+{
+    // make uniformity provable: the pointer halves go through readfirstlane (cdna_hip_programming.md T20)
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    char *p = reinterpret_cast<char *>(((uint64_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, /*stride*/ 0, (int)__builtin_amdgcn_readfirstlane(num_bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct GatherArgs {
     const char *value;
     const int64_t *shapes;
@@ -176,6 +194,7 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     const char *base = p.value + (HEAD_MAJOR ? ((int64_t)b * p.M + m) * p.Nv * (int64_t)kPixelBytesHM
                                              : (int64_t)b * p.Nv * (int64_t)pixel_bytes);
     const uint32_t lane_off = (HEAD_MAJOR ? 0u : (uint32_t)(m * D * sizeof(VT))) + (uint32_t)(j * 16);
+    const __amdgpu_buffer_rsrc_t rsrc = make_uniform_rsrc(base, (uint32_t)((int64_t)p.Nv * pixel_bytes));
 
     // ---- fused mode: softmax statistics over this row's L*P logits, spread over the G lanes ----
     // All of a lane's logits are loaded in ONE batch (clamped indices, no per-sample branch) so the set-up
@@ -307,16 +326,15 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
             // Software-pipelined gather: batches of 2 samples (8 x 16-byte loads), two register buffers; the
             // loads of batch k+1 are issued BEFORE batch k is accumulated, so the memory pipe never drains
             // while the wave does its unpack/FMA work (the loop was latency-bound with load -> wait -> math).
-            const char *lane_base = base + lane_off;
             auto issue = [&](uint4 (&v)[2][4], int t) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int tt = min(t + u, ns - 1);  // clamped: a tail slot re-reads a valid sample
                     const uint4 o = *reinterpret_cast<const uint4 *>(my_desc + tt * 8);
-                    v[u][0] = *reinterpret_cast<const uint4 *>(lane_base + o.x);
-                    v[u][1] = *reinterpret_cast<const uint4 *>(lane_base + o.y);
-                    v[u][2] = *reinterpret_cast<const uint4 *>(lane_base + o.z);
-                    v[u][3] = *reinterpret_cast<const uint4 *>(lane_base + o.w);
+                    v[u][0] = buffer_load16(rsrc, o.x + lane_off);
+                    v[u][1] = buffer_load16(rsrc, o.y + lane_off);
+                    v[u][2] = buffer_load16(rsrc, o.z + lane_off);
+                    v[u][3] = buffer_load16(rsrc, o.w + lane_off);
                 }
             };
             auto accumulate = [&](const uint4 (&v)[2][4], int t) {
