@@ -14,10 +14,11 @@ B = int(os.environ.get("B", 2))
 Nq = int(os.environ.get("NQ", 11363))
 reps = int(os.environ.get("REPS", 5))
 tok, ref, proj, shapes, lsi = syn.make_encoder_like_queries(B, Nq, LEVELS, 8, 4, seed=1, offset_px=1.5)
-hm = M.value_to_head_major(torch.randn(B, 22323, 256, device=DEV), None, 8, torch.bfloat16)
+VDT = torch.float16 if os.environ.get("VALUE", "f16") == "f16" else torch.bfloat16
+hm = M.value_to_head_major(torch.randn(B, 22323, 256, device=DEV), None, 8, VDT)
 sh, ls, rf, pj = shapes.to(DEV), lsi.to(DEV), ref.to(DEV), proj.to(torch.bfloat16).to(DEV)
 for _ in range(reps):
     M.msda_fused_forward(hm, sh, ls, rf, pj, 4, 4, out_dtype=torch.bfloat16)
-    if os.environ.get("TILED", "1") == "1":
+    if os.environ.get("TILED", "0") == "1" and VDT == torch.bfloat16:
         M.msda_tiled_forward(hm, sh, ls, rf, pj, LEVELS[0], 4, 4, out_dtype=torch.bfloat16)
 torch.cuda.synchronize()

@@ -165,6 +165,8 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *desc = smem;                                  // [GPB][DSTRIDE]
     int *lvl_tab = reinterpret_cast<int *>(smem + GPB * DSTRIDE);  // [L][3] = H, W, start
+    float *lvl_inv = reinterpret_cast<float *>(lvl_tab + kMaxLevels * 3);  // [L][2] = 1/W, 1/H
+    uint8_t *lvl_of = reinterpret_cast<uint8_t *>(lvl_inv + kMaxLevels * 2);  // [kChunk] level of a round's slot
 
     const int tid = threadIdx.x;
     const int m = blockIdx.x % p.M;
@@ -178,10 +180,13 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     int q = 0;
     if (active) q = p.order ? p.order[(int64_t)b * p.Nq + slot] : slot;
 
-    if (tid < p.L) {
-        lvl_tab[tid * 3 + 0] = (int)p.shapes[2 * tid];
-        lvl_tab[tid * 3 + 1] = (int)p.shapes[2 * tid + 1];
+    if (tid < p.L) {  // the only divisions of the kernel: once per level per block
+        const int H = (int)p.shapes[2 * tid], W = (int)p.shapes[2 * tid + 1];
+        lvl_tab[tid * 3 + 0] = H;
+        lvl_tab[tid * 3 + 1] = W;
         lvl_tab[tid * 3 + 2] = (int)p.lsi[tid];
+        lvl_inv[tid * 2 + 0] = 1.0f / (float)W;
+        lvl_inv[tid * 2 + 1] = 1.0f / (float)H;
     }
     __syncthreads();
     const float inv_P = 0.5f / (float)p.P;  // offsets / num_points * wh * 0.5 (4-d reference boxes)
@@ -242,12 +247,14 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     for (int c0 = 0; c0 < LP; c0 += kChunk) {
         const int ns = min(kChunk, LP - c0);
         if (c0 > 0) __syncthreads();  // previous chunk fully consumed
+        if (tid < kChunk) lvl_of[tid] = (uint8_t)(min(c0 + tid, LP - 1) / p.P);  // one division per slot per block
+        __syncthreads();
         {
             // raw per-sample inputs of this lane, all loads first
             float rx[TMAX], ry[TMAX], ra[TMAX], rr[TMAX][4];
             int lv[TMAX];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) lv[t] = min(c0 + j + t * G, LP - 1) / p.P;
+            for (int t = 0; t < TMAX; ++t) lv[t] = lvl_of[min(j + t * G, kChunk - 1)];
             if (FUSED) {
                 if (p.proj_bf16) {
 #pragma unroll
@@ -303,8 +310,8 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
                     if (FUSED) {
                         a = __expf(ra[t] - sm_max) * sm_inv;
                         if (p.ref_dim == 2) {  // ref + offset / (W, H): reciprocal + fma (<= 1 ulp from a true division)
-                            x = fmaf(rx[t], __frcp_rn((float)W), rr[t][0]);
-                            y = fmaf(ry[t], __frcp_rn((float)H), rr[t][1]);
+                            x = fmaf(rx[t], lvl_inv[l * 2], rr[t][0]);
+                            y = fmaf(ry[t], lvl_inv[l * 2 + 1], rr[t][1]);
                         } else {
                             x = fmaf(rx[t] * inv_P, rr[t][2], rr[t][0]);
                             y = fmaf(ry[t] * inv_P, rr[t][3], rr[t][1]);
@@ -379,6 +386,164 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Salience-DETR shape -- head-major 16-bit value, D = 32 (4 lanes per row), L = 4, P = 4, fused
+// projections -- with everything that shape makes constant folded in: lane j of a row's quad owns level j
+// (its four points are contiguous in the projection row: ONE 16-byte load of offsets, one 8-byte load of
+// logits, one reference point), softmax across the quad by two shuffles, no clamps, no integer division,
+// no per-slot level table.  Same descriptors / gather loop as the general kernel.
+template <typename VT>
+__global__ void __launch_bounds__(kBlock) msda_gather_l4p4_kernel(GatherArgs p)
+{
+    using T = ValTraits<VT>;
+    constexpr int D = 32, G = 4, GPB = kBlock / G, LP = 16, P = 4, L = 4;
+    constexpr int DSTRIDE = LP * 8 + 4;
+    constexpr uint32_t kPixBytes = D * sizeof(VT);
+    static_assert(sizeof(VT) == 2, "16-bit value maps");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *desc = smem;
+
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x % p.M;
+    const int chunk_global = blockIdx.x / p.M;
+    const int b = chunk_global / p.nchunk;
+    const int chunk = chunk_global - b * p.nchunk;
+    const int g = tid >> 2, j = tid & 3;
+    const int slot = chunk * GPB + g;
+    const bool active = slot < p.Nq;
+    const int q = active ? (p.order ? p.order[(int64_t)b * p.Nq + slot] : slot) : 0;
+
+    // this lane's level (uniform across quads): scalar loads, no LDS table
+    const int H = (int)p.shapes[2 * j], W = (int)p.shapes[2 * j + 1], start = (int)p.lsi[j];
+    const float invW = 1.0f / (float)W, invH = 1.0f / (float)H;
+
+    const int64_t bq = (int64_t)b * p.Nq + q;
+    const int64_t row = bq * p.M + m;
+    const char *base = p.value + ((int64_t)b * p.M + m) * p.Nv * (int64_t)kPixBytes;
+    const __amdgpu_buffer_rsrc_t rsrc = make_uniform_rsrc(base, (uint32_t)((int64_t)p.Nv * kPixBytes));
+    const uint32_t lane_off = (uint32_t)(j * 16);
+
+    // ---- raw inputs: offsets of my 4 points (x,y), their logits, my level's reference point ----
+    float ox[4], oy[4], lg[4];
+    {
+        const int64_t o_idx = bq * p.proj_stride + (m * LP + j * P) * 2;
+        const int64_t l_idx = bq * p.proj_stride + p.M * LP * 2 + m * LP + j * P;
+        if (p.proj_bf16) {
+            const bf16_t *pp = reinterpret_cast<const bf16_t *>(p.proj);
+            const uint4 o = *reinterpret_cast<const uint4 *>(pp + o_idx);
+            const uint2 gg = *reinterpret_cast<const uint2 *>(pp + l_idx);
+            ox[0] = bf16_lo(o.x); oy[0] = bf16_hi(o.x); ox[1] = bf16_lo(o.y); oy[1] = bf16_hi(o.y);
+            ox[2] = bf16_lo(o.z); oy[2] = bf16_hi(o.z); ox[3] = bf16_lo(o.w); oy[3] = bf16_hi(o.w);
+            lg[0] = bf16_lo(gg.x); lg[1] = bf16_hi(gg.x); lg[2] = bf16_lo(gg.y); lg[3] = bf16_hi(gg.y);
+        } else {
+            const float *pp = reinterpret_cast<const float *>(p.proj);
+            const float4 o0 = *reinterpret_cast<const float4 *>(pp + o_idx);
+            const float4 o1 = *reinterpret_cast<const float4 *>(pp + o_idx + 4);
+            const float4 gg = *reinterpret_cast<const float4 *>(pp + l_idx);
+            ox[0] = o0.x; oy[0] = o0.y; ox[1] = o0.z; oy[1] = o0.w;
+            ox[2] = o1.x; oy[2] = o1.y; ox[3] = o1.z; oy[3] = o1.w;
+            lg[0] = gg.x; lg[1] = gg.y; lg[2] = gg.z; lg[3] = gg.w;
+        }
+    }
+    float rx, ry, rw = 0.f, rh = 0.f;
+    if (p.ref_dim == 4) {
+        const float4 r = *reinterpret_cast<const float4 *>(p.ref + (bq * L + j) * 4);
+        rx = r.x; ry = r.y; rw = r.z; rh = r.w;
+    } else {
+        const float2 r = *reinterpret_cast<const float2 *>(p.ref + (bq * L + j) * 2);
+        rx = r.x; ry = r.y;
+    }
+    // softmax over the quad's 16 logits
+    float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 4));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 4));
+    float e[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) e[t] = __expf(lg[t] - mx);
+    float sum = (e[0] + e[1]) + (e[2] + e[3]);
+    sum += __shfl_xor(sum, 1, 4);
+    sum += __shfl_xor(sum, 2, 4);
+    const float inv = active ? __builtin_amdgcn_rcpf(sum) : 0.f;  // inactive rows: all weights zero
+
+    uint32_t *my_desc = desc + g * DSTRIDE;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float x, y;
+        if (p.ref_dim == 2) {
+            x = fmaf(ox[t], invW, rx);
+            y = fmaf(oy[t], invH, ry);
+        } else {
+            x = fmaf(ox[t] * 0.125f, rw, rx);  // offset / num_points * w * 0.5, num_points = 4
+            y = fmaf(oy[t] * 0.125f, rh, ry);
+        }
+        uint32_t d[8];
+        make_descriptor(x, y, e[t] * inv, H, W, start, kPixBytes, d);
+        *reinterpret_cast<uint4 *>(my_desc + (j * 4 + t) * 8) = make_uint4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4 *>(my_desc + (j * 4 + t) * 8 + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+    }
+    // the four lanes of a quad are in one wavefront: LDS writes above are visible to the reads below once the
+    // wave's own LDS queue drains -- no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    auto issue = [&](uint4 (&v)[2][4], int t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(my_desc + (t + u) * 8);
+            v[u][0] = buffer_load16(rsrc, o.x + lane_off);
+            v[u][1] = buffer_load16(rsrc, o.y + lane_off);
+            v[u][2] = buffer_load16(rsrc, o.z + lane_off);
+            v[u][3] = buffer_load16(rsrc, o.w + lane_off);
+        }
+    };
+    auto accumulate = [&](const uint4 (&v)[2][4], int t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(my_desc + (t + u) * 8 + 4);
+            T::fma4(acc, v[u][0], __uint_as_float(w.x));
+            T::fma4(acc, v[u][1], __uint_as_float(w.y));
+            T::fma4(acc, v[u][2], __uint_as_float(w.z));
+            T::fma4(acc, v[u][3], __uint_as_float(w.w));
+        }
+    };
+    uint4 va[2][4], vb[2][4];
+    issue(va, 0);
+#pragma unroll
+    for (int t = 0; t < LP; t += 4) {
+        issue(vb, t + 2);
+        accumulate(va, t);
+        if (t + 4 < LP) issue(va, t + 4);
+        accumulate(vb, t + 2);
+    }
+    if (active) {
+        const int64_t o = row * D + j * 8;
+        if (p.out_bf16) {
+            *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + o) =
+                make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                           pack_bf16x2(acc[6], acc[7]));
+        } else {
+            float *out = reinterpret_cast<float *>(p.out) + o;
+            *reinterpret_cast<float4 *>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4 *>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
+template <typename VT>
+static int launch_gather_l4p4(hipStream_t stream, GatherArgs &a)
+{
+    constexpr int GPB = kBlock / 4;
+    a.nchunk = (a.Nq + GPB - 1) / GPB;
+    const int64_t blocks = (int64_t)a.B * a.nchunk * a.M;
+    if (blocks > 0x7fffffffLL) return fail("msda: grid too large");
+    const size_t lds = (size_t)GPB * (16 * 8 + 4) * 4;
+    hipLaunchKernelGGL((msda_gather_l4p4_kernel<VT>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    return check_launch("msda_gather_l4p4");
+}
+
 // Generic fallback: any head dim, fp32/fp64, reference layout.  One thread per (b,q,m,c).
 template <typename S>
 __global__ void __launch_bounds__(kBlock) msda_generic_kernel(int64_t n, const S *value, const int64_t *shapes,
@@ -428,7 +593,7 @@ static int launch_gather(hipStream_t stream, GatherArgs &a)
     const int64_t blocks = (int64_t)a.B * a.nchunk * a.M;
     if (blocks == 0) return 0;
     if (blocks > 0x7fffffffLL) return fail("msda: grid too large");
-    const size_t lds = (size_t)(GPB * (kChunk * 8 + 4) + kMaxLevels * 3) * 4;
+    const size_t lds = (size_t)(GPB * (kChunk * 8 + 4) + kMaxLevels * 5) * 4 + kChunk;
     hipLaunchKernelGGL((msda_gather_kernel<VT, D, HM, FUSED>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
     return check_launch("msda_gather");
 }
@@ -537,6 +702,10 @@ extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value
     a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;
     a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
+    const bool l4p4 = D == 32 && L == 4 && P == 4 && (proj_row_stride % 8) == 0 &&
+                      (reinterpret_cast<uintptr_t>(proj) % 16) == 0 && (reinterpret_cast<uintptr_t>(ref) % 16) == 0;
+    if (l4p4 && value_dtype == SDETR_BF16) return launch_gather_l4p4<bf16_t>(stream, a);
+    if (l4p4 && value_dtype == SDETR_F16) return launch_gather_l4p4<half_t>(stream, a);
     if (value_dtype == SDETR_F32) return dispatch_d<float, true, true>(stream, a, D);
     if (value_dtype == SDETR_BF16) return dispatch_d<bf16_t, true, true>(stream, a, D);
     if (value_dtype == SDETR_F16) return dispatch_d<half_t, true, true>(stream, a, D);
