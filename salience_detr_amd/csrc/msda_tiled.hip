@@ -23,22 +23,11 @@
 // Supported shape: D = 32 bf16 head-major value, L = 4, P = 4 (every Salience-DETR config); anything
 // else is routed to the direct kernel by the host wrapper.
 #include "common.h"
+#include "tiled_geometry.h"
 
 namespace sdetr {
 
-constexpr int kTX = 16, kTY = 8, kHalo = 4;  // level-0 region and window padding (pixels of each level)
-constexpr int kTL = 4, kTP = 4, kTD = 32;    // levels, points, head dim
 constexpr int kPixBytes = kTD * 2;           // bf16
-
-__host__ __device__ constexpr int tile_w_cap(int l) { return (kTX >> l) + 2 * kHalo + 2; }
-__host__ __device__ constexpr int tile_h_cap(int l) { return ((kTY >> l) > 0 ? (kTY >> l) : 1) + 2 * kHalo + 2; }
-__host__ __device__ constexpr int tile_base_px(int l)
-{
-    int s = 0;
-    for (int i = 0; i < l; ++i) s += tile_w_cap(i) * tile_h_cap(i);
-    return s;
-}
-constexpr int kTilePx = tile_base_px(kTL);
 constexpr int kTileBytes = kTilePx * kPixBytes;          // 65 280
 constexpr int kDescW = 4 * 8 * 16 * 16;                  // [wave][sample][row] float4
 constexpr int kDescO = 4 * 8 * 16 * 4;                   // [wave][sample][row] u32
@@ -52,19 +41,38 @@ static_assert(kTiledLds / 16 < 65536, "16-bit LDS offsets");
 // queries (the zero-offset sample pixel on level l) -- everything the gather workgroup needs to place
 // its windows arrives with ONE scalar load instead of a dependent ord -> ref -> reduce chain.
 struct BucketArgs {
-    const float *ref;  // [B,Nq,L,ref_dim]
+    // position source: pos[q*q_stride + h*head_stride + l*lvl_stride + {0,1}], averaged over n_heads heads.
+    // reference points [B,Nq,L,ref_dim]: q_stride = L*ref_dim, lvl_stride = ref_dim, n_heads = 1;
+    // sampling locations [B,Nq,M,L,P,2] (backward op, no reference points at hand): q_stride = M*L*P*2,
+    // head_stride = L*P*2, lvl_stride = P*2, n_heads = M -- the mean of point 0 over the heads is the
+    // reference point up to the (direction-symmetric) learned offsets.
+    const float *ref;
+    int64_t q_stride;
+    int head_stride, lvl_stride, n_heads;
     const int64_t *shapes;
-    int ref_dim, B, Nq, L, H0, W0, RX, RY;
+    int B, Nq, L, H0, W0, RX, RY;
     int32_t *order;         // [B,Nq]
     int32_t *region_start;  // [B,RX*RY+1]
     int32_t *region_box;    // [B,RX*RY,kTL,4]
 };
 
+__device__ __forceinline__ float2 bucket_pos(const BucketArgs &p, int b, int q, int l)
+{
+    const float *r = p.ref + ((int64_t)b * p.Nq + q) * p.q_stride + l * p.lvl_stride;
+    float x = 0.f, y = 0.f;
+    for (int h = 0; h < p.n_heads; ++h) {
+        x += r[h * p.head_stride];
+        y += r[h * p.head_stride + 1];
+    }
+    const float inv = 1.f / (float)p.n_heads;
+    return make_float2(x * inv, y * inv);
+}
+
 __device__ __forceinline__ int region_of(const BucketArgs &p, int b, int q)
 {
-    const float *r = p.ref + ((int64_t)b * p.Nq + q) * p.L * p.ref_dim;
-    int rx = (int)floorf(r[0] * (float)p.W0) / kTX;
-    int ry = (int)floorf(r[1] * (float)p.H0) / kTY;
+    const float2 r = bucket_pos(p, b, q, 0);
+    int rx = (int)floorf(r.x * (float)p.W0) / kTX;
+    int ry = (int)floorf(r.y * (float)p.H0) / kTY;
     rx = rx < 0 ? 0 : (rx >= p.RX ? p.RX - 1 : rx);
     ry = ry < 0 ? 0 : (ry >= p.RY ? p.RY - 1 : ry);
     return ry * p.RX + rx;
@@ -112,11 +120,11 @@ __global__ void __launch_bounds__(1024) region_bucket_kernel(BucketArgs p)
         const int rid = region_of(p, b, q);
         const int pos = atomicAdd(&cnt[rid], 1);
         p.order[(int64_t)b * p.Nq + pos] = q;
-        const float *r = p.ref + ((int64_t)b * p.Nq + q) * p.L * p.ref_dim;
 #pragma unroll
         for (int l = 0; l < kTL; ++l) {
-            const int ix = (int)floorf(r[l * p.ref_dim] * (float)p.shapes[2 * l + 1] - 0.5f);
-            const int iy = (int)floorf(r[l * p.ref_dim + 1] * (float)p.shapes[2 * l] - 0.5f);
+            const float2 r = bucket_pos(p, b, q, l);
+            const int ix = (int)floorf(r.x * (float)p.shapes[2 * l + 1] - 0.5f);
+            const int iy = (int)floorf(r.y * (float)p.shapes[2 * l] - 0.5f);
             int *bx = box + (rid * kTL + l) * 4;
             atomicMin(&bx[0], ix);
             atomicMin(&bx[1], iy);
@@ -507,7 +515,8 @@ extern "C" int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_point
     if (!ref_points || !shapes || !order || !region_start || !region_box) return fail("region_bucket: null pointer");
     if (L != kTL) return fail("region_bucket: %d levels (the staged kernel handles exactly %d)", L, kTL);
     BucketArgs a{};
-    a.ref = ref_points; a.shapes = shapes; a.ref_dim = ref_dim; a.B = B; a.Nq = Nq; a.L = L; a.H0 = level0_h; a.W0 = level0_w;
+    a.ref = ref_points; a.shapes = shapes; a.q_stride = (int64_t)L * ref_dim; a.head_stride = 0; a.lvl_stride = ref_dim;
+    a.n_heads = 1; a.B = B; a.Nq = Nq; a.L = L; a.H0 = level0_h; a.W0 = level0_w;
     a.RX = (level0_w + kTX - 1) / kTX;
     a.RY = (level0_h + kTY - 1) / kTY;
     a.order = order; a.region_start = region_start; a.region_box = region_box;
@@ -517,6 +526,25 @@ extern "C" int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_point
     hipLaunchKernelGGL(region_bucket_kernel, dim3((unsigned)B), dim3(1024), (size_t)(R + 16 + R * kTL * 4) * 4, stream, a);
     return check_launch("region_bucket");
 }
+
+namespace sdetr {
+// bucketing from sampling locations [B,Nq,M,L,P,2] (used by the LDS-accumulating backward)
+int launch_region_bucket_from_loc(hipStream_t stream, const float *loc, const int64_t *shapes, int B, int Nq, int M, int L,
+                                  int P, int level0_h, int level0_w, int32_t *order, int32_t *region_start,
+                                  int32_t *region_box)
+{
+    BucketArgs a{};
+    a.ref = loc; a.shapes = shapes; a.q_stride = (int64_t)M * L * P * 2; a.head_stride = L * P * 2; a.lvl_stride = P * 2;
+    a.n_heads = M; a.B = B; a.Nq = Nq; a.L = L; a.H0 = level0_h; a.W0 = level0_w;
+    a.RX = (level0_w + kTX - 1) / kTX;
+    a.RY = (level0_h + kTY - 1) / kTY;
+    a.order = order; a.region_start = region_start; a.region_box = region_box;
+    const int R = a.RX * a.RY;
+    if (R > 2048) return fail("region_bucket: %d regions exceed the LDS histogram", R);
+    hipLaunchKernelGGL(region_bucket_kernel, dim3((unsigned)B), dim3(1024), (size_t)(R + 16 + R * kTL * 4) * 4, stream, a);
+    return check_launch("region_bucket");
+}
+}  // namespace sdetr
 
 extern "C" int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm, const int64_t *shapes,
                                         const int64_t *lsi, const float *ref, int ref_dim, const void *proj,
