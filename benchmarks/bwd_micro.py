@@ -8,7 +8,7 @@ LEVELS = [(100, 168), (50, 84), (25, 42), (13, 21)]
 for Nq in (11363, 4545, 2272):
     value, shapes, lsi, loc, aw = syn.make_msda_inputs(2, Nq, LEVELS, 8, 32, 4, seed=0, spread_px=3.0)
     args = [t.cuda() for t in (value, shapes, lsi, loc, aw)] + [torch.randn(2, Nq, 256, device="cuda")]
-    for name, kw in (("atomic", {}), ("lds", {"level0_hw": LEVELS[0]})):
+    for name, kw in (("atomic", {}),):
         for _ in range(2):
             M.ms_deform_attn_backward(*args, 64, **kw)
         torch.cuda.synchronize()

@@ -82,19 +82,6 @@ int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const d
                           int num_levels, int num_query, int num_point, double *grad_value,
                           double *grad_sampling_loc, double *grad_attn_weight);
 
-/* LDS-accumulating variant of sdetr_msda_col2im_f32 (same operands and results): queries are bucketed by the
- * level-0 region of their sampling position, each (image, head, region) workgroup accumulates grad_value in an
- * fp32 LDS window and flushes it with coalesced atomics.  head_dim 32, 4 levels, 4 points; level0_h/w are the
- * finest level's size (host ints); workspace >= sdetr_msda_col2im_tiled_workspace_bytes(...). */
-size_t sdetr_msda_col2im_tiled_workspace_bytes(int batch_size, int num_query, int level0_h, int level0_w);
-int sdetr_msda_col2im_tiled_f32(sdetr_stream_t stream, const float *grad_col, const float *data_value,
-                                const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
-                                const float *data_sampling_loc, const float *data_attn_weight, int batch_size,
-                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                                int num_point, int level0_h, int level0_w, float *grad_value,
-                                float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
-                                size_t workspace_bytes);
-
 /* ---------------------------------------------------------------------------------------------
  * (3) Native MI355X path behind MultiScaleDeformableAttention.forward
  *     (models/bricks/ms_deform_attn.py:286-377).

@@ -3,13 +3,19 @@
 // (models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:76-148: grad_value += w_i*g*aw,
 // grad_aw = g*val, grad_loc = (W*gw, H*gh)*g*aw, summed over the D channels of the head).
 //
-// Structure (not the reference's 32-thread blocks with serial thread-0 reductions,
-// :290-392): a group of G = D/4 adjacent lanes of a 64-lane wavefront owns one (b,q,m) row,
-// each lane 4 channels; sample set-up is done once per sample by one lane and broadcast
-// through LDS; the three per-sample channel sums are reduced across the G lanes with
-// wavefront shuffles (no LDS, no barrier); grad_value goes out as hardware fp32 atomics
-// (global_atomic_add_f32).  Summation order of those atomics is not deterministic, exactly
-// as in the reference.
+// Structure (not the reference's 32-thread blocks with serial thread-0 reductions, :290-392): sample set-up
+// is done once per sample by one lane and broadcast through LDS; the three per-sample channel sums are
+// reduced with wavefront shuffles (no barrier); grad_value goes out as hardware fp32 atomics
+// (global_atomic_add_f32).  Summation order of those atomics is not deterministic, exactly as in the reference.
+//
+// Two lane mappings:
+//  * msda_col2im_chan_kernel (D = 32 / 64, the shapes that matter): ONE CHANNEL PER LANE, D adjacent lanes own a
+//    (b,q,m) row, so every atomic wave-instruction covers whole 128-byte lines (2 rows x 32 channels).  Measured
+//    on MI355X the L2 retires atomics per line-sized request, not per element: 64 consecutive floats per
+//    instruction sustain ~680 G adds/s, the 8-lanes-x-4-channels mapping below (8 partial lines per instruction)
+//    only ~88 G adds/s -- 4.4 ms vs ~0.6 ms for encoder layer 0 at batch 2.  (Accumulating in LDS instead was
+//    tried and dropped: ds_add_f32 is far slower still, 2.6 ms for the same work.)
+//  * msda_col2im_kernel: G = D/4 lanes per row, 4 channels per lane -- kept for the remaining head dims.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
@@ -154,6 +160,104 @@ __global__ void __launch_bounds__(kBlock) msda_col2im_kernel(BackwardArgs p)
     }
 }
 
+
+// ---- one channel per lane ------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(kBlock) msda_col2im_chan_kernel(BackwardArgs p)
+{
+    static_assert(D == 32 || D == 64, "lane-per-channel mapping");
+    constexpr int RPB = kBlock / D;          // rows per block
+    constexpr int DSTRIDE = kBChunk * 8 + 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *desc = smem;
+    int *lvl_tab = reinterpret_cast<int *>(smem + RPB * DSTRIDE);
+
+    const int tid = threadIdx.x;
+    const int m = blockIdx.x % p.M;
+    const int chunk_global = blockIdx.x / p.M;
+    const int b = chunk_global / p.nchunk;
+    const int chunk = chunk_global - b * p.nchunk;
+    const int g = tid / D, c = tid - g * D;   // row in block, channel
+    const int q = chunk * RPB + g;
+    const bool active = q < p.Nq;
+
+    if (tid < p.L) {
+        lvl_tab[tid * 3 + 0] = (int)p.shapes[2 * tid];
+        lvl_tab[tid * 3 + 1] = (int)p.shapes[2 * tid + 1];
+        lvl_tab[tid * 3 + 2] = (int)p.lsi[tid];
+    }
+    __syncthreads();
+
+    const int LP = p.L * p.P;
+    const int64_t row = ((int64_t)b * p.Nq + (active ? q : 0)) * p.M + m;
+    const int64_t pix_stride = (int64_t)p.M * D;  // floats between pixels (reference layout)
+    const float *vbase = reinterpret_cast<const float *>(p.value) + (int64_t)b * p.Nv * pix_stride + m * D + c;
+    float *gbase = reinterpret_cast<float *>(p.grad_value) + (int64_t)b * p.Nv * pix_stride + m * D + c;
+    const float go = active ? p.grad_out[row * D + c] : 0.f;
+
+    uint32_t *my_desc = desc + g * DSTRIDE;
+    for (int c0 = 0; c0 < LP; c0 += kBChunk) {
+        const int ns = min(kBChunk, LP - c0);
+        if (c0 > 0) __syncthreads();
+        if (active && c < ns) {  // lane c of the row prepares sample c0 + c
+            const int s = c0 + c;
+            const int l = s / p.P;
+            const int H = lvl_tab[l * 3], W = lvl_tab[l * 3 + 1], start = lvl_tab[l * 3 + 2];
+            const float2 xy = reinterpret_cast<const float2 *>(p.loc)[row * LP + s];
+            const float a = p.aw[row * LP + s];
+            const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+            const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+            const float fy = floorf(h_im), fx = floorf(w_im);
+            const int y0 = inside ? (int)fy : 0, x0 = inside ? (int)fx : 0;
+            const uint32_t flags = !inside ? 0u
+                : ((uint32_t)(y0 >= 0 && x0 >= 0) | ((uint32_t)(y0 >= 0 && x0 + 1 <= W - 1) << 1) |
+                   ((uint32_t)(y0 + 1 <= H - 1 && x0 >= 0) << 2) | ((uint32_t)(y0 + 1 <= H - 1 && x0 + 1 <= W - 1) << 3));
+            *reinterpret_cast<uint4 *>(my_desc + c * 8) =
+                make_uint4((uint32_t)(start + y0 * W + x0), (uint32_t)W, flags | ((uint32_t)l << 8), 0u);
+            *reinterpret_cast<uint4 *>(my_desc + c * 8 + 4) =
+                make_uint4(__float_as_uint(h_im - fy), __float_as_uint(w_im - fx), __float_as_uint(a), 0u);
+        }
+        __syncthreads();
+        if (active) {
+            for (int t = 0; t < ns; ++t) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(my_desc + t * 8);
+                const uint4 e = *reinterpret_cast<const uint4 *>(my_desc + t * 8 + 4);
+                const int pix = (int)o.x, W = (int)o.y;
+                const uint32_t flags = o.z;
+                const float ly = __uint_as_float(e.x), lx = __uint_as_float(e.y), a = __uint_as_float(e.z);
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float v00 = (flags & 1u) ? vbase[(int64_t)pix * pix_stride] : 0.f;
+                const float v01 = (flags & 2u) ? vbase[(int64_t)(pix + 1) * pix_stride] : 0.f;
+                const float v10 = (flags & 4u) ? vbase[(int64_t)(pix + W) * pix_stride] : 0.f;
+                const float v11 = (flags & 8u) ? vbase[(int64_t)(pix + W + 1) * pix_stride] : 0.f;
+                const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+                const float ga = go * a;
+                // whole 128-byte lines per instruction: lanes c = 0..D-1 hit consecutive floats
+                if (flags & 1u) unsafeAtomicAdd(gbase + (int64_t)pix * pix_stride, w00 * ga);
+                if (flags & 2u) unsafeAtomicAdd(gbase + (int64_t)(pix + 1) * pix_stride, w01 * ga);
+                if (flags & 4u) unsafeAtomicAdd(gbase + (int64_t)(pix + W) * pix_stride, w10 * ga);
+                if (flags & 8u) unsafeAtomicAdd(gbase + (int64_t)(pix + W + 1) * pix_stride, w11 * ga);
+                float s_aw = go * (w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11);
+                float s_x = go * (hy * (v01 - v00) + ly * (v11 - v10));
+                float s_y = go * (hx * (v10 - v00) + lx * (v11 - v01));
+#pragma unroll
+                for (int sh = D / 2; sh > 0; sh >>= 1) {
+                    s_aw += __shfl_xor(s_aw, sh, D);
+                    s_x += __shfl_xor(s_x, sh, D);
+                    s_y += __shfl_xor(s_y, sh, D);
+                }
+                if (c == (t & (D - 1))) {
+                    const int l = (int)(flags >> 8);
+                    const int64_t si = row * LP + c0 + t;
+                    p.grad_aw[si] = s_aw;
+                    reinterpret_cast<float2 *>(p.grad_loc)[si] =
+                        make_float2((float)W * s_x * a, (float)lvl_tab[l * 3] * s_y * a);
+                }
+            }
+        }
+    }
+}
+
 // Generic fallback (any head dim, fp32/fp64, reference layout): one thread per (b,q,m) row.
 template <typename S>
 __global__ void __launch_bounds__(kBlock) msda_col2im_generic_kernel(int64_t rows, const S *grad_out, const S *value,
@@ -219,9 +323,24 @@ static int launch_bwd(hipStream_t stream, BackwardArgs &a)
     return check_launch("msda_col2im");
 }
 
+template <int D>
+static int launch_bwd_chan(hipStream_t stream, BackwardArgs &a)
+{
+    constexpr int RPB = kBlock / D;
+    a.nchunk = (a.Nq + RPB - 1) / RPB;
+    const int64_t blocks = (int64_t)a.B * a.nchunk * a.M;
+    if (blocks == 0) return 0;
+    if (blocks > 0x7fffffffLL) return fail("msda backward: grid too large");
+    const size_t lds = (size_t)(RPB * (kBChunk * 8 + 4) + kMaxLevels * 3) * 4;
+    hipLaunchKernelGGL((msda_col2im_chan_kernel<D>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    return check_launch("msda_col2im_chan");
+}
+
 template <bool HM>
 static int dispatch_bwd(hipStream_t stream, BackwardArgs &a, int D)
 {
+    if (!HM && D == 32) return launch_bwd_chan<32>(stream, a);
+    if (!HM && D == 64) return launch_bwd_chan<64>(stream, a);
     switch (D) {
         case 4: return launch_bwd<4, HM>(stream, a);
         case 8: return launch_bwd<8, HM>(stream, a);

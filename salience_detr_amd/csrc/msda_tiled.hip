@@ -527,25 +527,6 @@ extern "C" int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_point
     return check_launch("region_bucket");
 }
 
-namespace sdetr {
-// bucketing from sampling locations [B,Nq,M,L,P,2] (used by the LDS-accumulating backward)
-int launch_region_bucket_from_loc(hipStream_t stream, const float *loc, const int64_t *shapes, int B, int Nq, int M, int L,
-                                  int P, int level0_h, int level0_w, int32_t *order, int32_t *region_start,
-                                  int32_t *region_box)
-{
-    BucketArgs a{};
-    a.ref = loc; a.shapes = shapes; a.q_stride = (int64_t)M * L * P * 2; a.head_stride = L * P * 2; a.lvl_stride = P * 2;
-    a.n_heads = M; a.B = B; a.Nq = Nq; a.L = L; a.H0 = level0_h; a.W0 = level0_w;
-    a.RX = (level0_w + kTX - 1) / kTX;
-    a.RY = (level0_h + kTY - 1) / kTY;
-    a.order = order; a.region_start = region_start; a.region_box = region_box;
-    const int R = a.RX * a.RY;
-    if (R > 2048) return fail("region_bucket: %d regions exceed the LDS histogram", R);
-    hipLaunchKernelGGL(region_bucket_kernel, dim3((unsigned)B), dim3(1024), (size_t)(R + 16 + R * kTL * 4) * 4, stream, a);
-    return check_launch("region_bucket");
-}
-}  // namespace sdetr
-
 extern "C" int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm, const int64_t *shapes,
                                         const int64_t *lsi, const float *ref, int ref_dim, const void *proj,
                                         int proj_dtype, int64_t proj_row_stride, const int32_t *order,

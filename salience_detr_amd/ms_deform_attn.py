@@ -78,19 +78,10 @@ def ms_deform_attn_forward(value: Tensor, spatial_shapes: Tensor, level_start_in
     return out
 
 
-# below this many queries per image the per-region LDS windows cost more than the atomics they save
-TILED_BACKWARD_MIN_QUERIES = 1500
-
-
 def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
-                            sampling_loc: Tensor, attn_weight: Tensor, grad_output: Tensor, im2col_step: int,
-                            level0_hw=None):
+                            sampling_loc: Tensor, attn_weight: Tensor, grad_output: Tensor, im2col_step: int):
     """``_C.ms_deform_attn_backward`` (ms_deform_attn_cuda.cu:75-145).
-    Returns ``[grad_value, grad_sampling_loc, grad_attn_weight]``.
-
-    ``level0_hw`` (optional, python ints (H_0, W_0) of the finest level -- a host-side fact the reference's
-    signature does not carry) enables the LDS-accumulating scatter for dense query sets; without it the plain
-    atomic kernel runs.  Results are the same up to fp32 summation order (atomics in both)."""
+    Returns ``[grad_value, grad_sampling_loc, grad_attn_weight]``."""
     B, Nv, M, D, L, Nq, P = _op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                                      im2col_step, "ms_deform_attn_backward")
     _hip.require_device("ms_deform_attn_backward", grad_output=grad_output)
@@ -99,24 +90,11 @@ def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_i
     grad_value = torch.zeros_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_aw = torch.empty_like(attn_weight)
-    lib = _hip.lib()
+    fn = _hip.lib().sdetr_msda_col2im_f32 if value.dtype == torch.float32 else _hip.lib().sdetr_msda_col2im_f64
     with torch.cuda.device(value.device):
-        if (level0_hw is not None and value.dtype == torch.float32 and D == 32 and L == 4 and P == 4
-                and Nq >= TILED_BACKWARD_MIN_QUERIES):
-            # dense query sets (the encoder): LDS-accumulating scatter instead of one global atomic per element
-            H0, W0 = int(level0_hw[0]), int(level0_hw[1])
-            ws_bytes = lib.sdetr_msda_col2im_tiled_workspace_bytes(B, Nq, H0, W0)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
-            code = lib.sdetr_msda_col2im_tiled_f32(
-                _hip.stream_ptr(), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-                B, Nv, M, D, L, Nq, P, H0, W0, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr(),
-                ws.data_ptr(), ws_bytes)
-        else:
-            fn = lib.sdetr_msda_col2im_f32 if value.dtype == torch.float32 else lib.sdetr_msda_col2im_f64
-            code = fn(_hip.stream_ptr(), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                      level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-                      B, Nv, M, D, L, Nq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr())
+        code = fn(_hip.stream_ptr(), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+                  level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                  B, Nv, M, D, L, Nq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr())
     _hip.check(code, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_aw]
 
@@ -124,15 +102,10 @@ def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_i
 class MultiScaleDeformableAttnFunction(Function):
     """Autograd wrapper with the reference's argument order (ms_deform_attn.py:35-84)."""
 
-    # (H_0, W_0) of the finest level as python ints, set by callers that know the pyramid geometry on the host
-    # (the encoder); lets backward pick the LDS-accumulating kernel without a device->host sync
-    level0_hw_hint = None
-
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
-        ctx.level0_hw = MultiScaleDeformableAttnFunction.level0_hw_hint
         output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                         sampling_locations, attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -144,7 +117,7 @@ class MultiScaleDeformableAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, aw = ctx.saved_tensors
         grad_value, grad_loc, grad_aw = ms_deform_attn_backward(
-            value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step, level0_hw=ctx.level0_hw)
+            value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_aw, None
 
 

@@ -26,7 +26,7 @@ from torch.nn import functional as F
 
 from . import pyramid
 from .filter_ops import class_max_times, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_
-from .ms_deform_attn import MultiScaleDeformableAttention, MultiScaleDeformableAttnFunction, value_to_head_major
+from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
 
@@ -153,7 +153,6 @@ class SalienceTransformerEncoderLayer(nn.Module):
             src2 = self.self_attn.forward_native(self.with_pos_embed(query, query_pos), reference_points, value_hm,
                                                  spatial_shapes, level_start_index, level0_hw=level0_hw)
         else:
-            MultiScaleDeformableAttnFunction.level0_hw_hint = level0_hw
             src2 = self.self_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
                                   value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                   key_padding_mask=query_key_padding_mask)

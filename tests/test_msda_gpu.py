@@ -266,30 +266,3 @@ def test_tiled_with_clustered_queries_and_empty_regions():
     tiled = M.msda_tiled_forward(hm, shapes.to(DEV), lsi.to(DEV), ref.to(DEV), proj.to(DEV), levels[0], L, P,
                                  out_dtype=torch.float32)
     assert np.abs(tiled.cpu().numpy() - expect).max() < 2e-4
-
-
-@pytest.mark.parametrize("levels,B,Nq,spread", [(LEVELS_SMALL, 2, 700, 3.0), (LEVELS_SMALL, 1, 300, 12.0),
-                                                 (LEVELS_FULL, 2, 4545, 4.0)])
-def test_lds_accumulating_backward_matches_atomic_backward(levels, B, Nq, spread):
-    """Same operands through the plain atomic kernel and the per-region LDS-accumulating kernel (incl. samples
-    outside the windows -> global fallback); small case also against the C oracle."""
-    M_, D, P = 8, 32, 4
-    value, shapes, lsi, loc, aw = syn.make_msda_inputs(B, Nq, levels, M_, D, P, seed=6, spread_px=spread)
-    go = syn.det_randn("bt.go", (B, Nq, M_ * D))
-    args = [t.to(DEV) for t in (value, shapes, lsi, loc, aw, go)]
-    old = M.TILED_BACKWARD_MIN_QUERIES
-    M.TILED_BACKWARD_MIN_QUERIES = 1
-    try:
-        gv_t, gl_t, ga_t = M.ms_deform_attn_backward(*args, 64, level0_hw=levels[0])
-    finally:
-        M.TILED_BACKWARD_MIN_QUERIES = old
-    gv_a, gl_a, ga_a = M.ms_deform_attn_backward(*args, 64)
-    scale = max(1.0, gv_a.abs().max().item())
-    assert (gv_t - gv_a).abs().max().item() < 2e-4 * scale
-    assert torch.equal(gl_t, gl_a) or (gl_t - gl_a).abs().max().item() < 1e-3 * max(1.0, gl_a.abs().max().item())
-    assert (ga_t - ga_a).abs().max().item() < 1e-4 * max(1.0, ga_a.abs().max().item())
-    if B * Nq <= 1500:
-        rgv, _, rga = msda_c.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(),
-                                           go.numpy())
-        assert np.abs(gv_t.cpu().numpy() - rgv).max() < 2e-4 * max(1.0, np.abs(rgv).max())
-        assert np.abs(ga_t.cpu().numpy() - rga).max() < 2e-4 * max(1.0, np.abs(rga).max())
