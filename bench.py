@@ -244,7 +244,7 @@ def main():
     images_per_s = world * args.batch * args.steps / elapsed
 
     # ---- instrumented eager pass: events around every fused-MSDA launch and every layer boundary ----
-    msda_events, layer_events, launches = [], [], []
+    msda_events, layer_events, launches, launch_nq = [], [], [], []
     real_fused = msda_mod.msda_fused_forward
 
     def timed_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
@@ -262,6 +262,7 @@ def main():
         e1.record()
         msda_events.append((e0, e1))
         B, M, Nv, D = value_hm.shape
+        launch_nq.append(int(proj.shape[1]))
         launches.append(algorithmic_bytes(B, Nv, proj.shape[1], M, D, num_levels, num_points,
                                           value_hm.element_size(), proj.element_size(), o.element_size(),
                                           reference_points.shape[-1]))
@@ -296,7 +297,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_traffic.json")))
-        nqs = [int(round((b_ / args.batch - 22323 * 256 * 2) / (384 * 2 + 32 + 512))) for b_ in bytes_per_layer]
+        nqs = launch_nq[:nl]
         if (args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same") and args.batch == tj["batch"]
                 and all(str(n) in tj["per_num_query"] for n in nqs)):
             traffic = int(sum(tj["per_num_query"][str(n)]["hbm_bytes"] for n in nqs) / nl)
@@ -308,7 +309,7 @@ def main():
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(total_bytes / nl),
-        "launches_per_step": nl, "avg_launch_us": round(total_us / nl, 2),
+        "launches_per_step": nl, "num_queries_per_layer": launch_nq[:nl], "avg_launch_us": round(total_us / nl, 2),
         "per_layer_us": [round(u, 2) for u in msda_us],
         "per_layer_algorithmic_MB": [round(b / 1e6, 2) for b in bytes_per_layer],
     }
