@@ -1,4 +1,4 @@
-"""MSDA backward timings: atomic kernel vs LDS-accumulating kernel (kernel time via rocprofv3 or events)."""
+"""MSDA backward (col2im) timings at the encoder's query counts (stream events; includes the grad_value zero-fill)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -209,6 +209,42 @@ int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void *residual, 
 int sdetr_column_mean_f32(sdetr_stream_t stream, const float *x, int64_t batch_stride, int64_t row_stride,
                           int batch_size, int rows, int channels, float *out);
 
+/* ---- (6) the salience head, fused -----------------------------------------------------------------------------
+ * MaskPredictor (models/bricks/salience_transformer.py:16-47) for embed_dim = hidden_dim = 256, optionally with
+ * enc_output + enc_output_norm (models/bricks/base_transformer.py:110-111) in front, fp32 throughout (f32-input
+ * MFMA).  All tensors fp32, contiguous unless strides are given.
+ *
+ *   sdetr_pack_linear_f32: packed[S][n][h][j] = weight[n][8S+4h+j] -- the operand order the stage kernels stream
+ *     an nn.Linear weight ([out_features, in_features], row stride in elements) in; do it once per weight.
+ *   sdetr_salience_head_blocks: number of token blocks stage 1 uses for a level (= rows of partial_sums).
+ *   sdetr_salience_head_stage1: z = GELU(layer1.1(layer1.0(m + m * up * alpha))) with
+ *       m  = enc_output_norm(enc_output(x))   when enc_weight_packed != NULL (memory_out, if given, receives m:
+ *            [batch, tokens, 256] with the given batch stride), else m = x;
+ *       up = row_scale[b, t] if given, else the bilinear align_corners=True resize of coarse_score
+ *            [batch, coarse_h, coarse_w] to level_h x level_w (:139-142), else no modulation;  alpha: device scalar.
+ *     Writes z[..., :128] to z_local [batch, tokens, 128] and the per-block column sums of z[..., 128:] to
+ *     partial_sums [batch, blocks, 128] (the token mean of :43-45 is finished by stage 2).
+ *   sdetr_salience_head_stage2: score = layer2(cat(z_local, mean(z_global))) -> score [batch, tokens] (and, if
+ *     score_flat != NULL, also score_flat[b * score_flat_stride + t]).  weight2 is layer2.0.weight [128, 256]
+ *     (unpacked, its [:, 128:] half multiplies the mean), weight2_local_packed = pack(weight2[:, :128]),
+ *     weight3_packed = pack(layer2.2.weight [64,128]), weight4 = layer2.4.weight [1,64];
+ *     const_workspace: [batch, 128] floats of scratch. */
+int sdetr_pack_linear_f32(sdetr_stream_t stream, const float *weight, int64_t row_stride, int out_features,
+                          int in_features, float *packed);
+int sdetr_salience_head_blocks(int batch_size, int tokens);
+int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride,
+                               int batch_size, int tokens, int channels, const float *enc_weight_packed,
+                               const float *enc_bias, const float *enc_norm_weight, const float *enc_norm_bias,
+                               float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+                               int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight,
+                               const float *norm_bias, float norm_eps, const float *weight_packed, const float *bias,
+                               float *memory_out, int64_t memory_batch_stride, float *z_local, float *partial_sums);
+int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums, int batch_size,
+                               int tokens, const float *weight2, const float *bias2,
+                               const float *weight2_local_packed, const float *weight3_packed, const float *bias3,
+                               const float *weight4, const float *bias4, float *const_workspace, float *score,
+                               float *score_flat, int64_t score_flat_stride);
+
 #ifdef __cplusplus
 }
 #endif

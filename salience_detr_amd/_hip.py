@@ -43,6 +43,11 @@ SIGNATURES = {
     "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _p]),
     "sdetr_layernorm": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i, ctypes.c_float, _i, _i, _i, _p, _i]),
     "sdetr_column_mean_f32": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
+    "sdetr_pack_linear_f32": (_i, [_p, _p, _i64, _i, _i, _p]),
+    "sdetr_salience_head_blocks": (_i, [_i, _i]),
+    "sdetr_salience_head_stage1": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
+                                        _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p]),
+    "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
 }

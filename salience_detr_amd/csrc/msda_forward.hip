@@ -68,24 +68,6 @@ struct ValTraits<half_t> {
     }
 };
 
-// 16-byte load through a buffer resource: the block-uniform base lives in the (SGPR) descriptor, the lane
-// supplies a 32-bit byte offset -- one v_add_u32 per corner instead of a 64-bit VALU address
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_uniform_rsrc(const char *base, uint32_t num_bytes)
-{
-    // make uniformity provable: the pointer halves go through readfirstlane (cdna_hip_programming.md T20)
-    const uint64_t a = reinterpret_cast<uint64_t>(base);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    char *p = reinterpret_cast<char *>(((uint64_t)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(p, /*stride*/ 0, (int)__builtin_amdgcn_readfirstlane(num_bytes), 0x00020000);
-}
-__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
-{
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
 struct GatherArgs {
     const char *value;
     const int64_t *shapes;

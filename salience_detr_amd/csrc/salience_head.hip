@@ -1,0 +1,591 @@
+// The salience head (MaskPredictor, models/bricks/salience_transformer.py:16-47) and the projection in front of
+// it (enc_output + enc_output_norm, models/bricks/base_transformer.py:110-111) as three launches per level
+// instead of ~20 library/elementwise launches:
+//
+//   stage 1  x -> [enc_output GEMM -> +bias -> enc_output_norm] -> x + x*up*alpha (:143, `up` = bilinear
+//            align_corners resize of the coarser level's score, :139-142) -> layer1 LayerNorm -> layer1 GEMM ->
+//            GELU;  the "local" half (columns 0..127) is stored, the "global" half (128..255) only contributes
+//            its per-block column sums (the token mean of :43-45)
+//   const    per-image constant of layer2[0]:  W2[:,128:] @ mean_global + b2
+//   stage 2  GELU(z_local @ W2[:, :128]^T + const) -> GELU(. @ W3^T + b3) -> . w4 + b4  = the token's score
+//
+// Everything is fp32 -- the scores decide WHICH tokens are kept, and the selection is pinned index-for-index to
+// the fp32 reference -- so the GEMMs run on the f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains,
+// 157 TFLOP/s dense peak on MI355X, the same as the vector rate but without per-lane operand broadcasts).  The
+// path is bound by that peak: 2*(2*256*256 + 128*128 + 128*64) flops per token.
+//
+// Tiling: one 256-thread block owns 32 (or 64) tokens, kept in LDS as [32][256+4] fp32 (the +4 makes the 16-byte
+// A reads and the row-wise LayerNorm passes bank-conflict free); wave w owns output columns [64w, 64w+64) as 1x2
+// (2x2) MFMA tiles.  The contraction index is visited in the order k = 8S + 4h + j (h = lane>>5, j = 0..3) so that a lane
+// fetches its four A values with one ds_read_b128 and its four B values with one 16-byte global load from the
+// pre-packed weight P[S][n][h][j] = W[n][8S+4h+j] (sdetr_pack_linear_f32) -- consecutive lanes read consecutive
+// 16-byte pieces.  Four blocks fit a CU (39 KB LDS each).  Deterministic: no atomics, fixed summation order.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace sdetr {
+
+constexpr int kC = 256;        // embed dim == hidden dim of the head
+constexpr int kHalf = 128;
+constexpr int kTM = 64;        // tokens per block
+constexpr int kXS = kC + 4;    // LDS row stride of the token tile (floats)
+constexpr int kZS = kHalf + 4;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 c)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// ---- the weight operand -----------------------------------------------------------------------------------
+// It comes straight from L2 (every block streams the same 256 KB), so its loads run PD steps (PD * CT KB per wave)
+// ahead of the MFMAs that consume them: one step of 4*RT*CT MFMAs is only ~0.1-0.4 us, an L2 hit ~0.5 us and the
+// first touch after other kernels flushed the L2 ~2 us.  Buffer loads (uniform base and step offset in SGPRs, one
+// lane offset) keep the 16-byte loads whole and cost no address VALU.  The first PD steps are requested by
+// start() -- callers do that BEFORE the barrier / LayerNorm phase in front of the GEMM, so the pipeline is already
+// full when the MFMAs begin.
+template <int CT, int PD>
+struct WeightStream {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t lane_off, step;
+    u32x4_t bq[PD][CT];
+
+    __device__ __forceinline__ void start(const float4 *wp, int N, int ksteps, int n0, int lane)
+    {
+        step = (uint32_t)N * 32;   // bytes per k-step of the packed weight
+        rs = make_uniform_rsrc(reinterpret_cast<const char *>(wp), step * (uint32_t)ksteps);
+        lane_off = (uint32_t)((n0 + (lane & 31)) * 2 + (lane >> 5)) * 16;
+#pragma unroll
+        for (int u = 0; u < PD; ++u)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                bq[u][ct] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + ct * 1024), (int)(u * step), 0);
+    }
+};
+
+// acc[rt][ct] += tile[32rt + i][k] * W[n0 + 32ct + j][k]   (tile in LDS with row stride XS; W through `ws`)
+template <int KDIM, int XS, int RT, int CT, int PD>
+__device__ __forceinline__ void block_gemm(const float *tile, WeightStream<CT, PD> &ws, int lane, f32x16 (&acc)[RT][CT])
+{
+    constexpr int NS = KDIM / 8;
+    static_assert(NS % PD == 0, "prefetch depth must divide the step count");
+    const float *ap = tile + (lane & 31) * XS + 4 * (lane >> 5);
+    // fully unrolled: a rolled loop carries the in-flight registers across the back edge through copies, and
+    // every copy waits for its load (the pipeline would drain once per PD steps)
+#pragma unroll
+    for (int S0 = 0; S0 < NS; S0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int S = S0 + u;
+            u32x4_t b[CT];
+            float4 a[RT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) b[ct] = ws.bq[u][ct];
+            if (S + PD < NS) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    ws.bq[u][ct] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + ct * 1024),
+                                                                         (int)((S + PD) * ws.step), 0);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const float4 *>(ap + rt * 32 * XS + 8 * S);
+            // pin this step's prefetch in front of its MFMAs (the scheduler otherwise sinks the loads next to
+            // their uses, which serialises every step on L2 latency)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float4 bf = make_float4(__uint_as_float(b[ct].x), __uint_as_float(b[ct].y),
+                                                  __uint_as_float(b[ct].z), __uint_as_float(b[ct].w));
+                    acc[rt][ct] = mfma4(a[rt], bf, acc[rt][ct]);
+                }
+        }
+    }
+}
+
+template <int RT, int CT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT][CT])
+{
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+}
+
+// row of accumulator register `reg` inside a 32x32 tile
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+struct Stage1Args {
+    const float *x;            // [B, n, 256] with strides
+    int64_t x_batch_stride, x_row_stride;
+    const float4 *w_enc;       // packed enc_output weight or NULL (x is already enc_output_norm's output)
+    const float *b_enc, *g_enc, *beta_enc;
+    float eps_enc;
+    const float *row_scale;    // [B, n] or NULL
+    const float *coarse;       // [B, ch, cw] coarser score map or NULL
+    int ch, cw, h, w;
+    const float *alpha;        // device scalar (NULL = 1)
+    const float *g1, *beta1;
+    float eps1;
+    const float4 *w1;          // packed layer1 Linear weight
+    const float *b1;
+    float *memory_out;         // enc_output_norm output [B, n, 256] (batch stride given) or NULL
+    int64_t mem_batch_stride;
+    float *z_local;            // [B, n, 128]
+    float *partial;            // [B, nblk, 128]
+    int n, nblk;
+};
+
+// two-pass LayerNorm statistics of a row held as NV float4 per thread by the TPR threads of the row
+template <int NV, int TPR>
+__device__ __forceinline__ void row_stats(const float4 (&v)[NV], float eps, float &mean, float &rstd)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, TPR);
+    mean = s * (1.f / kC);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o, TPR);
+    rstd = rsqrtf(q * (1.f / kC) + eps);
+}
+
+__device__ __forceinline__ float4 ln_apply(float4 v, float mean, float rstd, float4 g, float4 be)
+{
+    return make_float4((v.x - mean) * rstd * g.x + be.x, (v.y - mean) * rstd * g.y + be.y,
+                       (v.z - mean) * rstd * g.z + be.z, (v.w - mean) * rstd * g.w + be.w);
+}
+
+// LDS parameter rows
+enum { kParBEnc = 0, kParGEnc, kParBetaEnc, kParG1, kParBeta1, kParB1, kParRows };
+
+// RT = row tiles of 32 tokens per block: 2 halves the weight traffic per token, 1 doubles the blocks (more CUs
+// busy on the small levels, finer load balance on the big one; four blocks fit a CU).
+// Blocks that share a CU start together and stay in lock step (same work), so nothing hides the phases between
+// the two GEMMs except what the block overlaps itself: every global read of those phases (LayerNorm parameters,
+// biases, the coarse score for the resize, alpha) is issued up front into LDS together with the token tile, and
+// each GEMM's first weight steps are requested before the barrier / LayerNorm phase in front of it.
+template <int RT>
+__global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_kernel(Stage1Args p)
+{
+    constexpr int TM = 32 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tile = smem;                           // [TM][kXS]
+    float *par = smem + TM * kXS;                 // [kParRows][kC]
+    float *srow = par + kParRows * kC;            // [TM] modulation factor up * alpha (0 when absent)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int t0 = blk * TM;
+    const int nvalid = min(TM, p.n - t0);
+    const int n0 = wave * 64;
+    const bool with_enc = p.w_enc != nullptr;
+
+    WeightStream<2, 4> ws;
+    ws.start(with_enc ? p.w_enc : p.w1, kC, kC / 8, n0, lane);
+
+    // ---- token tile, parameters and row factors -> LDS ----
+    {
+        const float *xb = p.x + (int64_t)b * p.x_batch_stride + (int64_t)t0 * p.x_row_stride;
+        float4 v[TM / 4];
+#pragma unroll
+        for (int i = 0; i < TM / 4; ++i) {   // unconditional (clamped) loads: all in flight at once
+            const int idx = tid + i * kBlock;
+            const int r = idx >> 6, c4 = idx & 63;
+            v[i] = *reinterpret_cast<const float4 *>(xb + (int64_t)min(r, nvalid - 1) * p.x_row_stride + c4 * 4);
+        }
+        {
+            const int row = tid >> 6, c4 = tid & 63;   // 4 parameter rows per pass
+            const float *src0 = row == 0 ? p.b_enc : row == 1 ? p.g_enc : row == 2 ? p.beta_enc : p.g1;
+            const float *src1 = row == 0 ? p.beta1 : p.b1;
+            if (with_enc || row == 3) *reinterpret_cast<float4 *>(par + row * kC + c4 * 4) =
+                                          *reinterpret_cast<const float4 *>(src0 + c4 * 4);
+            if (row < 2) *reinterpret_cast<float4 *>(par + (4 + row) * kC + c4 * 4) =
+                             *reinterpret_cast<const float4 *>(src1 + c4 * 4);
+        }
+        if (tid < TM) {
+            float s = 0.f;
+            const int t = min(t0 + tid, p.n - 1);
+            if (p.row_scale) {
+                s = p.row_scale[(int64_t)b * p.n + t];
+            } else if (p.coarse) {
+                // bilinear, align_corners=True (F.interpolate, salience_transformer.py:139-142)
+                const int y = t / p.w, x = t - y * p.w;
+                const float sh = p.h > 1 ? (float)(p.ch - 1) / (float)(p.h - 1) : 0.f;
+                const float sw = p.w > 1 ? (float)(p.cw - 1) / (float)(p.w - 1) : 0.f;
+                const float fy = sh * (float)y, fx = sw * (float)x;
+                const int y1 = (int)fy, x1 = (int)fx;
+                const int yp = y1 < p.ch - 1 ? 1 : 0, xp = x1 < p.cw - 1 ? 1 : 0;
+                const float ly = fy - (float)y1, lx = fx - (float)x1;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float *cm = p.coarse + (int64_t)b * p.ch * p.cw;
+                s = hy * (hx * cm[y1 * p.cw + x1] + lx * cm[y1 * p.cw + x1 + xp]) +
+                    ly * (hx * cm[(y1 + yp) * p.cw + x1] + lx * cm[(y1 + yp) * p.cw + x1 + xp]);
+            }
+            // reference order of operations: mem + mem * up * alpha  ==  mem + (mem * up) * alpha
+            srow[tid] = s;
+            if (tid == 0) srow[TM] = (p.row_scale || p.coarse) ? (p.alpha ? *p.alpha : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM / 4; ++i) {
+            const int idx = tid + i * kBlock;
+            const int r = idx >> 6, c4 = idx & 63;
+            *reinterpret_cast<float4 *>(tile + r * kXS + c4 * 4) = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[RT][2];
+    if (with_enc) {
+        zero_acc(acc);
+        block_gemm<kC, kXS, RT, 2, 4>(tile, ws, lane, acc);
+        ws.start(p.w1, kC, kC / 8, n0, lane);   // layer1's first steps travel during the LayerNorm phase
+        __syncthreads();   // every wave is done reading the input tile
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int c = n0 + 32 * ct + (lane & 31);
+            const float bias = par[kParBEnc * kC + c];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tile[(32 * rt + acc_row(i, lane)) * kXS + c] = acc[rt][ct][i] + bias;
+        }
+        __syncthreads();
+    }
+
+    // ---- enc_output_norm -> modulation -> layer1 LayerNorm, in place; TPR threads per row, each NV float4 ----
+    {
+        constexpr int TPR = kBlock / TM, NV = kC / 4 / TPR, CS = 4 * TPR;   // column step between a thread's float4s
+        const int r = tid / TPR, q = tid % TPR;
+        float *row = tile + r * kXS + 4 * q;
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4 *>(row + CS * i);
+        float mean, rstd;
+        if (with_enc) {
+            row_stats<NV, TPR>(v, p.eps_enc, mean, rstd);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                v[i] = ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParGEnc * kC + CS * i + 4 * q),
+                                *reinterpret_cast<const float4 *>(par + kParBetaEnc * kC + CS * i + 4 * q));
+            if (p.memory_out && r < nvalid) {
+                float *mo = p.memory_out + (int64_t)b * p.mem_batch_stride + (int64_t)(t0 + r) * kC + 4 * q;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) *reinterpret_cast<float4 *>(mo + CS * i) = v[i];
+            }
+        }
+        const float s = srow[r], a = srow[TM];
+        if (a != 0.f) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                v[i] = make_float4(v[i].x + v[i].x * s * a, v[i].y + v[i].y * s * a, v[i].z + v[i].z * s * a,
+                                   v[i].w + v[i].w * s * a);
+        }
+        row_stats<NV, TPR>(v, p.eps1, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            *reinterpret_cast<float4 *>(row + CS * i) =
+                ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParG1 * kC + CS * i + 4 * q),
+                         *reinterpret_cast<const float4 *>(par + kParBeta1 * kC + CS * i + 4 * q));
+    }
+    __syncthreads();
+
+    // ---- layer1 Linear + GELU ----
+    zero_acc(acc);
+    block_gemm<kC, kXS, RT, 2, 4>(tile, ws, lane, acc);
+    if (wave < 2) {
+        float *zl = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int c = n0 + 32 * ct + (lane & 31);
+            const float bias = par[kParB1 * kC + c];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 32 * rt + acc_row(i, lane);
+                    if (r < nvalid) zl[(int64_t)r * kHalf + c] = gelu_erf(acc[rt][ct][i] + bias);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int c = n0 + 32 * ct + (lane & 31);
+            const float bias = par[kParB1 * kC + c];
+            float s = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = 32 * rt + acc_row(i, lane);
+                    s += r < nvalid ? gelu_erf(acc[rt][ct][i] + bias) : 0.f;
+                }
+            s += __shfl_xor(s, 32);
+            if (lane < 32) p.partial[((int64_t)b * p.nblk + blk) * kHalf + (c - kHalf)] = s;
+        }
+    }
+}
+
+// const[b][j] = b2[j] + sum_c W2[j][128 + c] * mean_c,  mean_c = (sum over blocks of partial) / n.
+// 8 groups of 128 threads sum interleaved blocks (fixed order), then a fixed-order tree over the groups.
+constexpr int kConstGroups = 8;
+__global__ void __launch_bounds__(kHalf * kConstGroups) salience_head_const_kernel(const float *partial, int nblk, int n,
+                                                                                   const float *w2, const float *b2,
+                                                                                   float *out)
+{
+    __shared__ float part[kConstGroups][kHalf];
+    __shared__ float mean[kHalf];
+    const int b = blockIdx.x, j = threadIdx.x & (kHalf - 1), g = threadIdx.x / kHalf;
+    const float *pp = partial + (int64_t)b * nblk * kHalf + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = g;
+    for (; i + 3 * kConstGroups < nblk; i += 4 * kConstGroups) {
+        s0 += pp[(int64_t)i * kHalf];
+        s1 += pp[(int64_t)(i + kConstGroups) * kHalf];
+        s2 += pp[(int64_t)(i + 2 * kConstGroups) * kHalf];
+        s3 += pp[(int64_t)(i + 3 * kConstGroups) * kHalf];
+    }
+    for (; i < nblk; i += kConstGroups) s0 += pp[(int64_t)i * kHalf];
+    part[g][j] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kConstGroups; ++k) t += part[k][j];
+        mean[j] = t / (float)n;
+    }
+    __syncthreads();
+    // 8 threads per output row j2 = tid / 8, each 16 of the 128 columns
+    const int j2 = threadIdx.x >> 3, q = threadIdx.x & 7;
+    const float *wr = w2 + (int64_t)j2 * kC + kHalf + q * 16;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+        const float4 wv = *reinterpret_cast<const float4 *>(wr + c);
+        a += (wv.x * mean[q * 16 + c] + wv.y * mean[q * 16 + c + 1]) +
+             (wv.z * mean[q * 16 + c + 2] + wv.w * mean[q * 16 + c + 3]);
+    }
+    a += __shfl_xor(a, 1, 8);
+    a += __shfl_xor(a, 2, 8);
+    a += __shfl_xor(a, 4, 8);
+    if (q == 0) out[(int64_t)b * kHalf + j2] = b2[j2] + a;
+}
+
+struct Stage2Args {
+    const float *z_local;   // [B, n, 128]
+    const float *cst;       // [B, 128]
+    const float4 *w2a;      // packed W2[:, :128]   (128 x 128)
+    const float4 *w3;       // packed W3            (64 x 128)
+    const float *b3, *w4, *b4;
+    float *score;           // [B, n]
+    float *score2;          // optional second destination, row stride score2_stride (flattened score buffer)
+    int64_t score2_stride;
+    int n;
+};
+
+__global__ void __launch_bounds__(kBlock, 2) salience_head_stage2_kernel(Stage2Args p)
+{
+    __shared__ __attribute__((aligned(16))) float zt[kTM * kZS];
+    __shared__ float red[2][kTM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * kTM;
+    const int nvalid = min(kTM, p.n - t0);
+    WeightStream<1, 8> ws;
+    ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
+    const float cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
+    const int rt2 = wave >> 1, ct2 = wave & 1;
+    const float bias3 = p.b3[ct2 * 32 + (lane & 31)], wo = p.w4[ct2 * 32 + (lane & 31)], b4 = p.b4[0];
+    {
+        const float *zb = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
+        float4 v[kTM * (kHalf / 4) / kBlock];
+#pragma unroll
+        for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
+            const int idx = tid + i * kBlock;
+            const int r = idx >> 5, c4 = idx & 31;
+            v[i] = *reinterpret_cast<const float4 *>(zb + (int64_t)min(r, nvalid - 1) * kHalf + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
+            const int idx = tid + i * kBlock;
+            const int r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<float4 *>(zt + r * kZS + c4 * 4) = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // layer2[0] (local half; the global half is the per-image constant) + GELU: wave w -> columns [32w, 32w+32)
+    {
+        f32x16 acc[2][1];
+        zero_acc(acc);
+        block_gemm<kHalf, kZS, 2, 1, 8>(zt, ws, lane, acc);
+        ws.start(p.w3, kHalf / 2, kHalf / 8, ct2 * 32, lane);
+        __syncthreads();
+        const int c = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zt[(32 * rt + acc_row(i, lane)) * kZS + c] = gelu_erf(acc[rt][0][i] + cb);
+    }
+    __syncthreads();
+    // layer2[2] + GELU, layer2[4]: wave -> (row tile, column tile) of the [64 x 64] hidden state
+    {
+        f32x16 acc[1][1];
+        zero_acc(acc);
+        block_gemm<kHalf, kZS, 1, 1, 8>(zt + rt2 * 32 * kZS, ws, lane, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = gelu_erf(acc[0][0][i] + bias3) * wo;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+            if ((lane & 31) == 0) red[ct2][32 * rt2 + acc_row(i, lane)] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < nvalid) {
+        const float s = (red[0][tid] + red[1][tid]) + b4;
+        p.score[(int64_t)b * p.n + t0 + tid] = s;
+        if (p.score2) p.score2[(int64_t)b * p.score2_stride + t0 + tid] = s;
+    }
+}
+
+// P[S][n][h][j] = W[n][8S + 4h + j]
+__global__ void pack_linear_kernel(const float *w, int64_t row_stride, int N, int K, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int j = (int)(i & 3), h = (int)((i >> 2) & 1);
+    const int64_t rest = i >> 3;
+    const int n = (int)(rest % N), S = (int)(rest / N);
+    out[i] = w[(int64_t)n * row_stride + 8 * S + 4 * h + j];
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int sdetr_pack_linear_f32(sdetr_stream_t stream, const float *weight, int64_t row_stride, int out_features,
+                                     int in_features, float *packed)
+{
+    if (!weight || !packed) return fail("pack_linear: NULL pointer");
+    if (out_features <= 0 || in_features <= 0 || in_features % 8 != 0)
+        return fail("pack_linear: in_features must be a positive multiple of 8 (got %d x %d)", out_features, in_features);
+    const int64_t total = (int64_t)out_features * in_features;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), weight, row_stride, out_features, in_features, packed);
+    return check_launch("pack_linear");
+}
+
+// 32-token blocks everywhere: measured on MI355X at 800x1333 (2 x 16 700 tokens on level 0) they take 110 us vs
+// 137 us for 64-token blocks -- 1044 blocks spread over 256 CUs x 4 resident blocks with a one-block tail instead
+// of 522 over 256 x 2 -- and on the small levels they are what fills the chip at all.  The 64-token variant
+// (half the weight traffic per token) stays selectable for experiments: SDETR_HEAD_ROWTILES=2.
+static int stage1_lds_bytes(int tm) { return (tm * kXS + kParRows * kC + tm + 4) * (int)sizeof(float); }
+
+static int stage1_block_tokens(int batch_size, int tokens)
+{
+    static const int forced = [] { const char *e = getenv("SDETR_HEAD_ROWTILES"); return e ? atoi(e) : 0; }();
+    (void)batch_size; (void)tokens;
+    return forced == 2 ? 64 : 32;
+}
+
+extern "C" int sdetr_salience_head_blocks(int batch_size, int tokens)
+{
+    if (tokens <= 0 || batch_size <= 0) return 0;
+    const int tm = stage1_block_tokens(batch_size, tokens);
+    return (tokens + tm - 1) / tm;
+}
+
+extern "C" int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x, int64_t x_batch_stride,
+                                          int64_t x_row_stride, int batch_size, int tokens, int channels,
+                                          const float *enc_weight_packed, const float *enc_bias,
+                                          const float *enc_norm_weight, const float *enc_norm_bias, float enc_norm_eps,
+                                          const float *row_scale, const float *coarse_score, int coarse_h, int coarse_w,
+                                          int level_h, int level_w, const float *alpha, const float *norm_weight,
+                                          const float *norm_bias, float norm_eps, const float *weight_packed,
+                                          const float *bias, float *memory_out, int64_t memory_batch_stride,
+                                          float *z_local, float *partial_sums)
+{
+    if (channels != kC) return fail("salience_head_stage1: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
+    if (batch_size < 0 || tokens < 0) return fail("salience_head_stage1: negative size");
+    if (batch_size == 0 || tokens == 0) return 0;
+    if (!x || !norm_weight || !norm_bias || !weight_packed || !bias || !z_local || !partial_sums)
+        return fail("salience_head_stage1: NULL pointer");
+    if (enc_weight_packed && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
+        return fail("salience_head_stage1: enc_output parameters incomplete");
+    if (row_scale && coarse_score) return fail("salience_head_stage1: give row_scale OR coarse_score");
+    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
+        return fail("salience_head_stage1: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
+    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("salience_head_stage1: rows must be 16-byte aligned");
+    Stage1Args a;
+    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
+    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_packed);
+    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
+    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
+    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
+    a.w1 = reinterpret_cast<const float4 *>(weight_packed); a.b1 = bias;
+    a.memory_out = enc_weight_packed ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
+    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = 0;
+
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (stage1_block_tokens(batch_size, tokens) == 64) {
+        static bool attr_set = false;   // > 64 KiB of dynamic LDS has to be requested once
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(salience_head_stage1_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, stage1_lds_bytes(64));
+            attr_set = true;
+        }
+        a.nblk = (tokens + 63) / 64;
+        hipLaunchKernelGGL(salience_head_stage1_kernel<2>, dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
+                           (size_t)stage1_lds_bytes(64), s, a);
+    } else {
+        a.nblk = (tokens + 31) / 32;
+        hipLaunchKernelGGL(salience_head_stage1_kernel<1>, dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
+                           (size_t)stage1_lds_bytes(32), s, a);
+    }
+    return check_launch("salience_head_stage1");
+}
+
+extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums,
+                                          int batch_size, int tokens, const float *weight2, const float *bias2,
+                                          const float *weight2_local_packed, const float *weight3_packed,
+                                          const float *bias3, const float *weight4, const float *bias4,
+                                          float *const_workspace, float *score, float *score_flat,
+                                          int64_t score_flat_stride)
+{
+    if (batch_size < 0 || tokens < 0) return fail("salience_head_stage2: negative size");
+    if (batch_size == 0 || tokens == 0) return 0;
+    if (!z_local || !partial_sums || !weight2 || !bias2 || !weight2_local_packed || !weight3_packed || !bias3 ||
+        !weight4 || !bias4 || !const_workspace || !score)
+        return fail("salience_head_stage2: NULL pointer");
+    const int nblk = (tokens + kTM - 1) / kTM;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(salience_head_const_kernel, dim3((unsigned)batch_size), dim3(kHalf * kConstGroups), 0, s,
+                       partial_sums, sdetr_salience_head_blocks(batch_size, tokens), tokens, weight2, bias2,
+                       const_workspace);
+    int rc = check_launch("salience_head_const");
+    if (rc) return rc;
+    Stage2Args a;
+    a.z_local = z_local; a.cst = const_workspace;
+    a.w2a = reinterpret_cast<const float4 *>(weight2_local_packed);
+    a.w3 = reinterpret_cast<const float4 *>(weight3_packed);
+    a.b3 = bias3; a.w4 = weight4; a.b4 = bias4; a.score = score; a.score2 = score_flat;
+    a.score2_stride = score_flat_stride; a.n = tokens;
+    hipLaunchKernelGGL(salience_head_stage2_kernel, dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, a);
+    return check_launch("salience_head_stage2");
+}

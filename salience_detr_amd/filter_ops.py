@@ -199,3 +199,93 @@ def column_mean(x: Tensor) -> Tensor:
                                                 out.data_ptr())
     _hip.check(code, "column_mean")
     return out
+
+
+def packed_linear_weight(weight: Tensor, cols=None) -> Tensor:
+    """``weight[:, cols[0]:cols[1]]`` ([out, in] fp32 parameter) in the operand order of the salience-head kernels
+    (``sdetr_pack_linear_f32``).  The packed copy lives on the parameter object itself and is refreshed when the
+    parameter's storage, device or version changes (optimizer step, ``load_state_dict``, ``.to()``)."""
+    w = weight.detach()
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise RuntimeError("packed_linear_weight: fp32 [out,in] HIP tensor with a contiguous last dim expected")
+    cache = weight.__dict__.setdefault("_sdetr_packed", {})
+    tag = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape))
+    hit = cache.get(cols)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    if cols is not None:
+        w = w[:, cols[0]:cols[1]]
+    out = torch.empty(w.shape[0] * w.shape[1], dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        code = _hip.lib().sdetr_pack_linear_f32(_hip.stream_ptr(), w.data_ptr(), w.stride(0), w.shape[0], w.shape[1],
+                                                out.data_ptr())
+    _hip.check(code, "pack_linear")
+    cache[cols] = (tag, out)
+    return out
+
+
+def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coarse_score: Optional[Tensor] = None,
+                  level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
+                  memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None) -> Tensor:
+    """The salience head on one level in three launches (include/salience_hip.h (6)).
+
+    ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
+    ``in_dim == h_dim == 256``.  With ``enc_output`` / ``enc_output_norm`` (``nn.Linear`` / ``nn.LayerNorm``) they
+    are applied first and ``memory_out`` (a ``[B,n,256]`` slice, optional) receives their result.  The
+    coarse-to-fine modulation takes either ``row_scale`` [B,n] or the coarser level's ``coarse_score``
+    [B,1,h',w'] (resized in-kernel to ``level_hw``), times the device scalar ``alpha``.  ``score_flat``
+    (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy.  Returns ``[B,n]``."""
+    if not x.is_cuda:
+        raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
+    if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
+        raise RuntimeError("salience_head: fp32 [B,n,C] with a contiguous last dim expected")
+    B, n, C = x.shape
+    lib = _hip.lib()
+    l1n, l1 = predictor.layer1[0], predictor.layer1[1]
+    l2a, l2b, l2c = predictor.layer2[0], predictor.layer2[2], predictor.layer2[4]
+    half = predictor.h_dim // 2
+    if row_scale is not None:
+        row_scale = row_scale.reshape(B, n)
+        if row_scale.dtype != torch.float32 or not row_scale.is_contiguous():
+            row_scale = row_scale.float().contiguous()
+    ch = cw = lh = lw = 0
+    if coarse_score is not None:
+        ch, cw = coarse_score.shape[-2:]
+        lh, lw = level_hw
+        _hip.require_device("salience_head", coarse_score=coarse_score)
+    w_enc = b_enc = g_enc = be_enc = None
+    eps_enc = 0.0
+    mbs = 0
+    if enc_output is not None:
+        w_enc = packed_linear_weight(enc_output.weight)
+        b_enc, g_enc, be_enc = enc_output.bias.detach(), enc_output_norm.weight.detach(), enc_output_norm.bias.detach()
+        eps_enc = float(enc_output_norm.eps)
+        if memory_out is not None:
+            if memory_out.shape != x.shape or memory_out.stride(2) != 1 or memory_out.stride(1) != C:
+                raise RuntimeError("salience_head: memory_out must be a [B,n,C] slice with contiguous rows")
+            mbs = memory_out.stride(0)
+    nblk = lib.sdetr_salience_head_blocks(B, n)
+    z_local = torch.empty((B, n, half), dtype=torch.float32, device=x.device)
+    partial = torch.empty((B, max(nblk, 1), half), dtype=torch.float32, device=x.device)
+    cst = torch.empty((B, half), dtype=torch.float32, device=x.device)
+    score = torch.empty((B, n), dtype=torch.float32, device=x.device)
+    sfs = 0
+    if score_flat is not None:
+        if score_flat.shape != score.shape or score_flat.stride(1) != 1 or score_flat.dtype != torch.float32:
+            raise RuntimeError("salience_head: score_flat must be a fp32 [B,n] slice with a contiguous last dim")
+        sfs = score_flat.stride(0)
+    with torch.cuda.device(x.device):
+        s = _hip.stream_ptr()
+        code = lib.sdetr_salience_head_stage1(
+            s, x.data_ptr(), x.stride(0), x.stride(1), B, n, C, _hip.ptr(w_enc), _hip.ptr(b_enc), _hip.ptr(g_enc),
+            _hip.ptr(be_enc), eps_enc, _hip.ptr(row_scale), _hip.ptr(coarse_score), ch, cw, lh, lw, _hip.ptr(alpha),
+            l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps), packed_linear_weight(l1.weight).data_ptr(),
+            l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
+        _hip.check(code, "salience_head_stage1")
+        code = lib.sdetr_salience_head_stage2(
+            s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
+            packed_linear_weight(l2a.weight, cols=(0, half)).data_ptr(), packed_linear_weight(l2b.weight).data_ptr(),
+            l2b.bias.data_ptr(), l2c.weight.data_ptr(), l2c.bias.data_ptr(), cst.data_ptr(), score.data_ptr(),
+            _hip.ptr(score_flat), sfs)
+        _hip.check(code, "salience_head_stage2")
+    return score

@@ -112,7 +112,14 @@ class SalienceEncoderHotPath(nn.Module):
         for h, w in level_shapes[:-1]:
             starts.append(starts[-1] + h * w)
 
-        if enc_in is not None:
+        # the no-grad path keeps enc_output + enc_output_norm inside the salience-head kernel
+        fuse_enc = (enc_in is not None and self.enc_mask_predictor.fused_kernels_apply(enc_in)
+                    and self.enc_output.weight.dtype == torch.float32)
+        backbone_output_memory = None
+        if fuse_enc:
+            if return_aux:
+                backbone_output_memory = torch.empty_like(enc_in)
+        elif enc_in is not None:
             from .filter_ops import fused_layer_norm
             backbone_output_memory = fused_layer_norm(self.enc_output(enc_in), self.enc_output_norm)
         else:
@@ -135,11 +142,19 @@ class SalienceEncoderHotPath(nn.Module):
             level_token_nums = level_dev.tolist()  # the stage's single host sync
             focus_token_nums = focus_token_nums.to(torch.int64)
 
-        salience_score, level_inds, level_score = level_filtering(
-            backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
-            self.alpha)
+        score_flat = None
+        if fuse_enc:
+            score_flat = torch.empty(mask_flatten.shape, dtype=torch.float32, device=mask_flatten.device)
+            salience_score, level_inds, level_score = level_filtering(
+                enc_in, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor, self.alpha,
+                enc_output=self.enc_output, enc_output_norm=self.enc_output_norm, memory_out=backbone_output_memory,
+                score_flat=score_flat)
+        else:
+            salience_score, level_inds, level_score = level_filtering(
+                backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
+                self.alpha)
         foreground_inds, foreground_score = salience_filtering(salience_score, level_inds, level_score, mask_flatten,
-                                                               layer_ratio)
+                                                               layer_ratio, score_flat=score_flat)
         if feat_enc is None:
             feat_enc, pos_enc = feat_flatten.to(edt), lvl_pos_embed_flatten.to(edt)
         memory = self.encoder(

@@ -20,7 +20,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import column_mean, fused_layer_norm, masked_topk_desc
+from .filter_ops import column_mean, fused_layer_norm, masked_topk_desc, salience_head
 
 
 class MaskPredictor(nn.Module):
@@ -38,6 +38,12 @@ class MaskPredictor(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.constant_(m.bias, 0)
 
+    def fused_kernels_apply(self, x: Tensor) -> bool:
+        """The three-launch MFMA path (csrc/salience_head.hip) is built for the released configuration:
+        in_dim == h_dim == 256, fp32."""
+        return (self.h_dim == 256 and x.shape[-1] == 256 and x.dtype == torch.float32
+                and self.layer1[1].weight.dtype == torch.float32 and x.dim() == 3 and x.stride(2) == 1)
+
     def forward(self, x: Tensor, row_scale: Optional[Tensor] = None, alpha: Optional[Tensor] = None) -> Tensor:
         """``x`` [B,N,C].  With ``row_scale`` [B,N] (+ ``alpha``, one element) the input is first modulated as
         ``x + x * row_scale * alpha`` (the coarse-to-fine update of salience_transformer.py:143)."""
@@ -50,7 +56,9 @@ class MaskPredictor(nn.Module):
             # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
             z = torch.cat([z[..., :half], z[..., half:].mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
             return self.layer2(z)
-        # native path: modulation + LayerNorm in one launch; the global half enters layer2[0] as a per-image
+        if self.fused_kernels_apply(x):
+            return salience_head(x, self, row_scale=row_scale, alpha=alpha).unsqueeze(-1)
+        # other widths: modulation + LayerNorm in one launch; the global half enters layer2[0] as a per-image
         # constant  W[:, half:] @ mean + b  (no [B,N,h] concat, half the GEMM), its token mean from a
         # deterministic column-mean kernel
         B, N, _ = x.shape
@@ -77,13 +85,19 @@ def token_budgets(multi_level_masks: Sequence[Tensor], level_filter_ratio: Tenso
 
 def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_shapes: Sequence[Tuple[int, int]],
                     level_start_index: Sequence[int], level_token_nums: Sequence[int], mask_predictor: nn.Module,
-                    alpha: Tensor):
+                    alpha: Tensor, enc_output: Optional[nn.Module] = None, enc_output_norm: Optional[nn.Module] = None,
+                    memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None):
     """Coarse-to-fine salience scores + per-level top-k (salience_transformer.py:123-154).
 
     ``level_shapes`` / ``level_start_index`` / ``level_token_nums`` are python ints (shapes come from the
     tensors' own sizes; budgets from ``token_budgets``/``host_token_budgets``).
     Returns ``(salience_score: list[L] of [B,1,H_l,W_l], level_inds: list[L] of [B,k_l] int64 (global token
     index), level_score: list[L] of [B,k_l])`` ordered low level -> high level.
+
+    With ``enc_output`` / ``enc_output_norm`` the first argument is the INPUT of ``enc_output`` (the masked
+    ``feat + pos`` tokens of base_transformer.py:107-109) and the projection + norm run inside the salience-head
+    kernel (no-grad MI355X path only); ``memory_out`` [B,S,C] then optionally receives ``backbone_output_memory``
+    and ``score_flat`` [B,S] the flattened scores.
     """
     B = backbone_output_memory.shape[0]
     L = len(level_shapes)
@@ -91,11 +105,30 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     level_inds: List[Optional[Tensor]] = [None] * L
     level_score: List[Optional[Tensor]] = [None] * L
     score = None
+    fused = (isinstance(mask_predictor, MaskPredictor) and backbone_output_memory.is_cuda
+             and mask_predictor.fused_kernels_apply(backbone_output_memory)
+             and not (torch.is_grad_enabled() and (backbone_output_memory.requires_grad or alpha.requires_grad or
+                                                   any(p.requires_grad for p in mask_predictor.parameters()))))
+    if enc_output is not None and not fused:
+        raise RuntimeError("level_filtering: enc_output fusion needs the no-grad fp32 256-wide MaskPredictor path")
     for lvl in range(L - 1, -1, -1):
         h, w = level_shapes[lvl]
         start = int(level_start_index[lvl])
         level_memory = backbone_output_memory[:, start:start + h * w, :]
         mask = mask_flatten[:, start:start + h * w].contiguous()
+        if fused:
+            # resize of the coarser score, modulation, both LayerNorms, all five Linear layers: three launches
+            token_score = salience_head(
+                level_memory, mask_predictor, coarse_score=score, level_hw=(h, w),
+                alpha=alpha[lvl:lvl + 1] if score is not None else None, enc_output=enc_output,
+                enc_output_norm=enc_output_norm,
+                memory_out=None if memory_out is None else memory_out[:, start:start + h * w, :],
+                score_flat=None if score_flat is None else score_flat[:, start:start + h * w])
+            score = token_score.view(B, 1, h, w)
+            ls, li = masked_topk_desc(token_score, int(level_token_nums[lvl]), mask=mask, fill_with_global_min=True,
+                                      index_offset=start)
+            salience_score[lvl], level_inds[lvl], level_score[lvl] = score, li, ls
+            continue
         if lvl != L - 1:
             up = F.interpolate(score, size=(h, w), mode="bilinear", align_corners=True)
             token_score = mask_predictor(level_memory, row_scale=up.reshape(B, h * w), alpha=alpha[lvl:lvl + 1])
@@ -113,11 +146,12 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
 
 
 def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Tensor], level_score: Sequence[Tensor],
-                       mask_flatten: Tensor, layer_filter_ratio: Sequence[float]):
+                       mask_flatten: Tensor, layer_filter_ratio: Sequence[float], score_flat: Optional[Tensor] = None):
     """Global sort, per-layer prefixes and foreground score (salience_transformer.py:156-168).
 
     Returns ``(foreground_inds: list[num_layers] of [B,Nq_k] int64, foreground_score [B,S])`` -- exactly the
     ``foreground_inds`` / ``foreground_score`` keyword arguments of ``SalienceTransformerEncoder.forward``.
+    ``score_flat`` [B,S]: the already flattened ``salience_score`` (saves the concatenation).
     """
     selected_score = torch.cat(list(level_score), 1)
     selected_inds = torch.cat(list(level_inds), 1)
@@ -125,6 +159,6 @@ def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Te
     _, sorted_inds = masked_topk_desc(selected_score, n, payload=selected_inds, want_scores=False)
     counts = pyramid.layer_token_counts(n, layer_filter_ratio)
     foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c].contiguous() for c in counts]
-    fg = pyramid.flatten_multi_level(salience_score).squeeze(-1)
+    fg = score_flat if score_flat is not None else pyramid.flatten_multi_level(salience_score).squeeze(-1)
     fg = torch.where(mask_flatten, fg.min(), fg)
     return foreground_inds, fg

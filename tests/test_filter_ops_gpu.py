@@ -162,3 +162,82 @@ def test_column_mean_strided():
     assert (got.cpu() - z[..., 128:].cpu().double().mean(1, keepdim=True).float()).abs().max() < 1e-6
     again = F.column_mean(z[..., 128:])
     assert torch.equal(got, again)  # deterministic
+
+
+def _head_reference(pred, x, up=None, alpha=None, enc=None, enc_norm=None):
+    """fp32 torch restatement of salience_transformer.py:36-47 (+ :143, + base_transformer.py:110-111), on CPU in
+    float64-free plain fp32 so that it is the same arithmetic the oracle uses."""
+    mem = enc_norm(enc(x)) if enc is not None else x
+    y = mem if up is None else mem + mem * up.unsqueeze(-1) * alpha
+    return pred(y).squeeze(-1), mem
+
+
+@pytest.mark.parametrize("n,hw", [(1, (1, 1)), (63, (7, 9)), (64, (8, 8)), (77, (7, 11)), (1050, (25, 42)),
+                                  (4200, (50, 84))])
+@pytest.mark.parametrize("mode", ["plain", "row_scale", "coarse", "enc+coarse"])
+def test_salience_head_matches_fp32_reference(n, hw, mode):
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    torch.manual_seed(n)
+    B, C = 2, 256
+    pred = MaskPredictor(C, C)
+    for p in pred.parameters():          # non-trivial biases / norm parameters
+        if p.dim() == 1:
+            p.data = syn.det_randn(f"hp{p.numel()}", tuple(p.shape)) * 0.3 + (1.0 if p.numel() == C else 0.0)
+    enc, enc_norm = torch.nn.Linear(C, C), torch.nn.LayerNorm(C)
+    enc_norm.weight.data = 1 + 0.2 * syn.det_randn("eg", (C,))
+    enc_norm.bias.data = 0.2 * syn.det_randn("eb", (C,))
+    # the level sits inside a longer [B,S,C] buffer, as in the hot path
+    full = syn.det_randn(f"hx{n}", (B, n + 13, C)) * 1.5
+    x = full[:, 5:5 + n]
+    alpha = torch.tensor([0.27])
+    ch, cw = max(1, (hw[0] + 1) // 2), max(1, (hw[1] + 1) // 2)
+    coarse = syn.det_randn(f"hc{n}", (B, 1, ch, cw))
+    up = None
+    if mode == "row_scale":
+        up = syn.det_randn(f"hu{n}", (B, n))
+    elif "coarse" in mode:
+        up = torch.nn.functional.interpolate(coarse, size=hw, mode="bilinear", align_corners=True).reshape(B, n)
+    with torch.no_grad():
+        ref, ref_mem = _head_reference(pred, x, up, alpha if up is not None else None,
+                                       enc if mode.startswith("enc") else None, enc_norm)
+    pd, ed, nd = pred.to(DEV), enc.to(DEV), enc_norm.to(DEV)
+    xd = full.to(DEV)[:, 5:5 + n]
+    flat = torch.full((B, n + 3), -7.0, device=DEV)
+    mem_out = torch.zeros(B, n + 2, C, device=DEV)
+    kw = {}
+    if mode == "row_scale":
+        kw = dict(row_scale=up.to(DEV), alpha=alpha.to(DEV))
+    elif "coarse" in mode:
+        kw = dict(coarse_score=coarse.to(DEV), level_hw=hw, alpha=alpha.to(DEV))
+    if mode.startswith("enc"):
+        kw.update(enc_output=ed, enc_output_norm=nd, memory_out=mem_out[:, 1:1 + n])
+    with torch.no_grad():
+        got = F.salience_head(xd, pd, score_flat=flat[:, 2:2 + n], **kw)
+        if mode == "row_scale":   # the module's own forward takes the same kernels
+            via_module = pd(xd, row_scale=up.to(DEV), alpha=alpha.to(DEV)).squeeze(-1)
+            assert torch.equal(via_module, got)
+    scale = ref.abs().max().item() + 1.0
+    assert (got.cpu() - ref).abs().max().item() <= 2e-5 * scale
+    assert torch.equal(flat[:, 2:2 + n], got) and (flat[:, :2] == -7).all() and (flat[:, 2 + n:] == -7).all()
+    if mode.startswith("enc"):
+        assert (mem_out[:, 1:1 + n].cpu() - ref_mem).abs().max().item() <= 2e-5 * (ref_mem.abs().max().item() + 1)
+        assert (mem_out[:, 0] == 0).all() and (mem_out[:, 1 + n:] == 0).all()
+
+
+def test_salience_head_is_deterministic_and_rejects_bad_input():
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    pred = MaskPredictor(256, 256).to(DEV)
+    x = syn.det_randn("hdet", (2, 16700, 256)).to(DEV)
+    with torch.no_grad():
+        a, b = F.salience_head(x, pred), F.salience_head(x, pred)
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        F.salience_head(x.cpu(), pred)
+    with pytest.raises(RuntimeError):
+        F.salience_head(x[..., :128].contiguous(), pred)
+    small = MaskPredictor(64, 64).to(DEV)          # other widths run the generic native path
+    xs = syn.det_randn("hsm", (2, 50, 64)).to(DEV)
+    with torch.no_grad():
+        ref = small.cpu()(xs.cpu())
+        got = small.to(DEV)(xs)
+    assert (got.cpu() - ref).abs().max().item() <= 1e-4
