@@ -94,7 +94,8 @@ int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const d
  *
  * sdetr_msda_fused_forward: softmax over the L*P logits, sampling-location arithmetic
  *   (ms_deform_attn.py:322-355, 2-d or 4-d reference points) and the gather-reduce, in one launch.
- *   value_hm  [B,M,Nv,D] (value_dtype)        ref_points [B,Nq,L,ref_dim] f32, ref_dim in {2,4}
+ *   value_hm  [B,M,Nv,D] (value_dtype)        ref_points [B,Nq,L,ref_dim] f32, ref_dim in {2,4}; images are
+ *             ref_batch_stride floats apart (0 = contiguous), so a row prefix of a longer buffer can be passed
  *   proj      [B,Nq,row_stride] (proj_dtype): row = [ M*L*P*2 offsets | M*L*P logits | ... ]
  *             i.e. the concatenated output of sampling_offsets and attention_weights Linear.
  *   order     [B,Nq] int32 processing order (slot i handles query order[b][i]) or NULL
@@ -108,7 +109,8 @@ int sdetr_value_to_head_major(sdetr_stream_t stream, const void *src, int src_dt
 int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
                              const int64_t *data_spatial_shapes,
                              const int64_t *data_level_start_index, const float *ref_points,
-                             int ref_dim, const void *proj, int proj_dtype, int64_t proj_row_stride,
+                             int ref_dim, int64_t ref_batch_stride, const void *proj, int proj_dtype,
+                             int64_t proj_row_stride,
                              const int32_t *order, int batch_size, int spatial_size, int num_heads,
                              int channels, int num_levels, int num_query, int num_point, void *out,
                              int out_dtype);
@@ -174,6 +176,33 @@ int sdetr_gather_rows(sdetr_stream_t stream, const void *src, const int64_t *idx
 int sdetr_scatter_rows(sdetr_stream_t stream, void *dst, const int64_t *idx, const void *src,
                        const int64_t *count, int batch_size, int dst_rows, int n, int row_bytes);
 
+/* Row movers for index sets that are PREFIXES of one sorted list -- what salience_transformer.py:156-163 builds
+ * (foreground_inds[k] = sorted_index[:, :rows_k], rows_k non-increasing).  The loop then keeps the tokens in sorted
+ * order between layers instead of scattering to / gathering from token space (:454-485).
+ *   sdetr_advance_rows: after a layer.  For i < rows:  live = i < count[b] (count NULL = all);
+ *       live rows: sorted_result[b,i] = layer_out[b,i];
+ *       next_query[b,i] (i < next_rows) = live ? layer_out[b,i] : tokens[b, sorted_index[b,i]]   (rows past the
+ *       image's focus count are never updated, :474-485).  sorted_result [batch, sorted_rows, .], tokens
+ *       [batch, spatial_size, .], sorted_index rows index_batch_stride apart; next_query may be NULL (next_rows 0).
+ *   sdetr_select_stack: out[b,i] = query[b,index[b,i]] + pos[b,index[b,i]], out[b,num_select+i] = query[b,index[b,i]]
+ *       (the q/k and v inputs of the top-k dense self-attention, :366-376); query / pos images are *_batch_stride
+ *       elements apart; dtype SDETR_F32 | SDETR_BF16; out [batch, 2*num_select, channels].
+ *   sdetr_encoder_finalize: token space again + background embedding (:487-495):
+ *       out[b,t] = tokens[b,t] + (padding[b,t] ? 0 : background[t])                       for t not in the sorted list
+ *       out[b,t] = (i < count[b] ? sorted_result[b,i] : tokens[b,t]) + (i >= last_rows && !padding[b,t] ? background[t] : 0)
+ *                                                                                           for t = sorted_index[b,i]. */
+int sdetr_advance_rows(sdetr_stream_t stream, const void *layer_out, void *sorted_result, void *next_query,
+                       const void *tokens, const int64_t *sorted_index, int64_t index_batch_stride,
+                       const int64_t *count, int batch_size, int rows, int sorted_rows, int next_rows,
+                       int spatial_size, int row_bytes);
+int sdetr_select_stack(sdetr_stream_t stream, const void *query, int64_t query_batch_stride, const void *pos,
+                       int64_t pos_batch_stride, const int64_t *index, int batch_size, int num_select, int channels,
+                       int dtype, void *out);
+int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
+                           const int64_t *sorted_index, const int64_t *count, const void *background,
+                           const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,
+                           int last_rows, int channels, int dtype, void *out);
+
 /* ---------------------------------------------------------------------------------------------
  * (6) Plumbing that feeds / surrounds the path.
  *   sdetr_pyramid_flatten_level: one level of flatten_multi_level + get_lvl_pos_embed
@@ -182,8 +211,9 @@ int sdetr_scatter_rows(sdetr_stream_t stream, void *dst, const int64_t *idx, con
  *     sum_out = (feat + pos_out) * keep (the input of enc_output), mask_out (flattened padding mask),
  *     optional bf16 copies.  mask [B,H,W] bytes (1 = padding); outputs are [B,S,C] / [B,S], this level
  *     occupying tokens [level_start, level_start + H*W).
- *   sdetr_class_max_times: out[r] = max_c score[r,c] * scale[r]  (mc_score of
- *     models/bricks/salience_transformer.py:366), score [rows,num_classes] f32|bf16, out f32.
+ *   sdetr_class_max_times: out[b,i] = max_c score[b,i,c] * scale[b,i]  (mc_score of
+ *     models/bricks/salience_transformer.py:366), score [batch,rows_per_batch,num_classes] f32|bf16 contiguous,
+ *     scale f32 with images scale_batch_stride floats apart, out f32 [batch,rows_per_batch].
  * ------------------------------------------------------------------------------------------- */
 int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const float *pos, const uint8_t *mask,
                                 const float *level_embed, int batch_size, int channels, int height, int width,
@@ -192,20 +222,22 @@ int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const 
                                 float *valid_ratio /* this level's (w,h) of image 0, or NULL */,
                                 int valid_ratio_stride /* floats between images */);
 int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
-                          int64_t rows, int num_classes, float *out);
+                          int64_t scale_batch_stride, int batch_size, int rows_per_batch, int num_classes, float *out);
 
 /*   sdetr_layernorm: out = LayerNorm((x [+ residual]) * (1 + row_scale[row] * *alpha)) * gamma + beta, eps as
  *     nn.LayerNorm.  Covers the encoder's residual LayerNorms (models/bricks/salience_transformer.py:347-351,
  *     377-378, 390-391), the level modulation + MaskPredictor LayerNorm (:143, :20) and enc_output_norm
  *     (models/bricks/base_transformer.py:111).  x / residual are [batch_size, rows_per_batch, channels] with the
  *     given element strides (last dim contiguous); residual, row_scale ([batch*rows] f32) and alpha (device
- *     scalar) may be NULL; out is contiguous.  dtypes: SDETR_F32 | SDETR_BF16 (x and residual share x_dtype).
+ *     scalar) may be NULL; out is contiguous, or -- with scatter_index [batch*rows] -- row (b,i) is written to row
+ *     scatter_index[b,i] of out [batch, out_batch_rows, channels] (norm + scatter of :377-379 in one pass).
+ *     dtypes: SDETR_F32 | SDETR_BF16 (x and residual share x_dtype).
  *   sdetr_column_mean_f32: out[b,c] = mean_i x[b,i,c]   (global half of the salience head, :43-45). */
 int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void *residual, int x_dtype,
                     int64_t x_batch_stride, int64_t x_row_stride, int64_t res_batch_stride, int64_t res_row_stride,
                     const float *row_scale, const float *alpha, const void *gamma, const void *beta,
                     int param_dtype, float eps, int batch_size, int rows_per_batch, int channels, void *out,
-                    int out_dtype);
+                    int out_dtype, const int64_t *scatter_index, int64_t out_batch_rows);
 int sdetr_column_mean_f32(sdetr_stream_t stream, const float *x, int64_t batch_stride, int64_t row_stride,
                           int batch_size, int rows, int channels, float *out);
 

@@ -32,7 +32,7 @@ SIGNATURES = {
     "sdetr_msda_col2im_f32": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
     "sdetr_msda_col2im_f64": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
     "sdetr_value_to_head_major": (_i, [_p, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _p, _i]),
-    "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _p, _i, _i64, _p] + [_i] * 7 + [_p, _i]),
+    "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _i64, _p, _i, _i64, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_msda_forward_head_major": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_tiled_config": (None, [_p, _p, _p]),
     "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
@@ -40,8 +40,12 @@ SIGNATURES = {
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i64, _p, _p, _p, _sz]),
     "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i]),
-    "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _p]),
-    "sdetr_layernorm": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i, ctypes.c_float, _i, _i, _i, _p, _i]),
+    "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _i, _i, _p]),
+    "sdetr_layernorm": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i, ctypes.c_float, _i, _i, _i, _p, _i,
+                             _p, _i64]),
+    "sdetr_advance_rows": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _i]),
+    "sdetr_select_stack": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
+    "sdetr_encoder_finalize": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sdetr_column_mean_f32": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "sdetr_pack_linear_f32": (_i, [_p, _p, _i64, _i, _i, _p]),
     "sdetr_salience_head_blocks": (_i, [_i, _i]),

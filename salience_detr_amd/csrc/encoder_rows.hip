@@ -1,0 +1,229 @@
+// Row movers of the encoder loop when every layer's index set is a PREFIX of one globally sorted list
+// (models/bricks/salience_transformer.py:156-163 builds the sets exactly like that: selected_inds[:, :k]).
+//
+// The reference gathers each layer's queries from, and scatters them back into, the full [B,S,C] token buffer
+// (:454-485).  With prefix sets the rows a layer reads are simply the first rows of what the previous layer
+// wrote, so the loop keeps the tokens in sorted order and never goes back to token space until the end:
+//
+//   * advance_rows   after layer k: rows i < focus_token_nums[b] of its output are (1) recorded in the sorted
+//                    result buffer and (2) handed to layer k+1 (its first c_{k+1} rows); rows past the image's
+//                    focus count are never updated by any layer (:474-485), so layer k+1 sees the original token
+//                    there -- one pass over the layer output instead of scatter + 4 gathers.
+//   * select_stack   the [q+pos ; q] rows of the top-k dense self-attention (:366-376: gather tgt, gather pos,
+//                    add, and the stacked in-projection input) in one launch.
+//   * encoder_finalize  back to token space + the learnt background embedding of every token that is neither
+//                    padding nor in the last layer's set (:487-495), two launches.
+//
+// All HBM-bound byte movers: one 16-byte chunk per thread, indices read once per row.
+#include "common.h"
+
+namespace sdetr {
+
+static unsigned rows_grid(int64_t total)
+{
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    const int64_t cap = 256 * 32;
+    return (unsigned)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks));
+}
+
+__global__ void __launch_bounds__(kBlock) advance_rows_kernel(const uint4 *y, uint4 *result, uint4 *next,
+                                                              const uint4 *tokens, const int64_t *sorted_index,
+                                                              int64_t index_batch_stride, const int64_t *count,
+                                                              int64_t total, int c, int n0, int c_next, int S, int vpr)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(t % vpr);
+        const int64_t r = t / vpr;
+        const int b = (int)(r / c), i = (int)(r - (int64_t)b * c);
+        const bool live = !count || i < count[b];
+        uint4 val;
+        if (live) {
+            val = y[t];
+            result[((int64_t)b * n0 + i) * vpr + v] = val;
+        }
+        if (next && i < c_next) {
+            if (!live) val = tokens[((int64_t)b * S + sorted_index[(int64_t)b * index_batch_stride + i]) * vpr + v];
+            next[((int64_t)b * c_next + i) * vpr + v] = val;
+        }
+    }
+}
+
+// out[b][i] = q[b][idx] + pos[b][idx],  out[b][N + i] = q[b][idx];  8 channels per thread
+template <typename T>
+__global__ void __launch_bounds__(kBlock) select_stack_kernel(const T *q, int64_t q_batch_stride, const T *pos,
+                                                              int64_t pos_batch_stride, const int64_t *idx,
+                                                              int64_t total, int N, int C, T *out)
+{
+    const int cpr = C / 8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % cpr) * 8;
+        const int64_t r = t / cpr;
+        const int b = (int)(r / N), i = (int)(r - (int64_t)b * N);
+        const int64_t s = idx[r];
+        const T *qs = q + b * q_batch_stride + s * C + ch, *ps = pos + b * pos_batch_stride + s * C + ch;
+        T *o0 = out + ((int64_t)b * 2 * N + i) * C + ch, *o1 = o0 + (int64_t)N * C;
+        if (sizeof(T) == 4) {
+            const float4 a0 = reinterpret_cast<const float4 *>(qs)[0], a1 = reinterpret_cast<const float4 *>(qs)[1];
+            const float4 p0 = reinterpret_cast<const float4 *>(ps)[0], p1 = reinterpret_cast<const float4 *>(ps)[1];
+            reinterpret_cast<float4 *>(o1)[0] = a0;
+            reinterpret_cast<float4 *>(o1)[1] = a1;
+            reinterpret_cast<float4 *>(o0)[0] = make_float4(a0.x + p0.x, a0.y + p0.y, a0.z + p0.z, a0.w + p0.w);
+            reinterpret_cast<float4 *>(o0)[1] = make_float4(a1.x + p1.x, a1.y + p1.y, a1.z + p1.z, a1.w + p1.w);
+        } else {
+            const uint4 a = *reinterpret_cast<const uint4 *>(qs), pp = *reinterpret_cast<const uint4 *>(ps);
+            *reinterpret_cast<uint4 *>(o1) = a;
+            *reinterpret_cast<uint4 *>(o0) =
+                make_uint4(pack_bf16x2(bf16_lo(a.x) + bf16_lo(pp.x), bf16_hi(a.x) + bf16_hi(pp.x)),
+                           pack_bf16x2(bf16_lo(a.y) + bf16_lo(pp.y), bf16_hi(a.y) + bf16_hi(pp.y)),
+                           pack_bf16x2(bf16_lo(a.z) + bf16_lo(pp.z), bf16_hi(a.z) + bf16_hi(pp.z)),
+                           pack_bf16x2(bf16_lo(a.w) + bf16_lo(pp.w), bf16_hi(a.w) + bf16_hi(pp.w)));
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void add8(const T *a, const T *b, bool use_b, T *o)
+{
+    if (sizeof(T) == 4) {
+        float4 a0 = reinterpret_cast<const float4 *>(a)[0], a1 = reinterpret_cast<const float4 *>(a)[1];
+        if (use_b) {
+            const float4 b0 = reinterpret_cast<const float4 *>(b)[0], b1 = reinterpret_cast<const float4 *>(b)[1];
+            a0 = make_float4(a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w);
+            a1 = make_float4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
+        }
+        reinterpret_cast<float4 *>(o)[0] = a0;
+        reinterpret_cast<float4 *>(o)[1] = a1;
+    } else {
+        uint4 x = *reinterpret_cast<const uint4 *>(a);
+        if (use_b) {
+            const uint4 y = *reinterpret_cast<const uint4 *>(b);
+            x = make_uint4(pack_bf16x2(bf16_lo(x.x) + bf16_lo(y.x), bf16_hi(x.x) + bf16_hi(y.x)),
+                           pack_bf16x2(bf16_lo(x.y) + bf16_lo(y.y), bf16_hi(x.y) + bf16_hi(y.y)),
+                           pack_bf16x2(bf16_lo(x.z) + bf16_lo(y.z), bf16_hi(x.z) + bf16_hi(y.z)),
+                           pack_bf16x2(bf16_lo(x.w) + bf16_lo(y.w), bf16_hi(x.w) + bf16_hi(y.w)));
+        }
+        *reinterpret_cast<uint4 *>(o) = x;
+    }
+}
+
+// every token: out = tokens + (padding ? 0 : background)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) finalize_all_kernel(const T *tokens, const T *background, const uint8_t *pad,
+                                                              int64_t total, int S, int C, T *out)
+{
+    const int cpr = C / 8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % cpr) * 8;
+        const int64_t r = t / cpr;  // b*S + s
+        const int s = (int)(r % S);
+        add8<T>(tokens + r * C + ch, background + (int64_t)s * C + ch, !(pad && pad[r]), out + r * C + ch);
+    }
+}
+
+// sorted rows: out[token] = (i < count ? result[i] : tokens[token]) + (i >= c_last && !padding ? background : 0)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) finalize_sorted_kernel(const T *tokens, const T *result,
+                                                                 const int64_t *sorted_index, const int64_t *count,
+                                                                 const T *background, const uint8_t *pad,
+                                                                 int64_t total, int n0, int c_last, int S, int C, T *out)
+{
+    const int cpr = C / 8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % cpr) * 8;
+        const int64_t r = t / cpr;  // b*n0 + i
+        const int b = (int)(r / n0), i = (int)(r - (int64_t)b * n0);
+        const int64_t tok = (int64_t)b * S + sorted_index[r];
+        const bool live = !count || i < count[b];
+        const T *base = live ? result + r * C + ch : tokens + tok * C + ch;
+        const bool bg = i >= c_last && !(pad && pad[tok]);
+        add8<T>(base, background + (tok - (int64_t)b * S) * C + ch, bg, out + tok * C + ch);
+    }
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int sdetr_advance_rows(sdetr_stream_t stream, const void *layer_out, void *sorted_result, void *next_query,
+                                  const void *tokens, const int64_t *sorted_index, int64_t index_batch_stride,
+                                  const int64_t *count, int batch_size, int rows, int sorted_rows, int next_rows,
+                                  int spatial_size, int row_bytes)
+{
+    if (batch_size < 0 || rows < 0 || sorted_rows < rows || next_rows < 0 || next_rows > rows || row_bytes <= 0 ||
+        (row_bytes & 15))
+        return fail("advance_rows: bad sizes (rows %d of %d, next %d, row bytes %d)", rows, sorted_rows, next_rows, row_bytes);
+    if ((int64_t)batch_size * rows == 0) return 0;
+    if (!layer_out || !sorted_result || !tokens || !sorted_index) return fail("advance_rows: null pointer");
+    if (index_batch_stride < rows) return fail("advance_rows: index batch stride too small");
+    const int vpr = row_bytes / 16;
+    const int64_t total = (int64_t)batch_size * rows * vpr;
+    hipLaunchKernelGGL(advance_rows_kernel, dim3(rows_grid(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       (const uint4 *)layer_out, (uint4 *)sorted_result, next_rows > 0 ? (uint4 *)next_query : nullptr,
+                       (const uint4 *)tokens, sorted_index, index_batch_stride, count, total, rows, sorted_rows,
+                       next_rows, spatial_size, vpr);
+    return check_launch("advance_rows");
+}
+
+extern "C" int sdetr_select_stack(sdetr_stream_t stream, const void *query, int64_t query_batch_stride, const void *pos,
+                                  int64_t pos_batch_stride, const int64_t *index, int batch_size, int num_select,
+                                  int channels, int dtype, void *out)
+{
+    if (batch_size < 0 || num_select < 0 || channels <= 0 || (channels % 8)) return fail("select_stack: bad sizes");
+    if ((query_batch_stride % 8) || (pos_batch_stride % 8)) return fail("select_stack: strides must be multiples of 8");
+    if ((int64_t)batch_size * num_select == 0) return 0;
+    if (!query || !pos || !index || !out) return fail("select_stack: null pointer");
+    const int64_t total = (int64_t)batch_size * num_select * (channels / 8);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SDETR_F32)
+        hipLaunchKernelGGL(select_stack_kernel<float>, dim3(rows_grid(total)), dim3(kBlock), 0, s, (const float *)query,
+                           query_batch_stride, (const float *)pos, pos_batch_stride, index, total, num_select, channels,
+                           (float *)out);
+    else if (dtype == SDETR_BF16)
+        hipLaunchKernelGGL(select_stack_kernel<bf16_t>, dim3(rows_grid(total)), dim3(kBlock), 0, s,
+                           (const bf16_t *)query, query_batch_stride, (const bf16_t *)pos, pos_batch_stride, index, total,
+                           num_select, channels, (bf16_t *)out);
+    else
+        return fail("select_stack: bad dtype %d", dtype);
+    return check_launch("select_stack");
+}
+
+template <typename T>
+static int launch_finalize(hipStream_t s, const void *tokens, const void *result, const int64_t *sorted_index,
+                           const int64_t *count, const void *background, const uint8_t *pad, int B, int S, int n0,
+                           int c_last, int C, void *out)
+{
+    const int64_t total_all = (int64_t)B * S * (C / 8), total_sorted = (int64_t)B * n0 * (C / 8);
+    hipLaunchKernelGGL(finalize_all_kernel<T>, dim3(rows_grid(total_all)), dim3(kBlock), 0, s, (const T *)tokens,
+                       (const T *)background, pad, total_all, S, C, (T *)out);
+    int rc = check_launch("encoder_finalize");
+    if (rc || total_sorted == 0) return rc;
+    hipLaunchKernelGGL(finalize_sorted_kernel<T>, dim3(rows_grid(total_sorted)), dim3(kBlock), 0, s, (const T *)tokens,
+                       (const T *)result, sorted_index, count, (const T *)background, pad, total_sorted, n0, c_last, S,
+                       C, (T *)out);
+    return check_launch("encoder_finalize");
+}
+
+extern "C" int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
+                                      const int64_t *sorted_index, const int64_t *count, const void *background,
+                                      const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,
+                                      int last_rows, int channels, int dtype, void *out)
+{
+    if (batch_size < 0 || spatial_size < 0 || sorted_rows < 0 || sorted_rows > spatial_size || last_rows < 0 ||
+        last_rows > sorted_rows || channels <= 0 || (channels % 8))
+        return fail("encoder_finalize: bad sizes");
+    if ((int64_t)batch_size * spatial_size == 0) return 0;
+    if (!tokens || !background || !out || (sorted_rows && (!sorted_result || !sorted_index)))
+        return fail("encoder_finalize: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SDETR_F32)
+        return launch_finalize<float>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
+                                      batch_size, spatial_size, sorted_rows, last_rows, channels, out);
+    if (dtype == SDETR_BF16)
+        return launch_finalize<bf16_t>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
+                                       batch_size, spatial_size, sorted_rows, last_rows, channels, out);
+    return fail("encoder_finalize: bad dtype %d", dtype);
+}

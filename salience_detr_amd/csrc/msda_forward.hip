@@ -77,6 +77,7 @@ struct GatherArgs {
     const float *aw;
     // fused mode
     const float *ref;
+    int64_t ref_batch_stride;   // floats between images (Nq * L * ref_dim when contiguous)
     int ref_dim;
     const void *proj;
     int proj_bf16;
@@ -262,13 +263,13 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
                 if (p.ref_dim == 4) {
 #pragma unroll
                     for (int t = 0; t < TMAX; ++t) {
-                        const float4 r = *reinterpret_cast<const float4 *>(p.ref + (((int64_t)b * p.Nq + q) * p.L + lv[t]) * 4);
+                        const float4 r = *reinterpret_cast<const float4 *>(p.ref + (int64_t)b * p.ref_batch_stride + ((int64_t)q * p.L + lv[t]) * 4);
                         rr[t][0] = r.x; rr[t][1] = r.y; rr[t][2] = r.z; rr[t][3] = r.w;
                     }
                 } else {
 #pragma unroll
                     for (int t = 0; t < TMAX; ++t) {
-                        const float2 r = *reinterpret_cast<const float2 *>(p.ref + (((int64_t)b * p.Nq + q) * p.L + lv[t]) * 2);
+                        const float2 r = *reinterpret_cast<const float2 *>(p.ref + (int64_t)b * p.ref_batch_stride + ((int64_t)q * p.L + lv[t]) * 2);
                         rr[t][0] = r.x; rr[t][1] = r.y; rr[t][2] = 0.f; rr[t][3] = 0.f;
                     }
                 }
@@ -429,10 +430,10 @@ __global__ void __launch_bounds__(kBlock) msda_gather_l4p4_kernel(GatherArgs p)
     }
     float rx, ry, rw = 0.f, rh = 0.f;
     if (p.ref_dim == 4) {
-        const float4 r = *reinterpret_cast<const float4 *>(p.ref + (bq * L + j) * 4);
+        const float4 r = *reinterpret_cast<const float4 *>(p.ref + (int64_t)b * p.ref_batch_stride + ((int64_t)q * L + j) * 4);
         rx = r.x; ry = r.y; rw = r.z; rh = r.w;
     } else {
-        const float2 r = *reinterpret_cast<const float2 *>(p.ref + (bq * L + j) * 2);
+        const float2 r = *reinterpret_cast<const float2 *>(p.ref + (int64_t)b * p.ref_batch_stride + ((int64_t)q * L + j) * 2);
         rx = r.x; ry = r.y;
     }
     // softmax over the quad's 16 logits
@@ -667,11 +668,14 @@ extern "C" int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *
 
 extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
                                         const int64_t *shapes, const int64_t *lsi, const float *ref, int ref_dim,
-                                        const void *proj, int proj_dtype, int64_t proj_row_stride,
-                                        const int32_t *order, int B, int Nv, int M, int D, int L, int Nq, int P,
-                                        void *out, int out_dtype)
+                                        int64_t ref_batch_stride, const void *proj, int proj_dtype,
+                                        int64_t proj_row_stride, const int32_t *order, int B, int Nv, int M, int D,
+                                        int L, int Nq, int P, void *out, int out_dtype)
 {
     if (int e = check_dims(B, Nv, M, D, L, Nq, P)) return e;
+    if (ref_batch_stride == 0) ref_batch_stride = (int64_t)Nq * L * ref_dim;
+    if (ref_batch_stride < (int64_t)Nq * L * ref_dim || (ref_batch_stride % ref_dim))
+        return fail("msda_fused_forward: bad reference point batch stride");
     if (!value_hm || !shapes || !lsi || !ref || !proj || !out) return fail("msda_fused_forward: null pointer");
     if (ref_dim != 2 && ref_dim != 4)
         return fail("Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
@@ -680,8 +684,8 @@ extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value
     if ((int64_t)B * Nq == 0) return 0;
     GatherArgs a{};
     a.value = reinterpret_cast<const char *>(value_hm);
-    a.shapes = shapes; a.lsi = lsi; a.ref = ref; a.ref_dim = ref_dim; a.proj = proj;
-    a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;
+    a.shapes = shapes; a.lsi = lsi; a.ref = ref; a.ref_dim = ref_dim; a.ref_batch_stride = ref_batch_stride;
+    a.proj = proj; a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;
     a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
     const bool l4p4 = D == 32 && L == 4 && P == 4 && (proj_row_stride % 8) == 0 &&

@@ -6,6 +6,8 @@
 //      - the level modulation "level_memory + level_memory * upsample_score * alpha[level]" followed by the
 //        MaskPredictor's LayerNorm (:143 and :20),
 //      - plain LayerNorm when r and s are NULL (enc_output_norm, base_transformer.py:111).
+//    With scatter_index the normalised row i of image b goes to row scatter_index[b,i] of out [B, out_batch_rows, C]
+//    (the top-k self-attention block's norm + scatter back into the layer's queries, :377-379).
 //    HBM-bound: each row is read once and written once.  C/8 lanes own one row (8 channels = one 16/32-byte
 //    vector per lane), statistics in fp32 with a two-pass (mean, then centred variance) reduction done with
 //    wavefront shuffles -- no LDS, no barrier.  The framework path costs an add kernel plus a LayerNorm kernel
@@ -24,7 +26,9 @@ struct NormArgs {
     const float *alpha;     // device scalar or NULL (treated as 1)
     const void *gamma;
     const void *beta;
-    void *out;              // [B*n, C] contiguous
+    void *out;              // [B*n, C] contiguous, or [B, out_batch_rows, C] when scatter_index is given
+    const int64_t *scatter_index;  // [B*n] destination row inside the image, or NULL
+    int64_t out_batch_rows;
     int64_t x_batch_stride, x_row_stride, res_batch_stride, res_row_stride;
     int64_t rows;
     int n_per_batch, C;
@@ -110,7 +114,8 @@ __global__ void __launch_bounds__(kBlock) layernorm_kernel(NormArgs p)
         load8<PT>(reinterpret_cast<const PT *>(p.beta) + l * 8, be);
 #pragma unroll
         for (int k = 0; k < 8; ++k) y[k] = (v[k] - mean) * rstd * g[k] + be[k];
-        store8<OT>(reinterpret_cast<OT *>(p.out) + row * p.C + l * 8, y);
+        const int64_t orow = p.scatter_index ? b * p.out_batch_rows + p.scatter_index[row] : row;
+        store8<OT>(reinterpret_cast<OT *>(p.out) + orow * p.C + l * 8, y);
     }
 }
 
@@ -183,7 +188,8 @@ extern "C" int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void 
                                int64_t x_batch_stride, int64_t x_row_stride, int64_t res_batch_stride,
                                int64_t res_row_stride, const float *row_scale, const float *alpha, const void *gamma,
                                const void *beta, int param_dtype, float eps, int batch_size, int rows_per_batch,
-                               int channels, void *out, int out_dtype)
+                               int channels, void *out, int out_dtype, const int64_t *scatter_index,
+                               int64_t out_batch_rows)
 {
     if (batch_size < 0 || rows_per_batch < 0 || channels <= 0) return fail("layernorm: bad dims");
     if (channels % 8 != 0 || channels > 512) return fail("layernorm: channels (%d) must be a multiple of 8, <= 512", channels);
@@ -197,6 +203,7 @@ extern "C" int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void 
     a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
     a.res_batch_stride = res_batch_stride; a.res_row_stride = res_row_stride;
     a.rows = rows; a.n_per_batch = rows_per_batch; a.C = channels; a.eps = eps;
+    a.scatter_index = scatter_index; a.out_batch_rows = out_batch_rows;
     const int key = x_dtype * 4 + param_dtype * 2 + out_dtype;
     switch (key) {
         case 0: return launch_ln<float, float, float>(stream, a);

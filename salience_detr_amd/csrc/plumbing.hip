@@ -105,7 +105,7 @@ __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __uint_as_flo
 // 16 lanes per row; rows = B*Nq
 template <typename T>
 __global__ void __launch_bounds__(256) class_max_times_kernel(const T *score, const float *fg, int64_t rows, int C,
-                                                              float *out)
+                                                              int rows_per_batch, int64_t fg_batch_stride, float *out)
 {
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
@@ -116,7 +116,10 @@ __global__ void __launch_bounds__(256) class_max_times_kernel(const T *score, co
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-    if (row < rows && l == 0) out[row] = mx * fg[row];
+    if (row < rows && l == 0) {
+        const int64_t b = row / rows_per_batch;
+        out[row] = mx * fg[b * fg_batch_stride + (row - b * rows_per_batch)];
+    }
 }
 
 }  // namespace sdetr
@@ -147,18 +150,21 @@ extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *f
 }
 
 extern "C" int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
-                                     int64_t rows, int num_classes, float *out)
+                                     int64_t scale_batch_stride, int batch_size, int rows_per_batch, int num_classes,
+                                     float *out)
 {
-    if (rows < 0 || num_classes <= 0) return fail("class_max_times: bad dims");
+    const int64_t rows = (int64_t)batch_size * rows_per_batch;
+    if (batch_size < 0 || rows_per_batch < 0 || num_classes <= 0 || scale_batch_stride < rows_per_batch)
+        return fail("class_max_times: bad dims");
     if (rows == 0) return 0;
     if (!score || !scale || !out) return fail("class_max_times: null pointer");
     const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
     if (score_dtype == SDETR_F32)
         hipLaunchKernelGGL(class_max_times_kernel<float>, grid, block, 0, stream, (const float *)score, scale, rows,
-                           num_classes, out);
+                           num_classes, rows_per_batch, scale_batch_stride, out);
     else if (score_dtype == SDETR_BF16)
         hipLaunchKernelGGL(class_max_times_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t *)score, scale, rows,
-                           num_classes, out);
+                           num_classes, rows_per_batch, scale_batch_stride, out);
     else
         return fail("class_max_times: bad dtype %d", score_dtype);
     return check_launch("class_max_times");

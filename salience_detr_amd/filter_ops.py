@@ -51,12 +51,22 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
 def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
     """``dst[b, i] = src[b, idx[b, i]]`` for ``src`` [B,S,C], ``idx`` [B,n] int64
     (the torch.gather calls of salience_transformer.py:454-461 without the expanded index)."""
-    _hip.require_device("gather_rows", src=src, idx=idx)
+    _hip.require_device("gather_rows", idx=idx)
     if idx.dtype != torch.int64 or src.dim() < 2 or idx.dim() != 2 or idx.shape[0] != src.shape[0]:
         raise RuntimeError("gather_rows: src [B,S,...], idx [B,n] int64 expected")
     B, S = src.shape[:2]
     n = idx.shape[1]
-    row_bytes = src[0, 0].numel() * src.element_size() if S > 0 else 0
+    row_elems = src[0, 0].numel() if S > 0 else 0
+    row_bytes = row_elems * src.element_size()
+    if not src.is_cuda:
+        raise RuntimeError("gather_rows: src must be a HIP (cuda) tensor; the hot path has no CPU fallback")
+    if S > 0 and not src[0].is_contiguous():
+        raise RuntimeError("gather_rows: src rows have to be contiguous")
+    if B > 1 and S > 0 and row_elems > 0:
+        # a row prefix [B, :S] of a longer [B, S', ...] buffer is fine: images are S' rows apart
+        if src.stride(0) % row_elems or src.stride(0) < S * row_elems:
+            raise RuntimeError("gather_rows: src tensor has to be contiguous (or a row prefix of one)")
+        S = src.stride(0) // row_elems
     dst = torch.empty((B, n) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
     if B * n == 0:
         return dst
@@ -131,15 +141,19 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
 
 def class_max_times(score: Tensor, scale: Tensor) -> Tensor:
     """``score.max(-1)[0] * scale`` in one pass: score ``[B,Nq,num_classes]`` (fp32 | bf16), scale ``[B,Nq]``
-    fp32 -> fp32 ``[B,Nq]`` (mc_score of salience_transformer.py:366)."""
-    _hip.require_device("class_max_times", score=score, scale=scale)
-    if scale.dtype != torch.float32:
-        scale = scale.float()
+    fp32 (may be a row prefix of a longer ``[B,n]`` buffer) -> fp32 ``[B,Nq]`` (mc_score of
+    salience_transformer.py:366)."""
+    _hip.require_device("class_max_times", score=score)
+    if not scale.is_cuda:
+        raise RuntimeError("class_max_times: scale must be a HIP (cuda) tensor; the hot path has no CPU fallback")
     B, Nq, C = score.shape
+    if scale.dtype != torch.float32 or scale.dim() != 2 or (Nq > 1 and scale.stride(1) != 1):
+        scale = scale.float().contiguous()
     out = torch.empty((B, Nq), dtype=torch.float32, device=score.device)
     with torch.cuda.device(score.device):
         code = _hip.lib().sdetr_class_max_times(_hip.stream_ptr(), score.data_ptr(), _hip.dtype_code(score.dtype),
-                                                scale.data_ptr(), B * Nq, C, out.data_ptr())
+                                                scale.data_ptr(), scale.stride(0) if B > 1 else max(Nq, 1), B, Nq, C,
+                                                out.data_ptr())
     _hip.check(code, "class_max_times")
     return out
 
@@ -157,9 +171,12 @@ def _bn_view(t: Tensor):
 
 def fused_layer_norm(x: Tensor, norm: torch.nn.LayerNorm, residual: Optional[Tensor] = None,
                      row_scale: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
-                     out_dtype: Optional[torch.dtype] = None) -> Tensor:
+                     out_dtype: Optional[torch.dtype] = None, scatter_index: Optional[Tensor] = None,
+                     scatter_into: Optional[Tensor] = None) -> Tensor:
     """``norm((x [+ residual]) * (1 + row_scale * alpha))`` in one launch (see include/salience_hip.h (6)).
-    ``x`` may be a batch-strided view (e.g. one level's slice of ``[B,S,C]``); the result is contiguous."""
+    ``x`` may be a batch-strided view (e.g. one level's slice of ``[B,S,C]``); the result is contiguous.
+    With ``scatter_index`` [B,n] int64 and ``scatter_into`` [B,m,C] (contiguous) row ``(b,i)`` of the result is
+    written to ``scatter_into[b, scatter_index[b,i]]`` instead (in place; returns ``scatter_into``)."""
     if not x.is_cuda:
         raise RuntimeError("fused_layer_norm: HIP device tensors required; there is no CPU fallback")
     shape = x.shape
@@ -175,15 +192,23 @@ def fused_layer_norm(x: Tensor, norm: torch.nn.LayerNorm, residual: Optional[Ten
         if row_scale.dtype != torch.float32 or row_scale.numel() != B * n or not row_scale.is_contiguous():
             row_scale = row_scale.float().contiguous()
     w, b = norm.weight.detach(), norm.bias.detach()
-    out_dtype = out_dtype or x.dtype
-    out = torch.empty((B, n, C), dtype=out_dtype, device=x.device)
+    out_rows = 0
+    if scatter_index is not None:
+        _hip.require_device("fused_layer_norm", scatter_index=scatter_index, scatter_into=scatter_into)
+        if (scatter_index.dtype != torch.int64 or tuple(scatter_index.shape) != (B, n) or scatter_into.dim() != 3
+                or scatter_into.shape[0] != B or scatter_into.shape[2] != C):
+            raise RuntimeError("fused_layer_norm: scatter_index [B,n] int64 and scatter_into [B,m,C] expected")
+        out, out_dtype, out_rows = scatter_into, scatter_into.dtype, scatter_into.shape[1]
+    else:
+        out_dtype = out_dtype or x.dtype
+        out = torch.empty((B, n, C), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
         code = _hip.lib().sdetr_layernorm(
             _hip.stream_ptr(), xv.data_ptr(), _hip.ptr(rv), _hip.dtype_code(x.dtype), xbs, xrs, rbs, rrs,
             _hip.ptr(row_scale), _hip.ptr(alpha), w.data_ptr(), b.data_ptr(), _hip.dtype_code(w.dtype),
-            float(norm.eps), B, n, C, out.data_ptr(), _hip.dtype_code(out_dtype))
+            float(norm.eps), B, n, C, out.data_ptr(), _hip.dtype_code(out_dtype), _hip.ptr(scatter_index), out_rows)
     _hip.check(code, "fused_layer_norm")
-    return out.view(shape)
+    return out if scatter_index is not None else out.view(shape)
 
 
 def column_mean(x: Tensor) -> Tensor:
@@ -289,3 +314,72 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             _hip.ptr(score_flat), sfs)
         _hip.check(code, "salience_head_stage2")
     return score
+
+
+def advance_rows(layer_out: Tensor, sorted_result: Tensor, next_rows: int, tokens: Tensor, sorted_index: Tensor,
+                 count: Optional[Tensor] = None) -> Optional[Tensor]:
+    """End of an encoder layer whose index set is ``sorted_index[:, :rows]`` (include/salience_hip.h (5)):
+    records the live rows (``i < count[b]``) of ``layer_out`` [B,rows,C] in ``sorted_result`` [B,n0,C] (in place)
+    and returns the next layer's queries [B,next_rows,C] -- live rows from ``layer_out``, the others straight
+    from ``tokens`` [B,S,C] (never-updated originals); ``None`` when ``next_rows == 0``."""
+    _hip.require_device("advance_rows", layer_out=layer_out, sorted_result=sorted_result, tokens=tokens, count=count)
+    B, rows, C = layer_out.shape
+    if (sorted_result.dtype != layer_out.dtype or tokens.dtype != layer_out.dtype or sorted_index.dtype != torch.int64
+            or sorted_index.dim() != 2 or sorted_index.stride(1) != 1 or not sorted_index.is_cuda):
+        raise RuntimeError("advance_rows: dtype / layout mismatch")
+    if count is not None and (count.dtype != torch.int64 or count.numel() != B):
+        raise RuntimeError("advance_rows: count must be int64 [B]")
+    nxt = torch.empty((B, next_rows, C), dtype=layer_out.dtype, device=layer_out.device) if next_rows > 0 else None
+    with torch.cuda.device(layer_out.device):
+        code = _hip.lib().sdetr_advance_rows(
+            _hip.stream_ptr(), layer_out.data_ptr(), sorted_result.data_ptr(), _hip.ptr(nxt), tokens.data_ptr(),
+            sorted_index.data_ptr(), sorted_index.stride(0), _hip.ptr(count), B, rows, sorted_result.shape[1],
+            int(next_rows), tokens.shape[1], C * layer_out.element_size())
+    _hip.check(code, "advance_rows")
+    return nxt
+
+
+def _batch_stride(t: Tensor, what: str) -> int:
+    """Element stride between images of a [B,n,C] tensor whose rows are contiguous (a row prefix is fine)."""
+    if not t.is_cuda or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+        raise RuntimeError(f"{what}: [B,n,C] HIP tensor with contiguous rows expected")
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2]
+
+
+def select_stack(query: Tensor, pos: Tensor, index: Tensor) -> Tensor:
+    """``cat([query[index] + pos[index], query[index]], 1)`` -> [B, 2N, C]: the q/k rows and the value rows of the
+    top-k dense self-attention (salience_transformer.py:366-376) in one launch."""
+    _hip.require_device("select_stack", index=index)
+    if query.dtype != pos.dtype or index.dtype != torch.int64 or index.dim() != 2:
+        raise RuntimeError("select_stack: query / pos of one dtype and an int64 [B,N] index expected")
+    B, _, C = query.shape
+    N = index.shape[1]
+    out = torch.empty((B, 2 * N, C), dtype=query.dtype, device=query.device)
+    with torch.cuda.device(query.device):
+        code = _hip.lib().sdetr_select_stack(
+            _hip.stream_ptr(), query.data_ptr(), _batch_stride(query, "select_stack"), pos.data_ptr(),
+            _batch_stride(pos, "select_stack"), index.data_ptr(), B, N, C, _hip.dtype_code(query.dtype), out.data_ptr())
+    _hip.check(code, "select_stack")
+    return out
+
+
+def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor, count: Optional[Tensor],
+                     background: Tensor, padding_mask: Optional[Tensor], last_rows: int) -> Tensor:
+    """Encoder output in token space (include/salience_hip.h (5), salience_transformer.py:474-495): live sorted
+    rows replace their tokens, and every token that is neither padding nor among the first ``last_rows`` sorted
+    rows (the last layer's set) receives its background embedding."""
+    _hip.require_device("encoder_finalize", tokens=tokens, sorted_result=sorted_result, sorted_index=sorted_index,
+                        count=count, background=background, padding_mask=padding_mask)
+    B, S, C = tokens.shape
+    if background.dtype != tokens.dtype or sorted_result.dtype != tokens.dtype or tuple(background.shape) != (S, C):
+        raise RuntimeError("encoder_finalize: background [S,C] / sorted_result of the tokens' dtype expected")
+    pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
+                                             else padding_mask)
+    out = torch.empty_like(tokens)
+    with torch.cuda.device(tokens.device):
+        code = _hip.lib().sdetr_encoder_finalize(
+            _hip.stream_ptr(), tokens.data_ptr(), sorted_result.data_ptr(), sorted_index.data_ptr(), _hip.ptr(count),
+            background.data_ptr(), _hip.ptr(pad), B, S, sorted_result.shape[1], int(last_rows), C,
+            _hip.dtype_code(tokens.dtype), out.data_ptr())
+    _hip.check(code, "encoder_finalize")
+    return out

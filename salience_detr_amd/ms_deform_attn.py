@@ -164,7 +164,7 @@ def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
     ``[B, Nq, >= 3*M*L*P]``; ``reference_points`` is ``[B, Nq, L, 2|4]`` fp32.
     """
     _hip.require_device("msda_fused_forward", value_hm=value_hm, spatial_shapes=spatial_shapes,
-                        level_start_index=level_start_index, reference_points=reference_points, order=order)
+                        level_start_index=level_start_index, order=order)
     if reference_points.shape[-1] not in (2, 4):
         raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
             reference_points.shape[-1]))
@@ -172,14 +172,20 @@ def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
     Nq = proj.shape[1]
     if proj.stride(2) != 1 or proj.stride(0) != Nq * proj.stride(1):
         proj = proj.contiguous()
+    if not reference_points.is_cuda:
+        raise RuntimeError("msda_fused_forward: reference_points must be a HIP (cuda) tensor; no CPU fallback")
     if reference_points.dtype != torch.float32:
         reference_points = reference_points.float()
+    # a row prefix [B, :Nq] of a longer reference-point buffer is accepted as is (images a batch stride apart)
+    if Nq > 0 and not reference_points[0].is_contiguous():
+        reference_points = reference_points.contiguous()
+    ref_bs = reference_points.stride(0) if (B > 1 and Nq > 0) else 0
     out_dtype = out_dtype or proj.dtype
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
     with torch.cuda.device(out.device):
         code = _hip.lib().sdetr_msda_fused_forward(
             _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), spatial_shapes.data_ptr(),
-            level_start_index.data_ptr(), reference_points.data_ptr(), reference_points.shape[-1],
+            level_start_index.data_ptr(), reference_points.data_ptr(), reference_points.shape[-1], ref_bs,
             proj.data_ptr(), _hip.dtype_code(proj.dtype), proj.stride(1), _hip.ptr(order),
             B, Nv, M, D, num_levels, Nq, num_points, out.data_ptr(), _hip.dtype_code(out_dtype))
     _hip.check(code, "msda_fused_forward")

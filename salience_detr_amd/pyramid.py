@@ -155,6 +155,18 @@ class PositionEmbeddingLearned(nn.Module):
     def flat(self, level_shapes: Sequence[Tuple[int, int]]) -> Tensor:
         return torch.cat([self.level_table(h, w).reshape(h * w, -1) for h, w in level_shapes], 0)
 
+    def flat_cached(self, level_shapes: Sequence[Tuple[int, int]], dtype: torch.dtype) -> Tensor:
+        """``flat(level_shapes).to(dtype)`` detached, rebuilt only when the embeddings (or the request) change --
+        for the no-grad path, where it is a constant of the weights."""
+        ws = (self.row_embed.weight, self.col_embed.weight)
+        key = (tuple(map(tuple, level_shapes)), dtype) + tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
+        hit = self.__dict__.get("_flat_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, self.flat(level_shapes).to(dtype).contiguous())
+            self.__dict__["_flat_cache"] = hit
+        return hit[1]
+
     def forward(self, mask: Tensor) -> Tensor:
         h, w = mask.shape[-2:]
         return self.level_table(h, w).permute(2, 0, 1).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1)

@@ -25,7 +25,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import class_max_times, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_
+from .filter_ops import (advance_rows, class_max_times, encoder_finalize, fused_layer_norm, gather_rows,
+                         masked_topk_desc, scatter_rows_, select_stack)
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -96,17 +97,21 @@ class SalienceTransformerEncoderLayer(nn.Module):
         (salience_transformer.py:371-376).  The 300-token problem is launch-latency bound, so it is arranged as
         few launches: ONE in-projection GEMM over the stacked [qk ; v] rows (q,k are read from the first half,
         v from the second), one fused scaled-dot-product attention, one out-projection."""
+        return self._pre_attention_stacked(torch.cat([qk, v], 1), qk.shape[1], qk.requires_grad)
+
+    def _pre_attention_stacked(self, stacked: Tensor, N: int, needs_grad: bool = False) -> Tensor:
+        """``stacked`` = ``[q/k rows ; value rows]`` [B, 2N, E] (see ``_pre_attention``)."""
         mha = self.pre_attention
-        B, N, E = qk.shape
+        B, _, E = stacked.shape
         H = mha.num_heads
         hd = E // H
-        proj = F.linear(torch.cat([qk, v], 1), mha.in_proj_weight, mha.in_proj_bias)   # [B, 2N, 3E]
+        proj = F.linear(stacked, mha.in_proj_weight, mha.in_proj_bias)   # [B, 2N, 3E]
         q = proj[:, :N, :E].view(B, N, H, hd).transpose(1, 2)
         k = proj[:, :N, E:2 * E].view(B, N, H, hd).transpose(1, 2)
         vv = proj[:, N:, 2 * E:].view(B, N, H, hd).transpose(1, 2)
         drop = mha.dropout if self.training else 0.0
         o = None
-        if not (torch.is_grad_enabled() and qk.requires_grad):
+        if not (torch.is_grad_enabled() and needs_grad):
             try:
                 o = F.scaled_dot_product_attention(q, k, vv, dropout_p=drop)
             except RuntimeError:
@@ -118,6 +123,24 @@ class SalienceTransformerEncoderLayer(nn.Module):
             o = torch.matmul(att, vv)
         o = o.transpose(1, 2).reshape(B, N, E)
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+
+    def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
+                       score_tgt):
+        """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
+        in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
+        (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
+        sorted-order buffers of which the first ``c`` rows belong to this layer.  Same arithmetic as ``forward``."""
+        c = query.shape[1]
+        mc_score = class_max_times(score_tgt, fg_sorted[:, :c])
+        sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
+        N = sel.shape[1]
+        stacked = select_stack(query, pos_sorted, sel)                       # [q+pos ; q] rows, [B,2N,E]
+        tgt2 = self._pre_attention_stacked(stacked, N)
+        # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
+        fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
+        src2 = self.self_attn.forward_native(query + pos_sorted[:, :c], ref_sorted[:, :c], value_hm, spatial_shapes,
+                                             level_start_index)
+        return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2))
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
                 query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None,
@@ -204,6 +227,24 @@ class SalienceTransformerEncoder(nn.Module):
         centre = pix[None] / (own * sz[None])                             # (idx + 0.5) / (valid_ratio * size)
         return centre[:, :, None] * valid_ratios[:, None]
 
+    @staticmethod
+    def _prefix_counts(foreground_inds) -> Optional[List[int]]:
+        """Row counts per layer when ``foreground_inds[k]`` are views ``sorted[:, :c_k]`` of ONE contiguous
+        ``[B,n0]`` tensor with non-increasing ``c_k`` (checked structurally: same storage offset and strides --
+        no device read), else ``None``."""
+        first = foreground_inds[0]
+        if first.dim() != 2 or first.dtype != torch.int64 or not first.is_contiguous() or first.shape[1] == 0:
+            return None
+        counts = []
+        for t in foreground_inds:
+            if (t.dim() != 2 or t.dtype != torch.int64 or t.data_ptr() != first.data_ptr() or t.shape[0] != first.shape[0]
+                    or t.shape[1] == 0 or (t.shape[1] > 1 and t.stride(1) != 1)
+                    or (t.shape[0] > 1 and t.stride(0) != first.stride(0))
+                    or (counts and t.shape[1] > counts[-1])):
+                return None
+            counts.append(int(t.shape[1]))
+        return counts
+
     def _all_value_projections(self):
         """[6*E, E] weight / [6*E] bias of every layer's value_proj, cached per parameter version."""
         ps = [p for l in self.layers for p in (l.self_attn.value_proj.weight, l.self_attn.value_proj.bias)]
@@ -230,7 +271,7 @@ class SalienceTransformerEncoder(nn.Module):
         ori_reference_points = reference_points.reshape(b, n, s * p).contiguous()
         ori_pos = query_pos
         value = query
-        output = query.clone() if native else query
+        output = query
         focus64 = focus_token_nums.to(torch.int64).contiguous()
 
         value_hm_all = None
@@ -243,6 +284,33 @@ class SalienceTransformerEncoder(nn.Module):
             if self.num_layers == 1:
                 value_hm_all = value_hm_all[None]
 
+        counts = self._prefix_counts(foreground_inds) if native else None
+        if counts is not None:
+            # every layer's set is a prefix of one sorted list (what salience_filtering produces): keep the tokens
+            # in sorted order across the layers -- one gather in, one pass back to token space at the end
+            sorted_index = foreground_inds[0]
+            n0 = counts[0]
+            q = gather_rows(value, sorted_index)
+            pos_s = gather_rows(ori_pos, sorted_index)
+            ref_s = gather_rows(ori_reference_points, sorted_index).view(b, n0, s, p)
+            fg_s = torch.gather(foreground_score, 1, sorted_index)
+            result = torch.empty_like(q)
+            for layer_id, layer in enumerate(self.layers):
+                if self.layer_marker is not None:
+                    self.layer_marker(layer_id)
+                y = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
+                                         level_start_index, self.enhance_mcsp(q))
+                nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
+                q = advance_rows(y, result, nxt, value, sorted_index, focus64)
+            if self.layer_marker is not None:
+                self.layer_marker(self.num_layers)
+            if multi_level_masks is not None:
+                bg = self.background_embedding.flat_cached(level_shapes, value.dtype)
+                return encoder_finalize(value, result, sorted_index, focus64, bg, query_key_padding_mask, counts[-1])
+            return scatter_rows_(value.clone(), sorted_index, result, count=focus64)
+
+        if native:
+            output = query.clone()   # the general path scatters every layer's rows back in place
         inds = None
         for layer_id, layer in enumerate(self.layers):
             if self.layer_marker is not None:

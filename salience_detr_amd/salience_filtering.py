@@ -158,7 +158,8 @@ def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Te
     n = selected_inds.shape[1]
     _, sorted_inds = masked_topk_desc(selected_score, n, payload=selected_inds, want_scores=False)
     counts = pyramid.layer_token_counts(n, layer_filter_ratio)
-    foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c].contiguous() for c in counts]
+    # views of ONE sorted list: the encoder recognises the prefix structure and keeps the tokens in sorted order
+    foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c] for c in counts]
     fg = score_flat if score_flat is not None else pyramid.flatten_multi_level(salience_score).squeeze(-1)
     fg = torch.where(mask_flatten, fg.min(), fg)
     return foreground_inds, fg

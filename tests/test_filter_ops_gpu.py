@@ -241,3 +241,81 @@ def test_salience_head_is_deterministic_and_rejects_bad_input():
         ref = small.cpu()(xs.cpu())
         got = small.to(DEV)(xs)
     assert (got.cpu() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prefix_row_movers_match_gather_scatter_semantics(dtype):
+    """advance_rows / select_stack / encoder_finalize against the reference's gather / scatter formulation
+    (salience_transformer.py:366-376, 454-495), incl. images whose focus count is below the layer's row count."""
+    B, S, C, n0 = 3, 500, 256, 300
+    counts = [300, 240, 120]
+    torch.manual_seed(5)
+    tokens = syn.det_randn("pt", (B, S, C)).to(dtype)
+    perm = torch.stack([torch.randperm(S)[:n0] for _ in range(B)])
+    focus = torch.tensor([300, 200, 90])
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[1, 400:] = True
+    pad[2, 100:160] = True
+    bg = syn.det_randn("pbg", (S, C)).to(dtype)
+    outs = [syn.det_randn(f"py{k}", (B, c, C)).to(dtype) for k, c in enumerate(counts)]
+
+    # reference formulation on the CPU: scatter every layer's live rows into token space, gather the next layer
+    ref_out = tokens.clone()
+    ref_next = []
+    for k, c in enumerate(counts):
+        for b in range(B):
+            live = min(c, int(focus[b]))
+            ref_out[b, perm[b, :live]] = outs[k][b, :live]
+        if k + 1 < len(counts):
+            ref_next.append(torch.stack([ref_out[b, perm[b, :counts[k + 1]]] for b in range(B)]))
+    keep = torch.ones(B, S)
+    keep.scatter_(1, perm[:, :counts[-1]], 0.0)
+    keep = keep * (~pad)
+    ref_final = (ref_out.float() + bg.float().unsqueeze(0) * keep.unsqueeze(-1)).to(dtype)
+
+    tok_d, perm_d, focus_d = tokens.to(DEV), perm.to(DEV), focus.to(DEV)
+    result = torch.zeros(B, n0, C, dtype=dtype, device=DEV)
+    for k, c in enumerate(counts):
+        nxt_rows = counts[k + 1] if k + 1 < len(counts) else 0
+        nxt = F.advance_rows(outs[k].to(DEV), result, nxt_rows, tok_d, perm_d, focus_d)
+        if nxt_rows:
+            assert torch.equal(nxt.cpu(), ref_next[k])
+        else:
+            assert nxt is None
+    final = F.encoder_finalize(tok_d, result, perm_d, focus_d, bg.to(DEV), pad.to(DEV), counts[-1])
+    assert torch.equal(final.cpu(), ref_final)
+    # without a count every row is live
+    r2 = torch.zeros(B, n0, C, dtype=dtype, device=DEV)
+    n2 = F.advance_rows(outs[1].to(DEV), r2, 100, tok_d, perm_d, None)
+    assert torch.equal(n2.cpu(), outs[1][:, :100]) and torch.equal(r2[:, :240].cpu(), outs[1])
+
+    # select_stack: query is a [B,c,C] buffer, pos a row prefix of a longer sorted buffer
+    q = outs[1].to(DEV)
+    pos_long = syn.det_randn("ppos", (B, n0, C)).to(dtype).to(DEV)
+    sel = torch.stack([torch.randperm(240)[:37] for _ in range(B)]).to(DEV)
+    st = F.select_stack(q, pos_long[:, :240], sel)
+    qs = torch.stack([q[b, sel[b]] for b in range(B)])
+    ps = torch.stack([pos_long[b, sel[b]] for b in range(B)])
+    assert torch.equal(st[:, 37:], qs) and torch.equal(st[:, :37], qs + ps)
+    # gather_rows from a row prefix; class_max_times with a strided scale
+    g = F.gather_rows(pos_long[:, :240], sel)
+    assert torch.equal(g, ps)
+    score = syn.det_randn("pcs", (B, 240, 91)).to(dtype).to(DEV)
+    fg_long = syn.det_randn("pfg", (B, n0)).to(DEV)
+    got = F.class_max_times(score, fg_long[:, :240])
+    assert torch.equal(got, score.float().max(-1)[0] * fg_long[:, :240])
+
+
+def test_layer_norm_scatter_destination():
+    B, n, m, C = 2, 37, 200, 256
+    x = syn.det_randn("lsx", (B, 2 * n, C)).to(DEV)
+    r = syn.det_randn("lsr", (B, n, C)).to(DEV)
+    norm = torch.nn.LayerNorm(C).to(DEV)
+    idx = torch.stack([torch.randperm(m)[:n] for _ in range(B)]).to(DEV)
+    dst = syn.det_randn("lsd", (B, m, C)).to(DEV)
+    want = dst.clone()
+    plain = F.fused_layer_norm(x[:, n:], norm, residual=r)
+    for b in range(B):
+        want[b, idx[b]] = plain[b]
+    out = F.fused_layer_norm(x[:, n:], norm, residual=r, scatter_index=idx, scatter_into=dst)
+    assert out is dst and torch.equal(dst, want)

@@ -171,3 +171,23 @@ def test_autograd_path_matches_native_and_oracle_grads():
         ref = sd[name].grad
         tol = 2e-3 * max(1.0, ref.abs().max().item())
         assert (got - ref).abs().max().item() < tol, name
+
+
+@pytest.mark.parametrize("tag", ["single", "mixed"])
+def test_sorted_order_loop_equals_token_space_loop(tag):
+    """The encoder keeps the tokens in sorted order across layers when the per-layer index sets are prefix views
+    of one sorted list; with independent index tensors it runs the reference's gather / scatter formulation.
+    Same arithmetic per row -> same memory."""
+    d, m, feats, masks, pos, layers = _small(tag)
+    with torch.no_grad():
+        memory, _, aux = m(feats, masks, pos, return_aux=True)
+        enc = m.encoder
+        assert enc._prefix_counts(aux["foreground_inds"]) is not None
+        copies = [t.clone() for t in aux["foreground_inds"]]
+        assert enc._prefix_counts(copies) is None
+        general = enc(query=aux["feat_flatten"], query_pos=aux["lvl_pos_embed_flatten"],
+                      query_key_padding_mask=aux["mask_flatten"], spatial_shapes=aux["spatial_shapes"],
+                      level_start_index=aux["level_start_index"], valid_ratios=aux["valid_ratios"],
+                      foreground_score=aux["foreground_score"], focus_token_nums=aux["focus_token_nums"],
+                      foreground_inds=copies, multi_level_masks=masks)
+    assert (general - memory).abs().max().item() <= 2e-5
