@@ -277,6 +277,24 @@ int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, cons
                                const float *weight4, const float *bias4, float *const_workspace, float *score,
                                float *score_flat, int64_t score_flat_stride);
 
+/* ---- (7) the encoder layer's feed-forward block, fused ----------------------------------------------------------
+ * out = LayerNorm(x + W2 relu(W1 x + b1) + b2)   (models/bricks/salience_transformer.py:347-351 forward_ffn with the
+ * released configuration: ReLU, embed_dim 256), bf16 activations and weights, fp32 accumulation / bias / LayerNorm.
+ * The [tokens, hidden] intermediate never leaves the register file.
+ *   sdetr_ffn_packed_bytes: size of the packed weight buffer for `hidden` units (hidden/32 chunks of 32 KiB).
+ *   sdetr_ffn_pack_bf16: weight1 [hidden, 256] (linear1.weight), weight2 [256, hidden] (linear2.weight), bf16
+ *     row-major -> packed: per 32 hidden units 16 W1 MFMA A-fragments (k-steps) then 16 W2 fragments
+ *     ((e-tile, k-block), contraction index permuted to the accumulator layout), 1 KiB each, lane-ordered.
+ *     Do it once per weight version.
+ *   sdetr_ffn_fused_bf16: x, out [tokens, 256] bf16 contiguous (out may not alias x); bias1 [hidden], bias2,
+ *     norm_weight, norm_bias [256] fp32. */
+int64_t sdetr_ffn_packed_bytes(int hidden);
+int sdetr_ffn_pack_bf16(sdetr_stream_t stream, const void *weight1, const void *weight2, int embed_dim, int hidden,
+                        void *packed);
+int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights, const float *bias1,
+                         const float *bias2, const float *norm_weight, const float *norm_bias, float norm_eps,
+                         int tokens, int embed_dim, int hidden, void *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,9 +51,14 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f)
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// two floats -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays
+// NaN -- the rule of f32_to_bf16_bits above, without its compare / select chain)
+typedef float f32x2_vec_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_vec_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    const f32x2_vec_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_vec_t));
 }
 
 // ---- IEEE fp16 storage (distinct C++ type so templates can tell it from bf16) -----------------

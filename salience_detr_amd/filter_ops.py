@@ -383,3 +383,46 @@ def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor
             _hip.dtype_code(tokens.dtype), out.data_ptr())
     _hip.check(code, "encoder_finalize")
     return out
+
+
+def fused_ffn_applies(x: Tensor, linear1, linear2, norm, activation) -> bool:
+    """The one-launch MFMA feed-forward (csrc/ffn.hip) covers the released configuration: bf16, embed_dim 256, ReLU,
+    hidden a multiple of 32 that fits its LDS budget.  Its run time is flat in the token count (one 32-token wave per
+    SIMD, ~68 us at hidden 2048 on MI355X); below ~6000 tokens the two library GEMMs are faster."""
+    return (x.numel() >= 6000 * 256 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and isinstance(activation, torch.nn.ReLU)
+            and linear1.weight.dtype == torch.bfloat16 and linear2.weight.dtype == torch.bfloat16
+            and linear1.in_features == 256 and linear2.out_features == 256
+            and linear1.out_features == linear2.in_features and linear1.out_features % 32 == 0
+            and linear1.out_features <= 8192 and linear1.bias is not None and linear2.bias is not None)
+
+
+def fused_ffn(x: Tensor, linear1, linear2, norm) -> Tensor:
+    """``norm(x + linear2(relu(linear1(x))))`` in one launch (include/salience_hip.h (7)).  The packed weights and
+    fp32 copies of the small vectors live on ``linear1.weight`` and are refreshed when any parameter changes."""
+    if not x.is_cuda:
+        raise RuntimeError("fused_ffn: HIP device tensors required; there is no CPU fallback")
+    params = (linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias)
+    tag = tuple((t.data_ptr(), t._version) for t in params) + (str(x.device),)
+    cache = linear1.weight.__dict__.get("_sdetr_ffn")
+    lib = _hip.lib()
+    F = linear1.out_features
+    if cache is None or cache[0] != tag:
+        with torch.no_grad(), torch.cuda.device(x.device):
+            packed = torch.empty(lib.sdetr_ffn_packed_bytes(F), dtype=torch.uint8, device=x.device)
+            w1, w2 = linear1.weight.detach().contiguous(), linear2.weight.detach().contiguous()
+            code = lib.sdetr_ffn_pack_bf16(_hip.stream_ptr(), w1.data_ptr(), w2.data_ptr(), 256, F, packed.data_ptr())
+            _hip.check(code, "ffn_pack")
+            small = [t.detach().float().contiguous() for t in (linear1.bias, linear2.bias, norm.weight, norm.bias)]
+        cache = (tag, packed, small)
+        linear1.weight.__dict__["_sdetr_ffn"] = cache
+    _, packed, (b1, b2, g, be) = cache
+    x2 = x.reshape(-1, 256)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    out = torch.empty_like(x2)
+    with torch.cuda.device(x.device):
+        code = lib.sdetr_ffn_fused_bf16(_hip.stream_ptr(), x2.data_ptr(), packed.data_ptr(), b1.data_ptr(),
+                                        b2.data_ptr(), g.data_ptr(), be.data_ptr(), float(norm.eps), x2.shape[0], 256, F,
+                                        out.data_ptr())
+    _hip.check(code, "ffn_fused")
+    return out.view(x.shape)

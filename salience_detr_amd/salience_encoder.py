@@ -25,8 +25,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import (advance_rows, class_max_times, encoder_finalize, fused_layer_norm, gather_rows,
-                         masked_topk_desc, scatter_rows_, select_stack)
+from .filter_ops import (advance_rows, class_max_times, encoder_finalize, fused_ffn, fused_ffn_applies,
+                         fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_, select_stack)
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -81,6 +81,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
     def _forward_ffn_native(self, query):
         """No-grad FFN: ReLU in the first GEMM's epilogue when the activation is ReLU, residual + LayerNorm in
         one launch."""
+        if fused_ffn_applies(query, self.linear1, self.linear2, self.norm2, self.activation):
+            return fused_ffn(query, self.linear1, self.linear2, self.norm2)   # hidden state stays in registers
         if isinstance(self.activation, nn.ReLU):
             x2d = query.reshape(-1, query.shape[-1])
             try:
