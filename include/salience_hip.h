@@ -295,6 +295,33 @@ int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packe
                          const float *bias2, const float *norm_weight, const float *norm_bias, float norm_eps,
                          int tokens, int embed_dim, int hidden, void *out);
 
+/* ---- (8) token-resident linear layers (256 input features, bf16) -------------------------------------------------
+ * y = W x + b with the activations of 32 tokens resident in a wave's registers and the weights streamed through
+ * LDS; the output tile (32 features) is consumed from registers by one of three epilogues.  fp32 accumulation.
+ *   sdetr_linear_packed_bytes / sdetr_linear_pack_bf16: weight [out_features, 256] bf16 (row stride in elements)
+ *     -> per 32 output features 16 lane-ordered 1 KiB MFMA A-fragments (rows past out_features are zero).
+ *   bias_padded: fp32 [ceil(out_features/32)*32], zero past out_features.
+ *   sdetr_token_linear_bf16: out[t, :out_features] = bf16(W (x[t] (+ x_add[t])) + b), out row stride in elements;
+ *     x [tokens,256]; x_add (optional, e.g. the position embedding of salience_transformer.py:380-381) holds
+ *     rows_per_batch rows per image, images x_add_batch_stride elements apart.  Replaces the
+ *     sampling_offsets / attention_weights Linear of ms_deform_attn.py:322-329 (one 256 -> 384 call).
+ *   sdetr_value_proj_head_major: value_proj + masked_fill + head-major re-layout (ms_deform_attn.py:316-321) for
+ *     num_groups stacked projections: x [batch*spatial, 256] -> dst [groups][batch][heads][spatial][32] fp16|bf16.
+ *   sdetr_class_head_max_times: out[b,i] = bf16(max_c (W x + b)[c]) * scale[b,i] -- mc_score of
+ *     salience_transformer.py:366 without materialising the class logits; scale images scale_batch_stride apart. */
+int64_t sdetr_linear_packed_bytes(int out_features);
+int sdetr_linear_pack_bf16(sdetr_stream_t stream, const void *weight, int64_t row_stride, int out_features,
+                           int in_features, void *packed);
+int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, const void *x_add, int64_t x_add_batch_stride,
+                            int rows_per_batch, int tokens, int in_features, const void *packed_weight,
+                            const float *bias_padded, int out_features, void *out, int64_t out_row_stride);
+int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x, const void *packed_weight,
+                                const float *bias_padded, const uint8_t *pad_mask, int batch_size, int spatial_size,
+                                int in_features, int num_heads, int channels, int num_groups, void *dst, int dst_dtype);
+int sdetr_class_head_max_times(sdetr_stream_t stream, const void *x, const void *packed_weight,
+                               const float *bias_padded, int in_features, int num_classes, const float *scale,
+                               int64_t scale_batch_stride, int batch_size, int rows_per_batch, float *out);
+
 #ifdef __cplusplus
 }
 #endif

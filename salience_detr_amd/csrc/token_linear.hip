@@ -1,0 +1,311 @@
+// Token-resident linear layers for 256-wide bf16 tokens:  y[t][n] = sum_k W[n][k] x[t][k] + b[n],  K = 256.
+//
+// Every projection of the encoder loop has this shape (value_proj of all six layers: N = 1536;
+// sampling_offsets|attention_weights: N = 384; class head: N = 91) with M = 10^4..10^5 tokens.  A library GEMM
+// treats them as generic [M,256]x[256,N] problems, writes y row-major, and a second kernel then re-lays / reduces
+// it.  Here a wave keeps 32 tokens' activations X^T in 64 VGPRs (the B operands of v_mfma_f32_32x32x16_bf16) for
+// the whole kernel and walks the output features in tiles of 32: Y^T[32 x 32] = W[tile] X^T is 16 MFMAs whose
+// accumulator STARTS as the bias, and the epilogue consumes the tile straight from registers:
+//
+//   kStore      bf16 row-major store (lane (t,h) holds features 8g+4h+{0..3} of token t: 8-byte stores);
+//               optional prologue x = x + x2 (query + position embedding, salience_transformer.py:380-381)
+//   kHeadMajor  value_proj's tail (ms_deform_attn.py:316-321): zero the padded tokens, convert to fp16 / bf16 and
+//               store head-major [layer][B][head][pixel][32] -- a 32-feature tile IS one (layer, head), so the
+//               re-layout costs nothing and the [tokens, 1536] intermediate never exists
+//   kClassMax   mc_score (salience_transformer.py:366): running max over the class logits, times the foreground
+//               score -- the [tokens, 91] logits never exist
+//
+// Weights: pre-packed per tile into 16 lane-ordered 1 KB A-fragments (sdetr_linear_pack_bf16, rows past N are
+// zero), copied global -> LDS by LDS-DMA (inline asm + counted waits, see ffn.hip), triple-buffered, shared by the
+// block's four waves.  ~130 registers, 56 KB LDS: two to three blocks per CU hide the copy issue cost and the
+// barriers.  Bound: bf16 MFMA for N = 384 / 91, the 137 MB head-major store for value_proj.
+#include "common.h"
+
+namespace sdetr {
+
+constexpr int kTLK = 256;
+constexpr int kTLTileBytes = 16384;    // 32 output features x 256 k, as 16 1-KB A fragments
+constexpr int kTLTokWave = 32, kTLTokBlock = 128;
+
+typedef __bf16 tl_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float tl_f32x16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) const char *tl_lds_cptr_t;
+
+enum { kStore = 0, kHeadMajor = 1, kClassMax = 2 };
+
+struct TLArgs {
+    const bf16_t *x;          // [T, 256]
+    const bf16_t *x2;         // optional addend, rows_per_batch rows per image, images x2_batch_stride elements apart
+    int64_t x2_batch_stride;
+    int rows_per_batch;       // tokens per image (x2 / scale / head-major addressing)
+    const char *pw;           // packed weights, ntiles * 16 KB
+    const float *bias;        // [ntiles * 32] (zero padded)
+    int T, N, ntiles;
+    // kStore
+    bf16_t *out;
+    int64_t out_row_stride;
+    // kHeadMajor
+    const uint8_t *pad;       // [T] or NULL
+    void *hm;                 // [groups][B][M][rows_per_batch][32]
+    int heads, batch, hm_f16;
+    // kClassMax
+    const float *scale;       // [B, rows_per_batch] with batch stride
+    int64_t scale_batch_stride;
+    float *cmax;              // [T]
+};
+
+__device__ __forceinline__ tl_f32x16_t tl_mfma(uint4 a, uint4 b, tl_f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tl_bf16x8_t, a), __builtin_bit_cast(tl_bf16x8_t, b),
+                                                   c, 0, 0, 0);
+}
+
+// a wave's quarter (4 KB = 4 pieces of 1 KB) of one weight tile, global -> LDS
+__device__ __forceinline__ void tl_issue_tile(const char *tile, uint32_t voff, uint32_t dst_lds)
+{
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(dst_lds);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %2\n\t"
+                 "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %2 offset:3072"
+                 :
+                 : "v"(voff), "s"(d0), "s"(tile)
+                 : "memory", "m0");
+}
+
+__device__ __forceinline__ uint4 tl_lds_read16(tl_lds_cptr_t p)
+{
+    const u32x4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b)
+{
+    return pack_bf16x2(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
+}
+
+template <int EPI, bool ADD2>
+__global__ void __launch_bounds__(kBlock, 2) token_linear_kernel(TLArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *wbuf = lds;                                                   // 3 tile buffers
+    float *bs = reinterpret_cast<float *>(lds + 3 * kTLTileBytes);      // [ntiles * 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = lane & 31, h = lane >> 5;
+    const int tok = blockIdx.x * kTLTokBlock + wave * kTLTokWave + t;
+    const bool valid = tok < p.T;
+    const int tk = valid ? tok : p.T - 1;
+    const int img = tk / p.rows_per_batch, ri = tk - img * p.rows_per_batch;
+
+    const uint32_t wbuf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)wbuf;
+    const uint32_t voff = (uint32_t)(wave * 4096 + lane * 16);
+    const uint32_t wave_lds = wbuf_lds + wave * 4096;
+    tl_issue_tile(p.pw, voff, wave_lds);
+    if (p.ntiles > 1) tl_issue_tile(p.pw + kTLTileBytes, voff, wave_lds + kTLTileBytes);
+    for (int i = tid; i < p.ntiles * 32; i += kBlock) bs[i] = p.bias[i];
+
+    uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
+    {
+        const bf16_t *xr = p.x + (int64_t)tk * kTLK + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const uint4 *>(xr + 16 * ks);
+        if (ADD2) {
+            const bf16_t *x2r = p.x2 + (int64_t)img * p.x2_batch_stride + (int64_t)ri * kTLK + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(x2r + 16 * ks);
+                xb[ks] = make_uint4(add_bf16x2(xb[ks].x, o.x), add_bf16x2(xb[ks].y, o.y), add_bf16x2(xb[ks].z, o.z),
+                                    add_bf16x2(xb[ks].w, o.w));
+            }
+        }
+    }
+    // consume the loads here so that hipcc's wait for them is not placed inside the loop (it would drain the LDS
+    // copies it cannot see on every iteration)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
+
+    float run_max = -INFINITY;
+    const bool masked = EPI == kHeadMajor && p.pad && p.pad[tk];
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;
+    for (int nt = 0; nt < p.ntiles; ++nt) {
+        const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + buf * kTLTileBytes + lane * 16;
+        const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)bs + nt * 128 + 16 * h;
+        tl_f32x16_t acc;   // starts as the bias: registers 4g..4g+3 are features 8g + 4h + {0..3} of the tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 bv = tl_lds_read16(bb + 32 * g);
+            acc[4 * g] = __uint_as_float(bv.x);
+            acc[4 * g + 1] = __uint_as_float(bv.y);
+            acc[4 * g + 2] = __uint_as_float(bv.z);
+            acc[4 * g + 3] = __uint_as_float(bv.w);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = tl_mfma(tl_lds_read16(cb + ks * 1024), xb[ks], acc);
+
+        // tile nt+1 has landed for me, then for everyone; every wave is done with tile nt-1's buffer, which the copy
+        // of tile nt+2 overwrites
+        if (nt + 1 < p.ntiles) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (nt + 2 < p.ntiles) {
+                const int pbuf = buf == 0 ? 2 : buf - 1;
+                tl_issue_tile(p.pw + (int64_t)(nt + 2) * kTLTileBytes, voff, wave_lds + pbuf * kTLTileBytes);
+            }
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+
+        if (EPI == kStore) {
+            if (valid) {
+                bf16_t *o = p.out + (int64_t)tok * p.out_row_stride + nt * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (nt * 32 + 8 * g + 4 * h < p.N)   // N is a multiple of 4
+                        *reinterpret_cast<uint2 *>(o + 8 * g) =
+                            make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+            }
+        } else if (EPI == kHeadMajor) {
+            if (valid) {
+                const int grp = nt / p.heads, m = nt - grp * p.heads;
+                const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + m) * p.rows_per_batch + ri;
+                uint16_t *o = reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 v = make_uint2(0u, 0u);
+                    if (!masked)
+                        v = p.hm_f16 ? make_uint2(pack_f16x2(acc[4 * g], acc[4 * g + 1]), pack_f16x2(acc[4 * g + 2], acc[4 * g + 3]))
+                                     : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+                    *reinterpret_cast<uint2 *>(o + 8 * g) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (n < p.N) run_max = fmaxf(run_max, acc[i]);
+            }
+        }
+    }
+    if (EPI == kClassMax) {
+        run_max = fmaxf(run_max, __shfl_xor(run_max, 32));
+        if (valid && h == 0) {
+            // the logits are bf16 in the reference (round is monotone: max of the rounded = rounded max)
+            const float mx = bf16_lo(pack_bf16x2(run_max, 0.f));
+            p.cmax[tok] = mx * p.scale[(int64_t)img * p.scale_batch_stride + ri];
+        }
+    }
+}
+
+// packed[nt][ks][lane = h*32 + j][s] = W[32nt + j][16ks + 8h + s]   (zero for rows >= N)
+__global__ void linear_pack_kernel(const bf16_t *w, int64_t row_stride, int N, int ntiles, bf16_t *out)
+{
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (int64_t)ntiles * 8192) return;
+    const int nt = (int)(o >> 13), idx = (int)(o & 8191);
+    const int s = idx & 7, l = (idx >> 3) & 63, ks = idx >> 9;
+    const int n = 32 * nt + (l & 31);
+    out[o] = n < N ? w[(int64_t)n * row_stride + 16 * ks + 8 * (l >> 5) + s] : (bf16_t)0;
+}
+
+static int tl_launch(hipStream_t s, int epi, bool add2, TLArgs &a)
+{
+    const size_t lds = 3 * (size_t)kTLTileBytes + (size_t)a.ntiles * 128;
+    const dim3 grid((unsigned)((a.T + kTLTokBlock - 1) / kTLTokBlock)), block(kBlock);
+    if (epi == kStore && add2) hipLaunchKernelGGL((token_linear_kernel<kStore, true>), grid, block, lds, s, a);
+    else if (epi == kStore) hipLaunchKernelGGL((token_linear_kernel<kStore, false>), grid, block, lds, s, a);
+    else if (epi == kHeadMajor) hipLaunchKernelGGL((token_linear_kernel<kHeadMajor, false>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((token_linear_kernel<kClassMax, false>), grid, block, lds, s, a);
+    return check_launch("token_linear");
+}
+
+static int tl_common(TLArgs &a, const void *x, const void *packed, const float *bias, int tokens, int in_features,
+                     int out_features)
+{
+    if (in_features != kTLK) return fail("token_linear: built for 256 input features (got %d)", in_features);
+    if (tokens < 0 || out_features <= 0) return fail("token_linear: bad sizes");
+    if (!x || !packed || !bias) return fail("token_linear: null pointer");
+    a = TLArgs{};
+    a.x = (const bf16_t *)x; a.pw = (const char *)packed; a.bias = bias; a.T = tokens; a.N = out_features;
+    a.ntiles = (out_features + 31) / 32; a.rows_per_batch = tokens > 0 ? tokens : 1;
+    if ((size_t)a.ntiles * 128 + 3 * kTLTileBytes > 64 * 1024) return fail("token_linear: too many output features");
+    return 0;
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int64_t sdetr_linear_packed_bytes(int out_features)
+{
+    return out_features > 0 ? (int64_t)((out_features + 31) / 32) * kTLTileBytes : 0;
+}
+
+extern "C" int sdetr_linear_pack_bf16(sdetr_stream_t stream, const void *weight, int64_t row_stride, int out_features,
+                                      int in_features, void *packed)
+{
+    if (in_features != kTLK) return fail("linear_pack: built for 256 input features (got %d)", in_features);
+    if (out_features <= 0 || !weight || !packed || row_stride < kTLK) return fail("linear_pack: bad arguments");
+    const int ntiles = (out_features + 31) / 32;
+    const int64_t total = (int64_t)ntiles * 8192;
+    hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), (const bf16_t *)weight, row_stride, out_features, ntiles,
+                       (bf16_t *)packed);
+    return check_launch("linear_pack");
+}
+
+extern "C" int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, const void *x_add, int64_t x_add_batch_stride,
+                                       int rows_per_batch, int tokens, int in_features, const void *packed_weight,
+                                       const float *bias_padded, int out_features, void *out, int64_t out_row_stride)
+{
+    TLArgs a;
+    if (int rc = tl_common(a, x, packed_weight, bias_padded, tokens, in_features, out_features)) return rc;
+    if (tokens == 0) return 0;
+    if (!out || (out_features % 4) || out_row_stride < out_features || (out_row_stride % 4))
+        return fail("token_linear: out_features and the output row stride must be multiples of 4");
+    if (x_add) {
+        if (rows_per_batch <= 0 || tokens % rows_per_batch || x_add_batch_stride < (int64_t)rows_per_batch * kTLK ||
+            (x_add_batch_stride % 8))
+            return fail("token_linear: bad addend layout");
+        a.x2 = (const bf16_t *)x_add; a.x2_batch_stride = x_add_batch_stride; a.rows_per_batch = rows_per_batch;
+    }
+    a.out = (bf16_t *)out; a.out_row_stride = out_row_stride;
+    return tl_launch(static_cast<hipStream_t>(stream), kStore, x_add != nullptr, a);
+}
+
+extern "C" int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x, const void *packed_weight,
+                                           const float *bias_padded, const uint8_t *pad_mask, int batch_size,
+                                           int spatial_size, int in_features, int num_heads, int channels,
+                                           int num_groups, void *dst, int dst_dtype)
+{
+    if (channels != 32) return fail("value_proj_head_major: built for 32 channels per head (got %d)", channels);
+    if (batch_size < 0 || spatial_size < 0 || num_heads <= 0 || num_groups <= 0) return fail("value_proj_head_major: bad sizes");
+    if (dst_dtype != SDETR_F16 && dst_dtype != SDETR_BF16) return fail("value_proj_head_major: dst must be fp16 or bf16");
+    TLArgs a;
+    const int64_t tokens = (int64_t)batch_size * spatial_size;
+    if (tokens > 0x7fffffff) return fail("value_proj_head_major: too many tokens");
+    if (int rc = tl_common(a, x, packed_weight, bias_padded, (int)tokens, in_features, num_groups * num_heads * 32)) return rc;
+    if (tokens == 0) return 0;
+    if (!dst) return fail("value_proj_head_major: null pointer");
+    a.rows_per_batch = spatial_size; a.pad = pad_mask; a.hm = dst; a.heads = num_heads; a.batch = batch_size;
+    a.hm_f16 = dst_dtype == SDETR_F16;
+    return tl_launch(static_cast<hipStream_t>(stream), kHeadMajor, false, a);
+}
+
+extern "C" int sdetr_class_head_max_times(sdetr_stream_t stream, const void *x, const void *packed_weight,
+                                          const float *bias_padded, int in_features, int num_classes, const float *scale,
+                                          int64_t scale_batch_stride, int batch_size, int rows_per_batch, float *out)
+{
+    if (batch_size < 0 || rows_per_batch < 0) return fail("class_head_max_times: bad sizes");
+    TLArgs a;
+    const int64_t tokens = (int64_t)batch_size * rows_per_batch;
+    if (tokens > 0x7fffffff) return fail("class_head_max_times: too many tokens");
+    if (int rc = tl_common(a, x, packed_weight, bias_padded, (int)tokens, in_features, num_classes)) return rc;
+    if (tokens == 0) return 0;
+    if (!scale || !out || scale_batch_stride < rows_per_batch) return fail("class_head_max_times: bad scale / out");
+    a.rows_per_batch = rows_per_batch; a.scale = scale; a.scale_batch_stride = scale_batch_stride; a.cmax = out;
+    return tl_launch(static_cast<hipStream_t>(stream), kClassMax, false, a);
+}

@@ -426,3 +426,97 @@ def fused_ffn(x: Tensor, linear1, linear2, norm) -> Tensor:
                                         out.data_ptr())
     _hip.check(code, "ffn_fused")
     return out.view(x.shape)
+
+
+def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):
+    """(packed weight, zero-padded fp32 bias) of a ``[N,256]`` bf16 Linear for the token-resident kernels, cached on
+    the weight tensor object and refreshed when weight / bias storage or version change."""
+    tag = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version),
+           str(weight.device), tuple(weight.shape))
+    hit = weight.__dict__.get("_sdetr_tl")
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    lib = _hip.lib()
+    w = weight.detach()
+    N = w.shape[0]
+    npad = (N + 31) // 32 * 32
+    with torch.no_grad(), torch.cuda.device(w.device):
+        packed = torch.empty(lib.sdetr_linear_packed_bytes(N), dtype=torch.uint8, device=w.device)
+        code = lib.sdetr_linear_pack_bf16(_hip.stream_ptr(), w.data_ptr(), w.stride(0), N, w.shape[1], packed.data_ptr())
+        _hip.check(code, "linear_pack")
+        b = torch.zeros(npad, dtype=torch.float32, device=w.device)
+        if bias is not None:
+            b[:N] = bias.detach().float()
+    weight.__dict__["_sdetr_tl"] = (tag, packed, b)
+    return packed, b
+
+
+def token_linear_applies(x: Tensor, weight: Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] == 256
+            and weight.dim() == 2 and weight.shape[1] == 256 and weight.stride(1) == 1)
+
+
+def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optional[Tensor] = None) -> Tensor:
+    """``F.linear(x (+ x_add), weight, bias)`` for bf16 ``[B,n,256]`` tokens with the activations resident in
+    registers (include/salience_hip.h (8)); ``x_add`` may be a row prefix of a longer ``[B,n',256]`` buffer."""
+    if not token_linear_applies(x, weight):
+        raise RuntimeError("token_linear: bf16 HIP tensors with 256 input features expected; no CPU fallback")
+    shape = x.shape
+    x3 = x if x.dim() == 3 else x.reshape(1, -1, 256)
+    if not x3.is_contiguous():
+        x3 = x3.contiguous()
+    B, n, _ = x3.shape
+    N = weight.shape[0]
+    if N % 4:
+        raise RuntimeError("token_linear: out_features must be a multiple of 4")
+    packed, b = _packed_linear_bf16(weight, bias)
+    out = torch.empty((B, n, N), dtype=torch.bfloat16, device=x.device)
+    abs_ = 0
+    if x_add is not None:
+        if x_add.dtype != torch.bfloat16 or tuple(x_add.shape) != (B, n, 256):
+            raise RuntimeError("token_linear: x_add must match x")
+        abs_ = _batch_stride(x_add, "token_linear")
+    with torch.cuda.device(x.device):
+        code = _hip.lib().sdetr_token_linear_bf16(_hip.stream_ptr(), x3.data_ptr(), _hip.ptr(x_add), abs_, n, B * n, 256,
+                                                  packed.data_ptr(), b.data_ptr(), N, out.data_ptr(), N)
+    _hip.check(code, "token_linear")
+    return out.view(tuple(shape[:-1]) + (N,))
+
+
+def value_proj_head_major(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],
+                          num_heads: int, num_groups: int, dtype: torch.dtype) -> Tensor:
+    """``value_proj`` of ``num_groups`` stacked layers + ``masked_fill`` + head-major re-layout in one launch:
+    value ``[B,Nv,256]`` bf16, weight ``[groups*heads*32, 256]`` -> ``[groups,B,heads,Nv,32]`` fp16 | bf16."""
+    if not token_linear_applies(value, weight) or weight.shape[0] != num_groups * num_heads * 32:
+        raise RuntimeError("value_proj_head_major: bf16 [B,Nv,256] tokens and 32-channel heads expected")
+    _hip.require_device("value_proj_head_major", value=value, padding_mask=padding_mask)
+    B, Nv, _ = value.shape
+    packed, b = _packed_linear_bf16(weight, bias)
+    pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
+                                             else padding_mask)
+    dst = torch.empty((num_groups, B, num_heads, Nv, 32), dtype=dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        code = _hip.lib().sdetr_value_proj_head_major(
+            _hip.stream_ptr(), value.data_ptr(), packed.data_ptr(), b.data_ptr(), _hip.ptr(pad), B, Nv, 256, num_heads,
+            32, num_groups, dst.data_ptr(), _hip.dtype_code(dtype))
+    _hip.check(code, "value_proj_head_major")
+    return dst
+
+
+def class_head_max_times(x: Tensor, class_head, scale: Tensor) -> Tensor:
+    """``class_head(x).max(-1)[0] * scale`` (mc_score, salience_transformer.py:365-366) without the logits:
+    x ``[B,n,256]`` bf16, scale ``[B,n]`` fp32 (may be a row prefix of a longer buffer) -> fp32 ``[B,n]``."""
+    if not token_linear_applies(x, class_head.weight) or x.dim() != 3:
+        raise RuntimeError("class_head_max_times: bf16 [B,n,256] HIP tokens expected; no CPU fallback")
+    _hip.require_device("class_head_max_times", x=x)
+    B, n, _ = x.shape
+    if scale.dtype != torch.float32 or scale.dim() != 2 or (n > 1 and scale.stride(1) != 1) or not scale.is_cuda:
+        scale = scale.float().contiguous()
+    packed, b = _packed_linear_bf16(class_head.weight, class_head.bias)
+    out = torch.empty((B, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib().sdetr_class_head_max_times(
+            _hip.stream_ptr(), x.data_ptr(), packed.data_ptr(), b.data_ptr(), 256, class_head.out_features,
+            scale.data_ptr(), scale.stride(0) if B > 1 else max(n, 1), B, n, out.data_ptr())
+    _hip.check(code, "class_head_max_times")
+    return out

@@ -369,9 +369,16 @@ class MultiScaleDeformableAttention(nn.Module):
     tiled_min_queries_per_region = None
 
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
-                       level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None) -> Tensor:
+                       level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None,
+                       query_pos: Optional[Tensor] = None) -> Tensor:
+        """``query_pos`` (optional): position embedding still to be added to ``query`` -- folded into the projection
+        kernel's prologue on the bf16 path."""
+        from .filter_ops import token_linear, token_linear_applies
         w, b = self._fused_query_projection()
-        proj = F.linear(query, w, b)
+        if token_linear_applies(query, w) and query.dim() == 3:
+            proj = token_linear(query, w, b, x_add=query_pos)
+        else:
+            proj = F.linear(query if query_pos is None else query + query_pos, w, b)
         use_tiled = False
         if (level0_hw is not None and self.tiled_min_queries_per_region is not None
                 and tiled_supported(value_hm, self.num_levels, self.num_points)):

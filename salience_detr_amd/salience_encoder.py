@@ -25,8 +25,9 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import (advance_rows, class_max_times, encoder_finalize, fused_ffn, fused_ffn_applies,
-                         fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_, select_stack)
+from .filter_ops import (advance_rows, class_head_max_times, class_max_times, encoder_finalize, fused_ffn,
+                         fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
+                         select_stack, token_linear_applies, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -127,21 +128,24 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
-                       score_tgt):
+                       class_head):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
         sorted-order buffers of which the first ``c`` rows belong to this layer.  Same arithmetic as ``forward``."""
         c = query.shape[1]
-        mc_score = class_max_times(score_tgt, fg_sorted[:, :c])
+        if token_linear_applies(query, class_head.weight):
+            mc_score = class_head_max_times(query, class_head, fg_sorted[:, :c])   # logits never materialised
+        else:
+            mc_score = class_max_times(class_head(query), fg_sorted[:, :c])
         sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
         N = sel.shape[1]
         stacked = select_stack(query, pos_sorted, sel)                       # [q+pos ; q] rows, [B,2N,E]
         tgt2 = self._pre_attention_stacked(stacked, N)
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
         fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
-        src2 = self.self_attn.forward_native(query + pos_sorted[:, :c], ref_sorted[:, :c], value_hm, spatial_shapes,
-                                             level_start_index)
+        src2 = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes, level_start_index,
+                                             query_pos=pos_sorted[:, :c])
         return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2))
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
@@ -280,11 +284,17 @@ class SalienceTransformerEncoder(nn.Module):
         if native:
             heads = self.layers[0].self_attn.num_heads
             w_all, b_all = self._all_value_projections()
-            v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
-            vdt = self.layers[0].self_attn.value_dtype or v_all.dtype
-            value_hm_all = value_to_head_major(v_all, query_key_padding_mask, heads, vdt, num_groups=self.num_layers)
-            if self.num_layers == 1:
-                value_hm_all = value_hm_all[None]
+            vdt = self.layers[0].self_attn.value_dtype or value.dtype
+            if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
+                    and value.is_contiguous()):
+                # projection, padding mask, 16-bit conversion and head-major layout in one launch
+                value_hm_all = value_proj_head_major(value, w_all, b_all, query_key_padding_mask, heads,
+                                                     self.num_layers, vdt)
+            else:
+                v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
+                value_hm_all = value_to_head_major(v_all, query_key_padding_mask, heads, vdt, num_groups=self.num_layers)
+                if self.num_layers == 1:
+                    value_hm_all = value_hm_all[None]
 
         counts = self._prefix_counts(foreground_inds) if native else None
         if counts is not None:
@@ -301,7 +311,7 @@ class SalienceTransformerEncoder(nn.Module):
                 if self.layer_marker is not None:
                     self.layer_marker(layer_id)
                 y = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
-                                         level_start_index, self.enhance_mcsp(q))
+                                         level_start_index, self.enhance_mcsp)
                 nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
                 q = advance_rows(y, result, nxt, value, sorted_index, focus64)
             if self.layer_marker is not None:

@@ -347,3 +347,58 @@ def test_fused_ffn_matches_fp32_reference(T, hidden):
     err, base_err = (got - ref).abs().max().item(), (base - ref).abs().max().item()
     assert err <= max(1.5 * base_err, 0.03), (err, base_err)
     assert (got - ref).abs().mean().item() <= 6e-3
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,n", [(1, 1), (2, 31), (2, 128), (3, 333), (2, 4545)])
+def test_token_linear_kernels_match_framework_bf16_path(B, n):
+    """Token-resident linear kernels vs the framework's own bf16 ops on the same rounded parameters; the fp32
+    evaluation of the same block bounds both."""
+    torch.manual_seed(B * 1000 + n)
+    x = _bf(syn.det_randn(f"tlx{n}", (B, n, 256)) * 1.3).to(DEV)
+    long_pos = _bf(syn.det_randn(f"tlp{n}", (B, n + 7, 256))).to(DEV)
+    pos = long_pos[:, :n]
+    lin = torch.nn.Linear(256, 384).to(DEV).to(torch.bfloat16)
+    lin.bias.data = _bf(syn.det_randn("tlb", (384,))).to(DEV)
+    with torch.no_grad():
+        # plain and with the fused addend
+        got = F.token_linear(x, lin.weight, lin.bias)
+        ref32 = torch.nn.functional.linear(x.float(), lin.weight.float(), lin.bias.float())
+        assert (got.float() - ref32).abs().max().item() <= 0.02 * (ref32.abs().max().item() + 1)
+        got2 = F.token_linear(x, lin.weight, lin.bias, x_add=pos)
+        ref2 = torch.nn.functional.linear((x + pos).float(), lin.weight.float(), lin.bias.float())
+        assert (got2.float() - ref2).abs().max().item() <= 0.02 * (ref2.abs().max().item() + 1)
+        # class head + max * scale
+        head = torch.nn.Linear(256, 91).to(DEV).to(torch.bfloat16)
+        head.bias.data = _bf(syn.det_randn("tlc", (91,)) - 2.0).to(DEV)
+        fg_long = syn.det_randn(f"tlf{n}", (B, n + 5)).to(DEV)
+        mc = F.class_head_max_times(x, head, fg_long[:, :n])
+        logits32 = torch.nn.functional.linear(x.float(), head.weight.float(), head.bias.float())
+        want = _bf(logits32.max(-1)[0]).float() * fg_long[:, :n]
+        assert (mc - want).abs().max().item() <= 0.02 * (want.abs().max().item() + 1)
+        frame = F.class_max_times(head(x), fg_long[:, :n])
+        assert (mc - frame).abs().max().item() <= 0.02 * (want.abs().max().item() + 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_value_proj_head_major_matches_two_step_path(dtype):
+    from salience_detr_amd.ms_deform_attn import value_to_head_major
+    B, Nv, heads, groups = 2, 1234, 8, 3
+    value = _bf(syn.det_randn("vpx", (B, Nv, 256))).to(DEV)
+    w = _bf(syn.det_randn("vpw", (groups * 256, 256)) * 0.06).to(DEV)
+    b = _bf(syn.det_randn("vpb", (groups * 256,))).to(DEV)
+    pad = torch.zeros(B, Nv, dtype=torch.bool, device=DEV)
+    pad[1, 1000:] = True
+    with torch.no_grad():
+        got = F.value_proj_head_major(value, w, b, pad, heads, groups, dtype)
+        ref32 = torch.nn.functional.linear(value.float(), w.float(), b.float()).masked_fill(pad[..., None], 0.0)
+        want = ref32.view(B, Nv, groups, heads, 32).permute(2, 0, 3, 1, 4)
+        two_step = value_to_head_major(torch.nn.functional.linear(value, w, b), pad, heads, dtype, num_groups=groups)
+    assert got.shape == (groups, B, heads, Nv, 32) and got.dtype == dtype
+    tol = 0.02 * (want.abs().max().item() + 1)
+    assert (got.float() - want).abs().max().item() <= tol
+    assert (got.float() - two_step.float()).abs().max().item() <= tol
+    assert (got[:, 1, :, 1000:] == 0).all()
