@@ -150,19 +150,22 @@ int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, i
  *     models/bricks/salience_transformer.py:146-150 (per-level top-k with
  *     masked_fill(mask, score.min())), :156-158 (global sort + index gather) and :366-367
  *     (per-layer top-300).
- *   score [B,N] f32; mask [B,N] bytes or NULL.  fill_mode 0: masked scores are left alone (mask
- *   must be NULL); 1: masked scores are replaced by min(score) over the WHOLE [B,N] array
- *   (computed in-kernel, masked entries included -- reference :146).
+ *   score [B,N] f32; mask [B,N] bytes (rows mask_row_stride bytes apart, 0 = N) or NULL.  fill_mode 0: masked
+ *   scores are left alone (mask must be NULL); 1: masked scores are replaced by min(score) over the WHOLE
+ *   [B,N] array (computed here, masked entries included -- reference :146); 2: by the device scalar
+ *   *fill_value (e.g. the minimum sdetr_salience_head_stage2 already produced).
  *   payload [B,N] int64 or NULL: out_index[b][j] = payload[b][pos] if given, else pos+index_offset.
- *   out_score [B,k] f32 (may be NULL), out_index [B,k] int64.
+ *   out_score [B,k] f32 (may be NULL), out_index [B,k] int64, rows out_row_stride elements apart (0 = k) so that
+ *   several calls can fill column blocks of one buffer (the concatenation of :155).
  *   workspace: device scratch of at least sdetr_topk_workspace_bytes(B,N,k) bytes (may be NULL
  *   when that returns 0, i.e. whenever the problem fits the in-LDS path).
  * ------------------------------------------------------------------------------------------- */
 size_t sdetr_topk_workspace_bytes(int batch_size, int n, int k);
 int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
-                               int fill_mode, const int64_t *payload, int batch_size, int n, int k,
+                               int64_t mask_row_stride, int fill_mode, const float *fill_value,
+                               const int64_t *payload, int batch_size, int n, int k,
                                int64_t index_offset, float *out_score, int64_t *out_index,
-                               void *workspace, size_t workspace_bytes);
+                               int64_t out_row_stride, void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * (5) Token row movement of the encoder loop (models/bricks/salience_transformer.py:454-461
@@ -209,7 +212,8 @@ int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens, const void
  *     (models/bricks/base_transformer.py:22-33) and the token validity of gen_encoder_output_proposals
  *     (:74-112): NCHW feat/pos -> token-major feat_out, pos_out (= pos + level_embed),
  *     sum_out = (feat + pos_out) * keep (the input of enc_output), mask_out (flattened padding mask),
- *     optional bf16 copies.  mask [B,H,W] bytes (1 = padding); outputs are [B,S,C] / [B,S], this level
+ *     optional bf16 copies; feat_out / pos_out may be NULL when only the bf16 copies are wanted.  mask [B,H,W]
+ *     bytes (1 = padding); outputs are [B,S,C] / [B,S], this level
  *     occupying tokens [level_start, level_start + H*W).
  *   sdetr_class_max_times: out[b,i] = max_c score[b,i,c] * scale[b,i]  (mc_score of
  *     models/bricks/salience_transformer.py:366), score [batch,rows_per_batch,num_classes] f32|bf16 contiguous,
@@ -221,6 +225,15 @@ int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const 
                                 float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16,
                                 float *valid_ratio /* this level's (w,h) of image 0, or NULL */,
                                 int valid_ratio_stride /* floats between images */);
+/*   sdetr_masked_fill_min: out[i] = mask[i] ? min(mins[0..num_mins)) : score[i] -- foreground_score of
+ *     models/bricks/salience_transformer.py:164-168 from the per-level minima that are already known.
+ *   sdetr_encoder_reference_points: get_reference_points (:418-432) for the tokens index[b][i] (index NULL: token i):
+ *     out [batch, rows, num_levels, 2]; valid_ratios [batch, num_levels, 2]; shapes / level_start_index int64. */
+int sdetr_masked_fill_min(sdetr_stream_t stream, const float *score, const uint8_t *mask, const float *mins,
+                          int num_mins, int64_t total, float *out);
+int sdetr_encoder_reference_points(sdetr_stream_t stream, const float *valid_ratios, const int64_t *shapes,
+                                   const int64_t *level_start_index, const int64_t *index, int64_t index_batch_stride,
+                                   int batch_size, int rows, int num_levels, float *out);
 int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
                           int64_t scale_batch_stride, int batch_size, int rows_per_batch, int num_classes, float *out);
 
@@ -260,7 +273,8 @@ int sdetr_column_mean_f32(sdetr_stream_t stream, const float *x, int64_t batch_s
  *     score_flat != NULL, also score_flat[b * score_flat_stride + t]).  weight2 is layer2.0.weight [128, 256]
  *     (unpacked, its [:, 128:] half multiplies the mean), weight2_local_packed = pack(weight2[:, :128]),
  *     weight3_packed = pack(layer2.2.weight [64,128]), weight4 = layer2.4.weight [1,64];
- *     const_workspace: [batch, 128] floats of scratch. */
+ *     const_workspace: [batch, 128] floats of scratch; score_min (optional device scalar) receives the minimum
+ *     over all scores of the call -- the masked_fill value of salience_transformer.py:146-147. */
 int sdetr_pack_linear_f32(sdetr_stream_t stream, const float *weight, int64_t row_stride, int out_features,
                           int in_features, float *packed);
 int sdetr_salience_head_blocks(int batch_size, int tokens);
@@ -275,7 +289,7 @@ int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, cons
                                int tokens, const float *weight2, const float *bias2,
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,
                                const float *weight4, const float *bias4, float *const_workspace, float *score,
-                               float *score_flat, int64_t score_flat_stride);
+                               float *score_flat, int64_t score_flat_stride, float *score_min);
 
 /* ---- (7) the encoder layer's feed-forward block, fused ----------------------------------------------------------
  * out = LayerNorm(x + W2 relu(W1 x + b1) + b2)   (models/bricks/salience_transformer.py:347-351 forward_ffn with the

@@ -38,7 +38,9 @@ SIGNATURES = {
     "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i, _p, _i, _i, _i, _i64, _p, _p, _p, _sz]),
+    "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
+    "sdetr_masked_fill_min": (_i, [_p, _p, _p, _p, _i, _i64, _p]),
+    "sdetr_encoder_reference_points": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i]),
     "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _i, _i, _p]),
     "sdetr_layernorm": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i, ctypes.c_float, _i, _i, _i, _p, _i,
@@ -51,7 +53,7 @@ SIGNATURES = {
     "sdetr_salience_head_blocks": (_i, [_i, _i]),
     "sdetr_salience_head_stage1": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p]),
-    "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64]),
+    "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "sdetr_ffn_packed_bytes": (_i64, [_i]),
     "sdetr_ffn_pack_bf16": (_i, [_p, _p, _p, _i, _i, _p]),
     "sdetr_ffn_fused_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p]),

@@ -85,11 +85,14 @@ __global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
                               p.box_wh > 0.01f && p.box_wh < 0.99f;
             const float f = tf[tx][ty + 8 * r], q = tp[tx][ty + 8 * r];
             const int64_t o = ((int64_t)b * p.S + p.start + t) * p.C + c;
-            p.feat_out[o] = f;
-            p.pos_out[o] = q;
+            if (p.feat_out) p.feat_out[o] = f;
+            if (p.pos_out) p.pos_out[o] = q;
             p.sum_out[o] = keep ? f + q : 0.f;
-            if (p.feat_bf16) p.feat_bf16[o] = (bf16_t)f32_to_bf16_bits(f);
-            if (p.pos_bf16) p.pos_bf16[o] = (bf16_t)f32_to_bf16_bits(q);
+            // bf16 copies: even lanes store channel pairs (4-byte stores; C is even)
+            if (!(tx & 1) && c + 1 < p.C) {
+                if (p.feat_bf16) *reinterpret_cast<uint32_t *>(p.feat_bf16 + o) = pack_bf16x2(f, tf[tx + 1][ty + 8 * r]);
+                if (p.pos_bf16) *reinterpret_cast<uint32_t *>(p.pos_bf16 + o) = pack_bf16x2(q, tp[tx + 1][ty + 8 * r]);
+            }
             if (c == 0) p.mask_out[(int64_t)b * p.S + p.start + t] = pad ? 1 : 0;
         }
     }
@@ -122,9 +125,74 @@ __global__ void __launch_bounds__(256) class_max_times_kernel(const T *score, co
     }
 }
 
+// out = mask ? min(mins[0..L)) : score   (foreground_score of salience_transformer.py:164-168: the per-level
+// minima are already known, torch would re-reduce the whole [B,S] array)
+__global__ void __launch_bounds__(256) masked_fill_min_kernel(const float *score, const uint8_t *mask, const float *mins,
+                                                              int L, int64_t total, float *out)
+{
+    float m = mins[0];
+    for (int l = 1; l < L; ++l) m = fminf(m, mins[l]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = mask[i] ? m : score[i];
+}
+
+// reference points of the encoder (salience_transformer.py:418-432) for the tokens index[b][i] (or token i):
+// out[b][i][j] = ((x + 0.5) / (vr[b][l][0] * W_l), (y + 0.5) / (vr[b][l][1] * H_l)) * vr[b][j], l = the token's level
+__global__ void __launch_bounds__(256) reference_points_kernel(const float *vr, const int64_t *shapes, const int64_t *lsi,
+                                                               const int64_t *index, int64_t index_batch_stride, int B,
+                                                               int n, int L, float *out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (int64_t)B * n) return;
+    const int b = (int)(r / n), i = (int)(r - (int64_t)b * n);
+    const int64_t tok = index ? index[(int64_t)b * index_batch_stride + i] : i;
+    int l = 0;
+    for (int j = 1; j < L; ++j) l = tok >= lsi[j] ? j : l;
+    const int W = (int)shapes[2 * l + 1], H = (int)shapes[2 * l];
+    const int t = (int)(tok - lsi[l]);
+    const int y = t / W, x = t - y * W;
+    const float *v = vr + (int64_t)b * L * 2;
+    const float cx = ((float)x + 0.5f) / (v[2 * l] * (float)W), cy = ((float)y + 0.5f) / (v[2 * l + 1] * (float)H);
+    float *o = out + r * L * 2;
+    for (int j = 0; j < L; ++j) {
+        o[2 * j] = cx * v[2 * j];
+        o[2 * j + 1] = cy * v[2 * j + 1];
+    }
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
+
+extern "C" int sdetr_masked_fill_min(sdetr_stream_t stream, const float *score, const uint8_t *mask, const float *mins,
+                                     int num_mins, int64_t total, float *out)
+{
+    if (total < 0 || num_mins <= 0) return fail("masked_fill_min: bad sizes");
+    if (total == 0) return 0;
+    if (!score || !mask || !mins || !out) return fail("masked_fill_min: null pointer");
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(masked_fill_min_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), score,
+                       mask, mins, num_mins, total, out);
+    return check_launch("masked_fill_min");
+}
+
+extern "C" int sdetr_encoder_reference_points(sdetr_stream_t stream, const float *valid_ratios, const int64_t *shapes,
+                                              const int64_t *level_start_index, const int64_t *index,
+                                              int64_t index_batch_stride, int batch_size, int rows, int num_levels,
+                                              float *out)
+{
+    if (batch_size < 0 || rows < 0 || num_levels <= 0 || num_levels > kMaxLevels) return fail("reference_points: bad sizes");
+    if ((int64_t)batch_size * rows == 0) return 0;
+    if (!valid_ratios || !shapes || !level_start_index || !out) return fail("reference_points: null pointer");
+    if (index && index_batch_stride < rows) return fail("reference_points: index batch stride too small");
+    const int64_t total = (int64_t)batch_size * rows;
+    hipLaunchKernelGGL(reference_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), valid_ratios, shapes, level_start_index, index,
+                       index_batch_stride, batch_size, rows, num_levels, out);
+    return check_launch("reference_points");
+}
+
 
 extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const float *pos,
                                            const uint8_t *mask, const float *level_embed, int B, int C, int H, int W,
@@ -134,8 +202,9 @@ extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *f
 {
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || level < 0 || level_start < 0 || S < level_start + H * W)
         return fail("pyramid_flatten_level: bad dims");
-    if (!feat || !pos || !mask || !level_embed || !feat_out || !pos_out || !sum_out || !mask_out)
+    if (!feat || !pos || !mask || !level_embed || !sum_out || !mask_out)
         return fail("pyramid_flatten_level: null pointer");
+    if ((feat_bf16 || pos_bf16) && (C & 1)) return fail("pyramid_flatten_level: bf16 copies need an even channel count");
     if (B == 0) return 0;
     FlattenArgs a{};
     a.feat = feat; a.pos = pos; a.mask = mask; a.level_embed = level_embed;

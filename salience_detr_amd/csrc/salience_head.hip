@@ -348,8 +348,9 @@ __global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_
 constexpr int kConstGroups = 8;
 __global__ void __launch_bounds__(kHalf * kConstGroups) salience_head_const_kernel(const float *partial, int nblk, int n,
                                                                                    const float *w2, const float *b2,
-                                                                                   float *out)
+                                                                                   float *out, float *score_min)
 {
+    if (score_min && blockIdx.x == 0 && threadIdx.x == 0) *score_min = INFINITY;   // stage 2 takes the min into it
     __shared__ float part[kConstGroups][kHalf];
     __shared__ float mean[kHalf];
     const int b = blockIdx.x, j = threadIdx.x & (kHalf - 1), g = threadIdx.x / kHalf;
@@ -396,6 +397,7 @@ struct Stage2Args {
     const float *b3, *w4, *b4;
     float *score;           // [B, n]
     float *score2;          // optional second destination, row stride score2_stride (flattened score buffer)
+    float *score_min;       // optional device scalar: min over every score of the launch (initialised by const kernel)
     int64_t score2_stride;
     int n;
 };
@@ -457,10 +459,20 @@ __global__ void __launch_bounds__(kBlock, 2) salience_head_stage2_kernel(Stage2A
         }
     }
     __syncthreads();
+    float s = INFINITY;
     if (tid < nvalid) {
-        const float s = (red[0][tid] + red[1][tid]) + b4;
+        s = (red[0][tid] + red[1][tid]) + b4;
         p.score[(int64_t)b * p.n + t0 + tid] = s;
         if (p.score2) p.score2[(int64_t)b * p.score2_stride + t0 + tid] = s;
+    }
+    if (p.score_min && tid < kTM) {   // wave 0 holds the block's scores: min is order-independent, so atomics are exact
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fminf(s, __shfl_xor(s, o));
+        if (tid == 0) {
+            // float min through integer atomics: non-negative floats order like signed ints, negative ones reversed
+            if (s >= 0.f) atomicMin(reinterpret_cast<int *>(p.score_min), __float_as_int(s));
+            else atomicMax(reinterpret_cast<unsigned int *>(p.score_min), __float_as_uint(s));
+        }
     }
 }
 
@@ -566,7 +578,7 @@ extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_
                                           const float *weight2_local_packed, const float *weight3_packed,
                                           const float *bias3, const float *weight4, const float *bias4,
                                           float *const_workspace, float *score, float *score_flat,
-                                          int64_t score_flat_stride)
+                                          int64_t score_flat_stride, float *score_min)
 {
     if (batch_size < 0 || tokens < 0) return fail("salience_head_stage2: negative size");
     if (batch_size == 0 || tokens == 0) return 0;
@@ -577,7 +589,7 @@ extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(salience_head_const_kernel, dim3((unsigned)batch_size), dim3(kHalf * kConstGroups), 0, s,
                        partial_sums, sdetr_salience_head_blocks(batch_size, tokens), tokens, weight2, bias2,
-                       const_workspace);
+                       const_workspace, score_min);
     int rc = check_launch("salience_head_const");
     if (rc) return rc;
     Stage2Args a;
@@ -585,7 +597,7 @@ extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_
     a.w2a = reinterpret_cast<const float4 *>(weight2_local_packed);
     a.w3 = reinterpret_cast<const float4 *>(weight3_packed);
     a.b3 = bias3; a.w4 = weight4; a.b4 = bias4; a.score = score; a.score2 = score_flat;
-    a.score2_stride = score_flat_stride; a.n = tokens;
+    a.score2_stride = score_flat_stride; a.n = tokens; a.score_min = score_min;
     hipLaunchKernelGGL(salience_head_stage2_kernel, dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, a);
     return check_launch("salience_head_stage2");
 }

@@ -76,6 +76,7 @@ constexpr int kPreWaves = kPreThreads / 64;
 struct PrefilterArgs {
     const float *score;
     const uint8_t *mask;
+    int64_t mask_stride;
     const float *fill;
     int N, k;
     uint32_t *cand_key;   // [B][N]
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterAr
     __shared__ uint32_t thr_s;
     const int tid = threadIdx.x, b = blockIdx.x;
     const float *srow = p.score + (int64_t)b * p.N;
-    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.N : nullptr;
+    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
     const float fill = p.fill ? *p.fill : 0.f;
     const int chunk = (p.N + kPreThreads - 1) / kPreThreads;  // <= KPT
     const int lo = tid * chunk, hi = min(p.N, lo + chunk);
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterAr
 struct RankArgs {
     const float *score;
     const uint8_t *mask;
+    int64_t mask_stride;  // bytes between mask rows
     const float *fill;  // device scalar or NULL
     const int64_t *payload;
     // candidate mode (after topk_prefilter): keys / positions / count per row instead of raw scores
@@ -195,6 +197,7 @@ struct RankArgs {
     int64_t index_offset;
     float *out_score;
     int64_t *out_index;
+    int64_t out_stride;   // elements between output rows (>= k)
 };
 
 __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
     const int n_keys = cand ? p.cand_count[b] : p.N;  // length of the ranked list
     if (base >= n_keys) return;                        // uniform per workgroup
     const float *srow = p.score + (int64_t)b * p.N;
-    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.N : nullptr;
+    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
     const uint32_t *ckey = cand ? p.cand_key + (int64_t)b * p.N : nullptr;
     const float fill = p.fill ? *p.fill : 0.f;
     auto key_at = [&](int i) -> uint32_t {  // i < n_keys
@@ -285,8 +288,8 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
         const uint32_t r = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
         if (r < (uint32_t)p.k) {
             const int pos = cand ? (int)p.cand_pos[(int64_t)b * p.N + mypos] : mypos;
-            if (p.out_score) p.out_score[(int64_t)b * p.k + r] = undesc_bits(mine);
-            p.out_index[(int64_t)b * p.k + r] =
+            if (p.out_score) p.out_score[(int64_t)b * p.out_stride + r] = undesc_bits(mine);
+            p.out_index[(int64_t)b * p.out_stride + r] =
                 p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
         }
     }
@@ -311,20 +314,26 @@ extern "C" size_t sdetr_topk_workspace_bytes(int B, int n, int k)
 }
 
 extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
-                                          int fill_mode, const int64_t *payload, int B, int n, int k,
-                                          int64_t index_offset, float *out_score, int64_t *out_index, void *workspace,
-                                          size_t workspace_bytes)
+                                          int64_t mask_row_stride, int fill_mode, const float *fill_value,
+                                          const int64_t *payload, int B, int n, int k,
+                                          int64_t index_offset, float *out_score, int64_t *out_index,
+                                          int64_t out_row_stride, void *workspace, size_t workspace_bytes)
 {
+    if (out_row_stride == 0) out_row_stride = k;
+    if (out_row_stride < k) return fail("masked_topk: output row stride too small");
     if (B < 0 || n < 0 || k < 0) return fail("masked_topk: negative size");
     if (k > n) return fail("masked_topk: k (%d) out of range for a row of %d scores", k, n);
-    if (fill_mode != 0 && fill_mode != 1) return fail("masked_topk: bad fill_mode %d", fill_mode);
-    if (fill_mode == 0 && mask) return fail("masked_topk: a mask needs fill_mode 1");
+    if (fill_mode < 0 || fill_mode > 2) return fail("masked_topk: bad fill_mode %d", fill_mode);
+    if (fill_mode == 0 && mask) return fail("masked_topk: a mask needs a fill mode");
+    if (fill_mode == 2 && !fill_value) return fail("masked_topk: fill_mode 2 needs the device scalar fill_value");
+    if (mask && mask_row_stride == 0) mask_row_stride = n;
+    if (mask && mask_row_stride < n) return fail("masked_topk: mask row stride too small");
     if (B == 0 || k == 0) return 0;
     if (!score || !out_index) return fail("masked_topk: null pointer");
     if (n >= (1 << 30) || B > 65535) return fail("masked_topk: row too long / too many rows");
     RankArgs r{};
-    r.score = score; r.mask = mask; r.payload = payload; r.N = n; r.k = k;
-    r.index_offset = index_offset; r.out_score = out_score; r.out_index = out_index;
+    r.score = score; r.mask = mask; r.mask_stride = mask_row_stride; r.payload = payload; r.N = n; r.k = k;
+    r.index_offset = index_offset; r.out_score = out_score; r.out_index = out_index; r.out_stride = out_row_stride;
     if (fill_mode == 1) {
         if (!workspace || workspace_bytes < sizeof(float))
             return fail("masked_topk: needs %zu bytes of workspace, got %zu", sizeof(float), workspace_bytes);
@@ -332,6 +341,8 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
                            reinterpret_cast<float *>(workspace));
         if (int e = check_launch("topk_min")) return e;
         r.fill = reinterpret_cast<const float *>(workspace);
+    } else if (fill_mode == 2) {
+        r.fill = fill_value;
     }
     int ranked = n;
     if (use_prefilter(n, k)) {
@@ -339,7 +350,7 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
         if (!workspace || workspace_bytes < need)
             return fail("masked_topk: needs %zu bytes of workspace, got %zu", need, workspace_bytes);
         PrefilterArgs f{};
-        f.score = score; f.mask = mask; f.fill = r.fill; f.N = n; f.k = k;
+        f.score = score; f.mask = mask; f.mask_stride = mask_row_stride; f.fill = r.fill; f.N = n; f.k = k;
         f.cand_key = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(workspace) + 16);
         f.cand_pos = f.cand_key + (size_t)B * n;
         f.cand_count = reinterpret_cast<int32_t *>(f.cand_pos + (size_t)B * n);

@@ -9,7 +9,8 @@ from . import _hip
 
 
 def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_with_global_min: bool = False,
-                     payload: Optional[Tensor] = None, index_offset: int = 0, want_scores: bool = True):
+                     payload: Optional[Tensor] = None, index_offset: int = 0, want_scores: bool = True,
+                     fill_value: Optional[Tensor] = None, out=None):
     """Sorted-descending top-k per row with ties -> lower index first.
 
     ``score`` [B,N] fp32.  With ``mask`` (bool [B,N], True = masked) and ``fill_with_global_min`` the
@@ -17,8 +18,11 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
     does with ``masked_fill(mask, score.min())`` before ``topk`` (salience_transformer.py:146-150).
     Returns ``(values [B,k] or None, indices [B,k] int64)``; ``indices`` are ``payload[b, pos]`` when a
     payload is given (the index gather after the global sort, :156-158), else ``pos + index_offset``.
+    ``fill_value`` (one-element fp32 device tensor) supplies ``score.min()`` when the caller already has it;
+    ``mask`` may be a column slice of a wider ``[B,S]`` mask.  ``out = (scores, indices)``: column slices
+    ``[B,k]`` of wider buffers to write into (same row stride), instead of fresh tensors.
     """
-    _hip.require_device("masked_topk_desc", score=score, mask=mask, payload=payload)
+    _hip.require_device("masked_topk_desc", score=score, payload=payload, fill_value=fill_value)
     if score.dtype != torch.float32 or score.dim() != 2:
         raise RuntimeError("masked_topk_desc: score must be a 2-d float32 tensor")
     B, N = score.shape
@@ -28,21 +32,36 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
         raise RuntimeError(f"masked_topk_desc: selected index k out of range (k={k}, row length {N})")
     if mask is not None and not fill_with_global_min:
         raise RuntimeError("masked_topk_desc: a mask requires fill_with_global_min=True")
+    mask_stride = 0
     if mask is not None:
-        if mask.shape != score.shape:
-            raise RuntimeError("masked_topk_desc: mask shape mismatch")
+        if mask.shape != score.shape or not mask.is_cuda:
+            raise RuntimeError("masked_topk_desc: mask shape / device mismatch")
         mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        if N > 1 and mask.stride(1) != 1:
+            mask = mask.contiguous()
+        mask_stride = mask.stride(0) if B > 1 else N
     if payload is not None and (payload.dtype != torch.int64 or payload.shape != score.shape):
         raise RuntimeError("masked_topk_desc: payload must be int64 with score's shape")
-    out_score = torch.empty((B, k), dtype=torch.float32, device=score.device) if want_scores else None
-    out_index = torch.empty((B, k), dtype=torch.int64, device=score.device)
+    out_stride = 0
+    if out is not None:
+        out_score, out_index = out
+        if (tuple(out_index.shape) != (B, k) or out_index.dtype != torch.int64 or not out_index.is_cuda
+                or (k > 1 and out_index.stride(1) != 1)
+                or (out_score is not None and (tuple(out_score.shape) != (B, k) or out_score.dtype != torch.float32
+                                               or out_score.stride() != out_index.stride()))):
+            raise RuntimeError("masked_topk_desc: out must be ([B,k] fp32 | None, [B,k] int64) column slices of equal stride")
+        out_stride = out_index.stride(0) if B > 1 else k
+    else:
+        out_score = torch.empty((B, k), dtype=torch.float32, device=score.device) if want_scores else None
+        out_index = torch.empty((B, k), dtype=torch.int64, device=score.device)
     lib = _hip.lib()
     ws_bytes = lib.sdetr_topk_workspace_bytes(B, N, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=score.device) if ws_bytes else None
     with torch.cuda.device(score.device):
         code = lib.sdetr_masked_topk_desc_f32(
-            _hip.stream_ptr(), score.data_ptr(), _hip.ptr(mask), 1 if fill_with_global_min else 0,
-            _hip.ptr(payload), B, N, k, int(index_offset), _hip.ptr(out_score), out_index.data_ptr(),
+            _hip.stream_ptr(), score.data_ptr(), _hip.ptr(mask), mask_stride,
+            (2 if fill_value is not None else 1) if fill_with_global_min else 0, _hip.ptr(fill_value),
+            _hip.ptr(payload), B, N, k, int(index_offset), _hip.ptr(out_score), out_index.data_ptr(), out_stride,
             _hip.ptr(ws), ws_bytes)
     _hip.check(code, "masked_topk_desc")
     return out_score, out_index
@@ -98,14 +117,15 @@ def scatter_rows_(dst: Tensor, idx: Tensor, src: Tensor, count: Optional[Tensor]
 
 
 def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks, level_embeds: Tensor,
-                    want_bf16: bool = False):
+                    want_bf16: bool = False, want_fp32: bool = True):
     """F0 in one launch per level: ``flatten_multi_level`` + ``get_lvl_pos_embed``
     (base_transformer.py:22-33) + the token validity of ``gen_encoder_output_proposals`` (:74-112).
 
     Returns ``(feat_flatten [B,S,C], lvl_pos_embed_flatten [B,S,C], enc_output_input [B,S,C] =
     (feat + pos) * keep, mask_flatten [B,S] bool, feat_bf16 | None, pos_bf16 | None, valid_ratios [B,L,2])``;
     ``valid_ratios`` is ``get_valid_ratios`` of every level (base_transformer.py:48-56), a by-product of the
-    extents the kernel counts anyway.
+    extents the kernel counts anyway.  ``want_fp32=False`` skips the fp32 feat / pos outputs (``None`` is returned
+    for them): the bf16 encoder only reads the bf16 copies.
     """
     feats = [f.contiguous() for f in multi_level_feats]
     pos = [p.contiguous() for p in multi_level_pos_embeds]
@@ -116,9 +136,9 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
     B, C = feats[0].shape[:2]
     S = sum(int(f.shape[2]) * int(f.shape[3]) for f in feats)
     dev = feats[0].device
-    feat_out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
-    pos_out = torch.empty_like(feat_out)
-    sum_out = torch.empty_like(feat_out)
+    feat_out = torch.empty((B, S, C), dtype=torch.float32, device=dev) if want_fp32 else None
+    pos_out = torch.empty((B, S, C), dtype=torch.float32, device=dev) if want_fp32 else None
+    sum_out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
     mask_out = torch.empty((B, S), dtype=torch.bool, device=dev)
     feat_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     pos_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
@@ -132,7 +152,7 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
             mu8 = m.view(torch.uint8) if m.dtype == torch.bool else m
             code = lib.sdetr_pyramid_flatten_level(
                 _hip.stream_ptr(), f.data_ptr(), p.data_ptr(), mu8.data_ptr(), le[lvl].data_ptr(), B, C, H, W, lvl,
-                start, S, feat_out.data_ptr(), pos_out.data_ptr(), sum_out.data_ptr(), mask_out.data_ptr(),
+                start, S, _hip.ptr(feat_out), _hip.ptr(pos_out), sum_out.data_ptr(), mask_out.data_ptr(),
                 _hip.ptr(feat_bf16), _hip.ptr(pos_bf16), valid_ratios.data_ptr() + lvl * 8, len(feats) * 2)
             _hip.check(code, "pyramid_flatten_level")
             start += H * W
@@ -251,7 +271,8 @@ def packed_linear_weight(weight: Tensor, cols=None) -> Tensor:
 
 def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coarse_score: Optional[Tensor] = None,
                   level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
-                  memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None) -> Tensor:
+                  memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
+                  score_min: Optional[Tensor] = None) -> Tensor:
     """The salience head on one level in three launches (include/salience_hip.h (6)).
 
     ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
@@ -259,7 +280,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     are applied first and ``memory_out`` (a ``[B,n,256]`` slice, optional) receives their result.  The
     coarse-to-fine modulation takes either ``row_scale`` [B,n] or the coarser level's ``coarse_score``
     [B,1,h',w'] (resized in-kernel to ``level_hw``), times the device scalar ``alpha``.  ``score_flat``
-    (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy.  Returns ``[B,n]``."""
+    (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy; ``score_min`` (one-element
+    fp32 tensor) the minimum over all ``B*n`` scores.  Returns ``[B,n]``."""
     if not x.is_cuda:
         raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
     if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
@@ -311,7 +333,7 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
             packed_linear_weight(l2a.weight, cols=(0, half)).data_ptr(), packed_linear_weight(l2b.weight).data_ptr(),
             l2b.bias.data_ptr(), l2c.weight.data_ptr(), l2c.bias.data_ptr(), cst.data_ptr(), score.data_ptr(),
-            _hip.ptr(score_flat), sfs)
+            _hip.ptr(score_flat), sfs, _hip.ptr(score_min))
         _hip.check(code, "salience_head_stage2")
     return score
 
@@ -519,4 +541,43 @@ def class_head_max_times(x: Tensor, class_head, scale: Tensor) -> Tensor:
             _hip.stream_ptr(), x.data_ptr(), packed.data_ptr(), b.data_ptr(), 256, class_head.out_features,
             scale.data_ptr(), scale.stride(0) if B > 1 else max(n, 1), B, n, out.data_ptr())
     _hip.check(code, "class_head_max_times")
+    return out
+
+
+def masked_fill_min(score: Tensor, mask: Tensor, mins: Tensor) -> Tensor:
+    """``torch.where(mask, mins.min(), score)`` in one launch (foreground_score, salience_transformer.py:164-168,
+    from the per-level minima that are already on the device)."""
+    _hip.require_device("masked_fill_min", score=score, mask=mask, mins=mins)
+    if score.dtype != torch.float32 or mins.dtype != torch.float32 or mask.shape != score.shape:
+        raise RuntimeError("masked_fill_min: fp32 score / mins and a mask of score's shape expected")
+    m = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    out = torch.empty_like(score)
+    with torch.cuda.device(score.device):
+        code = _hip.lib().sdetr_masked_fill_min(_hip.stream_ptr(), score.data_ptr(), m.data_ptr(), mins.data_ptr(),
+                                                mins.numel(), score.numel(), out.data_ptr())
+    _hip.check(code, "masked_fill_min")
+    return out
+
+
+def encoder_reference_points(valid_ratios: Tensor, spatial_shapes: Tensor, level_start_index: Tensor, rows: int,
+                             index: Optional[Tensor] = None) -> Tensor:
+    """``get_reference_points`` (salience_transformer.py:418-432) evaluated only for the tokens ``index[b,i]``
+    (all ``rows`` tokens in order when ``index`` is None) -> ``[B,rows,L,2]`` fp32."""
+    _hip.require_device("encoder_reference_points", valid_ratios=valid_ratios, spatial_shapes=spatial_shapes,
+                        level_start_index=level_start_index)
+    B, L, _ = valid_ratios.shape
+    if valid_ratios.dtype != torch.float32 or spatial_shapes.dtype != torch.int64:
+        raise RuntimeError("encoder_reference_points: fp32 valid ratios and int64 shapes expected")
+    ibs = 0
+    if index is not None:
+        if index.dtype != torch.int64 or index.dim() != 2 or not index.is_cuda or (index.shape[1] > 1 and index.stride(1) != 1):
+            raise RuntimeError("encoder_reference_points: int64 [B,n] index with a contiguous last dim expected")
+        rows = index.shape[1]
+        ibs = index.stride(0) if B > 1 else rows
+    out = torch.empty((B, rows, L, 2), dtype=torch.float32, device=valid_ratios.device)
+    with torch.cuda.device(valid_ratios.device):
+        code = _hip.lib().sdetr_encoder_reference_points(
+            _hip.stream_ptr(), valid_ratios.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            _hip.ptr(index), ibs, B, int(rows), L, out.data_ptr())
+    _hip.check(code, "encoder_reference_points")
     return out

@@ -95,7 +95,7 @@ class SalienceEncoderHotPath(nn.Module):
             from .filter_ops import pyramid_flatten
             feat_flatten, lvl_pos_embed_flatten, enc_in, mask_flatten, feat_enc, pos_enc, valid_ratios_k = pyramid_flatten(
                 multi_level_feats, multi_level_pos_embeds, multi_level_masks, self.level_embeds,
-                want_bf16=(edt == torch.bfloat16))
+                want_bf16=(edt == torch.bfloat16), want_fp32=(return_aux or edt != torch.bfloat16))
         else:
             enc_in = valid_ratios_k = None
             feat_flatten = pyramid.flatten_multi_level(multi_level_feats)
@@ -104,7 +104,7 @@ class SalienceEncoderHotPath(nn.Module):
                                                               multi_level_pos_embeds)
         level_shapes = pyramid.level_shapes_of(multi_level_masks)
         if valid_ratios_k is not None:
-            spatial_shapes, level_start_index = pyramid.shape_tensors(level_shapes, feat_flatten.device)
+            spatial_shapes, level_start_index = pyramid.shape_tensors(level_shapes, mask_flatten.device)
             valid_ratios = valid_ratios_k
         else:
             spatial_shapes, level_start_index, valid_ratios = pyramid.multi_level_misc(multi_level_masks)
@@ -132,29 +132,30 @@ class SalienceEncoderHotPath(nn.Module):
                 raise ValueError("image_sizes needs the padded canvas size as well")
             def build():
                 focus_host, level_host, _ = pyramid.host_token_budgets(image_sizes, canvas, level_shapes, level_ratio)
-                return (torch.as_tensor(focus_host, dtype=torch.int64).to(feat_flatten.device),
+                return (torch.as_tensor(focus_host, dtype=torch.int64).to(mask_flatten.device),
                         [int(v) for v in level_host])
             focus_token_nums, level_token_nums = pyramid.static_tensor(
                 ("budgets", tuple(map(tuple, image_sizes)), tuple(canvas), tuple(level_shapes), level_ratio,
-                 str(feat_flatten.device)), build)
+                 str(mask_flatten.device)), build)
         else:
             focus_token_nums, level_dev, _ = token_budgets(multi_level_masks, self.level_filter_ratio.float())
             level_token_nums = level_dev.tolist()  # the stage's single host sync
             focus_token_nums = focus_token_nums.to(torch.int64)
 
         score_flat = None
+        extras: dict = {}
         if fuse_enc:
             score_flat = torch.empty(mask_flatten.shape, dtype=torch.float32, device=mask_flatten.device)
             salience_score, level_inds, level_score = level_filtering(
                 enc_in, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor, self.alpha,
                 enc_output=self.enc_output, enc_output_norm=self.enc_output_norm, memory_out=backbone_output_memory,
-                score_flat=score_flat)
+                score_flat=score_flat, extras=extras)
         else:
             salience_score, level_inds, level_score = level_filtering(
                 backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
                 self.alpha)
         foreground_inds, foreground_score = salience_filtering(salience_score, level_inds, level_score, mask_flatten,
-                                                               layer_ratio, score_flat=score_flat)
+                                                               layer_ratio, score_flat=score_flat, extras=extras)
         if feat_enc is None:
             feat_enc, pos_enc = feat_flatten.to(edt), lvl_pos_embed_flatten.to(edt)
         memory = self.encoder(

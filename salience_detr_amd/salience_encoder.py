@@ -25,7 +25,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import (advance_rows, class_head_max_times, class_max_times, encoder_finalize, fused_ffn,
+from .filter_ops import (advance_rows, class_head_max_times, class_max_times, encoder_finalize,
+                         encoder_reference_points, fused_ffn,
                          fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
@@ -272,9 +273,12 @@ class SalienceTransformerEncoder(nn.Module):
         E = self.embed_dim
         level_shapes = pyramid.level_shapes_of(multi_level_masks) if multi_level_masks is not None \
             else [tuple(s) for s in spatial_shapes.tolist()]
-        reference_points = self.get_reference_points(level_shapes, valid_ratios, device=query.device)
-        b, n, s, p = reference_points.shape
-        ori_reference_points = reference_points.reshape(b, n, s * p).contiguous()
+        counts = self._prefix_counts(foreground_inds) if native else None
+        b, n = query.shape[:2]
+        s, p = len(level_shapes), 2
+        if counts is None:
+            reference_points = self.get_reference_points(level_shapes, valid_ratios, device=query.device)
+            ori_reference_points = reference_points.reshape(b, n, s * p).contiguous()
         ori_pos = query_pos
         value = query
         output = query
@@ -296,7 +300,6 @@ class SalienceTransformerEncoder(nn.Module):
                 if self.num_layers == 1:
                     value_hm_all = value_hm_all[None]
 
-        counts = self._prefix_counts(foreground_inds) if native else None
         if counts is not None:
             # every layer's set is a prefix of one sorted list (what salience_filtering produces): keep the tokens
             # in sorted order across the layers -- one gather in, one pass back to token space at the end
@@ -304,7 +307,9 @@ class SalienceTransformerEncoder(nn.Module):
             n0 = counts[0]
             q = gather_rows(value, sorted_index)
             pos_s = gather_rows(ori_pos, sorted_index)
-            ref_s = gather_rows(ori_reference_points, sorted_index).view(b, n0, s, p)
+            # reference points of the selected tokens only, straight from their indices
+            ref_s = encoder_reference_points(valid_ratios.float().contiguous(), spatial_shapes, level_start_index, n0,
+                                             index=sorted_index)
             fg_s = torch.gather(foreground_score, 1, sorted_index)
             result = torch.empty_like(q)
             for layer_id, layer in enumerate(self.layers):

@@ -20,7 +20,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import column_mean, fused_layer_norm, masked_topk_desc, salience_head
+from .filter_ops import column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, salience_head
 
 
 class MaskPredictor(nn.Module):
@@ -86,7 +86,8 @@ def token_budgets(multi_level_masks: Sequence[Tensor], level_filter_ratio: Tenso
 def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_shapes: Sequence[Tuple[int, int]],
                     level_start_index: Sequence[int], level_token_nums: Sequence[int], mask_predictor: nn.Module,
                     alpha: Tensor, enc_output: Optional[nn.Module] = None, enc_output_norm: Optional[nn.Module] = None,
-                    memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None):
+                    memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
+                    extras: Optional[dict] = None):
     """Coarse-to-fine salience scores + per-level top-k (salience_transformer.py:123-154).
 
     ``level_shapes`` / ``level_start_index`` / ``level_token_nums`` are python ints (shapes come from the
@@ -97,7 +98,9 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     With ``enc_output`` / ``enc_output_norm`` the first argument is the INPUT of ``enc_output`` (the masked
     ``feat + pos`` tokens of base_transformer.py:107-109) and the projection + norm run inside the salience-head
     kernel (no-grad MI355X path only); ``memory_out`` [B,S,C] then optionally receives ``backbone_output_memory``
-    and ``score_flat`` [B,S] the flattened scores.
+    and ``score_flat`` [B,S] the flattened scores.  ``extras`` (a dict) receives by-products that
+    ``salience_filtering`` can reuse: ``level_min`` [L] (``score.min()`` per level) and ``selected`` (the
+    concatenated ``(scores, indices)`` [B, sum k] the per-level top-k calls already wrote side by side).
     """
     B = backbone_output_memory.shape[0]
     L = len(level_shapes)
@@ -111,11 +114,21 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                                                    any(p.requires_grad for p in mask_predictor.parameters()))))
     if enc_output is not None and not fused:
         raise RuntimeError("level_filtering: enc_output fusion needs the no-grad fp32 256-wide MaskPredictor path")
+    level_min = sel_score = sel_inds = None
+    if fused:
+        # per-level minima (stage 2 takes them) and ONE [B, sum k] buffer pair the per-level top-k calls fill column
+        # block by column block (the concatenation of :155 for free)
+        dev = backbone_output_memory.device
+        level_min = torch.empty(L, dtype=torch.float32, device=dev)
+        ks = [int(k) for k in level_token_nums]
+        offs = [sum(ks[:i]) for i in range(L)]
+        sel_score = torch.empty((B, sum(ks)), dtype=torch.float32, device=dev)
+        sel_inds = torch.empty((B, sum(ks)), dtype=torch.int64, device=dev)
     for lvl in range(L - 1, -1, -1):
         h, w = level_shapes[lvl]
         start = int(level_start_index[lvl])
         level_memory = backbone_output_memory[:, start:start + h * w, :]
-        mask = mask_flatten[:, start:start + h * w].contiguous()
+        mask = mask_flatten[:, start:start + h * w]
         if fused:
             # resize of the coarser score, modulation, both LayerNorms, all five Linear layers: three launches
             token_score = salience_head(
@@ -123,12 +136,17 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 alpha=alpha[lvl:lvl + 1] if score is not None else None, enc_output=enc_output,
                 enc_output_norm=enc_output_norm,
                 memory_out=None if memory_out is None else memory_out[:, start:start + h * w, :],
-                score_flat=None if score_flat is None else score_flat[:, start:start + h * w])
+                score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
+                score_min=level_min[lvl:lvl + 1])
             score = token_score.view(B, 1, h, w)
-            ls, li = masked_topk_desc(token_score, int(level_token_nums[lvl]), mask=mask, fill_with_global_min=True,
-                                      index_offset=start)
+            # the strided mask slice and the minimum stage 2 already took go straight to the kernel
+            ls, li = masked_topk_desc(token_score, ks[lvl], mask=mask, fill_with_global_min=True, index_offset=start,
+                                      fill_value=level_min[lvl:lvl + 1],
+                                      out=(sel_score[:, offs[lvl]:offs[lvl] + ks[lvl]],
+                                           sel_inds[:, offs[lvl]:offs[lvl] + ks[lvl]]))
             salience_score[lvl], level_inds[lvl], level_score[lvl] = score, li, ls
             continue
+        mask = mask.contiguous()
         if lvl != L - 1:
             up = F.interpolate(score, size=(h, w), mode="bilinear", align_corners=True)
             token_score = mask_predictor(level_memory, row_scale=up.reshape(B, h * w), alpha=alpha[lvl:lvl + 1])
@@ -142,24 +160,36 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
         salience_score[lvl] = score
         level_inds[lvl] = li
         level_score[lvl] = ls
+    if extras is not None and fused:
+        extras["level_min"] = level_min
+        extras["selected"] = (sel_score, sel_inds)
     return salience_score, level_inds, level_score
 
 
 def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Tensor], level_score: Sequence[Tensor],
-                       mask_flatten: Tensor, layer_filter_ratio: Sequence[float], score_flat: Optional[Tensor] = None):
+                       mask_flatten: Tensor, layer_filter_ratio: Sequence[float], score_flat: Optional[Tensor] = None,
+                       extras: Optional[dict] = None):
     """Global sort, per-layer prefixes and foreground score (salience_transformer.py:156-168).
 
     Returns ``(foreground_inds: list[num_layers] of [B,Nq_k] int64, foreground_score [B,S])`` -- exactly the
     ``foreground_inds`` / ``foreground_score`` keyword arguments of ``SalienceTransformerEncoder.forward``.
-    ``score_flat`` [B,S]: the already flattened ``salience_score`` (saves the concatenation).
+    ``score_flat`` [B,S]: the already flattened ``salience_score`` (saves the concatenation); ``extras``: the
+    by-products dict filled by ``level_filtering``.
     """
-    selected_score = torch.cat(list(level_score), 1)
-    selected_inds = torch.cat(list(level_inds), 1)
+    extras = extras or {}
+    if "selected" in extras:
+        selected_score, selected_inds = extras["selected"]
+    else:
+        selected_score = torch.cat(list(level_score), 1)
+        selected_inds = torch.cat(list(level_inds), 1)
     n = selected_inds.shape[1]
     _, sorted_inds = masked_topk_desc(selected_score, n, payload=selected_inds, want_scores=False)
     counts = pyramid.layer_token_counts(n, layer_filter_ratio)
     # views of ONE sorted list: the encoder recognises the prefix structure and keeps the tokens in sorted order
     foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c] for c in counts]
     fg = score_flat if score_flat is not None else pyramid.flatten_multi_level(salience_score).squeeze(-1)
-    fg = torch.where(mask_flatten, fg.min(), fg)
+    if "level_min" in extras and fg.is_cuda and fg.is_contiguous() and mask_flatten.is_contiguous():
+        fg = masked_fill_min(fg, mask_flatten, extras["level_min"])   # fg.min() == min of the level minima
+    else:
+        fg = torch.where(mask_flatten, fg.min(), fg)
     return foreground_inds, fg

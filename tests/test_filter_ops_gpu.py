@@ -5,6 +5,7 @@ import torch
 
 from oracle import salience_ref as R
 from salience_detr_amd import filter_ops as F
+from salience_detr_amd import pyramid
 from salience_detr_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -402,3 +403,40 @@ def test_value_proj_head_major_matches_two_step_path(dtype):
     assert (got.float() - want).abs().max().item() <= tol
     assert (got.float() - two_step.float()).abs().max().item() <= tol
     assert (got[:, 1, :, 1000:] == 0).all()
+
+
+def test_reference_points_and_fill_min_kernels():
+    from salience_detr_amd.salience_encoder import SalienceTransformerEncoder
+    shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    S = sum(h * w for h, w in shapes)
+    B = 3
+    vr = (0.5 + 0.5 * torch.rand(B, 4, 2)).to(DEV)
+    st, lsi = pyramid.shape_tensors(shapes, DEV)
+    want = SalienceTransformerEncoder.get_reference_points(shapes, vr, device=DEV)       # [B,S,L,2]
+    got = F.encoder_reference_points(vr, st, lsi, S)
+    assert torch.equal(got, want)
+    idx_long = torch.stack([torch.randperm(S)[:500] for _ in range(B)]).to(DEV)
+    idx = idx_long[:, :333]                                                                # a row prefix view
+    got_i = F.encoder_reference_points(vr, st, lsi, 0, index=idx)
+    assert torch.equal(got_i, torch.stack([want[b, idx[b]] for b in range(B)]))
+    score = syn.det_randn("fm", (B, S)).to(DEV)
+    mask = torch.rand(B, S, device=DEV) < 0.3
+    mins = torch.tensor([0.5, score.min().item(), 1.0, 2.0], device=DEV)
+    assert torch.equal(F.masked_fill_min(score, mask, mins), torch.where(mask, score.min(), score))
+
+
+def test_topk_into_column_slices_with_strided_mask_and_given_fill():
+    B, S = 2, 900
+    score_all = syn.det_randn("tkc", (B, S)).to(DEV)
+    mask_all = torch.rand(B, S, device=DEV) < 0.2
+    out_s = torch.full((B, 700), -9.0, device=DEV)
+    out_i = torch.full((B, 700), -1, dtype=torch.int64, device=DEV)
+    off = 0
+    for start, n, k in ((0, 600, 400), (600, 300, 300)):
+        sc = score_all[:, start:start + n].contiguous()
+        fill = sc.min().reshape(1)
+        v, i = F.masked_topk_desc(sc, k, mask=mask_all[:, start:start + n], fill_with_global_min=True, index_offset=start,
+                                  fill_value=fill, out=(out_s[:, off:off + k], out_i[:, off:off + k]))
+        rv, ri = R.topk_desc_stable(sc.cpu().masked_fill(mask_all[:, start:start + n].cpu(), sc.min().item()), k)
+        assert torch.equal(out_i[:, off:off + k].cpu(), ri + start) and torch.equal(out_s[:, off:off + k].cpu(), rv)
+        off += k
