@@ -262,11 +262,30 @@ class SalienceTransformerEncoder(nn.Module):
             self._value_proj_cache = (key, w, b)
         return self._value_proj_cache[1], self._value_proj_cache[2]
 
+    def project_values(self, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+        """Head-major value maps of ALL layers ``[num_layers,B,heads,Nv,D]`` (no-grad path).  The six layers sample
+        the same, never-updated feature map (salience_transformer.py:452), so their ``value_proj`` run as one
+        projection; it only depends on the flattened features, which lets a caller overlap it with the filtering
+        stage on a second stream (``SalienceEncoderHotPath`` does)."""
+        E = self.embed_dim
+        heads = self.layers[0].self_attn.num_heads
+        w_all, b_all = self._all_value_projections()
+        vdt = self.layers[0].self_attn.value_dtype or value.dtype
+        if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
+                and value.is_contiguous()):
+            # projection, padding mask, 16-bit conversion and head-major layout in one launch
+            return value_proj_head_major(value, w_all, b_all, padding_mask, heads, self.num_layers, vdt)
+        v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
+        value_hm_all = value_to_head_major(v_all, padding_mask, heads, vdt, num_groups=self.num_layers)
+        return value_hm_all[None] if self.num_layers == 1 else value_hm_all
+
     def forward(self, query, spatial_shapes, level_start_index, valid_ratios, query_pos=None,
                 query_key_padding_mask=None, foreground_score=None, focus_token_nums=None, foreground_inds=None,
-                multi_level_masks=None):
+                multi_level_masks=None, precomputed_value_maps=None):
         """Reference signature (salience_transformer.py:434-447).  ``foreground_inds`` is the list of
-        per-layer ``[B,Nq_k]`` index tensors, ``focus_token_nums`` ``[B]`` the per-image valid prefix."""
+        per-layer ``[B,Nq_k]`` index tensors, ``focus_token_nums`` ``[B]`` the per-image valid prefix.
+        ``precomputed_value_maps``: the result of ``project_values(query, query_key_padding_mask)`` if the caller
+        already launched it."""
         if not query.is_cuda:
             raise RuntimeError("SalienceTransformerEncoder: HIP device tensors required; there is no CPU fallback")
         native = not _needs_grad(self, query, query_pos)
@@ -284,21 +303,9 @@ class SalienceTransformerEncoder(nn.Module):
         output = query
         focus64 = focus_token_nums.to(torch.int64).contiguous()
 
-        value_hm_all = None
-        if native:
-            heads = self.layers[0].self_attn.num_heads
-            w_all, b_all = self._all_value_projections()
-            vdt = self.layers[0].self_attn.value_dtype or value.dtype
-            if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
-                    and value.is_contiguous()):
-                # projection, padding mask, 16-bit conversion and head-major layout in one launch
-                value_hm_all = value_proj_head_major(value, w_all, b_all, query_key_padding_mask, heads,
-                                                     self.num_layers, vdt)
-            else:
-                v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
-                value_hm_all = value_to_head_major(v_all, query_key_padding_mask, heads, vdt, num_groups=self.num_layers)
-                if self.num_layers == 1:
-                    value_hm_all = value_hm_all[None]
+        value_hm_all = precomputed_value_maps
+        if native and value_hm_all is None:
+            value_hm_all = self.project_values(value, query_key_padding_mask)
 
         if counts is not None:
             # every layer's set is a prefix of one sorted list (what salience_filtering produces): keep the tokens
