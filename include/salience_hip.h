@@ -313,8 +313,9 @@ int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packe
  * y = W x + b with the activations of 32 tokens resident in a wave's registers and the weights streamed through
  * LDS; the output tile (32 features) is consumed from registers by one of three epilogues.  fp32 accumulation.
  *   sdetr_linear_packed_bytes / sdetr_linear_pack_bf16: weight [out_features, 256] bf16 (row stride in elements)
- *     -> per 32 output features 16 lane-ordered 1 KiB MFMA A-fragments (rows past out_features are zero).
- *   bias_padded: fp32 [ceil(out_features/32)*32], zero past out_features.
+ *     -> per 32 output features 16 lane-ordered 1 KiB MFMA A-fragments, padded with zero rows to whole steps
+ *     of 128 features.
+ *   bias_padded: fp32 [ceil(out_features/128)*128], zero past out_features.
  *   sdetr_token_linear_bf16: out[t, :out_features] = bf16(W (x[t] (+ x_add[t])) + b), out row stride in elements;
  *     x [tokens,256]; x_add (optional, e.g. the position embedding of salience_transformer.py:380-381) holds
  *     rows_per_batch rows per image, images x_add_batch_stride elements apart.  Replaces the
@@ -335,6 +336,16 @@ int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x, const void
 int sdetr_class_head_max_times(sdetr_stream_t stream, const void *x, const void *packed_weight,
                                const float *bias_padded, int in_features, int num_classes, const float *scale,
                                int64_t scale_batch_stride, int batch_size, int rows_per_batch, float *out);
+/*   sdetr_token_linear_ln_bf16: out = LayerNorm(residual + W x + b) for a 256 -> 256 Linear: output_proj + residual
+ *     + norm1 of the deformable attention (salience_transformer.py:385-391), or out_proj + residual + pre_norm of
+ *     the top-k dense attention written straight back to the selected query rows (:376-379, scatter_index [tokens]
+ *     = row inside the image, out [batch, out_batch_rows, 256]).  residual: rows_per_batch rows per image, images
+ *     residual_batch_stride elements apart; bias / norm_weight / norm_bias fp32 [256]. */
+int sdetr_token_linear_ln_bf16(sdetr_stream_t stream, const void *x, const void *residual,
+                               int64_t residual_batch_stride, int rows_per_batch, int tokens, int in_features,
+                               const void *packed_weight, const float *bias, const float *norm_weight,
+                               const float *norm_bias, float norm_eps, void *out, const int64_t *scatter_index,
+                               int64_t out_batch_rows);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "sdetr_token_linear_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _i64]),
     "sdetr_value_proj_head_major": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_class_head_max_times": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _i, _i, _p]),
+    "sdetr_token_linear_ln_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i64]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
 }

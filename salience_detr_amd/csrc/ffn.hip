@@ -227,13 +227,21 @@ __global__ void __launch_bounds__(kBlock, 1) ffn_fused_kernel(FfnArgs p)
     }
 
     // ---- + b2 + residual, LayerNorm over the 256 channels held by lanes (t, 0) and (t, 1), store ----
+    // all 32 residual pieces are requested before the first is used (one by one in front of their adds each would
+    // cost a full memory latency)
+    uint2 rbuf[32];
+#pragma unroll
+    for (int et = 0; et < 8; ++et)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rbuf[et * 4 + g] = *reinterpret_cast<const uint2 *>(p.x + row + 32 * et + 8 * g + 4 * h);
+    __builtin_amdgcn_sched_barrier(0);
     float sum = 0.f;
 #pragma unroll
     for (int et = 0; et < 8; ++et)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int e0 = 32 * et + 8 * g + 4 * h;
-            const uint2 r = *reinterpret_cast<const uint2 *>(p.x + row + e0);
+            const uint2 r = rbuf[et * 4 + g];
             const float4 bv = *reinterpret_cast<const float4 *>(par + e0);
             yacc[et][4 * g] += bv.x + bf16_lo(r.x);
             yacc[et][4 * g + 1] += bv.y + bf16_hi(r.x);

@@ -16,9 +16,8 @@
 //               score -- the [tokens, 91] logits never exist
 //
 // Weights: pre-packed per tile into 16 lane-ordered 1 KB A-fragments (sdetr_linear_pack_bf16, rows past N are
-// zero), copied global -> LDS by LDS-DMA (inline asm + counted waits, see ffn.hip), triple-buffered, shared by the
-// block's four waves.  ~130 registers, 56 KB LDS: two to three blocks per CU hide the copy issue cost and the
-// barriers.  Bound: bf16 MFMA for N = 384 / 91, the 137 MB head-major store for value_proj.
+// zero), copied global -> LDS by LDS-DMA (inline asm + explicit waits, see ffn.hip) four tiles at a time,
+// double-buffered, shared by the block's four waves.  Bound: bf16 MFMA for N = 384 / 91, the 137 MB head-major store for value_proj.
 #include "common.h"
 
 namespace sdetr {
@@ -60,18 +59,28 @@ __device__ __forceinline__ tl_f32x16_t tl_mfma(uint4 a, uint4 b, tl_f32x16_t c)
                                                    c, 0, 0, 0);
 }
 
-// a wave's quarter (4 KB = 4 pieces of 1 KB) of one weight tile, global -> LDS
-__device__ __forceinline__ void tl_issue_tile(const char *tile, uint32_t voff, uint32_t dst_lds)
+// Weights move in STEPS of four tiles (64 KB): one block barrier and one round of LDS-DMA latency per 64 MFMAs
+// instead of per 16 (with a barrier per tile the 12 tiles of the 256 -> 384 projection took 17 us, ~1.3 us each for
+// 0.26 us of MFMA work).  A wave copies its quarter of the step, 16 KB = 16 LDS-DMA instructions of 1 KB
+// (destination = M0 base + instruction offset + lane * 16; the offset also advances the global source).
+constexpr int kTLStepTiles = 4;
+constexpr int kTLStepBytes = kTLStepTiles * kTLTileBytes;
+
+__device__ __forceinline__ void tl_issue_step(const char *step, uint32_t voff, uint32_t dst_lds)
 {
-    const uint32_t d0 = __builtin_amdgcn_readfirstlane(dst_lds);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %2\n\t"
-                 "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, %2 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %0, %2 offset:3072"
-                 :
-                 : "v"(voff), "s"(d0), "s"(tile)
-                 : "memory", "m0");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t d = __builtin_amdgcn_readfirstlane(dst_lds + q * 4096);
+        const uint32_t v = voff + q * 4096;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %2\n\t"
+                     "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %0, %2 offset:3072"
+                     :
+                     : "v"(v), "s"(d), "s"(step)
+                     : "memory", "m0");
+    }
 }
 
 __device__ __forceinline__ uint4 tl_lds_read16(tl_lds_cptr_t p)
@@ -86,11 +95,12 @@ __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b)
 }
 
 template <int EPI, bool ADD2>
-__global__ void __launch_bounds__(kBlock, 2) token_linear_kernel(TLArgs p)
+__global__ void __launch_bounds__(kBlock, 1) token_linear_kernel(TLArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char *wbuf = lds;                                                   // 3 tile buffers
-    float *bs = reinterpret_cast<float *>(lds + 3 * kTLTileBytes);      // [ntiles * 32]
+    char *wbuf = lds;                                                   // 2 step buffers
+    float *bs = reinterpret_cast<float *>(lds + 2 * kTLStepBytes);      // [nsteps * 128]
+    const int nsteps = (p.ntiles + kTLStepTiles - 1) / kTLStepTiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = lane & 31, h = lane >> 5;
     const int tok = blockIdx.x * kTLTokBlock + wave * kTLTokWave + t;
@@ -99,11 +109,10 @@ __global__ void __launch_bounds__(kBlock, 2) token_linear_kernel(TLArgs p)
     const int img = tk / p.rows_per_batch, ri = tk - img * p.rows_per_batch;
 
     const uint32_t wbuf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)wbuf;
-    const uint32_t voff = (uint32_t)(wave * 4096 + lane * 16);
-    const uint32_t wave_lds = wbuf_lds + wave * 4096;
-    tl_issue_tile(p.pw, voff, wave_lds);
-    if (p.ntiles > 1) tl_issue_tile(p.pw + kTLTileBytes, voff, wave_lds + kTLTileBytes);
-    for (int i = tid; i < p.ntiles * 32; i += kBlock) bs[i] = p.bias[i];
+    const uint32_t voff = (uint32_t)(wave * 16384 + lane * 16);
+    const uint32_t wave_lds = wbuf_lds + wave * 16384;
+    tl_issue_step(p.pw, voff, wave_lds);
+    for (int i = tid; i < nsteps * 128; i += kBlock) bs[i] = p.bias[i];
 
     uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
     {
@@ -131,62 +140,71 @@ __global__ void __launch_bounds__(kBlock, 2) token_linear_kernel(TLArgs p)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    int buf = 0;
-    for (int nt = 0; nt < p.ntiles; ++nt) {
-        const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + buf * kTLTileBytes + lane * 16;
-        const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)bs + nt * 128 + 16 * h;
-        tl_f32x16_t acc;   // starts as the bias: registers 4g..4g+3 are features 8g + 4h + {0..3} of the tile
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint4 bv = tl_lds_read16(bb + 32 * g);
-            acc[4 * g] = __uint_as_float(bv.x);
-            acc[4 * g + 1] = __uint_as_float(bv.y);
-            acc[4 * g + 2] = __uint_as_float(bv.z);
-            acc[4 * g + 3] = __uint_as_float(bv.w);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = tl_mfma(tl_lds_read16(cb + ks * 1024), xb[ks], acc);
-
-        // tile nt+1 has landed for me, then for everyone; every wave is done with tile nt-1's buffer, which the copy
-        // of tile nt+2 overwrites
-        if (nt + 1 < p.ntiles) {
+    // A fragments come from LDS through an 8-deep ring of registers (requested 8 MFMAs before use, refilled right
+    // after the MFMA that consumed the slot): with one wave per SIMD nothing else hides the ~130-cycle LDS latency,
+    // and an MFMA waiting on the read issued just before it runs at a fifth of its rate.
+    constexpr int R = 8;
+    for (int st = 0; st < nsteps; ++st) {
+        if (st > 0) {   // step st has landed for me, then for everyone; every wave is done with step st-1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (nt + 2 < p.ntiles) {
-                const int pbuf = buf == 0 ? 2 : buf - 1;
-                tl_issue_tile(p.pw + (int64_t)(nt + 2) * kTLTileBytes, voff, wave_lds + pbuf * kTLTileBytes);
-            }
         }
-        buf = buf == 2 ? 0 : buf + 1;
-
-        if (EPI == kStore) {
-            if (valid) {
-                bf16_t *o = p.out + (int64_t)tok * p.out_row_stride + nt * 32 + 4 * h;
+        if (st + 1 < nsteps)   // ... whose buffer the copy of step st+1 overwrites while this step computes
+            tl_issue_step(p.pw + (int64_t)(st + 1) * kTLStepBytes, voff, wave_lds + ((st + 1) & 1) * kTLStepBytes);
+        const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + (st & 1) * kTLStepBytes + lane * 16;
+        uint4 ring[R];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (nt * 32 + 8 * g + 4 * h < p.N)   // N is a multiple of 4
-                        *reinterpret_cast<uint2 *>(o + 8 * g) =
-                            make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+        for (int f = 0; f < R; ++f) ring[f] = tl_lds_read16(cb + f * 1024);
+#pragma unroll
+        for (int j = 0; j < kTLStepTiles; ++j) {
+            const int nt = st * kTLStepTiles + j;
+            const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)bs + nt * 128 + 16 * h;
+            tl_f32x16_t acc;   // starts as the bias: registers 4g..4g+3 are features 8g + 4h + {0..3} of the tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 bv = tl_lds_read16(bb + 32 * g);
+                acc[4 * g] = __uint_as_float(bv.x);
+                acc[4 * g + 1] = __uint_as_float(bv.y);
+                acc[4 * g + 2] = __uint_as_float(bv.z);
+                acc[4 * g + 3] = __uint_as_float(bv.w);
             }
-        } else if (EPI == kHeadMajor) {
-            if (valid) {
-                const int grp = nt / p.heads, m = nt - grp * p.heads;
-                const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + m) * p.rows_per_batch + ri;
-                uint16_t *o = reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 v = make_uint2(0u, 0u);
-                    if (!masked)
-                        v = p.hm_f16 ? make_uint2(pack_f16x2(acc[4 * g], acc[4 * g + 1]), pack_f16x2(acc[4 * g + 2], acc[4 * g + 3]))
-                                     : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
-                    *reinterpret_cast<uint2 *>(o + 8 * g) = v;
+            for (int ks = 0; ks < 16; ++ks) {
+                const int f = j * 16 + ks;
+                acc = tl_mfma(ring[f % R], xb[ks], acc);
+                if (f + R < kTLStepTiles * 16) ring[f % R] = tl_lds_read16(cb + (f + R) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (nt >= p.ntiles) continue;   // (padding tile of the last step: zero weights, nothing to emit)
+            if (EPI == kStore) {
+                if (valid) {
+                    bf16_t *o = p.out + (int64_t)tok * p.out_row_stride + nt * 32 + 4 * h;
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (nt * 32 + 8 * g + 4 * h < p.N)   // N is a multiple of 4
+                            *reinterpret_cast<uint2 *>(o + 8 * g) =
+                                make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
                 }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (n < p.N) run_max = fmaxf(run_max, acc[i]);
+            } else if (EPI == kHeadMajor) {
+                if (valid) {
+                    const int grp = nt / p.heads, m = nt - grp * p.heads;
+                    const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + m) * p.rows_per_batch + ri;
+                    uint16_t *o = reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 4 * h;
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 v = make_uint2(0u, 0u);
+                        if (!masked)
+                            v = p.hm_f16 ? make_uint2(pack_f16x2(acc[4 * g], acc[4 * g + 1]), pack_f16x2(acc[4 * g + 2], acc[4 * g + 3]))
+                                         : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+                        *reinterpret_cast<uint2 *>(o + 8 * g) = v;
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (n < p.N) run_max = fmaxf(run_max, acc[i]);
+                }
             }
         }
     }
@@ -197,6 +215,138 @@ __global__ void __launch_bounds__(kBlock, 2) token_linear_kernel(TLArgs p)
             const float mx = bf16_lo(pack_bf16x2(run_max, 0.f));
             p.cmax[tok] = mx * p.scale[(int64_t)img * p.scale_batch_stride + ri];
         }
+    }
+}
+
+// ---- y = LayerNorm(residual + W x + b), N = 256, optionally scattered ------------------------------------------
+// The attention blocks' tails: output_proj + dropout/residual + norm1 of the deformable attention
+// (salience_transformer.py:385-391) and out_proj + residual + pre_norm + scatter of the top-k dense attention
+// (:376-379).  Same token-resident scheme; the eight output tiles stay in 128 accumulator registers and the
+// epilogue (bias is the accumulator init; + residual, two-pass LayerNorm over the 256 channels a lane pair holds,
+// bf16 store) runs in registers like the feed-forward kernel's.
+struct TLNArgs {
+    const bf16_t *x;           // [T, 256]
+    const bf16_t *res;         // residual rows: rows_per_batch per image, images res_batch_stride elements apart
+    int64_t res_batch_stride;
+    int rows_per_batch;
+    const char *pw;            // 8 packed tiles
+    const float *bias, *gamma, *beta;
+    float eps;
+    bf16_t *out;               // [T,256], or [B, out_batch_rows, 256] with scatter_index
+    const int64_t *scatter_index;   // [T] destination row inside the image, or NULL
+    int64_t out_batch_rows;
+    int T;
+};
+
+__global__ void __launch_bounds__(kBlock, 1) token_linear_ln_kernel(TLNArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *wbuf = lds;                                                   // 2 step buffers = all 8 tiles
+    float *par = reinterpret_cast<float *>(lds + 2 * kTLStepBytes);     // bias | gamma | beta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = lane & 31, h = lane >> 5;
+    const int tok = blockIdx.x * kTLTokBlock + wave * kTLTokWave + t;
+    const bool valid = tok < p.T;
+    const int tk = valid ? tok : p.T - 1;
+    const int img = tk / p.rows_per_batch, ri = tk - img * p.rows_per_batch;
+
+    const uint32_t wbuf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)wbuf;
+    const uint32_t voff = (uint32_t)(wave * 16384 + lane * 16);
+    const uint32_t wave_lds = wbuf_lds + wave * 16384;
+    tl_issue_step(p.pw, voff, wave_lds);                                   // the whole 256 x 256 weight fits:
+    tl_issue_step(p.pw + kTLStepBytes, voff, wave_lds + kTLStepBytes);     // no copy inside the MFMA loop
+    par[tid] = p.bias[tid];
+    par[kTLK + tid] = p.gamma[tid];
+    par[2 * kTLK + tid] = p.beta[tid];
+
+    uint4 xb[16];
+    {
+        const bf16_t *xr = p.x + (int64_t)tk * kTLK + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const uint4 *>(xr + 16 * ks);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    tl_f32x16_t acc[8];
+    constexpr int R = 8;
+    const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + lane * 16;   // 128 consecutive fragments: tile nt, k-step ks = 16 nt + ks
+    uint4 ring[R];
+#pragma unroll
+    for (int f = 0; f < R; ++f) ring[f] = tl_lds_read16(cb + f * 1024);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)par + nt * 128 + 16 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 bv = tl_lds_read16(bb + 32 * g);
+            acc[nt][4 * g] = __uint_as_float(bv.x);
+            acc[nt][4 * g + 1] = __uint_as_float(bv.y);
+            acc[nt][4 * g + 2] = __uint_as_float(bv.z);
+            acc[nt][4 * g + 3] = __uint_as_float(bv.w);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int f = nt * 16 + ks;
+            acc[nt] = tl_mfma(ring[f % R], xb[ks], acc[nt]);
+            if (f + R < 128) ring[f % R] = tl_lds_read16(cb + (f + R) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // + residual, LayerNorm over the 256 channels held by lanes (t, 0) and (t, 1), store
+    const bf16_t *rr = p.res + (int64_t)img * p.res_batch_stride + (int64_t)ri * kTLK;
+    // all 32 residual pieces are requested before the first is used: issued one by one in front of their adds, each
+    // costs a full memory latency (measured 9.7k cycles for this loop, more than the 128 MFMAs)
+    uint2 rbuf[32];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rbuf[nt * 4 + g] = *reinterpret_cast<const uint2 *>(rr + 32 * nt + 8 * g + 4 * h);
+    __builtin_amdgcn_sched_barrier(0);
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint2 r = rbuf[nt * 4 + g];
+            acc[nt][4 * g] += bf16_lo(r.x);
+            acc[nt][4 * g + 1] += bf16_hi(r.x);
+            acc[nt][4 * g + 2] += bf16_lo(r.y);
+            acc[nt][4 * g + 3] += bf16_hi(r.y);
+            sum += (acc[nt][4 * g] + acc[nt][4 * g + 1]) + (acc[nt][4 * g + 2] + acc[nt][4 * g + 3]);
+        }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.f / kTLK);
+    float sq = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = acc[nt][i] - mean;
+            sq += d * d;
+        }
+    sq += __shfl_xor(sq, 32);
+    const float rstd = rsqrtf(sq * (1.f / kTLK) + p.eps);
+    if (valid) {
+        const int64_t orow = p.scatter_index ? (int64_t)img * p.out_batch_rows + p.scatter_index[tok] : (int64_t)tok;
+        bf16_t *o = p.out + orow * kTLK;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int e0 = 32 * nt + 8 * g + 4 * h;
+                const float4 gv = *reinterpret_cast<const float4 *>(par + kTLK + e0);
+                const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kTLK + e0);
+                const float y0 = (acc[nt][4 * g] - mean) * rstd * gv.x + be.x;
+                const float y1 = (acc[nt][4 * g + 1] - mean) * rstd * gv.y + be.y;
+                const float y2 = (acc[nt][4 * g + 2] - mean) * rstd * gv.z + be.z;
+                const float y3 = (acc[nt][4 * g + 3] - mean) * rstd * gv.w + be.w;
+                *reinterpret_cast<uint2 *>(o + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+            }
     }
 }
 
@@ -211,15 +361,28 @@ __global__ void linear_pack_kernel(const bf16_t *w, int64_t row_stride, int N, i
     out[o] = n < N ? w[(int64_t)n * row_stride + 16 * ks + 8 * (l >> 5) + s] : (bf16_t)0;
 }
 
+template <int EPI, bool ADD2>
+static int tl_launch_one(hipStream_t s, const TLArgs &a)
+{
+    const int nsteps = (a.ntiles + kTLStepTiles - 1) / kTLStepTiles;
+    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
+    static bool attr_set = false;   // (one flag per instantiation)
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_kernel<EPI, ADD2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((token_linear_kernel<EPI, ADD2>), dim3((unsigned)((a.T + kTLTokBlock - 1) / kTLTokBlock)),
+                       dim3(kBlock), lds, s, a);
+    return check_launch("token_linear");
+}
+
 static int tl_launch(hipStream_t s, int epi, bool add2, TLArgs &a)
 {
-    const size_t lds = 3 * (size_t)kTLTileBytes + (size_t)a.ntiles * 128;
-    const dim3 grid((unsigned)((a.T + kTLTokBlock - 1) / kTLTokBlock)), block(kBlock);
-    if (epi == kStore && add2) hipLaunchKernelGGL((token_linear_kernel<kStore, true>), grid, block, lds, s, a);
-    else if (epi == kStore) hipLaunchKernelGGL((token_linear_kernel<kStore, false>), grid, block, lds, s, a);
-    else if (epi == kHeadMajor) hipLaunchKernelGGL((token_linear_kernel<kHeadMajor, false>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((token_linear_kernel<kClassMax, false>), grid, block, lds, s, a);
-    return check_launch("token_linear");
+    if (epi == kStore && add2) return tl_launch_one<kStore, true>(s, a);
+    if (epi == kStore) return tl_launch_one<kStore, false>(s, a);
+    if (epi == kHeadMajor) return tl_launch_one<kHeadMajor, false>(s, a);
+    return tl_launch_one<kClassMax, false>(s, a);
 }
 
 static int tl_common(TLArgs &a, const void *x, const void *packed, const float *bias, int tokens, int in_features,
@@ -231,7 +394,7 @@ static int tl_common(TLArgs &a, const void *x, const void *packed, const float *
     a = TLArgs{};
     a.x = (const bf16_t *)x; a.pw = (const char *)packed; a.bias = bias; a.T = tokens; a.N = out_features;
     a.ntiles = (out_features + 31) / 32; a.rows_per_batch = tokens > 0 ? tokens : 1;
-    if ((size_t)a.ntiles * 128 + 3 * kTLTileBytes > 64 * 1024) return fail("token_linear: too many output features");
+    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 1024 > 156 * 1024) return fail("token_linear: too many output features");
     return 0;
 }
 
@@ -241,7 +404,7 @@ using namespace sdetr;
 
 extern "C" int64_t sdetr_linear_packed_bytes(int out_features)
 {
-    return out_features > 0 ? (int64_t)((out_features + 31) / 32) * kTLTileBytes : 0;
+    return out_features > 0 ? (int64_t)((out_features + 127) / 128) * kTLStepBytes : 0;
 }
 
 extern "C" int sdetr_linear_pack_bf16(sdetr_stream_t stream, const void *weight, int64_t row_stride, int out_features,
@@ -249,7 +412,7 @@ extern "C" int sdetr_linear_pack_bf16(sdetr_stream_t stream, const void *weight,
 {
     if (in_features != kTLK) return fail("linear_pack: built for 256 input features (got %d)", in_features);
     if (out_features <= 0 || !weight || !packed || row_stride < kTLK) return fail("linear_pack: bad arguments");
-    const int ntiles = (out_features + 31) / 32;
+    const int ntiles = (out_features + 127) / 128 * kTLStepTiles;   // whole steps (zero rows past out_features)
     const int64_t total = (int64_t)ntiles * 8192;
     hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), (const bf16_t *)weight, row_stride, out_features, ntiles,
@@ -308,4 +471,35 @@ extern "C" int sdetr_class_head_max_times(sdetr_stream_t stream, const void *x, 
     if (!scale || !out || scale_batch_stride < rows_per_batch) return fail("class_head_max_times: bad scale / out");
     a.rows_per_batch = rows_per_batch; a.scale = scale; a.scale_batch_stride = scale_batch_stride; a.cmax = out;
     return tl_launch(static_cast<hipStream_t>(stream), kClassMax, false, a);
+}
+
+extern "C" int sdetr_token_linear_ln_bf16(sdetr_stream_t stream, const void *x, const void *residual,
+                                          int64_t residual_batch_stride, int rows_per_batch, int tokens, int in_features,
+                                          const void *packed_weight, const float *bias, const float *norm_weight,
+                                          const float *norm_bias, float norm_eps, void *out, const int64_t *scatter_index,
+                                          int64_t out_batch_rows)
+{
+    if (in_features != kTLK) return fail("token_linear_ln: built for 256 features (got %d)", in_features);
+    if (tokens < 0 || rows_per_batch <= 0) return fail("token_linear_ln: bad sizes");
+    if (tokens == 0) return 0;
+    if (!x || !residual || !packed_weight || !bias || !norm_weight || !norm_bias || !out)
+        return fail("token_linear_ln: null pointer");
+    if (tokens % rows_per_batch || residual_batch_stride < (int64_t)rows_per_batch * kTLK || (residual_batch_stride % 4))
+        return fail("token_linear_ln: bad residual layout");
+    if (scatter_index && out_batch_rows <= 0) return fail("token_linear_ln: scatter needs the rows per image of out");
+    TLNArgs a{};
+    a.x = (const bf16_t *)x; a.res = (const bf16_t *)residual; a.res_batch_stride = residual_batch_stride;
+    a.rows_per_batch = rows_per_batch; a.pw = (const char *)packed_weight; a.bias = bias; a.gamma = norm_weight;
+    a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out; a.scatter_index = scatter_index;
+    a.out_batch_rows = out_batch_rows; a.T = tokens;
+    const size_t lds = 2 * (size_t)kTLStepBytes + 3 * kTLK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_ln_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(token_linear_ln_kernel, dim3((unsigned)((tokens + kTLTokBlock - 1) / kTLTokBlock)), dim3(kBlock),
+                       lds, static_cast<hipStream_t>(stream), a);
+    return check_launch("token_linear_ln");
 }

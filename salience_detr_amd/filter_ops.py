@@ -461,7 +461,7 @@ def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):
     lib = _hip.lib()
     w = weight.detach()
     N = w.shape[0]
-    npad = (N + 31) // 32 * 32
+    npad = (N + 127) // 128 * 128
     with torch.no_grad(), torch.cuda.device(w.device):
         packed = torch.empty(lib.sdetr_linear_packed_bytes(N), dtype=torch.uint8, device=w.device)
         code = lib.sdetr_linear_pack_bf16(_hip.stream_ptr(), w.data_ptr(), w.stride(0), N, w.shape[1], packed.data_ptr())
@@ -580,4 +580,40 @@ def encoder_reference_points(valid_ratios: Tensor, spatial_shapes: Tensor, level
             _hip.stream_ptr(), valid_ratios.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             _hip.ptr(index), ibs, B, int(rows), L, out.data_ptr())
     _hip.check(code, "encoder_reference_points")
+    return out
+
+
+def token_linear_ln(x: Tensor, linear, norm, residual: Tensor, scatter_index: Optional[Tensor] = None,
+                    scatter_into: Optional[Tensor] = None) -> Tensor:
+    """``norm(residual + linear(x))`` for a 256 -> 256 bf16 Linear in one launch (include/salience_hip.h (8));
+    ``residual`` [B,n,256] may be a row range of a longer buffer.  With ``scatter_index`` [B,n] / ``scatter_into``
+    [B,m,256] the rows are written to ``scatter_into[b, scatter_index[b,i]]`` (in place) instead."""
+    if not token_linear_applies(x, linear.weight) or linear.out_features != 256 or x.dim() != 3:
+        raise RuntimeError("token_linear_ln: bf16 [B,n,256] HIP tokens and a 256 -> 256 Linear expected")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, n, _ = x.shape
+    if residual.dtype != torch.bfloat16 or tuple(residual.shape) != (B, n, 256):
+        raise RuntimeError("token_linear_ln: residual must match x")
+    packed, b = _packed_linear_bf16(linear.weight, linear.bias)
+    tag = (norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
+    hit = norm.weight.__dict__.get("_sdetr_f32")
+    if hit is None or hit[0] != tag:
+        hit = (tag, norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous())
+        norm.weight.__dict__["_sdetr_f32"] = hit
+    out_rows = 0
+    if scatter_index is not None:
+        _hip.require_device("token_linear_ln", scatter_index=scatter_index, scatter_into=scatter_into)
+        if (scatter_index.dtype != torch.int64 or tuple(scatter_index.shape) != (B, n) or scatter_into.dim() != 3
+                or scatter_into.shape[0] != B or scatter_into.shape[2] != 256 or scatter_into.dtype != torch.bfloat16):
+            raise RuntimeError("token_linear_ln: scatter_index [B,n] int64 and scatter_into [B,m,256] bf16 expected")
+        out, out_rows = scatter_into, scatter_into.shape[1]
+    else:
+        out = torch.empty((B, n, 256), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib().sdetr_token_linear_ln_bf16(
+            _hip.stream_ptr(), x.data_ptr(), residual.data_ptr(), _batch_stride(residual, "token_linear_ln"), n, B * n,
+            256, packed.data_ptr(), b.data_ptr(), hit[1].data_ptr(), hit[2].data_ptr(), float(norm.eps), out.data_ptr(),
+            _hip.ptr(scatter_index), out_rows)
+    _hip.check(code, "token_linear_ln")
     return out

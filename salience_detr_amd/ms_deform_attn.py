@@ -370,9 +370,10 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
                        level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None,
-                       query_pos: Optional[Tensor] = None) -> Tensor:
+                       query_pos: Optional[Tensor] = None, apply_output_proj: bool = True) -> Tensor:
         """``query_pos`` (optional): position embedding still to be added to ``query`` -- folded into the projection
-        kernel's prologue on the bf16 path."""
+        kernel's prologue on the bf16 path.  ``apply_output_proj=False`` returns the sampled heads ``[B,Nq,E]`` for a
+        caller that fuses ``output_proj`` with what follows it."""
         from .filter_ops import token_linear, token_linear_applies
         w, b = self._fused_query_projection()
         if token_linear_applies(query, w) and query.dim() == 3:
@@ -391,6 +392,8 @@ class MultiScaleDeformableAttention(nn.Module):
         else:
             out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
                                      self.num_levels, self.num_points, order=order, out_dtype=query.dtype)
+        if not apply_output_proj:
+            return out
         return F.linear(out, self.output_proj.weight, self.output_proj.bias)
 
     # -- reference signature -------------------------------------------------------------------

@@ -28,7 +28,7 @@ from . import pyramid
 from .filter_ops import (advance_rows, class_head_max_times, class_max_times, encoder_finalize,
                          encoder_reference_points, fused_ffn,
                          fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
-                         select_stack, token_linear_applies, value_proj_head_major)
+                         select_stack, token_linear_applies, token_linear_ln, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -103,8 +103,10 @@ class SalienceTransformerEncoderLayer(nn.Module):
         v from the second), one fused scaled-dot-product attention, one out-projection."""
         return self._pre_attention_stacked(torch.cat([qk, v], 1), qk.shape[1], qk.requires_grad)
 
-    def _pre_attention_stacked(self, stacked: Tensor, N: int, needs_grad: bool = False) -> Tensor:
-        """``stacked`` = ``[q/k rows ; value rows]`` [B, 2N, E] (see ``_pre_attention``)."""
+    def _pre_attention_stacked(self, stacked: Tensor, N: int, needs_grad: bool = False,
+                               apply_out_proj: bool = True) -> Tensor:
+        """``stacked`` = ``[q/k rows ; value rows]`` [B, 2N, E] (see ``_pre_attention``).  ``apply_out_proj=False``
+        returns the concatenated heads for a caller that fuses ``out_proj`` with the residual + norm."""
         mha = self.pre_attention
         B, _, E = stacked.shape
         H = mha.num_heads
@@ -126,6 +128,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
                 att = F.dropout(att, drop)
             o = torch.matmul(att, vv)
         o = o.transpose(1, 2).reshape(B, N, E)
+        if not apply_out_proj:
+            return o
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
@@ -142,6 +146,18 @@ class SalienceTransformerEncoderLayer(nn.Module):
         sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
         N = sel.shape[1]
         stacked = select_stack(query, pos_sorted, sel)                       # [q+pos ; q] rows, [B,2N,E]
+        fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
+        if fuse_tail:
+            # out_proj + residual + pre_norm, written straight back to the selected rows of the layer's queries
+            heads_out = self._pre_attention_stacked(stacked, N, apply_out_proj=False)
+            token_linear_ln(heads_out, self.pre_attention.out_proj, self.pre_norm, residual=stacked[:, N:],
+                            scatter_index=sel, scatter_into=query)
+            sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
+                                                    level_start_index, query_pos=pos_sorted[:, :c],
+                                                    apply_output_proj=False)
+            # output_proj + residual + norm1
+            query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
+            return self._forward_ffn_native(query)
         tgt2 = self._pre_attention_stacked(stacked, N)
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
         fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)

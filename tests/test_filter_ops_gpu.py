@@ -440,3 +440,31 @@ def test_topk_into_column_slices_with_strided_mask_and_given_fill():
         rv, ri = R.topk_desc_stable(sc.cpu().masked_fill(mask_all[:, start:start + n].cpu(), sc.min().item()), k)
         assert torch.equal(out_i[:, off:off + k].cpu(), ri + start) and torch.equal(out_s[:, off:off + k].cpu(), rv)
         off += k
+
+
+@pytest.mark.parametrize("B,n", [(1, 1), (2, 300), (2, 1000), (3, 129)])
+def test_token_linear_ln_matches_reference_and_scatters(B, n):
+    torch.manual_seed(n)
+    lin = torch.nn.Linear(256, 256).to(DEV).to(torch.bfloat16)
+    lin.bias.data = _bf(syn.det_randn("tnb", (256,))).to(DEV)
+    norm = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)
+    norm.weight.data = _bf(1 + 0.3 * syn.det_randn("tng", (256,))).to(DEV)
+    norm.bias.data = _bf(0.3 * syn.det_randn("tnbb", (256,))).to(DEV)
+    x = _bf(syn.det_randn(f"tnx{n}", (B, n, 256))).to(DEV)
+    long_res = _bf(syn.det_randn(f"tnr{n}", (B, 2 * n + 3, 256))).to(DEV)
+    res = long_res[:, n:2 * n]                                   # a row range of a longer buffer
+    with torch.no_grad():
+        ref = torch.nn.functional.layer_norm(res.float() + torch.nn.functional.linear(x.float(), lin.weight.float(), lin.bias.float()),
+                                             (256,), norm.weight.float(), norm.bias.float(), norm.eps)
+        base = norm(res + lin(x)).float()
+        got = F.token_linear_ln(x, lin, norm, residual=res)
+        err, base_err = (got.float() - ref).abs().max().item(), (base - ref).abs().max().item()
+        assert err <= max(1.5 * base_err, 0.03), (err, base_err)
+        m = n + 40
+        idx = torch.stack([torch.randperm(m)[:n] for _ in range(B)]).to(DEV)
+        dst = _bf(syn.det_randn(f"tnd{n}", (B, m, 256))).to(DEV)
+        want = dst.clone()
+        for b in range(B):
+            want[b, idx[b]] = got[b]
+        out = F.token_linear_ln(x, lin, norm, residual=res, scatter_index=idx, scatter_into=dst)
+        assert out is dst and torch.equal(dst, want)
