@@ -248,9 +248,9 @@ def main():
     real_fused = msda_mod.msda_fused_forward
 
     def timed_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
-                    order=None, out_dtype=None):
+                    order=None, out_dtype=None, proj_head_major=False):
         o = real_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
-                       order=order, out_dtype=out_dtype)
+                       order=order, out_dtype=out_dtype, proj_head_major=proj_head_major)
         # the step's own launch is above; the SAME launch (same operands, straight after its producers) is then
         # repeated back to back between two events on the launch stream, so the measured time is kernel time
         # (what rocprofv3 --kernel-trace reports), not host launch gaps of the eager instrumented pass
@@ -258,12 +258,13 @@ def main():
         e0.record()
         for _ in range(MSDA_REPEATS):
             real_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
-                       order=order, out_dtype=out_dtype)
+                       order=order, out_dtype=out_dtype, proj_head_major=proj_head_major)
         e1.record()
         msda_events.append((e0, e1))
         B, M, Nv, D = value_hm.shape
-        launch_nq.append(int(proj.shape[1]))
-        launches.append(algorithmic_bytes(B, Nv, proj.shape[1], M, D, num_levels, num_points,
+        nq = int(proj.shape[2] if proj_head_major else proj.shape[1])
+        launch_nq.append(nq)
+        launches.append(algorithmic_bytes(B, Nv, nq, M, D, num_levels, num_points,
                                           value_hm.element_size(), proj.element_size(), o.element_size(),
                                           reference_points.shape[-1]))
         return o

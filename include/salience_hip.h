@@ -97,7 +97,9 @@ int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const d
  *   value_hm  [B,M,Nv,D] (value_dtype)        ref_points [B,Nq,L,ref_dim] f32, ref_dim in {2,4}; images are
  *             ref_batch_stride floats apart (0 = contiguous), so a row prefix of a longer buffer can be passed
  *   proj      [B,Nq,row_stride] (proj_dtype): row = [ M*L*P*2 offsets | M*L*P logits | ... ]
- *             i.e. the concatenated output of sampling_offsets and attention_weights Linear.
+ *             i.e. the concatenated output of sampling_offsets and attention_weights Linear;
+ *             with proj_head_major != 0 instead [B,M,Nq,3*L*P]: per (image, head, query) the 2*L*P offsets then the
+ *             L*P logits (D=32, L=P=4, bf16 only) -- each head's slab is then read by one XCD only.
  *   order     [B,Nq] int32 processing order (slot i handles query order[b][i]) or NULL
  *   out       [B,Nq,M*D] (out_dtype)
  * ------------------------------------------------------------------------------------------- */
@@ -110,7 +112,7 @@ int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int va
                              const int64_t *data_spatial_shapes,
                              const int64_t *data_level_start_index, const float *ref_points,
                              int ref_dim, int64_t ref_batch_stride, const void *proj, int proj_dtype,
-                             int64_t proj_row_stride,
+                             int64_t proj_row_stride, int proj_head_major,
                              const int32_t *order, int batch_size, int spatial_size, int num_heads,
                              int channels, int num_levels, int num_query, int num_point, void *out,
                              int out_dtype);
@@ -318,7 +320,9 @@ int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packe
  *   bias_padded: fp32 [ceil(out_features/128)*128], zero past out_features.
  *   sdetr_token_linear_bf16: out[t, :out_features] = bf16(W (x[t] (+ x_add[t])) + b), out row stride in elements;
  *     x [tokens,256]; x_add (optional, e.g. the position embedding of salience_transformer.py:380-381) holds
- *     rows_per_batch rows per image, images x_add_batch_stride elements apart.  Replaces the
+ *     rows_per_batch rows per image, images x_add_batch_stride elements apart.  group_features > 0 stores
+ *     feature-group-major instead: out [batch][out_features/group][rows_per_batch][group] (the head-major
+ *     projection layout of sdetr_msda_fused_forward when the weight rows are ordered by head).  Replaces the
  *     sampling_offsets / attention_weights Linear of ms_deform_attn.py:322-329 (one 256 -> 384 call).
  *   sdetr_value_proj_head_major: value_proj + masked_fill + head-major re-layout (ms_deform_attn.py:316-321) for
  *     num_groups stacked projections: x [batch*spatial, 256] -> dst [groups][batch][heads][spatial][32] fp16|bf16.
@@ -329,7 +333,8 @@ int sdetr_linear_pack_bf16(sdetr_stream_t stream, const void *weight, int64_t ro
                            int in_features, void *packed);
 int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, const void *x_add, int64_t x_add_batch_stride,
                             int rows_per_batch, int tokens, int in_features, const void *packed_weight,
-                            const float *bias_padded, int out_features, void *out, int64_t out_row_stride);
+                            const float *bias_padded, int out_features, void *out, int64_t out_row_stride,
+                            int group_features);
 int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x, const void *packed_weight,
                                 const float *bias_padded, const uint8_t *pad_mask, int batch_size, int spatial_size,
                                 int in_features, int num_heads, int channels, int num_groups, void *dst, int dst_dtype);

@@ -32,7 +32,7 @@ SIGNATURES = {
     "sdetr_msda_col2im_f32": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
     "sdetr_msda_col2im_f64": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
     "sdetr_value_to_head_major": (_i, [_p, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _p, _i]),
-    "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _i64, _p, _i, _i64, _p] + [_i] * 7 + [_p, _i]),
+    "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _i64, _p, _i, _i64, _i, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_msda_forward_head_major": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_tiled_config": (None, [_p, _p, _p]),
     "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
@@ -59,7 +59,7 @@ SIGNATURES = {
     "sdetr_ffn_fused_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p]),
     "sdetr_linear_packed_bytes": (_i64, [_i]),
     "sdetr_linear_pack_bf16": (_i, [_p, _p, _i64, _i, _i, _p]),
-    "sdetr_token_linear_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _i64]),
+    "sdetr_token_linear_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _i64, _i]),
     "sdetr_value_proj_head_major": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_class_head_max_times": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _i, _i, _p]),
     "sdetr_token_linear_ln_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i64]),

@@ -81,6 +81,7 @@ struct GatherArgs {
     int ref_dim;
     const void *proj;
     int proj_bf16;
+    int proj_hm;          // 1: [B, M, Nq, 3*L*P] (per head: offsets then logits), 0: token rows of proj_stride
     int64_t proj_stride;
     const int32_t *order;
     void *out;
@@ -409,8 +410,12 @@ __global__ void __launch_bounds__(kBlock) msda_gather_l4p4_kernel(GatherArgs p)
     // ---- raw inputs: offsets of my 4 points (x,y), their logits, my level's reference point ----
     float ox[4], oy[4], lg[4];
     {
-        const int64_t o_idx = bq * p.proj_stride + (m * LP + j * P) * 2;
-        const int64_t l_idx = bq * p.proj_stride + p.M * LP * 2 + m * LP + j * P;
+        // head-major projection: this head's 32 offsets + 16 logits of a query are one 96-byte piece of a slab that
+        // only this head (= this XCD) reads; in token rows the 128-byte lines are shared by 2 (offsets) or 4 (logits)
+        // heads and every XCD's L2 fetches them again (measured 1.65x the algorithmic bytes at layer 0)
+        const int64_t hq = p.proj_hm ? (((int64_t)b * p.M + m) * p.Nq + q) * (LP * 3) : 0;
+        const int64_t o_idx = p.proj_hm ? hq + j * (P * 2) : bq * p.proj_stride + (m * LP + j * P) * 2;
+        const int64_t l_idx = p.proj_hm ? hq + LP * 2 + j * P : bq * p.proj_stride + p.M * LP * 2 + m * LP + j * P;
         if (p.proj_bf16) {
             const bf16_t *pp = reinterpret_cast<const bf16_t *>(p.proj);
             const uint4 o = *reinterpret_cast<const uint4 *>(pp + o_idx);
@@ -669,8 +674,8 @@ extern "C" int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *
 extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
                                         const int64_t *shapes, const int64_t *lsi, const float *ref, int ref_dim,
                                         int64_t ref_batch_stride, const void *proj, int proj_dtype,
-                                        int64_t proj_row_stride, const int32_t *order, int B, int Nv, int M, int D,
-                                        int L, int Nq, int P, void *out, int out_dtype)
+                                        int64_t proj_row_stride, int proj_head_major, const int32_t *order, int B,
+                                        int Nv, int M, int D, int L, int Nq, int P, void *out, int out_dtype)
 {
     if (int e = check_dims(B, Nv, M, D, L, Nq, P)) return e;
     if (ref_batch_stride == 0) ref_batch_stride = (int64_t)Nq * L * ref_dim;
@@ -680,15 +685,21 @@ extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value
     if (ref_dim != 2 && ref_dim != 4)
         return fail("Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
     if (L > kMaxLevels) return fail("msda_fused_forward: at most %d levels", kMaxLevels);
-    if (proj_row_stride < (int64_t)M * L * P * 3) return fail("msda_fused_forward: proj row stride too small");
+    if (!proj_head_major && proj_row_stride < (int64_t)M * L * P * 3)
+        return fail("msda_fused_forward: proj row stride too small");
+    if (proj_head_major && !(D == 32 && L == 4 && P == 4 && proj_dtype == SDETR_BF16 &&
+                             (value_dtype == SDETR_BF16 || value_dtype == SDETR_F16)))
+        return fail("msda_fused_forward: the head-major projection layout is built for D=32, L=P=4, bf16 projections "
+                    "and 16-bit value maps");
     if ((int64_t)B * Nq == 0) return 0;
     GatherArgs a{};
     a.value = reinterpret_cast<const char *>(value_hm);
     a.shapes = shapes; a.lsi = lsi; a.ref = ref; a.ref_dim = ref_dim; a.ref_batch_stride = ref_batch_stride;
     a.proj = proj; a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;
+    a.proj_hm = proj_head_major ? 1 : 0;
     a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
-    const bool l4p4 = D == 32 && L == 4 && P == 4 && (proj_row_stride % 8) == 0 &&
+    const bool l4p4 = D == 32 && L == 4 && P == 4 && (proj_head_major || (proj_row_stride % 8) == 0) &&
                       (reinterpret_cast<uintptr_t>(proj) % 16) == 0 && (reinterpret_cast<uintptr_t>(ref) % 16) == 0;
     if (l4p4 && value_dtype == SDETR_BF16) return launch_gather_l4p4<bf16_t>(stream, a);
     if (l4p4 && value_dtype == SDETR_F16) return launch_gather_l4p4<half_t>(stream, a);

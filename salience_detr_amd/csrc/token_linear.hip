@@ -43,6 +43,7 @@ struct TLArgs {
     // kStore
     bf16_t *out;
     int64_t out_row_stride;
+    int group;                // > 0: features per group, out is [B][N/group][rows_per_batch][group] (head-major)
     // kHeadMajor
     const uint8_t *pad;       // [T] or NULL
     void *hm;                 // [groups][B][M][rows_per_batch][32]
@@ -184,18 +185,28 @@ __global__ void __launch_bounds__(64 * WAVES, 1) token_linear_kernel(TLArgs p)
             if (EPI == kStore) {
                 if (valid) {
                     bf16_t *o = p.out + (int64_t)tok * p.out_row_stride + nt * 32 + 4 * h;
-    #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (nt * 32 + 8 * g + 4 * h < p.N)   // N is a multiple of 4
-                            *reinterpret_cast<uint2 *>(o + 8 * g) =
-                                make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+                    const int ngroups = p.group > 0 ? p.N / p.group : 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = nt * 32 + 8 * g + 4 * h;   // N and the group size are multiples of 4
+                        if (n >= p.N) continue;
+                        const uint2 v = make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]),
+                                                   pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+                        if (p.group > 0) {
+                            const int gi = n / p.group, within = n - gi * p.group;
+                            *reinterpret_cast<uint2 *>(p.out + (((int64_t)img * ngroups + gi) * p.rows_per_batch + ri) * p.group +
+                                                       within) = v;
+                        } else {
+                            *reinterpret_cast<uint2 *>(o + 8 * g) = v;
+                        }
+                    }
                 }
             } else if (EPI == kHeadMajor) {
                 if (valid) {
                     const int grp = nt / p.heads, m = nt - grp * p.heads;
                     const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + m) * p.rows_per_batch + ri;
                     uint16_t *o = reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 4 * h;
-    #pragma unroll
+#pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         uint2 v = make_uint2(0u, 0u);
                         if (!masked)
@@ -205,7 +216,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) token_linear_kernel(TLArgs p)
                     }
                 }
             } else {
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int n = nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     if (n < p.N) run_max = fmaxf(run_max, acc[i]);
@@ -429,7 +440,8 @@ extern "C" int sdetr_linear_pack_bf16(sdetr_stream_t stream, const void *weight,
 
 extern "C" int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, const void *x_add, int64_t x_add_batch_stride,
                                        int rows_per_batch, int tokens, int in_features, const void *packed_weight,
-                                       const float *bias_padded, int out_features, void *out, int64_t out_row_stride)
+                                       const float *bias_padded, int out_features, void *out, int64_t out_row_stride,
+                                       int group_features)
 {
     TLArgs a;
     if (int rc = tl_common(a, x, packed_weight, bias_padded, tokens, in_features, out_features)) return rc;
@@ -442,7 +454,11 @@ extern "C" int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, con
             return fail("token_linear: bad addend layout");
         a.x2 = (const bf16_t *)x_add; a.x2_batch_stride = x_add_batch_stride; a.rows_per_batch = rows_per_batch;
     }
-    a.out = (bf16_t *)out; a.out_row_stride = out_row_stride;
+    if (group_features < 0 || (group_features > 0 && ((group_features % 4) || out_features % group_features ||
+                                                      rows_per_batch <= 0 || tokens % rows_per_batch)))
+        return fail("token_linear: bad feature grouping");
+    if (group_features > 0) a.rows_per_batch = rows_per_batch;
+    a.out = (bf16_t *)out; a.out_row_stride = out_row_stride; a.group = group_features;
     return tl_launch(static_cast<hipStream_t>(stream), kStore, x_add != nullptr, a);
 }
 

@@ -478,9 +478,11 @@ def token_linear_applies(x: Tensor, weight: Tensor) -> bool:
             and weight.dim() == 2 and weight.shape[1] == 256 and weight.stride(1) == 1)
 
 
-def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optional[Tensor] = None) -> Tensor:
+def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optional[Tensor] = None,
+                 group_features: int = 0) -> Tensor:
     """``F.linear(x (+ x_add), weight, bias)`` for bf16 ``[B,n,256]`` tokens with the activations resident in
-    registers (include/salience_hip.h (8)); ``x_add`` may be a row prefix of a longer ``[B,n',256]`` buffer."""
+    registers (include/salience_hip.h (8)); ``x_add`` may be a row prefix of a longer ``[B,n',256]`` buffer.
+    ``group_features = g`` returns the result feature-group-major, ``[B, N/g, n, g]``."""
     if not token_linear_applies(x, weight):
         raise RuntimeError("token_linear: bf16 HIP tensors with 256 input features expected; no CPU fallback")
     shape = x.shape
@@ -492,7 +494,10 @@ def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optio
     if N % 4:
         raise RuntimeError("token_linear: out_features must be a multiple of 4")
     packed, b = _packed_linear_bf16(weight, bias)
-    out = torch.empty((B, n, N), dtype=torch.bfloat16, device=x.device)
+    if group_features and (N % group_features or group_features % 4):
+        raise RuntimeError("token_linear: group_features must divide out_features and be a multiple of 4")
+    out = torch.empty((B, N // group_features, n, group_features) if group_features else (B, n, N),
+                      dtype=torch.bfloat16, device=x.device)
     abs_ = 0
     if x_add is not None:
         if x_add.dtype != torch.bfloat16 or tuple(x_add.shape) != (B, n, 256):
@@ -500,9 +505,10 @@ def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optio
         abs_ = _batch_stride(x_add, "token_linear")
     with torch.cuda.device(x.device):
         code = _hip.lib().sdetr_token_linear_bf16(_hip.stream_ptr(), x3.data_ptr(), _hip.ptr(x_add), abs_, n, B * n, 256,
-                                                  packed.data_ptr(), b.data_ptr(), N, out.data_ptr(), N)
+                                                  packed.data_ptr(), b.data_ptr(), N, out.data_ptr(), N,
+                                                  int(group_features))
     _hip.check(code, "token_linear")
-    return out.view(tuple(shape[:-1]) + (N,))
+    return out if group_features else out.view(tuple(shape[:-1]) + (N,))
 
 
 def value_proj_head_major(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],

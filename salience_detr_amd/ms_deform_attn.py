@@ -157,11 +157,13 @@ def value_to_head_major(value_proj_out: Tensor, key_padding_mask: Optional[Tenso
 
 def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                        reference_points: Tensor, proj: Tensor, num_levels: int, num_points: int,
-                       order: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+                       order: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                       proj_head_major: bool = False) -> Tensor:
     """softmax + sampling locations + gather-reduce in one launch (ms_deform_attn.py:322-372).
 
     ``proj`` is the concatenated ``[sampling_offsets | attention_weights]`` projection of the query,
-    ``[B, Nq, >= 3*M*L*P]``; ``reference_points`` is ``[B, Nq, L, 2|4]`` fp32.
+    ``[B, Nq, >= 3*M*L*P]``; ``reference_points`` is ``[B, Nq, L, 2|4]`` fp32.  With ``proj_head_major`` it is
+    ``[B, M, Nq, 3*L*P]`` instead (per head: offsets, then logits).
     """
     _hip.require_device("msda_fused_forward", value_hm=value_hm, spatial_shapes=spatial_shapes,
                         level_start_index=level_start_index, order=order)
@@ -169,9 +171,15 @@ def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
         raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
             reference_points.shape[-1]))
     B, M, Nv, D = value_hm.shape
-    Nq = proj.shape[1]
-    if proj.stride(2) != 1 or proj.stride(0) != Nq * proj.stride(1):
-        proj = proj.contiguous()
+    if proj_head_major:
+        if proj.dim() != 4 or proj.shape[1] != M or proj.shape[3] != 3 * num_levels * num_points or not proj.is_contiguous():
+            raise RuntimeError("msda_fused_forward: head-major proj must be a contiguous [B, M, Nq, 3*L*P] tensor")
+        Nq, proj_stride = proj.shape[2], 0
+    else:
+        Nq = proj.shape[1]
+        if proj.stride(2) != 1 or proj.stride(0) != Nq * proj.stride(1):
+            proj = proj.contiguous()
+        proj_stride = proj.stride(1)
     if not reference_points.is_cuda:
         raise RuntimeError("msda_fused_forward: reference_points must be a HIP (cuda) tensor; no CPU fallback")
     if reference_points.dtype != torch.float32:
@@ -186,7 +194,7 @@ def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
         code = _hip.lib().sdetr_msda_fused_forward(
             _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), reference_points.data_ptr(), reference_points.shape[-1], ref_bs,
-            proj.data_ptr(), _hip.dtype_code(proj.dtype), proj.stride(1), _hip.ptr(order),
+            proj.data_ptr(), _hip.dtype_code(proj.dtype), proj_stride, 1 if proj_head_major else 0, _hip.ptr(order),
             B, Nv, M, D, num_levels, Nq, num_points, out.data_ptr(), _hip.dtype_code(out_dtype))
     _hip.check(code, "msda_fused_forward")
     return out
@@ -357,6 +365,19 @@ class MultiScaleDeformableAttention(nn.Module):
             self._fused_cache = (key, w, b)
         return self._fused_cache[1], self._fused_cache[2]
 
+    def _fused_query_projection_head_major(self):
+        """The same operand with its rows ordered by head -- head m: its 2*L*P offset rows, then its L*P logit rows --
+        so that the token-resident projection kernel can store ``[B, M, Nq, 3*L*P]`` directly."""
+        w, b = self._fused_query_projection()
+        hit = getattr(self, "_fused_hm_cache", None)
+        if hit is None or hit[0] is not w:
+            M, LP = self.num_heads, self.num_levels * self.num_points
+            order = torch.cat([torch.cat([torch.arange(m * 2 * LP, (m + 1) * 2 * LP),
+                                          M * 2 * LP + torch.arange(m * LP, (m + 1) * LP)]) for m in range(M)]).to(w.device)
+            hit = (w, w[order].contiguous(), b[order].contiguous())
+            self._fused_hm_cache = hit
+        return hit[1], hit[2]
+
     def project_value(self, value: Tensor, key_padding_mask: Optional[Tensor]) -> Tensor:
         """value_proj + padding zero-fill + head-major re-layout -> ``[B, M, Nv, D]``."""
         v = F.linear(value, self.value_proj.weight, self.value_proj.bias)
@@ -376,6 +397,19 @@ class MultiScaleDeformableAttention(nn.Module):
         caller that fuses ``output_proj`` with what follows it."""
         from .filter_ops import token_linear, token_linear_applies
         w, b = self._fused_query_projection()
+        head_major = (token_linear_applies(query, w) and query.dim() == 3 and order is None and self.num_levels == 4
+                      and self.num_points == 4 and value_hm.shape[-1] == 32
+                      and value_hm.dtype in (torch.float16, torch.bfloat16)
+                      and self.tiled_min_queries_per_region is None)
+        if head_major:
+            # per-head slabs: every XCD's L2 then fetches only its own head's projection values
+            wh, bh = self._fused_query_projection_head_major()
+            proj = token_linear(query, wh, bh, x_add=query_pos, group_features=3 * self.num_levels * self.num_points)
+            out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
+                                     self.num_levels, self.num_points, out_dtype=query.dtype, proj_head_major=True)
+            if not apply_output_proj:
+                return out
+            return F.linear(out, self.output_proj.weight, self.output_proj.bias)
         if token_linear_applies(query, w) and query.dim() == 3:
             proj = token_linear(query, w, b, x_add=query_pos)
         else:

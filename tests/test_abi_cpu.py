@@ -35,7 +35,7 @@ def test_argument_rejection_without_gpu(libpath):
     assert lib.sdetr_masked_topk_desc_f32(None, None, None, 0, 0, None, None, 2, 10, 11, 0, None, None, 0, None, 0) == _hip.EINVAL
     assert b"out of range" in lib.sdetr_last_error()
     assert lib.sdetr_msda_im2col_f32(None, None, None, None, None, None, 1, 1, 0, 32, 4, 1, 4, None) == _hip.EINVAL
-    assert lib.sdetr_msda_fused_forward(None, 1, 0, 1, 1, 1, 3, 0, 1, 0, 384, None, 1, 1, 8, 32, 4, 1, 4, 1, 0) == _hip.EINVAL
+    assert lib.sdetr_msda_fused_forward(None, 1, 0, 1, 1, 1, 3, 0, 1, 0, 384, 0, None, 1, 1, 8, 32, 4, 1, 4, 1, 0) == _hip.EINVAL
     assert b"must be 2 or 4" in lib.sdetr_last_error()
     assert lib.sdetr_topk_workspace_bytes(2, 1050, 1050) == 16  # one float: the masked-fill value
     assert lib.sdetr_topk_workspace_bytes(2, 11363, 300) == 16 + 2 * 11363 * 8 + 2 * 4 + 16  # + prefilter candidates

@@ -266,3 +266,35 @@ def test_tiled_with_clustered_queries_and_empty_regions():
     tiled = M.msda_tiled_forward(hm, shapes.to(DEV), lsi.to(DEV), ref.to(DEV), proj.to(DEV), levels[0], L, P,
                                  out_dtype=torch.float32)
     assert np.abs(tiled.cpu().numpy() - expect).max() < 2e-4
+
+
+def test_head_major_projection_layout_equals_token_rows():
+    """The fused kernel fed per-head projection slabs [B,M,Nq,48] (written directly by the token-resident linear
+    kernel) returns what it returns for the same numbers in token rows [B,Nq,384]."""
+    from salience_detr_amd import filter_ops as FO
+    from salience_detr_amd import ms_deform_attn as M_
+    torch.manual_seed(3)
+    levels = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    B, Nq, M, D, L, P = 2, 777, 8, 32, 4, 4
+    Nv = sum(h * w for h, w in levels)
+    shapes = torch.tensor(levels, dtype=torch.int64, device=DEV)
+    lsi = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    value_hm = (torch.randn(B, M, Nv, D, device=DEV)).to(torch.float16)
+    ref = torch.rand(B, Nq, L, 2, device=DEV)
+    x = torch.randn(B, Nq, 256, device=DEV).to(torch.bfloat16)
+    pos = torch.randn(B, Nq, 256, device=DEV).to(torch.bfloat16)
+    attn = M_.MultiScaleDeformableAttention(256, L, M, P).to(DEV).to(torch.bfloat16)
+    attn.sampling_offsets.weight.data.normal_(0, 0.02)
+    attn.attention_weights.weight.data.normal_(0, 0.05)
+    with torch.no_grad():
+        w, b = attn._fused_query_projection()
+        wh, bh = attn._fused_query_projection_head_major()
+        rows = FO.token_linear(x, w, b, x_add=pos)                                   # [B,Nq,384]
+        slabs = FO.token_linear(x, wh, bh, x_add=pos, group_features=48)             # [B,M,Nq,48]
+        # same numbers, two layouts
+        off = rows[..., :256].view(B, Nq, M, 32).permute(0, 2, 1, 3)
+        logit = rows[..., 256:].view(B, Nq, M, 16).permute(0, 2, 1, 3)
+        assert torch.equal(slabs, torch.cat([off, logit], -1))
+        o_rows = M_.msda_fused_forward(value_hm, shapes, lsi, ref, rows, L, P, out_dtype=torch.bfloat16)
+        o_hm = M_.msda_fused_forward(value_hm, shapes, lsi, ref, slabs, L, P, out_dtype=torch.bfloat16, proj_head_major=True)
+    assert torch.equal(o_rows, o_hm)
