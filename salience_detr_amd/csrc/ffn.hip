@@ -21,10 +21,11 @@
 //   * epilogue in registers: + b2 + residual, LayerNorm over the 256 channels a lane pair holds, bf16 store.
 //
 // Bound: bf16 MFMA peak -- 4*F*256 flops per token; one wave issues 64 chunks x 32 MFMAs.  Measured on MI355X (in-kernel
-// s_memtime, F = 2048): ~1800 cycles per chunk against 1056 for the bare MFMAs -- 550 + 590 for the two products, ~180
-// for MFMA drain + ReLU/bf16, ~490 for the barrier and the wave's 8 LDS-DMA issues (~45 cycles each, they stall the
-// issuing wave); 68 us for any token count up to 32 768 (one wave per SIMD, one round).  Next steps: loader waves
-// for the copies, and interleaving chunk jt's second product with chunk jt+1's first.
+// s_memtime, F = 2048) with the copies still issued by the compute waves: ~1800 cycles per chunk against 1056 for the
+// bare MFMAs -- 550 + 590 for the two products, ~180 for MFMA drain + ReLU/bf16, ~490 for the barrier and the wave's
+// 8 LDS-DMA issues (~45 cycles each, they stall the issuing wave): 64 us for any token count up to 32 768 (one compute
+// wave per SIMD, one round).  With the loader waves below: 54 us.  Next: interleaving chunk jt's second product with
+// chunk jt+1's first (hides the drain + ReLU phase and most of the barrier).
 #include "common.h"
 
 namespace sdetr {
@@ -107,23 +108,51 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, v), z));
 }
 
-__global__ void __launch_bounds__(kBlock, 1) ffn_fused_kernel(FfnArgs p)
+// Block = 4 compute waves (32 tokens each) + 4 LOADER waves, one of each per SIMD.  An LDS-DMA instruction stalls the
+// wave that issues it for ~45 cycles; issued by the compute waves the 8 copies per chunk cost a fifth of the loop
+// (measured: 490 cycles of 1800 for barrier + copies).  The loaders do nothing else: wait for their copies, meet the
+// compute waves at the chunk barrier, issue the next chunk.  (All waves get the same register allocation, so the
+// kernel has to fit 256 registers for two waves per SIMD.)
+constexpr int kFThreads = 512;
+
+__global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *wbuf = lds;                                                  // 3 chunk buffers
     float *b1s = reinterpret_cast<float *>(lds + 3 * kFChunkBytes);    // [F]
     float *par = b1s + p.nchunk * kFChunk;                             // b2 | gamma | beta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wbuf_lds = lds_address(wbuf);
+
+    if (wave >= 4) {
+        // ---- loader wave: a quarter (8 KB = 8 LDS-DMA instructions) of every 32 KB chunk ----
+        const int lw = wave - 4;
+        const uint32_t voff = (uint32_t)(lw * 8192 + lane * 16);
+        const uint32_t wave_lds = wbuf_lds + lw * 8192;
+        issue_chunk(p.pw, voff, wave_lds);
+        if (p.nchunk > 1) issue_chunk(p.pw + kFChunkBytes, voff, wave_lds + kFChunkBytes);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // chunks 0 and 1 are in LDS
+        int buf = 0;
+        for (int jt = 0; jt + 1 < p.nchunk; ++jt) {
+            // chunk jt+1 (requested one iteration ago) has landed; at the barrier every compute wave is past chunk
+            // jt-1, whose buffer the copy of chunk jt+2 may now overwrite
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (jt + 2 < p.nchunk) {
+                const int pbuf = buf == 0 ? 2 : buf - 1;
+                issue_chunk(p.pw + (int64_t)(jt + 2) * kFChunkBytes, voff, wave_lds + pbuf * kFChunkBytes);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        return;
+    }
+
     const int t = lane & 31, h = lane >> 5;
     const int tok = blockIdx.x * kFTokBlock + wave * kFTokWave + t;
     const bool valid = tok < p.T;
     const int64_t row = (int64_t)(valid ? tok : p.T - 1) * kFE;
 
-    const uint32_t wbuf_lds = lds_address(wbuf);
-    const uint32_t voff = (uint32_t)(wave * 8192 + lane * 16);     // my 16 bytes of each of my wave's 8 pieces
-    const uint32_t wave_lds = wbuf_lds + wave * 8192;
-    issue_chunk(p.pw, voff, wave_lds);
-    if (p.nchunk > 1) issue_chunk(p.pw + kFChunkBytes, voff, wave_lds + kFChunkBytes);
     for (int i = tid; i < p.nchunk * kFChunk; i += kBlock) b1s[i] = p.b1[i];
     par[tid] = p.b2[tid];
     par[kFE + tid] = p.gamma[tid];
@@ -152,11 +181,12 @@ __global__ void __launch_bounds__(kBlock, 1) ffn_fused_kernel(FfnArgs p)
     // STARTS as the bias (four 16-byte LDS reads land in the four register quads -- no zeroing, no adds), ReLU runs
     // on packed bf16 pairs, and the chunk copy uses one scalar base + immediate offsets.
     //
-    // A fragments come from LDS through an 8-deep ring of registers: fragment f of a chunk (0..15 = W1 k-steps,
-    // 16..31 = W2 (e-tile, k-block)) is requested 8 MFMAs (~256 cycles) before it is used, and a slot is refilled
+    // A fragments come from LDS through a 4-deep ring of registers (8 would not fit the 256-register budget the loader
+    // waves impose): fragment f of a chunk (0..15 = W1 k-steps, 16..31 = W2 (e-tile, k-block)) is requested 4 MFMAs
+    // (~130 cycles, the LDS latency) before it is used, and a slot is refilled
     // right AFTER the MFMA that consumed it, so no value ever needs a second register (nothing to copy on the loop's
-    // back edge).  The last 8 requests of a chunk fetch the first 8 fragments of the next one.
-    constexpr int R = 8;
+    // back edge).  The last requests of a chunk fetch the first fragments of the next one.
+    constexpr int R = 4;
     uint4 ring[R];
     lds_cptr_t cb = (lds_cptr_t)wbuf + lane * 16;
     const lds_cptr_t bias_base = (lds_cptr_t)(const char *)b1s + 16 * h;
@@ -203,16 +233,8 @@ __global__ void __launch_bounds__(kBlock, 1) ffn_fused_kernel(FfnArgs p)
         // accumulator between two of the MFMAs above, a copy that reads registers the MFMA before it has not written yet
         asm volatile("" : "+v"(hp[0].x), "+v"(hp[0].y), "+v"(hp[0].z), "+v"(hp[0].w), "+v"(hp[1].x), "+v"(hp[1].y), "+v"(hp[1].z), "+v"(hp[1].w));
         load_bias(jt + 1 < p.nchunk ? jt + 1 : jt);   // next chunk's bias into the now free accumulator registers
-        // Chunk jt+1 (requested one iteration ago) has landed for me, then for everyone; every wave is past chunk
-        // jt-1, whose buffer the copies of chunk jt+2 may now overwrite.
-        if (jt + 1 < p.nchunk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (jt + 2 < p.nchunk) {
-                const int pbuf = buf == 0 ? 2 : buf - 1;   // buffer of chunk jt-1 == buffer of chunk jt+2
-                issue_chunk(p.pw + (int64_t)(jt + 2) * kFChunkBytes, voff, wave_lds + pbuf * kFChunkBytes);
-            }
-        }
+        // chunk jt+1 is in LDS once the loaders reach this barrier; passing it also tells them chunk jt-1 is done with
+        if (jt + 1 < p.nchunk) __builtin_amdgcn_s_barrier();   // (the loader waves' side: see the top of the kernel)
         // Y^T[e][t] += sum_j W2[e][32jt + j] H^T[j][t]   (W2's j order permuted to the accumulator layout above)
 #pragma unroll
         for (int f = 16; f < 32; ++f) {
@@ -338,7 +360,7 @@ extern "C" int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const 
     FfnArgs a;
     a.x = (const bf16_t *)x; a.pw = (const char *)packed_weights; a.b1 = bias1; a.b2 = bias2; a.gamma = norm_weight;
     a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out; a.T = tokens; a.nchunk = hidden / kFChunk;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((tokens + kFTokBlock - 1) / kFTokBlock)), dim3(kBlock), lds,
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((tokens + kFTokBlock - 1) / kFTokBlock)), dim3(kFThreads), lds,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("ffn_fused");
 }

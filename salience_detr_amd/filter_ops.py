@@ -410,8 +410,8 @@ def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor
 def fused_ffn_applies(x: Tensor, linear1, linear2, norm, activation) -> bool:
     """The one-launch MFMA feed-forward (csrc/ffn.hip) covers the released configuration: bf16, embed_dim 256, ReLU,
     hidden a multiple of 32 that fits its LDS budget.  Its run time is flat in the token count (one 32-token wave per
-    SIMD, ~68 us at hidden 2048 on MI355X); below ~6000 tokens the two library GEMMs are faster."""
-    return (x.numel() >= 6000 * 256 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and isinstance(activation, torch.nn.ReLU)
+    SIMD, ~54 us at hidden 2048 on MI355X); below ~5000 tokens the two library GEMMs are faster."""
+    return (x.numel() >= 5000 * 256 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and isinstance(activation, torch.nn.ReLU)
             and linear1.weight.dtype == torch.bfloat16 and linear2.weight.dtype == torch.bfloat16
             and linear1.in_features == 256 and linear2.out_features == 256
             and linear1.out_features == linear2.in_features and linear1.out_features % 32 == 0
