@@ -169,6 +169,15 @@ int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const 
                                int64_t index_offset, float *out_score, int64_t *out_index,
                                int64_t out_row_stride, void *workspace, size_t workspace_bytes);
 
+/*   sdetr_merge_sorted_desc: stable descending sort of a [B,n] score array that is the concatenation of
+ *   num_segments segments (host array segment_start, first = 0), each already sorted descending with ties in position
+ *   order -- exactly what the per-level calls above leave in the column blocks of one buffer -- done as a merge
+ *   (one thread per element, num_segments-1 binary searches).  out_index[b][rank] = payload[b][pos]; out_score
+ *   optional.  Bit-identical to the stable sort of salience_transformer.py:156-158. */
+int sdetr_merge_sorted_desc(sdetr_stream_t stream, const float *score, const int64_t *payload,
+                            const int *segment_start, int num_segments, int batch_size, int n, int64_t *out_index,
+                            float *out_score);
+
 /* ---------------------------------------------------------------------------------------------
  * (5) Token row movement of the encoder loop (models/bricks/salience_transformer.py:454-461
  *     torch.gather by foreground_inds; :474-485 per-image scatter of the first

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
+    "sdetr_merge_sorted_desc": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sdetr_masked_fill_min": (_i, [_p, _p, _p, _p, _i, _i64, _p]),
     "sdetr_encoder_reference_points": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i]),

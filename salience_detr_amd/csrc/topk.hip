@@ -295,6 +295,50 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
     }
 }
 
+
+// ---- merge of descending-sorted segments ------------------------------------------------------------------------
+// The global sort of salience_transformer.py:156-158 runs over the concatenation of the per-level top-k results,
+// each of which is already sorted (descending, ties in position order).  A stable descending sort of that
+// concatenation is therefore an L-way merge: an element's final rank is its position inside its own segment plus, for
+// every other segment, the number of elements that precede it there -- strictly greater scores, and equal scores only
+// if that segment comes earlier in the concatenation.  One thread per element, L-1 binary searches: O(n log n)
+// compares in total instead of the rank kernel's n^2, and bit-identical to the stable sort.
+constexpr int kMaxSegments = 8;
+struct MergeArgs {
+    const float *score;       // [B, n]
+    const int64_t *payload;   // [B, n]
+    int seg_start[kMaxSegments + 1];
+    int nseg, n;
+    int64_t *out_index;       // [B, n]
+    float *out_score;         // [B, n] or NULL
+};
+
+__global__ void __launch_bounds__(256) merge_sorted_kernel(MergeArgs p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const float *row = p.score + (int64_t)blockIdx.y * p.n;
+    const uint32_t key = desc_bits(row[i]);   // ascending in this key == descending in score (same total order as the rank kernel)
+    int seg = 0;
+    for (int s = 1; s < p.nseg; ++s) seg = i >= p.seg_start[s] ? s : seg;
+    int rank = i - p.seg_start[seg];
+    for (int s = 0; s < p.nseg; ++s) {
+        if (s == seg) continue;
+        // number of elements of segment s with key < mine (s after my segment) or key <= mine (s before it)
+        int lo = p.seg_start[s], hi = p.seg_start[s + 1];
+        const bool inclusive = s < seg;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t k = desc_bits(row[mid]);
+            if (inclusive ? k <= key : k < key) lo = mid + 1; else hi = mid;
+        }
+        rank += lo - p.seg_start[s];
+    }
+    const int64_t o = (int64_t)blockIdx.y * p.n + rank;
+    p.out_index[o] = p.payload[(int64_t)blockIdx.y * p.n + i];
+    if (p.out_score) p.out_score[o] = row[i];
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
@@ -369,4 +413,25 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
     }
     hipLaunchKernelGGL(topk_rank_kernel, dim3((unsigned)((ranked + 63) / 64), (unsigned)B), dim3(kRankThreads), 0, stream, r);
     return check_launch("topk_rank");
+}
+
+extern "C" int sdetr_merge_sorted_desc(sdetr_stream_t stream, const float *score, const int64_t *payload,
+                                       const int *segment_start, int num_segments, int B, int n, int64_t *out_index,
+                                       float *out_score)
+{
+    if (B < 0 || n < 0 || num_segments <= 0 || num_segments > kMaxSegments) return fail("merge_sorted: bad sizes");
+    if ((int64_t)B * n == 0) return 0;
+    if (!score || !payload || !segment_start || !out_index) return fail("merge_sorted: null pointer");
+    MergeArgs a{};
+    a.score = score; a.payload = payload; a.nseg = num_segments; a.n = n; a.out_index = out_index; a.out_score = out_score;
+    for (int s = 0; s < num_segments; ++s) {
+        a.seg_start[s] = segment_start[s];
+        if (segment_start[s] < 0 || segment_start[s] > n || (s > 0 && segment_start[s] < segment_start[s - 1]))
+            return fail("merge_sorted: segment starts must be non-decreasing inside [0, n]");
+    }
+    if (segment_start[0] != 0) return fail("merge_sorted: the first segment starts at 0");
+    a.seg_start[num_segments] = n;
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("merge_sorted");
 }

@@ -623,3 +623,22 @@ def token_linear_ln(x: Tensor, linear, norm, residual: Tensor, scatter_index: Op
             _hip.ptr(scatter_index), out_rows)
     _hip.check(code, "token_linear_ln")
     return out
+
+
+def merge_sorted_desc(score: Tensor, payload: Tensor, segment_start, want_scores: bool = False):
+    """Stable descending sort of ``score`` [B,n] = concatenation of descending-sorted segments starting at the
+    columns ``segment_start`` (python ints, first 0), as a merge (include/salience_hip.h (4)).  Returns
+    ``(sorted scores | None, payload in sorted order)``."""
+    import ctypes
+    _hip.require_device("merge_sorted_desc", score=score, payload=payload)
+    if score.dtype != torch.float32 or payload.dtype != torch.int64 or payload.shape != score.shape or score.dim() != 2:
+        raise RuntimeError("merge_sorted_desc: fp32 [B,n] scores and an int64 payload of the same shape expected")
+    B, n = score.shape
+    seg = (ctypes.c_int * len(segment_start))(*[int(v) for v in segment_start])
+    out_index = torch.empty_like(payload)
+    out_score = torch.empty_like(score) if want_scores else None
+    with torch.cuda.device(score.device):
+        code = _hip.lib().sdetr_merge_sorted_desc(_hip.stream_ptr(), score.data_ptr(), payload.data_ptr(), seg,
+                                                  len(segment_start), B, n, out_index.data_ptr(), _hip.ptr(out_score))
+    _hip.check(code, "merge_sorted_desc")
+    return out_score, out_index

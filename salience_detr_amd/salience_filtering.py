@@ -20,7 +20,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, salience_head
+from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, merge_sorted_desc,
+                         salience_head)
 
 
 class MaskPredictor(nn.Module):
@@ -163,6 +164,7 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     if extras is not None and fused:
         extras["level_min"] = level_min
         extras["selected"] = (sel_score, sel_inds)
+        extras["segments"] = offs          # every column block is sorted descending, ties in index order
     return salience_score, level_inds, level_score
 
 
@@ -183,7 +185,11 @@ def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Te
         selected_score = torch.cat(list(level_score), 1)
         selected_inds = torch.cat(list(level_inds), 1)
     n = selected_inds.shape[1]
-    _, sorted_inds = masked_topk_desc(selected_score, n, payload=selected_inds, want_scores=False)
+    if "segments" in extras:
+        # the per-level results are sorted already: the stable global sort is a 4-way merge
+        _, sorted_inds = merge_sorted_desc(selected_score, selected_inds, extras["segments"])
+    else:
+        _, sorted_inds = masked_topk_desc(selected_score, n, payload=selected_inds, want_scores=False)
     counts = pyramid.layer_token_counts(n, layer_filter_ratio)
     # views of ONE sorted list: the encoder recognises the prefix structure and keeps the tokens in sorted order
     foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c] for c in counts]

@@ -468,3 +468,25 @@ def test_token_linear_ln_matches_reference_and_scatters(B, n):
             want[b, idx[b]] = got[b]
         out = F.token_linear_ln(x, lin, norm, residual=res, scatter_index=idx, scatter_into=dst)
         assert out is dst and torch.equal(dst, want)
+
+
+@pytest.mark.parametrize("sizes", [[5], [300, 200, 100, 7], [6680, 3360, 1050, 273], [1, 1, 1], [0, 4, 0, 9]])
+def test_merge_of_sorted_segments_is_the_stable_sort(sizes):
+    B = 2
+    torch.manual_seed(sum(sizes))
+    segs = []
+    for n in sizes:
+        v = torch.randn(B, n)
+        v[:, : n // 3] = v[:, :1] if n else v[:, :0]            # ties inside a segment
+        segs.append(torch.sort(v, dim=1, descending=True, stable=True)[0])
+    score = torch.cat(segs, 1)
+    if len(sizes) > 1 and sizes[0] and sizes[1]:
+        score[:, sizes[0]:sizes[0] + max(1, sizes[1] // 4)] = score[:, :1]     # ties across segments
+        score[:, sizes[0]:sizes[0] + sizes[1]] = torch.sort(score[:, sizes[0]:sizes[0] + sizes[1]], dim=1, descending=True, stable=True)[0]
+    n = score.shape[1]
+    payload = torch.stack([torch.randperm(n) for _ in range(B)]) + 1000
+    starts = [sum(sizes[:i]) for i in range(len(sizes))]
+    rv, ri = R.topk_desc_stable(score, n)
+    gs, gi = F.merge_sorted_desc(score.to(DEV), payload.to(DEV), starts, want_scores=True)
+    assert torch.equal(gs.cpu(), rv)
+    assert torch.equal(gi.cpu(), torch.gather(payload, 1, ri))
