@@ -79,6 +79,7 @@ struct PrefilterArgs {
     int64_t mask_stride;
     const float *fill;
     int N, k;
+    int stage;            // 1: stage the keys through (dynamic) LDS, N * 4 bytes
     uint32_t *cand_key;   // [B][N]
     uint32_t *cand_pos;   // [B][N]
     int32_t *cand_count;  // [B]
@@ -120,7 +121,29 @@ __global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterAr
     const int chunk = (p.N + kPreThreads - 1) / kPreThreads;  // <= KPT
     const int lo = tid * chunk, hi = min(p.N, lo + chunk);
     uint32_t keys[KPT];
-    {
+    if (p.stage) {
+        // Coalesced global reads (thread t takes elements t, t + 1024, ...) staged through LDS, from which every
+        // thread then takes its CONTIGUOUS chunk -- the candidate list must stay in position order (the rank kernel's
+        // tie rule), and reading the chunks straight from global memory makes every load instruction of a wave touch
+        // ~48 cache lines: 16 waves x KPT loads on this one CU's address unit was ~4 us of the kernel's 11.
+        extern __shared__ uint32_t keybuf[];
+        for (int c0 = 0; c0 < KPT; c0 += 6) {
+            float sv[6];
+            uint8_t mk[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sv[c] = srow[min((c0 + c) * kPreThreads + tid, p.N - 1)];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) mk[c] = mrow ? mrow[min((c0 + c) * kPreThreads + tid, p.N - 1)] : (uint8_t)0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int i = (c0 + c) * kPreThreads + tid;
+                if (i < p.N) keybuf[i] = desc_bits(mk[c] ? fill : sv[c]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) keys[c] = (lo + c < hi) ? keybuf[lo + c] : 0xffffffffu;
+    } else {
         float sv[KPT];
         uint8_t mk[KPT];
 #pragma unroll
@@ -399,7 +422,19 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
         f.cand_pos = f.cand_key + (size_t)B * n;
         f.cand_count = reinterpret_cast<int32_t *>(f.cand_pos + (size_t)B * n);
         const int chunk = (n + kPreThreads - 1) / kPreThreads;
-#define SDETR_PRE(KPT) hipLaunchKernelGGL(topk_prefilter_kernel<KPT>, dim3((unsigned)B), dim3(kPreThreads), 0, stream, f)
+        // keys staged through LDS when they fit next to the kernel's static arrays
+        f.stage = (size_t)n * 4 <= 150 * 1024 ? 1 : 0;
+        const size_t dyn = f.stage ? (size_t)n * 4 : 0;
+#define SDETR_PRE(KPT)                                                                                              \
+    do {                                                                                                            \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(topk_prefilter_kernel<KPT>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                      \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL(topk_prefilter_kernel<KPT>, dim3((unsigned)B), dim3(kPreThreads), dyn, stream, f);       \
+    } while (0)
         if (chunk <= 5) SDETR_PRE(5);
         else if (chunk <= 12) SDETR_PRE(12);
         else if (chunk <= 17) SDETR_PRE(17);
