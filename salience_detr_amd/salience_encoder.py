@@ -148,15 +148,19 @@ class SalienceTransformerEncoderLayer(nn.Module):
         stacked = select_stack(query, pos_sorted, sel)                       # [q+pos ; q] rows, [B,2N,E]
         fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
         if fuse_tail:
-            # out_proj + residual + pre_norm, written straight back to the selected rows of the layer's queries
-            heads_out = self._pre_attention_stacked(stacked, N, apply_out_proj=False)
-            token_linear_ln(heads_out, self.pre_attention.out_proj, self.pre_norm, residual=stacked[:, N:],
-                            scatter_index=sel, scatter_into=query)
+            # The 2 x 300 selected rows are too few for the token-resident kernel (its weight copy + row-strided
+            # epilogue cost 16 us whatever the row count; library GEMM + fused norm/scatter: 11 us) ...
+            tgt2 = self._pre_attention_stacked(stacked, N)
+            fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
             sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
                                                     level_start_index, query_pos=pos_sorted[:, :c],
                                                     apply_output_proj=False)
-            # output_proj + residual + norm1
-            query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
+            # ... but it pays for ten thousand queries and more: output_proj + residual + norm1 in one launch
+            if query.shape[0] * c >= 12000:
+                query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
+            else:
+                src2 = F.linear(sampled, self.self_attn.output_proj.weight, self.self_attn.output_proj.bias)
+                query = fused_layer_norm(query, self.norm1, residual=src2)
             return self._forward_ffn_native(query)
         tgt2 = self._pre_attention_stacked(stacked, N)
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
