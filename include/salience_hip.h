@@ -254,14 +254,15 @@ int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dt
  *     (models/bricks/base_transformer.py:111).  x / residual are [batch_size, rows_per_batch, channels] with the
  *     given element strides (last dim contiguous); residual, row_scale ([batch*rows] f32) and alpha (device
  *     scalar) may be NULL; out is contiguous, or -- with scatter_index [batch*rows] -- row (b,i) is written to row
- *     scatter_index[b,i] of out [batch, out_batch_rows, channels] (norm + scatter of :377-379 in one pass).
+ *     scatter_index[b,i] of out [batch, out_batch_rows, channels] (norm + scatter of :377-379 in one pass); with
+ *     gather_x the x row is read at that index too (x = the buffer being updated: gather + norm + scatter).
  *     dtypes: SDETR_F32 | SDETR_BF16 (x and residual share x_dtype).
  *   sdetr_column_mean_f32: out[b,c] = mean_i x[b,i,c]   (global half of the salience head, :43-45). */
 int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void *residual, int x_dtype,
                     int64_t x_batch_stride, int64_t x_row_stride, int64_t res_batch_stride, int64_t res_row_stride,
                     const float *row_scale, const float *alpha, const void *gamma, const void *beta,
                     int param_dtype, float eps, int batch_size, int rows_per_batch, int channels, void *out,
-                    int out_dtype, const int64_t *scatter_index, int64_t out_batch_rows);
+                    int out_dtype, const int64_t *scatter_index, int64_t out_batch_rows, int gather_x);
 int sdetr_column_mean_f32(sdetr_stream_t stream, const float *x, int64_t batch_stride, int64_t row_stride,
                           int batch_size, int rows, int channels, float *out);
 
@@ -360,6 +361,17 @@ int sdetr_token_linear_ln_bf16(sdetr_stream_t stream, const void *x, const void 
                                const void *packed_weight, const float *bias, const float *norm_weight,
                                const float *norm_bias, float norm_eps, void *out, const int64_t *scatter_index,
                                int64_t out_batch_rows);
+
+/* ---- (9) dense self-attention over the selected queries ---------------------------------------------------------
+ * models/bricks/salience_transformer.py:366-376 up to the concatenated heads, one launch: gather tgt / pos rows by
+ * index [batch, num_select], q = k = tgt + pos, v = tgt, in-projection (packed_in_proj = sdetr_linear_pack_bf16 of
+ * nn.MultiheadAttention.in_proj_weight [768,256]; in_proj_bias fp32 [768]), softmax(q k^T / sqrt(32)) v per head ->
+ * out [batch, num_select, 256] bf16 (the input of out_proj).  embed_dim 256, 8 heads, num_select <= 320; query / pos
+ * images are *_batch_stride elements apart. */
+int sdetr_topk_attention_heads_bf16(sdetr_stream_t stream, const void *query, int64_t query_batch_stride,
+                                    const void *pos, int64_t pos_batch_stride, const int64_t *index, int batch_size,
+                                    int num_select, int embed_dim, int num_heads, const void *packed_in_proj,
+                                    const float *in_proj_bias, void *out);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ SIGNATURES = {
     "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i]),
     "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _i, _i, _p]),
     "sdetr_layernorm": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i, ctypes.c_float, _i, _i, _i, _p, _i,
-                             _p, _i64]),
+                             _p, _i64, _i]),
     "sdetr_advance_rows": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _i]),
     "sdetr_select_stack": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
     "sdetr_encoder_finalize": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -64,6 +64,7 @@ SIGNATURES = {
     "sdetr_value_proj_head_major": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_class_head_max_times": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _i, _i, _p]),
     "sdetr_token_linear_ln_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i64]),
+    "sdetr_topk_attention_heads_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p, _p, _p]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
 }

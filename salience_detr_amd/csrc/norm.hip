@@ -29,6 +29,7 @@ struct NormArgs {
     void *out;              // [B*n, C] contiguous, or [B, out_batch_rows, C] when scatter_index is given
     const int64_t *scatter_index;  // [B*n] destination row inside the image, or NULL
     int64_t out_batch_rows;
+    int gather_x;                  // 1: x row i is read at scatter_index[b,i] as well (in-place update of selected rows)
     int64_t x_batch_stride, x_row_stride, res_batch_stride, res_row_stride;
     int64_t rows;
     int n_per_batch, C;
@@ -80,7 +81,8 @@ __global__ void __launch_bounds__(kBlock) layernorm_kernel(NormArgs p)
     const int64_t rr = row < p.rows ? row : 0;
     const int64_t b = rr / p.n_per_batch, i = rr - b * p.n_per_batch;
     if (live) {
-        load8<XT>(reinterpret_cast<const XT *>(p.x) + b * p.x_batch_stride + i * p.x_row_stride + l * 8, v);
+        const int64_t xi = p.gather_x ? p.scatter_index[rr] : i;
+        load8<XT>(reinterpret_cast<const XT *>(p.x) + b * p.x_batch_stride + xi * p.x_row_stride + l * 8, v);
         if (p.res) {
             float r[8];
             load8<XT>(reinterpret_cast<const XT *>(p.res) + b * p.res_batch_stride + i * p.res_row_stride + l * 8, r);
@@ -189,8 +191,9 @@ extern "C" int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void 
                                int64_t res_row_stride, const float *row_scale, const float *alpha, const void *gamma,
                                const void *beta, int param_dtype, float eps, int batch_size, int rows_per_batch,
                                int channels, void *out, int out_dtype, const int64_t *scatter_index,
-                               int64_t out_batch_rows)
+                               int64_t out_batch_rows, int gather_x)
 {
+    if (gather_x && !scatter_index) return fail("layernorm: gather_x needs the row index");
     if (batch_size < 0 || rows_per_batch < 0 || channels <= 0) return fail("layernorm: bad dims");
     if (channels % 8 != 0 || channels > 512) return fail("layernorm: channels (%d) must be a multiple of 8, <= 512", channels);
     if ((x_row_stride % 8) || (x_batch_stride % 8) || (residual && ((res_row_stride % 8) || (res_batch_stride % 8))))
@@ -203,7 +206,7 @@ extern "C" int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void 
     a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
     a.res_batch_stride = res_batch_stride; a.res_row_stride = res_row_stride;
     a.rows = rows; a.n_per_batch = rows_per_batch; a.C = channels; a.eps = eps;
-    a.scatter_index = scatter_index; a.out_batch_rows = out_batch_rows;
+    a.scatter_index = scatter_index; a.out_batch_rows = out_batch_rows; a.gather_x = gather_x ? 1 : 0;
     const int key = x_dtype * 4 + param_dtype * 2 + out_dtype;
     switch (key) {
         case 0: return launch_ln<float, float, float>(stream, a);

@@ -192,20 +192,26 @@ def _bn_view(t: Tensor):
 def fused_layer_norm(x: Tensor, norm: torch.nn.LayerNorm, residual: Optional[Tensor] = None,
                      row_scale: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                      out_dtype: Optional[torch.dtype] = None, scatter_index: Optional[Tensor] = None,
-                     scatter_into: Optional[Tensor] = None) -> Tensor:
+                     scatter_into: Optional[Tensor] = None, gather_x: bool = False) -> Tensor:
     """``norm((x [+ residual]) * (1 + row_scale * alpha))`` in one launch (see include/salience_hip.h (6)).
     ``x`` may be a batch-strided view (e.g. one level's slice of ``[B,S,C]``); the result is contiguous.
     With ``scatter_index`` [B,n] int64 and ``scatter_into`` [B,m,C] (contiguous) row ``(b,i)`` of the result is
-    written to ``scatter_into[b, scatter_index[b,i]]`` instead (in place; returns ``scatter_into``)."""
+    written to ``scatter_into[b, scatter_index[b,i]]`` instead (in place; returns ``scatter_into``).  ``gather_x``:
+    ``x`` is a ``[B,m,C]`` buffer whose rows ``scatter_index[b,i]`` are the inputs (``x = scatter_into`` updates the
+    selected rows in place: gather + residual + norm + scatter in one launch); ``residual`` stays ``[B,n,C]``."""
     if not x.is_cuda:
         raise RuntimeError("fused_layer_norm: HIP device tensors required; there is no CPU fallback")
     shape = x.shape
     xv, xbs, xrs = _bn_view(x)
     B, n, C = xv.shape
+    if gather_x:
+        if scatter_index is None or scatter_index.shape[0] != B:
+            raise RuntimeError("fused_layer_norm: gather_x needs scatter_index [B,n]")
+        n = scatter_index.shape[1]
     rv, rbs, rrs = (None, 0, 0)
     if residual is not None:
-        if residual.dtype != x.dtype or residual.shape != x.shape:
-            raise RuntimeError("fused_layer_norm: residual must match x")
+        if residual.dtype != x.dtype or tuple(residual.shape) != (B, n, C):
+            raise RuntimeError("fused_layer_norm: residual must match the normalised rows")
         rv, rbs, rrs = _bn_view(residual)
     if row_scale is not None:
         row_scale = row_scale.reshape(-1)
@@ -226,7 +232,8 @@ def fused_layer_norm(x: Tensor, norm: torch.nn.LayerNorm, residual: Optional[Ten
         code = _hip.lib().sdetr_layernorm(
             _hip.stream_ptr(), xv.data_ptr(), _hip.ptr(rv), _hip.dtype_code(x.dtype), xbs, xrs, rbs, rrs,
             _hip.ptr(row_scale), _hip.ptr(alpha), w.data_ptr(), b.data_ptr(), _hip.dtype_code(w.dtype),
-            float(norm.eps), B, n, C, out.data_ptr(), _hip.dtype_code(out_dtype), _hip.ptr(scatter_index), out_rows)
+            float(norm.eps), B, n, C, out.data_ptr(), _hip.dtype_code(out_dtype), _hip.ptr(scatter_index), out_rows,
+            1 if gather_x else 0)
     _hip.check(code, "fused_layer_norm")
     return out if scatter_index is not None else out.view(shape)
 
@@ -642,3 +649,30 @@ def merge_sorted_desc(score: Tensor, payload: Tensor, segment_start, want_scores
                                                   len(segment_start), B, n, out_index.data_ptr(), _hip.ptr(out_score))
     _hip.check(code, "merge_sorted_desc")
     return out_score, out_index
+
+
+def topk_attention_applies(query: Tensor, mha, num_select: int) -> bool:
+    return (query.is_cuda and query.dtype == torch.bfloat16 and query.shape[-1] == 256 and mha.embed_dim == 256
+            and mha.num_heads == 8 and mha.in_proj_weight is not None and mha.in_proj_weight.dtype == torch.bfloat16
+            and mha.in_proj_bias is not None and 0 < num_select <= 320)
+
+
+def topk_attention_heads(query: Tensor, pos: Tensor, index: Tensor, mha) -> Tensor:
+    """Concatenated heads ``[B,N,256]`` of ``mha(q = k = query[index] + pos[index], v = query[index])`` before its
+    out-projection, in one launch (include/salience_hip.h (9)); ``query`` / ``pos`` may be row prefixes of longer
+    buffers."""
+    _hip.require_device("topk_attention_heads", index=index)
+    if index.dtype != torch.int64 or index.dim() != 2 or pos.dtype != query.dtype:
+        raise RuntimeError("topk_attention_heads: int64 [B,N] index and query / pos of one dtype expected")
+    B, N = index.shape
+    if not topk_attention_applies(query, mha, N):
+        raise RuntimeError("topk_attention_heads: bf16, embed_dim 256, 8 heads, <= 320 selected tokens; no CPU fallback")
+    packed, bias = _packed_linear_bf16(mha.in_proj_weight, mha.in_proj_bias)
+    out = torch.empty((B, N, 256), dtype=torch.bfloat16, device=query.device)
+    with torch.cuda.device(query.device):
+        code = _hip.lib().sdetr_topk_attention_heads_bf16(
+            _hip.stream_ptr(), query.data_ptr(), _batch_stride(query, "topk_attention_heads"), pos.data_ptr(),
+            _batch_stride(pos, "topk_attention_heads"), index.data_ptr(), B, N, 256, mha.num_heads, packed.data_ptr(),
+            bias.data_ptr(), out.data_ptr())
+    _hip.check(code, "topk_attention_heads")
+    return out

@@ -28,7 +28,8 @@ from . import pyramid
 from .filter_ops import (advance_rows, class_head_max_times, class_max_times, encoder_finalize,
                          encoder_reference_points, fused_ffn,
                          fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
-                         select_stack, token_linear_applies, token_linear_ln, value_proj_head_major)
+                         select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
+                         topk_attention_heads, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
 from .pyramid import PositionEmbeddingLearned
 
@@ -49,6 +50,9 @@ class SalienceTransformerEncoderLayer(nn.Module):
         self.embed_dim = embed_dim
         self.topk_sa = topk_sa
         self.n_heads = n_heads
+        # one-launch gather + in-projection + attention of the selected rows (csrc/mha_topk.hip): correct, but on
+        # MI355X it only ties the three-launch path (its row gather is bound by one CU's L1 per head), so it is opt-in
+        self.fused_topk_attention = False
         # pre attention
         self.pre_attention = nn.MultiheadAttention(embed_dim, n_heads, dropout, batch_first=True)
         self.pre_dropout = nn.Dropout(dropout)
@@ -145,13 +149,24 @@ class SalienceTransformerEncoderLayer(nn.Module):
             mc_score = class_max_times(class_head(query), fg_sorted[:, :c])
         sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
         N = sel.shape[1]
-        stacked = select_stack(query, pos_sorted, sel)                       # [q+pos ; q] rows, [B,2N,E]
         fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
+        if (self.fused_topk_attention and fuse_tail and topk_attention_applies(query, self.pre_attention, N)
+                and not self.training):
+            # gather + position add + in-projection + attention of the selected rows in one launch, then
+            # out-projection (library GEMM: 600 rows) and gather + residual + pre_norm + scatter in one launch
+            mha = self.pre_attention
+            heads_out = topk_attention_heads(query, pos_sorted[:, :c], sel, mha)
+            tgt2 = F.linear(heads_out, mha.out_proj.weight, mha.out_proj.bias)
+            fused_layer_norm(query, self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query, gather_x=True)
+            stacked = None
+        else:
+            stacked = select_stack(query, pos_sorted, sel)                   # [q+pos ; q] rows, [B,2N,E]
         if fuse_tail:
             # The 2 x 300 selected rows are too few for the token-resident kernel (its weight copy + row-strided
             # epilogue cost 16 us whatever the row count; library GEMM + fused norm/scatter: 11 us) ...
-            tgt2 = self._pre_attention_stacked(stacked, N)
-            fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
+            if stacked is not None:
+                tgt2 = self._pre_attention_stacked(stacked, N)
+                fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
             sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
                                                     level_start_index, query_pos=pos_sorted[:, :c],
                                                     apply_output_proj=False)
