@@ -397,9 +397,10 @@ class MultiScaleDeformableAttention(nn.Module):
         caller that fuses ``output_proj`` with what follows it."""
         from .filter_ops import token_linear, token_linear_applies
         w, b = self._fused_query_projection()
-        # (the token-resident kernel's run time is flat in the token count, ~17 us: below ~12 000 tokens the library
-        # GEMM behind an elementwise add is faster)
-        big = query.dim() == 3 and query.shape[0] * query.shape[1] >= 12000
+        # (the token-resident kernel's run time is flat in the token count, ~17 us; below ~12 000 tokens the library GEMM
+        # behind an elementwise add is 2-3 us faster, but only the resident kernel writes the per-head slabs that save
+        # the gather kernel as much -- so it is used down to a few thousand tokens)
+        big = query.dim() == 3 and query.shape[0] * query.shape[1] >= 3000
         head_major = (big and token_linear_applies(query, w) and order is None and self.num_levels == 4
                       and self.num_points == 4 and value_hm.shape[-1] == 32
                       and value_hm.dtype in (torch.float16, torch.bfloat16)
