@@ -373,6 +373,22 @@ int sdetr_topk_attention_heads_bf16(sdetr_stream_t stream, const void *query, in
                                     int num_select, int embed_dim, int num_heads, const void *packed_in_proj,
                                     const float *in_proj_bias, void *out);
 
+/* ---- (10) decoder box-refinement loop, elementwise stages (row N2) -----------------------------------------------
+ * models/bricks/salience_transformer.py:641-671.
+ *   sdetr_decoder_query_sine_embed: reference_points [batch, num_queries, 4] (cx, cy, w, h) and valid_ratios
+ *     [batch, num_levels, 2] -> reference_points_input [batch, num_queries, num_levels, 4] = box * (rw, rh, rw, rh)
+ *     (:642; may be NULL) and embed [batch, num_queries, 4*num_pos_feats] (f32 | bf16) =
+ *     get_sine_pos_embed(reference_points_input[:, :, 0, :]) (:643; models/bricks/position_encoding.py:105-132 with
+ *     exchange_xy: blocks in (y, x, w, h) order, feature pair (2p, 2p+1) = (sin, cos) of c * 2*pi / T^(2p/F)).
+ *   sdetr_box_refine: out[g, i, :] = sigmoid(delta[g, i, :] + inverse_sigmoid(reference_points[i, :], eps))
+ *     (:659-660 and :666-668; util/misc.py:31-35); delta rows (f32 | bf16) delta_row_stride elements apart in one
+ *     [groups * num_boxes] sequence, out fp32 [groups, num_boxes, 4]. */
+int sdetr_decoder_query_sine_embed(sdetr_stream_t stream, const float *reference_points, const float *valid_ratios,
+                                   int batch_size, int num_queries, int num_levels, int num_pos_feats,
+                                   float temperature, void *embed, int embed_dtype, float *reference_points_input);
+int sdetr_box_refine(sdetr_stream_t stream, const void *delta, int delta_dtype, int64_t delta_row_stride,
+                     const float *reference_points, int64_t num_boxes, int groups, float eps, float *out);
+
 #ifdef __cplusplus
 }
 #endif

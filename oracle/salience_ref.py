@@ -352,3 +352,75 @@ def hot_path(sd: SD, feats, masks, pos, heads=8, points=4, topk_sa=300, num_laye
                 focus_token_nums=focus, level_token_nums=level_token_nums, score_maps=score_maps,
                 level_inds=level_inds, level_score=level_score, foreground_inds=fg_inds,
                 foreground_score=fg_score, layer_out=layer_out, memory=memory)
+
+
+# ----------------------------------------------------------------------------- D1 decoder (row N2)
+def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-3) -> torch.Tensor:
+    """util/misc.py:31-35."""
+    x = x.clamp(0, 1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def coordinate_sine_embed(pos: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0) -> torch.Tensor:
+    """position_encoding.py:105-132 with exchange_xy=True: per coordinate c, feature 2j is sin(2*pi*c / T^(2j/F)),
+    feature 2j+1 the cosine; the x and y blocks are emitted in (y, x) order, further coordinates follow in order."""
+    out = []
+    j = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (j // 2) / num_pos_feats)
+    for c in range(pos.shape[-1]):
+        a = pos[..., c, None] * (2 * math.pi) / dim_t
+        e = torch.zeros_like(a)
+        e[..., 0::2] = a[..., 0::2].sin()
+        e[..., 1::2] = a[..., 1::2].cos()
+        out.append(e)
+    if len(out) >= 2:
+        out[0], out[1] = out[1], out[0]
+    return torch.cat(out, -1)
+
+
+def mlp(sd: SD, prefix: str, x: torch.Tensor, num_layers: int) -> torch.Tensor:
+    """basic.py:6-26."""
+    for i in range(num_layers):
+        x = linear(sd, "{}.layers.{}".format(prefix, i), x)
+        if i + 1 < num_layers:
+            x = F.relu(x)
+    return x
+
+
+def decoder_layer(sd: SD, prefix: str, query, query_pos, ref_in, value, shapes, lsi, pad_mask, heads: int,
+                  levels: int, points: int, core=msda_core_c):
+    """salience_transformer.py:553-588 (eval mode: dropouts are identity, no attention mask)."""
+    qk = query + query_pos
+    query = layer_norm(sd, prefix + ".norm2", query + mha_self(sd, prefix + ".self_attn", qk, query, heads))
+    q2 = msda_module(sd, prefix + ".cross_attn", query + query_pos, ref_in, value, shapes, lsi, pad_mask, heads,
+                     levels, points, core=core)
+    query = layer_norm(sd, prefix + ".norm1", query + q2)
+    h = F.relu(linear(sd, prefix + ".linear1", query))
+    return layer_norm(sd, prefix + ".norm3", query + linear(sd, prefix + ".linear2", h))
+
+
+def decoder(sd: SD, query, reference_points, value, shapes, lsi, valid_ratios, pad_mask, num_layers: int,
+            heads: int = 8, points: int = 4, core=msda_core_c, trace=None):
+    """salience_transformer.py:625-674 -> (class logits [num_layers,B,Nq,C], boxes [num_layers,B,Nq,4]).
+    ``trace`` (a list) receives per layer ``(query_in, reference_points_in, query_pos, ref_in, query_out)``."""
+    E = query.shape[-1]
+    levels = shapes.shape[0]
+    ratio = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+    classes, coords = [], []
+    for i in range(num_layers):
+        ref_in = reference_points.detach()[:, :, None] * ratio
+        query_pos = mlp(sd, "ref_point_head", coordinate_sine_embed(ref_in[:, :, 0, :], E // 2), 2)
+        query_in = query
+        query = decoder_layer(sd, "layers.{}".format(i), query, query_pos, ref_in, value, shapes, lsi, pad_mask,
+                              heads, levels, points, core=core)
+        if trace is not None:
+            trace.append((query_in, reference_points, query_pos, ref_in, query))
+        normed = layer_norm(sd, "norm", query)
+        classes.append(linear(sd, "class_head.{}".format(i), normed))
+        coords.append((mlp(sd, "bbox_head.{}".format(i), normed, 3) + inverse_sigmoid(reference_points)).sigmoid())
+        if i + 1 == num_layers:
+            break
+        # the next reference keeps the gradient through bbox_head(query) ("look forward twice", :666-668)
+        reference_points = (mlp(sd, "bbox_head.{}".format(i), query, 3)
+                            + inverse_sigmoid(reference_points.detach())).sigmoid()
+    return torch.stack(classes), torch.stack(coords)

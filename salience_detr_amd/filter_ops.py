@@ -596,6 +596,46 @@ def encoder_reference_points(valid_ratios: Tensor, spatial_shapes: Tensor, level
     return out
 
 
+def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num_pos_feats: int,
+                             dtype: torch.dtype, temperature: float = 10000.0):
+    """``reference_points_input`` and its sine embedding for one decoder layer (salience_transformer.py:642-643):
+    boxes ``[B,Nq,4]`` fp32, ``valid_ratios`` ``[B,L,2]`` -> (``[B,Nq,L,4]`` fp32, ``[B,Nq,4*num_pos_feats]``)."""
+    _hip.require_device("decoder_query_sine_embed", reference_points=reference_points, valid_ratios=valid_ratios)
+    if reference_points.dim() != 3 or reference_points.shape[-1] != 4 or dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("decoder_query_sine_embed: [B,Nq,4] boxes and an fp32 | bf16 embedding expected")
+    ref = reference_points.detach().float().contiguous()
+    vr = valid_ratios.float().contiguous()
+    B, Nq, _ = ref.shape
+    L = vr.shape[1]
+    embed = torch.empty((B, Nq, 4 * num_pos_feats), dtype=dtype, device=ref.device)
+    ref_in = torch.empty((B, Nq, L, 4), dtype=torch.float32, device=ref.device)
+    with torch.cuda.device(ref.device):
+        code = _hip.lib().sdetr_decoder_query_sine_embed(
+            _hip.stream_ptr(), ref.data_ptr(), vr.data_ptr(), B, Nq, L, int(num_pos_feats), float(temperature),
+            embed.data_ptr(), _hip.dtype_code(dtype), ref_in.data_ptr())
+    _hip.check(code, "decoder_query_sine_embed")
+    return ref_in, embed
+
+
+def box_refine(delta: Tensor, reference_points: Tensor, eps: float = 1e-3) -> Tensor:
+    """``sigmoid(delta + inverse_sigmoid(reference_points))`` (salience_transformer.py:659-660, 666-668) in one launch:
+    ``delta`` ``[..., 4]`` (fp32 | bf16) whose leading dims are ``reference_points``' ``[B,Nq]`` or ``[G,B,Nq]``
+    (G deltas refining the same boxes) -> fp32 of ``delta``'s shape."""
+    _hip.require_device("box_refine", delta=delta, reference_points=reference_points)
+    ref = reference_points.detach().float().contiguous()
+    n = ref.numel() // 4
+    if delta.shape[-1] != 4 or ref.shape[-1] != 4 or n == 0 or delta.numel() % (4 * n) != 0 \
+            or delta.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("box_refine: delta [(G,)B,Nq,4] fp32 | bf16 against boxes [B,Nq,4] expected")
+    d = delta.detach().contiguous()
+    out = torch.empty(d.shape, dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        code = _hip.lib().sdetr_box_refine(_hip.stream_ptr(), d.data_ptr(), _hip.dtype_code(d.dtype), 4, ref.data_ptr(),
+                                           n, d.numel() // (4 * n), float(eps), out.data_ptr())
+    _hip.check(code, "box_refine")
+    return out
+
+
 def token_linear_ln(x: Tensor, linear, norm, residual: Tensor, scatter_index: Optional[Tensor] = None,
                     scatter_into: Optional[Tensor] = None) -> Tensor:
     """``norm(residual + linear(x))`` for a 256 -> 256 bf16 Linear in one launch (include/salience_hip.h (8));

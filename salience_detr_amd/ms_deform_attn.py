@@ -302,6 +302,34 @@ def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_star
     return out
 
 
+def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+    """Head-major value maps ``[len(attn_modules), B, M, Nv, D]`` of several ``MultiScaleDeformableAttention``
+    modules that sample the SAME ``value`` (the six encoder layers, salience_transformer.py:452; the decoder layers'
+    cross-attentions, :575-582): their ``value_proj`` run as one projection.  No-grad path only."""
+    from .filter_ops import token_linear_applies, value_proj_head_major
+    first = attn_modules[0]
+    heads, E = first.num_heads, first.embed_dim
+    owner = first.__dict__
+    ps = [p for m in attn_modules for p in (m.value_proj.weight, m.value_proj.bias)]
+    key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
+    hit = owner.get("_batched_value_proj")
+    if hit is None or hit[0] != key:
+        w = torch.cat([m.value_proj.weight.detach() for m in attn_modules], 0).contiguous()
+        b = torch.cat([m.value_proj.bias.detach() for m in attn_modules], 0).contiguous()
+        hit = (key, w, b)
+        owner["_batched_value_proj"] = hit
+    w_all, b_all = hit[1], hit[2]
+    vdt = first.value_dtype or value.dtype
+    n = len(attn_modules)
+    if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
+            and value.is_contiguous()):
+        # projection, padding mask, 16-bit conversion and head-major layout in one launch
+        return value_proj_head_major(value, w_all, b_all, padding_mask, heads, n, vdt)
+    v_all = F.linear(value, w_all, b_all)                      # [B, Nv, n*E]
+    out = value_to_head_major(v_all, padding_mask, heads, vdt, num_groups=n)
+    return out[None] if n == 1 else out
+
+
 class MultiScaleDeformableAttention(nn.Module):
     """Multi-Scale Deformable Attention Module (Deformable-DETR), MI355X-native inside.
 

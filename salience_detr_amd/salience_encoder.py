@@ -30,7 +30,7 @@ from .filter_ops import (advance_rows, class_head_max_times, class_max_times, en
                          fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
                          topk_attention_heads, value_proj_head_major)
-from .ms_deform_attn import MultiScaleDeformableAttention, value_to_head_major
+from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 
 
@@ -237,7 +237,6 @@ class SalienceTransformerEncoder(nn.Module):
         self.embed_dim = encoder_layer.embed_dim
         # learnt background embed for prediction
         self.background_embedding = PositionEmbeddingLearned(max_num_embedding, num_pos_feats=self.embed_dim // 2)
-        self._value_proj_cache = None
         # optional instrumentation: a callable(tag) invoked at every layer boundary of the loop
         # (bench.py records a stream event there to report ms per encoder layer)
         self.layer_marker = None
@@ -287,32 +286,12 @@ class SalienceTransformerEncoder(nn.Module):
             counts.append(int(t.shape[1]))
         return counts
 
-    def _all_value_projections(self):
-        """[6*E, E] weight / [6*E] bias of every layer's value_proj, cached per parameter version."""
-        ps = [p for l in self.layers for p in (l.self_attn.value_proj.weight, l.self_attn.value_proj.bias)]
-        key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
-        if self._value_proj_cache is None or self._value_proj_cache[0] != key:
-            w = torch.cat([l.self_attn.value_proj.weight.detach() for l in self.layers], 0).contiguous()
-            b = torch.cat([l.self_attn.value_proj.bias.detach() for l in self.layers], 0).contiguous()
-            self._value_proj_cache = (key, w, b)
-        return self._value_proj_cache[1], self._value_proj_cache[2]
-
     def project_values(self, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
         """Head-major value maps of ALL layers ``[num_layers,B,heads,Nv,D]`` (no-grad path).  The six layers sample
         the same, never-updated feature map (salience_transformer.py:452), so their ``value_proj`` run as one
         projection; it only depends on the flattened features, which lets a caller overlap it with the filtering
         stage on a second stream (``SalienceEncoderHotPath`` does)."""
-        E = self.embed_dim
-        heads = self.layers[0].self_attn.num_heads
-        w_all, b_all = self._all_value_projections()
-        vdt = self.layers[0].self_attn.value_dtype or value.dtype
-        if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
-                and value.is_contiguous()):
-            # projection, padding mask, 16-bit conversion and head-major layout in one launch
-            return value_proj_head_major(value, w_all, b_all, padding_mask, heads, self.num_layers, vdt)
-        v_all = F.linear(value, w_all, b_all)                      # [B, Nv, num_layers*E]
-        value_hm_all = value_to_head_major(v_all, padding_mask, heads, vdt, num_groups=self.num_layers)
-        return value_hm_all[None] if self.num_layers == 1 else value_hm_all
+        return batched_value_maps([l.self_attn for l in self.layers], value, padding_mask)
 
     def forward(self, query, spatial_shapes, level_start_index, valid_ratios, query_pos=None,
                 query_key_padding_mask=None, foreground_score=None, focus_token_nums=None, foreground_inds=None,
