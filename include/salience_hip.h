@@ -389,6 +389,30 @@ int sdetr_decoder_query_sine_embed(sdetr_stream_t stream, const float *reference
 int sdetr_box_refine(sdetr_stream_t stream, const void *delta, int delta_dtype, int64_t delta_row_stride,
                      const float *reference_points, int64_t num_boxes, int groups, float eps, float *out);
 
+/* ---- (11) two-stage proposal selection after the encoder (row N1) ---------------------------------------------------
+ * models/bricks/salience_transformer.py:194-212, 249-295; models/bricks/base_transformer.py:74-112.
+ * level_shapes_host: HOST array [num_levels][2] of (h, w); the levels are laid out back to back in the token dimension.
+ *   sdetr_encoder_output_proposals: gen_encoder_output_proposals minus its Linear + LayerNorm: keep [batch, S] (1 = not
+ *     padding and proposal (cx, cy, w, h) inside (0.01, 0.99)) and proposal_logit [batch, S, 4] = log(p / (1 - p)),
+ *     +inf where keep is 0.  Either output may be NULL.
+ *   sdetr_grid_nms_topk: nms_on_topk_index.  topk_index [batch, num_topk] = token ids in descending score order
+ *     (images index_batch_stride elements apart).  The reference's boxes are the 2x2 cells [x-1, y-1, x+1, y+1] with one
+ *     NMS category per (image, level), for which greedy NMS is neighbour suppression: neighbourhood = 4 when
+ *     2/6 > iou_threshold (fp32), 8 when also 1/7 > iou_threshold, 0 when neither (nothing is suppressed).  Writes the
+ *     first max_keep kept ids per image in score order to out_index [batch, max_keep] and the number kept (unclamped)
+ *     to out_count [batch] (device int32).  num_topk <= 65534; 2*S + num_topk bytes must fit 150 KB of LDS.
+ *   sdetr_proposal_refine: out [batch, num_select, 4] = sigmoid(delta[b, i] + proposal_logit[b, index[b, i]])
+ *     (enc_outputs_coord of the selected tokens, :198-199 + :209); delta f32 | bf16 contiguous. */
+int sdetr_encoder_output_proposals(sdetr_stream_t stream, const uint8_t *padding_mask, const int64_t *level_shapes_host,
+                                   int num_levels, int batch_size, int spatial_size, uint8_t *keep,
+                                   float *proposal_logit);
+int sdetr_grid_nms_topk(sdetr_stream_t stream, const int64_t *topk_index, int64_t index_batch_stride,
+                        const int64_t *level_shapes_host, int num_levels, int batch_size, int num_topk,
+                        int spatial_size, int neighbourhood, int max_keep, int64_t *out_index, int *out_count);
+int sdetr_proposal_refine(sdetr_stream_t stream, const void *delta, int delta_dtype, const float *proposal_logit,
+                          const int64_t *index, int64_t index_batch_stride, int batch_size, int spatial_size,
+                          int num_select, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -424,3 +424,127 @@ def decoder(sd: SD, query, reference_points, value, shapes, lsi, valid_ratios, p
         reference_points = (mlp(sd, "bbox_head.{}".format(i), query, 3)
                             + inverse_sigmoid(reference_points.detach())).sigmoid()
     return torch.stack(classes), torch.stack(coords)
+
+
+# ----------------------------------------------------------------------------- row N1: two-stage proposals
+def encoder_output_proposals(sd: SD, memory: torch.Tensor, mask_flat: torch.Tensor, shapes: torch.Tensor):
+    """base_transformer.py:74-112, both return values: (LayerNorm(Linear(memory * keep)), proposal logits with
+    +inf on padding / out-of-range tokens)."""
+    n = memory.shape[0]
+    props = []
+    cur = 0
+    for lvl, (h, w) in enumerate(shapes.tolist()):
+        m = mask_flat[:, cur:cur + h * w].view(n, h, w)
+        vh = (~m[:, :, 0]).sum(1).view(n, 1, 1).float()
+        vw = (~m[:, 0, :]).sum(1).view(n, 1, 1).float()
+        gy = torch.arange(h, dtype=torch.float32).view(1, h, 1)
+        gx = torch.arange(w, dtype=torch.float32).view(1, 1, w)
+        cx = ((gx + 0.5) / vw).expand(n, h, w)
+        cy = ((gy + 0.5) / vh).expand(n, h, w)
+        wh = torch.ones(n, h, w) * 0.05 * 2.0 ** lvl
+        props.append(torch.stack([cx, cy, wh, wh], -1).view(n, h * w, 4))
+        cur += h * w
+    prop = torch.cat(props, 1)
+    valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
+    logit = torch.log(prop / (1 - prop))
+    logit = logit.masked_fill(mask_flat[..., None] | ~valid, float("inf"))
+    x = memory * (~mask_flat[..., None]) * valid
+    return layer_norm(sd, "enc_output_norm", linear(sd, "enc_output", x)), logit
+
+
+def nms_greedy(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Restatement of ``torchvision.ops.nms`` (torchvision is a dependency of the reference that is NOT present in
+    this image -- requirements.txt of the reference lists it unpinned; the algorithm below is the one published in
+    torchvision/csrc/ops/cpu/nms_kernel.cpp, v0.13 ... v0.22: boxes are visited in descending score order (stable
+    sort), a box is kept unless a previously kept box overlaps it with inter / (area_i + area_j - inter) >
+    iou_threshold; widths/heights are x2-x1 / y2-y1 clamped at 0, all arithmetic in the box dtype).  Returns the kept
+    indices in descending score order.  PARITY UNPINNED: no torchvision build here to check this against."""
+    order = torch.sort(scores, descending=True, stable=True)[1].tolist()
+    b = boxes.float().numpy()
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    thr = np.float32(iou_threshold)
+    kept = np.zeros(len(order), dtype=np.int64)
+    nk = 0
+    for i in order:
+        j = kept[:nk]
+        iw = np.maximum(np.float32(0), np.minimum(b[i, 2], b[j, 2]) - np.maximum(b[i, 0], b[j, 0]))
+        ih = np.maximum(np.float32(0), np.minimum(b[i, 3], b[j, 3]) - np.maximum(b[i, 1], b[j, 1]))
+        inter = (iw * ih).astype(np.float32)
+        if not np.any(inter / (area[i] + area[j] - inter) > thr):
+            kept[nk] = i
+            nk += 1
+    kept = kept[:nk].tolist()
+    return torch.tensor(kept, dtype=torch.int64)
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """``torchvision.ops.batched_nms`` (torchvision/ops/boxes.py): NMS per category, the union of the kept indices
+    returned in descending score order (ties in list order).  Same provenance note as ``nms_greedy``."""
+    keep = torch.zeros(scores.shape[0], dtype=torch.bool)
+    for c in torch.unique(idxs).tolist():
+        cur = torch.nonzero(idxs == c)[:, 0]
+        keep[cur[nms_greedy(boxes[cur], scores[cur], iou_threshold)]] = True
+    kept = torch.nonzero(keep)[:, 0]
+    return kept[torch.sort(scores[kept], descending=True, stable=True)[1]]
+
+
+def nms_inputs(topk_index: torch.Tensor, shapes: torch.Tensor, lsi: torch.Tensor):
+    """salience_transformer.py:249-277: unit boxes around the grid cell of every selected token and the
+    (image, level) category id."""
+    B, K = topk_index.shape
+    flat = topk_index.reshape(-1)
+    level = (flat[:, None] >= lsi[None, :]).sum(1) - 1
+    width = shapes[level, 1]
+    sp = flat - lsi[level]
+    x = (sp % width).float()
+    y = torch.div(sp, width, rounding_mode="trunc").float()
+    boxes = torch.stack([x - 1.0, y - 1.0, x + 1.0, y + 1.0], -1)
+    image = torch.arange(B).repeat_interleave(K)
+    return boxes, level + lsi.shape[0] * image, image
+
+
+def nms_on_topk_index(topk_scores, topk_index, shapes, lsi, num_proposals: int, iou_threshold: float = 0.3,
+                      nms=batched_nms):
+    """salience_transformer.py:249-295."""
+    B, K = topk_scores.shape
+    boxes, idxs, image = nms_inputs(topk_index, shapes, lsi)
+    kept = nms(boxes, topk_scores.reshape(-1), idxs, iou_threshold)
+    flat = topk_index.reshape(-1)
+    per_image = [flat[kept[image[kept] == b]] for b in range(B)]
+    n = min([num_proposals] + [int(t.shape[0]) for t in per_image])
+    return torch.stack([t[:n] for t in per_image])
+
+
+def two_stage_proposals(sd: SD, memory, mask_flat, shapes, lsi, num_proposals: int, iou_threshold: float = 0.3):
+    """salience_transformer.py:194-212 -> dict(enc_outputs_class, enc_outputs_coord (selected), topk_scores,
+    topk_index (before NMS), index (after NMS), class_all, coord_all)."""
+    om, logit = encoder_output_proposals(sd, memory, mask_flat, shapes)
+    cls_all = linear(sd, "encoder_class_head", om)
+    coord_all = (mlp(sd, "encoder_bbox_head", om, 3) + logit).sigmoid()
+    k = min(num_proposals * 4, cls_all.shape[1])
+    topk_scores, topk_index = topk_desc_stable(cls_all.max(-1)[0], k)
+    index = nms_on_topk_index(topk_scores, topk_index, shapes, lsi, num_proposals, iou_threshold)
+    C = cls_all.shape[-1]
+    return dict(class_all=cls_all, coord_all=coord_all, topk_scores=topk_scores, topk_index=topk_index, index=index,
+                enc_outputs_class=cls_all.gather(1, index[..., None].expand(-1, -1, C)),
+                enc_outputs_coord=coord_all.gather(1, index[..., None].expand(-1, -1, 4)))
+
+
+def _sub(sd: SD, prefix: str) -> SD:
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def transformer(sd: SD, feats, masks, pos, num_proposals: int, heads=8, points=4, topk_sa=300, enc_layers=6,
+                dec_layers=6, core=msda_core_c):
+    """SalienceTransformer.forward, inference (no denoising queries, neck=None; salience_transformer.py:97-226)."""
+    hp = hot_path(sd, feats, masks, pos, heads, points, topk_sa, enc_layers, core=core)
+    memory = hp["memory"]
+    ts = two_stage_proposals(sd, memory, hp["mask_flatten"], hp["spatial_shapes"], hp["level_start_index"],
+                             num_proposals)
+    B = memory.shape[0]
+    target = sd["tgt_embed.weight"][None].expand(B, -1, -1)
+    ref = ts["enc_outputs_coord"]
+    cls, box = decoder(_sub(sd, "decoder."), target, ref, memory,
+                       hp["spatial_shapes"], hp["level_start_index"], hp["valid_ratios"], hp["mask_flatten"],
+                       dec_layers, heads, points, core=core)
+    return dict(outputs_classes=cls, outputs_coords=box, salience_score=hp["score_maps"], memory=memory, **ts)

@@ -596,6 +596,78 @@ def encoder_reference_points(valid_ratios: Tensor, spatial_shapes: Tensor, level
     return out
 
 
+def _host_level_shapes(level_shapes):
+    import ctypes
+    flat = [int(v) for hw in level_shapes for v in hw]
+    return (ctypes.c_int64 * len(flat))(*flat)
+
+
+def encoder_output_proposals(padding_mask: Tensor, level_shapes, want_logit: bool = True):
+    """The geometry half of ``gen_encoder_output_proposals`` (base_transformer.py:74-112): ``keep`` ``[B,S]`` bool
+    (token not padding and its proposal inside (0.01, 0.99)) and the proposal logits ``[B,S,4]`` fp32 (+inf where
+    ``keep`` is False).  ``level_shapes``: host list of (h, w)."""
+    _hip.require_device("encoder_output_proposals", padding_mask=padding_mask)
+    B, S = padding_mask.shape
+    m = padding_mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m
+    keep = torch.empty((B, S), dtype=torch.uint8, device=m.device)
+    logit = torch.empty((B, S, 4), dtype=torch.float32, device=m.device) if want_logit else None
+    shapes = _host_level_shapes(level_shapes)
+    with torch.cuda.device(m.device):
+        code = _hip.lib().sdetr_encoder_output_proposals(_hip.stream_ptr(), m.data_ptr(), shapes, len(level_shapes), B, S,
+                                                         keep.data_ptr(), _hip.ptr(logit))
+    _hip.check(code, "encoder_output_proposals")
+    return keep.view(torch.bool), logit
+
+
+def nms_neighbourhood(iou_threshold: float) -> int:
+    """Which grid neighbours the reference's unit boxes suppress at ``iou_threshold``: the IoU of two 2x2 boxes one
+    cell apart is 2/6 (edge) or 1/7 (corner), compared in fp32 like torchvision's kernel does."""
+    import numpy as np
+    thr = np.float32(iou_threshold)
+    edge = np.float32(2) / np.float32(6) > thr
+    corner = np.float32(1) / np.float32(7) > thr
+    return 8 if corner else (4 if edge else 0)
+
+
+def grid_nms_topk(topk_index: Tensor, level_shapes, spatial_size: int, iou_threshold: float, max_keep: int):
+    """``nms_on_topk_index`` (salience_transformer.py:249-295) up to the final truncation: ``topk_index`` ``[B,K]``
+    int64 token ids in descending score order -> (kept ids ``[B,max_keep]`` in score order, kept count ``[B]`` int32,
+    device; entries of a row beyond its count are undefined)."""
+    _hip.require_device("grid_nms_topk", topk_index=topk_index)
+    if topk_index.dtype != torch.int64 or topk_index.dim() != 2 or (topk_index.shape[1] > 1 and topk_index.stride(1) != 1):
+        raise RuntimeError("grid_nms_topk: int64 [B,K] index with a contiguous last dim expected")
+    B, K = topk_index.shape
+    out = torch.empty((B, max_keep), dtype=torch.int64, device=topk_index.device)
+    count = torch.empty((B,), dtype=torch.int32, device=topk_index.device)
+    shapes = _host_level_shapes(level_shapes)
+    with torch.cuda.device(topk_index.device):
+        code = _hip.lib().sdetr_grid_nms_topk(
+            _hip.stream_ptr(), topk_index.data_ptr(), topk_index.stride(0) if B > 1 else K, shapes, len(level_shapes), B,
+            K, int(spatial_size), nms_neighbourhood(iou_threshold), int(max_keep), out.data_ptr(), count.data_ptr())
+    _hip.check(code, "grid_nms_topk")
+    return out, count
+
+
+def proposal_refine(delta: Tensor, proposal_logit: Tensor, index: Tensor) -> Tensor:
+    """``sigmoid(delta + proposal_logit.gather(index))``: enc_outputs_coord of the selected tokens
+    (salience_transformer.py:198-199, 209).  delta ``[B,n,4]`` fp32 | bf16, logits ``[B,S,4]`` fp32, index ``[B,n]``."""
+    _hip.require_device("proposal_refine", delta=delta, proposal_logit=proposal_logit, index=index)
+    B, n, _ = delta.shape
+    if (delta.dtype not in (torch.float32, torch.bfloat16) or proposal_logit.dtype != torch.float32
+            or index.dtype != torch.int64 or tuple(index.shape) != (B, n) or (n > 1 and index.stride(1) != 1)):
+        raise RuntimeError("proposal_refine: delta [B,n,4] fp32 | bf16, logits fp32 [B,S,4], index int64 [B,n] expected")
+    d = delta.contiguous()
+    lg = proposal_logit.contiguous()
+    out = torch.empty((B, n, 4), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        code = _hip.lib().sdetr_proposal_refine(_hip.stream_ptr(), d.data_ptr(), _hip.dtype_code(d.dtype), lg.data_ptr(),
+                                                index.data_ptr(), index.stride(0) if B > 1 else n, B, lg.shape[1], n,
+                                                out.data_ptr())
+    _hip.check(code, "proposal_refine")
+    return out
+
+
 def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num_pos_feats: int,
                              dtype: torch.dtype, temperature: float = 10000.0):
     """``reference_points_input`` and its sine embedding for one decoder layer (salience_transformer.py:642-643):

@@ -1,0 +1,179 @@
+"""GPU: row N1 (two-stage proposal selection: proposal geometry, top-k, NMS, heads on the survivors) and the whole
+``SalienceTransformer.forward`` (rows N1 + N2 on top of the encoder hot path).
+
+Index work is compared bit-exactly with the oracle; floating point at 1e-3 (logits) / 1e-4 (boxes) against the
+reference's fixture.  The NMS itself is pinned to the oracle's restated torchvision algorithm (torchvision is absent
+here; see tests/test_transformer_cpu.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import salience_ref as R
+from salience_detr_amd import synthetic as syn
+from salience_detr_amd.filter_ops import (encoder_output_proposals, grid_nms_topk, nms_neighbourhood, proposal_refine)
+from test_transformer_cpu import _t, build_product_transformer, inputs
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+FULL_SHAPES = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "transformer_small.npz"))
+
+
+def _levels(shapes):
+    t = torch.tensor(shapes, dtype=torch.int64)
+    sizes = t.prod(1)
+    return t, torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]]), int(sizes.sum())
+
+
+@pytest.mark.parametrize("image_sizes", [[(800, 1333)], [(800, 1333), (800, 1066), (401, 640)], [(64, 96), (48, 80)]])
+def test_proposal_geometry_matches_oracle(image_sizes):
+    _, masks = syn.make_masks(image_sizes)
+    shapes = [tuple(m.shape[-2:]) for m in masks]
+    mask_flat = R.flatten_levels(masks)
+    E = 8
+    sd = {"enc_output.weight": torch.eye(E), "enc_output.bias": torch.zeros(E),
+          "enc_output_norm.weight": torch.ones(E), "enc_output_norm.bias": torch.zeros(E)}
+    mem = torch.ones(len(image_sizes), mask_flat.shape[1], E)
+    _, want = R.encoder_output_proposals(sd, mem, mask_flat, torch.tensor(shapes))
+    keep, logit = encoder_output_proposals(mask_flat.cuda(), shapes)
+    want_keep = torch.isfinite(want).all(-1)
+    assert torch.equal(keep.cpu(), want_keep)
+    assert torch.equal(torch.isinf(logit.cpu()), torch.isinf(want))
+    fin = want_keep[..., None].expand_as(want)
+    assert (logit.cpu()[fin] - want[fin]).abs().max() < 2e-6
+
+
+def _score_maps(kind, B, S, shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "random":
+        return torch.randn(B, S, generator=g)
+    if kind == "ties":
+        s = torch.randn(B, S, generator=g)
+        return (s * 4).round() / 4                    # heavy ties: list order decides
+    # "ramp": strictly increasing along every row of every level -- the longest possible suppression chains
+    return torch.arange(S, dtype=torch.float32).repeat(B, 1) + torch.rand(B, 1, generator=g)
+
+
+@pytest.mark.parametrize("kind", ["random", "ties", "ramp"])
+@pytest.mark.parametrize("thr", [0.3, 0.1, 0.5])
+def test_grid_nms_matches_restated_batched_nms(kind, thr):
+    shapes = [(40, 67), (20, 34), (10, 17), (5, 9)]
+    t_shapes, lsi, S = _levels(shapes)
+    B, K, keep_n = 2, 900, 300
+    ts, ti = R.topk_desc_stable(_score_maps(kind, B, S, shapes, 3), K)
+    want = R.nms_on_topk_index(ts, ti, t_shapes, lsi, num_proposals=keep_n, iou_threshold=thr)
+    kept, count = grid_nms_topk(ti.cuda(), shapes, S, thr, keep_n)
+    n = min(int(count.min()), keep_n)
+    assert n == want.shape[1]
+    assert torch.equal(kept[:, :n].cpu(), want)
+    assert nms_neighbourhood(thr) == {0.3: 4, 0.1: 8, 0.5: 0}[thr]
+
+
+def test_grid_nms_full_size_counts_and_order():
+    """3600 candidates per image on the 800x1333 pyramid: identical to the restated NMS, kept tokens in score order,
+    and the unclamped counts equal the oracle's."""
+    t_shapes, lsi, S = _levels(FULL_SHAPES)
+    B, K = 2, 3600
+    score = _score_maps("random", B, S, FULL_SHAPES, 11)
+    score[:, :16700] += 1.0                                  # most candidates on the fine level, like real maps
+    ts, ti = R.topk_desc_stable(score, K)
+    boxes, idxs, image = R.nms_inputs(ti, t_shapes, lsi)
+    kept_all = R.batched_nms(boxes, ts.reshape(-1), idxs, 0.3)
+    per_image = [ti.reshape(-1)[kept_all[image[kept_all] == b]] for b in range(B)]
+    kept, count = grid_nms_topk(ti.cuda(), FULL_SHAPES, S, 0.3, 900)
+    assert count.cpu().tolist() == [int(p.shape[0]) for p in per_image]
+    for b in range(B):
+        assert torch.equal(kept[b].cpu(), per_image[b][:900])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_proposal_refine_matches_gather_sigmoid(dtype):
+    B, S, n = 2, 500, 77
+    logit = syn.det_randn("pr.l", (B, S, 4))
+    logit[0, 3] = float("inf")
+    index = torch.stack([torch.randperm(S, generator=torch.Generator().manual_seed(b))[:n] for b in range(B)])
+    index[0, 0] = 3
+    delta = syn.det_randn("pr.d", (B, n, 4)).to(dtype)
+    got = proposal_refine(delta.cuda(), logit.cuda(), index.cuda())
+    want = (delta.float() + logit.gather(1, index[..., None].expand(-1, -1, 4))).sigmoid()
+    assert got.dtype == torch.float32 and (got.cpu() - want).abs().max() < 1e-6
+    assert got[0, 0].cpu().tolist() == [1.0, 1.0, 1.0, 1.0]
+
+
+def test_transformer_small_matches_reference_fixture(gold):
+    d = gold
+    tr, sd = build_product_transformer(d)
+    tr = tr.cuda()
+    feats, masks, pos = inputs(d)
+    with torch.no_grad():
+        out_cls, out_box, enc_cls, enc_box, sal = tr([f.cuda() for f in feats], [m.cuda() for m in masks],
+                                                     [p.cuda() for p in pos], None, None, None)
+    assert (enc_cls.cpu() - _t(d["enc_outputs_class"])).abs().max() < 1e-3
+    assert (enc_box.cpu() - _t(d["enc_outputs_coord"])).abs().max() < 1e-4
+    assert (out_cls.cpu() - _t(d["outputs_classes"])).abs().max() < 1e-3
+    assert (out_box.cpu() - _t(d["outputs_coords"])).abs().max() < 1e-4
+    for l in range(4):
+        assert (sal[l].cpu() - _t(d[f"salience{l}"])).abs().max() < 1e-3
+
+
+def test_proposal_stage_on_reference_memory(gold):
+    """Row N1 alone, fed the reference's own ``memory``: the selected tokens (after top-k + NMS) are the oracle's,
+    bit for bit, and their class / box outputs the fixture's."""
+    d = gold
+    tr, sd = build_product_transformer(d)
+    tr = tr.cuda()
+    proposals = int(d["hyper"][8])
+    shapes = [tuple(r) for r in d["level_shapes"].tolist()]
+    memory, mask = _t(d["memory"]), _t(d["mask_flatten"])
+    want = R.two_stage_proposals(sd, memory, mask, _t(d["spatial_shapes"]), _t(d["level_start_index"]), proposals)
+    with torch.no_grad():
+        om, logit = tr.gen_encoder_output_proposals(memory.cuda(), mask.cuda(), shapes)
+        best = tr.encoder_class_head(om).max(-1)[0]
+        from salience_detr_amd.filter_ops import masked_topk_desc
+        ts, ti = masked_topk_desc(best, min(4 * proposals, best.shape[1]))
+        index = tr.nms_on_topk_index(ts, ti, shapes, None, 0.3)
+        enc_cls, enc_box = tr.select_proposals(memory.cuda(), mask.cuda(), shapes)
+    assert torch.equal(ti.cpu(), want["topk_index"])
+    assert torch.equal(index.cpu(), want["index"])
+    assert (enc_cls.cpu() - _t(d["enc_outputs_class"])).abs().max() < 1e-3
+    assert (enc_box.cpu() - _t(d["enc_outputs_coord"])).abs().max() < 1e-4
+
+
+def test_transformer_full_size_bf16_runs_and_agrees_with_fp32_selection():
+    """Full configuration (800x1333 + 800x1066, 900 proposals, 6+6 layers): fp32 and bf16 runs pick largely the same
+    proposals (the selection is a discontinuous function of the scores, so this is a statistical statement: >= 80% of
+    the 900 tokens per image in common), outputs are finite and shaped like the reference's."""
+    from salience_detr_amd.salience_transformer import build_salience_transformer
+    image_sizes = [(800, 1333), (800, 1066)]
+    tr = build_salience_transformer()
+    tr.load_state_dict(syn.det_state_dict(tr.state_dict()))
+    tr = tr.eval().cuda()
+    _, masks = syn.make_masks(image_sizes)
+    shapes = [tuple(m.shape[-2:]) for m in masks]
+    feats = [f.cuda() for f in syn.make_feats(2, shapes, 256, 0)]
+    from salience_detr_amd.pyramid import PositionEmbeddingSine
+    pe = PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5).cuda()
+    masks = [m.cuda() for m in masks]
+    pos = [pe(m) for m in masks]
+    with torch.no_grad():
+        o32 = tr(feats, masks, pos)
+        i32 = tr.last_proposal_index.cpu()
+        tr.set_dtype(torch.bfloat16, torch.float16)
+        o16 = tr(feats, masks, pos)
+        i16 = tr.last_proposal_index.cpu()
+    for o in (o32, o16):
+        assert o[0].shape == (6, 2, 900, 91) and o[1].shape == (6, 2, 900, 4)
+        assert o[2].shape == (2, 900, 91) and o[3].shape == (2, 900, 4)
+        assert all(torch.isfinite(t.float()).all() for t in o[:4])
+        assert (o[3] >= 0).all() and (o[3] <= 1).all()
+    for b in range(2):
+        common = len(set(i32[b].tolist()) & set(i16[b].tolist()))
+        print("image", b, "proposals in common", common)
+        assert common >= 0.8 * 900, common
