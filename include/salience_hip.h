@@ -399,8 +399,8 @@ int sdetr_box_refine(sdetr_stream_t stream, const void *delta, int delta_dtype, 
  *     (images index_batch_stride elements apart).  The reference's boxes are the 2x2 cells [x-1, y-1, x+1, y+1] with one
  *     NMS category per (image, level), for which greedy NMS is neighbour suppression: neighbourhood = 4 when
  *     2/6 > iou_threshold (fp32), 8 when also 1/7 > iou_threshold, 0 when neither (nothing is suppressed).  Writes the
- *     first max_keep kept ids per image in score order to out_index [batch, max_keep] and the number kept (unclamped)
- *     to out_count [batch] (device int32).  num_topk <= 65534; 2*S + num_topk bytes must fit 150 KB of LDS.
+ *     first max_keep kept ids per image in score order to out_index [batch, max_keep] (padded with id 0 when fewer
+ *     survive) and the number kept (unclamped) to out_count [batch] (device int32).  num_topk <= 65534; 2*S + num_topk bytes must fit 150 KB of LDS.
  *   sdetr_proposal_refine: out [batch, num_select, 4] = sigmoid(delta[b, i] + proposal_logit[b, index[b, i]])
  *     (enc_outputs_coord of the selected tokens, :198-199 + :209); delta f32 | bf16 contiguous. */
 int sdetr_encoder_output_proposals(sdetr_stream_t stream, const uint8_t *padding_mask, const int64_t *level_shapes_host,

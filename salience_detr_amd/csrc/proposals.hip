@@ -162,6 +162,9 @@ __global__ void __launch_bounds__(kNmsThreads) grid_nms_kernel(NmsArgs p)
         __syncthreads();
     }
     if (tid == 0) p.out_count[b] = carry;
+    // rows with fewer than max_keep survivors: pad with token 0 so that a caller that does not read the count back
+    // (graph replay) never dereferences an undefined id
+    for (int i = carry + tid; i < p.max_keep; i += kNmsThreads) p.out_index[(int64_t)b * p.max_keep + i] = 0;
 }
 
 template <typename DT>

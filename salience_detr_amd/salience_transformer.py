@@ -44,6 +44,11 @@ class SalienceTransformer(SalienceEncoderHotPath):
         self.encoder_bbox_head = MLP(self.embed_dim, self.embed_dim, 4, 3)
         self.nms_iou_threshold = 0.3
         self.last_proposal_index = None
+        # The reference truncates the proposals to the smallest per-image survivor count (:286-295), a data-dependent
+        # shape that costs a device->host read-back -- and then fails in the decoder unless that count reaches
+        # two_stage_num_proposals (tgt_embed has exactly that many rows).  With static_proposals the count is not read
+        # back (hipGraph-capturable); images with fewer survivors get token 0 as filler instead of an exception.
+        self.static_proposals = False
         nn.init.normal_(self.tgt_embed.weight)
         nn.init.constant_(self.encoder_bbox_head.layers[-1].weight, 0.0)
         nn.init.constant_(self.encoder_bbox_head.layers[-1].bias, 0.0)
@@ -80,6 +85,8 @@ class SalienceTransformer(SalienceEncoderHotPath):
         level_shapes = spatial_shapes if isinstance(spatial_shapes, (list, tuple)) else spatial_shapes.tolist()
         S = sum(h * w for h, w in level_shapes)
         kept, count = grid_nms_topk(topk_index, level_shapes, S, iou_threshold, self.two_stage_num_proposals)
+        if self.static_proposals:
+            return kept
         n = min(int(count.min()), self.two_stage_num_proposals)       # the stage's host sync (reference: :286-294)
         return kept[:, :n]
 
