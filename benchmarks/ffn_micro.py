@@ -16,19 +16,29 @@ def main():
     lin1 = torch.nn.Linear(256, 2048).to(DEV).to(torch.bfloat16)
     lin2 = torch.nn.Linear(2048, 256).to(DEV).to(torch.bfloat16)
     norm = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)
-    for T in (22726, 18180, 13634, 9090, 4544):
-        x = torch.randn(T, 256, device=DEV).to(torch.bfloat16)
+    from salience_detr_amd import _hip
+
+    def timed(fn):
         with torch.no_grad():
             for _ in range(3):
-                F.fused_ffn(x, lin1, lin2, norm)
+                fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                F.fused_ffn(x, lin1, lin2, norm)
+                fn()
             e1.record()
             torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 20
-        print("T=%6d  %.1f us  %.0f TFLOP/s" % (T, us, 4.0 * T * 256 * 2048 / us / 1e6))
+        return e0.elapsed_time(e1) * 1e3 / 20
+
+    for T in (22726, 18180, 13634, 9090, 4544, 1800):
+        x = torch.randn(T, 256, device=DEV).to(torch.bfloat16)
+        auto = _hip.lib().sdetr_ffn_auto_splits(T, 2048)
+        lib_us = timed(lambda: F.fused_layer_norm(x[None], norm, residual=lin2(torch.relu(lin1(x)))[None]))
+        line = "T=%6d  library %.1f us | auto=%d" % (T, lib_us, auto)
+        for s in sorted({1, 2, 3, 4, 5, 7, 10, 16, auto}):
+            us = timed(lambda: F.fused_ffn(x, lin1, lin2, norm, hidden_splits=s))
+            line += "  s%d: %.1f" % (s, us)
+        print(line + "  (best fused: %.0f TFLOP/s)" % (4.0 * T * 256 * 2048 / us / 1e6), flush=True)
 
 
 if __name__ == "__main__":

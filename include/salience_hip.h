@@ -313,13 +313,19 @@ int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, cons
  *     ((e-tile, k-block), contraction index permuted to the accumulator layout), 1 KiB each, lane-ordered.
  *     Do it once per weight version.
  *   sdetr_ffn_fused_bf16: x, out [tokens, 256] bf16 contiguous (out may not alias x); bias1 [hidden], bias2,
- *     norm_weight, norm_bias [256] fp32. */
+ *     norm_weight, norm_bias [256] fp32.  hidden_splits > 1 cuts the hidden dimension into that many pieces per
+ *     128-token block (more workgroups for small token counts) whose fp32 partial products go through `workspace`
+ *     (sdetr_ffn_workspace_bytes) and are finished by a second launch; sdetr_ffn_auto_splits picks the count for
+ *     the current device. */
 int64_t sdetr_ffn_packed_bytes(int hidden);
+int sdetr_ffn_auto_splits(int tokens, int hidden);
+int64_t sdetr_ffn_workspace_bytes(int tokens, int hidden_splits);
 int sdetr_ffn_pack_bf16(sdetr_stream_t stream, const void *weight1, const void *weight2, int embed_dim, int hidden,
                         void *packed);
 int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights, const float *bias1,
                          const float *bias2, const float *norm_weight, const float *norm_bias, float norm_eps,
-                         int tokens, int embed_dim, int hidden, void *out);
+                         int tokens, int embed_dim, int hidden, void *out, int hidden_splits, void *workspace,
+                         int64_t workspace_bytes);
 
 /* ---- (8) token-resident linear layers (256 input features, bf16) -------------------------------------------------
  * y = W x + b with the activations of 32 tokens resident in a wave's registers and the weights streamed through

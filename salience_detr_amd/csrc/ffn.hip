@@ -14,18 +14,29 @@
 //     of the first product (lane = token column, registers = hidden rows 8g+4h+{0..3}) exactly a B operand of the
 //     second once W2's contraction index is permuted to match -- no LDS round trip, no cross-lane traffic;
 //   * the weights are the only stream: both matrices are pre-packed (sdetr_ffn_pack_bf16) into 32 KB chunks of
-//     lane-ordered 1 KB MFMA A-fragments, which the four waves of a block copy global -> LDS with
-//     global_load_lds_dwordx4 (no registers, lane-linear destination = fragment order), triple-buffered with a
-//     counted s_waitcnt so one chunk is always in flight across the block barrier.  Each fragment is read from LDS
-//     once per wave (128 B/clk/CU at full MFMA rate, half the LDS peak); L2 sees 2 MB per 128 tokens.
-//   * epilogue in registers: + b2 + residual, LayerNorm over the 256 channels a lane pair holds, bf16 store.
+//     lane-ordered 1 KB MFMA A-fragments.  Four LOADER waves (one per SIMD, next to the compute wave) bring them
+//     global -> registers -> LDS: a chunk is requested four iterations before it is written into one of four LDS
+//     buffers (inline-asm loads with hand-counted s_waitcnt; see the loader).  Each fragment is read from LDS once per
+//     compute wave; L2 sees 2 MB per 128 tokens.
+//   * the main loop alternates the first product of chunk jt+1 with the second product of chunk jt (two independent
+//     MFMA streams), fragments reach the MFMAs through a 4-deep register ring.
+//   * epilogue in registers: the accumulator starts as b2, the residual comes out of the X^T operand registers through
+//     v_permlane32_swap, LayerNorm over the 256 channels a lane pair holds, bf16 store.
 //
-// Bound: bf16 MFMA peak -- 4*F*256 flops per token; one wave issues 64 chunks x 32 MFMAs.  Measured on MI355X (in-kernel
-// s_memtime, F = 2048) with the copies still issued by the compute waves: ~1800 cycles per chunk against 1056 for the
-// bare MFMAs -- 550 + 590 for the two products, ~180 for MFMA drain + ReLU/bf16, ~490 for the barrier and the wave's
-// 8 LDS-DMA issues (~45 cycles each, they stall the issuing wave): 64 us for any token count up to 32 768 (one compute
-// wave per SIMD, one round).  With the loader waves below: 54 us.  Next: interleaving chunk jt's second product with
-// chunk jt+1's first (hides the drain + ReLU phase and most of the barrier).
+// Bound: bf16 MFMA peak -- 4*F*256 flops per token; one wave issues 64 chunks x 32 MFMAs (1024 cycles per chunk).
+// Measured on MI355X (hipGraph replay, benchmarks/ffn_hidden_sweep.py, F = 2048): 63 us at 22 726 tokens (178 blocks),
+// 51 us at 1800 (15 blocks) = ~13 us of launch + prologue + epilogue and 0.63-0.78 us (1500-1850 cycles) per chunk.
+// History of the loop, each step measured:
+//   * LDS-DMA (global_load_lds_dwordx4) issued by the compute waves: 64 us total; by dedicated loader waves: 54 us.
+//   * PMC (matrix pipe busy 37 %) and ablations then showed that NOTHING inside the loop set its pace: without the
+//     MFMAs, without the fragment reads, without any loader work the kernel took the same 73-77 us.  A sweep over F
+//     separated the costs: 26 us were fixed -- an epilogue that reloaded the residual with 32 row-strided loads per lane
+//     and spilled (tuple copies of the accumulators) -- and the per-chunk time is what the LDS read latency (~185 cycles)
+//     allows a 4-deep ring (8 would spill inside the loop): 32 reads x latency / 4.
+//   * what did NOT help and was dropped: rotating the chunk order per block (L2 channel spreading).
+//
+// A block keeps a CU for the whole hidden dimension, so small token counts leave most of the chip idle: the hidden
+// dimension can be cut into `nsplit` pieces per token block (fp32 partial products + ffn_reduce_ln_kernel).
 #include "common.h"
 
 namespace sdetr {
@@ -46,6 +57,8 @@ struct FfnArgs {
     float eps;
     bf16_t *out;            // [T, 256]
     int T, nchunk;
+    int nsplit;             // hidden-dimension pieces per token block (1: the block finishes its tokens itself)
+    float *partial;         // nsplit > 1: [nsplit, T, 256] fp32 partial products, finished by ffn_reduce_ln_kernel
 };
 
 __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c)
@@ -66,35 +79,6 @@ __device__ __forceinline__ void mfma_bf16_vgpr(uint4 a, uint4 b, f32x16_t &c)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
 }
 
-// one 32 KB chunk global -> LDS: a wave copies its 8 KB as 8 LDS-DMA instructions of 1 KB (destination = M0 base +
-// instruction offset + lane * 16; the instruction offset advances the global source as well, so two M0 values cover
-// the 8 pieces).  Issued as inline asm on purpose: hipcc does not know which LDS bytes an LDS-DMA instruction it can
-// see will write and drains ALL of them (s_waitcnt vmcnt(0)) in front of the next ds_read -- which would serialise
-// the copy of chunk jt+2 with the MFMAs of chunk jt.  The counted waits in the main loop are the synchronisation.
-__device__ __forceinline__ void issue_chunk(const char *chunk, uint32_t voff, uint32_t dst_lds)
-{
-    const uint32_t d0 = __builtin_amdgcn_readfirstlane(dst_lds), d1 = d0 + 4096;
-    const uint32_t voff1 = voff + 4096;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %4\n\t"
-                 "global_load_lds_dwordx4 %0, %4 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, %4 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %0, %4 offset:3072\n\t"
-                 "s_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %4\n\t"
-                 "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %4 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, %4 offset:3072"
-                 :
-                 : "v"(voff), "v"(voff1), "s"(d0), "s"(d1), "s"(chunk)
-                 : "memory", "m0");
-}
-
-__device__ __forceinline__ uint32_t lds_address(const void *p)
-{
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-
 __device__ __forceinline__ uint4 lds_read16(lds_cptr_t p)
 {
     const u32x4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(p);
@@ -108,48 +92,105 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, v), z));
 }
 
-// Block = 4 compute waves (32 tokens each) + 4 LOADER waves, one of each per SIMD.  An LDS-DMA instruction stalls the
-// wave that issues it for ~45 cycles; issued by the compute waves the 8 copies per chunk cost a fifth of the loop
-// (measured: 490 cycles of 1800 for barrier + copies).  The loaders do nothing else: wait for their copies, meet the
-// compute waves at the chunk barrier, issue the next chunk.  (All waves get the same register allocation, so the
-// kernel has to fit 256 registers for two waves per SIMD.)
+// Block = 4 compute waves (32 tokens each) + 4 LOADER waves, one of each per SIMD.  (All waves get the same register
+// allocation, so the kernel has to fit 256 registers for two waves per SIMD.)
 constexpr int kFThreads = 512;
 
 __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char *wbuf = lds;                                                  // 3 chunk buffers
-    float *b1s = reinterpret_cast<float *>(lds + 3 * kFChunkBytes);    // [F]
+    char *wbuf = lds;                                                  // 4 chunk buffers
+    float *b1s = reinterpret_cast<float *>(lds + 4 * kFChunkBytes);    // [F]
     float *par = b1s + p.nchunk * kFChunk;                             // b2 | gamma | beta
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t wbuf_lds = lds_address(wbuf);
+    // hidden split: block = (token block, piece); piece sp walks chunks [c0, c0 + nloc) of the hidden dimension
+    const int tblock = blockIdx.x / p.nsplit, sp = blockIdx.x - tblock * p.nsplit;
+    const int c0 = (int)((int64_t)sp * p.nchunk / p.nsplit);
+    const int nloc = (int)((int64_t)(sp + 1) * p.nchunk / p.nsplit) - c0;
+    const char *pw = p.pw + (int64_t)c0 * kFChunkBytes;
+    auto chunk_at = [&](int jt) { return jt; };
 
     if (wave >= 4) {
-        // ---- loader wave: a quarter (8 KB = 8 LDS-DMA instructions) of every 32 KB chunk ----
+        // ---- loader wave: a quarter (8 KB) of every 32 KB chunk, global -> registers -> LDS, FOUR chunk buffers ----
+        // (LDS-DMA, global_load_lds_dwordx4, would need no registers, but a copy then has to complete within the one
+        // iteration between two barriers; ordinary loads into the loader's own, otherwise idle registers can run four
+        // chunks ahead.)
+        // Chunk c lives in buffer c & 3.  During main-loop iteration jt the compute waves read chunk jt+1 (first
+        // product of the NEXT chunk), chunk jt (second product) and the head of chunk jt+2 (for the register ring);
+        // chunk jt+3 is written into the buffer chunk jt-1 left, and chunk jt+4 is on its way from L2.
         const int lw = wave - 4;
-        const uint32_t voff = (uint32_t)(lw * 8192 + lane * 16);
-        const uint32_t wave_lds = wbuf_lds + lw * 8192;
-        issue_chunk(p.pw, voff, wave_lds);
-        if (p.nchunk > 1) issue_chunk(p.pw + kFChunkBytes, voff, wave_lds + kFChunkBytes);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // chunks 0 and 1 are in LDS
-        int buf = 0;
-        for (int jt = 0; jt + 1 < p.nchunk; ++jt) {
-            // chunk jt+1 (requested one iteration ago) has landed; at the barrier every compute wave is past chunk
-            // jt-1, whose buffer the copy of chunk jt+2 may now overwrite
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (jt + 2 < p.nchunk) {
-                const int pbuf = buf == 0 ? 2 : buf - 1;
-                issue_chunk(p.pw + (int64_t)(jt + 2) * kFChunkBytes, voff, wave_lds + pbuf * kFChunkBytes);
-            }
-            buf = buf == 2 ? 0 : buf + 1;
+        const uint4 *src = reinterpret_cast<const uint4 *>(pw) + lw * 512 + lane;
+        char *dst = wbuf + lw * 8192 + lane * 16;
+        // Chunk c travels in register set c & 3 and is requested FOUR iterations before it is written to LDS.
+        // The loads are inline asm with hand-counted waits: hipcc's own wait insertion merges the conditional paths of
+        // the tail and then drains every outstanding load (vmcnt(0)) in front of each store.  Loads complete in order,
+        // so "at most 24 outstanding" = the oldest set has arrived.  (Plain named registers: an array passed to a
+        // helper stays in scratch memory under the asm memory clobbers.)
+#define SDETR_GLD(dst, base, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(base) : "memory")
+#define SDETR_FETCH8(P, c)                                                                                        \
+    {                                                                                                             \
+        const uint4 *q0_ = src + (int64_t)chunk_at(c) * 2048, *q1_ = q0_ + 256;                                   \
+        SDETR_GLD(P##0, q0_, 0); SDETR_GLD(P##1, q0_, 1024); SDETR_GLD(P##2, q0_, 2048); SDETR_GLD(P##3, q0_, 3072); \
+        SDETR_GLD(P##4, q1_, 0); SDETR_GLD(P##5, q1_, 1024); SDETR_GLD(P##6, q1_, 2048); SDETR_GLD(P##7, q1_, 3072); \
+    }
+#define SDETR_STASH8(P, c)                                                                                        \
+    {                                                                                                             \
+        char *d_ = dst + ((c) & 3) * kFChunkBytes;                                                                \
+        *reinterpret_cast<uint4 *>(d_) = P##0; *reinterpret_cast<uint4 *>(d_ + 1024) = P##1;                      \
+        *reinterpret_cast<uint4 *>(d_ + 2048) = P##2; *reinterpret_cast<uint4 *>(d_ + 3072) = P##3;               \
+        *reinterpret_cast<uint4 *>(d_ + 4096) = P##4; *reinterpret_cast<uint4 *>(d_ + 5120) = P##5;               \
+        *reinterpret_cast<uint4 *>(d_ + 6144) = P##6; *reinterpret_cast<uint4 *>(d_ + 7168) = P##7;               \
+    }
+        uint4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+        uint4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rd0, rd1, rd2, rd3, rd4, rd5, rd6, rd7;
+        // prologue: chunks 0..2 into LDS, chunks 3..6 on their way
+        SDETR_FETCH8(ra, 0);
+        SDETR_FETCH8(rb, nloc > 1 ? 1 : 0);
+        SDETR_FETCH8(rc, nloc > 2 ? 2 : 0);
+        SDETR_FETCH8(rd, nloc > 3 ? 3 : 0);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        SDETR_STASH8(ra, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDETR_FETCH8(ra, nloc > 4 ? 4 : 0);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (nloc > 1) SDETR_STASH8(rb, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDETR_FETCH8(rb, nloc > 5 ? 5 : 0);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (nloc > 2) SDETR_STASH8(rc, 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDETR_FETCH8(rc, nloc > 6 ? 6 : 0);
+        __builtin_amdgcn_s_barrier();
+        // iteration j: past its barrier every compute wave is done with chunk j-1, whose buffer takes chunk j+3; the
+        // register set that held it goes back to L2 for chunk j+7 (the tail re-requests chunk 0: every phase issues
+        // exactly 8 loads, which is what keeps the wait count a constant)
+#define SDETR_PHASE(P, j)                                                                                         \
+    {                                                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                                         \
+        if ((j) + 3 < nloc) SDETR_STASH8(P, (j) + 3);                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+        SDETR_FETCH8(P, (j) + 7 < nloc ? (j) + 7 : 0);                                                            \
+    }
+        for (int jt = 0; jt + 1 < nloc; jt += 4) {
+            SDETR_PHASE(rd, jt);
+            if (jt + 2 >= nloc) break;
+            SDETR_PHASE(ra, jt + 1);
+            if (jt + 3 >= nloc) break;
+            SDETR_PHASE(rb, jt + 2);
+            if (jt + 4 >= nloc) break;
+            SDETR_PHASE(rc, jt + 3);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dummy requests of the tail)
+#undef SDETR_PHASE
+#undef SDETR_FETCH8
+#undef SDETR_STASH8
+#undef SDETR_GLD
         return;
     }
 
     const int t = lane & 31, h = lane >> 5;
-    const int tok = blockIdx.x * kFTokBlock + wave * kFTokWave + t;
+    const int tok = tblock * kFTokBlock + wave * kFTokWave + t;
     const bool valid = tok < p.T;
     const int64_t row = (int64_t)(valid ? tok : p.T - 1) * kFE;
 
@@ -166,33 +207,39 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
 
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the staged vectors; the loaders bring chunks 0..2
+    __builtin_amdgcn_s_barrier();
+
+    // the output accumulator STARTS as b2 (a piece of a split hidden dimension starts at zero: its second pass adds it)
     f32x16_t yacc[8];
 #pragma unroll
     for (int et = 0; et < 8; ++et)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) yacc[et][i] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            float4 bv = *reinterpret_cast<const float4 *>(par + 32 * et + 8 * g + 4 * h);
+            if (p.nsplit > 1) bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            yacc[et][4 * g] = bv.x; yacc[et][4 * g + 1] = bv.y; yacc[et][4 * g + 2] = bv.z; yacc[et][4 * g + 3] = bv.w;
+        }
 
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // chunks 0 and 1, biases
-    __builtin_amdgcn_s_barrier();
-
-    // The loop is ISSUE-bound if it is not kept lean: one wave per SIMD hides ~5 other instructions behind each
-    // 32-cycle MFMA, so a chunk (32 MFMAs) may cost ~160: 32 fragment reads + 4 bias reads, their waits, 16 VALU for
-    // ReLU + bf16, ~16 for the LDS copy of chunk jt+2, the loop itself.  Hence: the accumulator of the first product
-    // STARTS as the bias (four 16-byte LDS reads land in the four register quads -- no zeroing, no adds), ReLU runs
-    // on packed bf16 pairs, and the chunk copy uses one scalar base + immediate offsets.
+    // SOFTWARE PIPELINE over the chunks.  A chunk is two dependent products (H = relu(W1 X + b1), Y += W2 H).  The first
+    // is a chain of 16 MFMAs into ONE accumulator and the second pairs its MFMAs on each of 8 accumulators: issued
+    // back to back, a dependent MFMA waits for the full 16-pass latency of its predecessor, not the 8-pass issue
+    // interval (PMC: the matrix pipe was busy 37 % of the kernel, SQ_WAIT_INST_ANY 38 % of the compute waves' cycles).
+    // So iteration jt ALTERNATES the first product of chunk jt+1 with the second product of chunk jt -- two independent
+    // streams, every dependent pair now two or more MFMAs apart -- and walks the second product k-block-major (the 8
+    // e-tiles of k-block 0, then those of k-block 1).  The conversion of the hidden tile (ReLU, bf16) sits at the
+    // iteration boundary.
     //
-    // A fragments come from LDS through a 4-deep ring of registers (8 would not fit the 256-register budget the loader
-    // waves impose): fragment f of a chunk (0..15 = W1 k-steps, 16..31 = W2 (e-tile, k-block)) is requested 4 MFMAs
-    // (~130 cycles, the LDS latency) before it is used, and a slot is refilled
-    // right AFTER the MFMA that consumed it, so no value ever needs a second register (nothing to copy on the loop's
-    // back edge).  The last requests of a chunk fetch the first fragments of the next one.
+    // The accumulator of the first product STARTS as the bias (four 16-byte LDS reads land in its register quads -- no
+    // zeroing, no adds), ReLU runs on packed bf16 pairs.  A fragments come from LDS through a 4-deep ring of registers:
+    // slot s of an iteration (even: W1[jt+1] k-step s/2, odd: W2[jt] fragment of (k-block, e-tile) = (s>>4, (s>>1)&7))
+    // is requested 4 MFMAs before its use and the slot is refilled right AFTER the MFMA that consumed it; the last four
+    // requests fetch the head of the next iteration's stream.
     constexpr int R = 4;
     uint4 ring[R];
-    lds_cptr_t cb = (lds_cptr_t)wbuf + lane * 16;
+    const lds_cptr_t lbase = (lds_cptr_t)wbuf + lane * 16;
+    auto chunk_lds = [&](int c) { return lbase + (c & 3) * kFChunkBytes; };
     const lds_cptr_t bias_base = (lds_cptr_t)(const char *)b1s + 16 * h;
-#pragma unroll
-    for (int f = 0; f < R; ++f) ring[f] = lds_read16(cb + f * 1024);
-    int buf = 0;   // buffer of chunk jt
     f32x16_t hacc;
     auto load_bias = [&](int chunk) {
         const lds_cptr_t bb = bias_base + chunk * (kFChunk * 4);
@@ -205,100 +252,193 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
             hacc[4 * g + 3] = __uint_as_float(bv.w);
         }
     };
-    load_bias(0);
-
-    for (int jt = 0; jt < p.nchunk; ++jt) {
-        const int nbuf = buf == 2 ? 0 : buf + 1;                       // buffer of chunk jt+1
-        const lds_cptr_t cn = (lds_cptr_t)wbuf + nbuf * kFChunkBytes + lane * 16;
-        // H^T[j][t] = b1[32jt + j] + sum_k W1[32jt + j][k] X[t][k]; registers 4g..4g+3 are rows 8g + 4h + {0..3}
-        // (hacc already holds the bias: loaded during the previous chunk's second product)
-#pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            mfma_bf16_vgpr(ring[f % R], xb[f], hacc);
-            ring[f % R] = lds_read16(cb + (f + R) * 1024);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the VALU below reads registers the last MFMA is still writing: hipcc cannot see that through the inline
-        // asm, so the required wait states (8-pass XDL write -> VALU read) are spelled out
-        // (the accumulator is an operand of the statement so that its readers cannot be scheduled above it)
+    uint4 hp[2];   // packed relu(H) of the chunk in its second product: k-blocks 0 and 1
+    // ReLU + bf16 of the finished hidden tile, then the NEXT chunk's bias into the freed accumulator registers
+    auto convert = [&](int next_bias_chunk) {
+        // the VALU below reads registers an inline-asm MFMA wrote: hipcc cannot see that, so the wait states
+        // (XDL write -> VALU read) are spelled out; the accumulator is an operand so that its readers stay below
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hacc));
-        // ReLU, bf16
-        uint4 hp[2];
         hp[0] = make_uint4(relu_bf16x2(pack_bf16x2(hacc[0], hacc[1])), relu_bf16x2(pack_bf16x2(hacc[2], hacc[3])),
                            relu_bf16x2(pack_bf16x2(hacc[4], hacc[5])), relu_bf16x2(pack_bf16x2(hacc[6], hacc[7])));
         hp[1] = make_uint4(relu_bf16x2(pack_bf16x2(hacc[8], hacc[9])), relu_bf16x2(pack_bf16x2(hacc[10], hacc[11])),
                            relu_bf16x2(pack_bf16x2(hacc[12], hacc[13])), relu_bf16x2(pack_bf16x2(hacc[14], hacc[15])));
-        // pin the conversion HERE: once it has run, the accumulator registers are free and the next chunk's bias can
-        // land in them -- were its live range to reach past load_bias, the allocator would have to move the
-        // accumulator between two of the MFMAs above, a copy that reads registers the MFMA before it has not written yet
+        // pin the conversion HERE: once it has run the accumulator registers are free and the next bias can land in
+        // them -- were its live range to reach past load_bias, the allocator would have to move the accumulator
+        // between two asm MFMAs, a copy that reads registers the MFMA before it has not written yet
         asm volatile("" : "+v"(hp[0].x), "+v"(hp[0].y), "+v"(hp[0].z), "+v"(hp[0].w), "+v"(hp[1].x), "+v"(hp[1].y), "+v"(hp[1].z), "+v"(hp[1].w));
-        load_bias(jt + 1 < p.nchunk ? jt + 1 : jt);   // next chunk's bias into the now free accumulator registers
-        // chunk jt+1 is in LDS once the loaders reach this barrier; passing it also tells them chunk jt-1 is done with
-        if (jt + 1 < p.nchunk) __builtin_amdgcn_s_barrier();   // (the loader waves' side: see the top of the kernel)
-        // Y^T[e][t] += sum_j W2[e][32jt + j] H^T[j][t]   (W2's j order permuted to the accumulator layout above)
+        load_bias(next_bias_chunk);
+    };
+    // byte offset inside a chunk of the W2 fragment that the q-th MFMA of the k-block-major walk uses
+    auto w2_frag = [](int q) { return (16 + 2 * (q & 7) + (q >> 3)) * 1024; };
+
+    // ---- prologue: first product + conversion of chunk 0 (a bare dependent chain, once per piece) ----
 #pragma unroll
-        for (int f = 16; f < 32; ++f) {
-            const int et = (f - 16) >> 1;
-            yacc[et] = mfma_bf16(ring[f % R], hp[f & 1], yacc[et]);
-            if (f + R < 32) ring[f % R] = lds_read16(cb + (f + R) * 1024);
-            else ring[f % R] = lds_read16(cn + (f + R - 32) * 1024);   // (unused after the last chunk)
+    for (int f = 0; f < R; ++f) ring[f] = lds_read16(chunk_lds(0) + f * 1024);
+    load_bias(c0 + chunk_at(0));
+    {
+        const lds_cptr_t a0 = chunk_lds(0), a1 = chunk_lds(1);
+        const bool more = nloc > 1;   // then the interleaved stream follows: W1[1] k-step, W2[0] fragment, ...
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            mfma_bf16_vgpr(ring[f % R], xb[f], hacc);
+            if (f + R < 16) {
+                ring[f % R] = lds_read16(a0 + (f + R) * 1024);
+            } else {
+                const int s2 = f + R - 16;   // slot of the next stream
+                const lds_cptr_t inter = (s2 & 1) ? a0 + w2_frag(s2 >> 1) : a1 + (s2 >> 1) * 1024;
+                ring[f % R] = lds_read16(more ? inter : a0 + w2_frag(s2));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        cb = cn;
-        buf = nbuf;
+    }
+    convert(c0 + chunk_at(nloc > 1 ? 1 : 0));
+
+    for (int jt = 0; jt + 1 < nloc; ++jt) {
+        // chunks jt+1 and jt+2 are in LDS (the head of jt+2 feeds the ring at the end of this iteration); the loaders
+        // learn that chunk jt-1 is done with
+        __builtin_amdgcn_s_barrier();
+        const lds_cptr_t ca = chunk_lds(jt + 1), cb = chunk_lds(jt), cn = chunk_lds(jt + 2);
+        const bool more = jt + 2 < nloc;   // is the next iteration interleaved as well (or the bare tail)?
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            if (s & 1) {
+                const int q = s >> 1;
+                yacc[q & 7] = mfma_bf16(ring[s % R], hp[q >> 3], yacc[q & 7]);
+            } else {
+                mfma_bf16_vgpr(ring[s % R], xb[s >> 1], hacc);
+            }
+            if (s + R < 32) {
+                ring[s % R] = (s & 1) ? lds_read16(cb + w2_frag((s + R) >> 1)) : lds_read16(ca + ((s + R) >> 1) * 1024);
+            } else {
+                const int s2 = s + R - 32;
+                const lds_cptr_t inter = (s2 & 1) ? ca + w2_frag(s2 >> 1) : cn + (s2 >> 1) * 1024;
+                ring[s % R] = lds_read16(more ? inter : ca + w2_frag(s2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        convert(c0 + chunk_at(more ? jt + 2 : jt + 1));
+    }
+    // ---- tail: second product of the last chunk ----
+    {
+        const lds_cptr_t cb = chunk_lds(nloc - 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            yacc[q & 7] = mfma_bf16(ring[q % R], hp[q >> 3], yacc[q & 7]);
+            if (q + R < 16) ring[q % R] = lds_read16(cb + w2_frag(q + R));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
-    // ---- + b2 + residual, LayerNorm over the 256 channels held by lanes (t, 0) and (t, 1), store ----
-    // all 32 residual pieces are requested before the first is used (one by one in front of their adds each would
-    // cost a full memory latency)
-    uint2 rbuf[32];
+    if (p.nsplit > 1) {
+        // a piece of the hidden dimension: raw partial product, 16 bytes per (e-tile, quad) and lane
+        if (valid) {
+            float *prow = p.partial + ((int64_t)sp * p.T + tok) * kFE;
 #pragma unroll
-    for (int et = 0; et < 8; ++et)
+            for (int et = 0; et < 8; ++et)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rbuf[et * 4 + g] = *reinterpret_cast<const uint2 *>(p.x + row + 32 * et + 8 * g + 4 * h);
-    __builtin_amdgcn_sched_barrier(0);
-    float sum = 0.f;
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(prow + 32 * et + 8 * g + 4 * h) =
+                        make_float4(yacc[et][4 * g], yacc[et][4 * g + 1], yacc[et][4 * g + 2], yacc[et][4 * g + 3]);
+        }
+        return;
+    }
+
+    // ---- + residual, LayerNorm over the 256 channels held by lanes (t, 0) and (t, 1), store ----
+    // The residual is X itself and X^T is still in the B-operand registers: lane (t, h) holds channels 16ks + 8h .. +7
+    // of its token and needs 32et + 8g + 4h .. +3, i.e. half of each of its own pieces and half of its partner's
+    // (t, 1-h) -- v_permlane32_swap exchanges exactly those halves between the two 32-lane rows.  No reload from
+    // memory (32 row-strided 8-byte loads per lane and the registers to hold them).
+    // The accumulators are only READ from here on (writing elements of a 16-register tuple makes the allocator copy
+    // tuples, and with 128 + 64 registers live that spilled: the epilogue ran 13 us): pass 1 sums v = y + x and v^2,
+    // pass 2 recomputes v and writes (v - mean) * rstd * gamma + beta.
 #pragma unroll
-    for (int et = 0; et < 8; ++et)
+    for (int ks = 0; ks < 16; ++ks) {
+        // upper dwords of row 0 <-> lower dwords of row 1: afterwards (x, y) are the residual of quad g = 2 (ks & 1) of
+        // e-tile ks >> 1 and (z, w) that of quad g + 1
+        const auto s0 = __builtin_amdgcn_permlane32_swap(xb[ks].x, xb[ks].z, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(xb[ks].y, xb[ks].w, false, false);
+        xb[ks] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
+    auto residual = [&](int et, int g, float (&r)[4]) {
+        const uint4 q = xb[2 * et + (g >> 1)];
+        const uint32_t d0 = (g & 1) ? q.z : q.x, d1 = (g & 1) ? q.w : q.y;
+        r[0] = bf16_lo(d0); r[1] = bf16_hi(d0); r[2] = bf16_lo(d1); r[3] = bf16_hi(d1);
+    };
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int et = 0; et < 8; ++et) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int e0 = 32 * et + 8 * g + 4 * h;
-            const uint2 r = rbuf[et * 4 + g];
-            const float4 bv = *reinterpret_cast<const float4 *>(par + e0);
-            yacc[et][4 * g] += bv.x + bf16_lo(r.x);
-            yacc[et][4 * g + 1] += bv.y + bf16_hi(r.x);
-            yacc[et][4 * g + 2] += bv.z + bf16_lo(r.y);
-            yacc[et][4 * g + 3] += bv.w + bf16_hi(r.y);
-            sum += (yacc[et][4 * g] + yacc[et][4 * g + 1]) + (yacc[et][4 * g + 2] + yacc[et][4 * g + 3]);
+            float r[4];
+            residual(et, g, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = yacc[et][4 * g + i] + r[i];
+                sum += v;
+                sq = fmaf(v, v, sq);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.f / kFE);
-    float sq = 0.f;
-#pragma unroll
-    for (int et = 0; et < 8; ++et)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float d = yacc[et][i] - mean;
-            sq += d * d;
-        }
     sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq * (1.f / kFE) + p.eps);
+    const float mean = sum * (1.f / kFE);
+    const float rstd = rsqrtf(fmaxf(sq * (1.f / kFE) - mean * mean, 0.f) + p.eps);
+    const float shift = -mean * rstd;
     if (valid) {
         bf16_t *orow = p.out + row;
 #pragma unroll
-        for (int et = 0; et < 8; ++et)
+        for (int et = 0; et < 8; ++et) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int e0 = 32 * et + 8 * g + 4 * h;
                 const float4 gv = *reinterpret_cast<const float4 *>(par + kFE + e0);
                 const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kFE + e0);
-                const float y0 = (yacc[et][4 * g] - mean) * rstd * gv.x + be.x;
-                const float y1 = (yacc[et][4 * g + 1] - mean) * rstd * gv.y + be.y;
-                const float y2 = (yacc[et][4 * g + 2] - mean) * rstd * gv.z + be.z;
-                const float y3 = (yacc[et][4 * g + 3] - mean) * rstd * gv.w + be.w;
+                float r[4];
+                residual(et, g, r);
+                // (v - mean) * rstd * gamma + beta = (v * rstd + shift) * gamma + beta
+                const float y0 = fmaf(fmaf(yacc[et][4 * g] + r[0], rstd, shift), gv.x, be.x);
+                const float y1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
+                const float y2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
+                const float y3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
                 *reinterpret_cast<uint2 *>(orow + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
             }
+            // one e-tile at a time: hoisting all 64 gamma / beta reads above the arithmetic costs 256 registers
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+}
+
+// Second pass of the hidden-split form: out = LayerNorm(x + b2 + sum_s partial[s]).  One wave per token, lane l owns
+// channels 4l .. 4l+3 (1 KB coalesced row reads).
+__global__ void __launch_bounds__(256) ffn_reduce_ln_kernel(const float *partial, int nsplit, int T, const bf16_t *x,
+                                                            const float *b2, const float *gamma, const float *beta,
+                                                            float eps, bf16_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= T) return;
+    const int64_t o = (int64_t)tok * kFE + 4 * lane;
+    const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
+    const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
+    float v0 = bv.x + bf16_lo(r.x), v1 = bv.y + bf16_hi(r.x), v2 = bv.z + bf16_lo(r.y), v3 = bv.w + bf16_hi(r.y);
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 pv = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
+        v0 += pv.x; v1 += pv.y; v2 += pv.z; v3 += pv.w;
+    }
+    float sum = (v0 + v1) + (v2 + v3);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+    const float mean = sum * (1.f / kFE);
+    const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+    float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+    const float rstd = rsqrtf(sq * (1.f / kFE) + eps);
+    const float4 gv = *reinterpret_cast<const float4 *>(gamma + 4 * lane);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * lane);
+    *reinterpret_cast<uint2 *>(out + o) = make_uint2(pack_bf16x2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
+                                                     pack_bf16x2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
 }
 
 // hidden index inside a 16-wide k-block that MFMA operand slot (h, s) stands for: the accumulator rows a lane of
@@ -340,16 +480,59 @@ extern "C" int sdetr_ffn_pack_bf16(sdetr_stream_t stream, const void *weight1, c
     return check_launch("ffn_pack");
 }
 
+static int device_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+// A block keeps a whole CU (128 KB of weight buffers, one compute wave per SIMD): measured on MI355X (hipGraph replay,
+// benchmarks/ffn_hidden_sweep.py) a piece costs ~0.7 us per 32-unit chunk plus ~13 us of launch + prologue + epilogue;
+// the second pass of a split launch reads nsplit + 1 KB per token.  With one piece per token block the kernel runs ~60 us
+// whether 15 or 178 CUs have work: splitting the hidden dimension fills the chip for the encoder's smaller layers.
+extern "C" int sdetr_ffn_auto_splits(int tokens, int hidden)
+{
+    if (tokens <= 0 || hidden <= 0) return 1;
+    const int nchunk = hidden / kFChunk, cus = device_cus();
+    const int tblocks = (tokens + kFTokBlock - 1) / kFTokBlock;
+    int best = 1;
+    double best_us = 1e30;
+    for (int s = 1; s <= nchunk && s <= 16; ++s) {
+        const int rounds = (tblocks * s + cus - 1) / cus;
+        const int chunks = (nchunk + s - 1) / s;
+        double us = rounds * (chunks * 0.7 + 13.0);
+        if (s > 1) us += 4.0 + (double)tokens * (s + 1) * 1024.0 / 3.0e6;   // second launch + its traffic at ~3 TB/s
+        if (us < best_us - 1e-9) { best_us = us; best = s; }
+    }
+    return best;
+}
+
+extern "C" int64_t sdetr_ffn_workspace_bytes(int tokens, int hidden_splits)
+{
+    return hidden_splits > 1 && tokens > 0 ? (int64_t)hidden_splits * tokens * kFE * 4 : 0;
+}
+
 extern "C" int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights, const float *bias1,
                                     const float *bias2, const float *norm_weight, const float *norm_bias, float norm_eps,
-                                    int tokens, int embed_dim, int hidden, void *out)
+                                    int tokens, int embed_dim, int hidden, void *out, int hidden_splits, void *workspace,
+                                    int64_t workspace_bytes)
 {
     if (embed_dim != kFE) return fail("ffn_fused: built for embed_dim %d (got %d)", kFE, embed_dim);
     if (hidden <= 0 || hidden % kFChunk) return fail("ffn_fused: hidden (%d) must be a positive multiple of %d", hidden, kFChunk);
     if (tokens < 0) return fail("ffn_fused: negative token count");
+    if (hidden_splits < 1 || hidden_splits > hidden / kFChunk) return fail("ffn_fused: hidden_splits must be in 1 .. hidden/32");
     if (tokens == 0) return 0;
     if (!x || !packed_weights || !bias1 || !bias2 || !norm_weight || !norm_bias || !out) return fail("ffn_fused: null pointer");
-    const size_t lds = 3 * (size_t)kFChunkBytes + (size_t)hidden * 4 + 3 * kFE * 4;
+    if (hidden_splits > 1 && (!workspace || workspace_bytes < sdetr_ffn_workspace_bytes(tokens, hidden_splits)))
+        return fail("ffn_fused: %d hidden splits need a workspace of %lld bytes", hidden_splits,
+                    (long long)sdetr_ffn_workspace_bytes(tokens, hidden_splits));
+    const size_t lds = 4 * (size_t)kFChunkBytes + (size_t)hidden * 4 + 3 * kFE * 4;
     if (lds > 160 * 1024) return fail("ffn_fused: hidden %d needs %zu bytes of LDS", hidden, lds);
     static bool attr_set = false;
     if (!attr_set) {
@@ -360,7 +543,13 @@ extern "C" int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const 
     FfnArgs a;
     a.x = (const bf16_t *)x; a.pw = (const char *)packed_weights; a.b1 = bias1; a.b2 = bias2; a.gamma = norm_weight;
     a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out; a.T = tokens; a.nchunk = hidden / kFChunk;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((tokens + kFTokBlock - 1) / kFTokBlock)), dim3(kFThreads), lds,
+    a.nsplit = hidden_splits; a.partial = hidden_splits > 1 ? (float *)workspace : nullptr;
+    const int64_t tblocks = (tokens + kFTokBlock - 1) / kFTokBlock;
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds,
                        static_cast<hipStream_t>(stream), a);
+    if (hidden_splits > 1)
+        hipLaunchKernelGGL(ffn_reduce_ln_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), (const float *)workspace, hidden_splits, tokens,
+                           (const bf16_t *)x, bias2, norm_weight, norm_bias, norm_eps, (bf16_t *)out);
     return check_launch("ffn_fused");
 }

@@ -323,8 +323,8 @@ def test_layer_norm_scatter_destination():
 
 
 @pytest.mark.parametrize("T", [1, 31, 128, 129, 1000, 4545])
-@pytest.mark.parametrize("hidden", [64, 2048])
-def test_fused_ffn_matches_fp32_reference(T, hidden):
+@pytest.mark.parametrize("hidden,splits", [(64, None), (64, 2), (2048, None), (2048, 1), (2048, 3), (2048, 7), (2048, 64)])
+def test_fused_ffn_matches_fp32_reference(T, hidden, splits):
     """One-launch bf16 feed-forward vs the same block evaluated in fp32 on the bf16-rounded parameters; the
     framework's own bf16 path (two GEMMs + LayerNorm) sets the error scale."""
     torch.manual_seed(T + hidden)
@@ -343,7 +343,7 @@ def test_fused_ffn_matches_fp32_reference(T, hidden):
         ref = fn(x.float() + f2(torch.relu(f1(x.float()))))
         assert F.fused_ffn_applies(torch.empty(8000, 256, dtype=torch.bfloat16, device=DEV), mods[0], mods[1], mods[2],
                                    torch.nn.ReLU())   # (small token counts are routed to the library GEMMs)
-        got = F.fused_ffn(xd, *mods).float().cpu()
+        got = F.fused_ffn(xd, *mods, hidden_splits=splits).float().cpu()
         base = mods[2](xd + mods[1](torch.relu(mods[0](xd)))).float().cpu()
     err, base_err = (got - ref).abs().max().item(), (base - ref).abs().max().item()
     assert err <= max(1.5 * base_err, 0.03), (err, base_err)
