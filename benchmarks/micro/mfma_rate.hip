@@ -1,0 +1,207 @@
+// Ground-truth issue rates on gfx950 for the building blocks of the token-resident kernels: one wave per SIMD issuing
+// v_mfma_f32_32x32x16_bf16 (independent / dependent accumulators), with and without an LDS fragment ring.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_rate benchmarks/micro/mfma_rate.hip && ./mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// MODE 0: NACC independent accumulators, operands in registers
+// MODE 1: as 0 + every MFMA's A operand comes from LDS through a ring of depth R (refilled after use)
+template <int NACC, int MODE, int R>
+__global__ void __launch_bounds__(256, 1) k(int iters, uint64_t *cycles, float *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += 256) reinterpret_cast<uint32_t *>(lds)[i] = i * 2654435761u;
+    __syncthreads();
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    u32x4_t a = {1u + lane, 2u, 3u, 4u}, b = {5u, 6u + lane, 7u, 8u};
+    u32x4_t ring[R > 0 ? R : 1];
+    const __attribute__((address_space(3))) char *base = (const __attribute__((address_space(3))) char *)lds + lane * 16;
+    if (MODE == 1) {
+#pragma unroll
+        for (int f = 0; f < R; ++f) ring[f] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + f * 1024);
+    }
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int f = 0; f < 64; ++f) {
+            if (MODE == 1) {
+                acc[f % NACC] = mfma(ring[f % R], b, acc[f % NACC]);
+                ring[f % R] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + ((f + R) & 63) * 1024);
+            } else {
+                acc[f % NACC] = mfma(a, b, acc[f % NACC]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][7];
+    if (s == 123.456f) sink[0] = s;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+// The token-resident kernels' step loop, feature by feature: 4 compute waves (64 MFMAs per step, A through an 8-deep
+// ring from LDS) + optionally 4 loader waves that rewrite 64 KB of LDS per step and meet the compute waves at a
+// barrier, + optionally the row-strided 8-byte output stores of four 32-feature tiles per step.
+//   FEAT bit 0: loader waves + barrier per step;  bit 1: loaders really write LDS;  bit 2: global stores;
+//   bit 3: per-tile bias reads (4 x ds_read_b128) and bf16 packing of the accumulators
+template <int FEAT>
+__global__ void __launch_bounds__(512, 1) step_kernel(int steps, uint64_t *cycles, float *sink, uint16_t *out, int out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 32768; i += 512) reinterpret_cast<uint32_t *>(lds)[i] = i * 2654435761u;
+    __syncthreads();
+    if (wave >= 4) {
+        if (!(FEAT & 1)) return;
+        u32x4_t v = {1u, 2u, 3u, 4u};
+        __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)lds + (wave - 4) * 16384 + lane * 16;
+        for (int st = 0; st < steps; ++st) {
+            if (FEAT & 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(dst + ((st & 1) ^ 1) * 65536 + i * 1024) = v;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    f32x16_t acc[4];
+    u32x4_t b = {5u, 6u + lane, 7u, 8u};
+    u32x4_t ring[8];
+    const uint64_t t0 = __builtin_readcyclecounter();
+    const int t = lane & 31, h = lane >> 5;
+    uint16_t *orow = out + ((size_t)(blockIdx.x * 4 + wave) * 32 + t) * out_stride + 4 * h;
+    for (int st = 0; st < steps; ++st) {
+        const __attribute__((address_space(3))) char *base =
+            (const __attribute__((address_space(3))) char *)lds + (st & 1) * 65536 + lane * 16;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) ring[f] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + f * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (FEAT & 8) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4_t bv = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + 60000 + j * 128 + 32 * g);
+                    acc[j][4 * g] = __uint_as_float(bv.x); acc[j][4 * g + 1] = __uint_as_float(bv.y);
+                    acc[j][4 * g + 2] = __uint_as_float(bv.z); acc[j][4 * g + 3] = __uint_as_float(bv.w);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 64; ++f) {
+            acc[f & 3] = mfma(ring[f % 8], b, acc[f & 3]);
+            if (f + 8 < 64) ring[f % 8] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + (f + 8) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FEAT & 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 v;
+                    if (FEAT & 8) {
+                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        v.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){acc[j][4 * g], acc[j][4 * g + 1]}, bf2));
+                        v.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){acc[j][4 * g + 2], acc[j][4 * g + 3]}, bf2));
+                    } else {
+                        v = make_uint2(__float_as_uint(acc[j][4 * g]), __float_as_uint(acc[j][4 * g + 2]));
+                    }
+                    *reinterpret_cast<uint2 *>(orow + ((st & 3) * 4 + j) * 32 + 8 * g) = v;
+                }
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][9];
+            if (s == 123.456f) sink[0] = s;
+        }
+        if (FEAT & 1) __builtin_amdgcn_s_barrier();
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+template <int FEAT>
+void run_step(const char *name, int blocks)
+{
+    uint64_t *d; float *sink; uint16_t *out;
+    const int steps = 48, stride = 512;
+    hipMalloc(&d, blocks * 8); hipMalloc(&sink, 4); hipMalloc(&out, (size_t)blocks * 128 * stride * 2);
+    hipFuncSetAttribute((const void *)step_kernel<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step_kernel<FEAT>), dim3(blocks), dim3(512), 131072, 0, steps, d, sink, out, stride);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((step_kernel<FEAT>), dim3(blocks), dim3(512), 131072, 0, steps, d, sink, out, stride);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h(blocks);
+    hipMemcpy(h.data(), d, blocks * 8, hipMemcpyDeviceToHost);
+    printf("%-62s blocks %3d: %.0f ticks / step (2048 = MFMA bound), %.2f us / tile (wall)\n", name, blocks, (double)h[0] / steps,
+           ms * 1e3 / (steps * 4));
+    hipFree(d); hipFree(sink); hipFree(out);
+}
+
+template <int NACC, int MODE, int R>
+void run(const char *name, int blocks)
+{
+    uint64_t *d; float *sink;
+    hipMalloc(&d, blocks * 8); hipMalloc(&sink, 4);
+    const int iters = 200;
+    hipFuncSetAttribute((const void *)k<NACC, MODE, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<NACC, MODE, R>), dim3(blocks), dim3(256), 65536, 0, iters, d, sink);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<NACC, MODE, R>), dim3(blocks), dim3(256), 65536, 0, iters, d, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h(blocks);
+    hipMemcpy(h.data(), d, blocks * 8, hipMemcpyDeviceToHost);
+    const double n = 64.0 * iters;
+    printf("%-46s blocks %3d: %.1f counter ticks / MFMA, %.1f ns / MFMA (wall), %.0f TFLOP/s\n", name, blocks, h[0] / n,
+           ms * 1e6 / n, blocks * 4 * n * 32768.0 / (ms * 1e-3) / 1e12);
+    hipFree(d); hipFree(sink);
+}
+
+int main()
+{
+    for (int blocks : {16, 256}) {
+        run<4, 0, 0>("4 independent accumulators, register operands", blocks);
+        run<2, 0, 0>("2 accumulators (dependent distance 2)", blocks);
+        run<1, 0, 0>("1 accumulator (fully dependent chain)", blocks);
+        run<4, 1, 4>("4 accumulators, A from LDS, ring depth 4", blocks);
+        run<4, 1, 8>("4 accumulators, A from LDS, ring depth 8", blocks);
+        run<1, 1, 8>("1 accumulator, A from LDS, ring depth 8", blocks);
+    }
+    for (int blocks : {36, 178}) {
+        run_step<0>("step loop: MFMAs + ring only", blocks);
+        run_step<8>("+ bias reads / bf16 packing", blocks);
+        run_step<1>("+ loader waves at a barrier (idle)", blocks);
+        run_step<3>("+ loader waves rewriting 64 KB of LDS per step", blocks);
+        run_step<4>("+ row-strided 8-byte stores (no loaders)", blocks);
+        run_step<12>("+ stores + packing (no loaders)", blocks);
+        run_step<15>("everything", blocks);
+    }
+    return 0;
+}

@@ -66,6 +66,7 @@ __device__ __forceinline__ tl_f32x16_t tl_mfma(uint4 a, uint4 b, tl_f32x16_t c)
 // (destination = M0 base + instruction offset + lane * 16; the offset also advances the global source).
 constexpr int kTLStepTiles = 4;
 constexpr int kTLStepBytes = kTLStepTiles * kTLTileBytes;
+constexpr int kTLStageRow = 136;   // bytes per token row of the output staging tile: 64 features + 8 bytes of padding
 
 template <int GROUPS = 4>   // 4 KB groups per wave: 4 with four waves per block, 2 with eight
 __device__ __forceinline__ void tl_issue_step(const char *step, uint32_t voff, uint32_t dst_lds)
@@ -99,26 +100,94 @@ __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b)
 // WAVES = 4: 128 tokens per block (the per-layer projections: <= 256 blocks, one per CU); WAVES = 8: 256 tokens per
 // block, two waves per SIMD sharing one weight stream (the value projection over all 44 646 tokens: 175 blocks in one
 // round instead of 349 in two, half the copy issues per wave, and the second wave's MFMAs cover the first's stores).
+// 16 named uint4 registers (a loader wave's 16 KB of a 64 KB step); named, because an array handed to a helper stays in
+// scratch memory under the asm memory clobbers
+#define SDETR_TL_DECL16(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7, P##8, P##9, P##10, P##11, P##12, P##13, P##14, P##15
+#define SDETR_TL_GLD(dst, base, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(base) : "memory")
+#define SDETR_TL_FETCH16(P, step)                                                                                  \
+    {                                                                                                              \
+        const uint4 *q0_ = src + (int64_t)(step) * (kTLStepBytes / 16), *q1_ = q0_ + 256, *q2_ = q0_ + 512, *q3_ = q0_ + 768; \
+        SDETR_TL_GLD(P##0, q0_, 0); SDETR_TL_GLD(P##1, q0_, 1024); SDETR_TL_GLD(P##2, q0_, 2048); SDETR_TL_GLD(P##3, q0_, 3072);   \
+        SDETR_TL_GLD(P##4, q1_, 0); SDETR_TL_GLD(P##5, q1_, 1024); SDETR_TL_GLD(P##6, q1_, 2048); SDETR_TL_GLD(P##7, q1_, 3072);   \
+        SDETR_TL_GLD(P##8, q2_, 0); SDETR_TL_GLD(P##9, q2_, 1024); SDETR_TL_GLD(P##10, q2_, 2048); SDETR_TL_GLD(P##11, q2_, 3072); \
+        SDETR_TL_GLD(P##12, q3_, 0); SDETR_TL_GLD(P##13, q3_, 1024); SDETR_TL_GLD(P##14, q3_, 2048); SDETR_TL_GLD(P##15, q3_, 3072); \
+    }
+#define SDETR_TL_ST(P, i) *reinterpret_cast<uint4 *>(d_ + (i) * 1024) = P##i
+#define SDETR_TL_STASH16(P, step)                                                                                  \
+    {                                                                                                              \
+        char *d_ = dst + ((step) & 1) * kTLStepBytes;                                                              \
+        SDETR_TL_ST(P, 0); SDETR_TL_ST(P, 1); SDETR_TL_ST(P, 2); SDETR_TL_ST(P, 3); SDETR_TL_ST(P, 4); SDETR_TL_ST(P, 5);       \
+        SDETR_TL_ST(P, 6); SDETR_TL_ST(P, 7); SDETR_TL_ST(P, 8); SDETR_TL_ST(P, 9); SDETR_TL_ST(P, 10); SDETR_TL_ST(P, 11);     \
+        SDETR_TL_ST(P, 12); SDETR_TL_ST(P, 13); SDETR_TL_ST(P, 14); SDETR_TL_ST(P, 15);                                         \
+    }
+
+// Block = WAVES compute waves (32 tokens each) + 4 LOADER waves.  WAVES = 4: 128 tokens per block; WAVES = 8: 256
+// tokens per block, two compute waves per SIMD sharing one weight stream (the value projection over all 44 646 tokens:
+// 175 blocks in one round instead of 349 in two).
+// The loaders bring the weights global -> registers -> LDS in steps of four tiles (64 KB, two LDS buffers), running two
+// steps ahead.  (When the compute waves issued the copies themselves -- LDS-DMA plus s_waitcnt vmcnt(0) at every step --
+// the wait also covered their own row-strided output STORES of the step before: ~1 us per tile against 0.22 us of MFMA
+// work, the same at 36 and at 178 blocks.)  The compute waves now never wait on memory inside the loop.
 template <int EPI, bool ADD2, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 1) token_linear_kernel(TLArgs p)
+__global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArgs p)
 {
-    constexpr int kThreads = 64 * WAVES, kWaveBytes = kTLStepBytes / WAVES;
+    constexpr int kThreads = 64 * WAVES;   // compute threads
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *wbuf = lds;                                                   // 2 step buffers
     float *bs = reinterpret_cast<float *>(lds + 2 * kTLStepBytes);      // [nsteps * 128]
     const int nsteps = (p.ntiles + kTLStepTiles - 1) / kTLStepTiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (wave >= WAVES) {
+        // ---- loader wave: a quarter (16 KB) of every 64 KB step.  Step s travels in register set s & 1 and is written
+        // into LDS buffer s & 1 while the compute waves work on step s - 1.  The packed buffer is padded to whole steps.
+        const int lw = wave - WAVES;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.pw) + lw * 1024 + lane;
+        char *dst = wbuf + lw * 16384 + lane * 16;
+        SDETR_TL_DECL16(ra);
+        SDETR_TL_DECL16(rb);
+        SDETR_TL_FETCH16(ra, 0);
+        SDETR_TL_FETCH16(rb, nsteps > 1 ? 1 : 0);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        SDETR_TL_STASH16(ra, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SDETR_TL_FETCH16(ra, nsteps > 2 ? 2 : 0);
+        __builtin_amdgcn_s_barrier();                       // step 0 is in LDS
+        for (int st = 0; st + 1 < nsteps; st += 2) {
+            // compute is on step st (even): step st+1 (set rb) goes into the other buffer, step st+3 is requested
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            SDETR_TL_STASH16(rb, st + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDETR_TL_FETCH16(rb, st + 3 < nsteps ? st + 3 : 0);
+            __builtin_amdgcn_s_barrier();                   // step st+1 is in LDS, everyone is done with step st
+            if (st + 2 >= nsteps) break;
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            SDETR_TL_STASH16(ra, st + 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SDETR_TL_FETCH16(ra, st + 4 < nsteps ? st + 4 : 0);
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the dummy requests of the tail)
+        return;
+    }
+
     const int t = lane & 31, h = lane >> 5;
     const int tok = blockIdx.x * (kTLTokWave * WAVES) + wave * kTLTokWave + t;
     const bool valid = tok < p.T;
     const int tk = valid ? tok : p.T - 1;
     const int img = tk / p.rows_per_batch, ri = tk - img * p.rows_per_batch;
 
-    const uint32_t wbuf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)wbuf;
-    const uint32_t voff = (uint32_t)(wave * kWaveBytes + lane * 16);
-    const uint32_t wave_lds = wbuf_lds + wave * kWaveBytes;
-    tl_issue_step<kWaveBytes / 4096>(p.pw, voff, wave_lds);
     for (int i = tid; i < nsteps * 128; i += kThreads) bs[i] = p.bias[i];
+    // staging tile of this wave for the coalesced output (rows padded by 8 bytes: conflict-free in both directions)
+    char *stage = reinterpret_cast<char *>(bs + nsteps * 128) + wave * (32 * kTLStageRow);
+    const int tok0 = blockIdx.x * (kTLTokWave * WAVES) + wave * kTLTokWave;
+    int rimg[4], rri[4];   // image / row-in-image of the four token rows this lane stores
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tr = min(tok0 + (lane >> 3) + 8 * i, p.T - 1);
+        rimg[i] = tr / p.rows_per_batch;
+        rri[i] = tr - rimg[i] * p.rows_per_batch;
+    }
 
     uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
     {
@@ -143,7 +212,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) token_linear_kernel(TLArgs p)
     float run_max = -INFINITY;
     const bool masked = EPI == kHeadMajor && p.pad && p.pad[tk];
 
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my activations and the staged bias
     __builtin_amdgcn_s_barrier();
 
     // A fragments come from LDS through an 8-deep ring of registers (requested 8 MFMAs before use, refilled right
@@ -151,76 +220,109 @@ __global__ void __launch_bounds__(64 * WAVES, 1) token_linear_kernel(TLArgs p)
     // and an MFMA waiting on the read issued just before it runs at a fifth of its rate.
     constexpr int R = 8;
     for (int st = 0; st < nsteps; ++st) {
-        if (st > 0) {   // step st has landed for me, then for everyone; every wave is done with step st-1
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        if (st + 1 < nsteps)   // ... whose buffer the copy of step st+1 overwrites while this step computes
-            tl_issue_step<kWaveBytes / 4096>(p.pw + (int64_t)(st + 1) * kTLStepBytes, voff, wave_lds + ((st + 1) & 1) * kTLStepBytes);
+        if (st > 0) __builtin_amdgcn_s_barrier();   // step st is in LDS; the loaders learn that step st-1 is done with
         const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + (st & 1) * kTLStepBytes + lane * 16;
+        // The four tiles of a step are walked k-step-major: MFMA 4 ks + j feeds tile j, so two MFMAs into the same
+        // accumulator are four issues apart.  (Tile-major, each tile was a chain of 16 dependent MFMAs and a dependent
+        // MFMA waits for the full latency of its predecessor, twice the issue interval: ~1 us per tile measured against
+        // 0.22 us of MFMA work.)  Fragment of consumption slot f: tile f & 3, k-step f >> 2.
+        auto frag = [](int f) { return ((f & 3) * 16 + (f >> 2)) * 1024; };
         uint4 ring[R];
 #pragma unroll
-        for (int f = 0; f < R; ++f) ring[f] = tl_lds_read16(cb + f * 1024);
+        for (int f = 0; f < R; ++f) ring[f] = tl_lds_read16(cb + frag(f));
+        tl_f32x16_t accs[kTLStepTiles];   // start as the bias: registers 4g..4g+3 are features 8g + 4h + {0..3} of the tile
 #pragma unroll
         for (int j = 0; j < kTLStepTiles; ++j) {
-            const int nt = st * kTLStepTiles + j;
-            const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)bs + nt * 128 + 16 * h;
-            tl_f32x16_t acc;   // starts as the bias: registers 4g..4g+3 are features 8g + 4h + {0..3} of the tile
+            const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)bs + (st * kTLStepTiles + j) * 128 + 16 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint4 bv = tl_lds_read16(bb + 32 * g);
-                acc[4 * g] = __uint_as_float(bv.x);
-                acc[4 * g + 1] = __uint_as_float(bv.y);
-                acc[4 * g + 2] = __uint_as_float(bv.z);
-                acc[4 * g + 3] = __uint_as_float(bv.w);
+                accs[j][4 * g] = __uint_as_float(bv.x);
+                accs[j][4 * g + 1] = __uint_as_float(bv.y);
+                accs[j][4 * g + 2] = __uint_as_float(bv.z);
+                accs[j][4 * g + 3] = __uint_as_float(bv.w);
             }
+        }
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int f = j * 16 + ks;
-                acc = tl_mfma(ring[f % R], xb[ks], acc);
-                if (f + R < kTLStepTiles * 16) ring[f % R] = tl_lds_read16(cb + (f + R) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (nt >= p.ntiles) continue;   // (padding tile of the last step: zero weights, nothing to emit)
-            if (EPI == kStore) {
-                if (valid) {
-                    bf16_t *o = p.out + (int64_t)tok * p.out_row_stride + nt * 32 + 4 * h;
-                    const int ngroups = p.group > 0 ? p.N / p.group : 0;
+        for (int f = 0; f < kTLStepTiles * 16; ++f) {
+            accs[f & 3] = tl_mfma(ring[f % R], xb[f >> 2], accs[f & 3]);
+            if (f + R < kTLStepTiles * 16) ring[f % R] = tl_lds_read16(cb + frag(f + R));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (EPI == kClassMax) {
+#pragma unroll
+            for (int j = 0; j < kTLStepTiles; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = (st * kTLStepTiles + j) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (n < p.N) run_max = fmaxf(run_max, accs[j][i]);
+                }
+        } else {
+            // Output through a per-wave LDS staging tile.  Straight from the accumulator layout a lane owns 4 features of
+            // one token: 8-byte stores that hit 32 different rows per instruction, ~110 cycles of issue each -- 16 of
+            // them per step cost as much as the step's 64 MFMAs (benchmarks/micro/mfma_rate.hip).  Two tiles at a time
+            // (64 features = 128 bytes per token) are written to LDS in accumulator order and read back row-major, so a
+            // lane stores 16 bytes and an instruction covers 8 tokens x 128 contiguous bytes.
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nt0 = st * kTLStepTiles + 2 * half;
+                if (nt0 >= p.ntiles) break;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const tl_f32x16_t acc = accs[2 * half + jj];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int n = nt * 32 + 8 * g + 4 * h;   // N and the group size are multiples of 4
-                        if (n >= p.N) continue;
-                        const uint2 v = make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]),
-                                                   pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
-                        if (p.group > 0) {
-                            const int gi = n / p.group, within = n - gi * p.group;
-                            *reinterpret_cast<uint2 *>(p.out + (((int64_t)img * ngroups + gi) * p.rows_per_batch + ri) * p.group +
+                        uint2 v;
+                        if (EPI == kHeadMajor)
+                            v = masked ? make_uint2(0u, 0u)
+                                : p.hm_f16 ? make_uint2(pack_f16x2(acc[4 * g], acc[4 * g + 1]), pack_f16x2(acc[4 * g + 2], acc[4 * g + 3]))
+                                           : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+                        else
+                            v = make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
+                        *reinterpret_cast<uint2 *>(stage + t * kTLStageRow + (jj * 32 + 8 * g + 4 * h) * 2) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-local: the staging tile is this wave's own)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 3) + 8 * i, piece = lane & 7;     // token row of the wave, 16-byte piece
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * kTLStageRow + piece * 16);
+                    const int tr = tok0 + row;
+                    if (tr >= p.T) continue;
+                    const int n0 = nt0 * 32 + piece * 8;                       // first of the piece's 8 features
+                    if (EPI == kHeadMajor) {
+                        const int nt = nt0 + (piece >> 2);
+                        if (nt >= p.ntiles) continue;
+                        const int grp = nt / p.heads, m = nt - grp * p.heads;
+                        const int64_t pix = (((int64_t)grp * p.batch + rimg[i]) * p.heads + m) * p.rows_per_batch + rri[i];
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + (piece & 3) * 8) = v;
+                    } else if (p.group > 0) {
+                        // feature-group-major [B][N/group][rows][group]: the group size is a multiple of 4
+                        const int ngroups = p.N / p.group;
+                        if ((p.group & 7) == 0 && n0 + 8 <= p.N) {   // the piece lies inside one group
+                            const int gi = n0 / p.group, within = n0 - gi * p.group;
+                            *reinterpret_cast<uint4 *>(p.out + (((int64_t)rimg[i] * ngroups + gi) * p.rows_per_batch + rri[i]) * p.group +
                                                        within) = v;
-                        } else {
-                            *reinterpret_cast<uint2 *>(o + 8 * g) = v;
+                            continue;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int n = n0 + 4 * q;
+                            if (n >= p.N) continue;
+                            const int gi = n / p.group, within = n - gi * p.group;
+                            *reinterpret_cast<uint2 *>(p.out + (((int64_t)rimg[i] * ngroups + gi) * p.rows_per_batch + rri[i]) * p.group +
+                                                       within) = q ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
+                        }
+                    } else {
+                        bf16_t *o = p.out + (int64_t)tr * p.out_row_stride + n0;
+                        if (n0 + 8 <= p.N && (p.out_row_stride & 7) == 0) *reinterpret_cast<uint4 *>(o) = v;
+                        else {
+                            if (n0 < p.N) *reinterpret_cast<uint2 *>(o) = make_uint2(v.x, v.y);
+                            if (n0 + 4 < p.N) *reinterpret_cast<uint2 *>(o + 4) = make_uint2(v.z, v.w);
                         }
                     }
                 }
-            } else if (EPI == kHeadMajor) {
-                if (valid) {
-                    const int grp = nt / p.heads, m = nt - grp * p.heads;
-                    const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + m) * p.rows_per_batch + ri;
-                    uint16_t *o = reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 4 * h;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint2 v = make_uint2(0u, 0u);
-                        if (!masked)
-                            v = p.hm_f16 ? make_uint2(pack_f16x2(acc[4 * g], acc[4 * g + 1]), pack_f16x2(acc[4 * g + 2], acc[4 * g + 3]))
-                                         : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
-                        *reinterpret_cast<uint2 *>(o + 8 * g) = v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int n = nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (n < p.N) run_max = fmaxf(run_max, acc[i]);
-                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pair overwrites the tile
             }
         }
     }
@@ -289,10 +391,7 @@ __global__ void __launch_bounds__(kBlock, 1) token_linear_ln_kernel(TLNArgs p)
 
     tl_f32x16_t acc[8];
     constexpr int R = 8;
-    const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + lane * 16;   // 128 consecutive fragments: tile nt, k-step ks = 16 nt + ks
-    uint4 ring[R];
-#pragma unroll
-    for (int f = 0; f < R; ++f) ring[f] = tl_lds_read16(cb + f * 1024);
+    const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + lane * 16;   // 128 consecutive fragments: (tile nt, k-step ks) at 16 nt + ks
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
         const tl_lds_cptr_t bb = (tl_lds_cptr_t)(const char *)par + nt * 128 + 16 * h;
@@ -304,65 +403,67 @@ __global__ void __launch_bounds__(kBlock, 1) token_linear_ln_kernel(TLNArgs p)
             acc[nt][4 * g + 2] = __uint_as_float(bv.z);
             acc[nt][4 * g + 3] = __uint_as_float(bv.w);
         }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int f = nt * 16 + ks;
-            acc[nt] = tl_mfma(ring[f % R], xb[ks], acc[nt]);
-            if (f + R < 128) ring[f % R] = tl_lds_read16(cb + (f + R) * 1024);
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
-
-    // + residual, LayerNorm over the 256 channels held by lanes (t, 0) and (t, 1), store
+    // the residual rows are requested before the MFMAs and arrive behind them
     const bf16_t *rr = p.res + (int64_t)img * p.res_batch_stride + (int64_t)ri * kTLK;
-    // all 32 residual pieces are requested before the first is used: issued one by one in front of their adds, each
-    // costs a full memory latency (measured 9.7k cycles for this loop, more than the 128 MFMAs)
     uint2 rbuf[32];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) rbuf[nt * 4 + g] = *reinterpret_cast<const uint2 *>(rr + 32 * nt + 8 * g + 4 * h);
-    __builtin_amdgcn_sched_barrier(0);
-    float sum = 0.f;
+    // k-step-major over the eight tiles: two MFMAs into the same accumulator are eight issues apart (tile-major they
+    // were chains of 16 dependent MFMAs, each waiting for the full latency of the one before)
+    auto frag = [](int f) { return ((f & 7) * 16 + (f >> 3)) * 1024; };
+    uint4 ring[R];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
+    for (int f = 0; f < R; ++f) ring[f] = tl_lds_read16(cb + frag(f));
+#pragma unroll
+    for (int f = 0; f < 128; ++f) {
+        acc[f & 7] = tl_mfma(ring[f % R], xb[f >> 3], acc[f & 7]);
+        if (f + R < 128) ring[f % R] = tl_lds_read16(cb + frag(f + R));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // + residual, LayerNorm over the 256 channels held by lanes (t, 0) and (t, 1), store.  The accumulators are only
+    // READ (writing elements of a 16-register tuple makes the allocator copy tuples; with 128 + 64 registers live that
+    // spills): pass 1 sums v = y + r and v^2, pass 2 recomputes v and writes (v - mean) * rstd * gamma + beta.
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const uint2 r = rbuf[nt * 4 + g];
-            acc[nt][4 * g] += bf16_lo(r.x);
-            acc[nt][4 * g + 1] += bf16_hi(r.x);
-            acc[nt][4 * g + 2] += bf16_lo(r.y);
-            acc[nt][4 * g + 3] += bf16_hi(r.y);
-            sum += (acc[nt][4 * g] + acc[nt][4 * g + 1]) + (acc[nt][4 * g + 2] + acc[nt][4 * g + 3]);
+            const float v0 = acc[nt][4 * g] + bf16_lo(r.x), v1 = acc[nt][4 * g + 1] + bf16_hi(r.x);
+            const float v2 = acc[nt][4 * g + 2] + bf16_lo(r.y), v3 = acc[nt][4 * g + 3] + bf16_hi(r.y);
+            sum += (v0 + v1) + (v2 + v3);
+            sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, sq))));
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.f / kTLK);
-    float sq = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float d = acc[nt][i] - mean;
-            sq += d * d;
-        }
     sq += __shfl_xor(sq, 32);
-    const float rstd = rsqrtf(sq * (1.f / kTLK) + p.eps);
+    const float mean = sum * (1.f / kTLK);
+    const float rstd = rsqrtf(fmaxf(sq * (1.f / kTLK) - mean * mean, 0.f) + p.eps);
+    const float shift = -mean * rstd;
     if (valid) {
         const int64_t orow = p.scatter_index ? (int64_t)img * p.out_batch_rows + p.scatter_index[tok] : (int64_t)tok;
         bf16_t *o = p.out + orow * kTLK;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
+        for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int e0 = 32 * nt + 8 * g + 4 * h;
                 const float4 gv = *reinterpret_cast<const float4 *>(par + kTLK + e0);
                 const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kTLK + e0);
-                const float y0 = (acc[nt][4 * g] - mean) * rstd * gv.x + be.x;
-                const float y1 = (acc[nt][4 * g + 1] - mean) * rstd * gv.y + be.y;
-                const float y2 = (acc[nt][4 * g + 2] - mean) * rstd * gv.z + be.z;
-                const float y3 = (acc[nt][4 * g + 3] - mean) * rstd * gv.w + be.w;
+                const uint2 r = rbuf[nt * 4 + g];
+                const float y0 = fmaf(fmaf(acc[nt][4 * g] + bf16_lo(r.x), rstd, shift), gv.x, be.x);
+                const float y1 = fmaf(fmaf(acc[nt][4 * g + 1] + bf16_hi(r.x), rstd, shift), gv.y, be.y);
+                const float y2 = fmaf(fmaf(acc[nt][4 * g + 2] + bf16_lo(r.y), rstd, shift), gv.z, be.z);
+                const float y3 = fmaf(fmaf(acc[nt][4 * g + 3] + bf16_hi(r.y), rstd, shift), gv.w, be.w);
                 *reinterpret_cast<uint2 *>(o + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
             }
+            __builtin_amdgcn_sched_barrier(0);   // one tile at a time: all 64 gamma / beta reads up front cost 256 registers
+        }
     }
 }
 
@@ -381,7 +482,7 @@ template <int EPI, bool ADD2, int WAVES>
 static int tl_launch_one(hipStream_t s, const TLArgs &a)
 {
     const int nsteps = (a.ntiles + kTLStepTiles - 1) / kTLStepTiles;
-    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
+    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512 + (size_t)WAVES * 32 * kTLStageRow;
     static bool attr_set = false;   // (one flag per instantiation)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_kernel<EPI, ADD2, WAVES>),
@@ -389,17 +490,16 @@ static int tl_launch_one(hipStream_t s, const TLArgs &a)
         attr_set = true;
     }
     const int tpb = kTLTokWave * WAVES;
-    hipLaunchKernelGGL((token_linear_kernel<EPI, ADD2, WAVES>), dim3((unsigned)((a.T + tpb - 1) / tpb)), dim3(64 * WAVES), lds,
+    hipLaunchKernelGGL((token_linear_kernel<EPI, ADD2, WAVES>), dim3((unsigned)((a.T + tpb - 1) / tpb)), dim3(64 * (WAVES + 4)), lds,
                        s, a);
     return check_launch("token_linear");
 }
 
 static int tl_launch(hipStream_t s, int epi, bool add2, TLArgs &a)
 {
-    const bool wide = a.T > 256 * kTLTokBlock;   // more 128-token blocks than CUs: two waves per SIMD instead
     if (epi == kStore && add2) return tl_launch_one<kStore, true, 4>(s, a);
-    if (epi == kStore) return wide ? tl_launch_one<kStore, false, 8>(s, a) : tl_launch_one<kStore, false, 4>(s, a);
-    if (epi == kHeadMajor) return wide ? tl_launch_one<kHeadMajor, false, 8>(s, a) : tl_launch_one<kHeadMajor, false, 4>(s, a);
+    if (epi == kStore) return tl_launch_one<kStore, false, 4>(s, a);
+    if (epi == kHeadMajor) return tl_launch_one<kHeadMajor, false, 4>(s, a);
     return tl_launch_one<kClassMax, false, 4>(s, a);
 }
 
@@ -412,7 +512,7 @@ static int tl_common(TLArgs &a, const void *x, const void *packed, const float *
     a = TLArgs{};
     a.x = (const bf16_t *)x; a.pw = (const char *)packed; a.bias = bias; a.T = tokens; a.N = out_features;
     a.ntiles = (out_features + 31) / 32; a.rows_per_batch = tokens > 0 ? tokens : 1;
-    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 1024 > 156 * 1024) return fail("token_linear: too many output features");
+    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 4 * 32 * kTLStageRow + 1024 > 160 * 1024) return fail("token_linear: too many output features");
     return 0;
 }
 
