@@ -66,7 +66,6 @@ __device__ __forceinline__ tl_f32x16_t tl_mfma(uint4 a, uint4 b, tl_f32x16_t c)
 // (destination = M0 base + instruction offset + lane * 16; the offset also advances the global source).
 constexpr int kTLStepTiles = 4;
 constexpr int kTLStepBytes = kTLStepTiles * kTLTileBytes;
-constexpr int kTLStageRow = 136;   // bytes per token row of the output staging tile: 64 features + 8 bytes of padding
 
 template <int GROUPS = 4>   // 4 KB groups per wave: 4 with four waves per block, 2 with eight
 __device__ __forceinline__ void tl_issue_step(const char *step, uint32_t voff, uint32_t dst_lds)
@@ -132,6 +131,13 @@ template <int EPI, bool ADD2, int WAVES>
 __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArgs p)
 {
     constexpr int kThreads = 64 * WAVES;   // compute threads
+    // two compute waves per SIMD hide each other's LDS latency and epilogue, and leave 168 registers per wave: a ring of
+    // 4 and a one-tile staging buffer (8 x 2.3 KB) there, 8 and two tiles (4 x 4.3 KB) with one wave per SIMD
+    constexpr int R = WAVES == 8 ? 4 : 8;
+    constexpr int kStgTiles = WAVES == 8 ? 1 : 2;
+    constexpr int kStgRow = kStgTiles * 64 + 8;          // bytes per token row of the staging tile (8 bytes of padding)
+    constexpr int kPieces = kStgTiles * 4;               // 16-byte pieces per row
+    constexpr int kRowsPerStore = 64 / kPieces, kStores = 32 / kRowsPerStore;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *wbuf = lds;                                                   // 2 step buffers
     float *bs = reinterpret_cast<float *>(lds + 2 * kTLStepBytes);      // [nsteps * 128]
@@ -179,12 +185,12 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
 
     for (int i = tid; i < nsteps * 128; i += kThreads) bs[i] = p.bias[i];
     // staging tile of this wave for the coalesced output (rows padded by 8 bytes: conflict-free in both directions)
-    char *stage = reinterpret_cast<char *>(bs + nsteps * 128) + wave * (32 * kTLStageRow);
+    char *stage = reinterpret_cast<char *>(bs + nsteps * 128) + wave * (32 * kStgRow);
     const int tok0 = blockIdx.x * (kTLTokWave * WAVES) + wave * kTLTokWave;
-    int rimg[4], rri[4];   // image / row-in-image of the four token rows this lane stores
+    int rimg[kStores], rri[kStores];   // image / row-in-image of the token rows this lane stores
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tr = min(tok0 + (lane >> 3) + 8 * i, p.T - 1);
+    for (int i = 0; i < kStores; ++i) {
+        const int tr = min(tok0 + lane / kPieces + kRowsPerStore * i, p.T - 1);
         rimg[i] = tr / p.rows_per_batch;
         rri[i] = tr - rimg[i] * p.rows_per_batch;
     }
@@ -215,10 +221,8 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my activations and the staged bias
     __builtin_amdgcn_s_barrier();
 
-    // A fragments come from LDS through an 8-deep ring of registers (requested 8 MFMAs before use, refilled right
-    // after the MFMA that consumed the slot): with one wave per SIMD nothing else hides the ~130-cycle LDS latency,
-    // and an MFMA waiting on the read issued just before it runs at a fifth of its rate.
-    constexpr int R = 8;
+    // A fragments come from LDS through a ring of R registers (requested R MFMAs before use, refilled right after the
+    // MFMA that consumed the slot): with one wave per SIMD nothing else hides the LDS latency.
     for (int st = 0; st < nsteps; ++st) {
         if (st > 0) __builtin_amdgcn_s_barrier();   // step st is in LDS; the loaders learn that step st-1 is done with
         const tl_lds_cptr_t cb = (tl_lds_cptr_t)wbuf + (st & 1) * kTLStepBytes + lane * 16;
@@ -260,16 +264,16 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
         } else {
             // Output through a per-wave LDS staging tile.  Straight from the accumulator layout a lane owns 4 features of
             // one token: 8-byte stores that hit 32 different rows per instruction, ~110 cycles of issue each -- 16 of
-            // them per step cost as much as the step's 64 MFMAs (benchmarks/micro/mfma_rate.hip).  Two tiles at a time
-            // (64 features = 128 bytes per token) are written to LDS in accumulator order and read back row-major, so a
-            // lane stores 16 bytes and an instruction covers 8 tokens x 128 contiguous bytes.
+            // them per step cost as much as the step's 64 MFMAs (benchmarks/micro/mfma_rate.hip).  One or two tiles at
+            // a time are written to LDS in accumulator order and read back row-major, so that a lane stores 16 bytes
+            // and an instruction covers whole 64- / 128-byte runs per token.
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int nt0 = st * kTLStepTiles + 2 * half;
+            for (int part = 0; part < kTLStepTiles / kStgTiles; ++part) {
+                const int nt0 = st * kTLStepTiles + kStgTiles * part;
                 if (nt0 >= p.ntiles) break;
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const tl_f32x16_t acc = accs[2 * half + jj];
+                for (int jj = 0; jj < kStgTiles; ++jj) {
+                    const tl_f32x16_t acc = accs[kStgTiles * part + jj];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         uint2 v;
@@ -279,14 +283,14 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
                                            : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
                         else
                             v = make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
-                        *reinterpret_cast<uint2 *>(stage + t * kTLStageRow + (jj * 32 + 8 * g + 4 * h) * 2) = v;
+                        *reinterpret_cast<uint2 *>(stage + t * kStgRow + (jj * 32 + 8 * g + 4 * h) * 2) = v;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-local: the staging tile is this wave's own)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = (lane >> 3) + 8 * i, piece = lane & 7;     // token row of the wave, 16-byte piece
-                    const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * kTLStageRow + piece * 16);
+                for (int i = 0; i < kStores; ++i) {
+                    const int row = lane / kPieces + kRowsPerStore * i, piece = lane % kPieces;   // token row, 16-byte piece
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * kStgRow + piece * 16);
                     const int tr = tok0 + row;
                     if (tr >= p.T) continue;
                     const int n0 = nt0 * 32 + piece * 8;                       // first of the piece's 8 features
@@ -322,7 +326,7 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
                         }
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pair overwrites the tile
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next part overwrites the tile
             }
         }
     }
@@ -482,7 +486,7 @@ template <int EPI, bool ADD2, int WAVES>
 static int tl_launch_one(hipStream_t s, const TLArgs &a)
 {
     const int nsteps = (a.ntiles + kTLStepTiles - 1) / kTLStepTiles;
-    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512 + (size_t)WAVES * 32 * kTLStageRow;
+    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512 + (size_t)WAVES * 32 * (WAVES == 8 ? 72 : 136);
     static bool attr_set = false;   // (one flag per instantiation)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_kernel<EPI, ADD2, WAVES>),
@@ -497,9 +501,10 @@ static int tl_launch_one(hipStream_t s, const TLArgs &a)
 
 static int tl_launch(hipStream_t s, int epi, bool add2, TLArgs &a)
 {
+    const bool wide = a.T > 256 * kTLTokBlock;   // more 128-token blocks than CUs: two compute waves per SIMD instead
     if (epi == kStore && add2) return tl_launch_one<kStore, true, 4>(s, a);
-    if (epi == kStore) return tl_launch_one<kStore, false, 4>(s, a);
-    if (epi == kHeadMajor) return tl_launch_one<kHeadMajor, false, 4>(s, a);
+    if (epi == kStore) return wide ? tl_launch_one<kStore, false, 8>(s, a) : tl_launch_one<kStore, false, 4>(s, a);
+    if (epi == kHeadMajor) return wide ? tl_launch_one<kHeadMajor, false, 8>(s, a) : tl_launch_one<kHeadMajor, false, 4>(s, a);
     return tl_launch_one<kClassMax, false, 4>(s, a);
 }
 
@@ -512,7 +517,7 @@ static int tl_common(TLArgs &a, const void *x, const void *packed, const float *
     a = TLArgs{};
     a.x = (const bf16_t *)x; a.pw = (const char *)packed; a.bias = bias; a.T = tokens; a.N = out_features;
     a.ntiles = (out_features + 31) / 32; a.rows_per_batch = tokens > 0 ? tokens : 1;
-    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 4 * 32 * kTLStageRow + 1024 > 160 * 1024) return fail("token_linear: too many output features");
+    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 8 * 32 * 72 + 1024 > 160 * 1024) return fail("token_linear: too many output features");
     return 0;
 }
 
