@@ -78,9 +78,11 @@ def algorithmic_bytes(B, Nv, Nq, M, D, L, P, value_bytes, proj_bytes, out_bytes,
 
 def train_main(args, model, device, rank, world, dist):
     """configs[2]: one training step of the hot-path modules per batch of 2 images per GPU -- fp32 forward
-    through the autograd path (HIP MSDA forward/backward op), a synthetic loss on `memory` and the salience
-    maps, backward, ONE flat all-reduce of the ~38 MB of gradients over RCCL, AdamW."""
+    through the autograd path (HIP MSDA forward/backward op), the salience criterion (row N4: targets + focal loss
+    on the salience maps, synthetic ground-truth boxes) plus a synthetic loss on `memory`, backward, ONE flat
+    all-reduce of the ~38 MB of gradients over RCCL, AdamW."""
     from salience_detr_amd.data_parallel import FlatGradAllReducer, broadcast_parameters
+    from salience_detr_amd.salience_criterion import SalienceCriterion
     sizes, canvas, level_shapes, _, (feats, masks, pos) = make_inputs(args.batch, args.height, args.width, device,
                                                                       seed=rank)
     model.train()
@@ -90,6 +92,13 @@ def train_main(args, model, device, rank, world, dist):
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
     reducer = FlatGradAllReducer(params) if dist is not None else None
     w = None
+    criterion = SalienceCriterion()
+    strides = [(canvas[0] / h, canvas[1] / w_) for h, w_ in level_shapes]
+    targets = []
+    for i in range(args.batch):   # 12 deterministic boxes per image over all four scale ranges
+        c = syn.det_rand(f"bench.box.c{i}", (12, 2), salt=rank) * 0.8 + 0.1
+        wh = 0.02 + syn.det_rand(f"bench.box.wh{i}", (12, 2), salt=rank) ** 2 * 0.9
+        targets.append({"boxes": torch.cat([c, wh], -1).to(device)})
 
     def step():
         nonlocal w
@@ -97,7 +106,7 @@ def train_main(args, model, device, rank, world, dist):
         memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
         if w is None:
             w = torch.randn_like(memory)
-        loss = (memory * w).mean() + sum((s.float() ** 2).mean() for s in score_maps)
+        loss = (memory * w).mean() + criterion(score_maps, targets, strides, sizes)["loss_salience"]
         loss.backward()
         if reducer is not None:
             reducer.all_reduce(average=True)
@@ -151,7 +160,7 @@ def train_main(args, model, device, rank, world, dist):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
         "config": {"workload": "salience_detr_resnet50_800_1333 training step of the hot path (filtering + 6-layer "
-                               "encoder fwd+bwd, synthetic loss, AdamW), batch=%d per MI355X" % args.batch,
+                               "encoder fwd+bwd, salience focal loss + synthetic memory loss, AdamW), batch=%d per MI355X" % args.batch,
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": "data parallel, one flat gradient all-reduce per step over RCCL"
                                   if world > 1 else "single GPU",

@@ -419,6 +419,31 @@ int sdetr_proposal_refine(sdetr_stream_t stream, const void *delta, int delta_dt
                           const int64_t *index, int64_t index_batch_stride, int batch_size, int spatial_size,
                           int num_select, float *out);
 
+/* ---- (12) salience supervision (row N4) -------------------------------------------------------------------------------
+ * models/detectors/salience_detr.py:13-116 (SalienceCriterion), models/bricks/losses.py:4-13 (sigmoid_focal_loss).
+ *   sdetr_salience_targets: mask_targets [batch, S] (S = sum of the levels' h*w, levels back to back): for every pixel
+ *     centre the scale-independent salience confidence of get_mask_single_level (:75-116).  boxes_xyxy [sum m, 4] fp32
+ *     ground-truth boxes in input-image pixels, image b owning rows box_offset[b] .. box_offset[b+1] (device int32
+ *     [batch+1]).  HOST arrays per level: level_shapes (h, w) int64, level_strides (stride_y, stride_x) fp32,
+ *     limit_range (lo, hi) fp32.  noise_scale != 0 mixes in `noise` [batch, S] (the reference's rand_like draws).
+ *   sdetr_salience_focal_loss: loss_and_num_pos[0] = sum_i focal(logits_i, target_i) / num_pos, [1] = num_pos =
+ *     max(#{target > positive_threshold}, 1) -- SalienceCriterion.forward's loss_salience (:48-58; the "/ S ... * S" of
+ *     the reference cancels).  Deterministic two-stage reduction through `workspace`
+ *     (sdetr_focal_loss_workspace_bytes).
+ *   sdetr_salience_focal_loss_backward: grad_logits = *grad_loss * d loss / d logits (the focal weight keeps its
+ *     gradient, as in the reference). */
+int sdetr_salience_targets(sdetr_stream_t stream, const float *boxes_xyxy, const int *box_offset, int batch_size,
+                           const int64_t *level_shapes_host, const float *level_strides_host,
+                           const float *limit_range_host, int num_levels, float noise_scale, const float *noise,
+                           float *target);
+int64_t sdetr_focal_loss_workspace_bytes(int64_t count);
+int sdetr_salience_focal_loss(sdetr_stream_t stream, const float *logits, const float *target, int64_t count, float alpha,
+                              float gamma, float positive_threshold, void *workspace, int64_t workspace_bytes,
+                              float *loss_and_num_pos);
+int sdetr_salience_focal_loss_backward(sdetr_stream_t stream, const float *logits, const float *target, int64_t count,
+                                       float alpha, float gamma, const float *loss_and_num_pos, const float *grad_loss,
+                                       float *grad_logits);
+
 #ifdef __cplusplus
 }
 #endif

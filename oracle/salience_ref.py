@@ -548,3 +548,66 @@ def transformer(sd: SD, feats, masks, pos, num_proposals: int, heads=8, points=4
                        hp["spatial_shapes"], hp["level_start_index"], hp["valid_ratios"], hp["mask_flatten"],
                        dec_layers, heads, points, core=core)
     return dict(outputs_classes=cls, outputs_coords=box, salience_score=hp["score_maps"], memory=memory, **ts)
+
+
+# ----------------------------------------------------------------------------- row N4: salience criterion
+def salience_targets(boxes_xyxy: Sequence[torch.Tensor], level_shapes, strides, limit_range, noise_scale: float = 0.0,
+                     noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """models/detectors/salience_detr.py:36-45, 61-116: per level and image the scale-independent salience confidence
+    of every pixel centre, [B, S].  ``boxes_xyxy``: per image [m,4] in input-image pixels; ``strides``: (sy, sx) per
+    level; ``noise`` [B,S] stands for the reference's ``torch.rand_like`` draws when ``noise_scale`` > 0."""
+    out = []
+    for lvl, ((h, w), (sy, sx)) in enumerate(zip(level_shapes, strides)):
+        cy = (torch.linspace(0.5, h - 0.5, h, dtype=torch.float32) * sy).view(h, 1).expand(h, w).reshape(-1)
+        cx = (torch.linspace(0.5, w - 0.5, w, dtype=torch.float32) * sx).view(1, w).expand(h, w).reshape(-1)
+        lo, hi = limit_range[lvl]
+        per_image = []
+        for gt in boxes_xyxy:
+            if gt.shape[0] == 0:
+                per_image.append(torch.zeros(h * w))
+                continue
+            l = cx[:, None] - gt[None, :, 0]
+            t = cy[:, None] - gt[None, :, 1]
+            r = gt[None, :, 2] - cx[:, None]
+            b = gt[None, :, 3] - cy[:, None]
+            d = torch.stack([l, t, r, b], -1)
+            dmin, dmax = d.min(-1)[0], d.max(-1)[0]
+            inside = dmin > 0
+            in_level = (dmax > lo) & (dmax <= hi)
+            dx = (l - r) / (l + r)
+            dy = (t - b) / (t + b)
+            conf = 1 - torch.sqrt(dx ** 2 + dy ** 2) / 2
+            conf = torch.where(inside, conf, torch.zeros_like(conf))
+            m = conf.max(-1)[0]
+            pos = (inside & in_level).any(-1)
+            per_image.append(torch.where(pos, m, torch.zeros_like(m)))
+        out.append(torch.stack(per_image))
+    target = torch.cat(out, 1)
+    if noise_scale:
+        target = (1 - noise_scale) * target + noise_scale * noise
+    return target
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: float = 2.0):
+    """models/bricks/losses.py:4-13 (the weight keeps its gradient)."""
+    prob = inputs.sigmoid()
+    weight = (1 - alpha) * prob ** gamma * (1 - targets) + targets * alpha * (1 - prob) ** gamma
+    loss = F.binary_cross_entropy_with_logits(inputs, targets.to(inputs.dtype), reduction="none") * weight
+    return (loss.sum(1) / max(loss.shape[1], 1)).sum() / num_boxes
+
+
+def salience_criterion(foreground_mask: Sequence[torch.Tensor], boxes_cxcywh: Sequence[torch.Tensor], strides, image_sizes,
+                       limit_range=((-1, 64), (64, 128), (128, 256), (256, 99999)), noise_scale: float = 0.0,
+                       alpha: float = 0.25, gamma: float = 2.0, noise: Optional[torch.Tensor] = None):
+    """SalienceCriterion.forward (salience_detr.py:27-59) -> (loss_salience, mask_targets [B,S])."""
+    xyxy = []
+    for bx, (ih, iw) in zip(boxes_cxcywh, image_sizes):
+        cx, cy, w, h = bx.unbind(-1)
+        xyxy.append(torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), -1)
+                    * torch.tensor([iw, ih, iw, ih], dtype=bx.dtype))
+    shapes = [tuple(m.shape[-2:]) for m in foreground_mask]
+    target = salience_targets(xyxy, shapes, strides, limit_range, noise_scale, noise)
+    logits = torch.cat([m.flatten(-2) for m in foreground_mask], -1).squeeze(1)
+    num_pos = (target > 0.5 * noise_scale).sum().clamp(min=1)
+    loss = sigmoid_focal_loss(logits, target, num_pos, alpha, gamma) * logits.shape[1]
+    return loss, target

@@ -31,6 +31,14 @@ def install():
         tv = _stub("torchvision", _is_tracing=lambda: False)
         ops = _stub("torchvision.ops", batched_nms=None)
         tv.ops = ops
+        # the one torchvision function the salience criterion calls (row N4): torchvision/ops/_box_convert.py,
+        # (cx, cy, w, h) -> (cx - w/2, cy - h/2, cx + w/2, cy + h/2).  A three-line coordinate conversion restated
+        # here because torchvision is absent; make_golden.py says so next to the fixture it affects.
+        def _box_cxcywh_to_xyxy(boxes):
+            import torch
+            cx, cy, w, h = boxes.unbind(-1)
+            return torch.stack((cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h), dim=-1)
+        ops.boxes = _stub("torchvision.ops.boxes", _box_cxcywh_to_xyxy=_box_cxcywh_to_xyxy)
         _stub("torchvision.models")
         _stub("torchvision.models.detection")
         _stub("torchvision.models.detection.image_list", ImageList=object)
