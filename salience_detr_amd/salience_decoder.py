@@ -58,10 +58,19 @@ class MLP(nn.Module):
             nn.init.constant_(layer.bias, 0.0)
 
     def forward(self, x):
+        fused = x.is_cuda and not torch.is_grad_enabled()
         for i, layer in enumerate(self.layers):
-            x = layer(x)
             if i + 1 < self.num_layers:
-                x = F.relu(x)
+                if fused:   # ReLU in the GEMM's epilogue (hipBLASLt) instead of a separate elementwise launch
+                    try:
+                        x = torch._addmm_activation(layer.bias, x.reshape(-1, x.shape[-1]), layer.weight.t(),
+                                                    use_gelu=False).view(*x.shape[:-1], layer.out_features)
+                        continue
+                    except (RuntimeError, AttributeError):
+                        fused = False
+                x = F.relu(layer(x))
+            else:
+                x = layer(x)
         return x
 
 
@@ -111,13 +120,31 @@ class SalienceTransformerDecoderLayer(nn.Module):
     def _self_attention(self, qk: Tensor, v: Tensor, attn_mask: Optional[Tensor]) -> Tensor:
         return self.self_attn(query=qk, key=qk, value=v, attn_mask=attn_mask, need_weights=False)[0]
 
+    def _self_attention_native(self, query: Tensor, query_pos: Tensor, attn_mask: Optional[Tensor]) -> Tensor:
+        """nn.MultiheadAttention(q = k = query + pos, v = query) on its parameters without the module's layout copies:
+        two projections (q|k from query + pos, v from query), the flash kernel on strided head views, out_proj."""
+        mha = self.self_attn
+        B, n, E = query.shape
+        H = mha.num_heads
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        qk = F.linear(query + query_pos, w[:2 * E], b[:2 * E]).view(B, n, 2, H, E // H)
+        v = F.linear(query, w[2 * E:], b[2 * E:]).view(B, n, H, E // H)
+        mask = attn_mask
+        if mask is not None and mask.dtype == torch.bool:
+            mask = torch.zeros_like(mask, dtype=query.dtype).masked_fill_(mask, float("-inf"))   # True = not allowed
+        o = F.scaled_dot_product_attention(qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2), v.transpose(1, 2),
+                                           attn_mask=mask)
+        return F.linear(o.transpose(1, 2).reshape(B, n, E), mha.out_proj.weight, mha.out_proj.bias)
+
     def forward(self, query, query_pos, reference_points, value, spatial_shapes, level_start_index,
                 self_attn_mask=None, key_padding_mask=None, value_hm=None):
         """Reference signature (salience_transformer.py:553-563) plus the optional pre-projected head-major
         ``value_hm`` [B,M,Nv,D] the decoder's batched value projection supplies on the no-grad path."""
         native = query.is_cuda and not _needs_grad(self, query, value, reference_points)
-        qk = self.with_pos_embed(query, query_pos)
-        query2 = self._self_attention(qk, query, self_attn_mask)
+        if native and query_pos is not None:
+            query2 = self._self_attention_native(query, query_pos, self_attn_mask)
+        else:
+            query2 = self._self_attention(self.with_pos_embed(query, query_pos), query, self_attn_mask)
         if not native:
             query = self.norm2(query + self.dropout2(query2))
             query2 = self.cross_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
