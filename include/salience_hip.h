@@ -379,6 +379,17 @@ int sdetr_topk_attention_heads_bf16(sdetr_stream_t stream, const void *query, in
                                     int num_select, int embed_dim, int num_heads, const void *packed_in_proj,
                                     const float *in_proj_bias, void *out);
 
+/* ---- (9b) dense self-attention after the in-projection ---------------------------------------------------------------
+ * out[b, i, 32 h + :] = softmax(Q_h K_h^T * scale) V_h for 32-channel heads, bf16, no mask: nn.MultiheadAttention's
+ * attention proper for the encoder layer's selected queries (models/bricks/salience_transformer.py:371-376) and the
+ * decoder layer's object queries (:565-570).  Element [b][i][32 h + d] of q / k / v lies at base + b * batch_stride +
+ * i * row_stride + 32 h + d (so the three may be column slices of one in-projection output); out is
+ * [batch, num_tokens, num_heads * 32] contiguous.  num_tokens <= 1152. */
+int sdetr_attention_heads_bf16(sdetr_stream_t stream, const void *q, int64_t q_batch_stride, int64_t q_row_stride,
+                               const void *k, int64_t k_batch_stride, int64_t k_row_stride, const void *v,
+                               int64_t v_batch_stride, int64_t v_row_stride, int batch_size, int num_tokens,
+                               int num_heads, int head_dim, float scale, void *out);
+
 /* ---- (10) decoder box-refinement loop, elementwise stages (row N2) -----------------------------------------------
  * models/bricks/salience_transformer.py:641-671.
  *   sdetr_decoder_query_sine_embed: reference_points [batch, num_queries, 4] (cx, cy, w, h) and valid_ratios

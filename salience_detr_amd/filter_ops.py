@@ -1,5 +1,6 @@
 """Host wrappers of the filtering / row-movement kernels (C ABI sections (4) and (5) of
 include/salience_hip.h).  PyTorch only owns the memory and the stream."""
+import math
 from typing import Optional
 
 import torch
@@ -673,6 +674,27 @@ def proposal_refine(delta: Tensor, proposal_logit: Tensor, index: Tensor) -> Ten
                                                 index.data_ptr(), index.stride(0) if B > 1 else n, B, lg.shape[1], n,
                                                 out.data_ptr())
     _hip.check(code, "proposal_refine")
+    return out
+
+
+def attention_heads_applies(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> bool:
+    return (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.dim() == 3 and q.shape == k.shape == v.shape
+            and q.shape[-1] == 32 * num_heads and 0 < q.shape[1] <= 1152
+            and all(t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 for t in (q, k, v)))
+
+
+def attention_heads(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """``softmax(Q_h K_h^T / sqrt(32)) V_h`` per head, heads concatenated: q, k, v ``[B,n,32*heads]`` bf16 (column slices
+    of a wider projection output are fine) -> ``[B,n,32*heads]`` (the input of ``out_proj``).  No mask, n <= 1152."""
+    if not attention_heads_applies(q, k, v, num_heads):
+        raise RuntimeError("attention_heads: bf16 HIP tensors [B,n,32*heads] with n <= 1152 expected; no CPU fallback")
+    B, n, E = q.shape
+    out = torch.empty((B, n, E), dtype=torch.bfloat16, device=q.device)
+    with torch.cuda.device(q.device):
+        code = _hip.lib().sdetr_attention_heads_bf16(
+            _hip.stream_ptr(), q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(),
+            v.stride(0), v.stride(1), B, n, num_heads, 32, 1.0 / math.sqrt(32.0), out.data_ptr())
+    _hip.check(code, "attention_heads")
     return out
 
 

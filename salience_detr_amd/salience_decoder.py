@@ -22,7 +22,7 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
-from .filter_ops import box_refine, decoder_query_sine_embed, fused_ffn, fused_ffn_applies, fused_layer_norm
+from .filter_ops import attention_heads, attention_heads_applies, box_refine, decoder_query_sine_embed, fused_ffn, fused_ffn_applies, fused_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
 
@@ -127,8 +127,13 @@ class SalienceTransformerDecoderLayer(nn.Module):
         B, n, E = query.shape
         H = mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
-        qk = F.linear(query + query_pos, w[:2 * E], b[:2 * E]).view(B, n, 2, H, E // H)
-        v = F.linear(query, w[2 * E:], b[2 * E:]).view(B, n, H, E // H)
+        qk2 = F.linear(query + query_pos, w[:2 * E], b[:2 * E])
+        v2 = F.linear(query, w[2 * E:], b[2 * E:])
+        if attn_mask is None and attention_heads_applies(qk2[..., :E], qk2[..., E:], v2, H):
+            # own flash kernel on the strided projection slices; the heads come out concatenated
+            return F.linear(attention_heads(qk2[..., :E], qk2[..., E:], v2, H), mha.out_proj.weight, mha.out_proj.bias)
+        qk = qk2.view(B, n, 2, H, E // H)
+        v = v2.view(B, n, H, E // H)
         mask = attn_mask
         if mask is not None and mask.dtype == torch.bool:
             mask = torch.zeros_like(mask, dtype=query.dtype).masked_fill_(mask, float("-inf"))   # True = not allowed

@@ -25,9 +25,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import (advance_rows, class_head_max_times, class_max_times, encoder_finalize,
-                         encoder_reference_points, fused_ffn,
-                         fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
+from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, class_head_max_times,
+                         class_max_times, encoder_finalize, encoder_reference_points, fused_ffn, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
                          topk_attention_heads, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
@@ -121,6 +120,12 @@ class SalienceTransformerEncoderLayer(nn.Module):
         vv = proj[:, N:, 2 * E:].view(B, N, H, hd).transpose(1, 2)
         drop = mha.dropout if self.training else 0.0
         o = None
+        if not (torch.is_grad_enabled() and needs_grad) and drop == 0.0:
+            pq, pk, pv = proj[:, :N, :E], proj[:, :N, E:2 * E], proj[:, N:, 2 * E:]
+            if attention_heads_applies(pq, pk, pv, H):
+                # own flash kernel on the strided slices of the projection: heads come out concatenated, no layout copy
+                o = attention_heads(pq, pk, pv, H)
+                return o if not apply_out_proj else F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
         if not (torch.is_grad_enabled() and needs_grad):
             try:
                 o = F.scaled_dot_product_attention(q, k, vv, dropout_p=drop)

@@ -557,3 +557,25 @@ def test_layer_norm_in_place_row_update():
         want[b, idx[b]] = torch.nn.functional.layer_norm(buf[b, idx[b]] + r[b], (C,), norm.weight, norm.bias, norm.eps)
     out = F.fused_layer_norm(buf, norm, residual=r, scatter_index=idx, scatter_into=buf, gather_x=True)
     assert out is buf and (buf - want).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 31), (2, 300), (2, 320), (2, 900), (1, 1100), (3, 1152)])
+def test_attention_heads_matches_fp32_attention(B, N):
+    """Dense self-attention kernel (32-channel heads, strided q / k / v slices of one projection output) against the same
+    attention in fp32 on the bf16-rounded inputs; the framework's bf16 flash kernel sets the error scale."""
+    torch.manual_seed(N)
+    H = 8
+    qkv = (torch.randn(B, N, 3 * 32 * H) * 1.5).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv[..., :256], qkv[..., 256:512], qkv[..., 512:]
+    assert F.attention_heads_applies(q, k, v, H)
+    got = F.attention_heads(q, k, v, H).float().cpu()
+    split = lambda t: t.float().cpu().view(B, N, H, 32).transpose(1, 2)
+    ref = torch.nn.functional.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(B, N, 256)
+    lib = torch.nn.functional.scaled_dot_product_attention(
+        q.view(B, N, H, 32).transpose(1, 2), k.view(B, N, H, 32).transpose(1, 2), v.view(B, N, H, 32).transpose(1, 2)
+    ).transpose(1, 2).reshape(B, N, 256).float().cpu()
+    err, base = (got - ref).abs().max().item(), (lib - ref).abs().max().item()
+    assert err <= max(2.0 * base, 0.03), (err, base)
+    assert (got - ref).abs().mean().item() <= 4e-3
+    with pytest.raises(RuntimeError):
+        F.attention_heads(q.float(), k.float(), v.float(), H)
