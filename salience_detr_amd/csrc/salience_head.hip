@@ -183,10 +183,13 @@ enum { kParBEnc = 0, kParGEnc, kParBetaEnc, kParG1, kParBeta1, kParB1, kParRows 
 // the two GEMMs except what the block overlaps itself: every global read of those phases (LayerNorm parameters,
 // biases, the coarse score for the resize, alpha) is issued up front into LDS together with the token tile, and
 // each GEMM's first weight steps are requested before the barrier / LayerNorm phase in front of it.
-template <int RT>
-__global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_kernel(Stage1Args p)
+// WAVES = 8 (512 threads, one column tile per wave) halves a block's latency -- two chained 256 x 256 fp32 GEMMs of
+// 64-cycle MFMAs, ~7 us each with four waves -- for the coarse levels, whose few blocks leave the chip idle anyway.
+template <int RT, int WAVES = 4>
+__global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : (RT == 2 ? 2 : 4)) salience_head_stage1_kernel(Stage1Args p)
 {
-    constexpr int TM = 32 * RT;
+    constexpr int TM = 32 * RT, THREADS = 64 * WAVES, CT = 8 / WAVES;   // CT column tiles of 32 per wave
+    static_assert(TM * 64 % THREADS == 0 && THREADS % TM == 0, "tile / block shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tile = smem;                           // [TM][kXS]
     float *par = smem + TM * kXS;                 // [kParRows][kC]
@@ -195,23 +198,24 @@ __global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_
     const int b = blockIdx.y, blk = blockIdx.x;
     const int t0 = blk * TM;
     const int nvalid = min(TM, p.n - t0);
-    const int n0 = wave * 64;
+    const int n0 = wave * (32 * CT);
     const bool with_enc = p.w_enc != nullptr;
 
-    WeightStream<2, 4> ws;
+    WeightStream<CT, 4> ws;
     ws.start(with_enc ? p.w_enc : p.w1, kC, kC / 8, n0, lane);
 
     // ---- token tile, parameters and row factors -> LDS ----
     {
         const float *xb = p.x + (int64_t)b * p.x_batch_stride + (int64_t)t0 * p.x_row_stride;
-        float4 v[TM / 4];
+        constexpr int NL = TM * 64 / THREADS;   // float4 per thread
+        float4 v[NL];
 #pragma unroll
-        for (int i = 0; i < TM / 4; ++i) {   // unconditional (clamped) loads: all in flight at once
-            const int idx = tid + i * kBlock;
+        for (int i = 0; i < NL; ++i) {   // unconditional (clamped) loads: all in flight at once
+            const int idx = tid + i * THREADS;
             const int r = idx >> 6, c4 = idx & 63;
             v[i] = *reinterpret_cast<const float4 *>(xb + (int64_t)min(r, nvalid - 1) * p.x_row_stride + c4 * 4);
         }
-        {
+        if (tid < 256) {
             const int row = tid >> 6, c4 = tid & 63;   // 4 parameter rows per pass
             const float *src0 = row == 0 ? p.b_enc : row == 1 ? p.g_enc : row == 2 ? p.beta_enc : p.g1;
             const float *src1 = row == 0 ? p.beta1 : p.b1;
@@ -244,22 +248,22 @@ __global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_
             if (tid == 0) srow[TM] = (p.row_scale || p.coarse) ? (p.alpha ? *p.alpha : 1.f) : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < TM / 4; ++i) {
-            const int idx = tid + i * kBlock;
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * THREADS;
             const int r = idx >> 6, c4 = idx & 63;
             *reinterpret_cast<float4 *>(tile + r * kXS + c4 * 4) = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
 
-    f32x16 acc[RT][2];
+    f32x16 acc[RT][CT];
     if (with_enc) {
         zero_acc(acc);
-        block_gemm<kC, kXS, RT, 2, 4>(tile, ws, lane, acc);
+        block_gemm<kC, kXS, RT, CT, 4>(tile, ws, lane, acc);
         ws.start(p.w1, kC, kC / 8, n0, lane);   // layer1's first steps travel during the LayerNorm phase
         __syncthreads();   // every wave is done reading the input tile
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             const int c = n0 + 32 * ct + (lane & 31);
             const float bias = par[kParBEnc * kC + c];
 #pragma unroll
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_
 
     // ---- enc_output_norm -> modulation -> layer1 LayerNorm, in place; TPR threads per row, each NV float4 ----
     {
-        constexpr int TPR = kBlock / TM, NV = kC / 4 / TPR, CS = 4 * TPR;   // column step between a thread's float4s
+        constexpr int TPR = THREADS / TM, NV = kC / 4 / TPR, CS = 4 * TPR;   // column step between a thread's float4s
         const int r = tid / TPR, q = tid % TPR;
         float *row = tile + r * kXS + 4 * q;
         float4 v[NV];
@@ -309,11 +313,11 @@ __global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_
 
     // ---- layer1 Linear + GELU ----
     zero_acc(acc);
-    block_gemm<kC, kXS, RT, 2, 4>(tile, ws, lane, acc);
-    if (wave < 2) {
+    block_gemm<kC, kXS, RT, CT, 4>(tile, ws, lane, acc);
+    if (n0 < kHalf) {
         float *zl = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             const int c = n0 + 32 * ct + (lane & 31);
             const float bias = par[kParB1 * kC + c];
 #pragma unroll
@@ -326,7 +330,7 @@ __global__ void __launch_bounds__(kBlock, RT == 2 ? 2 : 4) salience_head_stage1_
         }
     } else {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             const int c = n0 + 32 * ct + (lane & 31);
             const float bias = par[kParB1 * kC + c];
             float s = 0.f;
@@ -558,16 +562,21 @@ extern "C" int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x,
     if (stage1_block_tokens(batch_size, tokens) == 64) {
         static bool attr_set = false;   // > 64 KiB of dynamic LDS has to be requested once
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(salience_head_stage1_kernel<2>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(salience_head_stage1_kernel<2, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, stage1_lds_bytes(64));
             attr_set = true;
         }
         a.nblk = (tokens + 63) / 64;
-        hipLaunchKernelGGL(salience_head_stage1_kernel<2>, dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
+        hipLaunchKernelGGL((salience_head_stage1_kernel<2, 4>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
                            (size_t)stage1_lds_bytes(64), s, a);
+    } else if ((int64_t)batch_size * ((tokens + 31) / 32) <= 512) {
+        // coarse levels: eight waves per block (every block still gets a CU slot of its own)
+        a.nblk = (tokens + 31) / 32;
+        hipLaunchKernelGGL((salience_head_stage1_kernel<1, 8>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(512),
+                           (size_t)stage1_lds_bytes(32), s, a);
     } else {
         a.nblk = (tokens + 31) / 32;
-        hipLaunchKernelGGL(salience_head_stage1_kernel<1>, dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
+        hipLaunchKernelGGL((salience_head_stage1_kernel<1, 4>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
                            (size_t)stage1_lds_bytes(32), s, a);
     }
     return check_launch("salience_head_stage1");
