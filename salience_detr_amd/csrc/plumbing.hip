@@ -160,9 +160,80 @@ __global__ void __launch_bounds__(256) reference_points_kernel(const float *vr, 
     }
 }
 
+// Entry of the encoder's sorted-order loop (salience_transformer.py:453-461 gathers + :418-432 reference points) in one
+// launch: for the tokens index[b][i] copy their query and position rows, gather their foreground score and evaluate
+// their reference points -- four launches of 5-7 us before.  One wave per row pair: 32 lanes x 16 bytes = a 512-byte row.
+struct PrepareArgs {
+    const uint4 *tokens, *pos;       // [B, S, vec_per_row]
+    const float *score;              // [B, S] or NULL
+    const int64_t *index;            // [B, n], images index_batch_stride apart
+    int64_t index_batch_stride;
+    const float *vr;                 // [B, L, 2]
+    const int64_t *shapes, *lsi;
+    int B, S, n, L, vec_per_row;
+    uint4 *q_out, *pos_out;          // [B, n, vec_per_row]
+    float *score_out;                // [B, n] or NULL
+    float *ref_out;                  // [B, n, L, 2]
+};
+
+__global__ void __launch_bounds__(256) encoder_prepare_kernel(PrepareArgs p)
+{
+    const int64_t total = (int64_t)p.B * p.n;
+    const int per_block = 256 / p.vec_per_row;                      // rows per block pass (vec_per_row divides 256)
+    const int sub = threadIdx.x / p.vec_per_row, c = threadIdx.x - sub * p.vec_per_row;
+    for (int64_t r = (int64_t)blockIdx.x * per_block + sub; r < total; r += (int64_t)gridDim.x * per_block) {
+        const int b = (int)(r / p.n), i = (int)(r - (int64_t)b * p.n);
+        const int64_t tok = p.index[(int64_t)b * p.index_batch_stride + i];
+        const int64_t src = ((int64_t)b * p.S + tok) * p.vec_per_row + c;
+        p.q_out[r * p.vec_per_row + c] = p.tokens[src];
+        p.pos_out[r * p.vec_per_row + c] = p.pos[src];
+        if (c == 0) {
+            if (p.score_out) p.score_out[r] = p.score[(int64_t)b * p.S + tok];
+            int l = 0;
+            for (int j = 1; j < p.L; ++j) l = tok >= p.lsi[j] ? j : l;
+            const int W = (int)p.shapes[2 * l + 1], H = (int)p.shapes[2 * l];
+            const int t = (int)(tok - p.lsi[l]);
+            const int y = t / W, x = t - y * W;
+            const float *v = p.vr + (int64_t)b * p.L * 2;
+            const float cx = ((float)x + 0.5f) / (v[2 * l] * (float)W), cy = ((float)y + 0.5f) / (v[2 * l + 1] * (float)H);
+            float *o = p.ref_out + r * p.L * 2;
+            for (int j = 0; j < p.L; ++j) {
+                o[2 * j] = cx * v[2 * j];
+                o[2 * j + 1] = cy * v[2 * j + 1];
+            }
+        }
+    }
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
+
+extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes,
+                                            const float *score, const int64_t *index, int64_t index_batch_stride,
+                                            int batch_size, int spatial_size, int rows, const float *valid_ratios,
+                                            const int64_t *shapes, const int64_t *level_start_index, int num_levels,
+                                            void *query_out, void *pos_out, float *score_out, float *reference_points_out)
+{
+    if (batch_size < 0 || spatial_size < 0 || rows < 0 || num_levels <= 0 || num_levels > kMaxLevels)
+        return fail("encoder_prepare: bad sizes");
+    if (row_bytes <= 0 || (row_bytes & 15) || 256 % (row_bytes / 16)) return fail("encoder_prepare: row_bytes must be 16 * a divisor of 256");
+    if ((int64_t)batch_size * rows == 0) return 0;
+    if (!tokens || !pos || !index || !valid_ratios || !shapes || !level_start_index || !query_out || !pos_out || !reference_points_out)
+        return fail("encoder_prepare: null pointer");
+    if (score_out && !score) return fail("encoder_prepare: score_out without score");
+    if (index_batch_stride < rows) return fail("encoder_prepare: index batch stride too small");
+    PrepareArgs a{};
+    a.tokens = (const uint4 *)tokens; a.pos = (const uint4 *)pos; a.score = score; a.index = index;
+    a.index_batch_stride = index_batch_stride; a.vr = valid_ratios; a.shapes = shapes; a.lsi = level_start_index;
+    a.B = batch_size; a.S = spatial_size; a.n = rows; a.L = num_levels; a.vec_per_row = row_bytes / 16;
+    a.q_out = (uint4 *)query_out; a.pos_out = (uint4 *)pos_out; a.score_out = score_out; a.ref_out = reference_points_out;
+    const int per_block = 256 / a.vec_per_row;
+    int64_t blocks = ((int64_t)batch_size * rows + per_block - 1) / per_block;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(encoder_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("encoder_prepare");
+}
 
 extern "C" int sdetr_masked_fill_min(sdetr_stream_t stream, const float *score, const uint8_t *mask, const float *mins,
                                      int num_mins, int64_t total, float *out)

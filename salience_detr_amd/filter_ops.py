@@ -738,6 +738,40 @@ def box_refine(delta: Tensor, reference_points: Tensor, eps: float = 1e-3) -> Te
     return out
 
 
+def encoder_prepare_sorted(tokens: Tensor, pos: Tensor, score: Optional[Tensor], sorted_index: Tensor, valid_ratios: Tensor,
+                           spatial_shapes: Tensor, level_start_index: Tensor):
+    """Entry of the sorted-order encoder loop in one launch: ``(tokens[b, idx], pos[b, idx], score[b, idx],
+    reference points of idx)`` for ``idx = sorted_index`` ``[B,n]`` -- the two row gathers of
+    salience_transformer.py:454-461, the score gather and ``get_reference_points`` (:418-432) restricted to them."""
+    _hip.require_device("encoder_prepare_sorted", tokens=tokens, pos=pos, score=score, valid_ratios=valid_ratios)
+    if not sorted_index.is_cuda:
+        raise RuntimeError("encoder_prepare_sorted: sorted_index must be a HIP (cuda) tensor; no CPU fallback")
+    B, S, C = tokens.shape
+    row_bytes = C * tokens.element_size()
+    if (pos.shape != tokens.shape or pos.dtype != tokens.dtype or not tokens.is_contiguous() or not pos.is_contiguous()
+            or sorted_index.dtype != torch.int64 or sorted_index.dim() != 2 or sorted_index.stride(1) != 1
+            or row_bytes % 16 or 256 % (row_bytes // 16)):
+        raise RuntimeError("encoder_prepare_sorted: contiguous [B,S,C] tokens / pos of one dtype and an int64 [B,n] index expected")
+    n = sorted_index.shape[1]
+    L = valid_ratios.shape[1]
+    vr = valid_ratios.float().contiguous()
+    q = torch.empty((B, n, C), dtype=tokens.dtype, device=tokens.device)
+    ps = torch.empty_like(q)
+    fg = None
+    if score is not None:
+        if score.dtype != torch.float32 or tuple(score.shape) != (B, S) or not score.is_contiguous():
+            raise RuntimeError("encoder_prepare_sorted: fp32 contiguous [B,S] score expected")
+        fg = torch.empty((B, n), dtype=torch.float32, device=tokens.device)
+    ref = torch.empty((B, n, L, 2), dtype=torch.float32, device=tokens.device)
+    with torch.cuda.device(tokens.device):
+        code = _hip.lib().sdetr_encoder_prepare_sorted(
+            _hip.stream_ptr(), tokens.data_ptr(), pos.data_ptr(), row_bytes, _hip.ptr(score), sorted_index.data_ptr(),
+            sorted_index.stride(0) if B > 1 else n, B, S, n, vr.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), L, q.data_ptr(), ps.data_ptr(), _hip.ptr(fg), ref.data_ptr())
+    _hip.check(code, "encoder_prepare_sorted")
+    return q, ps, fg, ref
+
+
 def token_linear_ln(x: Tensor, linear, norm, residual: Tensor, scatter_index: Optional[Tensor] = None,
                     scatter_into: Optional[Tensor] = None) -> Tensor:
     """``norm(residual + linear(x))`` for a 256 -> 256 bf16 Linear in one launch (include/salience_hip.h (8));

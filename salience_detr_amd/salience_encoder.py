@@ -26,7 +26,8 @@ from torch.nn import functional as F
 
 from . import pyramid
 from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, class_head_max_times,
-                         class_max_times, encoder_finalize, encoder_reference_points, fused_ffn, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
+                         class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
+                         fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
                          topk_attention_heads, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
@@ -331,12 +332,20 @@ class SalienceTransformerEncoder(nn.Module):
             # in sorted order across the layers -- one gather in, one pass back to token space at the end
             sorted_index = foreground_inds[0]
             n0 = counts[0]
-            q = gather_rows(value, sorted_index)
-            pos_s = gather_rows(ori_pos, sorted_index)
-            # reference points of the selected tokens only, straight from their indices
-            ref_s = encoder_reference_points(valid_ratios.float().contiguous(), spatial_shapes, level_start_index, n0,
-                                             index=sorted_index)
-            fg_s = torch.gather(foreground_score, 1, sorted_index)
+            if (value.is_contiguous() and ori_pos.is_contiguous() and ori_pos.dtype == value.dtype
+                    and foreground_score.dtype == torch.float32 and foreground_score.is_contiguous()
+                    and 256 % max(1, value.shape[-1] * value.element_size() // 16) == 0
+                    and (value.shape[-1] * value.element_size()) % 16 == 0):
+                # query / position rows, foreground scores and reference points of the selected tokens: one launch
+                q, pos_s, fg_s, ref_s = encoder_prepare_sorted(value, ori_pos, foreground_score, sorted_index, valid_ratios,
+                                                               spatial_shapes, level_start_index)
+            else:
+                q = gather_rows(value, sorted_index)
+                pos_s = gather_rows(ori_pos, sorted_index)
+                # reference points of the selected tokens only, straight from their indices
+                ref_s = encoder_reference_points(valid_ratios.float().contiguous(), spatial_shapes, level_start_index, n0,
+                                                 index=sorted_index)
+                fg_s = torch.gather(foreground_score, 1, sorted_index)
             result = torch.empty_like(q)
             for layer_id, layer in enumerate(self.layers):
                 if self.layer_marker is not None:

@@ -579,3 +579,27 @@ def test_attention_heads_matches_fp32_attention(B, N):
     assert (got - ref).abs().mean().item() <= 4e-3
     with pytest.raises(RuntimeError):
         F.attention_heads(q.float(), k.float(), v.float(), H)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_encoder_prepare_sorted_equals_its_four_parts(dtype):
+    """One launch = gather_rows(tokens), gather_rows(pos), score.gather, encoder_reference_points(index) -- bit for bit."""
+    B, C = 2, 256
+    shapes = [(13, 17), (7, 9), (4, 5), (2, 3)]
+    t_shapes = torch.tensor(shapes, dtype=torch.int64)
+    sizes = t_shapes.prod(1)
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    S = int(sizes.sum())
+    g = torch.Generator().manual_seed(5)
+    tokens = torch.randn(B, S, C, generator=g).to(dtype).to(DEV)
+    pos = torch.randn(B, S, C, generator=g).to(dtype).to(DEV)
+    score = torch.randn(B, S, generator=g).to(DEV)
+    n = 200
+    wide = torch.stack([torch.randperm(S, generator=g)[:n + 11] for _ in range(B)]).to(DEV)
+    index = wide[:, :n]                                    # a column prefix: batch stride > n
+    vr = (torch.rand(B, 4, 2, generator=g) * 0.4 + 0.6).to(DEV)
+    q, ps, fg, ref = F.encoder_prepare_sorted(tokens, pos, score, index, vr, t_shapes.to(DEV), lsi.to(DEV))
+    assert torch.equal(q, F.gather_rows(tokens, index.contiguous()))
+    assert torch.equal(ps, F.gather_rows(pos, index.contiguous()))
+    assert torch.equal(fg, torch.gather(score, 1, index))
+    assert torch.equal(ref, F.encoder_reference_points(vr, t_shapes.to(DEV), lsi.to(DEV), n, index=index))
