@@ -98,6 +98,75 @@ __global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
     }
 }
 
+// Wide form for levels whose pixel count is a multiple of 4 (and C of 64): tiles of 64 tokens x 64 channels, 16-byte
+// loads along the pixels of a channel row (a wave reads 4 rows x 256 contiguous bytes instead of 2 x 128) and 16-byte
+// fp32 / 8-byte bf16 stores along the channels of a token.  Same arithmetic, same outputs.
+__global__ void __launch_bounds__(256) pyramid_flatten_wide_kernel(FlattenArgs p)
+{
+    __shared__ float tf[64][65], tp[64][65];   // [token][channel]; odd stride: both phases at most 2-way conflicts
+    __shared__ int valid_hw[2];
+    const int HW = p.H * p.W;
+    const int b = blockIdx.z, tok0 = blockIdx.x * 64, ch0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const uint8_t *mb = p.mask + (int64_t)b * HW;
+    if (tid < 128) {
+        int cnt = 0;
+        if (tid < 64) { for (int i = tid; i < p.H; i += 64) cnt += mb[(int64_t)i * p.W] == 0; }
+        else          { for (int i = tid - 64; i < p.W; i += 64) cnt += mb[i] == 0; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if ((tid & 63) == 0) valid_hw[tid >> 6] = cnt;
+    }
+    // load: 16 lanes x 4 pixels along a channel row, 16 channel rows per pass
+    const int g = tid & 15, cr = tid >> 4;
+    float4 f[4], q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = ch0 + cr + 16 * r, t = tok0 + 4 * g;
+        f[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q[r] = f[r];
+        if (t < HW) {   // HW % 4 == 0: a piece is inside the level or outside it as a whole
+            const int64_t i = ((int64_t)b * p.C + c) * HW + t;
+            f[r] = *reinterpret_cast<const float4 *>(p.feat + i);
+            q[r] = *reinterpret_cast<const float4 *>(p.pos + i);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cl = cr + 16 * r;
+        const float e = p.level_embed[ch0 + cl];
+        tf[4 * g][cl] = f[r].x; tf[4 * g + 1][cl] = f[r].y; tf[4 * g + 2][cl] = f[r].z; tf[4 * g + 3][cl] = f[r].w;
+        tp[4 * g][cl] = q[r].x + e; tp[4 * g + 1][cl] = q[r].y + e; tp[4 * g + 2][cl] = q[r].z + e; tp[4 * g + 3][cl] = q[r].w + e;
+    }
+    __syncthreads();
+    const float vh = (float)valid_hw[0], vw = (float)valid_hw[1];
+    if (p.valid_ratio && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 0] = vw / (float)p.W;
+        p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 1] = vh / (float)p.H;
+    }
+    // store: 16 lanes x 4 channels along a token, 16 tokens per pass
+    const int c4 = 4 * (tid & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tl = (tid >> 4) + 16 * r, t = tok0 + tl;
+        if (t >= HW) continue;
+        const int y = t / p.W, x = t - y * p.W;
+        const bool pad = mb[t] != 0;
+        const float cx = ((float)x + 0.5f) / vw, cy = ((float)y + 0.5f) / vh;
+        const bool keep = !pad && cx > 0.01f && cx < 0.99f && cy > 0.01f && cy < 0.99f && p.box_wh > 0.01f && p.box_wh < 0.99f;
+        const float4 fv = make_float4(tf[tl][c4], tf[tl][c4 + 1], tf[tl][c4 + 2], tf[tl][c4 + 3]);
+        const float4 qv = make_float4(tp[tl][c4], tp[tl][c4 + 1], tp[tl][c4 + 2], tp[tl][c4 + 3]);
+        const int64_t o = ((int64_t)b * p.S + p.start + t) * p.C + ch0 + c4;
+        if (p.feat_out) *reinterpret_cast<float4 *>(p.feat_out + o) = fv;
+        if (p.pos_out) *reinterpret_cast<float4 *>(p.pos_out + o) = qv;
+        *reinterpret_cast<float4 *>(p.sum_out + o) =
+            keep ? make_float4(fv.x + qv.x, fv.y + qv.y, fv.z + qv.z, fv.w + qv.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.feat_bf16) *reinterpret_cast<uint2 *>(p.feat_bf16 + o) = make_uint2(pack_bf16x2(fv.x, fv.y), pack_bf16x2(fv.z, fv.w));
+        if (p.pos_bf16) *reinterpret_cast<uint2 *>(p.pos_bf16 + o) = make_uint2(pack_bf16x2(qv.x, qv.y), pack_bf16x2(qv.z, qv.w));
+        if (c4 == 0 && ch0 == 0) p.mask_out[(int64_t)b * p.S + p.start + t] = pad ? 1 : 0;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ float to_f32(T v);
 template <>
@@ -284,6 +353,11 @@ extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *f
     a.feat_out = feat_out; a.pos_out = pos_out; a.sum_out = sum_out; a.mask_out = mask_out;
     a.feat_bf16 = reinterpret_cast<bf16_t *>(feat_bf16); a.pos_bf16 = reinterpret_cast<bf16_t *>(pos_bf16);
     a.valid_ratio = valid_ratio; a.valid_ratio_stride = valid_ratio_stride;
+    if ((C & 63) == 0 && ((H * W) & 3) == 0 && ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(pos)) & 15) == 0) {
+        const dim3 grid((unsigned)((H * W + 63) / 64), (unsigned)(C / 64), (unsigned)B);
+        hipLaunchKernelGGL(pyramid_flatten_wide_kernel, grid, dim3(256), 0, stream, a);
+        return check_launch("pyramid_flatten_level");
+    }
     const dim3 grid((unsigned)((H * W + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
     hipLaunchKernelGGL(pyramid_flatten_kernel, grid, dim3(32, 8), 0, stream, a);
     return check_launch("pyramid_flatten_level");
