@@ -115,7 +115,32 @@ __global__ void __launch_bounds__(512, 1) step_kernel(int steps, uint64_t *cycle
             if (f + 8 < 64) ring[f % 8] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + (f + 8) * 1024);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (FEAT & 4) {
+        if (FEAT & 16) {
+            // halves exchange 8-byte pieces so that a lane owns features 16m .. 16m+7 (+8 for the upper half) of its token:
+            // two 16-byte stores per tile instead of four 8-byte ones, no LDS
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t d[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    d[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){acc[j][2 * i], acc[j][2 * i + 1]}, bf2));
+                // d[2g], d[2g+1] = features 8g + 4h + {0..3}.  swap (h=0: g odd) <-> (h=1: g even)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(d[4 * m + w], d[4 * m + 2 + w], false, false);
+                        d[4 * m + w] = r[0];
+                        d[4 * m + 2 + w] = r[1];
+                    }
+                // now: h = 0 holds features 16m + 0..7 in d[4m .. 4m+3]; h = 1 holds 16m + 8..15
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    *reinterpret_cast<u32x4_t *>(orow + ((st & 3) * 4 + j) * 32 + 16 * m + 4 * h) = (u32x4_t){d[4 * m], d[4 * m + 1], d[4 * m + 2], d[4 * m + 3]};
+            }
+        } else if (FEAT & 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -374,6 +399,8 @@ int main()
         run_step<4>("+ row-strided 8-byte stores (no loaders)", blocks);
         run_step<12>("+ stores + packing (no loaders)", blocks);
         run_step<15>("everything", blocks);
+        run_step<16 + 8>("permlane32_swap + 16-byte row-strided stores (no loaders)", blocks);
+        run_step<16 + 8 + 3>("permlane32_swap + 16-byte row-strided stores + loaders", blocks);
         run_piped<false>("loaders + LDS-staged coalesced stores after the MFMAs", blocks);
         run_piped<true>("loaders + staged stores of step s-1 under the MFMAs of step s", blocks);
         run_piped<true, 1>("  ... loaders idle", blocks);

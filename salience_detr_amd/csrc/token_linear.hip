@@ -131,13 +131,9 @@ template <int EPI, bool ADD2, int WAVES>
 __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArgs p)
 {
     constexpr int kThreads = 64 * WAVES;   // compute threads
-    // two compute waves per SIMD hide each other's LDS latency and epilogue, and leave 168 registers per wave: a ring of
-    // 4 and a one-tile staging buffer (8 x 2.3 KB) there, 8 and two tiles (4 x 4.3 KB) with one wave per SIMD
+    // two compute waves per SIMD hide each other's LDS latency and leave 168 registers per wave: a ring of 4 there, 8 with
+    // one wave per SIMD
     constexpr int R = WAVES == 8 ? 4 : 8;
-    constexpr int kStgTiles = WAVES == 8 ? 1 : 2;
-    constexpr int kStgRow = kStgTiles * 64 + 8;          // bytes per token row of the staging tile (8 bytes of padding)
-    constexpr int kPieces = kStgTiles * 4;               // 16-byte pieces per row
-    constexpr int kRowsPerStore = 64 / kPieces, kStores = 32 / kRowsPerStore;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *wbuf = lds;                                                   // 2 step buffers
     float *bs = reinterpret_cast<float *>(lds + 2 * kTLStepBytes);      // [nsteps * 128]
@@ -184,17 +180,6 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
     const int img = tk / p.rows_per_batch, ri = tk - img * p.rows_per_batch;
 
     for (int i = tid; i < nsteps * 128; i += kThreads) bs[i] = p.bias[i];
-    // staging tile of this wave for the coalesced output (rows padded by 8 bytes: conflict-free in both directions)
-    char *stage = reinterpret_cast<char *>(bs + nsteps * 128) + wave * (32 * kStgRow);
-    const int tok0 = blockIdx.x * (kTLTokWave * WAVES) + wave * kTLTokWave;
-    int rimg[kStores], rri[kStores];   // image / row-in-image of the token rows this lane stores
-#pragma unroll
-    for (int i = 0; i < kStores; ++i) {
-        const int tr = min(tok0 + lane / kPieces + kRowsPerStore * i, p.T - 1);
-        rimg[i] = tr / p.rows_per_batch;
-        rri[i] = tr - rimg[i] * p.rows_per_batch;
-    }
-
     uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
     {
         const bf16_t *xr = p.x + (int64_t)tk * kTLK + 8 * h;
@@ -262,51 +247,50 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
                     if (n < p.N) run_max = fmaxf(run_max, accs[j][i]);
                 }
         } else {
-            // Output through a per-wave LDS staging tile.  Straight from the accumulator layout a lane owns 4 features of
-            // one token: 8-byte stores that hit 32 different rows per instruction, ~110 cycles of issue each -- 16 of
-            // them per step cost as much as the step's 64 MFMAs (benchmarks/micro/mfma_rate.hip).  One or two tiles at
-            // a time are written to LDS in accumulator order and read back row-major, so that a lane stores 16 bytes
-            // and an instruction covers whole 64- / 128-byte runs per token.
+            // Output.  Straight from the accumulator layout a lane owns 4 features of one token (8-byte stores, 32 rows per
+            // instruction, ~110 cycles of issue each: the 16 of a step cost as much as its 64 MFMAs).  The two lanes of a
+            // token therefore first exchange 8-byte pieces with v_permlane32_swap so that each owns 8 consecutive
+            // features, and stores 16 bytes: half the store instructions, no LDS.  (A per-wave LDS staging tile for fully
+            // coalesced rows was slower: every extra LDS instruction between the MFMAs costs ~130 cycles of issue --
+            // benchmarks/micro/mfma_rate.hip.)
 #pragma unroll
-            for (int part = 0; part < kTLStepTiles / kStgTiles; ++part) {
-                const int nt0 = st * kTLStepTiles + kStgTiles * part;
-                if (nt0 >= p.ntiles) break;
+            for (int j = 0; j < kTLStepTiles; ++j) {
+                const int nt = st * kTLStepTiles + j;
+                if (nt >= p.ntiles) break;
+                const tl_f32x16_t acc = accs[j];
+                uint32_t d[8];   // d[2g], d[2g+1] = features 8g + 4h + {0,1}, {2,3} of the tile
 #pragma unroll
-                for (int jj = 0; jj < kStgTiles; ++jj) {
-                    const tl_f32x16_t acc = accs[kStgTiles * part + jj];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint2 v;
-                        if (EPI == kHeadMajor)
-                            v = masked ? make_uint2(0u, 0u)
-                                : p.hm_f16 ? make_uint2(pack_f16x2(acc[4 * g], acc[4 * g + 1]), pack_f16x2(acc[4 * g + 2], acc[4 * g + 3]))
-                                           : make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
-                        else
-                            v = make_uint2(pack_bf16x2(acc[4 * g], acc[4 * g + 1]), pack_bf16x2(acc[4 * g + 2], acc[4 * g + 3]));
-                        *reinterpret_cast<uint2 *>(stage + t * kStgRow + (jj * 32 + 8 * g + 4 * h) * 2) = v;
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    if (EPI == kHeadMajor)
+                        d[i] = masked ? 0u : (p.hm_f16 ? pack_f16x2(acc[2 * i], acc[2 * i + 1]) : pack_bf16x2(acc[2 * i], acc[2 * i + 1]));
+                    else
+                        d[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-local: the staging tile is this wave's own)
 #pragma unroll
-                for (int i = 0; i < kStores; ++i) {
-                    const int row = lane / kPieces + kRowsPerStore * i, piece = lane % kPieces;   // token row, 16-byte piece
-                    const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * kStgRow + piece * 16);
-                    const int tr = tok0 + row;
-                    if (tr >= p.T) continue;
-                    const int n0 = nt0 * 32 + piece * 8;                       // first of the piece's 8 features
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        // row 1's first piece <-> row 0's second piece of the 16-feature half m
+                        const auto r = __builtin_amdgcn_permlane32_swap(d[4 * m + w], d[4 * m + 2 + w], false, false);
+                        d[4 * m + w] = r[0];
+                        d[4 * m + 2 + w] = r[1];
+                    }
+                if (!valid) continue;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    // d[4m .. 4m+3] = features 16 m + 8 h + {0..7} of tile nt
+                    const uint4 v = make_uint4(d[4 * m], d[4 * m + 1], d[4 * m + 2], d[4 * m + 3]);
+                    const int n0 = nt * 32 + 16 * m + 8 * h;
                     if (EPI == kHeadMajor) {
-                        const int nt = nt0 + (piece >> 2);
-                        if (nt >= p.ntiles) continue;
-                        const int grp = nt / p.heads, m = nt - grp * p.heads;
-                        const int64_t pix = (((int64_t)grp * p.batch + rimg[i]) * p.heads + m) * p.rows_per_batch + rri[i];
-                        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + (piece & 3) * 8) = v;
+                        const int grp = nt / p.heads, hm = nt - grp * p.heads;
+                        const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + hm) * p.rows_per_batch + ri;
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 16 * m + 8 * h) = v;
                     } else if (p.group > 0) {
                         // feature-group-major [B][N/group][rows][group]: the group size is a multiple of 4
                         const int ngroups = p.N / p.group;
                         if ((p.group & 7) == 0 && n0 + 8 <= p.N) {   // the piece lies inside one group
                             const int gi = n0 / p.group, within = n0 - gi * p.group;
-                            *reinterpret_cast<uint4 *>(p.out + (((int64_t)rimg[i] * ngroups + gi) * p.rows_per_batch + rri[i]) * p.group +
-                                                       within) = v;
+                            *reinterpret_cast<uint4 *>(p.out + (((int64_t)img * ngroups + gi) * p.rows_per_batch + ri) * p.group + within) = v;
                             continue;
                         }
 #pragma unroll
@@ -314,11 +298,11 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
                             const int n = n0 + 4 * q;
                             if (n >= p.N) continue;
                             const int gi = n / p.group, within = n - gi * p.group;
-                            *reinterpret_cast<uint2 *>(p.out + (((int64_t)rimg[i] * ngroups + gi) * p.rows_per_batch + rri[i]) * p.group +
-                                                       within) = q ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
+                            *reinterpret_cast<uint2 *>(p.out + (((int64_t)img * ngroups + gi) * p.rows_per_batch + ri) * p.group + within) =
+                                q ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
                         }
                     } else {
-                        bf16_t *o = p.out + (int64_t)tr * p.out_row_stride + n0;
+                        bf16_t *o = p.out + (int64_t)tok * p.out_row_stride + n0;
                         if (n0 + 8 <= p.N && (p.out_row_stride & 7) == 0) *reinterpret_cast<uint4 *>(o) = v;
                         else {
                             if (n0 < p.N) *reinterpret_cast<uint2 *>(o) = make_uint2(v.x, v.y);
@@ -326,7 +310,6 @@ __global__ void __launch_bounds__(64 * (WAVES + 4), 1) token_linear_kernel(TLArg
                         }
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next part overwrites the tile
             }
         }
     }
@@ -486,7 +469,7 @@ template <int EPI, bool ADD2, int WAVES>
 static int tl_launch_one(hipStream_t s, const TLArgs &a)
 {
     const int nsteps = (a.ntiles + kTLStepTiles - 1) / kTLStepTiles;
-    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512 + (size_t)WAVES * 32 * (WAVES == 8 ? 72 : 136);
+    const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
     static bool attr_set = false;   // (one flag per instantiation)
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_kernel<EPI, ADD2, WAVES>),
@@ -517,7 +500,7 @@ static int tl_common(TLArgs &a, const void *x, const void *packed, const float *
     a = TLArgs{};
     a.x = (const bf16_t *)x; a.pw = (const char *)packed; a.bias = bias; a.T = tokens; a.N = out_features;
     a.ntiles = (out_features + 31) / 32; a.rows_per_batch = tokens > 0 ? tokens : 1;
-    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 8 * 32 * 72 + 1024 > 160 * 1024) return fail("token_linear: too many output features");
+    if ((size_t)a.ntiles * 128 + 2 * kTLStepBytes + 1024 > 160 * 1024) return fail("token_linear: too many output features");
     return 0;
 }
 
