@@ -1,5 +1,10 @@
-import torch, sys
-sys.path.insert(0, '/root/repo')
+"""Value projection of the six encoder layers (44 646 tokens x 1536 features, head-major fp16 output) under a hipGraph."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from salience_detr_amd import filter_ops as F
 x = torch.randn(2, 22323, 256, device='cuda').to(torch.bfloat16)
 w = torch.randn(1536, 256, device='cuda').to(torch.bfloat16); b = torch.randn(1536, device='cuda').to(torch.bfloat16)
