@@ -569,14 +569,11 @@ extern "C" int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x,
         a.nblk = (tokens + 63) / 64;
         hipLaunchKernelGGL((salience_head_stage1_kernel<2, 4>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
                            (size_t)stage1_lds_bytes(64), s, a);
-    } else if ((int64_t)batch_size * ((tokens + 31) / 32) <= 512) {
-        // coarse levels: eight waves per block (every block still gets a CU slot of its own)
+    } else {
+        // eight waves per 32-token block: half the block latency on the coarse levels (whose few blocks leave the chip
+        // idle anyway) and a shorter tail on the finest one (1050 blocks on 512 two-per-CU slots)
         a.nblk = (tokens + 31) / 32;
         hipLaunchKernelGGL((salience_head_stage1_kernel<1, 8>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(512),
-                           (size_t)stage1_lds_bytes(32), s, a);
-    } else {
-        a.nblk = (tokens + 31) / 32;
-        hipLaunchKernelGGL((salience_head_stage1_kernel<1, 4>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
                            (size_t)stage1_lds_bytes(32), s, a);
     }
     return check_launch("salience_head_stage1");
