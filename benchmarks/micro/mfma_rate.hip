@@ -69,6 +69,30 @@ __global__ void __launch_bounds__(512, 1) step_kernel(int steps, uint64_t *cycle
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 32768; i += 512) reinterpret_cast<uint32_t *>(lds)[i] = i * 2654435761u;
     __syncthreads();
+    // FEAT bit 5 (32): hand-off through LDS flags instead of s_barrier -- flags[b] = loader arrivals for buffer b (4 per
+    // step written into it), flags[2 + b] = compute waves finished with a step held in buffer b
+    volatile __attribute__((address_space(3))) int *flags = (volatile __attribute__((address_space(3))) int *)(lds + 131072 - 64);
+    if (FEAT & 32) {
+        if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    if (wave >= 4 && (FEAT & 32)) {
+        u32x4_t v = {1u, 2u, 3u, 4u};
+        __attribute__((address_space(3))) char *dst = (__attribute__((address_space(3))) char *)lds + (wave - 4) * 16000 + lane * 16;
+        for (int st = 0; st + 1 < steps; ++st) {
+            const int b = (st + 1) & 1;            // buffer of step st+1; last used by step st-1
+            if (st >= 1) {
+                const int need = 4 * ((st - 1) / 2 + 1);
+                while (flags[2 + b] < need) __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < 15; ++i)
+                *reinterpret_cast<__attribute__((address_space(3))) u32x4_t *>(dst + b * 65536 + i * 1024) = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)&flags[b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
     if (wave >= 4) {
         if (!(FEAT & 1)) return;
         u32x4_t v = {1u, 2u, 3u, 4u};
@@ -93,6 +117,10 @@ __global__ void __launch_bounds__(512, 1) step_kernel(int steps, uint64_t *cycle
     for (int st = 0; st < steps; ++st) {
         const __attribute__((address_space(3))) char *base =
             (const __attribute__((address_space(3))) char *)lds + (st & 1) * 65536 + lane * 16;
+        if ((FEAT & 32) && st >= 1) {
+            const int need = 4 * ((st - 1) / 2 + 1);   // the four loaders have written step st into this buffer
+            while (flags[st & 1] < need) __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int f = 0; f < 8; ++f) ring[f] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(base + f * 1024);
 #pragma unroll
@@ -162,7 +190,9 @@ __global__ void __launch_bounds__(512, 1) step_kernel(int steps, uint64_t *cycle
             for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][9];
             if (s == 123.456f) sink[0] = s;
         }
-        if (FEAT & 1) __builtin_amdgcn_s_barrier();
+        if (FEAT & 32) {
+            if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int *)&flags[2 + (st & 1)], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (FEAT & 1) __builtin_amdgcn_s_barrier();
     }
     const uint64_t t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
@@ -401,6 +431,9 @@ int main()
         run_step<15>("everything", blocks);
         run_step<16 + 8>("permlane32_swap + 16-byte row-strided stores (no loaders)", blocks);
         run_step<16 + 8 + 3>("permlane32_swap + 16-byte row-strided stores + loaders", blocks);
+        run_step<32 + 16 + 8>("  ... with LDS-flag hand-off instead of s_barrier", blocks);
+        run_step<32 + 4 + 8>("8-byte stores + loaders with LDS-flag hand-off", blocks);
+        run_step<32 + 8>("no stores, loaders with LDS-flag hand-off", blocks);
         run_piped<false>("loaders + LDS-staged coalesced stores after the MFMAs", blocks);
         run_piped<true>("loaders + staged stores of step s-1 under the MFMAs of step s", blocks);
         run_piped<true, 1>("  ... loaders idle", blocks);
