@@ -33,7 +33,9 @@
 //     separated the costs: 26 us were fixed -- an epilogue that reloaded the residual with 32 row-strided loads per lane
 //     and spilled (tuple copies of the accumulators) -- and the per-chunk time is what the LDS read latency (~185 cycles)
 //     allows a 4-deep ring (8 would spill inside the loop): 32 reads x latency / 4.
-//   * what did NOT help and was dropped: rotating the chunk order per block (L2 channel spreading).
+//   * what did NOT help and was dropped: rotating the chunk order per block (L2 channel spreading); in the epilogue (its
+//     32 row-strided 8-byte stores are 4.2 of the 14 us of fixed cost at 178 blocks, 2.7 at 15) both an LDS-staged
+//     coalesced store of whole rows (16.5 us fixed) and v_permlane32_swap + 16-byte stores (17.1 us).
 //
 // A block keeps a CU for the whole hidden dimension, so small token counts leave most of the chip idle: the hidden
 // dimension can be cut into `nsplit` pieces per token block (fp32 partial products + ffn_reduce_ln_kernel).
