@@ -69,3 +69,30 @@ def test_module_boundary_contract():
     assert torch.allclose(bias[0, :, :, 0], torch.arange(1.0, 5.0).expand(4, 4))  # head 0 points along +x
     assert torch.allclose(bias[:, :, 3].abs().max(-1)[0], torch.full((8, 4), 4.0))
     assert sum(p.numel() for p in m.parameters()) == 230272
+
+
+def test_host_side_size_helpers_need_no_gpu():
+    """Pure host functions of the C ABI: workspace / packed sizes and the feed-forward split heuristic (which falls back
+    to 256 compute units when no device can be queried)."""
+    from salience_detr_amd import _hip
+    lib = _hip.lib()
+    assert lib.sdetr_ffn_packed_bytes(2048) == 64 * 32768
+    assert lib.sdetr_ffn_workspace_bytes(1000, 1) == 0 and lib.sdetr_ffn_workspace_bytes(1000, 3) == 3 * 1000 * 256 * 4
+    assert lib.sdetr_ffn_auto_splits(22726, 2048) == 1          # 178 token blocks already fill most of the chip
+    assert lib.sdetr_ffn_auto_splits(13634, 2048) == 2
+    assert 4 <= lib.sdetr_ffn_auto_splits(1800, 2048) <= 16
+    assert lib.sdetr_ffn_auto_splits(0, 2048) == 1
+    assert lib.sdetr_linear_packed_bytes(91) == 65536 and lib.sdetr_linear_packed_bytes(384) == 3 * 65536
+    assert lib.sdetr_focal_loss_workspace_bytes(0) == 0 and lib.sdetr_focal_loss_workspace_bytes(10 ** 9) == 1024 * 8
+    assert lib.sdetr_topk_workspace_bytes(2, 11363, 300) > 2 * 11363 * 8
+
+
+def test_criterion_and_attention_refuse_cpu_tensors():
+    import torch
+    from salience_detr_amd.filter_ops import attention_heads
+    from salience_detr_amd.salience_criterion import SalienceCriterion
+    with pytest.raises(RuntimeError):
+        SalienceCriterion()([torch.zeros(1, 1, 4, 4)], [{"boxes": torch.zeros(0, 4)}], [(8.0, 8.0)], [(32, 32)])
+    x = torch.zeros(1, 8, 256, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        attention_heads(x, x, x, 8)
