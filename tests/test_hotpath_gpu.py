@@ -80,10 +80,13 @@ def test_positional_embeddings_match_golden():
         assert (got.cpu() - _t(d[f"pos{l}"])).abs().max() < 1e-5
 
 
-def _full_model_and_inputs(image_sizes):
-    m = build_hot_path()
+STRESS_LEVELS = [(200, 336), (100, 168), (50, 84), (25, 42)]  # the reference's 5scale config: Nv = 89 250
+
+
+def _full_model_and_inputs(image_sizes, level_shapes=None, max_emb=200):
+    m = build_hot_path(max_num_embedding=max_emb)
     m.load_state_dict(syn.det_state_dict(m.state_dict()))
-    _, masks = syn.make_masks(image_sizes)
+    _, masks = syn.make_masks(image_sizes, level_shapes)
     shapes = [tuple(x.shape[-2:]) for x in masks]
     feats = syn.make_feats(len(image_sizes), shapes, 256, seed=0)
     pe = pyramid.PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5)
@@ -91,11 +94,15 @@ def _full_model_and_inputs(image_sizes):
     return m, feats, masks, pos
 
 
-@pytest.mark.parametrize("tag,image_sizes", [("single", [(800, 1333)]), ("mixed", [(800, 1333), (800, 1066)])])
+@pytest.mark.parametrize("tag,image_sizes", [("single", [(800, 1333)]), ("mixed", [(800, 1333), (800, 1066)]),
+                                             ("stress", [(800, 1333)])])
 def test_hotpath_full_size_digest(tag, image_sizes):
-    """800x1333 benchmark shape, E=256, 6 layers: digests captured from the imported reference."""
-    d = np.load(os.path.join(G, "hotpath_full_digest.npz"))
-    m, feats, masks, pos = _full_model_and_inputs(image_sizes)
+    """800x1333 benchmark shape, E=256, 6 layers: digests captured from the imported reference.  "stress" is the
+    reference's largest pyramid (5scale config: strides 4-32, 89 250 tokens, 45 330 queries in the first layer,
+    max_num_embedding 500)."""
+    stress = tag == "stress"
+    d = np.load(os.path.join(G, "hotpath_stress_digest.npz" if stress else "hotpath_full_digest.npz"))
+    m, feats, masks, pos = _full_model_and_inputs(image_sizes, STRESS_LEVELS if stress else None, 500 if stress else 200)
     m = m.to(DEV).eval()
     with torch.no_grad():
         memory, score_maps, aux = m([f.to(DEV) for f in feats], [x.to(DEV) for x in masks],
