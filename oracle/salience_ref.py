@@ -534,11 +534,84 @@ def _sub(sd: SD, prefix: str) -> SD:
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+# ----------------------------------------------------------------------------- row N3: RepVGGPluX neck
+def silu(x: torch.Tensor) -> torch.Tensor:
+    return x * torch.sigmoid(x)
+
+
+def conv_norm(sd: SD, prefix: str, x: torch.Tensor, stride: int = 1, groups: int = 1, act: bool = True,
+              eps: float = 1e-5) -> torch.Tensor:
+    """Conv2dNormActivation in eval mode (models/bricks/misc.py:61-103): bias-free convolution with "same" padding,
+    BatchNorm2d on its running statistics, optional SiLU.  ``prefix.0`` is the convolution, ``prefix.1`` the norm."""
+    w = sd[prefix + "0.weight"]
+    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2, groups=groups)
+    inv = torch.rsqrt(sd[prefix + "1.running_var"] + eps) * sd[prefix + "1.weight"]
+    y = (y - sd[prefix + "1.running_mean"].view(1, -1, 1, 1)) * inv.view(1, -1, 1, 1) + sd[prefix + "1.bias"].view(1, -1, 1, 1)
+    return silu(y) if act else y
+
+
+def attention_pool_gate(sd: SD, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """SqueezeAndExcitation (models/bricks/basic.py:29-54): the pooled context is NOT a mean -- every pixel gets the
+    logit ``conv_mask(x)``, a softmax over all H*W pixels weights the pixels, the weighted channel sums go through
+    C -> C/16 -> ReLU -> C -> sigmoid, and that gate scales x."""
+    B, C, H, W = x.shape
+    logit = F.conv2d(x, sd[prefix + "conv_mask.weight"], sd[prefix + "conv_mask.bias"]).view(B, H * W)
+    context = torch.einsum("bcp,bp->bc", x.view(B, C, H * W), logit.softmax(-1))
+    hidden = torch.relu(context @ sd[prefix + "se_module.0.weight"].view(-1, C).t())
+    gate = torch.sigmoid(hidden @ sd[prefix + "se_module.2.weight"].view(C, -1).t())
+    return gate.view(B, C, 1, 1) * x
+
+
+def repvgg_block(sd: SD, prefix: str, x: torch.Tensor, groups: int) -> torch.Tensor:
+    """RepVggPluXBlock.forward (models/necks/repnet.py:61-64) with in == out channels (identity shortcut, alpha = 1):
+    grouped 3x3 + grouped 1x1, each with its own BatchNorm, SiLU, the attention-pooled gate, plus x."""
+    y = conv_norm(sd, prefix + "conv1.", x, groups=groups, act=False) + conv_norm(sd, prefix + "conv2.", x, groups=groups, act=False)
+    return attention_pool_gate(sd, prefix + "se_module.", silu(y)) + x
+
+
+def csp_layer(sd: SD, prefix: str, x: torch.Tensor, groups: int, num_blocks: int = 3) -> torch.Tensor:
+    """CSPRepPluXLayer.forward (repnet.py:120-123), expansion 1 (conv3 is the identity)."""
+    y = conv_norm(sd, prefix + "conv1.", x)
+    for j in range(num_blocks):
+        y = repvgg_block(sd, f"{prefix}bottlenecks.{j}.", y, groups)
+    return y + conv_norm(sd, prefix + "conv2.", x)
+
+
+def neck(sd: SD, feats: Sequence[torch.Tensor], groups: int = 4) -> List[torch.Tensor]:
+    """RepVGGPluXNetwork.forward (repnet.py:211-245) on NCHW levels, fine to coarse; ``sd`` holds the neck's own keys
+    (``lateral_convs.*``, ``layer_blocks.*``, ``downsample_blocks.*``, ``pan_blocks.*``).  Eval mode only: the
+    batch-statistics (training / SyncBN) form of the norms is outside this restatement."""
+    L = len(feats)
+    inner = [feats[-1]]
+    for idx in range(L - 1, 0, -1):  # top-down
+        high = conv_norm(sd, f"lateral_convs.{idx - 1}.", inner[0])
+        inner[0] = high
+        up = F.interpolate(high, size=feats[idx - 1].shape[-2:], mode="nearest")
+        inner.insert(0, csp_layer(sd, f"layer_blocks.{idx - 1}.", torch.cat([up, feats[idx - 1]], 1), groups))
+    outs = [inner[0]]
+    for idx in range(L - 1):  # bottom-up
+        down = conv_norm(sd, f"downsample_blocks.{idx}.", outs[-1], stride=2)
+        outs.append(csp_layer(sd, f"pan_blocks.{idx}.", torch.cat([down, inner[idx + 1]], 1), groups))
+    return outs
+
+
+def neck_on_memory(sd: SD, memory: torch.Tensor, shapes: torch.Tensor, groups: int = 4) -> torch.Tensor:
+    """salience_transformer.py:185-192: token-major memory -> NCHW levels -> neck -> token-major memory."""
+    B, _, C = memory.shape
+    sizes = [int(h) * int(w) for h, w in shapes.tolist()]
+    levels = [m.transpose(1, 2).reshape(B, C, int(h), int(w))
+              for m, (h, w) in zip(memory.split(sizes, 1), shapes.tolist())]
+    return torch.cat([o.flatten(2).transpose(1, 2) for o in neck(sd, levels, groups)], 1)
+
+
 def transformer(sd: SD, feats, masks, pos, num_proposals: int, heads=8, points=4, topk_sa=300, enc_layers=6,
                 dec_layers=6, core=msda_core_c):
-    """SalienceTransformer.forward, inference (no denoising queries, neck=None; salience_transformer.py:97-226)."""
+    """SalienceTransformer.forward, inference (no denoising queries; salience_transformer.py:97-226).  The neck runs
+    iff ``sd`` carries ``neck.*`` keys."""
     hp = hot_path(sd, feats, masks, pos, heads, points, topk_sa, enc_layers, core=core)
     memory = hp["memory"]
+    if any(k.startswith("neck.") for k in sd):
+        memory = neck_on_memory(_sub(sd, "neck."), memory, hp["spatial_shapes"])
     ts = two_stage_proposals(sd, memory, hp["mask_flatten"], hp["spatial_shapes"], hp["level_start_index"],
                              num_proposals)
     B = memory.shape[0]

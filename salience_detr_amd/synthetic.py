@@ -79,6 +79,12 @@ def det_state_dict(reference: Dict[str, torch.Tensor], num_heads: int = 8, num_l
             t = det_randn(name, shape, salt)
         elif name.endswith("_embed.weight"):  # learned row/col background embeddings
             t = det_rand(name, shape, salt)
+        elif leaf == "running_var":  # BatchNorm statistics of the neck: positive, away from zero
+            t = 0.5 + det_rand(name, shape, salt)
+        elif leaf == "running_mean":
+            t = 0.1 * det_randn(name, shape, salt)
+        elif len(shape) == 4:  # convolution kernels [out, in / groups, kh, kw]
+            t = det_randn(name, shape, salt) * (1.0 / math.sqrt(shape[1] * shape[2] * shape[3]))
         elif len(shape) == 2:  # Linear / in_proj weights
             t = det_randn(name, shape, salt) * (1.0 / math.sqrt(shape[1]))
         elif len(shape) == 1 and leaf == "weight":  # LayerNorm gains
