@@ -465,6 +465,39 @@ int sdetr_salience_focal_loss_backward(sdetr_stream_t stream, const float *logit
                                        float alpha, float gamma, const float *loss_and_num_pos, const float *grad_loss,
                                        float *grad_logits);
 
+/* ---- (13) RepVGGPluX neck on the encoder memory (row N3), eval mode ----------------------------------------------------
+ * models/necks/repnet.py:12-245, models/bricks/basic.py:29-54, call site models/bricks/salience_transformer.py:185-192.
+ * Feature maps are TOKEN-MAJOR (= channels-last): [batch, height * width, channels], f32 | bf16, arithmetic in fp32.  The
+ * caller folds every BatchNorm (running statistics) into the convolution before it, and conv1 + alpha * conv2 of a
+ * RepVggPluXBlock (:61-64) into one 3x3 kernel.
+ *   sdetr_neck_conv3x3: 3x3 convolution, padding 1, stride 1 | 2, `groups` groups of in_per_group -> out_per_group
+ *     channels (multiples of 4), + bias (+ SiLU when activation = 1).  x rows are x_row_stride elements apart (the
+ *     channels read are the first groups * in_per_group of a row); weight fp32 [groups][3][3][in_per_group]
+ *     [out_per_group]; bias fp32 [groups * out_per_group] or NULL; out contiguous
+ *     [batch, ((height - 1) / stride + 1) * ((width - 1) / stride + 1), groups * out_per_group].
+ *   sdetr_neck_combine: out = act(a + nearest_upsample(up) + bias) -- the epilogue of the 1x1 convolutions, whose
+ *     GEMMs run on the token rows: `a` [batch, height * width, channels] at the output resolution, `up` (NULL: absent)
+ *     [batch, up_height * up_width, channels] read at torch's nearest-neighbour source pixel
+ *     min(int(floorf(dst * (float)in / out)), in - 1) (F.interpolate(mode="nearest") at repnet.py:224-228; a 1x1
+ *     convolution commutes with it, so the coarse half of the concatenated input is convolved at ITS resolution).
+ *     Row strides in elements.
+ *   sdetr_neck_gate_shortcut: out = SqueezeAndExcitation(y) + shortcut (+ shortcut2): context = sum_p softmax_p(
+ *     mask_weight . y_p) y_p, gate = sigmoid(excite_weight [C, hidden] relu(squeeze_weight [hidden, C] context)),
+ *     out = gate * y + shortcut (repnet.py:63-64; shortcut2 = the CSP layer's second branch, :121, for its last
+ *     block).  y / out contiguous [batch, pixels, channels], channels <= 256; `gate` fp32 [batch, channels] scratch
+ *     that also returns the gate; workspace of sdetr_neck_gate_workspace_bytes. */
+int sdetr_neck_conv3x3(sdetr_stream_t stream, const void *x, int dtype, int batch_size, int height, int width,
+                       int x_row_stride, const float *weight, const float *bias, int groups, int in_per_group,
+                       int out_per_group, int stride, int activation, void *out);
+int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_row_stride, const void *up, int up_row_stride,
+                       int up_height, int up_width, const float *bias, int dtype, int batch_size, int height, int width,
+                       int channels, int activation, void *out, int out_row_stride);
+int64_t sdetr_neck_gate_workspace_bytes(int batch_size, int pixels, int channels);
+int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, int dtype, int batch_size, int pixels, int channels,
+                             const float *mask_weight, const float *squeeze_weight, const float *excite_weight,
+                             int hidden, const void *shortcut, int shortcut_row_stride, const void *shortcut2,
+                             int shortcut2_row_stride, void *workspace, int64_t workspace_bytes, float *gate, void *out);
+
 #ifdef __cplusplus
 }
 #endif

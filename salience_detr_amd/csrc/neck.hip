@@ -1,0 +1,462 @@
+// Row N3: the RepVGGPluX neck on TOKEN-MAJOR feature maps (include/salience_hip.h section (13)).
+//
+// The reference reshapes the encoder memory [B, sum H*W, C] to NCHW, runs the neck's convolutions and flattens back
+// (models/bricks/salience_transformer.py:185-192, models/necks/repnet.py).  Token-major IS channels-last, so nothing
+// is transposed here: a pixel's C channels are one contiguous row.  In eval mode every BatchNorm folds into the
+// convolution before it and the 3x3 + 1x1 pair of a RepVGG block folds into one 3x3 (host side, salience_neck.py);
+// what is left for the device is
+//   conv3x3_tokens_kernel   grouped / dense 3x3, stride 1 or 2, + bias (+ SiLU)
+//   neck_combine_kernel     act(a + nearest_upsample(b) + bias): the epilogue of the 1x1 convolutions, whose
+//                           GEMMs are plain library GEMMs on the token rows
+//   se_context / se_gate / se_apply   the attention-pooled gate of models/bricks/basic.py:29-54 and the shortcut
+// First version: fp32 VALU arithmetic on fp32 or bf16 storage, LDS-tiled; the MFMA form of the 3x3 is the next step.
+#include "common.h"
+
+namespace sdetr {
+namespace {
+
+template <typename T>
+struct Store;
+template <>
+struct Store<float> {
+    static __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <>
+struct Store<bf16_t> {
+    static __device__ __forceinline__ float4 load4(const bf16_t *p)
+    {
+        const uint2 u = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+    }
+    static __device__ __forceinline__ void store4(bf16_t *p, float4 v)
+    {
+        *reinterpret_cast<uint2 *>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+};
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolution, padding 1.  A workgroup owns a 4 x 16 tile of output pixels and 64 output channels of one
+// group; thread (tx = tid % 16, ty = tid / 16) owns output channels 4*tx .. 4*tx+3 of 4 pixels in a row.  The input
+// channels arrive 16 at a time: the tile's input patch and the 9 x 16 x 64 weight block go through LDS.
+constexpr int kTileH = 4, kTileW = 16, kCK = 16, kCB = 64;
+
+struct ConvArgs {
+    const void *x;
+    const float *w;     // [G][3][3][CiG][CoG]
+    const float *bias;  // [G * CoG] or NULL
+    void *out;
+    int B, H, W, Ho, Wo;
+    int ldx;            // elements between consecutive pixels of x (>= G * CiG)
+    int G, CiG, CoG;
+    int act;            // 0 none, 1 SiLU
+    int tiles_x;
+};
+
+template <typename T, int S>
+__global__ void __launch_bounds__(kBlock) conv3x3_tokens_kernel(ConvArgs p)
+{
+    constexpr int PR = 3 + (kTileH - 1) * S, PC = 3 + (kTileW - 1) * S, NC = 3 + 3 * S;
+    __shared__ __attribute__((aligned(16))) float in_s[PR * PC * kCK];
+    __shared__ __attribute__((aligned(16))) float w_s[9 * kCK * kCB];
+
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int r = ty >> 2, px0 = (ty & 3) * 4;
+    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    const int cblocks = (p.CoG + kCB - 1) / kCB;
+    const int g = blockIdx.y / cblocks, cb0 = (blockIdx.y % cblocks) * kCB;
+    const int b = blockIdx.z;
+    const int oy0 = tile_y * kTileH, ox0 = tile_x * kTileW;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const T *x = reinterpret_cast<const T *>(p.x) + (int64_t)b * p.H * p.W * p.ldx + (int64_t)g * p.CiG;
+    const float *w = p.w + (int64_t)g * 9 * p.CiG * p.CoG;
+
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int ck0 = 0; ck0 < p.CiG; ck0 += kCK) {
+        __syncthreads();
+        // input patch: [PR][PC][kCK], 4 channels per load, zero outside the image / past the group's channels
+        for (int e = tid; e < PR * PC * (kCK / 4); e += kBlock) {
+            const int c4 = e % (kCK / 4), pix = e / (kCK / 4);
+            const int pc = pix % PC, pr = pix / PC;
+            const int iy = iy0 + pr, ix = ix0 + pc, c = ck0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.CiG)
+                v = Store<T>::load4(x + ((int64_t)iy * p.W + ix) * p.ldx + c);
+            *reinterpret_cast<float4 *>(in_s + (pix * kCK + c4 * 4)) = v;
+        }
+        // weights: [9][kCK][kCB]
+        for (int e = tid; e < 9 * kCK * (kCB / 4); e += kBlock) {
+            const int co4 = e % (kCB / 4), rest = e / (kCB / 4);
+            const int c = rest % kCK, tap = rest / kCK;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ck0 + c < p.CiG && cb0 + co4 * 4 < p.CoG)
+                v = *reinterpret_cast<const float4 *>(w + ((int64_t)tap * p.CiG + ck0 + c) * p.CoG + cb0 + co4 * 4);
+            *reinterpret_cast<float4 *>(w_s + (tap * kCK + c) * kCB + co4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float *row = in_s + ((r * S + ky) * PC + px0 * S) * kCK;
+#pragma unroll
+            for (int c4 = 0; c4 < kCK / 4; ++c4) {
+                float4 iv[NC];
+#pragma unroll
+                for (int n = 0; n < NC; ++n) iv[n] = *reinterpret_cast<const float4 *>(row + n * kCK + c4 * 4);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float *wt = w_s + ((ky * 3 + kx) * kCK + c4 * 4) * kCB + tx * 4;
+                    const float4 w0 = *reinterpret_cast<const float4 *>(wt);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(wt + kCB);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(wt + 2 * kCB);
+                    const float4 w3 = *reinterpret_cast<const float4 *>(wt + 3 * kCB);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 a = iv[q * S + kx];
+                        acc[q][0] = fmaf(a.x, w0.x, acc[q][0]); acc[q][1] = fmaf(a.x, w0.y, acc[q][1]);
+                        acc[q][2] = fmaf(a.x, w0.z, acc[q][2]); acc[q][3] = fmaf(a.x, w0.w, acc[q][3]);
+                        acc[q][0] = fmaf(a.y, w1.x, acc[q][0]); acc[q][1] = fmaf(a.y, w1.y, acc[q][1]);
+                        acc[q][2] = fmaf(a.y, w1.z, acc[q][2]); acc[q][3] = fmaf(a.y, w1.w, acc[q][3]);
+                        acc[q][0] = fmaf(a.z, w2.x, acc[q][0]); acc[q][1] = fmaf(a.z, w2.y, acc[q][1]);
+                        acc[q][2] = fmaf(a.z, w2.z, acc[q][2]); acc[q][3] = fmaf(a.z, w2.w, acc[q][3]);
+                        acc[q][0] = fmaf(a.w, w3.x, acc[q][0]); acc[q][1] = fmaf(a.w, w3.y, acc[q][1]);
+                        acc[q][2] = fmaf(a.w, w3.z, acc[q][2]); acc[q][3] = fmaf(a.w, w3.w, acc[q][3]);
+                    }
+                }
+            }
+        }
+    }
+
+    const int co = cb0 + tx * 4;
+    const int oy = oy0 + r;
+    if (co >= p.CoG || oy >= p.Ho) return;
+    const int cout = p.G * p.CoG, cglob = g * p.CoG + co;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + cglob);
+    T *out = reinterpret_cast<T *>(p.out) + ((int64_t)b * p.Ho + oy) * p.Wo * cout + cglob;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ox = ox0 + px0 + q;
+        if (ox >= p.Wo) break;
+        float4 v = make_float4(acc[q][0] + bias.x, acc[q][1] + bias.y, acc[q][2] + bias.z, acc[q][3] + bias.w);
+        if (p.act) v = make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w));
+        Store<T>::store4(out + (int64_t)ox * cout, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b, y, x, :] = act(a[b, y, x, :] + up[b, ys, xs, :] + bias), (ys, xs) = the pixel torch's "nearest"
+// interpolation reads: min(int(floorf(dst * (float)in / out)), in - 1)   (F.interpolate at repnet.py:224-228)
+struct CombineArgs {
+    const void *a;
+    const void *up;    // NULL: no second term
+    const float *bias; // NULL: none
+    void *out;
+    int64_t rows;      // B * H * W
+    int H, W, Hs, Ws, C;
+    int lda, ldup, ldo;
+    int act;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) neck_combine_kernel(CombineArgs p)
+{
+    const int c4n = p.C / 4;
+    const int64_t n = p.rows * c4n;
+    const float sh = (float)p.Hs / (float)p.H, sw = (float)p.Ws / (float)p.W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % c4n) * 4;
+        const int64_t row = e / c4n;
+        float4 v = Store<T>::load4(reinterpret_cast<const T *>(p.a) + row * p.lda + c);
+        if (p.up) {
+            const int xq = (int)(row % p.W);
+            const int64_t t = row / p.W;
+            const int yq = (int)(t % p.H);
+            const int64_t b = t / p.H;
+            const int ys = min((int)floorf((float)yq * sh), p.Hs - 1);
+            const int xs = min((int)floorf((float)xq * sw), p.Ws - 1);
+            const float4 u = Store<T>::load4(reinterpret_cast<const T *>(p.up) + ((b * p.Hs + ys) * p.Ws + xs) * p.ldup + c);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (p.bias) {
+            const float4 bb = *reinterpret_cast<const float4 *>(p.bias + c);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (p.act) v = make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w));
+        Store<T>::store4(reinterpret_cast<T *>(p.out) + row * p.ldo + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention pooling of SqueezeAndExcitation (basic.py:43-54): context[c] = sum_p softmax_p(w_mask . y_p) y_p[c].
+// (conv_mask's bias is the same for every pixel and drops out of the softmax.)  One workgroup reduces kSePix pixels
+// with a running (max, sum, weighted vector) per wave -- lane l owns channels 4l .. 4l+3 (C <= 256) -- and writes one
+// partial [C + 2] = (vector, max, sum); se_gate_kernel merges the partials of an image and runs the two tiny layers.
+constexpr int kSePix = 128;
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) se_context_kernel(const void *y_, const float *w_mask, int N, int C,
+                                                            int nblk, float *partial)
+{
+    __shared__ float red[4][256 + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const T *y = reinterpret_cast<const T *>(y_) + (int64_t)b * N * C;
+    const int c = lane * 4;
+    const bool on = c < C;
+    float4 wm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) wm = *reinterpret_cast<const float4 *>(w_mask + c);
+    float M = -INFINITY, Ssum = 0.f;
+    float4 V = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int p_end = min(N, (blk + 1) * kSePix);
+    for (int pix = blk * kSePix + wave; pix < p_end; pix += 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) v = Store<T>::load4(y + (int64_t)pix * C + c);
+        float m = v.x * wm.x + v.y * wm.y + v.z * wm.z + v.w * wm.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+        const float nM = fmaxf(M, m);
+        const float sc = __expf(M - nM), e = __expf(m - nM);  // first pixel: exp(-inf) = 0
+        Ssum = Ssum * sc + e;
+        V.x = V.x * sc + e * v.x; V.y = V.y * sc + e * v.y; V.z = V.z * sc + e * v.z; V.w = V.w * sc + e * v.w;
+        M = nM;
+    }
+    if (on) {
+        red[wave][c] = V.x; red[wave][c + 1] = V.y; red[wave][c + 2] = V.z; red[wave][c + 3] = V.w;
+    }
+    if (lane == 0) {
+        red[wave][256] = M;
+        red[wave][257] = Ssum;
+    }
+    __syncthreads();
+    const float gM = fmaxf(fmaxf(red[0][256], red[1][256]), fmaxf(red[2][256], red[3][256]));
+    float *dst = partial + ((int64_t)b * nblk + blk) * (C + 2);
+    float f[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = red[i][256] == -INFINITY ? 0.f : __expf(red[i][256] - gM);
+    if (tid < C) dst[tid] = red[0][tid] * f[0] + red[1][tid] * f[1] + red[2][tid] * f[2] + red[3][tid] * f[3];
+    if (tid == 0) {
+        dst[C] = gM;
+        dst[C + 1] = red[0][257] * f[0] + red[1][257] * f[1] + red[2][257] * f[2] + red[3][257] * f[3];
+    }
+}
+
+// gate[b, c] = sigmoid(W2 relu(W1 context[b])), W1 [R, C], W2 [C, R]  (basic.py:34-39, bias-free 1x1 convolutions)
+__global__ void __launch_bounds__(kBlock) se_gate_kernel(const float *partial, int nblk, int C, int R, const float *w1,
+                                                         const float *w2, float *gate)
+{
+    __shared__ float ctx[256];
+    __shared__ float hid[64];
+    __shared__ float fac[256];
+    __shared__ float stat[2];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float *part = partial + (int64_t)b * nblk * (C + 2);
+    // global max over the partials, then each partial's factor and the total sum
+    float m = -INFINITY;
+    for (int i = tid; i < nblk; i += kBlock) m = fmaxf(m, part[(int64_t)i * (C + 2) + C]);
+    fac[tid] = m;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (tid < s) fac[tid] = fmaxf(fac[tid], fac[tid + s]);
+        __syncthreads();
+    }
+    const float gM = fac[0];
+    __syncthreads();
+    float ssum = 0.f;
+    for (int i = tid; i < nblk; i += kBlock) {
+        const float pm = part[(int64_t)i * (C + 2) + C];
+        ssum += pm == -INFINITY ? 0.f : part[(int64_t)i * (C + 2) + C + 1] * __expf(pm - gM);
+    }
+    fac[tid] = ssum;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (tid < s) fac[tid] += fac[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) stat[0] = fac[0];
+    __syncthreads();
+    const float inv = 1.0f / stat[0];
+    if (tid < C) {
+        float v = 0.f;
+        for (int i = 0; i < nblk; ++i) {
+            const float pm = part[(int64_t)i * (C + 2) + C];
+            if (pm != -INFINITY) v += part[(int64_t)i * (C + 2) + tid] * __expf(pm - gM);
+        }
+        ctx[tid] = v * inv;
+    }
+    __syncthreads();
+    if (tid < R) {
+        float h = 0.f;
+        for (int c = 0; c < C; ++c) h = fmaf(w1[(int64_t)tid * C + c], ctx[c], h);
+        hid[tid] = fmaxf(h, 0.f);
+    }
+    __syncthreads();
+    if (tid < C) {
+        float o = 0.f;
+        for (int j = 0; j < R; ++j) o = fmaf(w2[(int64_t)tid * R + j], hid[j], o);
+        gate[(int64_t)b * C + tid] = 1.0f / (1.0f + __expf(-o));
+    }
+}
+
+// out = gate[b, :] * y + x (+ x2): the gated activation plus the block's shortcut (repnet.py:64), and for the last
+// block of a CSP layer the layer's second branch as well (repnet.py:121)
+struct ApplyArgs {
+    const void *y, *x, *x2;
+    const float *gate;
+    void *out;
+    int64_t rows;
+    int N, C, ldx, ldx2;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) se_apply_kernel(ApplyArgs p)
+{
+    const int c4n = p.C / 4;
+    const int64_t n = p.rows * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % c4n) * 4;
+        const int64_t row = e / c4n;
+        const int64_t b = row / p.N;
+        const float4 g = *reinterpret_cast<const float4 *>(p.gate + b * p.C + c);
+        const float4 y = Store<T>::load4(reinterpret_cast<const T *>(p.y) + row * p.C + c);
+        const float4 x = Store<T>::load4(reinterpret_cast<const T *>(p.x) + row * p.ldx + c);
+        float4 v = make_float4(fmaf(g.x, y.x, x.x), fmaf(g.y, y.y, x.y), fmaf(g.z, y.z, x.z), fmaf(g.w, y.w, x.w));
+        if (p.x2) {
+            const float4 s = Store<T>::load4(reinterpret_cast<const T *>(p.x2) + row * p.ldx2 + c);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        Store<T>::store4(reinterpret_cast<T *>(p.out) + row * p.C + c, v);
+    }
+}
+
+inline unsigned grid_for(int64_t n)
+{
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+}
+
+}  // namespace
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int sdetr_neck_conv3x3(sdetr_stream_t stream, const void *x, int dtype, int batch_size, int height,
+                                  int width, int x_row_stride, const float *weight, const float *bias, int groups,
+                                  int in_per_group, int out_per_group, int stride, int activation, void *out)
+{
+    if (batch_size < 0 || height <= 0 || width <= 0 || groups <= 0 || in_per_group <= 0 || out_per_group <= 0)
+        return fail("neck_conv3x3: bad sizes");
+    if ((in_per_group % 4) || (out_per_group % 4) || (x_row_stride % 4) || x_row_stride < groups * in_per_group)
+        return fail("neck_conv3x3: channels per group and the row stride must be multiples of 4");
+    if (stride != 1 && stride != 2) return fail("neck_conv3x3: stride %d (1 or 2)", stride);
+    if (dtype != SDETR_F32 && dtype != SDETR_BF16) return fail("neck_conv3x3: bad dtype %d", dtype);
+    if (activation < 0 || activation > 1) return fail("neck_conv3x3: bad activation %d", activation);
+    if (batch_size == 0) return 0;
+    if (!x || !weight || !out) return fail("neck_conv3x3: null pointer");
+    if (batch_size > 65535) return fail("neck_conv3x3: batch too large");
+    ConvArgs a;
+    a.x = x; a.w = weight; a.bias = bias; a.out = out;
+    a.B = batch_size; a.H = height; a.W = width;
+    a.Ho = (height - 1) / stride + 1;  // (H + 2 - 3) / stride + 1
+    a.Wo = (width - 1) / stride + 1;
+    a.ldx = x_row_stride; a.G = groups; a.CiG = in_per_group; a.CoG = out_per_group; a.act = activation;
+    a.tiles_x = (a.Wo + kTileW - 1) / kTileW;
+    const int tiles_y = (a.Ho + kTileH - 1) / kTileH;
+    const int cblocks = (out_per_group + kCB - 1) / kCB;
+    if ((int64_t)groups * cblocks > 65535) return fail("neck_conv3x3: too many channel blocks");
+    const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups * cblocks), (unsigned)batch_size);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SDETR_F32) {
+        if (stride == 1) hipLaunchKernelGGL((conv3x3_tokens_kernel<float, 1>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_tokens_kernel<float, 2>), grid, dim3(kBlock), 0, s, a);
+    } else {
+        if (stride == 1) hipLaunchKernelGGL((conv3x3_tokens_kernel<bf16_t, 1>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_tokens_kernel<bf16_t, 2>), grid, dim3(kBlock), 0, s, a);
+    }
+    return check_launch("neck_conv3x3");
+}
+
+extern "C" int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_row_stride, const void *up,
+                                  int up_row_stride, int up_height, int up_width, const float *bias, int dtype,
+                                  int batch_size, int height, int width, int channels, int activation, void *out,
+                                  int out_row_stride)
+{
+    if (batch_size < 0 || height <= 0 || width <= 0 || channels <= 0 || (channels % 4))
+        return fail("neck_combine: bad sizes");
+    if ((a_row_stride % 4) || (out_row_stride % 4) || a_row_stride < channels || out_row_stride < channels)
+        return fail("neck_combine: row strides must be multiples of 4 and >= channels");
+    if (up && (up_height <= 0 || up_width <= 0 || (up_row_stride % 4) || up_row_stride < channels))
+        return fail("neck_combine: bad up-sampling source");
+    if (dtype != SDETR_F32 && dtype != SDETR_BF16) return fail("neck_combine: bad dtype %d", dtype);
+    if (activation < 0 || activation > 1) return fail("neck_combine: bad activation %d", activation);
+    if (batch_size == 0) return 0;
+    if (!a || !out) return fail("neck_combine: null pointer");
+    CombineArgs p;
+    p.a = a; p.up = up; p.bias = bias; p.out = out;
+    p.rows = (int64_t)batch_size * height * width;
+    p.H = height; p.W = width; p.Hs = up ? up_height : 1; p.Ws = up ? up_width : 1; p.C = channels;
+    p.lda = a_row_stride; p.ldup = up_row_stride; p.ldo = out_row_stride; p.act = activation;
+    const unsigned grid = grid_for(p.rows * (channels / 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SDETR_F32) hipLaunchKernelGGL((neck_combine_kernel<float>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((neck_combine_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, s, p);
+    return check_launch("neck_combine");
+}
+
+extern "C" int64_t sdetr_neck_gate_workspace_bytes(int batch_size, int pixels, int channels)
+{
+    if (batch_size <= 0 || pixels <= 0 || channels <= 0) return 0;
+    const int64_t nblk = ((int64_t)pixels + kSePix - 1) / kSePix;
+    return (int64_t)batch_size * nblk * ((int64_t)channels + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, int dtype, int batch_size, int pixels,
+                                        int channels, const float *mask_weight, const float *squeeze_weight,
+                                        const float *excite_weight, int hidden, const void *shortcut,
+                                        int shortcut_row_stride, const void *shortcut2, int shortcut2_row_stride,
+                                        void *workspace, int64_t workspace_bytes, float *gate, void *out)
+{
+    if (batch_size < 0 || pixels <= 0 || channels <= 0 || (channels % 4) || channels > 256)
+        return fail("neck_gate_shortcut: channels must be a multiple of 4, at most 256 (got %d)", channels);
+    if (hidden <= 0 || hidden > 64) return fail("neck_gate_shortcut: hidden width %d (1..64)", hidden);
+    if (dtype != SDETR_F32 && dtype != SDETR_BF16) return fail("neck_gate_shortcut: bad dtype %d", dtype);
+    if ((shortcut_row_stride % 4) || shortcut_row_stride < channels) return fail("neck_gate_shortcut: bad shortcut stride");
+    if (shortcut2 && ((shortcut2_row_stride % 4) || shortcut2_row_stride < channels))
+        return fail("neck_gate_shortcut: bad second shortcut stride");
+    if (batch_size == 0) return 0;
+    if (!y || !mask_weight || !squeeze_weight || !excite_weight || !shortcut || !gate || !out)
+        return fail("neck_gate_shortcut: null pointer");
+    if (batch_size > 65535) return fail("neck_gate_shortcut: batch too large");
+    const int64_t need = sdetr_neck_gate_workspace_bytes(batch_size, pixels, channels);
+    if (!workspace || workspace_bytes < need)
+        return fail("neck_gate_shortcut: needs %lld bytes of workspace, got %lld", (long long)need, (long long)workspace_bytes);
+    const int nblk = (pixels + kSePix - 1) / kSePix;
+    hipStream_t s = (hipStream_t)stream;
+    float *partial = reinterpret_cast<float *>(workspace);
+    if (dtype == SDETR_F32)
+        hipLaunchKernelGGL((se_context_kernel<float>), dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, y,
+                           mask_weight, pixels, channels, nblk, partial);
+    else
+        hipLaunchKernelGGL((se_context_kernel<bf16_t>), dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, y,
+                           mask_weight, pixels, channels, nblk, partial);
+    int rc = check_launch("neck_gate_shortcut(context)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)batch_size), dim3(kBlock), 0, s, partial, nblk, channels, hidden,
+                       squeeze_weight, excite_weight, gate);
+    rc = check_launch("neck_gate_shortcut(gate)");
+    if (rc) return rc;
+    ApplyArgs p;
+    p.y = y; p.x = shortcut; p.x2 = shortcut2; p.gate = gate; p.out = out;
+    p.rows = (int64_t)batch_size * pixels; p.N = pixels; p.C = channels;
+    p.ldx = shortcut_row_stride; p.ldx2 = shortcut2_row_stride;
+    const unsigned grid = grid_for(p.rows * (channels / 4));
+    if (dtype == SDETR_F32) hipLaunchKernelGGL((se_apply_kernel<float>), dim3(grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((se_apply_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, s, p);
+    return check_launch("neck_gate_shortcut(apply)");
+}

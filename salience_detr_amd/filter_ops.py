@@ -852,3 +852,96 @@ def topk_attention_heads(query: Tensor, pos: Tensor, index: Tensor, mha) -> Tens
             bias.data_ptr(), out.data_ptr())
     _hip.check(code, "topk_attention_heads")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- row N3: the neck
+def _token_map(what: str, name: str, t: Tensor, pixels: int, channels: int) -> int:
+    """Checks a token-major feature map ``[B, pixels, >= channels]`` (a channel slice of a wider buffer is fine) and
+    returns its row stride in elements."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: {name} must be a HIP (cuda) tensor; the neck has no CPU fallback")
+    if t.dim() != 3 or t.shape[1] != pixels or t.shape[2] < channels or t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"{what}: {name} must be [B, {pixels}, >= {channels}] fp32 | bf16, got {tuple(t.shape)} {t.dtype}")
+    ld = t.stride(1) if pixels > 1 else max(t.shape[2], t.stride(1))
+    if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != pixels * ld) or ld % 4 or t.data_ptr() % (4 * t.element_size()):
+        raise RuntimeError(f"{what}: {name} rows must be dense in the channel dim, 4-element aligned, images back to back")
+    return ld
+
+
+def neck_conv3x3(x: Tensor, height: int, width: int, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
+                 activation: bool = False) -> Tensor:
+    """3x3 convolution (padding 1) + bias (+ SiLU) on a token-major map (include/salience_hip.h (13)): ``x``
+    ``[B, height * width, >= G * Ci]``, ``weight`` fp32 ``[G, 3, 3, Ci, Co]`` (BatchNorm already folded in), ``bias``
+    fp32 ``[G * Co]`` -> ``[B, Ho * Wo, G * Co]`` in ``x``'s dtype."""
+    _hip.require_device("neck_conv3x3", weight=weight, bias=bias)
+    if weight.dim() != 5 or weight.shape[1:3] != (3, 3) or weight.dtype != torch.float32:
+        raise RuntimeError("neck_conv3x3: weight must be fp32 [groups, 3, 3, in_per_group, out_per_group]")
+    G, _, _, ci, co = weight.shape
+    B = x.shape[0]
+    ld = _token_map("neck_conv3x3", "x", x, height * width, G * ci)
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != G * co):
+        raise RuntimeError("neck_conv3x3: bias must be fp32 [groups * out_per_group]")
+    ho, wo = (height - 1) // stride + 1, (width - 1) // stride + 1
+    out = torch.empty((B, ho * wo, G * co), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib().sdetr_neck_conv3x3(_hip.stream_ptr(), x.data_ptr(), _hip.dtype_code(x.dtype), B, height, width,
+                                             ld, weight.data_ptr(), _hip.ptr(bias), G, ci, co, int(stride),
+                                             int(bool(activation)), out.data_ptr())
+    _hip.check(code, "neck_conv3x3")
+    return out
+
+
+def neck_combine(a: Tensor, height: int, width: int, up: Optional[Tensor] = None, up_hw=None,
+                 bias: Optional[Tensor] = None, activation: bool = True) -> Tensor:
+    """``act(a + nearest_upsample(up) + bias)`` on token-major maps: ``a`` ``[B, height * width, C]``, ``up``
+    ``[B, up_hw[0] * up_hw[1], C]`` read at the source pixel of ``F.interpolate(mode="nearest")``."""
+    B, _, C = a.shape
+    lda = _token_map("neck_combine", "a", a, height * width, C)
+    ldu, uh, uw = 0, 0, 0
+    if up is not None:
+        uh, uw = int(up_hw[0]), int(up_hw[1])
+        if up.dtype != a.dtype or up.shape[0] != B or up.shape[2] != C:
+            raise RuntimeError("neck_combine: `up` must have a's dtype, batch and channels")
+        ldu = _token_map("neck_combine", "up", up, uh * uw, C)
+    if bias is not None:
+        _hip.require_device("neck_combine", bias=bias)
+        if bias.dtype != torch.float32 or bias.numel() != C:
+            raise RuntimeError("neck_combine: bias must be fp32 [C]")
+    out = torch.empty((B, height * width, C), dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        code = _hip.lib().sdetr_neck_combine(_hip.stream_ptr(), a.data_ptr(), lda, _hip.ptr(up), ldu, uh, uw,
+                                             _hip.ptr(bias), _hip.dtype_code(a.dtype), B, height, width, C,
+                                             int(bool(activation)), out.data_ptr(), C)
+    _hip.check(code, "neck_combine")
+    return out
+
+
+def neck_gate_shortcut(y: Tensor, mask_weight: Tensor, squeeze_weight: Tensor, excite_weight: Tensor, shortcut: Tensor,
+                       shortcut2: Optional[Tensor] = None) -> Tensor:
+    """``SqueezeAndExcitation(y) + shortcut (+ shortcut2)`` (models/bricks/basic.py:43-54, models/necks/repnet.py:63-64)
+    on token-major maps: ``y`` contiguous ``[B, N, C]``; ``mask_weight`` fp32 ``[C]``, ``squeeze_weight`` ``[R, C]``,
+    ``excite_weight`` ``[C, R]``; the shortcuts may be channel slices of wider buffers."""
+    _hip.require_device("neck_gate_shortcut", y=y, mask_weight=mask_weight, squeeze_weight=squeeze_weight,
+                        excite_weight=excite_weight)
+    B, N, C = y.shape
+    R = squeeze_weight.shape[0]
+    if (mask_weight.numel() != C or tuple(squeeze_weight.shape) != (R, C) or tuple(excite_weight.shape) != (C, R)
+            or any(w.dtype != torch.float32 for w in (mask_weight, squeeze_weight, excite_weight))):
+        raise RuntimeError("neck_gate_shortcut: fp32 weights [C], [R, C], [C, R] expected")
+    _token_map("neck_gate_shortcut", "y", y, N, C)
+    ld1 = _token_map("neck_gate_shortcut", "shortcut", shortcut, N, C)
+    ld2 = _token_map("neck_gate_shortcut", "shortcut2", shortcut2, N, C) if shortcut2 is not None else 0
+    if shortcut.dtype != y.dtype or (shortcut2 is not None and shortcut2.dtype != y.dtype):
+        raise RuntimeError("neck_gate_shortcut: the shortcuts must have y's dtype")
+    lib = _hip.lib()
+    ws_bytes = lib.sdetr_neck_gate_workspace_bytes(B, N, C)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=y.device)
+    gate = torch.empty((B, C), dtype=torch.float32, device=y.device)
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        code = lib.sdetr_neck_gate_shortcut(_hip.stream_ptr(), y.data_ptr(), _hip.dtype_code(y.dtype), B, N, C,
+                                            mask_weight.data_ptr(), squeeze_weight.data_ptr(), excite_weight.data_ptr(),
+                                            R, shortcut.data_ptr(), ld1, _hip.ptr(shortcut2), ld2, ws.data_ptr(),
+                                            ws_bytes, gate.data_ptr(), out.data_ptr())
+    _hip.check(code, "neck_gate_shortcut")
+    return out

@@ -126,7 +126,10 @@ class SalienceTransformer(SalienceEncoderHotPath):
             return_aux=True)
         mask_flatten, spatial_shapes = aux["mask_flatten"], aux["spatial_shapes"]
         level_shapes = pyramid.level_shapes_of(multi_level_masks)
-        if self.neck is not None:
+        if self.neck is not None and hasattr(self.neck, "forward_memory"):
+            # row N3 (salience_neck.py): token-major in, token-major out -- no NCHW round trip
+            memory = self.neck.forward_memory(memory, level_shapes)
+        elif self.neck is not None:  # a foreign neck with the reference's NCHW interface (:185-192)
             B = memory.shape[0]
             feats, cur = {}, 0
             for i, (h, w) in enumerate(level_shapes):
@@ -149,8 +152,10 @@ class SalienceTransformer(SalienceEncoderHotPath):
 def build_salience_transformer(embed_dim=256, num_heads=8, d_ffn=2048, num_encoder_layers=6, num_decoder_layers=6,
                                num_classes=91, num_levels=4, num_points=4, topk_sa=300, max_num_embedding=200,
                                two_stage_num_proposals=900, level_filter_ratio=(0.4, 0.8, 1.0, 1.0),
-                               layer_filter_ratio=(1.0, 0.8, 0.6, 0.6, 0.4, 0.2)) -> SalienceTransformer:
-    """The transformer of ``configs/salience_detr/salience_detr_resnet50_800_1333.py:22-82`` (neck=None) by default."""
+                               layer_filter_ratio=(1.0, 0.8, 0.6, 0.6, 0.4, 0.2),
+                               with_neck: bool = False, neck_groups: int = 4) -> SalienceTransformer:
+    """The transformer of ``configs/salience_detr/salience_detr_resnet50_800_1333.py:22-103``; ``with_neck=True`` adds
+    its RepVGGPluX neck (:57-63, row N3; eval mode only), the default leaves it out."""
     enc_layer = SalienceTransformerEncoderLayer(embed_dim=embed_dim, d_ffn=d_ffn, dropout=0.0, n_heads=num_heads,
                                                 activation=nn.ReLU(inplace=True), n_levels=num_levels,
                                                 n_points=num_points, topk_sa=topk_sa)
@@ -159,5 +164,9 @@ def build_salience_transformer(embed_dim=256, num_heads=8, d_ffn=2048, num_encod
                                                 activation=nn.ReLU(inplace=True), n_levels=num_levels,
                                                 n_points=num_points)
     decoder = SalienceTransformerDecoder(dec_layer, num_decoder_layers, num_classes)
-    return SalienceTransformer(encoder, None, decoder, num_classes, num_levels, two_stage_num_proposals,
+    neck = None
+    if with_neck:
+        from .salience_neck import build_neck
+        neck = build_neck(embed_dim, num_levels, neck_groups)
+    return SalienceTransformer(encoder, neck, decoder, num_classes, num_levels, two_stage_num_proposals,
                                level_filter_ratio, layer_filter_ratio)

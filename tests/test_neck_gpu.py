@@ -1,0 +1,120 @@
+"""GPU: row N3, the RepVGGPluX neck.  Each kernel of include/salience_hip.h (13) against the torch restatement of its
+contract (tests/neck_emulation.py) through the C ABI, then the whole neck against the vectors captured from the
+imported reference (tests/golden/neck_cases.npz) at 1e-3 (fp32), and at the benchmark's pyramid against the oracle."""
+import pytest
+import torch
+
+import neck_emulation as EMU
+from oracle import salience_ref as R
+from salience_detr_amd import filter_ops as FO
+from salience_detr_amd import synthetic as syn
+from salience_detr_amd.salience_neck import build_neck
+from test_neck_cpu import CASES, neck_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(name, *shape):
+    return syn.det_randn("neck_gpu." + name, shape)
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 6e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,h,w,G,ci,co,stride", [
+    (2, 13, 21, 4, 8, 8, 1),      # the 32-channel fixture's grouped block
+    (1, 13, 21, 4, 64, 64, 1),    # the real block: groups of 64
+    (2, 5, 3, 1, 32, 32, 2),      # dense stride-2, smaller than one tile
+    (1, 25, 42, 1, 256, 256, 2),  # the real down-sampling convolution (4 output-channel blocks)
+    (1, 4, 16, 2, 20, 12, 1),     # channel counts that are not multiples of the 16-channel step / 64-channel block
+    (1, 1, 2, 4, 8, 8, 1),        # the coarsest fixture level
+])
+def test_conv3x3_matches_contract(dtype, B, h, w, G, ci, co, stride):
+    x = _rand("x", B, h * w, G * ci).to(dtype)
+    weight = _rand("w", G, 3, 3, ci, co) / (3.0 * ci ** 0.5)
+    bias = 0.1 * _rand("b", G * co)
+    for act in (False, True):
+        want = EMU.conv3x3(x.float(), h, w, weight, bias, stride, act)
+        got = FO.neck_conv3x3(x.to(DEV), h, w, weight.to(DEV), bias.to(DEV), stride, act)
+        assert got.dtype == dtype and got.shape == want.shape
+        assert (got.float().cpu() - want).abs().max() < _tol(dtype), (act,)
+    # the same input as the first half of a wider buffer (row stride 2x), no bias
+    wide = torch.cat([x, torch.full_like(x, 7.0)], 2).to(DEV)
+    got = FO.neck_conv3x3(wide[:, :, :G * ci], h, w, weight.to(DEV), None, stride, False)
+    want = EMU.conv3x3(x.float(), h, w, weight, None, stride, False)
+    assert (got.float().cpu() - want).abs().max() < _tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw,up_hw", [((13, 21), (7, 11)), ((8, 12), (4, 6)), ((100, 168), (50, 84)), ((3, 5), (3, 5)),
+                                      ((2, 3), (1, 2))])
+def test_combine_matches_contract(dtype, hw, up_hw):
+    B, C = 2, 64
+    a = _rand("a", B, hw[0] * hw[1], C).to(dtype)
+    up = _rand("up", B, up_hw[0] * up_hw[1], C).to(dtype)
+    bias = _rand("cb", C)
+    for use_up, use_bias, act in ((True, True, True), (False, True, True), (True, False, False)):
+        want = EMU.combine(a, hw[0], hw[1], up if use_up else None, up_hw, bias if use_bias else None, act)
+        got = FO.neck_combine(a.to(DEV), hw[0], hw[1], up.to(DEV) if use_up else None, up_hw,
+                              bias.to(DEV) if use_bias else None, act)
+        assert (got.float().cpu() - want.float()).abs().max() < (1e-5 if dtype == torch.float32 else 4e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,C", [(2, 273, 256), (1, 6, 32), (2, 16800, 256), (1, 129, 64)])
+def test_gate_shortcut_matches_contract(dtype, B, N, C):
+    R_ = C // 16
+    y = _rand("y", B, N, C).to(dtype)
+    both = _rand("s", B, N, 2 * C).to(dtype)
+    mask = 0.5 * _rand("m", C)
+    squeeze, excite = _rand("sq", R_, C) / C ** 0.5, _rand("ex", C, R_)
+    dev = [t.to(DEV) for t in (mask, squeeze, excite)]
+    both_d = both.to(DEV)
+    for second in (False, True):
+        want = EMU.gate_shortcut(y, mask, squeeze, excite, both[:, :, :C], both[:, :, C:] if second else None)
+        got = FO.neck_gate_shortcut(y.to(DEV), *dev, both_d[:, :, :C], both_d[:, :, C:] if second else None)
+        assert (got.float().cpu() - want.float()).abs().max() < (2e-5 if dtype == torch.float32 else 6e-2)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_neck_matches_reference_vectors(tag):
+    sd, feats, outs = neck_case(tag)
+    net = build_neck(int(feats[0].shape[1]))
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        got = list(net(dict(enumerate(f.to(DEV) for f in feats))).values())
+    for l in range(4):
+        err = (got[l].cpu() - outs[l]).abs().max().item()
+        assert err < 1e-3, (tag, l, err)
+    # bf16 storage: close to the fp32 result
+    shapes = [tuple(f.shape[-2:]) for f in feats]
+    mem = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1).to(DEV)
+    with torch.no_grad():
+        m32 = net.forward_memory(mem, shapes)
+        m16 = net.forward_memory(mem.bfloat16(), shapes)
+    ref = torch.cat([o.flatten(2).transpose(1, 2) for o in outs], 1)
+    assert (m32.cpu() - ref).abs().max() < 1e-3
+    assert m16.dtype == torch.bfloat16
+    assert (m16.float() - m32).abs().mean() < 0.03 and (m16.float() - m32).abs().max() < 0.6
+
+
+def test_neck_benchmark_pyramid_against_oracle():
+    """800x1333 pyramid, 256 channels, one image: the HIP neck against the oracle's restatement (itself pinned to the
+    reference's vectors by tests/test_neck_cpu.py)."""
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    net = build_neck(256)
+    sd = syn.det_state_dict(net.state_dict())
+    net.load_state_dict(sd)
+    feats = [syn.det_randn(f"neck.full.feat{l}", (1, 256, h, w)) for l, (h, w) in enumerate(shapes)]
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    want = R.neck(sd, feats, groups=4)
+    net = net.to(DEV).eval()
+    mem = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1).to(DEV)
+    with torch.no_grad():
+        got = net.forward_memory(mem, shapes).cpu()
+    ref = torch.cat([o.flatten(2).transpose(1, 2) for o in want], 1)
+    assert (got - ref).abs().max() < 1e-3

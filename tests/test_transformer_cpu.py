@@ -36,15 +36,22 @@ def reference_keys_state_dict(d, template):
     return sd
 
 
-def build_product_transformer(d):
+def build_product_transformer(d, neck_fixture=None):
+    """The product transformer with the fixture's hyper-parameters and name-seeded weights; ``neck_fixture``
+    (transformer_small_neck.npz) adds the RepVGGPluX neck and checks the weights against ITS key list."""
     from salience_detr_amd.salience_transformer import build_salience_transformer
     E, heads, d_ffn, enc_layers, dec_layers, classes, topk_sa, max_emb, proposals = d["hyper"].tolist()
     tr = build_salience_transformer(embed_dim=E, num_heads=heads, d_ffn=d_ffn, num_encoder_layers=enc_layers,
                                     num_decoder_layers=dec_layers, num_classes=classes, topk_sa=topk_sa,
                                     max_num_embedding=max_emb, two_stage_num_proposals=proposals,
                                     level_filter_ratio=tuple(d["level_ratio"].tolist()),
-                                    layer_filter_ratio=tuple(d["layer_ratio"].tolist()))
-    sd = reference_keys_state_dict(d, tr.state_dict())
+                                    layer_filter_ratio=tuple(d["layer_ratio"].tolist()),
+                                    with_neck=neck_fixture is not None)
+    if neck_fixture is not None:
+        keyed = dict(hyper=d["hyper"], sd_keys=neck_fixture["sd_keys"], sd_crc=neck_fixture["sd_crc"])
+        sd = reference_keys_state_dict(keyed, tr.state_dict())
+    else:
+        sd = reference_keys_state_dict(d, tr.state_dict())
     tr.load_state_dict(sd)
     return tr.eval(), sd
 
@@ -121,3 +128,20 @@ def test_restated_nms_equals_grid_neighbour_suppression(thr, nb):
     assert got.shape == (2, n)
     for b in range(2):
         assert got[b].tolist() == per_image[b][:n]
+
+
+def test_oracle_transformer_with_neck_matches_reference(gold):
+    """Row N3 in place: the reference transformer WITH its RepVGGPluX neck (transformer_small_neck.npz)."""
+    d, dn = gold, np.load(os.path.join(G, "transformer_small_neck.npz"))
+    _, sd = build_product_transformer(d, dn)
+    assert any(k.startswith("neck.") for k in sd)
+    E, heads, d_ffn, enc_layers, dec_layers, classes, topk_sa, max_emb, proposals = d["hyper"].tolist()
+    feats, masks, pos = inputs(d)
+    out = R.transformer(sd, feats, masks, pos, proposals, heads=heads, topk_sa=topk_sa, enc_layers=enc_layers,
+                        dec_layers=dec_layers)
+    assert (out["memory"] - _t(dn["memory_neck"])).abs().max() < 2e-4
+    assert (out["class_all"] - _t(dn["class_all"])).abs().max() < 5e-4
+    assert (out["enc_outputs_class"] - _t(dn["enc_outputs_class"])).abs().max() < 5e-4
+    assert (out["enc_outputs_coord"] - _t(dn["enc_outputs_coord"])).abs().max() < 2e-5
+    assert (out["outputs_classes"] - _t(dn["outputs_classes"])).abs().max() < 2e-3
+    assert (out["outputs_coords"] - _t(dn["outputs_coords"])).abs().max() < 2e-4

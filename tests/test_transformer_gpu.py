@@ -123,6 +123,21 @@ def test_transformer_small_matches_reference_fixture(gold):
         assert (sal[l].cpu() - _t(d[f"salience{l}"])).abs().max() < 1e-3
 
 
+def test_transformer_with_neck_matches_reference_fixture(gold):
+    """The whole forward with the RepVGGPluX neck between encoder and proposals, as in every reference config."""
+    d, dn = gold, np.load(os.path.join(G, "transformer_small_neck.npz"))
+    tr, sd = build_product_transformer(d, dn)
+    tr = tr.cuda()
+    feats, masks, pos = inputs(d)
+    with torch.no_grad():
+        out_cls, out_box, enc_cls, enc_box, sal = tr([f.cuda() for f in feats], [m.cuda() for m in masks],
+                                                     [p.cuda() for p in pos], None, None, None)
+    assert (enc_cls.cpu() - _t(dn["enc_outputs_class"])).abs().max() < 1e-3
+    assert (enc_box.cpu() - _t(dn["enc_outputs_coord"])).abs().max() < 1e-4
+    assert (out_cls.cpu() - _t(dn["outputs_classes"])).abs().max() < 2e-3
+    assert (out_box.cpu() - _t(dn["outputs_coords"])).abs().max() < 2e-4
+
+
 def test_proposal_stage_on_reference_memory(gold):
     """Row N1 alone, fed the reference's own ``memory``: the selected tokens (after top-k + NMS) are the oracle's,
     bit for bit, and their class / box outputs the fixture's."""
