@@ -2,7 +2,7 @@
 fp16 value maps, 800x1333 + 800x1066, 900 proposals), per stage with stream events (eager) and end to end under a
 hipGraph (static_proposals: no host read-back).
 
-    python benchmarks/transformer_micro.py [--iters 20]
+    python benchmarks/transformer_micro.py [--iters 20] [--neck]     (--neck: with the RepVGGPluX neck, row N3)
 """
 import argparse
 import os
@@ -19,10 +19,11 @@ from salience_detr_amd.salience_transformer import build_salience_transformer  #
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--neck", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     image_sizes = [(800, 1333), (800, 1066)]
-    tr = build_salience_transformer()
+    tr = build_salience_transformer(with_neck=a.neck)
     tr.load_state_dict(syn.det_state_dict(tr.state_dict()))
     tr = tr.eval().to(dev).set_dtype(torch.bfloat16, torch.float16)
     tr.static_proposals = True
@@ -39,11 +40,14 @@ def main():
             return tr(feats, masks, pos, image_sizes=image_sizes, canvas=canvas)
 
     def stages():
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         with torch.no_grad():
             ev[0].record()
             memory, sal, aux = SalienceEncoderHotPath.forward(tr, feats, masks, pos, image_sizes=image_sizes,
                                                               canvas=canvas, return_aux=True)
+            ev[4].record()
+            if tr.neck is not None:
+                memory = tr.neck.forward_memory(memory, shapes)
             ev[1].record()
             enc_cls, enc_box = tr.select_proposals(memory, aux["mask_flatten"], shapes)
             ev[2].record()
@@ -56,13 +60,16 @@ def main():
     for _ in range(5):
         whole()
     torch.cuda.synchronize()
-    acc = [0.0, 0.0, 0.0]
+    acc = [0.0, 0.0, 0.0, 0.0]
     for _ in range(a.iters):
         ev = stages()
         torch.cuda.synchronize()
-        for i in range(3):
+        acc[0] += ev[0].elapsed_time(ev[4])
+        acc[3] += ev[4].elapsed_time(ev[1])
+        for i in range(1, 3):
             acc[i] += ev[i].elapsed_time(ev[i + 1])
-    print("eager per stage (ms): encoder path %.3f, proposals %.3f, decoder %.3f" % tuple(v / a.iters for v in acc), flush=True)
+    print("eager per stage (ms): encoder path %.3f, proposals %.3f, decoder %.3f, neck %.3f" % tuple(v / a.iters for v in acc),
+          flush=True)
 
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):

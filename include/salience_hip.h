@@ -475,6 +475,10 @@ int sdetr_salience_focal_loss_backward(sdetr_stream_t stream, const float *logit
  *     channels read are the first groups * in_per_group of a row); weight fp32 [groups][3][3][in_per_group]
  *     [out_per_group]; bias fp32 [groups * out_per_group] or NULL; out contiguous
  *     [batch, ((height - 1) / stride + 1) * ((width - 1) / stride + 1), groups * out_per_group].
+ *   sdetr_neck_conv3x3_mfma_bf16: the same convolution for bf16 maps on the matrix cores (fp32 accumulate), for
+ *     in_per_group % 16 == 0 and out_per_group % 64 == 0; packed_weight = the fp32 weight above re-laid as bf16 MFMA
+ *     operand fragments by sdetr_neck_pack_conv3x3_bf16 into sdetr_neck_conv3x3_packed_bytes bytes (0: shape not
+ *     supported).  x rows 16-byte aligned, x_row_stride % 8 == 0.
  *   sdetr_neck_combine: out = act(a + nearest_upsample(up) + bias) -- the epilogue of the 1x1 convolutions, whose
  *     GEMMs run on the token rows: `a` [batch, height * width, channels] at the output resolution, `up` (NULL: absent)
  *     [batch, up_height * up_width, channels] read at torch's nearest-neighbour source pixel
@@ -489,6 +493,12 @@ int sdetr_salience_focal_loss_backward(sdetr_stream_t stream, const float *logit
 int sdetr_neck_conv3x3(sdetr_stream_t stream, const void *x, int dtype, int batch_size, int height, int width,
                        int x_row_stride, const float *weight, const float *bias, int groups, int in_per_group,
                        int out_per_group, int stride, int activation, void *out);
+int64_t sdetr_neck_conv3x3_packed_bytes(int groups, int in_per_group, int out_per_group);
+int sdetr_neck_pack_conv3x3_bf16(sdetr_stream_t stream, const float *weight, int groups, int in_per_group,
+                                 int out_per_group, void *packed);
+int sdetr_neck_conv3x3_mfma_bf16(sdetr_stream_t stream, const void *x, int batch_size, int height, int width,
+                                 int x_row_stride, const void *packed_weight, const float *bias, int groups,
+                                 int in_per_group, int out_per_group, int stride, int activation, void *out);
 int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_row_stride, const void *up, int up_row_stride,
                        int up_height, int up_width, const float *bias, int dtype, int batch_size, int height, int width,
                        int channels, int activation, void *out, int out_row_stride);

@@ -81,6 +81,9 @@ SIGNATURES = {
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
     "sdetr_neck_conv3x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "sdetr_neck_conv3x3_packed_bytes": (_i64, [_i, _i, _i]),
+    "sdetr_neck_pack_conv3x3_bf16": (_i, [_p, _p, _i, _i, _i, _p]),
+    "sdetr_neck_conv3x3_mfma_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "sdetr_neck_combine": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_neck_gate_workspace_bytes": (_i64, [_i, _i, _i]),
     "sdetr_neck_gate_shortcut": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i64, _p, _p]),

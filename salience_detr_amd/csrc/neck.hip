@@ -9,7 +9,8 @@
 //   neck_combine_kernel     act(a + nearest_upsample(b) + bias): the epilogue of the 1x1 convolutions, whose
 //                           GEMMs are plain library GEMMs on the token rows
 //   se_context / se_gate / se_apply   the attention-pooled gate of models/bricks/basic.py:29-54 and the shortcut
-// First version: fp32 VALU arithmetic on fp32 or bf16 storage, LDS-tiled; the MFMA form of the 3x3 is the next step.
+// fp32 VALU arithmetic on fp32 or bf16 storage (LDS-tiled conv3x3_tokens_kernel: any channel count, the parity path),
+// and conv3x3_mfma_kernel for bf16 maps with the real neck's channel counts.
 #include "common.h"
 
 namespace sdetr {
@@ -147,6 +148,132 @@ __global__ void __launch_bounds__(kBlock) conv3x3_tokens_kernel(ConvArgs p)
         float4 v = make_float4(acc[q][0] + bias.x, acc[q][1] + bias.y, acc[q][2] + bias.z, acc[q][3] + bias.w);
         if (p.act) v = make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w));
         Store<T>::store4(out + (int64_t)ox * cout, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same convolution on the matrix cores, bf16 in / fp32 accumulate, for channel counts of the real neck
+// (in_per_group % 16 == 0, out_per_group % 64 == 0).  Y^T[out-ch x pixel] = sum over (tap, 16 input channels) of
+// W[32 x 16] X^T[16 x 32] with v_mfma_f32_32x32x16_bf16: the B operand of lane (t = lane % 32, h = lane / 32) is 8
+// consecutive channels of pixel t shifted by the tap -- 16 contiguous bytes of the token-major map, loaded straight
+// from global memory (zero outside the image); the A operands are 1 KB lane-ordered fragments pre-packed by
+// sdetr_neck_pack_conv3x3_bf16.  A wave owns 64 output pixels (linear index over batch x Ho x Wo, so no tile is
+// wasted on narrow levels) x 64 output channels: 4 accumulators, 4 MFMAs per 4 loads.  No LDS, no barriers.
+typedef __bf16 nk_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float nk_f32x16_t __attribute__((ext_vector_type(16)));
+
+struct ConvMfmaArgs {
+    const bf16_t *x;
+    const char *pw;     // fragments [G][CoG/32][9][CiG/16][64 lanes][8] bf16
+    const float *bias;  // [G * CoG] or NULL
+    bf16_t *out;
+    int64_t P;          // B * Ho * Wo
+    int H, W, Ho, Wo, S;
+    int ldx, G, CiG, CoG, act;
+};
+
+__device__ __forceinline__ nk_f32x16_t nk_mfma(uint4 a, uint4 b, nk_f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nk_bf16x8_t, a), __builtin_bit_cast(nk_bf16x8_t, b),
+                                                   c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(kBlock) conv3x3_mfma_kernel(ConvMfmaArgs p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = lane & 31, h = lane >> 5;
+    const int MT = p.CoG / 32, KC = p.CiG / 16;
+    const int cblocks = p.CoG / 64;
+    const int g = blockIdx.y / cblocks, mt0 = (blockIdx.y % cblocks) * 2;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (p0 >= p.P) return;  // whole wave idle (no barriers in this kernel)
+
+    int oy[2], ox[2];
+    int64_t img[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t pix = p0 + u * 32 + t;
+        live[u] = pix < p.P;
+        const int64_t q = live[u] ? pix : 0;
+        const int64_t b = q / ((int64_t)p.Ho * p.Wo);
+        const int rem = (int)(q - b * (int64_t)p.Ho * p.Wo);
+        oy[u] = rem / p.Wo;
+        ox[u] = rem - oy[u] * p.Wo;
+        img[u] = b * p.H;
+    }
+    nk_f32x16_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][u][r] = 0.f;
+
+    const char *wbase = p.pw + ((int64_t)(g * MT + mt0) * 9 * KC) * 1024 + lane * 16;
+    const int64_t mstride = (int64_t)9 * KC * 1024;  // next 32-row tile of output channels
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const bf16_t *src[2];
+        bool inb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int iy = oy[u] * p.S + ky - 1, ix = ox[u] * p.S + kx - 1;
+            inb[u] = live[u] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            src[u] = p.x + ((img[u] + (inb[u] ? iy : 0)) * p.W + (inb[u] ? ix : 0)) * p.ldx + g * p.CiG + h * 8;
+        }
+        const char *wt = wbase + (int64_t)tap * KC * 1024;
+        for (int c = 0; c < KC; ++c) {
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(wt + (int64_t)c * 1024);
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(wt + mstride + (int64_t)c * 1024);
+            uint4 b0 = make_uint4(0u, 0u, 0u, 0u), b1 = make_uint4(0u, 0u, 0u, 0u);
+            if (inb[0]) b0 = *reinterpret_cast<const uint4 *>(src[0] + c * 16);
+            if (inb[1]) b1 = *reinterpret_cast<const uint4 *>(src[1] + c * 16);
+            acc[0][0] = nk_mfma(a0, b0, acc[0][0]);
+            acc[1][0] = nk_mfma(a1, b0, acc[1][0]);
+            acc[0][1] = nk_mfma(a0, b1, acc[0][1]);
+            acc[1][1] = nk_mfma(a1, b1, acc[1][1]);
+        }
+    }
+
+    // lane (t, h), register r of tile m: output channel (mt0 + m) * 32 + 8 * (r / 4) + 4 * h + r % 4 of pixel t
+    const int cout = p.G * p.CoG;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (!live[u]) continue;
+        bf16_t *orow = p.out + (p0 + u * 32 + t) * cout + g * p.CoG;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = (mt0 + m) * 32 + 8 * q + 4 * h;
+                float4 v = make_float4(acc[m][u][4 * q], acc[m][u][4 * q + 1], acc[m][u][4 * q + 2], acc[m][u][4 * q + 3]);
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4 *>(p.bias + g * p.CoG + co);
+                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                }
+                if (p.act) v = make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w));
+                Store<bf16_t>::store4(orow + co, v);
+            }
+        }
+    }
+}
+
+// fp32 [G][3][3][CiG][CoG] -> bf16 fragments [G][CoG/32][9][CiG/16][lane][8]:
+// element j of lane (n = lane % 32, h = lane / 32) = W[g][tap][c16 * 16 + h * 8 + j][mt * 32 + n]
+__global__ void __launch_bounds__(kBlock) conv3x3_pack_kernel(const float *w, int G, int CiG, int CoG, bf16_t *out)
+{
+    const int MT = CoG / 32, KC = CiG / 16;
+    const int64_t n = (int64_t)G * MT * 9 * KC * 512;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t f = e >> 9;
+        const int c16 = (int)(f % KC); f /= KC;
+        const int tap = (int)(f % 9); f /= 9;
+        const int mt = (int)(f % MT);
+        const int g = (int)(f / MT);
+        const int ci = c16 * 16 + (lane >> 5) * 8 + j, co = mt * 32 + (lane & 31);
+        out[e] = (bf16_t)f32_to_bf16_bits(w[(((int64_t)g * 9 + tap) * CiG + ci) * CoG + co]);
     }
 }
 
@@ -380,6 +507,58 @@ extern "C" int sdetr_neck_conv3x3(sdetr_stream_t stream, const void *x, int dtyp
         else hipLaunchKernelGGL((conv3x3_tokens_kernel<bf16_t, 2>), grid, dim3(kBlock), 0, s, a);
     }
     return check_launch("neck_conv3x3");
+}
+
+extern "C" int64_t sdetr_neck_conv3x3_packed_bytes(int groups, int in_per_group, int out_per_group)
+{
+    if (groups <= 0 || in_per_group <= 0 || out_per_group <= 0 || (in_per_group % 16) || (out_per_group % 64)) return 0;
+    return (int64_t)groups * 9 * in_per_group * out_per_group * 2;
+}
+
+extern "C" int sdetr_neck_pack_conv3x3_bf16(sdetr_stream_t stream, const float *weight, int groups, int in_per_group,
+                                            int out_per_group, void *packed)
+{
+    if (sdetr_neck_conv3x3_packed_bytes(groups, in_per_group, out_per_group) == 0)
+        return fail("neck_pack_conv3x3: needs in_per_group %% 16 == 0 and out_per_group %% 64 == 0 (got %d, %d)",
+                    in_per_group, out_per_group);
+    if (!weight || !packed) return fail("neck_pack_conv3x3: null pointer");
+    const int64_t n = (int64_t)groups * 9 * in_per_group * out_per_group;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, weight, groups,
+                       in_per_group, out_per_group, reinterpret_cast<bf16_t *>(packed));
+    return check_launch("neck_pack_conv3x3");
+}
+
+extern "C" int sdetr_neck_conv3x3_mfma_bf16(sdetr_stream_t stream, const void *x, int batch_size, int height, int width,
+                                            int x_row_stride, const void *packed_weight, const float *bias, int groups,
+                                            int in_per_group, int out_per_group, int stride, int activation, void *out)
+{
+    if (batch_size < 0 || height <= 0 || width <= 0) return fail("neck_conv3x3_mfma: bad sizes");
+    if (sdetr_neck_conv3x3_packed_bytes(groups, in_per_group, out_per_group) == 0)
+        return fail("neck_conv3x3_mfma: needs in_per_group %% 16 == 0 and out_per_group %% 64 == 0 (got %d, %d)",
+                    in_per_group, out_per_group);
+    if ((x_row_stride % 8) || x_row_stride < groups * in_per_group)
+        return fail("neck_conv3x3_mfma: the row stride must be a multiple of 8 elements");
+    if (stride != 1 && stride != 2) return fail("neck_conv3x3_mfma: stride %d (1 or 2)", stride);
+    if (activation < 0 || activation > 1) return fail("neck_conv3x3_mfma: bad activation %d", activation);
+    if (batch_size == 0) return 0;
+    if (!x || !packed_weight || !out) return fail("neck_conv3x3_mfma: null pointer");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(packed_weight) & 15))
+        return fail("neck_conv3x3_mfma: x and the packed weights must be 16-byte aligned");
+    ConvMfmaArgs a;
+    a.x = reinterpret_cast<const bf16_t *>(x);
+    a.pw = reinterpret_cast<const char *>(packed_weight);
+    a.bias = bias;
+    a.out = reinterpret_cast<bf16_t *>(out);
+    a.H = height; a.W = width; a.S = stride;
+    a.Ho = (height - 1) / stride + 1;
+    a.Wo = (width - 1) / stride + 1;
+    a.P = (int64_t)batch_size * a.Ho * a.Wo;
+    a.ldx = x_row_stride; a.G = groups; a.CiG = in_per_group; a.CoG = out_per_group; a.act = activation;
+    const int64_t gx = (a.P + 255) / 256;
+    const int64_t gy = (int64_t)groups * (out_per_group / 64);
+    if (gx > 0x7fffffffLL || gy > 65535) return fail("neck_conv3x3_mfma: grid too large");
+    hipLaunchKernelGGL(conv3x3_mfma_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, (hipStream_t)stream, a);
+    return check_launch("neck_conv3x3_mfma");
 }
 
 extern "C" int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_row_stride, const void *up,

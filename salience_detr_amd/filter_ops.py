@@ -868,11 +868,30 @@ def _token_map(what: str, name: str, t: Tensor, pixels: int, channels: int) -> i
     return ld
 
 
+def neck_pack_conv3x3(weight: Tensor) -> Optional[Tensor]:
+    """bf16 MFMA operand fragments of a ``[G, 3, 3, Ci, Co]`` fp32 kernel (``sdetr_neck_pack_conv3x3_bf16``), or None
+    when the matrix-core kernel does not take the shape (it needs Ci % 16 == 0 and Co % 64 == 0)."""
+    _hip.require_device("neck_pack_conv3x3", weight=weight)
+    if weight.dim() != 5 or weight.shape[1:3] != (3, 3) or weight.dtype != torch.float32:
+        raise RuntimeError("neck_pack_conv3x3: weight must be fp32 [groups, 3, 3, in_per_group, out_per_group]")
+    G, _, _, ci, co = weight.shape
+    lib = _hip.lib()
+    nbytes = lib.sdetr_neck_conv3x3_packed_bytes(G, ci, co)
+    if nbytes == 0:
+        return None
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        code = lib.sdetr_neck_pack_conv3x3_bf16(_hip.stream_ptr(), weight.data_ptr(), G, ci, co, packed.data_ptr())
+    _hip.check(code, "neck_pack_conv3x3")
+    return packed
+
+
 def neck_conv3x3(x: Tensor, height: int, width: int, weight: Tensor, bias: Optional[Tensor], stride: int = 1,
-                 activation: bool = False) -> Tensor:
+                 activation: bool = False, packed: Optional[Tensor] = None) -> Tensor:
     """3x3 convolution (padding 1) + bias (+ SiLU) on a token-major map (include/salience_hip.h (13)): ``x``
     ``[B, height * width, >= G * Ci]``, ``weight`` fp32 ``[G, 3, 3, Ci, Co]`` (BatchNorm already folded in), ``bias``
-    fp32 ``[G * Co]`` -> ``[B, Ho * Wo, G * Co]`` in ``x``'s dtype."""
+    fp32 ``[G * Co]`` -> ``[B, Ho * Wo, G * Co]`` in ``x``'s dtype.  With ``packed`` (``neck_pack_conv3x3(weight)``)
+    and a bf16 map the matrix-core kernel runs instead of the fp32 one."""
     _hip.require_device("neck_conv3x3", weight=weight, bias=bias)
     if weight.dim() != 5 or weight.shape[1:3] != (3, 3) or weight.dtype != torch.float32:
         raise RuntimeError("neck_conv3x3: weight must be fp32 [groups, 3, 3, in_per_group, out_per_group]")
@@ -883,6 +902,14 @@ def neck_conv3x3(x: Tensor, height: int, width: int, weight: Tensor, bias: Optio
         raise RuntimeError("neck_conv3x3: bias must be fp32 [groups * out_per_group]")
     ho, wo = (height - 1) // stride + 1, (width - 1) // stride + 1
     out = torch.empty((B, ho * wo, G * co), dtype=x.dtype, device=x.device)
+    if packed is not None and x.dtype == torch.bfloat16 and ld % 8 == 0 and x.data_ptr() % 16 == 0:
+        _hip.require_device("neck_conv3x3", packed=packed)
+        with torch.cuda.device(x.device):
+            code = _hip.lib().sdetr_neck_conv3x3_mfma_bf16(_hip.stream_ptr(), x.data_ptr(), B, height, width, ld,
+                                                           packed.data_ptr(), _hip.ptr(bias), G, ci, co, int(stride),
+                                                           int(bool(activation)), out.data_ptr())
+        _hip.check(code, "neck_conv3x3_mfma")
+        return out
     with torch.cuda.device(x.device):
         code = _hip.lib().sdetr_neck_conv3x3(_hip.stream_ptr(), x.data_ptr(), _hip.dtype_code(x.dtype), B, height, width,
                                              ld, weight.data_ptr(), _hip.ptr(bias), G, ci, co, int(stride),

@@ -16,8 +16,8 @@ How it runs (eval mode):
     with nearest up-sampling, so the coarse half of ``cat([upsample(high), low])`` is multiplied at the COARSE
     resolution (4x fewer rows) and up-sampled inside the combine kernel; ``conv1`` and ``conv2`` of a CSP layer read
     the same input and run as one GEMM of twice the width;
-  * 3x3 convolutions, the attention-pooled gate and the shortcuts are the HIP kernels of
-    ``include/salience_hip.h`` (13).
+  * 3x3 convolutions (fp32 LDS-tiled kernel; bf16 maps with the real channel counts: the MFMA kernel), the
+    attention-pooled gate and the shortcuts are the HIP kernels of ``include/salience_hip.h`` (13).
 Training mode (batch statistics; SyncBatchNorm under DDP) is not built: ``forward`` refuses it.
 """
 from collections import OrderedDict
@@ -86,7 +86,7 @@ class RepVggPluXBlock(nn.Module):
         self.se_module = SqueezeAndExcitation(out_channels)
         self.identity = nn.Identity()
 
-    def folded(self) -> Dict[str, Tensor]:
+    def folded(self, dtype=torch.float32) -> Dict[str, Tensor]:
         w3, b3 = self.conv1.folded()
         w1, b1 = self.conv2.folded()
         alpha = float(self.alpha)
@@ -98,6 +98,7 @@ class RepVggPluXBlock(nn.Module):
         se = self.se_module
         R = se.se_module[0].weight.shape[0]
         return dict(weight=packed, bias=(b3 + alpha * b1).contiguous(),
+                    mfma=FO.neck_pack_conv3x3(packed) if dtype == torch.bfloat16 and packed.is_cuda else None,
                     mask=se.conv_mask.weight.detach().float().reshape(C).contiguous(),
                     squeeze=se.se_module[0].weight.detach().float().reshape(R, C).contiguous(),
                     excite=se.se_module[2].weight.detach().float().reshape(C, R).contiguous())
@@ -127,7 +128,7 @@ class CSPRepPluXLayer(nn.Module):
         w = torch.cat([w1[:, :, 0, 0], w2[:, :, 0, 0]], 0)  # [2 * hidden, in]: conv1's outputs, then conv2's
         half = w.shape[1] // 2
         return dict(first=w[:, :half].to(dtype).contiguous(), second=w[:, half:].to(dtype).contiguous(),
-                    bias=torch.cat([b1, b2]).contiguous(), blocks=[blk.folded() for blk in self.bottlenecks])
+                    bias=torch.cat([b1, b2]).contiguous(), blocks=[blk.folded(dtype) for blk in self.bottlenecks])
 
 
 def _is_silu(act) -> bool:
@@ -186,7 +187,9 @@ class RepVGGPluXNetwork(nn.Module):
             plan["layer"].append(m.folded(dtype))
         for m in self.downsample_blocks:
             w, b = m.folded()  # dense [out, in, 3, 3] -> [1, 3, 3, in, out]
-            plan["down"].append((w.permute(2, 3, 1, 0).contiguous().unsqueeze(0), b.contiguous()))
+            wd = w.permute(2, 3, 1, 0).contiguous().unsqueeze(0)
+            plan["down"].append((wd, b.contiguous(),
+                                 FO.neck_pack_conv3x3(wd) if dtype == torch.bfloat16 and wd.is_cuda else None))
         for m in self.pan_blocks:
             plan["pan"].append(m.folded(dtype))
         self._plan = (tag, plan)
@@ -208,7 +211,7 @@ class RepVGGPluXNetwork(nn.Module):
         x, branch = both[:, :, :C], both[:, :, C:]
         last = len(p["blocks"]) - 1
         for j, blk in enumerate(p["blocks"]):
-            y = FO.neck_conv3x3(x, h, w, blk["weight"], blk["bias"], stride=1, activation=True)
+            y = FO.neck_conv3x3(x, h, w, blk["weight"], blk["bias"], stride=1, activation=True, packed=blk["mfma"])
             x = FO.neck_gate_shortcut(y, blk["mask"], blk["squeeze"], blk["excite"], shortcut=x,
                                       shortcut2=branch if j == last else None)
         if last < 0:
@@ -235,8 +238,8 @@ class RepVGGPluXNetwork(nn.Module):
         outs = [inner[0]]
         for idx in range(L - 1):  # bottom-up
             h, w = shapes[idx]
-            wd, bd = plan["down"][idx]
-            down = FO.neck_conv3x3(outs[-1], h, w, wd, bd, stride=2, activation=True)
+            wd, bd, pd = plan["down"][idx]
+            down = FO.neck_conv3x3(outs[-1], h, w, wd, bd, stride=2, activation=True, packed=pd)
             if down.shape[1] != shapes[idx + 1][0] * shapes[idx + 1][1]:
                 raise RuntimeError("RepVGGPluXNetwork: level sizes are not a stride-2 pyramid")
             outs.append(self._csp(plan["pan"][idx], down, shapes[idx + 1], inner[idx + 1], shapes[idx + 1], False))

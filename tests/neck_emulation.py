@@ -15,7 +15,7 @@ def _tokens(t):
     return t.flatten(2).transpose(1, 2).contiguous()
 
 
-def conv3x3(x, height, width, weight, bias, stride=1, activation=False):
+def conv3x3(x, height, width, weight, bias, stride=1, activation=False, packed=None):
     G, _, _, ci, co = weight.shape
     w = weight.permute(0, 4, 3, 1, 2).reshape(G * co, ci, 3, 3)  # [G][ky][kx][ci][co] -> [G*co, ci, ky, kx]
     y = F.conv2d(_nchw(x[:, :, :G * ci], height, width), w, bias, stride=stride, padding=1, groups=G)

@@ -26,7 +26,8 @@ def _tol(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,h,w,G,ci,co,stride", [
     (2, 13, 21, 4, 8, 8, 1),      # the 32-channel fixture's grouped block
-    (1, 13, 21, 4, 64, 64, 1),    # the real block: groups of 64
+    (2, 13, 21, 4, 64, 64, 1),    # the real block: groups of 64
+    (2, 50, 84, 4, 64, 64, 1),    # ... over many waves, the last one ragged
     (2, 5, 3, 1, 32, 32, 2),      # dense stride-2, smaller than one tile
     (1, 25, 42, 1, 256, 256, 2),  # the real down-sampling convolution (4 output-channel blocks)
     (1, 4, 16, 2, 20, 12, 1),     # channel counts that are not multiples of the 16-channel step / 64-channel block
@@ -41,6 +42,18 @@ def test_conv3x3_matches_contract(dtype, B, h, w, G, ci, co, stride):
         got = FO.neck_conv3x3(x.to(DEV), h, w, weight.to(DEV), bias.to(DEV), stride, act)
         assert got.dtype == dtype and got.shape == want.shape
         assert (got.float().cpu() - want).abs().max() < _tol(dtype), (act,)
+    packed = FO.neck_pack_conv3x3(weight.to(DEV))
+    assert (packed is not None) == (ci % 16 == 0 and co % 64 == 0)
+    if packed is not None and dtype == torch.bfloat16:  # the matrix-core kernel
+        for act in (False, True):
+            want = EMU.conv3x3(x.float(), h, w, weight, bias, stride, act)
+            got = FO.neck_conv3x3(x.to(DEV), h, w, weight.to(DEV), bias.to(DEV), stride, act, packed=packed)
+            assert got.dtype == dtype and got.shape == want.shape
+            assert (got.float().cpu() - want).abs().max() < 6e-2, ("mfma", act)
+        wide = torch.cat([x, torch.full_like(x, 7.0)], 2).to(DEV)
+        got = FO.neck_conv3x3(wide[:, :, :G * ci], h, w, weight.to(DEV), None, stride, False, packed=packed)
+        want = EMU.conv3x3(x.float(), h, w, weight, None, stride, False)
+        assert (got.float().cpu() - want).abs().max() < 6e-2
     # the same input as the first half of a wider buffer (row stride 2x), no bias
     wide = torch.cat([x, torch.full_like(x, 7.0)], 2).to(DEV)
     got = FO.neck_conv3x3(wide[:, :, :G * ci], h, w, weight.to(DEV), None, stride, False)
