@@ -374,49 +374,66 @@ __global__ void __launch_bounds__(kBlock) se_context_kernel(const void *y_, cons
     }
 }
 
-// gate[b, c] = sigmoid(W2 relu(W1 context[b])), W1 [R, C], W2 [C, R]  (basic.py:34-39, bias-free 1x1 convolutions)
-__global__ void __launch_bounds__(kBlock) se_gate_kernel(const float *partial, int nblk, int C, int R, const float *w1,
-                                                         const float *w2, float *gate)
+// gate[b, c] = sigmoid(W2 relu(W1 context[b])), W1 [R, C], W2 [C, R]  (basic.py:34-39, bias-free 1x1 convolutions).
+// One 1024-thread workgroup per image: thread (ch = tid % 256, grp = tid / 256) adds every fourth partial of channel ch.
+constexpr int kGateThreads = 1024;
+
+__global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *partial, int nblk, int C, int R,
+                                                               const float *w1, const float *w2, float *gate)
 {
     __shared__ float ctx[256];
     __shared__ float hid[64];
-    __shared__ float fac[256];
-    __shared__ float stat[2];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const float *part = partial + (int64_t)b * nblk * (C + 2);
-    // global max over the partials, then each partial's factor and the total sum
+    __shared__ float wf[256];
+    __shared__ float red[kGateThreads];
+    const int tid = threadIdx.x, ch = tid & 255, grp = tid >> 8, b = blockIdx.x;
+    const int64_t ld = C + 2;
+    const float *part = partial + (int64_t)b * nblk * ld;
+    // global max over the partials
     float m = -INFINITY;
-    for (int i = tid; i < nblk; i += kBlock) m = fmaxf(m, part[(int64_t)i * (C + 2) + C]);
-    fac[tid] = m;
+    for (int i = tid; i < nblk; i += kGateThreads) m = fmaxf(m, part[i * ld + C]);
+    red[tid] = m;
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if (tid < s) fac[tid] = fmaxf(fac[tid], fac[tid + s]);
+    for (int s = kGateThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
         __syncthreads();
     }
-    const float gM = fac[0];
+    const float gM = red[0];
     __syncthreads();
-    float ssum = 0.f;
-    for (int i = tid; i < nblk; i += kBlock) {
-        const float pm = part[(int64_t)i * (C + 2) + C];
-        ssum += pm == -INFINITY ? 0.f : part[(int64_t)i * (C + 2) + C + 1] * __expf(pm - gM);
-    }
-    fac[tid] = ssum;
-    __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if (tid < s) fac[tid] += fac[tid + s];
-        __syncthreads();
-    }
-    if (tid == 0) stat[0] = fac[0];
-    __syncthreads();
-    const float inv = 1.0f / stat[0];
-    if (tid < C) {
-        float v = 0.f;
-        for (int i = 0; i < nblk; ++i) {
-            const float pm = part[(int64_t)i * (C + 2) + C];
-            if (pm != -INFINITY) v += part[(int64_t)i * (C + 2) + tid] * __expf(pm - gM);
+    // each partial's factor exp(max_i - max) (256 at a time), the total weight, the weighted channel sums
+    float ssum = 0.f, v = 0.f;
+    for (int base = 0; base < nblk; base += 256) {
+        if (tid < 256) {
+            const int i = base + tid;
+            float f = 0.f;
+            if (i < nblk) {
+                const float pm = part[i * ld + C];
+                if (pm != -INFINITY) {
+                    f = __expf(pm - gM);
+                    ssum = fmaf(part[i * ld + C + 1], f, ssum);
+                }
+            }
+            wf[tid] = f;
         }
-        ctx[tid] = v * inv;
+        __syncthreads();
+        const int n = min(256, nblk - base);
+        if (ch < C) {
+            const float *col = part + base * ld + ch;
+#pragma unroll 8
+            for (int k = grp; k < n; k += 4) v = fmaf(col[k * ld], wf[k], v);
+        }
+        __syncthreads();
     }
+    red[tid] = tid < 256 ? ssum : 0.f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+    __syncthreads();
+    red[tid] = ch < C ? v : 0.f;
+    __syncthreads();
+    if (tid < C) ctx[tid] = (red[tid] + red[tid + 256] + red[tid + 512] + red[tid + 768]) * inv;
     __syncthreads();
     if (tid < R) {
         float h = 0.f;
@@ -626,7 +643,7 @@ extern "C" int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, in
                            mask_weight, pixels, channels, nblk, partial);
     int rc = check_launch("neck_gate_shortcut(context)");
     if (rc) return rc;
-    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)batch_size), dim3(kBlock), 0, s, partial, nblk, channels, hidden,
+    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)batch_size), dim3(kGateThreads), 0, s, partial, nblk, channels, hidden,
                        squeeze_weight, excite_weight, gate);
     rc = check_launch("neck_gate_shortcut(gate)");
     if (rc) return rc;
