@@ -178,6 +178,7 @@ __device__ __forceinline__ nk_f32x16_t nk_mfma(uint4 a, uint4 b, nk_f32x16_t c)
                                                    c, 0, 0, 0);
 }
 
+template <bool CHUNK4>  // in_per_group % 64 == 0: k-steps in groups of four
 __global__ void __launch_bounds__(kBlock) conv3x3_mfma_kernel(ConvMfmaArgs p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -223,16 +224,40 @@ __global__ void __launch_bounds__(kBlock) conv3x3_mfma_kernel(ConvMfmaArgs p)
             src[u] = p.x + ((img[u] + (inb[u] ? iy : 0)) * p.W + (inb[u] ? ix : 0)) * p.ldx + g * p.CiG + h * 8;
         }
         const char *wt = wbase + (int64_t)tap * KC * 1024;
-        for (int c = 0; c < KC; ++c) {
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(wt + (int64_t)c * 1024);
-            const uint4 a1 = *reinterpret_cast<const uint4 *>(wt + mstride + (int64_t)c * 1024);
-            uint4 b0 = make_uint4(0u, 0u, 0u, 0u), b1 = make_uint4(0u, 0u, 0u, 0u);
-            if (inb[0]) b0 = *reinterpret_cast<const uint4 *>(src[0] + c * 16);
-            if (inb[1]) b1 = *reinterpret_cast<const uint4 *>(src[1] + c * 16);
-            acc[0][0] = nk_mfma(a0, b0, acc[0][0]);
-            acc[1][0] = nk_mfma(a1, b0, acc[1][0]);
-            acc[0][1] = nk_mfma(a0, b1, acc[0][1]);
-            acc[1][1] = nk_mfma(a1, b1, acc[1][1]);
+        if constexpr (CHUNK4) {
+            // four k-steps at a time: their 16 loads are in flight together (a k-step per load round trip left the
+            // small levels at 36 x ~0.75 us whatever their size)
+            for (int c0 = 0; c0 < KC; c0 += 4) {
+                uint4 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a0[i] = *reinterpret_cast<const uint4 *>(wt + (int64_t)(c0 + i) * 1024);
+                    a1[i] = *reinterpret_cast<const uint4 *>(wt + mstride + (int64_t)(c0 + i) * 1024);
+                    b0[i] = make_uint4(0u, 0u, 0u, 0u);
+                    b1[i] = make_uint4(0u, 0u, 0u, 0u);
+                    if (inb[0]) b0[i] = *reinterpret_cast<const uint4 *>(src[0] + (c0 + i) * 16);
+                    if (inb[1]) b1[i] = *reinterpret_cast<const uint4 *>(src[1] + (c0 + i) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0][0] = nk_mfma(a0[i], b0[i], acc[0][0]);
+                    acc[1][0] = nk_mfma(a1[i], b0[i], acc[1][0]);
+                    acc[0][1] = nk_mfma(a0[i], b1[i], acc[0][1]);
+                    acc[1][1] = nk_mfma(a1[i], b1[i], acc[1][1]);
+                }
+            }
+        } else {
+            for (int c = 0; c < KC; ++c) {
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(wt + (int64_t)c * 1024);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(wt + mstride + (int64_t)c * 1024);
+                uint4 b0 = make_uint4(0u, 0u, 0u, 0u), b1 = make_uint4(0u, 0u, 0u, 0u);
+                if (inb[0]) b0 = *reinterpret_cast<const uint4 *>(src[0] + c * 16);
+                if (inb[1]) b1 = *reinterpret_cast<const uint4 *>(src[1] + c * 16);
+                acc[0][0] = nk_mfma(a0, b0, acc[0][0]);
+                acc[1][0] = nk_mfma(a1, b0, acc[1][0]);
+                acc[0][1] = nk_mfma(a0, b1, acc[0][1]);
+                acc[1][1] = nk_mfma(a1, b1, acc[1][1]);
+            }
         }
     }
 
@@ -341,18 +366,35 @@ __global__ void __launch_bounds__(kBlock) se_context_kernel(const void *y_, cons
     if (on) wm = *reinterpret_cast<const float4 *>(w_mask + c);
     float M = -INFINITY, Ssum = 0.f;
     float4 V = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int p_end = min(N, (blk + 1) * kSePix);
-    for (int pix = blk * kSePix + wave; pix < p_end; pix += 4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (on) v = Store<T>::load4(y + (int64_t)pix * C + c);
-        float m = v.x * wm.x + v.y * wm.y + v.z * wm.z + v.w * wm.w;
+    // a wave owns 32 consecutive pixels, four in flight at a time (one pixel per load round trip made every level
+    // cost the same 18 us)
+    const int w0 = blk * kSePix + wave * (kSePix / 4);
+    const int w_end = min(N, w0 + kSePix / 4);
+    for (int pix = w0; pix < w_end; pix += 4) {
+        float4 v[4];
+        float m[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
-        const float nM = fmaxf(M, m);
-        const float sc = __expf(M - nM), e = __expf(m - nM);  // first pixel: exp(-inf) = 0
-        Ssum = Ssum * sc + e;
-        V.x = V.x * sc + e * v.x; V.y = V.y * sc + e * v.y; V.z = V.z * sc + e * v.z; V.w = V.w * sc + e * v.w;
-        M = nM;
+        for (int i = 0; i < 4; ++i) {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (on && pix + i < w_end) v[i] = Store<T>::load4(y + (int64_t)(pix + i) * C + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = v[i].x * wm.x + v[i].y * wm.y + v[i].z * wm.z + v[i].w * wm.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] += __shfl_xor(m[i], o, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (pix + i < w_end) {  // wave-uniform
+                const float nM = fmaxf(M, m[i]);
+                const float sc = __expf(M - nM), e = __expf(m[i] - nM);  // first pixel: exp(-inf) = 0
+                Ssum = Ssum * sc + e;
+                V.x = V.x * sc + e * v[i].x; V.y = V.y * sc + e * v[i].y;
+                V.z = V.z * sc + e * v[i].z; V.w = V.w * sc + e * v[i].w;
+                M = nM;
+            }
+        }
     }
     if (on) {
         red[wave][c] = V.x; red[wave][c + 1] = V.y; red[wave][c + 2] = V.z; red[wave][c + 3] = V.w;
@@ -574,7 +616,10 @@ extern "C" int sdetr_neck_conv3x3_mfma_bf16(sdetr_stream_t stream, const void *x
     const int64_t gx = (a.P + 255) / 256;
     const int64_t gy = (int64_t)groups * (out_per_group / 64);
     if (gx > 0x7fffffffLL || gy > 65535) return fail("neck_conv3x3_mfma: grid too large");
-    hipLaunchKernelGGL(conv3x3_mfma_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, (hipStream_t)stream, a);
+    if (in_per_group % 64 == 0)
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, (hipStream_t)stream, a);
     return check_launch("neck_conv3x3_mfma");
 }
 

@@ -28,6 +28,7 @@ def _tol(dtype):
     (2, 13, 21, 4, 8, 8, 1),      # the 32-channel fixture's grouped block
     (2, 13, 21, 4, 64, 64, 1),    # the real block: groups of 64
     (2, 50, 84, 4, 64, 64, 1),    # ... over many waves, the last one ragged
+    (1, 9, 9, 2, 32, 64, 1),      # matrix-core kernel's one-k-step-at-a-time form (in_per_group % 64 != 0)
     (2, 5, 3, 1, 32, 32, 2),      # dense stride-2, smaller than one tile
     (1, 25, 42, 1, 256, 256, 2),  # the real down-sampling convolution (4 output-channel blocks)
     (1, 4, 16, 2, 20, 12, 1),     # channel counts that are not multiples of the 16-channel step / 64-channel block
