@@ -90,3 +90,56 @@ def test_neck_refuses_training_mode_and_cpu_tensors():
     net.eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(x)
+
+
+def _patched(monkeypatch):
+    monkeypatch.setattr(FO, "neck_conv3x3", EMU.conv3x3)
+    monkeypatch.setattr(FO, "neck_combine", EMU.combine)
+    monkeypatch.setattr(FO, "neck_gate_shortcut", EMU.gate_shortcut)
+
+
+def test_neck_folded_weights_follow_parameter_updates(monkeypatch):
+    """The folded / packed weights are cached on the module; an in-place update of any parameter or BatchNorm buffer
+    (optimizer step, load_state_dict) must invalidate them."""
+    _patched(monkeypatch)
+    sd, feats, _ = neck_case("small")
+    net = build_neck(32)
+    net.load_state_dict(sd)
+    net.eval()
+    x = dict(enumerate(feats))
+    with torch.no_grad():
+        first = [o.clone() for o in net(x).values()]
+        again = list(net(x).values())
+        assert all(torch.equal(a, b) for a, b in zip(first, again))
+        sd2 = dict(sd)
+        for key in ("pan_blocks.1.bottlenecks.2.conv2.1.running_var", "lateral_convs.0.0.weight",
+                    "layer_blocks.0.bottlenecks.0.se_module.conv_mask.weight"):
+            sd2[key] = sd[key] * 1.5
+        net.load_state_dict(sd2)
+        got = list(net(x).values())
+    want = R.neck(sd2, feats, groups=4)
+    assert any((a - b).abs().max() > 1e-3 for a, b in zip(first, got))
+    for l in range(4):
+        assert (got[l] - want[l]).abs().max() < 5e-5
+
+
+def test_neck_extra_block_and_constructor_checks(monkeypatch):
+    from torch import nn
+    from salience_detr_amd.salience_neck import RepVGGPluXNetwork
+    _patched(monkeypatch)
+    sd, feats, outs = neck_case("ragged")
+    net = RepVGGPluXNetwork([32] * 4, [32] * 4, groups=4, extra_block=True)
+    net.load_state_dict(sd)
+    net.eval()
+    with torch.no_grad():
+        out = net({"a": feats[0], "b": feats[1], "c": feats[2], "d": feats[3]})
+    assert list(out.keys()) == ["a", "b", "c", "d", "pool"]
+    # F.max_pool2d(x, kernel 1, stride 2, padding 0) of the coarsest output (models/necks/repnet.py:242-243)
+    assert torch.equal(out["pool"], torch.nn.functional.max_pool2d(out["d"], 1, 2, 0))
+    assert (out["d"] - outs[3]).abs().max() < 5e-5
+    with pytest.raises(ValueError):
+        RepVGGPluXNetwork([32, 64, 64, 64], [32, 64, 64, 64])          # one channel count on all levels
+    with pytest.raises(ValueError):
+        RepVGGPluXNetwork([32] * 4, [32] * 4, activation=nn.ReLU)      # the kernels implement SiLU
+    with pytest.raises(ValueError):
+        RepVGGPluXNetwork([0, 32, 32, 32], [32] * 4)                   # as the reference (repnet.py:147-149)
