@@ -315,7 +315,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     roofline = {
-        "kernel": "sdetr::msda_gather_kernel (fused softmax + sampling locations + bilinear gather)",
+        "kernel": "sdetr::msda_gather_l4p4_kernel<half_t | bf16> (fused softmax + sampling locations + bilinear gather)",
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(total_bytes / nl),
