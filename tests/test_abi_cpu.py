@@ -40,6 +40,18 @@ def test_argument_rejection_without_gpu(libpath):
     assert lib.sdetr_topk_workspace_bytes(2, 1050, 1050) == 16  # one float: the masked-fill value
     assert lib.sdetr_topk_workspace_bytes(2, 11363, 300) == 16 + 2 * 11363 * 8 + 2 * 4 + 16  # + prefilter candidates
     assert lib.sdetr_topk_workspace_bytes(0, 5, 1) == 0
+    # neck (13)
+    assert lib.sdetr_neck_conv3x3(None, None, 0, 1, 4, 4, 32, None, None, 4, 8, 8, 3, 0, None) == _hip.EINVAL
+    assert b"stride" in lib.sdetr_last_error()
+    assert lib.sdetr_neck_conv3x3(None, None, 0, 1, 4, 4, 32, None, None, 4, 6, 8, 1, 0, None) == _hip.EINVAL  # 6 % 4
+    assert lib.sdetr_neck_conv3x3_mfma_bf16(None, None, 1, 4, 4, 32, None, None, 4, 8, 8, 1, 0, None) == _hip.EINVAL
+    assert b"in_per_group" in lib.sdetr_last_error()
+    assert lib.sdetr_neck_pack_conv3x3_bf16(None, None, 4, 8, 8, None) == _hip.EINVAL
+    assert lib.sdetr_neck_combine(None, None, 6, None, 0, 0, 0, None, 0, 1, 2, 2, 6, 1, None, 6) == _hip.EINVAL
+    assert lib.sdetr_neck_gate_shortcut(None, None, 0, 1, 16, 512, None, None, None, 32, None, 512, None, 0, None, 0,
+                                        None, None) == _hip.EINVAL
+    assert b"at most 256" in lib.sdetr_last_error()
+    assert lib.sdetr_neck_conv3x3(None, None, 0, 0, 4, 4, 32, None, None, 4, 8, 8, 1, 0, None) == 0   # empty batch
 
 
 def test_no_cpu_fallback():
