@@ -540,13 +540,26 @@ def silu(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv_norm(sd: SD, prefix: str, x: torch.Tensor, stride: int = 1, groups: int = 1, act: bool = True,
-              eps: float = 1e-5) -> torch.Tensor:
-    """Conv2dNormActivation in eval mode (models/bricks/misc.py:61-103): bias-free convolution with "same" padding,
-    BatchNorm2d on its running statistics, optional SiLU.  ``prefix.0`` is the convolution, ``prefix.1`` the norm."""
+              eps: float = 1e-5, new_stats: Optional[SD] = None, momentum: float = 0.1) -> torch.Tensor:
+    """Conv2dNormActivation (models/bricks/misc.py:61-103): bias-free convolution with "same" padding, BatchNorm2d,
+    optional SiLU.  ``prefix.0`` is the convolution, ``prefix.1`` the norm.  Eval mode (``new_stats`` None): the
+    running statistics.  Training mode (``new_stats`` a dict): the batch statistics over (B, H, W) -- biased variance
+    for the normalisation -- and the updated running statistics (momentum 0.1, UNBIASED variance, as nn.BatchNorm2d;
+    single process, i.e. what SyncBatchNorm computes over all ranks' pixels) are written into ``new_stats``."""
     w = sd[prefix + "0.weight"]
     y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2, groups=groups)
-    inv = torch.rsqrt(sd[prefix + "1.running_var"] + eps) * sd[prefix + "1.weight"]
-    y = (y - sd[prefix + "1.running_mean"].view(1, -1, 1, 1)) * inv.view(1, -1, 1, 1) + sd[prefix + "1.bias"].view(1, -1, 1, 1)
+    if new_stats is None:
+        mean, var = sd[prefix + "1.running_mean"], sd[prefix + "1.running_var"]
+    else:
+        mean = y.mean((0, 2, 3))
+        var = y.var((0, 2, 3), unbiased=False)
+        n = y.numel() // y.shape[1]
+        with torch.no_grad():
+            new_stats[prefix + "1.running_mean"] = (1 - momentum) * sd[prefix + "1.running_mean"] + momentum * mean
+            new_stats[prefix + "1.running_var"] = (1 - momentum) * sd[prefix + "1.running_var"] \
+                + momentum * var * (n / max(n - 1, 1))
+    inv = torch.rsqrt(var + eps) * sd[prefix + "1.weight"]
+    y = (y - mean.view(1, -1, 1, 1)) * inv.view(1, -1, 1, 1) + sd[prefix + "1.bias"].view(1, -1, 1, 1)
     return silu(y) if act else y
 
 
@@ -562,36 +575,41 @@ def attention_pool_gate(sd: SD, prefix: str, x: torch.Tensor) -> torch.Tensor:
     return gate.view(B, C, 1, 1) * x
 
 
-def repvgg_block(sd: SD, prefix: str, x: torch.Tensor, groups: int) -> torch.Tensor:
+def repvgg_block(sd: SD, prefix: str, x: torch.Tensor, groups: int, new_stats: Optional[SD] = None) -> torch.Tensor:
     """RepVggPluXBlock.forward (models/necks/repnet.py:61-64) with in == out channels (identity shortcut, alpha = 1):
     grouped 3x3 + grouped 1x1, each with its own BatchNorm, SiLU, the attention-pooled gate, plus x."""
-    y = conv_norm(sd, prefix + "conv1.", x, groups=groups, act=False) + conv_norm(sd, prefix + "conv2.", x, groups=groups, act=False)
+    y = conv_norm(sd, prefix + "conv1.", x, groups=groups, act=False, new_stats=new_stats) \
+        + conv_norm(sd, prefix + "conv2.", x, groups=groups, act=False, new_stats=new_stats)
     return attention_pool_gate(sd, prefix + "se_module.", silu(y)) + x
 
 
-def csp_layer(sd: SD, prefix: str, x: torch.Tensor, groups: int, num_blocks: int = 3) -> torch.Tensor:
+def csp_layer(sd: SD, prefix: str, x: torch.Tensor, groups: int, num_blocks: int = 3,
+              new_stats: Optional[SD] = None) -> torch.Tensor:
     """CSPRepPluXLayer.forward (repnet.py:120-123), expansion 1 (conv3 is the identity)."""
-    y = conv_norm(sd, prefix + "conv1.", x)
+    y = conv_norm(sd, prefix + "conv1.", x, new_stats=new_stats)
     for j in range(num_blocks):
-        y = repvgg_block(sd, f"{prefix}bottlenecks.{j}.", y, groups)
-    return y + conv_norm(sd, prefix + "conv2.", x)
+        y = repvgg_block(sd, f"{prefix}bottlenecks.{j}.", y, groups, new_stats)
+    return y + conv_norm(sd, prefix + "conv2.", x, new_stats=new_stats)
 
 
-def neck(sd: SD, feats: Sequence[torch.Tensor], groups: int = 4) -> List[torch.Tensor]:
+def neck(sd: SD, feats: Sequence[torch.Tensor], groups: int = 4, new_stats: Optional[SD] = None) -> List[torch.Tensor]:
     """RepVGGPluXNetwork.forward (repnet.py:211-245) on NCHW levels, fine to coarse; ``sd`` holds the neck's own keys
-    (``lateral_convs.*``, ``layer_blocks.*``, ``downsample_blocks.*``, ``pan_blocks.*``).  Eval mode only: the
-    batch-statistics (training / SyncBN) form of the norms is outside this restatement."""
+    (``lateral_convs.*``, ``layer_blocks.*``, ``downsample_blocks.*``, ``pan_blocks.*``).  ``new_stats`` None: eval
+    mode (what the HIP path implements); a dict: training mode, see ``conv_norm`` (restated for the next round's
+    training form of the neck; differentiable through torch autograd)."""
     L = len(feats)
     inner = [feats[-1]]
     for idx in range(L - 1, 0, -1):  # top-down
-        high = conv_norm(sd, f"lateral_convs.{idx - 1}.", inner[0])
+        high = conv_norm(sd, f"lateral_convs.{idx - 1}.", inner[0], new_stats=new_stats)
         inner[0] = high
         up = F.interpolate(high, size=feats[idx - 1].shape[-2:], mode="nearest")
-        inner.insert(0, csp_layer(sd, f"layer_blocks.{idx - 1}.", torch.cat([up, feats[idx - 1]], 1), groups))
+        inner.insert(0, csp_layer(sd, f"layer_blocks.{idx - 1}.", torch.cat([up, feats[idx - 1]], 1), groups,
+                                  new_stats=new_stats))
     outs = [inner[0]]
     for idx in range(L - 1):  # bottom-up
-        down = conv_norm(sd, f"downsample_blocks.{idx}.", outs[-1], stride=2)
-        outs.append(csp_layer(sd, f"pan_blocks.{idx}.", torch.cat([down, inner[idx + 1]], 1), groups))
+        down = conv_norm(sd, f"downsample_blocks.{idx}.", outs[-1], stride=2, new_stats=new_stats)
+        outs.append(csp_layer(sd, f"pan_blocks.{idx}.", torch.cat([down, inner[idx + 1]], 1), groups,
+                              new_stats=new_stats))
     return outs
 
 

@@ -143,3 +143,32 @@ def test_neck_extra_block_and_constructor_checks(monkeypatch):
         RepVGGPluXNetwork([32] * 4, [32] * 4, activation=nn.ReLU)      # the kernels implement SiLU
     with pytest.raises(ValueError):
         RepVGGPluXNetwork([0, 32, 32, 32], [32] * 4)                   # as the reference (repnet.py:147-149)
+
+
+def test_oracle_neck_training_mode_matches_reference():
+    """Batch-statistics form (what the reference trains with; SyncBatchNorm over all ranks' pixels equals this on one
+    process): outputs, updated running statistics and gradients of a probe loss against the imported reference.  The
+    HIP neck is eval-only this round; this pins the checker the training form will be held to."""
+    d = np.load(os.path.join(G, "neck_cases.npz"))
+    sd, feats, _ = neck_case("small")
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    feats = [f.clone().requires_grad_(True) for f in feats]
+    stats = {}
+    outs = R.neck(sd, feats, groups=4, new_stats=stats)
+    probes = [syn.det_randn(f"neck.train.probe{l}", o.shape) for l, o in enumerate(outs)]
+    loss = sum((o * p).sum() for o, p in zip(outs, probes))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(d["train.loss"])) < 2e-3
+    for l in range(4):
+        assert (outs[l].detach() - _t(d[f"train.out{l}"])).abs().max() < 5e-5, l
+        assert (feats[l].grad - _t(d[f"train.grad_feat{l}"])).abs().max() < 2e-4, l
+    stat_keys = [k[len("train.stat."):] for k in d.files if k.startswith("train.stat.")]
+    grad_keys = [k[len("train.grad."):] for k in d.files if k.startswith("train.grad.")]
+    assert len(stat_keys) == 5 and len(grad_keys) == 4
+    for k in stat_keys:
+        assert (stats[k] - _t(d["train.stat." + k])).abs().max() < 1e-5, k
+    for k in grad_keys:
+        ref = _t(d["train.grad." + k])
+        assert (sd[k].grad - ref).abs().max() < 2e-4 * max(1.0, float(ref.abs().max())), k
+    # every norm of the neck reported new statistics: 3 lateral + 3 down + 6 CSP layers x (2 + 3 blocks x 2)
+    assert len(stats) == 2 * (3 + 3 + 6 * 8)
