@@ -221,7 +221,10 @@ def main():
                 step()
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # N > 1: the process group's helper threads exist by now; thread-local capture mode keeps anything they
+            # might call from invalidating this thread's capture (no collective is captured: the data path has none)
+            capture_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
+            with torch.cuda.graph(g, **capture_kw):
                 out = step()
             g.replay()
             torch.cuda.synchronize()
