@@ -259,26 +259,39 @@ def main():
     msda_events, layer_events, launches, launch_nq = [], [], [], []
     real_fused = msda_mod.msda_fused_forward
 
-    def timed_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
-                    order=None, out_dtype=None, proj_head_major=False):
-        o = real_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
-                       order=order, out_dtype=out_dtype, proj_head_major=proj_head_major)
-        # the step's own launch is above; the SAME launch (same operands, straight after its producers) is then
+    kernels_used = []
+
+    def record(real_call, value_hm, reference_points, proj, head_major, o, kernel):
+        # the step's own launch is done (o); the SAME launch (same operands, straight after its producers) is then
         # repeated back to back between two events on the launch stream, so the measured time is kernel time
         # (what rocprofv3 --kernel-trace reports), not host launch gaps of the eager instrumented pass
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(MSDA_REPEATS):
-            real_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
-                       order=order, out_dtype=out_dtype, proj_head_major=proj_head_major)
+            real_call()
         e1.record()
         msda_events.append((e0, e1))
         B, M, Nv, D = value_hm.shape
-        nq = int(proj.shape[2] if proj_head_major else proj.shape[1])
+        nq = int(proj.shape[2] if head_major else proj.shape[1])
         launch_nq.append(nq)
-        launches.append(algorithmic_bytes(B, Nv, nq, M, D, num_levels, num_points,
-                                          value_hm.element_size(), proj.element_size(), o.element_size(),
-                                          reference_points.shape[-1]))
+        kernels_used.append(kernel)
+        launches.append(algorithmic_bytes(B, Nv, nq, M, D, 4, 4, value_hm.element_size(), proj.element_size(),
+                                          o.element_size(), reference_points.shape[-1]))
+
+    def timed_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
+                    order=None, out_dtype=None, proj_head_major=False):
+        call = lambda: real_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels,
+                                  num_points, order=order, out_dtype=out_dtype, proj_head_major=proj_head_major)
+        o = call()
+        record(call, value_hm, reference_points, proj, proj_head_major, o, "msda_gather_l4p4_kernel<half_t>")
+        return o
+
+    real_resident = msda_mod.msda_resident_forward
+
+    def timed_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=None, chunks=0):
+        call = lambda: real_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=out_dtype, chunks=chunks)
+        o = call()
+        record(call, value_hm, reference_points, proj_hm, True, o, "msda_resident_kernel<half_t>")
         return o
 
     def marker(layer_id):
@@ -287,11 +300,13 @@ def main():
         layer_events.append((layer_id, e))
 
     msda_mod.msda_fused_forward = timed_fused
+    msda_mod.msda_resident_forward = timed_resident
     model.encoder.layer_marker = marker
     for _ in range(args.instrumented_steps):
         step()
     torch.cuda.synchronize()
     msda_mod.msda_fused_forward = real_fused
+    msda_mod.msda_resident_forward = real_resident
     model.encoder.layer_marker = None
 
     nl = model.encoder.num_layers
@@ -318,7 +333,9 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     roofline = {
-        "kernel": "sdetr::msda_gather_l4p4_kernel<half_t | bf16> (fused softmax + sampling locations + bilinear gather)",
+        "kernel": "sdetr::" + " / ".join(sorted(set(kernels_used[:nl])))
+                  + " (fused softmax + sampling locations + bilinear gather)",
+        "kernel_per_layer": kernels_used[:nl],
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(total_bytes / nl),

@@ -137,6 +137,28 @@ int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm_bf16,
                              const int32_t *region_box, int num_regions, int batch_size, int spatial_size, int num_heads, int channels,
                              int num_levels, int num_query, int num_point, void *out, int out_dtype);
 
+/* Coarse-levels-in-LDS variant of sdetr_msda_fused_forward (csrc/msda_resident.hip): one persistent 1024-thread
+ * workgroup per CU copies levels 2 and 3 of its (image, head) into LDS once and serves their samples from there, so
+ * the vector memory path only carries the level-0 / level-1 samples.  Same arithmetic and results as the direct
+ * kernel.  Shape: 4 levels, 4 points, 32 channels per head, fp16 | bf16 head-major value, bf16 head-major projection
+ * slab [B,M,Nq,48], levels 2+3 no larger than sdetr_msda_resident_max_pixels() pixels.
+ *   level_hw_host: HOST pointer to the 4 (H, W) pairs as int32 (the kernel takes the geometry as launch arguments
+ *                  instead of reading data_spatial_shapes / data_level_start_index from device memory)
+ *   chunks:        workgroups per (image, head); <= 0 = one workgroup per CU
+ * sdetr_msda_last_kernel(): which forward kernel the calling thread's last MSDA forward call dispatched to
+ *   (SDETR_KERNEL_*; lets a parity test assert that it exercised the kernel it names). */
+#define SDETR_KERNEL_MSDA_GENERIC 1  /* one thread per output element, reference layout, any shape */
+#define SDETR_KERNEL_MSDA_GATHER 2   /* msda_gather_kernel: lane groups per row, LDS descriptor table */
+#define SDETR_KERNEL_MSDA_L4P4 3     /* msda_gather_l4p4_kernel: the Salience-DETR shape, direct gather */
+#define SDETR_KERNEL_MSDA_RESIDENT 4 /* msda_resident_kernel: levels 2+3 resident in LDS */
+#define SDETR_KERNEL_MSDA_TILED 5    /* msda_tiled_kernel: per-region windows staged in LDS */
+int sdetr_msda_resident_max_pixels(void);
+int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                const int32_t *level_hw_host, const float *ref_points, int ref_dim,
+                                int64_t ref_batch_stride, const void *proj_head_major_bf16, int batch_size,
+                                int spatial_size, int num_heads, int num_query, void *out, int out_dtype, int chunks);
+int sdetr_msda_last_kernel(void);
+
 /* Same gather on a head-major value with explicit sampling locations / weights (the reference
  * op's math on the native layout); loc/aw as in (1), fp32. */
 int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, int value_dtype,

@@ -105,4 +105,11 @@ __device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t r, uint32_
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 buffer_load8(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    return make_uint2(v.x, v.y);
+}
+
 }  // namespace sdetr

@@ -21,6 +21,8 @@
 
 namespace sdetr {
 
+void note_forward_kernel(int which);  // abi.hip
+
 constexpr int kChunk = 16;  // samples staged per LDS round
 
 template <typename VT>
@@ -529,6 +531,7 @@ static int launch_gather_l4p4(hipStream_t stream, GatherArgs &a)
     if (blocks > 0x7fffffffLL) return fail("msda: grid too large");
     const size_t lds = (size_t)GPB * (16 * 8 + 4) * 4;
     hipLaunchKernelGGL((msda_gather_l4p4_kernel<VT>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    note_forward_kernel(SDETR_KERNEL_MSDA_L4P4);
     return check_launch("msda_gather_l4p4");
 }
 
@@ -583,6 +586,7 @@ static int launch_gather(hipStream_t stream, GatherArgs &a)
     if (blocks > 0x7fffffffLL) return fail("msda: grid too large");
     const size_t lds = (size_t)(GPB * (kChunk * 8 + 4) + kMaxLevels * 5) * 4 + kChunk;
     hipLaunchKernelGGL((msda_gather_kernel<VT, D, HM, FUSED>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    note_forward_kernel(SDETR_KERNEL_MSDA_GATHER);
     return check_launch("msda_gather");
 }
 
@@ -635,6 +639,7 @@ extern "C" int sdetr_msda_im2col_f32(sdetr_stream_t stream, const float *value, 
     const int64_t blocks = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(msda_generic_kernel<float>, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)),
                        dim3(kBlock), 0, stream, n, value, shapes, lsi, loc, aw, Nv, M, D, L, Nq, P, out);
+    note_forward_kernel(SDETR_KERNEL_MSDA_GENERIC);
     return check_launch("msda_generic_f32");
 }
 
@@ -649,6 +654,7 @@ extern "C" int sdetr_msda_im2col_f64(sdetr_stream_t stream, const double *value,
     const int64_t blocks = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(msda_generic_kernel<double>, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)),
                        dim3(kBlock), 0, stream, n, value, shapes, lsi, loc, aw, Nv, M, D, L, Nq, P, out);
+    note_forward_kernel(SDETR_KERNEL_MSDA_GENERIC);
     return check_launch("msda_generic_f64");
 }
 

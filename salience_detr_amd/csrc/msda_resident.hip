@@ -1,0 +1,407 @@
+// Multi-scale deformable attention forward with the two COARSE levels of the value pyramid resident in LDS
+// (gfx950, the Salience-DETR shape: head-major 16-bit value, 32 channels per head, 4 levels, 4 points).
+//
+// Semantics: models/bricks/ops/cuda/ms_deform_im2col_cuda.cuh:22-73, 226-288 (bilinear gather-reduce) fused with
+// models/bricks/ms_deform_attn.py:322-355 (softmax over the 16 logits, sampling locations from the reference
+// points and the projected offsets), exactly as msda_gather_l4p4_kernel (msda_forward.hip) computes them.
+//
+// Why this shape.  The direct gather moves 16 samples x 4 corners x 64 bytes per (query, head) through the vector
+// memory path: 745 MB per launch at encoder layer 0 (2 x 11 363 queries), 19 us at the L1's 64 B/clk/CU before any
+// arithmetic -- for 53 MB of algorithmic bytes.  Half of those samples fall on levels 2 and 3, whose maps are small:
+// (25x42 + 13x21) pixels x 64 B = 85 KB per (image, head).  So:
+//
+//  * one 1024-thread workgroup per CU, persistent over a chunk of one (image, head)'s queries.  It copies that
+//    head's level-2 and level-3 maps into LDS ONCE (coalesced 16-byte loads; 85 KB of the CU's 160 KB), then
+//    every sample of those levels is four ds_read_b128 instead of four L1 line fetches: the vector memory path
+//    carries only the level-0 / level-1 samples (half the bytes), the LDS (128-256 B/clk/CU) the other half, and
+//    the two pipes run side by side;
+//  * no spatial bucketing of the queries, no windows, no fallback path: the coarse maps are resident as a whole,
+//    so any sampling location is served (the LDS-windowed kernel of round 1 needed all three);
+//  * blockIdx % 8 = head, and block b runs on XCD b % 8: an XCD's L2 only ever sees its own head's slabs;
+//  * a quad of lanes owns one (query, head) row, lane j of the quad owns level j's four points for the set-up
+//    (softmax across the quad by two DPP shuffles) and 8 of the 32 channels for the gather.  The four bilinear x
+//    attention weights of a sample travel through a wave-private LDS table (one ds_read_b128 per sample, all 16
+//    quads in one conflict-free 256-byte row); the two row offsets of a sample stay in the owner lane's registers
+//    and reach the other three lanes through the DPP operand of the address add they need anyway;
+//  * a sample's two x-neighbours are ONE 128-byte span (pixel xa and xa+1 of a head-major row), addressed by the
+//    instruction's immediate offset: two address computations per sample instead of four.  At the left border the
+//    span starts at pixel 0 and the weights shift over; at the right border the second pixel has weight zero (it
+//    is the next row's first pixel, or the 64-byte zero pad after the resident slab).
+#include "common.h"
+
+namespace sdetr {
+
+void note_forward_kernel(int which);  // abi.hip
+
+constexpr int kRWaves = 16;                      // waves per workgroup, one workgroup per CU
+constexpr int kRThreads = kRWaves * kWave;       // 1024
+constexpr int kRWeightBytes = 16 * 16 * 16;      // per wave: [sample 16][row 16] float4
+constexpr int kRPad = 64;                        // zeroed pixel before and after the resident slab
+constexpr int kRStage = 6;                       // 16-byte pieces per thread while staging
+constexpr int kRLdsBudget = 160 * 1024;
+constexpr int kRMaxResidentPx = (kRLdsBudget - kRWaves * kRWeightBytes - 2 * kRPad) / 64;  // 1534 pixels
+static_assert(kRMaxResidentPx * 4 <= kRStage * kRThreads, "staging loop covers the largest resident slab");
+
+struct ResidentArgs {
+    const char *value;        // [B, M, Nv, 32] fp16 | bf16
+    const float *ref;         // [B, Nq, 4, ref_dim]
+    int64_t ref_batch_stride; // floats between images
+    int ref_dim;
+    const bf16_t *proj;       // [B, M, Nq, 48] bf16: 32 offsets (x,y per level, point) then 16 logits
+    void *out;                // [B, Nq, M*32]
+    int out_bf16;
+    int B, Nv, M, Nq;
+    int H0, W0, H1, W1, H2, W2, H3, W3;   // host copy of the level shapes
+    int S1, S2, S3;                       // level start pixels (S0 = 0)
+    int res_px;                           // Nv - S2: pixels resident in LDS
+    int chunks;                           // workgroups per (image, head)
+};
+
+template <typename VT>
+struct ResFma;
+template <>
+struct ResFma<half_t> {
+    __device__ static __forceinline__ void fma8(float *acc, const uint4 &v, float w)
+    {
+        acc[0] = fma_f16lo(v.x, w, acc[0]);
+        acc[1] = fma_f16hi(v.x, w, acc[1]);
+        acc[2] = fma_f16lo(v.y, w, acc[2]);
+        acc[3] = fma_f16hi(v.y, w, acc[3]);
+        acc[4] = fma_f16lo(v.z, w, acc[4]);
+        acc[5] = fma_f16hi(v.z, w, acc[5]);
+        acc[6] = fma_f16lo(v.w, w, acc[6]);
+        acc[7] = fma_f16hi(v.w, w, acc[7]);
+    }
+};
+template <>
+struct ResFma<bf16_t> {
+    __device__ static __forceinline__ void fma8(float *acc, const uint4 &v, float w)
+    {
+        acc[0] = fmaf(w, bf16_lo(v.x), acc[0]);
+        acc[1] = fmaf(w, bf16_hi(v.x), acc[1]);
+        acc[2] = fmaf(w, bf16_lo(v.y), acc[2]);
+        acc[3] = fmaf(w, bf16_hi(v.y), acc[3]);
+        acc[4] = fmaf(w, bf16_lo(v.z), acc[4]);
+        acc[5] = fmaf(w, bf16_hi(v.z), acc[5]);
+        acc[6] = fmaf(w, bf16_lo(v.w), acc[6]);
+        acc[7] = fmaf(w, bf16_hi(v.w), acc[7]);
+    }
+};
+
+// value of lane J of this lane's quad (DPP quad_perm broadcast; folds into the consuming VALU instruction)
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
+}
+
+template <typename VT, bool REF4, int GB>
+__global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p)
+{
+    using F = ResFma<VT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // [64 B zeros][resident slab: levels 2, 3][64 B zeros][weights: kRWaves x 4 KB]
+    const int slab_bytes = p.res_px * 64;
+    float4 *wts = reinterpret_cast<float4 *>(lds + 2 * kRPad + slab_bytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = blockIdx.x % p.M;
+    const int rest = blockIdx.x / p.M;
+    const int b = rest / p.chunks;
+    const int chunk = rest - b * p.chunks;
+    const int rows_per_chunk = (p.Nq + p.chunks - 1) / p.chunks;
+    const int q_lo = chunk * rows_per_chunk;
+    const int q_hi = min(p.Nq, q_lo + rows_per_chunk);
+    if (q_lo >= q_hi) return;  // workgroup-uniform
+
+    const char *base = p.value + ((int64_t)b * p.M + m) * p.Nv * 64;
+
+    // ---- stage levels 2 and 3 of this (image, head): every load is issued before the first LDS store.  Pieces past
+    // the slab are stored as zeros: the first four of them ARE the zero pad behind the slab, the rest land in the
+    // (not yet used) weight tables -- no per-piece branch, so the loads stay one batch (the launcher sizes the
+    // allocation for kRStage full rounds) ----
+    {
+        const int npieces = p.res_px * 4;
+        const char *src = base + (int64_t)p.S2 * 64;
+        uint4 v[kRStage];
+#pragma unroll
+        for (int i = 0; i < kRStage; ++i) {
+            const int piece = tid + i * kRThreads;
+            v[i] = *reinterpret_cast<const uint4 *>(src + (int64_t)min(piece, npieces - 1) * 16);
+        }
+        if (tid < 4) *reinterpret_cast<uint4 *>(lds + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < kRStage; ++i) {
+            const int piece = tid + i * kRThreads;
+            const bool real = piece < npieces;
+            *reinterpret_cast<uint4 *>(lds + kRPad + piece * 16) =
+                make_uint4(real ? v[i].x : 0u, real ? v[i].y : 0u, real ? v[i].z : 0u, real ? v[i].w : 0u);
+        }
+    }
+    __syncthreads();
+
+    // ---- rows: a quad per (query, head); lane j of the quad owns level j ----
+    const int g = lane >> 2, j = lane & 3;
+    const int H = j == 0 ? p.H0 : j == 1 ? p.H1 : j == 2 ? p.H2 : p.H3;
+    const int W = j == 0 ? p.W0 : j == 1 ? p.W1 : j == 2 ? p.W2 : p.W3;
+    const int S = j == 0 ? 0 : j == 1 ? p.S1 : j == 2 ? p.S2 : p.S3;
+    const float fH = (float)H, fW = (float)W;
+    const float invW = 1.0f / fW, invH = 1.0f / fH;
+    // byte offset of this lane's level: into the head's global slab (levels 0, 1) or into `lds` (levels 2, 3)
+    const uint32_t lvl_base = j < 2 ? (uint32_t)S * 64u : (uint32_t)(kRPad + (S - p.S2) * 64);
+    const uint32_t lane_off = (uint32_t)(j * 16);
+    const __amdgpu_buffer_rsrc_t rsrc = make_uniform_rsrc(base, (uint32_t)((int64_t)p.Nv * 64));
+    // the head's block of the projection slab and the image's reference points through buffer resources too:
+    // 32-bit lane offsets instead of 64-bit VALU address arithmetic
+    constexpr int RD = REF4 ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t proj_rsrc = make_uniform_rsrc(
+        reinterpret_cast<const char *>(p.proj + ((int64_t)b * p.M + m) * p.Nq * 48), (uint32_t)((int64_t)p.Nq * 96));
+    const __amdgpu_buffer_rsrc_t ref_rsrc = make_uniform_rsrc(
+        reinterpret_cast<const char *>(p.ref + (int64_t)b * p.ref_batch_stride), (uint32_t)((int64_t)p.Nq * 4 * RD * 4));
+    float4 *myW = wts + wave * 256;
+
+    // raw inputs of a row: my level's 4 offsets (x,y), 4 logits, reference point -- loaded one row group ahead
+    struct RowIn {
+        uint4 o;
+        uint2 gg;
+        float r[RD];
+    };
+    auto load_row = [&](int rg) {
+        const uint32_t slot = (uint32_t)min(q_lo + rg * 16 + g, q_hi - 1);
+        RowIn in;
+        in.o = buffer_load16(proj_rsrc, slot * 96u + (uint32_t)j * 16u);
+        in.gg = buffer_load8(proj_rsrc, slot * 96u + 64u + (uint32_t)j * 8u);
+        if (REF4) {
+            const uint4 r = buffer_load16(ref_rsrc, (slot * 4u + (uint32_t)j) * 16u);
+            in.r[0] = __uint_as_float(r.x); in.r[1] = __uint_as_float(r.y);
+            in.r[RD - 2] = __uint_as_float(r.z); in.r[RD - 1] = __uint_as_float(r.w);
+        } else {
+            const uint2 r = buffer_load8(ref_rsrc, (slot * 4u + (uint32_t)j) * 8u);
+            in.r[0] = __uint_as_float(r.x); in.r[1] = __uint_as_float(r.y);
+        }
+        return in;
+    };
+    const int ngroups = (q_hi - q_lo + 15) >> 4;
+    RowIn nxt = load_row(min(wave, ngroups - 1));
+    for (int rg = wave; rg < ngroups; rg += kRWaves) {
+        const int slot = q_lo + rg * 16 + g;
+        const bool active = slot < q_hi;
+        const int q = active ? slot : q_hi - 1;
+        const RowIn cur = nxt;
+        nxt = load_row(min(rg + kRWaves, ngroups - 1));
+        float ox[4], oy[4], lg[4];
+        ox[0] = bf16_lo(cur.o.x); oy[0] = bf16_hi(cur.o.x); ox[1] = bf16_lo(cur.o.y); oy[1] = bf16_hi(cur.o.y);
+        ox[2] = bf16_lo(cur.o.z); oy[2] = bf16_hi(cur.o.z); ox[3] = bf16_lo(cur.o.w); oy[3] = bf16_hi(cur.o.w);
+        lg[0] = bf16_lo(cur.gg.x); lg[1] = bf16_hi(cur.gg.x); lg[2] = bf16_lo(cur.gg.y); lg[3] = bf16_hi(cur.gg.y);
+        // softmax over the quad's 16 logits
+        float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 4));
+        float e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = __expf(lg[t] - mx);
+        float sum = (e[0] + e[1]) + (e[2] + e[3]);
+        sum += __shfl_xor(sum, 1, 4);
+        sum += __shfl_xor(sum, 2, 4);
+        const float inv = active ? __builtin_amdgcn_rcpf(sum) : 0.f;  // inactive rows: all weights zero
+
+        // ---- my four samples: two row offsets (kept in registers) + four weights (to the wave's LDS table) ----
+        uint32_t r0[4], r1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float x, y;
+            if (!REF4) {
+                x = fmaf(ox[t], invW, cur.r[0]);
+                y = fmaf(oy[t], invH, cur.r[1]);
+            } else {
+                x = fmaf(ox[t] * 0.125f, cur.r[RD - 2], cur.r[0]);  // offset / num_points * w * 0.5, num_points = 4
+                y = fmaf(oy[t] * 0.125f, cur.r[RD - 1], cur.r[1]);
+            }
+            const float h_im = fmaf(y, fH, -0.5f);
+            const float w_im = fmaf(x, fW, -0.5f);
+            const bool inside = (h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW);
+            const float a = inside ? e[t] * inv : 0.f;
+            const float fy = floorf(h_im), fx = floorf(w_im);
+            const float ly = h_im - fy, lx = w_im - fx;
+            const int y0 = (int)fy, x0 = (int)fx;  // saturating; the weights are zero for wild values
+            const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+            const bool in0 = (unsigned)x0 < (unsigned)W, in1 = (unsigned)(x0 + 1) < (unsigned)W;
+            const float wy0 = vy0 ? (1.f - ly) * a : 0.f;
+            const float wy1 = vy1 ? ly * a : 0.f;
+            // the span starts at pixel xa = clamp(x0): when x0 = -1 that pixel is the RIGHT corner
+            const float wa = in0 ? (1.f - lx) : (in1 ? lx : 0.f);
+            const float wb = (in0 & in1) ? lx : 0.f;
+            const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
+            const int xa = min(max(x0, 0), W - 1);
+            r0[t] = lvl_base + (uint32_t)(y0c * W + xa) * 64u;
+            r1[t] = lvl_base + (uint32_t)(y1c * W + xa) * 64u;
+            myW[(j * 4 + t) * 16 + g] = make_float4(wy0 * wa, wy0 * wb, wy1 * wa, wy1 * wb);
+        }
+        // the table is wave-private: visible to this wave's reads once its own LDS queue drains
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+
+        // GB samples of a global level (4 GB loads in flight) while GB samples of a resident level are accumulated
+#define SDETR_RES_GLOBAL_ISSUE(JL, T0)                                                                         \
+    _Pragma("unroll") for (int t = 0; t < GB; ++t)                                                             \
+    {                                                                                                          \
+        const uint32_t o0 = quad_bcast<JL>(r0[T0 + t]) + lane_off, o1 = quad_bcast<JL>(r1[T0 + t]) + lane_off; \
+        va[t][0] = buffer_load16(rsrc, o0);                                                                    \
+        va[t][1] = buffer_load16(rsrc, o0 + 64u);                                                              \
+        va[t][2] = buffer_load16(rsrc, o1);                                                                    \
+        va[t][3] = buffer_load16(rsrc, o1 + 64u);                                                              \
+    }
+#define SDETR_RES_GLOBAL_ACC(JL, T0)                                                                           \
+    _Pragma("unroll") for (int t = 0; t < GB; ++t)                                                             \
+    {                                                                                                          \
+        const float4 w = myW[(JL * 4 + T0 + t) * 16 + g];                                                      \
+        F::fma8(acc, va[t][0], w.x);                                                                           \
+        F::fma8(acc, va[t][1], w.y);                                                                           \
+        F::fma8(acc, va[t][2], w.z);                                                                           \
+        F::fma8(acc, va[t][3], w.w);                                                                           \
+    }
+#define SDETR_RES_LDS(JL, T0)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < GB; ++t)                                                             \
+    {                                                                                                          \
+        const uint32_t o0 = quad_bcast<JL>(r0[T0 + t]) + lane_off, o1 = quad_bcast<JL>(r1[T0 + t]) + lane_off; \
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(lds + o0);                                           \
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(lds + o0 + 64);                                      \
+        const uint4 v2 = *reinterpret_cast<const uint4 *>(lds + o1);                                           \
+        const uint4 v3 = *reinterpret_cast<const uint4 *>(lds + o1 + 64);                                      \
+        const float4 w = myW[(JL * 4 + T0 + t) * 16 + g];                                                      \
+        F::fma8(acc, v0, w.x);                                                                                 \
+        F::fma8(acc, v1, w.y);                                                                                 \
+        F::fma8(acc, v2, w.z);                                                                                 \
+        F::fma8(acc, v3, w.w);                                                                                 \
+    }
+        // scheduling fences: without them hipcc sinks every global load down to its first use (two in flight)
+#define SDETR_RES_ROUND(JG, JR, T0)                                                                            \
+    SDETR_RES_GLOBAL_ISSUE(JG, T0)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    SDETR_RES_LDS(JR, T0)                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    SDETR_RES_GLOBAL_ACC(JG, T0)                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+        uint4 va[GB][4];
+        if (GB == 4) {
+            SDETR_RES_ROUND(0, 2, 0)
+            SDETR_RES_ROUND(1, 3, 0)
+        } else {
+            SDETR_RES_ROUND(0, 2, 0)
+            SDETR_RES_ROUND(0, 2, (4 - GB))
+            SDETR_RES_ROUND(1, 3, 0)
+            SDETR_RES_ROUND(1, 3, (4 - GB))
+        }
+#undef SDETR_RES_ROUND
+#undef SDETR_RES_GLOBAL_ISSUE
+#undef SDETR_RES_GLOBAL_ACC
+#undef SDETR_RES_LDS
+
+        if (active) {
+            const int64_t o = (((int64_t)b * p.Nq + q) * p.M + m) * 32 + j * 8;
+            if (p.out_bf16) {
+                *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + o) =
+                    make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                               pack_bf16x2(acc[6], acc[7]));
+            } else {
+                float *out = reinterpret_cast<float *>(p.out) + o;
+                *reinterpret_cast<float4 *>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4 *>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
+        }
+        // the next row group rewrites the weight table: this wave's reads of it have all returned (their values
+        // were consumed above), and LDS operations of one wave complete in order
+    }
+}
+
+static int device_cu_count()
+{
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached_dev = dev;
+        cached_cus = cus;
+    }
+    return cached_cus;
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int sdetr_msda_resident_max_pixels(void) { return kRMaxResidentPx; }
+
+extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                           const int32_t *level_hw_host, const float *ref, int ref_dim,
+                                           int64_t ref_batch_stride, const void *proj_hm_bf16, int B, int Nv, int M,
+                                           int Nq, void *out, int out_dtype, int chunks)
+{
+    if (B < 0 || Nv <= 0 || M <= 0 || Nq < 0) return fail("msda_resident_forward: bad dims B=%d Nv=%d M=%d Nq=%d", B, Nv, M, Nq);
+    if (!value_hm || !level_hw_host || !ref || !proj_hm_bf16 || !out) return fail("msda_resident_forward: null pointer");
+    if (ref_dim != 2 && ref_dim != 4)
+        return fail("Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+    // (a bf16-map instantiation exists in the template but needs the unpack registers the 16 loads in flight
+    // occupy: it spills at the 128-register budget of a 16-wave workgroup, so bf16 maps stay on the direct kernel)
+    if (value_dtype != SDETR_F16)
+        return fail("msda_resident_forward: fp16 head-major value maps only (dtype %d)", value_dtype);
+    if (out_dtype != SDETR_BF16 && out_dtype != SDETR_F32) return fail("msda_resident_forward: out must be bf16 or f32");
+    if (ref_batch_stride == 0) ref_batch_stride = (int64_t)Nq * 4 * ref_dim;
+    if (ref_batch_stride < (int64_t)Nq * 4 * ref_dim || (ref_batch_stride % ref_dim))
+        return fail("msda_resident_forward: bad reference point batch stride");
+    if ((reinterpret_cast<uintptr_t>(proj_hm_bf16) % 16) || (reinterpret_cast<uintptr_t>(ref) % 16) ||
+        (reinterpret_cast<uintptr_t>(value_hm) % 16) || (reinterpret_cast<uintptr_t>(out) % 16))
+        return fail("msda_resident_forward: operands must be 16-byte aligned");
+    ResidentArgs a{};
+    const int32_t *hw = level_hw_host;
+    for (int l = 0; l < 4; ++l)
+        if (hw[2 * l] <= 0 || hw[2 * l + 1] <= 0) return fail("msda_resident_forward: bad level shape");
+    a.H0 = hw[0]; a.W0 = hw[1]; a.H1 = hw[2]; a.W1 = hw[3]; a.H2 = hw[4]; a.W2 = hw[5]; a.H3 = hw[6]; a.W3 = hw[7];
+    const int64_t s1 = (int64_t)a.H0 * a.W0, s2 = s1 + (int64_t)a.H1 * a.W1, s3 = s2 + (int64_t)a.H2 * a.W2;
+    if (s3 + (int64_t)a.H3 * a.W3 != Nv) return fail("msda_resident_forward: level shapes do not add up to %d pixels", Nv);
+    if ((int64_t)Nv * 64 >= 0xffffffffLL) return fail("msda_resident_forward: value map too large for 32-bit offsets");
+    a.S1 = (int)s1; a.S2 = (int)s2; a.S3 = (int)s3;
+    a.res_px = Nv - a.S2;
+    if (a.res_px > kRMaxResidentPx)
+        return fail("msda_resident_forward: levels 2+3 hold %d pixels, more than the %d that fit in LDS", a.res_px,
+                    kRMaxResidentPx);
+    if ((int64_t)B * Nq == 0) return 0;
+    a.value = reinterpret_cast<const char *>(value_hm);
+    a.ref = ref; a.ref_batch_stride = ref_batch_stride; a.ref_dim = ref_dim;
+    a.proj = reinterpret_cast<const bf16_t *>(proj_hm_bf16);
+    a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.B = B; a.Nv = Nv; a.M = M; a.Nq = Nq;
+    if (chunks <= 0) {
+        // one workgroup per CU: the (image, head) pairs share the CUs evenly; never less than one row group per wave
+        chunks = device_cu_count() / (B * M);
+        const int max_chunks = (Nq + 16 * kRWaves - 1) / (16 * kRWaves);
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+    }
+    a.chunks = chunks;
+    const int64_t blocks = (int64_t)B * M * chunks;
+    if (blocks > 0x7fffffffLL) return fail("msda_resident_forward: grid too large");
+    int lds_bytes = 2 * kRPad + a.res_px * 64 + kRWaves * kRWeightBytes;
+    if (lds_bytes < kRPad + kRStage * kRThreads * 16) lds_bytes = kRPad + kRStage * kRThreads * 16;  // see the staging loop
+    // the attribute is per device and the call is cheap: set before every launch (no process-wide flag)
+#define SDETR_RES_LAUNCH(VT, REF4, GB)                                                                         \
+    do {                                                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4, GB>),          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                    \
+        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4, GB>), dim3((unsigned)blocks), dim3(kRThreads),      \
+                           lds_bytes, stream, a);                                                              \
+    } while (0)
+    if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true, 4);
+    else SDETR_RES_LAUNCH(half_t, false, 4);
+#undef SDETR_RES_LAUNCH
+    note_forward_kernel(SDETR_KERNEL_MSDA_RESIDENT);
+    return check_launch("msda_resident");
+}

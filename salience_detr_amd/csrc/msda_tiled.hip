@@ -27,6 +27,8 @@
 
 namespace sdetr {
 
+void note_forward_kernel(int which);  // abi.hip
+
 constexpr int kPixBytes = kTD * 2;           // bf16
 constexpr int kTileBytes = kTilePx * kPixBytes;          // 65 280
 constexpr int kDescW = 4 * 8 * 16 * 16;                  // [wave][sample][row] float4
@@ -558,5 +560,6 @@ extern "C" int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value
     const int64_t blocks = (int64_t)B * num_regions * M;
     if (blocks > 0x7fffffffLL) return fail("msda_tiled_forward: grid too large");
     hipLaunchKernelGGL(msda_tiled_kernel, dim3((unsigned)blocks), dim3(kBlock), kTiledLds, stream, a);
+    note_forward_kernel(SDETR_KERNEL_MSDA_TILED);
     return check_launch("msda_tiled");
 }

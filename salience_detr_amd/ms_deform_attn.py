@@ -200,6 +200,67 @@ def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
     return out
 
 
+_RESIDENT_MAX = None
+
+
+def resident_supported(value_hm: Tensor, level_shapes, num_levels: int, num_points: int) -> bool:
+    """Whether ``msda_resident_forward`` (levels 2+3 of the pyramid resident in LDS) covers this call: fp16 head-major
+    maps with 32-channel heads, 4 levels x 4 points, a host copy of the level shapes, and coarse levels that fit."""
+    global _RESIDENT_MAX
+    if (level_shapes is None or len(level_shapes) != 4 or num_levels != 4 or num_points != 4
+            or value_hm.dtype != torch.float16 or value_hm.shape[-1] != 32):
+        return False
+    if sum(int(h) * int(w) for h, w in level_shapes) != value_hm.shape[2]:
+        return False
+    if _RESIDENT_MAX is None:
+        _RESIDENT_MAX = int(_hip.lib().sdetr_msda_resident_max_pixels())
+    return sum(int(h) * int(w) for h, w in level_shapes[2:]) <= _RESIDENT_MAX
+
+
+def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tensor, proj_hm: Tensor,
+                          out_dtype: Optional[torch.dtype] = None, chunks: int = 0) -> Tensor:
+    """``msda_fused_forward`` with the coarse levels served from LDS (csrc/msda_resident.hip): ``value_hm``
+    ``[B,M,Nv,32]`` fp16, ``level_shapes`` HOST list of the four (h, w), ``reference_points`` ``[B,Nq,4,2|4]`` fp32,
+    ``proj_hm`` the head-major bf16 projection slab ``[B,M,Nq,48]``.  ``chunks``: workgroups per (image, head),
+    0 = one workgroup per CU."""
+    import ctypes
+    _hip.require_device("msda_resident_forward", value_hm=value_hm, proj_hm=proj_hm)
+    if reference_points.shape[-1] not in (2, 4):
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+            reference_points.shape[-1]))
+    B, M, Nv, D = value_hm.shape
+    if not resident_supported(value_hm, level_shapes, 4, 4):
+        raise RuntimeError("msda_resident_forward: fp16 [B,M,Nv,32] maps of a 4-level pyramid whose two coarse levels "
+                           "fit in LDS expected")
+    if proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or proj_hm.dtype != torch.bfloat16:
+        raise RuntimeError("msda_resident_forward: proj must be a contiguous bf16 [B, M, Nq, 48] tensor")
+    Nq = proj_hm.shape[2]
+    if not reference_points.is_cuda:
+        raise RuntimeError("msda_resident_forward: reference_points must be a HIP (cuda) tensor; no CPU fallback")
+    if reference_points.dtype != torch.float32:
+        reference_points = reference_points.float()
+    if Nq > 0 and not reference_points[0].is_contiguous():
+        reference_points = reference_points.contiguous()
+    ref_bs = reference_points.stride(0) if (B > 1 and Nq > 0) else 0
+    out_dtype = out_dtype or proj_hm.dtype
+    out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
+    hw = (ctypes.c_int32 * 8)(*[int(v) for s in level_shapes for v in s])
+    with torch.cuda.device(out.device):
+        code = _hip.lib().sdetr_msda_resident_forward(
+            _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), hw, reference_points.data_ptr(),
+            reference_points.shape[-1], ref_bs, proj_hm.data_ptr(), B, Nv, M, Nq, out.data_ptr(),
+            _hip.dtype_code(out_dtype), int(chunks))
+    _hip.check(code, "msda_resident_forward")
+    return out
+
+
+def last_forward_kernel() -> int:
+    """``SDETR_KERNEL_*`` code of the kernel the calling thread's last MSDA forward call dispatched to."""
+    return int(_hip.lib().sdetr_msda_last_kernel())
+
+
+KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT, KERNEL_TILED = 1, 2, 3, 4, 5
+
 _TILED_CFG = None
 
 
@@ -417,9 +478,14 @@ class MultiScaleDeformableAttention(nn.Module):
     # it stays opt-in until it is restructured as a persistent double-buffered pipeline.
     tiled_min_queries_per_region = None
 
+    # queries per image from which the coarse-levels-in-LDS kernel replaces the direct gather when a host copy of
+    # the level shapes is at hand (below it the 85 KB staging per workgroup is not amortised); None disables it
+    resident_min_queries = 1500
+
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
                        level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None,
-                       query_pos: Optional[Tensor] = None, apply_output_proj: bool = True) -> Tensor:
+                       query_pos: Optional[Tensor] = None, apply_output_proj: bool = True,
+                       level_shapes=None) -> Tensor:
         """``query_pos`` (optional): position embedding still to be added to ``query`` -- folded into the projection
         kernel's prologue on the bf16 path.  ``apply_output_proj=False`` returns the sampled heads ``[B,Nq,E]`` for a
         caller that fuses ``output_proj`` with what follows it."""
@@ -437,8 +503,12 @@ class MultiScaleDeformableAttention(nn.Module):
             # per-head slabs: every XCD's L2 then fetches only its own head's projection values
             wh, bh = self._fused_query_projection_head_major()
             proj = token_linear(query, wh, bh, x_add=query_pos, group_features=3 * self.num_levels * self.num_points)
-            out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
-                                     self.num_levels, self.num_points, out_dtype=query.dtype, proj_head_major=True)
+            if (self.resident_min_queries is not None and query.shape[1] >= self.resident_min_queries
+                    and resident_supported(value_hm, level_shapes, self.num_levels, self.num_points)):
+                out = msda_resident_forward(value_hm, level_shapes, reference_points, proj, out_dtype=query.dtype)
+            else:
+                out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
+                                         self.num_levels, self.num_points, out_dtype=query.dtype, proj_head_major=True)
             if not apply_output_proj:
                 return out
             return F.linear(out, self.output_proj.weight, self.output_proj.bias)

@@ -143,7 +143,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
-                       class_head):
+                       class_head, level_shapes=None):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
@@ -175,7 +175,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
                 fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
             sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
                                                     level_start_index, query_pos=pos_sorted[:, :c],
-                                                    apply_output_proj=False)
+                                                    apply_output_proj=False, level_shapes=level_shapes)
             # ... but it pays for ten thousand queries and more: output_proj + residual + norm1 in one launch
             if query.shape[0] * c >= 12000:
                 query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
@@ -187,7 +187,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
         fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
         src2 = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes, level_start_index,
-                                             query_pos=pos_sorted[:, :c])
+                                             query_pos=pos_sorted[:, :c], level_shapes=level_shapes)
         return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2))
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
@@ -351,7 +351,7 @@ class SalienceTransformerEncoder(nn.Module):
                 if self.layer_marker is not None:
                     self.layer_marker(layer_id)
                 y = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
-                                         level_start_index, self.enhance_mcsp)
+                                         level_start_index, self.enhance_mcsp, level_shapes=level_shapes)
                 nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
                 q = advance_rows(y, result, nxt, value, sorted_index, focus64)
             if self.layer_marker is not None:
