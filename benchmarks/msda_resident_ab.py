@@ -28,13 +28,25 @@ def slab_of(proj):
 
 
 def timeit(fn, reps):
+    """Mean device time of one launch: `reps` launches captured in a hipGraph (no host launch gaps -- the python
+    wrapper costs more host time than the small layers' kernels take), replayed between two events."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps

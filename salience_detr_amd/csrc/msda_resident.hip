@@ -95,7 +95,16 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
 }
 
-template <typename VT, bool REF4, int GB>
+__device__ __forceinline__ float quad_xor1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+}
+
+template <typename VT, bool REF4>
 __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p)
 {
     using F = ResFma<VT>;
@@ -118,29 +127,19 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
 
     const char *base = p.value + ((int64_t)b * p.M + m) * p.Nv * 64;
 
-    // ---- stage levels 2 and 3 of this (image, head): every load is issued before the first LDS store.  Pieces past
-    // the slab are stored as zeros: the first four of them ARE the zero pad behind the slab, the rest land in the
-    // (not yet used) weight tables -- no per-piece branch, so the loads stay one batch (the launcher sizes the
-    // allocation for kRStage full rounds) ----
+    // ---- stage levels 2 and 3 of this (image, head): all loads first (the first row group's input loads are issued
+    // right behind them, see below), then the LDS stores.  Pieces past the slab are stored as zeros into the 64-byte
+    // pad behind it (all of them to its four slots: same value, benign overlap). ----
+    const int npieces = p.res_px * 4;
+    uint4 stage_v[kRStage];
     {
-        const int npieces = p.res_px * 4;
         const char *src = base + (int64_t)p.S2 * 64;
-        uint4 v[kRStage];
 #pragma unroll
         for (int i = 0; i < kRStage; ++i) {
             const int piece = tid + i * kRThreads;
-            v[i] = *reinterpret_cast<const uint4 *>(src + (int64_t)min(piece, npieces - 1) * 16);
-        }
-        if (tid < 4) *reinterpret_cast<uint4 *>(lds + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int i = 0; i < kRStage; ++i) {
-            const int piece = tid + i * kRThreads;
-            const bool real = piece < npieces;
-            *reinterpret_cast<uint4 *>(lds + kRPad + piece * 16) =
-                make_uint4(real ? v[i].x : 0u, real ? v[i].y : 0u, real ? v[i].z : 0u, real ? v[i].w : 0u);
+            stage_v[i] = *reinterpret_cast<const uint4 *>(src + (int64_t)min(piece, npieces - 1) * 16);
         }
     }
-    __syncthreads();
 
     // ---- rows: a quad per (query, head); lane j of the quad owns level j ----
     const int g = lane >> 2, j = lane & 3;
@@ -185,6 +184,19 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
     };
     const int ngroups = (q_hi - q_lo + 15) >> 4;
     RowIn nxt = load_row(min(wave, ngroups - 1));
+    __builtin_amdgcn_sched_barrier(0);  // the row loads above stay in flight across the staging stores
+    {
+        if (tid < 4) *reinterpret_cast<uint4 *>(lds + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < kRStage; ++i) {
+            const int piece = tid + i * kRThreads;
+            const bool real = piece < npieces;
+            *reinterpret_cast<uint4 *>(lds + kRPad + min(piece, npieces + 3) * 16) =
+                make_uint4(real ? stage_v[i].x : 0u, real ? stage_v[i].y : 0u, real ? stage_v[i].z : 0u,
+                           real ? stage_v[i].w : 0u);
+        }
+    }
+    __syncthreads();
     for (int rg = wave; rg < ngroups; rg += kRWaves) {
         const int slot = q_lo + rg * 16 + g;
         const bool active = slot < q_hi;
@@ -195,16 +207,16 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
         ox[0] = bf16_lo(cur.o.x); oy[0] = bf16_hi(cur.o.x); ox[1] = bf16_lo(cur.o.y); oy[1] = bf16_hi(cur.o.y);
         ox[2] = bf16_lo(cur.o.z); oy[2] = bf16_hi(cur.o.z); ox[3] = bf16_lo(cur.o.w); oy[3] = bf16_hi(cur.o.w);
         lg[0] = bf16_lo(cur.gg.x); lg[1] = bf16_hi(cur.gg.x); lg[2] = bf16_lo(cur.gg.y); lg[3] = bf16_hi(cur.gg.y);
-        // softmax over the quad's 16 logits
+        // softmax over the quad's 16 logits (quad_perm DPP: lane ^ 1, lane ^ 2 -- no LDS round trip)
         float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 4));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 4));
+        mx = fmaxf(mx, quad_xor1(mx));
+        mx = fmaxf(mx, quad_xor2(mx));
         float e[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) e[t] = __expf(lg[t] - mx);
         float sum = (e[0] + e[1]) + (e[2] + e[3]);
-        sum += __shfl_xor(sum, 1, 4);
-        sum += __shfl_xor(sum, 2, 4);
+        sum += quad_xor1(sum);
+        sum += quad_xor2(sum);
         const float inv = active ? __builtin_amdgcn_rcpf(sum) : 0.f;  // inactive rows: all weights zero
 
         // ---- my four samples: two row offsets (kept in registers) + four weights (to the wave's LDS table) ----
@@ -235,8 +247,8 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
             const float wb = (in0 & in1) ? lx : 0.f;
             const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
             const int xa = min(max(x0, 0), W - 1);
-            r0[t] = lvl_base + (uint32_t)(y0c * W + xa) * 64u;
-            r1[t] = lvl_base + (uint32_t)(y1c * W + xa) * 64u;
+            r0[t] = lvl_base + (__umul24((uint32_t)y0c, (uint32_t)W) + (uint32_t)xa) * 64u;  // 24-bit operands: full rate
+            r1[t] = lvl_base + (__umul24((uint32_t)y1c, (uint32_t)W) + (uint32_t)xa) * 64u;
             myW[(j * 4 + t) * 16 + g] = make_float4(wy0 * wa, wy0 * wb, wy1 * wa, wy1 * wb);
         }
         // the table is wave-private: visible to this wave's reads once its own LDS queue drains
@@ -247,60 +259,54 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
 
-        // GB samples of a global level (4 GB loads in flight) while GB samples of a resident level are accumulated
-#define SDETR_RES_GLOBAL_ISSUE(JL, T0)                                                                         \
-    _Pragma("unroll") for (int t = 0; t < GB; ++t)                                                             \
+        // Rolling schedule over the 8 global samples (levels 0, 1) and the 8 resident samples (levels 2, 3): four
+        // global samples (16 loads) are in flight from the start; step k accumulates resident sample k (four
+        // ds_read_b128), then global sample k, then issues global sample k + 4 into the registers just freed --
+        // 12 to 16 loads stay in flight for the whole row group.  The scheduling fences keep hipcc from sinking
+        // every load down to its first use (it then has two in flight).
+#define SDETR_RES_ISSUE(SLOT, JL, T)                                                                           \
     {                                                                                                          \
-        const uint32_t o0 = quad_bcast<JL>(r0[T0 + t]) + lane_off, o1 = quad_bcast<JL>(r1[T0 + t]) + lane_off; \
-        va[t][0] = buffer_load16(rsrc, o0);                                                                    \
-        va[t][1] = buffer_load16(rsrc, o0 + 64u);                                                              \
-        va[t][2] = buffer_load16(rsrc, o1);                                                                    \
-        va[t][3] = buffer_load16(rsrc, o1 + 64u);                                                              \
+        const uint32_t o0 = quad_bcast<JL>(r0[T]) + lane_off, o1 = quad_bcast<JL>(r1[T]) + lane_off;           \
+        va[SLOT][0] = buffer_load16(rsrc, o0);                                                                 \
+        va[SLOT][1] = buffer_load16(rsrc, o0 + 64u);                                                           \
+        va[SLOT][2] = buffer_load16(rsrc, o1);                                                                 \
+        va[SLOT][3] = buffer_load16(rsrc, o1 + 64u);                                                           \
     }
-#define SDETR_RES_GLOBAL_ACC(JL, T0)                                                                           \
-    _Pragma("unroll") for (int t = 0; t < GB; ++t)                                                             \
+#define SDETR_RES_ACC(SLOT, JL, T)                                                                             \
     {                                                                                                          \
-        const float4 w = myW[(JL * 4 + T0 + t) * 16 + g];                                                      \
-        F::fma8(acc, va[t][0], w.x);                                                                           \
-        F::fma8(acc, va[t][1], w.y);                                                                           \
-        F::fma8(acc, va[t][2], w.z);                                                                           \
-        F::fma8(acc, va[t][3], w.w);                                                                           \
+        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
+        F::fma8(acc, va[SLOT][0], w.x);                                                                        \
+        F::fma8(acc, va[SLOT][1], w.y);                                                                        \
+        F::fma8(acc, va[SLOT][2], w.z);                                                                        \
+        F::fma8(acc, va[SLOT][3], w.w);                                                                        \
     }
-#define SDETR_RES_LDS(JL, T0)                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < GB; ++t)                                                             \
+#define SDETR_RES_LDS(JL, T)                                                                                   \
     {                                                                                                          \
-        const uint32_t o0 = quad_bcast<JL>(r0[T0 + t]) + lane_off, o1 = quad_bcast<JL>(r1[T0 + t]) + lane_off; \
+        const uint32_t o0 = quad_bcast<JL>(r0[T]) + lane_off, o1 = quad_bcast<JL>(r1[T]) + lane_off;           \
         const uint4 v0 = *reinterpret_cast<const uint4 *>(lds + o0);                                           \
         const uint4 v1 = *reinterpret_cast<const uint4 *>(lds + o0 + 64);                                      \
         const uint4 v2 = *reinterpret_cast<const uint4 *>(lds + o1);                                           \
         const uint4 v3 = *reinterpret_cast<const uint4 *>(lds + o1 + 64);                                      \
-        const float4 w = myW[(JL * 4 + T0 + t) * 16 + g];                                                      \
+        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
         F::fma8(acc, v0, w.x);                                                                                 \
         F::fma8(acc, v1, w.y);                                                                                 \
         F::fma8(acc, v2, w.z);                                                                                 \
         F::fma8(acc, v3, w.w);                                                                                 \
     }
-        // scheduling fences: without them hipcc sinks every global load down to its first use (two in flight)
-#define SDETR_RES_ROUND(JG, JR, T0)                                                                            \
-    SDETR_RES_GLOBAL_ISSUE(JG, T0)                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    SDETR_RES_LDS(JR, T0)                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    SDETR_RES_GLOBAL_ACC(JG, T0)                                                                               \
-    __builtin_amdgcn_sched_barrier(0);
-        uint4 va[GB][4];
-        if (GB == 4) {
-            SDETR_RES_ROUND(0, 2, 0)
-            SDETR_RES_ROUND(1, 3, 0)
-        } else {
-            SDETR_RES_ROUND(0, 2, 0)
-            SDETR_RES_ROUND(0, 2, (4 - GB))
-            SDETR_RES_ROUND(1, 3, 0)
-            SDETR_RES_ROUND(1, 3, (4 - GB))
-        }
-#undef SDETR_RES_ROUND
-#undef SDETR_RES_GLOBAL_ISSUE
-#undef SDETR_RES_GLOBAL_ACC
+#define SDETR_FENCE __builtin_amdgcn_sched_barrier(0);
+        uint4 va[4][4];
+        SDETR_RES_ISSUE(0, 0, 0) SDETR_RES_ISSUE(1, 0, 1) SDETR_RES_ISSUE(2, 0, 2) SDETR_RES_ISSUE(3, 0, 3) SDETR_FENCE
+        SDETR_RES_LDS(2, 0) SDETR_FENCE SDETR_RES_ACC(0, 0, 0) SDETR_FENCE SDETR_RES_ISSUE(0, 1, 0) SDETR_FENCE
+        SDETR_RES_LDS(2, 1) SDETR_FENCE SDETR_RES_ACC(1, 0, 1) SDETR_FENCE SDETR_RES_ISSUE(1, 1, 1) SDETR_FENCE
+        SDETR_RES_LDS(2, 2) SDETR_FENCE SDETR_RES_ACC(2, 0, 2) SDETR_FENCE SDETR_RES_ISSUE(2, 1, 2) SDETR_FENCE
+        SDETR_RES_LDS(2, 3) SDETR_FENCE SDETR_RES_ACC(3, 0, 3) SDETR_FENCE SDETR_RES_ISSUE(3, 1, 3) SDETR_FENCE
+        SDETR_RES_LDS(3, 0) SDETR_FENCE SDETR_RES_ACC(0, 1, 0) SDETR_FENCE
+        SDETR_RES_LDS(3, 1) SDETR_FENCE SDETR_RES_ACC(1, 1, 1) SDETR_FENCE
+        SDETR_RES_LDS(3, 2) SDETR_FENCE SDETR_RES_ACC(2, 1, 2) SDETR_FENCE
+        SDETR_RES_LDS(3, 3) SDETR_FENCE SDETR_RES_ACC(3, 1, 3) SDETR_FENCE
+#undef SDETR_FENCE
+#undef SDETR_RES_ISSUE
+#undef SDETR_RES_ACC
 #undef SDETR_RES_LDS
 
         if (active) {
@@ -380,27 +386,27 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
     a.B = B; a.Nv = Nv; a.M = M; a.Nq = Nq;
     if (chunks <= 0) {
-        // one workgroup per CU: the (image, head) pairs share the CUs evenly; never less than one row group per wave
+        // one workgroup per CU: the (image, head) pairs share the CUs evenly; at least four row groups per workgroup
+        // (measured at 900 / 2272 queries: spreading a small layer over all CUs beats filling fewer CUs' waves)
         chunks = device_cu_count() / (B * M);
-        const int max_chunks = (Nq + 16 * kRWaves - 1) / (16 * kRWaves);
+        const int max_chunks = (Nq + 63) / 64;
         if (chunks > max_chunks) chunks = max_chunks;
         if (chunks < 1) chunks = 1;
     }
     a.chunks = chunks;
     const int64_t blocks = (int64_t)B * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_resident_forward: grid too large");
-    int lds_bytes = 2 * kRPad + a.res_px * 64 + kRWaves * kRWeightBytes;
-    if (lds_bytes < kRPad + kRStage * kRThreads * 16) lds_bytes = kRPad + kRStage * kRThreads * 16;  // see the staging loop
+    const int lds_bytes = 2 * kRPad + a.res_px * 64 + kRWaves * kRWeightBytes;
     // the attribute is per device and the call is cheap: set before every launch (no process-wide flag)
-#define SDETR_RES_LAUNCH(VT, REF4, GB)                                                                         \
+#define SDETR_RES_LAUNCH(VT, REF4)                                                                         \
     do {                                                                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4, GB>),          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                    \
-        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4, GB>), dim3((unsigned)blocks), dim3(kRThreads),      \
+        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4>), dim3((unsigned)blocks), dim3(kRThreads),      \
                            lds_bytes, stream, a);                                                              \
     } while (0)
-    if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true, 4);
-    else SDETR_RES_LAUNCH(half_t, false, 4);
+    if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true);
+    else SDETR_RES_LAUNCH(half_t, false);
 #undef SDETR_RES_LAUNCH
     note_forward_kernel(SDETR_KERNEL_MSDA_RESIDENT);
     return check_launch("msda_resident");

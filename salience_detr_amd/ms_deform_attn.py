@@ -480,7 +480,7 @@ class MultiScaleDeformableAttention(nn.Module):
 
     # queries per image from which the coarse-levels-in-LDS kernel replaces the direct gather when a host copy of
     # the level shapes is at hand (below it the 85 KB staging per workgroup is not amortised); None disables it
-    resident_min_queries = 1500
+    resident_min_queries = 1200
 
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
                        level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None,
