@@ -51,7 +51,12 @@ def parse():
                          "(default; 11-bit mantissa, gather via v_fma_mix_f32) or the activation dtype (bf16)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--instrumented-steps", type=int, default=10)
+    ap.add_argument("--plain", action="store_true",
+                    help="only the timed loop and a minimal JSON line (what the rocprofv3 counter passes wrap: no "
+                         "instrumented pass, no truncated graphs, no CPU baseline)")
+    ap.add_argument("--cpu-protocol", choices=["bounded", "full"], default="bounded",
+                    help="bounded (default): batch 2, all cores, 1 warm-up + 3 passes; full: SURVEY.md 8(d) -- 3 warm-ups + "
+                         "10 passes at all cores and at 8 threads, batch 1 and 2 (minutes)")
     return ap.parse_args()
 
 
@@ -61,8 +66,7 @@ def make_inputs(batch, h, w, device, seed):
     _, masks = syn.make_masks(sizes)
     shapes = pyramid.level_shapes_of(masks)
     feats = syn.make_feats(batch, shapes, 256, seed=seed)
-    pe = pyramid.PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5)
-    pos = [pe(m) for m in masks]
+    pos = [syn.sine_position_embedding(m, 128) for m in masks]
     cpu = (feats, masks, pos)
     dev = tuple([t.to(device) for t in ts] for ts in cpu)
     return sizes, canvas, shapes, cpu, dev
@@ -178,19 +182,179 @@ def train_main(args, model, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher environment re-executes itself under
+    torch.distributed.run with N ranks on this node, so the printed `n_gpus` is always the number of ranks that
+    actually ran (the reference launches its ranks with `accelerate launch`, main.py:94-103,144)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def kernel_source_tag():
+    """sha256 over the MSDA forward kernel sources: the identity the committed PMC traffic numbers are tagged with
+    (there is no .git on the benchmark box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("msda_resident.hip", "msda_forward.hip", "common.h"):
+        with open(os.path.join(ROOT, "salience_detr_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def graph_time_us(fn, reps):
+    """Mean device time of `fn`'s launches: `reps` repetitions captured in a hipGraph and replayed between two
+    events -- device time without host launch gaps (the python wrapper of a launch costs more host time than the
+    small layers' kernels run)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def capture(step, capture_kw):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, **capture_kw):
+        out = step()
+    g.replay()
+    torch.cuda.synchronize()
+    return g, out
+
+
+def time_replays(g, n):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
+    """The oracle's CPU port of the same path, timed on the host cores: per stage (F0-F3 filtering,
+    each encoder layer, the MSDA core alone).  Default: bounded to ~15-25 s (batch 2, all cores, 1 warm-up + 3 passes);
+    `--cpu-protocol full` runs the survey's whole protocol (3 warm-ups + 10 passes, all cores AND 8 threads, batch 1
+    AND 2 -- minutes; its result is committed under profiles/)."""
+    from oracle import salience_ref as R  # checker / baseline only; never on the product path
+    from oracle import msda_c
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    all_cores = os.cpu_count() or torch.get_num_threads()
+    full = args.cpu_protocol == "full"
+    plans = [(args.batch, all_cores, 3 if full else 1, 10 if full else 3)]
+    if full:
+        plans += [(1, all_cores, 3, 10), (args.batch, 8, 3, 10), (1, 8, 3, 10)]
+    legs, ref_out = [], None
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "")
+    except OSError:
+        pass
+    for batch, threads, warm, reps in plans:
+        torch.set_num_threads(threads)
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        cf, cm, cp = cpu_inputs_of(batch)
+        per_pass, stages = [], []
+        with torch.no_grad():
+            for i in range(warm + reps):
+                tm = {}
+                t1 = time.perf_counter()
+                r = R.hot_path(sd, cf, cm, cp, timings=tm)
+                dt = time.perf_counter() - t1
+                if i >= warm:
+                    per_pass.append(dt)
+                    stages.append(tm)
+                if batch == args.batch and threads == all_cores:
+                    ref_out = r
+        order = sorted(range(len(per_pass)), key=lambda i: per_pass[i])
+        med = order[len(order) // 2]
+        legs.append({"batch": batch, "threads": threads, "warmups": warm, "passes": reps,
+                     "ms_per_pass_median": round(per_pass[med] * 1e3, 1),
+                     "images_per_s": round(batch / per_pass[med], 3),
+                     "ms_per_stage": {k: round(v * 1e3, 1) for k, v in sorted(stages[med].items())}})
+    torch.set_num_threads(all_cores)
+    main_leg = legs[0]
+    result = {
+        "value": main_leg["images_per_s"], "unit": "images/s", "cores": main_leg["threads"], "kind": "port",
+        "cpu_model": cpu_model, "msda_core_threads": msda_c.num_threads(),
+        "sample": "%d timed passes (after %d warm-up) of the same batch-%d 800x1333 hot path (oracle/salience_ref.py, "
+                  "fp32, torch CPU ops + OpenMP C gather), median; per-stage ms of the median pass"
+                  % (main_leg["passes"], main_leg["warmups"], main_leg["batch"]),
+        "ms_per_pass": main_leg["ms_per_pass_median"], "ms_per_stage": main_leg["ms_per_stage"], "protocol": args.cpu_protocol,
+        "legs": legs,
+    }
+    # ---- parity of the timed GPU output against the oracle, selection flips separated from rounding ----
+    parity = None
+    if ref_out is not None:
+        err = (out.float().cpu() - ref_out["memory"]).abs()
+        per_token = err.max(-1)[0]
+        B, S = per_token.shape
+        flipped = torch.zeros(B, S, dtype=torch.bool)
+        for k, gsel in sorted(sel_log.items()):
+            inds = ref_out["foreground_inds"][k]
+            for b in range(B):
+                a = set(inds[b][ref_out["layer_sel"][k][b]].tolist())
+                g = set(inds[b][gsel[b]].tolist())
+                for tok in a ^ g:
+                    flipped[b, tok] = True
+        clean = per_token[~flipped]
+        parity = {"max_abs": round(float(err.max()), 5), "mean_abs": round(float(err.mean()), 6),
+                  "top300_selection_flips": {"tokens": int(flipped.sum()), "of": int(B * 300 * len(sel_log)),
+                                             "note": "tokens in exactly one of (GPU, oracle) top-300 sets of some layer: "
+                                                     "near-ties of the class score resolved differently under bf16"},
+                  "non_flipped_tokens": {"max_abs": round(float(clean.max()), 5), "mean_abs": round(float(clean.mean()), 6),
+                                         "p999_abs": round(float(clean.flatten().kthvalue(max(1, int(clean.numel() * 0.999)))[0]), 5)},
+                  "note": "GPU %s output vs fp32 CPU oracle on the same batch" % args.dtype}
+    return result, parity
+
+
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to print a "
+                         "line whose n_gpus is not the number of ranks that ran")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+        backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group size differs from --gpus")
 
     model = build_hot_path()
     model.load_state_dict(syn.det_state_dict(model.state_dict()))
@@ -213,21 +377,13 @@ def main():
 
     graphed = False
     run = step
+    g = None
+    # N > 1: the process group's helper threads exist by now; thread-local capture mode keeps anything they
+    # might call from invalidating this thread's capture (no collective is captured: the data path has none)
+    capture_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
     if not args.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            # N > 1: the process group's helper threads exist by now; thread-local capture mode keeps anything they
-            # might call from invalidating this thread's capture (no collective is captured: the data path has none)
-            capture_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}
-            with torch.cuda.graph(g, **capture_kw):
-                out = step()
-            g.replay()
-            torch.cuda.synchronize()
+            g, out = capture(step, capture_kw)
             run = g.replay
             graphed = True
         except Exception as e:  # keep the eager path measurable if capture is unavailable
@@ -255,28 +411,49 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     images_per_s = world * args.batch * args.steps / elapsed
 
-    # ---- instrumented eager pass: events around every fused-MSDA launch and every layer boundary ----
-    msda_events, layer_events, launches, launch_nq = [], [], [], []
+    nl = model.encoder.num_layers
+    if args.plain:
+        if rank == 0:
+            print(json.dumps({"metric": "images/s (whole node) + ms/encoder-layer, ResNet50 800x1333",
+                              "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "dtype": args.dtype,
+                              "hipgraph": graphed, "plain": True}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # ---- ms per encoder layer UNDER GRAPH REPLAY: graphs of the step truncated after k layers, differences ----
+    layer_ms, layer_note = [None] * nl, "unavailable (eager run)"
+    if graphed:
+        try:
+            trunc = []
+            for k in range(nl + 1):
+                model.encoder.max_layers = k
+                gk, _ = capture(step, capture_kw)
+                time_replays(gk, 3)
+                trunc.append(min(time_replays(gk, 10) for _ in range(3)))
+                del gk
+            model.encoder.max_layers = None
+            layer_ms = [trunc[k + 1] - trunc[k] for k in range(nl)]
+            layer_note = ("hipGraph replay: time of the step's graph truncated after k+1 encoder layers minus after k "
+                          "(min of 3 x 10 replays each); filtering + value projection + encoder entry: %.4f ms" % trunc[0])
+        except Exception as e:
+            model.encoder.max_layers = None
+            layer_note = f"truncated-graph timing failed: {e}"
+
+    # ---- instrumented eager pass: device time of every fused-MSDA launch (a captured graph of repeats), top-300 sets ----
+    launches, launch_nq, kernels_used, msda_us = [], [], [], []
     real_fused = msda_mod.msda_fused_forward
+    real_resident = msda_mod.msda_resident_forward
 
-    kernels_used = []
-
-    def record(real_call, value_hm, reference_points, proj, head_major, o, kernel):
-        # the step's own launch is done (o); the SAME launch (same operands, straight after its producers) is then
-        # repeated back to back between two events on the launch stream, so the measured time is kernel time
-        # (what rocprofv3 --kernel-trace reports), not host launch gaps of the eager instrumented pass
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(MSDA_REPEATS):
-            real_call()
-        e1.record()
-        msda_events.append((e0, e1))
+    def record(call, value_hm, reference_points, proj, head_major, o, kernel):
         B, M, Nv, D = value_hm.shape
         nq = int(proj.shape[2] if head_major else proj.shape[1])
         launch_nq.append(nq)
         kernels_used.append(kernel)
         launches.append(algorithmic_bytes(B, Nv, nq, M, D, 4, 4, value_hm.element_size(), proj.element_size(),
                                           o.element_size(), reference_points.shape[-1]))
+        msda_us.append(graph_time_us(call, MSDA_REPEATS))
 
     def timed_fused(value_hm, spatial_shapes, level_start_index, reference_points, proj, num_levels, num_points,
                     order=None, out_dtype=None, proj_head_major=False):
@@ -286,62 +463,56 @@ def main():
         record(call, value_hm, reference_points, proj, proj_head_major, o, "msda_gather_l4p4_kernel<half_t>")
         return o
 
-    real_resident = msda_mod.msda_resident_forward
-
     def timed_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=None, chunks=0):
         call = lambda: real_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=out_dtype, chunks=chunks)
         o = call()
         record(call, value_hm, reference_points, proj_hm, True, o, "msda_resident_kernel<half_t>")
         return o
 
-    def marker(layer_id):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        layer_events.append((layer_id, e))
-
+    sel_log = {}
     msda_mod.msda_fused_forward = timed_fused
     msda_mod.msda_resident_forward = timed_resident
-    model.encoder.layer_marker = marker
-    for _ in range(args.instrumented_steps):
-        step()
-    torch.cuda.synchronize()
-    msda_mod.msda_fused_forward = real_fused
-    msda_mod.msda_resident_forward = real_resident
-    model.encoder.layer_marker = None
-
-    nl = model.encoder.num_layers
-    msda_us = [0.0] * nl
-    for i, (e0, e1) in enumerate(msda_events):
-        msda_us[i % nl] += e0.elapsed_time(e1) * 1e3 / args.instrumented_steps / MSDA_REPEATS
-    layer_ms = [0.0] * nl
-    for (l0, e0), (l1, e1) in zip(layer_events[:-1], layer_events[1:]):
-        if l1 == l0 + 1:
-            layer_ms[l0] += e0.elapsed_time(e1) / args.instrumented_steps
-    bytes_per_layer = launches[:nl]
-    total_bytes, total_us = sum(bytes_per_layer), sum(msda_us)
-    achieved = total_bytes / total_us / 1e3  # GB/s
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same workload (bench.py cannot
-    # run the profiler on itself); null when the workload differs from the profiled one
-    traffic, traffic_src = None, None
+    model.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.cpu()) or s
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_msda_traffic.json")))
+        out_eager = step()
+        torch.cuda.synchronize()
+    finally:
+        msda_mod.msda_fused_forward = real_fused
+        msda_mod.msda_resident_forward = real_resident
+        model.encoder.selection_hook = None
+
+    bytes_per_layer = launches[:nl]
+    total_bytes, total_us = sum(bytes_per_layer), sum(msda_us[:nl])
+    achieved = total_bytes / total_us / 1e3  # GB/s
+    # HBM traffic per launch: rocprofv3 PMC passes of this same workload (benchmarks/profile_round.sh; bench.py cannot
+    # run the profiler on itself), valid only for the kernel sources they were measured with -> null otherwise
+    traffic, traffic_src = None, None
+    tag = kernel_source_tag()
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_traffic.json")))
         nqs = launch_nq[:nl]
-        if (args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same") and args.batch == tj["batch"]
-                and all(str(n) in tj["per_num_query"] for n in nqs)):
+        if (tj.get("kernel_source_tag") == tag and args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same")
+                and args.batch == tj["batch"] and all(str(n) in tj["per_num_query"] for n in nqs)):
             traffic = int(sum(tj["per_num_query"][str(n)]["hbm_bytes"] for n in nqs) / nl)
-            traffic_src = "profiles/r01_msda_traffic.json"
+            traffic_src = "profiles/r02_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tag
+        else:
+            traffic_src = "null: committed PMC passes were measured on other kernel sources (%s) than these (%s)" % (
+                tj.get("kernel_source_tag"), tag)
     except (OSError, ValueError, KeyError):
-        pass
+        traffic_src = "null: no PMC passes committed for this round"
     roofline = {
         "kernel": "sdetr::" + " / ".join(sorted(set(kernels_used[:nl])))
                   + " (fused softmax + sampling locations + bilinear gather)",
         "kernel_per_layer": kernels_used[:nl],
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-        "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(total_bytes / nl),
+        "traffic_source": traffic_src, "kernel_source_tag": tag, "algorithmic_bytes_per_launch": int(total_bytes / nl),
         "launches_per_step": nl, "num_queries_per_layer": launch_nq[:nl], "avg_launch_us": round(total_us / nl, 2),
-        "per_layer_us": [round(u, 2) for u in msda_us],
+        "per_layer_us": [round(u, 2) for u in msda_us[:nl]],
+        "per_layer_frac": [round(b / u / 1e3 / HBM_PEAK_GBPS, 4) for b, u in zip(bytes_per_layer, msda_us[:nl])],
         "per_layer_algorithmic_MB": [round(b / 1e6, 2) for b in bytes_per_layer],
+        "timing": "per launch: %d back-to-back repetitions of the step's own launch captured in a hipGraph, replayed "
+                  "between two events on the launch stream" % MSDA_REPEATS,
     }
 
     result = {
@@ -355,39 +526,21 @@ def main():
                    "image": [args.height, args.width], "levels": [list(s) for s in level_shapes],
                    "value_map_storage": ("fp16" if (args.dtype == "bf16" and args.value_dtype == "fp16") else args.dtype),
                    "parallelism": "replicas, images sharded across GPUs, no data-path collective",
-                   "hipgraph": graphed},
-        "ms_per_encoder_layer": {"mean": round(sum(layer_ms) / nl, 4), "per_layer": [round(x, 4) for x in layer_ms],
-                                 "note": "eager instrumented pass (stream events at layer boundaries)"},
+                   "hipgraph": graphed, "world_size": world, "backend": backend or "none (single process)"},
+        "ms_per_encoder_layer": {"mean": (round(sum(layer_ms) / nl, 4) if layer_ms[0] is not None else None),
+                                 "per_layer": [None if x is None else round(x, 4) for x in layer_ms], "note": layer_note},
         "roofline": roofline,
     }
 
     # ---- CPU baseline: the oracle's port of the same path on the host cores (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import salience_ref as R  # checker / baseline only; never on the product path
-        from oracle import msda_c
-        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-        cf, cm, cp = cpu_inputs
-        cores = torch.get_num_threads()
-        times = []
-        t_start = time.perf_counter()
-        with torch.no_grad():
-            R.hot_path(sd, cf, cm, cp)  # warm-up
-            while len(times) < 5 and time.perf_counter() - t_start < 20.0:
-                t1 = time.perf_counter()
-                ref = R.hot_path(sd, cf, cm, cp)
-                times.append(time.perf_counter() - t1)
-        times.sort()
-        med = times[len(times) // 2]
-        err = (out.float().cpu() - ref["memory"]).abs()
-        result["cpu_baseline"] = {
-            "value": round(args.batch / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d timed passes of the same batch-%d 800x1333 hot path (oracle/salience_ref.py, fp32, "
-                      "torch CPU ops + OpenMP C gather on %d threads), median" % (len(times), args.batch,
-                                                                                  msda_c.num_threads()),
-            "ms_per_pass": round(med * 1e3, 1),
-        }
-        result["parity_vs_cpu"] = {"max_abs": round(float(err.max()), 5), "mean_abs": round(float(err.mean()), 6),
-                                   "note": "GPU %s output vs fp32 CPU oracle on the same batch" % args.dtype}
+        def cpu_inputs_of(batch):
+            if batch == args.batch:
+                return cpu_inputs
+            return make_inputs(batch, args.height, args.width, "cpu", seed=rank)[3]
+        result["cpu_baseline"], parity = cpu_baseline(args, model, cpu_inputs_of, out_eager, sel_log)
+        if parity is not None:
+            result["parity_vs_cpu"] = parity
 
     if rank == 0:
         print(json.dumps(result))

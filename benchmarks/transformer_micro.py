@@ -32,7 +32,7 @@ def main():
     shapes = [tuple(m.shape[-2:]) for m in masks]
     feats = [f.to(dev) for f in syn.make_feats(2, shapes, 256, 0)]
     masks = [m.to(dev) for m in masks]
-    pe = pyramid.PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5).to(dev)
+    pe = lambda mask: syn.sine_position_embedding(mask, 128)
     pos = [pe(m) for m in masks]
 
     def whole():

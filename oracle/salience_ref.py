@@ -270,11 +270,13 @@ def encoder_reference_points(shapes: torch.Tensor, valid_ratios: torch.Tensor) -
 
 
 def encoder_layer(sd: SD, prefix: str, query, query_pos, value, ref, shapes, lsi, pad_mask, score_tgt,
-                  fg_pre, heads, levels, points, topk_sa, core=msda_core_c):
-    """salience_transformer.py:353-396 (dropout = 0)."""
+                  fg_pre, heads, levels, points, topk_sa, core=msda_core_c, collect_sel=None):
+    """salience_transformer.py:353-396 (dropout = 0).  ``collect_sel``: list that receives the top-k index set."""
     E = query.shape[-1]
     mc = score_tgt.max(-1)[0] * fg_pre
     sel = topk_desc_stable(mc, topk_sa)[1]
+    if collect_sel is not None:
+        collect_sel.append(sel)
     sel_e = sel.unsqueeze(-1).expand(-1, -1, E)
     tgt = torch.gather(query, 1, sel_e)
     pos = torch.gather(query_pos, 1, sel_e)
@@ -301,14 +303,17 @@ def learned_background(sd: SD, prefix: str, masks: Sequence[torch.Tensor]) -> to
 
 def encoder(sd: SD, query, shapes, lsi, valid_ratios, query_pos, pad_mask, foreground_score,
             focus_token_nums, foreground_inds, masks, heads, levels, points, topk_sa, num_layers,
-            prefix="encoder", core=msda_core_c, collect=None):
-    """salience_transformer.py:434-497."""
+            prefix="encoder", core=msda_core_c, collect=None, collect_sel=None, collect_in=None, timings=None):
+    """salience_transformer.py:434-497.  ``timings`` (dict, optional): wall seconds per encoder layer are added under
+    ``encoder_layer_<k>`` (the CPU-baseline leg of bench.py reports them per stage)."""
+    import time
     ref_all = encoder_reference_points(shapes, valid_ratios)
     B, S, Lr, two = ref_all.shape
     E = query.shape[-1]
     value = output = query
     inds_e = None
     for k in range(num_layers):
+        t_layer = time.perf_counter()
         inds = foreground_inds[k]
         inds_e = inds.unsqueeze(-1).expand(-1, -1, E)
         q = torch.gather(output, 1, inds_e)
@@ -316,8 +321,10 @@ def encoder(sd: SD, query, shapes, lsi, valid_ratios, query_pos, pad_mask, foreg
         fg = torch.gather(foreground_score, 1, inds)
         ref = torch.gather(ref_all.view(B, S, -1), 1, inds.unsqueeze(-1).expand(-1, -1, Lr * two)).view(B, -1, Lr, two)
         score_tgt = linear(sd, prefix + ".enhance_mcsp", q)
+        if collect_in is not None:   # the layer's inputs, for teacher-forced per-layer checks
+            collect_in.append(dict(query=q, query_pos=qp, ref=ref, fg=fg, inds=inds))
         q = encoder_layer(sd, f"{prefix}.layers.{k}", q, qp, value, ref, shapes, lsi, pad_mask, score_tgt, fg,
-                          heads, levels, points, topk_sa, core)
+                          heads, levels, points, topk_sa, core, collect_sel=collect_sel)
         if collect is not None:
             collect.append(q)
         new = []
@@ -325,6 +332,8 @@ def encoder(sd: SD, query, shapes, lsi, valid_ratios, query_pos, pad_mask, foreg
             n = int(focus_token_nums[i])
             new.append(output[i].scatter(0, inds[i, :n].unsqueeze(-1).expand(-1, E), q[i, :n]))
         output = torch.stack(new)
+        if timings is not None:
+            timings[f"encoder_layer_{k}"] = timings.get(f"encoder_layer_{k}", 0.0) + time.perf_counter() - t_layer
     bg = learned_background(sd, prefix + ".background_embedding", masks).clone()
     bg.scatter_(1, inds_e, 0)
     bg = bg * (~pad_mask).unsqueeze(-1)
@@ -332,8 +341,19 @@ def encoder(sd: SD, query, shapes, lsi, valid_ratios, query_pos, pad_mask, foreg
 
 
 # ----------------------------------------------------------------------------- whole hot path
-def hot_path(sd: SD, feats, masks, pos, heads=8, points=4, topk_sa=300, num_layers=6, core=msda_core_c):
-    """SalienceTransformer.forward up to ``memory`` (salience_transformer.py:97-183)."""
+def hot_path(sd: SD, feats, masks, pos, heads=8, points=4, topk_sa=300, num_layers=6, core=msda_core_c, timings=None):
+    """SalienceTransformer.forward up to ``memory`` (salience_transformer.py:97-183).  ``timings`` (dict, optional)
+    receives wall seconds of ``F0_F3_filtering``, ``encoder_layer_<k>`` and ``msda_core`` (the op alone, summed)."""
+    import time
+    t_start = time.perf_counter()
+    if timings is not None:
+        inner = core
+
+        def core(*a, **kw):   # noqa: F811 -- the same op, timed
+            t0 = time.perf_counter()
+            r = inner(*a, **kw)
+            timings["msda_core"] = timings.get("msda_core", 0.0) + time.perf_counter() - t0
+            return r
     L = len(feats)
     feat_flat = flatten_levels(feats)
     mask_flat = flatten_levels(masks)
@@ -344,14 +364,17 @@ def hot_path(sd: SD, feats, masks, pos, heads=8, points=4, topk_sa=300, num_laye
     score_maps, level_inds, level_score = level_filtering(sd, bom, mask_flat, shapes, lsi, level_token_nums)
     fg_inds, fg_score = salience_filtering(score_maps, level_inds, level_score, mask_flat,
                                            sd["layer_filter_ratio"])
-    layer_out = []
+    if timings is not None:
+        timings["F0_F3_filtering"] = timings.get("F0_F3_filtering", 0.0) + time.perf_counter() - t_start
+    layer_out, layer_sel, layer_in = [], [], []
     memory = encoder(sd, feat_flat, shapes, lsi, vr, pos_flat, mask_flat, fg_score, focus, fg_inds, masks,
-                     heads, L, points, topk_sa, num_layers, core=core, collect=layer_out)
+                     heads, L, points, topk_sa, num_layers, core=core, collect=layer_out, collect_sel=layer_sel,
+                     collect_in=layer_in, timings=timings)
     return dict(feat_flatten=feat_flat, mask_flatten=mask_flat, lvl_pos_embed_flatten=pos_flat,
                 spatial_shapes=shapes, level_start_index=lsi, valid_ratios=vr, backbone_output_memory=bom,
                 focus_token_nums=focus, level_token_nums=level_token_nums, score_maps=score_maps,
                 level_inds=level_inds, level_score=level_score, foreground_inds=fg_inds,
-                foreground_score=fg_score, layer_out=layer_out, memory=memory)
+                foreground_score=fg_score, layer_out=layer_out, layer_sel=layer_sel, layer_in=layer_in, memory=memory)
 
 
 # ----------------------------------------------------------------------------- D1 decoder (row N2)

@@ -101,3 +101,86 @@ class FlatGradAllReducer:
                 else:
                     p.grad.copy_(g)
                 off += n
+
+
+class OverlappedGradReducer(FlatGradAllReducer):
+    """``FlatGradAllReducer`` whose buckets are reduced WHILE backward is still running (the reference gets the
+    same from ``DistributedDataParallel``'s bucket hooks, ``main.py:94-103``, ``util/engine.py:58``).
+
+    Parameters are bucketed in REVERSE registration order -- roughly the order in which backward produces their
+    gradients -- and every parameter carries a ``post_accumulate_grad`` hook: the hook copies the finished gradient
+    into its slot of the flat bucket and, when the bucket's last gradient has arrived, starts that bucket's
+    all-reduce asynchronously (on RCCL's own stream, so it overlaps the remaining backward kernels).  ``finish()``
+    -- called after ``backward()`` -- starts the buckets that are still incomplete on this rank (parameters another
+    rank used and this one did not contribute zeros), waits, averages and writes the results back to ``p.grad``.
+    Every rank starts the buckets in the same order (bucket index), as collectives require: a bucket that completes
+    early waits for its predecessors.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: Optional[int] = 8 << 20, group=None):
+        ps = [p for p in params]
+        super().__init__(reversed(ps), bucket_bytes=bucket_bytes, group=group)
+        self._slot = {}
+        for bi, bucket in enumerate(self.buckets):
+            off = 0
+            for p in bucket:
+                self._slot[id(p)] = (bi, off)
+                off += p.numel()
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._reset()
+
+    def _reset(self):
+        self._arrived = [0] * len(self.buckets)
+        self._filled = set()
+        self._works = [None] * len(self.buckets)
+        self._next_launch = 0
+
+    def _launch_ready(self, force: bool = False):
+        while self._next_launch < len(self.buckets):
+            bi = self._next_launch
+            if not force and self._arrived[bi] < len(self.buckets[bi]):
+                return
+            if self._arrived[bi] < len(self.buckets[bi]):   # finish(): parameters without a gradient on this rank
+                off = 0
+                for p in self.buckets[bi]:
+                    if id(p) not in self._filled:
+                        self.flat[bi][off:off + p.numel()].zero_()
+                    off += p.numel()
+            self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._next_launch += 1
+
+    def _on_grad(self, p: torch.nn.Parameter):
+        bi, off = self._slot[id(p)]
+        self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
+        if id(p) not in self._filled:
+            self._filled.add(id(p))
+            self._arrived[bi] += 1
+        self._launch_ready()
+
+    def finish(self, average: bool = True) -> None:
+        """After ``backward()``: reduce what is left, wait, average, unpack into ``p.grad``; ready for the next step."""
+        world = dist.get_world_size(self.group)
+        self._launch_ready(force=True)
+        for w in self._works:
+            w.wait()
+        for bucket, flat in zip(self.buckets, self.flat):
+            if average:
+                flat.div_(world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        self._reset()
+
+    def all_reduce(self, average: bool = True) -> None:   # same call site as the non-overlapped reducer
+        self.finish(average)
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -97,40 +97,6 @@ def encoder_output_memory(enc_output: nn.Linear, enc_output_norm: nn.LayerNorm, 
     return enc_output_norm(enc_output(memory * keep.unsqueeze(-1).to(memory.dtype)))
 
 
-class PositionEmbeddingSine(nn.Module):
-    """DETR sine embedding of a padding mask (position_encoding.py:10-67); same constructor."""
-
-    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6,
-                 offset=0.0):
-        super().__init__()
-        dim_t = 2 * torch.arange(num_pos_feats).div(2, rounding_mode="floor") / num_pos_feats
-        if isinstance(temperature, int):
-            dim_tx = dim_ty = temperature ** dim_t
-        else:
-            assert len(temperature) == 2, "Only support two elements as (t_x, t_y) in temperature"
-            dim_tx, dim_ty = [t ** dim_t for t in temperature]
-        self.register_buffer("dim_tx", dim_tx)
-        self.register_buffer("dim_ty", dim_ty)
-        self.normalize, self.scale, self.eps, self.offset = normalize, scale, eps, offset
-
-    def forward(self, mask: Tensor) -> Tensor:
-        not_mask = 1 - mask.to(torch.int)
-        y_embed = not_mask.cumsum(1, dtype=torch.float32)
-        x_embed = not_mask.cumsum(2, dtype=torch.float32)
-        if self.normalize:
-            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
-            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
-        else:
-            y_embed = y_embed + self.offset
-            x_embed = x_embed + self.offset
-        pos_x = x_embed[:, :, :, None] / self.dim_tx
-        pos_y = y_embed[:, :, :, None] / self.dim_ty
-        pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
-        pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
-        # contiguous NCHW: the flatten kernel downstream then reads it without a per-forward re-layout copy
-        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2).contiguous()
-
-
 class PositionEmbeddingLearned(nn.Module):
     """Learned row/column embedding (position_encoding.py:70-99); used as the encoder's background
     embedding.  ``flat(level_shapes)`` returns the batch-independent ``[S, 2*num_pos_feats]`` table."""

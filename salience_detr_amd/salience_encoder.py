@@ -143,7 +143,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
-                       class_head, level_shapes=None):
+                       class_head, level_shapes=None, selection_hook=None):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
@@ -154,6 +154,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
         else:
             mc_score = class_max_times(class_head(query), fg_sorted[:, :c])
         sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
+        if selection_hook is not None:   # instrumentation: record the layer's top-k set, or force a given one
+            sel = selection_hook(sel)
         N = sel.shape[1]
         fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
         if (self.fused_topk_attention and fuse_tail and topk_attention_applies(query, self.pre_attention, N)
@@ -246,6 +248,11 @@ class SalienceTransformerEncoder(nn.Module):
         # optional instrumentation: a callable(tag) invoked at every layer boundary of the loop
         # (bench.py records a stream event there to report ms per encoder layer)
         self.layer_marker = None
+        # optional instrumentation (tests / bench.py): callable(layer_id, sel [B,topk] int64) -> sel, invoked with every
+        # layer's top-k selection (return it unchanged to record, or another index set to teacher-force the layer);
+        # `max_layers` stops the loop after that many layers (truncated graphs: ms per encoder layer under replay)
+        self.selection_hook = None
+        self.max_layers = None
         self.init_weights()
 
     def init_weights(self):
@@ -348,10 +355,16 @@ class SalienceTransformerEncoder(nn.Module):
                 fg_s = torch.gather(foreground_score, 1, sorted_index)
             result = torch.empty_like(q)
             for layer_id, layer in enumerate(self.layers):
+                if self.max_layers is not None and layer_id >= self.max_layers:
+                    break
                 if self.layer_marker is not None:
                     self.layer_marker(layer_id)
+                hook = None
+                if self.selection_hook is not None:
+                    hook = (lambda sel, k=layer_id: self.selection_hook(k, sel))
                 y = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
-                                         level_start_index, self.enhance_mcsp, level_shapes=level_shapes)
+                                         level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
+                                         selection_hook=hook)
                 nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
                 q = advance_rows(y, result, nxt, value, sorted_index, focus64)
             if self.layer_marker is not None:

@@ -180,3 +180,30 @@ def make_encoder_like_queries(B: int, Nq: int, level_shapes: Sequence[Tuple[int,
     proj = torch.cat([torch.randn(B, Nq, M * L * P * 2, generator=g) * offset_px,
                       torch.randn(B, Nq, M * L * P, generator=g)], -1)
     return tok, ref, proj.to(dtype), shapes, lsi
+
+
+def sine_position_embedding(mask: torch.Tensor, num_pos_feats: int = 128, temperature: float = 10000.0,
+                            eps: float = 1e-6, offset: float = -0.5) -> torch.Tensor:
+    """Caller-side input generation: the normalised 2-d sine position map the reference's detector feeds the
+    transformer (semantics of ``models/bricks/position_encoding.py:33-67`` with ``normalize=True``, pinned by the
+    ``pos{l}`` arrays of ``tests/golden/hotpath_small_*.npz``).  ``mask`` ``[B,H,W]`` bool, True on padding ->
+    ``[B, 2*num_pos_feats, H, W]`` fp32, channels = (y features, x features).
+
+    Written from the definition: along each axis the coordinate of a pixel is its 1-based rank among the valid
+    pixels of its column / row (+ offset), divided by that line's valid count and scaled to 2*pi; feature 2i / 2i+1
+    are sin / cos of coordinate / temperature^(2i / num_pos_feats).
+    """
+    valid = (~mask).to(torch.float32)
+    two_pi = 2.0 * math.pi
+    freq = temperature ** (2.0 * torch.div(torch.arange(num_pos_feats, dtype=torch.float32, device=mask.device), 2,
+                                           rounding_mode="floor") / num_pos_feats)
+
+    def axis_features(dim: int) -> torch.Tensor:
+        rank = valid.cumsum(dim)
+        total = rank.narrow(dim, rank.shape[dim] - 1, 1)
+        coord = (rank + offset) / (total + eps) * two_pi                 # [B,H,W]
+        phase = coord.unsqueeze(-1) / freq                               # [B,H,W,F]
+        even, odd = phase[..., 0::2].sin(), phase[..., 1::2].cos()
+        return torch.stack((even, odd), dim=-1).flatten(-2)              # sin, cos interleaved
+
+    return torch.cat((axis_features(1), axis_features(2)), dim=-1).permute(0, 3, 1, 2).contiguous()

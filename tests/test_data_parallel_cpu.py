@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from salience_detr_amd import synthetic as syn
-from salience_detr_amd.data_parallel import FlatGradAllReducer, broadcast_parameters, shard_range
+from salience_detr_amd.data_parallel import (FlatGradAllReducer, OverlappedGradReducer, broadcast_parameters,
+                                             shard_range)
 from salience_detr_amd.salience_filtering import MaskPredictor
 
 
@@ -84,3 +85,66 @@ def test_two_rank_gradients_match_single_process(tmp_path, bucket_bytes):
             expect = dict(m2.named_parameters())[name].grad
         assert torch.allclose(g0[name], expect, atol=1e-6), name
         assert torch.equal(g0[name], g1[name]), name
+
+
+# ---- the REAL hot-path parameter list (the module bench.py --mode train reduces): 300+ tensors, the class head shared
+# between `encoder_class_head` and `encoder.enhance_mcsp`, parameters one rank did not use, overlapped bucket hooks ----
+def _hot_path_model():
+    from salience_detr_amd.hot_path import build_hot_path
+    m = build_hot_path(embed_dim=32, num_heads=4, d_ffn=64, num_layers=2, num_classes=7, topk_sa=4, max_num_embedding=16)
+    m.load_state_dict(syn.det_state_dict(m.state_dict(), num_heads=4))
+    return m
+
+
+def _synthetic_loss(model, rank_salt, skip=()):
+    """A loss that touches every parameter (the HIP forward cannot run on the CPU): sum_p <p, r_p(rank)>^2."""
+    total = 0.0
+    for name, p in model.named_parameters():
+        if name in skip:
+            continue
+        total = total + (p * syn.det_randn("dp.w." + name, p.shape, salt=rank_salt)).sum() ** 2
+    return total
+
+
+def _hot_worker(rank, world, port, overlapped, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _hot_path_model()
+        params = list(model.parameters())
+        red = (OverlappedGradReducer(params, bucket_bytes=16 << 10) if overlapped
+               else FlatGradAllReducer(params, bucket_bytes=16 << 10))
+        assert len(red.buckets) > 3
+        skip = ("alpha", "encoder.layers.1.norm2.bias") if rank == 1 else ()
+        for step in range(2):   # two steps: the hook state must reset
+            model.zero_grad(set_to_none=True)
+            _synthetic_loss(model, rank + 10 * step, skip).backward()
+            red.all_reduce(average=True)
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"h{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_hot_path_parameter_list_two_ranks(tmp_path, overlapped):
+    model = _hot_path_model()
+    # the aliased class head is ONE parameter in the reducer's list
+    assert model.encoder.enhance_mcsp.weight is model.encoder_class_head.weight
+    names = [n for n, _ in model.named_parameters()]
+    assert ("encoder_class_head.weight" in names) != ("encoder.enhance_mcsp.weight" in names)   # listed once
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_hot_worker, args=(2, port, overlapped, str(tmp_path)), nprocs=2, join=True)
+    g0 = torch.load(os.path.join(tmp_path, "h0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "h1.pt"))
+    grads = []
+    for rank in range(2):
+        m = _hot_path_model()
+        skip = ("alpha", "encoder.layers.1.norm2.bias") if rank == 1 else ()
+        _synthetic_loss(m, rank + 10, skip).backward()      # second step's data
+        grads.append({n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()})
+    for n in g0:
+        expect = 0.5 * (grads[0][n] + grads[1][n])
+        assert torch.allclose(g0[n], expect, rtol=1e-5, atol=1e-6), n
+        assert torch.equal(g0[n], g1[n]), n

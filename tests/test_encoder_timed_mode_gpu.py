@@ -1,0 +1,100 @@
+"""The TIMED mode of bench.py -- bf16 activations, fp16 head-major value maps -- bounded against the oracle
+(VERDICT r1, items 1b / weak #2).
+
+Teacher-forced per layer: every encoder layer is handed the ORACLE's own layer input (the fp32 rows of
+`oracle/salience_ref.py::encoder`, rounded to bf16) and the oracle's top-300 index set, so a selection flip cannot
+hide in (or be blamed for) the error; its output is compared with `R.encoder_layer` (salience_transformer.py:353-396)
+at the benchmark shape (2 x 800x1333, E=256, 6 layers).  What remains is pure storage / arithmetic rounding of the
+bf16 mode: bf16 activations (2^-9 relative per stored value) through MHA-300, MSDA, FFN and three LayerNorms.
+
+Bars (outputs are LayerNorm outputs, |x| ~ 1): mean |err| <= 8e-3, 99.9 % of elements <= 6e-2, max <= 0.25.
+"""
+import pytest
+import torch
+
+from oracle import salience_ref as R
+from salience_detr_amd import ms_deform_attn as M
+from salience_detr_amd import pyramid
+from salience_detr_amd import synthetic as syn
+from salience_detr_amd.filter_ops import encoder_reference_points
+from salience_detr_amd.hot_path import build_hot_path
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def timed_case():
+    sizes = [(800, 1333), (800, 1333)]
+    m = build_hot_path()
+    m.load_state_dict(syn.det_state_dict(m.state_dict()))
+    _, masks = syn.make_masks(sizes)
+    shapes = [tuple(x.shape[-2:]) for x in masks]
+    feats = syn.make_feats(len(sizes), shapes, 256, seed=0)
+    pos = [syn.sine_position_embedding(x, 128) for x in masks]
+    sd = {k: v.detach().float().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = R.hot_path(sd, feats, masks, pos)
+    m = m.to(DEV).eval()
+    m.set_encoder_dtype(torch.bfloat16, torch.float16)
+    return m, sizes, shapes, feats, masks, pos, ref
+
+
+def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case):
+    m, sizes, level_shapes, feats, masks, pos, ref = timed_case
+    enc = m.encoder
+    feat_flat = ref["feat_flatten"].to(DEV).to(torch.bfloat16)
+    mask_flat = ref["mask_flatten"].to(DEV)
+    shapes_d, lsi_d = ref["spatial_shapes"].to(DEV), ref["level_start_index"].to(DEV)
+    with torch.no_grad():
+        value_maps = enc.project_values(feat_flat, mask_flat)          # [6,B,8,Nv,32] fp16
+        assert value_maps.dtype == torch.float16
+        stats = []
+        for k, layer in enumerate(enc.layers):
+            lin, sel = ref["layer_in"][k], ref["layer_sel"][k].to(DEV)
+            q = lin["query"].to(DEV).to(torch.bfloat16).contiguous()
+            qp = lin["query_pos"].to(DEV).to(torch.bfloat16).contiguous()
+            out = layer.forward_sorted(q, qp, lin["ref"].to(DEV).contiguous(), lin["fg"].to(DEV).contiguous(),
+                                       value_maps[k], shapes_d, lsi_d, enc.enhance_mcsp, level_shapes=level_shapes,
+                                       selection_hook=lambda s, forced=sel: forced)
+            kernel = M.last_forward_kernel()
+            assert kernel == (M.KERNEL_RESIDENT if q.shape[1] >= layer.self_attn.resident_min_queries else M.KERNEL_L4P4)
+            err = (out.float().cpu() - ref["layer_out"][k]).abs()
+            stats.append((k, q.shape[1], err.mean().item(), err.flatten().kthvalue(int(err.numel() * 0.999))[0].item(),
+                          err.max().item()))
+    print("teacher-forced bf16 layer errors (layer, Nq, mean, p99.9, max):", stats)
+    for k, nq, mean, p999, mx in stats:
+        assert mean <= 8e-3, (k, mean)
+        assert p999 <= 6e-2, (k, p999)
+        assert mx <= 0.25, (k, mx)
+
+
+def test_whole_path_selection_flips_are_the_only_large_errors(timed_case):
+    """End to end in the timed mode: tokens whose membership in some layer's top-300 set differs from the oracle's
+    are counted; every OTHER token stays within the accumulated bf16 rounding of six layers."""
+    m, sizes, level_shapes, feats, masks, pos, ref = timed_case
+    sel_log = {}
+    m.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.clone()) or s
+    try:
+        with torch.no_grad():
+            memory = m([f.to(DEV) for f in feats], [x.to(DEV) for x in masks], [p.to(DEV) for p in pos],
+                       image_sizes=sizes, canvas=syn.pad_to_32(800, 1333))[0]
+    finally:
+        m.encoder.selection_hook = None
+    assert M.last_forward_kernel() == M.KERNEL_RESIDENT           # layer 5: 2272 queries per image
+    B, S, _ = memory.shape
+    flipped = torch.zeros(B, S, dtype=torch.bool)
+    for k in range(6):
+        inds = ref["foreground_inds"][k]                         # [B, c_k] token ids of the layer's rows
+        for b in range(B):
+            a = set(inds[b][ref["layer_sel"][k][b]].tolist())
+            g = set(inds[b][sel_log[k][b].cpu()].tolist())
+            for tok in a ^ g:
+                flipped[b, tok] = True
+    err = (memory.float().cpu() - ref["memory"]).abs().max(-1)[0]   # per token
+    n_flip = int(flipped.sum())
+    clean = err[~flipped]
+    print(f"selection flips: {n_flip} tokens of {B * S}; non-flipped tokens: max {clean.max():.4f} mean {clean.mean():.5f}")
+    assert n_flip <= 0.02 * B * 300 * 6            # a handful of near-ties per layer at most
+    assert clean.mean().item() <= 0.03
+    assert (clean <= 0.3).float().mean().item() >= 0.999

@@ -31,7 +31,7 @@ def test_pyramid_plumbing_matches_golden(tag):
     lp = pyramid.get_lvl_pos_embed(_t(d["sd.level_embeds"]), pos)
     assert (lp - _t(d["lvl_pos_embed_flatten"])).abs().max() < 1e-6
     E = int(d["hyper"][0])
-    pe = pyramid.PositionEmbeddingSine(E // 2, temperature=10000, normalize=True, offset=-0.5)
+    pe = lambda mask: syn.sine_position_embedding(mask, E // 2)
     for l in range(4):
         assert (pe(masks[l]) - pos[l]).abs().max() < 2e-6
     lin = torch.nn.Linear(E, E)

@@ -74,7 +74,7 @@ def test_hotpath_small_golden(tag, host_budgets):
 def test_positional_embeddings_match_golden():
     d = np.load(os.path.join(G, "hotpath_small_mixed.npz"))
     E = int(d["hyper"][0])
-    pe = pyramid.PositionEmbeddingSine(E // 2, temperature=10000, normalize=True, offset=-0.5).to(DEV)
+    pe = lambda mask: syn.sine_position_embedding(mask, E // 2)
     for l in range(4):
         got = pe(_t(d[f"mask{l}"]).to(DEV))
         assert (got.cpu() - _t(d[f"pos{l}"])).abs().max() < 1e-5
@@ -89,8 +89,7 @@ def _full_model_and_inputs(image_sizes, level_shapes=None, max_emb=200):
     _, masks = syn.make_masks(image_sizes, level_shapes)
     shapes = [tuple(x.shape[-2:]) for x in masks]
     feats = syn.make_feats(len(image_sizes), shapes, 256, seed=0)
-    pe = pyramid.PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5)
-    pos = [pe(x) for x in masks]
+    pos = [syn.sine_position_embedding(x, 128) for x in masks]
     return m, feats, masks, pos
 
 

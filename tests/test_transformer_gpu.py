@@ -173,8 +173,7 @@ def test_transformer_full_size_bf16_runs_and_agrees_with_fp32_selection():
     _, masks = syn.make_masks(image_sizes)
     shapes = [tuple(m.shape[-2:]) for m in masks]
     feats = [f.cuda() for f in syn.make_feats(2, shapes, 256, 0)]
-    from salience_detr_amd.pyramid import PositionEmbeddingSine
-    pe = PositionEmbeddingSine(128, temperature=10000, normalize=True, offset=-0.5).cuda()
+    pe = lambda mask: syn.sine_position_embedding(mask, 128)
     masks = [m.cuda() for m in masks]
     pos = [pe(m) for m in masks]
     with torch.no_grad():
