@@ -30,6 +30,7 @@ from salience_detr_amd import ms_deform_attn as msda_mod  # noqa: E402
 from salience_detr_amd import pyramid, synthetic as syn  # noqa: E402
 from salience_detr_amd.hot_path import build_hot_path  # noqa: E402
 
+DEFAULT_THREADS = torch.get_num_threads()
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MSDA_REPEATS = 8
 
@@ -51,6 +52,8 @@ def parse():
                          "(default; 11-bit mantissa, gather via v_fma_mix_f32) or the activation dtype (bf16)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-value-proj", action="store_true",
+                    help="run the six layers' value projection on a side stream next to the filtering stage")
     ap.add_argument("--plain", action="store_true",
                     help="only the timed loop and a minimal JSON line (what the rocprofv3 counter passes wrap: no "
                          "instrumented pass, no truncated graphs, no CPU baseline)")
@@ -264,7 +267,9 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
     from oracle import salience_ref as R  # checker / baseline only; never on the product path
     from oracle import msda_c
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    all_cores = os.cpu_count() or torch.get_num_threads()
+    # torch's default intra-op thread count = the physical cores (hyper-thread siblings only slow the GEMMs down:
+    # 62 s per pass at 256 threads against 4 s at 128 on a 2 x 64-core EPYC 9575F)
+    all_cores = DEFAULT_THREADS
     full = args.cpu_protocol == "full"
     plans = [(args.batch, all_cores, 3 if full else 1, 10 if full else 3)]
     if full:
@@ -278,7 +283,6 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
         pass
     for batch, threads, warm, reps in plans:
         torch.set_num_threads(threads)
-        os.environ["OMP_NUM_THREADS"] = str(threads)
         cf, cm, cp = cpu_inputs_of(batch)
         per_pass, stages = [], []
         with torch.no_grad():
@@ -363,6 +367,7 @@ def main():
         return train_main(args, model, device, rank, world, dist)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_encoder_dtype(dtype, torch.float16 if (args.dtype == "bf16" and args.value_dtype == "fp16") else None)
+    model.overlap_value_projection = bool(args.overlap_value_proj)
 
     sizes, canvas, level_shapes, cpu_inputs, (feats, masks, pos) = make_inputs(
         args.batch, args.height, args.width, device, seed=rank)

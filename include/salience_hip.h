@@ -168,6 +168,24 @@ int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, i
                                   int num_heads, int channels, int num_levels, int num_query,
                                   int num_point, void *out, int out_dtype);
 
+/* The encoder layer's dense self-attention over its selected rows, bf16, embed_dim 256, 8 heads
+ * (models/bricks/salience_transformer.py:366-379: gather of select_tgt / select_pos, nn.MultiheadAttention with
+ * q = k = x + pos and v = x, residual + pre_norm, scatter back) in two launches (csrc/topk_attention.hip):
+ *   query   [B, num_rows, 256] bf16, images query_batch_stride elements apart: rows selected[b][i] are the inputs AND
+ *           receive pre_norm(x + out_proj(attention)) in place
+ *   pos     [B, >= num_rows, 256] bf16 position rows in the same row order, images pos_batch_stride elements apart
+ *   selected [B, num_selected] int64 distinct row numbers
+ *   in_proj_weight [768,256] / in_proj_bias [768], out_proj_weight [256,256] / out_proj_bias [256], norm weight /
+ *   bias [256]: bf16 device tensors exactly as nn.MultiheadAttention / nn.LayerNorm hold them
+ *   workspace: sdetr_topk_attention_workspace_bytes(B, num_selected) bytes of device scratch (q / k rows, V^T). */
+int64_t sdetr_topk_attention_workspace_bytes(int batch_size, int num_selected);
+int sdetr_topk_attention_bf16(sdetr_stream_t stream, void *query, int64_t query_batch_stride, const void *pos,
+                              int64_t pos_batch_stride, const int64_t *selected, int batch_size, int num_rows,
+                              int num_selected, const void *in_proj_weight, const void *in_proj_bias,
+                              const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
+                              const void *norm_bias, float norm_eps, int embed_dim, int num_heads, void *workspace,
+                              int64_t workspace_bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * (4) Salience filtering: masked top-k, sorted descending, ties -> lower index first.
  *     Replaces the torch.topk / torch.sort calls of the inline filtering code

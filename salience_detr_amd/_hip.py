@@ -37,6 +37,9 @@ SIGNATURES = {
     "sdetr_msda_resident_max_pixels": (_i, []),
     "sdetr_msda_resident_forward": (_i, [_p, _p, _i, _p, _p, _i, _i64, _p, _i, _i, _i, _i, _p, _i, _i]),
     "sdetr_msda_last_kernel": (_i, []),
+    "sdetr_topk_attention_workspace_bytes": (_i64, [_i, _i]),
+    "sdetr_topk_attention_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i,
+                                       _p, _i64]),
     "sdetr_tiled_config": (None, [_p, _p, _p]),
     "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),

@@ -972,3 +972,38 @@ def neck_gate_shortcut(y: Tensor, mask_weight: Tensor, squeeze_weight: Tensor, e
                                             ws_bytes, gate.data_ptr(), out.data_ptr())
     _hip.check(code, "neck_gate_shortcut")
     return out
+
+
+def topk_self_attention_applies(query: Tensor, pos: Tensor, mha, norm, num_selected: int) -> bool:
+    """The two-launch top-k self-attention (csrc/topk_attention.hip) covers the released configuration: bf16,
+    embed_dim 256, 8 heads, no dropout, batch-first parameters in bf16."""
+    return (query.is_cuda and query.dtype == torch.bfloat16 and pos.dtype == torch.bfloat16 and query.dim() == 3
+            and query.shape[-1] == 256 and mha.embed_dim == 256 and mha.num_heads == 8 and mha.in_proj_weight is not None
+            and mha.in_proj_weight.dtype == torch.bfloat16 and mha.in_proj_bias is not None
+            and mha.out_proj.bias is not None and norm.weight.dtype == torch.bfloat16 and norm.bias is not None
+            and 0 < num_selected <= 1152 and query.stride(2) == 1 and query.stride(1) == 256
+            and pos.stride(2) == 1 and pos.stride(1) == 256)
+
+
+def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm) -> Tensor:
+    """In place on ``query`` [B,rows,256] bf16: rows ``selected[b]`` become
+    ``norm(x + mha(q = k = x + pos, v = x))`` (salience_transformer.py:366-379); ``pos`` [B,>=rows,256] holds the position
+    rows in the same row order (may be a row prefix of a longer buffer).  Two launches, no library GEMM."""
+    _hip.require_device("topk_self_attention_", selected=selected)
+    B, rows, _ = query.shape
+    N = selected.shape[1]
+    if not topk_self_attention_applies(query, pos, mha, norm, N) or selected.dtype != torch.int64 or selected.shape[0] != B:
+        raise RuntimeError("topk_self_attention_: bf16 [B,rows,256] HIP tensors, 8 heads, int64 [B,N] selection expected; "
+                           "no CPU fallback")
+    lib = _hip.lib()
+    ws = torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, N), dtype=torch.uint8, device=query.device)
+    qbs = query.stride(0) if B > 1 else rows * 256
+    pbs = pos.stride(0) if B > 1 else pos.shape[1] * 256
+    with torch.cuda.device(query.device):
+        code = lib.sdetr_topk_attention_bf16(
+            _hip.stream_ptr(), query.data_ptr(), qbs, pos.data_ptr(), pbs, selected.data_ptr(), B, rows, N,
+            mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), mha.out_proj.weight.data_ptr(),
+            mha.out_proj.bias.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), 256, 8,
+            ws.data_ptr(), ws.numel())
+    _hip.check(code, "topk_self_attention_")
+    return query

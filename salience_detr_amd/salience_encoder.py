@@ -29,7 +29,7 @@ from .filter_ops import (advance_rows, attention_heads, attention_heads_applies,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
-                         topk_attention_heads, value_proj_head_major)
+                         topk_attention_heads, topk_self_attention_, topk_self_attention_applies, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 
@@ -53,6 +53,9 @@ class SalienceTransformerEncoderLayer(nn.Module):
         # one-launch gather + in-projection + attention of the selected rows (csrc/mha_topk.hip): correct, but on
         # MI355X it only ties the three-launch path (its row gather is bound by one CU's L1 per head), so it is opt-in
         self.fused_topk_attention = False
+        # the default on the bf16 path: in-projection (with the gather and the position add in its operand loads) and
+        # attention + out_proj + residual + pre_norm + scatter as two launches of csrc/topk_attention.hip
+        self.two_launch_topk_attention = True
         # pre attention
         self.pre_attention = nn.MultiheadAttention(embed_dim, n_heads, dropout, batch_first=True)
         self.pre_dropout = nn.Dropout(dropout)
@@ -158,7 +161,13 @@ class SalienceTransformerEncoderLayer(nn.Module):
             sel = selection_hook(sel)
         N = sel.shape[1]
         fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
-        if (self.fused_topk_attention and fuse_tail and topk_attention_applies(query, self.pre_attention, N)
+        if (fuse_tail and not self.training and self.two_launch_topk_attention and sel.is_contiguous()
+                and topk_self_attention_applies(query, pos_sorted, self.pre_attention, self.pre_norm, N)):
+            # gather + (x + pos) + in-projection, then attention + out_proj + residual + pre_norm + scatter: two launches,
+            # no library GEMM (csrc/topk_attention.hip)
+            topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm)
+            stacked = None
+        elif (self.fused_topk_attention and fuse_tail and topk_attention_applies(query, self.pre_attention, N)
                 and not self.training):
             # gather + position add + in-projection + attention of the selected rows in one launch, then
             # out-projection (library GEMM: 600 rows) and gather + residual + pre_norm + scatter in one launch
@@ -178,12 +187,9 @@ class SalienceTransformerEncoderLayer(nn.Module):
             sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
                                                     level_start_index, query_pos=pos_sorted[:, :c],
                                                     apply_output_proj=False, level_shapes=level_shapes)
-            # ... but it pays for ten thousand queries and more: output_proj + residual + norm1 in one launch
-            if query.shape[0] * c >= 12000:
-                query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
-            else:
-                src2 = F.linear(sampled, self.self_attn.output_proj.weight, self.self_attn.output_proj.bias)
-                query = fused_layer_norm(query, self.norm1, residual=src2)
+            # output_proj + residual + norm1 in one launch of the token-resident kernel at every layer size (below ~12 000
+            # rows the library GEMM + separate LayerNorm is 1-2 us faster, but keeps hipBLASLt in the hot-path graph)
+            query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
             return self._forward_ffn_native(query)
         tgt2 = self._pre_attention_stacked(stacked, N)
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries

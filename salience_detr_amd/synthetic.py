@@ -195,8 +195,10 @@ def sine_position_embedding(mask: torch.Tensor, num_pos_feats: int = 128, temper
     """
     valid = (~mask).to(torch.float32)
     two_pi = 2.0 * math.pi
-    freq = temperature ** (2.0 * torch.div(torch.arange(num_pos_feats, dtype=torch.float32, device=mask.device), 2,
-                                           rounding_mode="floor") / num_pos_feats)
+    # (the frequency table is computed on the host: a device pow() differs from the CPU's in the last bits, which the
+    # phases of the high-frequency features amplify to ~1e-3)
+    freq = (temperature ** (2.0 * torch.div(torch.arange(num_pos_feats, dtype=torch.float32), 2,
+                                            rounding_mode="floor") / num_pos_feats)).to(mask.device)
 
     def axis_features(dim: int) -> torch.Tensor:
         rank = valid.cumsum(dim)
