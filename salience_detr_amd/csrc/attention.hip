@@ -185,12 +185,8 @@ extern "C" int sdetr_attention_heads_bf16(sdetr_stream_t stream, const void *q, 
     a.qchunks = (num_tokens + 32 * kAttWaves - 1) / (32 * kAttWaves); a.scale = scale;
     const int nblk = (num_tokens + 31) / 32;
     const size_t lds = (size_t)nblk * 4096;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attention_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kAttMaxBlocks * 4096);
-        attr_set = true;
-    }
+    static DeviceOnce lds_once1;
+    allow_dynamic_lds(attention_heads_kernel, lds_once1, kAttMaxBlocks * 4096);
     hipLaunchKernelGGL(attention_heads_kernel, dim3((unsigned)(batch_size * num_heads * a.qchunks)), dim3(64 * kAttWaves), lds,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("attention_heads");

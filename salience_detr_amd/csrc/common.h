@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +36,23 @@ inline int check_launch(const char *what)
         return (int)err;
     }
     return 0;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: raise it once per (kernel, device), not once
+// per process (a second GPU driven from the same process would otherwise launch with the 64 KiB default and fail).
+// `slots` is a per-kernel static array of 64 flags indexed by the current device.
+struct DeviceOnce {
+    std::atomic<bool> done[64];
+};
+template <typename K>
+inline void allow_dynamic_lds(K kernel, DeviceOnce &slots, int bytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!slots.done[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        slots.done[dev].store(true, std::memory_order_release);
+    }
 }
 
 // ---- bf16 <-> f32 (storage type is a raw 16-bit pattern) -------------------------------------

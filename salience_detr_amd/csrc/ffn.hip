@@ -536,12 +536,8 @@ extern "C" int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const 
                     (long long)sdetr_ffn_workspace_bytes(tokens, hidden_splits));
     const size_t lds = 4 * (size_t)kFChunkBytes + (size_t)hidden * 4 + 3 * kFE * 4;
     if (lds > 160 * 1024) return fail("ffn_fused: hidden %d needs %zu bytes of LDS", hidden, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static DeviceOnce lds_once1;
+    allow_dynamic_lds(ffn_fused_kernel, lds_once1, 160 * 1024);
     FfnArgs a;
     a.x = (const bf16_t *)x; a.pw = (const char *)packed_weights; a.b1 = bias1; a.b2 = bias2; a.gamma = norm_weight;
     a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out; a.T = tokens; a.nchunk = hidden / kFChunk;

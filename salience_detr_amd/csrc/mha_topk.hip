@@ -259,12 +259,8 @@ extern "C" int sdetr_topk_attention_heads_bf16(sdetr_stream_t stream, const void
     a.out = (bf16_t *)out; a.N = num_select; a.heads = num_heads; a.scale = 0.17677669529663687f;   // 1/sqrt(32)
     constexpr int W = kMhaMaxTokens / 32;
     const size_t lds = 3 * 16384 + 2 * (size_t)W * 2048;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mha_topk_kernel<W>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static DeviceOnce lds_once1;
+    allow_dynamic_lds(mha_topk_kernel<W>, lds_once1, (int)lds);
     hipLaunchKernelGGL(mha_topk_kernel<W>, dim3((unsigned)(batch_size * num_heads)), dim3(64 * W), lds,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("topk_attention");

@@ -546,12 +546,8 @@ extern "C" int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value
     if (proj_row_stride < (int64_t)M * L * P * 3 || (proj_row_stride % 8) != 0)
         return fail("msda_tiled_forward: proj row stride must be >= 3*M*L*P and a multiple of 8");
     if ((int64_t)B * Nq == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_tiled_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kTiledLds);
-        attr_set = true;
-    }
+    static DeviceOnce lds_once1;
+    allow_dynamic_lds(msda_tiled_kernel, lds_once1, kTiledLds);
     TiledArgs a{};
     a.value = reinterpret_cast<const char *>(value_hm); a.shapes = shapes; a.lsi = lsi; a.ref = ref; a.ref_dim = ref_dim;
     a.proj = proj; a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;

@@ -256,12 +256,8 @@ extern "C" int sdetr_grid_nms_topk(sdetr_stream_t stream, const int64_t *topk_in
     a.index = topk_index; a.index_batch_stride = index_batch_stride; a.L = num_levels; a.K = num_topk;
     a.S = spatial_size; a.neighbourhood = neighbourhood; a.max_keep = max_keep; a.out_index = out_index;
     a.out_count = out_count;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)grid_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return fail("grid_nms_topk: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
+    static DeviceOnce lds_once;
+    allow_dynamic_lds(grid_nms_kernel, lds_once, 150 * 1024);
     hipLaunchKernelGGL(grid_nms_kernel, dim3(batch_size), dim3(kNmsThreads), lds, (hipStream_t)stream, a);
     return check_launch("grid_nms_topk");
 }

@@ -560,12 +560,8 @@ extern "C" int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x,
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (stage1_block_tokens(batch_size, tokens) == 64) {
-        static bool attr_set = false;   // > 64 KiB of dynamic LDS has to be requested once
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(salience_head_stage1_kernel<2, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, stage1_lds_bytes(64));
-            attr_set = true;
-        }
+        static DeviceOnce lds_once;   // > 64 KiB of dynamic LDS has to be requested once per device
+        allow_dynamic_lds(salience_head_stage1_kernel<2, 4>, lds_once, (int)stage1_lds_bytes(64));
         a.nblk = (tokens + 63) / 64;
         hipLaunchKernelGGL((salience_head_stage1_kernel<2, 4>), dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(kBlock),
                            (size_t)stage1_lds_bytes(64), s, a);

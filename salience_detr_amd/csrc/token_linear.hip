@@ -471,12 +471,8 @@ static int tl_launch_one(hipStream_t s, const TLArgs &a)
 {
     const int nsteps = (a.ntiles + kTLStepTiles - 1) / kTLStepTiles;
     const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
-    static bool attr_set = false;   // (one flag per instantiation)
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_kernel<EPI, ADD2, WAVES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static DeviceOnce lds_once;   // (one set of flags per instantiation)
+    allow_dynamic_lds(token_linear_kernel<EPI, ADD2, WAVES>, lds_once, 160 * 1024);
     const int tpb = kTLTokWave * WAVES;
     hipLaunchKernelGGL((token_linear_kernel<EPI, ADD2, WAVES>), dim3((unsigned)((a.T + tpb - 1) / tpb)), dim3(64 * (WAVES + 4)), lds,
                        s, a);
@@ -605,12 +601,8 @@ extern "C" int sdetr_token_linear_ln_bf16(sdetr_stream_t stream, const void *x, 
     a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out; a.scatter_index = scatter_index;
     a.out_batch_rows = out_batch_rows; a.T = tokens;
     const size_t lds = 2 * (size_t)kTLStepBytes + 3 * kTLK * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_ln_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static DeviceOnce lds_once1;
+    allow_dynamic_lds(token_linear_ln_kernel, lds_once1, 160 * 1024);
     hipLaunchKernelGGL(token_linear_ln_kernel, dim3((unsigned)((tokens + kTLTokBlock - 1) / kTLTokBlock)), dim3(kBlock),
                        lds, static_cast<hipStream_t>(stream), a);
     return check_launch("token_linear_ln");

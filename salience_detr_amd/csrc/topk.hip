@@ -427,12 +427,8 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
         const size_t dyn = f.stage ? (size_t)n * 4 : 0;
 #define SDETR_PRE(KPT)                                                                                              \
     do {                                                                                                            \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(topk_prefilter_kernel<KPT>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                      \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
+        static DeviceOnce lds_once;                                                                                 \
+        allow_dynamic_lds(topk_prefilter_kernel<KPT>, lds_once, 152 * 1024);                                        \
         hipLaunchKernelGGL(topk_prefilter_kernel<KPT>, dim3((unsigned)B), dim3(kPreThreads), dyn, stream, f);       \
     } while (0)
         if (chunk <= 5) SDETR_PRE(5);

@@ -58,7 +58,7 @@ class SalienceEncoderHotPath(nn.Module):
         nn.init.xavier_uniform_(self.enc_output.weight)
         nn.init.constant_(self.enc_output.bias, 0.0)
         nn.init.constant_(self.encoder_class_head.bias, -math.log((1 - 0.01) / 0.01))
-        self.alpha.data.uniform_(-0.3, 0.3)
+        nn.init.uniform_(self.alpha, -0.3, 0.3)
 
     def set_encoder_dtype(self, dtype: torch.dtype, value_dtype: Optional[torch.dtype] = None):
         """Run the six encoder layers (and the shared class head) in ``dtype`` (bf16 for the inference

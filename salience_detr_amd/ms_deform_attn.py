@@ -391,6 +391,24 @@ def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tenso
     return out[None] if n == 1 else out
 
 
+def invalidate_caches(module: nn.Module) -> None:
+    """Drop every derived-weight cache below ``module`` (fused / head-major projection operands, batched value
+    projections, packed MFMA operands of the Linear layers, folded neck plans, flattened background tables).
+
+    The caches are keyed on ``(data_ptr, _version)`` of their parameters, which ``optimizer.step()``, ``load_state_dict``,
+    ``.to()`` and every in-place op on the parameter change.  A write THROUGH ``p.data`` (``p.data.copy_()``, EMA helpers,
+    ``nn.init`` on ``.data``) changes neither: call this function afterwards, or write ``with torch.no_grad(): p.copy_(..)``.
+    """
+    for m in module.modules():
+        for attr in ("_fused_cache", "_fused_hm_cache", "_plan", "_flat_cache"):
+            if attr in m.__dict__:
+                m.__dict__[attr] = None
+        m.__dict__.pop("_batched_value_proj", None)
+        for p in m.parameters(recurse=False):
+            for key in ("_sdetr_packed", "_sdetr_ffn", "_sdetr_tl"):
+                p.__dict__.pop(key, None)
+
+
 class MultiScaleDeformableAttention(nn.Module):
     """Multi-Scale Deformable Attention Module (Deformable-DETR), MI355X-native inside.
 
@@ -425,7 +443,9 @@ class MultiScaleDeformableAttention(nn.Module):
     def init_weights(self):
         """Default initialisation (ms_deform_attn.py:262-284): zero offset weights, 8-direction ring
         bias scaled by the point index, uniform attention, xavier value/output projections."""
-        constant_(self.sampling_offsets.weight.data, 0.0)
+        # in-place on the parameters themselves (under no_grad inside nn.init): this bumps their version counters, which
+        # the derived-weight caches of the native path are keyed on -- writes through `.data` would not
+        constant_(self.sampling_offsets.weight, 0.0)
         thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
         grid = torch.stack([thetas.cos(), thetas.sin()], -1)
         grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2)
@@ -434,12 +454,13 @@ class MultiScaleDeformableAttention(nn.Module):
             grid[:, :, i, :] *= i + 1
         with torch.no_grad():
             self.sampling_offsets.bias = nn.Parameter(grid.view(-1))
-        constant_(self.attention_weights.weight.data, 0.0)
-        constant_(self.attention_weights.bias.data, 0.0)
-        xavier_uniform_(self.value_proj.weight.data)
-        constant_(self.value_proj.bias.data, 0.0)
-        xavier_uniform_(self.output_proj.weight.data)
-        constant_(self.output_proj.bias.data, 0.0)
+        constant_(self.attention_weights.weight, 0.0)
+        constant_(self.attention_weights.bias, 0.0)
+        xavier_uniform_(self.value_proj.weight)
+        constant_(self.value_proj.bias, 0.0)
+        xavier_uniform_(self.output_proj.weight)
+        constant_(self.output_proj.bias, 0.0)
+        invalidate_caches(self)
 
     # -- native path pieces --------------------------------------------------------------------
     def _fused_query_projection(self):

@@ -38,15 +38,22 @@ def get_valid_ratios(mask: Tensor) -> Tensor:
 # pixel-centre grids, host-computed budgets).  They originate on the host; caching them per
 # (geometry, device) removes the per-forward H2D copies, which also keeps the forward capturable
 # in a hipGraph (no host-memory copies inside the captured region).
-_STATIC = {}
+_STATIC = {}          # insertion-ordered: least recently used first
+_STATIC_LIMIT = 1024
 
 
 def static_tensor(key, build):
-    t = _STATIC.get(key)
+    """Cached device constants (shape tensors, reference grids, token budgets).  Eviction is least-recently-used, one
+    entry at a time: a captured hipGraph has the addresses of the tensors it was warmed up with baked in, so a
+    wholesale clear() -- which hands all of them back to the caching allocator at once -- would let a later replay read
+    recycled memory.  Entries in use by a live graph are the recently used ones; only a process that streams through
+    more than `_STATIC_LIMIT` distinct (image size, canvas) combinations evicts, oldest first."""
+    t = _STATIC.pop(key, None)
     if t is None:
-        if len(_STATIC) > 256:
-            _STATIC.clear()
-        t = _STATIC[key] = build()
+        while len(_STATIC) >= _STATIC_LIMIT:
+            _STATIC.pop(next(iter(_STATIC)))
+        t = build()
+    _STATIC[key] = t        # (re)insert as most recently used
     return t
 
 

@@ -116,3 +116,44 @@ def test_product_modules_keep_the_reference_state_dict_names():
               "decoder.ref_point_head.layers.1.bias", "decoder.class_head.0.weight", "decoder.bbox_head.0.layers.0.weight",
               "decoder.norm.weight", "level_filter_ratio", "layer_filter_ratio"):
         assert k in keys, k
+
+
+def test_static_tensor_cache_is_lru_not_clear_all():
+    """a full clear() would free tensors whose addresses a captured hipGraph still holds."""
+    saved, limit = dict(pyramid._STATIC), pyramid._STATIC_LIMIT
+    try:
+        pyramid._STATIC.clear()
+        pyramid._STATIC_LIMIT = 4
+        a = pyramid.static_tensor("a", lambda: torch.zeros(1))
+        for k in "bcd":
+            pyramid.static_tensor(k, lambda: torch.zeros(1))
+        assert pyramid.static_tensor("a", lambda: torch.ones(1)) is a        # hit, becomes most recent
+        pyramid.static_tensor("e", lambda: torch.zeros(1))                  # evicts ONE entry: the oldest ("b")
+        assert set(pyramid._STATIC) == {"a", "c", "d", "e"}
+        assert pyramid.static_tensor("a", lambda: torch.ones(1)) is a
+    finally:
+        pyramid._STATIC.clear()
+        pyramid._STATIC.update(saved)
+        pyramid._STATIC_LIMIT = limit
+
+
+def test_init_weights_bumps_versions_and_invalidate_caches():
+    """the derived-weight caches are keyed on parameter versions; init_weights must not write through
+    `.data` (which leaves the version unchanged), and `invalidate_caches` clears what a `.data` write would leave stale."""
+    from salience_detr_amd.ms_deform_attn import MultiScaleDeformableAttention, invalidate_caches
+    m = MultiScaleDeformableAttention(32, 4, 4, 4)
+    before = {n: p._version for n, p in m.named_parameters()}
+    m.init_weights()
+    for n, p in m.named_parameters():
+        if n != "sampling_offsets.bias":          # (re-created as a fresh Parameter by init_weights)
+            assert p._version > before[n], n
+    w1, _ = m._fused_query_projection()
+    with torch.no_grad():
+        m.attention_weights.weight.data.add_(1.0)          # the unsupported kind of write: version unchanged ...
+    assert m._fused_query_projection()[0] is w1             # ... so the cache is (knowingly) stale
+    invalidate_caches(m)
+    w2, _ = m._fused_query_projection()
+    assert w2 is not w1 and torch.equal(w2[-m.attention_weights.weight.shape[0]:], m.attention_weights.weight)
+    with torch.no_grad():
+        m.attention_weights.weight.add_(1.0)                # the supported kind: version bump -> automatic refresh
+    assert m._fused_query_projection()[0] is not w2
