@@ -145,3 +145,60 @@ def test_oracle_transformer_with_neck_matches_reference(gold):
     assert (out["enc_outputs_coord"] - _t(dn["enc_outputs_coord"])).abs().max() < 2e-5
     assert (out["outputs_classes"] - _t(dn["outputs_classes"])).abs().max() < 2e-3
     assert (out["outputs_coords"] - _t(dn["outputs_coords"])).abs().max() < 2e-4
+
+
+# ---- the restated torchvision NMS beyond the grid special case: random NON-grid boxes, several
+# thresholds, against an independent brute-force statement -- full pairwise IoU matrix in numpy, then the greedy sweep
+# "keep the best remaining box, drop everything it overlaps by more than thr".  (torchvision itself is not in this image:
+# `nms_greedy` stays labelled parity-unpinned; this pins the ALGORITHM it restates.)
+def _brute_force_nms(boxes, scores, thr):
+    import numpy as np
+    b = boxes.numpy().astype(np.float32)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(b[:, None, :2], b[None, :, :2])
+    rb = np.minimum(b[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    iou = inter / (area[:, None] + area[None, :] - inter)
+    order = sorted(range(len(b)), key=lambda i: (-float(scores[i]), i))     # stable descending
+    alive = np.ones(len(b), dtype=bool)
+    keep = []
+    for i in order:
+        if not alive[i]:
+            continue
+        keep.append(i)
+        alive &= ~(iou[i] > np.float32(thr))
+        alive[i] = False
+    return keep
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.3, 0.5, 0.7])
+@pytest.mark.parametrize("n,seed", [(1, 0), (17, 1), (300, 2), (900, 3)])
+def test_restated_nms_equals_brute_force_on_random_boxes(thr, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    centre = torch.rand(n, 2, generator=g) * 100
+    size = torch.rand(n, 2, generator=g) ** 2 * 40 + 1          # from tiny to large, heavy overlap
+    boxes = torch.cat([centre - size / 2, centre + size / 2], -1)
+    scores = torch.rand(n, generator=g)
+    if n > 20:
+        scores[5] = scores[9]                                   # a tie: the earlier index wins
+    got = R.nms_greedy(boxes, scores, thr).tolist()
+    assert got == _brute_force_nms(boxes, scores, thr)
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.6])
+def test_restated_batched_nms_is_per_category_nms(thr):
+    g = torch.Generator().manual_seed(7)
+    n = 400
+    centre = torch.rand(n, 2, generator=g) * 60
+    size = torch.rand(n, 2, generator=g) * 25 + 2
+    boxes = torch.cat([centre - size / 2, centre + size / 2], -1)
+    scores = torch.rand(n, generator=g)
+    idxs = torch.randint(0, 5, (n,), generator=g)
+    got = R.batched_nms(boxes, scores, idxs, thr).tolist()
+    expect = []
+    for c in range(5):
+        members = (idxs == c).nonzero().flatten()
+        expect += [int(members[i]) for i in _brute_force_nms(boxes[members], scores[members], thr)]
+    expect.sort(key=lambda i: (-float(scores[i]), i))
+    assert got == expect
