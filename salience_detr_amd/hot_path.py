@@ -18,6 +18,24 @@ from .salience_encoder import SalienceTransformerEncoder, SalienceTransformerEnc
 from .salience_filtering import MaskPredictor, level_filtering, salience_filtering, token_budgets
 
 
+def resolve_activation_dtype(dtype: torch.dtype, value_dtype: Optional[torch.dtype] = None):
+    """Map a requested 16-bit mode onto what the MI355X kernels run (BASELINE.json configs[4] asks for "fp16", the
+    reference's ``--mixed-precision fp16``, main.py:24-56).
+
+    ``torch.float16`` is served as **bf16 activations + fp16 value maps + fp32 accumulation / softmax / LayerNorm /
+    sampling locations**: on gfx950 the bf16 and fp16 MFMA rates are identical, so fp16 activations buy no speed, while
+    they would re-introduce what the reference's fp16 mode needs a GradScaler and autocast's fp32 fall-backs for --
+    a 65504 range on LayerNorm inputs, FFN hidden states (ReLU of 2048 pre-activations) and attention logits.  bf16
+    keeps fp32's exponent range there.  Where fp16's three extra mantissa bits matter -- the value maps the deformable
+    attention SAMPLES, each element of which is read ~32 times and weighted by fp32 bilinear x attention weights -- the
+    storage IS fp16 (consumed by v_fma_mix_f32 without an unpack).  The substitution is pinned by
+    tests/test_transformer_gpu.py::test_fp16_request_runs_config5_shape.
+    """
+    if dtype == torch.float16:
+        return torch.bfloat16, (value_dtype or torch.float16)
+    return dtype, value_dtype
+
+
 class SalienceEncoderHotPath(nn.Module):
     def __init__(self, encoder: SalienceTransformerEncoder, num_classes: int, num_feature_levels: int = 4,
                  level_filter_ratio: Tuple = (0.25, 0.5, 1.0, 1.0),
@@ -66,6 +84,7 @@ class SalienceEncoderHotPath(nn.Module):
         index sets do not depend on the encoder precision.  ``value_dtype`` is the storage type of the
         head-major value maps the MSDA kernel samples (default ``dtype``); ``torch.float16`` keeps 3 more
         mantissa bits than bf16 at the same size and lets the gather use ``v_fma_mix_f32`` (no unpack)."""
+        dtype, value_dtype = resolve_activation_dtype(dtype, value_dtype)
         self.encoder.to(dtype)
         for layer in self.encoder.layers:
             layer.self_attn.value_dtype = value_dtype or dtype

@@ -56,6 +56,8 @@ class SalienceTransformer(SalienceEncoderHotPath):
     def set_dtype(self, dtype: torch.dtype, value_dtype: Optional[torch.dtype] = None):
         """Encoder, proposal heads and decoder in ``dtype`` (the salience filtering stays fp32, see
         ``set_encoder_dtype``)."""
+        from .hot_path import resolve_activation_dtype
+        dtype, value_dtype = resolve_activation_dtype(dtype, value_dtype)   # fp16 request -> bf16 activations, fp16 maps
         self.set_encoder_dtype(dtype, value_dtype)
         self.decoder.to(dtype)
         self.tgt_embed.to(dtype)
@@ -74,10 +76,19 @@ class SalienceTransformer(SalienceEncoderHotPath):
     def _output_memory(self, memory: Tensor, keep: Tensor) -> Tensor:
         x = memory * keep.unsqueeze(-1).to(memory.dtype)
         w, b = self.enc_output.weight, self.enc_output.bias
+        if w.dtype != x.dtype:
+            # enc_output stays fp32 for the filtering stage (set_dtype); the proposal stage reads a cached copy in the
+            # activation dtype, refreshed when the parameters change
+            tag = (w.data_ptr(), w._version, b.data_ptr(), b._version, x.dtype)
+            hit = self.__dict__.get("_enc_output_cast")
+            if hit is None or hit[0] != tag:
+                hit = (tag, w.detach().to(x.dtype), b.detach().to(x.dtype))
+                self.__dict__["_enc_output_cast"] = hit
+            w, b = hit[1], hit[2]
         if token_linear_applies(x, w):
             y = token_linear(x, w, b)
         else:
-            y = torch.nn.functional.linear(x, w.to(x.dtype), b.to(x.dtype))
+            y = torch.nn.functional.linear(x, w, b)
         return fused_layer_norm(y, self.enc_output_norm)
 
     def nms_on_topk_index(self, topk_scores, topk_index, spatial_shapes, level_start_index, iou_threshold=0.3):
@@ -119,8 +130,10 @@ class SalienceTransformer(SalienceEncoderHotPath):
         [Ld,B,Nq,4], enc_outputs_class, enc_outputs_coord, salience_score)``.  ``image_sizes`` / ``canvas`` as in
         ``SalienceEncoderHotPath.forward`` (host-side token budgets, no sync in the filtering stage)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("SalienceTransformer: the proposal stage is inference-only (run under torch.no_grad()); "
-                               "the encoder hot path and the decoder have autograd paths of their own")
+            raise RuntimeError("SalienceTransformer.forward is INFERENCE-ONLY: call it under torch.no_grad() (model.eval() "
+                               "alone leaves grad mode on).  The proposal stage (top-k + NMS on the device) has no "
+                               "autograd path; for training use SalienceEncoderHotPath (encoder hot path) and "
+                               "SalienceTransformerDecoder, which have autograd paths of their own.")
         memory, salience_score, aux = SalienceEncoderHotPath.forward(
             self, multi_level_feats, multi_level_masks, multi_level_pos_embeds, image_sizes=image_sizes, canvas=canvas,
             return_aux=True)
