@@ -184,3 +184,56 @@ class OverlappedGradReducer(FlatGradAllReducer):
         for h in self._handles:
             h.remove()
         self._handles = []
+
+
+class _SyncBatchNormTrain(torch.autograd.Function):
+    """BatchNorm2d in training mode over ALL ranks' pixels (what ``nn.SyncBatchNorm`` gives the reference's neck under
+    DDP, ``main.py:126-127``; single process: plain batch statistics).  One collective per direction instead of the
+    framework's all_gather + all_reduce pair: forward all-reduces ``[sum(x), sum(x^2), count]`` (2C+1 floats),
+    backward all-reduces ``[sum(dy), sum(dy * xhat)]`` (2C floats).  Running statistics are updated in place with the
+    UNBIASED variance of the global batch (``nn.BatchNorm2d`` semantics)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        C = x.shape[1]
+        xf = x.float()
+        red = (0, 2, 3)
+        stats = torch.cat([xf.sum(red), (xf * xf).sum(red), xf.new_tensor([xf.numel() / C])])
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        n = stats[-1]
+        mean = stats[:C] / n
+        var = (stats[C:2 * C] / n - mean * mean).clamp_min_(0.0)          # biased: what normalises
+        invstd = torch.rsqrt(var + eps)
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
+            running_var.mul_(1 - momentum).add_(momentum * (var * (n / (n - 1).clamp_min(1.0))).to(running_var.dtype))
+        xhat = (xf - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+        ctx.save_for_backward(xhat, weight, invstd, n)
+        ctx.group, ctx.world = group, world
+        return (xhat * weight.float().view(1, C, 1, 1) + bias.float().view(1, C, 1, 1)).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, weight, invstd, n = ctx.saved_tensors
+        C = dy.shape[1]
+        dyf = dy.float()
+        red = (0, 2, 3)
+        sum_dy, sum_dy_xhat = dyf.sum(red), (dyf * xhat).sum(red)
+        both = torch.cat([sum_dy, sum_dy_xhat])
+        if ctx.world > 1:
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctx.group)
+        g_mean, g_proj = both[:C] / n, both[C:] / n
+        dx = (dyf - g_mean.view(1, C, 1, 1) - xhat * g_proj.view(1, C, 1, 1)) * (weight.float() * invstd).view(1, C, 1, 1)
+        # parameter gradients stay LOCAL sums: the gradient all-reduce of the step adds the ranks' contributions
+        return dx.to(dy.dtype), sum_dy_xhat.to(weight.dtype), sum_dy.to(weight.dtype), None, None, None, None, None
+
+
+def sync_batch_norm_train(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, group=None) -> torch.Tensor:
+    """``bn`` (an ``nn.BatchNorm2d`` parameter holder) applied to NCHW ``x`` with batch statistics over every rank of
+    ``group`` (all ranks of the default group when a process group exists, else this process alone)."""
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _SyncBatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, group)

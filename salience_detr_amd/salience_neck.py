@@ -18,7 +18,11 @@ How it runs (eval mode):
     the same input and run as one GEMM of twice the width;
   * 3x3 convolutions (fp32 LDS-tiled kernel; bf16 maps with the real channel counts: the MFMA kernel), the
     attention-pooled gate and the shortcuts are the HIP kernels of ``include/salience_hip.h`` (13).
-Training mode (batch statistics; SyncBatchNorm under DDP) is not built: ``forward`` refuses it.
+Training mode (``.train()``): the differentiable form -- NCHW convolutions on the parameter holders, every BatchNorm on
+BATCH statistics taken over all ranks' pixels (``data_parallel.sync_batch_norm_train``: one all-reduce per norm and
+direction where the reference's ``nn.SyncBatchNorm`` issues an all_gather + all_reduce pair, ``main.py:126-127``),
+running statistics updated as ``nn.BatchNorm2d`` does.  It is the autograd path of this row (device tensors only, like
+every other operator here); the HIP kernels above are the inference path.
 """
 from collections import OrderedDict
 from typing import Dict, List, Sequence, Tuple
@@ -162,6 +166,7 @@ class RepVGGPluXNetwork(nn.Module):
         self.pan_blocks = nn.ModuleList(CSPRepPluXLayer(2 * C, C, groups=groups, norm_layer=norm_layer,
                                                         activation_layer=activation) for _ in range(n - 1))
         self.extra_block = extra_block
+        self.process_group = None   # ranks whose pixels share the batch statistics in training mode (None = all)
         self._plan = None
         self.init_weights()
 
@@ -220,11 +225,13 @@ class RepVGGPluXNetwork(nn.Module):
 
     def forward_levels(self, levels: Sequence[Tensor], shapes: Sequence[Tuple[int, int]]) -> List[Tensor]:
         """Token-major levels ``[B, h*w, C]`` (fine to coarse) -> the same (repnet.py:211-245)."""
-        if self.training:
-            raise RuntimeError("RepVGGPluXNetwork: only the eval-mode (running statistics) form is built; "
-                               "call .eval() -- batch-statistics BatchNorm is not implemented")
         if len(levels) != len(self.layer_blocks) + 1:
             raise RuntimeError("RepVGGPluXNetwork: wrong number of levels")
+        if self.training:
+            if not levels[0].is_cuda:
+                raise RuntimeError("RepVGGPluXNetwork: HIP device tensors required; there is no CPU fallback")
+            maps = [x.transpose(1, 2).reshape(x.shape[0], x.shape[2], int(h), int(w)) for x, (h, w) in zip(levels, shapes)]
+            return [o.flatten(2).transpose(1, 2) for o in self.forward_train(maps)]
         plan = self._folded(levels[0].dtype)  # (the kernels' wrappers refuse CPU tensors: no fallback)
         shapes = [(int(h), int(w)) for h, w in shapes]
         L = len(levels)
@@ -243,6 +250,48 @@ class RepVGGPluXNetwork(nn.Module):
             if down.shape[1] != shapes[idx + 1][0] * shapes[idx + 1][1]:
                 raise RuntimeError("RepVGGPluXNetwork: level sizes are not a stride-2 pyramid")
             outs.append(self._csp(plan["pan"][idx], down, shapes[idx + 1], inner[idx + 1], shapes[idx + 1], False))
+        return outs
+
+    # ---- training form (repnet.py:211-245 with batch-statistics norms) ---------------------------------------------
+    def _conv_norm(self, m: Conv2dNormActivation, x: Tensor, act: bool = True) -> Tensor:
+        from .data_parallel import sync_batch_norm_train
+        conv = m[0]
+        y = torch.nn.functional.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, 1, conv.groups)
+        y = sync_batch_norm_train(y, m[1], self.process_group)
+        return torch.nn.functional.silu(y) if act else y
+
+    @staticmethod
+    def _gate(se: "SqueezeAndExcitation", x: Tensor) -> Tensor:
+        """Attention-pooled gate (models/bricks/basic.py:29-54): softmax over the pixels of conv_mask(x) weights the
+        pixels, the pooled vector goes through C -> C/16 -> ReLU -> C -> sigmoid and scales x."""
+        B, C, H, W = x.shape
+        logit = torch.nn.functional.conv2d(x, se.conv_mask.weight, se.conv_mask.bias).view(B, H * W)
+        context = torch.einsum("bcp,bp->bc", x.reshape(B, C, H * W), logit.softmax(-1))
+        hidden = torch.relu(context @ se.se_module[0].weight.view(-1, C).t())
+        gate = torch.sigmoid(hidden @ se.se_module[2].weight.view(C, -1).t())
+        return gate.view(B, C, 1, 1) * x
+
+    def _csp_train(self, layer: CSPRepPluXLayer, x: Tensor) -> Tensor:
+        y = self._conv_norm(layer.conv1, x)
+        for blk in layer.bottlenecks:
+            z = self._conv_norm(blk.conv1, y, act=False) + blk.alpha * self._conv_norm(blk.conv2, y, act=False)
+            y = self._gate(blk.se_module, torch.nn.functional.silu(z)) + y
+        return y + self._conv_norm(layer.conv2, x)
+
+    def forward_train(self, feats: Sequence[Tensor]) -> List[Tensor]:
+        """NCHW levels (fine to coarse) -> the same, training mode: differentiable, batch statistics over the
+        process group ``self.process_group`` (None = all ranks / this process), running statistics updated."""
+        L = len(feats)
+        inner = [feats[-1]]
+        for idx in range(L - 1, 0, -1):  # top-down
+            high = self._conv_norm(self.lateral_convs[idx - 1], inner[0])
+            inner[0] = high
+            up = torch.nn.functional.interpolate(high, size=feats[idx - 1].shape[-2:], mode="nearest")
+            inner.insert(0, self._csp_train(self.layer_blocks[idx - 1], torch.cat([up, feats[idx - 1]], 1)))
+        outs = [inner[0]]
+        for idx in range(L - 1):  # bottom-up
+            down = self._conv_norm(self.downsample_blocks[idx], outs[-1])
+            outs.append(self._csp_train(self.pan_blocks[idx], torch.cat([down, inner[idx + 1]], 1)))
         return outs
 
     def forward_memory(self, memory: Tensor, level_shapes: Sequence[Tuple[int, int]]) -> Tensor:

@@ -148,3 +148,62 @@ def test_hot_path_parameter_list_two_ranks(tmp_path, overlapped):
         expect = 0.5 * (grads[0][n] + grads[1][n])
         assert torch.allclose(g0[n], expect, rtol=1e-5, atol=1e-6), n
         assert torch.equal(g0[n], g1[n]), n
+
+
+# ---- SyncBatchNorm of the neck's training form (row N3): batch statistics over all ranks' pixels, one all-reduce per
+# direction; two ranks with half the batch each == one process with the whole batch (outputs, input gradients, summed
+# parameter gradients, running statistics) ----
+def _bn_case():
+    bn = torch.nn.BatchNorm2d(6)
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + 0.1 * syn.det_randn("sbn.w", (6,)))
+        bn.bias.copy_(0.1 * syn.det_randn("sbn.b", (6,)))
+        bn.running_mean.copy_(0.2 * syn.det_randn("sbn.rm", (6,)))
+        bn.running_var.copy_(0.5 + syn.det_rand("sbn.rv", (6,)))
+    x = syn.det_randn("sbn.x", (4, 6, 5, 7)) * 2.0 + 0.5
+    probe = syn.det_randn("sbn.p", (4, 6, 5, 7))
+    return bn, x, probe
+
+
+def _sbn_worker(rank, world, port, out_dir):
+    from salience_detr_amd.data_parallel import sync_batch_norm_train
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bn, x, probe = _bn_case()
+        a, b = shard_range(x.shape[0], rank, world)
+        xs = x[a:b].clone().requires_grad_(True)
+        y = sync_batch_norm_train(xs, bn)
+        (y * probe[a:b]).sum().backward()
+        torch.save(dict(y=y.detach(), dx=xs.grad, dw=bn.weight.grad, db=bn.bias.grad, rm=bn.running_mean.clone(),
+                        rv=bn.running_var.clone()), os.path.join(out_dir, f"sbn{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batch_norm_two_ranks_equal_one_process_full_batch(tmp_path):
+    from salience_detr_amd.data_parallel import sync_batch_norm_train
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"sbn{r}.pt")) for r in range(2))
+    # one process, whole batch: torch's own BatchNorm2d in training mode is the statement of what must come out
+    bn, x, probe = _bn_case()
+    bn.train()
+    xf = x.clone().requires_grad_(True)
+    y = bn(xf)
+    (y * probe).sum().backward()
+    assert torch.allclose(torch.cat([r0["y"], r1["y"]]), y.detach(), atol=1e-5)
+    assert torch.allclose(torch.cat([r0["dx"], r1["dx"]]), xf.grad, atol=1e-5)
+    assert torch.allclose(r0["dw"] + r1["dw"], bn.weight.grad, atol=1e-4)
+    assert torch.allclose(r0["db"] + r1["db"], bn.bias.grad, atol=1e-4)
+    for r in (r0, r1):
+        assert torch.allclose(r["rm"], bn.running_mean, atol=1e-6) and torch.allclose(r["rv"], bn.running_var, atol=1e-5)
+    # single process without a process group: plain batch statistics
+    bn2, x2, probe2 = _bn_case()
+    x2 = x2.clone().requires_grad_(True)
+    y2 = sync_batch_norm_train(x2, bn2)
+    (y2 * probe2).sum().backward()
+    assert torch.allclose(y2.detach(), y.detach(), atol=1e-5) and torch.allclose(x2.grad, xf.grad, atol=1e-5)
+    assert torch.allclose(bn2.weight.grad, bn.weight.grad, atol=1e-4)

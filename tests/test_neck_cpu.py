@@ -82,10 +82,10 @@ def test_neck_host_logic_against_reference(tag, monkeypatch):
     assert (mem - torch.cat([o.flatten(2).transpose(1, 2) for o in outs], 1)).abs().max() < 5e-5
 
 
-def test_neck_refuses_training_mode_and_cpu_tensors():
+def test_neck_refuses_cpu_tensors_in_both_modes():
     net = build_neck(32)
     x = dict(enumerate(torch.zeros(1, 32, h, w) for h, w in [(8, 12), (4, 6), (2, 3), (1, 2)]))
-    with pytest.raises(RuntimeError, match="eval"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # training form: device tensors only, too
         net(x)
     net.eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):

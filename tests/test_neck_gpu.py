@@ -132,3 +132,35 @@ def test_neck_benchmark_pyramid_against_oracle():
         got = net.forward_memory(mem, shapes).cpu()
     ref = torch.cat([o.flatten(2).transpose(1, 2) for o in want], 1)
     assert (got - ref).abs().max() < 1e-3
+
+
+def test_neck_training_form_matches_reference_fixture():
+    """Row N3, training mode: batch-statistics norms (one process = what SyncBatchNorm computes over all ranks'
+    pixels), running-statistic updates and gradients, against vectors generated by running the imported reference's
+    RepVGGPluXNetwork in .train() (tests/golden/make_golden.py; the same vectors pin the oracle's restatement in
+    tests/test_neck_cpu.py::test_oracle_neck_training_mode_matches_reference)."""
+    import os
+    from collections import OrderedDict
+    import numpy as np
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "neck_cases.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    sd, cpu_feats, _ = neck_case("small")
+    net = build_neck(32)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    feats = [f.clone().cuda().requires_grad_(True) for f in cpu_feats]
+    outs = list(net(OrderedDict((str(l), f) for l, f in enumerate(feats))).values())
+    probes = [syn.det_randn(f"neck.train.probe{l}", o.shape).cuda() for l, o in enumerate(outs)]
+    loss = sum((o * p).sum() for o, p in zip(outs, probes))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(d["train.loss"])) < 2e-3
+    for l in range(4):
+        assert (outs[l].detach().cpu() - t(d[f"train.out{l}"])).abs().max() < 1e-4, l
+        assert (feats[l].grad.cpu() - t(d[f"train.grad_feat{l}"])).abs().max() < 5e-4, l
+    new_sd = net.state_dict()
+    for k in [k[len("train.stat."):] for k in d.files if k.startswith("train.stat.")]:
+        assert (new_sd[k].cpu() - t(d["train.stat." + k])).abs().max() < 1e-5, k
+    params = dict(net.named_parameters())
+    for k in [k[len("train.grad."):] for k in d.files if k.startswith("train.grad.")]:
+        ref = t(d["train.grad." + k])
+        assert (params[k].grad.cpu() - ref).abs().max() < 2e-3 * max(1.0, float(ref.abs().max())), k
