@@ -261,7 +261,8 @@ def time_replays(g, n):
 
 def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
     """The oracle's CPU port of the same path, timed on the host cores: per stage (F0-F3 filtering,
-    each encoder layer, the MSDA core alone).  Default: bounded to ~15-25 s (batch 2, all cores, 1 warm-up + 3 passes);
+    each encoder layer, the MSDA core alone).  Default: bounded to ~15-30 s (batch 2; 8 threads 1 warm-up + 3 passes,
+    all cores 1 + 2 passes; the faster leg is `value`);
     `--cpu-protocol full` runs the survey's whole protocol (3 warm-ups + 10 passes, all cores AND 8 threads, batch 1
     AND 2 -- minutes; its result is committed under profiles/)."""
     from oracle import salience_ref as R  # checker / baseline only; never on the product path
@@ -271,9 +272,13 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
     # 62 s per pass at 256 threads against 4 s at 128 on a 2 x 64-core EPYC 9575F)
     all_cores = DEFAULT_THREADS
     full = args.cpu_protocol == "full"
-    plans = [(args.batch, all_cores, 3 if full else 1, 10 if full else 3)]
+    # (batch, threads, warm-ups, timed passes).  The torch CPU ops of this path run FASTER on 8 threads than on all
+    # 128 physical cores on the benchmark boxes (1.1 s against 4-10 s per batch-2 pass: the tensors are small, the
+    # thread fan-out dominates), so the bounded default times both and reports the faster one as `value`.
     if full:
-        plans += [(1, all_cores, 3, 10), (args.batch, 8, 3, 10), (1, 8, 3, 10)]
+        plans = [(args.batch, all_cores, 3, 10), (1, all_cores, 3, 10), (args.batch, 8, 3, 10), (1, 8, 3, 10)]
+    else:
+        plans = [(args.batch, 8, 1, 3), (args.batch, all_cores, 1, 2)]
     legs, ref_out = [], None
     cpu_model = ""
     try:
@@ -294,7 +299,7 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
                 if i >= warm:
                     per_pass.append(dt)
                     stages.append(tm)
-                if batch == args.batch and threads == all_cores:
+                if batch == args.batch:
                     ref_out = r
         order = sorted(range(len(per_pass)), key=lambda i: per_pass[i])
         med = order[len(order) // 2]
@@ -303,7 +308,7 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
                      "images_per_s": round(batch / per_pass[med], 3),
                      "ms_per_stage": {k: round(v * 1e3, 1) for k, v in sorted(stages[med].items())}})
     torch.set_num_threads(all_cores)
-    main_leg = legs[0]
+    main_leg = max((l for l in legs if l["batch"] == args.batch), key=lambda l: l["images_per_s"])
     result = {
         "value": main_leg["images_per_s"], "unit": "images/s", "cores": main_leg["threads"], "kind": "port",
         "cpu_model": cpu_model, "msda_core_threads": msda_c.num_threads(),

@@ -3,8 +3,10 @@
     python benchmarks/mfma_busy_summary.py <dir prefix of the passes> <out.md>
 
 Per kernel (sdetr:: kernels that issue MFMAs): launches, mean launch duration (kernel trace of the same passes), the
-fraction of the shader engines' busy time the matrix pipes were busy (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, both
-summed over the chip's SEs / SIMDs as rocprofv3 reports them -- the verdict's definition), and the flops the MFMAs
+utilisation of the matrix pipes -- SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES as rocprofv3 reports them, divided by 32:
+the busy counter is summed over the 32 shader engines (checked on a kernel of known duration: SQ_BUSY_CYCLES =
+32 x duration x clock), the MFMA counter over the 1024 SIMDs (one matrix pipe each), so the raw ratio is 1024 / 32 = 32
+times the per-pipe utilisation -- and the flops the MFMAs
 performed (SQ_INSTS_VALU_MFMA_MOPS_* x 512: the counters tally matrix operations in units of 512 flops at full EXEC) over
 the launch duration against the dense peak (2.5 PFLOP/s bf16, 157 TFLOP/s f32-input MFMA; MI355X_MICROARCH.md)."""
 import collections
@@ -45,7 +47,8 @@ for k in val:
 rows.sort(reverse=True)
 with open(out, "w") as fh:
     fh.write("# MFMA-busy counters of the dense kernels (rocprofv3 --pmc, bench.py --plain --no-graph, batch 2, bf16)\n\n")
-    fh.write("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (means per launch).  Achieved = MFMA flops per launch "
+    fh.write("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) (means per launch; SQ_BUSY_CYCLES is summed over "
+             "32 shader engines, the MFMA counter over 1024 SIMDs / matrix pipes).  Achieved = MFMA flops per launch "
              "(SQ_INSTS_VALU_MFMA_MOPS_{BF16,F32} x 512) / mean launch duration of the same passes; peak = 2500 TFLOP/s "
              "(bf16 MFMA) or 157 TFLOP/s (f32-input MFMA).  Durations under the counter passes run ~10-20 % above the "
              "un-profiled ones.\n\n")
@@ -53,6 +56,6 @@ with open(out, "w") as fh:
     for _, k, n, us, mb, b, bf16, f32 in rows:
         tb = bf16 / us / 1e6 if us else 0.0
         tf = f32 / us / 1e6 if us else 0.0
-        fh.write(f"| `{k[:90]}` | {n} | {us:.1f} | {mb / b if b else 0:.3f} | "
+        fh.write(f"| `{k[:90]}` | {n} | {us:.1f} | {mb / b / 32 if b else 0:.3f} | "
                  f"{tb:.0f} ({tb / 2500:.2f}) | {tf:.1f} ({tf / 157:.2f}) |\n")
 print(open(out).read())
