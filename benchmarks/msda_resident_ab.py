@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--chunks", default="0")
     ap.add_argument("--nq", default="11363,9090,6817,4545,2272,900")
+    ap.add_argument("--sorted", action="store_true", help="queries in spatial (token) order instead of random order")
     ap.add_argument("--out", default="gpurun_out/msda_ab.json")
     args = ap.parse_args()
     B = args.batch
@@ -65,7 +66,11 @@ def main():
     hm = M.value_to_head_major(torch.randn(B, Nv, 256, device=DEV), None, HEADS, torch.float16)
     rows = []
     for nq in [int(x) for x in args.nq.split(",")]:
-        _, ref, proj, shapes, lsi = syn.make_encoder_like_queries(B, nq, LEVELS, HEADS, P, seed=1, offset_px=1.0)
+        tok, ref, proj, shapes, lsi = syn.make_encoder_like_queries(B, nq, LEVELS, HEADS, P, seed=1, offset_px=1.0)
+        if args.sorted:   # queries in token (= spatial, row-major per level) order instead of random order
+            perm = tok.argsort(1)
+            ref = torch.gather(ref, 1, perm[:, :, None, None].expand_as(ref))
+            proj = torch.gather(proj, 1, perm[:, :, None].expand_as(proj))
         proj[..., :HEADS * L * P * 2] += syn._ring_bias(HEADS, L, P)     # the benchmark's offsets: ring + noise
         slab = slab_of(proj.to(torch.bfloat16)).to(DEV)
         sh, ls, rf = shapes.to(DEV), lsi.to(DEV), ref.to(DEV)

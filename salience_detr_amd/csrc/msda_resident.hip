@@ -95,6 +95,21 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
 }
 
+// clamp as ONE instruction (hipcc emits v_max + v_min: it cannot prove lo <= hi for run-time bounds)
+__device__ __forceinline__ int med3_i32(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+
+__device__ __forceinline__ float mul_f32(float a, float b)
+{
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float quad_xor1(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
@@ -231,13 +246,17 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
                 x = fmaf(ox[t] * 0.125f, cur.r[RD - 2], cur.r[0]);  // offset / num_points * w * 0.5, num_points = 4
                 y = fmaf(oy[t] * 0.125f, cur.r[RD - 1], cur.r[1]);
             }
-            const float h_im = fmaf(y, fH, -0.5f);
-            const float w_im = fmaf(x, fW, -0.5f);
-            const bool inside = (h_im > -1.f) & (w_im > -1.f) & (h_im < fH) & (w_im < fW);
-            const float a = inside ? e[t] * inv : 0.f;
+            // Pixel coordinates, clamped to [-2, size + 1] by one v_med3_f32 each: every position the reference's
+            // `h_im > -1 && w_im > -1 && h_im < H && w_im < W` test rejects lands on rows / columns that fail the
+            // corner tests below anyway (-2 -> corners -2 and -1; size + 1 -> corners size + 1, size + 2), a NaN
+            // becomes -2 (v_med3 returns the minimum when an operand is NaN), and the int conversion never saturates --
+            // four compares, three scalar ANDs and a select per sample less than the explicit test.
+            const float h_im = __builtin_amdgcn_fmed3f(fmaf(y, fH, -0.5f), -2.f, fH + 1.f);
+            const float w_im = __builtin_amdgcn_fmed3f(fmaf(x, fW, -0.5f), -2.f, fW + 1.f);
+            const float a = e[t] * inv;
             const float fy = floorf(h_im), fx = floorf(w_im);
             const float ly = h_im - fy, lx = w_im - fx;
-            const int y0 = (int)fy, x0 = (int)fx;  // saturating; the weights are zero for wild values
+            const int y0 = (int)fy, x0 = (int)fx;
             const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
             const bool in0 = (unsigned)x0 < (unsigned)W, in1 = (unsigned)(x0 + 1) < (unsigned)W;
             const float wy0 = vy0 ? (1.f - ly) * a : 0.f;
@@ -245,11 +264,12 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
             // the span starts at pixel xa = clamp(x0): when x0 = -1 that pixel is the RIGHT corner
             const float wa = in0 ? (1.f - lx) : (in1 ? lx : 0.f);
             const float wb = (in0 & in1) ? lx : 0.f;
-            const int y0c = min(max(y0, 0), H - 1), y1c = min(max(y0 + 1, 0), H - 1);
-            const int xa = min(max(x0, 0), W - 1);
+            const int y0c = med3_i32(y0, 0, H - 1), y1c = med3_i32(y0 + 1, 0, H - 1);
+            const int xa = med3_i32(x0, 0, W - 1);
             r0[t] = lvl_base + (__umul24((uint32_t)y0c, (uint32_t)W) + (uint32_t)xa) * 64u;  // 24-bit operands: full rate
             r1[t] = lvl_base + (__umul24((uint32_t)y1c, (uint32_t)W) + (uint32_t)xa) * 64u;
-            myW[(j * 4 + t) * 16 + g] = make_float4(wy0 * wa, wy0 * wb, wy1 * wa, wy1 * wb);
+            // (plain v_mul_f32 each: hipcc otherwise forms v_pk_mul_f32 pairs and pays for them in register shuffles)
+            myW[(j * 4 + t) * 16 + g] = make_float4(mul_f32(wy0, wa), mul_f32(wy0, wb), mul_f32(wy1, wa), mul_f32(wy1, wb));
         }
         // the table is wave-private: visible to this wave's reads once its own LDS queue drains
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

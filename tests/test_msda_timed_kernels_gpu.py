@@ -123,6 +123,8 @@ def test_resident_kernel_borders_and_wild_locations():
     proj = proj.float()
     proj[..., :HEADS * L * P * 2] = (proj[..., :HEADS * L * P * 2] * 0.5).round()   # whole-pixel offsets: exact borders
     proj[0, 0, :8] = 1e30   # wild offsets: every weight must be zero, no NaN
+    proj[0, 1, 8:12] = -1e30
+    proj[0, 2, 16:20] = float("inf")
     proj = proj.to(torch.bfloat16)
     expect = _expected(value.to(torch.float16).float(), shapes, lsi, ref, proj.float())
     hm = M.value_to_head_major(value.view(B, Nv, HEADS * D).to(DEV), None, HEADS, torch.float16)
