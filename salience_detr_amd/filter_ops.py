@@ -981,7 +981,7 @@ def topk_self_attention_applies(query: Tensor, pos: Tensor, mha, norm, num_selec
             and query.shape[-1] == 256 and mha.embed_dim == 256 and mha.num_heads == 8 and mha.in_proj_weight is not None
             and mha.in_proj_weight.dtype == torch.bfloat16 and mha.in_proj_bias is not None
             and mha.out_proj.bias is not None and norm.weight.dtype == torch.bfloat16 and norm.bias is not None
-            and 0 < num_selected <= 1152 and query.stride(2) == 1 and query.stride(1) == 256
+            and 0 < num_selected <= 384 and query.stride(2) == 1 and query.stride(1) == 256
             and pos.stride(2) == 1 and pos.stride(1) == 256)
 
 
