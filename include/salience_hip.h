@@ -82,6 +82,28 @@ int sdetr_msda_col2im_f64(sdetr_stream_t stream, const double *grad_col, const d
                           int num_levels, int num_query, int num_point, double *grad_value,
                           double *grad_sampling_loc, double *grad_attn_weight);
 
+/* LDS-accumulating variant of sdetr_msda_col2im_f32 (csrc/msda_backward_tiled.hip), same operands, same results up to
+ * summation order: grad_value is accumulated in per-workgroup LDS windows in fixed point (32x16-pixel tiles + 5-pixel
+ * halo of the large levels, small levels held whole) and flushed once per window as whole-line fp32 atomics; samples
+ * outside their window fall back to global atomics.  Shape: channels = 32, num_point = 4, num_levels <= 8, num_heads <= 64, value
+ * below 4 GiB per image (sdetr_msda_col2im_lds_supported).  Level geometry is read on the device from
+ * data_spatial_shapes / data_level_start_index (no host copy).  `workspace` = device scratch of at least
+ * sdetr_msda_col2im_lds_workspace_bytes(batch_size, num_query, num_heads, num_levels) bytes (query bucketing,
+ * row bounds, work counter; the entry clears what it needs).
+ * sdetr_msda_last_backward_kernel(): SDETR_KERNEL_MSDA_BWD_* of the calling thread's last backward call. */
+#define SDETR_KERNEL_MSDA_BWD_DIRECT 1 /* msda_col2im_*: every contribution an fp32 atomic on global memory */
+#define SDETR_KERNEL_MSDA_BWD_LDS 2    /* bt_main_kernel: fixed-point accumulation in LDS windows */
+size_t sdetr_msda_col2im_lds_workspace_bytes(int batch_size, int num_query, int num_heads, int num_levels);
+int sdetr_msda_col2im_lds_supported(int num_heads, int channels, int num_levels, int num_point, int spatial_size);
+int sdetr_msda_col2im_lds_f32(sdetr_stream_t stream, const float *grad_col, const float *data_value,
+                              const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
+                              const float *data_sampling_loc, const float *data_attn_weight,
+                              int batch_size, int spatial_size, int num_heads, int channels,
+                              int num_levels, int num_query, int num_point, float *grad_value,
+                              float *grad_sampling_loc, float *grad_attn_weight, void *workspace,
+                              size_t workspace_bytes);
+int sdetr_msda_last_backward_kernel(void);
+
 /* ---------------------------------------------------------------------------------------------
  * (3) Native MI355X path behind MultiScaleDeformableAttention.forward
  *     (models/bricks/ms_deform_attn.py:286-377).

@@ -31,6 +31,10 @@ SIGNATURES = {
     "sdetr_msda_im2col_f64": (_i, [_p] * 6 + [_i] * 7 + [_p]),
     "sdetr_msda_col2im_f32": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
     "sdetr_msda_col2im_f64": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3),
+    "sdetr_msda_col2im_lds_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sdetr_msda_col2im_lds_supported": (_i, [_i] * 5),
+    "sdetr_msda_col2im_lds_f32": (_i, [_p] * 7 + [_i] * 7 + [_p] * 3 + [_p, _sz]),
+    "sdetr_msda_last_backward_kernel": (_i, []),
     "sdetr_value_to_head_major": (_i, [_p, _p, _i, _i64, _p, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_msda_fused_forward": (_i, [_p, _p, _i, _p, _p, _p, _i, _i64, _p, _i, _i64, _i, _p] + [_i] * 7 + [_p, _i]),
     "sdetr_msda_forward_head_major": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 7 + [_p, _i]),

@@ -22,6 +22,8 @@
 
 namespace sdetr {
 
+void note_backward_kernel(int which);  // abi.hip
+
 constexpr int kBChunk = 16;
 
 struct BackwardArgs {
@@ -320,6 +322,7 @@ static int launch_bwd(hipStream_t stream, BackwardArgs &a)
     if (blocks > 0x7fffffffLL) return fail("msda backward: grid too large");
     const size_t lds = (size_t)(GPB * (kBChunk * 8 + 4) + kMaxLevels * 3) * 4;
     hipLaunchKernelGGL((msda_col2im_kernel<D, HM>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    note_backward_kernel(SDETR_KERNEL_MSDA_BWD_DIRECT);
     return check_launch("msda_col2im");
 }
 
@@ -333,6 +336,7 @@ static int launch_bwd_chan(hipStream_t stream, BackwardArgs &a)
     if (blocks > 0x7fffffffLL) return fail("msda backward: grid too large");
     const size_t lds = (size_t)(RPB * (kBChunk * 8 + 4) + kMaxLevels * 3) * 4;
     hipLaunchKernelGGL((msda_col2im_chan_kernel<D>), dim3((unsigned)blocks), dim3(kBlock), lds, stream, a);
+    note_backward_kernel(SDETR_KERNEL_MSDA_BWD_DIRECT);
     return check_launch("msda_col2im_chan");
 }
 
@@ -364,6 +368,7 @@ static int generic_bwd(hipStream_t stream, const S *grad_col, const S *value, co
     hipLaunchKernelGGL(msda_col2im_generic_kernel<S>, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)),
                        dim3(kBlock), 0, stream, rows, grad_col, value, shapes, lsi, loc, aw, Nv, M, D, L, Nq, P, gv, gl,
                        ga);
+    note_backward_kernel(SDETR_KERNEL_MSDA_BWD_DIRECT);
     return check_launch("msda_col2im_generic");
 }
 

@@ -1,0 +1,612 @@
+// Multi-scale deformable attention backward with grad_value accumulated in LDS (gfx950), D = 32, P = 4, fp32,
+// reference layout [B,Nv,M,D].  Arithmetic as msda_backward.hip / ms_deform_im2col_cuda.cuh:76-148,290-392.
+//
+// Why.  The direct kernel (msda_col2im_chan_kernel) sends every one of the 2048 per-row contributions to L2 as an
+// fp32 atomic: 372 M adds at encoder layer 0 (B = 2), and the L2 retires them per 128-byte line request
+// (~0.3-0.7 T adds/s measured): 0.6-0.9 ms per launch, 3 % of the HBM roofline.  Accumulating in LDS first was
+// tried in round 1 and dropped because `ds_add_f32` is slower still -- benchmarks/micro/lds_atomic_rate.hip puts
+// numbers on it: ds_add_f32 0.2 T adds/s (one lane every ~2.6 clocks, whatever the address pattern), but
+// ds_add_u32 >= 5.4 T adds/s.  So the accumulation here is FIXED POINT:
+//
+//  * a workgroup owns (image, head, level, part) where part = a 32x16-pixel tile of the level (levels too large for
+//    LDS; its rows = the queries whose sampling centroid on that level falls in the tile, bucketed by two small
+//    launches) or a chunk of the queries (levels of <= 1092 pixels, held whole);
+//  * its window -- tile + 5 pixels all round, or the whole level -- is 32 int32 accumulators per pixel in LDS
+//    (139 776 bytes); every contribution w_corner * aw * grad_out[c] is scaled by a power of two, rounded to nearest
+//    (v_cvt_rpi_i32_f32) and added with ds_add_u32.  The scale comes from a bound no accumulator of the item can
+//    exceed: (rows of the item) x (largest max_c|g| * sum_p|aw| over the queries of the (level, image, head), found
+//    by the bucketing launch), with 2 bits of headroom -- overflow is impossible, integer adds commute (the
+//    accumulation inside a window is exact and order-independent), and each add carries <= 2^-30 of that bound as
+//    rounding error (the fp32 atomics it replaces: 2^-24 of the running sum).  A NaN or an infinity in grad_out or
+//    the weights wins the maximum (compared as bit patterns) and sends the whole (level, image, head) to the
+//    floating-point path, so non-finite gradients still propagate;
+//  * the window is flushed once, as whole 128-byte lines of fp32 atomics (overlapping halos of neighbouring
+//    tiles meet there): ~10x fewer L2 atomics than the direct kernel at layer 0;
+//  * a sample whose 2x2 footprint leaves the window (offset beyond the halo) falls back to fp32 atomics on
+//    global memory for that sample only, so the result never depends on the window; levels with more than 1024
+//    tiles, or an item whose bound is not a normal number, take that path for every sample.
+//
+// Lane mapping: 8 lanes per (query, head) row, 128 rows per pass.  For the gather half of the backward
+// (grad_sampling_loc, grad_attn_weight) lane k holds channels 4k..4k+3 of a corner (one 16-byte buffer load,
+// out-of-image corners read as zero through the buffer's bounds check) and the four corner dot products
+// <grad_out, v_c> are reduced over the 8 lanes with three DPP adds; the gradients are linear combinations of
+// those four numbers.  For the scatter half lane k owns channels {8j + k}: in instruction i row r adds octet
+// j = (r & 3) ^ i, so the 32 lanes the LDS serves per clock (4 rows x 8 lanes) always cover 32 different banks
+// whatever pixels the rows hit -- no bank conflicts by construction, and no two lanes of an instruction ever share
+// an address.
+//
+// Measured (benchmarks/msda_backward_ab.py, B = 2, profiles/r02_msda_backward_ab.json): 334 us at 11 363 queries
+// against 1047 us for the direct kernel (fixed part ~100 us: the flush's ~35 M L2 atomics ~70 us, bucketing
+// ~20 us; below ~1200 queries the direct kernel wins and the host wrapper keeps it).  Where the rest goes, from
+// cycle stamps and knock-out builds: no single unit -- per 64-row pass ~2000 clocks of L1 requests (sixteen
+// 16-byte corner loads per lane: fp32 value is 128 bytes per corner), ~2600 of LDS atomics (64 per wave, ~5 clocks
+// each per CU), ~5000 of vector ALU (8 waves x ~650 instructions, of which ~250 are the per-sample set-up that all
+// eight lanes of a row repeat) and the flush, which runs with the rest of the CU idle (one workgroup per CU: the
+// window takes the LDS).  Tried without gain: sixteen waves at 128 VGPRs (spills), whole-pass phases instead of
+// the per-sample pipeline (same time), an exact per-item bound from a pre-pass over the rows (an extra round trip
+// per item for 2-3 bits of scale).  Next: the set-up computed once per sample by one lane of the row and
+// broadcast, two half-size windows per CU so that one workgroup's flush hides under the other's arithmetic.
+//
+// Everything that depends on the level shapes is decided on the device from the shape tensors (the reference
+// interface hands them over as device tensors; no host copy, no synchronisation): persistent workgroups draw
+// (level, image, head, part) items from a counter.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+
+namespace sdetr {
+
+void note_backward_kernel(int which);  // abi.hip
+
+constexpr int kBtD = 32, kBtP = 4;
+constexpr int kBtTileW = 32, kBtTileH = 16, kBtHalo = 5;
+constexpr int kBtWinW = kBtTileW + 2 * kBtHalo;      // 42
+constexpr int kBtWinH = kBtTileH + 2 * kBtHalo;      // 26
+constexpr int kBtWinPx = kBtWinW * kBtWinH;          // 1092
+constexpr int kBtWinBytes = kBtWinPx * kBtD * 4;     // 139 776
+constexpr int kBtMaxTiles = 1024;
+constexpr int kBtMaxL = 8, kBtMaxHeads = 64;
+constexpr int kBtChunkRows = 512, kBtMaxChunks = 16;
+constexpr int kBtThreads = 512, kBtRowsPerPass = kBtThreads / 8;   // 8 waves: 256 VGPRs each (16 corner loads in flight)
+constexpr int kBtLdsBytes = kBtWinBytes + 1024;
+enum { kBtTile = 0, kBtResident = 1, kBtDirect = 2 };
+
+struct BtLevel {
+    int H, W, start, mode, tx, ty, parts, items;
+};
+
+__device__ __forceinline__ BtLevel bt_level(const int64_t *shapes, const int64_t *lsi, int l, int B, int M, int Nq)
+{
+    BtLevel v;
+    v.H = (int)shapes[2 * l];
+    v.W = (int)shapes[2 * l + 1];
+    v.start = (int)lsi[l];
+    v.tx = (v.W + kBtTileW - 1) / kBtTileW;
+    v.ty = (v.H + kBtTileH - 1) / kBtTileH;
+    int chunks = (Nq + kBtChunkRows - 1) / kBtChunkRows;
+    chunks = chunks < 1 ? 1 : (chunks > kBtMaxChunks ? kBtMaxChunks : chunks);
+    if (v.H * v.W <= kBtWinPx) {
+        v.mode = kBtResident;
+        v.parts = chunks;
+    } else if (v.tx * v.ty <= kBtMaxTiles) {
+        v.mode = kBtTile;
+        v.parts = v.tx * v.ty;
+    } else {
+        v.mode = kBtDirect;
+        v.parts = chunks;
+    }
+    v.items = B * M * v.parts;
+    return v;
+}
+
+struct BtArgs {
+    const float *grad_out;   // [B,Nq,M,32]
+    const float *value;      // [B,Nv,M,32]
+    const int64_t *shapes;   // [L,2]
+    const int64_t *lsi;      // [L]
+    const float *loc;        // [B,Nq,M,L,4,2]
+    const float *aw;         // [B,Nq,M,L,4]
+    float *grad_value, *grad_loc, *grad_aw;
+    int B, Nv, M, L, Nq;
+    int *counter;            // work counter (zeroed by the tile-id launch)
+    int32_t *start;          // [L,B,kBtMaxTiles+1]
+    int32_t *order;          // [L,B,Nq]
+    uint16_t *tile_id;       // [L,B,Nq]
+    uint32_t *row_bound;     // [L,B,M] bits of max over the queries of max_c|g| * sum_p|aw| (zeroed before the tile-id launch)
+};
+
+// ------------------------------------------------------------------------------------------------
+// bucketing of the queries by tile, per tiled level: (1) tile of each (image, query) from the centroid of its
+// sampling locations on the level (mean over heads and points: the reference point up to the learned offsets);
+// (2) per (level, image) one workgroup: LDS histogram, scan, scatter.
+__global__ void __launch_bounds__(256) bt_tile_id_kernel(BtArgs p)
+{
+    __shared__ uint32_t sh_b[kBtMaxL * kBtMaxHeads];   // [l * M + m] bits of the block's largest row bound
+    const int blocks_per_image = (p.Nq + 31) / 32;
+    const int b = blockIdx.x / blocks_per_image;
+    const int q = (blockIdx.x - b * blocks_per_image) * 32 + (threadIdx.x >> 3), k = threadIdx.x & 7;
+    const bool act = q < p.Nq;
+    const int64_t gq = (int64_t)b * p.Nq + (act ? q : p.Nq - 1);
+    for (int i = threadIdx.x; i < p.L * p.M; i += 256) sh_b[i] = 0u;
+    __syncthreads();
+    // row bounds max_c|g| * sum_p|aw| per level: compared as bit patterns, so a NaN or an infinity anywhere wins the
+    // maximum and sends the (level, image, head) to the floating-point path instead of being rounded away
+    for (int m = k; m < p.M; m += 8) {
+        const int64_t row = gq * p.M + m;
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(p.grad_out + row * kBtD);
+        uint32_t mg = 0u;
+#pragma unroll
+        for (int i = 0; i < kBtD / 4; ++i) {
+            const uint4 g = g4[i];
+            mg = max(max(mg, g.x & 0x7fffffffu), max(max(g.y & 0x7fffffffu, g.z & 0x7fffffffu), g.w & 0x7fffffffu));
+        }
+        for (int l = 0; l < p.L; ++l) {
+            const float4 a = *reinterpret_cast<const float4 *>(p.aw + (row * p.L + l) * kBtP);
+            const float rb = __uint_as_float(mg) * ((fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w)));
+            if (act) atomicMax(&sh_b[l * p.M + m], __float_as_uint(rb) & 0x7fffffffu);
+        }
+    }
+    for (int l = 0; l < p.L; ++l) {
+        const BtLevel lv = bt_level(p.shapes, p.lsi, l, p.B, p.M, p.Nq);
+        if (lv.mode != kBtTile) continue;
+        float sx = 0.f, sy = 0.f;
+        for (int m = k; m < p.M; m += 8) {
+            const float4 *q4 = reinterpret_cast<const float4 *>(p.loc + ((gq * p.M + m) * p.L + l) * (kBtP * 2));
+            const float4 a = q4[0], c = q4[1];
+            sx += (a.x + a.z) + (c.x + c.z);
+            sy += (a.y + a.w) + (c.y + c.w);
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            sx += __shfl_xor(sx, o);
+            sy += __shfl_xor(sy, o);
+        }
+        if (act && k == 0) {
+            const float inv = 1.f / (float)(p.M * kBtP);
+            const float cx = sx * inv * (float)lv.W, cy = sy * inv * (float)lv.H;
+            int tx = cx > 0.f ? (int)fminf(cx, 1e9f) / kBtTileW : 0;   // NaN -> 0
+            int ty = cy > 0.f ? (int)fminf(cy, 1e9f) / kBtTileH : 0;
+            tx = tx >= lv.tx ? lv.tx - 1 : tx;
+            ty = ty >= lv.ty ? lv.ty - 1 : ty;
+            p.tile_id[((int64_t)l * p.B + b) * p.Nq + q] = (uint16_t)(ty * lv.tx + tx);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.L * p.M; i += 256) {
+        const int l = i / p.M, m = i - l * p.M;
+        if (sh_b[i]) atomicMax(&p.row_bound[((int64_t)l * p.B + b) * p.M + m], sh_b[i]);
+    }
+}
+
+__global__ void __launch_bounds__(1024) bt_order_kernel(BtArgs p)
+{
+    __shared__ int cnt[kBtMaxTiles];
+    __shared__ int part[16];
+    const int l = blockIdx.x / p.B, b = blockIdx.x - l * p.B, tid = threadIdx.x;
+    const BtLevel lv = bt_level(p.shapes, p.lsi, l, p.B, p.M, p.Nq);
+    if (lv.mode != kBtTile) return;
+    const int T = lv.parts;
+    const uint16_t *id = p.tile_id + ((int64_t)l * p.B + b) * p.Nq;
+    int32_t *start = p.start + ((int64_t)l * p.B + b) * (kBtMaxTiles + 1);
+    int32_t *order = p.order + ((int64_t)l * p.B + b) * p.Nq;
+    cnt[tid] = 0;
+    __syncthreads();
+    for (int q = tid; q < p.Nq; q += 1024) atomicAdd(&cnt[id[q]], 1);
+    __syncthreads();
+    const int c = cnt[tid];
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += n;
+    }
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < (tid >> 6); ++w) before += part[w];
+    const int excl = before + incl - c;
+    if (tid < T) start[tid] = excl;
+    if (tid == 0) start[T] = p.Nq;
+    cnt[tid] = excl;
+    __syncthreads();
+    for (int q = tid; q < p.Nq; q += 1024) order[atomicAdd(&cnt[id[q]], 1)] = q;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bt_xor1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float bt_xor2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float bt_up4(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, true));  // row_shl:4: lane i <- lane i+4
+}
+// sum over the 8 lanes of a row group; complete in lanes 0-3 of the group
+__device__ __forceinline__ float bt_sum8(float v)
+{
+    v += bt_xor1(v);
+    v += bt_xor2(v);
+    return v + bt_up4(v);
+}
+__device__ __forceinline__ float bt_max8(float v)
+{
+    v = fmaxf(v, bt_xor1(v));
+    v = fmaxf(v, bt_xor2(v));
+    return fmaxf(v, bt_up4(v));
+}
+__device__ __forceinline__ int bt_round(float v)   // floor(v + 0.5) in one instruction
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+typedef float bt_f32x2_t __attribute__((ext_vector_type(2)));
+// accumulate into an LDS word by byte address (no return value, nothing to wait for until the flush's barrier)
+__device__ __forceinline__ void bt_lds_add(uint32_t byte_addr, int v)
+{
+    asm volatile("ds_add_u32 %0, %1" : : "v"(byte_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ int bt_clamp(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float4 as_f4(uint4 v)
+{
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ int bt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One bilinear sample of a row, as the scatter and the gather halves need it.
+struct BtSample {
+    float lx, ly, a;
+    int pix;            // lstart + y0 * W + x0 (may be off the level; only valid corners are dereferenced)
+    uint32_t flags;     // bit c: corner c inside the image; bit 4: footprint inside the window; bit 5: inside the level
+};
+
+__device__ __forceinline__ BtSample bt_setup(float lxn, float lyn, float a, int H, int W, float fH, float fW, int lstart,
+                                             int ox, int oy, int ww, int wh, bool use_window, int &x0, int &y0)
+{
+    BtSample s;
+    const float w_im = lxn * fW - 0.5f, h_im = lyn * fH - 0.5f;
+    const bool inside = h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+    const float fx = floorf(w_im), fy = floorf(h_im);
+    s.lx = w_im - fx;
+    s.ly = h_im - fy;
+    s.a = a;
+    x0 = inside ? (int)fx : 0;
+    y0 = inside ? (int)fy : 0;
+    const bool vx0 = inside && x0 >= 0, vx1 = inside && x0 + 1 <= W - 1;
+    const bool vy0 = inside && y0 >= 0, vy1 = inside && y0 + 1 <= H - 1;
+    s.pix = lstart + y0 * W + x0;
+    const int x0v = max(x0, 0), x1v = min(x0 + 1, W - 1), y0v = max(y0, 0), y1v = min(y0 + 1, H - 1);
+    const bool in_window = use_window && ox <= x0v && x1v < ox + ww && oy <= y0v && y1v < oy + wh;
+    s.flags = (uint32_t)(vy0 && vx0) | ((uint32_t)(vy0 && vx1) << 1) | ((uint32_t)(vy1 && vx0) << 2) |
+              ((uint32_t)(vy1 && vx1) << 3) | ((uint32_t)in_window << 4) | ((uint32_t)inside << 5);
+    return s;
+}
+
+__global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem);
+    int *sh_i = reinterpret_cast<int *>(smem + kBtWinBytes);            // [8 l + f] level table, [64], [65] items
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = bt_uniform(tid >> 6);
+    const int slot = wave * 8 + (lane >> 3), k = lane & 7, rho = (lane >> 3) & 3;
+    const uint32_t lane_base = (uint32_t)(uint64_t)win + (uint32_t)(32 * rho + 4 * k);   // LDS byte address of my accumulator in pixel 0
+
+    if (tid < p.L) {
+        const BtLevel v = bt_level(p.shapes, p.lsi, tid, p.B, p.M, p.Nq);
+        int *t = sh_i + 8 * tid;
+        t[0] = v.H; t[1] = v.W; t[2] = v.start; t[3] = v.mode; t[4] = v.tx; t[5] = v.parts; t[6] = v.items;
+    }
+    if (tid == 0) sh_i[64] = atomicAdd(p.counter, 1);
+    for (int i = tid; i < kBtWinBytes / 16; i += kBtThreads) reinterpret_cast<uint4 *>(win)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    int total = 0;
+    for (int l = 0; l < p.L; ++l) total += sh_i[8 * l + 6];
+
+    const int64_t pix_floats = (int64_t)p.M * kBtD;
+    const uint32_t pix_bytes = (uint32_t)(p.M * kBtD * 4);
+
+    for (int iter = 0;; ++iter) {
+        int r = bt_uniform(sh_i[64 + (iter & 1)]);
+        if (r >= total) break;
+        // the next item's number is fetched now and published before this item's last barrier
+        int next_item = 0;
+        if (tid == 0) next_item = atomicAdd(p.counter, 1);
+        int l = 0;
+        while (r >= sh_i[8 * l + 6]) {
+            r -= sh_i[8 * l + 6];
+            ++l;
+        }
+        l = bt_uniform(l);
+        const int H = bt_uniform(sh_i[8 * l]), W = bt_uniform(sh_i[8 * l + 1]), lstart = bt_uniform(sh_i[8 * l + 2]);
+        const int mode = bt_uniform(sh_i[8 * l + 3]), tiles_x = bt_uniform(sh_i[8 * l + 4]);
+        const int parts = bt_uniform(sh_i[8 * l + 5]);
+        const int part = bt_uniform(r % parts), bm = r / parts;
+        const int m = bt_uniform(bm % p.M), b = bt_uniform(bm / p.M);
+
+        // rows of the item
+        int n, begin = 0;
+        const int32_t *ord = nullptr;
+        if (mode == kBtTile) {
+            const int32_t *st = p.start + ((int64_t)l * p.B + b) * (kBtMaxTiles + 1);
+            const int s0 = st[part];
+            n = st[part + 1] - s0;
+            ord = p.order + ((int64_t)l * p.B + b) * p.Nq + s0;
+        } else {
+            const int per = (p.Nq + parts - 1) / parts;
+            begin = part * per;
+            n = min(p.Nq, begin + per) - begin;
+        }
+        n = bt_uniform(n);
+        // window and fixed-point scale: no accumulator of the item can exceed n * (largest row bound of the
+        // (level, image, head)), bt_tile_id_kernel's max of max_c|g| * sum_p|aw|.  bound < 2^x -> scale 2^(29 - x).
+        int ox = 0, oy = 0, ww = 0, wh = 0;
+        if (mode == kBtTile) {
+            ox = kBtTileW * (part % tiles_x) - kBtHalo;
+            oy = kBtTileH * (part / tiles_x) - kBtHalo;
+            ww = kBtWinW;
+            wh = kBtWinH;
+        } else if (mode == kBtResident) {
+            ww = W;
+            wh = H;
+        }
+        float scale = 0.f, inv_scale = 0.f;
+        bool use_window = false;
+        if (mode != kBtDirect && n > 0) {
+            const float bound = (float)n * __uint_as_float(p.row_bound[((int64_t)l * p.B + b) * p.M + m]);
+            if (bound > 0x1p-90f && bound < 0x1p+90f) {
+                const int x = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
+                scale = __uint_as_float((uint32_t)(29 - x + 127) << 23);
+                inv_scale = __uint_as_float((uint32_t)(127 - (29 - x)) << 23);
+                use_window = true;
+            } else if (bound == 0.f) {
+                use_window = true;   // nothing to scatter: every contribution is an exact zero
+            }
+        }
+
+        const __amdgpu_buffer_rsrc_t vrsrc = make_uniform_rsrc(
+            reinterpret_cast<const char *>(p.value + ((int64_t)b * p.Nv * p.M + m) * kBtD),
+            (uint32_t)(((int64_t)p.Nv * p.M - m) * kBtD * 4));
+        float *gv_base = p.grad_value + ((int64_t)b * p.Nv * p.M + m) * kBtD;
+        const float fW = (float)W, fH = (float)H;
+
+        // row operands of a pass: loaded one pass ahead (the loads of pass i+1 fly under the arithmetic of pass i)
+        struct RowIn {
+            float4 g, l01, l23, a4;
+            float gs[4];
+            int64_t row;
+        };
+        auto load_row = [&](int i) {
+            RowIn r;
+            const int ii = min(i, n - 1);
+            const int q = ord ? ord[ii] : begin + ii;
+            r.row = ((int64_t)b * p.Nq + q) * p.M + m;
+            r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.gs[j] = p.grad_out[r.row * kBtD + 8 * (rho ^ j) + k];
+            const float4 *lp = reinterpret_cast<const float4 *>(p.loc + (r.row * p.L + l) * (kBtP * 2));
+            r.l01 = lp[0];
+            r.l23 = lp[1];
+            r.a4 = *reinterpret_cast<const float4 *>(p.aw + (r.row * p.L + l) * kBtP);
+            return r;
+        };
+        RowIn nxt;
+        if (n > 0) nxt = load_row(slot);
+        for (int base = 0; base < n; base += kBtRowsPerPass) {
+            const int i = base + slot;
+            const bool act = i < n;
+            const RowIn cur = nxt;
+            if (base + kBtRowsPerPass < n) nxt = load_row(i + kBtRowsPerPass);
+            const int64_t row = cur.row;
+            float4 g = cur.g;
+            float gs[4] = {cur.gs[0], cur.gs[1], cur.gs[2], cur.gs[3]};
+            const float4 l01 = cur.l01, l23 = cur.l23, a4 = cur.a4;
+            if (!act) {
+                g = make_float4(0.f, 0.f, 0.f, 0.f);
+                gs[0] = gs[1] = gs[2] = gs[3] = 0.f;
+            }
+            const float lx_[4] = {l01.x, l01.z, l23.x, l23.z}, ly_[4] = {l01.y, l01.w, l23.y, l23.w};
+            const float aw_[4] = {a4.x, a4.y, a4.z, a4.w};
+
+            // ---- software pipeline over the row's four samples: [set-up + corner loads of s+1] [scatter of s]
+            // [dots of s].  The three stages load three different units (vector memory, LDS atomics, vector ALU); run
+            // as three whole-pass phases the eight waves of the workgroup hit the same unit at the same time and the
+            // other two idle (measured: phase times simply added up)
+            BtSample sm[kBtP];
+            float4 v[kBtP][4];
+            float wa[kBtP][4];
+            uint32_t ad[kBtP][4];
+            float o_aw[kBtP], o_x[kBtP], o_y[kBtP];
+            uint32_t fallback = 0;
+            const bt_f32x2_t gs01 = {gs[0], gs[1]}, gs23 = {gs[2], gs[3]};
+            auto stage_a = [&](int s) {
+                int x0, y0;
+                sm[s] = bt_setup(lx_[s], ly_[s], aw_[s], H, W, fH, fW, lstart, ox, oy, ww, wh, use_window, x0, y0);
+                const uint32_t f = sm[s].flags;
+                const uint32_t o00 = (uint32_t)sm[s].pix * pix_bytes + 16u * k;
+                v[s][0] = as_f4(buffer_load16(vrsrc, (f & 1u) ? o00 : 0xffffffffu));
+                v[s][1] = as_f4(buffer_load16(vrsrc, (f & 2u) ? o00 + pix_bytes : 0xffffffffu));
+                v[s][2] = as_f4(buffer_load16(vrsrc, (f & 4u) ? o00 + (uint32_t)W * pix_bytes : 0xffffffffu));
+                v[s][3] = as_f4(buffer_load16(vrsrc, (f & 8u) ? o00 + (uint32_t)(W + 1) * pix_bytes : 0xffffffffu));
+                // scaled corner weights (zero for corners off the image and for samples that leave the window:
+                // their adds are exact zeros on a clamped address) and the accumulator address of each corner
+                const float hx = 1.f - sm[s].lx, hy = 1.f - sm[s].ly;
+                const float as = (f & 16u) ? sm[s].a * scale : 0.f;
+                wa[s][0] = (f & 1u) ? hy * hx * as : 0.f;
+                wa[s][1] = (f & 2u) ? hy * sm[s].lx * as : 0.f;
+                wa[s][2] = (f & 4u) ? sm[s].ly * hx * as : 0.f;
+                wa[s][3] = (f & 8u) ? sm[s].ly * sm[s].lx * as : 0.f;
+                const int cx0 = bt_clamp(x0 - ox, 0, ww - 1), cx1 = bt_clamp(x0 + 1 - ox, 0, ww - 1);
+                const int cy0 = bt_clamp(y0 - oy, 0, wh - 1), cy1 = bt_clamp(y0 + 1 - oy, 0, wh - 1);
+                ad[s][0] = ((uint32_t)(cy0 * ww + cx0) << 7) + lane_base;
+                ad[s][1] = ((uint32_t)(cy0 * ww + cx1) << 7) + lane_base;
+                ad[s][2] = ((uint32_t)(cy1 * ww + cx0) << 7) + lane_base;
+                ad[s][3] = ((uint32_t)(cy1 * ww + cx1) << 7) + lane_base;
+            };
+            auto stage_b = [&](int s) {
+                if (use_window) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bt_f32x2_t w2 = {wa[s][c], wa[s][c]};
+                        const bt_f32x2_t p01 = gs01 * w2, p23 = gs23 * w2;   // v_pk_mul_f32
+                        bt_lds_add(ad[s][c], bt_round(p01.x));
+                        bt_lds_add(ad[s][c] ^ 32u, bt_round(p01.y));
+                        bt_lds_add(ad[s][c] ^ 64u, bt_round(p23.x));
+                        bt_lds_add(ad[s][c] ^ 96u, bt_round(p23.y));
+                    }
+                }
+            };
+            auto stage_c = [&](int s) {
+                float d[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    d[c] = bt_sum8(g.x * v[s][c].x + g.y * v[s][c].y + g.z * v[s][c].z + g.w * v[s][c].w);
+                const float lx = sm[s].lx, ly = sm[s].ly, hx = 1.f - lx, hy = 1.f - ly, a = sm[s].a;
+                o_aw[s] = hy * hx * d[0] + hy * lx * d[1] + ly * hx * d[2] + ly * lx * d[3];
+                o_x[s] = fW * a * (hy * (d[1] - d[0]) + ly * (d[3] - d[2]));
+                o_y[s] = fH * a * (hx * (d[2] - d[0]) + lx * (d[3] - d[1]));
+                fallback |= ((sm[s].flags & 0x30u) == 0x20u) ? (1u << s) : 0u;   // inside the level, not in the window
+            };
+            stage_a(0);
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) {
+                if (s + 1 < kBtP) stage_a(s + 1);
+                stage_b(s);
+                stage_c(s);
+            }
+            if (act && k == 0) {
+                *reinterpret_cast<float4 *>(p.grad_aw + (row * p.L + l) * kBtP) = make_float4(o_aw[0], o_aw[1], o_aw[2], o_aw[3]);
+                float4 *gl = reinterpret_cast<float4 *>(p.grad_loc + (row * p.L + l) * (kBtP * 2));
+                gl[0] = make_float4(o_x[0], o_y[0], o_x[1], o_y[1]);
+                gl[1] = make_float4(o_x[2], o_y[2], o_x[3], o_y[3]);
+            }
+            // ---- samples that left their window (or items without one): fp32 atomics on global memory ----
+            if (act && fallback) {
+#pragma unroll
+                for (int s = 0; s < kBtP; ++s) {
+                    if (!(fallback & (1u << s))) continue;
+                    const float lx = sm[s].lx, ly = sm[s].ly, hx = 1.f - lx, hy = 1.f - ly, a = sm[s].a;
+                    float *gp = gv_base + (int64_t)sm[s].pix * pix_floats + k;
+                    const float wf[4] = {hy * hx * a, hy * lx * a, ly * hx * a, ly * lx * a};
+                    const int64_t co[4] = {0, pix_floats, (int64_t)W * pix_floats, (int64_t)(W + 1) * pix_floats};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (sm[s].flags & (1u << c)) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gp + co[c] + 8 * (rho ^ j), wf[c] * gs[j]);
+                        }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the inline-asm adds are invisible to the compiler's counters
+        __syncthreads();
+        // ---- flush: whole 128-byte lines of fp32 atomics, accumulators left at zero for the next item ----
+        if (use_window && scale != 0.f && n > 0) {
+            const int c = tid & 31, npx = ww * wh;
+            constexpr int kStep = kBtThreads / 32, kAhead = 4;
+            int wy = 0, wx = tid >> 5;
+            while (wx >= ww) {
+                wx -= ww;
+                ++wy;
+            }
+            for (int px0 = tid >> 5; px0 < npx; px0 += kAhead * kStep) {
+                int v[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) v[u] = px0 + u * kStep < npx ? (int)win[(px0 + u * kStep) * 32 + c] : 0;
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (v[u] != 0) {
+                        win[(px0 + u * kStep) * 32 + c] = 0u;
+                        const int X = ox + wx, Y = oy + wy;
+                        if (X >= 0 && X < W && Y >= 0 && Y < H)
+                            unsafeAtomicAdd(gv_base + (int64_t)(lstart + Y * W + X) * pix_floats + c, (float)v[u] * inv_scale);
+                    }
+                    wx += kStep;
+                    while (wx >= ww) {
+                        wx -= ww;
+                        ++wy;
+                    }
+                }
+            }
+        }
+        if (tid == 0) sh_i[64 + ((iter + 1) & 1)] = next_item;
+        __syncthreads();
+    }
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+static size_t bt_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t bt_header_bytes(int B, int M, int L) { return 256 + bt_align((size_t)L * B * M * 4); }
+
+extern "C" size_t sdetr_msda_col2im_lds_workspace_bytes(int B, int Nq, int M, int L)
+{
+    if (B <= 0 || Nq <= 0 || L <= 0 || M <= 0) return 256;
+    return bt_header_bytes(B, M, L) + bt_align((size_t)L * B * (kBtMaxTiles + 1) * 4) + bt_align((size_t)L * B * Nq * 4) +
+           bt_align((size_t)L * B * Nq * 2);
+}
+
+extern "C" int sdetr_msda_col2im_lds_supported(int M, int D, int L, int P, int Nv)
+{
+    return D == kBtD && P == kBtP && L >= 1 && L <= kBtMaxL && M >= 1 && M <= kBtMaxHeads &&
+           (int64_t)Nv * M * D * 4 < 0xffffffffLL;
+}
+
+extern "C" int sdetr_msda_col2im_lds_f32(sdetr_stream_t stream, const float *grad_col, const float *value,
+                                         const int64_t *shapes, const int64_t *lsi, const float *loc, const float *aw,
+                                         int B, int Nv, int M, int D, int L, int Nq, int P, float *grad_value,
+                                         float *grad_loc, float *grad_aw, void *workspace, size_t workspace_bytes)
+{
+    if (B < 0 || Nv < 0 || M <= 0 || D <= 0 || L <= 0 || Nq < 0 || P <= 0) return fail("msda_col2im_lds_f32: bad dims");
+    if (!sdetr_msda_col2im_lds_supported(M, D, L, P, Nv))
+        return fail("msda_col2im_lds_f32: needs D = 32, P = 4, L <= 8, M <= 64 and a value tensor below 4 GiB per image "
+                    "(got D=%d P=%d L=%d M=%d)", D, P, L, M);
+    if (B == 0 || Nq == 0) return 0;
+    if (!grad_col || !value || !shapes || !lsi || !loc || !aw || !grad_value || !grad_loc || !grad_aw)
+        return fail("msda_col2im_lds_f32: null pointer");
+    if (!workspace || workspace_bytes < sdetr_msda_col2im_lds_workspace_bytes(B, Nq, M, L))
+        return fail("msda_col2im_lds_f32: workspace too small");
+    if ((int64_t)B * ((Nq + 31) / 32) > 0x7fffffffLL) return fail("msda_col2im_lds_f32: too many rows");
+    BtArgs a{};
+    a.grad_out = grad_col; a.value = value; a.shapes = shapes; a.lsi = lsi; a.loc = loc; a.aw = aw;
+    a.grad_value = grad_value; a.grad_loc = grad_loc; a.grad_aw = grad_aw;
+    a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq;
+    char *ws = static_cast<char *>(workspace);
+    a.counter = reinterpret_cast<int *>(ws);
+    a.row_bound = reinterpret_cast<uint32_t *>(ws + 256);
+    ws += bt_header_bytes(B, M, L);
+    a.start = reinterpret_cast<int32_t *>(ws);
+    ws += bt_align((size_t)L * B * (kBtMaxTiles + 1) * 4);
+    a.order = reinterpret_cast<int32_t *>(ws);
+    ws += bt_align((size_t)L * B * Nq * 4);
+    a.tile_id = reinterpret_cast<uint16_t *>(ws);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(workspace, 0, bt_header_bytes(B, M, L), s) != hipSuccess)
+        return fail("msda_col2im_lds_f32: clearing the workspace header failed");
+    hipLaunchKernelGGL(bt_tile_id_kernel, dim3((unsigned)(B * ((Nq + 31) / 32))), dim3(256), 0, s, a);
+    if (int rc = check_launch("msda_col2im_lds tile ids")) return rc;
+    hipLaunchKernelGGL(bt_order_kernel, dim3((unsigned)(L * B)), dim3(1024), 0, s, a);
+    if (int rc = check_launch("msda_col2im_lds order")) return rc;
+    static DeviceOnce lds_slots;
+    allow_dynamic_lds(bt_main_kernel, lds_slots, kBtLdsBytes);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    hipLaunchKernelGGL(bt_main_kernel, dim3((unsigned)cus), dim3(kBtThreads), kBtLdsBytes, s, a);
+    note_backward_kernel(SDETR_KERNEL_MSDA_BWD_LDS);
+    return check_launch("msda_col2im_lds");
+}

@@ -78,6 +78,22 @@ def ms_deform_attn_forward(value: Tensor, spatial_shapes: Tensor, level_start_in
     return out
 
 
+# The LDS-accumulating backward pays three launches and a flush of every window (~100 us at the benchmark pyramid,
+# whatever the query count): measured on MI355X (benchmarks/msda_backward_ab.py) it wins from ~1200 queries per
+# image up (3.1x at 11 363), the direct kernel (one launch, global atomics) below.  `lds_backward = False` forces
+# the direct kernel.
+lds_backward = True
+lds_backward_min_queries = 1200
+
+
+def last_backward_kernel() -> int:
+    """``SDETR_KERNEL_MSDA_BWD_*`` code of the kernel the calling thread's last MSDA backward call dispatched to."""
+    return int(_hip.lib().sdetr_msda_last_backward_kernel())
+
+
+KERNEL_BWD_DIRECT, KERNEL_BWD_LDS = 1, 2
+
+
 def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                             sampling_loc: Tensor, attn_weight: Tensor, grad_output: Tensor, im2col_step: int):
     """``_C.ms_deform_attn_backward`` (ms_deform_attn_cuda.cu:75-145).
@@ -90,11 +106,20 @@ def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_i
     grad_value = torch.zeros_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_aw = torch.empty_like(attn_weight)
-    fn = _hip.lib().sdetr_msda_col2im_f32 if value.dtype == torch.float32 else _hip.lib().sdetr_msda_col2im_f64
+    lib = _hip.lib()
+    common = (grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+              sampling_loc.data_ptr(), attn_weight.data_ptr(), B, Nv, M, D, L, Nq, P, grad_value.data_ptr(),
+              grad_loc.data_ptr(), grad_aw.data_ptr())
     with torch.cuda.device(value.device):
-        code = fn(_hip.stream_ptr(), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
-                  level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-                  B, Nv, M, D, L, Nq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_aw.data_ptr())
+        if (lds_backward and value.dtype == torch.float32 and Nq >= lds_backward_min_queries
+                and lib.sdetr_msda_col2im_lds_supported(M, D, L, P, Nv)):
+            # grad_value accumulated in LDS windows (msda_backward_tiled.hip); scratch for the query bucketing
+            nbytes = lib.sdetr_msda_col2im_lds_workspace_bytes(B, Nq, M, L)
+            workspace = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+            code = lib.sdetr_msda_col2im_lds_f32(_hip.stream_ptr(), *common, workspace.data_ptr(), nbytes)
+        else:
+            fn = lib.sdetr_msda_col2im_f32 if value.dtype == torch.float32 else lib.sdetr_msda_col2im_f64
+            code = fn(_hip.stream_ptr(), *common)
     _hip.check(code, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_aw]
 
