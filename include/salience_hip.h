@@ -358,7 +358,11 @@ int sdetr_column_mean_f32(sdetr_stream_t stream, const float *x, int64_t batch_s
  *     (unpacked, its [:, 128:] half multiplies the mean), weight2_local_packed = pack(weight2[:, :128]),
  *     weight3_packed = pack(layer2.2.weight [64,128]), weight4 = layer2.4.weight [1,64];
  *     const_workspace: [batch, 128] floats of scratch; score_min (optional device scalar) receives the minimum
- *     over all scores of the call -- the masked_fill value of salience_transformer.py:146-147. */
+ *     over all scores of the call -- the masked_fill value of salience_transformer.py:146-147.
+ *   sdetr_salience_head_stage1_x3 / sdetr_pack_linear_bf16x3: stage 1 with its two 256 x 256 GEMMs on the bf16 matrix
+ *     cores at fp32 accuracy (every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per product
+ *     -- csrc/salience_head.hip); same arguments and results as sdetr_salience_head_stage1, the two weights packed by
+ *     sdetr_pack_linear_bf16x3 instead (6 bytes per element: packed[k/16][n/32][plane][lane][8] bf16). */
 int sdetr_pack_linear_f32(sdetr_stream_t stream, const float *weight, int64_t row_stride, int out_features,
                           int in_features, float *packed);
 int sdetr_salience_head_blocks(int batch_size, int tokens);
@@ -369,6 +373,15 @@ int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x, int64_t x_
                                int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight,
                                const float *norm_bias, float norm_eps, const float *weight_packed, const float *bias,
                                float *memory_out, int64_t memory_batch_stride, float *z_local, float *partial_sums);
+int sdetr_pack_linear_bf16x3(sdetr_stream_t stream, const float *weight, int64_t row_stride, int out_features,
+                             int in_features, void *packed);
+int sdetr_salience_head_stage1_x3(sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride,
+                                  int batch_size, int tokens, int channels, const void *enc_weight_x3,
+                                  const float *enc_bias, const float *enc_norm_weight, const float *enc_norm_bias,
+                                  float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+                                  int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight,
+                                  const float *norm_bias, float norm_eps, const void *weight_x3, const float *bias,
+                                  float *memory_out, int64_t memory_batch_stride, float *z_local, float *partial_sums);
 int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums, int batch_size,
                                int tokens, const float *weight2, const float *bias2,
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,

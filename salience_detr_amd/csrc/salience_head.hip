@@ -347,6 +347,279 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : (RT == 2 ? 2 : 4)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stage 1 on the bf16 matrix cores at fp32 accuracy ("bf16 x 3").  The fp32-input MFMA of the kernel above runs at
+// 157 TFLOP/s and the two 256 x 256 GEMMs keep it busy for half of the kernel's time (profiles/r02_mfma_busy.md);
+// v_mfma_f32_32x32x16_bf16 is 16 times faster per multiply-add.  Every fp32 operand is split exactly into three
+// bf16 terms, x = x0 + x1 + x2 (24 mantissa bits = 3 x 8), and the product a.b is taken as the six bf16 MFMAs
+// a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0: each bf16 x bf16 product is exact in fp32, accumulation is fp32 as before,
+// and the dropped terms (a1b2, a2b1, a2b2) are below 2^-24 of the product -- the rounding the fp32 MFMA makes on the
+// product itself.  6/16 of the matrix time for the same scores (tests/test_filter_gpu.py compares both kernels with
+// the oracle; the selection is identical).  Weights are split once at pack time (sdetr_pack_linear_bf16x3: three
+// planes in operand order, [k-step of 16][32-column tile][plane][lane][8]); the token tile is split once per GEMM
+// into three LDS planes (the split costs 8 VALU operations per element: done per wave on its operand fragments it
+// would cost more than the MFMAs it feeds).
+typedef __bf16 sh_bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int kPlaneRow = kC * 2 + 16;                 // bytes per token row of a plane (16 bytes of padding)
+constexpr int kPlaneBytes = 32 * kPlaneRow;            // 32-token tile
+constexpr int kX3Region = 3 * kPlaneBytes;             // 50 688 bytes: three planes, or the fp32 tile (33 280)
+static_assert(kX3Region >= 32 * kXS * 4, "the fp32 tile aliases the planes");
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sh_bf16x8_t, a), __builtin_bit_cast(sh_bf16x8_t, b), c, 0, 0, 0);
+}
+
+// exact three-way split of four consecutive elements -> 4 bf16 of each plane
+__device__ __forceinline__ void split3(const float4 v, uint2 &p0, uint2 &p1, uint2 &p2)
+{
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = f32_to_bf16_bits(x[i]);
+        const float r1 = x[i] - __uint_as_float(h[i] << 16);
+        m[i] = f32_to_bf16_bits(r1);
+        const float r2 = r1 - __uint_as_float(m[i] << 16);
+        l[i] = f32_to_bf16_bits(r2);
+    }
+    p0 = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    p1 = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    p2 = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+__device__ __forceinline__ void store_split(char *planes, int row, int col, const float4 v)
+{
+    uint2 p0, p1, p2;
+    split3(v, p0, p1, p2);
+    char *d = planes + row * kPlaneRow + col * 2;
+    *reinterpret_cast<uint2 *>(d) = p0;
+    *reinterpret_cast<uint2 *>(d + kPlaneBytes) = p1;
+    *reinterpret_cast<uint2 *>(d + 2 * kPlaneBytes) = p2;
+}
+
+// the split weight of one wave's 32-column tile, PD k-steps (3 KB each) ahead of the MFMAs
+template <int PD>
+struct WeightStreamX3 {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t lane_off;
+    u32x4_t bq[PD][3];
+    static constexpr uint32_t kStep = 8 * 3 * 1024;   // bytes per k-step: 8 column tiles x 3 planes x 1 KB
+
+    __device__ __forceinline__ void start(const void *wp, int ctile, int lane)
+    {
+        rs = make_uniform_rsrc(reinterpret_cast<const char *>(wp), kStep * (kC / 16));
+        lane_off = (uint32_t)(ctile * 3 * 1024 + lane * 16);
+#pragma unroll
+        for (int u = 0; u < PD; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + pl * 1024), (int)(u * kStep), 0);
+    }
+};
+
+// acc += tile[32][256] (three planes in LDS) * W[my 32 columns][256]^T
+template <int PD>
+__device__ __forceinline__ void block_gemm_x3(const char *planes, WeightStreamX3<PD> &ws, int lane, f32x16 &acc)
+{
+    constexpr int NS = kC / 16;
+    static_assert(NS % PD == 0, "prefetch depth must divide the step count");
+    const char *ap = planes + (lane & 31) * kPlaneRow + (lane >> 5) * 16;
+#pragma unroll
+    for (int S0 = 0; S0 < NS; S0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int S = S0 + u;
+            u32x4_t b[3], a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[pl] = ws.bq[u][pl];
+            if (S + PD < NS) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    ws.bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + pl * 1024),
+                                                                         (int)((S + PD) * ws.kStep), 0);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const u32x4_t *>(ap + pl * kPlaneBytes + S * 32);
+            __builtin_amdgcn_sched_barrier(0);   // this step's prefetch stays in front of its MFMAs (see block_gemm)
+            acc = mfma_bf16(a[2], b[0], acc);    // smallest terms first
+            acc = mfma_bf16(a[0], b[2], acc);
+            acc = mfma_bf16(a[1], b[1], acc);
+            acc = mfma_bf16(a[1], b[0], acc);
+            acc = mfma_bf16(a[0], b[1], acc);
+            acc = mfma_bf16(a[0], b[0], acc);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512, 2) salience_head_stage1_x3_kernel(Stage1Args p)
+{
+    constexpr int TM = 32, THREADS = 512;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char *planes = reinterpret_cast<char *>(smem);               // three bf16 planes of the GEMM operand ...
+    float *tile = smem;                                           // ... or the fp32 tile [TM][kXS] between the GEMMs
+    float *par = smem + kX3Region / 4;                            // [kParRows][kC]
+    float *srow = par + kParRows * kC;                            // [TM] modulation factor, [TM] = alpha
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int t0 = blk * TM;
+    const int nvalid = min(TM, p.n - t0);
+    const int n0 = wave * 32;
+    const bool with_enc = p.w_enc != nullptr;
+
+    WeightStreamX3<4> ws;
+    ws.start(with_enc ? (const void *)p.w_enc : (const void *)p.w1, wave, lane);
+
+    // ---- token tile (split into planes when a GEMM consumes it directly), parameters and row factors -> LDS ----
+    {
+        const float *xb = p.x + (int64_t)b * p.x_batch_stride + (int64_t)t0 * p.x_row_stride;
+        constexpr int NL = TM * 64 / THREADS;   // float4 per thread
+        float4 v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * THREADS;
+            const int r = idx >> 6, c4 = idx & 63;
+            v[i] = *reinterpret_cast<const float4 *>(xb + (int64_t)min(r, nvalid - 1) * p.x_row_stride + c4 * 4);
+        }
+        if (tid < 256) {
+            const int row = tid >> 6, c4 = tid & 63;
+            const float *src0 = row == 0 ? p.b_enc : row == 1 ? p.g_enc : row == 2 ? p.beta_enc : p.g1;
+            const float *src1 = row == 0 ? p.beta1 : p.b1;
+            if (with_enc || row == 3) *reinterpret_cast<float4 *>(par + row * kC + c4 * 4) =
+                                          *reinterpret_cast<const float4 *>(src0 + c4 * 4);
+            if (row < 2) *reinterpret_cast<float4 *>(par + (4 + row) * kC + c4 * 4) =
+                             *reinterpret_cast<const float4 *>(src1 + c4 * 4);
+        }
+        if (tid < TM) {
+            float s = 0.f;
+            const int t = min(t0 + tid, p.n - 1);
+            if (p.row_scale) {
+                s = p.row_scale[(int64_t)b * p.n + t];
+            } else if (p.coarse) {
+                // bilinear, align_corners=True (F.interpolate, salience_transformer.py:139-142)
+                const int y = t / p.w, x = t - y * p.w;
+                const float sh = p.h > 1 ? (float)(p.ch - 1) / (float)(p.h - 1) : 0.f;
+                const float sw = p.w > 1 ? (float)(p.cw - 1) / (float)(p.w - 1) : 0.f;
+                const float fy = sh * (float)y, fx = sw * (float)x;
+                const int y1 = (int)fy, x1 = (int)fx;
+                const int yp = y1 < p.ch - 1 ? 1 : 0, xp = x1 < p.cw - 1 ? 1 : 0;
+                const float ly = fy - (float)y1, lx = fx - (float)x1;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float *cm = p.coarse + (int64_t)b * p.ch * p.cw;
+                s = hy * (hx * cm[y1 * p.cw + x1] + lx * cm[y1 * p.cw + x1 + xp]) +
+                    ly * (hx * cm[(y1 + yp) * p.cw + x1] + lx * cm[(y1 + yp) * p.cw + x1 + xp]);
+            }
+            srow[tid] = s;
+            if (tid == 0) srow[TM] = (p.row_scale || p.coarse) ? (p.alpha ? *p.alpha : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * THREADS;
+            const int r = idx >> 6, c4 = idx & 63;
+            const float4 val = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (with_enc) store_split(planes, r, c4 * 4, val);
+            else *reinterpret_cast<float4 *>(tile + r * kXS + c4 * 4) = val;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc;
+    if (with_enc) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        block_gemm_x3<4>(planes, ws, lane, acc);
+        ws.start(p.w1, wave, lane);   // layer1's first steps travel during the LayerNorm phase
+        __syncthreads();   // every wave is done reading the planes: the fp32 tile takes their place
+        const int c = n0 + (lane & 31);
+        const float bias = par[kParBEnc * kC + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tile[acc_row(i, lane) * kXS + c] = acc[i] + bias;
+        __syncthreads();
+    }
+
+    // ---- enc_output_norm -> modulation -> layer1 LayerNorm; 16 threads per row, each 4 float4; result -> planes ----
+    {
+        constexpr int TPR = THREADS / TM, NV = kC / 4 / TPR, CS = 4 * TPR;
+        const int r = tid / TPR, q = tid % TPR;
+        const float *row = tile + r * kXS + 4 * q;
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4 *>(row + CS * i);
+        float mean, rstd;
+        if (with_enc) {
+            row_stats<NV, TPR>(v, p.eps_enc, mean, rstd);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                v[i] = ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParGEnc * kC + CS * i + 4 * q),
+                                *reinterpret_cast<const float4 *>(par + kParBetaEnc * kC + CS * i + 4 * q));
+            if (p.memory_out && r < nvalid) {
+                float *mo = p.memory_out + (int64_t)b * p.mem_batch_stride + (int64_t)(t0 + r) * kC + 4 * q;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) *reinterpret_cast<float4 *>(mo + CS * i) = v[i];
+            }
+        }
+        const float s = srow[r], a = srow[TM];
+        if (a != 0.f) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                v[i] = make_float4(v[i].x + v[i].x * s * a, v[i].y + v[i].y * s * a, v[i].z + v[i].z * s * a,
+                                   v[i].w + v[i].w * s * a);
+        }
+        row_stats<NV, TPR>(v, p.eps1, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            v[i] = ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParG1 * kC + CS * i + 4 * q),
+                            *reinterpret_cast<const float4 *>(par + kParBeta1 * kC + CS * i + 4 * q));
+        __syncthreads();   // every thread holds its part of the tile in registers: the planes may overwrite it
+#pragma unroll
+        for (int i = 0; i < NV; ++i) store_split(planes, r, CS * i + 4 * q, v[i]);
+    }
+    __syncthreads();
+
+    // ---- layer1 Linear + GELU ----
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    block_gemm_x3<4>(planes, ws, lane, acc);
+    {
+        const int c = n0 + (lane & 31);
+        const float bias = par[kParB1 * kC + c];
+        if (n0 < kHalf) {
+            float *zl = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = acc_row(i, lane);
+                if (r < nvalid) zl[(int64_t)r * kHalf + c] = gelu_erf(acc[i] + bias);
+            }
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += acc_row(i, lane) < nvalid ? gelu_erf(acc[i] + bias) : 0.f;
+            s += __shfl_xor(s, 32);
+            if (lane < 32) p.partial[((int64_t)b * p.nblk + blk) * kHalf + (c - kHalf)] = s;
+        }
+    }
+}
+
+// P[S][ctile][plane][lane][j] = plane of W[32 ctile + (lane & 31)][16 S + 8 (lane >> 5) + j]
+__global__ void pack_linear_bf16x3_kernel(const float *w, int64_t row_stride, int N, int K, uint16_t *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * K) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const int64_t rest = i >> 9;
+    const int ctile = (int)(rest % (N / 32)), S = (int)(rest / (N / 32));
+    const float x = w[(int64_t)(32 * ctile + (lane & 31)) * row_stride + 16 * S + 8 * (lane >> 5) + j];
+    const uint32_t h = f32_to_bf16_bits(x);
+    const float r1 = x - __uint_as_float(h << 16);
+    const uint32_t m = f32_to_bf16_bits(r1);
+    const float r2 = r1 - __uint_as_float(m << 16);
+    const uint32_t l = f32_to_bf16_bits(r2);
+    uint16_t *o = out + ((int64_t)(S * (N / 32) + ctile) * 3) * 512 + lane * 8 + j;
+    o[0] = (uint16_t)h;
+    o[512] = (uint16_t)m;
+    o[1024] = (uint16_t)l;
+}
+
 // const[b][j] = b2[j] + sum_c W2[j][128 + c] * mean_c,  mean_c = (sum over blocks of partial) / n.
 // 8 groups of 128 threads sum interleaved blocks (fixed order), then a fixed-order tree over the groups.
 constexpr int kConstGroups = 8;
@@ -573,6 +846,58 @@ extern "C" int sdetr_salience_head_stage1(sdetr_stream_t stream, const float *x,
                            (size_t)stage1_lds_bytes(32), s, a);
     }
     return check_launch("salience_head_stage1");
+}
+
+extern "C" int sdetr_pack_linear_bf16x3(sdetr_stream_t stream, const float *weight, int64_t row_stride, int out_features,
+                                        int in_features, void *packed)
+{
+    if (!weight || !packed) return fail("pack_linear_bf16x3: NULL pointer");
+    if (out_features <= 0 || in_features <= 0 || in_features % 16 != 0 || out_features % 32 != 0)
+        return fail("pack_linear_bf16x3: [out,in] must be multiples of (32,16) (got %d x %d)", out_features, in_features);
+    const int64_t total = (int64_t)out_features * in_features;
+    hipLaunchKernelGGL(pack_linear_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), weight, row_stride, out_features, in_features,
+                       static_cast<uint16_t *>(packed));
+    return check_launch("pack_linear_bf16x3");
+}
+
+static int stage1_x3_lds_bytes() { return kX3Region + (kParRows * kC + 32 + 4) * (int)sizeof(float); }
+
+extern "C" int sdetr_salience_head_stage1_x3(sdetr_stream_t stream, const float *x, int64_t x_batch_stride,
+                                             int64_t x_row_stride, int batch_size, int tokens, int channels,
+                                             const void *enc_weight_x3, const float *enc_bias,
+                                             const float *enc_norm_weight, const float *enc_norm_bias, float enc_norm_eps,
+                                             const float *row_scale, const float *coarse_score, int coarse_h, int coarse_w,
+                                             int level_h, int level_w, const float *alpha, const float *norm_weight,
+                                             const float *norm_bias, float norm_eps, const void *weight_x3,
+                                             const float *bias, float *memory_out, int64_t memory_batch_stride,
+                                             float *z_local, float *partial_sums)
+{
+    if (channels != kC) return fail("salience_head_stage1_x3: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
+    if (batch_size < 0 || tokens < 0) return fail("salience_head_stage1_x3: negative size");
+    if (batch_size == 0 || tokens == 0) return 0;
+    if (!x || !norm_weight || !norm_bias || !weight_x3 || !bias || !z_local || !partial_sums)
+        return fail("salience_head_stage1_x3: NULL pointer");
+    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
+        return fail("salience_head_stage1_x3: enc_output parameters incomplete");
+    if (row_scale && coarse_score) return fail("salience_head_stage1_x3: give row_scale OR coarse_score");
+    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
+        return fail("salience_head_stage1_x3: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
+    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("salience_head_stage1_x3: rows must be 16-byte aligned");
+    if (stage1_block_tokens(batch_size, tokens) != 32)
+        return fail("salience_head_stage1_x3: 32-token blocks only (unset SDETR_HEAD_ROWTILES)");
+    Stage1Args a;
+    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
+    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
+    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
+    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
+    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
+    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = bias;
+    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
+    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = (tokens + 31) / 32;
+    hipLaunchKernelGGL(salience_head_stage1_x3_kernel, dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(512),
+                       (size_t)stage1_x3_lds_bytes(), static_cast<hipStream_t>(stream), a);
+    return check_launch("salience_head_stage1_x3");
 }
 
 extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums,

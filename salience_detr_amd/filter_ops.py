@@ -254,26 +254,38 @@ def column_mean(x: Tensor) -> Tensor:
     return out
 
 
-def packed_linear_weight(weight: Tensor, cols=None) -> Tensor:
+# Stage 1 of the salience head on the bf16 matrix cores at fp32 accuracy (three-way exact split of both operands,
+# six MFMAs per product; csrc/salience_head.hip).  False = the fp32-input MFMA kernel.
+salience_head_bf16x3 = True
+
+
+def packed_linear_weight(weight: Tensor, cols=None, split3: bool = False) -> Tensor:
     """``weight[:, cols[0]:cols[1]]`` ([out, in] fp32 parameter) in the operand order of the salience-head kernels
-    (``sdetr_pack_linear_f32``).  The packed copy lives on the parameter object itself and is refreshed when the
-    parameter's storage, device or version changes (optimizer step, ``load_state_dict``, ``.to()``)."""
+    (``sdetr_pack_linear_f32``; ``split3``: the three bf16 planes of ``sdetr_pack_linear_bf16x3``).  The packed copy
+    lives on the parameter object itself and is refreshed when the parameter's storage, device or version changes
+    (optimizer step, ``load_state_dict``, ``.to()``)."""
     w = weight.detach()
     if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
         raise RuntimeError("packed_linear_weight: fp32 [out,in] HIP tensor with a contiguous last dim expected")
     cache = weight.__dict__.setdefault("_sdetr_packed", {})
     tag = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape))
-    hit = cache.get(cols)
+    key = (cols, split3)
+    hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
     if cols is not None:
         w = w[:, cols[0]:cols[1]]
-    out = torch.empty(w.shape[0] * w.shape[1], dtype=torch.float32, device=w.device)
     with torch.cuda.device(w.device):
-        code = _hip.lib().sdetr_pack_linear_f32(_hip.stream_ptr(), w.data_ptr(), w.stride(0), w.shape[0], w.shape[1],
-                                                out.data_ptr())
+        if split3:
+            out = torch.empty(w.shape[0] * w.shape[1] * 3, dtype=torch.bfloat16, device=w.device)
+            code = _hip.lib().sdetr_pack_linear_bf16x3(_hip.stream_ptr(), w.data_ptr(), w.stride(0), w.shape[0],
+                                                       w.shape[1], out.data_ptr())
+        else:
+            out = torch.empty(w.shape[0] * w.shape[1], dtype=torch.float32, device=w.device)
+            code = _hip.lib().sdetr_pack_linear_f32(_hip.stream_ptr(), w.data_ptr(), w.stride(0), w.shape[0],
+                                                    w.shape[1], out.data_ptr())
     _hip.check(code, "pack_linear")
-    cache[cols] = (tag, out)
+    cache[key] = (tag, out)
     return out
 
 
@@ -308,11 +320,12 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
         ch, cw = coarse_score.shape[-2:]
         lh, lw = level_hw
         _hip.require_device("salience_head", coarse_score=coarse_score)
+    x3 = bool(salience_head_bf16x3)
     w_enc = b_enc = g_enc = be_enc = None
     eps_enc = 0.0
     mbs = 0
     if enc_output is not None:
-        w_enc = packed_linear_weight(enc_output.weight)
+        w_enc = packed_linear_weight(enc_output.weight, split3=x3)
         b_enc, g_enc, be_enc = enc_output.bias.detach(), enc_output_norm.weight.detach(), enc_output_norm.bias.detach()
         eps_enc = float(enc_output_norm.eps)
         if memory_out is not None:
@@ -331,10 +344,12 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
         sfs = score_flat.stride(0)
     with torch.cuda.device(x.device):
         s = _hip.stream_ptr()
-        code = lib.sdetr_salience_head_stage1(
+        stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
+        code = stage1(
             s, x.data_ptr(), x.stride(0), x.stride(1), B, n, C, _hip.ptr(w_enc), _hip.ptr(b_enc), _hip.ptr(g_enc),
             _hip.ptr(be_enc), eps_enc, _hip.ptr(row_scale), _hip.ptr(coarse_score), ch, cw, lh, lw, _hip.ptr(alpha),
-            l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps), packed_linear_weight(l1.weight).data_ptr(),
+            l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps),
+            packed_linear_weight(l1.weight, split3=x3).data_ptr(),
             l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
         _hip.check(code, "salience_head_stage1")
         code = lib.sdetr_salience_head_stage2(

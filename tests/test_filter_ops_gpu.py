@@ -203,8 +203,12 @@ def _head_reference(pred, x, up=None, alpha=None, enc=None, enc_norm=None):
 @pytest.mark.parametrize("n,hw", [(1, (1, 1)), (63, (7, 9)), (64, (8, 8)), (77, (7, 11)), (1050, (25, 42)),
                                   (4200, (50, 84))])
 @pytest.mark.parametrize("mode", ["plain", "row_scale", "coarse", "enc+coarse"])
-def test_salience_head_matches_fp32_reference(n, hw, mode):
+@pytest.mark.parametrize("x3", [True, False], ids=["bf16x3", "f32mfma"])
+def test_salience_head_matches_fp32_reference(n, hw, mode, x3, monkeypatch):
+    """Both stage-1 kernels (fp32-input MFMA; bf16 MFMA on exact three-way splits) against the fp32 reference at the
+    same bar: the split loses nothing the fp32 kernel keeps."""
     from salience_detr_amd.salience_filtering import MaskPredictor
+    monkeypatch.setattr(F, "salience_head_bf16x3", x3)
     torch.manual_seed(n)
     B, C = 2, 256
     pred = MaskPredictor(C, C)
