@@ -411,6 +411,17 @@ int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const void *packe
                          const float *bias2, const float *norm_weight, const float *norm_bias, float norm_eps,
                          int tokens, int embed_dim, int hidden, void *out, int hidden_splits, void *workspace,
                          int64_t workspace_bytes);
+/* sdetr_ffn_fused_bf16 on the [batch_size * rows, 256] queries of an encoder layer, followed by that layer's
+ * sdetr_advance_rows (same argument meaning) without the layer output ever being handed back: with hidden_splits > 1
+ * the reduce + LayerNorm pass stores straight into sorted_result / next_query (one launch less per layer), with
+ * hidden_splits == 1 the two existing launches run.  workspace: sdetr_ffn_workspace_bytes(batch_size * rows,
+ * hidden_splits) bytes plus, for hidden_splits == 1, batch_size * rows * 512 bytes for the layer output. */
+int sdetr_ffn_fused_advance_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights, const float *bias1,
+                                 const float *bias2, const float *norm_weight, const float *norm_bias, float norm_eps,
+                                 int batch_size, int rows, int embed_dim, int hidden, int hidden_splits,
+                                 void *workspace, int64_t workspace_bytes, void *sorted_result, void *next_query,
+                                 const void *tokens, const int64_t *sorted_index, int64_t index_batch_stride,
+                                 const int64_t *count, int sorted_rows, int next_rows, int spatial_size);
 
 /* ---- (8) token-resident linear layers (256 input features, bf16) -------------------------------------------------
  * y = W x + b with the activations of 32 tokens resident in a wave's registers and the weights streamed through

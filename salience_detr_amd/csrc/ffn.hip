@@ -443,6 +443,62 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_kernel(const float *partial
                                                      pack_bf16x2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
 }
 
+// The same second pass with the end-of-layer bookkeeping of sdetr_advance_rows in its store (the four hidden-split
+// layers of the encoder: one launch less each): row i of image b goes to sorted_result[b,i] when live (i < count[b])
+// and to next_query[b,i] when i < next_rows -- live rows the LayerNorm output, the others the never-updated original
+// tokens[b, sorted_index[b,i]].
+struct FfnAdvance {
+    bf16_t *sorted_result;        // [B, sorted_rows, 256]
+    bf16_t *next_query;           // [B, next_rows, 256] or NULL
+    const bf16_t *tokens;         // [B, spatial_size, 256]
+    const int64_t *sorted_index;  // rows index_batch_stride apart
+    int64_t index_batch_stride;
+    const int64_t *count;         // [B] or NULL
+    int rows, sorted_rows, next_rows, spatial_size;
+};
+
+__global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float *partial, int nsplit, int T, const bf16_t *x,
+                                                                    const float *b2, const float *gamma,
+                                                                    const float *beta, float eps, FfnAdvance a)
+{
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= T) return;
+    const int b = tok / a.rows, i = tok - b * a.rows;
+    const bool live = !a.count || i < a.count[b];
+    const bool feeds_next = a.next_query && i < a.next_rows;
+    if (!live) {   // the row is not part of this image's focus set: the next layer sees the original token
+        if (feeds_next)
+            *reinterpret_cast<uint2 *>(a.next_query + ((int64_t)b * a.next_rows + i) * kFE + 4 * lane) =
+                *reinterpret_cast<const uint2 *>(a.tokens + ((int64_t)b * a.spatial_size +
+                                                             a.sorted_index[(int64_t)b * a.index_batch_stride + i]) * kFE + 4 * lane);
+        return;
+    }
+    const int64_t o = (int64_t)tok * kFE + 4 * lane;
+    const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
+    const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
+    float v0 = bv.x + bf16_lo(r.x), v1 = bv.y + bf16_hi(r.x), v2 = bv.z + bf16_lo(r.y), v3 = bv.w + bf16_hi(r.y);
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 pv = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
+        v0 += pv.x; v1 += pv.y; v2 += pv.z; v3 += pv.w;
+    }
+    float sum = (v0 + v1) + (v2 + v3);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+    const float mean = sum * (1.f / kFE);
+    const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+    float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+    const float rstd = rsqrtf(sq * (1.f / kFE) + eps);
+    const float4 gv = *reinterpret_cast<const float4 *>(gamma + 4 * lane);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * lane);
+    const uint2 y = make_uint2(pack_bf16x2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
+                               pack_bf16x2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
+    *reinterpret_cast<uint2 *>(a.sorted_result + ((int64_t)b * a.sorted_rows + i) * kFE + 4 * lane) = y;
+    if (feeds_next) *reinterpret_cast<uint2 *>(a.next_query + ((int64_t)b * a.next_rows + i) * kFE + 4 * lane) = y;
+}
+
 // hidden index inside a 16-wide k-block that MFMA operand slot (h, s) stands for: the accumulator rows a lane of
 // half h holds in registers 0..7 (kb = 0) / 8..15 (kb = 1)
 __device__ __forceinline__ int acc_hidden(int h, int s) { return s < 4 ? 4 * h + s : 8 + 4 * h + (s - 4); }
@@ -550,4 +606,66 @@ extern "C" int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const 
                            static_cast<hipStream_t>(stream), (const float *)workspace, hidden_splits, tokens,
                            (const bf16_t *)x, bias2, norm_weight, norm_bias, norm_eps, (bf16_t *)out);
     return check_launch("ffn_fused");
+}
+
+extern "C" int sdetr_advance_rows(sdetr_stream_t stream, const void *layer_out, void *sorted_result, void *next_query,
+                                  const void *tokens, const int64_t *sorted_index, int64_t index_batch_stride,
+                                  const int64_t *count, int batch_size, int rows, int sorted_rows, int next_rows,
+                                  int spatial_size, int row_bytes);
+
+extern "C" int sdetr_ffn_fused_advance_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights,
+                                            const float *bias1, const float *bias2, const float *norm_weight,
+                                            const float *norm_bias, float norm_eps, int batch_size, int rows,
+                                            int embed_dim, int hidden, int hidden_splits, void *workspace,
+                                            int64_t workspace_bytes, void *sorted_result, void *next_query,
+                                            const void *tokens, const int64_t *sorted_index,
+                                            int64_t index_batch_stride, const int64_t *count, int sorted_rows,
+                                            int next_rows, int spatial_size)
+{
+    if (batch_size < 0 || rows < 0) return fail("ffn_fused_advance: negative size");
+    if (next_rows < 0 || next_rows > rows || rows > sorted_rows)
+        return fail("ffn_fused_advance: need next_rows <= rows <= sorted_rows");
+    if ((int64_t)batch_size * rows > 0x7fffffffLL) return fail("ffn_fused_advance: too many rows");
+    const int tokens_total = batch_size * rows;
+    if (tokens_total == 0) return 0;
+    if (!sorted_result || !tokens || !sorted_index || (next_rows > 0 && !next_query))
+        return fail("ffn_fused_advance: null pointer");
+    if (index_batch_stride < rows) return fail("ffn_fused_advance: index batch stride too small");
+    // the layer output itself: the head of the workspace (after the split partials), never seen by the caller
+    const int64_t partial_bytes = sdetr_ffn_workspace_bytes(tokens_total, hidden_splits);
+    const int64_t out_bytes = hidden_splits > 1 ? 0 : (int64_t)tokens_total * kFE * 2;
+    if (workspace_bytes < partial_bytes + out_bytes || (partial_bytes + out_bytes > 0 && !workspace))
+        return fail("ffn_fused_advance: workspace of %lld bytes needed", (long long)(partial_bytes + out_bytes));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hidden_splits == 1) {
+        void *out = static_cast<char *>(workspace) + partial_bytes;
+        if (int rc = sdetr_ffn_fused_bf16(stream, x, packed_weights, bias1, bias2, norm_weight, norm_bias, norm_eps,
+                                          tokens_total, embed_dim, hidden, out, 1, nullptr, 0))
+            return rc;
+        return sdetr_advance_rows(stream, out, sorted_result, next_query, tokens, sorted_index, index_batch_stride, count,
+                                  batch_size, rows, sorted_rows, next_rows, spatial_size, kFE * 2);
+    }
+    if (embed_dim != kFE) return fail("ffn_fused: built for embed_dim %d (got %d)", kFE, embed_dim);
+    if (hidden <= 0 || hidden % kFChunk) return fail("ffn_fused: hidden (%d) must be a positive multiple of %d", hidden, kFChunk);
+    if (hidden_splits < 1 || hidden_splits > hidden / kFChunk) return fail("ffn_fused: hidden_splits must be in 1 .. hidden/32");
+    if (!x || !packed_weights || !bias1 || !bias2 || !norm_weight || !norm_bias) return fail("ffn_fused: null pointer");
+    const size_t lds = 4 * (size_t)kFChunkBytes + (size_t)hidden * 4 + 3 * kFE * 4;
+    if (lds > 160 * 1024) return fail("ffn_fused: hidden %d needs %zu bytes of LDS", hidden, lds);
+    static DeviceOnce lds_once2;
+    allow_dynamic_lds(ffn_fused_kernel, lds_once2, 160 * 1024);
+    FfnArgs a;
+    a.x = (const bf16_t *)x; a.pw = (const char *)packed_weights; a.b1 = bias1; a.b2 = bias2; a.gamma = norm_weight;
+    a.beta = norm_bias; a.eps = norm_eps; a.out = nullptr; a.T = tokens_total; a.nchunk = hidden / kFChunk;
+    a.nsplit = hidden_splits; a.partial = (float *)workspace;
+    const int64_t tblocks = (tokens_total + kFTokBlock - 1) / kFTokBlock;
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds, s, a);
+    FfnAdvance adv;
+    adv.sorted_result = (bf16_t *)sorted_result; adv.next_query = next_rows > 0 ? (bf16_t *)next_query : nullptr;
+    adv.tokens = (const bf16_t *)tokens; adv.sorted_index = sorted_index; adv.index_batch_stride = index_batch_stride;
+    adv.count = count; adv.rows = rows; adv.sorted_rows = sorted_rows; adv.next_rows = next_rows;
+    adv.spatial_size = spatial_size;
+    hipLaunchKernelGGL(ffn_reduce_ln_advance_kernel, dim3((unsigned)((tokens_total + 3) / 4)), dim3(256), 0, s,
+                       (const float *)workspace, hidden_splits, tokens_total, (const bf16_t *)x, bias2, norm_weight,
+                       norm_bias, norm_eps, adv);
+    return check_launch("ffn_fused_advance");
 }

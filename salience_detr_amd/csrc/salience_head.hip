@@ -360,6 +360,8 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : (RT == 2 ? 2 : 4)
 // into three LDS planes (the split costs 8 VALU operations per element: done per wave on its operand fragments it
 // would cost more than the MFMAs it feeds).
 typedef __bf16 sh_bf16x8_t __attribute__((ext_vector_type(8)));
+// k-steps of weight (3 KB per wave and step) in flight: a step's six MFMAs take ~0.09 us, an L2 hit ~0.5-0.8 us
+constexpr int kX3Depth = 5;
 constexpr int kPlaneRow = kC * 2 + 16;                 // bytes per token row of a plane (16 bytes of padding)
 constexpr int kPlaneBytes = 32 * kPlaneRow;            // 32-token tile
 constexpr int kX3Region = 3 * kPlaneBytes;             // 50 688 bytes: three planes, or the fp32 tile (33 280)
@@ -422,32 +424,29 @@ template <int PD>
 __device__ __forceinline__ void block_gemm_x3(const char *planes, WeightStreamX3<PD> &ws, int lane, f32x16 &acc)
 {
     constexpr int NS = kC / 16;
-    static_assert(NS % PD == 0, "prefetch depth must divide the step count");
     const char *ap = planes + (lane & 31) * kPlaneRow + (lane >> 5) * 16;
+    // fully unrolled, the PD in-flight steps live in a ring indexed at compile time (see block_gemm)
 #pragma unroll
-    for (int S0 = 0; S0 < NS; S0 += PD) {
+    for (int S = 0; S < NS; ++S) {
+        const int u = S % PD;
+        u32x4_t b[3], a[3];
 #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int S = S0 + u;
-            u32x4_t b[3], a[3];
+        for (int pl = 0; pl < 3; ++pl) b[pl] = ws.bq[u][pl];
+        if (S + PD < NS) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[pl] = ws.bq[u][pl];
-            if (S + PD < NS) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    ws.bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + pl * 1024),
-                                                                         (int)((S + PD) * ws.kStep), 0);
-            }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const u32x4_t *>(ap + pl * kPlaneBytes + S * 32);
-            __builtin_amdgcn_sched_barrier(0);   // this step's prefetch stays in front of its MFMAs (see block_gemm)
-            acc = mfma_bf16(a[2], b[0], acc);    // smallest terms first
-            acc = mfma_bf16(a[0], b[2], acc);
-            acc = mfma_bf16(a[1], b[1], acc);
-            acc = mfma_bf16(a[1], b[0], acc);
-            acc = mfma_bf16(a[0], b[1], acc);
-            acc = mfma_bf16(a[0], b[0], acc);
+            for (int pl = 0; pl < 3; ++pl)
+                ws.bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + pl * 1024),
+                                                                     (int)((S + PD) * ws.kStep), 0);
         }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const u32x4_t *>(ap + pl * kPlaneBytes + S * 32);
+        __builtin_amdgcn_sched_barrier(0);   // this step's prefetch stays in front of its MFMAs (see block_gemm)
+        acc = mfma_bf16(a[2], b[0], acc);    // smallest terms first
+        acc = mfma_bf16(a[0], b[2], acc);
+        acc = mfma_bf16(a[1], b[1], acc);
+        acc = mfma_bf16(a[1], b[0], acc);
+        acc = mfma_bf16(a[0], b[1], acc);
+        acc = mfma_bf16(a[0], b[0], acc);
     }
 }
 
@@ -467,7 +466,7 @@ __global__ void __launch_bounds__(512, 2) salience_head_stage1_x3_kernel(Stage1A
     const int n0 = wave * 32;
     const bool with_enc = p.w_enc != nullptr;
 
-    WeightStreamX3<4> ws;
+    WeightStreamX3<kX3Depth> ws;
     ws.start(with_enc ? (const void *)p.w_enc : (const void *)p.w1, wave, lane);
 
     // ---- token tile (split into planes when a GEMM consumes it directly), parameters and row factors -> LDS ----
@@ -527,7 +526,7 @@ __global__ void __launch_bounds__(512, 2) salience_head_stage1_x3_kernel(Stage1A
     if (with_enc) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        block_gemm_x3<4>(planes, ws, lane, acc);
+        block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
         ws.start(p.w1, wave, lane);   // layer1's first steps travel during the LayerNorm phase
         __syncthreads();   // every wave is done reading the planes: the fp32 tile takes their place
         const int c = n0 + (lane & 31);
@@ -579,7 +578,7 @@ __global__ void __launch_bounds__(512, 2) salience_head_stage1_x3_kernel(Stage1A
     // ---- layer1 Linear + GELU ----
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    block_gemm_x3<4>(planes, ws, lane, acc);
+    block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
     {
         const int c = n0 + (lane & 31);
         const float bias = par[kParB1 * kC + c];

@@ -443,13 +443,9 @@ def fused_ffn_applies(x: Tensor, linear1, linear2, norm, activation) -> bool:
             and linear1.out_features <= 8192 and linear1.bias is not None and linear2.bias is not None)
 
 
-def fused_ffn(x: Tensor, linear1, linear2, norm, hidden_splits: Optional[int] = None) -> Tensor:
-    """``norm(x + linear2(relu(linear1(x))))`` in one launch (include/salience_hip.h (7)).  The packed weights and
-    fp32 copies of the small vectors live on ``linear1.weight`` and are refreshed when any parameter changes.
-    ``hidden_splits``: pieces of the hidden dimension per 128-token block (default: chosen for the device so that
-    small token counts still fill it; > 1 adds a reduce + LayerNorm launch)."""
-    if not x.is_cuda:
-        raise RuntimeError("fused_ffn: HIP device tensors required; there is no CPU fallback")
+def _ffn_operands(x: Tensor, linear1, linear2, norm):
+    """(packed weights, fp32 bias1, bias2, norm weight, norm bias) of the fused feed-forward, cached on
+    ``linear1.weight`` and refreshed when any parameter changes."""
     params = (linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias)
     tag = tuple((t.data_ptr(), t._version) for t in params) + (str(x.device),)
     cache = linear1.weight.__dict__.get("_sdetr_ffn")
@@ -464,7 +460,19 @@ def fused_ffn(x: Tensor, linear1, linear2, norm, hidden_splits: Optional[int] = 
             small = [t.detach().float().contiguous() for t in (linear1.bias, linear2.bias, norm.weight, norm.bias)]
         cache = (tag, packed, small)
         linear1.weight.__dict__["_sdetr_ffn"] = cache
-    _, packed, (b1, b2, g, be) = cache
+    return cache[1], cache[2]
+
+
+def fused_ffn(x: Tensor, linear1, linear2, norm, hidden_splits: Optional[int] = None) -> Tensor:
+    """``norm(x + linear2(relu(linear1(x))))`` in one launch (include/salience_hip.h (7)).  The packed weights and
+    fp32 copies of the small vectors live on ``linear1.weight`` and are refreshed when any parameter changes.
+    ``hidden_splits``: pieces of the hidden dimension per 128-token block (default: chosen for the device so that
+    small token counts still fill it; > 1 adds a reduce + LayerNorm launch)."""
+    if not x.is_cuda:
+        raise RuntimeError("fused_ffn: HIP device tensors required; there is no CPU fallback")
+    lib = _hip.lib()
+    F = linear1.out_features
+    packed, (b1, b2, g, be) = _ffn_operands(x, linear1, linear2, norm)
     x2 = x.reshape(-1, 256)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
@@ -479,6 +487,40 @@ def fused_ffn(x: Tensor, linear1, linear2, norm, hidden_splits: Optional[int] = 
                                         out.data_ptr(), splits, _hip.ptr(ws), ws_bytes)
     _hip.check(code, "ffn_fused")
     return out.view(x.shape)
+
+
+def fused_ffn_advance(x: Tensor, linear1, linear2, norm, sorted_result: Tensor, next_rows: int, tokens: Tensor,
+                      sorted_index: Tensor, count: Optional[Tensor] = None,
+                      hidden_splits: Optional[int] = None) -> Optional[Tensor]:
+    """``advance_rows(fused_ffn(x, ...), sorted_result, next_rows, tokens, sorted_index, count)`` as one operator
+    (``sdetr_ffn_fused_advance_bf16``): the end of an encoder layer.  With a split hidden dimension the reduce +
+    LayerNorm pass writes the live rows straight into ``sorted_result`` and the next layer's queries -- the layer
+    output is never materialised and ``advance_rows`` is no launch of its own."""
+    _hip.require_device("fused_ffn_advance", x=x, sorted_result=sorted_result, tokens=tokens, count=count)
+    if x.dim() != 3 or not x.is_contiguous() or x.shape[2] != 256:
+        raise RuntimeError("fused_ffn_advance: contiguous [B, rows, 256] queries expected")
+    B, rows, C = x.shape
+    if (sorted_result.dtype != x.dtype or tokens.dtype != x.dtype or sorted_index.dtype != torch.int64
+            or sorted_index.dim() != 2 or sorted_index.stride(1) != 1 or not sorted_index.is_cuda
+            or not sorted_result.is_contiguous() or not tokens.is_contiguous()):
+        raise RuntimeError("fused_ffn_advance: dtype / layout mismatch")
+    if count is not None and (count.dtype != torch.int64 or count.numel() != B):
+        raise RuntimeError("fused_ffn_advance: count must be int64 [B]")
+    lib = _hip.lib()
+    F = linear1.out_features
+    packed, (b1, b2, g, be) = _ffn_operands(x, linear1, linear2, norm)
+    nxt = torch.empty((B, next_rows, C), dtype=x.dtype, device=x.device) if next_rows > 0 else None
+    with torch.cuda.device(x.device):
+        splits = int(hidden_splits) if hidden_splits else lib.sdetr_ffn_auto_splits(B * rows, F)
+        ws_bytes = lib.sdetr_ffn_workspace_bytes(B * rows, splits) + (B * rows * 512 if splits == 1 else 0)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        code = lib.sdetr_ffn_fused_advance_bf16(
+            _hip.stream_ptr(), x.data_ptr(), packed.data_ptr(), b1.data_ptr(), b2.data_ptr(), g.data_ptr(),
+            be.data_ptr(), float(norm.eps), B, rows, 256, F, splits, ws.data_ptr(), ws_bytes, sorted_result.data_ptr(),
+            _hip.ptr(nxt), tokens.data_ptr(), sorted_index.data_ptr(), sorted_index.stride(0), _hip.ptr(count),
+            sorted_result.shape[1], int(next_rows), tokens.shape[1])
+    _hip.check(code, "ffn_fused_advance")
+    return nxt
 
 
 def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):

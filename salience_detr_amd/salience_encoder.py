@@ -27,7 +27,7 @@ from torch.nn import functional as F
 from . import pyramid
 from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
-                         fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
+                         fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
                          topk_attention_heads, topk_self_attention_, topk_self_attention_applies, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
@@ -87,11 +87,16 @@ class SalienceTransformerEncoderLayer(nn.Module):
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(query))))
         return self.norm2(query + self.dropout3(src2))
 
-    def _forward_ffn_native(self, query):
+    def _forward_ffn_native(self, query, advance=None):
         """No-grad FFN: ReLU in the first GEMM's epilogue when the activation is ReLU, residual + LayerNorm in
-        one launch."""
+        one launch.  ``advance`` = ``(sorted_result, next_rows, tokens, sorted_index, count)`` (the encoder's sorted
+        loop): the end-of-layer row bookkeeping (``advance_rows``) is part of the operator and the NEXT layer's
+        queries are returned instead of this layer's output."""
         if fused_ffn_applies(query, self.linear1, self.linear2, self.norm2, self.activation):
-            return fused_ffn(query, self.linear1, self.linear2, self.norm2)   # hidden state stays in registers
+            if advance is not None and query.dim() == 3 and query.is_contiguous():
+                return fused_ffn_advance(query, self.linear1, self.linear2, self.norm2, *advance)
+            out = fused_ffn(query, self.linear1, self.linear2, self.norm2)   # hidden state stays in registers
+            return out if advance is None else advance_rows(out, *advance)
         if isinstance(self.activation, nn.ReLU):
             x2d = query.reshape(-1, query.shape[-1])
             try:
@@ -101,7 +106,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
         else:
             hidden = self.activation(self.linear1(query))
         src2 = F.linear(hidden, self.linear2.weight, self.linear2.bias).view(query.shape)
-        return fused_layer_norm(query, self.norm2, residual=src2)
+        out = fused_layer_norm(query, self.norm2, residual=src2)
+        return out if advance is None else advance_rows(out, *advance)
 
     def _pre_attention(self, qk: Tensor, v: Tensor) -> Tensor:
         """nn.MultiheadAttention(q=k=qk, value=v) with the module's own parameters
@@ -146,11 +152,13 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
-                       class_head, level_shapes=None, selection_hook=None):
+                       class_head, level_shapes=None, selection_hook=None, advance=None):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
-        sorted-order buffers of which the first ``c`` rows belong to this layer.  Same arithmetic as ``forward``."""
+        sorted-order buffers of which the first ``c`` rows belong to this layer.  Same arithmetic as ``forward``.
+        With ``advance`` (see ``_forward_ffn_native``) the layer finishes with the encoder's row bookkeeping and
+        returns the next layer's queries."""
         c = query.shape[1]
         if token_linear_applies(query, class_head.weight):
             mc_score = class_head_max_times(query, class_head, fg_sorted[:, :c])   # logits never materialised
@@ -190,13 +198,13 @@ class SalienceTransformerEncoderLayer(nn.Module):
             # output_proj + residual + norm1 in one launch of the token-resident kernel at every layer size (below ~12 000
             # rows the library GEMM + separate LayerNorm is 1-2 us faster, but keeps hipBLASLt in the hot-path graph)
             query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
-            return self._forward_ffn_native(query)
+            return self._forward_ffn_native(query, advance)
         tgt2 = self._pre_attention_stacked(stacked, N)
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
         fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
         src2 = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes, level_start_index,
                                              query_pos=pos_sorted[:, :c], level_shapes=level_shapes)
-        return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2))
+        return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2), advance)
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
                 query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None,
@@ -368,11 +376,11 @@ class SalienceTransformerEncoder(nn.Module):
                 hook = None
                 if self.selection_hook is not None:
                     hook = (lambda sel, k=layer_id: self.selection_hook(k, sel))
-                y = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
-                                         level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
-                                         selection_hook=hook)
                 nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
-                q = advance_rows(y, result, nxt, value, sorted_index, focus64)
+                # the layer ends with the row bookkeeping (live rows recorded in `result`, next layer's queries)
+                q = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
+                                         level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
+                                         selection_hook=hook, advance=(result, nxt, value, sorted_index, focus64))
             if self.layer_marker is not None:
                 self.layer_marker(self.num_layers)
             if multi_level_masks is not None:

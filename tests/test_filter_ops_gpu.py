@@ -607,3 +607,29 @@ def test_encoder_prepare_sorted_equals_its_four_parts(dtype):
     assert torch.equal(ps, F.gather_rows(pos, index.contiguous()))
     assert torch.equal(fg, torch.gather(score, 1, index))
     assert torch.equal(ref, F.encoder_reference_points(vr, t_shapes.to(DEV), lsi.to(DEV), n, index=index))
+
+
+@pytest.mark.parametrize("rows,next_rows,splits", [(300, 200, 4), (1200, 1200, 2), (1500, 0, 8), (700, 300, 1)])
+def test_fused_ffn_advance_equals_ffn_then_advance_rows(rows, next_rows, splits):
+    """The end-of-layer operator (FFN + row bookkeeping in the reduce pass) against the two operators it replaces:
+    identical bits in sorted_result and the next layer's queries, rows past an image's focus count untouched / taken
+    from the original tokens (salience_transformer.py:474-485)."""
+    B, S, n0, C, Fh = 2, 2000, 1600, 256, 512
+    torch.manual_seed(rows)
+    l1, l2, norm = torch.nn.Linear(C, Fh), torch.nn.Linear(Fh, C), torch.nn.LayerNorm(C)
+    l1, l2, norm = (m.to(DEV).to(torch.bfloat16) for m in (l1, l2, norm))
+    x = (syn.det_randn(f"ffa{rows}", (B, rows, C)) * 0.7).to(DEV).to(torch.bfloat16)
+    tokens = syn.det_randn("ffa_tok", (B, S, C)).to(DEV).to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(S)[:n0] for _ in range(B)]).to(DEV)
+    count = torch.tensor([rows - 37, max(rows // 3, 1)], dtype=torch.int64, device=DEV)
+    res_a = torch.full((B, n0, C), -3.0, dtype=torch.bfloat16, device=DEV)
+    res_b = res_a.clone()
+    with torch.no_grad():
+        want_next = F.advance_rows(F.fused_ffn(x, l1, l2, norm, hidden_splits=splits), res_a, next_rows, tokens, idx, count)
+        got_next = F.fused_ffn_advance(x, l1, l2, norm, res_b, next_rows, tokens, idx, count, hidden_splits=splits)
+    assert torch.equal(res_a, res_b)
+    assert (res_b[0, rows - 37:] == -3).all() and (res_b[1, max(rows // 3, 1):] == -3).all()
+    if next_rows == 0:
+        assert want_next is None and got_next is None
+    else:
+        assert torch.equal(want_next, got_next)
