@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, BASELINE.json configs[1]) or train: fp32 forward+backward of the hot path, "
-                         "flat RCCL gradient all-reduce, AdamW step (configs[2])")
+                         "bucketed RCCL gradient all-reduce overlapped with backward, AdamW step (configs[2])")
+    ap.add_argument("--x3-linear", dest="x3_linear", action="store_true", default=True,
+                    help="train mode: weight gradients of the nn.Linear layers through sdetr_gemm_x3_f32 (default)")
+    ap.add_argument("--no-x3-linear", dest="x3_linear", action="store_false")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--value-dtype", choices=["same", "fp16"], default="fp16",
@@ -93,10 +96,13 @@ def train_main(args, model, device, rank, world, dist):
     sizes, canvas, level_shapes, _, (feats, masks, pos) = make_inputs(args.batch, args.height, args.width, device,
                                                                       seed=rank)
     model.train()
+    if args.x3_linear:
+        from salience_detr_amd.linear_x3 import use_x3_linear_
+        use_x3_linear_(model)   # weight gradients of the Linear layers on the bf16 matrix cores at fp32 accuracy
     if dist is not None:
         broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True)
     # 8 MiB buckets in reverse registration order, each all-reduced (RCCL) as soon as backward has produced its last
     # gradient: the exchange runs under the rest of backward; finish() after backward() waits and unpacks
     reducer = OverlappedGradReducer(params) if dist is not None else None
@@ -109,13 +115,16 @@ def train_main(args, model, device, rank, world, dist):
         wh = 0.02 + syn.det_rand(f"bench.box.wh{i}", (12, 2), salt=rank) ** 2 * 0.9
         targets.append({"boxes": torch.cat([c, wh], -1).to(device)})
 
+    # ground-truth boxes staged on the device once (the data loader's side); the target maps are built every step
+    staged = criterion.stage_boxes(targets, sizes, device)
+
     def step():
         nonlocal w
         opt.zero_grad(set_to_none=True)
         memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
         if w is None:
             w = torch.randn_like(memory)
-        loss = (memory * w).mean() + criterion(score_maps, targets, strides, sizes)["loss_salience"]
+        loss = (memory * w).mean() + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
         loss.backward()
         if reducer is not None:
             reducer.all_reduce(average=True)
@@ -131,10 +140,34 @@ def train_main(args, model, device, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the whole step (forward, backward, AdamW) as ONE hipGraph: the eager step issues ~1600 launches from Python and
+    # is host-bound as soon as the kernels get faster.  Single process only (the bucketed all-reduce hooks stay eager).
+    graph = None
+    graph_note = "eager"
+    if not args.no_graph and dist is None:
+        try:
+            graph, loss_static = capture(step, {})
+            graph_note = "hipGraph replay of the whole step"
+        except Exception as e:   # a host synchronisation inside the autograd path: report it, time the eager step
+            graph = None
+            graph_note = "eager (capture failed: %s)" % str(e).split("\n")[0][:120]
+            if os.environ.get("SDETR_BENCH_TRACEBACK"):
+                import traceback
+                traceback.print_exc()
+            torch.cuda.synchronize()
+            for _ in range(2):
+                step()
+
+    def timed_step():
+        if graph is not None:
+            graph.replay()
+            return loss_static
+        return step()
+
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = timed_step()
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -175,7 +208,8 @@ def train_main(args, model, device, rank, world, dist):
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "parallelism": "data parallel, bucketed gradient all-reduce over RCCL overlapped with backward"
                                   if world > 1 else "single GPU",
-                   "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params)},
+                   "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params),
+                   "execution": graph_note, "x3_linear": bool(args.x3_linear)},
         "roofline": {"kernel": "MSDA backward op: sdetr::bt_main_kernel (fixed-point LDS windows) + bucketing, "
                                "sdetr::msda_col2im_chan_kernel below 1200 queries", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -594,6 +594,17 @@ int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, int dtype, in
                              int hidden, const void *shortcut, int shortcut_row_stride, const void *shortcut2,
                              int shortcut2_row_stride, void *workspace, int64_t workspace_bytes, float *gate, void *out);
 
+/* ---- fp32 GEMM on the bf16 matrix cores at fp32 accuracy (csrc/gemm_x3.hip) -- the Linear layers of the training
+ * step (y = x w^T, dx = dy w, dw = dy^T x without transposed copies); replaces the at::linear / at::mm calls autograd
+ * makes for nn.Linear (models/bricks/salience_transformer.py:347-351, ms_deform_attn.py:312-331).
+ *   C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n]);  a_kmajor: A(m,k) = a[m * lda + k], else a[k * lda + m]; b likewise.
+ *   reduction_splits > 1: slices of the reduction accumulate into C with fp32 atomics (C must be zero on entry).
+ *   Every operand 16-byte aligned, leading dimensions multiples of 4; a k-major operand needs K % 4 == 0, the other
+ *   kind its row count % 4 == 0. */
+int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b, int64_t ldb,
+                      int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
+                      int reduction_splits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,246 @@
+// fp32 GEMM on the bf16 matrix cores at fp32 accuracy ("bf16 x 3"), for the training step's Linear layers (gfx950).
+//
+// The fp32-input MFMA peaks at 157 TFLOP/s and the library's fp32 GEMMs reach ~56 TFLOP/s on the step's skinny shapes
+// (K = 256: profiles/r02_train_kernel_stats.csv, 12.8 ms of the 27 ms step).  v_mfma_f32_32x32x16_bf16 is 16 times
+// faster per multiply-add.  Every fp32 operand element is split exactly into three bf16 terms, x = x0 + x1 + x2
+// (24 mantissa bits = 3 x 8), and a.b is taken as the six bf16 products a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0:
+// each is exact in fp32, accumulation is fp32, and the dropped terms are below 2^-24 of the product -- the rounding
+// an fp32 multiply makes anyway.  Same technique as stage 1 of the salience head (salience_head.hip), here as a
+// general tiled GEMM whose operands are split ON THE WAY INTO LDS: 128 x 128 x 32 tiles, global fp32 -> registers
+// (the next step's loads fly under this step's MFMAs) -> three bf16 planes per operand in LDS (row stride 80 bytes:
+// conflict-free 16-byte fragment reads) -> 48 MFMAs per wave and step.  Either operand may have the reduction index as
+// its contiguous one or as its row index (the LDS store transposes 4 x 4 blocks in registers), which covers the three
+// products of a Linear layer without a transposed copy:
+//     y  = x  w^T      A = x  [T,K]  k-major,   B = w [N,K]  k-major
+//     dx = dy w        A = dy [T,N]  k-major,   B = w [N,K]  reduction index = row
+//     dw = dy^T x      A = dy [T,N]  reduction index = row,  B = x [T,K]  reduction index = row   (split over T)
+// A reduction split over blockIdx.z accumulates with fp32 atomics into a zeroed C (the few-tile weight gradients).
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "common.h"
+
+namespace sdetr {
+
+constexpr int kGTile = 128, kGK = 32, kGThreads = 256;
+constexpr int kGRow = kGK * 2 + 16;              // bytes per row of a plane
+constexpr int kGPlane = kGTile * kGRow;          // 10 240
+constexpr int kGOperand = 3 * kGPlane;           // 30 720
+constexpr int kGLds = 2 * kGOperand;             // 61 440: two workgroups per CU
+
+typedef __bf16 g_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float g_f32x16_t __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float *a, *b;
+    float *c;
+    const float *bias;     // [N] or NULL (added by the blockIdx.z == 0 slice)
+    int64_t lda, ldb, ldc;
+    int M, N, K;
+    int k_per_split;       // reduction elements per blockIdx.z slice (multiple of 32)
+    int atomic;            // accumulate into C with atomics (split reduction)
+};
+
+__device__ __forceinline__ g_f32x16_t g_mfma(u32x4_t a, u32x4_t b, g_f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8_t, a), __builtin_bit_cast(g_bf16x8_t, b), c, 0, 0, 0);
+}
+
+// exact three-way split of four elements (consecutive along the reduction index) -> one 8-byte store per plane.
+// By TRUNCATION: h = top 16 bits of x (a bf16), r1 = x - h exactly, m = top 16 bits of r1, r2 = r1 - m exactly and
+// with at most 8 significant bits left, i.e. already a bf16.  5.5 VALU operations per element (and, sub, and, sub and
+// three half-instruction byte permutes that pack the high halves of two floats) -- the rounding converter
+// (compare / select / add chains of f32_to_bf16_bits) cost ~25 and made the split, not the MFMAs, the kernel's bound.
+__device__ __forceinline__ uint32_t g_pack_hi(float lo, float hi)   // bf16(lo) | bf16(hi) << 16, both by truncation
+{
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ void g_store_split(char *planes, int row, int k, float x0, float x1, float x2, float x3)
+{
+    const float x[4] = {x0, x1, x2, x3};
+    float r1[4], r2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
+        r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
+    }
+    char *d = planes + row * kGRow + k * 2;
+    *reinterpret_cast<uint2 *>(d) = make_uint2(g_pack_hi(x[0], x[1]), g_pack_hi(x[2], x[3]));
+    *reinterpret_cast<uint2 *>(d + kGPlane) = make_uint2(g_pack_hi(r1[0], r1[1]), g_pack_hi(r1[2], r1[3]));
+    *reinterpret_cast<uint2 *>(d + 2 * kGPlane) = make_uint2(g_pack_hi(r2[0], r2[1]), g_pack_hi(r2[2], r2[3]));
+}
+
+// One operand's 128 x 32 tile: 16 floats per thread.  KMAJOR: element (row, k) at src[row * ld + k]; otherwise at
+// src[k * ld + row].  Out-of-range rows / reduction indices read as zero.
+template <bool KMAJOR>
+struct TileLoad {
+    float4 v[4];
+    __device__ __forceinline__ void load(const float *src, int64_t ld, int row0, int rows, int k0, int kend, int tid)
+    {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KMAJOR) {
+            const int c4 = tid & 7, r = tid >> 3;
+            const int k = k0 + 4 * c4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + r + 32 * j;
+                v[j] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (int64_t)row * ld + k) : zero;
+            }
+        } else {
+            const int kb = tid >> 5, mb = tid & 31;
+            const int row = row0 + 4 * mb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 4 * kb + i;
+                v[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (int64_t)k * ld + row) : zero;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char *planes, int tid) const
+    {
+        if (KMAJOR) {
+            const int c4 = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g_store_split(planes, r + 32 * j, 4 * c4, v[j].x, v[j].y, v[j].z, v[j].w);
+        } else {
+            const int kb = tid >> 5, mb = tid & 31;   // 4 x 4 block transposed in registers
+            g_store_split(planes, 4 * mb + 0, 4 * kb, v[0].x, v[1].x, v[2].x, v[3].x);
+            g_store_split(planes, 4 * mb + 1, 4 * kb, v[0].y, v[1].y, v[2].y, v[3].y);
+            g_store_split(planes, 4 * mb + 2, 4 * kb, v[0].z, v[1].z, v[2].z, v[3].z);
+            g_store_split(planes, 4 * mb + 3, 4 * kb, v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+    }
+};
+
+__device__ __forceinline__ int g_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *pa = lds, *pb = lds + kGOperand;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * kGTile, n0 = blockIdx.x * kGTile;
+    const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+
+    g_f32x16_t acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+
+    // operand tiles travel TWO steps ahead of the MFMAs that consume them (one step = ~0.7 us of matrix work per
+    // wave, an L2 / HBM trip under load 1-2 us): two register sets, the loop unrolled by two
+    TileLoad<A_KMAJOR> ta0, ta1;
+    TileLoad<B_KMAJOR> tb0, tb1;
+    ta0.load(p.a, p.lda, m0, p.M, kbeg, kend, tid);
+    tb0.load(p.b, p.ldb, n0, p.N, kbeg, kend, tid);
+    ta1.load(p.a, p.lda, m0, p.M, kbeg + kGK, kend, tid);
+    tb1.load(p.b, p.ldb, n0, p.N, kbeg + kGK, kend, tid);
+    const char *fa = pa + (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 16;
+    const char *fb = pb + (64 * wn + (lane & 31)) * kGRow + (lane >> 5) * 16;
+
+    auto step = [&](TileLoad<A_KMAJOR> &ta, TileLoad<B_KMAJOR> &tb, int k0) {
+        ta.store(pa, tid);
+        tb.store(pb, tid);
+        __syncthreads();
+        ta.load(p.a, p.lda, m0, p.M, k0 + 2 * kGK, kend, tid);   // (reads as zeros past the end)
+        tb.load(p.b, p.ldb, n0, p.N, k0 + 2 * kGK, kend, tid);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t a[2][3], b[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[t][pl] = *reinterpret_cast<const u32x4_t *>(fa + t * 32 * kGRow + pl * kGPlane + kk * 32);
+                    b[t][pl] = *reinterpret_cast<const u32x4_t *>(fb + t * 32 * kGRow + pl * kGPlane + kk * 32);
+                }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    g_f32x16_t c = acc[rt][ct];
+                    c = g_mfma(a[rt][2], b[ct][0], c);   // smallest terms first
+                    c = g_mfma(a[rt][0], b[ct][2], c);
+                    c = g_mfma(a[rt][1], b[ct][1], c);
+                    c = g_mfma(a[rt][1], b[ct][0], c);
+                    c = g_mfma(a[rt][0], b[ct][1], c);
+                    c = g_mfma(a[rt][0], b[ct][0], c);
+                    acc[rt][ct] = c;
+                }
+        }
+        __syncthreads();   // every wave is done with this step's planes
+    };
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * kGK) {
+        step(ta0, tb0, k0);
+        if (k0 + kGK < kend) step(ta1, tb1, k0 + kGK);
+    }
+
+    const bool add_bias = p.bias && blockIdx.z == 0;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int n = n0 + 64 * wn + 32 * ct + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = add_bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + 64 * wm + 32 * rt + g_acc_row(i, lane);
+                if (m < p.M) {
+                    float *dst = p.c + (int64_t)m * p.ldc + n;
+                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
+                    else *dst = acc[rt][ct][i] + bias;
+                }
+            }
+    }
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+template <bool AK, bool BK>
+static int launch_gemm_x3(hipStream_t s, const GemmArgs &a, int splits)
+{
+    static DeviceOnce once;
+    allow_dynamic_lds(gemm_x3_kernel<AK, BK>, once, kGLds);
+    const dim3 grid((unsigned)((a.N + kGTile - 1) / kGTile), (unsigned)((a.M + kGTile - 1) / kGTile), (unsigned)splits);
+    hipLaunchKernelGGL((gemm_x3_kernel<AK, BK>), grid, dim3(kGThreads), kGLds, s, a);
+    return check_launch("gemm_x3");
+}
+
+// C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n]).  a_kmajor: A(m,k) = a[m * lda + k], else a[k * lda + m]; b likewise with n.
+// reduction_splits > 1: the reduction is cut into that many slices whose partial products are accumulated into C with
+// fp32 atomics -- C must be zero on entry.  Alignment: every operand 16-byte aligned, its leading dimension a multiple
+// of 4; a k-major operand needs K % 4 == 0, the other kind its row count % 4 == 0.
+extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b,
+                                 int64_t ldb, int b_kmajor, float *c, int64_t ldc, int M, int N, int K,
+                                 const float *bias, int reduction_splits)
+{
+    if (M < 0 || N < 0 || K < 0) return fail("gemm_x3: negative size");
+    if (M == 0 || N == 0) return 0;
+    if (!a || !b || !c) return fail("gemm_x3: null pointer");
+    if ((lda & 3) || (ldb & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15))
+        return fail("gemm_x3: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+    if ((a_kmajor && (K & 3)) || (!a_kmajor && (M & 3)) || (b_kmajor && (K & 3)) || (!b_kmajor && (N & 3)))
+        return fail("gemm_x3: M=%d N=%d K=%d do not meet the alignment rule of the chosen layouts", M, N, K);
+    if (reduction_splits < 1) reduction_splits = 1;
+    GemmArgs g{};
+    g.a = a; g.b = b; g.c = c; g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    const int steps = (K + kGK - 1) / kGK;
+    int splits = reduction_splits > steps ? (steps > 0 ? steps : 1) : reduction_splits;
+    g.k_per_split = ((steps + splits - 1) / splits) * kGK;
+    splits = g.k_per_split > 0 ? (K + g.k_per_split - 1) / g.k_per_split : 1;
+    if (splits < 1) splits = 1;
+    g.atomic = splits > 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a_kmajor && b_kmajor) return launch_gemm_x3<true, true>(s, g, splits);
+    if (a_kmajor && !b_kmajor) return launch_gemm_x3<true, false>(s, g, splits);
+    if (!a_kmajor && b_kmajor) return launch_gemm_x3<false, true>(s, g, splits);
+    return launch_gemm_x3<false, false>(s, g, splits);
+}

@@ -1,0 +1,126 @@
+"""fp32 ``nn.Linear`` forward / backward on the bf16 matrix cores at fp32 accuracy (``csrc/gemm_x3.hip``).
+
+The training step's Linear layers (``models/bricks/salience_transformer.py:347-351`` FFN, ``:366-379`` attention
+projections, ``ms_deform_attn.py:312-331`` value / offset / weight / output projections) are fp32 GEMMs with K = 256
+or 2048; autograd sends them to the library's fp32 GEMM, which runs at ~56 TFLOP/s on these shapes.
+``sdetr_gemm_x3_f32`` splits every fp32 operand exactly into three bf16 terms on its way into LDS and takes each
+product as six bf16 MFMAs -- the result is an fp32 product (error below 2^-24 of each term), the rate is that of the
+bf16 matrix cores divided by six.  ``use_x3_linear_(model)`` switches a model's ``nn.Linear`` modules to it in place
+(same parameters, same ``state_dict`` keys); inputs that do not meet the kernel's alignment rules, CPU tensors and
+non-fp32 dtypes keep going through ``F.linear``.
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+from torch.nn import functional as F
+
+from . import _hip
+
+
+def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int, K: int,
+            bias: Optional[Tensor] = None, reduction_splits: int = 1, out: Optional[Tensor] = None) -> Tensor:
+    """``C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n])`` with ``A(m,k) = a[m,k]`` (k-major) or ``a[k,m]``; ``b`` likewise
+    (``include/salience_hip.h``).  ``a`` / ``b`` are 2-d fp32 HIP tensors with a contiguous last dimension."""
+    _hip.require_device("gemm_x3", a=a, b=b, bias=bias)
+    for t, what in ((a, "a"), (b, "b")):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"gemm_x3: {what} must be a 2-d fp32 tensor with a contiguous last dimension")
+    if tuple(a.shape) != ((M, K) if a_kmajor else (K, M)) or tuple(b.shape) != ((N, K) if b_kmajor else (K, N)):
+        raise RuntimeError("gemm_x3: operand shapes do not match (M, N, K) and the layouts")
+    if out is None:
+        c = (torch.zeros if reduction_splits > 1 else torch.empty)((M, N), dtype=torch.float32, device=a.device)
+    else:   # a contiguous fp32 buffer of M * N elements in any shape (zeroed by the caller for a split reduction)
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != M * N or out.device != a.device:
+            raise RuntimeError("gemm_x3: out must be a contiguous fp32 tensor of M * N elements on the operands' device")
+        c = out.view(M, N)
+    with torch.cuda.device(a.device):
+        code = _hip.lib().sdetr_gemm_x3_f32(_hip.stream_ptr(), a.data_ptr(), a.stride(0), int(a_kmajor), b.data_ptr(),
+                                            b.stride(0), int(b_kmajor), c.data_ptr(), c.stride(0), M, N, K,
+                                            _hip.ptr(bias), int(reduction_splits))
+    _hip.check(code, "gemm_x3")
+    return c if out is None else out
+
+
+def x3_linear_applies(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> bool:
+    """fp32 HIP tensors whose sizes meet the kernel's alignment rule (in / out features multiples of 4)."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2
+            and weight.is_contiguous() and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0
+            and x.shape[-1] == weight.shape[1] and x.numel() > 0
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())))
+
+
+def _weight_grad_splits(T: int, N: int, K: int) -> int:
+    """Slices of the token dimension for ``dw = dy^T x``: its output is only (N/128) x (K/128) tiles, so the
+    reduction over the tokens is what has to fill the chip (512 workgroup slots)."""
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    return max(1, min((T + 255) // 256, (512 + tiles - 1) // tiles))
+
+
+# Which of a Linear layer's three products take the x3 kernel (the others go to the library's fp32 GEMM).  Measured on
+# MI355X (benchmarks/gemm_x3_bench.py, profiles/r02_gemm_x3.json): the kernel is LDS-bandwidth bound (three planes per
+# operand: 144 KB through LDS per 128 x 128 x 32 step) at 85-110 TFLOP/s fp32-equivalent -- on a par with the
+# library for y = x w^T and dx = dy w (86-120), 1.3-1.9x faster for the weight gradient dw = dy^T x, whose few output
+# tiles the library does not split over the token dimension.
+X3_FORWARD, X3_DX, X3_DW = False, False, True
+
+
+class _LinearX3(Function):
+    """2-d only (``x`` [T,K] contiguous): the caller reshapes outside, because a view made inside a custom Function
+    may not be modified in place afterwards (``nn.ReLU(inplace=True)`` follows ``linear1``)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        T, K = x2.shape
+        N = weight.shape[0]
+        y = gemm_x3(x2, True, weight, True, T, N, K, bias=bias) if X3_FORWARD else F.linear(x2, weight, bias)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        T, K = x2.shape
+        N = weight.shape[0]
+        g2 = gy if gy.is_contiguous() else gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:                                                    # dx = dy w
+            gx = gemm_x3(g2, True, weight, False, T, K, N) if X3_DX else g2 @ weight
+        if ctx.needs_input_grad[1]:                                                    # dw = dy^T x
+            gw = (gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=_weight_grad_splits(T, N, K)) if X3_DW
+                  else g2.t() @ x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def x3_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    """``F.linear`` with the fp32 products on the bf16 matrix cores (differentiable)."""
+    if not x3_linear_applies(x, weight, bias):
+        return F.linear(x, weight, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    return _LinearX3.apply(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
+
+
+class X3Linear(nn.Linear):
+    """``nn.Linear`` whose fp32 HIP forward / backward run through ``x3_linear``."""
+
+    def forward(self, input: Tensor) -> Tensor:   # noqa: A002 (nn.Linear's own argument name)
+        return x3_linear(input, self.weight, self.bias)
+
+
+def use_x3_linear_(model: nn.Module) -> int:
+    """Switch every plain ``nn.Linear`` of ``model`` to ``X3Linear`` in place (parameters and ``state_dict`` keys
+    unchanged; ``NonDynamicallyQuantizableLinear`` -- the out_proj of ``nn.MultiheadAttention``, which is called
+    through ``F.multi_head_attention_forward`` and never through its own ``forward`` -- is left alone).  Returns the
+    number of modules switched."""
+    n = 0
+    for m in model.modules():
+        if type(m) is nn.Linear:
+            m.__class__ = X3Linear
+            n += 1
+    return n

@@ -89,9 +89,11 @@ class SalienceCriterion(nn.Module):
         self.alpha = alpha
         self.gamma = gamma
 
-    def mask_targets(self, targets: List[Dict[str, Tensor]], level_shapes, feature_strides, image_sizes, device) -> Tensor:
-        """The supervision maps ``[B,S]`` (levels flattened back to back) for ``targets[i]["boxes"]`` (cx, cy, w, h in
-        [0,1] of image i, as in the reference's datasets)."""
+    @staticmethod
+    def stage_boxes(targets: List[Dict[str, Tensor]], image_sizes, device):
+        """Host side of the supervision: the ground-truth boxes of the batch as one device tensor of absolute
+        ``(x0, y0, x1, y1)`` plus the per-image offsets -- input staging (host lists, host -> device copies), done by
+        the data loader's side of a training loop; ``mask_targets`` / ``forward`` take the result as ``staged``."""
         xyxy, counts = [], []
         for t, (img_h, img_w) in zip(targets, image_sizes):
             b = t["boxes"].to(device=device, dtype=torch.float32)
@@ -104,16 +106,26 @@ class SalienceCriterion(nn.Module):
             offs.append(offs[-1] + c)
         boxes = torch.cat(xyxy, 0) if offs[-1] else torch.zeros((1, 4), dtype=torch.float32, device=device)
         box_offset = torch.tensor(offs, dtype=torch.int32).to(device)
+        return boxes, box_offset
+
+    def mask_targets(self, targets: List[Dict[str, Tensor]], level_shapes, feature_strides, image_sizes, device,
+                     staged=None) -> Tensor:
+        """The supervision maps ``[B,S]`` (levels flattened back to back) for ``targets[i]["boxes"]`` (cx, cy, w, h in
+        [0,1] of image i, as in the reference's datasets)."""
+        boxes, box_offset = staged if staged is not None else self.stage_boxes(targets, image_sizes, device)
         S = sum(h * w for h, w in level_shapes)
         noise = torch.rand((len(targets), S), dtype=torch.float32, device=device) if self.noise_scale else None
         return salience_targets(boxes, box_offset, level_shapes, feature_strides, self.limit_range, self.noise_scale, noise)
 
-    def forward(self, foreground_mask: Sequence[Tensor], targets, feature_strides, image_sizes):
-        """Reference signature (:27): ``foreground_mask`` = the salience maps ``[B,1,H_l,W_l]`` per level."""
+    def forward(self, foreground_mask: Sequence[Tensor], targets, feature_strides, image_sizes, staged=None):
+        """Reference signature (:27): ``foreground_mask`` = the salience maps ``[B,1,H_l,W_l]`` per level.  ``staged``
+        = ``stage_boxes(...)`` of the same targets when the caller has the boxes on the device already (a step captured
+        in a hipGraph: no host -> device copies inside); the target maps themselves are still built here."""
         if not foreground_mask[0].is_cuda:
             raise RuntimeError("SalienceCriterion: HIP device tensors required; there is no CPU fallback")
         level_shapes = [tuple(m.shape[-2:]) for m in foreground_mask]
-        target = self.mask_targets(targets, level_shapes, feature_strides, image_sizes, foreground_mask[0].device)
+        target = self.mask_targets(targets, level_shapes, feature_strides, image_sizes, foreground_mask[0].device,
+                                   staged=staged)
         logits = torch.cat([m.flatten(-2) for m in foreground_mask], -1).squeeze(1)
         loss = _FocalLoss.apply(logits, target, self.alpha, self.gamma, 0.5 * self.noise_scale)
         return {"loss_salience": loss}

@@ -1,0 +1,82 @@
+"""fp32 GEMM / Linear on the bf16 matrix cores at fp32 accuracy (csrc/gemm_x3.hip) against float64 products: the
+error bar is the one torch's own fp32 matmul meets on the same operands."""
+import pytest
+import torch
+
+from salience_detr_amd import linear_x3 as X
+from salience_detr_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _err(got, want64):
+    return ((got.double().cpu() - want64).abs().max() / want64.abs().max()).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 260, 256), (22726, 256, 2048), (4545, 384, 256), (4, 4, 4),
+                                   (1000, 2048, 256)])
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
+def test_gemm_x3_matches_float64(M, N, K, ak, bk):
+    a = syn.det_randn(f"ga{M}{K}", (M, K)) * 1.3
+    b = syn.det_randn(f"gb{N}{K}", (N, K)) * 0.7
+    want = a.double() @ b.double().t()
+    ad = (a if ak else a.t().contiguous()).to(DEV)
+    bd = (b if bk else b.t().contiguous()).to(DEV)
+    if (not ak and M % 4) or (not bk and N % 4):
+        pytest.skip("row counts of a row-major-reduction operand must be multiples of 4")
+    got = X.gemm_x3(ad, ak, bd, bk, M, N, K)
+    ref32 = (a.to(DEV) @ b.to(DEV).t())
+    assert _err(got, want) <= max(2.0 * _err(ref32, want), 2e-6)
+    if K >= 256:   # split reduction (atomics into a zeroed C)
+        got2 = X.gemm_x3(ad, ak, bd, bk, M, N, K, reduction_splits=4)
+        assert _err(got2, want) <= max(2.0 * _err(ref32, want), 2e-6)
+
+
+def test_gemm_x3_bias_and_argument_checks():
+    a, b = syn.det_randn("gba", (70, 64)).to(DEV), syn.det_randn("gbb", (36, 64)).to(DEV)
+    bias = syn.det_randn("gbias", (36,)).to(DEV)
+    got = X.gemm_x3(a, True, b, True, 70, 36, 64, bias=bias)
+    want = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
+    assert _err(got, want) < 2e-6
+    with pytest.raises(RuntimeError):
+        X.gemm_x3(a.cpu(), True, b, True, 70, 36, 64)
+    with pytest.raises(RuntimeError):
+        X.gemm_x3(a, True, b, True, 70, 36, 60)
+    with pytest.raises(RuntimeError):   # K-major operand with K % 4 != 0
+        X.gemm_x3(a[:, :62].contiguous(), True, b[:, :62].contiguous(), True, 70, 36, 62)
+
+
+@pytest.mark.parametrize("shape,N", [((2, 1137, 256), 2048), ((3000, 2048), 256), ((2, 300, 256), 384)])
+def test_x3_linear_forward_backward_match_float64(shape, N, monkeypatch):
+    for flag in ("X3_FORWARD", "X3_DX", "X3_DW"):   # all three products through the kernel under test
+        monkeypatch.setattr(X, flag, True)
+    K = shape[-1]
+    lin = torch.nn.Linear(K, N)
+    x = syn.det_randn(f"lx{N}", shape)
+    gy = syn.det_randn(f"lg{N}", shape[:-1] + (N,))
+    x64 = x.double().requires_grad_(True)
+    l64 = torch.nn.Linear(K, N).double()
+    l64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    l64(x64).backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    ld = torch.nn.Linear(K, N).to(DEV)
+    ld.load_state_dict(lin.state_dict())
+    assert X.use_x3_linear_(ld) == 1 and isinstance(ld, X.X3Linear)
+    y = ld(xd)
+    y.backward(gy.to(DEV))
+    xr = x.to(DEV).requires_grad_(True)
+    lr = torch.nn.Linear(K, N).to(DEV)
+    lr.load_state_dict(lin.state_dict())
+    lr(xr).backward(gy.to(DEV))
+    for got, ref, want in ((y, lr(xr), l64(x64)), (xd.grad, xr.grad, x64.grad), (ld.weight.grad, lr.weight.grad, l64.weight.grad),
+                           (ld.bias.grad, lr.bias.grad, l64.bias.grad)):
+        assert _err(got.detach(), want.detach()) <= max(3.0 * _err(ref.detach(), want.detach()), 3e-6)
+
+
+def test_x3_linear_falls_back_where_the_kernel_does_not_apply():
+    lin = X.X3Linear(256, 91).to(DEV)       # 91 classes: out features not a multiple of 4
+    x = syn.det_randn("lfb", (5, 256)).to(DEV)
+    assert torch.equal(lin(x), torch.nn.functional.linear(x, lin.weight, lin.bias))
+    cpu = X.X3Linear(8, 8)
+    assert torch.equal(cpu(torch.ones(2, 8)), torch.nn.functional.linear(torch.ones(2, 8), cpu.weight, cpu.bias))
