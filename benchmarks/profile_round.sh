@@ -46,4 +46,7 @@ python bench.py --cpu-protocol full > $O/${R}_bench_cpu_full.json 2> $O/${R}_ben
 python bench.py --mode train --steps 5 --warmup 2 > $O/${R}_train.json 2> $O/${R}_train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o p -- python bench.py --mode train --steps 3 --warmup 1 > /dev/null 2> $O/${R}_prof_train.err
 cp $(find $O/${R}_prof_train -name '*kernel_stats.csv' | head -1) $O/${R}_train_kernel_stats.csv
+# 8. the MSDA backward kernels side by side, the fp32-accurate GEMM against the library
+python benchmarks/msda_backward_ab.py > $O/${R}_msda_backward_ab.json 2> /dev/null
+python benchmarks/gemm_x3_bench.py > $O/${R}_gemm_x3.json 2> /dev/null
 ls $O | grep "^${R}" | head -40
