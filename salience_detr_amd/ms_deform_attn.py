@@ -425,12 +425,12 @@ def invalidate_caches(module: nn.Module) -> None:
     ``nn.init`` on ``.data``) changes neither: call this function afterwards, or write ``with torch.no_grad(): p.copy_(..)``.
     """
     for m in module.modules():
-        for attr in ("_fused_cache", "_fused_hm_cache", "_plan", "_flat_cache"):
+        for attr in ("_fused_cache", "_fused_hm_cache", "_plan", "_flat_cache", "_enc_output_cast"):
             if attr in m.__dict__:
                 m.__dict__[attr] = None
         m.__dict__.pop("_batched_value_proj", None)
         for p in m.parameters(recurse=False):
-            for key in ("_sdetr_packed", "_sdetr_ffn", "_sdetr_tl"):
+            for key in ("_sdetr_packed", "_sdetr_ffn", "_sdetr_tl", "_sdetr_f32"):
                 p.__dict__.pop(key, None)
 
 
