@@ -6,9 +6,9 @@
 // (24 mantissa bits = 3 x 8), and a.b is taken as the six bf16 products a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0:
 // each is exact in fp32, accumulation is fp32, and the dropped terms are below 2^-24 of the product -- the rounding
 // an fp32 multiply makes anyway.  Same technique as stage 1 of the salience head (salience_head.hip), here as a
-// general tiled GEMM whose operands are split ON THE WAY INTO LDS: 128 x 128 x 32 tiles, global fp32 -> registers
-// (the next step's loads fly under this step's MFMAs) -> three bf16 planes per operand in LDS (row stride 80 bytes:
-// conflict-free 16-byte fragment reads) -> 48 MFMAs per wave and step.  Either operand may have the reduction index as
+// general tiled GEMM: 128 x 128 x 32 tiles, global fp32 -> registers (two steps ahead of the MFMAs) -> fp32 tiles in
+// LDS (row stride 144 bytes: conflict-free 16-byte fragment reads) -> every wave splits the fragments it reads ->
+// 48 MFMAs per wave and step.  Either operand may have the reduction index as
 // its contiguous one or as its row index (the LDS store transposes 4 x 4 blocks in registers), which covers the three
 // products of a Linear layer without a transposed copy:
 //     y  = x  w^T      A = x  [T,K]  k-major,   B = w [N,K]  k-major
@@ -22,10 +22,10 @@
 namespace sdetr {
 
 constexpr int kGTile = 128, kGK = 32, kGThreads = 256;
-constexpr int kGRow = kGK * 2 + 16;              // bytes per row of a plane
-constexpr int kGPlane = kGTile * kGRow;          // 10 240
-constexpr int kGOperand = 3 * kGPlane;           // 30 720
-constexpr int kGLds = 2 * kGOperand;             // 61 440: two workgroups per CU
+constexpr int kGRow = kGK * 4 + 16;              // bytes per fp32 row of an operand tile (16 bytes of padding:
+                                                 // conflict-free 16-byte fragment reads at stride 36 dwords)
+constexpr int kGOperand = kGTile * kGRow;        // 18 432
+constexpr int kGLds = 2 * kGOperand;             // 36 864
 
 typedef __bf16 g_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float g_f32x16_t __attribute__((ext_vector_type(16)));
@@ -45,73 +45,127 @@ __device__ __forceinline__ g_f32x16_t g_mfma(u32x4_t a, u32x4_t b, g_f32x16_t c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8_t, a), __builtin_bit_cast(g_bf16x8_t, b), c, 0, 0, 0);
 }
 
-// exact three-way split of four elements (consecutive along the reduction index) -> one 8-byte store per plane.
-// By TRUNCATION: h = top 16 bits of x (a bf16), r1 = x - h exactly, m = top 16 bits of r1, r2 = r1 - m exactly and
-// with at most 8 significant bits left, i.e. already a bf16.  5.5 VALU operations per element (and, sub, and, sub and
-// three half-instruction byte permutes that pack the high halves of two floats) -- the rounding converter
-// (compare / select / add chains of f32_to_bf16_bits) cost ~25 and made the split, not the MFMAs, the kernel's bound.
+// Exact three-way split of an MFMA operand fragment (8 fp32 values consecutive along the reduction index) into
+// three bf16x8 fragments, by TRUNCATION: h = top 16 bits of x (a bf16), r1 = x - h exactly, m = top 16 bits of r1,
+// r2 = r1 - m exactly and with at most 8 significant bits left, i.e. already a bf16.  5.5 VALU operations per
+// element (and, sub, and, sub and three half-instruction byte permutes that pack the high halves of two floats) --
+// the rounding converter (compare / select / add chains of f32_to_bf16_bits) costs ~25.
+// The operands stay fp32 in LDS and every wave splits the fragments it reads: splitting before the LDS store (three
+// bf16 planes per operand) moves 1.6x the bytes through LDS and made LDS bandwidth the bound of the first version
+// (82-103 TFLOP/s fp32-equivalent).
 __device__ __forceinline__ uint32_t g_pack_hi(float lo, float hi)   // bf16(lo) | bf16(hi) << 16, both by truncation
 {
     return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
-__device__ __forceinline__ void g_store_split(char *planes, int row, int k, float x0, float x1, float x2, float x3)
+struct Frag3 {
+    u32x4_t p[3];
+};
+__device__ __forceinline__ Frag3 g_split(const float4 lo, const float4 hi)
 {
-    const float x[4] = {x0, x1, x2, x3};
-    float r1[4], r2[4];
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float r1[8], r2[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         r1[i] = x[i] - __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
         r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
     }
-    char *d = planes + row * kGRow + k * 2;
-    *reinterpret_cast<uint2 *>(d) = make_uint2(g_pack_hi(x[0], x[1]), g_pack_hi(x[2], x[3]));
-    *reinterpret_cast<uint2 *>(d + kGPlane) = make_uint2(g_pack_hi(r1[0], r1[1]), g_pack_hi(r1[2], r1[3]));
-    *reinterpret_cast<uint2 *>(d + 2 * kGPlane) = make_uint2(g_pack_hi(r2[0], r2[1]), g_pack_hi(r2[2], r2[3]));
+    Frag3 f;
+    f.p[0] = u32x4_t{g_pack_hi(x[0], x[1]), g_pack_hi(x[2], x[3]), g_pack_hi(x[4], x[5]), g_pack_hi(x[6], x[7])};
+    f.p[1] = u32x4_t{g_pack_hi(r1[0], r1[1]), g_pack_hi(r1[2], r1[3]), g_pack_hi(r1[4], r1[5]), g_pack_hi(r1[6], r1[7])};
+    f.p[2] = u32x4_t{g_pack_hi(r2[0], r2[1]), g_pack_hi(r2[2], r2[3]), g_pack_hi(r2[4], r2[5]), g_pack_hi(r2[6], r2[7])};
+    return f;
 }
 
 // One operand's 128 x 32 tile: 16 floats per thread.  KMAJOR: element (row, k) at src[row * ld + k]; otherwise at
-// src[k * ld + row].  Out-of-range rows / reduction indices read as zero.
+// src[k * ld + row].  Out-of-range rows / reduction indices read as zero.  The LDS tile is [row][k] fp32 either way.
 template <bool KMAJOR>
 struct TileLoad {
-    float4 v[4];
+    float4 v0, v1, v2, v3;   // (named members: an array here ends up in scratch memory)
+    __device__ __forceinline__ static float4 ld4(const float *ptr, bool ok)
+    {
+        return ok ? *reinterpret_cast<const float4 *>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __device__ __forceinline__ void load(const float *src, int64_t ld, int row0, int rows, int k0, int kend, int tid)
     {
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KMAJOR) {
-            const int c4 = tid & 7, r = tid >> 3;
+            const int c4 = tid & 7, r = row0 + (tid >> 3);
             const int k = k0 + 4 * c4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = row0 + r + 32 * j;
-                v[j] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (int64_t)row * ld + k) : zero;
-            }
+            const float *q = src + (int64_t)r * ld + k;
+            const bool kok = k < kend;
+            v0 = ld4(q, kok && r < rows);
+            v1 = ld4(q + 32 * ld, kok && r + 32 < rows);
+            v2 = ld4(q + 64 * ld, kok && r + 64 < rows);
+            v3 = ld4(q + 96 * ld, kok && r + 96 < rows);
         } else {
             const int kb = tid >> 5, mb = tid & 31;
-            const int row = row0 + 4 * mb;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k0 + 4 * kb + i;
-                v[i] = (row < rows && k < kend) ? *reinterpret_cast<const float4 *>(src + (int64_t)k * ld + row) : zero;
-            }
+            const int row = row0 + 4 * mb, k = k0 + 4 * kb;
+            const float *q = src + (int64_t)k * ld + row;
+            const bool rok = row < rows;
+            v0 = ld4(q, rok && k < kend);
+            v1 = ld4(q + ld, rok && k + 1 < kend);
+            v2 = ld4(q + 2 * ld, rok && k + 2 < kend);
+            v3 = ld4(q + 3 * ld, rok && k + 3 < kend);
         }
     }
-    __device__ __forceinline__ void store(char *planes, int tid) const
+    __device__ __forceinline__ void store(char *tile, int tid) const
     {
         if (KMAJOR) {
             const int c4 = tid & 7, r = tid >> 3;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g_store_split(planes, r + 32 * j, 4 * c4, v[j].x, v[j].y, v[j].z, v[j].w);
+            char *d = tile + r * kGRow + 16 * c4;
+            *reinterpret_cast<float4 *>(d) = v0;
+            *reinterpret_cast<float4 *>(d + 32 * kGRow) = v1;
+            *reinterpret_cast<float4 *>(d + 64 * kGRow) = v2;
+            *reinterpret_cast<float4 *>(d + 96 * kGRow) = v3;
         } else {
             const int kb = tid >> 5, mb = tid & 31;   // 4 x 4 block transposed in registers
-            g_store_split(planes, 4 * mb + 0, 4 * kb, v[0].x, v[1].x, v[2].x, v[3].x);
-            g_store_split(planes, 4 * mb + 1, 4 * kb, v[0].y, v[1].y, v[2].y, v[3].y);
-            g_store_split(planes, 4 * mb + 2, 4 * kb, v[0].z, v[1].z, v[2].z, v[3].z);
-            g_store_split(planes, 4 * mb + 3, 4 * kb, v[0].w, v[1].w, v[2].w, v[3].w);
+            char *d = tile + (4 * mb) * kGRow + 16 * kb;
+            *reinterpret_cast<float4 *>(d) = make_float4(v0.x, v1.x, v2.x, v3.x);
+            *reinterpret_cast<float4 *>(d + kGRow) = make_float4(v0.y, v1.y, v2.y, v3.y);
+            *reinterpret_cast<float4 *>(d + 2 * kGRow) = make_float4(v0.z, v1.z, v2.z, v3.z);
+            *reinterpret_cast<float4 *>(d + 3 * kGRow) = make_float4(v0.w, v1.w, v2.w, v3.w);
         }
     }
 };
 
 __device__ __forceinline__ int g_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__device__ __forceinline__ void gemm_x3_step(const GemmArgs &p, TileLoad<A_KMAJOR> &ta, TileLoad<B_KMAJOR> &tb, char *pa,
+                                             char *pb, const char *fa, const char *fb, int m0, int n0, int k0, int kend,
+                                             int tid, g_f32x16_t (&acc)[2][2])
+{
+
+    ta.store(pa, tid);
+    tb.store(pb, tid);
+    __syncthreads();
+    ta.load(p.a, p.lda, m0, p.M, k0 + 2 * kGK, kend, tid);   // (reads as zeros past the end)
+    tb.load(p.b, p.ldb, n0, p.N, k0 + 2 * kGK, kend, tid);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        Frag3 a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 *qa = reinterpret_cast<const float4 *>(fa + t * 32 * kGRow + kk * 64);
+            const float4 *qb = reinterpret_cast<const float4 *>(fb + t * 32 * kGRow + kk * 64);
+            a[t] = g_split(qa[0], qa[1]);
+            b[t] = g_split(qb[0], qb[1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                g_f32x16_t c = acc[rt][ct];
+                c = g_mfma(a[rt].p[2], b[ct].p[0], c);   // smallest terms first
+                c = g_mfma(a[rt].p[0], b[ct].p[2], c);
+                c = g_mfma(a[rt].p[1], b[ct].p[1], c);
+                c = g_mfma(a[rt].p[1], b[ct].p[0], c);
+                c = g_mfma(a[rt].p[0], b[ct].p[1], c);
+                c = g_mfma(a[rt].p[0], b[ct].p[0], c);
+                acc[rt][ct] = c;
+            }
+    }
+    __syncthreads();   // every wave is done with this step's tiles
+}
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
@@ -140,44 +194,12 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
     tb0.load(p.b, p.ldb, n0, p.N, kbeg, kend, tid);
     ta1.load(p.a, p.lda, m0, p.M, kbeg + kGK, kend, tid);
     tb1.load(p.b, p.ldb, n0, p.N, kbeg + kGK, kend, tid);
-    const char *fa = pa + (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 16;
-    const char *fb = pb + (64 * wn + (lane & 31)) * kGRow + (lane >> 5) * 16;
+    const char *fa = pa + (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 32;
+    const char *fb = pb + (64 * wn + (lane & 31)) * kGRow + (lane >> 5) * 32;
 
-    auto step = [&](TileLoad<A_KMAJOR> &ta, TileLoad<B_KMAJOR> &tb, int k0) {
-        ta.store(pa, tid);
-        tb.store(pb, tid);
-        __syncthreads();
-        ta.load(p.a, p.lda, m0, p.M, k0 + 2 * kGK, kend, tid);   // (reads as zeros past the end)
-        tb.load(p.b, p.ldb, n0, p.N, k0 + 2 * kGK, kend, tid);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4_t a[2][3], b[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[t][pl] = *reinterpret_cast<const u32x4_t *>(fa + t * 32 * kGRow + pl * kGPlane + kk * 32);
-                    b[t][pl] = *reinterpret_cast<const u32x4_t *>(fb + t * 32 * kGRow + pl * kGPlane + kk * 32);
-                }
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    g_f32x16_t c = acc[rt][ct];
-                    c = g_mfma(a[rt][2], b[ct][0], c);   // smallest terms first
-                    c = g_mfma(a[rt][0], b[ct][2], c);
-                    c = g_mfma(a[rt][1], b[ct][1], c);
-                    c = g_mfma(a[rt][1], b[ct][0], c);
-                    c = g_mfma(a[rt][0], b[ct][1], c);
-                    c = g_mfma(a[rt][0], b[ct][0], c);
-                    acc[rt][ct] = c;
-                }
-        }
-        __syncthreads();   // every wave is done with this step's planes
-    };
     for (int k0 = kbeg; k0 < kend; k0 += 2 * kGK) {
-        step(ta0, tb0, k0);
-        if (k0 + kGK < kend) step(ta1, tb1, k0 + kGK);
+        gemm_x3_step<A_KMAJOR, B_KMAJOR>(p, ta0, tb0, pa, pb, fa, fb, m0, n0, k0, kend, tid, acc);
+        if (k0 + kGK < kend) gemm_x3_step<A_KMAJOR, B_KMAJOR>(p, ta1, tb1, pa, pb, fa, fb, m0, n0, k0 + kGK, kend, tid, acc);
     }
 
     const bool add_bias = p.bias && blockIdx.z == 0;

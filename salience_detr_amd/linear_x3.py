@@ -59,9 +59,9 @@ def _weight_grad_splits(T: int, N: int, K: int) -> int:
 
 
 # Which of a Linear layer's three products take the x3 kernel (the others go to the library's fp32 GEMM).  Measured on
-# MI355X (benchmarks/gemm_x3_bench.py, profiles/r02_gemm_x3.json): the kernel is LDS-bandwidth bound (three planes per
-# operand: 144 KB through LDS per 128 x 128 x 32 step) at 85-110 TFLOP/s fp32-equivalent -- on a par with the
-# library for y = x w^T and dx = dy w (86-120), 1.3-1.9x faster for the weight gradient dw = dy^T x, whose few output
+# MI355X (benchmarks/gemm_x3_bench.py, profiles/r02_gemm_x3.json): 100-127 TFLOP/s fp32-equivalent at 22 726 tokens
+# (the split of the operand fragments costs as many vector-ALU cycles as the six MFMAs take) -- within +-15 % of the
+# library for y = x w^T and dx = dy w (87-124), 1.3-2x faster for the weight gradient dw = dy^T x, whose few output
 # tiles the library does not split over the token dimension.
 X3_FORWARD, X3_DX, X3_DW = False, False, True
 
