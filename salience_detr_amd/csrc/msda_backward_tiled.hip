@@ -42,7 +42,8 @@
 // 16-byte corner loads per lane: fp32 value is 128 bytes per corner), ~2600 of LDS atomics (64 per wave, ~5 clocks
 // each per CU), ~5000 of vector ALU (8 waves x ~650 instructions, of which ~250 are the per-sample set-up that all
 // eight lanes of a row repeat) and the flush, which runs with the rest of the CU idle (one workgroup per CU: the
-// window takes the LDS).  Tried without gain: sixteen waves at 128 VGPRs (spills), whole-pass phases instead of
+// window takes the LDS).  Tried without gain: two 256-thread workgroups per CU on half-size windows (24x8 tiles) so that one's flush runs
+// under the other's arithmetic (438 us: 1.5x the flush atomics, smaller passes), sixteen waves at 128 VGPRs (spills), whole-pass phases instead of
 // the per-sample pipeline (same time), an exact per-item bound from a pre-pass over the rows (an extra round trip
 // per item for 2-3 bits of scale).  Next: the set-up computed once per sample by one lane of the row and
 // broadcast, two half-size windows per CU so that one workgroup's flush hides under the other's arithmetic.
