@@ -46,7 +46,7 @@
 // under the other's arithmetic (438 us: 1.5x the flush atomics, smaller passes), sixteen waves at 128 VGPRs (spills), whole-pass phases instead of
 // the per-sample pipeline (same time), an exact per-item bound from a pre-pass over the rows (an extra round trip
 // per item for 2-3 bits of scale).  Next: the set-up computed once per sample by one lane of the row and
-// broadcast, two half-size windows per CU so that one workgroup's flush hides under the other's arithmetic.
+// broadcast; `ds_add_u64` on channel pairs (same lane rate, half the instructions).
 //
 // Everything that depends on the level shapes is decided on the device from the shape tensors (the reference
 // interface hands them over as device tensors; no host copy, no synchronisation): persistent workgroups draw
