@@ -13,7 +13,7 @@
 //             the value the reference substitutes for masked scores (score.min(), masked entries included).
 //   topk_rank (ceil(N/64) workgroups per row): workgroup w owns keys [64w, 64w+64) of its row.  All keys
 //             of the row (key = descending-orderable score bits, masked -> fill) are staged in LDS in
-//             12 K-key tiles; the four wavefronts stream them as broadcast ds_read_b128 and count, per owned
+//             12 K-key tiles; the eight wavefronts stream them as broadcast ds_read_b128 and count, per owned
 //             key, the keys that sort before it.  The list is in index order, so the tie rule is positional:
 //             "<=" for keys before the owned block, "<" after it, exact only inside it (two VALU ops per
 //             comparison, branch-free loops, 8 LDS reads in flight).  rank < k  =>  out[rank] = (score, index):
@@ -31,7 +31,8 @@
 
 namespace sdetr {
 
-constexpr int kRankThreads = 256;
+constexpr int kRankThreads = 512;   // 8 waves share a workgroup's list scan (4 until round 2: the per-lane loop was the kernel's time)
+constexpr int kRankWaves = kRankThreads / 64;
 constexpr int kRankTile = 12288;  // keys staged per LDS round (48 KiB)
 
 __device__ __forceinline__ uint32_t desc_bits(float s)
@@ -226,7 +227,7 @@ struct RankArgs {
 __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile[kRankTile];
-    __shared__ uint32_t partial[4][64];
+    __shared__ uint32_t partial[kRankWaves][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int base = blockIdx.x * 64;  // owned keys [base, base+64)
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
         if (t0 > 0) __syncthreads();
         // stage: all global loads of this thread first (<= 48 scalars), then the LDS stores; padding keys
         // (positions >= N) are 0xffffffff, which no "<" test counts and whose positions fail the tie rule
-        constexpr int kPer = kRankTile / kRankThreads;  // 48
+        constexpr int kPer = kRankTile / kRankThreads;  // 24
         for (int c0 = 0; c0 < kPer; c0 += 12) {
             uint32_t kv[12];
             if (cand) {
@@ -277,20 +278,20 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
             if ((c0 + 12) * kRankThreads >= tn) break;
         }
         __syncthreads();
-        // groups of 4 keys, round-robin over the 4 wavefronts; the list splits into three ranges relative to
+        // groups of 4 keys, round-robin over the wavefronts; the list splits into three ranges relative to
         // the owned block so every loop body is branch-free and the LDS reads pipeline (8 in flight)
         const int ngroups = (tn + 3) / 4;
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tile);
         const int g_own0 = min(ngroups, max(0, (base - t0) / 4));           // first group inside the owned block
         const int g_own1 = min(ngroups, max(0, (base + 64 - t0 + 3) / 4));  // first group after it
-        auto first_at_or_after = [&](int g0) { return g0 + ((wave - g0) % 4 + 4) % 4; };
+        auto first_at_or_after = [&](int g0) { return g0 + ((wave - g0) % kRankWaves + kRankWaves) % kRankWaves; };
         int g = wave;
 #pragma unroll 8
-        for (; g < g_own0; g += 4) {  // before: ties sort before us
+        for (; g < g_own0; g += kRankWaves) {  // before: ties sort before us
             const uint4 c = t4[g];
             rank += (c.x <= mine) + (c.y <= mine) + (c.z <= mine) + (c.w <= mine);
         }
-        for (g = first_at_or_after(g_own0); g < g_own1; g += 4) {  // inside: exact positional tie rule
+        for (g = first_at_or_after(g_own0); g < g_own1; g += kRankWaves) {  // inside: exact positional tie rule
             const uint4 c = t4[g];
             const int j = t0 + g * 4;
             rank += (c.x < mine || (c.x == mine && j + 0 < mypos)) ? 1u : 0u;
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
         }
         g = first_at_or_after(g_own1);
 #pragma unroll 8
-        for (; g < ngroups; g += 4) {  // after: ties sort after us (padding keys 0xffffffff are never "<")
+        for (; g < ngroups; g += kRankWaves) {  // after: ties sort after us (padding keys 0xffffffff are never "<")
             const uint4 c = t4[g];
             rank += (c.x < mine) + (c.y < mine) + (c.z < mine) + (c.w < mine);
         }
@@ -308,7 +309,9 @@ __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
     partial[wave][lane] = rank;
     __syncthreads();
     if (wave == 0 && mypos < n_keys) {
-        const uint32_t r = partial[0][lane] + partial[1][lane] + partial[2][lane] + partial[3][lane];
+        uint32_t r = 0;
+#pragma unroll
+        for (int w = 0; w < kRankWaves; ++w) r += partial[w][lane];
         if (r < (uint32_t)p.k) {
             const int pos = cand ? (int)p.cand_pos[(int64_t)b * p.N + mypos] : mypos;
             if (p.out_score) p.out_score[(int64_t)b * p.out_stride + r] = undesc_bits(mine);
