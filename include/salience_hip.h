@@ -382,6 +382,20 @@ int sdetr_salience_head_stage1_x3(sdetr_stream_t stream, const float *x, int64_t
                                   int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight,
                                   const float *norm_bias, float norm_eps, const void *weight_x3, const float *bias,
                                   float *memory_out, int64_t memory_batch_stride, float *z_local, float *partial_sums);
+/* sdetr_salience_head_stage1_x3 and the value projection of `vp_num_groups` stacked layers (the arguments of
+ * sdetr_value_proj_head_major; weight / bias / dst already point at the first of those layers) in ONE launch
+ * (csrc/fused_head_value.hip): the stage-1 launches of the two coarsest levels leave the chip nearly empty, the value
+ * projection depends only on the flattened tokens -- workgroups [0, blocks * batch) run stage 1, the rest the
+ * projection. */
+int sdetr_stage1_x3_with_value_proj(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
+    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
+    float *z_local, float *partial_sums, const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded,
+    const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
+    void *vp_dst, int vp_dst_dtype);
 int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums, int batch_size,
                                int tokens, const float *weight2, const float *bias2,
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,

@@ -1,0 +1,89 @@
+// One launch, two jobs: stage 1 of the salience head on a COARSE level and a slice of the value projection.
+//
+// The filtering stage walks the levels coarse to fine (each level's scores modulate the next finer one), so the
+// launches of the two coarsest levels run on a nearly empty chip: stage 1 has 10 workgroups on level 3 and 34 on
+// level 2 of the 800 x 1333 pyramid, each ~20 us of dependent phases.  The value projection of the six encoder
+// layers (token_linear_kernel<kHeadMajor>, 175 workgroups that keep a CU for ~60 us each) depends only on the
+// flattened tokens, not on the filtering.  Putting it on a second graph branch costs more than it hides on this
+// stack (a fork / join pair ~80 us under hipGraph replay), and one queue cannot express the partial
+// order.  So the two kernel BODIES share a launch: workgroups [0, n1) run stage 1 (their first 512 threads; the
+// other four waves exit, which the hardware barrier accounts for), workgroups [n1, n1 + n2) run the value
+// projection of half the layers.  Level 3 carries layers 0-2, level 2 layers 3-5: the 42 us of the two stage-1
+// launches disappear under the projection (which no longer has a launch of its own).
+#include "salience_head_core.h"
+#include "token_linear_core.h"
+
+namespace sdetr {
+
+__global__ void __launch_bounds__(768, 1) fused_stage1_value_kernel(Stage1Args s1, int s1_blocks, int s1_images, TLArgs tl)
+{
+    const int blk = (int)blockIdx.x;
+    const int n1 = s1_blocks * s1_images;   // stage-1 workgroups: (image, token block) folded into blockIdx.x
+    if (blk < n1) {
+        if (threadIdx.x >= 512) return;
+        stage1_x3_body(s1, blk % s1_blocks, blk / s1_blocks);
+    } else {
+        token_linear_body<kHeadMajor, false, 8>(tl, blk - n1);
+    }
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+// sdetr_salience_head_stage1_x3 (same arguments, same checks by the caller's usual entry) + the value projection of
+// `num_groups` stacked layers of sdetr_value_proj_head_major (same arguments; `packed_weight`, `bias_padded` and
+// `dst` already point at the first of those layers) in one launch.
+extern "C" int sdetr_stage1_x3_with_value_proj(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
+    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
+    float *z_local, float *partial_sums,
+    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+{
+    if (channels != kC) return fail("stage1_x3_with_value_proj: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
+    if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_value_proj: empty level");
+    if (!x || !norm_weight || !norm_bias || !weight_x3 || !bias || !z_local || !partial_sums)
+        return fail("stage1_x3_with_value_proj: NULL pointer");
+    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
+        return fail("stage1_x3_with_value_proj: enc_output parameters incomplete");
+    if (row_scale && coarse_score) return fail("stage1_x3_with_value_proj: give row_scale OR coarse_score");
+    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
+        return fail("stage1_x3_with_value_proj: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
+    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("stage1_x3_with_value_proj: rows must be 16-byte aligned");
+    if (vp_batch_size <= 0 || vp_spatial_size <= 0 || vp_num_heads <= 0 || vp_num_groups <= 0)
+        return fail("stage1_x3_with_value_proj: bad value-projection sizes");
+    if (vp_dst_dtype != SDETR_F16 && vp_dst_dtype != SDETR_BF16) return fail("stage1_x3_with_value_proj: dst must be fp16 or bf16");
+    if (!vp_x || !vp_packed_weight || !vp_bias_padded || !vp_dst) return fail("stage1_x3_with_value_proj: NULL pointer");
+    const int64_t vp_tokens = (int64_t)vp_batch_size * vp_spatial_size;
+    if (vp_tokens > 0x7fffffff) return fail("stage1_x3_with_value_proj: too many tokens");
+    Stage1Args a;
+    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
+    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
+    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
+    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
+    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
+    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = bias;
+    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
+    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = (tokens + 31) / 32;
+    TLArgs t{};
+    t.x = (const bf16_t *)vp_x; t.pw = (const char *)vp_packed_weight; t.bias = vp_bias_padded; t.T = (int)vp_tokens;
+    t.N = vp_num_groups * vp_num_heads * 32; t.ntiles = t.N / 32; t.rows_per_batch = vp_spatial_size;
+    t.pad = vp_pad_mask; t.hm = vp_dst; t.heads = vp_num_heads; t.batch = vp_batch_size; t.hm_f16 = vp_dst_dtype == SDETR_F16;
+    const int nsteps = (t.ntiles + kTLStepTiles - 1) / kTLStepTiles;
+    if ((size_t)t.ntiles * 128 + 2 * kTLStepBytes + 1024 > 160 * 1024) return fail("stage1_x3_with_value_proj: too many output features");
+    const size_t lds_tl = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
+    const size_t lds_s1 = (size_t)kX3Region + (kParRows * kC + 32 + 4) * sizeof(float);
+    const size_t lds = lds_tl > lds_s1 ? lds_tl : lds_s1;
+    static DeviceOnce once;
+    allow_dynamic_lds(fused_stage1_value_kernel, once, 160 * 1024);
+    const int n1 = a.nblk * batch_size;
+    const int tpb = kTLTokWave * 8;
+    const int n2 = (int)((vp_tokens + tpb - 1) / tpb);
+    hipLaunchKernelGGL(fused_stage1_value_kernel, dim3((unsigned)(n1 + n2)), dim3(768), lds, static_cast<hipStream_t>(stream),
+                       a, a.nblk, batch_size, t);
+    return check_launch("stage1_x3_with_value_proj");
+}

@@ -24,165 +24,16 @@
 
 #include "common.h"
 
+#include "salience_head_core.h"
+
 namespace sdetr {
 
-constexpr int kC = 256;        // embed dim == hidden dim of the head
-constexpr int kHalf = 128;
-constexpr int kTM = 64;        // tokens per block
-constexpr int kXS = kC + 4;    // LDS row stride of the token tile (floats)
-constexpr int kZS = kHalf + 4;
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-
-__device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 c)
+__global__ void __launch_bounds__(512, 2) salience_head_stage1_x3_kernel(Stage1Args p)
 {
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
-    return c;
+    stage1_x3_body(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
-// ---- the weight operand -----------------------------------------------------------------------------------
-// It comes straight from L2 (every block streams the same 256 KB), so its loads run PD steps (PD * CT KB per wave)
-// ahead of the MFMAs that consume them: one step of 4*RT*CT MFMAs is only ~0.1-0.4 us, an L2 hit ~0.5 us and the
-// first touch after other kernels flushed the L2 ~2 us.  Buffer loads (uniform base and step offset in SGPRs, one
-// lane offset) keep the 16-byte loads whole and cost no address VALU.  The first PD steps are requested by
-// start() -- callers do that BEFORE the barrier / LayerNorm phase in front of the GEMM, so the pipeline is already
-// full when the MFMAs begin.
-template <int CT, int PD>
-struct WeightStream {
-    __amdgpu_buffer_rsrc_t rs;
-    uint32_t lane_off, step;
-    u32x4_t bq[PD][CT];
 
-    __device__ __forceinline__ void start(const float4 *wp, int N, int ksteps, int n0, int lane)
-    {
-        step = (uint32_t)N * 32;   // bytes per k-step of the packed weight
-        rs = make_uniform_rsrc(reinterpret_cast<const char *>(wp), step * (uint32_t)ksteps);
-        lane_off = (uint32_t)((n0 + (lane & 31)) * 2 + (lane >> 5)) * 16;
-#pragma unroll
-        for (int u = 0; u < PD; ++u)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                bq[u][ct] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + ct * 1024), (int)(u * step), 0);
-    }
-};
-
-// acc[rt][ct] += tile[32rt + i][k] * W[n0 + 32ct + j][k]   (tile in LDS with row stride XS; W through `ws`)
-template <int KDIM, int XS, int RT, int CT, int PD>
-__device__ __forceinline__ void block_gemm(const float *tile, WeightStream<CT, PD> &ws, int lane, f32x16 (&acc)[RT][CT])
-{
-    constexpr int NS = KDIM / 8;
-    static_assert(NS % PD == 0, "prefetch depth must divide the step count");
-    const float *ap = tile + (lane & 31) * XS + 4 * (lane >> 5);
-    // fully unrolled: a rolled loop carries the in-flight registers across the back edge through copies, and
-    // every copy waits for its load (the pipeline would drain once per PD steps)
-#pragma unroll
-    for (int S0 = 0; S0 < NS; S0 += PD) {
-#pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int S = S0 + u;
-            u32x4_t b[CT];
-            float4 a[RT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) b[ct] = ws.bq[u][ct];
-            if (S + PD < NS) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    ws.bq[u][ct] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + ct * 1024),
-                                                                         (int)((S + PD) * ws.step), 0);
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const float4 *>(ap + rt * 32 * XS + 8 * S);
-            // pin this step's prefetch in front of its MFMAs (the scheduler otherwise sinks the loads next to
-            // their uses, which serialises every step on L2 latency)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float4 bf = make_float4(__uint_as_float(b[ct].x), __uint_as_float(b[ct].y),
-                                                  __uint_as_float(b[ct].z), __uint_as_float(b[ct].w));
-                    acc[rt][ct] = mfma4(a[rt], bf, acc[rt][ct]);
-                }
-        }
-    }
-}
-
-template <int RT, int CT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT][CT])
-{
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
-}
-
-// row of accumulator register `reg` inside a 32x32 tile
-__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-
-struct Stage1Args {
-    const float *x;            // [B, n, 256] with strides
-    int64_t x_batch_stride, x_row_stride;
-    const float4 *w_enc;       // packed enc_output weight or NULL (x is already enc_output_norm's output)
-    const float *b_enc, *g_enc, *beta_enc;
-    float eps_enc;
-    const float *row_scale;    // [B, n] or NULL
-    const float *coarse;       // [B, ch, cw] coarser score map or NULL
-    int ch, cw, h, w;
-    const float *alpha;        // device scalar (NULL = 1)
-    const float *g1, *beta1;
-    float eps1;
-    const float4 *w1;          // packed layer1 Linear weight
-    const float *b1;
-    float *memory_out;         // enc_output_norm output [B, n, 256] (batch stride given) or NULL
-    int64_t mem_batch_stride;
-    float *z_local;            // [B, n, 128]
-    float *partial;            // [B, nblk, 128]
-    int n, nblk;
-};
-
-// two-pass LayerNorm statistics of a row held as NV float4 per thread by the TPR threads of the row
-template <int NV, int TPR>
-__device__ __forceinline__ void row_stats(const float4 (&v)[NV], float eps, float &mean, float &rstd)
-{
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, TPR);
-    mean = s * (1.f / kC);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-        q += (a * a + b * b) + (c * c + d * d);
-    }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o, TPR);
-    rstd = rsqrtf(q * (1.f / kC) + eps);
-}
-
-__device__ __forceinline__ float4 ln_apply(float4 v, float mean, float rstd, float4 g, float4 be)
-{
-    return make_float4((v.x - mean) * rstd * g.x + be.x, (v.y - mean) * rstd * g.y + be.y,
-                       (v.z - mean) * rstd * g.z + be.z, (v.w - mean) * rstd * g.w + be.w);
-}
-
-// LDS parameter rows
-enum { kParBEnc = 0, kParGEnc, kParBetaEnc, kParG1, kParBeta1, kParB1, kParRows };
-
-// RT = row tiles of 32 tokens per block: 2 halves the weight traffic per token, 1 doubles the blocks (more CUs
-// busy on the small levels, finer load balance on the big one; four blocks fit a CU).
-// Blocks that share a CU start together and stay in lock step (same work), so nothing hides the phases between
-// the two GEMMs except what the block overlaps itself: every global read of those phases (LayerNorm parameters,
-// biases, the coarse score for the resize, alpha) is issued up front into LDS together with the token tile, and
-// each GEMM's first weight steps are requested before the barrier / LayerNorm phase in front of it.
 // WAVES = 8 (512 threads, one column tile per wave) halves a block's latency -- two chained 256 x 256 fp32 GEMMs of
 // 64-cycle MFMAs, ~7 us each with four waves -- for the coarse levels, whose few blocks leave the chip idle anyway.
 template <int RT, int WAVES = 4>
@@ -341,258 +192,6 @@ __global__ void __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : (RT == 2 ? 2 : 4)
                     const int r = 32 * rt + acc_row(i, lane);
                     s += r < nvalid ? gelu_erf(acc[rt][ct][i] + bias) : 0.f;
                 }
-            s += __shfl_xor(s, 32);
-            if (lane < 32) p.partial[((int64_t)b * p.nblk + blk) * kHalf + (c - kHalf)] = s;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Stage 1 on the bf16 matrix cores at fp32 accuracy ("bf16 x 3").  The fp32-input MFMA of the kernel above runs at
-// 157 TFLOP/s and the two 256 x 256 GEMMs keep it busy for half of the kernel's time (profiles/r02_mfma_busy.md);
-// v_mfma_f32_32x32x16_bf16 is 16 times faster per multiply-add.  Every fp32 operand is split exactly into three
-// bf16 terms, x = x0 + x1 + x2 (24 mantissa bits = 3 x 8), and the product a.b is taken as the six bf16 MFMAs
-// a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0: each bf16 x bf16 product is exact in fp32, accumulation is fp32 as before,
-// and the dropped terms (a1b2, a2b1, a2b2) are below 2^-24 of the product -- the rounding the fp32 MFMA makes on the
-// product itself.  6/16 of the matrix time for the same scores (tests/test_filter_gpu.py compares both kernels with
-// the oracle; the selection is identical).  Weights are split once at pack time (sdetr_pack_linear_bf16x3: three
-// planes in operand order, [k-step of 16][32-column tile][plane][lane][8]); the token tile is split once per GEMM
-// into three LDS planes (the split costs 8 VALU operations per element: done per wave on its operand fragments it
-// would cost more than the MFMAs it feeds).
-typedef __bf16 sh_bf16x8_t __attribute__((ext_vector_type(8)));
-// k-steps of weight (3 KB per wave and step) in flight: a step's six MFMAs take ~0.09 us, an L2 hit ~0.5-0.8 us
-constexpr int kX3Depth = 5;
-constexpr int kPlaneRow = kC * 2 + 16;                 // bytes per token row of a plane (16 bytes of padding)
-constexpr int kPlaneBytes = 32 * kPlaneRow;            // 32-token tile
-constexpr int kX3Region = 3 * kPlaneBytes;             // 50 688 bytes: three planes, or the fp32 tile (33 280)
-static_assert(kX3Region >= 32 * kXS * 4, "the fp32 tile aliases the planes");
-
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sh_bf16x8_t, a), __builtin_bit_cast(sh_bf16x8_t, b), c, 0, 0, 0);
-}
-
-// exact three-way split of four consecutive elements -> 4 bf16 of each plane
-__device__ __forceinline__ void split3(const float4 v, uint2 &p0, uint2 &p1, uint2 &p2)
-{
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    uint32_t h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = f32_to_bf16_bits(x[i]);
-        const float r1 = x[i] - __uint_as_float(h[i] << 16);
-        m[i] = f32_to_bf16_bits(r1);
-        const float r2 = r1 - __uint_as_float(m[i] << 16);
-        l[i] = f32_to_bf16_bits(r2);
-    }
-    p0 = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    p1 = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    p2 = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-}
-__device__ __forceinline__ void store_split(char *planes, int row, int col, const float4 v)
-{
-    uint2 p0, p1, p2;
-    split3(v, p0, p1, p2);
-    char *d = planes + row * kPlaneRow + col * 2;
-    *reinterpret_cast<uint2 *>(d) = p0;
-    *reinterpret_cast<uint2 *>(d + kPlaneBytes) = p1;
-    *reinterpret_cast<uint2 *>(d + 2 * kPlaneBytes) = p2;
-}
-
-// the split weight of one wave's 32-column tile, PD k-steps (3 KB each) ahead of the MFMAs
-template <int PD>
-struct WeightStreamX3 {
-    __amdgpu_buffer_rsrc_t rs;
-    uint32_t lane_off;
-    u32x4_t bq[PD][3];
-    static constexpr uint32_t kStep = 8 * 3 * 1024;   // bytes per k-step: 8 column tiles x 3 planes x 1 KB
-
-    __device__ __forceinline__ void start(const void *wp, int ctile, int lane)
-    {
-        rs = make_uniform_rsrc(reinterpret_cast<const char *>(wp), kStep * (kC / 16));
-        lane_off = (uint32_t)(ctile * 3 * 1024 + lane * 16);
-#pragma unroll
-        for (int u = 0; u < PD; ++u)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + pl * 1024), (int)(u * kStep), 0);
-    }
-};
-
-// acc += tile[32][256] (three planes in LDS) * W[my 32 columns][256]^T
-template <int PD>
-__device__ __forceinline__ void block_gemm_x3(const char *planes, WeightStreamX3<PD> &ws, int lane, f32x16 &acc)
-{
-    constexpr int NS = kC / 16;
-    const char *ap = planes + (lane & 31) * kPlaneRow + (lane >> 5) * 16;
-    // fully unrolled, the PD in-flight steps live in a ring indexed at compile time (see block_gemm)
-#pragma unroll
-    for (int S = 0; S < NS; ++S) {
-        const int u = S % PD;
-        u32x4_t b[3], a[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[pl] = ws.bq[u][pl];
-        if (S + PD < NS) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                ws.bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + pl * 1024),
-                                                                     (int)((S + PD) * ws.kStep), 0);
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const u32x4_t *>(ap + pl * kPlaneBytes + S * 32);
-        __builtin_amdgcn_sched_barrier(0);   // this step's prefetch stays in front of its MFMAs (see block_gemm)
-        acc = mfma_bf16(a[2], b[0], acc);    // smallest terms first
-        acc = mfma_bf16(a[0], b[2], acc);
-        acc = mfma_bf16(a[1], b[1], acc);
-        acc = mfma_bf16(a[1], b[0], acc);
-        acc = mfma_bf16(a[0], b[1], acc);
-        acc = mfma_bf16(a[0], b[0], acc);
-    }
-}
-
-__global__ void __launch_bounds__(512, 2) salience_head_stage1_x3_kernel(Stage1Args p)
-{
-    constexpr int TM = 32, THREADS = 512;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char *planes = reinterpret_cast<char *>(smem);               // three bf16 planes of the GEMM operand ...
-    float *tile = smem;                                           // ... or the fp32 tile [TM][kXS] between the GEMMs
-    float *par = smem + kX3Region / 4;                            // [kParRows][kC]
-    float *srow = par + kParRows * kC;                            // [TM] modulation factor, [TM] = alpha
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, blk = blockIdx.x;
-    const int t0 = blk * TM;
-    const int nvalid = min(TM, p.n - t0);
-    const int n0 = wave * 32;
-    const bool with_enc = p.w_enc != nullptr;
-
-    WeightStreamX3<kX3Depth> ws;
-    ws.start(with_enc ? (const void *)p.w_enc : (const void *)p.w1, wave, lane);
-
-    // ---- token tile (split into planes when a GEMM consumes it directly), parameters and row factors -> LDS ----
-    {
-        const float *xb = p.x + (int64_t)b * p.x_batch_stride + (int64_t)t0 * p.x_row_stride;
-        constexpr int NL = TM * 64 / THREADS;   // float4 per thread
-        float4 v[NL];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = tid + i * THREADS;
-            const int r = idx >> 6, c4 = idx & 63;
-            v[i] = *reinterpret_cast<const float4 *>(xb + (int64_t)min(r, nvalid - 1) * p.x_row_stride + c4 * 4);
-        }
-        if (tid < 256) {
-            const int row = tid >> 6, c4 = tid & 63;
-            const float *src0 = row == 0 ? p.b_enc : row == 1 ? p.g_enc : row == 2 ? p.beta_enc : p.g1;
-            const float *src1 = row == 0 ? p.beta1 : p.b1;
-            if (with_enc || row == 3) *reinterpret_cast<float4 *>(par + row * kC + c4 * 4) =
-                                          *reinterpret_cast<const float4 *>(src0 + c4 * 4);
-            if (row < 2) *reinterpret_cast<float4 *>(par + (4 + row) * kC + c4 * 4) =
-                             *reinterpret_cast<const float4 *>(src1 + c4 * 4);
-        }
-        if (tid < TM) {
-            float s = 0.f;
-            const int t = min(t0 + tid, p.n - 1);
-            if (p.row_scale) {
-                s = p.row_scale[(int64_t)b * p.n + t];
-            } else if (p.coarse) {
-                // bilinear, align_corners=True (F.interpolate, salience_transformer.py:139-142)
-                const int y = t / p.w, x = t - y * p.w;
-                const float sh = p.h > 1 ? (float)(p.ch - 1) / (float)(p.h - 1) : 0.f;
-                const float sw = p.w > 1 ? (float)(p.cw - 1) / (float)(p.w - 1) : 0.f;
-                const float fy = sh * (float)y, fx = sw * (float)x;
-                const int y1 = (int)fy, x1 = (int)fx;
-                const int yp = y1 < p.ch - 1 ? 1 : 0, xp = x1 < p.cw - 1 ? 1 : 0;
-                const float ly = fy - (float)y1, lx = fx - (float)x1;
-                const float hy = 1.f - ly, hx = 1.f - lx;
-                const float *cm = p.coarse + (int64_t)b * p.ch * p.cw;
-                s = hy * (hx * cm[y1 * p.cw + x1] + lx * cm[y1 * p.cw + x1 + xp]) +
-                    ly * (hx * cm[(y1 + yp) * p.cw + x1] + lx * cm[(y1 + yp) * p.cw + x1 + xp]);
-            }
-            srow[tid] = s;
-            if (tid == 0) srow[TM] = (p.row_scale || p.coarse) ? (p.alpha ? *p.alpha : 1.f) : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int idx = tid + i * THREADS;
-            const int r = idx >> 6, c4 = idx & 63;
-            const float4 val = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (with_enc) store_split(planes, r, c4 * 4, val);
-            else *reinterpret_cast<float4 *>(tile + r * kXS + c4 * 4) = val;
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc;
-    if (with_enc) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
-        ws.start(p.w1, wave, lane);   // layer1's first steps travel during the LayerNorm phase
-        __syncthreads();   // every wave is done reading the planes: the fp32 tile takes their place
-        const int c = n0 + (lane & 31);
-        const float bias = par[kParBEnc * kC + c];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tile[acc_row(i, lane) * kXS + c] = acc[i] + bias;
-        __syncthreads();
-    }
-
-    // ---- enc_output_norm -> modulation -> layer1 LayerNorm; 16 threads per row, each 4 float4; result -> planes ----
-    {
-        constexpr int TPR = THREADS / TM, NV = kC / 4 / TPR, CS = 4 * TPR;
-        const int r = tid / TPR, q = tid % TPR;
-        const float *row = tile + r * kXS + 4 * q;
-        float4 v[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4 *>(row + CS * i);
-        float mean, rstd;
-        if (with_enc) {
-            row_stats<NV, TPR>(v, p.eps_enc, mean, rstd);
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                v[i] = ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParGEnc * kC + CS * i + 4 * q),
-                                *reinterpret_cast<const float4 *>(par + kParBetaEnc * kC + CS * i + 4 * q));
-            if (p.memory_out && r < nvalid) {
-                float *mo = p.memory_out + (int64_t)b * p.mem_batch_stride + (int64_t)(t0 + r) * kC + 4 * q;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) *reinterpret_cast<float4 *>(mo + CS * i) = v[i];
-            }
-        }
-        const float s = srow[r], a = srow[TM];
-        if (a != 0.f) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                v[i] = make_float4(v[i].x + v[i].x * s * a, v[i].y + v[i].y * s * a, v[i].z + v[i].z * s * a,
-                                   v[i].w + v[i].w * s * a);
-        }
-        row_stats<NV, TPR>(v, p.eps1, mean, rstd);
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            v[i] = ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParG1 * kC + CS * i + 4 * q),
-                            *reinterpret_cast<const float4 *>(par + kParBeta1 * kC + CS * i + 4 * q));
-        __syncthreads();   // every thread holds its part of the tile in registers: the planes may overwrite it
-#pragma unroll
-        for (int i = 0; i < NV; ++i) store_split(planes, r, CS * i + 4 * q, v[i]);
-    }
-    __syncthreads();
-
-    // ---- layer1 Linear + GELU ----
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
-    {
-        const int c = n0 + (lane & 31);
-        const float bias = par[kParB1 * kC + c];
-        if (n0 < kHalf) {
-            float *zl = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = acc_row(i, lane);
-                if (r < nvalid) zl[(int64_t)r * kHalf + c] = gelu_erf(acc[i] + bias);
-            }
-        } else {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += acc_row(i, lane) < nvalid ? gelu_erf(acc[i] + bias) : 0.f;
             s += __shfl_xor(s, 32);
             if (lane < 32) p.partial[((int64_t)b * p.nblk + blk) * kHalf + (c - kHalf)] = s;
         }

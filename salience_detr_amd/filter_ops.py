@@ -289,10 +289,61 @@ def packed_linear_weight(weight: Tensor, cols=None, split3: bool = False) -> Ten
     return out
 
 
+class ValueProjectionJob:
+    """A slice (``groups`` consecutive layers) of a batched value projection (``value_proj_head_major``) that has not
+    been launched yet: ``salience_head(..., value_job=job)`` carries it in its stage-1 launch (the coarse levels leave
+    the chip nearly empty), ``job.run()`` launches it on its own.  Either way ``job.done`` is set."""
+
+    def __init__(self, value, packed, bias, pad, heads, groups, dst, first_group):
+        self.value, self.packed, self.bias, self.pad = value, packed, bias, pad
+        self.heads, self.groups, self.dst, self.first_group = heads, groups, dst, first_group
+        self.done = False
+
+    def pointers(self):
+        """(x, packed weight, padded bias, pad mask, B, Nv, heads, groups, dst, dtype code) of the slice."""
+        B, Nv, _ = self.value.shape
+        tiles = self.first_group * self.heads        # 32-feature tiles in front of the slice (32 channels per head)
+        d = self.dst[self.first_group]
+        return (self.value.data_ptr(), self.packed.data_ptr() + tiles * 16384, self.bias.data_ptr() + tiles * 32 * 4,
+                _hip.ptr(self.pad), B, Nv, self.heads, self.groups, d.data_ptr(), _hip.dtype_code(self.dst.dtype))
+
+    def run(self):
+        if self.done:
+            return
+        x, pw, b, pad, B, Nv, heads, groups, dst, code_ = self.pointers()
+        with torch.cuda.device(self.value.device):
+            code = _hip.lib().sdetr_value_proj_head_major(_hip.stream_ptr(), x, pw, b, pad, B, Nv, 256, heads, 32, groups,
+                                                          dst, code_)
+        _hip.check(code, "value_proj_head_major")
+        self.done = True
+
+
+def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],
+                          num_heads: int, num_groups: int, dtype: torch.dtype, parts: int = 2):
+    """``value_proj_head_major`` split into ``parts`` jobs over consecutive layer groups that share one destination
+    ``[groups,B,heads,Nv,32]``: returns ``(dst, [ValueProjectionJob, ...])``."""
+    if not token_linear_applies(value, weight) or weight.shape[0] != num_groups * num_heads * 32:
+        raise RuntimeError("plan_value_projection: bf16 [B,Nv,256] tokens and 32-channel heads expected")
+    _hip.require_device("plan_value_projection", value=value, padding_mask=padding_mask)
+    B, Nv, _ = value.shape
+    packed, b = _packed_linear_bf16(weight, bias)
+    pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
+                                             else padding_mask)
+    dst = torch.empty((num_groups, B, num_heads, Nv, 32), dtype=dtype, device=value.device)
+    parts = max(1, min(int(parts), num_groups))
+    jobs, g0 = [], 0
+    for i in range(parts):
+        g1 = (num_groups * (i + 1)) // parts
+        if g1 > g0:
+            jobs.append(ValueProjectionJob(value, packed, b, pad, num_heads, g1 - g0, dst, g0))
+        g0 = g1
+    return dst, jobs
+
+
 def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coarse_score: Optional[Tensor] = None,
                   level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
                   memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
-                  score_min: Optional[Tensor] = None) -> Tensor:
+                  score_min: Optional[Tensor] = None, value_job: Optional[ValueProjectionJob] = None) -> Tensor:
     """The salience head on one level in three launches (include/salience_hip.h (6)).
 
     ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
@@ -301,7 +352,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     coarse-to-fine modulation takes either ``row_scale`` [B,n] or the coarser level's ``coarse_score``
     [B,1,h',w'] (resized in-kernel to ``level_hw``), times the device scalar ``alpha``.  ``score_flat``
     (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy; ``score_min`` (one-element
-    fp32 tensor) the minimum over all ``B*n`` scores.  Returns ``[B,n]``."""
+    fp32 tensor) the minimum over all ``B*n`` scores.  ``value_job``: a pending slice of the encoder's value projection
+    that stage 1's launch carries along (bf16x3 kernel only; otherwise it is left pending).  Returns ``[B,n]``."""
     if not x.is_cuda:
         raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
     if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
@@ -344,13 +396,18 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
         sfs = score_flat.stride(0)
     with torch.cuda.device(x.device):
         s = _hip.stream_ptr()
-        stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
-        code = stage1(
+        stage1_args = (
             s, x.data_ptr(), x.stride(0), x.stride(1), B, n, C, _hip.ptr(w_enc), _hip.ptr(b_enc), _hip.ptr(g_enc),
             _hip.ptr(be_enc), eps_enc, _hip.ptr(row_scale), _hip.ptr(coarse_score), ch, cw, lh, lw, _hip.ptr(alpha),
             l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps),
             packed_linear_weight(l1.weight, split3=x3).data_ptr(),
             l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
+        if x3 and value_job is not None and not value_job.done and value_job.value.device == x.device:
+            code = lib.sdetr_stage1_x3_with_value_proj(*stage1_args, *value_job.pointers())
+            value_job.done = True
+        else:
+            stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
+            code = stage1(*stage1_args)
         _hip.check(code, "salience_head_stage1")
         code = lib.sdetr_salience_head_stage2(
             s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),

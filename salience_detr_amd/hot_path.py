@@ -61,6 +61,9 @@ class SalienceEncoderHotPath(nn.Module):
         # measured on MI355X (batch 2, hipGraph replay): the overlap hides ~60 of the projection's 81 us behind the
         # coarse levels' launches but slows those and costs two graph joins -- 1.81 ms vs 1.77 ms per step; off
         self.overlap_value_projection = False
+        # the value projection rides in the stage-1 launches of the two coarsest levels (csrc/fused_head_value.hip):
+        # same kernels, two launches' worth of an idle chip put to use
+        self.fuse_value_projection = True
         self._streams = {}
         self.init_weights()
 
@@ -142,6 +145,11 @@ class SalienceEncoderHotPath(nn.Module):
             with torch.cuda.stream(side):
                 value_maps = self.encoder.project_values(feat_enc, mask_flatten)
             value_maps.record_stream(main)
+        value_jobs = None
+        if native and feat_enc is not None and value_maps is None and self.fuse_value_projection:
+            plan = self.encoder.plan_values(feat_enc, mask_flatten)
+            if plan is not None:
+                value_maps, value_jobs = plan
         level_shapes = pyramid.level_shapes_of(multi_level_masks)
         if valid_ratios_k is not None:
             spatial_shapes, level_start_index = pyramid.shape_tensors(level_shapes, mask_flatten.device)
@@ -189,7 +197,7 @@ class SalienceEncoderHotPath(nn.Module):
             salience_score, level_inds, level_score = level_filtering(
                 enc_in, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor, self.alpha,
                 enc_output=self.enc_output, enc_output_norm=self.enc_output_norm, memory_out=backbone_output_memory,
-                score_flat=score_flat, extras=extras)
+                score_flat=score_flat, extras=extras, value_jobs=value_jobs)
         else:
             salience_score, level_inds, level_score = level_filtering(
                 backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
@@ -200,6 +208,8 @@ class SalienceEncoderHotPath(nn.Module):
             feat_enc, pos_enc = feat_flatten.to(edt), lvl_pos_embed_flatten.to(edt)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        for job in value_jobs or ():   # whatever no stage-1 launch carried
+            job.run()
         memory = self.encoder(
             precomputed_value_maps=value_maps, query=feat_enc, query_pos=pos_enc, query_key_padding_mask=mask_flatten,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index, valid_ratios=valid_ratios,

@@ -388,13 +388,9 @@ def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_star
     return out
 
 
-def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
-    """Head-major value maps ``[len(attn_modules), B, M, Nv, D]`` of several ``MultiScaleDeformableAttention``
-    modules that sample the SAME ``value`` (the six encoder layers, salience_transformer.py:452; the decoder layers'
-    cross-attentions, :575-582): their ``value_proj`` run as one projection.  No-grad path only."""
-    from .filter_ops import token_linear_applies, value_proj_head_major
+def _stacked_value_proj(attn_modules):
+    """Concatenated ``value_proj`` weights / biases of the modules, cached on the first one."""
     first = attn_modules[0]
-    heads, E = first.num_heads, first.embed_dim
     owner = first.__dict__
     ps = [p for m in attn_modules for p in (m.value_proj.weight, m.value_proj.bias)]
     key = tuple((p.data_ptr(), p._version, p.dtype) for p in ps)
@@ -404,7 +400,32 @@ def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tenso
         b = torch.cat([m.value_proj.bias.detach() for m in attn_modules], 0).contiguous()
         hit = (key, w, b)
         owner["_batched_value_proj"] = hit
-    w_all, b_all = hit[1], hit[2]
+    return hit[1], hit[2]
+
+
+def plan_batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor], parts: int = 2):
+    """``batched_value_maps`` as pending jobs: ``(maps [n,B,M,Nv,D], [ValueProjectionJob, ...])`` -- slices of the one
+    projection that other launches can carry (``filter_ops.salience_head(value_job=...)``) -- or ``None`` when the
+    one-launch kernel does not cover the configuration (call ``batched_value_maps`` then)."""
+    from .filter_ops import plan_value_projection, token_linear_applies
+    first = attn_modules[0]
+    heads, E = first.num_heads, first.embed_dim
+    w_all, b_all = _stacked_value_proj(attn_modules)
+    vdt = first.value_dtype or value.dtype
+    if not (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
+            and value.is_contiguous() and value.dim() == 3):
+        return None
+    return plan_value_projection(value, w_all, b_all, padding_mask, heads, len(attn_modules), vdt, parts=parts)
+
+
+def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+    """Head-major value maps ``[len(attn_modules), B, M, Nv, D]`` of several ``MultiScaleDeformableAttention``
+    modules that sample the SAME ``value`` (the six encoder layers, salience_transformer.py:452; the decoder layers'
+    cross-attentions, :575-582): their ``value_proj`` run as one projection.  No-grad path only."""
+    from .filter_ops import token_linear_applies, value_proj_head_major
+    first = attn_modules[0]
+    heads, E = first.num_heads, first.embed_dim
+    w_all, b_all = _stacked_value_proj(attn_modules)
     vdt = first.value_dtype or value.dtype
     n = len(attn_modules)
     if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)

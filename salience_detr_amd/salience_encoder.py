@@ -30,7 +30,7 @@ from .filter_ops import (advance_rows, attention_heads, attention_heads_applies,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
                          topk_attention_heads, topk_self_attention_, topk_self_attention_applies, value_proj_head_major)
-from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
+from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps, plan_batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 
 
@@ -319,6 +319,12 @@ class SalienceTransformerEncoder(nn.Module):
         projection; it only depends on the flattened features, which lets a caller overlap it with the filtering
         stage on a second stream (``SalienceEncoderHotPath`` does)."""
         return batched_value_maps([l.self_attn for l in self.layers], value, padding_mask)
+
+    def plan_values(self, value: Tensor, padding_mask: Optional[Tensor], parts: int = 2):
+        """``project_values`` as pending jobs ``(maps, [ValueProjectionJob, ...])`` (``None`` when the one-launch
+        projection does not apply): the caller lets other launches carry the jobs (the salience head's stage 1 on the
+        coarse levels), runs the rest, and hands ``maps`` to ``forward`` as ``precomputed_value_maps``."""
+        return plan_batched_value_maps([l.self_attn for l in self.layers], value, padding_mask, parts=parts)
 
     def forward(self, query, spatial_shapes, level_start_index, valid_ratios, query_pos=None,
                 query_key_padding_mask=None, foreground_score=None, focus_token_nums=None, foreground_inds=None,

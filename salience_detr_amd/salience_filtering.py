@@ -88,7 +88,7 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                     level_start_index: Sequence[int], level_token_nums: Sequence[int], mask_predictor: nn.Module,
                     alpha: Tensor, enc_output: Optional[nn.Module] = None, enc_output_norm: Optional[nn.Module] = None,
                     memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
-                    extras: Optional[dict] = None):
+                    extras: Optional[dict] = None, value_jobs: Optional[list] = None):
     """Coarse-to-fine salience scores + per-level top-k (salience_transformer.py:123-154).
 
     ``level_shapes`` / ``level_start_index`` / ``level_token_nums`` are python ints (shapes come from the
@@ -102,6 +102,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     and ``score_flat`` [B,S] the flattened scores.  ``extras`` (a dict) receives by-products that
     ``salience_filtering`` can reuse: ``level_min`` [L] (``score.min()`` per level) and ``selected`` (the
     concatenated ``(scores, indices)`` [B, sum k] the per-level top-k calls already wrote side by side).
+    ``value_jobs``: pending ``filter_ops.ValueProjectionJob`` slices of the encoder's value projection; the stage-1
+    launches of the coarsest levels (few workgroups on an otherwise empty chip) carry one each, coarsest first.
     """
     B = backbone_output_memory.shape[0]
     L = len(level_shapes)
@@ -138,7 +140,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 enc_output_norm=enc_output_norm,
                 memory_out=None if memory_out is None else memory_out[:, start:start + h * w, :],
                 score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
-                score_min=level_min[lvl:lvl + 1])
+                score_min=level_min[lvl:lvl + 1],
+                value_job=next((j for j in (value_jobs or ()) if not j.done), None) if lvl >= L - 2 and L > 2 else None)
             score = token_score.view(B, 1, h, w)
             # the strided mask slice and the minimum stage 2 already took go straight to the kernel
             ls, li = masked_topk_desc(token_score, ks[lvl], mask=mask, fill_with_global_min=True, index_offset=start,

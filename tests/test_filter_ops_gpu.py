@@ -633,3 +633,36 @@ def test_fused_ffn_advance_equals_ffn_then_advance_rows(rows, next_rows, splits)
         assert want_next is None and got_next is None
     else:
         assert torch.equal(want_next, got_next)
+
+
+@pytest.mark.parametrize("n,hw,mode", [(273, (13, 21), "enc"), (1050, (25, 42), "enc+coarse")])
+def test_salience_head_carrying_a_value_projection_job(n, hw, mode):
+    """fused_head_value.hip: stage 1 of a coarse level and a slice of the encoder's value projection in ONE launch
+    give the same bits as the two launches on their own (scores, enc_output memory, head-major value maps)."""
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    torch.manual_seed(7)
+    B, C, Nv, heads, groups = 2, 256, 1500, 8, 6
+    pred, enc, enc_norm = MaskPredictor(C, C).to(DEV), torch.nn.Linear(C, C).to(DEV), torch.nn.LayerNorm(C).to(DEV)
+    x = (syn.det_randn(f"vx{n}", (B, n, C)) * 1.2).to(DEV)
+    coarse = syn.det_randn(f"vc{n}", (B, 1, (hw[0] + 1) // 2, (hw[1] + 1) // 2)).to(DEV)
+    alpha = torch.tensor([0.2], device=DEV)
+    tokens = syn.det_randn("vtok", (B, Nv, C)).to(DEV).to(torch.bfloat16)
+    w = (syn.det_randn("vw", (groups * heads * 32, C)) * 0.05).to(DEV).to(torch.bfloat16)
+    bias = (syn.det_randn("vb", (groups * heads * 32,)) * 0.1).to(DEV).to(torch.bfloat16)
+    pad = (syn.det_rand("vpad", (B, Nv)) > 0.9).to(DEV)
+    kw = dict(enc_output=enc, enc_output_norm=enc_norm)
+    if "coarse" in mode:
+        kw.update(coarse_score=coarse, level_hw=hw, alpha=alpha)
+    with torch.no_grad():
+        mem_a, mem_b = torch.zeros(B, n, C, device=DEV), torch.zeros(B, n, C, device=DEV)
+        want_score = F.salience_head(x, pred, memory_out=mem_a, **kw)
+        want_maps = F.value_proj_head_major(tokens, w, bias, pad, heads, groups, torch.float16)
+        maps, jobs = F.plan_value_projection(tokens, w, bias, pad, heads, groups, torch.float16, parts=2)
+        maps.fill_(-5.0)
+        got_score = F.salience_head(x, pred, memory_out=mem_b, value_job=jobs[0], **kw)
+        assert jobs[0].done and not jobs[1].done
+        assert torch.equal(maps[:3], want_maps[:3]) and (maps[3:] == -5).all()
+        jobs[1].run()
+        jobs[1].run()   # idempotent
+    assert torch.equal(got_score, want_score) and torch.equal(mem_a, mem_b)
+    assert torch.equal(maps, want_maps)
