@@ -396,6 +396,18 @@ int sdetr_stage1_x3_with_value_proj(
     float *z_local, float *partial_sums, const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded,
     const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
     void *vp_dst, int vp_dst_dtype);
+/* sdetr_salience_head_const: the per-image constant of stage 2 as a launch of its own; sdetr_stage2_with_value_proj:
+ * stage 2 proper (arguments as sdetr_salience_head_stage2; const_workspace already filled) + a value-projection job
+ * in one launch (csrc/fused_head_value.hip). */
+int sdetr_salience_head_const(sdetr_stream_t stream, const float *partial_sums, int batch_size, int tokens,
+                              const float *weight2, const float *bias2, float *const_workspace, float *score_min);
+int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *z_local, int batch_size, int tokens,
+                                 const float *weight2_local_packed, const float *weight3_packed, const float *bias3,
+                                 const float *weight4, const float *bias4, const float *const_workspace, float *score,
+                                 float *score_flat, int64_t score_flat_stride, float *score_min, const void *vp_x,
+                                 const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+                                 int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
+                                 void *vp_dst, int vp_dst_dtype);
 int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums, int batch_size,
                                int tokens, const float *weight2, const float *bias2,
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,

@@ -77,6 +77,9 @@ SIGNATURES = {
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p]),
     "sdetr_salience_head_stage1_x3": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p]),
+    "sdetr_salience_head_const": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
+    "sdetr_stage2_with_value_proj": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p,
+                                          _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
     "sdetr_stage1_x3_with_value_proj": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
                                              _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),

@@ -27,9 +27,81 @@ __global__ void __launch_bounds__(768, 1) fused_stage1_value_kernel(Stage1Args s
     }
 }
 
+// The same for stage 2 (64-token blocks, first 256 threads; its tile lives behind the projection's LDS buffers).
+__global__ void __launch_bounds__(768, 1) fused_stage2_value_kernel(Stage2Args s2, int s2_blocks, int s2_images, TLArgs tl)
+{
+    extern __shared__ __attribute__((aligned(16))) char fused_lds[];
+    const int blk = (int)blockIdx.x;
+    const int n1 = s2_blocks * s2_images;
+    if (blk < n1) {
+        if (threadIdx.x >= kBlock) return;
+        float *zt = reinterpret_cast<float *>(fused_lds);
+        stage2_body(s2, blk % s2_blocks, blk / s2_blocks, zt, zt + kTM * kZS);
+    } else {
+        token_linear_body<kHeadMajor, false, 8>(tl, blk - n1);
+    }
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
+
+static int fill_value_job(TLArgs &t, size_t &lds_tl, int &n2, const void *vp_x, const void *vp_packed_weight,
+                          const float *vp_bias_padded, const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size,
+                          int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+{
+    if (vp_batch_size <= 0 || vp_spatial_size <= 0 || vp_num_heads <= 0 || vp_num_groups <= 0)
+        return fail("value-projection job: bad sizes");
+    if (vp_dst_dtype != SDETR_F16 && vp_dst_dtype != SDETR_BF16) return fail("value-projection job: dst must be fp16 or bf16");
+    if (!vp_x || !vp_packed_weight || !vp_bias_padded || !vp_dst) return fail("value-projection job: NULL pointer");
+    const int64_t vp_tokens = (int64_t)vp_batch_size * vp_spatial_size;
+    if (vp_tokens > 0x7fffffff) return fail("value-projection job: too many tokens");
+    t = TLArgs{};
+    t.x = (const bf16_t *)vp_x; t.pw = (const char *)vp_packed_weight; t.bias = vp_bias_padded; t.T = (int)vp_tokens;
+    t.N = vp_num_groups * vp_num_heads * 32; t.ntiles = t.N / 32; t.rows_per_batch = vp_spatial_size;
+    t.pad = vp_pad_mask; t.hm = vp_dst; t.heads = vp_num_heads; t.batch = vp_batch_size; t.hm_f16 = vp_dst_dtype == SDETR_F16;
+    const int nsteps = (t.ntiles + kTLStepTiles - 1) / kTLStepTiles;
+    if ((size_t)t.ntiles * 128 + 2 * kTLStepBytes + 1024 > 160 * 1024) return fail("value-projection job: too many output features");
+    lds_tl = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
+    n2 = (int)((vp_tokens + kTLTokWave * 8 - 1) / (kTLTokWave * 8));
+    return 0;
+}
+
+// The stage-2 half of sdetr_salience_head_stage2 (the caller has launched the per-image constant already:
+// `const_workspace` holds it) + a value-projection job in one launch.
+extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *z_local, int batch_size, int tokens,
+                                            const float *weight2_local_packed, const float *weight3_packed,
+                                            const float *bias3, const float *weight4, const float *bias4,
+                                            const float *const_workspace, float *score, float *score_flat,
+                                            int64_t score_flat_stride, float *score_min, const void *vp_x,
+                                            const void *vp_packed_weight, const float *vp_bias_padded,
+                                            const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size,
+                                            int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+{
+    if (batch_size <= 0 || tokens <= 0) return fail("stage2_with_value_proj: empty level");
+    if (!z_local || !weight2_local_packed || !weight3_packed || !bias3 || !weight4 || !bias4 || !const_workspace || !score)
+        return fail("stage2_with_value_proj: NULL pointer");
+    TLArgs t;
+    size_t lds_tl = 0;
+    int n2 = 0;
+    if (int rc = fill_value_job(t, lds_tl, n2, vp_x, vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size,
+                                vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype))
+        return rc;
+    Stage2Args a;
+    a.z_local = z_local; a.cst = const_workspace;
+    a.w2a = reinterpret_cast<const float4 *>(weight2_local_packed);
+    a.w3 = reinterpret_cast<const float4 *>(weight3_packed);
+    a.b3 = bias3; a.w4 = weight4; a.b4 = bias4; a.score = score; a.score2 = score_flat;
+    a.score2_stride = score_flat_stride; a.n = tokens; a.score_min = score_min;
+    const int nblk = (tokens + kTM - 1) / kTM;
+    const size_t lds_s2 = (size_t)kStage2LdsFloats * sizeof(float);
+    const size_t lds = lds_tl > lds_s2 ? lds_tl : lds_s2;
+    static DeviceOnce once;
+    allow_dynamic_lds(fused_stage2_value_kernel, once, 160 * 1024);
+    hipLaunchKernelGGL(fused_stage2_value_kernel, dim3((unsigned)(nblk * batch_size + n2)), dim3(768), lds,
+                       static_cast<hipStream_t>(stream), a, nblk, batch_size, t);
+    return check_launch("stage2_with_value_proj");
+}
 
 // sdetr_salience_head_stage1_x3 (same arguments, same checks by the caller's usual entry) + the value projection of
 // `num_groups` stacked layers of sdetr_value_proj_head_major (same arguments; `packed_weight`, `bias_padded` and

@@ -264,91 +264,11 @@ __global__ void __launch_bounds__(kHalf * kConstGroups) salience_head_const_kern
     if (q == 0) out[(int64_t)b * kHalf + j2] = b2[j2] + a;
 }
 
-struct Stage2Args {
-    const float *z_local;   // [B, n, 128]
-    const float *cst;       // [B, 128]
-    const float4 *w2a;      // packed W2[:, :128]   (128 x 128)
-    const float4 *w3;       // packed W3            (64 x 128)
-    const float *b3, *w4, *b4;
-    float *score;           // [B, n]
-    float *score2;          // optional second destination, row stride score2_stride (flattened score buffer)
-    float *score_min;       // optional device scalar: min over every score of the launch (initialised by const kernel)
-    int64_t score2_stride;
-    int n;
-};
-
 __global__ void __launch_bounds__(kBlock, 2) salience_head_stage2_kernel(Stage2Args p)
 {
     __shared__ __attribute__((aligned(16))) float zt[kTM * kZS];
-    __shared__ float red[2][kTM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * kTM;
-    const int nvalid = min(kTM, p.n - t0);
-    WeightStream<1, 8> ws;
-    ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
-    const float cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
-    const int rt2 = wave >> 1, ct2 = wave & 1;
-    const float bias3 = p.b3[ct2 * 32 + (lane & 31)], wo = p.w4[ct2 * 32 + (lane & 31)], b4 = p.b4[0];
-    {
-        const float *zb = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
-        float4 v[kTM * (kHalf / 4) / kBlock];
-#pragma unroll
-        for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
-            const int idx = tid + i * kBlock;
-            const int r = idx >> 5, c4 = idx & 31;
-            v[i] = *reinterpret_cast<const float4 *>(zb + (int64_t)min(r, nvalid - 1) * kHalf + c4 * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
-            const int idx = tid + i * kBlock;
-            const int r = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<float4 *>(zt + r * kZS + c4 * 4) = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __syncthreads();
-    // layer2[0] (local half; the global half is the per-image constant) + GELU: wave w -> columns [32w, 32w+32)
-    {
-        f32x16 acc[2][1];
-        zero_acc(acc);
-        block_gemm<kHalf, kZS, 2, 1, 8>(zt, ws, lane, acc);
-        ws.start(p.w3, kHalf / 2, kHalf / 8, ct2 * 32, lane);
-        __syncthreads();
-        const int c = wave * 32 + (lane & 31);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) zt[(32 * rt + acc_row(i, lane)) * kZS + c] = gelu_erf(acc[rt][0][i] + cb);
-    }
-    __syncthreads();
-    // layer2[2] + GELU, layer2[4]: wave -> (row tile, column tile) of the [64 x 64] hidden state
-    {
-        f32x16 acc[1][1];
-        zero_acc(acc);
-        block_gemm<kHalf, kZS, 1, 1, 8>(zt + rt2 * 32 * kZS, ws, lane, acc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = gelu_erf(acc[0][0][i] + bias3) * wo;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
-            if ((lane & 31) == 0) red[ct2][32 * rt2 + acc_row(i, lane)] = v;
-        }
-    }
-    __syncthreads();
-    float s = INFINITY;
-    if (tid < nvalid) {
-        s = (red[0][tid] + red[1][tid]) + b4;
-        p.score[(int64_t)b * p.n + t0 + tid] = s;
-        if (p.score2) p.score2[(int64_t)b * p.score2_stride + t0 + tid] = s;
-    }
-    if (p.score_min && tid < kTM) {   // wave 0 holds the block's scores: min is order-independent, so atomics are exact
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s = fminf(s, __shfl_xor(s, o));
-        if (tid == 0) {
-            // float min through integer atomics: non-negative floats order like signed ints, negative ones reversed
-            if (s >= 0.f) atomicMin(reinterpret_cast<int *>(p.score_min), __float_as_int(s));
-            else atomicMax(reinterpret_cast<unsigned int *>(p.score_min), __float_as_uint(s));
-        }
-    }
+    __shared__ float red[2 * kTM];
+    stage2_body(p, (int)blockIdx.x, (int)blockIdx.y, zt, red);
 }
 
 // P[S][n][h][j] = W[n][8S + 4h + j]
@@ -496,6 +416,21 @@ extern "C" int sdetr_salience_head_stage1_x3(sdetr_stream_t stream, const float 
     hipLaunchKernelGGL(salience_head_stage1_x3_kernel, dim3((unsigned)a.nblk, (unsigned)batch_size), dim3(512),
                        (size_t)stage1_x3_lds_bytes(), static_cast<hipStream_t>(stream), a);
     return check_launch("salience_head_stage1_x3");
+}
+
+// The per-image constant of layer2[0] on its own (sdetr_salience_head_stage2 launches it itself; a caller that puts stage
+// 2 in a launch of its own -- sdetr_stage2_with_value_proj -- runs it first).
+extern "C" int sdetr_salience_head_const(sdetr_stream_t stream, const float *partial_sums, int batch_size, int tokens,
+                                         const float *weight2, const float *bias2, float *const_workspace,
+                                         float *score_min)
+{
+    if (batch_size < 0 || tokens < 0) return fail("salience_head_const: negative size");
+    if (batch_size == 0 || tokens == 0) return 0;
+    if (!partial_sums || !weight2 || !bias2 || !const_workspace) return fail("salience_head_const: NULL pointer");
+    hipLaunchKernelGGL(salience_head_const_kernel, dim3((unsigned)batch_size), dim3(kHalf * kConstGroups), 0,
+                       static_cast<hipStream_t>(stream), partial_sums, sdetr_salience_head_blocks(batch_size, tokens),
+                       tokens, weight2, bias2, const_workspace, score_min);
+    return check_launch("salience_head_const");
 }
 
 extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums,

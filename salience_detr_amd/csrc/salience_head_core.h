@@ -423,6 +423,96 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
     }
 }
 
+struct Stage2Args {
+    const float *z_local;   // [B, n, 128]
+    const float *cst;       // [B, 128]
+    const float4 *w2a;      // packed W2[:, :128]   (128 x 128)
+    const float4 *w3;       // packed W3            (64 x 128)
+    const float *b3, *w4, *b4;
+    float *score;           // [B, n]
+    float *score2;          // optional second destination, row stride score2_stride (flattened score buffer)
+    float *score_min;       // optional device scalar: min over every score of the launch (initialised by const kernel)
+    int64_t score2_stride;
+    int n;
+};
+
+constexpr int kStage2LdsFloats = kTM * kZS + 2 * kTM;   // zt | red
+
+// (`blk` / `b` = token block and image; `zt` [kTM * kZS] and `red` [2 * kTM] floats of LDS: the kernel's own static
+// arrays, or a piece of the dynamic LDS of a launch that also carries other work -- fused_head_value.hip.  The first
+// 256 threads of the workgroup take part.)
+__device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b, float *zt, float *red)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blk * kTM;
+    const int nvalid = min(kTM, p.n - t0);
+    WeightStream<1, 8> ws;
+    ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
+    const float cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
+    const int rt2 = wave >> 1, ct2 = wave & 1;
+    const float bias3 = p.b3[ct2 * 32 + (lane & 31)], wo = p.w4[ct2 * 32 + (lane & 31)], b4 = p.b4[0];
+    {
+        const float *zb = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
+        float4 v[kTM * (kHalf / 4) / kBlock];
+#pragma unroll
+        for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
+            const int idx = tid + i * kBlock;
+            const int r = idx >> 5, c4 = idx & 31;
+            v[i] = *reinterpret_cast<const float4 *>(zb + (int64_t)min(r, nvalid - 1) * kHalf + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
+            const int idx = tid + i * kBlock;
+            const int r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<float4 *>(zt + r * kZS + c4 * 4) = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // layer2[0] (local half; the global half is the per-image constant) + GELU: wave w -> columns [32w, 32w+32)
+    {
+        f32x16 acc[2][1];
+        zero_acc(acc);
+        block_gemm<kHalf, kZS, 2, 1, 8>(zt, ws, lane, acc);
+        ws.start(p.w3, kHalf / 2, kHalf / 8, ct2 * 32, lane);
+        __syncthreads();
+        const int c = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zt[(32 * rt + acc_row(i, lane)) * kZS + c] = gelu_erf(acc[rt][0][i] + cb);
+    }
+    __syncthreads();
+    // layer2[2] + GELU, layer2[4]: wave -> (row tile, column tile) of the [64 x 64] hidden state
+    {
+        f32x16 acc[1][1];
+        zero_acc(acc);
+        block_gemm<kHalf, kZS, 1, 1, 8>(zt + rt2 * 32 * kZS, ws, lane, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = gelu_erf(acc[0][0][i] + bias3) * wo;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+            if ((lane & 31) == 0) red[ct2 * kTM + 32 * rt2 + acc_row(i, lane)] = v;
+        }
+    }
+    __syncthreads();
+    float s = INFINITY;
+    if (tid < nvalid) {
+        s = (red[tid] + red[kTM + tid]) + b4;
+        p.score[(int64_t)b * p.n + t0 + tid] = s;
+        if (p.score2) p.score2[(int64_t)b * p.score2_stride + t0 + tid] = s;
+    }
+    if (p.score_min && tid < kTM) {   // wave 0 holds the block's scores: min is order-independent, so atomics are exact
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fminf(s, __shfl_xor(s, o));
+        if (tid == 0) {
+            // float min through integer atomics: non-negative floats order like signed ints, negative ones reversed
+            if (s >= 0.f) atomicMin(reinterpret_cast<int *>(p.score_min), __float_as_int(s));
+            else atomicMax(reinterpret_cast<unsigned int *>(p.score_min), __float_as_uint(s));
+        }
+    }
+}
+
 }  // namespace sdetr
 
 #pragma clang fp contract(fast)

@@ -319,9 +319,10 @@ class ValueProjectionJob:
 
 
 def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],
-                          num_heads: int, num_groups: int, dtype: torch.dtype, parts: int = 2):
-    """``value_proj_head_major`` split into ``parts`` jobs over consecutive layer groups that share one destination
-    ``[groups,B,heads,Nv,32]``: returns ``(dst, [ValueProjectionJob, ...])``."""
+                          num_heads: int, num_groups: int, dtype: torch.dtype, parts=2):
+    """``value_proj_head_major`` split into jobs over consecutive layer groups that share one destination
+    ``[groups,B,heads,Nv,32]``: returns ``(dst, [ValueProjectionJob, ...])``.  ``parts``: a number of (nearly) equal
+    parts, or a sequence of layer counts per job (they must add up to ``num_groups``)."""
     if not token_linear_applies(value, weight) or weight.shape[0] != num_groups * num_heads * 32:
         raise RuntimeError("plan_value_projection: bf16 [B,Nv,256] tokens and 32-channel heads expected")
     _hip.require_device("plan_value_projection", value=value, padding_mask=padding_mask)
@@ -330,20 +331,26 @@ def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor],
     pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
                                              else padding_mask)
     dst = torch.empty((num_groups, B, num_heads, Nv, 32), dtype=dtype, device=value.device)
-    parts = max(1, min(int(parts), num_groups))
+    if isinstance(parts, int):
+        k = max(1, min(int(parts), num_groups))
+        sizes = [(num_groups * (i + 1)) // k - (num_groups * i) // k for i in range(k)]
+    else:
+        sizes = [int(v) for v in parts]
+        if sum(sizes) != num_groups or any(v < 0 for v in sizes):
+            raise RuntimeError("plan_value_projection: the parts must add up to num_groups")
     jobs, g0 = [], 0
-    for i in range(parts):
-        g1 = (num_groups * (i + 1)) // parts
-        if g1 > g0:
-            jobs.append(ValueProjectionJob(value, packed, b, pad, num_heads, g1 - g0, dst, g0))
-        g0 = g1
+    for n in sizes:
+        if n > 0:
+            jobs.append(ValueProjectionJob(value, packed, b, pad, num_heads, n, dst, g0))
+        g0 += n
     return dst, jobs
 
 
 def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coarse_score: Optional[Tensor] = None,
                   level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
                   memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
-                  score_min: Optional[Tensor] = None, value_job: Optional[ValueProjectionJob] = None) -> Tensor:
+                  score_min: Optional[Tensor] = None, value_job: Optional[ValueProjectionJob] = None,
+                  value_job2: Optional[ValueProjectionJob] = None) -> Tensor:
     """The salience head on one level in three launches (include/salience_hip.h (6)).
 
     ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
@@ -353,7 +360,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     [B,1,h',w'] (resized in-kernel to ``level_hw``), times the device scalar ``alpha``.  ``score_flat``
     (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy; ``score_min`` (one-element
     fp32 tensor) the minimum over all ``B*n`` scores.  ``value_job``: a pending slice of the encoder's value projection
-    that stage 1's launch carries along (bf16x3 kernel only; otherwise it is left pending).  Returns ``[B,n]``."""
+    that stage 1's launch carries along (bf16x3 kernel only; otherwise it is left pending), ``value_job2`` one for
+    stage 2's launch.  Returns ``[B,n]``."""
     if not x.is_cuda:
         raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
     if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
@@ -409,11 +417,22 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
             code = stage1(*stage1_args)
         _hip.check(code, "salience_head_stage1")
-        code = lib.sdetr_salience_head_stage2(
-            s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
-            packed_linear_weight(l2a.weight, cols=(0, half)).data_ptr(), packed_linear_weight(l2b.weight).data_ptr(),
-            l2b.bias.data_ptr(), l2c.weight.data_ptr(), l2c.bias.data_ptr(), cst.data_ptr(), score.data_ptr(),
-            _hip.ptr(score_flat), sfs, _hip.ptr(score_min))
+        w2_local = packed_linear_weight(l2a.weight, cols=(0, half)).data_ptr()
+        w3 = packed_linear_weight(l2b.weight).data_ptr()
+        if value_job2 is not None and not value_job2.done and value_job2.value.device == x.device:
+            code = lib.sdetr_salience_head_const(s, partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
+                                                 cst.data_ptr(), _hip.ptr(score_min))
+            _hip.check(code, "salience_head_const")
+            code = lib.sdetr_stage2_with_value_proj(
+                s, z_local.data_ptr(), B, n, w2_local, w3, l2b.bias.data_ptr(), l2c.weight.data_ptr(),
+                l2c.bias.data_ptr(), cst.data_ptr(), score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min),
+                *value_job2.pointers())
+            value_job2.done = True
+        else:
+            code = lib.sdetr_salience_head_stage2(
+                s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
+                w2_local, w3, l2b.bias.data_ptr(), l2c.weight.data_ptr(), l2c.bias.data_ptr(), cst.data_ptr(),
+                score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min))
         _hip.check(code, "salience_head_stage2")
     return score
 

@@ -403,7 +403,7 @@ def _stacked_value_proj(attn_modules):
     return hit[1], hit[2]
 
 
-def plan_batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor], parts: int = 2):
+def plan_batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor], parts=2):
     """``batched_value_maps`` as pending jobs: ``(maps [n,B,M,Nv,D], [ValueProjectionJob, ...])`` -- slices of the one
     projection that other launches can carry (``filter_ops.salience_head(value_job=...)``) -- or ``None`` when the
     one-launch kernel does not cover the configuration (call ``batched_value_maps`` then)."""

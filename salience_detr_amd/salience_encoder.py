@@ -320,7 +320,7 @@ class SalienceTransformerEncoder(nn.Module):
         stage on a second stream (``SalienceEncoderHotPath`` does)."""
         return batched_value_maps([l.self_attn for l in self.layers], value, padding_mask)
 
-    def plan_values(self, value: Tensor, padding_mask: Optional[Tensor], parts: int = 2):
+    def plan_values(self, value: Tensor, padding_mask: Optional[Tensor], parts=2):
         """``project_values`` as pending jobs ``(maps, [ValueProjectionJob, ...])`` (``None`` when the one-launch
         projection does not apply): the caller lets other launches carry the jobs (the salience head's stage 1 on the
         coarse levels), runs the rest, and hands ``maps`` to ``forward`` as ``precomputed_value_maps``."""

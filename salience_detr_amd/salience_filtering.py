@@ -84,6 +84,12 @@ def token_budgets(multi_level_masks: Sequence[Tensor], level_filter_ratio: Tenso
     return focus.sum(-1), focus.max(0)[0], valid
 
 
+def _next_value_jobs(value_jobs) -> dict:
+    """The next two pending value-projection jobs as ``salience_head``'s ``value_job`` / ``value_job2``."""
+    pending = [j for j in (value_jobs or ()) if not j.done]
+    return dict(value_job=pending[0] if pending else None, value_job2=pending[1] if len(pending) > 1 else None)
+
+
 def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_shapes: Sequence[Tuple[int, int]],
                     level_start_index: Sequence[int], level_token_nums: Sequence[int], mask_predictor: nn.Module,
                     alpha: Tensor, enc_output: Optional[nn.Module] = None, enc_output_norm: Optional[nn.Module] = None,
@@ -103,7 +109,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     ``salience_filtering`` can reuse: ``level_min`` [L] (``score.min()`` per level) and ``selected`` (the
     concatenated ``(scores, indices)`` [B, sum k] the per-level top-k calls already wrote side by side).
     ``value_jobs``: pending ``filter_ops.ValueProjectionJob`` slices of the encoder's value projection; the stage-1
-    launches of the coarsest levels (few workgroups on an otherwise empty chip) carry one each, coarsest first.
+    launches of the two coarsest levels (few workgroups on an otherwise empty chip) carry one each -- stage 1, then
+    stage 2 -- coarsest level first.
     """
     B = backbone_output_memory.shape[0]
     L = len(level_shapes)
@@ -141,7 +148,7 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 memory_out=None if memory_out is None else memory_out[:, start:start + h * w, :],
                 score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
                 score_min=level_min[lvl:lvl + 1],
-                value_job=next((j for j in (value_jobs or ()) if not j.done), None) if lvl >= L - 2 and L > 2 else None)
+                **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None))
             score = token_score.view(B, 1, h, w)
             # the strided mask slice and the minimum stage 2 already took go straight to the kernel
             ls, li = masked_topk_desc(token_score, ks[lvl], mask=mask, fill_with_global_min=True, index_offset=start,

@@ -657,12 +657,12 @@ def test_salience_head_carrying_a_value_projection_job(n, hw, mode):
         mem_a, mem_b = torch.zeros(B, n, C, device=DEV), torch.zeros(B, n, C, device=DEV)
         want_score = F.salience_head(x, pred, memory_out=mem_a, **kw)
         want_maps = F.value_proj_head_major(tokens, w, bias, pad, heads, groups, torch.float16)
-        maps, jobs = F.plan_value_projection(tokens, w, bias, pad, heads, groups, torch.float16, parts=2)
+        maps, jobs = F.plan_value_projection(tokens, w, bias, pad, heads, groups, torch.float16, parts=(2, 1, 3))
         maps.fill_(-5.0)
-        got_score = F.salience_head(x, pred, memory_out=mem_b, value_job=jobs[0], **kw)
-        assert jobs[0].done and not jobs[1].done
+        got_score = F.salience_head(x, pred, memory_out=mem_b, value_job=jobs[0], value_job2=jobs[1], **kw)
+        assert jobs[0].done and jobs[1].done and not jobs[2].done      # stage 1 carried two layers, stage 2 one
         assert torch.equal(maps[:3], want_maps[:3]) and (maps[3:] == -5).all()
-        jobs[1].run()
-        jobs[1].run()   # idempotent
+        jobs[2].run()
+        jobs[2].run()   # idempotent
     assert torch.equal(got_score, want_score) and torch.equal(mem_a, mem_b)
     assert torch.equal(maps, want_maps)
