@@ -17,81 +17,9 @@
 // Replaces select_stack + library GEMM + attention_heads + library GEMM + layernorm/scatter (five launches).
 #include "common.h"
 
+#include "topk_attention_core.h"
+
 namespace sdetr {
-
-typedef __bf16 tk_bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float tk_f32x16_t __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ tk_f32x16_t tk_mfma(uint4 a, uint4 b, tk_f32x16_t c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tk_bf16x8_t, a), __builtin_bit_cast(tk_bf16x8_t, b),
-                                                   c, 0, 0, 0);
-}
-// accumulator row of register i for lane half h (v_mfma_f32_32x32x16: C[row][col = lane & 31])
-__device__ __forceinline__ int tk_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
-__device__ __forceinline__ uint4 tk_pack_half(const tk_f32x16_t &c, int m)
-{
-    return make_uint4(pack_bf16x2(c[8 * m], c[8 * m + 1]), pack_bf16x2(c[8 * m + 2], c[8 * m + 3]),
-                      pack_bf16x2(c[8 * m + 4], c[8 * m + 5]), pack_bf16x2(c[8 * m + 6], c[8 * m + 7]));
-}
-__device__ __forceinline__ float tk_bf16(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
-
-constexpr int kTkE = 256, kTkHeads = 8, kTkHd = 32;
-
-struct TkInArgs {
-    const bf16_t *query;   // [B, rows, 256] the layer's rows; images q_bs elements apart
-    int64_t q_bs;
-    const bf16_t *pos;     // [B, n0, 256] position rows in the same (sorted) order; images p_bs elements apart
-    int64_t p_bs;
-    const int64_t *sel;    // [B, N] selected row numbers
-    const bf16_t *w;       // in_proj_weight [768, 256]
-    const bf16_t *bias;    // in_proj_bias [768]
-    bf16_t *qk;            // q rows [B, Npad, 256], then the K fragments [B, 8, Npad/16, 64 lanes, 8]
-    bf16_t *vt;            // V^T fragments [B, 8, Npad/32, 2, 64 lanes, 8]
-    int B, N, Npad;
-};
-// Fragment-major K and V^T: the attention kernel's operand fragments are stored exactly as its lanes hold them, so
-// each of its loads is one contiguous kilobyte per wave (row-major slabs made every K load touch 16 rows and every
-// V^T load 64 separate 8-byte pieces: the address unit, not the latency, was 40 % of that kernel's time).
-//   K  (A operand of S^T = K Q^T, 16 keys x 32 channels per tile): lane = 16 (ch / 8) + key % 16, slot = ch % 8
-//   V^T (A operand of O^T += V^T P^T, 16 channels x 32 keys per block and channel half c): lane = 16 g + ch % 16 where
-//       the lane group g holds keys {4g..4g+3} (slots 0-3) and {16+4g..16+4g+3} (slots 4-7) of the block
-__device__ __forceinline__ int64_t tk_k_index(int b, int head, int key, int ch, int Npad)
-{
-    return ((((int64_t)b * kTkHeads + head) * (Npad / 16) + key / 16) * 64 + 16 * (ch / 8) + key % 16) * 8 + ch % 8;
-}
-__device__ __forceinline__ int64_t tk_vt_index(int b, int head, int key, int ch, int Npad)
-{
-    const int kk = key % 32, hi = kk / 16, g = (kk % 16) / 4, pos = 4 * hi + kk % 4;
-    return (((((int64_t)b * kTkHeads + head) * (Npad / 32) + key / 32) * 2 + ch / 16) * 64 + 16 * g + ch % 16) * 8 + pos;
-}
-
-// one 32-feature x 32-token tile; QK = the tile holds q or k features (the position rows are added).  Straight-line
-// code per variant: with a branch inside, hipcc sinks the operand loads into the MFMA sequence (two in flight)
-template <bool QK>
-__device__ __forceinline__ tk_f32x16_t inproj_tile(const bf16_t *wr, const bf16_t *xr, const bf16_t *pr)
-{
-    tk_f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {               // 8 k-steps of 16 at a time: 16 / 24 fragments in flight
-        uint4 a[8], bx[8], bp[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a[j] = *reinterpret_cast<const uint4 *>(wr + (half * 8 + j) * 16);
-            bx[j] = *reinterpret_cast<const uint4 *>(xr + (half * 8 + j) * 16);
-            if (QK) bp[j] = *reinterpret_cast<const uint4 *>(pr + (half * 8 + j) * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // every load of the half issued before its first MFMA
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc = tk_mfma(a[j], bx[j], acc);
-            if (QK) acc = tk_mfma(a[j], bp[j], acc);   // W (x + pos) = W x + W pos
-        }
-    }
-    return acc;
-}
 
 __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
 {
@@ -146,210 +74,24 @@ __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
     }
 }
 
-struct TkOutArgs {
-    const bf16_t *qk;      // q rows [B, Npad, 256], then the K fragments (see tk_k_index)
-    const bf16_t *vt;      // V^T fragments (see tk_vt_index)
-    const int64_t *sel;    // [B, N]
-    bf16_t *query;         // [B, rows, 256]: residual rows are read from it, results written back to it
-    int64_t q_bs;
-    const bf16_t *wo;      // out_proj.weight [256, 256]
-    const bf16_t *bo;      // out_proj.bias [256]
-    const bf16_t *gamma, *beta;   // pre_norm
-    float eps, scale;
-    int B, N, Npad;
-};
-
-typedef float tk_f32x4_t __attribute__((ext_vector_type(4)));
-// v_mfma_f32_16x16x32_bf16: A lane l = row l & 15, k = 8 (l >> 4) .. +7; B lane l = column l & 15, same k;
-// C lane l = column l & 15, rows 4 (l >> 4) + 0..3
-__device__ __forceinline__ tk_f32x4_t tk_mfma16(uint4 a, uint4 b, tk_f32x4_t c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8_t, a), __builtin_bit_cast(tk_bf16x8_t, b),
-                                                   c, 0, 0, 0);
-}
-
-constexpr int kTkQ = 16;            // queries per workgroup
-constexpr int kTkORow = 528;        // bytes per query row of the heads' outputs in LDS (512 + 16: bank spread)
-constexpr int kTkMaxKeyTiles = 24;  // 16-key tiles held in registers at once: up to 384 selected rows
-
-// One 8-wave workgroup per (image, 16 queries), wave = head.  The head dimension (32) is ONE k-step of the 16x16x32
-// MFMA, so S^T = K Q^T is one instruction per 16 keys and all of a query's scores (<= 384 keys: 96 registers) stay in
-// registers: a plain two-pass softmax (max, exp2 with the 1/sqrt(32) scale folded in, sum), no running rescale.  The
-// scores of two neighbouring key tiles ARE the B operand of O^T += V^T P^T after bf16 rounding (lane group g holds keys
-// {4g..4g+3, 16+4g..16+4g+3} of a 32-key block; the V^T fragments are loaded in that key order, two 8-byte pieces).
-// 40 workgroups for 2 x 300 rows (the 32-query version: 20, with four times the per-SIMD softmax arithmetic).
-// A load whose result is discarded: brings the line into this XCD's L2. The compiler does not know the write to
-// `sink` is still pending when the statement ends, so the caller keeps that register reserved (tk_touch_done) until
-// the loads must have landed.
-__device__ __forceinline__ void tk_touch(const void *ptr, uint32_t &sink)
-{
-    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(ptr) : "memory");
-}
-__device__ __forceinline__ void tk_touch_done(uint32_t &sink) { asm volatile("" : "+v"(sink)); }
-
-template <int KT>   // key tiles (of 16) = Npad / 16, compile time: the score array must live in registers
+template <int KT>
 __global__ void __launch_bounds__(512) topk_attn_out_kernel(TkOutArgs p)
 {
-    __shared__ __attribute__((aligned(16))) char o_lds[kTkQ * kTkORow];
-    __shared__ float part[2][8][kTkQ];
-    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = head
-    const int t = lane & 15, g = lane >> 4;
-    const int tiles = (p.N + kTkQ - 1) / kTkQ;
-    const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
-    const int qi = tile * kTkQ + t;                 // < Npad (rows past N are zero rows of the slab)
-    const bool valid = qi < p.N;
-    const bf16_t *kfb = p.qk + (int64_t)p.B * p.Npad * 256 + (((int64_t)b * kTkHeads + head) * KT) * 512 + lane * 8;
-    const bf16_t *vfb = p.vt + (((int64_t)b * kTkHeads + head) * (KT / 2)) * 1024 + lane * 8;
-
-    // ---- everything this wave reads from global memory, issued up front ----
-    // oldest load in flight: the residual row's index (loads return in order, so its consumer waits for it alone)
-    const int64_t row = p.sel[(int64_t)b * p.N + min(qi, p.N - 1)];
-    uint32_t sink = 0;
-    // warm the out_proj rows this wave will want after the softmax (their registers are not free until then; untouched
-    // they cost a second exposed trip to memory in the middle of the kernel)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tk_touch(p.wo + (int64_t)(head * 32 + 16 * c + t) * kTkE + 32 * j + 8 * g, sink);
-    const uint4 qfrag = *reinterpret_cast<const uint4 *>(p.qk + ((int64_t)b * p.Npad + qi) * 256 + head * kTkHd + 8 * g);
-    uint4 kfr[KT];
-#pragma unroll
-    for (int j = 0; j < KT; ++j) kfr[j] = *reinterpret_cast<const uint4 *>(kfb + j * 512);   // one contiguous KB per wave
-    // V^T fragments (A operand of the second product): per 32-key block and 16-channel half, keys {4g..4g+3} and
-    // {16+4g..16+4g+3} of channel t (+16).  Requested together with K: one round trip for both (the scores take over
-    // the K fragments' registers tile by tile)
-    uint4 vfr[KT / 2][2];
-#pragma unroll
-    for (int m = 0; m < KT / 2; ++m)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) vfr[m][c] = *reinterpret_cast<const uint4 *>(vfb + (m * 2 + c) * 512);
-    bf16_t *xrow = p.query + (int64_t)b * p.q_bs + row * kTkE + head * 32 + 4 * g;   // my features: 32 head + 16 c + 4 g + r
-    uint2 res_v[2], bo_v[2], gamma_v[2], beta_v[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        res_v[c] = *reinterpret_cast<const uint2 *>(xrow + 16 * c);
-        bo_v[c] = *reinterpret_cast<const uint2 *>(p.bo + head * 32 + 16 * c + 4 * g);
-        gamma_v[c] = *reinterpret_cast<const uint2 *>(p.gamma + head * 32 + 16 * c + 4 * g);
-        beta_v[c] = *reinterpret_cast<const uint2 *>(p.beta + head * 32 + 16 * c + 4 * g);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- scores: S^T[key][query], one MFMA per 16 keys ----
-    tk_f32x4_t s[KT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        s[j] = tk_f32x4_t{0.f, 0.f, 0.f, 0.f};
-        s[j] = tk_mfma16(kfr[j], qfrag, s[j]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < KT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (j * 16 + 4 * g + r >= p.N) s[j][r] = -INFINITY;    // padded keys (only the last tiles: folds for full ones)
-            mx = fmaxf(mx, s[j][r]);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float c2 = p.scale * 1.4426950408889634f, shift = -mx * c2;
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < KT; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[j][r] = __builtin_amdgcn_exp2f(fmaf(s[j][r], c2, shift));
-            sum += s[j][r];
-        }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    // ---- O^T[channel][query] += V^T P^T, 32 keys per MFMA, two channel halves ----
-    tk_f32x4_t o[2] = {tk_f32x4_t{0.f, 0.f, 0.f, 0.f}, tk_f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int m = 0; m < KT / 2; ++m) {
-        const uint4 pf = make_uint4(pack_bf16x2(s[2 * m][0], s[2 * m][1]), pack_bf16x2(s[2 * m][2], s[2 * m][3]),
-                                    pack_bf16x2(s[2 * m + 1][0], s[2 * m + 1][1]), pack_bf16x2(s[2 * m + 1][2], s[2 * m + 1][3]));
-        o[0] = tk_mfma16(vfr[m][0], pf, o[0]);
-        o[1] = tk_mfma16(vfr[m][1], pf, o[1]);
-    }
-    // out_proj fragments of my 32 features (two 16-feature tiles x 8 k-steps of 32): issued once the score and V^T
-    // registers are free (together they would not fit in 256), their round trip overlaps the LDS exchange
-    tk_touch_done(sink);   // every load issued before the scores has returned by now (the score MFMAs waited for them)
-    uint4 wfrag[2][8];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            wfrag[c][j] = *reinterpret_cast<const uint4 *>(p.wo + (int64_t)(head * 32 + 16 * c + t) * kTkE + 32 * j + 8 * g);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- the heads meet in LDS: O[query][32 head + channel] bf16 (my channels: 16 c + 4 g + r) ----
-    {
-        const float inv = 1.f / sum;
-        char *orow = o_lds + t * kTkORow + (head * kTkHd + 4 * g) * 2;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            *reinterpret_cast<uint2 *>(orow + 32 * c) =
-                make_uint2(pack_bf16x2(o[c][0] * inv, o[c][1] * inv), pack_bf16x2(o[c][2] * inv, o[c][3] * inv));
-    }
-    __syncthreads();
-    // ---- out_proj: Z^T[feature][query] = Wo O^T, my 32 features as two 16-feature tiles ----
-    tk_f32x4_t z[2] = {tk_f32x4_t{0.f, 0.f, 0.f, 0.f}, tk_f32x4_t{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint4 of = *reinterpret_cast<const uint4 *>(o_lds + t * kTkORow + (32 * j + 8 * g) * 2);
-        z[0] = tk_mfma16(wfrag[0][j], of, z[0]);
-        z[1] = tk_mfma16(wfrag[1][j], of, z[1]);
-    }
-    // + bias + residual; LayerNorm over the 256 features of a query (8 here, 32 per wave, 8 waves)
-    float tot = 0.f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const float rv[4] = {bf16_lo(res_v[c].x), bf16_hi(res_v[c].x), bf16_lo(res_v[c].y), bf16_hi(res_v[c].y)};
-        const float bv[4] = {bf16_lo(bo_v[c].x), bf16_hi(bo_v[c].x), bf16_lo(bo_v[c].y), bf16_hi(bo_v[c].y)};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            z[c][r] += bv[r] + rv[r];
-            tot += z[c][r];
-        }
-    }
-    tot += __shfl_xor(tot, 16);
-    tot += __shfl_xor(tot, 32);
-    if (g == 0) part[0][head][t] = tot;
-    __syncthreads();
-    float mean = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) mean += part[0][w][t];
-    mean *= (1.f / kTkE);
-    float sq = 0.f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = z[c][r] - mean;
-            sq += d * d;
-        }
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
-    if (g == 0) part[1][head][t] = sq;
-    __syncthreads();
-    float var = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) var += part[1][w][t];
-    const float rstd = rsqrtf(var * (1.f / kTkE) + p.eps);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const float gm[4] = {bf16_lo(gamma_v[c].x), bf16_hi(gamma_v[c].x), bf16_lo(gamma_v[c].y), bf16_hi(gamma_v[c].y)};
-        const float bt[4] = {bf16_lo(beta_v[c].x), bf16_hi(beta_v[c].x), bf16_lo(beta_v[c].y), bf16_hi(beta_v[c].y)};
-        float y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = (z[c][r] - mean) * rstd * gm[r] + bt[r];
-        if (valid) *reinterpret_cast<uint2 *>(xrow + 16 * c) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
-    }
+    topk_attn_out_body<KT>(p, (int)blockIdx.x);
 }
 
 }  // namespace sdetr
 
 using namespace sdetr;
+
+// (internal, for fused_head_value.hip: the in-projection launch with a filled TkInArgs)
+extern "C" int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in_args)
+{
+    const TkInArgs &a = *static_cast<const TkInArgs *>(tk_in_args);
+    hipLaunchKernelGGL(topk_inproj_kernel, dim3((unsigned)(a.B * (a.Npad / 32) * 6)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("topk_inproj");
+}
 
 extern "C" int64_t sdetr_topk_attention_workspace_bytes(int batch_size, int num_selected)
 {

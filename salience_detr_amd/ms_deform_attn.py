@@ -549,13 +549,23 @@ class MultiScaleDeformableAttention(nn.Module):
     # the level shapes is at hand (below it the 85 KB staging per workgroup is not amortised); None disables it
     resident_min_queries = 1200
 
+    def head_major_projection_applies(self, query: Tensor, value_hm: Tensor) -> bool:
+        """``forward_native`` (no ``order``) takes the per-head projection slabs for this input."""
+        from .filter_ops import token_linear_applies
+        w, _ = self._fused_query_projection()
+        return (query.dim() == 3 and query.shape[0] * query.shape[1] >= 3000 and token_linear_applies(query, w)
+                and self.num_levels == 4 and self.num_points == 4 and self.num_heads == 8 and value_hm.shape[-1] == 32
+                and value_hm.dtype in (torch.float16, torch.bfloat16) and self.tiled_min_queries_per_region is None)
+
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
                        level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None,
                        query_pos: Optional[Tensor] = None, apply_output_proj: bool = True,
-                       level_shapes=None) -> Tensor:
+                       level_shapes=None, head_major_projection: Optional[Tensor] = None) -> Tensor:
         """``query_pos`` (optional): position embedding still to be added to ``query`` -- folded into the projection
         kernel's prologue on the bf16 path.  ``apply_output_proj=False`` returns the sampled heads ``[B,Nq,E]`` for a
-        caller that fuses ``output_proj`` with what follows it."""
+        caller that fuses ``output_proj`` with what follows it.  ``head_major_projection``: the offset | weight
+        projection ``[B,M,Nq,48]`` if another launch already produced it (``head_major_projection_applies`` says when
+        this method would take that form)."""
         from .filter_ops import token_linear, token_linear_applies
         w, b = self._fused_query_projection()
         # (the token-resident kernel's run time is flat in the token count, ~17 us; below ~12 000 tokens the library GEMM
@@ -568,8 +578,10 @@ class MultiScaleDeformableAttention(nn.Module):
                       and self.tiled_min_queries_per_region is None)
         if head_major:
             # per-head slabs: every XCD's L2 then fetches only its own head's projection values
-            wh, bh = self._fused_query_projection_head_major()
-            proj = token_linear(query, wh, bh, x_add=query_pos, group_features=3 * self.num_levels * self.num_points)
+            proj = head_major_projection
+            if proj is None:
+                wh, bh = self._fused_query_projection_head_major()
+                proj = token_linear(query, wh, bh, x_add=query_pos, group_features=3 * self.num_levels * self.num_points)
             if (self.resident_min_queries is not None and query.shape[1] >= self.resident_min_queries
                     and resident_supported(value_hm, level_shapes, self.num_levels, self.num_points)):
                 out = msda_resident_forward(value_hm, level_shapes, reference_points, proj, out_dtype=query.dtype)

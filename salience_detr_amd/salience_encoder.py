@@ -56,6 +56,9 @@ class SalienceTransformerEncoderLayer(nn.Module):
         # the default on the bf16 path: in-projection (with the gather and the position add in its operand loads) and
         # attention + out_proj + residual + pre_norm + scatter as two launches of csrc/topk_attention.hip
         self.two_launch_topk_attention = True
+        # the MSDA offset | weight projection of the layer's rows rides in the top-k attention's launch
+        # (csrc/fused_head_value.hip); False = a launch of its own after the attention
+        self.carry_sampling_projection = True
         # pre attention
         self.pre_attention = nn.MultiheadAttention(embed_dim, n_heads, dropout, batch_first=True)
         self.pre_dropout = nn.Dropout(dropout)
@@ -160,6 +163,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         With ``advance`` (see ``_forward_ffn_native``) the layer finishes with the encoder's row bookkeeping and
         returns the next layer's queries."""
         c = query.shape[1]
+        proj = None
         if token_linear_applies(query, class_head.weight):
             mc_score = class_head_max_times(query, class_head, fg_sorted[:, :c])   # logits never materialised
         else:
@@ -173,7 +177,12 @@ class SalienceTransformerEncoderLayer(nn.Module):
                 and topk_self_attention_applies(query, pos_sorted, self.pre_attention, self.pre_norm, N)):
             # gather + (x + pos) + in-projection, then attention + out_proj + residual + pre_norm + scatter: two launches,
             # no library GEMM (csrc/topk_attention.hip)
-            topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm)
+            if self.carry_sampling_projection and self.self_attn.head_major_projection_applies(query, value_hm):
+                # the MSDA offset | weight projection of all rows rides in the attention's launch
+                proj = topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm,
+                                            projection=self.self_attn._fused_query_projection_head_major())
+            else:
+                topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm)
             stacked = None
         elif (self.fused_topk_attention and fuse_tail and topk_attention_applies(query, self.pre_attention, N)
                 and not self.training):
@@ -194,7 +203,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
                 fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
             sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
                                                     level_start_index, query_pos=pos_sorted[:, :c],
-                                                    apply_output_proj=False, level_shapes=level_shapes)
+                                                    apply_output_proj=False, level_shapes=level_shapes,
+                                                    head_major_projection=proj)
             # output_proj + residual + norm1 in one launch of the token-resident kernel at every layer size (below ~12 000
             # rows the library GEMM + separate LayerNorm is 1-2 us faster, but keeps hipBLASLt in the hot-path graph)
             query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
