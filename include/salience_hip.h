@@ -633,18 +633,20 @@ int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_
 
 /* sdetr_topk_attention_bf16 of an encoder layer together with the deformable attention's offset | weight projection of
  * the layer's queries (sdetr_token_linear_bf16 with x_add = pos and group_features = 48: the head-major slab
- * [batch, 8, num_rows, 48] the MSDA kernel reads) -- csrc/fused_head_value.hip: in-projection launch, ONE launch for
- * the attention (40 workgroups) and the projection of all rows (from the queries as they stand before the attention;
- * the attention kernel projects its 300 updated rows itself, into `side`), a scatter of those rows over the slab.
+ * [batch, 8, num_rows, 48] the MSDA kernel reads) -- csrc/fused_head_value.hip: in-projection launch, then ONE launch
+ * for the attention (40 workgroups, which also re-project their 300 updated rows) and the projection of all other rows
+ * (from the queries as they stand before the attention).
  *   proj_weight: [384, 256] bf16, rows in head-major order (48 per head); proj_packed / proj_bias_padded: its
- *   sdetr_linear_pack_bf16 packing and zero-padded fp32 bias; side: >= batch * 8 * num_selected * 96 bytes of scratch.
+ *   sdetr_linear_pack_bf16 packing and zero-padded fp32 bias; hint: int32 [batch, hint_batch_stride >= num_rows],
+ *   zero before its first use and left alone by the caller afterwards (the in-projection marks the selected rows in
+ *   it; marks are validated against `selected`, stale ones are harmless).
  *   289 <= num_selected <= 320 only; the layer's queries contiguous [batch, num_rows, 256]. */
 int sdetr_topk_attention_with_projection_bf16(
     sdetr_stream_t stream, void *query, int64_t query_batch_stride, const void *pos, int64_t pos_batch_stride,
     const int64_t *selected, int batch_size, int num_rows, int num_selected, const void *in_proj_weight,
     const void *in_proj_bias, const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
     const void *norm_bias, float norm_eps, void *workspace, int64_t workspace_bytes, const void *proj_weight,
-    const void *proj_packed, const float *proj_bias_padded, void *slab, void *side);
+    const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride);
 /* (internal: the in-projection launch of sdetr_topk_attention_bf16 for csrc/fused_head_value.hip) */
 int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in_args);
 

@@ -45,27 +45,15 @@ __global__ void __launch_bounds__(768, 1) fused_stage2_value_kernel(Stage2Args s
 
 // The top-300 attention (40 workgroups of ~15 us) carries the layer's offset | weight projection of ALL rows
 // (token_linear<kStore, x + pos>, ~107 workgroups x ~17 us): the projection reads the queries as they are before the
-// attention updates 300 of them, the attention kernel projects those 300 rows itself from the updated values into a
-// side buffer, and topk_proj_scatter_kernel puts them over the stale slab rows afterwards (inside one launch the two
-// writers of a slab row would race).
+// attention updates 300 of them and skips those rows (the in-projection launch in front marked them in a hint array
+// that the projection validates against the selection, so stale marks of earlier calls are harmless); the attention
+// kernel projects its 300 rows itself from the updated values.  One writer per slab row, no ordering needed.
 template <int KT>
 __global__ void __launch_bounds__(512, 1) fused_attn_proj_kernel(TkOutArgs at, int at_blocks, TLArgs tl)
 {
     const int blk = (int)blockIdx.x;
     if (blk < at_blocks) topk_attn_out_body<KT>(at, blk);
     else token_linear_body<kStore, true, 4>(tl, blk - at_blocks);
-}
-
-// slab[b][head][sel[b][i]][0..47] = side[b][head][i][0..47]; one 16-byte piece per thread
-__global__ void __launch_bounds__(256) topk_proj_scatter_kernel(const uint4 *side, const int64_t *sel, uint4 *slab, int B,
-                                                                int N, int rows)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)B * kTkHeads * N * 6) return;
-    const int piece = (int)(i % 6);
-    const int64_t r = i / 6;
-    const int qi = (int)(r % N), bh = (int)(r / N), b = bh / kTkHeads;
-    slab[((int64_t)bh * rows + sel[(int64_t)b * N + qi]) * 6 + piece] = side[i];
 }
 
 }  // namespace sdetr
@@ -190,25 +178,26 @@ extern "C" int sdetr_stage1_x3_with_value_proj(
 
 // sdetr_topk_attention_bf16 of an encoder layer + the deformable attention's offset | weight projection of the layer's
 // queries (sdetr_token_linear_bf16 with x_add = pos, group_features = 48: the head-major slab [B, 8, rows, 48] the MSDA
-// kernel reads), as: in-projection launch, ONE launch for attention (40 workgroups) and projection of all rows
-// (from the queries as they stand BEFORE the attention), scatter of the 300 re-projected rows.  `proj_weight` is the
-// plain [384, 256] bf16 weight in head-major row order, `proj_packed` / `proj_bias_padded` its token-linear packing;
-// `side` >= batch * 8 * num_selected * 96 bytes of scratch.  Only for 289..320 selected rows (the model's 300); other
-// counts: call the two operators one after the other.
+// kernel reads): in-projection launch (which also marks the selected rows in `hint`), then ONE launch for the attention
+// (40 workgroups; re-projects its 300 updated rows) and the projection of all other rows.  `proj_weight` is the plain
+// [384, 256] bf16 weight in head-major row order, `proj_packed` / `proj_bias_padded` its token-linear packing; `hint`:
+// int32 [batch, hint_batch_stride >= rows], zero before its first use and otherwise left alone by the caller (marks are
+// validated against the selection, stale ones are harmless).  Only for 289..320 selected rows (the model's 300).
 extern "C" int sdetr_topk_attention_with_projection_bf16(
     sdetr_stream_t stream, void *query, int64_t query_batch_stride, const void *pos, int64_t pos_batch_stride,
     const int64_t *selected, int batch_size, int num_rows, int num_selected, const void *in_proj_weight,
     const void *in_proj_bias, const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
     const void *norm_bias, float norm_eps, void *workspace, int64_t workspace_bytes, const void *proj_weight,
-    const void *proj_packed, const float *proj_bias_padded, void *slab, void *side)
+    const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride)
 {
     if (batch_size <= 0 || num_rows <= 0 || num_selected <= 0 || num_selected > num_rows)
         return fail("topk_attention_with_projection: bad sizes (rows %d, selected %d)", num_rows, num_selected);
     const int npad = (num_selected + 31) / 32 * 32;
     if (npad != 320) return fail("topk_attention_with_projection: built for 289..320 selected rows (got %d)", num_selected);
     if (!query || !pos || !selected || !in_proj_weight || !in_proj_bias || !out_proj_weight || !out_proj_bias ||
-        !norm_weight || !norm_bias || !workspace || !proj_weight || !proj_packed || !proj_bias_padded || !slab || !side)
+        !norm_weight || !norm_bias || !workspace || !proj_weight || !proj_packed || !proj_bias_padded || !slab || !hint)
         return fail("topk_attention_with_projection: null pointer");
+    if (hint_batch_stride < num_rows) return fail("topk_attention_with_projection: hint rows shorter than the layer");
     if (workspace_bytes < (int64_t)batch_size * npad * (512 + 256) * 2)
         return fail("topk_attention_with_projection: workspace too small");
     if (query_batch_stride < (int64_t)num_rows * kTkE || pos_batch_stride < (int64_t)num_rows * kTkE ||
@@ -221,7 +210,7 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     a.query = (const bf16_t *)query; a.q_bs = query_batch_stride; a.pos = (const bf16_t *)pos; a.p_bs = pos_batch_stride;
     a.sel = selected; a.w = (const bf16_t *)in_proj_weight; a.bias = (const bf16_t *)in_proj_bias;
     a.qk = (bf16_t *)workspace; a.vt = a.qk + (int64_t)batch_size * npad * 512;
-    a.B = batch_size; a.N = num_selected; a.Npad = npad;
+    a.B = batch_size; a.N = num_selected; a.Npad = npad; a.hint = hint; a.hint_bs = hint_batch_stride;
     if (int rc = sdetr_topk_inproj_launch(stream, &a)) return rc;
     TkOutArgs o{};
     o.qk = a.qk; o.vt = a.vt; o.sel = selected; o.query = (bf16_t *)query; o.q_bs = query_batch_stride;
@@ -230,12 +219,13 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     o.scale = 0.17677669529663687f;   // 1 / sqrt(32)
     o.B = batch_size; o.N = num_selected; o.Npad = npad;
     o.fx_w = (const bf16_t *)proj_weight; o.fx_b = proj_bias_padded; o.fx_pos = (const bf16_t *)pos;
-    o.fx_p_bs = pos_batch_stride; o.fx_slab = (bf16_t *)side; o.fx_rows = num_selected; o.fx_by_selection = 1;
+    o.fx_p_bs = pos_batch_stride; o.fx_slab = (bf16_t *)slab; o.fx_rows = num_rows; o.fx_by_selection = 0;
     TLArgs t{};
     t.x = (const bf16_t *)query; t.pw = (const char *)proj_packed; t.bias = proj_bias_padded;
     t.T = batch_size * num_rows; t.N = 384; t.ntiles = 12; t.rows_per_batch = num_rows;
     t.x2 = (const bf16_t *)pos; t.x2_batch_stride = pos_batch_stride;
     t.out = (bf16_t *)slab; t.out_row_stride = 384; t.group = 48;
+    t.skip_hint = hint; t.skip_hint_bs = hint_batch_stride; t.skip_sel = selected; t.skip_n = num_selected;
     const int nsteps = (t.ntiles + kTLStepTiles - 1) / kTLStepTiles;
     const size_t lds = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
     static DeviceOnce once;
@@ -243,9 +233,5 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     const int at_blocks = batch_size * ((num_selected + kTkQ - 1) / kTkQ);
     const int tl_blocks = (t.T + kTLTokBlock - 1) / kTLTokBlock;
     hipLaunchKernelGGL((fused_attn_proj_kernel<20>), dim3((unsigned)(at_blocks + tl_blocks)), dim3(512), lds, hs, o, at_blocks, t);
-    if (int rc = check_launch("topk_attention_with_projection")) return rc;
-    const int64_t pieces = (int64_t)batch_size * kTkHeads * num_selected * 6;
-    hipLaunchKernelGGL(topk_proj_scatter_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, hs,
-                       (const uint4 *)side, selected, (uint4 *)slab, batch_size, num_selected, num_rows);
-    return check_launch("topk_proj_scatter");
+    return check_launch("topk_attention_with_projection");
 }

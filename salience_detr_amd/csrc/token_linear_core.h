@@ -27,6 +27,12 @@ struct TLArgs {
     bf16_t *out;
     int64_t out_row_stride;
     int group;                // > 0: features per group, out is [B][N/group][rows_per_batch][group] (head-major)
+    // rows another part of the same launch writes instead (fused_head_value.hip): token (img, ri) is skipped when
+    // skip_hint[img][ri] = m in 1..skip_n and skip_sel[img][m - 1] == ri (hints are validated, stale ones are harmless)
+    const int32_t *skip_hint;
+    int64_t skip_hint_bs;
+    const int64_t *skip_sel;
+    int skip_n;
     // kHeadMajor
     const uint8_t *pad;       // [T] or NULL
     void *hm;                 // [groups][B][M][rows_per_batch][32]
@@ -187,6 +193,11 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
 
     float run_max = -INFINITY;
     const bool masked = EPI == kHeadMajor && p.pad && p.pad[tk];
+    bool skip = false;
+    if (EPI == kStore && p.skip_hint) {
+        const int m = p.skip_hint[(int64_t)img * p.skip_hint_bs + ri];
+        if (m > 0 && m <= p.skip_n) skip = p.skip_sel[(int64_t)img * p.skip_n + m - 1] == ri;
+    }
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my activations and the staged bias
     __builtin_amdgcn_s_barrier();
@@ -260,7 +271,7 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
                         d[4 * m + w] = r[0];
                         d[4 * m + 2 + w] = r[1];
                     }
-                if (!valid) continue;
+                if (!valid || skip) continue;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     // d[4m .. 4m+3] = features 16 m + 8 h + {0..7} of tile nt

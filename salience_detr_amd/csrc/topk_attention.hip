@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
     const int i = tile * 32 + t;                          // my token (as B-operand / accumulator column)
     const bool valid = i < p.N;
     const int64_t row = p.sel[(int64_t)b * p.N + min(i, p.N - 1)];
+    if (p.hint && ftile == 0 && h == 0 && valid) p.hint[(int64_t)b * p.hint_bs + row] = i + 1;
     const bf16_t *xr = p.query + (int64_t)b * p.q_bs + row * kTkE + 8 * h;
     const bf16_t *pr = p.pos + (int64_t)b * p.p_bs + row * kTkE + 8 * h;
     const bf16_t *wr = p.w + (int64_t)(ftile * 32 + t) * kTkE + 8 * h;

@@ -36,6 +36,8 @@ struct TkInArgs {
     bf16_t *qk;            // q rows [B, Npad, 256], then the K fragments [B, 8, Npad/16, 64 lanes, 8]
     bf16_t *vt;            // V^T fragments [B, 8, Npad/32, 2, 64 lanes, 8]
     int B, N, Npad;
+    int32_t *hint;         // optional [B, hint_bs]: hint[b][sel[b][i]] = i + 1 (see TLArgs::skip_hint)
+    int64_t hint_bs;
 };
 // Fragment-major K and V^T: the attention kernel's operand fragments are stored exactly as its lanes hold them, so
 // each of its loads is one contiguous kilobyte per wave (row-major slabs made every K load touch 16 rows and every
@@ -101,8 +103,7 @@ struct TkOutArgs {
     bf16_t *fx_slab;       // [B, 8, fx_rows, 48]
     int fx_rows;
     int fx_by_selection;   // 0: row index = the query's row in the layer (writes the MSDA slab itself); 1: its position
-                           // in the selection (a side buffer [B, 8, N, 48] that topk_proj_scatter_kernel applies later:
-                           // needed when the slab is being written by another part of the same launch)
+                           // in the selection (a side buffer [B, 8, N, 48])
 };
 
 typedef float tk_f32x4_t __attribute__((ext_vector_type(4)));
