@@ -387,6 +387,30 @@ int sdetr_salience_head_stage1_x3(sdetr_stream_t stream, const float *x, int64_t
  * (csrc/fused_head_value.hip): the stage-1 launches of the two coarsest levels leave the chip nearly empty, the value
  * projection depends only on the flattened tokens -- workgroups [0, blocks * batch) run stage 1, the rest the
  * projection. */
+/* A masked top-k by rank counting, as a job another launch carries (the arguments of sdetr_masked_topk_desc_f32 with
+ * fill_mode 2 -- or no mask --, no payload; rows short enough that no prefilter is involved):
+ * sdetr_stage1_x3_with_jobs = sdetr_salience_head_stage1_x3 + an optional value-projection job (vp_x != NULL) + an
+ * optional rank job in one launch. */
+typedef struct {
+    const float *score;          /* [batch, n] */
+    const uint8_t *mask;         /* [batch, n] rows mask_row_stride bytes apart, or NULL */
+    int64_t mask_row_stride;
+    const float *fill_value;     /* device scalar substituted for masked scores */
+    int batch, n, k;
+    int64_t index_offset;
+    float *out_score;            /* [batch, k] rows out_row_stride apart, or NULL */
+    int64_t *out_index;
+    int64_t out_row_stride;
+} sdetr_rank_job;
+int sdetr_stage1_x3_with_jobs(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
+    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
+    float *z_local, float *partial_sums, const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded,
+    const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
+    void *vp_dst, int vp_dst_dtype, const sdetr_rank_job *rank);
 int sdetr_stage1_x3_with_value_proj(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,

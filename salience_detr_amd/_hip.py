@@ -19,6 +19,14 @@ EINVAL = -1
 _lib = None
 
 _i = ctypes.c_int
+
+
+class RankJobStruct(ctypes.Structure):
+    """``sdetr_rank_job`` of include/salience_hip.h."""
+    _fields_ = [("score", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("mask_row_stride", ctypes.c_int64),
+                ("fill_value", ctypes.c_void_p), ("batch", ctypes.c_int), ("n", ctypes.c_int), ("k", ctypes.c_int),
+                ("index_offset", ctypes.c_int64), ("out_score", ctypes.c_void_p), ("out_index", ctypes.c_void_p),
+                ("out_row_stride", ctypes.c_int64)]
 _i64 = ctypes.c_int64
 _p = ctypes.c_void_p
 _sz = ctypes.c_size_t
@@ -48,6 +56,7 @@ SIGNATURES = {
     "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sdetr_topk_uses_prefilter": (_i, [_i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
     "sdetr_merge_sorted_desc": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sdetr_masked_fill_min": (_i, [_p, _p, _p, _p, _i, _i64, _p]),
@@ -83,6 +92,9 @@ SIGNATURES = {
     "sdetr_stage1_x3_with_value_proj": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
                                              _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+    "sdetr_stage1_x3_with_jobs": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
+                                        _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
+                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "sdetr_pack_linear_bf16x3": (_i, [_p, _p, _i64, _i, _i, _p]),
     "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "sdetr_ffn_packed_bytes": (_i64, [_i]),

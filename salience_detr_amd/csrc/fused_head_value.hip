@@ -13,18 +13,45 @@
 #include "salience_head_core.h"
 #include "token_linear_core.h"
 #include "topk_attention_core.h"
+#include "topk_core.h"
 
 namespace sdetr {
 
-__global__ void __launch_bounds__(768, 1) fused_stage1_value_kernel(Stage1Args s1, int s1_blocks, int s1_images, TLArgs tl)
+// Roles by block index: [0, n1) stage 1 of the head; then `tl_blocks` workgroups of the value projection; then the
+// rank-by-counting top-k of the NEXT COARSER level (its indices are not needed before the merge at the end of the
+// filtering, its scores are: the level's stage 2 has run) -- `rk_blocks_x` key blocks x `rk_rows` rows.
+__global__ void __launch_bounds__(768, 1) fused_stage1_value_kernel(Stage1Args s1, int s1_blocks, int s1_images, TLArgs tl,
+                                                                    int tl_blocks, RankArgs rk, int rk_blocks_x)
 {
+    extern __shared__ __attribute__((aligned(16))) char fused_lds[];
     const int blk = (int)blockIdx.x;
     const int n1 = s1_blocks * s1_images;   // stage-1 workgroups: (image, token block) folded into blockIdx.x
     if (blk < n1) {
         if (threadIdx.x >= 512) return;
         stage1_x3_body(s1, blk % s1_blocks, blk / s1_blocks);
-    } else {
+    } else if (blk < n1 + tl_blocks) {
         token_linear_body<kHeadMajor, false, 8>(tl, blk - n1);
+    } else {
+        if (threadIdx.x >= kRankThreads) return;
+        const int r = blk - n1 - tl_blocks;
+        uint32_t *lds = reinterpret_cast<uint32_t *>(fused_lds);
+        topk_rank_body(rk, r % rk_blocks_x, r / rk_blocks_x, lds, lds + kRankTile);
+    }
+}
+
+// Stage 1 with only a rank job: the head kernel's own shape (512 threads, two workgroups per CU).
+__global__ void __launch_bounds__(512, 2) fused_stage1_rank_kernel(Stage1Args s1, int s1_blocks, int s1_images, RankArgs rk,
+                                                                   int rk_blocks_x)
+{
+    extern __shared__ __attribute__((aligned(16))) char fused_lds[];
+    const int blk = (int)blockIdx.x;
+    const int n1 = s1_blocks * s1_images;
+    if (blk < n1) {
+        stage1_x3_body(s1, blk % s1_blocks, blk / s1_blocks);
+    } else {
+        const int r = blk - n1;
+        uint32_t *lds = reinterpret_cast<uint32_t *>(fused_lds);
+        topk_rank_body(rk, r % rk_blocks_x, r / rk_blocks_x, lds, lds + kRankTile);
     }
 }
 
@@ -83,6 +110,101 @@ static int fill_value_job(TLArgs &t, size_t &lds_tl, int &n2, const void *vp_x, 
     return 0;
 }
 
+// sdetr_salience_head_stage1_x3 (same arguments) + up to two jobs carried by the same launch: the value projection of
+// `vp_num_groups` stacked layers (arguments of sdetr_value_proj_head_major; `vp_packed_weight`, `vp_bias_padded` and
+// `vp_dst` already point at the first of those layers; vp_x == NULL: none) and a plain masked top-k by rank counting
+// (`rank`: the arguments of sdetr_masked_topk_desc_f32 with fill_mode 2 and no payload / prefilter; NULL: none).
+extern "C" int sdetr_stage1_x3_with_jobs(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
+    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
+    float *z_local, float *partial_sums,
+    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+    const sdetr_rank_job *rank)
+{
+    if (channels != kC) return fail("stage1_x3_with_jobs: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
+    if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_jobs: empty level");
+    if (!x || !norm_weight || !norm_bias || !weight_x3 || !bias || !z_local || !partial_sums)
+        return fail("stage1_x3_with_jobs: NULL pointer");
+    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
+        return fail("stage1_x3_with_jobs: enc_output parameters incomplete");
+    if (row_scale && coarse_score) return fail("stage1_x3_with_jobs: give row_scale OR coarse_score");
+    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
+        return fail("stage1_x3_with_jobs: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
+    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("stage1_x3_with_jobs: rows must be 16-byte aligned");
+    Stage1Args a;
+    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
+    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
+    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
+    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
+    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
+    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = bias;
+    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
+    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = (tokens + 31) / 32;
+    const int n1 = a.nblk * batch_size;
+    const size_t lds_s1 = (size_t)kX3Region + (kParRows * kC + 32 + 4) * sizeof(float);
+    // the rank job
+    RankArgs r{};
+    int rk_bx = 1, n3 = 0;
+    size_t lds_rk = 0;
+    if (rank) {
+        if (rank->batch <= 0 || rank->n <= 0 || rank->k <= 0 || rank->k > rank->n || !rank->score || !rank->out_index)
+            return fail("stage1_x3_with_jobs: bad rank job");
+        if (rank->n >= (1 << 30) || rank->batch > 65535) return fail("stage1_x3_with_jobs: rank row too long / too many rows");
+        const int64_t ors = rank->out_row_stride ? rank->out_row_stride : rank->k;
+        const int64_t mrs = rank->mask && !rank->mask_row_stride ? rank->n : rank->mask_row_stride;
+        if (ors < rank->k || (rank->mask && mrs < rank->n)) return fail("stage1_x3_with_jobs: rank job strides too small");
+        if (rank->mask && !rank->fill_value) return fail("stage1_x3_with_jobs: a masked rank job needs its fill value");
+        r.score = rank->score; r.mask = rank->mask; r.mask_stride = mrs; r.fill = rank->fill_value; r.N = rank->n;
+        r.k = rank->k; r.index_offset = rank->index_offset; r.out_score = rank->out_score; r.out_index = rank->out_index;
+        r.out_stride = ors;
+        rk_bx = (rank->n + 63) / 64;
+        n3 = rk_bx * rank->batch;
+        lds_rk = (size_t)kRankLdsWords * 4;
+    }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (!vp_x) {
+        const size_t lds = lds_s1 > lds_rk ? lds_s1 : lds_rk;
+        hipLaunchKernelGGL(fused_stage1_rank_kernel, dim3((unsigned)(n1 + n3)), dim3(512), lds, hs, a, a.nblk, batch_size, r, rk_bx);
+        return check_launch("stage1_x3_with_jobs");
+    }
+    TLArgs t;
+    size_t lds_tl = 0;
+    int n2 = 0;
+    if (int rc = fill_value_job(t, lds_tl, n2, vp_x, vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size,
+                                vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype))
+        return rc;
+    size_t lds = lds_tl > lds_s1 ? lds_tl : lds_s1;
+    if (lds_rk > lds) lds = lds_rk;
+    static DeviceOnce once;
+    allow_dynamic_lds(fused_stage1_value_kernel, once, 160 * 1024);
+    hipLaunchKernelGGL(fused_stage1_value_kernel, dim3((unsigned)(n1 + n2 + n3)), dim3(768), lds, hs, a, a.nblk, batch_size, t,
+                       n2, r, rk_bx);
+    return check_launch("stage1_x3_with_jobs");
+}
+
+extern "C" int sdetr_stage1_x3_with_value_proj(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
+    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
+    float *z_local, float *partial_sums,
+    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+{
+    if (!vp_x) return fail("stage1_x3_with_value_proj: NULL pointer");
+    return sdetr_stage1_x3_with_jobs(stream, x, x_batch_stride, x_row_stride, batch_size, tokens, channels, enc_weight_x3,
+                                     enc_bias, enc_norm_weight, enc_norm_bias, enc_norm_eps, row_scale, coarse_score,
+                                     coarse_h, coarse_w, level_h, level_w, alpha, norm_weight, norm_bias, norm_eps,
+                                     weight_x3, bias, memory_out, memory_batch_stride, z_local, partial_sums, vp_x,
+                                     vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size, vp_spatial_size,
+                                     vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, nullptr);
+}
+
 // The stage-2 half of sdetr_salience_head_stage2 (the caller has launched the per-image constant already:
 // `const_workspace` holds it) + a value-projection job in one launch.
 extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *z_local, int batch_size, int tokens,
@@ -117,63 +239,6 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
     hipLaunchKernelGGL(fused_stage2_value_kernel, dim3((unsigned)(nblk * batch_size + n2)), dim3(768), lds,
                        static_cast<hipStream_t>(stream), a, nblk, batch_size, t);
     return check_launch("stage2_with_value_proj");
-}
-
-// sdetr_salience_head_stage1_x3 (same arguments, same checks by the caller's usual entry) + the value projection of
-// `num_groups` stacked layers of sdetr_value_proj_head_major (same arguments; `packed_weight`, `bias_padded` and
-// `dst` already point at the first of those layers) in one launch.
-extern "C" int sdetr_stage1_x3_with_value_proj(
-    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
-    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
-    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
-    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
-    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
-    float *z_local, float *partial_sums,
-    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
-    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
-{
-    if (channels != kC) return fail("stage1_x3_with_value_proj: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
-    if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_value_proj: empty level");
-    if (!x || !norm_weight || !norm_bias || !weight_x3 || !bias || !z_local || !partial_sums)
-        return fail("stage1_x3_with_value_proj: NULL pointer");
-    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
-        return fail("stage1_x3_with_value_proj: enc_output parameters incomplete");
-    if (row_scale && coarse_score) return fail("stage1_x3_with_value_proj: give row_scale OR coarse_score");
-    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
-        return fail("stage1_x3_with_value_proj: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
-    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("stage1_x3_with_value_proj: rows must be 16-byte aligned");
-    if (vp_batch_size <= 0 || vp_spatial_size <= 0 || vp_num_heads <= 0 || vp_num_groups <= 0)
-        return fail("stage1_x3_with_value_proj: bad value-projection sizes");
-    if (vp_dst_dtype != SDETR_F16 && vp_dst_dtype != SDETR_BF16) return fail("stage1_x3_with_value_proj: dst must be fp16 or bf16");
-    if (!vp_x || !vp_packed_weight || !vp_bias_padded || !vp_dst) return fail("stage1_x3_with_value_proj: NULL pointer");
-    const int64_t vp_tokens = (int64_t)vp_batch_size * vp_spatial_size;
-    if (vp_tokens > 0x7fffffff) return fail("stage1_x3_with_value_proj: too many tokens");
-    Stage1Args a;
-    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
-    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
-    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
-    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
-    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
-    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = bias;
-    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
-    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = (tokens + 31) / 32;
-    TLArgs t{};
-    t.x = (const bf16_t *)vp_x; t.pw = (const char *)vp_packed_weight; t.bias = vp_bias_padded; t.T = (int)vp_tokens;
-    t.N = vp_num_groups * vp_num_heads * 32; t.ntiles = t.N / 32; t.rows_per_batch = vp_spatial_size;
-    t.pad = vp_pad_mask; t.hm = vp_dst; t.heads = vp_num_heads; t.batch = vp_batch_size; t.hm_f16 = vp_dst_dtype == SDETR_F16;
-    const int nsteps = (t.ntiles + kTLStepTiles - 1) / kTLStepTiles;
-    if ((size_t)t.ntiles * 128 + 2 * kTLStepBytes + 1024 > 160 * 1024) return fail("stage1_x3_with_value_proj: too many output features");
-    const size_t lds_tl = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
-    const size_t lds_s1 = (size_t)kX3Region + (kParRows * kC + 32 + 4) * sizeof(float);
-    const size_t lds = lds_tl > lds_s1 ? lds_tl : lds_s1;
-    static DeviceOnce once;
-    allow_dynamic_lds(fused_stage1_value_kernel, once, 160 * 1024);
-    const int n1 = a.nblk * batch_size;
-    const int tpb = kTLTokWave * 8;
-    const int n2 = (int)((vp_tokens + tpb - 1) / tpb);
-    hipLaunchKernelGGL(fused_stage1_value_kernel, dim3((unsigned)(n1 + n2)), dim3(768), lds, static_cast<hipStream_t>(stream),
-                       a, a.nblk, batch_size, t);
-    return check_launch("stage1_x3_with_value_proj");
 }
 
 // sdetr_topk_attention_bf16 of an encoder layer + the deformable attention's offset | weight projection of the layer's

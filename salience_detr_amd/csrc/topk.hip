@@ -29,25 +29,9 @@
 //   after every candidate, so candidate ranks are global ranks).  Exactness never depends on the sample.
 #include "common.h"
 
+#include "topk_core.h"
+
 namespace sdetr {
-
-constexpr int kRankThreads = 512;   // 8 waves share a workgroup's list scan (4 until round 2: the per-lane loop was the kernel's time)
-constexpr int kRankWaves = kRankThreads / 64;
-constexpr int kRankTile = 12288;  // keys staged per LDS round (48 KiB)
-
-__device__ __forceinline__ uint32_t desc_bits(float s)
-{
-    if (s == 0.f) s = 0.f;  // -0 == +0
-    const uint32_t u = __float_as_uint(s);
-    const uint32_t asc = u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
-    return ~asc;
-}
-__device__ __forceinline__ float undesc_bits(uint32_t d)
-{
-    const uint32_t asc = ~d;
-    const uint32_t u = (asc & 0x80000000u) ? (asc ^ 0x80000000u) : ~asc;
-    return __uint_as_float(u);
-}
 
 __global__ void __launch_bounds__(1024) topk_min_kernel(const float *score, int64_t total, float *out)
 {
@@ -207,120 +191,11 @@ __global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterAr
     if (tid == 0) p.cand_count[b] = (int)total;
 }
 
-struct RankArgs {
-    const float *score;
-    const uint8_t *mask;
-    int64_t mask_stride;  // bytes between mask rows
-    const float *fill;  // device scalar or NULL
-    const int64_t *payload;
-    // candidate mode (after topk_prefilter): keys / positions / count per row instead of raw scores
-    const uint32_t *cand_key;
-    const uint32_t *cand_pos;
-    const int32_t *cand_count;
-    int N, k;
-    int64_t index_offset;
-    float *out_score;
-    int64_t *out_index;
-    int64_t out_stride;   // elements between output rows (>= k)
-};
-
 __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile[kRankTile];
-    __shared__ uint32_t partial[kRankWaves][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int base = blockIdx.x * 64;  // owned keys [base, base+64)
-    const bool cand = p.cand_key != nullptr;
-    const int n_keys = cand ? p.cand_count[b] : p.N;  // length of the ranked list
-    if (base >= n_keys) return;                        // uniform per workgroup
-    const float *srow = p.score + (int64_t)b * p.N;
-    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
-    const uint32_t *ckey = cand ? p.cand_key + (int64_t)b * p.N : nullptr;
-    const float fill = p.fill ? *p.fill : 0.f;
-    auto key_at = [&](int i) -> uint32_t {  // i < n_keys
-        if (cand) return ckey[i];
-        float s = srow[i];
-        if (mrow && mrow[i]) s = fill;
-        return desc_bits(s);
-    };
-    const int mypos = base + lane;
-    const uint32_t mine = mypos < n_keys ? key_at(mypos) : 0u;
-    uint32_t rank = 0;
-
-    for (int t0 = 0; t0 < n_keys; t0 += kRankTile) {
-        const int tn = min(kRankTile, n_keys - t0);
-        if (t0 > 0) __syncthreads();
-        // stage: all global loads of this thread first (<= 48 scalars), then the LDS stores; padding keys
-        // (positions >= N) are 0xffffffff, which no "<" test counts and whose positions fail the tie rule
-        constexpr int kPer = kRankTile / kRankThreads;  // 24
-        for (int c0 = 0; c0 < kPer; c0 += 12) {
-            uint32_t kv[12];
-            if (cand) {
-#pragma unroll
-                for (int c = 0; c < 12; ++c) kv[c] = ckey[min(t0 + (c0 + c) * kRankThreads + tid, n_keys - 1)];
-            } else {
-                float sv[12];
-                uint8_t mk[12];
-#pragma unroll
-                for (int c = 0; c < 12; ++c) sv[c] = srow[min(t0 + (c0 + c) * kRankThreads + tid, n_keys - 1)];
-#pragma unroll
-                for (int c = 0; c < 12; ++c)
-                    mk[c] = mrow ? mrow[min(t0 + (c0 + c) * kRankThreads + tid, n_keys - 1)] : (uint8_t)0;
-#pragma unroll
-                for (int c = 0; c < 12; ++c) kv[c] = desc_bits(mk[c] ? fill : sv[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const int li = (c0 + c) * kRankThreads + tid;
-                if (li < ((tn + 3) & ~3)) tile[li] = (t0 + li < n_keys) ? kv[c] : 0xffffffffu;
-            }
-            if ((c0 + 12) * kRankThreads >= tn) break;
-        }
-        __syncthreads();
-        // groups of 4 keys, round-robin over the wavefronts; the list splits into three ranges relative to
-        // the owned block so every loop body is branch-free and the LDS reads pipeline (8 in flight)
-        const int ngroups = (tn + 3) / 4;
-        const uint4 *t4 = reinterpret_cast<const uint4 *>(tile);
-        const int g_own0 = min(ngroups, max(0, (base - t0) / 4));           // first group inside the owned block
-        const int g_own1 = min(ngroups, max(0, (base + 64 - t0 + 3) / 4));  // first group after it
-        auto first_at_or_after = [&](int g0) { return g0 + ((wave - g0) % kRankWaves + kRankWaves) % kRankWaves; };
-        int g = wave;
-#pragma unroll 8
-        for (; g < g_own0; g += kRankWaves) {  // before: ties sort before us
-            const uint4 c = t4[g];
-            rank += (c.x <= mine) + (c.y <= mine) + (c.z <= mine) + (c.w <= mine);
-        }
-        for (g = first_at_or_after(g_own0); g < g_own1; g += kRankWaves) {  // inside: exact positional tie rule
-            const uint4 c = t4[g];
-            const int j = t0 + g * 4;
-            rank += (c.x < mine || (c.x == mine && j + 0 < mypos)) ? 1u : 0u;
-            rank += (c.y < mine || (c.y == mine && j + 1 < mypos)) ? 1u : 0u;
-            rank += (c.z < mine || (c.z == mine && j + 2 < mypos)) ? 1u : 0u;
-            rank += (c.w < mine || (c.w == mine && j + 3 < mypos)) ? 1u : 0u;
-        }
-        g = first_at_or_after(g_own1);
-#pragma unroll 8
-        for (; g < ngroups; g += kRankWaves) {  // after: ties sort after us (padding keys 0xffffffff are never "<")
-            const uint4 c = t4[g];
-            rank += (c.x < mine) + (c.y < mine) + (c.z < mine) + (c.w < mine);
-        }
-    }
-    partial[wave][lane] = rank;
-    __syncthreads();
-    if (wave == 0 && mypos < n_keys) {
-        uint32_t r = 0;
-#pragma unroll
-        for (int w = 0; w < kRankWaves; ++w) r += partial[w][lane];
-        if (r < (uint32_t)p.k) {
-            const int pos = cand ? (int)p.cand_pos[(int64_t)b * p.N + mypos] : mypos;
-            if (p.out_score) p.out_score[(int64_t)b * p.out_stride + r] = undesc_bits(mine);
-            p.out_index[(int64_t)b * p.out_stride + r] =
-                p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
-        }
-    }
+    __shared__ __attribute__((aligned(16))) uint32_t rank_lds[kRankLdsWords];
+    topk_rank_body(p, (int)blockIdx.x, (int)blockIdx.y, rank_lds, rank_lds + kRankTile);
 }
-
 
 // ---- merge of descending-sorted segments ------------------------------------------------------------------------
 // The global sort of salience_transformer.py:156-158 runs over the concatenation of the per-level top-k results,
@@ -374,6 +249,9 @@ static bool use_prefilter(int n, int k)
     // worth it when the ranked set shrinks at least ~2x and the row fits the register-resident prefilter
     return n >= 2048 && n <= kPreThreads * 24 && (int64_t)k * 5 <= (int64_t)n * 2;
 }
+
+// whether sdetr_masked_topk_desc_f32 puts the sampled-threshold prefilter in front of the rank kernel for this shape
+extern "C" int sdetr_topk_uses_prefilter(int n, int k) { return use_prefilter(n, k) ? 1 : 0; }
 
 extern "C" size_t sdetr_topk_workspace_bytes(int B, int n, int k)
 {

@@ -1,5 +1,6 @@
 """Host wrappers of the filtering / row-movement kernels (C ABI sections (4) and (5) of
 include/salience_hip.h).  PyTorch only owns the memory and the stream."""
+import ctypes
 import math
 from typing import Optional
 
@@ -66,6 +67,57 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
             _hip.ptr(ws), ws_bytes)
     _hip.check(code, "masked_topk_desc")
     return out_score, out_index
+
+
+class RankJob:
+    """A plain masked top-k (``masked_topk_desc`` with a given ``fill_value``, no payload, a row short enough that no
+    prefilter is involved) that has not been launched yet: ``salience_head(..., rank_job=job)`` carries it in its
+    stage-1 launch, ``job.run()`` launches it on its own.  The outputs are the ``out`` slices it was planned with."""
+
+    def __init__(self, score, k, mask, fill_value, index_offset, out):
+        self.score, self.k, self.mask, self.fill_value, self.index_offset, self.out = score, int(k), mask, fill_value, index_offset, out
+        self.done = False
+
+    def struct(self):
+        B, N = self.score.shape
+        mask = self.mask
+        if mask is not None:
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        out_score, out_index = self.out
+        st = _hip.RankJobStruct()
+        st.score = self.score.data_ptr()
+        st.mask = _hip.ptr(mask)
+        st.mask_row_stride = (mask.stride(0) if B > 1 else N) if mask is not None else 0
+        st.fill_value = _hip.ptr(self.fill_value)
+        st.batch, st.n, st.k = B, N, self.k
+        st.index_offset = int(self.index_offset)
+        st.out_score = _hip.ptr(out_score)
+        st.out_index = out_index.data_ptr()
+        st.out_row_stride = out_index.stride(0) if B > 1 else self.k
+        self._keep = (mask, st)
+        return st
+
+    def run(self):
+        if self.done:
+            return
+        masked_topk_desc(self.score, self.k, mask=self.mask, fill_with_global_min=self.mask is not None,
+                         index_offset=self.index_offset, fill_value=self.fill_value, out=self.out)
+        self.done = True
+
+
+def plan_masked_topk(score: Tensor, k: int, mask: Optional[Tensor], fill_value: Tensor, index_offset: int, out):
+    """``masked_topk_desc(score, k, mask, True, index_offset=..., fill_value=..., out=out)`` as a pending ``RankJob`` when
+    the launch would be the rank kernel alone (no prefilter, a contiguous fp32 ``score`` with a contiguous-row mask);
+    otherwise runs it now and returns ``None``."""
+    B, N = score.shape
+    plain = (score.is_cuda and score.dtype == torch.float32 and score.is_contiguous() and 0 < int(k) <= N
+             and fill_value is not None and not _hip.lib().sdetr_topk_uses_prefilter(N, int(k))
+             and (mask is None or (mask.shape == score.shape and (N == 1 or mask.stride(1) == 1))))
+    if not plain:
+        masked_topk_desc(score, k, mask=mask, fill_with_global_min=mask is not None, index_offset=index_offset,
+                         fill_value=fill_value, out=out)
+        return None
+    return RankJob(score, k, mask, fill_value, index_offset, out)
 
 
 def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
@@ -350,7 +402,7 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
                   level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
                   memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
                   score_min: Optional[Tensor] = None, value_job: Optional[ValueProjectionJob] = None,
-                  value_job2: Optional[ValueProjectionJob] = None) -> Tensor:
+                  value_job2: Optional[ValueProjectionJob] = None, rank_job: Optional["RankJob"] = None) -> Tensor:
     """The salience head on one level in three launches (include/salience_hip.h (6)).
 
     ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
@@ -361,7 +413,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy; ``score_min`` (one-element
     fp32 tensor) the minimum over all ``B*n`` scores.  ``value_job``: a pending slice of the encoder's value projection
     that stage 1's launch carries along (bf16x3 kernel only; otherwise it is left pending), ``value_job2`` one for
-    stage 2's launch.  Returns ``[B,n]``."""
+    stage 2's launch; ``rank_job``: a pending top-k of the next coarser level, also for stage 1's launch.
+    Returns ``[B,n]``."""
     if not x.is_cuda:
         raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
     if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
@@ -410,9 +463,16 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps),
             packed_linear_weight(l1.weight, split3=x3).data_ptr(),
             l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
-        if x3 and value_job is not None and not value_job.done and value_job.value.device == x.device:
-            code = lib.sdetr_stage1_x3_with_value_proj(*stage1_args, *value_job.pointers())
-            value_job.done = True
+        carry_value = x3 and value_job is not None and not value_job.done and value_job.value.device == x.device
+        carry_rank = x3 and rank_job is not None and not rank_job.done and rank_job.score.device == x.device
+        if carry_value or carry_rank:
+            vp = value_job.pointers() if carry_value else (None, None, None, None, 0, 0, 0, 0, None, 0)
+            rk = ctypes.byref(rank_job.struct()) if carry_rank else None
+            code = lib.sdetr_stage1_x3_with_jobs(*stage1_args, *vp, rk)
+            if carry_value:
+                value_job.done = True
+            if carry_rank:
+                rank_job.done = True
         else:
             stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
             code = stage1(*stage1_args)

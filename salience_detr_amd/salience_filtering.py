@@ -21,7 +21,7 @@ from torch.nn import functional as F
 
 from . import pyramid
 from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, merge_sorted_desc,
-                         salience_head)
+                         plan_masked_topk, salience_head)
 
 
 class MaskPredictor(nn.Module):
@@ -125,6 +125,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     if enc_output is not None and not fused:
         raise RuntimeError("level_filtering: enc_output fusion needs the no-grad fp32 256-wide MaskPredictor path")
     level_min = sel_score = sel_inds = None
+    pending_rank = None
+    defer_ranks = fused
     if fused:
         # per-level minima (stage 2 takes them) and ONE [B, sum k] buffer pair the per-level top-k calls fill column
         # block by column block (the concatenation of :155 for free)
@@ -148,13 +150,20 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 memory_out=None if memory_out is None else memory_out[:, start:start + h * w, :],
                 score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
                 score_min=level_min[lvl:lvl + 1],
-                **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None))
+                rank_job=pending_rank, **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None))
+            if pending_rank is not None:
+                pending_rank.run()          # (no-op when stage 1 carried it)
+                pending_rank = None
             score = token_score.view(B, 1, h, w)
-            # the strided mask slice and the minimum stage 2 already took go straight to the kernel
-            ls, li = masked_topk_desc(token_score, ks[lvl], mask=mask, fill_with_global_min=True, index_offset=start,
-                                      fill_value=level_min[lvl:lvl + 1],
-                                      out=(sel_score[:, offs[lvl]:offs[lvl] + ks[lvl]],
-                                           sel_inds[:, offs[lvl]:offs[lvl] + ks[lvl]]))
+            # the strided mask slice and the minimum stage 2 already took go straight to the kernel.  The level's
+            # INDICES are not needed before the merge at the end of the filtering (only its scores feed the next finer
+            # level), so the rank launch of every level but the finest is deferred: the next level's stage 1 carries it
+            ls, li = sel_score[:, offs[lvl]:offs[lvl] + ks[lvl]], sel_inds[:, offs[lvl]:offs[lvl] + ks[lvl]]
+            if lvl > 0 and defer_ranks:
+                pending_rank = plan_masked_topk(token_score, ks[lvl], mask, level_min[lvl:lvl + 1], start, (ls, li))
+            else:
+                masked_topk_desc(token_score, ks[lvl], mask=mask, fill_with_global_min=True, index_offset=start,
+                                 fill_value=level_min[lvl:lvl + 1], out=(ls, li))
             salience_score[lvl], level_inds[lvl], level_score[lvl] = score, li, ls
             continue
         mask = mask.contiguous()

@@ -666,3 +666,43 @@ def test_salience_head_carrying_a_value_projection_job(n, hw, mode):
         jobs[2].run()   # idempotent
     assert torch.equal(got_score, want_score) and torch.equal(mem_a, mem_b)
     assert torch.equal(maps, want_maps)
+
+
+def test_salience_head_carrying_a_rank_job():
+    """fused_head_value.hip: stage 1 of a level also carries the (deferred) top-k of the next coarser level -- with and
+    without a value-projection job in the same launch -- and gives the bits of the separate launches."""
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    torch.manual_seed(11)
+    B, C, n = 2, 256, 1050
+    pred = MaskPredictor(C, C).to(DEV)
+    x = (syn.det_randn("rjx", (B, n, C)) * 1.1).to(DEV)
+    score = syn.det_randn("rjs", (B, 4200)).to(DEV)
+    score[0, 100:140] = score[0, 7]                      # ties: resolved by position
+    mask = torch.zeros(B, 6000, dtype=torch.bool, device=DEV)[:, 900:5100]
+    mask[:, 4000:] = True
+    fill = score.min().reshape(1)
+    k = 3360
+    want_s, want_i = F.masked_topk_desc(score, k, mask=mask, fill_with_global_min=True, index_offset=21, fill_value=fill)
+    tokens = syn.det_randn("rjt", (B, 900, C)).to(DEV).to(torch.bfloat16)
+    w = (syn.det_randn("rjw", (2 * 8 * 32, C)) * 0.05).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        want_head = F.salience_head(x, pred)
+        want_maps = F.value_proj_head_major(tokens, w, None, None, 8, 2, torch.float16)
+        for with_value in (False, True):
+            out = (torch.full((B, k + 5), -1.0, device=DEV), torch.full((B, k + 5), -1, dtype=torch.int64, device=DEV))
+            job = F.plan_masked_topk(score, k, mask, fill, 21, (out[0][:, 2:2 + k], out[1][:, 2:2 + k]))
+            assert job is not None and not job.done
+            vjob = None
+            if with_value:
+                maps, (vjob,) = F.plan_value_projection(tokens, w, None, None, 8, 2, torch.float16, parts=1)
+            got_head = F.salience_head(x, pred, rank_job=job, value_job=vjob)
+            assert job.done and torch.equal(got_head, want_head)
+            assert torch.equal(out[0][:, 2:2 + k], want_s) and torch.equal(out[1][:, 2:2 + k], want_i)
+            assert (out[1][:, :2] == -1).all() and (out[1][:, 2 + k:] == -1).all()
+            if with_value:
+                assert vjob.done and torch.equal(maps, want_maps)
+    # a shape that needs the prefilter is run at once instead of being planned
+    big = syn.det_randn("rjb", (B, 16800)).to(DEV)
+    o = (torch.empty(B, 300, device=DEV), torch.empty(B, 300, dtype=torch.int64, device=DEV))
+    assert F.plan_masked_topk(big, 300, None, fill, 0, o) is None
+    assert torch.equal(o[1], F.masked_topk_desc(big, 300)[1])
