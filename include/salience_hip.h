@@ -225,6 +225,8 @@ int sdetr_topk_attention_bf16(sdetr_stream_t stream, void *query, int64_t query_
  *   when that returns 0, i.e. whenever the problem fits the in-LDS path).
  * ------------------------------------------------------------------------------------------- */
 size_t sdetr_topk_workspace_bytes(int batch_size, int n, int k);
+/* 1 when sdetr_masked_topk_desc_f32 runs its prefilter launch for this shape (then the call is two launches) */
+int sdetr_topk_uses_prefilter(int n, int k);
 int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
                                int64_t mask_row_stride, int fill_mode, const float *fill_value,
                                const int64_t *payload, int batch_size, int n, int k,
