@@ -157,3 +157,30 @@ def test_init_weights_bumps_versions_and_invalidate_caches():
     with torch.no_grad():
         m.attention_weights.weight.add_(1.0)                # the supported kind: version bump -> automatic refresh
     assert m._fused_query_projection()[0] is not w2
+
+
+def test_x3_linear_swap_keeps_parameters_and_falls_back_on_cpu():
+    """`use_x3_linear_` switches the class of plain nn.Linear modules only (state-dict keys and parameters untouched,
+    the out_proj of nn.MultiheadAttention left alone); without a HIP tensor the forward / backward are F.linear's."""
+    from salience_detr_amd import linear_x3 as X
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8),
+                                torch.nn.MultiheadAttention(8, 2, batch_first=True))
+    ref = [p.detach().clone() for p in model.parameters()]
+    keys = list(model.state_dict().keys())
+    assert X.use_x3_linear_(model) == 2
+    assert isinstance(model[0], X.X3Linear) and isinstance(model[2], X.X3Linear)
+    assert type(model[3].out_proj) is not X.X3Linear
+    assert list(model.state_dict().keys()) == keys
+    assert all(torch.equal(a, b) for a, b in zip(ref, model.parameters()))
+    x = torch.randn(5, 16, requires_grad=True)
+    y = model[2](model[1](model[0](x)))
+    y.sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x2, ref[0], ref[1])), ref[2], ref[3])
+    y2.sum().backward()
+    assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad)
+    # the split of dw's token reduction: never more slices than 256-token pieces, more for fewer output tiles
+    assert X._weight_grad_splits(100, 256, 256) == 1
+    assert X._weight_grad_splits(22726, 256, 256) > X._weight_grad_splits(22726, 2048, 256) >= 1
+    assert X._weight_grad_splits(22726, 256, 256) <= (22726 + 255) // 256
