@@ -276,6 +276,12 @@ int sdetr_advance_rows(sdetr_stream_t stream, const void *layer_out, void *sorte
 int sdetr_select_stack(sdetr_stream_t stream, const void *query, int64_t query_batch_stride, const void *pos,
                        int64_t pos_batch_stride, const int64_t *index, int batch_size, int num_select, int channels,
                        int dtype, void *out);
+/* sdetr_encoder_finalize_sorted: the second launch of sdetr_encoder_finalize alone (same arguments; `out` already holds
+ * the token-space pass, e.g. from a sdetr_finalize_job). */
+int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
+                                  const int64_t *sorted_index, const int64_t *count, const void *background,
+                                  const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,
+                                  int last_rows, int channels, int dtype, void *out);
 int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
                            const int64_t *sorted_index, const int64_t *count, const void *background,
                            const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,
@@ -404,6 +410,15 @@ typedef struct {
     int64_t *out_index;
     int64_t out_row_stride;
 } sdetr_rank_job;
+/* The token-space pass of sdetr_encoder_finalize (out = tokens + (padding ? 0 : background), bf16 rows of 256) as a
+ * job: it depends on nothing the filtering or the encoder compute; sdetr_encoder_finalize_sorted then finishes alone. */
+typedef struct {
+    const void *tokens;          /* [batch, spatial_size, 256] bf16 */
+    const void *background;      /* [spatial_size, 256] bf16 */
+    const uint8_t *padding_mask; /* [batch, spatial_size] or NULL */
+    int batch, spatial_size;
+    void *out;                   /* [batch, spatial_size, 256] bf16 */
+} sdetr_finalize_job;
 int sdetr_stage1_x3_with_jobs(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
@@ -412,7 +427,7 @@ int sdetr_stage1_x3_with_jobs(
     float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
     float *z_local, float *partial_sums, const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded,
     const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
-    void *vp_dst, int vp_dst_dtype, const sdetr_rank_job *rank);
+    void *vp_dst, int vp_dst_dtype, const sdetr_rank_job *rank, const sdetr_finalize_job *finalize);
 int sdetr_stage1_x3_with_value_proj(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,

@@ -21,6 +21,12 @@ _lib = None
 _i = ctypes.c_int
 
 
+class FinalizeJobStruct(ctypes.Structure):
+    """``sdetr_finalize_job`` of include/salience_hip.h."""
+    _fields_ = [("tokens", ctypes.c_void_p), ("background", ctypes.c_void_p), ("padding_mask", ctypes.c_void_p),
+                ("batch", ctypes.c_int), ("spatial_size", ctypes.c_int), ("out", ctypes.c_void_p)]
+
+
 class RankJobStruct(ctypes.Structure):
     """``sdetr_rank_job`` of include/salience_hip.h."""
     _fields_ = [("score", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("mask_row_stride", ctypes.c_int64),
@@ -78,6 +84,7 @@ SIGNATURES = {
                              _p, _i64, _i]),
     "sdetr_advance_rows": (_i, [_p, _p, _p, _p, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _i]),
     "sdetr_select_stack": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p]),
+    "sdetr_encoder_finalize_sorted": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sdetr_encoder_finalize": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "sdetr_column_mean_f32": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p]),
     "sdetr_pack_linear_f32": (_i, [_p, _p, _i64, _i, _i, _p]),
@@ -94,7 +101,7 @@ SIGNATURES = {
                                              _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
     "sdetr_stage1_x3_with_jobs": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
-                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "sdetr_pack_linear_bf16x3": (_i, [_p, _p, _i64, _i, _i, _p]),
     "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "sdetr_ffn_packed_bytes": (_i64, [_i]),

@@ -194,12 +194,15 @@ extern "C" int sdetr_select_stack(sdetr_stream_t stream, const void *query, int6
 template <typename T>
 static int launch_finalize(hipStream_t s, const void *tokens, const void *result, const int64_t *sorted_index,
                            const int64_t *count, const void *background, const uint8_t *pad, int B, int S, int n0,
-                           int c_last, int C, void *out)
+                           int c_last, int C, void *out, bool all_pass = true)
 {
     const int64_t total_all = (int64_t)B * S * (C / 8), total_sorted = (int64_t)B * n0 * (C / 8);
-    hipLaunchKernelGGL(finalize_all_kernel<T>, dim3(rows_grid(total_all)), dim3(kBlock), 0, s, (const T *)tokens,
-                       (const T *)background, pad, total_all, S, C, (T *)out);
-    int rc = check_launch("encoder_finalize");
+    int rc = 0;
+    if (all_pass) {
+        hipLaunchKernelGGL(finalize_all_kernel<T>, dim3(rows_grid(total_all)), dim3(kBlock), 0, s, (const T *)tokens,
+                           (const T *)background, pad, total_all, S, C, (T *)out);
+        rc = check_launch("encoder_finalize");
+    }
     if (rc || total_sorted == 0) return rc;
     hipLaunchKernelGGL(finalize_sorted_kernel<T>, dim3(rows_grid(total_sorted)), dim3(kBlock), 0, s, (const T *)tokens,
                        (const T *)result, sorted_index, count, (const T *)background, pad, total_sorted, n0, c_last, S,
@@ -226,4 +229,24 @@ extern "C" int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens,
         return launch_finalize<bf16_t>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
                                        batch_size, spatial_size, sorted_rows, last_rows, channels, out);
     return fail("encoder_finalize: bad dtype %d", dtype);
+}
+
+extern "C" int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
+                                             const int64_t *sorted_index, const int64_t *count, const void *background,
+                                             const uint8_t *padding_mask, int batch_size, int spatial_size,
+                                             int sorted_rows, int last_rows, int channels, int dtype, void *out)
+{
+    if (batch_size < 0 || spatial_size < 0 || sorted_rows < 0 || sorted_rows > spatial_size || last_rows < 0 ||
+        last_rows > sorted_rows || channels <= 0 || (channels % 8))
+        return fail("encoder_finalize_sorted: bad sizes");
+    if ((int64_t)batch_size * spatial_size == 0 || sorted_rows == 0) return 0;
+    if (!tokens || !background || !out || !sorted_result || !sorted_index) return fail("encoder_finalize_sorted: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == SDETR_F32)
+        return launch_finalize<float>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
+                                      batch_size, spatial_size, sorted_rows, last_rows, channels, out, false);
+    if (dtype == SDETR_BF16)
+        return launch_finalize<bf16_t>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
+                                       batch_size, spatial_size, sorted_rows, last_rows, channels, out, false);
+    return fail("encoder_finalize_sorted: bad dtype %d", dtype);
 }

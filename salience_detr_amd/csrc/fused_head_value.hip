@@ -11,10 +11,10 @@
 // (device functions in *_core.h) share launches: block ranges take roles, waves a role does not use exit (the hardware
 // barrier accounts for them), LDS is the larger of the roles' needs.
 //   fused_stage1_value_kernel   stage 1 (level 3 / 2) | value projection of 2 layers | rank of the level before
-//   fused_stage1_rank_kernel    stage 1 (level 1 / 0) | rank of the level before
+//   fused_stage1_rank_kernel    stage 1 (level 1 / 0) | rank of the level before | token-space pass of the output
 //   fused_stage2_value_kernel   stage 2 (level 3 / 2) | value projection of 1 layer
 //   fused_attn_proj_kernel      top-300 attention (+ projection of its own updated rows) | projection of all other rows
-// Measured: 1.391 -> 1.30 ms per step, 93 -> 77 launches.
+// Measured: 1.391 -> 1.29 ms per step, 93 -> 76 launches.
 #include "salience_head_core.h"
 #include "token_linear_core.h"
 #include "topk_attention_core.h"
@@ -44,19 +44,51 @@ __global__ void __launch_bounds__(768, 1) fused_stage1_value_kernel(Stage1Args s
     }
 }
 
-// Stage 1 with only a rank job: the head kernel's own shape (512 threads, two workgroups per CU).
+// out[b, s, :] = tokens[b, s, :] + (pad[b, s] ? 0 : background[s, :]), bf16 rows of 256 -- the token-space pass of the
+// encoder's output (sdetr_encoder_finalize's first launch): it depends on nothing the filtering or the encoder compute,
+// so a filtering launch carries it; the sorted rows are overwritten at the very end as before.
+struct FinalizeJob {
+    const uint4 *tokens;       // [B * S * 32] 16-byte pieces
+    const uint4 *background;   // [S * 32]
+    const uint8_t *pad;        // [B * S] or NULL
+    uint4 *out;
+    int64_t total;             // B * S * 32
+    int S;
+};
+__device__ __forceinline__ void finalize_all_role(const FinalizeJob &j, int role_block, int role_blocks)
+{
+    for (int64_t t = (int64_t)role_block * blockDim.x + threadIdx.x; t < j.total; t += (int64_t)role_blocks * blockDim.x) {
+        const int64_t r = t >> 5;   // b * S + s
+        const int piece = (int)(t & 31);
+        const uint4 a = j.tokens[t];
+        uint4 o = a;
+        if (!(j.pad && j.pad[r])) {
+            const uint4 g = j.background[(r % j.S) * 32 + piece];
+            o = make_uint4(pack_bf16x2(bf16_lo(a.x) + bf16_lo(g.x), bf16_hi(a.x) + bf16_hi(g.x)),
+                           pack_bf16x2(bf16_lo(a.y) + bf16_lo(g.y), bf16_hi(a.y) + bf16_hi(g.y)),
+                           pack_bf16x2(bf16_lo(a.z) + bf16_lo(g.z), bf16_hi(a.z) + bf16_hi(g.z)),
+                           pack_bf16x2(bf16_lo(a.w) + bf16_lo(g.w), bf16_hi(a.w) + bf16_hi(g.w)));
+        }
+        j.out[t] = o;
+    }
+}
+
+// Stage 1 with a rank job and / or the finalize pass: the head kernel's own shape (512 threads, two workgroups per CU).
 __global__ void __launch_bounds__(512, 2) fused_stage1_rank_kernel(Stage1Args s1, int s1_blocks, int s1_images, RankArgs rk,
-                                                                   int rk_blocks_x)
+                                                                   int rk_blocks_x, int rk_blocks, FinalizeJob fin,
+                                                                   int fin_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) char fused_lds[];
     const int blk = (int)blockIdx.x;
     const int n1 = s1_blocks * s1_images;
     if (blk < n1) {
         stage1_x3_body(s1, blk % s1_blocks, blk / s1_blocks);
-    } else {
+    } else if (blk < n1 + rk_blocks) {
         const int r = blk - n1;
         uint32_t *lds = reinterpret_cast<uint32_t *>(fused_lds);
         topk_rank_body(rk, r % rk_blocks_x, r / rk_blocks_x, lds, lds + kRankTile);
+    } else {
+        finalize_all_role(fin, blk - n1 - rk_blocks, fin_blocks);
     }
 }
 
@@ -128,7 +160,7 @@ extern "C" int sdetr_stage1_x3_with_jobs(
     float *z_local, float *partial_sums,
     const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
     int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
-    const sdetr_rank_job *rank)
+    const sdetr_rank_job *rank, const sdetr_finalize_job *finalize)
 {
     if (channels != kC) return fail("stage1_x3_with_jobs: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
     if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_jobs: empty level");
@@ -171,9 +203,21 @@ extern "C" int sdetr_stage1_x3_with_jobs(
         lds_rk = (size_t)kRankLdsWords * 4;
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
+    FinalizeJob fj{};
+    int n4 = 0;
+    if (finalize) {
+        if (vp_x) return fail("stage1_x3_with_jobs: the finalize pass rides with launches that carry no value projection");
+        if (finalize->batch <= 0 || finalize->spatial_size <= 0 || !finalize->tokens || !finalize->background || !finalize->out)
+            return fail("stage1_x3_with_jobs: bad finalize job");
+        fj.tokens = (const uint4 *)finalize->tokens; fj.background = (const uint4 *)finalize->background;
+        fj.pad = finalize->padding_mask; fj.out = (uint4 *)finalize->out; fj.S = finalize->spatial_size;
+        fj.total = (int64_t)finalize->batch * finalize->spatial_size * 32;
+        n4 = 128;   // 65 536 threads in a grid-stride loop over the 16-byte pieces
+    }
     if (!vp_x) {
         const size_t lds = lds_s1 > lds_rk ? lds_s1 : lds_rk;
-        hipLaunchKernelGGL(fused_stage1_rank_kernel, dim3((unsigned)(n1 + n3)), dim3(512), lds, hs, a, a.nblk, batch_size, r, rk_bx);
+        hipLaunchKernelGGL(fused_stage1_rank_kernel, dim3((unsigned)(n1 + n3 + n4)), dim3(512), lds, hs, a, a.nblk, batch_size, r,
+                           rk_bx, n3, fj, n4);
         return check_launch("stage1_x3_with_jobs");
     }
     TLArgs t;
@@ -207,7 +251,7 @@ extern "C" int sdetr_stage1_x3_with_value_proj(
                                      coarse_h, coarse_w, level_h, level_w, alpha, norm_weight, norm_bias, norm_eps,
                                      weight_x3, bias, memory_out, memory_batch_stride, z_local, partial_sums, vp_x,
                                      vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size, vp_spatial_size,
-                                     vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, nullptr);
+                                     vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, nullptr, nullptr);
 }
 
 // The stage-2 half of sdetr_salience_head_stage2 (the caller has launched the per-image constant already:

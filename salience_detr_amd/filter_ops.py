@@ -402,7 +402,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
                   level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
                   memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
                   score_min: Optional[Tensor] = None, value_job: Optional[ValueProjectionJob] = None,
-                  value_job2: Optional[ValueProjectionJob] = None, rank_job: Optional["RankJob"] = None) -> Tensor:
+                  value_job2: Optional[ValueProjectionJob] = None, rank_job: Optional["RankJob"] = None,
+                  finalize_job: Optional["FinalizeJob"] = None) -> Tensor:
     """The salience head on one level in three launches (include/salience_hip.h (6)).
 
     ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
@@ -413,7 +414,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     (a ``[B,n]`` slice of the flattened score buffer) optionally receives a second copy; ``score_min`` (one-element
     fp32 tensor) the minimum over all ``B*n`` scores.  ``value_job``: a pending slice of the encoder's value projection
     that stage 1's launch carries along (bf16x3 kernel only; otherwise it is left pending), ``value_job2`` one for
-    stage 2's launch; ``rank_job``: a pending top-k of the next coarser level, also for stage 1's launch.
+    stage 2's launch; ``rank_job``: a pending top-k of the next coarser level, ``finalize_job``: the token-space
+    pass of the encoder's output -- also for stage 1's launch (the latter only next to no value job).
     Returns ``[B,n]``."""
     if not x.is_cuda:
         raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
@@ -465,14 +467,19 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
         carry_value = x3 and value_job is not None and not value_job.done and value_job.value.device == x.device
         carry_rank = x3 and rank_job is not None and not rank_job.done and rank_job.score.device == x.device
-        if carry_value or carry_rank:
+        carry_fin = (x3 and finalize_job is not None and not finalize_job.done and not carry_value
+                     and finalize_job.tokens.device == x.device)
+        if carry_value or carry_rank or carry_fin:
             vp = value_job.pointers() if carry_value else (None, None, None, None, 0, 0, 0, 0, None, 0)
             rk = ctypes.byref(rank_job.struct()) if carry_rank else None
-            code = lib.sdetr_stage1_x3_with_jobs(*stage1_args, *vp, rk)
+            fj = ctypes.byref(finalize_job.struct()) if carry_fin else None
+            code = lib.sdetr_stage1_x3_with_jobs(*stage1_args, *vp, rk, fj)
             if carry_value:
                 value_job.done = True
             if carry_rank:
                 rank_job.done = True
+            if carry_fin:
+                finalize_job.done = True
         else:
             stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
             code = stage1(*stage1_args)
@@ -544,8 +551,42 @@ def select_stack(query: Tensor, pos: Tensor, index: Tensor) -> Tensor:
     return out
 
 
+class FinalizeJob:
+    """The token-space pass of ``encoder_finalize`` (``out = tokens + (padding ? 0 : background)``) as a pending job:
+    it depends on nothing the filtering or the encoder compute, so ``salience_head(..., finalize_job=job)`` carries it
+    in a stage-1 launch; ``run()`` launches it on its own.  ``encoder_finalize(..., finalize_job=job)`` then only
+    overwrites the sorted rows."""
+
+    def __init__(self, tokens: Tensor, background: Tensor, padding_mask: Optional[Tensor]):
+        _hip.require_device("FinalizeJob", tokens=tokens, background=background, padding_mask=padding_mask)
+        B, S, C = tokens.shape
+        if (tokens.dtype != torch.bfloat16 or C != 256 or not tokens.is_contiguous() or background.dtype != tokens.dtype
+                or tuple(background.shape) != (S, C) or not background.is_contiguous()):
+            raise RuntimeError("FinalizeJob: contiguous bf16 [B,S,256] tokens and [S,256] background expected")
+        self.tokens, self.background = tokens, background
+        self.pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
+                                                      else padding_mask).contiguous()
+        self.out = torch.empty_like(tokens)
+        self.done = False
+
+    def struct(self):
+        st = _hip.FinalizeJobStruct()
+        st.tokens, st.background, st.padding_mask = self.tokens.data_ptr(), self.background.data_ptr(), _hip.ptr(self.pad)
+        st.batch, st.spatial_size, st.out = self.tokens.shape[0], self.tokens.shape[1], self.out.data_ptr()
+        self._keep = st
+        return st
+
+    def run(self):
+        if self.done:
+            return
+        self.out = self.tokens + torch.where(self.pad.bool()[..., None], torch.zeros_like(self.background[None]),
+                                             self.background[None]) if self.pad is not None else self.tokens + self.background
+        self.done = True
+
+
 def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor, count: Optional[Tensor],
-                     background: Tensor, padding_mask: Optional[Tensor], last_rows: int) -> Tensor:
+                     background: Tensor, padding_mask: Optional[Tensor], last_rows: int,
+                     finalize_job: Optional[FinalizeJob] = None) -> Tensor:
     """Encoder output in token space (include/salience_hip.h (5), salience_transformer.py:474-495): live sorted
     rows replace their tokens, and every token that is neither padding nor among the first ``last_rows`` sorted
     rows (the last layer's set) receives its background embedding."""
@@ -556,6 +597,15 @@ def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor
         raise RuntimeError("encoder_finalize: background [S,C] / sorted_result of the tokens' dtype expected")
     pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
                                              else padding_mask)
+    if finalize_job is not None and finalize_job.done and finalize_job.tokens is tokens:
+        out = finalize_job.out      # the token-space pass has run (carried by a filtering launch): sorted rows only
+        with torch.cuda.device(tokens.device):
+            code = _hip.lib().sdetr_encoder_finalize_sorted(
+                _hip.stream_ptr(), tokens.data_ptr(), sorted_result.data_ptr(), sorted_index.data_ptr(), _hip.ptr(count),
+                background.data_ptr(), _hip.ptr(pad), B, S, sorted_result.shape[1], int(last_rows), C,
+                _hip.dtype_code(tokens.dtype), out.data_ptr())
+        _hip.check(code, "encoder_finalize")
+        return out
     out = torch.empty_like(tokens)
     with torch.cuda.device(tokens.device):
         code = _hip.lib().sdetr_encoder_finalize(

@@ -155,6 +155,9 @@ class SalienceEncoderHotPath(nn.Module):
             if plan is not None:
                 value_maps, value_jobs = plan
         level_shapes = pyramid.level_shapes_of(multi_level_masks)
+        finalize_job = None
+        if native and feat_enc is not None and self.fuse_value_projection:
+            finalize_job = self.encoder.plan_finalize(feat_enc, mask_flatten, level_shapes)
         if valid_ratios_k is not None:
             spatial_shapes, level_start_index = pyramid.shape_tensors(level_shapes, mask_flatten.device)
             valid_ratios = valid_ratios_k
@@ -201,7 +204,7 @@ class SalienceEncoderHotPath(nn.Module):
             salience_score, level_inds, level_score = level_filtering(
                 enc_in, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor, self.alpha,
                 enc_output=self.enc_output, enc_output_norm=self.enc_output_norm, memory_out=backbone_output_memory,
-                score_flat=score_flat, extras=extras, value_jobs=value_jobs)
+                score_flat=score_flat, extras=extras, value_jobs=value_jobs, finalize_job=finalize_job)
         else:
             salience_score, level_inds, level_score = level_filtering(
                 backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
@@ -218,7 +221,7 @@ class SalienceEncoderHotPath(nn.Module):
             precomputed_value_maps=value_maps, query=feat_enc, query_pos=pos_enc, query_key_padding_mask=mask_flatten,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index, valid_ratios=valid_ratios,
             foreground_score=foreground_score, focus_token_nums=focus_token_nums, foreground_inds=foreground_inds,
-            multi_level_masks=multi_level_masks)
+            multi_level_masks=multi_level_masks, finalize_job=finalize_job)
         if not return_aux:
             return memory, salience_score
         aux = dict(feat_flatten=feat_flatten, mask_flatten=mask_flatten, lvl_pos_embed_flatten=lvl_pos_embed_flatten,

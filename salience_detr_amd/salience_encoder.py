@@ -331,6 +331,14 @@ class SalienceTransformerEncoder(nn.Module):
         stage on a second stream (``SalienceEncoderHotPath`` does)."""
         return batched_value_maps([l.self_attn for l in self.layers], value, padding_mask)
 
+    def plan_finalize(self, value: Tensor, padding_mask: Optional[Tensor], level_shapes):
+        """The token-space pass of the output (``tokens + background`` outside the padding) as a pending
+        ``filter_ops.FinalizeJob`` (bf16 tokens only; ``None`` otherwise)."""
+        from .filter_ops import FinalizeJob
+        if value.dtype != torch.bfloat16 or value.dim() != 3 or value.shape[2] != 256 or not value.is_contiguous():
+            return None
+        return FinalizeJob(value, self.background_embedding.flat_cached(level_shapes, value.dtype), padding_mask)
+
     def plan_values(self, value: Tensor, padding_mask: Optional[Tensor], parts=2):
         """``project_values`` as pending jobs ``(maps, [ValueProjectionJob, ...])`` (``None`` when the one-launch
         projection does not apply): the caller lets other launches carry the jobs (the salience head's stage 1 on the
@@ -339,11 +347,12 @@ class SalienceTransformerEncoder(nn.Module):
 
     def forward(self, query, spatial_shapes, level_start_index, valid_ratios, query_pos=None,
                 query_key_padding_mask=None, foreground_score=None, focus_token_nums=None, foreground_inds=None,
-                multi_level_masks=None, precomputed_value_maps=None):
+                multi_level_masks=None, precomputed_value_maps=None, finalize_job=None):
         """Reference signature (salience_transformer.py:434-447).  ``foreground_inds`` is the list of
         per-layer ``[B,Nq_k]`` index tensors, ``focus_token_nums`` ``[B]`` the per-image valid prefix.
         ``precomputed_value_maps``: the result of ``project_values(query, query_key_padding_mask)`` if the caller
-        already launched it."""
+        already launched it; ``finalize_job``: the token-space pass of the output if a caller had another launch carry it
+        (``plan_finalize``)."""
         if not query.is_cuda:
             raise RuntimeError("SalienceTransformerEncoder: HIP device tensors required; there is no CPU fallback")
         native = not _needs_grad(self, query, query_pos)
@@ -402,7 +411,8 @@ class SalienceTransformerEncoder(nn.Module):
                 self.layer_marker(self.num_layers)
             if multi_level_masks is not None:
                 bg = self.background_embedding.flat_cached(level_shapes, value.dtype)
-                return encoder_finalize(value, result, sorted_index, focus64, bg, query_key_padding_mask, counts[-1])
+                return encoder_finalize(value, result, sorted_index, focus64, bg, query_key_padding_mask, counts[-1],
+                                        finalize_job=finalize_job)
             return scatter_rows_(value.clone(), sorted_index, result, count=focus64)
 
         if native:

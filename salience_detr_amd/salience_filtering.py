@@ -94,7 +94,7 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                     level_start_index: Sequence[int], level_token_nums: Sequence[int], mask_predictor: nn.Module,
                     alpha: Tensor, enc_output: Optional[nn.Module] = None, enc_output_norm: Optional[nn.Module] = None,
                     memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
-                    extras: Optional[dict] = None, value_jobs: Optional[list] = None):
+                    extras: Optional[dict] = None, value_jobs: Optional[list] = None, finalize_job=None):
     """Coarse-to-fine salience scores + per-level top-k (salience_transformer.py:123-154).
 
     ``level_shapes`` / ``level_start_index`` / ``level_token_nums`` are python ints (shapes come from the
@@ -110,7 +110,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
     concatenated ``(scores, indices)`` [B, sum k] the per-level top-k calls already wrote side by side).
     ``value_jobs``: pending ``filter_ops.ValueProjectionJob`` slices of the encoder's value projection; the stage-1
     launches of the two coarsest levels (few workgroups on an otherwise empty chip) carry one each -- stage 1, then
-    stage 2 -- coarsest level first.
+    stage 2 -- coarsest level first.  ``finalize_job``: the pending token-space pass of the encoder's output
+    (``filter_ops.FinalizeJob``); the first stage-1 launch without a value job carries it.
     """
     B = backbone_output_memory.shape[0]
     L = len(level_shapes)
@@ -150,7 +151,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 memory_out=None if memory_out is None else memory_out[:, start:start + h * w, :],
                 score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
                 score_min=level_min[lvl:lvl + 1],
-                rank_job=pending_rank, **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None))
+                rank_job=pending_rank, finalize_job=finalize_job,
+                **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None))
             if pending_rank is not None:
                 pending_rank.run()          # (no-op when stage 1 carried it)
                 pending_rank = None

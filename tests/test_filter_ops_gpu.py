@@ -706,3 +706,27 @@ def test_salience_head_carrying_a_rank_job():
     o = (torch.empty(B, 300, device=DEV), torch.empty(B, 300, dtype=torch.int64, device=DEV))
     assert F.plan_masked_topk(big, 300, None, fill, 0, o) is None
     assert torch.equal(o[1], F.masked_topk_desc(big, 300)[1])
+
+
+def test_salience_head_carrying_the_finalize_pass():
+    """The token-space pass of the encoder output carried by a stage-1 launch + the sorted-rows pass alone give the
+    bits of ``encoder_finalize``'s two launches."""
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    torch.manual_seed(13)
+    B, S, C, n0 = 2, 3000, 256, 1700
+    pred = MaskPredictor(C, C).to(DEV)
+    x = syn.det_randn("fjx", (B, 4200, C)).to(DEV)
+    tokens = syn.det_randn("fjt", (B, S, C)).to(DEV).to(torch.bfloat16)
+    bg = syn.det_randn("fjb", (S, C)).to(DEV).to(torch.bfloat16)
+    pad = (syn.det_rand("fjp", (B, S)) > 0.8).to(DEV)
+    result = syn.det_randn("fjr", (B, n0, C)).to(DEV).to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(S)[:n0] for _ in range(B)]).to(DEV)
+    count = torch.tensor([n0 - 100, 900], dtype=torch.int64, device=DEV)
+    with torch.no_grad():
+        want = F.encoder_finalize(tokens, result, idx, count, bg, pad, 400)
+        want_head = F.salience_head(x, pred)
+        job = F.FinalizeJob(tokens, bg, pad)
+        got_head = F.salience_head(x, pred, finalize_job=job)
+        assert job.done and torch.equal(got_head, want_head)
+        got = F.encoder_finalize(tokens, result, idx, count, bg, pad, 400, finalize_job=job)
+    assert torch.equal(got, want)
