@@ -112,18 +112,18 @@ __global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterAr
         // tie rule), and reading the chunks straight from global memory makes every load instruction of a wave touch
         // ~48 cache lines: 16 waves x KPT loads on this one CU's address unit was ~4 us of the kernel's 11.
         extern __shared__ uint32_t keybuf[];
-        for (int c0 = 0; c0 < KPT; c0 += 6) {
-            float sv[6];
-            uint8_t mk[6];
+        // every load of the thread in flight at once (batches of 6 cost one trip to memory each: three for the
+        // finest level's 17 keys per thread)
+        float sv[KPT];
+        uint8_t mk[KPT];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) sv[c] = srow[min((c0 + c) * kPreThreads + tid, p.N - 1)];
+        for (int c = 0; c < KPT; ++c) sv[c] = srow[min(c * kPreThreads + tid, p.N - 1)];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) mk[c] = mrow ? mrow[min((c0 + c) * kPreThreads + tid, p.N - 1)] : (uint8_t)0;
+        for (int c = 0; c < KPT; ++c) mk[c] = mrow ? mrow[min(c * kPreThreads + tid, p.N - 1)] : (uint8_t)0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const int i = (c0 + c) * kPreThreads + tid;
-                if (i < p.N) keybuf[i] = desc_bits(mk[c] ? fill : sv[c]);
-            }
+        for (int c = 0; c < KPT; ++c) {
+            const int i = c * kPreThreads + tid;
+            if (i < p.N) keybuf[i] = desc_bits(mk[c] ? fill : sv[c]);
         }
         __syncthreads();
 #pragma unroll
