@@ -667,10 +667,11 @@ int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, int dtype, in
  *   C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n]);  a_kmajor: A(m,k) = a[m * lda + k], else a[k * lda + m]; b likewise.
  *   reduction_splits > 1: slices of the reduction accumulate into C with fp32 atomics (C must be zero on entry).
  *   Every operand 16-byte aligned, leading dimensions multiples of 4; a k-major operand needs K % 4 == 0, the other
- *   kind its row count % 4 == 0. */
+ *   kind its row count % 4 == 0.  a_row_sum (optional, [M], zero on entry, reduction-major A only) receives
+ *   sum_k A(m,k): the bias gradient sum_t dy[t][n] that comes with dw = dy^T x. */
 int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b, int64_t ldb,
                       int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
-                      int reduction_splits);
+                      int reduction_splits, float *a_row_sum);
 
 /* sdetr_topk_attention_bf16 of an encoder layer together with the deformable attention's offset | weight projection of
  * the layer's queries (sdetr_token_linear_bf16 with x_add = pos and group_features = 48: the head-major slab

@@ -38,6 +38,8 @@ struct GemmArgs {
     int M, N, K;
     int k_per_split;       // reduction elements per blockIdx.z slice (multiple of 32)
     int atomic;            // accumulate into C with atomics (split reduction)
+    float *a_row_sum;      // optional [M]: sum_k A(m, k) accumulated with atomics (zero on entry) -- the bias gradient
+                           // sum_t dy[t][n] next to dw = dy^T x; reduction-major A only
 };
 
 __device__ __forceinline__ g_f32x16_t g_mfma(u32x4_t a, u32x4_t b, g_f32x16_t c)
@@ -132,8 +134,14 @@ __device__ __forceinline__ int g_acc_row(int reg, int lane) { return (reg & 3) +
 template <bool A_KMAJOR, bool B_KMAJOR>
 __device__ __forceinline__ void gemm_x3_step(const GemmArgs &p, TileLoad<A_KMAJOR> &ta, TileLoad<B_KMAJOR> &tb, char *pa,
                                              char *pb, const char *fa, const char *fb, int m0, int n0, int k0, int kend,
-                                             int tid, g_f32x16_t (&acc)[2][2])
+                                             int tid, g_f32x16_t (&acc)[2][2], float4 &row_sum, bool want_row_sum)
 {
+    if (!A_KMAJOR && want_row_sum) {   // my 4 rows x 4 reduction indices of this step's A tile
+        row_sum.x += (ta.v0.x + ta.v1.x) + (ta.v2.x + ta.v3.x);
+        row_sum.y += (ta.v0.y + ta.v1.y) + (ta.v2.y + ta.v3.y);
+        row_sum.z += (ta.v0.z + ta.v1.z) + (ta.v2.z + ta.v3.z);
+        row_sum.w += (ta.v0.w + ta.v1.w) + (ta.v2.w + ta.v3.w);
+    }
 
     ta.store(pa, tid);
     tb.store(pb, tid);
@@ -197,11 +205,26 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
     const char *fa = pa + (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 32;
     const char *fb = pb + (64 * wn + (lane & 31)) * kGRow + (lane >> 5) * 32;
 
+    float4 row_sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool want_row_sum = !A_KMAJOR && p.a_row_sum != nullptr && blockIdx.x == 0;
     for (int k0 = kbeg; k0 < kend; k0 += 2 * kGK) {
-        gemm_x3_step<A_KMAJOR, B_KMAJOR>(p, ta0, tb0, pa, pb, fa, fb, m0, n0, k0, kend, tid, acc);
-        if (k0 + kGK < kend) gemm_x3_step<A_KMAJOR, B_KMAJOR>(p, ta1, tb1, pa, pb, fa, fb, m0, n0, k0 + kGK, kend, tid, acc);
+        gemm_x3_step<A_KMAJOR, B_KMAJOR>(p, ta0, tb0, pa, pb, fa, fb, m0, n0, k0, kend, tid, acc, row_sum, want_row_sum);
+        if (k0 + kGK < kend)
+            gemm_x3_step<A_KMAJOR, B_KMAJOR>(p, ta1, tb1, pa, pb, fa, fb, m0, n0, k0 + kGK, kend, tid, acc, row_sum, want_row_sum);
     }
 
+    if (want_row_sum) {   // (uniform per workgroup) 8 threads hold pieces of each row's sum: meet in LDS, one atomic per row
+        float *red = reinterpret_cast<float *>(pa);   // [8][128]; the operand tiles are no longer needed
+        const int kb = tid >> 5, mb = tid & 31;
+        *reinterpret_cast<float4 *>(red + kb * 128 + 4 * mb) = row_sum;
+        __syncthreads();
+        if (tid < 128 && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += red[j * 128 + tid];
+            unsafeAtomicAdd(p.a_row_sum + m0 + tid, t);
+        }
+    }
     const bool add_bias = p.bias && blockIdx.z == 0;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -239,10 +262,11 @@ static int launch_gemm_x3(hipStream_t s, const GemmArgs &a, int splits)
 // C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n]).  a_kmajor: A(m,k) = a[m * lda + k], else a[k * lda + m]; b likewise with n.
 // reduction_splits > 1: the reduction is cut into that many slices whose partial products are accumulated into C with
 // fp32 atomics -- C must be zero on entry.  Alignment: every operand 16-byte aligned, its leading dimension a multiple
-// of 4; a k-major operand needs K % 4 == 0, the other kind its row count % 4 == 0.
+// of 4; a k-major operand needs K % 4 == 0, the other kind its row count % 4 == 0.  a_row_sum (optional, [M], zero on
+// entry, reduction-major A only): receives sum_k A(m, k) -- the bias gradient that comes with dw = dy^T x.
 extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b,
                                  int64_t ldb, int b_kmajor, float *c, int64_t ldc, int M, int N, int K,
-                                 const float *bias, int reduction_splits)
+                                 const float *bias, int reduction_splits, float *a_row_sum)
 {
     if (M < 0 || N < 0 || K < 0) return fail("gemm_x3: negative size");
     if (M == 0 || N == 0) return 0;
@@ -252,7 +276,9 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
     if ((a_kmajor && (K & 3)) || (!a_kmajor && (M & 3)) || (b_kmajor && (K & 3)) || (!b_kmajor && (N & 3)))
         return fail("gemm_x3: M=%d N=%d K=%d do not meet the alignment rule of the chosen layouts", M, N, K);
     if (reduction_splits < 1) reduction_splits = 1;
+    if (a_row_sum && a_kmajor) return fail("gemm_x3: a_row_sum needs a reduction-major A");
     GemmArgs g{};
+    g.a_row_sum = a_row_sum;
     g.a = a; g.b = b; g.c = c; g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     const int steps = (K + kGK - 1) / kGK;
     int splits = reduction_splits > steps ? (steps > 0 ? steps : 1) : reduction_splits;

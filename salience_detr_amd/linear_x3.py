@@ -20,9 +20,11 @@ from . import _hip
 
 
 def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int, K: int,
-            bias: Optional[Tensor] = None, reduction_splits: int = 1, out: Optional[Tensor] = None) -> Tensor:
+            bias: Optional[Tensor] = None, reduction_splits: int = 1, out: Optional[Tensor] = None,
+            a_row_sum: Optional[Tensor] = None) -> Tensor:
     """``C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n])`` with ``A(m,k) = a[m,k]`` (k-major) or ``a[k,m]``; ``b`` likewise
-    (``include/salience_hip.h``).  ``a`` / ``b`` are 2-d fp32 HIP tensors with a contiguous last dimension."""
+    (``include/salience_hip.h``).  ``a`` / ``b`` are 2-d fp32 HIP tensors with a contiguous last dimension.
+    ``a_row_sum`` (fp32 [M], zeroed by the caller, reduction-major ``a`` only) receives ``sum_k A(m,k)``."""
     _hip.require_device("gemm_x3", a=a, b=b, bias=bias)
     for t, what in ((a, "a"), (b, "b")):
         if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
@@ -38,7 +40,7 @@ def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int
     with torch.cuda.device(a.device):
         code = _hip.lib().sdetr_gemm_x3_f32(_hip.stream_ptr(), a.data_ptr(), a.stride(0), int(a_kmajor), b.data_ptr(),
                                             b.stride(0), int(b_kmajor), c.data_ptr(), c.stride(0), M, N, K,
-                                            _hip.ptr(bias), int(reduction_splits))
+                                            _hip.ptr(bias), int(reduction_splits), _hip.ptr(a_row_sum))
     _hip.check(code, "gemm_x3")
     return c if out is None else out
 
@@ -88,10 +90,15 @@ class _LinearX3(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                                    # dx = dy w
             gx = gemm_x3(g2, True, weight, False, T, K, N) if X3_DX else g2 @ weight
-        if ctx.needs_input_grad[1]:                                                    # dw = dy^T x
-            gw = (gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=_weight_grad_splits(T, N, K)) if X3_DW
-                  else g2.t() @ x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:                                                    # dw = dy^T x (+ db = sum_t dy)
+            if X3_DW:
+                if want_gb:   # the kernel has dy's tiles in registers anyway: the bias gradient is their row sums
+                    gb = torch.zeros(N, dtype=torch.float32, device=g2.device)
+                gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=_weight_grad_splits(T, N, K), a_row_sum=gb)
+            else:
+                gw = g2.t() @ x2
+        if want_gb and gb is None:
             gb = g2.sum(0)
         return gx, gw, gb
 

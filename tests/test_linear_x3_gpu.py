@@ -33,6 +33,22 @@ def test_gemm_x3_matches_float64(M, N, K, ak, bk):
         assert _err(got2, want) <= max(2.0 * _err(ref32, want), 2e-6)
 
 
+def test_gemm_x3_row_sums_of_a_reduction_major_operand():
+    """dw = dy^T x with db = sum_t dy from the same launch (with and without a split reduction)."""
+    T, N, K = 3001 * 4, 260, 256
+    dy, x = syn.det_randn("rs_dy", (T, N)).to(DEV), syn.det_randn("rs_x", (T, K)).to(DEV)
+    want = dy.double().sum(0).cpu()
+    want_dw = dy.double().cpu().t() @ x.double().cpu()
+    bar = max(2.0 * _err(dy.t() @ x, want_dw), 3e-6)      # what torch's own fp32 product loses over 12 004 terms
+    for splits in (1, 7):
+        db = torch.zeros(N, device=DEV)
+        dw = X.gemm_x3(dy, False, x, False, N, K, T, reduction_splits=splits, a_row_sum=db)
+        assert _err(db, want) < 3e-6
+        assert _err(dw, want_dw) <= bar
+    with pytest.raises(RuntimeError):
+        X.gemm_x3(x, True, x, True, T, T, K, a_row_sum=torch.zeros(T, device=DEV))
+
+
 def test_gemm_x3_bias_and_argument_checks():
     a, b = syn.det_randn("gba", (70, 64)).to(DEV), syn.det_randn("gbb", (36, 64)).to(DEV)
     bias = syn.det_randn("gbias", (36,)).to(DEV)
