@@ -102,7 +102,12 @@ def train_main(args, model, device, rank, world, dist):
     if dist is not None:
         broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True)
+    # one fused multi-tensor update for the ~300 parameter tensors (the single-tensor path is ~10 tiny launches per
+    # parameter: ~3000 per step); capturable: the step lives in a hipGraph
+    try:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True, foreach=True)
     # 8 MiB buckets in reverse registration order, each all-reduced (RCCL) as soon as backward has produced its last
     # gradient: the exchange runs under the rest of backward; finish() after backward() waits and unpacks
     reducer = OverlappedGradReducer(params) if dist is not None else None
