@@ -34,6 +34,8 @@ def main():
         for name, ours, ref in (
                 ("y=xw^T", lambda: X.gemm_x3(x, True, w, True, T, N, K), lambda: x @ w.t()),
                 ("dx=dy w", lambda: X.gemm_x3(gy, True, w, False, T, K, N), lambda: gy @ w),
+                ("y=xw^T presplit", lambda: X.gemm_x3_presplit_b(x, True, X.presplit(w), T, N, K), lambda: x @ w.t()),
+                ("dx presplit", lambda: X.gemm_x3_presplit_b(gy, True, X.presplit(w, transpose=True), T, K, N), lambda: gy @ w),
                 ("dw=dy^T x", lambda: X.gemm_x3(gy, False, x, False, N, K, T, reduction_splits=X._weight_grad_splits(T, N, K)),
                  lambda: gy.t() @ x)):
             a, b = time_us(ours), time_us(ref)

@@ -669,6 +669,11 @@ int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, int dtype, in
  *   Every operand 16-byte aligned, leading dimensions multiples of 4; a k-major operand needs K % 4 == 0, the other
  *   kind its row count % 4 == 0.  a_row_sum (optional, [M], zero on entry, reduction-major A only) receives
  *   sum_k A(m,k): the bias gradient sum_t dy[t][n] that comes with dw = dy^T x. */
+/* sdetr_gemm_x3_presplit: the three bf16 planes of an fp32 matrix [rows, cols] (rows ld apart), optionally transposed,
+ * out = 3 * rows * cols bf16 -- the form of a B operand passed with b_kmajor = 2 (planes [3][N][K], rows ldb
+ * elements apart, K % 8 == 0): a weight is split once per call instead of in every workgroup that reads it. */
+int sdetr_gemm_x3_presplit(sdetr_stream_t stream, const float *w, int64_t ld, int rows, int cols, int transpose,
+                           void *out);
 int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b, int64_t ldb,
                       int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
                       int reduction_splits, float *a_row_sum);

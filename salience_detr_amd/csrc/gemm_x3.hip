@@ -26,6 +26,9 @@ constexpr int kGRow = kGK * 4 + 16;              // bytes per fp32 row of an ope
                                                  // conflict-free 16-byte fragment reads at stride 36 dwords)
 constexpr int kGOperand = kGTile * kGRow;        // 18 432
 constexpr int kGLds = 2 * kGOperand;             // 36 864
+constexpr int kGPreRow = kGK * 2 + 16;           // bytes per row of a pre-split plane tile (bf16)
+constexpr int kGPrePlane = kGTile * kGPreRow;    // 10 240
+constexpr int kGLdsPre = kGOperand + 3 * kGPrePlane;   // 49 152: fp32 A tile + three B planes
 
 typedef __bf16 g_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float g_f32x16_t __attribute__((ext_vector_type(16)));
@@ -38,6 +41,7 @@ struct GemmArgs {
     int M, N, K;
     int k_per_split;       // reduction elements per blockIdx.z slice (multiple of 32)
     int atomic;            // accumulate into C with atomics (split reduction)
+    int64_t b_plane;       // pre-split B: elements between its three planes
     float *a_row_sum;      // optional [M]: sum_k A(m, k) accumulated with atomics (zero on entry) -- the bias gradient
                            // sum_t dy[t][n] next to dw = dy^T x; reduction-major A only
 };
@@ -125,6 +129,34 @@ struct TileLoad {
             *reinterpret_cast<float4 *>(d + kGRow) = make_float4(v0.y, v1.y, v2.y, v3.y);
             *reinterpret_cast<float4 *>(d + 2 * kGRow) = make_float4(v0.z, v1.z, v2.z, v3.z);
             *reinterpret_cast<float4 *>(d + 3 * kGRow) = make_float4(v0.w, v1.w, v2.w, v3.w);
+        }
+    }
+};
+
+// A PRE-SPLIT operand: three bf16 planes [3][rows][K] (k-major), made once per call by gemm_x3_presplit_kernel -- a
+// weight is shared by all row tiles of the other operand, so splitting it in every workgroup that reads it repeats
+// the work M / 128 times (and the split is what the kernel's vector ALUs spend their time on).
+struct PreTileLoad {
+    uint4 q[3][2];
+    __device__ __forceinline__ void load(const uint16_t *src, int64_t ld, int64_t plane, int row0, int rows, int k0, int kend,
+                                         int tid)
+    {
+        const int r = row0 + (tid >> 1), k = k0 + 16 * (tid & 1);
+        const uint16_t *ptr = src + (int64_t)r * ld + k;
+        const bool ok0 = r < rows && k < kend, ok1 = r < rows && k + 8 < kend;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            q[pl][0] = ok0 ? *reinterpret_cast<const uint4 *>(ptr + pl * plane) : make_uint4(0u, 0u, 0u, 0u);
+            q[pl][1] = ok1 ? *reinterpret_cast<const uint4 *>(ptr + pl * plane + 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __device__ __forceinline__ void store(char *planes, int tid) const
+    {
+        char *d = planes + (tid >> 1) * kGPreRow + 32 * (tid & 1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<uint4 *>(d + pl * kGPrePlane) = q[pl][0];
+            *reinterpret_cast<uint4 *>(d + pl * kGPrePlane + 16) = q[pl][1];
         }
     }
 };
@@ -245,6 +277,112 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
     }
 }
 
+template <bool A_KMAJOR>
+__device__ __forceinline__ void gemm_x3_pre_step(const GemmArgs &p, TileLoad<A_KMAJOR> &ta, PreTileLoad &tb, char *pa, char *pb,
+                                                 const char *fa, const char *fb, int m0, int n0, int k0, int kend, int tid,
+                                                 g_f32x16_t (&acc)[2][2])
+{
+    ta.store(pa, tid);
+    tb.store(pb, tid);
+    __syncthreads();
+    ta.load(p.a, p.lda, m0, p.M, k0 + 2 * kGK, kend, tid);
+    tb.load(reinterpret_cast<const uint16_t *>(p.b), p.ldb, p.b_plane, n0, p.N, k0 + 2 * kGK, kend, tid);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        Frag3 a[2];
+        u32x4_t b[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 *qa = reinterpret_cast<const float4 *>(fa + t * 32 * kGRow + kk * 64);
+            a[t] = g_split(qa[0], qa[1]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[t][pl] = *reinterpret_cast<const u32x4_t *>(fb + t * 32 * kGPreRow + pl * kGPrePlane + kk * 32);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                g_f32x16_t c = acc[rt][ct];
+                c = g_mfma(a[rt].p[2], b[ct][0], c);   // smallest terms first
+                c = g_mfma(a[rt].p[0], b[ct][2], c);
+                c = g_mfma(a[rt].p[1], b[ct][1], c);
+                c = g_mfma(a[rt].p[1], b[ct][0], c);
+                c = g_mfma(a[rt].p[0], b[ct][1], c);
+                c = g_mfma(a[rt].p[0], b[ct][0], c);
+                acc[rt][ct] = c;
+            }
+    }
+    __syncthreads();
+}
+
+template <bool A_KMAJOR>
+__global__ void __launch_bounds__(kGThreads, 2) gemm_x3_pre_kernel(GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *pa = lds, *pb = lds + kGOperand;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * kGTile, n0 = blockIdx.x * kGTile;
+    const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+    g_f32x16_t acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+    TileLoad<A_KMAJOR> ta0, ta1;
+    PreTileLoad tb0, tb1;
+    const uint16_t *bp = reinterpret_cast<const uint16_t *>(p.b);
+    ta0.load(p.a, p.lda, m0, p.M, kbeg, kend, tid);
+    tb0.load(bp, p.ldb, p.b_plane, n0, p.N, kbeg, kend, tid);
+    ta1.load(p.a, p.lda, m0, p.M, kbeg + kGK, kend, tid);
+    tb1.load(bp, p.ldb, p.b_plane, n0, p.N, kbeg + kGK, kend, tid);
+    const char *fa = pa + (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 32;
+    const char *fb = pb + (64 * wn + (lane & 31)) * kGPreRow + (lane >> 5) * 16;
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * kGK) {
+        gemm_x3_pre_step<A_KMAJOR>(p, ta0, tb0, pa, pb, fa, fb, m0, n0, k0, kend, tid, acc);
+        if (k0 + kGK < kend) gemm_x3_pre_step<A_KMAJOR>(p, ta1, tb1, pa, pb, fa, fb, m0, n0, k0 + kGK, kend, tid, acc);
+    }
+    const bool add_bias = p.bias && blockIdx.z == 0;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int n = n0 + 64 * wn + 32 * ct + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = add_bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + 64 * wm + 32 * rt + g_acc_row(i, lane);
+                if (m < p.M) {
+                    float *dst = p.c + (int64_t)m * p.ldc + n;
+                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
+                    else *dst = acc[rt][ct][i] + bias;
+                }
+            }
+    }
+}
+
+// planes[pl][i][j] = plane pl of (transpose ? w[j][i] : w[i][j]); rows_out x cols_out = transpose ? cols x rows : rows x cols
+__global__ void __launch_bounds__(256) gemm_x3_presplit_kernel(const float *w, int64_t ld, int rows, int cols, int transpose,
+                                                               uint16_t *out)
+{
+    const int ro = transpose ? cols : rows, co = transpose ? rows : cols;
+    const int64_t total = (int64_t)ro * co;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / co), j = (int)(t - (int64_t)i * co);
+        const float x = transpose ? w[(int64_t)j * ld + i] : w[(int64_t)i * ld + j];
+        const float r1 = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+        const float r2 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        out[t] = (uint16_t)(__float_as_uint(x) >> 16);
+        out[total + t] = (uint16_t)(__float_as_uint(r1) >> 16);
+        out[2 * total + t] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
@@ -271,6 +409,27 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
     if (M < 0 || N < 0 || K < 0) return fail("gemm_x3: negative size");
     if (M == 0 || N == 0) return 0;
     if (!a || !b || !c) return fail("gemm_x3: null pointer");
+    if (b_kmajor == 2) {   // pre-split B planes [3][N][K] bf16 (sdetr_gemm_x3_presplit), rows ldb elements apart
+        if ((lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || (ldb & 7) || (K & 7) || ldb < K)
+            return fail("gemm_x3: a pre-split B needs K % 8 == 0, rows of >= K elements, 16-byte aligned operands");
+        if ((a_kmajor && (K & 3)) || (!a_kmajor && (M & 3))) return fail("gemm_x3: M=%d K=%d do not meet A's alignment rule", M, K);
+        if (a_row_sum) return fail("gemm_x3: a_row_sum is not available with a pre-split B");
+        if (reduction_splits < 1) reduction_splits = 1;
+        GemmArgs g{};
+        g.a = a; g.b = b; g.c = c; g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+        g.b_plane = (int64_t)N * ldb;
+        const int steps = (K + kGK - 1) / kGK;
+        int splits = reduction_splits > steps ? (steps > 0 ? steps : 1) : reduction_splits;
+        g.k_per_split = ((steps + splits - 1) / splits) * kGK;
+        splits = g.k_per_split > 0 ? (K + g.k_per_split - 1) / g.k_per_split : 1;
+        if (splits < 1) splits = 1;
+        g.atomic = splits > 1;
+        const dim3 grid((unsigned)((N + kGTile - 1) / kGTile), (unsigned)((M + kGTile - 1) / kGTile), (unsigned)splits);
+        hipStream_t hs = static_cast<hipStream_t>(stream);
+        if (a_kmajor) hipLaunchKernelGGL((gemm_x3_pre_kernel<true>), grid, dim3(kGThreads), kGLdsPre, hs, g);
+        else hipLaunchKernelGGL((gemm_x3_pre_kernel<false>), grid, dim3(kGThreads), kGLdsPre, hs, g);
+        return check_launch("gemm_x3");
+    }
     if ((lda & 3) || (ldb & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15))
         return fail("gemm_x3: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
     if ((a_kmajor && (K & 3)) || (!a_kmajor && (M & 3)) || (b_kmajor && (K & 3)) || (!b_kmajor && (N & 3)))
@@ -291,4 +450,19 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
     if (a_kmajor && !b_kmajor) return launch_gemm_x3<true, false>(s, g, splits);
     if (!a_kmajor && b_kmajor) return launch_gemm_x3<false, true>(s, g, splits);
     return launch_gemm_x3<false, false>(s, g, splits);
+}
+
+// Three bf16 planes of an fp32 matrix (exact split by truncation), optionally transposed: the form in which
+// sdetr_gemm_x3_f32 takes a B operand with b_kmajor = 2.  out: 3 * rows * cols bf16.
+extern "C" int sdetr_gemm_x3_presplit(sdetr_stream_t stream, const float *w, int64_t ld, int rows, int cols, int transpose,
+                                      void *out)
+{
+    if (rows < 0 || cols < 0) return fail("gemm_x3_presplit: negative size");
+    if ((int64_t)rows * cols == 0) return 0;
+    if (!w || !out || ld < cols) return fail("gemm_x3_presplit: bad arguments");
+    const int64_t total = (int64_t)rows * cols;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(gemm_x3_presplit_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, ld, rows, cols, transpose, static_cast<uint16_t *>(out));
+    return check_launch("gemm_x3_presplit");
 }

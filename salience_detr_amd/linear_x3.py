@@ -45,6 +45,39 @@ def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int
     return c if out is None else out
 
 
+def presplit(w: Tensor, transpose: bool = False) -> Tensor:
+    """The three bf16 planes ``[3, rows, cols]`` (or ``[3, cols, rows]`` transposed) of an fp32 matrix: the pre-split
+    form ``gemm_x3`` takes for ``b`` (``b_kmajor = 2``) -- a weight is split once per call instead of in every
+    workgroup that reads it."""
+    _hip.require_device("presplit", w=w)
+    if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise RuntimeError("presplit: 2-d fp32 tensor with a contiguous last dimension expected")
+    R, C = w.shape
+    out = torch.empty((3, C, R) if transpose else (3, R, C), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        code = _hip.lib().sdetr_gemm_x3_presplit(_hip.stream_ptr(), w.data_ptr(), w.stride(0), R, C, int(transpose),
+                                                 out.data_ptr())
+    _hip.check(code, "presplit")
+    return out
+
+
+def gemm_x3_presplit_b(a: Tensor, a_kmajor: bool, b_planes: Tensor, M: int, N: int, K: int,
+                       bias: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """``gemm_x3`` with ``b`` given as ``presplit`` planes ``[3, N, K]`` (K a multiple of 8)."""
+    _hip.require_device("gemm_x3", a=a, b=b_planes, bias=bias)
+    if (a.dtype != torch.float32 or a.dim() != 2 or a.stride(1) != 1 or b_planes.dtype != torch.bfloat16
+            or tuple(b_planes.shape) != (3, N, K) or not b_planes.is_contiguous()
+            or tuple(a.shape) != ((M, K) if a_kmajor else (K, M))):
+        raise RuntimeError("gemm_x3_presplit_b: fp32 a, contiguous bf16 planes [3, N, K] expected")
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device) if out is None else out.view(M, N)
+    with torch.cuda.device(a.device):
+        code = _hip.lib().sdetr_gemm_x3_f32(_hip.stream_ptr(), a.data_ptr(), a.stride(0), int(a_kmajor),
+                                            b_planes.data_ptr(), K, 2, c.data_ptr(), c.stride(0), M, N, K,
+                                            _hip.ptr(bias), 1, None)
+    _hip.check(code, "gemm_x3")
+    return c if out is None else out
+
+
 def x3_linear_applies(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> bool:
     """fp32 HIP tensors whose sizes meet the kernel's alignment rule (in / out features multiples of 4)."""
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2
@@ -64,8 +97,11 @@ def _weight_grad_splits(T: int, N: int, K: int) -> int:
 # MI355X (benchmarks/gemm_x3_bench.py, profiles/r02_gemm_x3.json): 100-127 TFLOP/s fp32-equivalent at 22 726 tokens
 # (the split of the operand fragments costs as many vector-ALU cycles as the six MFMAs take) -- within +-15 % of the
 # library for y = x w^T and dx = dy w (87-124), 1.3-2x faster for the weight gradient dw = dy^T x, whose few output
-# tiles the library does not split over the token dimension.
+# tiles the library does not split over the token dimension.  With the weight pre-split once per call (``presplit``,
+# ``gemm_x3_presplit_b``: half the split work) the other two reach 115-128 TFLOP/s: 1.3x the library on two of the four
+# large FFN products, equal on the rest -- not enough to route them by default.
 X3_FORWARD, X3_DX, X3_DW = False, False, True
+X3_MIN_ROWS = 2048      # below this many tokens the library's small-GEMM kernels win
 
 
 class _LinearX3(Function):
@@ -76,7 +112,10 @@ class _LinearX3(Function):
     def forward(ctx, x2, weight, bias):
         T, K = x2.shape
         N = weight.shape[0]
-        y = gemm_x3(x2, True, weight, True, T, N, K, bias=bias) if X3_FORWARD else F.linear(x2, weight, bias)
+        if X3_FORWARD and K % 8 == 0 and T >= X3_MIN_ROWS:
+            y = gemm_x3_presplit_b(x2, True, presplit(weight), T, N, K, bias=bias)     # y = x w^T, w split once
+        else:
+            y = F.linear(x2, weight, bias)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         return y
@@ -89,7 +128,10 @@ class _LinearX3(Function):
         g2 = gy if gy.is_contiguous() else gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                                    # dx = dy w
-            gx = gemm_x3(g2, True, weight, False, T, K, N) if X3_DX else g2 @ weight
+            if X3_DX and N % 8 == 0 and T >= X3_MIN_ROWS:
+                gx = gemm_x3_presplit_b(g2, True, presplit(weight, transpose=True), T, K, N)   # dx = dy w
+            else:
+                gx = g2 @ weight
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:                                                    # dw = dy^T x (+ db = sum_t dy)
             if X3_DW:

@@ -49,6 +49,27 @@ def test_gemm_x3_row_sums_of_a_reduction_major_operand():
         X.gemm_x3(x, True, x, True, T, T, K, a_row_sum=torch.zeros(T, device=DEV))
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 260, 256), (22726, 256, 2048), (4545, 384, 256), (130, 8, 8)])
+@pytest.mark.parametrize("ak", [True, False])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_gemm_x3_with_a_presplit_operand(M, N, K, ak, transposed):
+    """B given as three bf16 planes made once per call (from the matrix or from its transpose)."""
+    if not ak and M % 4:
+        pytest.skip("row counts of a reduction-major operand must be multiples of 4")
+    a = syn.det_randn(f"pa{M}{K}", (M, K)) * 1.3
+    b = syn.det_randn(f"pb{N}{K}", (N, K)) * 0.7
+    want = a.double() @ b.double().t()
+    ad = (a if ak else a.t().contiguous()).to(DEV)
+    planes = X.presplit(b.t().contiguous().to(DEV), transpose=True) if transposed else X.presplit(b.to(DEV))
+    assert planes.shape == (3, N, K)
+    assert torch.equal(planes.float().sum(0).cpu(), b)          # the split is exact
+    bias = syn.det_randn(f"pbias{N}", (N,)).to(DEV)
+    got = X.gemm_x3_presplit_b(ad, ak, planes, M, N, K, bias=bias)
+    ref32 = a.to(DEV) @ b.to(DEV).t() + bias
+    want = want + bias.double().cpu()
+    assert _err(got, want) <= max(2.0 * _err(ref32, want), 2e-6)
+
+
 def test_gemm_x3_bias_and_argument_checks():
     a, b = syn.det_randn("gba", (70, 64)).to(DEV), syn.det_randn("gbb", (36, 64)).to(DEV)
     bias = syn.det_randn("gbias", (36,)).to(DEV)
@@ -67,6 +88,7 @@ def test_gemm_x3_bias_and_argument_checks():
 def test_x3_linear_forward_backward_match_float64(shape, N, monkeypatch):
     for flag in ("X3_FORWARD", "X3_DX", "X3_DW"):   # all three products through the kernel under test
         monkeypatch.setattr(X, flag, True)
+    monkeypatch.setattr(X, "X3_MIN_ROWS", 1)
     K = shape[-1]
     lin = torch.nn.Linear(K, N)
     x = syn.det_randn(f"lx{N}", shape)
