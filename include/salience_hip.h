@@ -684,9 +684,9 @@ int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_
  * for the attention (40 workgroups, which also re-project their 300 updated rows) and the projection of all other rows
  * (from the queries as they stand before the attention).
  *   proj_weight: [384, 256] bf16, rows in head-major order (48 per head); proj_packed / proj_bias_padded: its
- *   sdetr_linear_pack_bf16 packing and zero-padded fp32 bias; hint: int32 [batch, hint_batch_stride >= num_rows],
- *   zero before its first use and left alone by the caller afterwards (the in-projection marks the selected rows in
- *   it; marks are validated against `selected`, stale ones are harmless).
+ *   sdetr_linear_pack_bf16 packing and zero-padded fp32 bias; hint: int32 [batch, hint_batch_stride >= num_rows]
+ *   of scratch, contents irrelevant on entry (the in-projection marks the selected rows in it; a mark only counts
+ *   if `selected` confirms it, so garbage is harmless) -- one per call in flight.
  *   289 <= num_selected <= 320 only; the layer's queries contiguous [batch, num_rows, 256]. */
 int sdetr_topk_attention_with_projection_bf16(
     sdetr_stream_t stream, void *query, int64_t query_batch_stride, const void *pos, int64_t pos_batch_stride,

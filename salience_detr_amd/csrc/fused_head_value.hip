@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(768, 1) fused_stage2_value_kernel(Stage2Args s
 // The top-300 attention (40 workgroups of ~15 us) carries the layer's offset | weight projection of ALL rows
 // (token_linear<kStore, x + pos>, ~107 workgroups x ~17 us): the projection reads the queries as they are before the
 // attention updates 300 of them and skips those rows (the in-projection launch in front marked them in a hint array
-// that the projection validates against the selection, so stale marks of earlier calls are harmless); the attention
+// that the projection validates against the selection, so the array needs no initialisation); the attention
 // kernel projects its 300 rows itself from the updated values.  One writer per slab row, no ordering needed.
 template <int KT>
 __global__ void __launch_bounds__(512, 1) fused_attn_proj_kernel(TkOutArgs at, int at_blocks, TLArgs tl)
@@ -295,8 +295,8 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
 // kernel reads): in-projection launch (which also marks the selected rows in `hint`), then ONE launch for the attention
 // (40 workgroups; re-projects its 300 updated rows) and the projection of all other rows.  `proj_weight` is the plain
 // [384, 256] bf16 weight in head-major row order, `proj_packed` / `proj_bias_padded` its token-linear packing; `hint`:
-// int32 [batch, hint_batch_stride >= rows], zero before its first use and otherwise left alone by the caller (marks are
-// validated against the selection, stale ones are harmless).  Only for 289..320 selected rows (the model's 300).
+// int32 [batch, hint_batch_stride >= rows] of scratch, contents irrelevant on entry (a mark only counts if the
+// selection confirms it); one per call in flight.  Only for 289..320 selected rows (the model's 300).
 extern "C" int sdetr_topk_attention_with_projection_bf16(
     sdetr_stream_t stream, void *query, int64_t query_batch_stride, const void *pos, int64_t pos_batch_stride,
     const int64_t *selected, int batch_size, int num_rows, int num_selected, const void *in_proj_weight,

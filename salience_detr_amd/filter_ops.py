@@ -1217,16 +1217,6 @@ def neck_gate_shortcut(y: Tensor, mask_weight: Tensor, squeeze_weight: Tensor, e
     return out
 
 
-def selection_hint_buffer(owner, batch: int, rows: int, device) -> Tensor:
-    """The persistent int32 ``[batch, >= rows]`` hint array of ``topk_self_attention_(projection=...)``, kept on
-    ``owner`` (a module): zero when created, never cleared afterwards (the kernels validate every mark)."""
-    buf = owner.__dict__.get("_selection_hint")
-    if buf is None or buf.shape[0] != batch or buf.shape[1] < rows or buf.device != torch.device(device):
-        buf = torch.zeros((batch, max(rows, 1)), dtype=torch.int32, device=device)
-        owner.__dict__["_selection_hint"] = buf
-    return buf
-
-
 def topk_self_attention_applies(query: Tensor, pos: Tensor, mha, norm, num_selected: int) -> bool:
     """The two-launch top-k self-attention (csrc/topk_attention.hip) covers the released configuration: bf16,
     embed_dim 256, 8 heads, no dropout, batch-first parameters in bf16."""
@@ -1238,7 +1228,7 @@ def topk_self_attention_applies(query: Tensor, pos: Tensor, mha, norm, num_selec
             and pos.stride(2) == 1 and pos.stride(1) == 256)
 
 
-def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm, projection=None, hint=None):
+def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm, projection=None):
     """In place on ``query`` [B,rows,256] bf16: rows ``selected[b]`` become
     ``norm(x + mha(q = k = x + pos, v = x))`` (salience_transformer.py:366-379); ``pos`` [B,>=rows,256] holds the position
     rows in the same row order (may be a row prefix of a longer buffer).  Two launches, no library GEMM.
@@ -1246,8 +1236,7 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
     ``projection = (weight [384,256] bf16 head-major rows, bias)``: the deformable attention's offset | weight
     projection of the UPDATED queries (``token_linear(query, weight, bias, x_add=pos, group_features=48)``) rides in the
     attention's launch (``sdetr_topk_attention_with_projection_bf16``) and is returned as ``[B,8,rows,48]``; ``None`` is
-    returned in its place when that launch does not cover the shape (the caller projects afterwards).  ``hint``: a
-    persistent int32 ``[B, >= rows]`` scratch tensor, zero when first used (``selection_hint_buffer``)."""
+    returned in its place when that launch does not cover the shape (the caller projects afterwards)."""
     _hip.require_device("topk_self_attention_", selected=selected)
     B, rows, _ = query.shape
     N = selected.shape[1]
@@ -1258,9 +1247,7 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
     ws = torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, N), dtype=torch.uint8, device=query.device)
     qbs = query.stride(0) if B > 1 else rows * 256
     pbs = pos.stride(0) if B > 1 else pos.shape[1] * 256
-    carried = (projection is not None and hint is not None and hint.dtype == torch.int32 and hint.dim() == 2
-               and hint.shape[0] == B and hint.shape[1] >= rows and hint.stride(1) == 1 and hint.device == query.device
-               and 289 <= N <= 320 and query.is_contiguous()
+    carried = (projection is not None and 289 <= N <= 320 and query.is_contiguous()
                and token_linear_applies(query, projection[0]) and tuple(projection[0].shape) == (384, 256)
                and projection[0].is_contiguous())
     with torch.cuda.device(query.device):
@@ -1268,6 +1255,10 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
             w, b = projection
             packed, b_pad = _packed_linear_bf16(w, b)
             slab = torch.empty((B, 8, rows, 48), dtype=torch.bfloat16, device=query.device)
+            # marks of the selected rows for the projection part of the launch: UNINITIALISED on purpose -- a mark m
+            # counts only if selected[b][m - 1] is the row it sits on, which no garbage value can fake, and the
+            # in-projection writes the true marks before anything reads them
+            hint = torch.empty((B, rows), dtype=torch.int32, device=query.device)
             code = lib.sdetr_topk_attention_with_projection_bf16(
                 _hip.stream_ptr(), query.data_ptr(), qbs, pos.data_ptr(), pbs, selected.data_ptr(), B, rows, N,
                 mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), mha.out_proj.weight.data_ptr(),

@@ -27,7 +27,7 @@ from torch.nn import functional as F
 from . import pyramid
 from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
-                         fused_ffn_advance, fused_ffn_applies, selection_hint_buffer, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
+                         fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
                          topk_attention_heads, topk_self_attention_, topk_self_attention_applies, value_proj_head_major)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps, plan_batched_value_maps
@@ -180,8 +180,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
             if self.carry_sampling_projection and self.self_attn.head_major_projection_applies(query, value_hm):
                 # the MSDA offset | weight projection of all rows rides in the attention's launch
                 proj = topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm,
-                                            projection=self.self_attn._fused_query_projection_head_major(),
-                                            hint=selection_hint_buffer(self, query.shape[0], c, query.device))
+                                            projection=self.self_attn._fused_query_projection_head_major())
             else:
                 topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm)
             stacked = None

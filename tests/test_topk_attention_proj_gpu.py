@@ -28,9 +28,7 @@ def test_attention_carrying_the_projection_equals_the_two_operators(rows, N):
         qa, qb = q0.clone(), q0.clone()
         F.topk_self_attention_(qa, pos, sel, mha, norm)
         want = F.token_linear(qa, w, b, x_add=pos[:, :rows], group_features=48)
-        hint = torch.zeros(B, rows, dtype=torch.int32, device=DEV)
-        hint[:, ::7] = 5          # stale marks of an earlier call: validated against the selection, harmless
-        got = F.topk_self_attention_(qb, pos, sel, mha, norm, projection=(w, b), hint=hint)
+        got = F.topk_self_attention_(qb, pos, sel, mha, norm, projection=(w, b))
     assert got is not None and got.shape == (B, 8, rows, 48)
     assert torch.equal(qa, qb)                              # the attention itself: same bits
     untouched = torch.ones(B, rows, dtype=torch.bool, device=DEV)
