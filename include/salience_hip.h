@@ -306,6 +306,14 @@ int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *feat, const 
                                 float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16,
                                 float *valid_ratio /* this level's (w,h) of image 0, or NULL */,
                                 int valid_ratio_stride /* floats between images */);
+/*   sdetr_pyramid_flatten: the whole pyramid in ONE launch -- the outputs of `num_levels` calls of
+ *     sdetr_pyramid_flatten_level with level_start = the running pixel count (bit-identical).  feats / pos / masks are
+ *     HOST arrays of `num_levels` (<= 8) device pointers, heights / widths host arrays; level_embeds [num_levels,C] and
+ *     valid_ratios [batch,num_levels,2] (or NULL) live on the device; spatial_size must be the pyramid's pixel count. */
+int sdetr_pyramid_flatten(sdetr_stream_t stream, int num_levels, const float *const *feats, const float *const *pos,
+                          const uint8_t *const *masks, const int *heights, const int *widths, const float *level_embeds,
+                          int batch_size, int channels, int spatial_size, float *feat_out, float *pos_out,
+                          float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16, float *valid_ratios);
 /*   sdetr_masked_fill_min: out[i] = mask[i] ? min(mins[0..num_mins)) : score[i] -- foreground_score of
  *     models/bricks/salience_transformer.py:164-168 from the per-level minima that are already known.
  *   sdetr_encoder_reference_points: get_reference_points (:418-432) for the tokens index[b][i] (index NULL: token i):

@@ -79,6 +79,7 @@ SIGNATURES = {
     "sdetr_encoder_prepare_sorted": (_i, [_p, _p, _p, _i, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p]),
     "sdetr_encoder_reference_points": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i]),
+    "sdetr_pyramid_flatten": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sdetr_class_max_times": (_i, [_p, _p, _i, _p, _i64, _i, _i, _i, _p]),
     "sdetr_layernorm": (_i, [_p, _p, _p, _i, _i64, _i64, _i64, _i64, _p, _p, _p, _p, _i, ctypes.c_float, _i, _i, _i, _p, _i,
                              _p, _i64, _i]),

@@ -33,16 +33,16 @@ struct FlattenArgs {
     int valid_ratio_stride;
 };
 
-// block (32, 8): tile of 32 tokens x 32 channels
-__global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
+// 256 threads as (32, 8): tile of 32 tokens x 32 channels.  `lds`: 2 * 32 * 33 floats + 2 ints.
+__device__ __forceinline__ void pyramid_flatten_body(const FlattenArgs &p, int bx, int by, int b, float *lds)
 {
-    __shared__ float tf[32][33], tp[32][33];
-    __shared__ int valid_hw[2];
+    float (*tf)[33] = reinterpret_cast<float (*)[33]>(lds);
+    float (*tp)[33] = reinterpret_cast<float (*)[33]>(lds + 32 * 33);
+    int *valid_hw = reinterpret_cast<int *>(lds + 2 * 32 * 33);
     const int HW = p.H * p.W;
-    const int b = blockIdx.z;
-    const int tok0 = blockIdx.x * 32, ch0 = blockIdx.y * 32;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * 32 + tx;
+    const int tok0 = bx * 32, ch0 = by * 32;
+    const int tid = (int)threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
     const uint8_t *mb = p.mask + (int64_t)b * HW;
 
     // valid extents: number of unmasked entries in column 0 (height) and row 0 (width)
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
     }
     __syncthreads();
     const float vh = (float)valid_hw[0], vw = (float)valid_hw[1];
-    if (p.valid_ratio && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // get_valid_ratios: (w, h)
+    if (p.valid_ratio && bx == 0 && by == 0 && tid == 0) {  // get_valid_ratios: (w, h)
         p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 0] = vw / (float)p.W;
         p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 1] = vh / (float)p.H;
     }
@@ -101,13 +101,15 @@ __global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
 // Wide form for levels whose pixel count is a multiple of 4 (and C of 64): tiles of 64 tokens x 64 channels, 16-byte
 // loads along the pixels of a channel row (a wave reads 4 rows x 256 contiguous bytes instead of 2 x 128) and 16-byte
 // fp32 / 8-byte bf16 stores along the channels of a token.  Same arithmetic, same outputs.
-__global__ void __launch_bounds__(256) pyramid_flatten_wide_kernel(FlattenArgs p)
+// `lds`: 2 * 64 * 65 floats + 2 ints.
+__device__ __forceinline__ void pyramid_flatten_wide_body(const FlattenArgs &p, int bx, int by, int b, float *lds)
 {
-    __shared__ float tf[64][65], tp[64][65];   // [token][channel]; odd stride: both phases at most 2-way conflicts
-    __shared__ int valid_hw[2];
+    float (*tf)[65] = reinterpret_cast<float (*)[65]>(lds);   // [token][channel]; odd stride: both phases at most 2-way conflicts
+    float (*tp)[65] = reinterpret_cast<float (*)[65]>(lds + 64 * 65);
+    int *valid_hw = reinterpret_cast<int *>(lds + 2 * 64 * 65);
     const int HW = p.H * p.W;
-    const int b = blockIdx.z, tok0 = blockIdx.x * 64, ch0 = blockIdx.y * 64;
-    const int tid = threadIdx.x;
+    const int tok0 = bx * 64, ch0 = by * 64;
+    const int tid = (int)threadIdx.x;
     const uint8_t *mb = p.mask + (int64_t)b * HW;
     if (tid < 128) {
         int cnt = 0;
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(256) pyramid_flatten_wide_kernel(FlattenArgs p
     }
     __syncthreads();
     const float vh = (float)valid_hw[0], vw = (float)valid_hw[1];
-    if (p.valid_ratio && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    if (p.valid_ratio && bx == 0 && by == 0 && tid == 0) {
         p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 0] = vw / (float)p.W;
         p.valid_ratio[(int64_t)b * p.valid_ratio_stride + 1] = vh / (float)p.H;
     }
@@ -165,6 +167,45 @@ __global__ void __launch_bounds__(256) pyramid_flatten_wide_kernel(FlattenArgs p
         if (p.pos_bf16) *reinterpret_cast<uint2 *>(p.pos_bf16 + o) = make_uint2(pack_bf16x2(qv.x, qv.y), pack_bf16x2(qv.z, qv.w));
         if (c4 == 0 && ch0 == 0) p.mask_out[(int64_t)b * p.S + p.start + t] = pad ? 1 : 0;
     }
+}
+
+constexpr int kFlattenLdsFloats = 2 * 64 * 65 + 2;
+constexpr int kFlattenMaxLevels = 8;
+
+__global__ void __launch_bounds__(256) pyramid_flatten_kernel(FlattenArgs p)
+{
+    __shared__ float lds[2 * 32 * 33 + 2];
+    pyramid_flatten_body(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
+}
+
+__global__ void __launch_bounds__(256) pyramid_flatten_wide_kernel(FlattenArgs p)
+{
+    __shared__ float lds[kFlattenLdsFloats];
+    pyramid_flatten_wide_body(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds);
+}
+
+// All levels in one launch: the blocks of level 0 first (the long tail of small levels runs beside them instead of
+// after them -- three of the four per-level launches of the 800x1333 pyramid are latency, not bandwidth).
+struct FlattenAllArgs {
+    FlattenArgs lv[kFlattenMaxLevels];
+    int first_block[kFlattenMaxLevels + 1];   // prefix sums of the levels' block counts
+    int blocks_x[kFlattenMaxLevels], blocks_y[kFlattenMaxLevels];
+    int wide[kFlattenMaxLevels];
+    int levels;
+};
+
+__global__ void __launch_bounds__(256) pyramid_flatten_all_kernel(FlattenAllArgs a)
+{
+    __shared__ float lds[kFlattenLdsFloats];
+    const int blk = (int)blockIdx.x;
+    int l = 0;
+    while (l + 1 < a.levels && blk >= a.first_block[l + 1]) ++l;
+    int r = blk - a.first_block[l];
+    const int bx = r % a.blocks_x[l];
+    r /= a.blocks_x[l];
+    const int by = r % a.blocks_y[l], b = r / a.blocks_y[l];
+    if (a.wide[l]) pyramid_flatten_wide_body(a.lv[l], bx, by, b, lds);
+    else pyramid_flatten_body(a.lv[l], bx, by, b, lds);
 }
 
 template <typename T>
@@ -359,8 +400,54 @@ extern "C" int sdetr_pyramid_flatten_level(sdetr_stream_t stream, const float *f
         return check_launch("pyramid_flatten_level");
     }
     const dim3 grid((unsigned)((H * W + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
-    hipLaunchKernelGGL(pyramid_flatten_kernel, grid, dim3(32, 8), 0, stream, a);
+    hipLaunchKernelGGL(pyramid_flatten_kernel, grid, dim3(256), 0, stream, a);
     return check_launch("pyramid_flatten_level");
+}
+
+// The whole pyramid in one launch: the same per-level arithmetic and outputs as `num_levels` calls of
+// sdetr_pyramid_flatten_level with level_start = the running pixel count.  feats / pos / masks: HOST arrays of
+// `num_levels` device pointers; heights / widths: host arrays; level_embeds [num_levels, C] and valid_ratios
+// [B, num_levels, 2] (may be NULL) on the device.
+extern "C" int sdetr_pyramid_flatten(sdetr_stream_t stream, int num_levels, const float *const *feats,
+                                     const float *const *pos, const uint8_t *const *masks, const int *heights,
+                                     const int *widths, const float *level_embeds, int B, int C, int S, float *feat_out,
+                                     float *pos_out, float *sum_out, uint8_t *mask_out, void *feat_bf16, void *pos_bf16,
+                                     float *valid_ratios)
+{
+    if (num_levels <= 0 || num_levels > kFlattenMaxLevels) return fail("pyramid_flatten: 1..%d levels", kFlattenMaxLevels);
+    if (B < 0 || C <= 0 || S <= 0) return fail("pyramid_flatten: bad dims");
+    if (!feats || !pos || !masks || !heights || !widths || !level_embeds || !sum_out || !mask_out)
+        return fail("pyramid_flatten: null pointer");
+    if ((feat_bf16 || pos_bf16) && (C & 1)) return fail("pyramid_flatten: bf16 copies need an even channel count");
+    FlattenAllArgs a{};
+    a.levels = num_levels;
+    int64_t start = 0, blocks = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        const int H = heights[l], W = widths[l];
+        if (H <= 0 || W <= 0 || !feats[l] || !pos[l] || !masks[l]) return fail("pyramid_flatten: bad level %d", l);
+        FlattenArgs &v = a.lv[l];
+        v.feat = feats[l]; v.pos = pos[l]; v.mask = masks[l]; v.level_embed = level_embeds + (int64_t)l * C;
+        v.B = B; v.C = C; v.H = H; v.W = W; v.S = S; v.start = (int)start;
+        v.box_wh = 0.05f * (float)(1u << l);
+        v.feat_out = feat_out; v.pos_out = pos_out; v.sum_out = sum_out; v.mask_out = mask_out;
+        v.feat_bf16 = reinterpret_cast<bf16_t *>(feat_bf16); v.pos_bf16 = reinterpret_cast<bf16_t *>(pos_bf16);
+        v.valid_ratio = valid_ratios ? valid_ratios + 2 * l : nullptr;
+        v.valid_ratio_stride = 2 * num_levels;
+        const int64_t HW = (int64_t)H * W;
+        a.wide[l] = (C & 63) == 0 && (HW & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(feats[l]) | reinterpret_cast<uintptr_t>(pos[l])) & 15) == 0;
+        a.blocks_x[l] = (int)(a.wide[l] ? (HW + 63) / 64 : (HW + 31) / 32);
+        a.blocks_y[l] = a.wide[l] ? C / 64 : (C + 31) / 32;
+        a.first_block[l] = (int)blocks;
+        blocks += (int64_t)a.blocks_x[l] * a.blocks_y[l] * B;
+        start += HW;
+        if (blocks > 0x7fffffff || start > S) return fail("pyramid_flatten: sizes out of range");
+    }
+    a.first_block[num_levels] = (int)blocks;
+    if (start != S) return fail("pyramid_flatten: spatial_size %d is not the pixel count %lld", S, (long long)start);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(pyramid_flatten_all_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return check_launch("pyramid_flatten");
 }
 
 extern "C" int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,

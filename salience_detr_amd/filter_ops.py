@@ -169,9 +169,12 @@ def scatter_rows_(dst: Tensor, idx: Tensor, src: Tensor, count: Optional[Tensor]
     return dst
 
 
+flatten_one_launch = True     # F0 as one launch for the whole pyramid (False: one per level; same bits)
+
+
 def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks, level_embeds: Tensor,
-                    want_bf16: bool = False, want_fp32: bool = True):
-    """F0 in one launch per level: ``flatten_multi_level`` + ``get_lvl_pos_embed``
+                    want_bf16: bool = False, want_fp32: bool = True, one_launch: Optional[bool] = None):
+    """F0 in one launch (``one_launch=False``: one per level, same bits): ``flatten_multi_level`` + ``get_lvl_pos_embed``
     (base_transformer.py:22-33) + the token validity of ``gen_encoder_output_proposals`` (:74-112).
 
     Returns ``(feat_flatten [B,S,C], lvl_pos_embed_flatten [B,S,C], enc_output_input [B,S,C] =
@@ -199,6 +202,18 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
     valid_ratios = torch.empty((B, len(feats), 2), dtype=torch.float32, device=dev)
     lib = _hip.lib()
     start = 0
+    L = len(feats)
+    if (flatten_one_launch if one_launch is None else one_launch) and L <= 8:
+        mu8s = [m.view(torch.uint8) if m.dtype == torch.bool else m for m in masks]
+        ptrs = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+        ints = lambda vs: (ctypes.c_int * L)(*vs)
+        with torch.cuda.device(dev):
+            code = lib.sdetr_pyramid_flatten(
+                _hip.stream_ptr(), L, ptrs(feats), ptrs(pos), ptrs(mu8s), ints([int(f.shape[2]) for f in feats]),
+                ints([int(f.shape[3]) for f in feats]), le.data_ptr(), B, C, S, _hip.ptr(feat_out), _hip.ptr(pos_out),
+                sum_out.data_ptr(), mask_out.data_ptr(), _hip.ptr(feat_bf16), _hip.ptr(pos_bf16), valid_ratios.data_ptr())
+        _hip.check(code, "pyramid_flatten")
+        return feat_out, pos_out, sum_out, mask_out, feat_bf16, pos_bf16, valid_ratios
     with torch.cuda.device(dev):
         for lvl, (f, p, m) in enumerate(zip(feats, pos, masks)):
             H, W = int(f.shape[2]), int(f.shape[3])

@@ -127,7 +127,8 @@ def test_class_max_times(dtype):
 
 @pytest.mark.parametrize("sizes", [[(64, 96), (48, 80)], [(800, 1333)], [(300, 500), (333, 480), (100, 37)]])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_pyramid_flatten_matches_reference_plumbing(sizes, bf16):
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_pyramid_flatten_matches_reference_plumbing(sizes, bf16, one_launch):
     from salience_detr_amd import pyramid
     E = 64
     _, masks = syn.make_masks(sizes)
@@ -136,7 +137,8 @@ def test_pyramid_flatten_matches_reference_plumbing(sizes, bf16):
     pos = [syn.det_randn(f"pos{l}", tuple(f.shape)) for l, f in enumerate(feats)]
     le = syn.det_randn("le", (4, E))
     feat, posf, enc_in, mask, fb, pb, vr = F.pyramid_flatten([f.to(DEV) for f in feats], [p.to(DEV) for p in pos],
-                                                             [m.to(DEV) for m in masks], le.to(DEV), want_bf16=bf16)
+                                                             [m.to(DEV) for m in masks], le.to(DEV), want_bf16=bf16,
+                                                             one_launch=one_launch)
     assert (vr.cpu() - R.level_misc(masks)[2]).abs().max() < 1e-7
     ref_feat = R.flatten_levels(feats)
     ref_mask = R.flatten_levels(masks)
