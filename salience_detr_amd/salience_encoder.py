@@ -53,6 +53,9 @@ class SalienceTransformerEncoderLayer(nn.Module):
         # one-launch gather + in-projection + attention of the selected rows (csrc/mha_topk.hip): correct, but on
         # MI355X it only ties the three-launch path (its row gather is bound by one CU's L1 per head), so it is opt-in
         self.fused_topk_attention = False
+        # training: the attention's in / out projections (F.linear on the MHA module's own parameters) through
+        # linear_x3.x3_linear (set by use_x3_linear_)
+        self.x3_projections = False
         # the default on the bf16 path: in-projection (with the gather and the position add in its operand loads) and
         # attention + out_proj + residual + pre_norm + scatter as two launches of csrc/topk_attention.hip
         self.two_launch_topk_attention = True
@@ -127,7 +130,11 @@ class SalienceTransformerEncoderLayer(nn.Module):
         B, _, E = stacked.shape
         H = mha.num_heads
         hd = E // H
-        proj = F.linear(stacked, mha.in_proj_weight, mha.in_proj_bias)   # [B, 2N, 3E]
+        linear = F.linear
+        if self.x3_projections and torch.is_grad_enabled() and stacked.dtype == torch.float32:
+            from .linear_x3 import x3_linear as linear   # weight / bias gradients from the x3 kernel (the library takes
+            # 145 us for the 256 x 600 x 256 weight gradient of out_proj: one 256 x 256 tile, no split of the reduction)
+        proj = linear(stacked, mha.in_proj_weight, mha.in_proj_bias)   # [B, 2N, 3E]
         q = proj[:, :N, :E].view(B, N, H, hd).transpose(1, 2)
         k = proj[:, :N, E:2 * E].view(B, N, H, hd).transpose(1, 2)
         vv = proj[:, N:, 2 * E:].view(B, N, H, hd).transpose(1, 2)
@@ -152,7 +159,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         o = o.transpose(1, 2).reshape(B, N, E)
         if not apply_out_proj:
             return o
-        return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+        return linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
                        class_head, level_shapes=None, selection_hook=None, advance=None):
