@@ -10,7 +10,9 @@ import sys
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    first = [i for i, r in enumerate(rows) if "pyramid_flatten" in r["Kernel_Name"]][::4]
+    # a step starts at its first flatten launch (one for the whole pyramid, or one per level back to back)
+    first = [i for i, r in enumerate(rows) if "pyramid_flatten" in r["Kernel_Name"]
+             and (i == 0 or "pyramid_flatten" not in rows[i - 1]["Kernel_Name"])]
     k = int(sys.argv[2]) if len(sys.argv) > 2 else len(first) // 2
     s, e = first[k], first[k + 1]
     t0 = int(rows[s]["Start_Timestamp"])
