@@ -213,3 +213,42 @@ def test_opt_in_fused_topk_attention_matches_default_path():
     diff = (fused - base).abs()
     assert diff.mean().item() < 0.02 * base.abs().mean().item()
     assert (diff.max(-1)[0] < 0.25).float().mean().item() > 0.98
+
+
+@pytest.mark.parametrize("image_sizes", [[(480, 640)], [(800, 1333), (608, 911), (333, 500)],
+                                         [(800, 1333), (800, 1333), (736, 1100), (800, 1201)]])
+def test_bf16_launch_fusions_do_not_change_the_result(image_sizes):
+    """The bf16 inference path with every carried launch (value projection / ranks / output pass inside the salience
+    head's launches, query projection inside the top-300 attention, one-launch pyramid flatten) against the same
+    modules launched one by one, at batch sizes and pyramids other than the benchmark's: the filtering is the same
+    arithmetic in both (scores, selections and value maps bit-identical); the carried query projection computes the
+    300 updated rows with another MFMA shape, so the encoder output agrees to bf16 round-off."""
+    from salience_detr_amd import filter_ops as F
+    m, feats, masks, pos = _full_model_and_inputs(image_sizes)
+    m = m.to(DEV).eval()
+    m.set_encoder_dtype(torch.bfloat16, torch.float16)
+    args = ([f.to(DEV) for f in feats], [x.to(DEV) for x in masks], [p.to(DEV) for p in pos])
+
+    def run(fused):
+        m.fuse_value_projection = fused
+        for layer in m.encoder.layers:
+            layer.carry_sampling_projection = fused
+        F.flatten_one_launch = fused
+        try:
+            with torch.no_grad():
+                mem, scores, aux = m(*args, return_aux=True)
+            torch.cuda.synchronize()
+        finally:
+            F.flatten_one_launch = True
+        return mem, scores, aux
+
+    mem1, sc1, aux1 = run(True)
+    mem0, sc0, aux0 = run(False)
+    for a, b in zip(sc1, sc0):
+        assert torch.equal(a, b)
+    for a, b in zip(aux1["foreground_inds"], aux0["foreground_inds"]):
+        assert torch.equal(a, b)
+    diff = (mem1.float() - mem0.float()).abs()
+    scale = mem0.float().abs().mean().item()
+    assert diff.mean().item() < 0.01 * scale
+    assert (diff.max(-1)[0] < 0.25).float().mean().item() > 0.99
