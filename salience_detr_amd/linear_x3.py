@@ -143,9 +143,17 @@ class _LinearX3(Function):
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:                                                    # dw = dy^T x (+ db = sum_t dy)
             if X3_DW:
+                splits = _weight_grad_splits(T, N, K)
+                out = None
                 if want_gb:   # the kernel has dy's tiles in registers anyway: the bias gradient is their row sums
-                    gb = torch.zeros(N, dtype=torch.float32, device=g2.device)
-                gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=_weight_grad_splits(T, N, K), a_row_sum=gb)
+                    # (one zero fill for both gradients: the split reduction adds into dw as the row sums add into db)
+                    buf = torch.zeros(N * K + N, dtype=torch.float32, device=g2.device)
+                    out, gb = buf[:N * K].view(N, K), buf[N * K:]
+                elif splits > 1:
+                    out = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
+                gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=splits, out=out, a_row_sum=gb)
+                if out is not None:
+                    gw = out
             else:
                 gw = g2.t() @ x2
         if want_gb and gb is None:

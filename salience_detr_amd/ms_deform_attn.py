@@ -635,7 +635,9 @@ class MultiScaleDeformableAttention(nn.Module):
         # autograd path: reference layout, fp32 op with the HIP forward/backward kernels
         value = self.value_proj(value)
         if key_padding_mask is not None:
-            value = value.masked_fill(key_padding_mask[..., None], float(0))
+            # in place: the projection's output is a fresh tensor nothing else holds and no backward needs
+            # (the out-of-place form copies the [B, Nv, 256] map first)
+            value = value.masked_fill_(key_padding_mask[..., None], float(0))
         value = value.view(batch_size, num_value, self.num_heads, self.embed_dim // self.num_heads)
         sampling_offsets = self.sampling_offsets(query).view(
             batch_size, num_query, self.num_heads, self.num_levels, self.num_points, 2)

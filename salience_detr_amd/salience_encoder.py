@@ -235,8 +235,14 @@ class SalienceTransformerEncoderLayer(nn.Module):
             select_tgt = gather_rows(query, select_tgt_index)
             select_pos = gather_rows(query_pos, select_tgt_index)
         else:
-            mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
-            select_tgt_index = torch.sort(mc_score, dim=1, descending=True, stable=True)[1][:, :self.topk_sa]
+            if score_tgt.is_cuda and score_tgt.dtype == torch.float32 and score_tgt.shape[1] >= self.topk_sa:
+                # the selection carries no gradient: the no-grad path's kernels (same order: descending, ties by position)
+                with torch.no_grad():
+                    mc_score = class_max_times(score_tgt.detach(), foreground_pre_layer.detach())
+                    select_tgt_index = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
+            else:
+                mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
+                select_tgt_index = torch.sort(mc_score, dim=1, descending=True, stable=True)[1][:, :self.topk_sa]
             index_e = select_tgt_index.unsqueeze(-1).expand(-1, -1, self.embed_dim)
             select_tgt = torch.gather(query, 1, index_e)
             select_pos = torch.gather(query_pos, 1, index_e)
