@@ -505,7 +505,7 @@ def main():
         torch.cuda.synchronize()
 
     lanes = []
-    if args.plain and graphed and args.in_flight > 1:
+    if args.plain and graphed and args.in_flight > 1 and args.dtype == "bf16":
         lanes = make_lanes(model, args, device, rank, (g, out, step), args.in_flight, capture_kw, sizes, canvas)
         run = lane_runner(lanes)
         for _ in range(2 * len(lanes)):
@@ -650,7 +650,8 @@ def main():
     # ---- informational: the same K steps with three independent batches in flight (own inputs, graph, stream) ----
     # One batch is a dependent chain of ~76 launches, most of which fill a fraction of the 256 CUs; a server with
     # queued requests overlaps chains.  NOT the headline: `value` above is one batch at a time.
-    if graphed and world == 1 and args.in_flight_report > 1:
+    # (bf16 only: library GEMMs of the fp32 mode must not replay side by side -- salience_detr_amd/graph_lanes.py)
+    if graphed and world == 1 and args.in_flight_report > 1 and args.dtype == "bf16":
         try:
             lanes = make_lanes(model, args, device, rank, (g, out, step), args.in_flight_report, capture_kw, sizes, canvas)
             lrun = lane_runner(lanes)
