@@ -184,3 +184,28 @@ def test_x3_linear_swap_keeps_parameters_and_falls_back_on_cpu():
     assert X._weight_grad_splits(100, 256, 256) == 1
     assert X._weight_grad_splits(22726, 256, 256) > X._weight_grad_splits(22726, 2048, 256) >= 1
     assert X._weight_grad_splits(22726, 256, 256) <= (22726 + 255) // 256
+
+
+def test_graph_lanes_input_structure_checks_and_device_requirement():
+    """Host side of graph_lanes: static-input bookkeeping (structure, shape and dtype must match the example the lanes
+    were captured with) and the refusal to run without a HIP device (no CPU fallback)."""
+    from salience_detr_amd import graph_lanes as GL
+    a = ([torch.zeros(2, 3), torch.zeros(4)], [torch.zeros(2, dtype=torch.bool)])
+    clone = GL._map(a, lambda t: t.clone())
+    assert isinstance(clone, tuple) and isinstance(clone[0], list) and clone[0][0] is not a[0][0]
+    src = ([torch.ones(2, 3), torch.ones(4)], [torch.ones(2, dtype=torch.bool)])
+    GL._zip_apply(clone, src, lambda d, s: d.copy_(s))
+    assert clone[0][0].sum() == 6 and bool(clone[1][0].all())
+    with pytest.raises(ValueError):
+        GL._zip_apply(clone, ([torch.ones(2, 3)], [torch.ones(2, dtype=torch.bool)]), lambda d, s: None)   # a tensor short
+    with pytest.raises(ValueError):
+        GL._zip_apply(clone, ([torch.ones(3, 3), torch.ones(4)], [torch.ones(2, dtype=torch.bool)]), lambda d, s: None)
+    with pytest.raises(ValueError):
+        GL._zip_apply(clone, ([torch.ones(2, 3), torch.ones(4)], [torch.ones(2)]), lambda d, s: None)      # dtype
+    with pytest.raises(TypeError):
+        GL._map({"x": torch.zeros(1)}, lambda t: t)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=1)
+    with pytest.raises(ValueError):
+        GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=0)
