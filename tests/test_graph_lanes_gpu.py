@@ -7,7 +7,8 @@ from salience_detr_amd import synthetic as syn
 from salience_detr_amd.graph_lanes import GraphLanes
 from salience_detr_amd.hot_path import build_hot_path
 
-pytestmark = pytest.mark.gpu
+# (thread method: a replay that never completes blocks inside a C call, where the signal method cannot interrupt)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180, method="thread")]
 DEV = "cuda:0"
 
 
