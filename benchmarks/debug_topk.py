@@ -1,4 +1,4 @@
-import math, os, sys, torch
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from salience_detr_amd import _hip, synthetic as syn

@@ -11,7 +11,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from salience_detr_amd import pyramid, synthetic as syn  # noqa: E402
+from salience_detr_amd import synthetic as syn  # noqa: E402
 from salience_detr_amd.hot_path import SalienceEncoderHotPath  # noqa: E402
 from salience_detr_amd.salience_transformer import build_salience_transformer  # noqa: E402
 

@@ -14,7 +14,7 @@ collective.  Here:
   is what DDP's default 25 MB buckets would multiply.  ``bucket_bytes`` is still configurable for overlap
   with a longer backward.
 """
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist

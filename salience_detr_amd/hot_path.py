@@ -8,7 +8,7 @@ path touches, under the SAME state_dict keys (``level_embeds``, ``enc_output*``,
 checkpoint loads with ``load_state_dict(strict=False)``; the neck, two-stage proposal head and decoder
 (everything after ``memory``) are out of scope.
 """
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn

@@ -4,13 +4,11 @@ embeddings the hot path needs.  Device-side torch glue only; no arithmetic kerne
 Reference: ``models/bricks/base_transformer.py:22-56, 74-112`` and
 ``models/bricks/position_encoding.py:10-99``.
 """
-import math
 from typing import List, Sequence, Tuple
 
 import numpy as np
 import torch
 from torch import Tensor, nn
-from torch.nn import functional as F
 
 
 def flatten_multi_level(multi_level_elements: Sequence[Tensor]) -> Tensor:

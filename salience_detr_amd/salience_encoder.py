@@ -18,7 +18,7 @@ forward/backward op (``MultiScaleDeformableAttnFunction``).
 """
 import copy
 import math
-from typing import List, Optional, Sequence
+from typing import List, Optional
 
 import torch
 from torch import Tensor, nn
@@ -29,7 +29,7 @@ from .filter_ops import (advance_rows, attention_heads, attention_heads_applies,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
-                         topk_attention_heads, topk_self_attention_, topk_self_attention_applies, value_proj_head_major)
+                         topk_attention_heads, topk_self_attention_, topk_self_attention_applies)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps, plan_batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 

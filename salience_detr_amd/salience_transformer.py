@@ -17,14 +17,13 @@ The stages after ``memory`` on the no-grad path:
 Denoising queries (training) are accepted and concatenated as in the reference; the neck (row N3) is not built: a
 module passed as ``neck`` is applied with plain torch ops exactly where the reference applies it.
 """
-import math
 from typing import Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
 
 from . import pyramid
-from .filter_ops import (class_head_max_times, class_max_times, encoder_output_proposals, fused_layer_norm, gather_rows,
+from .filter_ops import (class_head_max_times, encoder_output_proposals, fused_layer_norm, gather_rows,
                          grid_nms_topk, masked_topk_desc, proposal_refine, token_linear, token_linear_applies)
 from .hot_path import SalienceEncoderHotPath
 from .salience_decoder import MLP, SalienceTransformerDecoder, SalienceTransformerDecoderLayer

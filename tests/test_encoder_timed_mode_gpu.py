@@ -14,9 +14,7 @@ import torch
 
 from oracle import salience_ref as R
 from salience_detr_amd import ms_deform_attn as M
-from salience_detr_amd import pyramid
 from salience_detr_amd import synthetic as syn
-from salience_detr_amd.filter_ops import encoder_reference_points
 from salience_detr_amd.hot_path import build_hot_path
 
 pytestmark = pytest.mark.gpu

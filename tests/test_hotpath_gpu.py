@@ -9,7 +9,6 @@ import pytest
 import torch
 
 from oracle import salience_ref as R
-from salience_detr_amd import pyramid
 from salience_detr_amd import synthetic as syn
 from salience_detr_amd.hot_path import build_hot_path
 
