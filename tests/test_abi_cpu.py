@@ -114,3 +114,39 @@ def test_criterion_and_attention_refuse_cpu_tensors():
     x = torch.zeros(1, 8, 256, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         attention_heads(x, x, x, 8)
+
+
+def test_round2_entry_points_reject_bad_arguments(libpath):
+    """Host-side checks of the entries added in round 2 (no launch is reached, safe without a GPU)."""
+    from salience_detr_amd import _hip
+    lib = _hip.lib()
+    L = 2
+    ptrs = (ctypes.c_void_p * L)(8, 8)              # non-null dummies: rejected before anything dereferences them
+    hs, ws = (ctypes.c_int * L)(4, 2), (ctypes.c_int * L)(4, 2)
+    flat = lambda levels, S, p=ptrs, h=hs, w=ws: lib.sdetr_pyramid_flatten(
+        None, levels, p, p, p, h, w, 8, 1, 64, S, None, None, 8, 8, None, None, None)
+    assert flat(0, 20) == _hip.EINVAL and b"levels" in lib.sdetr_last_error()
+    assert flat(9, 20) == _hip.EINVAL
+    assert flat(L, 21) == _hip.EINVAL and b"pixel count" in lib.sdetr_last_error()      # 4*4 + 2*2 = 20
+    assert flat(L, 20, h=(ctypes.c_int * L)(4, 0)) == _hip.EINVAL and b"bad level" in lib.sdetr_last_error()
+    assert flat(L, 20, p=(ctypes.c_void_p * L)(8, None)) == _hip.EINVAL
+    assert lib.sdetr_pyramid_flatten(None, L, ptrs, ptrs, ptrs, hs, ws, 8, 0, 64, 20, None, None, 8, 8, None, None,
+                                     None) == 0                                            # empty batch: nothing to do
+    # fp32-accurate GEMM
+    assert lib.sdetr_gemm_x3_f32(None, 8, 4, 1, 8, 4, 1, 8, 4, -1, 4, 4, None, 1, None) == _hip.EINVAL
+    assert b"negative" in lib.sdetr_last_error()
+    assert lib.sdetr_gemm_x3_f32(None, None, 4, 1, 8, 4, 1, 8, 4, 4, 4, 4, None, 1, None) == _hip.EINVAL
+    assert b"null" in lib.sdetr_last_error()
+    # LDS-accumulating MSDA backward: shape support and scratch size are host functions
+    assert lib.sdetr_msda_col2im_lds_supported(8, 32, 4, 4, 22323) == 1
+    assert lib.sdetr_msda_col2im_lds_supported(8, 64, 4, 4, 22323) == 0      # head_dim 64
+    assert lib.sdetr_msda_col2im_lds_supported(8, 32, 9, 4, 22323) == 0      # more than 8 levels
+    assert lib.sdetr_msda_col2im_lds_workspace_bytes(0, 100, 8, 4) == 256
+    big = lib.sdetr_msda_col2im_lds_workspace_bytes(2, 11363, 8, 4)
+    assert big > 4 * 2 * 11363 * 6 and big % 256 == 0
+    assert lib.sdetr_msda_col2im_lds_f32(None, None, None, None, None, None, None, 2, 100, 8, 64, 4, 10, 4, None, None,
+                                         None, None, 0) == _hip.EINVAL
+    assert b"D = 32" in lib.sdetr_last_error()
+    # which top-k shapes go through the prefilter, how many stage-1 blocks a level takes
+    assert lib.sdetr_topk_uses_prefilter(11363, 300) == 1 and lib.sdetr_topk_uses_prefilter(1050, 1050) == 0
+    assert lib.sdetr_salience_head_blocks(2, 16800) == 525 and lib.sdetr_salience_head_blocks(2, 0) == 0
