@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds the standalone micro-benchmarks for gfx950 next to their sources (cross-compiles without a GPU; the binaries
+# are git-ignored and travel to the GPU box with the snapshot).      bash benchmarks/micro/build.sh
+set -e
+cd "$(dirname "$0")"
+for f in lds_atomic_rate mfma_rate ffn_two_wave graph_launch_floor valu_rate gather_rate kernel_cold_start; do
+  [ -f $f.hip ] || continue
+  extra=""
+  [ $f = lds_atomic_rate ] && extra="-munsafe-fp-atomics"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $extra -o $f $f.hip 2> /dev/null && echo "built $f"
+done

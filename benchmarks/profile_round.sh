@@ -49,4 +49,8 @@ cp $(find $O/${R}_prof_train -name '*kernel_stats.csv' | head -1) $O/${R}_train_
 # 8. the MSDA backward kernels side by side, the fp32-accurate GEMM against the library
 python benchmarks/msda_backward_ab.py > $O/${R}_msda_backward_ab.json 2> /dev/null
 python benchmarks/gemm_x3_bench.py > $O/${R}_gemm_x3.json 2> /dev/null
+# 9. standalone micro-benchmarks behind the statements in DESIGN.md 6 / 8 (built by benchmarks/micro/build.sh)
+for m in ffn_two_wave graph_launch_floor valu_rate gather_rate kernel_cold_start; do
+  [ -x benchmarks/micro/$m ] && timeout 60 ./benchmarks/micro/$m > $O/${R}_$m.json 2> /dev/null
+done
 ls $O | grep "^${R}" | head -40
