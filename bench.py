@@ -60,8 +60,6 @@ def parse():
                          "(default; 11-bit mantissa, gather via v_fma_mix_f32) or the activation dtype (bf16)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-value-proj", action="store_true",
-                    help="run the six layers' value projection on a side stream next to the filtering stage")
     ap.add_argument("--plain", action="store_true",
                     help="only the timed loop and a minimal JSON line (what the rocprofv3 counter passes wrap: no "
                          "instrumented pass, no truncated graphs, no CPU baseline)")
@@ -468,7 +466,6 @@ def main():
         return train_main(args, model, device, rank, world, dist)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_encoder_dtype(dtype, torch.float16 if (args.dtype == "bf16" and args.value_dtype == "fp16") else None)
-    model.overlap_value_projection = bool(args.overlap_value_proj)
 
     sizes, canvas, level_shapes, cpu_inputs, (feats, masks, pos) = make_inputs(
         args.batch, args.height, args.width, device, seed=rank)

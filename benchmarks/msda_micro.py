@@ -87,11 +87,6 @@ def main():
             hm16 = hm.float().to(torch.float16)
             t = timeit(lambda: M.msda_fused_forward(hm16, sh, ls, rf, pj, 4, 4, out_dtype=torch.bfloat16))
             res.append(dict(case="enc_direct_f16value", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
-            order = M.region_bucket(rf, sh, LEVELS[0])[0]
-            t = timeit(lambda: M.msda_fused_forward(hm, sh, ls, rf, pj, 4, 4, order=order, out_dtype=torch.bfloat16))
-            res.append(dict(case="enc_direct_bf16_region_order", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
-            t = timeit(lambda: M.msda_tiled_forward(hm, sh, ls, rf, pj, LEVELS[0], 4, 4, out_dtype=torch.bfloat16))
-            res.append(dict(case="enc_tiled_bf16(+bucket)", Nq=Nq, offset_px=off, us=t, GBps=alg / t / 1e3))
     value = torch.randn(B, 22323, 256, device=DEV)
     for sdt in (torch.float32, torch.bfloat16):
         for ddt in (torch.float32, torch.bfloat16):

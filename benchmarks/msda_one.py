@@ -19,6 +19,4 @@ hm = M.value_to_head_major(torch.randn(B, 22323, 256, device=DEV), None, 8, VDT)
 sh, ls, rf, pj = shapes.to(DEV), lsi.to(DEV), ref.to(DEV), proj.to(torch.bfloat16).to(DEV)
 for _ in range(reps):
     M.msda_fused_forward(hm, sh, ls, rf, pj, 4, 4, out_dtype=torch.bfloat16)
-    if os.environ.get("TILED", "0") == "1" and VDT == torch.bfloat16:
-        M.msda_tiled_forward(hm, sh, ls, rf, pj, LEVELS[0], 4, 4, out_dtype=torch.bfloat16)
 torch.cuda.synchronize()

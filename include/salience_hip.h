@@ -139,26 +139,6 @@ int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value_hm, int va
                              int channels, int num_levels, int num_query, int num_point, void *out,
                              int out_dtype);
 
-/* LDS-staged variant of sdetr_msda_fused_forward for dense query sets (the encoder): queries are first
- * bucketed by the level-0 region of their reference point (sdetr_region_bucket), then one workgroup per
- * (image, head, region) stages that region's window of every level in LDS and gathers from there; samples
- * outside the window fall back to global loads inside the kernel, so results equal the direct kernel's.
- * Shape support: bf16 head-major value, head_dim 32, 4 levels, 4 points (all Salience-DETR configs).
- *   sdetr_tiled_config : compile-time region size (level-0 pixels) and window halo
- *   sdetr_region_bucket: order [B,Nq] int32 (query slots grouped by region), region_start [B,R+1] int32,
- *                        R = ceil(level0_w/region_w) * ceil(level0_h/region_h)
- */
-void sdetr_tiled_config(int *region_w, int *region_h, int *halo);
-int sdetr_region_bucket(sdetr_stream_t stream, const float *ref_points, const int64_t *data_spatial_shapes,
-                        int ref_dim, int batch_size, int num_query, int num_levels, int level0_h, int level0_w,
-                        int32_t *order, int32_t *region_start, int32_t *region_box /* [B,R,4 levels,4] */);
-int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm_bf16,
-                             const int64_t *data_spatial_shapes, const int64_t *data_level_start_index,
-                             const float *ref_points, int ref_dim, const void *proj, int proj_dtype,
-                             int64_t proj_row_stride, const int32_t *order, const int32_t *region_start,
-                             const int32_t *region_box, int num_regions, int batch_size, int spatial_size, int num_heads, int channels,
-                             int num_levels, int num_query, int num_point, void *out, int out_dtype);
-
 /* Coarse-levels-in-LDS variant of sdetr_msda_fused_forward (csrc/msda_resident.hip): one persistent 1024-thread
  * workgroup per CU copies levels 2 and 3 of its (image, head) into LDS once and serves their samples from there, so
  * the vector memory path only carries the level-0 / level-1 samples.  Same arithmetic and results as the direct
@@ -173,7 +153,6 @@ int sdetr_msda_tiled_forward(sdetr_stream_t stream, const void *value_hm_bf16,
 #define SDETR_KERNEL_MSDA_GATHER 2   /* msda_gather_kernel: lane groups per row, LDS descriptor table */
 #define SDETR_KERNEL_MSDA_L4P4 3     /* msda_gather_l4p4_kernel: the Salience-DETR shape, direct gather */
 #define SDETR_KERNEL_MSDA_RESIDENT 4 /* msda_resident_kernel: levels 2+3 resident in LDS */
-#define SDETR_KERNEL_MSDA_TILED 5    /* msda_tiled_kernel: per-region windows staged in LDS */
 int sdetr_msda_resident_max_pixels(void);
 int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *value_hm, int value_dtype,
                                 const int32_t *level_hw_host, const float *ref_points, int ref_dim,
@@ -539,18 +518,7 @@ int sdetr_token_linear_ln_bf16(sdetr_stream_t stream, const void *x, const void 
                                const float *norm_bias, float norm_eps, void *out, const int64_t *scatter_index,
                                int64_t out_batch_rows);
 
-/* ---- (9) dense self-attention over the selected queries ---------------------------------------------------------
- * models/bricks/salience_transformer.py:366-376 up to the concatenated heads, one launch: gather tgt / pos rows by
- * index [batch, num_select], q = k = tgt + pos, v = tgt, in-projection (packed_in_proj = sdetr_linear_pack_bf16 of
- * nn.MultiheadAttention.in_proj_weight [768,256]; in_proj_bias fp32 [768]), softmax(q k^T / sqrt(32)) v per head ->
- * out [batch, num_select, 256] bf16 (the input of out_proj).  embed_dim 256, 8 heads, num_select <= 320; query / pos
- * images are *_batch_stride elements apart. */
-int sdetr_topk_attention_heads_bf16(sdetr_stream_t stream, const void *query, int64_t query_batch_stride,
-                                    const void *pos, int64_t pos_batch_stride, const int64_t *index, int batch_size,
-                                    int num_select, int embed_dim, int num_heads, const void *packed_in_proj,
-                                    const float *in_proj_bias, void *out);
-
-/* ---- (9b) dense self-attention after the in-projection ---------------------------------------------------------------
+/* ---- (9) dense self-attention after the in-projection ---------------------------------------------------------------
  * out[b, i, 32 h + :] = softmax(Q_h K_h^T * scale) V_h for 32-channel heads, bf16, no mask: nn.MultiheadAttention's
  * attention proper for the encoder layer's selected queries (models/bricks/salience_transformer.py:371-376) and the
  * decoder layer's object queries (:565-570).  Element [b][i][32 h + d] of q / k / v lies at base + b * batch_stride +

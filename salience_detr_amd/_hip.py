@@ -58,9 +58,6 @@ SIGNATURES = {
     "sdetr_topk_attention_workspace_bytes": (_i64, [_i, _i]),
     "sdetr_topk_attention_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i,
                                        _p, _i64]),
-    "sdetr_tiled_config": (None, [_p, _p, _p]),
-    "sdetr_region_bucket": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "sdetr_msda_tiled_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _i, _i64, _p, _p, _p, _i] + [_i] * 7 + [_p, _i]),
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdetr_topk_uses_prefilter": (_i, [_i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
@@ -123,7 +120,6 @@ SIGNATURES = {
     "sdetr_value_proj_head_major": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i]),
     "sdetr_class_head_max_times": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _i, _i, _p]),
     "sdetr_token_linear_ln_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i64]),
-    "sdetr_topk_attention_heads_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _i, _p, _p, _p]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "sdetr_scatter_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i]),
     "sdetr_neck_conv3x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -115,10 +115,25 @@ class OverlappedGradReducer(FlatGradAllReducer):
     rank used and this one did not contribute zeros), waits, averages and writes the results back to ``p.grad``.
     Every rank starts the buckets in the same order (bucket index), as collectives require: a bucket that completes
     early waits for its predecessors.
+
+    Contract: ONE ``backward()`` with the hooks live per ``finish()``.  Gradient accumulation (the reference's
+    ``--accumulate-steps``, ``util/engine.py:44`` ``accelerator.accumulate``) runs the first micro-steps under
+    ``no_sync()`` -- the hooks do nothing, ``p.grad`` accumulates locally -- and the last one outside it: its hooks
+    then pack the accumulated ``p.grad``.  A second backward WITHOUT ``no_sync()`` is detected (a hook fires for a
+    parameter that is already packed): ``finish()`` then waits for whatever was launched and falls back to the
+    pack-at-the-end reduction of the base class over the accumulated ``p.grad`` -- correct, just not overlapped.
+
+    Collective order.  By default the reducer owns a process group of its own (``own_group=True``): other collectives
+    issued during backward on the default group -- the neck's SyncBatchNorm statistics, ``_SyncBatchNormTrain.backward``
+    -- interleave with the bucket all-reduces differently on ranks that did not use a parameter (they launch that bucket
+    only in ``finish()``); on one communicator that is a mismatched collective order, on separate ones it is legal.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: Optional[int] = 8 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: Optional[int] = 8 << 20, group=None,
+                 own_group: bool = True):
         ps = [p for p in params]
+        if group is None and own_group and dist.is_available() and dist.is_initialized():
+            group = dist.new_group()   # collective: every rank constructs its reducer at the same point
         super().__init__(reversed(ps), bucket_bytes=bucket_bytes, group=group)
         self._slot = {}
         for bi, bucket in enumerate(self.buckets):
@@ -127,6 +142,7 @@ class OverlappedGradReducer(FlatGradAllReducer):
                 self._slot[id(p)] = (bi, off)
                 off += p.numel()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._enabled = True
         self._reset()
 
     def _reset(self):
@@ -134,6 +150,7 @@ class OverlappedGradReducer(FlatGradAllReducer):
         self._filled = set()
         self._works = [None] * len(self.buckets)
         self._next_launch = 0
+        self._repack = False
 
     def _launch_ready(self, force: bool = False):
         while self._next_launch < len(self.buckets):
@@ -149,17 +166,49 @@ class OverlappedGradReducer(FlatGradAllReducer):
             self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._next_launch += 1
 
+    def no_sync(self):
+        """Context manager for the non-final micro-steps of gradient accumulation: the hooks do nothing, gradients
+        accumulate in ``p.grad`` (``DistributedDataParallel.no_sync`` / ``accelerator.accumulate`` semantics)."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, reducer._enabled = reducer._enabled, False
+
+            def __exit__(self, *exc):
+                reducer._enabled = self.prev
+                return False
+        return _NoSync()
+
     def _on_grad(self, p: torch.nn.Parameter):
+        if not self._enabled:
+            return
+        if id(p) in self._filled:
+            # a second backward since the last finish(): the slot may already be on the wire.  Leave the buffers
+            # alone; finish() reduces the accumulated p.grad after the launched collectives have drained.
+            self._repack = True
+            return
         bi, off = self._slot[id(p)]
         self.flat[bi][off:off + p.numel()].copy_(p.grad.reshape(-1))
-        if id(p) not in self._filled:
-            self._filled.add(id(p))
-            self._arrived[bi] += 1
-        self._launch_ready()
+        self._filled.add(id(p))
+        self._arrived[bi] += 1
+        if not self._repack:
+            self._launch_ready()
 
     def finish(self, average: bool = True) -> None:
         """After ``backward()``: reduce what is left, wait, average, unpack into ``p.grad``; ready for the next step."""
         world = dist.get_world_size(self.group)
+        if self._repack:
+            # more than one backward reached the hooks.  Ranks may have launched different numbers of buckets by now
+            # (a rank that did not use a parameter launches its bucket late): launch the rest so that every rank has
+            # issued every bucket exactly once, drain them (results discarded), then reduce the accumulated p.grad the
+            # non-overlapped way
+            self._launch_ready(force=True)
+            for w in self._works:
+                w.wait()
+            self._reset()
+            FlatGradAllReducer.all_reduce(self, average)
+            return
         self._launch_ready(force=True)
         for w in self._works:
             w.wait()
@@ -189,30 +238,43 @@ class OverlappedGradReducer(FlatGradAllReducer):
 class _SyncBatchNormTrain(torch.autograd.Function):
     """BatchNorm2d in training mode over ALL ranks' pixels (what ``nn.SyncBatchNorm`` gives the reference's neck under
     DDP, ``main.py:126-127``; single process: plain batch statistics).  One collective per direction instead of the
-    framework's all_gather + all_reduce pair: forward all-reduces ``[sum(x), sum(x^2), count]`` (2C+1 floats),
-    backward all-reduces ``[sum(dy), sum(dy * xhat)]`` (2C floats).  Running statistics are updated in place with the
-    UNBIASED variance of the global batch (``nn.BatchNorm2d`` semantics)."""
+    framework's all_gather + all_reduce pair: forward all-reduces ``[sum(x - s), sum((x - s)^2), count]`` (2C+1
+    floats), backward all-reduces ``[sum(dy), sum(dy * xhat)]`` (2C floats).  ``s`` is a per-channel shift that is
+    identical on every rank (the running mean: updated from global statistics only, so replicas agree): the variance
+    ``E[(x-s)^2] - E[x-s]^2`` then cancels only as far as the batch mean has moved from the running mean, not as far as
+    it is from zero (torch's SyncBatchNorm merges per-rank mean / M2 instead, which needs the gathered per-rank
+    statistics).  Running statistics are updated in place with the UNBIASED variance of the global batch
+    (``nn.BatchNorm2d`` semantics); ``weight`` / ``bias`` / running statistics may be ``None``."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
         C = x.shape[1]
         xf = x.float()
         red = (0, 2, 3)
-        stats = torch.cat([xf.sum(red), (xf * xf).sum(red), xf.new_tensor([xf.numel() / C])])
+        shift = running_mean.detach().float() if running_mean is not None else xf.new_zeros(C)
+        xs = xf - shift.view(1, C, 1, 1)
+        stats = torch.cat([xs.sum(red), (xs * xs).sum(red), xf.new_tensor([xf.numel() / C])])
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         if world > 1:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         n = stats[-1]
-        mean = stats[:C] / n
-        var = (stats[C:2 * C] / n - mean * mean).clamp_min_(0.0)          # biased: what normalises
+        dmean = stats[:C] / n                                              # E[x - s]
+        var = (stats[C:2 * C] / n - dmean * dmean).clamp_min_(0.0)         # biased: what normalises
+        mean = dmean + shift
         invstd = torch.rsqrt(var + eps)
-        with torch.no_grad():
-            running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
-            running_var.mul_(1 - momentum).add_(momentum * (var * (n / (n - 1).clamp_min(1.0))).to(running_var.dtype))
-        xhat = (xf - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+        if running_mean is not None and running_var is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
+                running_var.mul_(1 - momentum).add_(momentum * (var * (n / (n - 1).clamp_min(1.0))).to(running_var.dtype))
+        xhat = (xs - dmean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
         ctx.save_for_backward(xhat, weight, invstd, n)
-        ctx.group, ctx.world = group, world
-        return (xhat * weight.float().view(1, C, 1, 1) + bias.float().view(1, C, 1, 1)).to(x.dtype)
+        ctx.group, ctx.world, ctx.has_bias = group, world, bias is not None
+        y = xhat
+        if weight is not None:
+            y = y * weight.float().view(1, C, 1, 1)
+        if bias is not None:
+            y = y + bias.float().view(1, C, 1, 1)
+        return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dy):
@@ -225,15 +287,24 @@ class _SyncBatchNormTrain(torch.autograd.Function):
         if ctx.world > 1:
             dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctx.group)
         g_mean, g_proj = both[:C] / n, both[C:] / n
-        dx = (dyf - g_mean.view(1, C, 1, 1) - xhat * g_proj.view(1, C, 1, 1)) * (weight.float() * invstd).view(1, C, 1, 1)
+        scale = invstd if weight is None else weight.float() * invstd
+        dx = (dyf - g_mean.view(1, C, 1, 1) - xhat * g_proj.view(1, C, 1, 1)) * scale.view(1, C, 1, 1)
         # parameter gradients stay LOCAL sums: the gradient all-reduce of the step adds the ranks' contributions
-        return dx.to(dy.dtype), sum_dy_xhat.to(weight.dtype), sum_dy.to(weight.dtype), None, None, None, None, None
+        gw = sum_dy_xhat.to(weight.dtype) if weight is not None else None
+        gb = sum_dy.to(dy.dtype if weight is None else weight.dtype) if ctx.has_bias else None
+        return dx.to(dy.dtype), gw, gb, None, None, None, None, None
 
 
 def sync_batch_norm_train(x: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm, group=None) -> torch.Tensor:
     """``bn`` (an ``nn.BatchNorm2d`` parameter holder) applied to NCHW ``x`` with batch statistics over every rank of
-    ``group`` (all ranks of the default group when a process group exists, else this process alone)."""
-    momentum = 0.1 if bn.momentum is None else bn.momentum
-    if bn.num_batches_tracked is not None:
+    ``group`` (all ranks of the default group when a process group exists, else this process alone).  Follows
+    ``nn.BatchNorm2d``'s conventions: ``momentum=None`` is the cumulative moving average (factor ``1 / num_batches``),
+    ``affine=False`` / ``track_running_stats=False`` holders have no weight / running statistics."""
+    factor = 0.0
+    if bn.running_mean is not None and getattr(bn, "num_batches_tracked", None) is not None:
         bn.num_batches_tracked.add_(1)
-    return _SyncBatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, group)
+        # (momentum=None reads the counter: one host read per call, only in that rarely used mode)
+        factor = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+    elif bn.momentum is not None:
+        factor = bn.momentum
+    return _SyncBatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, factor, group)

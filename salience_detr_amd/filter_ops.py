@@ -1085,33 +1085,6 @@ def merge_sorted_desc(score: Tensor, payload: Tensor, segment_start, want_scores
     return out_score, out_index
 
 
-def topk_attention_applies(query: Tensor, mha, num_select: int) -> bool:
-    return (query.is_cuda and query.dtype == torch.bfloat16 and query.shape[-1] == 256 and mha.embed_dim == 256
-            and mha.num_heads == 8 and mha.in_proj_weight is not None and mha.in_proj_weight.dtype == torch.bfloat16
-            and mha.in_proj_bias is not None and 0 < num_select <= 320)
-
-
-def topk_attention_heads(query: Tensor, pos: Tensor, index: Tensor, mha) -> Tensor:
-    """Concatenated heads ``[B,N,256]`` of ``mha(q = k = query[index] + pos[index], v = query[index])`` before its
-    out-projection, in one launch (include/salience_hip.h (9)); ``query`` / ``pos`` may be row prefixes of longer
-    buffers."""
-    _hip.require_device("topk_attention_heads", index=index)
-    if index.dtype != torch.int64 or index.dim() != 2 or pos.dtype != query.dtype:
-        raise RuntimeError("topk_attention_heads: int64 [B,N] index and query / pos of one dtype expected")
-    B, N = index.shape
-    if not topk_attention_applies(query, mha, N):
-        raise RuntimeError("topk_attention_heads: bf16, embed_dim 256, 8 heads, <= 320 selected tokens; no CPU fallback")
-    packed, bias = _packed_linear_bf16(mha.in_proj_weight, mha.in_proj_bias)
-    out = torch.empty((B, N, 256), dtype=torch.bfloat16, device=query.device)
-    with torch.cuda.device(query.device):
-        code = _hip.lib().sdetr_topk_attention_heads_bf16(
-            _hip.stream_ptr(), query.data_ptr(), _batch_stride(query, "topk_attention_heads"), pos.data_ptr(),
-            _batch_stride(pos, "topk_attention_heads"), index.data_ptr(), B, N, 256, mha.num_heads, packed.data_ptr(),
-            bias.data_ptr(), out.data_ptr())
-    _hip.check(code, "topk_attention_heads")
-    return out
-
-
 # ----------------------------------------------------------------------------------------------- row N3: the neck
 def _token_map(what: str, name: str, t: Tensor, pixels: int, channels: int) -> int:
     """Checks a token-major feature map ``[B, pixels, >= channels]`` (a channel slice of a wider buffer is fine) and

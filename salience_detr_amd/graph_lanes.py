@@ -75,10 +75,17 @@ class Lane:
 
     def load(self, inputs) -> "Lane":
         """Copy ``inputs`` (same structure, shapes and dtypes as the example) into the lane's static tensors, ordered
-        after the current stream's work (their producer) and after the lane's previous launch."""
+        after the current stream's work (their producer) and after the lane's previous launch.  The sources may be
+        temporaries: each is marked as in use on the lane's stream (``record_stream``), so the caching allocator does
+        not hand its memory to new current-stream work before the asynchronous copy has read it."""
         self.stream.wait_stream(torch.cuda.current_stream())
+
+        def copy(d, s):
+            d.copy_(s, non_blocking=True)
+            if s.is_cuda:
+                s.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
-            _zip_apply(self.inputs, inputs, lambda d, s: d.copy_(s, non_blocking=True))
+            _zip_apply(self.inputs, inputs, copy)
         return self
 
     def launch(self) -> "Lane":

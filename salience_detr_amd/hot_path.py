@@ -58,20 +58,10 @@ class SalienceEncoderHotPath(nn.Module):
         self.encoder.enhance_mcsp = self.encoder_class_head
         self.enc_mask_predictor = MaskPredictor(self.embed_dim, self.embed_dim)
         self._ratio_host = (tuple(float(r) for r in level_filter_ratio), tuple(float(r) for r in layer_filter_ratio))
-        # measured on MI355X (batch 2, hipGraph replay): the overlap hides ~60 of the projection's 81 us behind the
-        # coarse levels' launches but slows those and costs two graph joins -- 1.81 ms vs 1.77 ms per step; off
-        self.overlap_value_projection = False
         # the value projection rides in the stage-1 launches of the two coarsest levels (csrc/fused_head_value.hip):
         # same kernels, two launches' worth of an idle chip put to use
         self.fuse_value_projection = True
-        self._streams = {}
         self.init_weights()
-
-    def _side_stream(self, device):
-        key = str(device)
-        if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=device)
-        return self._streams[key]
 
     def init_weights(self):
         import math
@@ -134,19 +124,11 @@ class SalienceEncoderHotPath(nn.Module):
             mask_flatten = pyramid.flatten_multi_level(multi_level_masks)
             lvl_pos_embed_flatten = pyramid.get_lvl_pos_embed(self.level_embeds.to(multi_level_pos_embeds[0].dtype),
                                                               multi_level_pos_embeds)
-        # The value projection of all six layers depends only on the flattened features: launch it on a second stream
-        # so that it fills the CUs the small, strictly sequential filtering launches of the coarse levels leave idle
-        # (joined again right before the encoder; under hipGraph capture this becomes a parallel branch).
-        value_maps = side = None
-        if native and feat_enc is not None and self.overlap_value_projection:
-            main = torch.cuda.current_stream()
-            side = self._side_stream(feat_enc.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                value_maps = self.encoder.project_values(feat_enc, mask_flatten)
-            value_maps.record_stream(main)
+        # The value projection of all six layers depends only on the flattened features: the stage-1 / stage-2 launches
+        # of the two coarsest levels carry it (a second stream / graph branch was measured slower: benchmarks/experiments)
+        value_maps = None
         value_jobs = None
-        if native and feat_enc is not None and value_maps is None and self.fuse_value_projection:
+        if native and feat_enc is not None and self.fuse_value_projection:
             # four carriers (stage 1 and stage 2 of the two coarsest levels): two layers with each stage 1 (~20 us
             # of projection under ~20 us of head), one with each stage 2 (~10 under ~17)
             n_layers = len(self.encoder.layers)
@@ -213,8 +195,6 @@ class SalienceEncoderHotPath(nn.Module):
                                                                layer_ratio, score_flat=score_flat, extras=extras)
         if feat_enc is None:
             feat_enc, pos_enc = feat_flatten.to(edt), lvl_pos_embed_flatten.to(edt)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
         for job in value_jobs or ():   # whatever no stage-1 launch carried
             job.run()
         memory = self.encoder(

@@ -284,91 +284,7 @@ def last_forward_kernel() -> int:
     return int(_hip.lib().sdetr_msda_last_kernel())
 
 
-KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT, KERNEL_TILED = 1, 2, 3, 4, 5
-
-_TILED_CFG = None
-
-
-def tiled_config():
-    """(region_w, region_h, halo) compiled into the LDS-staged kernel."""
-    global _TILED_CFG
-    if _TILED_CFG is None:
-        import ctypes
-        rw, rh, halo = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        _hip.lib().sdetr_tiled_config(ctypes.byref(rw), ctypes.byref(rh), ctypes.byref(halo))
-        _TILED_CFG = (rw.value, rh.value, halo.value)
-    return _TILED_CFG
-
-
-def tiled_supported(value_hm: Tensor, num_levels: int, num_points: int) -> bool:
-    return value_hm.dtype == torch.bfloat16 and value_hm.shape[-1] == 32 and num_levels == 4 and num_points == 4
-
-
-def region_bucket(reference_points: Tensor, spatial_shapes: Tensor, level0_hw, num_levels: int = 4):
-    """Group query slots by the level-0 region of their reference point.  Returns
-    ``(order [B,Nq] int32, region_start [B,R+1] int32, region_box [B,R,4,4] int32, R)``."""
-    _hip.require_device("region_bucket", reference_points=reference_points, spatial_shapes=spatial_shapes)
-    if reference_points.dtype != torch.float32:
-        reference_points = reference_points.float()
-    B, Nq = reference_points.shape[:2]
-    rw, rh, _ = tiled_config()
-    H0, W0 = int(level0_hw[0]), int(level0_hw[1])
-    R = ((W0 + rw - 1) // rw) * ((H0 + rh - 1) // rh)
-    dev = reference_points.device
-    order = torch.empty((B, Nq), dtype=torch.int32, device=dev)
-    region_start = torch.empty((B, R + 1), dtype=torch.int32, device=dev)
-    region_box = torch.empty((B, R, 4, 4), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        code = _hip.lib().sdetr_region_bucket(_hip.stream_ptr(), reference_points.data_ptr(),
-                                              spatial_shapes.data_ptr(), reference_points.shape[-1], B, Nq,
-                                              num_levels, H0, W0, order.data_ptr(), region_start.data_ptr(),
-                                              region_box.data_ptr())
-    _hip.check(code, "region_bucket")
-    return order, region_start, region_box, R
-
-
-def msda_tiled_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
-                       reference_points: Tensor, proj: Tensor, level0_hw, num_levels: int = 4, num_points: int = 4,
-                       out_dtype: Optional[torch.dtype] = None) -> Tensor:
-    """LDS-staged fused MSDA (same contract as ``msda_fused_forward``); ``level0_hw`` = python ints
-    (H_0, W_0) of the finest level, known on the host from the tensors' shapes."""
-    _hip.require_device("msda_tiled_forward", value_hm=value_hm, spatial_shapes=spatial_shapes,
-                        level_start_index=level_start_index, reference_points=reference_points)
-    if reference_points.shape[-1] not in (2, 4):
-        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
-            reference_points.shape[-1]))
-    if not tiled_supported(value_hm, num_levels, num_points):
-        raise RuntimeError("msda_tiled_forward: needs a bf16 head-major value with head_dim 32, 4 levels, 4 points")
-    B, M, Nv, D = value_hm.shape
-    Nq = proj.shape[1]
-    if proj.stride(2) != 1 or proj.stride(0) != Nq * proj.stride(1) or proj.stride(1) % 8:
-        proj = proj.contiguous()
-    if reference_points.dtype != torch.float32:
-        reference_points = reference_points.float()
-    rw, rh, _ = tiled_config()
-    H0, W0 = int(level0_hw[0]), int(level0_hw[1])
-    R = ((W0 + rw - 1) // rw) * ((H0 + rh - 1) // rh)
-    out_dtype = out_dtype or proj.dtype
-    dev = value_hm.device
-    order = torch.empty((B, Nq), dtype=torch.int32, device=dev)
-    region_start = torch.empty((B, R + 1), dtype=torch.int32, device=dev)
-    region_box = torch.empty((B, R, 4, 4), dtype=torch.int32, device=dev)
-    out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=dev)
-    lib = _hip.lib()
-    with torch.cuda.device(dev):
-        code = lib.sdetr_region_bucket(_hip.stream_ptr(), reference_points.data_ptr(), spatial_shapes.data_ptr(),
-                                       reference_points.shape[-1], B, Nq, num_levels, H0, W0, order.data_ptr(),
-                                       region_start.data_ptr(), region_box.data_ptr())
-        _hip.check(code, "region_bucket")
-        code = lib.sdetr_msda_tiled_forward(
-            _hip.stream_ptr(), value_hm.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            reference_points.data_ptr(), reference_points.shape[-1], proj.data_ptr(), _hip.dtype_code(proj.dtype),
-            proj.stride(1), order.data_ptr(), region_start.data_ptr(), region_box.data_ptr(), R, B, Nv, M, D,
-            num_levels, Nq, num_points,
-            out.data_ptr(), _hip.dtype_code(out_dtype))
-    _hip.check(code, "msda_tiled_forward")
-    return out
-
+KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT = 1, 2, 3, 4
 
 def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                             sampling_loc: Tensor, attn_weight: Tensor,
@@ -539,12 +455,6 @@ class MultiScaleDeformableAttention(nn.Module):
         v = F.linear(value, self.value_proj.weight, self.value_proj.bias)
         return value_to_head_major(v, key_padding_mask, self.num_heads, self.value_dtype or v.dtype)
 
-    # queries per level-0 region above which the LDS-staged kernel is used; None disables it.  Round-1
-    # measurement (profiles/r01_msda_pmc.md): the staged kernel is correct but ~1.5x SLOWER than the direct
-    # gather at every encoder density (per-workgroup serial latency with only 2 workgroups/CU resident), so
-    # it stays opt-in until it is restructured as a persistent double-buffered pipeline.
-    tiled_min_queries_per_region = None
-
     # queries per image from which the coarse-levels-in-LDS kernel replaces the direct gather when a host copy of
     # the level shapes is at hand (below it the 85 KB staging per workgroup is not amortised); None disables it
     resident_min_queries = 1200
@@ -555,10 +465,10 @@ class MultiScaleDeformableAttention(nn.Module):
         w, _ = self._fused_query_projection()
         return (query.dim() == 3 and query.shape[0] * query.shape[1] >= 3000 and token_linear_applies(query, w)
                 and self.num_levels == 4 and self.num_points == 4 and self.num_heads == 8 and value_hm.shape[-1] == 32
-                and value_hm.dtype in (torch.float16, torch.bfloat16) and self.tiled_min_queries_per_region is None)
+                and value_hm.dtype in (torch.float16, torch.bfloat16))
 
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
-                       level_start_index: Tensor, order: Optional[Tensor] = None, level0_hw=None,
+                       level_start_index: Tensor, order: Optional[Tensor] = None,
                        query_pos: Optional[Tensor] = None, apply_output_proj: bool = True,
                        level_shapes=None, head_major_projection: Optional[Tensor] = None) -> Tensor:
         """``query_pos`` (optional): position embedding still to be added to ``query`` -- folded into the projection
@@ -575,7 +485,7 @@ class MultiScaleDeformableAttention(nn.Module):
         head_major = (big and token_linear_applies(query, w) and order is None and self.num_levels == 4
                       and self.num_points == 4 and value_hm.shape[-1] == 32
                       and value_hm.dtype in (torch.float16, torch.bfloat16)
-                      and self.tiled_min_queries_per_region is None)
+                     )
         if head_major:
             # per-head slabs: every XCD's L2 then fetches only its own head's projection values
             proj = head_major_projection
@@ -595,18 +505,8 @@ class MultiScaleDeformableAttention(nn.Module):
             proj = token_linear(query, w, b, x_add=query_pos)
         else:
             proj = F.linear(query if query_pos is None else query + query_pos, w, b)
-        use_tiled = False
-        if (level0_hw is not None and self.tiled_min_queries_per_region is not None
-                and tiled_supported(value_hm, self.num_levels, self.num_points)):
-            rw, rh, _ = tiled_config()
-            regions = ((level0_hw[1] + rw - 1) // rw) * ((level0_hw[0] + rh - 1) // rh)
-            use_tiled = query.shape[1] >= self.tiled_min_queries_per_region * regions
-        if use_tiled:
-            out = msda_tiled_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj, level0_hw,
-                                     self.num_levels, self.num_points, out_dtype=query.dtype)
-        else:
-            out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
-                                     self.num_levels, self.num_points, order=order, out_dtype=query.dtype)
+        out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,
+                                 self.num_levels, self.num_points, order=order, out_dtype=query.dtype)
         if not apply_output_proj:
             return out
         return F.linear(out, self.output_proj.weight, self.output_proj.bias)

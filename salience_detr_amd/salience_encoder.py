@@ -28,8 +28,8 @@ from . import pyramid
 from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
-                         select_stack, token_linear_applies, token_linear_ln, topk_attention_applies,
-                         topk_attention_heads, topk_self_attention_, topk_self_attention_applies)
+                         select_stack, token_linear_applies, token_linear_ln, topk_self_attention_,
+                         topk_self_attention_applies)
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps, plan_batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 
@@ -50,9 +50,6 @@ class SalienceTransformerEncoderLayer(nn.Module):
         self.embed_dim = embed_dim
         self.topk_sa = topk_sa
         self.n_heads = n_heads
-        # one-launch gather + in-projection + attention of the selected rows (csrc/mha_topk.hip): correct, but on
-        # MI355X it only ties the three-launch path (its row gather is bound by one CU's L1 per head), so it is opt-in
-        self.fused_topk_attention = False
         # training: the attention's in / out projections (F.linear on the MHA module's own parameters) through
         # linear_x3.x3_linear (set by use_x3_linear_)
         self.x3_projections = False
@@ -191,15 +188,6 @@ class SalienceTransformerEncoderLayer(nn.Module):
             else:
                 topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm)
             stacked = None
-        elif (self.fused_topk_attention and fuse_tail and topk_attention_applies(query, self.pre_attention, N)
-                and not self.training):
-            # gather + position add + in-projection + attention of the selected rows in one launch, then
-            # out-projection (library GEMM: 600 rows) and gather + residual + pre_norm + scatter in one launch
-            mha = self.pre_attention
-            heads_out = topk_attention_heads(query, pos_sorted[:, :c], sel, mha)
-            tgt2 = F.linear(heads_out, mha.out_proj.weight, mha.out_proj.bias)
-            fused_layer_norm(query, self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query, gather_x=True)
-            stacked = None
         else:
             stacked = select_stack(query, pos_sorted, sel)                   # [q+pos ; q] rows, [B,2N,E]
         if fuse_tail:
@@ -224,8 +212,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2), advance)
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
-                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None,
-                level0_hw=None):
+                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None):
         """Reference signature (salience_transformer.py:353-364) plus an optional pre-projected
         head-major ``value_hm`` (``[B,M,Nv,D]``) supplied by the encoder's batched value projection."""
         native = not _needs_grad(self, query, value)
@@ -261,7 +248,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
             if value_hm is None:
                 value_hm = self.self_attn.project_value(value, query_key_padding_mask)
             src2 = self.self_attn.forward_native(self.with_pos_embed(query, query_pos), reference_points, value_hm,
-                                                 spatial_shapes, level_start_index, level0_hw=level0_hw)
+                                                 spatial_shapes, level_start_index)
         else:
             src2 = self.self_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
                                   value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -448,7 +435,7 @@ class SalienceTransformerEncoder(nn.Module):
                 ref = torch.gather(ori_reference_points, 1, inds.unsqueeze(-1).repeat(1, 1, s * p)).view(b, -1, s, p)
             score_tgt = self.enhance_mcsp(q)
             q = layer(q, q_pos, value, ref, spatial_shapes, level_start_index, query_key_padding_mask, score_tgt, fg,
-                      value_hm=value_hm_all[layer_id] if native else None, level0_hw=level_shapes[0])
+                      value_hm=value_hm_all[layer_id] if native else None)
             if native:
                 scatter_rows_(output, inds, q, count=focus64)
             else:

@@ -207,3 +207,92 @@ def test_sync_batch_norm_two_ranks_equal_one_process_full_batch(tmp_path):
     (y2 * probe2).sum().backward()
     assert torch.allclose(y2.detach(), y.detach(), atol=1e-5) and torch.allclose(x2.grad, xf.grad, atol=1e-5)
     assert torch.allclose(bn2.weight.grad, bn.weight.grad, atol=1e-4)
+
+
+def test_sync_batch_norm_large_mean_and_optional_parts():
+    """E[x^2] - mean^2 cancels when |mean| >> std; the shifted sums do not once the running mean tracks the
+    data.  affine=False / track_running_stats=False / momentum=None follow nn.BatchNorm2d."""
+    from salience_detr_amd.data_parallel import sync_batch_norm_train
+    x = syn.det_randn("sbn.big", (4, 3, 6, 5)) * 0.01 + 1000.0
+    bn = torch.nn.BatchNorm2d(3)
+    with torch.no_grad():
+        bn.running_mean.fill_(1000.0)
+    ref = torch.nn.BatchNorm2d(3)
+    with torch.no_grad():
+        ref.running_mean.fill_(1000.0)
+    ref.train()
+    y = sync_batch_norm_train(x, bn)
+    # fp64 statement of the same normalisation
+    xd = x.double()
+    m = xd.mean((0, 2, 3), keepdim=True)
+    v = xd.var((0, 2, 3), unbiased=False, keepdim=True)
+    want = ((xd - m) / torch.sqrt(v + bn.eps)).float()
+    assert torch.allclose(y, want, atol=2e-3), float((y - want).abs().max())
+    ref(x)
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-3)
+
+    # affine=False, no running statistics
+    plain = torch.nn.BatchNorm2d(6, affine=False, track_running_stats=False)
+    _, x2, probe = _bn_case()
+    xa = x2.clone().requires_grad_(True)
+    ya = sync_batch_norm_train(xa, plain)
+    (ya * probe).sum().backward()
+    xb = x2.clone().requires_grad_(True)
+    yb = plain.train()(xb)
+    (yb * probe).sum().backward()
+    assert torch.allclose(ya, yb, atol=1e-5) and torch.allclose(xa.grad, xb.grad, atol=1e-5)
+
+    # momentum=None: cumulative moving average
+    cma, cma_ref = torch.nn.BatchNorm2d(6, momentum=None), torch.nn.BatchNorm2d(6, momentum=None)
+    cma_ref.train()
+    for k in range(3):
+        xk = x2 + 0.3 * k
+        sync_batch_norm_train(xk, cma)
+        cma_ref(xk)
+    assert int(cma.num_batches_tracked) == 3
+    assert torch.allclose(cma.running_mean, cma_ref.running_mean, atol=1e-5)
+    assert torch.allclose(cma.running_var, cma_ref.running_var, atol=1e-4)
+
+
+# ---- gradient accumulation (the reference's --accumulate-steps, util/engine.py:44): no_sync() for the first micro-steps;
+# a second backward without it is detected and reduced correctly (not overlapped) ----
+def _accum_worker(rank, world, port, use_no_sync, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _hot_path_model()
+        red = OverlappedGradReducer(list(model.parameters()), bucket_bytes=16 << 10)
+        skip = ("alpha",) if rank == 1 else ()
+        for step in range(2):
+            model.zero_grad(set_to_none=True)
+            if use_no_sync:
+                with red.no_sync():
+                    _synthetic_loss(model, rank + 10 * step, skip).backward()
+            else:
+                _synthetic_loss(model, rank + 10 * step, skip).backward()
+            _synthetic_loss(model, rank + 10 * step + 100, skip).backward()
+            red.all_reduce(average=True)
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"a{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_no_sync", [True, False])
+def test_overlapped_reducer_gradient_accumulation(tmp_path, use_no_sync):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_accum_worker, args=(2, port, use_no_sync, str(tmp_path)), nprocs=2, join=True)
+    g0 = torch.load(os.path.join(tmp_path, "a0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "a1.pt"))
+    grads = []
+    for rank in range(2):
+        m = _hot_path_model()
+        skip = ("alpha",) if rank == 1 else ()
+        _synthetic_loss(m, rank + 10, skip).backward()
+        _synthetic_loss(m, rank + 110, skip).backward()
+        grads.append({n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()})
+    for n in g0:
+        expect = 0.5 * (grads[0][n] + grads[1][n])
+        assert torch.allclose(g0[n], expect, rtol=1e-5, atol=1e-6), n
+        assert torch.equal(g0[n], g1[n]), n

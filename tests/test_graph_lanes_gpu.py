@@ -71,3 +71,39 @@ def test_lane_rejects_inputs_of_another_shape():
         lanes.submit(other)
     with pytest.raises(ValueError):
         lanes.submit(a[:2])
+
+
+def test_submit_of_temporaries_survives_reallocation():
+    """`lanes.submit(make_batch())` drops the sources as soon as submit returns; the caching allocator may
+    hand their memory to new current-stream work before the lane's asynchronous copy has run.  `Lane.load` marks the
+    sources as in use on the lane's stream: the reallocated scratch must land elsewhere (or wait)."""
+    sizes = [(320, 480)]
+    canvas = syn.pad_to_32(320, 480)
+    m = build_hot_path()
+    m.load_state_dict(syn.det_state_dict(m.state_dict()))
+    m = m.to(DEV).eval()
+    m.set_encoder_dtype(torch.bfloat16, torch.float16)
+
+    def fn(f, mk, p):
+        return m(f, mk, p, image_sizes=sizes, canvas=canvas)[0]
+
+    keep = _inputs(sizes, 7)
+    with torch.no_grad():
+        expect = fn(*keep).clone()
+    lanes = GraphLanes(fn, keep, lanes=2)
+    for _ in range(4):
+        # hold the lane's stream back so that the copy is still pending when the sources are released
+        lane = lanes.next_lane()
+        with torch.cuda.stream(lane.stream):
+            torch.cuda._sleep(20_000_000)
+        tmp = tuple([t.clone() for t in ts] for ts in keep)
+        lane.load(tmp)
+        shapes = [[t.shape for t in ts] for ts in tmp]
+        dtypes = [[t.dtype for t in ts] for ts in tmp]
+        del tmp
+        # same sizes -> the allocator's first candidates are the blocks just released
+        junk = [[torch.full(s, 3, dtype=d, device=DEV) if d != torch.bool else torch.ones(s, dtype=d, device=DEV)
+                 for s, d in zip(ss, dd)] for ss, dd in zip(shapes, dtypes)]
+        lane.launch().synchronize()
+        assert torch.equal(lane.outputs, expect)
+        del junk

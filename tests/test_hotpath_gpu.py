@@ -198,22 +198,6 @@ def test_sorted_order_loop_equals_token_space_loop(tag):
     assert (general - memory).abs().max().item() <= 2e-5
 
 
-def test_opt_in_fused_topk_attention_matches_default_path():
-    """bf16 encoder with the one-launch top-k attention (opt-in) vs the default three-launch path."""
-    m, feats, masks, pos = _full_model_and_inputs([(800, 1333), (800, 1066)])
-    m = m.to(DEV).eval()
-    m.set_encoder_dtype(torch.bfloat16, torch.float16)
-    args = ([f.to(DEV) for f in feats], [x.to(DEV) for x in masks], [p.to(DEV) for p in pos])
-    with torch.no_grad():
-        base = m(*args)[0].float()
-        for layer in m.encoder.layers:
-            layer.fused_topk_attention = True
-        fused = m(*args)[0].float()
-    diff = (fused - base).abs()
-    assert diff.mean().item() < 0.02 * base.abs().mean().item()
-    assert (diff.max(-1)[0] < 0.25).float().mean().item() > 0.98
-
-
 @pytest.mark.parametrize("image_sizes", [[(480, 640)], [(800, 1333), (608, 911), (333, 500)],
                                          [(800, 1333), (800, 1333), (736, 1100), (800, 1201)]])
 def test_bf16_launch_fusions_do_not_change_the_result(image_sizes):

@@ -224,50 +224,6 @@ def _value_hm_bf16(B, levels, M_=8, D=32, seed=9):
     return value.to(torch.bfloat16).float().view(B, Nv, M_, D), hm
 
 
-@pytest.mark.parametrize("levels,B,Nq,offset_px,ref_dim,pdt", [
-    (LEVELS_SMALL, 2, 333, 2.0, 2, torch.float32),        # all samples inside the staged windows
-    (LEVELS_SMALL, 2, 333, 2.0, 2, torch.bfloat16),
-    (LEVELS_SMALL, 1, 70, 14.0, 2, torch.float32),        # huge offsets: exercises the global fallback
-    (LEVELS_SMALL, 2, 129, 3.0, 4, torch.float32),        # box reference points (decoder form)
-    ([(37, 53), (19, 27), (10, 14), (5, 7)], 3, 1000, 2.5, 2, torch.float32),   # odd sizes, partial regions
-    (LEVELS_FULL, 2, 11363, 2.0, 2, torch.bfloat16),      # encoder layer 0 at the benchmark shape
-    (LEVELS_FULL, 1, 2272, 5.0, 2, torch.float32),
-])
-def test_tiled_forward_matches_direct_and_oracle(levels, B, Nq, offset_px, ref_dim, pdt):
-    M_, D, P, L = 8, 32, 4, 4
-    vq, hm = _value_hm_bf16(B, levels)
-    tok, ref, proj, shapes, lsi = syn.make_encoder_like_queries(B, Nq, levels, M_, P, seed=3, offset_px=offset_px)
-    if ref_dim == 4:
-        ref = torch.cat([ref, syn.det_rand("tiled.wh", (B, Nq, L, 2)) * 0.3 + 0.02], -1)
-    proj = proj.to(pdt)
-    sh, ls = shapes.to(DEV), lsi.to(DEV)
-    direct = M.msda_fused_forward(hm, sh, ls, ref.to(DEV), proj.to(DEV), L, P, out_dtype=torch.float32)
-    tiled = M.msda_tiled_forward(hm, sh, ls, ref.to(DEV), proj.to(DEV), levels[0], L, P, out_dtype=torch.float32)
-    assert (tiled - direct).abs().max().item() < 2e-5
-    if B * Nq <= 4000:
-        expect = _fused_reference(vq, shapes, lsi, ref, proj.float(), M_, L, P)
-        assert np.abs(tiled.cpu().numpy() - expect).max() < 2e-4
-    out_bf16 = M.msda_tiled_forward(hm, sh, ls, ref.to(DEV), proj.to(DEV), levels[0], L, P, out_dtype=torch.bfloat16)
-    assert (out_bf16.float() - tiled).abs().max().item() < 0.05 * max(1.0, tiled.abs().max().item())
-
-
-def test_tiled_with_clustered_queries_and_empty_regions():
-    """All queries in one corner (most regions empty) + a padded image (valid ratio < 1)."""
-    M_, D, P, L, levels, B, Nq = 8, 32, 4, 4, LEVELS_SMALL, 2, 90
-    vq, hm = _value_hm_bf16(B, levels)
-    g = torch.Generator().manual_seed(5)
-    ref = (torch.rand(B, Nq, 1, 2, generator=g) * 0.2).expand(B, Nq, L, 2) * torch.tensor([1.0, 0.9, 0.8, 0.7]).view(1, 1, L, 1)
-    ref = ref.contiguous()
-    proj = torch.cat([torch.randn(B, Nq, 256, generator=g) * 2.0, torch.randn(B, Nq, 128, generator=g)], -1)
-    shapes = torch.tensor(levels, dtype=torch.int64)
-    sizes = shapes.prod(1)
-    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
-    expect = _fused_reference(vq, shapes, lsi, ref, proj, M_, L, P)
-    tiled = M.msda_tiled_forward(hm, shapes.to(DEV), lsi.to(DEV), ref.to(DEV), proj.to(DEV), levels[0], L, P,
-                                 out_dtype=torch.float32)
-    assert np.abs(tiled.cpu().numpy() - expect).max() < 2e-4
-
-
 def test_head_major_projection_layout_equals_token_rows():
     """The fused kernel fed per-head projection slabs [B,M,Nq,48] (written directly by the token-resident linear
     kernel) returns what it returns for the same numbers in token rows [B,Nq,384]."""
