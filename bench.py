@@ -33,6 +33,7 @@ from salience_detr_amd.hot_path import build_hot_path  # noqa: E402
 DEFAULT_THREADS = torch.get_num_threads()
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MSDA_REPEATS = 8
+CUT_PAIRS, CUT_REPLAYS = 15, 20   # in-step MSDA timing: paired cut-graph measurements
 
 
 def parse():
@@ -353,7 +354,7 @@ def time_replays(g, n):
     return e0.elapsed_time(e1) / n
 
 
-def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
+def cpu_baseline(args, model, cpu_inputs_of, out, sel_log, gpu_inds=None):
     """The oracle's CPU port of the same path, timed on the host cores: per stage (F0-F3 filtering,
     each encoder layer, the MSDA core alone).  Default: bounded to ~15-30 s (batch 2; 8 threads 1 warm-up + 3 passes,
     all cores 1 + 2 passes; the faster leg is `value`);
@@ -419,17 +420,24 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log):
         per_token = err.max(-1)[0]
         B, S = per_token.shape
         flipped = torch.zeros(B, S, dtype=torch.bool)
+        flips_per_layer = []
         for k, gsel in sorted(sel_log.items()):
             inds = ref_out["foreground_inds"][k]
+            ginds = gpu_inds[k] if gpu_inds is not None else inds
+            n_layer = 0
             for b in range(B):
                 a = set(inds[b][ref_out["layer_sel"][k][b]].tolist())
-                g = set(inds[b][gsel[b]].tolist())
+                g = set(ginds[b][gsel[b]].tolist())
+                n_layer += len(a ^ g)
                 for tok in a ^ g:
                     flipped[b, tok] = True
+            flips_per_layer.append(n_layer)
         clean = per_token[~flipped]
         parity = {"max_abs": round(float(err.max()), 5), "mean_abs": round(float(err.mean()), 6),
                   "top300_selection_flips": {"tokens": int(flipped.sum()), "of": int(B * 300 * len(sel_log)),
-                                             "note": "tokens in exactly one of (GPU, oracle) top-300 sets of some layer: "
+                                             "per_layer_symmetric_difference": flips_per_layer,
+                                             "note": "tokens in exactly one of (GPU, oracle) top-300 sets of some layer "
+                                                     "(each side's positions mapped through its own sorted index list): "
                                                      "near-ties of the class score resolved differently under bf16"},
                   "non_flipped_tokens": {"max_abs": round(float(clean.max()), 5), "mean_abs": round(float(clean.mean()), 6),
                                          "p999_abs": round(float(clean.flatten().kthvalue(max(1, int(clean.numel() * 0.999)))[0]), 5)},
@@ -585,8 +593,15 @@ def main():
     msda_mod.msda_fused_forward = timed_fused
     msda_mod.msda_resident_forward = timed_resident
     model.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.cpu()) or s
+    gpu_inds = None
     try:
-        out_eager = step()
+        with torch.no_grad():
+            out_eager, _, aux_eager = model(feats, masks, pos, image_sizes=sizes, canvas=canvas, return_aux=True)
+        # the GPU's own sorted index lists: a layer's selection is a set of POSITIONS in them.  (Until round 3 the
+        # positions were mapped through the ORACLE's lists; the two orders differ wherever scores tie -- the ~700 border
+        # tokens per image whose zeroed rows give identical salience scores -- which showed up as ~1400 phantom flips.)
+        gpu_inds = [t.cpu() for t in aux_eager["foreground_inds"]]
+        del aux_eager
         torch.cuda.synchronize()
     finally:
         msda_mod.msda_fused_forward = real_fused
@@ -594,19 +609,82 @@ def main():
         model.encoder.selection_hook = None
 
     bytes_per_layer = launches[:nl]
-    total_bytes, total_us = sum(bytes_per_layer), sum(msda_us[:nl])
+    total_bytes, warm_total_us = sum(bytes_per_layer), sum(msda_us[:nl])
+
+    # ---- the same launches AS THEY RUN IN THE STEP: graphs of the step cut right before and right after the k-th
+    # fused-MSDA launch, difference of their replay times (the launch with its cold operands -- this layer's value maps
+    # were written ~0.5 ms earlier, its projection slab by the launch in front -- and one launch boundary).  This is
+    # what `roofline.frac` is computed from; the warm back-to-back replay above is kept as `frac_warm`. ----
+    in_step_us, in_step_note = [None] * nl, "unavailable (eager run)"
+    if graphed:
+        class _Cut(Exception):
+            pass
+        state = {"k": 0, "after": False, "n": 0}
+
+        def cutting(real):
+            def call(*a, **kw):
+                if state["n"] == state["k"] and not state["after"]:
+                    raise _Cut()
+                o = real(*a, **kw)
+                state["n"] += 1
+                if state["n"] == state["k"] + 1 and state["after"]:
+                    raise _Cut()
+                return o
+            return call
+
+        def cut_step():
+            state["n"] = 0
+            try:
+                with torch.no_grad():
+                    model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
+            except _Cut:
+                pass
+
+        msda_mod.msda_fused_forward = cutting(real_fused)
+        msda_mod.msda_resident_forward = cutting(real_resident)
+        try:
+            for k in range(nl):
+                pair = []
+                for after in (False, True):
+                    state["k"], state["after"] = k, after
+                    gk, _ = capture(cut_step, capture_kw)
+                    time_replays(gk, 3)
+                    pair.append(gk)
+                # the two graphs take turns (clock / power state drifts between measurements that are taken minutes
+                # apart: a difference of two ~1 ms numbers needs them taken under the same conditions); median of the
+                # paired differences
+                diffs = []
+                for _ in range(CUT_PAIRS):
+                    t0_ = time_replays(pair[0], CUT_REPLAYS)
+                    t1_ = time_replays(pair[1], CUT_REPLAYS)
+                    diffs.append(t1_ - t0_)
+                diffs.sort()
+                in_step_us[k] = diffs[len(diffs) // 2] * 1e3
+                del pair
+            in_step_note = ("hipGraph replay of the step cut right after the layer's fused-MSDA launch minus cut right "
+                            "before it (the two graphs replayed in turns, %d x %d replays each, median of the paired "
+                            "differences): the launch with the operands as cold as the step leaves them, one launch "
+                            "boundary included" % (CUT_PAIRS, CUT_REPLAYS))
+        except Exception as e:
+            in_step_us, in_step_note = [None] * nl, f"cut-graph timing failed: {e}"
+        finally:
+            msda_mod.msda_fused_forward = real_fused
+            msda_mod.msda_resident_forward = real_resident
+    have_in_step = all(u is not None and u > 0 for u in in_step_us)
+    total_us = sum(in_step_us) if have_in_step else warm_total_us
     achieved = total_bytes / total_us / 1e3  # GB/s
+    achieved_warm = total_bytes / warm_total_us / 1e3
     # HBM traffic per launch: rocprofv3 PMC passes of this same workload (benchmarks/profile_round.sh; bench.py cannot
     # run the profiler on itself), valid only for the kernel sources they were measured with -> null otherwise
     traffic, traffic_src = None, None
     tag = kernel_source_tag()
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_msda_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_msda_traffic.json")))
         nqs = launch_nq[:nl]
         if (tj.get("kernel_source_tag") == tag and args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same")
                 and args.batch == tj["batch"] and all(str(n) in tj["per_num_query"] for n in nqs)):
             traffic = int(sum(tj["per_num_query"][str(n)]["hbm_bytes"] for n in nqs) / nl)
-            traffic_src = "profiles/r02_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tag
+            traffic_src = "profiles/r03_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tag
         else:
             traffic_src = "null: committed PMC passes were measured on other kernel sources (%s) than these (%s)" % (
                 tj.get("kernel_source_tag"), tag)
@@ -620,11 +698,16 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         "traffic_source": traffic_src, "kernel_source_tag": tag, "algorithmic_bytes_per_launch": int(total_bytes / nl),
         "launches_per_step": nl, "num_queries_per_layer": launch_nq[:nl], "avg_launch_us": round(total_us / nl, 2),
-        "per_layer_us": [round(u, 2) for u in msda_us[:nl]],
-        "per_layer_frac": [round(b / u / 1e3 / HBM_PEAK_GBPS, 4) for b, u in zip(bytes_per_layer, msda_us[:nl])],
+        "per_layer_us": [round(u, 2) for u in (in_step_us if have_in_step else msda_us[:nl])],
+        "per_layer_frac": [round(b / u / 1e3 / HBM_PEAK_GBPS, 4)
+                           for b, u in zip(bytes_per_layer, in_step_us if have_in_step else msda_us[:nl])],
         "per_layer_algorithmic_MB": [round(b / 1e6, 2) for b in bytes_per_layer],
-        "timing": "per launch: %d back-to-back repetitions of the step's own launch captured in a hipGraph, replayed "
-                  "between two events on the launch stream" % MSDA_REPEATS,
+        "timing": in_step_note if have_in_step else "warm replay only (see frac_warm)",
+        "frac_warm": round(achieved_warm / HBM_PEAK_GBPS, 4), "achieved_warm": round(achieved_warm, 1),
+        "avg_launch_us_warm": round(warm_total_us / nl, 2), "per_layer_us_warm": [round(u, 2) for u in msda_us[:nl]],
+        "timing_warm": "per launch: %d back-to-back repetitions of the step's own launch captured in a hipGraph, replayed "
+                       "between two events on the launch stream (operands hot in the XCDs' L2: NOT the step's condition)"
+                       % MSDA_REPEATS,
     }
 
     result = {
@@ -675,7 +758,7 @@ def main():
             if batch == args.batch:
                 return cpu_inputs
             return make_inputs(batch, args.height, args.width, "cpu", seed=rank)[3]
-        result["cpu_baseline"], parity = cpu_baseline(args, model, cpu_inputs_of, out_eager, sel_log)
+        result["cpu_baseline"], parity = cpu_baseline(args, model, cpu_inputs_of, out_eager, sel_log, gpu_inds)
         if parity is not None:
             result["parity_vs_cpu"] = parity
 

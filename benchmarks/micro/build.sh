@@ -3,7 +3,7 @@
 # are git-ignored and travel to the GPU box with the snapshot).      bash benchmarks/micro/build.sh
 set -e
 cd "$(dirname "$0")"
-for f in lds_atomic_rate mfma_rate ffn_two_wave graph_launch_floor valu_rate gather_rate kernel_cold_start; do
+for f in lds_atomic_rate mfma_rate ffn_two_wave graph_launch_floor valu_rate gather_rate kernel_cold_start l2_prefetch; do
   [ -f $f.hip ] || continue
   extra=""
   [ $f = lds_atomic_rate ] && extra="-munsafe-fp-atomics"

@@ -27,6 +27,8 @@
 //   it lets everything pass -- compacts them STABLY (index order, block scan) into a scratch list.  The
 //   rank kernel then counts among those ~1.2 k candidates only (any key that fails the threshold sorts
 //   after every candidate, so candidate ranks are global ranks).  Exactness never depends on the sample.
+#include <cstdlib>
+
 #include "common.h"
 
 #include "topk_core.h"
@@ -191,6 +193,280 @@ __global__ void __launch_bounds__(kPreThreads) topk_prefilter_kernel(PrefilterAr
     if (tid == 0) p.cand_count[b] = (int)total;
 }
 
+// ---- one-launch sorted top-k by histogram sort (one workgroup per row) -----------------------------------------------
+// The per-layer top-300 of ~2 000-11 000 class scores (models/bricks/salience_transformer.py:366-367) and the finest
+// level's top-6680 of 16 800 salience scores (:146-150) used to be two launches each -- a sampled-threshold prefilter
+// on one workgroup, then the chip-wide rank-by-counting of the candidates (n_cand^2 compares): 17 us per encoder layer
+// and 48 us for level 0, for problems whose data is 45-67 KB.  Rank by counting is quadratic; with the keys spread
+// over bins that are MONOTONE in the sort order, a key's rank is (keys in earlier bins) + (bin mates that sort before
+// it), which is linear for any row that does not pile up in single bins.  One 1024-thread workgroup per row:
+//   1. keys (descending-orderable score bits, masked -> fill) into registers, thread t holds positions t, t + 1024, ...
+//   2. the FLOOR group -- keys equal to the row's smallest score (the fill value floods it when an image is padded) --
+//      is set aside: it sorts after everything else, ties by position, so its ranks are position prefix counts (a
+//      bitmap of the members' positions + a scan of its popcounts), never comparisons; only needed when k exceeds the
+//      number of other keys;
+//   3. the other keys: bin = floor((smax - score) * nbins / (smax - smin)) over the FINITE range of the row -- linear in
+//      the score, so a bell-shaped row fills the bins evenly where a digit of the key bits would pile a row into a
+//      handful (round 2's radix attempt: 2-4x slower than the two launches); infinities clamp to the end bins;
+//      ds_add_u32 histogram, block scan -> bin offsets, the bin in which the running count crosses k is the CUT bin;
+//   4. keys of bins <= cut are scattered into the LDS list of their bin (slot from a returning ds_add); then one thread
+//      per LIST ENTRY (neighbouring lanes = the same few bins: similar trip counts, near-broadcast reads) counts the bin
+//      mates that sort before it (key, then position: the tie rule of the rank kernel); rank < k is the output slot;
+//   5. CROWDED bins (> 48 keys) are left out of 4 and taken one at a time by the whole workgroup.  They come from
+//      near-ties: the ~700 border tokens per image whose zeroed rows (base_transformer.py:104-111) give salience scores
+//      that differ in the last bits or not at all, all inside one bin next to a few ordinary scores.  Up to 2048
+//      entries: a bitonic sort of the 48-bit (key, position) pairs in LDS (55 barrier-separated steps for 1024 entries,
+//      ~4 us, whatever the keys are), the sorted index is the rank inside the bin.  Above that: comparisons with the
+//      mates (correct for every input, quadratic in the bin).
+// Bit-identical to prefilter + rank.
+constexpr int kHsThreads = 1024;
+constexpr int kHsWaves = kHsThreads / 64;
+constexpr int kHsBins = 4096;
+constexpr int kHsBinsPerThread = kHsBins / kHsThreads;   // 4
+constexpr int kHsMaxKpt = 17;
+constexpr int kHsMaxN = kHsThreads * kHsMaxKpt;          // 17 408 keys: the scatter list covers a whole row
+constexpr int kHsCrowd = 48;                             // bins above this many keys are taken cooperatively
+constexpr int kHsMaxCrowded = 64;                        // listed crowded bins (further ones are ranked entry by entry)
+constexpr int kHsMapWords = (kHsMaxN + 31) / 32;         // 544
+constexpr uint32_t kHsFlag = 0x80000000u;                // in off[bin]: the bin is on the crowded list
+constexpr int kHsTmp = 2048;                             // entries of a crowded bin that are sorted in LDS
+
+struct SelectArgs {
+    const float *score;
+    const uint8_t *mask;
+    int64_t mask_stride;
+    const float *fill;
+    const int64_t *payload;
+    int N, k;
+    int64_t index_offset;
+    float *out_score;
+    int64_t *out_index;
+    int64_t out_stride;
+};
+
+template <int KPT>
+__global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_lds[];
+    // [off: kHsBins + 1 (+3 pad)][cur: kHsBins][list keys: N][list positions (u16): N]
+    uint32_t *off = hs_lds;
+    uint32_t *cur = hs_lds + kHsBins + 4;
+    uint32_t *lkey = cur + kHsBins;
+    uint16_t *lpos = reinterpret_cast<uint16_t *>(lkey + p.N);
+    __shared__ uint32_t scan_buf[kHsWaves];
+    __shared__ uint32_t red_u[kHsWaves];
+    __shared__ float red_f[2 * kHsWaves];
+    __shared__ uint32_t misc[4];                       // cut bin, crowded bins listed, (per crowded bin) equal / less counts
+    __shared__ uint32_t crowded[kHsMaxCrowded];
+    __shared__ uint32_t bitmap[kHsMapWords];           // positions of a tie group's members
+    __shared__ uint32_t bit_prefix[kHsMapWords];       // members in the words before
+    __shared__ uint64_t tmp[kHsTmp];                   // a crowded bin's (key << 16 | position) pairs while they are sorted
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *srow = p.score + (int64_t)b * p.N;
+    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
+    const float fill = p.fill ? *p.fill : 0.f;
+    uint32_t keys[KPT];
+    {
+        float sv[KPT];
+        uint8_t mk[KPT];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) sv[c] = srow[min(c * kHsThreads + tid, p.N - 1)];
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) mk[c] = mrow ? mrow[min(c * kHsThreads + tid, p.N - 1)] : (uint8_t)0;
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) keys[c] = desc_bits(mk[c] ? fill : sv[c]);
+    }
+#pragma unroll
+    for (int i = 0; i < kHsBinsPerThread; ++i) cur[tid * kHsBinsPerThread + i] = 0u;
+    if (tid == 0) { misc[0] = 0u; misc[1] = 0u; }
+    auto real = [&](int c) { return c * kHsThreads + tid < p.N; };
+    auto emit = [&](uint32_t rank, uint32_t key, int pos) {
+        if (p.out_score) p.out_score[(int64_t)b * p.out_stride + rank] = undesc_bits(key);
+        p.out_index[(int64_t)b * p.out_stride + rank] = p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
+    };
+    // Ranks of a group of EQUAL keys `tie` (every thread finds its members in its registers): base + number of members at
+    // earlier positions, emitted when < limit.  Uniform control flow (barriers inside).
+    auto rank_ties_by_position = [&](uint32_t tie, uint32_t base, uint32_t limit) {
+        const int words = (p.N + 31) >> 5;
+        if (tid < words) bitmap[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) {
+            const int pos = c * kHsThreads + tid;
+            if (real(c) && keys[c] == tie) atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+        }
+        __syncthreads();
+        uint32_t total;
+        const uint32_t before = block_exclusive_scan(tid < words ? (uint32_t)__popc(bitmap[tid]) : 0u, scan_buf, tid, total);
+        if (tid < words) bit_prefix[tid] = before;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) {
+            const int pos = c * kHsThreads + tid;
+            if (real(c) && keys[c] == tie) {
+                const uint32_t rank = base + bit_prefix[pos >> 5] + (uint32_t)__popc(bitmap[pos >> 5] & ((1u << (pos & 31)) - 1u));
+                if (rank < limit) emit(rank, tie, pos);
+            }
+        }
+        __syncthreads();   // the bitmap is free again
+    };
+
+    // ---- the floor group: keys equal to the largest key (= smallest score) ----
+    uint32_t kmax = 0u;
+#pragma unroll
+    for (int c = 0; c < KPT; ++c)
+        if (real(c)) kmax = max(kmax, keys[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    if (lane == 0) red_u[wave] = kmax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kHsWaves; ++w) kmax = max(kmax, red_u[w]);
+    // finite score range of the other keys, number of floor keys
+    float smin = INFINITY, smax = -INFINITY;
+    uint32_t n_floor = 0;
+#pragma unroll
+    for (int c = 0; c < KPT; ++c) {
+        if (!real(c)) continue;
+        if (keys[c] == kmax) {
+            ++n_floor;
+        } else {
+            const float v = undesc_bits(keys[c]);
+            if (fabsf(v) < INFINITY) { smin = fminf(smin, v); smax = fmaxf(smax, v); }
+        }
+    }
+    {
+        uint32_t total;
+        (void)block_exclusive_scan(n_floor, scan_buf, tid, total);   // (barrier inside: red_u is free again)
+        n_floor = total;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        smin = fminf(smin, __shfl_xor(smin, o, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    }
+    if (lane == 0) { red_f[wave] = smin; red_f[kHsWaves + wave] = smax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kHsWaves; ++w) { smin = fminf(smin, red_f[w]); smax = fmaxf(smax, red_f[kHsWaves + w]); }
+    const uint32_t n_other = (uint32_t)p.N - n_floor;
+    const uint32_t kk = min((uint32_t)p.k, n_other);           // ranks [0, kk) go to the other keys
+    const float span = smax - smin;
+    // (no finite key, or one value: everything lands in bin 0 and is ranked among its mates)
+    const float scale = (span > 0.f && span < INFINITY) ? (float)kHsBins / span : 0.f;
+    const float top = (span >= 0.f && span < INFINITY) ? smax : 0.f;
+    auto bin_of = [&](uint32_t key) -> uint32_t {
+        // monotone in the key order: fl(top - v) and the product are monotone, the clamp sends +inf to bin 0 and -inf
+        // to the last bin, the conversion truncates
+        const float d = (top - undesc_bits(key)) * scale;
+        return (uint32_t)fminf(fmaxf(d, 0.f), (float)(kHsBins - 1));   // (fmaxf(NaN, 0) = 0)
+    };
+    // ---- histogram of the other keys ----
+    if (kk > 0) {
+#pragma unroll
+        for (int c = 0; c < KPT; ++c)
+            if (real(c) && keys[c] != kmax) atomicAdd(&cur[bin_of(keys[c])], 1u);
+    }
+    __syncthreads();
+    uint32_t h[kHsBinsPerThread], hsum = 0;
+#pragma unroll
+    for (int i = 0; i < kHsBinsPerThread; ++i) { h[i] = cur[tid * kHsBinsPerThread + i]; hsum += h[i]; }
+    uint32_t total;
+    const uint32_t before = block_exclusive_scan(hsum, scan_buf, tid, total);
+    __syncthreads();
+    {
+        uint32_t run = before;
+#pragma unroll
+        for (int i = 0; i < kHsBinsPerThread; ++i) {
+            const int bin = tid * kHsBinsPerThread + i;
+            uint32_t flag = 0u;
+            if (run < kk && h[i] > (uint32_t)kHsCrowd) {   // a crowded bin that holds ranks below k
+                const uint32_t slot = atomicAdd(&misc[1], 1u);
+                if (slot < (uint32_t)kHsMaxCrowded) { crowded[slot] = (uint32_t)bin; flag = kHsFlag; }
+            }
+            off[bin] = run | flag;
+            cur[bin] = run;          // the bin's scatter cursor
+            if (run < kk && kk <= run + h[i]) misc[0] = (uint32_t)bin;   // exactly one bin: the counts partition the keys
+            run += h[i];
+        }
+        if (tid == kHsThreads - 1) off[kHsBins] = run;
+    }
+    __syncthreads();
+    const uint32_t cut = misc[0];
+    const uint32_t n_crowded = min(misc[1], (uint32_t)kHsMaxCrowded);
+    const uint32_t n_keep = kk > 0 ? (off[cut + 1] & ~kHsFlag) : 0u;   // keys of the bins <= cut
+    // ---- scatter the keys of bins <= cut into their bins' lists ----
+    if (kk > 0) {
+#pragma unroll
+        for (int c = 0; c < KPT; ++c) {
+            if (!real(c) || keys[c] == kmax) continue;
+            const uint32_t bin = bin_of(keys[c]);
+            if (bin > cut) continue;
+            const uint32_t slot = atomicAdd(&cur[bin], 1u);
+            lkey[slot] = keys[c];
+            lpos[slot] = (uint16_t)(c * kHsThreads + tid);   // N <= 17 408 < 2^16
+        }
+    }
+    __syncthreads();
+    // ---- one thread per list entry: rank among the bin mates (bins on the crowded list are skipped) ----
+    for (uint32_t e = (uint32_t)tid; e < n_keep; e += kHsThreads) {
+        const uint32_t key = lkey[e];
+        const int pos = (int)lpos[e];
+        const uint32_t bin = bin_of(key);
+        const uint32_t o = off[bin];
+        if (o & kHsFlag) continue;
+        const uint32_t lo = o, hi = off[bin + 1] & ~kHsFlag;
+        uint32_t rank = lo;
+        for (uint32_t j = lo; j < hi; ++j) {
+            const uint32_t kj = lkey[j];
+            rank += (kj < key || (kj == key && (int)lpos[j] < pos)) ? 1u : 0u;
+        }
+        if (rank < kk) emit(rank, key, pos);
+    }
+    // ---- crowded bins, one at a time ----
+    for (uint32_t ci = 0; ci < n_crowded; ++ci) {
+        const uint32_t bin = crowded[ci];
+        const uint32_t lo = off[bin] & ~kHsFlag, hi = off[bin + 1] & ~kHsFlag, m = hi - lo;
+        if (m <= (uint32_t)kHsTmp) {
+            uint32_t P = 64;
+            while (P < m) P <<= 1;
+            for (uint32_t t = tid; t < P; t += kHsThreads)
+                tmp[t] = t < m ? (((uint64_t)lkey[lo + t] << 16) | (uint64_t)lpos[lo + t]) : ~0ull;
+            for (uint32_t size = 2; size <= P; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    __syncthreads();
+                    for (uint32_t t = tid; t < (P >> 1); t += kHsThreads) {
+                        const uint32_t i = ((t & ~(stride - 1u)) << 1) | (t & (stride - 1u));   // bit `stride` clear
+                        const uint32_t j = i | stride;
+                        const uint64_t a = tmp[i], c = tmp[j];
+                        if ((a > c) == ((i & size) == 0u)) { tmp[i] = c; tmp[j] = a; }
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t t = tid; t < m; t += kHsThreads) {
+                const uint64_t e = tmp[t];
+                const uint32_t rank = lo + t;
+                if (rank < kk) emit(rank, (uint32_t)(e >> 16), (int)(e & 0xffffu));
+            }
+            __syncthreads();   // tmp is rewritten by the next crowded bin
+        } else {
+            for (uint32_t e = lo + tid; e < hi; e += kHsThreads) {
+                const uint32_t key = lkey[e];
+                const int pos = (int)lpos[e];
+                uint32_t rank = lo;
+                for (uint32_t j = lo; j < hi; ++j) {
+                    const uint32_t kj = lkey[j];
+                    rank += (kj < key || (kj == key && (int)lpos[j] < pos)) ? 1u : 0u;
+                }
+                if (rank < kk) emit(rank, key, pos);
+            }
+        }
+    }
+    // ---- the floor group fills the ranks the other keys leave ----
+    if ((uint32_t)p.k > n_other) rank_ties_by_position(kmax, n_other, (uint32_t)p.k);
+}
+
 __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t rank_lds[kRankLdsWords];
@@ -244,19 +520,30 @@ __global__ void __launch_bounds__(256) merge_sorted_kernel(MergeArgs p)
 
 using namespace sdetr;
 
+static bool use_select(int n, int k)
+{
+    // the shapes that used to take prefilter + rank (k well below n) and fit one workgroup: histogram sort in ONE launch
+    // (SDETR_TOPK_SELECT=0: the two-launch path, for A/B runs)
+    static const bool enabled = [] { const char *e = getenv("SDETR_TOPK_SELECT"); return !(e && e[0] == '0'); }();
+    if (!enabled) return false;
+    return n >= 1024 && n <= kHsMaxN && (int64_t)k * 5 <= (int64_t)n * 2;
+}
+
 static bool use_prefilter(int n, int k)
 {
     // worth it when the ranked set shrinks at least ~2x and the row fits the register-resident prefilter
     return n >= 2048 && n <= kPreThreads * 24 && (int64_t)k * 5 <= (int64_t)n * 2;
 }
 
-// whether sdetr_masked_topk_desc_f32 puts the sampled-threshold prefilter in front of the rank kernel for this shape
-extern "C" int sdetr_topk_uses_prefilter(int n, int k) { return use_prefilter(n, k) ? 1 : 0; }
+// whether sdetr_masked_topk_desc_f32 runs something else than the plain rank kernel for this shape (the one-launch
+// select, or the sampled-threshold prefilter in front of the rank kernel): such a call cannot ride in another launch
+extern "C" int sdetr_topk_uses_prefilter(int n, int k) { return (use_select(n, k) || use_prefilter(n, k)) ? 1 : 0; }
 
 extern "C" size_t sdetr_topk_workspace_bytes(int B, int n, int k)
 {
     if (B <= 0 || n <= 0 || k <= 0) return 0;
     size_t bytes = 16;  // one float: the masked-fill value
+    if (use_select(n, k)) return bytes;
     if (use_prefilter(n, k)) bytes += (size_t)B * n * 8 + (size_t)B * 4 + 16;  // candidate keys, positions, counts
     return bytes;
 }
@@ -291,6 +578,28 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
         r.fill = reinterpret_cast<const float *>(workspace);
     } else if (fill_mode == 2) {
         r.fill = fill_value;
+    }
+    if (use_select(n, k)) {
+        SelectArgs a{};
+        a.score = score; a.mask = mask; a.mask_stride = mask_row_stride; a.fill = r.fill; a.payload = payload; a.N = n;
+        a.k = k; a.index_offset = index_offset; a.out_score = out_score; a.out_index = out_index;
+        a.out_stride = out_row_stride;
+        const int chunk = (n + kHsThreads - 1) / kHsThreads;
+        const size_t dyn = ((size_t)(2 * kHsBins + 4) + (size_t)n) * 4 + (((size_t)n * 2 + 15) & ~(size_t)15);
+#define SDETR_HS(KPT)                                                                                               \
+    do {                                                                                                            \
+        static DeviceOnce lds_once;                                                                                 \
+        allow_dynamic_lds(topk_hsort_kernel<KPT>, lds_once, 136 * 1024);   /* + ~14 KB of static LDS */                                            \
+        hipLaunchKernelGGL(topk_hsort_kernel<KPT>, dim3((unsigned)B), dim3(kHsThreads), dyn, stream, a);            \
+    } while (0)
+        if (chunk <= 3) SDETR_HS(3);
+        else if (chunk <= 5) SDETR_HS(5);
+        else if (chunk <= 7) SDETR_HS(7);
+        else if (chunk <= 9) SDETR_HS(9);
+        else if (chunk <= 12) SDETR_HS(12);
+        else SDETR_HS(17);
+#undef SDETR_HS
+        return check_launch("topk_hsort");
     }
     int ranked = n;
     if (use_prefilter(n, k)) {

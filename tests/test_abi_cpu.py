@@ -38,7 +38,9 @@ def test_argument_rejection_without_gpu(libpath):
     assert lib.sdetr_msda_fused_forward(None, 1, 0, 1, 1, 1, 3, 0, 1, 0, 384, 0, None, 1, 1, 8, 32, 4, 1, 4, 1, 0) == _hip.EINVAL
     assert b"must be 2 or 4" in lib.sdetr_last_error()
     assert lib.sdetr_topk_workspace_bytes(2, 1050, 1050) == 16  # one float: the masked-fill value
-    assert lib.sdetr_topk_workspace_bytes(2, 11363, 300) == 16 + 2 * 11363 * 8 + 2 * 4 + 16  # + prefilter candidates
+    assert lib.sdetr_topk_workspace_bytes(2, 11363, 300) == 16  # the one-launch histogram sort keeps its lists in LDS
+    assert lib.sdetr_topk_workspace_bytes(2, 16800, 6680) == 16
+    assert lib.sdetr_topk_workspace_bytes(2, 20000, 6680) == 16 + 2 * 20000 * 8 + 2 * 4 + 16  # + prefilter candidates
     assert lib.sdetr_topk_workspace_bytes(0, 5, 1) == 0
     # neck (13)
     assert lib.sdetr_neck_conv3x3(None, None, 0, 1, 4, 4, 32, None, None, 4, 8, 8, 3, 0, None) == _hip.EINVAL
@@ -96,7 +98,7 @@ def test_host_side_size_helpers_need_no_gpu():
     assert lib.sdetr_ffn_auto_splits(0, 2048) == 1
     assert lib.sdetr_linear_packed_bytes(91) == 65536 and lib.sdetr_linear_packed_bytes(384) == 3 * 65536
     assert lib.sdetr_focal_loss_workspace_bytes(0) == 0 and lib.sdetr_focal_loss_workspace_bytes(10 ** 9) == 1024 * 8
-    assert lib.sdetr_topk_workspace_bytes(2, 11363, 300) > 2 * 11363 * 8
+    assert lib.sdetr_topk_workspace_bytes(2, 20000, 6680) > 2 * 20000 * 8 and lib.sdetr_topk_workspace_bytes(2, 11363, 300) == 16
     # neck (13): pooling partials = ceil(pixels / 128) x (channels + 2) floats per image; MFMA weight fragments in bf16
     assert lib.sdetr_neck_gate_workspace_bytes(2, 16800, 256) == 2 * 132 * 258 * 4
     assert lib.sdetr_neck_gate_workspace_bytes(0, 16800, 256) == 0

@@ -71,34 +71,45 @@ def test_whole_path_selection_flips_are_the_only_large_errors(timed_case):
     """End to end in the timed mode: tokens whose membership in some layer's top-300 set differs from the oracle's
     are counted; every OTHER token stays within the accumulated bf16 rounding of six layers.
 
-    The class scores that pick the 300 are near-ties by the hundred (11 363 candidates, ~750 per unit of score around
-    the cut), so the ~0.03 that six bf16 layers put on a query row moves dozens of tokens across the cut per layer:
-    measured 1412 of the 3600 (image, layer, slot) selections differ from the fp32 oracle's.  That is a property of
-    running the reference's selection rule on bf16 activations (its own autocast mode does the same), not of a
-    kernel: the teacher-forced test above holds every layer to the rounding bar with the selection fixed."""
+    The class scores that pick the 300 are near-ties (11 363 candidates, ~2000 per unit of score around the cut), so
+    the ~1e-3 that bf16 rows and weights put on a score -- growing with the rounding the earlier layers leave on the
+    rows -- moves a few tokens across the cut per layer: measured 2 / 18 / 28 / 40 / 54 / 98 tokens in exactly one of
+    the two sets at layers 0-5 (240 of 3600 = 6.7 %), with the class score taken from the fp32 accumulators.  (Rounds
+    1-2 reported ~1400: the GPU's selected POSITIONS were mapped through the oracle's sorted list, whose order differs
+    from the GPU's among tied salience scores -- a bookkeeping artefact, fixed in round 3.)  The teacher-forced test
+    above holds every layer to the rounding bar with the selection fixed."""
     m, sizes, level_shapes, feats, masks, pos, ref = timed_case
     sel_log = {}
     m.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.clone()) or s
     try:
         with torch.no_grad():
-            memory = m([f.to(DEV) for f in feats], [x.to(DEV) for x in masks], [p.to(DEV) for p in pos],
-                       image_sizes=sizes, canvas=syn.pad_to_32(800, 1333))[0]
+            memory, _, aux = m([f.to(DEV) for f in feats], [x.to(DEV) for x in masks], [p.to(DEV) for p in pos],
+                               image_sizes=sizes, canvas=syn.pad_to_32(800, 1333), return_aux=True)
     finally:
         m.encoder.selection_hook = None
+    gpu_inds = [t.cpu() for t in aux["foreground_inds"]]
     assert M.last_forward_kernel() == M.KERNEL_RESIDENT           # layer 5: 2272 queries per image
     B, S, _ = memory.shape
     flipped = torch.zeros(B, S, dtype=torch.bool)
     for k in range(6):
-        inds = ref["foreground_inds"][k]                         # [B, c_k] token ids of the layer's rows
+        inds = ref["foreground_inds"][k]                         # [B, c_k] token ids of the layer's rows (oracle order)
+        assert all(set(gpu_inds[k][b].tolist()) == set(inds[b].tolist()) for b in range(B))   # the same SET of rows
         for b in range(B):
+            # a selection is a set of POSITIONS in the side's own sorted list (the two orders differ among tied scores:
+            # the ~700 border tokens per image whose zeroed rows give identical salience scores)
             a = set(inds[b][ref["layer_sel"][k][b]].tolist())
-            g = set(inds[b][sel_log[k][b].cpu()].tolist())
+            g = set(gpu_inds[k][b][sel_log[k][b].cpu()].tolist())
             for tok in a ^ g:
                 flipped[b, tok] = True
     err = (memory.float().cpu() - ref["memory"]).abs().max(-1)[0]   # per token
     n_flip = int(flipped.sum())
     clean = err[~flipped]
     print(f"selection flips: {n_flip} tokens of {B * S}; non-flipped tokens: max {clean.max():.4f} mean {clean.mean():.5f}")
-    assert n_flip <= 0.5 * B * 300 * 6
+    # (round 3: the class score comes from fp32 accumulators -- under 10 % of the selections differ; it was 39 % with
+    # the maximum rounded to bf16 first)
+    assert n_flip <= 0.1 * B * 300 * 6
+    # every other token: rounding of six bf16 layers, plus -- for the rows a layer selected -- the second-order effect
+    # of a different neighbour in its 300-row attention (measured: mean 0.030, 99.9 % <= 0.30, max 0.52)
     assert clean.mean().item() <= 0.04
-    assert (clean <= 0.25).float().mean().item() >= 0.999
+    assert (clean <= 0.35).float().mean().item() >= 0.999
+    assert clean.max().item() <= 1.0

@@ -42,13 +42,16 @@ def test_masked_topk_with_ties(B, N, k):
     assert torch.equal(v.cpu(), rv)
 
 
-@pytest.mark.parametrize("B,N,k", [(2, 1024, 256), (2, 11363, 300), (3, 4096, 1024), (2, 9090, 300), (2, 2272, 300)])
-@pytest.mark.parametrize("kind", ["random", "ties", "constant", "masked"])
+@pytest.mark.parametrize("B,N,k", [(2, 1024, 256), (2, 11363, 300), (3, 4096, 1024), (2, 9090, 300), (2, 2272, 300),
+                                   (2, 6817, 300), (2, 4545, 300), (1, 24576, 1024), (2, 2560, 1024), (2, 5000, 1),
+                                   (1, 24577, 300), (2, 1023, 300), (2, 16800, 6680), (2, 17408, 6000), (1, 17409, 6000)])
+@pytest.mark.parametrize("kind", ["random", "ties", "constant", "masked", "sigmoid", "two_values", "padded_tail"])
 def test_small_k_selection(B, N, k, kind):
-    """Small k of a long row (the encoder layers' top-300).  Heavy ties, a constant row, +-inf / +-0, a mask whose
-    fill value floods the row, a payload and an index offset -- bit-exact against the stable descending sort.
-    (A one-workgroup-per-row selection kernel was tried for this case -- radix histogram, then a counting search with
-    the keys in LDS, then in registers -- and measured 33-64 us against 17 us for prefilter + rank: dropped.)"""
+    """k well below the row length (the encoder layers' top-300, the finest level's top-6680 of 16 800): the one-launch
+    histogram sort (csrc/topk.hip, topk_hsort_kernel: rows of 1024 ... 17 408 keys) and, outside its shape, prefilter +
+    rank.  Heavy ties, a constant row, +-inf / +-0, a mask whose fill value floods the
+    row, scores squeezed into a narrow band (class score x foreground score), two key values only, a padded tail that
+    ties at the minimum, a payload and an index offset -- bit-exact against the stable descending sort."""
     g = torch.Generator().manual_seed(N + k)
     score = torch.randn(B, N, generator=g)
     mask = None
@@ -59,7 +62,15 @@ def test_small_k_selection(B, N, k, kind):
         score[0, 5] = -0.0
     elif kind == "masked":
         mask = torch.rand(B, N, generator=g) < 0.7
-    score[0, :4] = torch.tensor([0.0, -0.0, float("inf"), -float("inf")])
+    elif kind == "sigmoid":
+        score = torch.sigmoid(score - 4.0) * torch.sigmoid(torch.randn(B, N, generator=g))
+    elif kind == "two_values":
+        score = (score > 1.0).float() * 0.5 + 0.125
+    elif kind == "padded_tail":
+        score = torch.sigmoid(score)
+        score[:, N // 3:] = float(score.min())
+    if kind not in ("sigmoid", "two_values", "padded_tail"):
+        score[0, :4] = torch.tensor([0.0, -0.0, float("inf"), -float("inf")])
     payload = torch.stack([torch.randperm(5 * N, generator=torch.Generator().manual_seed(b))[:N] for b in range(B)])
     kw = dict(mask=mask.to(DEV), fill_with_global_min=True) if mask is not None else {}
     v, i = F.masked_topk_desc(score.to(DEV), k, index_offset=7, **kw)
@@ -411,8 +422,9 @@ def test_token_linear_kernels_match_framework_bf16_path(B, n):
         fg_long = syn.det_randn(f"tlf{n}", (B, n + 5)).to(DEV)
         mc = F.class_head_max_times(x, head, fg_long[:, :n])
         logits32 = torch.nn.functional.linear(x.float(), head.weight.float(), head.bias.float())
-        want = _bf(logits32.max(-1)[0]).float() * fg_long[:, :n]
-        assert (mc - want).abs().max().item() <= 0.02 * (want.abs().max().item() + 1)
+        # the maximum comes from the fp32 accumulators (no bf16 rounding of the logits: the score picks the top-300)
+        want = logits32.max(-1)[0] * fg_long[:, :n]
+        assert (mc - want).abs().max().item() <= 2e-4 * (want.abs().max().item() + 1)
         frame = F.class_max_times(head(x), fg_long[:, :n])
         assert (mc - frame).abs().max().item() <= 0.02 * (want.abs().max().item() + 1)
 
