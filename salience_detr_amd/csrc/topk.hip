@@ -231,6 +231,15 @@ constexpr int kHsMapWords = (kHsMaxN + 31) / 32;         // 544
 constexpr uint32_t kHsFlag = 0x80000000u;                // in off[bin]: the bin is on the crowded list
 constexpr int kHsTmp = 2048;                             // entries of a crowded bin that are sorted in LDS
 
+// (benchmarks/micro/hsort_phases.hip compiles this file with SDETR_HS_STAMPS: cycle stamps of workgroup 0 at the phase
+// boundaries.  Empty in the library.)
+#ifdef SDETR_HS_STAMPS
+__device__ unsigned long long hs_stamps[16];
+#define HS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) hs_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HS_STAMP(i) do { } while (0)
+#endif
+
 struct SelectArgs {
     const float *score;
     const uint8_t *mask;
@@ -266,6 +275,7 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
     const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
     const float fill = p.fill ? *p.fill : 0.f;
     uint32_t keys[KPT];
+    HS_STAMP(0);
     {
         float sv[KPT];
         uint8_t mk[KPT];
@@ -311,46 +321,32 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
         __syncthreads();   // the bitmap is free again
     };
 
-    // ---- the floor group: keys equal to the largest key (= smallest score) ----
+    // ---- one reduction: the largest key (= smallest score: the FLOOR group) and the finite score range ----
     uint32_t kmax = 0u;
-#pragma unroll
-    for (int c = 0; c < KPT; ++c)
-        if (real(c)) kmax = max(kmax, keys[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
-    if (lane == 0) red_u[wave] = kmax;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < kHsWaves; ++w) kmax = max(kmax, red_u[w]);
-    // finite score range of the other keys, number of floor keys
     float smin = INFINITY, smax = -INFINITY;
-    uint32_t n_floor = 0;
 #pragma unroll
     for (int c = 0; c < KPT; ++c) {
         if (!real(c)) continue;
-        if (keys[c] == kmax) {
-            ++n_floor;
-        } else {
-            const float v = undesc_bits(keys[c]);
-            if (fabsf(v) < INFINITY) { smin = fminf(smin, v); smax = fmaxf(smax, v); }
-        }
-    }
-    {
-        uint32_t total;
-        (void)block_exclusive_scan(n_floor, scan_buf, tid, total);   // (barrier inside: red_u is free again)
-        n_floor = total;
+        kmax = max(kmax, keys[c]);
+        const float v = undesc_bits(keys[c]);
+        if (fabsf(v) < INFINITY) { smin = fminf(smin, v); smax = fmaxf(smax, v); }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
         smin = fminf(smin, __shfl_xor(smin, o, 64));
         smax = fmaxf(smax, __shfl_xor(smax, o, 64));
     }
-    if (lane == 0) { red_f[wave] = smin; red_f[kHsWaves + wave] = smax; }
+    if (lane == 0) { red_u[wave] = kmax; red_f[wave] = smin; red_f[kHsWaves + wave] = smax; }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < kHsWaves; ++w) { smin = fminf(smin, red_f[w]); smax = fmaxf(smax, red_f[kHsWaves + w]); }
-    const uint32_t n_other = (uint32_t)p.N - n_floor;
-    const uint32_t kk = min((uint32_t)p.k, n_other);           // ranks [0, kk) go to the other keys
+    for (int w = 0; w < kHsWaves; ++w) {
+        kmax = max(kmax, red_u[w]);
+        smin = fminf(smin, red_f[w]);
+        smax = fmaxf(smax, red_f[kHsWaves + w]);
+    }
+    // (the range includes the floor value when it is finite: a fill value far below an image's own scores costs bin
+    // resolution, never exactness)
     const float span = smax - smin;
     // (no finite key, or one value: everything lands in bin 0 and is ranked among its mates)
     const float scale = (span > 0.f && span < INFINITY) ? (float)kHsBins / span : 0.f;
@@ -361,18 +357,19 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
         const float d = (top - undesc_bits(key)) * scale;
         return (uint32_t)fminf(fmaxf(d, 0.f), (float)(kHsBins - 1));   // (fmaxf(NaN, 0) = 0)
     };
+    HS_STAMP(1);   // keys loaded, floor group and score range known
     // ---- histogram of the other keys ----
-    if (kk > 0) {
 #pragma unroll
-        for (int c = 0; c < KPT; ++c)
-            if (real(c) && keys[c] != kmax) atomicAdd(&cur[bin_of(keys[c])], 1u);
-    }
+    for (int c = 0; c < KPT; ++c)
+        if (real(c) && keys[c] != kmax) atomicAdd(&cur[bin_of(keys[c])], 1u);
     __syncthreads();
+    HS_STAMP(2);   // histogram
     uint32_t h[kHsBinsPerThread], hsum = 0;
 #pragma unroll
     for (int i = 0; i < kHsBinsPerThread; ++i) { h[i] = cur[tid * kHsBinsPerThread + i]; hsum += h[i]; }
-    uint32_t total;
-    const uint32_t before = block_exclusive_scan(hsum, scan_buf, tid, total);
+    uint32_t n_other;
+    const uint32_t before = block_exclusive_scan(hsum, scan_buf, tid, n_other);   // total = keys outside the floor group
+    const uint32_t kk = min((uint32_t)p.k, n_other);           // ranks [0, kk) go to them
     __syncthreads();
     {
         uint32_t run = before;
@@ -395,6 +392,7 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
     const uint32_t cut = misc[0];
     const uint32_t n_crowded = min(misc[1], (uint32_t)kHsMaxCrowded);
     const uint32_t n_keep = kk > 0 ? (off[cut + 1] & ~kHsFlag) : 0u;   // keys of the bins <= cut
+    HS_STAMP(3);   // offsets, cut bin
     // ---- scatter the keys of bins <= cut into their bins' lists ----
     if (kk > 0) {
 #pragma unroll
@@ -408,6 +406,7 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
         }
     }
     __syncthreads();
+    HS_STAMP(4);   // scatter
     // ---- one thread per list entry: rank among the bin mates (bins on the crowded list are skipped) ----
     for (uint32_t e = (uint32_t)tid; e < n_keep; e += kHsThreads) {
         const uint32_t key = lkey[e];
@@ -417,17 +416,60 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
         if (o & kHsFlag) continue;
         const uint32_t lo = o, hi = off[bin + 1] & ~kHsFlag;
         uint32_t rank = lo;
-        for (uint32_t j = lo; j < hi; ++j) {
-            const uint32_t kj = lkey[j];
-            rank += (kj < key || (kj == key && (int)lpos[j] < pos)) ? 1u : 0u;
+        // four mates per round, all eight LDS reads issued before the first compare (clamped indices: a read past the
+        // bin's end repeats its last entry and is masked out)
+        for (uint32_t j = lo; j < hi; j += 4) {
+            uint32_t kj[4];
+            int pj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t jj = min(j + u, hi - 1u);
+                kj[u] = lkey[jj];
+                pj[u] = (int)lpos[jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                rank += (j + u < hi && (kj[u] < key || (kj[u] == key && pj[u] < pos))) ? 1u : 0u;
         }
         if (rank < kk) emit(rank, key, pos);
     }
+    HS_STAMP(5);   // ranks of the ordinary bins (thread 0's share)
     // ---- crowded bins, one at a time ----
     for (uint32_t ci = 0; ci < n_crowded; ++ci) {
         const uint32_t bin = crowded[ci];
         const uint32_t lo = off[bin] & ~kHsFlag, hi = off[bin + 1] & ~kHsFlag, m = hi - lo;
-        if (m <= (uint32_t)kHsTmp) {
+        if (m <= (uint32_t)kHsThreads) {
+            // one entry per thread: partners less than a wavefront apart exchange through lane permutes (no LDS, no
+            // barrier: 45 of the 55 steps of a 1024-entry sort), the others through `tmp`
+            uint32_t P = 64;
+            while (P < m) P <<= 1;
+            uint64_t mine = (uint32_t)tid < m ? (((uint64_t)lkey[lo + tid] << 16) | (uint64_t)lpos[lo + tid]) : ~0ull;
+            for (uint32_t size = 2; size <= P; size <<= 1) {
+                const bool asc = ((uint32_t)tid & size) == 0u;
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    uint64_t other;
+                    if (stride >= 64u) {
+                        tmp[tid] = mine;
+                        __syncthreads();
+                        other = tmp[(uint32_t)tid ^ stride];
+                        __syncthreads();
+                    } else {
+                        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)mine, (int)stride, 64);
+                        const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), (int)stride, 64);
+                        other = ((uint64_t)ohi << 32) | olo;
+                    }
+                    const bool lower = ((uint32_t)tid & stride) == 0u;
+                    const uint64_t mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+                    mine = (lower == asc) ? mn : mx;
+                }
+            }
+            // (threads >= P hold ~0 and only ever meet each other: P is a multiple of 64 and, for the LDS steps, a power
+            // of two that their partner index stays above)
+            if ((uint32_t)tid < m) {
+                const uint32_t rank = lo + (uint32_t)tid;
+                if (rank < kk) emit(rank, (uint32_t)(mine >> 16), (int)(mine & 0xffffu));
+            }
+        } else if (m <= (uint32_t)kHsTmp) {
             uint32_t P = 64;
             while (P < m) P <<= 1;
             for (uint32_t t = tid; t < P; t += kHsThreads)
@@ -463,8 +505,10 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
             }
         }
     }
+    HS_STAMP(6);   // crowded bins
     // ---- the floor group fills the ranks the other keys leave ----
     if ((uint32_t)p.k > n_other) rank_ties_by_position(kmax, n_other, (uint32_t)p.k);
+    HS_STAMP(7);
 }
 
 __global__ void __launch_bounds__(kRankThreads) topk_rank_kernel(RankArgs p)
