@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--x3-linear", dest="x3_linear", action="store_true", default=True,
                     help="train mode: weight gradients of the nn.Linear layers through sdetr_gemm_x3_f32 (default)")
     ap.add_argument("--no-x3-linear", dest="x3_linear", action="store_false")
+    ap.add_argument("--force-dist-path", action="store_true",
+                    help="train mode, one process: take the N > 1 execution path anyway (captured forward + backward + "
+                         "gradient pack, eager flat all-reduce + optimizer) -- how that path is exercised on a 1-GPU box")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="the default line's `train_step` sub-record: this many timed training steps (0: skip)")
     ap.add_argument("--in-flight", dest="in_flight", type=int, default=1,
                     help="--plain only, informational: this many independent batches (own inputs, own graph, own "
                          "stream) replayed side by side; the official line is 1")
@@ -90,12 +95,17 @@ def algorithmic_bytes(B, Nv, Nq, M, D, L, P, value_bytes, proj_bytes, out_bytes,
                 + Nq * M * D * out_bytes)
 
 
-def train_main(args, model, device, rank, world, dist):
+def train_record(args, model, device, rank, world, dist, steps, warmup, force_dist_path=False):
     """configs[2]: one training step of the hot-path modules per batch of 2 images per GPU -- fp32 forward
     through the autograd path (HIP MSDA forward/backward op), the salience criterion (row N4: targets + focal loss
-    on the salience maps, synthetic ground-truth boxes) plus a synthetic loss on `memory`, backward with the ~38 MB
-    of gradients all-reduced over RCCL in buckets that overlap it, AdamW."""
-    from salience_detr_amd.data_parallel import OverlappedGradReducer, broadcast_parameters
+    on the salience maps, synthetic ground-truth boxes) plus a synthetic loss on `memory`, backward, gradient
+    all-reduce over RCCL, AdamW.  Returns the result record (every rank; rank 0 prints it).
+
+    Execution: forward + backward (+ the pack of the gradients into one flat buffer) is ONE replayed hipGraph at every
+    world size.  A single process also captures the optimizer step; with ranks, the replay is followed by one all-reduce
+    of the flat gradient buffer and the fused AdamW step, both eager (3 host calls per step: the step stays
+    device-bound, and N = 1 and N > 1 run the same captured kernels)."""
+    from salience_detr_amd.data_parallel import StaticGradAllReducer, broadcast_parameters
     from salience_detr_amd.salience_criterion import SalienceCriterion
     sizes, canvas, level_shapes, _, (feats, masks, pos) = make_inputs(args.batch, args.height, args.width, device,
                                                                       seed=rank)
@@ -112,9 +122,8 @@ def train_main(args, model, device, rank, world, dist):
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True, fused=True)
     except (RuntimeError, TypeError, ValueError):
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True, foreach=True)
-    # 8 MiB buckets in reverse registration order, each all-reduced (RCCL) as soon as backward has produced its last
-    # gradient: the exchange runs under the rest of backward; finish() after backward() waits and unpacks
-    reducer = OverlappedGradReducer(params) if dist is not None else None
+    use_ranks_path = dist is not None or force_dist_path
+    reducer = StaticGradAllReducer(params) if use_ranks_path else None
     w = None
     criterion = SalienceCriterion()
     strides = [(canvas[0] / h, canvas[1] / w_) for h, w_ in level_shapes]
@@ -127,7 +136,7 @@ def train_main(args, model, device, rank, world, dist):
     # ground-truth boxes staged on the device once (the data loader's side); the target maps are built every step
     staged = criterion.stage_boxes(targets, sizes, device)
 
-    def step():
+    def forward_backward():
         nonlocal w
         opt.zero_grad(set_to_none=True)
         memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
@@ -136,11 +145,22 @@ def train_main(args, model, device, rank, world, dist):
         loss = (memory * w).mean() + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
         loss.backward()
         if reducer is not None:
-            reducer.all_reduce(average=True)
-        opt.step()
+            reducer.pack()
         return loss
 
-    for _ in range(max(args.warmup, 2)):
+    def finish():   # what follows the captured region when there are ranks
+        reducer.all_reduce(average=True)
+        opt.step()
+
+    def step():
+        loss = forward_backward()
+        if reducer is not None:
+            finish()
+        else:
+            opt.step()
+        return loss
+
+    for _ in range(max(warmup, 2)):
         step()
 
     def fence():
@@ -149,14 +169,19 @@ def train_main(args, model, device, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the whole step (forward, backward, AdamW) as ONE hipGraph: the eager step issues ~1600 launches from Python and
-    # is host-bound as soon as the kernels get faster.  Single process only (the bucketed all-reduce hooks stay eager).
+    # the eager step issues ~1600 launches from Python and is host-bound as soon as the kernels get faster
     graph = None
     graph_note = "eager"
-    if not args.no_graph and dist is None:
+    capture_kw = {"capture_error_mode": "thread_local"} if dist is not None else {}
+    if not args.no_graph:
         try:
-            graph, loss_static = capture(step, {})
-            graph_note = "hipGraph replay of the whole step"
+            graph, loss_static = capture(step if reducer is None else forward_backward, capture_kw)
+            if reducer is not None:
+                finish()      # (capture() replays once: complete that step)
+                graph_note = ("hipGraph replay of forward + backward + gradient pack, then one eager all-reduce of the "
+                              "flat gradient buffer and the fused AdamW step")
+            else:
+                graph_note = "hipGraph replay of the whole step"
         except Exception as e:   # a host synchronisation inside the autograd path: report it, time the eager step
             graph = None
             graph_note = "eager (capture failed: %s)" % str(e).split("\n")[0][:120]
@@ -170,12 +195,14 @@ def train_main(args, model, device, rank, world, dist):
     def timed_step():
         if graph is not None:
             graph.replay()
+            if reducer is not None:
+                finish()
             return loss_static
         return step()
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = timed_step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -201,22 +228,24 @@ def train_main(args, model, device, rank, world, dist):
         return r
 
     msda_mod.ms_deform_attn_backward = timed_bwd
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    msda_mod.ms_deform_attn_backward = real_bwd
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        msda_mod.ms_deform_attn_backward = real_bwd
     tot_us = sum(e0.elapsed_time(e1) for e0, e1 in evs) * 1e3
     achieved = sum(nbytes) / tot_us / 1e3
-    result = {
+    return {
         "metric": "images/s (whole node) + ms/encoder-layer, ResNet50 800x1333",
-        "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "value": round(world * args.batch * steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
         "config": {"workload": "salience_detr_resnet50_800_1333 training step of the hot path (filtering + 6-layer "
                                "encoder fwd+bwd, salience focal loss + synthetic memory loss, AdamW), batch=%d per MI355X" % args.batch,
                    "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "parallelism": "data parallel, bucketed gradient all-reduce over RCCL overlapped with backward"
-                                  if world > 1 else "single GPU",
+                   "parallelism": "data parallel, one all-reduce of the flat gradient buffer over RCCL after the replayed "
+                                  "forward + backward" if use_ranks_path else "single GPU",
                    "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params),
                    "execution": graph_note, "x3_linear": bool(args.x3_linear)},
         "roofline": {"kernel": "MSDA backward op: sdetr::bt_main_kernel (fixed-point LDS windows) + bucketing, "
@@ -224,8 +253,13 @@ def train_main(args, model, device, rank, world, dist):
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "avg_launch_us": round(tot_us / max(1, len(evs)), 1)},
-        "loss": float(loss),
+        "loss": float(loss.detach()),
     }
+
+
+def train_main(args, model, device, rank, world, dist):
+    result = train_record(args, model, device, rank, world, dist, args.steps, args.warmup,
+                          force_dist_path=args.force_dist_path)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
@@ -460,9 +494,22 @@ def main():
     device = torch.device("cuda", local_rank)
     dist = None
     backend = None
-    if world > 1:
+    if world > 1 or (args.force_dist_path and "RANK" in os.environ):
+        # (--force-dist-path under a launcher: a one-rank RCCL group, so that a 1-GPU box runs the collectives too)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line
+        # there -- send whatever the library writes during start-up to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         backend = dist.get_backend()
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group size differs from --gpus")
@@ -751,6 +798,24 @@ def main():
             del lanes, lrun
         except Exception as e:
             result["batches_in_flight"] = {"error": str(e)[:200]}
+
+    # ---- configs[2] next to it: a few training steps of the same modules (fp32 forward + backward + AdamW, gradient
+    # all-reduce when there are ranks), so that the run which produces this line also corroborates the training numbers
+    # (`python bench.py --mode train` is the standalone form) ----
+    if args.train_steps > 0:
+        try:
+            tmodel = build_hot_path()
+            tmodel.load_state_dict(syn.det_state_dict(tmodel.state_dict()))
+            tmodel = tmodel.to(device)
+            tr = train_record(args, tmodel, device, rank, world, dist, args.train_steps, 2)
+            result["train_step"] = {"ms_per_step": tr["ms_per_step"], "images_per_s": tr["value"], "steps": tr["steps"],
+                                    "dtype": tr["dtype"], "execution": tr["config"]["execution"],
+                                    "grad_bytes": tr["config"]["grad_bytes"], "msda_backward_roofline": tr["roofline"],
+                                    "loss": tr["loss"], "workload": tr["config"]["workload"]}
+            del tmodel
+            torch.cuda.empty_cache()
+        except Exception as e:
+            result["train_step"] = {"error": str(e).split("\n")[0][:200]}
 
     # ---- CPU baseline: the oracle's port of the same path on the host cores (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -235,6 +235,61 @@ class OverlappedGradReducer(FlatGradAllReducer):
         self._handles = []
 
 
+class StaticGradAllReducer:
+    """Gradient all-reduce for a step whose forward + backward is REPLAYED as a captured hipGraph.
+
+    Hook-driven bucket reducers issue their collectives from autograd hooks -- host code that a graph replay never
+    runs.  Here the captured region ends with ``pack()``: one multi-tensor copy of the step's gradients (which live at
+    fixed addresses inside the graph's memory pool) into ONE flat buffer, zero where this rank produced none.  After the
+    replay the host issues a single all-reduce of that buffer (38 MB of hot-path gradients: one collective, the latency
+    of a bucket chain is what xGMI's seven point-to-point links would multiply, see the module docstring) and points
+    every ``p.grad`` at its slice, which is what the (eager, fused) optimizer step then reads.  Same result as
+    ``FlatGradAllReducer``; world size 1 works without a process group.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
+        seen, self.params = set(), []
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        first = self.params[0]
+        if any(p.dtype != first.dtype or p.device != first.device for p in self.params):
+            raise ValueError("all parameters of one reducer must share dtype and device")
+        self.group = group
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=first.dtype, device=first.device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    @property
+    def num_bytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def pack(self) -> None:
+        """Last call of the captured region (after ``backward()``): gradients -> flat buffer."""
+        self.flat.zero_()
+        dst = [v for v, p in zip(self.views, self.params) if p.grad is not None and p.grad is not v]
+        src = [p.grad for v, p in zip(self.views, self.params) if p.grad is not None and p.grad is not v]
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def all_reduce(self, average: bool = True) -> None:
+        """After the replay: one all-reduce, then every ``p.grad`` is its slice of the reduced buffer."""
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            if world > 1 or self.group is not None:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if average and world > 1:
+            self.flat.div_(world)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
 class _SyncBatchNormTrain(torch.autograd.Function):
     """BatchNorm2d in training mode over ALL ranks' pixels (what ``nn.SyncBatchNorm`` gives the reference's neck under
     DDP, ``main.py:126-127``; single process: plain batch statistics).  One collective per direction instead of the

@@ -296,3 +296,52 @@ def test_overlapped_reducer_gradient_accumulation(tmp_path, use_no_sync):
         expect = 0.5 * (grads[0][n] + grads[1][n])
         assert torch.allclose(g0[n], expect, rtol=1e-5, atol=1e-6), n
         assert torch.equal(g0[n], g1[n]), n
+
+
+# ---- the reducer of the graph-replayed training step: pack (end of the captured region) -> one all-reduce -> p.grad
+# becomes a slice of the reduced flat buffer ----
+def _static_worker(rank, world, port, out_dir):
+    from salience_detr_amd.data_parallel import StaticGradAllReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _hot_path_model()
+        red = StaticGradAllReducer(model.parameters())
+        skip = ("alpha", "encoder.layers.1.norm2.bias") if rank == 1 else ()
+        for step in range(2):   # two steps: stale slices of the first must not leak into the second
+            model.zero_grad(set_to_none=True)
+            _synthetic_loss(model, rank + 10 * step, skip).backward()
+            red.pack()
+            red.all_reduce(average=True)
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))
+        torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, os.path.join(out_dir, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_static_grad_all_reducer_two_ranks(tmp_path):
+    from salience_detr_amd.data_parallel import StaticGradAllReducer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_static_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0 = torch.load(os.path.join(tmp_path, "s0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "s1.pt"))
+    grads = []
+    for rank in range(2):
+        m = _hot_path_model()
+        skip = ("alpha", "encoder.layers.1.norm2.bias") if rank == 1 else ()
+        _synthetic_loss(m, rank + 10, skip).backward()      # second step's data
+        grads.append({n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()})
+    for n in g0:
+        assert torch.allclose(g0[n], 0.5 * (grads[0][n] + grads[1][n]), rtol=1e-5, atol=1e-6), n
+        assert torch.equal(g0[n], g1[n]), n
+    # one process, no process group: the gradients pass through unchanged
+    m = _hot_path_model()
+    red = StaticGradAllReducer(m.parameters())
+    _synthetic_loss(m, 3).backward()
+    want = {n: p.grad.clone() for n, p in m.named_parameters()}
+    red.pack()
+    red.all_reduce()
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, want[n]), n
