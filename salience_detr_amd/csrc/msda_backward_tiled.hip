@@ -239,6 +239,18 @@ __device__ __forceinline__ float bt_max8(float v)
     v = fmaxf(v, bt_xor2(v));
     return fmaxf(v, bt_up4(v));
 }
+__device__ __forceinline__ float bt_down4(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));  // row_shr:4: lane i <- lane i-4
+}
+// max over the 8 lanes of a row group of a NON-NEGATIVE value, complete in all eight lanes (k = lane within the group)
+__device__ __forceinline__ float bt_max8_all(float v, int k)
+{
+    v = fmaxf(v, bt_xor1(v));
+    v = fmaxf(v, bt_xor2(v));
+    const float up = bt_up4(v), down = bt_down4(v);
+    return fmaxf(v, k < 4 ? up : down);
+}
 __device__ __forceinline__ int bt_round(float v)   // floor(v + 0.5) in one instruction
 {
     int r;
@@ -362,9 +374,16 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
             wh = H;
         }
         float scale = 0.f, inv_scale = 0.f;
+        // A row whose own bound max_c|g| * sum_p|aw| lies more than 2^-20 below the item's accumulator bound would have
+        // its contributions rounded at a quantum (2^-30 of the bound) that is coarse for THEM: one outlier query, or a
+        // heavy-tailed loss scale, must not cost the small gradients their bits.  Such rows take the fp32
+        // path (direct atomics), like samples outside the window.  Rows above the threshold keep a relative rounding
+        // error <= 2^-11 per add before the exact integer accumulation; typical gradients are nowhere near it.
+        float small_row = 0.f;
         bool use_window = false;
         if (mode != kBtDirect && n > 0) {
             const float bound = (float)n * __uint_as_float(p.row_bound[((int64_t)l * p.B + b) * p.M + m]);
+            small_row = bound * 0x1p-20f;
             if (bound > 0x1p-90f && bound < 0x1p+90f) {
                 const int x = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
                 scale = __uint_as_float((uint32_t)(29 - x + 127) << 23);
@@ -418,6 +437,10 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
             }
             const float lx_[4] = {l01.x, l01.z, l23.x, l23.z}, ly_[4] = {l01.y, l01.w, l23.y, l23.w};
             const float aw_[4] = {a4.x, a4.y, a4.z, a4.w};
+            // this row's own bound (all eight lanes of the row agree on it)
+            const float row_mag = bt_max8_all(fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))), k) *
+                                  ((fabsf(a4.x) + fabsf(a4.y)) + (fabsf(a4.z) + fabsf(a4.w)));
+            const bool row_in_window = use_window && !(row_mag < small_row);   // (a NaN stays with the window's NaN handling)
 
             // ---- software pipeline over the row's four samples: [set-up + corner loads of s+1] [scatter of s]
             // [dots of s].  The three stages load three different units (vector memory, LDS atomics, vector ALU); run
@@ -432,7 +455,7 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
             const bt_f32x2_t gs01 = {gs[0], gs[1]}, gs23 = {gs[2], gs[3]};
             auto stage_a = [&](int s) {
                 int x0, y0;
-                sm[s] = bt_setup(lx_[s], ly_[s], aw_[s], H, W, fH, fW, lstart, ox, oy, ww, wh, use_window, x0, y0);
+                sm[s] = bt_setup(lx_[s], ly_[s], aw_[s], H, W, fH, fW, lstart, ox, oy, ww, wh, row_in_window, x0, y0);
                 const uint32_t f = sm[s].flags;
                 const uint32_t o00 = (uint32_t)sm[s].pix * pix_bytes + 16u * k;
                 v[s][0] = as_f4(buffer_load16(vrsrc, (f & 1u) ? o00 : 0xffffffffu));

@@ -257,8 +257,11 @@ def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tens
     if not resident_supported(value_hm, level_shapes, 4, 4):
         raise RuntimeError("msda_resident_forward: fp16 [B,M,Nv,32] maps of a 4-level pyramid whose two coarse levels "
                            "fit in LDS expected")
-    if proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or proj_hm.dtype != torch.bfloat16:
+    if (proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or proj_hm.dtype != torch.bfloat16
+            or not proj_hm.is_contiguous()):
         raise RuntimeError("msda_resident_forward: proj must be a contiguous bf16 [B, M, Nq, 48] tensor")
+    if not value_hm.is_contiguous():   # the kernel addresses dense [B,M,Nv,32] maps
+        raise RuntimeError("msda_resident_forward: value_hm must be contiguous [B, M, Nv, 32]")
     Nq = proj_hm.shape[2]
     if not reference_points.is_cuda:
         raise RuntimeError("msda_resident_forward: reference_points must be a HIP (cuda) tensor; no CPU fallback")

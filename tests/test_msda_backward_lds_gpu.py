@@ -93,3 +93,31 @@ def test_lds_backward_extreme_gradients():
             assert not gv.any()
         else:
             assert np.abs(gv / factor - base).max() < 2e-4 * max(1.0, np.abs(base).max())
+
+
+def test_lds_backward_heavy_tailed_gradients_keep_the_small_ones():
+    """the window's fixed-point quantum follows the LARGEST row bound of a (level, image, head).  One
+    outlier query (here 2^28 times the others) must not round everybody else's contributions away: rows far below the
+    bound take the fp32 path.  Checked on pixels the outlier's samples do not touch, against the C oracle."""
+    B, Nq, M_ = 1, 600, 8
+    value, shapes, lsi, loc, aw = syn.make_msda_inputs(B, Nq, LEVELS_SMALL, M_, 32, 4, seed=11, spread_px=2.0)
+    go = syn.det_randn("gout_tail", (B, Nq, M_ * 32))
+    base = msda_c.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), go.numpy())[0]
+    go_tail = go.clone()
+    go_tail[0, 17] *= 2.0 ** 28
+    only = torch.zeros_like(go)
+    only[0, 17] = go_tail[0, 17]
+    spike = msda_c.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), only.numpy())[0]
+    untouched = spike == 0            # grad_value entries that receive nothing from the outlier row
+    assert untouched.mean() > 0.5
+    dev = [t.to(DEV) for t in (value, shapes, lsi, loc, aw, go_tail)]
+    (gv, _, _), which = _run(True, *dev)
+    assert which == M.KERNEL_BWD_LDS
+    # without query 17 the oracle's sum on those entries is the sum of the ordinary rows (query 17 adds exact zeros)
+    rest = go.clone()
+    rest[0, 17] = 0
+    want = msda_c.msda_backward(value.numpy(), shapes.numpy(), lsi.numpy(), loc.numpy(), aw.numpy(), rest.numpy())[0]
+    err = np.abs(gv - want)[untouched].max()
+    assert err < 2e-4 * max(1.0, np.abs(base).max()), err
+    # and the spike itself arrives
+    assert np.abs(gv - (want + spike))[~untouched].max() < 1e-5 * np.abs(spike).max()
