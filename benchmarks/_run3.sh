@@ -1,9 +1,16 @@
-mkdir -p gpurun_out/r3g; O=gpurun_out/r3g
-python bench.py --mode train --steps 5 --warmup 2 > $O/train_n1.json 2> $O/train_n1.err; tail -c 700 $O/train_n1.json; echo
-python bench.py --mode train --steps 5 --warmup 2 --force-dist-path > $O/train_ranks_path.json 2> $O/train_ranks_path.err; tail -c 600 $O/train_ranks_path.json; echo; tail -3 $O/train_ranks_path.err
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --mode train --steps 5 --warmup 2 --force-dist-path > $O/train_rccl1.json 2> $O/train_rccl1.err; tail -c 600 $O/train_rccl1.json; echo; tail -3 $O/train_rccl1.err
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+mkdir -p gpurun_out/r3h; O=gpurun_out/r3h
+python -m pytest tests/test_filter_ops_gpu.py -x -q -k "attn_tail or ffn" 2>&1 | tail -6
+python -m pytest tests/test_hotpath_gpu.py tests/test_encoder_timed_mode_gpu.py tests/test_msda_backward_lds_gpu.py -x -q 2>&1 | tail -4
+python bench.py --steps 30 --warmup 5 --in-flight-report 0 --train-steps 0 > $O/bench.json 2> $O/bench.err
 python -c "
-import json
-d=json.load(open('$O/bench.json')); print(d['value'], d['ms_per_step'], d.get('train_step'))
+import json,sys
+d=json.load(open('$O/bench.json')); r=d['roofline']
+print(d['value'], d['ms_per_step'], r['frac'], r['frac_warm'], r['per_layer_us'])
+print(d['ms_per_encoder_layer'])
+print(d.get('parity_vs_cpu'))
 "
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python bench.py --plain --steps 20 > $O/bench_profiled.json 2> $O/prof.err
+python benchmarks/step_timeline.py $(find $O/prof -name '*kernel_trace.csv' | head -1) > $O/step_timeline.txt
+rm -rf $O/prof
+grep -i "ffn\|advance" $O/step_timeline.txt | head -20; tail -1 $O/step_timeline.txt

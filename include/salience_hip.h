@@ -654,6 +654,26 @@ int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_
                       int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
                       int reduction_splits, float *a_row_sum);
 
+/* The END of an encoder layer in one operator (csrc/ffn.hip, ffn_fused_kernel<true>): the deformable attention's tail
+ *     x = norm1(residual + output_proj(sampled))              models/bricks/salience_transformer.py:390-391,
+ *                                                              models/bricks/ms_deform_attn.py:375
+ * runs in front of the feed-forward inside the SAME launch -- Wo streams through the feed-forward's weight ring as
+ * four extra chunks, x goes from the accumulators into the B-operand registers of the first feed-forward product and
+ * never reaches memory -- followed by sdetr_ffn_fused_advance_bf16's feed-forward, second LayerNorm and row
+ * bookkeeping.  sampled / residual: [batch, rows, 256] bf16 contiguous (the MSDA kernel's output, the layer's queries).
+ *   packed_tail_ffn: sdetr_attn_tail_packed_bytes() bytes written by sdetr_attn_tail_pack_bf16(output_proj.weight
+ *   [256, 256] bf16) immediately followed by the sdetr_ffn_pack_bf16 packing of the two feed-forward weights.
+ * All other arguments as sdetr_ffn_fused_advance_bf16 (the workspace has its size). */
+int64_t sdetr_attn_tail_packed_bytes(void);
+int sdetr_attn_tail_pack_bf16(sdetr_stream_t stream, const void *weight_o, int embed_dim, void *packed);
+int sdetr_attn_tail_ffn_advance_bf16(
+    sdetr_stream_t stream, const void *sampled, const void *residual, const void *packed_tail_ffn, const float *bias_o,
+    const float *norm1_weight, const float *norm1_bias, float norm1_eps, const float *bias1, const float *bias2,
+    const float *norm_weight, const float *norm_bias, float norm_eps, int batch_size, int rows, int embed_dim, int hidden,
+    int hidden_splits, void *workspace, int64_t workspace_bytes, void *sorted_result, void *next_query, const void *tokens,
+    const int64_t *sorted_index, int64_t index_batch_stride, const int64_t *count, int sorted_rows, int next_rows,
+    int spatial_size);
+
 /* sdetr_topk_attention_bf16 of an encoder layer together with the deformable attention's offset | weight projection of
  * the layer's queries (sdetr_token_linear_bf16 with x_add = pos and group_features = 48: the head-major slab
  * [batch, 8, num_rows, 48] the MSDA kernel reads) -- csrc/fused_head_value.hip: in-projection launch, then ONE launch

@@ -61,7 +61,16 @@ struct FfnArgs {
     int T, nchunk;
     int nsplit;             // hidden-dimension pieces per token block (1: the block finishes its tokens itself)
     float *partial;         // nsplit > 1: [nsplit, T, 256] fp32 partial products, finished by ffn_reduce_ln_kernel
+    // TAIL form (ffn_fused_kernel<true>): the deformable attention's tail runs in front of the feed-forward,
+    //     x = LayerNorm1(res + Wo s + bo)        (salience_transformer.py:390-391, ms_deform_attn.py:375)
+    // `pw` then starts with kTailChunks chunks of Wo fragments, `x` is not read.
+    const bf16_t *s;        // [T, 256] sampled heads (the MSDA kernel's output)
+    const bf16_t *res;      // [T, 256] the layer's queries (residual)
+    const float *bo, *g1, *be1;   // [256] output_proj bias, norm1 weight / bias
+    float eps1;
 };
+
+constexpr int kTailChunks = 4;   // Wo [256 x 256] as 128 1-KB A-fragments: chunk a = k-steps 4a .. 4a+3 of all 8 output tiles
 
 __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c)
 {
@@ -98,19 +107,26 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v)
 // allocation, so the kernel has to fit 256 registers for two waves per SIMD.)
 constexpr int kFThreads = 512;
 
+// TAIL: the layer's attention tail (output_proj + residual + norm1) in front, see FfnArgs.  The weight STREAM of a
+// block is then [tail chunks 0..3][its piece of the hidden dimension]: stream chunk c lives in LDS buffer c & 3 and the
+// loaders / barriers below count stream chunks; the feed-forward part addresses its chunk j as stream chunk NT + j.
+template <bool TAIL>
 __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *wbuf = lds;                                                  // 4 chunk buffers
     float *b1s = reinterpret_cast<float *>(lds + 4 * kFChunkBytes);    // [F]
-    float *par = b1s + p.nchunk * kFChunk;                             // b2 | gamma | beta
+    float *par = b1s + p.nchunk * kFChunk;                             // b2 | gamma | beta (| bo | gamma1 | beta1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // hidden split: block = (token block, piece); piece sp walks chunks [c0, c0 + nloc) of the hidden dimension
     const int tblock = blockIdx.x / p.nsplit, sp = blockIdx.x - tblock * p.nsplit;
     const int c0 = (int)((int64_t)sp * p.nchunk / p.nsplit);
     const int nloc = (int)((int64_t)(sp + 1) * p.nchunk / p.nsplit) - c0;
-    const char *pw = p.pw + (int64_t)c0 * kFChunkBytes;
-    auto chunk_at = [&](int jt) { return jt; };
+    constexpr int NT = TAIL ? kTailChunks : 0;
+    const int nl = nloc + NT;                                          // chunks in this block's stream
+    const char *pw = p.pw;
+    // stream chunk -> chunk of the packed buffer
+    auto chunk_at = [&](int c) { return TAIL ? (c < NT ? c : NT + c0 + (c - NT)) : c0 + c; };
 
     if (wave >= 4) {
         // ---- loader wave: a quarter (8 KB) of every 32 KB chunk, global -> registers -> LDS, FOUR chunk buffers ----
@@ -147,21 +163,21 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
         uint4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rd0, rd1, rd2, rd3, rd4, rd5, rd6, rd7;
         // prologue: chunks 0..2 into LDS, chunks 3..6 on their way
         SDETR_FETCH8(ra, 0);
-        SDETR_FETCH8(rb, nloc > 1 ? 1 : 0);
-        SDETR_FETCH8(rc, nloc > 2 ? 2 : 0);
-        SDETR_FETCH8(rd, nloc > 3 ? 3 : 0);
+        SDETR_FETCH8(rb, nl > 1 ? 1 : 0);
+        SDETR_FETCH8(rc, nl > 2 ? 2 : 0);
+        SDETR_FETCH8(rd, nl > 3 ? 3 : 0);
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         SDETR_STASH8(ra, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SDETR_FETCH8(ra, nloc > 4 ? 4 : 0);
+        SDETR_FETCH8(ra, nl > 4 ? 4 : 0);
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        if (nloc > 1) SDETR_STASH8(rb, 1);
+        if (nl > 1) SDETR_STASH8(rb, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SDETR_FETCH8(rb, nloc > 5 ? 5 : 0);
+        SDETR_FETCH8(rb, nl > 5 ? 5 : 0);
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        if (nloc > 2) SDETR_STASH8(rc, 2);
+        if (nl > 2) SDETR_STASH8(rc, 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SDETR_FETCH8(rc, nloc > 6 ? 6 : 0);
+        SDETR_FETCH8(rc, nl > 6 ? 6 : 0);
         __builtin_amdgcn_s_barrier();
         // iteration j: past its barrier every compute wave is done with chunk j-1, whose buffer takes chunk j+3; the
         // register set that held it goes back to L2 for chunk j+7 (the tail re-requests chunk 0: every phase issues
@@ -170,17 +186,17 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     {                                                                                                             \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                                         \
-        if ((j) + 3 < nloc) SDETR_STASH8(P, (j) + 3);                                                             \
+        if ((j) + 3 < nl) SDETR_STASH8(P, (j) + 3);                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-        SDETR_FETCH8(P, (j) + 7 < nloc ? (j) + 7 : 0);                                                            \
+        SDETR_FETCH8(P, (j) + 7 < nl ? (j) + 7 : 0);                                                            \
     }
-        for (int jt = 0; jt + 1 < nloc; jt += 4) {
+        for (int jt = 0; jt + 1 < nl; jt += 4) {
             SDETR_PHASE(rd, jt);
-            if (jt + 2 >= nloc) break;
+            if (jt + 2 >= nl) break;
             SDETR_PHASE(ra, jt + 1);
-            if (jt + 3 >= nloc) break;
+            if (jt + 3 >= nl) break;
             SDETR_PHASE(rb, jt + 2);
-            if (jt + 4 >= nloc) break;
+            if (jt + 4 >= nl) break;
             SDETR_PHASE(rc, jt + 3);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the dummy requests of the tail)
@@ -200,10 +216,18 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     par[tid] = p.b2[tid];
     par[kFE + tid] = p.gamma[tid];
     par[2 * kFE + tid] = p.beta[tid];
+    if (TAIL) {
+        par[3 * kFE + tid] = p.bo[tid];
+        par[4 * kFE + tid] = p.g1[tid];
+        par[5 * kFE + tid] = p.be1[tid];
+    }
 
-    uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
+    uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token (TAIL: first S^T)
+    {
+        const bf16_t *xin = TAIL ? p.s : p.x;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const uint4 *>(p.x + row + 16 * ks + 8 * h);
+        for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const uint4 *>(xin + row + 16 * ks + 8 * h);
+    }
     // Consume the loads HERE: hipcc places the wait for a pending load at its first use, which would be inside the
     // main loop -- a vmcnt(0) there every iteration also drains the LDS copies it cannot see.
 #pragma unroll
@@ -212,16 +236,135 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the staged vectors; the loaders bring chunks 0..2
     __builtin_amdgcn_s_barrier();
 
-    // the output accumulator STARTS as b2 (a piece of a split hidden dimension starts at zero: its second pass adds it)
-    f32x16_t yacc[8];
+    constexpr int R = 4;
+    uint4 ring[R];
+    const lds_cptr_t lbase = (lds_cptr_t)wbuf + lane * 16;
+    auto chunk_lds = [&](int c) { return lbase + (c & 3) * kFChunkBytes; };   // c = STREAM chunk
+    // x <-> the form in which lane (t, h) holds the channels of ITS accumulator quads: upper dwords of row 0 <-> lower
+    // dwords of row 1 (v_permlane32_swap); afterwards (x, y) of piece ks are quad g = 2 (ks & 1) of e-tile ks >> 1 and
+    // (z, w) quad g + 1.  The exchange is its own inverse.
+    auto swap_halves = [&]() {
 #pragma unroll
-    for (int et = 0; et < 8; ++et)
+        for (int ks = 0; ks < 16; ++ks) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(xb[ks].x, xb[ks].z, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(xb[ks].y, xb[ks].w, false, false);
+            xb[ks] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    };
+    auto residual = [&](int et, int g, float (&r)[4]) {   // (after swap_halves)
+        const uint4 q = xb[2 * et + (g >> 1)];
+        const uint32_t d0 = (g & 1) ? q.z : q.x, d1 = (g & 1) ? q.w : q.y;
+        r[0] = bf16_lo(d0); r[1] = bf16_hi(d0); r[2] = bf16_lo(d1); r[3] = bf16_hi(d1);
+    };
+
+    f32x16_t yacc[8];
+    if (TAIL) {
+        // ---- Z^T = Wo S^T + bo in the output accumulators: chunk a holds k-steps 4a .. 4a+3 of the 8 output tiles
+        // (fragment f = 8 (k-step) + tile: eight independent accumulator chains).  Once a chunk's MFMAs are issued its
+        // four k-steps of S^T are dead and the registers take the RESIDUAL rows -- their trip to memory runs under the
+        // rest of the product. ----
+#pragma unroll
+        for (int et = 0; et < 8; ++et)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(par + 3 * kFE + 32 * et + 8 * g + 4 * h);
+                yacc[et][4 * g] = bv.x; yacc[et][4 * g + 1] = bv.y; yacc[et][4 * g + 2] = bv.z; yacc[et][4 * g + 3] = bv.w;
+            }
+#pragma unroll
+        for (int a = 0; a < kTailChunks; ++a) {
+            if (a > 0) __builtin_amdgcn_s_barrier();   // stream chunk a is in LDS; the loaders learn that a - 1 is done with
+            const lds_cptr_t ca = chunk_lds(a);
+#pragma unroll
+            for (int f = 0; f < R; ++f) ring[f] = lds_read16(ca + f * 1024);
+#pragma unroll
+            for (int f = 0; f < 32; ++f) {
+                yacc[f & 7] = mfma_bf16(ring[f % R], xb[4 * a + (f >> 3)], yacc[f & 7]);
+                if (f + R < 32) ring[f % R] = lds_read16(ca + (f + R) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xb[4 * a + q] = *reinterpret_cast<const uint4 *>(p.res + row + 16 * (4 * a + q) + 8 * h);
+        }
+        __builtin_amdgcn_s_barrier();   // done with the tail chunks (the feed-forward's first chunks are in LDS)
+        // ---- x = LayerNorm1(z + res), two passes over read-only accumulators as in the epilogue below ----
+        swap_halves();
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int et = 0; et < 8; ++et) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float r[4];
+                residual(et, g, r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = yacc[et][4 * g + i] + r[i];
+                    sum += v;
+                    sq = fmaf(v, v, sq);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sum += __shfl_xor(sum, 32);
+        sq += __shfl_xor(sq, 32);
+        const float mean = sum * (1.f / kFE);
+        const float rstd = rsqrtf(fmaxf(sq * (1.f / kFE) - mean * mean, 0.f) + p.eps1);
+        const float shift = -mean * rstd;
+        // (the residual pieces are made opaque between the passes: otherwise the compiler keeps pass 1's 128 unpacked
+        // residual values alive across the reduction instead of unpacking again -- 300 spilled registers)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int et = ks >> 1, g0 = 2 * (ks & 1);
+            uint32_t d[4];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = g0 + gg, e0 = 32 * et + 8 * g + 4 * h;
+                const float4 gv = *reinterpret_cast<const float4 *>(par + 4 * kFE + e0);
+                const float4 be = *reinterpret_cast<const float4 *>(par + 5 * kFE + e0);
+                float r[4];
+                residual(et, g, r);
+                const float x0 = fmaf(fmaf(yacc[et][4 * g] + r[0], rstd, shift), gv.x, be.x);
+                const float x1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
+                const float x2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
+                const float x3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
+                d[2 * gg] = pack_bf16x2(x0, x1);
+                d[2 * gg + 1] = pack_bf16x2(x2, x3);
+            }
+            xb[ks] = make_uint4(d[0], d[1], d[2], d[3]);   // x (bf16) in the accumulator-quad form
+            // (pinned here: the code-sinking pass otherwise moves this arithmetic down to the first reader of x, past
+            // the scheduling fence, and the gamma / beta reads above -- which cannot follow -- stay alive and spill)
+            asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the output accumulator STARTS as b2 (a piece of a split hidden dimension starts at zero: its second pass adds b2
+    // and the residual -- except in the TAIL form, where the residual x exists nowhere but here: piece 0 starts at
+    // b2 + x and the second pass only sums)
+#pragma unroll
+    for (int et = 0; et < 8; ++et) {
+        f32x16_t start;   // (a fresh tuple: element writes into the old one would tie the new value to z's registers)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 bv = *reinterpret_cast<const float4 *>(par + 32 * et + 8 * g + 4 * h);
-            if (p.nsplit > 1) bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            yacc[et][4 * g] = bv.x; yacc[et][4 * g + 1] = bv.y; yacc[et][4 * g + 2] = bv.z; yacc[et][4 * g + 3] = bv.w;
+            if (p.nsplit > 1) {
+                if (TAIL && sp == 0) {
+                    float r[4];
+                    residual(et, g, r);
+                    bv = make_float4(bv.x + r[0], bv.y + r[1], bv.z + r[2], bv.w + r[3]);
+                } else {
+                    bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            start[4 * g] = bv.x; start[4 * g + 1] = bv.y; start[4 * g + 2] = bv.z; start[4 * g + 3] = bv.w;
         }
+        yacc[et] = start;
+    }
+    if (TAIL) {
+        __builtin_amdgcn_sched_barrier(0);
+        swap_halves();   // x^T as B operands
+    }
 
     // SOFTWARE PIPELINE over the chunks.  A chunk is two dependent products (H = relu(W1 X + b1), Y += W2 H).  The first
     // is a chain of 16 MFMAs into ONE accumulator and the second pairs its MFMAs on each of 8 accumulators: issued
@@ -237,10 +380,6 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     // slot s of an iteration (even: W1[jt+1] k-step s/2, odd: W2[jt] fragment of (k-block, e-tile) = (s>>4, (s>>1)&7))
     // is requested 4 MFMAs before its use and the slot is refilled right AFTER the MFMA that consumed it; the last four
     // requests fetch the head of the next iteration's stream.
-    constexpr int R = 4;
-    uint4 ring[R];
-    const lds_cptr_t lbase = (lds_cptr_t)wbuf + lane * 16;
-    auto chunk_lds = [&](int c) { return lbase + (c & 3) * kFChunkBytes; };
     const lds_cptr_t bias_base = (lds_cptr_t)(const char *)b1s + 16 * h;
     f32x16_t hacc;
     auto load_bias = [&](int chunk) {
@@ -275,10 +414,10 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
 
     // ---- prologue: first product + conversion of chunk 0 (a bare dependent chain, once per piece) ----
 #pragma unroll
-    for (int f = 0; f < R; ++f) ring[f] = lds_read16(chunk_lds(0) + f * 1024);
-    load_bias(c0 + chunk_at(0));
+    for (int f = 0; f < R; ++f) ring[f] = lds_read16(chunk_lds(NT) + f * 1024);
+    load_bias(c0);
     {
-        const lds_cptr_t a0 = chunk_lds(0), a1 = chunk_lds(1);
+        const lds_cptr_t a0 = chunk_lds(NT), a1 = chunk_lds(NT + 1);
         const bool more = nloc > 1;   // then the interleaved stream follows: W1[1] k-step, W2[0] fragment, ...
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
@@ -293,13 +432,13 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    convert(c0 + chunk_at(nloc > 1 ? 1 : 0));
+    convert(c0 + (nloc > 1 ? 1 : 0));
 
     for (int jt = 0; jt + 1 < nloc; ++jt) {
         // chunks jt+1 and jt+2 are in LDS (the head of jt+2 feeds the ring at the end of this iteration); the loaders
         // learn that chunk jt-1 is done with
         __builtin_amdgcn_s_barrier();
-        const lds_cptr_t ca = chunk_lds(jt + 1), cb = chunk_lds(jt), cn = chunk_lds(jt + 2);
+        const lds_cptr_t ca = chunk_lds(NT + jt + 1), cb = chunk_lds(NT + jt), cn = chunk_lds(NT + jt + 2);
         const bool more = jt + 2 < nloc;   // is the next iteration interleaved as well (or the bare tail)?
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
@@ -318,11 +457,11 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        convert(c0 + chunk_at(more ? jt + 2 : jt + 1));
+        convert(c0 + (more ? jt + 2 : jt + 1));
     }
     // ---- tail: second product of the last chunk ----
     {
-        const lds_cptr_t cb = chunk_lds(nloc - 1);
+        const lds_cptr_t cb = chunk_lds(NT + nloc - 1);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             yacc[q & 7] = mfma_bf16(ring[q % R], hp[q >> 3], yacc[q & 7]);
@@ -353,19 +492,7 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     // The accumulators are only READ from here on (writing elements of a 16-register tuple makes the allocator copy
     // tuples, and with 128 + 64 registers live that spilled: the epilogue ran 13 us): pass 1 sums v = y + x and v^2,
     // pass 2 recomputes v and writes (v - mean) * rstd * gamma + beta.
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        // upper dwords of row 0 <-> lower dwords of row 1: afterwards (x, y) are the residual of quad g = 2 (ks & 1) of
-        // e-tile ks >> 1 and (z, w) that of quad g + 1
-        const auto s0 = __builtin_amdgcn_permlane32_swap(xb[ks].x, xb[ks].z, false, false);
-        const auto s1 = __builtin_amdgcn_permlane32_swap(xb[ks].y, xb[ks].w, false, false);
-        xb[ks] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-    }
-    auto residual = [&](int et, int g, float (&r)[4]) {
-        const uint4 q = xb[2 * et + (g >> 1)];
-        const uint32_t d0 = (g & 1) ? q.z : q.x, d1 = (g & 1) ? q.w : q.y;
-        r[0] = bf16_lo(d0); r[1] = bf16_hi(d0); r[2] = bf16_lo(d1); r[3] = bf16_hi(d1);
-    };
+    swap_halves();
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int et = 0; et < 8; ++et) {
@@ -421,9 +548,12 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_kernel(const float *partial
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= T) return;
     const int64_t o = (int64_t)tok * kFE + 4 * lane;
-    const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
-    const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
-    float v0 = bv.x + bf16_lo(r.x), v1 = bv.y + bf16_hi(r.x), v2 = bv.z + bf16_lo(r.y), v3 = bv.w + bf16_hi(r.y);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (x) {   // (NULL: piece 0 of the partial products already carries bias + residual -- the TAIL form)
+        const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
+        const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
+        v0 = bv.x + bf16_lo(r.x); v1 = bv.y + bf16_hi(r.x); v2 = bv.z + bf16_lo(r.y); v3 = bv.w + bf16_hi(r.y);
+    }
     for (int s = 0; s < nsplit; ++s) {
         const float4 pv = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
         v0 += pv.x; v1 += pv.y; v2 += pv.z; v3 += pv.w;
@@ -475,9 +605,12 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float 
         return;
     }
     const int64_t o = (int64_t)tok * kFE + 4 * lane;
-    const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
-    const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
-    float v0 = bv.x + bf16_lo(r.x), v1 = bv.y + bf16_hi(r.x), v2 = bv.z + bf16_lo(r.y), v3 = bv.w + bf16_hi(r.y);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (x) {   // (NULL: piece 0 of the partial products already carries bias + residual -- the TAIL form)
+        const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
+        const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
+        v0 = bv.x + bf16_lo(r.x); v1 = bv.y + bf16_hi(r.x); v2 = bv.z + bf16_lo(r.y); v3 = bv.w + bf16_hi(r.y);
+    }
     for (int s = 0; s < nsplit; ++s) {
         const float4 pv = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
         v0 += pv.x; v1 += pv.y; v2 += pv.z; v3 += pv.w;
@@ -519,9 +652,32 @@ __global__ void ffn_pack_kernel(const bf16_t *w1, const bf16_t *w2, int F, bf16_
     }
 }
 
+// Wo [256 out, 256 in] -> kTailChunks chunks of 32 A-fragments: chunk a, fragment f = 8 ksl + et holds
+// A[m = 32 et + (lane & 31)][k = 16 (4 a + ksl) + 8 (lane >> 5) .. +7] as 16 bytes per lane.
+__global__ void attn_tail_pack_kernel(const bf16_t *wo, bf16_t *out)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;   // over 4 * 16384 elements
+    if (o >= kTailChunks * 16384) return;
+    const int a = o / 16384, idx = o % 16384;
+    const int s = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
+    const int ksl = f >> 3, et = f & 7;
+    out[o] = wo[(int64_t)(32 * et + (l & 31)) * kFE + 16 * (4 * a + ksl) + 8 * (l >> 5) + s];
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
+
+extern "C" int64_t sdetr_attn_tail_packed_bytes(void) { return (int64_t)kTailChunks * kFChunkBytes; }
+
+extern "C" int sdetr_attn_tail_pack_bf16(sdetr_stream_t stream, const void *weight_o, int embed_dim, void *packed)
+{
+    if (embed_dim != kFE) return fail("attn_tail_pack: built for embed_dim %d (got %d)", kFE, embed_dim);
+    if (!weight_o || !packed) return fail("attn_tail_pack: null pointer");
+    hipLaunchKernelGGL(attn_tail_pack_kernel, dim3((kTailChunks * 16384 + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), (const bf16_t *)weight_o, (bf16_t *)packed);
+    return check_launch("attn_tail_pack");
+}
 
 extern "C" int64_t sdetr_ffn_packed_bytes(int hidden) { return hidden > 0 ? (int64_t)(hidden / kFChunk) * kFChunkBytes : 0; }
 
@@ -593,13 +749,13 @@ extern "C" int sdetr_ffn_fused_bf16(sdetr_stream_t stream, const void *x, const 
     const size_t lds = 4 * (size_t)kFChunkBytes + (size_t)hidden * 4 + 3 * kFE * 4;
     if (lds > 160 * 1024) return fail("ffn_fused: hidden %d needs %zu bytes of LDS", hidden, lds);
     static DeviceOnce lds_once1;
-    allow_dynamic_lds(ffn_fused_kernel, lds_once1, 160 * 1024);
+    allow_dynamic_lds(ffn_fused_kernel<false>, lds_once1, 160 * 1024);
     FfnArgs a;
     a.x = (const bf16_t *)x; a.pw = (const char *)packed_weights; a.b1 = bias1; a.b2 = bias2; a.gamma = norm_weight;
     a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out; a.T = tokens; a.nchunk = hidden / kFChunk;
     a.nsplit = hidden_splits; a.partial = hidden_splits > 1 ? (float *)workspace : nullptr;
     const int64_t tblocks = (tokens + kFTokBlock - 1) / kFTokBlock;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds,
+    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds,
                        static_cast<hipStream_t>(stream), a);
     if (hidden_splits > 1)
         hipLaunchKernelGGL(ffn_reduce_ln_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0,
@@ -613,15 +769,20 @@ extern "C" int sdetr_advance_rows(sdetr_stream_t stream, const void *layer_out, 
                                   const int64_t *count, int batch_size, int rows, int sorted_rows, int next_rows,
                                   int spatial_size, int row_bytes);
 
-extern "C" int sdetr_ffn_fused_advance_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights,
-                                            const float *bias1, const float *bias2, const float *norm_weight,
-                                            const float *norm_bias, float norm_eps, int batch_size, int rows,
-                                            int embed_dim, int hidden, int hidden_splits, void *workspace,
-                                            int64_t workspace_bytes, void *sorted_result, void *next_query,
-                                            const void *tokens, const int64_t *sorted_index,
-                                            int64_t index_batch_stride, const int64_t *count, int sorted_rows,
-                                            int next_rows, int spatial_size)
+struct TailArgs {   // the attention tail in front of the feed-forward (NULL sampled = plain feed-forward)
+    const void *sampled, *residual;
+    const float *bias_o, *norm1_weight, *norm1_bias;
+    float norm1_eps;
+};
+
+static int ffn_advance_impl(sdetr_stream_t stream, const void *x, const TailArgs &tail, const void *packed_weights,
+                            const float *bias1, const float *bias2, const float *norm_weight, const float *norm_bias,
+                            float norm_eps, int batch_size, int rows, int embed_dim, int hidden, int hidden_splits,
+                            void *workspace, int64_t workspace_bytes, void *sorted_result, void *next_query,
+                            const void *tokens, const int64_t *sorted_index, int64_t index_batch_stride,
+                            const int64_t *count, int sorted_rows, int next_rows, int spatial_size)
 {
+    const bool with_tail = tail.sampled != nullptr;
     if (batch_size < 0 || rows < 0) return fail("ffn_fused_advance: negative size");
     if (next_rows < 0 || next_rows > rows || rows > sorted_rows)
         return fail("ffn_fused_advance: need next_rows <= rows <= sorted_rows");
@@ -631,13 +792,15 @@ extern "C" int sdetr_ffn_fused_advance_bf16(sdetr_stream_t stream, const void *x
     if (!sorted_result || !tokens || !sorted_index || (next_rows > 0 && !next_query))
         return fail("ffn_fused_advance: null pointer");
     if (index_batch_stride < rows) return fail("ffn_fused_advance: index batch stride too small");
+    if (with_tail && (!tail.residual || !tail.bias_o || !tail.norm1_weight || !tail.norm1_bias))
+        return fail("attn_tail_ffn_advance: null pointer");
     // the layer output itself: the head of the workspace (after the split partials), never seen by the caller
     const int64_t partial_bytes = sdetr_ffn_workspace_bytes(tokens_total, hidden_splits);
     const int64_t out_bytes = hidden_splits > 1 ? 0 : (int64_t)tokens_total * kFE * 2;
     if (workspace_bytes < partial_bytes + out_bytes || (partial_bytes + out_bytes > 0 && !workspace))
         return fail("ffn_fused_advance: workspace of %lld bytes needed", (long long)(partial_bytes + out_bytes));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hidden_splits == 1) {
+    if (hidden_splits == 1 && !with_tail) {
         void *out = static_cast<char *>(workspace) + partial_bytes;
         if (int rc = sdetr_ffn_fused_bf16(stream, x, packed_weights, bias1, bias2, norm_weight, norm_bias, norm_eps,
                                           tokens_total, embed_dim, hidden, out, 1, nullptr, 0))
@@ -648,24 +811,68 @@ extern "C" int sdetr_ffn_fused_advance_bf16(sdetr_stream_t stream, const void *x
     if (embed_dim != kFE) return fail("ffn_fused: built for embed_dim %d (got %d)", kFE, embed_dim);
     if (hidden <= 0 || hidden % kFChunk) return fail("ffn_fused: hidden (%d) must be a positive multiple of %d", hidden, kFChunk);
     if (hidden_splits < 1 || hidden_splits > hidden / kFChunk) return fail("ffn_fused: hidden_splits must be in 1 .. hidden/32");
-    if (!x || !packed_weights || !bias1 || !bias2 || !norm_weight || !norm_bias) return fail("ffn_fused: null pointer");
-    const size_t lds = 4 * (size_t)kFChunkBytes + (size_t)hidden * 4 + 3 * kFE * 4;
+    if ((!with_tail && !x) || !packed_weights || !bias1 || !bias2 || !norm_weight || !norm_bias) return fail("ffn_fused: null pointer");
+    const size_t lds = 4 * (size_t)kFChunkBytes + (size_t)hidden * 4 + (with_tail ? 6 : 3) * kFE * 4;
     if (lds > 160 * 1024) return fail("ffn_fused: hidden %d needs %zu bytes of LDS", hidden, lds);
-    static DeviceOnce lds_once2;
-    allow_dynamic_lds(ffn_fused_kernel, lds_once2, 160 * 1024);
-    FfnArgs a;
+    FfnArgs a{};
     a.x = (const bf16_t *)x; a.pw = (const char *)packed_weights; a.b1 = bias1; a.b2 = bias2; a.gamma = norm_weight;
     a.beta = norm_bias; a.eps = norm_eps; a.out = nullptr; a.T = tokens_total; a.nchunk = hidden / kFChunk;
-    a.nsplit = hidden_splits; a.partial = (float *)workspace;
+    a.nsplit = hidden_splits; a.partial = hidden_splits > 1 ? (float *)workspace : nullptr;
+    a.s = (const bf16_t *)tail.sampled; a.res = (const bf16_t *)tail.residual; a.bo = tail.bias_o;
+    a.g1 = tail.norm1_weight; a.be1 = tail.norm1_bias; a.eps1 = tail.norm1_eps;
     const int64_t tblocks = (tokens_total + kFTokBlock - 1) / kFTokBlock;
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds, s, a);
+    if (hidden_splits == 1) a.out = reinterpret_cast<bf16_t *>(static_cast<char *>(workspace) + partial_bytes);
+    if (with_tail) {
+        static DeviceOnce lds_once3;
+        allow_dynamic_lds(ffn_fused_kernel<true>, lds_once3, 160 * 1024);
+        hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds, s, a);
+    } else {
+        static DeviceOnce lds_once2;
+        allow_dynamic_lds(ffn_fused_kernel<false>, lds_once2, 160 * 1024);
+        hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)(tblocks * hidden_splits)), dim3(kFThreads), lds, s, a);
+    }
+    if (hidden_splits == 1) {
+        if (int rc = check_launch("attn_tail_ffn")) return rc;
+        return sdetr_advance_rows(stream, a.out, sorted_result, next_query, tokens, sorted_index, index_batch_stride, count,
+                                  batch_size, rows, sorted_rows, next_rows, spatial_size, kFE * 2);
+    }
     FfnAdvance adv;
     adv.sorted_result = (bf16_t *)sorted_result; adv.next_query = next_rows > 0 ? (bf16_t *)next_query : nullptr;
     adv.tokens = (const bf16_t *)tokens; adv.sorted_index = sorted_index; adv.index_batch_stride = index_batch_stride;
     adv.count = count; adv.rows = rows; adv.sorted_rows = sorted_rows; adv.next_rows = next_rows;
     adv.spatial_size = spatial_size;
+    // (TAIL: piece 0 of the partial products carries b2 + x, the pass only sums)
     hipLaunchKernelGGL(ffn_reduce_ln_advance_kernel, dim3((unsigned)((tokens_total + 3) / 4)), dim3(256), 0, s,
-                       (const float *)workspace, hidden_splits, tokens_total, (const bf16_t *)x, bias2, norm_weight,
-                       norm_bias, norm_eps, adv);
+                       (const float *)workspace, hidden_splits, tokens_total, with_tail ? nullptr : (const bf16_t *)x, bias2,
+                       norm_weight, norm_bias, norm_eps, adv);
     return check_launch("ffn_fused_advance");
+}
+
+extern "C" int sdetr_ffn_fused_advance_bf16(sdetr_stream_t stream, const void *x, const void *packed_weights,
+                                            const float *bias1, const float *bias2, const float *norm_weight,
+                                            const float *norm_bias, float norm_eps, int batch_size, int rows,
+                                            int embed_dim, int hidden, int hidden_splits, void *workspace,
+                                            int64_t workspace_bytes, void *sorted_result, void *next_query,
+                                            const void *tokens, const int64_t *sorted_index,
+                                            int64_t index_batch_stride, const int64_t *count, int sorted_rows,
+                                            int next_rows, int spatial_size)
+{
+    return ffn_advance_impl(stream, x, TailArgs{}, packed_weights, bias1, bias2, norm_weight, norm_bias, norm_eps, batch_size,
+                            rows, embed_dim, hidden, hidden_splits, workspace, workspace_bytes, sorted_result, next_query,
+                            tokens, sorted_index, index_batch_stride, count, sorted_rows, next_rows, spatial_size);
+}
+
+extern "C" int sdetr_attn_tail_ffn_advance_bf16(
+    sdetr_stream_t stream, const void *sampled, const void *residual, const void *packed_tail_ffn, const float *bias_o,
+    const float *norm1_weight, const float *norm1_bias, float norm1_eps, const float *bias1, const float *bias2,
+    const float *norm_weight, const float *norm_bias, float norm_eps, int batch_size, int rows, int embed_dim, int hidden,
+    int hidden_splits, void *workspace, int64_t workspace_bytes, void *sorted_result, void *next_query, const void *tokens,
+    const int64_t *sorted_index, int64_t index_batch_stride, const int64_t *count, int sorted_rows, int next_rows,
+    int spatial_size)
+{
+    if (!sampled) return fail("attn_tail_ffn_advance: null pointer");
+    TailArgs t{sampled, residual, bias_o, norm1_weight, norm1_bias, norm1_eps};
+    return ffn_advance_impl(stream, nullptr, t, packed_tail_ffn, bias1, bias2, norm_weight, norm_bias, norm_eps, batch_size, rows,
+                            embed_dim, hidden, hidden_splits, workspace, workspace_bytes, sorted_result, next_query, tokens,
+                            sorted_index, index_batch_stride, count, sorted_rows, next_rows, spatial_size);
 }

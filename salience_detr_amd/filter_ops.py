@@ -724,6 +724,78 @@ def fused_ffn_advance(x: Tensor, linear1, linear2, norm, sorted_result: Tensor, 
     return nxt
 
 
+def attn_tail_ffn_applies(sampled: Tensor, residual: Tensor, output_proj, norm1, linear1, linear2, norm2, activation) -> bool:
+    """The layer-end operator (``attn_tail_ffn_advance``) covers the bf16 benchmark configuration."""
+    return (sampled.dim() == 3 and sampled.shape == residual.shape and sampled.is_contiguous() and residual.is_contiguous()
+            and residual.dtype == torch.bfloat16 and sampled.dtype == torch.bfloat16
+            and fused_ffn_applies(residual, linear1, linear2, norm2, activation)
+            and output_proj.weight.dtype == torch.bfloat16 and tuple(output_proj.weight.shape) == (256, 256)
+            and output_proj.bias is not None and norm1.weight is not None and norm1.bias is not None
+            and norm1.normalized_shape == (256,))
+
+
+def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2):
+    """``(packed [Wo tail | feed-forward], fp32 (bo, gamma1, beta1, b1, b2, gamma2, beta2))``, cached on
+    ``output_proj.weight`` and refreshed when any of the parameters changes."""
+    params = (output_proj.weight, output_proj.bias, norm1.weight, norm1.bias, linear1.weight, linear1.bias, linear2.weight,
+              linear2.bias, norm2.weight, norm2.bias)
+    tag = tuple((t.data_ptr(), t._version) for t in params) + (str(x.device),)
+    cache = output_proj.weight.__dict__.get("_sdetr_tail_ffn")
+    if cache is None or cache[0] != tag:
+        lib = _hip.lib()
+        F = linear1.out_features
+        with torch.no_grad(), torch.cuda.device(x.device):
+            tail_bytes = lib.sdetr_attn_tail_packed_bytes()
+            packed = torch.empty(tail_bytes + lib.sdetr_ffn_packed_bytes(F), dtype=torch.uint8, device=x.device)
+            wo = output_proj.weight.detach().contiguous()
+            _hip.check(lib.sdetr_attn_tail_pack_bf16(_hip.stream_ptr(), wo.data_ptr(), 256, packed.data_ptr()), "attn_tail_pack")
+            w1, w2 = linear1.weight.detach().contiguous(), linear2.weight.detach().contiguous()
+            _hip.check(lib.sdetr_ffn_pack_bf16(_hip.stream_ptr(), w1.data_ptr(), w2.data_ptr(), 256, F,
+                                               packed.data_ptr() + tail_bytes), "ffn_pack")
+            small = [t.detach().float().contiguous() for t in (output_proj.bias, norm1.weight, norm1.bias, linear1.bias,
+                                                               linear2.bias, norm2.weight, norm2.bias)]
+        cache = (tag, packed, small)
+        output_proj.weight.__dict__["_sdetr_tail_ffn"] = cache
+    return cache[1], cache[2]
+
+
+def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1, linear1, linear2, norm2,
+                          sorted_result: Tensor, next_rows: int, tokens: Tensor, sorted_index: Tensor,
+                          count: Optional[Tensor] = None, hidden_splits: Optional[int] = None) -> Optional[Tensor]:
+    """The end of an encoder layer as ONE operator (``sdetr_attn_tail_ffn_advance_bf16``):
+    ``x = norm1(residual + output_proj(sampled))``, ``y = norm2(x + linear2(relu(linear1(x))))``, then
+    ``advance_rows(y, ...)`` -- i.e. ``fused_ffn_advance(token_linear_ln(sampled, output_proj, norm1, residual), ...)``
+    without the launch, the weight pipeline start-up and the [rows, 256] round trip of the first half."""
+    _hip.require_device("attn_tail_ffn_advance", sampled=sampled, residual=residual, sorted_result=sorted_result, tokens=tokens,
+                        count=count)
+    if sampled.dim() != 3 or sampled.shape != residual.shape or sampled.shape[2] != 256 or not sampled.is_contiguous() \
+            or not residual.is_contiguous() or sampled.dtype != torch.bfloat16 or residual.dtype != torch.bfloat16:
+        raise RuntimeError("attn_tail_ffn_advance: contiguous bf16 [B, rows, 256] sampled heads and queries expected")
+    B, rows, C = residual.shape
+    if (sorted_result.dtype != residual.dtype or tokens.dtype != residual.dtype or sorted_index.dtype != torch.int64
+            or sorted_index.dim() != 2 or sorted_index.stride(1) != 1 or not sorted_index.is_cuda
+            or not sorted_result.is_contiguous() or not tokens.is_contiguous()):
+        raise RuntimeError("attn_tail_ffn_advance: dtype / layout mismatch")
+    if count is not None and (count.dtype != torch.int64 or count.numel() != B):
+        raise RuntimeError("attn_tail_ffn_advance: count must be int64 [B]")
+    lib = _hip.lib()
+    F = linear1.out_features
+    packed, (bo, g1, be1, b1, b2, g2, be2) = _tail_ffn_operands(residual, output_proj, norm1, linear1, linear2, norm2)
+    nxt = torch.empty((B, next_rows, C), dtype=residual.dtype, device=residual.device) if next_rows > 0 else None
+    with torch.cuda.device(residual.device):
+        splits = int(hidden_splits) if hidden_splits else lib.sdetr_ffn_auto_splits(B * rows, F)
+        ws_bytes = lib.sdetr_ffn_workspace_bytes(B * rows, splits) + (B * rows * 512 if splits == 1 else 0)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=residual.device)
+        code = lib.sdetr_attn_tail_ffn_advance_bf16(
+            _hip.stream_ptr(), sampled.data_ptr(), residual.data_ptr(), packed.data_ptr(), bo.data_ptr(), g1.data_ptr(),
+            be1.data_ptr(), float(norm1.eps), b1.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr(), float(norm2.eps),
+            B, rows, 256, F, splits, ws.data_ptr(), ws_bytes, sorted_result.data_ptr(), _hip.ptr(nxt), tokens.data_ptr(),
+            sorted_index.data_ptr(), sorted_index.stride(0), _hip.ptr(count), sorted_result.shape[1], int(next_rows),
+            tokens.shape[1])
+    _hip.check(code, "attn_tail_ffn_advance")
+    return nxt
+
+
 def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):
     """(packed weight, zero-padded fp32 bias) of a ``[N,256]`` bf16 Linear for the token-resident kernels, cached on
     the weight tensor object and refreshed when weight / bias storage or version change."""

@@ -25,7 +25,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
-from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, class_head_max_times,
+from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, attn_tail_ffn_advance,
+                         attn_tail_ffn_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_self_attention_,
@@ -59,6 +60,9 @@ class SalienceTransformerEncoderLayer(nn.Module):
         # the MSDA offset | weight projection of the layer's rows rides in the top-k attention's launch
         # (csrc/fused_head_value.hip); False = a launch of its own after the attention
         self.carry_sampling_projection = True
+        # output_proj + residual + norm1 inside the feed-forward's launch (csrc/ffn.hip, TAIL form); False = a launch of
+        # their own in front of it (tests compare the two)
+        self.fuse_attention_tail = True
         # pre attention
         self.pre_attention = nn.MultiheadAttention(embed_dim, n_heads, dropout, batch_first=True)
         self.pre_dropout = nn.Dropout(dropout)
@@ -200,6 +204,13 @@ class SalienceTransformerEncoderLayer(nn.Module):
                                                     level_start_index, query_pos=pos_sorted[:, :c],
                                                     apply_output_proj=False, level_shapes=level_shapes,
                                                     head_major_projection=proj)
+            if (advance is not None and self.fuse_attention_tail and not self.training
+                    and attn_tail_ffn_applies(sampled, query, self.self_attn.output_proj, self.norm1, self.linear1,
+                                              self.linear2, self.norm2, self.activation)):
+                # output_proj + residual + norm1 run in FRONT of the feed-forward inside its launch (csrc/ffn.hip, TAIL
+                # form): one launch and one [rows, 256] round trip less per layer
+                return attn_tail_ffn_advance(sampled, query, self.self_attn.output_proj, self.norm1, self.linear1,
+                                             self.linear2, self.norm2, *advance)
             # output_proj + residual + norm1 in one launch of the token-resident kernel at every layer size (below ~12 000
             # rows the library GEMM + separate LayerNorm is 1-2 us faster, but keeps hipBLASLt in the hot-path graph)
             query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)

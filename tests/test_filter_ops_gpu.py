@@ -622,6 +622,63 @@ def test_fused_ffn_advance_equals_ffn_then_advance_rows(rows, next_rows, splits)
         assert torch.equal(want_next, got_next)
 
 
+@pytest.mark.parametrize("rows,next_rows,splits,hidden", [(300, 200, 4, 512), (1200, 1200, 2, 512), (1500, 0, 8, 512),
+                                                          (700, 300, 1, 512), (1111, 900, 1, 2048), (2272, 0, 5, 2048),
+                                                          (640, 640, 16, 512)])
+def test_attn_tail_ffn_advance_equals_the_two_launches(rows, next_rows, splits, hidden):
+    """The layer-end operator (csrc/ffn.hip, TAIL form: output_proj + residual + norm1 in front of the feed-forward in
+    ONE launch) against the launches it replaces -- token_linear_ln, then fused_ffn_advance -- and against an fp32
+    evaluation of the same block (salience_transformer.py:390-394, 347-351).  Both bf16 paths round x = norm1(...) to bf16
+    before the feed-forward; they differ in accumulation order only."""
+    B, S, n0, C = 2, 3000, 2400, 256
+    torch.manual_seed(rows + splits)
+    mk = lambda m: m.to(DEV).to(torch.bfloat16)
+    wo, n1 = mk(torch.nn.Linear(C, C)), mk(torch.nn.LayerNorm(C))
+    l1, l2, n2 = mk(torch.nn.Linear(C, hidden)), mk(torch.nn.Linear(hidden, C)), mk(torch.nn.LayerNorm(C))
+    with torch.no_grad():
+        for m, tag in ((n1, "g1"), (n2, "g2")):
+            m.weight.copy_((1.0 + 0.2 * syn.det_randn("atf." + tag, (C,))).to(DEV))
+            m.bias.copy_((0.2 * syn.det_randn("atf.b" + tag, (C,))).to(DEV))
+        wo.bias.copy_((0.3 * syn.det_randn("atf.bo", (C,))).to(DEV))
+    sampled = (syn.det_randn(f"atf.s{rows}", (B, rows, C)) * 0.8).to(DEV).to(torch.bfloat16)
+    query = (syn.det_randn(f"atf.q{rows}", (B, rows, C)) * 0.9).to(DEV).to(torch.bfloat16)
+    tokens = syn.det_randn("atf.tok", (B, S, C)).to(DEV).to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(S)[:n0] for _ in range(B)]).to(DEV)
+    count = torch.tensor([rows - 37, max(rows // 3, 1)], dtype=torch.int64, device=DEV)
+    res_a = torch.full((B, n0, C), -3.0, dtype=torch.bfloat16, device=DEV)
+    res_b = res_a.clone()
+    act = torch.nn.ReLU()
+    assert F.attn_tail_ffn_applies(sampled, query, wo, n1, l1, l2, n2, act) == (B * rows >= 1000)
+    with torch.no_grad():
+        x = F.token_linear_ln(sampled, wo, n1, residual=query)
+        want_next = F.fused_ffn_advance(x, l1, l2, n2, res_a, next_rows, tokens, idx, count, hidden_splits=splits)
+        got_next = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_b, next_rows, tokens, idx, count,
+                                           hidden_splits=splits)
+        # fp32 statement with x rounded to bf16 where both kernels round it
+        x32 = torch.nn.functional.layer_norm(query.float() + torch.nn.functional.linear(sampled.float(), wo.weight.float(), wo.bias.float()),
+                                             (C,), n1.weight.float(), n1.bias.float(), n1.eps)
+        xb = x32.to(torch.bfloat16).float()
+        y32 = torch.nn.functional.layer_norm(xb + torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(
+            xb, l1.weight.float(), l1.bias.float())), l2.weight.float(), l2.bias.float()), (C,), n2.weight.float(), n2.bias.float(), n2.eps)
+    live0, live1 = rows - 37, max(rows // 3, 1)
+    # untouched rows stay untouched, the rest agree with the two-launch path to bf16 round-off of the outputs
+    assert (res_b[0, live0:] == -3).all() and (res_b[1, live1:] == -3).all()
+    for b, live in ((0, live0), (1, live1)):
+        got, ref2, ref32 = res_b[b, :live].float(), res_a[b, :live].float(), y32[b, :live]
+        assert (got - ref32).abs().max().item() <= 0.06, (got - ref32).abs().max().item()
+        assert (got - ref32).abs().mean().item() <= 4e-3
+        # as close to the fp32 statement as the two-launch path is, and close to that path itself
+        assert (got - ref32).abs().mean().item() <= 1.5 * (ref2 - ref32).abs().mean().item() + 1e-4
+        assert (got - ref2).abs().max().item() <= 0.06
+    if next_rows == 0:
+        assert want_next is None and got_next is None
+    else:
+        for b, live in ((0, live0), (1, live1)):
+            n_live = min(live, next_rows)
+            assert (got_next[b, :n_live].float() - want_next[b, :n_live].float()).abs().max().item() <= 0.06
+            assert torch.equal(got_next[b, n_live:], want_next[b, n_live:])     # original tokens, copied
+
+
 @pytest.mark.parametrize("n,hw,mode", [(273, (13, 21), "enc"), (1050, (25, 42), "enc+coarse")])
 def test_salience_head_carrying_a_value_projection_job(n, hw, mode):
     """fused_head_value.hip: stage 1 of a coarse level and a slice of the encoder's value projection in ONE launch
