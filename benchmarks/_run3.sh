@@ -1,6 +1,6 @@
-mkdir -p gpurun_out/r3h; O=gpurun_out/r3h
-python -m pytest tests/test_filter_ops_gpu.py -x -q -k "attn_tail or ffn" 2>&1 | tail -6
-python -m pytest tests/test_hotpath_gpu.py tests/test_encoder_timed_mode_gpu.py tests/test_msda_backward_lds_gpu.py -x -q 2>&1 | tail -4
+mkdir -p gpurun_out/r3i; O=gpurun_out/r3i
+python -m pytest tests/test_filter_ops_gpu.py -x -q -k "attn_tail or ffn or layer_end" 2>&1 | tail -6
+python -m pytest tests/test_hotpath_gpu.py tests/test_encoder_timed_mode_gpu.py -x -q 2>&1 | tail -4
 python bench.py --steps 30 --warmup 5 --in-flight-report 0 --train-steps 0 > $O/bench.json 2> $O/bench.err
 python -c "
 import json,sys
@@ -13,4 +13,4 @@ export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python bench.py --plain --steps 20 > $O/bench_profiled.json 2> $O/prof.err
 python benchmarks/step_timeline.py $(find $O/prof -name '*kernel_trace.csv' | head -1) > $O/step_timeline.txt
 rm -rf $O/prof
-grep -i "ffn\|advance" $O/step_timeline.txt | head -20; tail -1 $O/step_timeline.txt
+sed -n '18,40p' $O/step_timeline.txt | cut -c1-100; tail -1 $O/step_timeline.txt

@@ -672,7 +672,17 @@ int sdetr_attn_tail_ffn_advance_bf16(
     const float *norm_weight, const float *norm_bias, float norm_eps, int batch_size, int rows, int embed_dim, int hidden,
     int hidden_splits, void *workspace, int64_t workspace_bytes, void *sorted_result, void *next_query, const void *tokens,
     const int64_t *sorted_index, int64_t index_batch_stride, const int64_t *count, int sorted_rows, int next_rows,
-    int spatial_size);
+    int spatial_size, const float *class_bias_padded, const float *foreground, int64_t foreground_batch_stride,
+    float *next_class_score);
+/* next_class_score (may be NULL) [batch, next_rows] fp32: with ONE hidden piece and next_rows > 0 the same launch also
+ * does the row bookkeeping in its epilogue and writes the NEXT layer's selection score of the rows it hands on,
+ *     max_c(class_head(next_query[b, i])) * foreground[b, i]        models/bricks/salience_transformer.py:462, 366
+ * (fp32 accumulators, no logits in memory).  packed_tail_ffn then ends with sdetr_class_head_packed_bytes() bytes of
+ * sdetr_class_head_pack_bf16(class head weight [num_classes <= 96, 256] bf16); class_bias_padded fp32 [96] (-inf on the
+ * padded classes); foreground fp32 rows of at least next_rows, images foreground_batch_stride apart.  With more hidden
+ * pieces the score is NOT written (the caller launches the class head). */
+int64_t sdetr_class_head_packed_bytes(void);
+int sdetr_class_head_pack_bf16(sdetr_stream_t stream, const void *weight, int num_classes, int embed_dim, void *packed);
 
 /* sdetr_topk_attention_bf16 of an encoder layer together with the deformable attention's offset | weight projection of
  * the layer's queries (sdetr_token_linear_bf16 with x_add = pos and group_features = 48: the head-major slab

@@ -111,7 +111,9 @@ SIGNATURES = {
     "sdetr_attn_tail_packed_bytes": (_i64, []),
     "sdetr_attn_tail_pack_bf16": (_i, [_p, _p, _i, _p]),
     "sdetr_attn_tail_ffn_advance_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float, _p, _p, _p, _p, ctypes.c_float, _i, _i,
-                                              _i, _i, _i, _p, _i64, _p, _p, _p, _p, _i64, _p, _i, _i, _i]),
+                                              _i, _i, _i, _p, _i64, _p, _p, _p, _p, _i64, _p, _i, _i, _i, _p, _p, _i64, _p]),
+    "sdetr_class_head_packed_bytes": (_i64, []),
+    "sdetr_class_head_pack_bf16": (_i, [_p, _p, _i, _i, _p]),
     "sdetr_gemm_x3_presplit": (_i, [_p, _p, _i64, _i, _i, _i, _p]),
     "sdetr_gemm_x3_f32": (_i, [_p, _p, _i64, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _i, _p]),
     "sdetr_topk_attention_with_projection_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p,

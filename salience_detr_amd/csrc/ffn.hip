@@ -51,6 +51,19 @@ constexpr int kFTokWave = 32, kFTokBlock = 128;
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+// End-of-layer row bookkeeping (sdetr_advance_rows): row i of image b goes to sorted_result[b,i] when live
+// (i < count[b]) and to next_query[b,i] when i < next_rows -- live rows the layer output, the others the never-updated
+// original tokens[b, sorted_index[b,i]].
+struct FfnAdvance {
+    bf16_t *sorted_result;        // [B, sorted_rows, 256]
+    bf16_t *next_query;           // [B, next_rows, 256] or NULL
+    const bf16_t *tokens;         // [B, spatial_size, 256]
+    const int64_t *sorted_index;  // rows index_batch_stride apart
+    int64_t index_batch_stride;
+    const int64_t *count;         // [B] or NULL
+    int rows, sorted_rows, next_rows, spatial_size;
+};
+
 struct FfnArgs {
     const bf16_t *x;        // [T, 256]
     const char *pw;         // packed weights, nchunk * 32 KB
@@ -68,8 +81,17 @@ struct FfnArgs {
     const bf16_t *res;      // [T, 256] the layer's queries (residual)
     const float *bo, *g1, *be1;   // [256] output_proj bias, norm1 weight / bias
     float eps1;
+    // NEXT form (ffn_fused_kernel<., true>, nsplit == 1): the epilogue does the row bookkeeping itself (`adv`, no `out`)
+    // and computes the NEXT layer's class score max_c(Wc q + bc) * fg of the rows it hands on
+    // (salience_transformer.py:462, 366) -- `pw` then ends with kClsChunks chunks of Wc fragments.
+    FfnAdvance adv;
+    const float *cls_bias;  // [96]: the class head's bias, -inf on the padded classes
+    const float *fg;        // [B, >= next_rows] foreground scores of the rows, images fg_bs apart
+    int64_t fg_bs;
+    float *cmax;            // [B, next_rows]
 };
 
+constexpr int kClsChunks = 2;    // Wc [96 x 256] (91 classes, zero padded) as 48 fragments: f = 3 (k-step) + tile
 constexpr int kTailChunks = 4;   // Wo [256 x 256] as 128 1-KB A-fragments: chunk a = k-steps 4a .. 4a+3 of all 8 output tiles
 
 __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c)
@@ -110,7 +132,7 @@ constexpr int kFThreads = 512;
 // TAIL: the layer's attention tail (output_proj + residual + norm1) in front, see FfnArgs.  The weight STREAM of a
 // block is then [tail chunks 0..3][its piece of the hidden dimension]: stream chunk c lives in LDS buffer c & 3 and the
 // loaders / barriers below count stream chunks; the feed-forward part addresses its chunk j as stream chunk NT + j.
-template <bool TAIL>
+template <bool TAIL, bool NEXT = false>
 __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -123,10 +145,13 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     const int c0 = (int)((int64_t)sp * p.nchunk / p.nsplit);
     const int nloc = (int)((int64_t)(sp + 1) * p.nchunk / p.nsplit) - c0;
     constexpr int NT = TAIL ? kTailChunks : 0;
-    const int nl = nloc + NT;                                          // chunks in this block's stream
+    constexpr int NC = NEXT ? kClsChunks : 0;
+    const int nl = nloc + NT + NC;                                     // chunks in this block's stream
     const char *pw = p.pw;
-    // stream chunk -> chunk of the packed buffer
-    auto chunk_at = [&](int c) { return TAIL ? (c < NT ? c : NT + c0 + (c - NT)) : c0 + c; };
+    // stream chunk -> chunk of the packed buffer [tail][feed-forward: nchunk][class head]
+    auto chunk_at = [&](int c) {
+        return c < NT ? c : (c < NT + nloc ? NT + c0 + (c - NT) : NT + p.nchunk + (c - NT - nloc));
+    };
 
     if (wave >= 4) {
         // ---- loader wave: a quarter (8 KB) of every 32 KB chunk, global -> registers -> LDS, FOUR chunk buffers ----
@@ -221,6 +246,7 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
         par[4 * kFE + tid] = p.g1[tid];
         par[5 * kFE + tid] = p.be1[tid];
     }
+    if (NEXT && tid < 96) par[6 * kFE + tid] = p.cls_bias[tid];
 
     uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token (TAIL: first S^T)
     {
@@ -514,27 +540,109 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     const float mean = sum * (1.f / kFE);
     const float rstd = rsqrtf(fmaxf(sq * (1.f / kFE) - mean * mean, 0.f) + p.eps);
     const float shift = -mean * rstd;
-    if (valid) {
-        bf16_t *orow = p.out + row;
+    if (!NEXT) {
+        if (valid) {
+            bf16_t *orow = p.out + row;
 #pragma unroll
-        for (int et = 0; et < 8; ++et) {
+            for (int et = 0; et < 8; ++et) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int e0 = 32 * et + 8 * g + 4 * h;
+                    const float4 gv = *reinterpret_cast<const float4 *>(par + kFE + e0);
+                    const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kFE + e0);
+                    float r[4];
+                    residual(et, g, r);
+                    // (v - mean) * rstd * gamma + beta = (v * rstd + shift) * gamma + beta
+                    const float y0 = fmaf(fmaf(yacc[et][4 * g] + r[0], rstd, shift), gv.x, be.x);
+                    const float y1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
+                    const float y2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
+                    const float y3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
+                    *reinterpret_cast<uint2 *>(orow + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+                }
+                // one e-tile at a time: hoisting all 64 gamma / beta reads above the arithmetic costs 256 registers
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
+    // ---- NEXT form: y (bf16) replaces the residual in the operand registers, piece by piece (cf. the TAIL's second
+    // pass: opaque residual pieces between the passes, every piece pinned where it is computed) ----
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int et = ks >> 1, g0 = 2 * (ks & 1);
+        uint32_t d[4];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int g = g0 + gg, e0 = 32 * et + 8 * g + 4 * h;
+            const float4 gv = *reinterpret_cast<const float4 *>(par + kFE + e0);
+            const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kFE + e0);
+            float r[4];
+            residual(et, g, r);
+            const float y0 = fmaf(fmaf(yacc[et][4 * g] + r[0], rstd, shift), gv.x, be.x);
+            const float y1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
+            const float y2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
+            const float y3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
+            d[2 * gg] = pack_bf16x2(y0, y1);
+            d[2 * gg + 1] = pack_bf16x2(y2, y3);
+        }
+        xb[ks] = make_uint4(d[0], d[1], d[2], d[3]);
+        asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    swap_halves();   // y^T: lane (t, h) holds channels 16ks + 8h .. +7 of its row -- 16-byte stores, and the class head's B operands
+    {
+        const FfnAdvance &a = p.adv;
+        const int tk = valid ? tok : p.T - 1;
+        const int b = tk / a.rows, i = tk - b * a.rows;
+        const bool live = !a.count || i < a.count[b];
+        const bool feeds = i < a.next_rows;
+        if (live) {
+            if (valid) {
+                bf16_t *o = a.sorted_result + ((int64_t)b * a.sorted_rows + i) * kFE + 8 * h;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) *reinterpret_cast<uint4 *>(o + 16 * ks) = xb[ks];
+            }
+        } else if (feeds) {
+            // not part of this image's focus set: the next layer sees (and scores) the original token
+            const bf16_t *src = a.tokens + ((int64_t)b * a.spatial_size + a.sorted_index[(int64_t)b * a.index_batch_stride + i]) * kFE + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const uint4 *>(src + 16 * ks);
+        }
+        if (valid && feeds) {
+            bf16_t *o = a.next_query + ((int64_t)b * a.next_rows + i) * kFE + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) *reinterpret_cast<uint4 *>(o + 16 * ks) = xb[ks];
+        }
+        // ---- class head of the NEXT layer on the rows just handed on: logits^T [96 x 32] = Wc q^T + bc ----
+        __builtin_amdgcn_s_barrier();   // both class-head chunks are in LDS (stashed during the last two iterations)
+        const lds_cptr_t cc = chunk_lds(NT + nloc), cd = chunk_lds(NT + nloc + 1);
+        f32x16_t cacc[3];
+#pragma unroll
+        for (int et = 0; et < 3; ++et)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int e0 = 32 * et + 8 * g + 4 * h;
-                const float4 gv = *reinterpret_cast<const float4 *>(par + kFE + e0);
-                const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kFE + e0);
-                float r[4];
-                residual(et, g, r);
-                // (v - mean) * rstd * gamma + beta = (v * rstd + shift) * gamma + beta
-                const float y0 = fmaf(fmaf(yacc[et][4 * g] + r[0], rstd, shift), gv.x, be.x);
-                const float y1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
-                const float y2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
-                const float y3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
-                *reinterpret_cast<uint2 *>(orow + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+                const float4 bv = *reinterpret_cast<const float4 *>(par + 6 * kFE + 32 * et + 8 * g + 4 * h);
+                cacc[et][4 * g] = bv.x; cacc[et][4 * g + 1] = bv.y; cacc[et][4 * g + 2] = bv.z; cacc[et][4 * g + 3] = bv.w;
             }
-            // one e-tile at a time: hoisting all 64 gamma / beta reads above the arithmetic costs 256 registers
+        auto cls_frag = [&](int f) { return f < 32 ? cc + f * 1024 : cd + (f - 32) * 1024; };
+#pragma unroll
+        for (int f = 0; f < R; ++f) ring[f] = lds_read16(cls_frag(f));
+#pragma unroll
+        for (int f = 0; f < 48; ++f) {
+            cacc[f % 3] = mfma_bf16(ring[f % R], xb[f / 3], cacc[f % 3]);
+            if (f + R < 48) ring[f % R] = lds_read16(cls_frag(f + R));
             __builtin_amdgcn_sched_barrier(0);
         }
+        __builtin_amdgcn_s_barrier();   // (the loaders' last phase)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int et = 0; et < 3; ++et)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, cacc[et][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (valid && feeds && h == 0) p.cmax[(int64_t)b * a.next_rows + i] = mx * p.fg[(int64_t)b * p.fg_bs + i];
     }
 }
 
@@ -577,15 +685,6 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_kernel(const float *partial
 // layers of the encoder: one launch less each): row i of image b goes to sorted_result[b,i] when live (i < count[b])
 // and to next_query[b,i] when i < next_rows -- live rows the LayerNorm output, the others the never-updated original
 // tokens[b, sorted_index[b,i]].
-struct FfnAdvance {
-    bf16_t *sorted_result;        // [B, sorted_rows, 256]
-    bf16_t *next_query;           // [B, next_rows, 256] or NULL
-    const bf16_t *tokens;         // [B, spatial_size, 256]
-    const int64_t *sorted_index;  // rows index_batch_stride apart
-    int64_t index_batch_stride;
-    const int64_t *count;         // [B] or NULL
-    int rows, sorted_rows, next_rows, spatial_size;
-};
 
 __global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float *partial, int nsplit, int T, const bf16_t *x,
                                                                     const float *b2, const float *gamma,
@@ -664,9 +763,32 @@ __global__ void attn_tail_pack_kernel(const bf16_t *wo, bf16_t *out)
     out[o] = wo[(int64_t)(32 * et + (l & 31)) * kFE + 16 * (4 * a + ksl) + 8 * (l >> 5) + s];
 }
 
+// Wc [num_classes <= 96, 256] -> kClsChunks chunks: fragment f = 3 ks + et (48 of the 64 slots used) holds
+// A[m = 32 et + (lane & 31)][k = 16 ks + 8 (lane >> 5) .. +7], zero rows for the padded classes.
+__global__ void class_head_pack_kernel(const bf16_t *wc, int num_classes, bf16_t *out)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;   // over 2 * 16384 elements
+    if (o >= kClsChunks * 16384) return;
+    const int s = o & 7, l = (o >> 3) & 63, f = o >> 9;
+    const int ks = f / 3, et = f - 3 * ks, m = 32 * et + (l & 31);
+    out[o] = (f < 48 && m < num_classes) ? wc[(int64_t)m * kFE + 16 * ks + 8 * (l >> 5) + s] : (bf16_t)0;
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
+
+extern "C" int64_t sdetr_class_head_packed_bytes(void) { return (int64_t)kClsChunks * kFChunkBytes; }
+
+extern "C" int sdetr_class_head_pack_bf16(sdetr_stream_t stream, const void *weight, int num_classes, int embed_dim, void *packed)
+{
+    if (embed_dim != kFE) return fail("class_head_pack: built for embed_dim %d (got %d)", kFE, embed_dim);
+    if (num_classes <= 0 || num_classes > 96) return fail("class_head_pack: 1..96 classes (got %d)", num_classes);
+    if (!weight || !packed) return fail("class_head_pack: null pointer");
+    hipLaunchKernelGGL(class_head_pack_kernel, dim3((kClsChunks * 16384 + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), (const bf16_t *)weight, num_classes, (bf16_t *)packed);
+    return check_launch("class_head_pack");
+}
 
 extern "C" int64_t sdetr_attn_tail_packed_bytes(void) { return (int64_t)kTailChunks * kFChunkBytes; }
 
@@ -773,6 +895,10 @@ struct TailArgs {   // the attention tail in front of the feed-forward (NULL sam
     const void *sampled, *residual;
     const float *bias_o, *norm1_weight, *norm1_bias;
     float norm1_eps;
+    // the next layer's class score out of the epilogue (NULL next_score = none; only with one hidden piece)
+    const float *cls_bias, *fg;
+    int64_t fg_bs;
+    float *next_score;
 };
 
 static int ffn_advance_impl(sdetr_stream_t stream, const void *x, const TailArgs &tail, const void *packed_weights,
@@ -822,6 +948,20 @@ static int ffn_advance_impl(sdetr_stream_t stream, const void *x, const TailArgs
     a.g1 = tail.norm1_weight; a.be1 = tail.norm1_bias; a.eps1 = tail.norm1_eps;
     const int64_t tblocks = (tokens_total + kFTokBlock - 1) / kFTokBlock;
     if (hidden_splits == 1) a.out = reinterpret_cast<bf16_t *>(static_cast<char *>(workspace) + partial_bytes);
+    FfnAdvance adv;
+    adv.sorted_result = (bf16_t *)sorted_result; adv.next_query = next_rows > 0 ? (bf16_t *)next_query : nullptr;
+    adv.tokens = (const bf16_t *)tokens; adv.sorted_index = sorted_index; adv.index_batch_stride = index_batch_stride;
+    adv.count = count; adv.rows = rows; adv.sorted_rows = sorted_rows; adv.next_rows = next_rows;
+    adv.spatial_size = spatial_size;
+    if (with_tail && tail.next_score && hidden_splits == 1 && next_rows > 0) {
+        // layer end + row bookkeeping + the next layer's class score: ONE launch
+        if (!tail.cls_bias || !tail.fg || tail.fg_bs < next_rows) return fail("attn_tail_ffn_advance: bad class-score operands");
+        a.adv = adv; a.out = nullptr; a.cls_bias = tail.cls_bias; a.fg = tail.fg; a.fg_bs = tail.fg_bs; a.cmax = tail.next_score;
+        static DeviceOnce lds_once4;
+        allow_dynamic_lds(ffn_fused_kernel<true, true>, lds_once4, 160 * 1024);
+        hipLaunchKernelGGL((ffn_fused_kernel<true, true>), dim3((unsigned)tblocks), dim3(kFThreads), lds + 96 * 4, s, a);
+        return check_launch("attn_tail_ffn_next");
+    }
     if (with_tail) {
         static DeviceOnce lds_once3;
         allow_dynamic_lds(ffn_fused_kernel<true>, lds_once3, 160 * 1024);
@@ -836,11 +976,6 @@ static int ffn_advance_impl(sdetr_stream_t stream, const void *x, const TailArgs
         return sdetr_advance_rows(stream, a.out, sorted_result, next_query, tokens, sorted_index, index_batch_stride, count,
                                   batch_size, rows, sorted_rows, next_rows, spatial_size, kFE * 2);
     }
-    FfnAdvance adv;
-    adv.sorted_result = (bf16_t *)sorted_result; adv.next_query = next_rows > 0 ? (bf16_t *)next_query : nullptr;
-    adv.tokens = (const bf16_t *)tokens; adv.sorted_index = sorted_index; adv.index_batch_stride = index_batch_stride;
-    adv.count = count; adv.rows = rows; adv.sorted_rows = sorted_rows; adv.next_rows = next_rows;
-    adv.spatial_size = spatial_size;
     // (TAIL: piece 0 of the partial products carries b2 + x, the pass only sums)
     hipLaunchKernelGGL(ffn_reduce_ln_advance_kernel, dim3((unsigned)((tokens_total + 3) / 4)), dim3(256), 0, s,
                        (const float *)workspace, hidden_splits, tokens_total, with_tail ? nullptr : (const bf16_t *)x, bias2,
@@ -868,10 +1003,12 @@ extern "C" int sdetr_attn_tail_ffn_advance_bf16(
     const float *norm_weight, const float *norm_bias, float norm_eps, int batch_size, int rows, int embed_dim, int hidden,
     int hidden_splits, void *workspace, int64_t workspace_bytes, void *sorted_result, void *next_query, const void *tokens,
     const int64_t *sorted_index, int64_t index_batch_stride, const int64_t *count, int sorted_rows, int next_rows,
-    int spatial_size)
+    int spatial_size, const float *class_bias_padded, const float *foreground, int64_t foreground_batch_stride,
+    float *next_class_score)
 {
     if (!sampled) return fail("attn_tail_ffn_advance: null pointer");
-    TailArgs t{sampled, residual, bias_o, norm1_weight, norm1_bias, norm1_eps};
+    TailArgs t{sampled, residual, bias_o, norm1_weight, norm1_bias, norm1_eps, class_bias_padded, foreground,
+               foreground_batch_stride, next_class_score};
     return ffn_advance_impl(stream, nullptr, t, packed_tail_ffn, bias1, bias2, norm_weight, norm_bias, norm_eps, batch_size, rows,
                             embed_dim, hidden, hidden_splits, workspace, workspace_bytes, sorted_result, next_query, tokens,
                             sorted_index, index_batch_stride, count, sorted_rows, next_rows, spatial_size);

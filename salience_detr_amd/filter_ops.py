@@ -734,19 +734,22 @@ def attn_tail_ffn_applies(sampled: Tensor, residual: Tensor, output_proj, norm1,
             and norm1.normalized_shape == (256,))
 
 
-def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2):
-    """``(packed [Wo tail | feed-forward], fp32 (bo, gamma1, beta1, b1, b2, gamma2, beta2))``, cached on
-    ``output_proj.weight`` and refreshed when any of the parameters changes."""
+def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2, class_head=None):
+    """``(packed [Wo tail | feed-forward | class head], fp32 (bo, gamma1, beta1, b1, b2, gamma2, beta2, class bias padded
+    to 96 with -inf))``, cached on ``output_proj.weight`` and refreshed when any of the parameters changes."""
     params = (output_proj.weight, output_proj.bias, norm1.weight, norm1.bias, linear1.weight, linear1.bias, linear2.weight,
               linear2.bias, norm2.weight, norm2.bias)
+    if class_head is not None:
+        params = params + (class_head.weight, class_head.bias)
     tag = tuple((t.data_ptr(), t._version) for t in params) + (str(x.device),)
     cache = output_proj.weight.__dict__.get("_sdetr_tail_ffn")
     if cache is None or cache[0] != tag:
         lib = _hip.lib()
         F = linear1.out_features
         with torch.no_grad(), torch.cuda.device(x.device):
-            tail_bytes = lib.sdetr_attn_tail_packed_bytes()
-            packed = torch.empty(tail_bytes + lib.sdetr_ffn_packed_bytes(F), dtype=torch.uint8, device=x.device)
+            tail_bytes, ffn_bytes = lib.sdetr_attn_tail_packed_bytes(), lib.sdetr_ffn_packed_bytes(F)
+            cls_bytes = lib.sdetr_class_head_packed_bytes() if class_head is not None else 0
+            packed = torch.empty(tail_bytes + ffn_bytes + cls_bytes, dtype=torch.uint8, device=x.device)
             wo = output_proj.weight.detach().contiguous()
             _hip.check(lib.sdetr_attn_tail_pack_bf16(_hip.stream_ptr(), wo.data_ptr(), 256, packed.data_ptr()), "attn_tail_pack")
             w1, w2 = linear1.weight.detach().contiguous(), linear2.weight.detach().contiguous()
@@ -754,6 +757,13 @@ def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2):
                                                packed.data_ptr() + tail_bytes), "ffn_pack")
             small = [t.detach().float().contiguous() for t in (output_proj.bias, norm1.weight, norm1.bias, linear1.bias,
                                                                linear2.bias, norm2.weight, norm2.bias)]
+            if class_head is not None:
+                wc = class_head.weight.detach().contiguous()
+                _hip.check(lib.sdetr_class_head_pack_bf16(_hip.stream_ptr(), wc.data_ptr(), wc.shape[0], 256,
+                                                          packed.data_ptr() + tail_bytes + ffn_bytes), "class_head_pack")
+                cb = torch.full((96,), float("-inf"), dtype=torch.float32, device=x.device)
+                cb[:wc.shape[0]] = class_head.bias.detach().float()
+                small.append(cb)
         cache = (tag, packed, small)
         output_proj.weight.__dict__["_sdetr_tail_ffn"] = cache
     return cache[1], cache[2]
@@ -761,13 +771,19 @@ def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2):
 
 def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1, linear1, linear2, norm2,
                           sorted_result: Tensor, next_rows: int, tokens: Tensor, sorted_index: Tensor,
-                          count: Optional[Tensor] = None, hidden_splits: Optional[int] = None) -> Optional[Tensor]:
+                          count: Optional[Tensor] = None, hidden_splits: Optional[int] = None, next_class_head=None,
+                          foreground: Optional[Tensor] = None):
     """The end of an encoder layer as ONE operator (``sdetr_attn_tail_ffn_advance_bf16``):
     ``x = norm1(residual + output_proj(sampled))``, ``y = norm2(x + linear2(relu(linear1(x))))``, then
     ``advance_rows(y, ...)`` -- i.e. ``fused_ffn_advance(token_linear_ln(sampled, output_proj, norm1, residual), ...)``
-    without the launch, the weight pipeline start-up and the [rows, 256] round trip of the first half."""
+    without the launch, the weight pipeline start-up and the [rows, 256] round trip of the first half.
+
+    ``next_class_head`` + ``foreground`` ([B, >= next_rows] fp32): returns ``(next_query, score)`` where ``score``
+    [B, next_rows] is the NEXT layer's selection score ``class_head_max_times(next_query, next_class_head, foreground)`` --
+    computed in the same launch's epilogue when the feed-forward runs in one hidden piece (``next_class_score_applies``),
+    else ``None`` (the caller launches the class head)."""
     _hip.require_device("attn_tail_ffn_advance", sampled=sampled, residual=residual, sorted_result=sorted_result, tokens=tokens,
-                        count=count)
+                        count=count, foreground=foreground)
     if sampled.dim() != 3 or sampled.shape != residual.shape or sampled.shape[2] != 256 or not sampled.is_contiguous() \
             or not residual.is_contiguous() or sampled.dtype != torch.bfloat16 or residual.dtype != torch.bfloat16:
         raise RuntimeError("attn_tail_ffn_advance: contiguous bf16 [B, rows, 256] sampled heads and queries expected")
@@ -780,10 +796,21 @@ def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1,
         raise RuntimeError("attn_tail_ffn_advance: count must be int64 [B]")
     lib = _hip.lib()
     F = linear1.out_features
-    packed, (bo, g1, be1, b1, b2, g2, be2) = _tail_ffn_operands(residual, output_proj, norm1, linear1, linear2, norm2)
-    nxt = torch.empty((B, next_rows, C), dtype=residual.dtype, device=residual.device) if next_rows > 0 else None
     with torch.cuda.device(residual.device):
         splits = int(hidden_splits) if hidden_splits else lib.sdetr_ffn_auto_splits(B * rows, F)
+    want_score = next_class_head is not None
+    with_score = (want_score and splits == 1 and next_rows > 0 and foreground is not None
+                  and next_class_head.weight.dtype == torch.bfloat16 and next_class_head.weight.shape[0] <= 96
+                  and next_class_head.weight.shape[1] == 256 and next_class_head.bias is not None)
+    if with_score and (foreground.dtype != torch.float32 or foreground.dim() != 2 or foreground.shape[0] != B
+                       or foreground.shape[1] < next_rows or foreground.stride(1) != 1):
+        raise RuntimeError("attn_tail_ffn_advance: foreground must be fp32 [B, >= next_rows] rows")
+    ops = _tail_ffn_operands(residual, output_proj, norm1, linear1, linear2, norm2, next_class_head if with_score else None)
+    packed, (bo, g1, be1, b1, b2, g2, be2) = ops[0], ops[1][:7]
+    cls_bias = ops[1][7] if with_score else None
+    nxt = torch.empty((B, next_rows, C), dtype=residual.dtype, device=residual.device) if next_rows > 0 else None
+    score = torch.empty((B, next_rows), dtype=torch.float32, device=residual.device) if with_score else None
+    with torch.cuda.device(residual.device):
         ws_bytes = lib.sdetr_ffn_workspace_bytes(B * rows, splits) + (B * rows * 512 if splits == 1 else 0)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=residual.device)
         code = lib.sdetr_attn_tail_ffn_advance_bf16(
@@ -791,9 +818,10 @@ def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1,
             be1.data_ptr(), float(norm1.eps), b1.data_ptr(), b2.data_ptr(), g2.data_ptr(), be2.data_ptr(), float(norm2.eps),
             B, rows, 256, F, splits, ws.data_ptr(), ws_bytes, sorted_result.data_ptr(), _hip.ptr(nxt), tokens.data_ptr(),
             sorted_index.data_ptr(), sorted_index.stride(0), _hip.ptr(count), sorted_result.shape[1], int(next_rows),
-            tokens.shape[1])
+            tokens.shape[1], _hip.ptr(cls_bias), _hip.ptr(foreground) if with_score else None,
+            (foreground.stride(0) if B > 1 else foreground.shape[1]) if with_score else 0, _hip.ptr(score))
     _hip.check(code, "attn_tail_ffn_advance")
-    return nxt
+    return (nxt, score) if want_score else nxt
 
 
 def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):

@@ -163,16 +163,20 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
-                       class_head, level_shapes=None, selection_hook=None, advance=None):
+                       class_head, level_shapes=None, selection_hook=None, advance=None, mc_score=None,
+                       want_next_score=False):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
         sorted-order buffers of which the first ``c`` rows belong to this layer.  Same arithmetic as ``forward``.
         With ``advance`` (see ``_forward_ffn_native``) the layer finishes with the encoder's row bookkeeping and
-        returns the next layer's queries."""
+        returns the next layer's queries.  ``mc_score`` [B,c]: this layer's selection score if the previous layer's last
+        launch already produced it; ``want_next_score``: return ``(next queries, next layer's score or None)``."""
         c = query.shape[1]
         proj = None
-        if token_linear_applies(query, class_head.weight):
+        if mc_score is not None:
+            pass
+        elif token_linear_applies(query, class_head.weight):
             mc_score = class_head_max_times(query, class_head, fg_sorted[:, :c])   # logits never materialised
         else:
             mc_score = class_max_times(class_head(query), fg_sorted[:, :c])
@@ -209,18 +213,25 @@ class SalienceTransformerEncoderLayer(nn.Module):
                                               self.linear2, self.norm2, self.activation)):
                 # output_proj + residual + norm1 run in FRONT of the feed-forward inside its launch (csrc/ffn.hip, TAIL
                 # form): one launch and one [rows, 256] round trip less per layer
+                if want_next_score:
+                    # ... and the next layer's class score comes out of the same launch's epilogue when it can
+                    return attn_tail_ffn_advance(sampled, query, self.self_attn.output_proj, self.norm1, self.linear1,
+                                                 self.linear2, self.norm2, *advance, next_class_head=class_head,
+                                                 foreground=fg_sorted)
                 return attn_tail_ffn_advance(sampled, query, self.self_attn.output_proj, self.norm1, self.linear1,
                                              self.linear2, self.norm2, *advance)
             # output_proj + residual + norm1 in one launch of the token-resident kernel at every layer size (below ~12 000
             # rows the library GEMM + separate LayerNorm is 1-2 us faster, but keeps hipBLASLt in the hot-path graph)
             query = token_linear_ln(sampled, self.self_attn.output_proj, self.norm1, residual=query)
-            return self._forward_ffn_native(query, advance)
+            out = self._forward_ffn_native(query, advance)
+            return (out, None) if want_next_score else out
         tgt2 = self._pre_attention_stacked(stacked, N)
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
         fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
         src2 = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes, level_start_index,
                                              query_pos=pos_sorted[:, :c], level_shapes=level_shapes)
-        return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2), advance)
+        out = self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2), advance)
+        return (out, None) if want_next_score else out
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
                 query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None):
@@ -404,6 +415,7 @@ class SalienceTransformerEncoder(nn.Module):
                                                  index=sorted_index)
                 fg_s = torch.gather(foreground_score, 1, sorted_index)
             result = torch.empty_like(q)
+            score = None
             for layer_id, layer in enumerate(self.layers):
                 if self.max_layers is not None and layer_id >= self.max_layers:
                     break
@@ -413,10 +425,12 @@ class SalienceTransformerEncoder(nn.Module):
                 if self.selection_hook is not None:
                     hook = (lambda sel, k=layer_id: self.selection_hook(k, sel))
                 nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
-                # the layer ends with the row bookkeeping (live rows recorded in `result`, next layer's queries)
-                q = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
-                                         level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
-                                         selection_hook=hook, advance=(result, nxt, value, sorted_index, focus64))
+                # the layer ends with the row bookkeeping (live rows recorded in `result`, next layer's queries) and,
+                # when its last launch can, the next layer's selection score
+                q, score = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
+                                                level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
+                                                selection_hook=hook, advance=(result, nxt, value, sorted_index, focus64),
+                                                mc_score=score, want_next_score=True)
             if self.layer_marker is not None:
                 self.layer_marker(self.num_layers)
             if multi_level_masks is not None:

@@ -679,6 +679,47 @@ def test_attn_tail_ffn_advance_equals_the_two_launches(rows, next_rows, splits, 
             assert torch.equal(got_next[b, n_live:], want_next[b, n_live:])     # original tokens, copied
 
 
+@pytest.mark.parametrize("rows,next_rows,hidden", [(700, 300, 512), (1111, 900, 2048), (640, 640, 512), (1300, 1, 512)])
+def test_layer_end_hands_on_the_next_layers_class_score(rows, next_rows, hidden):
+    """One hidden piece: the layer-end launch also does the row bookkeeping in its epilogue and returns the NEXT layer's
+    selection score of the rows it hands on (salience_transformer.py:462, 366) -- against the separate launches:
+    identical rows, score = class_head_max_times(next rows) up to fp32 accumulation order."""
+    B, S, n0, C = 2, 3000, 2400, 256
+    torch.manual_seed(rows)
+    mk = lambda m: m.to(DEV).to(torch.bfloat16)
+    wo, n1 = mk(torch.nn.Linear(C, C)), mk(torch.nn.LayerNorm(C))
+    l1, l2, n2 = mk(torch.nn.Linear(C, hidden)), mk(torch.nn.Linear(hidden, C)), mk(torch.nn.LayerNorm(C))
+    head = mk(torch.nn.Linear(C, 91))
+    with torch.no_grad():
+        head.bias.copy_((syn.det_randn("nx.hb", (91,)) - 2.0).to(DEV))
+    sampled = (syn.det_randn(f"nx.s{rows}", (B, rows, C)) * 0.8).to(DEV).to(torch.bfloat16)
+    query = (syn.det_randn(f"nx.q{rows}", (B, rows, C)) * 0.9).to(DEV).to(torch.bfloat16)
+    tokens = syn.det_randn("nx.tok", (B, S, C)).to(DEV).to(torch.bfloat16)
+    idx = torch.stack([torch.randperm(S)[:n0] for _ in range(B)]).to(DEV)
+    count = torch.tensor([rows - 37, max(rows // 3, 1)], dtype=torch.int64, device=DEV)
+    fg_long = syn.det_randn(f"nx.fg{rows}", (B, n0)).to(DEV)
+    res_a = torch.full((B, n0, C), -3.0, dtype=torch.bfloat16, device=DEV)
+    res_b = res_a.clone()
+    with torch.no_grad():
+        want_next = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_a, next_rows, tokens, idx, count,
+                                            hidden_splits=1)
+        got_next, score = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_b, next_rows, tokens, idx, count,
+                                                  hidden_splits=1, next_class_head=head, foreground=fg_long)
+        assert score is not None and score.shape == (B, next_rows)
+        assert torch.equal(res_a, res_b) and torch.equal(want_next, got_next)
+        want_score = F.class_head_max_times(got_next, head, fg_long[:, :next_rows]) if B * next_rows >= 32 else None
+        logits = torch.nn.functional.linear(got_next.float(), head.weight.float(), head.bias.float())
+        ref = logits.max(-1)[0] * fg_long[:, :next_rows]
+        assert (score - ref).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1)
+        if want_score is not None:
+            assert (score - want_score).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1)
+        # more hidden pieces: rows as before, no score from this launch
+        res_c = torch.full((B, n0, C), -3.0, dtype=torch.bfloat16, device=DEV)
+        nxt3, none = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_c, next_rows, tokens, idx, count,
+                                             hidden_splits=3, next_class_head=head, foreground=fg_long)
+        assert none is None and nxt3.shape == got_next.shape
+
+
 @pytest.mark.parametrize("n,hw,mode", [(273, (13, 21), "enc"), (1050, (25, 42), "enc+coarse")])
 def test_salience_head_carrying_a_value_projection_job(n, hw, mode):
     """fused_head_value.hip: stage 1 of a coarse level and a slice of the encoder's value projection in ONE launch
