@@ -1,16 +1,18 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): the official bench line, its rocprofv3 kernel summary, the PMC passes behind
-# roofline.traffic, the MSDA kernel counters, the MFMA-busy counters of the dense kernels, the kernel A/B and the
-# full CPU-baseline protocol.      bash benchmarks/profile_round.sh r02
+# Runs on the GPU box (gpurun): the official bench line, its rocprofv3 kernel summary + step timeline, the PMC passes
+# behind roofline.traffic, the MSDA kernel counters, the MFMA-busy counters of the dense kernels, the kernel A/B, the
+# training step and the standalone micro-benchmarks.      bash benchmarks/profile_round.sh r03
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 # Counter passes carry --kernel-trace only (no other trace domain), one --pmc set per pass.
+# (The survey's full CPU-baseline protocol -- minutes of host time -- is `python bench.py --cpu-protocol full`; the
+# committed run of it is profiles/r02_bench_cpu_full.json: the CPU oracle has not changed since.)
 set -u
-R=${1:-r02}
+R=${1:-r03}
 O=$PWD/gpurun_out
 mkdir -p $O profiles
 export TMPDIR=/tmp
-# 1. PMC traffic passes first: the bench line's roofline.traffic is read from profiles/r02_msda_traffic.json
-python bench.py --no-cpu-baseline > $O/${R}_bench_quick.json 2> $O/${R}_bench_quick.err
+# 1. PMC traffic passes first: the bench line's roofline.traffic is read from profiles/r03_msda_traffic.json
+python bench.py --no-cpu-baseline --train-steps 0 --in-flight-report 0 > $O/${R}_bench_quick.json 2> $O/${R}_bench_quick.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${R}_pmc_$c -o p -- \
     python bench.py --plain --no-graph --steps 5 --warmup 3 > /dev/null 2> $O/${R}_pmc_$c.err
@@ -18,39 +20,36 @@ done
 F=$(find $O/${R}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find $O/${R}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 python benchmarks/pmc_to_traffic.py $F $W $O/${R}_bench_quick.json $O/${R}_msda_traffic.json && \
-  cp $O/${R}_msda_traffic.json profiles/r02_msda_traffic.json      # (this box's copy: what the bench run below reads)
-# 2. the official bench line; its kernel summary from the plain timed loop (six layers in equal proportion)
-python bench.py > $O/${R}_bench.json 2> $O/${R}_bench.err
-tail -c 400 $O/${R}_bench.json
+  cp $O/${R}_msda_traffic.json profiles/r03_msda_traffic.json      # (this box's copy: what the bench run below reads)
+rm -rf $O/${R}_pmc_FETCH_SIZE $O/${R}_pmc_WRITE_SIZE
+# 2. the official bench line (with the train_step sub-record and the CPU baseline); its kernel summary from the plain
+#    timed loop (six layers in equal proportion)
+python bench.py --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/${R}_bench.err
+tail -c 300 $O/${R}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof -o p -- python bench.py --plain --steps 50 > $O/${R}_bench_profiled.json 2> $O/${R}_prof.err
 cp $(find $O/${R}_prof -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv
 python benchmarks/step_timeline.py $(find $O/${R}_prof -name '*kernel_trace.csv' | head -1) > $O/${R}_step_timeline.txt
-head -12 $O/${R}_bench_kernel_stats.csv | cut -c1-150
-# 3. counters of the two fused MSDA forward kernels (layer 0 and layer 5 sizes)
+rm -rf $O/${R}_prof
+head -8 $O/${R}_bench_kernel_stats.csv | cut -c1-150
+# 3. counters of the two fused MSDA forward kernels (layer 0 size)
 bash benchmarks/pmc_msda.sh ${R} 11363 2 > /dev/null 2>&1
-bash benchmarks/pmc_msda.sh ${R}s 2272 2 > /dev/null 2>&1
+rm -rf $O/${R}_pmc_[1-5]
 # 4. MFMA-busy counters of the dense kernels
-i=0
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${R}_mfma_$i -o p -- \
-    python bench.py --plain --no-graph --steps 5 --warmup 3 > /dev/null 2> $O/${R}_mfma_$i.err
-done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES \
+  --kernel-trace --output-format csv -d $O/${R}_mfma_1 -o p -- \
+  python bench.py --plain --no-graph --steps 5 --warmup 3 > /dev/null 2> $O/${R}_mfma_1.err
 python benchmarks/mfma_busy_summary.py $O/${R}_mfma_ $O/${R}_mfma_busy.md > /dev/null
+rm -rf $O/${R}_mfma_1
 # 5. kernel A/B at batch 2 and at batch 16 (value maps beyond the 256 MiB Infinity Cache)
 python benchmarks/msda_resident_ab.py --out $O/${R}_msda_ab.json > /dev/null 2>&1
 python benchmarks/msda_resident_ab.py --batch 16 --reps 10 --out $O/${R}_msda_ab_b16.json > /dev/null 2>&1
-# 6. the survey's full CPU-baseline protocol (minutes)
-python bench.py --cpu-protocol full > $O/${R}_bench_cpu_full.json 2> $O/${R}_bench_cpu_full.err
-# 7. training step, for the backward kernel
+# 6. training step, for the backward kernel
 python bench.py --mode train --steps 5 --warmup 2 > $O/${R}_train.json 2> $O/${R}_train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o p -- python bench.py --mode train --steps 3 --warmup 1 > /dev/null 2> $O/${R}_prof_train.err
 cp $(find $O/${R}_prof_train -name '*kernel_stats.csv' | head -1) $O/${R}_train_kernel_stats.csv
-# 8. the MSDA backward kernels side by side, the fp32-accurate GEMM against the library
-python benchmarks/msda_backward_ab.py > $O/${R}_msda_backward_ab.json 2> /dev/null
-python benchmarks/gemm_x3_bench.py > $O/${R}_gemm_x3.json 2> /dev/null
-# 9. standalone micro-benchmarks behind the statements in DESIGN.md 6 / 8 (built by benchmarks/micro/build.sh)
-for m in ffn_two_wave graph_launch_floor valu_rate gather_rate kernel_cold_start; do
+rm -rf $O/${R}_prof_train
+# 7. standalone micro-benchmarks of this round (built by benchmarks/micro/build.sh)
+for m in l2_prefetch hsort_phases; do
   [ -x benchmarks/micro/$m ] && timeout 60 ./benchmarks/micro/$m > $O/${R}_$m.json 2> /dev/null
 done
 ls $O | grep "^${R}" | head -40

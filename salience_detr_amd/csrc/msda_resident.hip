@@ -37,10 +37,8 @@ constexpr int kRWaves = 16;                      // waves per workgroup, one wor
 constexpr int kRThreads = kRWaves * kWave;       // 1024
 constexpr int kRWeightBytes = 16 * 16 * 16;      // per wave: [sample 16][row 16] float4
 constexpr int kRPad = 64;                        // zeroed pixel before and after the resident slab
-constexpr int kRStage = 6;                       // 16-byte pieces per thread while staging
 constexpr int kRLdsBudget = 160 * 1024;
 constexpr int kRMaxResidentPx = (kRLdsBudget - kRWaves * kRWeightBytes - 2 * kRPad) / 64;  // 1534 pixels
-static_assert(kRMaxResidentPx * 4 <= kRStage * kRThreads, "staging loop covers the largest resident slab");
 
 struct ResidentArgs {
     const char *value;        // [B, M, Nv, 32] fp16 | bf16
@@ -142,18 +140,28 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
 
     const char *base = p.value + ((int64_t)b * p.M + m) * p.Nv * 64;
 
-    // ---- stage levels 2 and 3 of this (image, head): all loads first (the first row group's input loads are issued
-    // right behind them, see below), then the LDS stores.  Pieces past the slab are stored as zeros into the 64-byte
-    // pad behind it (all of them to its four slots: same value, benign overlap). ----
-    const int npieces = p.res_px * 4;
-    uint4 stage_v[kRStage];
+    // ---- stage levels 2 and 3 of this (image, head) with LDS-DMA (global_load_lds_dwordx4: no registers, no LDS store
+    // instructions): wave w copies the 1-KB pieces w, w + 16, ... of the slab; the copies fly while the first row
+    // group's inputs are loaded, its locations and weights are set up and its first level-0 / level-1 samples are
+    // requested -- the wait for them sits in front of the first LDS read of a map (first iteration of the loop below).
+    // The 64-byte zero pads in front of and behind the slab are plain stores. ----
     {
         const char *src = base + (int64_t)p.S2 * 64;
-#pragma unroll
-        for (int i = 0; i < kRStage; ++i) {
-            const int piece = tid + i * kRThreads;
-            stage_v[i] = *reinterpret_cast<const uint4 *>(src + (int64_t)min(piece, npieces - 1) * 16);
+        const uint32_t lds0 = (uint32_t)(uint64_t)(lds + kRPad);
+        const int pieces = (slab_bytes + 1023) >> 10;
+        for (int piece = wave; piece < pieces; piece += kRWaves) {
+            const uint32_t goff = (uint32_t)piece * 1024u + (uint32_t)lane * 16u;
+            if (goff < (uint32_t)slab_bytes) {   // (the last piece is partial: its idle lanes copy nothing)
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)piece * 1024u);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %2"
+                             :
+                             : "v"(goff), "s"(m0v), "s"(src)
+                             : "memory", "m0");
+            }
         }
+        if (tid < 4) *reinterpret_cast<uint4 *>(lds + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+        else if (tid < 8) *reinterpret_cast<uint4 *>(lds + kRPad + slab_bytes + (tid - 4) * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
 
     // ---- rows: a quad per (query, head); lane j of the quad owns level j ----
@@ -199,19 +207,13 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
     };
     const int ngroups = (q_hi - q_lo + 15) >> 4;
     RowIn nxt = load_row(min(wave, ngroups - 1));
-    __builtin_amdgcn_sched_barrier(0);  // the row loads above stay in flight across the staging stores
-    {
-        if (tid < 4) *reinterpret_cast<uint4 *>(lds + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int i = 0; i < kRStage; ++i) {
-            const int piece = tid + i * kRThreads;
-            const bool real = piece < npieces;
-            *reinterpret_cast<uint4 *>(lds + kRPad + min(piece, npieces + 3) * 16) =
-                make_uint4(real ? stage_v[i].x : 0u, real ? stage_v[i].y : 0u, real ? stage_v[i].z : 0u,
-                           real ? stage_v[i].w : 0u);
-        }
+    bool maps_pending = true;   // the staged maps have not been waited for yet (wave-uniform)
+    if (wave >= ngroups) {
+        // no row group for this wave: its pieces of the maps still have to land before the others read them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        return;
     }
-    __syncthreads();
     for (int rg = wave; rg < ngroups; rg += kRWaves) {
         const int slot = q_lo + rg * 16 + g;
         const bool active = slot < q_hi;
@@ -316,6 +318,15 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
 #define SDETR_FENCE __builtin_amdgcn_sched_barrier(0);
         uint4 va[4][4];
         SDETR_RES_ISSUE(0, 0, 0) SDETR_RES_ISSUE(1, 0, 1) SDETR_RES_ISSUE(2, 0, 2) SDETR_RES_ISSUE(3, 0, 3) SDETR_FENCE
+        if (maps_pending) {
+            // first row group of this wave: everything it could do without the resident maps is under way.  Loads
+            // complete in order, so an empty queue means this wave's copies have landed; the barrier does the same for
+            // the other waves' pieces (waves without a row group have exited: the barrier does not count them).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            maps_pending = false;
+        }
+        SDETR_FENCE
         SDETR_RES_LDS(2, 0) SDETR_FENCE SDETR_RES_ACC(0, 0, 0) SDETR_FENCE SDETR_RES_ISSUE(0, 1, 0) SDETR_FENCE
         SDETR_RES_LDS(2, 1) SDETR_FENCE SDETR_RES_ACC(1, 0, 1) SDETR_FENCE SDETR_RES_ISSUE(1, 1, 1) SDETR_FENCE
         SDETR_RES_LDS(2, 2) SDETR_FENCE SDETR_RES_ACC(2, 0, 2) SDETR_FENCE SDETR_RES_ISSUE(2, 1, 2) SDETR_FENCE

@@ -515,7 +515,7 @@ def test_token_linear_ln_matches_reference_and_scatters(B, n):
         assert out is dst and torch.equal(dst, want)
 
 
-@pytest.mark.parametrize("sizes", [[5], [300, 200, 100, 7], [6680, 3360, 1050, 273], [1, 1, 1], [0, 4, 0, 9]])
+@pytest.mark.parametrize("sizes", [[5], [300, 200, 100, 7], [6680, 3360, 1050, 273], [1, 1, 1], [0, 4, 0, 9], [12000, 5000, 2000]])
 def test_merge_of_sorted_segments_is_the_stable_sort(sizes):
     B = 2
     torch.manual_seed(sum(sizes))
