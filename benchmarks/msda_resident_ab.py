@@ -59,9 +59,14 @@ def main():
     ap.add_argument("--chunks", default="0")
     ap.add_argument("--nq", default="11363,9090,6817,4545,2272,900")
     ap.add_argument("--sorted", action="store_true", help="queries in spatial (token) order instead of random order")
+    ap.add_argument("--levels", default="4scale", choices=["4scale", "5scale"],
+                    help="5scale: the reference's strides 4-32 pyramid (level 3 alone resident in LDS)")
     ap.add_argument("--out", default="gpurun_out/msda_ab.json")
     args = ap.parse_args()
     B = args.batch
+    global LEVELS
+    if args.levels == "5scale":
+        LEVELS = [(200, 336), (100, 168), (50, 84), (25, 42)]
     Nv = sum(h * w for h, w in LEVELS)
     hm = M.value_to_head_major(torch.randn(B, Nv, 256, device=DEV), None, HEADS, torch.float16)
     rows = []

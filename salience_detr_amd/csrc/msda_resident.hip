@@ -51,7 +51,8 @@ struct ResidentArgs {
     int B, Nv, M, Nq;
     int H0, W0, H1, W1, H2, W2, H3, W3;   // host copy of the level shapes
     int S1, S2, S3;                       // level start pixels (S0 = 0)
-    int res_px;                           // Nv - S2: pixels resident in LDS
+    int res_start;                        // first resident pixel: S2 (levels 2 + 3 resident) or S3 (level 3 only)
+    int res_px;                           // Nv - res_start: pixels resident in LDS
     int chunks;                           // workgroups per (image, head)
 };
 
@@ -117,7 +118,10 @@ __device__ __forceinline__ float quad_xor2(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
 }
 
-template <typename VT, bool REF4>
+// RES = number of resident levels: 2 (levels 2 + 3, the benchmark pyramid: 8 of a row's 16 samples come from LDS) or 1
+// (level 3 only, for pyramids whose two coarse levels together exceed the LDS -- the reference's 5scale configuration,
+// configs/salience_detr/salience_detr_resnet50_5scale_800_1333.py:33-36: 4 of the 16 samples).
+template <typename VT, bool REF4, int RES = 2>
 __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p)
 {
     using F = ResFma<VT>;
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
     // requested -- the wait for them sits in front of the first LDS read of a map (first iteration of the loop below).
     // The 64-byte zero pads in front of and behind the slab are plain stores. ----
     {
-        const char *src = base + (int64_t)p.S2 * 64;
+        const char *src = base + (int64_t)p.res_start * 64;
         const uint32_t lds0 = (uint32_t)(uint64_t)(lds + kRPad);
         const int pieces = (slab_bytes + 1023) >> 10;
         for (int piece = wave; piece < pieces; piece += kRWaves) {
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
     const float fH = (float)H, fW = (float)W;
     const float invW = 1.0f / fW, invH = 1.0f / fH;
     // byte offset of this lane's level: into the head's global slab (levels 0, 1) or into `lds` (levels 2, 3)
-    const uint32_t lvl_base = j < 2 ? (uint32_t)S * 64u : (uint32_t)(kRPad + (S - p.S2) * 64);
+    const uint32_t lvl_base = j < 4 - RES ? (uint32_t)S * 64u : (uint32_t)(kRPad + (S - p.res_start) * 64);
     const uint32_t lane_off = (uint32_t)(j * 16);
     const __amdgpu_buffer_rsrc_t rsrc = make_uniform_rsrc(base, (uint32_t)((int64_t)p.Nv * 64));
     // the head's block of the projection slab and the image's reference points through buffer resources too:
@@ -327,14 +331,28 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
             maps_pending = false;
         }
         SDETR_FENCE
-        SDETR_RES_LDS(2, 0) SDETR_FENCE SDETR_RES_ACC(0, 0, 0) SDETR_FENCE SDETR_RES_ISSUE(0, 1, 0) SDETR_FENCE
-        SDETR_RES_LDS(2, 1) SDETR_FENCE SDETR_RES_ACC(1, 0, 1) SDETR_FENCE SDETR_RES_ISSUE(1, 1, 1) SDETR_FENCE
-        SDETR_RES_LDS(2, 2) SDETR_FENCE SDETR_RES_ACC(2, 0, 2) SDETR_FENCE SDETR_RES_ISSUE(2, 1, 2) SDETR_FENCE
-        SDETR_RES_LDS(2, 3) SDETR_FENCE SDETR_RES_ACC(3, 0, 3) SDETR_FENCE SDETR_RES_ISSUE(3, 1, 3) SDETR_FENCE
-        SDETR_RES_LDS(3, 0) SDETR_FENCE SDETR_RES_ACC(0, 1, 0) SDETR_FENCE
-        SDETR_RES_LDS(3, 1) SDETR_FENCE SDETR_RES_ACC(1, 1, 1) SDETR_FENCE
-        SDETR_RES_LDS(3, 2) SDETR_FENCE SDETR_RES_ACC(2, 1, 2) SDETR_FENCE
-        SDETR_RES_LDS(3, 3) SDETR_FENCE SDETR_RES_ACC(3, 1, 3) SDETR_FENCE
+        if (RES == 2) {
+            SDETR_RES_LDS(2, 0) SDETR_FENCE SDETR_RES_ACC(0, 0, 0) SDETR_FENCE SDETR_RES_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_RES_LDS(2, 1) SDETR_FENCE SDETR_RES_ACC(1, 0, 1) SDETR_FENCE SDETR_RES_ISSUE(1, 1, 1) SDETR_FENCE
+            SDETR_RES_LDS(2, 2) SDETR_FENCE SDETR_RES_ACC(2, 0, 2) SDETR_FENCE SDETR_RES_ISSUE(2, 1, 2) SDETR_FENCE
+            SDETR_RES_LDS(2, 3) SDETR_FENCE SDETR_RES_ACC(3, 0, 3) SDETR_FENCE SDETR_RES_ISSUE(3, 1, 3) SDETR_FENCE
+            SDETR_RES_LDS(3, 0) SDETR_FENCE SDETR_RES_ACC(0, 1, 0) SDETR_FENCE
+            SDETR_RES_LDS(3, 1) SDETR_FENCE SDETR_RES_ACC(1, 1, 1) SDETR_FENCE
+            SDETR_RES_LDS(3, 2) SDETR_FENCE SDETR_RES_ACC(2, 1, 2) SDETR_FENCE
+            SDETR_RES_LDS(3, 3) SDETR_FENCE SDETR_RES_ACC(3, 1, 3) SDETR_FENCE
+        } else {
+            // level 3 from LDS, levels 0-2 through the L1: twelve global samples rolling through the four slots
+            SDETR_RES_LDS(3, 0) SDETR_FENCE SDETR_RES_ACC(0, 0, 0) SDETR_FENCE SDETR_RES_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_RES_LDS(3, 1) SDETR_FENCE SDETR_RES_ACC(1, 0, 1) SDETR_FENCE SDETR_RES_ISSUE(1, 1, 1) SDETR_FENCE
+            SDETR_RES_LDS(3, 2) SDETR_FENCE SDETR_RES_ACC(2, 0, 2) SDETR_FENCE SDETR_RES_ISSUE(2, 1, 2) SDETR_FENCE
+            SDETR_RES_LDS(3, 3) SDETR_FENCE SDETR_RES_ACC(3, 0, 3) SDETR_FENCE SDETR_RES_ISSUE(3, 1, 3) SDETR_FENCE
+            SDETR_RES_ACC(0, 1, 0) SDETR_FENCE SDETR_RES_ISSUE(0, 2, 0) SDETR_FENCE
+            SDETR_RES_ACC(1, 1, 1) SDETR_FENCE SDETR_RES_ISSUE(1, 2, 1) SDETR_FENCE
+            SDETR_RES_ACC(2, 1, 2) SDETR_FENCE SDETR_RES_ISSUE(2, 2, 2) SDETR_FENCE
+            SDETR_RES_ACC(3, 1, 3) SDETR_FENCE SDETR_RES_ISSUE(3, 2, 3) SDETR_FENCE
+            SDETR_RES_ACC(0, 2, 0) SDETR_FENCE SDETR_RES_ACC(1, 2, 1) SDETR_FENCE
+            SDETR_RES_ACC(2, 2, 2) SDETR_FENCE SDETR_RES_ACC(3, 2, 3) SDETR_FENCE
+        }
 #undef SDETR_FENCE
 #undef SDETR_RES_ISSUE
 #undef SDETR_RES_ACC
@@ -406,9 +424,16 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     if (s3 + (int64_t)a.H3 * a.W3 != Nv) return fail("msda_resident_forward: level shapes do not add up to %d pixels", Nv);
     if ((int64_t)Nv * 64 >= 0xffffffffLL) return fail("msda_resident_forward: value map too large for 32-bit offsets");
     a.S1 = (int)s1; a.S2 = (int)s2; a.S3 = (int)s3;
-    a.res_px = Nv - a.S2;
+    // levels 2 + 3 resident when they fit together, else level 3 alone
+    int res_levels = 2;
+    a.res_start = a.S2;
+    if (Nv - a.S2 > kRMaxResidentPx) {
+        res_levels = 1;
+        a.res_start = a.S3;
+    }
+    a.res_px = Nv - a.res_start;
     if (a.res_px > kRMaxResidentPx)
-        return fail("msda_resident_forward: levels 2+3 hold %d pixels, more than the %d that fit in LDS", a.res_px,
+        return fail("msda_resident_forward: level 3 alone holds %d pixels, more than the %d that fit in LDS", a.res_px,
                     kRMaxResidentPx);
     if ((int64_t)B * Nq == 0) return 0;
     a.value = reinterpret_cast<const char *>(value_hm);
@@ -429,15 +454,20 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     if (blocks > 0x7fffffffLL) return fail("msda_resident_forward: grid too large");
     const int lds_bytes = 2 * kRPad + a.res_px * 64 + kRWaves * kRWeightBytes;
     // the attribute is per device and the call is cheap: set before every launch (no process-wide flag)
-#define SDETR_RES_LAUNCH(VT, REF4)                                                                         \
+#define SDETR_RES_LAUNCH(VT, REF4, RES)                                                                    \
     do {                                                                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4>),          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4, RES>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                    \
-        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4>), dim3((unsigned)blocks), dim3(kRThreads),      \
+        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4, RES>), dim3((unsigned)blocks), dim3(kRThreads), \
                            lds_bytes, stream, a);                                                              \
     } while (0)
-    if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true);
-    else SDETR_RES_LAUNCH(half_t, false);
+    if (res_levels == 2) {
+        if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true, 2);
+        else SDETR_RES_LAUNCH(half_t, false, 2);
+    } else {
+        if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true, 1);
+        else SDETR_RES_LAUNCH(half_t, false, 1);
+    }
 #undef SDETR_RES_LAUNCH
     note_forward_kernel(SDETR_KERNEL_MSDA_RESIDENT);
     return check_launch("msda_resident");

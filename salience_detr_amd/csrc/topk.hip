@@ -352,10 +352,12 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
     const float scale = (span > 0.f && span < INFINITY) ? (float)kHsBins / span : 0.f;
     const float top = (span >= 0.f && span < INFINITY) ? smax : 0.f;
     auto bin_of = [&](uint32_t key) -> uint32_t {
-        // monotone in the key order: fl(top - v) and the product are monotone, the clamp sends +inf to bin 0 and -inf
-        // to the last bin, the conversion truncates
+        // monotone in the key order: fl(top - v) and the product are monotone, the conversion truncates
+        // keys outside the finite range (infinities, NaN bit patterns) sort before or after every finite key: end bins
+        if (key <= 0x007fffffu) return 0u;                         // +inf and what the key order puts in front of it
+        if (key >= 0xff800000u) return (uint32_t)(kHsBins - 1);    // -inf and what it puts behind
         const float d = (top - undesc_bits(key)) * scale;
-        return (uint32_t)fminf(fmaxf(d, 0.f), (float)(kHsBins - 1));   // (fmaxf(NaN, 0) = 0)
+        return (uint32_t)fminf(fmaxf(d, 0.f), (float)(kHsBins - 1));
     };
     HS_STAMP(1);   // keys loaded, floor group and score range known
     // ---- histogram of the other keys ----

@@ -229,8 +229,9 @@ _RESIDENT_MAX = None
 
 
 def resident_supported(value_hm: Tensor, level_shapes, num_levels: int, num_points: int) -> bool:
-    """Whether ``msda_resident_forward`` (levels 2+3 of the pyramid resident in LDS) covers this call: fp16 head-major
-    maps with 32-channel heads, 4 levels x 4 points, a host copy of the level shapes, and coarse levels that fit."""
+    """Whether ``msda_resident_forward`` (levels 2+3 of the pyramid resident in LDS, or level 3 alone when the two do not
+    fit together -- the reference's 5scale pyramid) covers this call: fp16 head-major maps with 32-channel heads, 4 levels
+    x 4 points, a host copy of the level shapes, and a coarsest level that fits."""
     global _RESIDENT_MAX
     if (level_shapes is None or len(level_shapes) != 4 or num_levels != 4 or num_points != 4
             or value_hm.dtype != torch.float16 or value_hm.shape[-1] != 32):
@@ -239,7 +240,7 @@ def resident_supported(value_hm: Tensor, level_shapes, num_levels: int, num_poin
         return False
     if _RESIDENT_MAX is None:
         _RESIDENT_MAX = int(_hip.lib().sdetr_msda_resident_max_pixels())
-    return sum(int(h) * int(w) for h, w in level_shapes[2:]) <= _RESIDENT_MAX
+    return int(level_shapes[3][0]) * int(level_shapes[3][1]) <= _RESIDENT_MAX
 
 
 def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tensor, proj_hm: Tensor,

@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 LEVELS_FULL = [(100, 168), (50, 84), (25, 42), (13, 21)]
 LEVELS_SMALL = [(20, 30), (10, 15), (5, 8), (3, 4)]
+LEVELS_5SCALE = [(200, 336), (100, 168), (50, 84), (25, 42)]   # levels 2 + 3 exceed the LDS: level 3 alone is resident
+LEVELS_L3_ONLY = [(40, 60), (40, 50), (30, 45), (16, 20)]       # a small pyramid that takes the same variant
 HEADS, D, L, P = 8, 32, 4, 4
 TOL = 2e-4
 
@@ -92,7 +94,8 @@ def test_l4p4_kernel_vs_oracle(B, Nq, levels, vdt, ref_dim):
 
 @pytest.mark.parametrize("ref_dim", [2, 4])
 @pytest.mark.parametrize("chunks", [0, 1, 7])
-@pytest.mark.parametrize("B,Nq,levels", CASES + [(1, 40, LEVELS_SMALL), (3, 1000, LEVELS_FULL)])
+@pytest.mark.parametrize("B,Nq,levels", CASES + [(1, 40, LEVELS_SMALL), (3, 1000, LEVELS_FULL), (2, 777, LEVELS_L3_ONLY),
+                                                 (1, 4533, LEVELS_5SCALE)])
 def test_resident_kernel_vs_oracle(B, Nq, levels, chunks, ref_dim):
     if chunks and Nq > 3000:
         pytest.skip("chunk sweeps on the small cases only")
@@ -137,7 +140,10 @@ def test_resident_rejects_unsupported():
     hm = torch.zeros(1, 8, 20 * 30 + 10 * 15 + 5 * 8 + 3 * 4, 32, dtype=torch.bfloat16, device=DEV)
     assert not M.resident_supported(hm, LEVELS_SMALL, 4, 4)            # bf16 maps stay on the direct kernel
     assert not M.resident_supported(hm.half(), LEVELS_SMALL[:3], 4, 4)
-    big = [(200, 336), (100, 168), (50, 84), (25, 42)]                  # the 5scale pyramid: coarse levels too large
+    # the 5scale pyramid: levels 2 + 3 do not fit together, level 3 does -> the level-3-only variant takes it
+    assert M.resident_supported(torch.zeros(1, 1, sum(h * w for h, w in LEVELS_5SCALE), 32, dtype=torch.float16,
+                                            device=DEV), LEVELS_5SCALE, 4, 4)
+    big = [(400, 672), (200, 336), (100, 168), (50, 84)]                # a coarsest level of 4200 pixels: too large
     assert not M.resident_supported(torch.zeros(1, 1, sum(h * w for h, w in big), 32, dtype=torch.float16, device=DEV),
                                     big, 4, 4)
     with pytest.raises(RuntimeError):
