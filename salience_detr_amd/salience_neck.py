@@ -223,11 +223,13 @@ class RepVGGPluXNetwork(nn.Module):
             x = x + branch
         return x
 
-    def forward_levels(self, levels: Sequence[Tensor], shapes: Sequence[Tuple[int, int]]) -> List[Tensor]:
-        """Token-major levels ``[B, h*w, C]`` (fine to coarse) -> the same (repnet.py:211-245)."""
+    def forward_levels(self, levels: Sequence[Tensor], shapes: Sequence[Tuple[int, int]],
+                       differentiable: bool = False) -> List[Tensor]:
+        """Token-major levels ``[B, h*w, C]`` (fine to coarse) -> the same (repnet.py:211-245).  ``differentiable``: take
+        the torch-op form also in eval mode (running statistics in the norms) -- the fused kernels have no backward."""
         if len(levels) != len(self.layer_blocks) + 1:
             raise RuntimeError("RepVGGPluXNetwork: wrong number of levels")
-        if self.training:
+        if self.training or differentiable:
             if not levels[0].is_cuda:
                 raise RuntimeError("RepVGGPluXNetwork: HIP device tensors required; there is no CPU fallback")
             maps = [x.transpose(1, 2).reshape(x.shape[0], x.shape[2], int(h), int(w)) for x, (h, w) in zip(levels, shapes)]
@@ -257,7 +259,11 @@ class RepVGGPluXNetwork(nn.Module):
         from .data_parallel import sync_batch_norm_train
         conv = m[0]
         y = torch.nn.functional.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, 1, conv.groups)
-        y = sync_batch_norm_train(y, m[1], self.process_group)
+        if self.training:
+            y = sync_batch_norm_train(y, m[1], self.process_group)
+        else:   # eval mode under autograd: running statistics, as nn.BatchNorm2d.eval()
+            bn = m[1]
+            y = torch.nn.functional.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         return torch.nn.functional.silu(y) if act else y
 
     @staticmethod
@@ -294,12 +300,12 @@ class RepVGGPluXNetwork(nn.Module):
             outs.append(self._csp_train(self.pan_blocks[idx], torch.cat([down, inner[idx + 1]], 1)))
         return outs
 
-    def forward_memory(self, memory: Tensor, level_shapes: Sequence[Tuple[int, int]]) -> Tensor:
+    def forward_memory(self, memory: Tensor, level_shapes: Sequence[Tuple[int, int]], differentiable: bool = False) -> Tensor:
         """``memory`` ``[B, sum h*w, C]`` -> the neck's output in the same layout
         (models/bricks/salience_transformer.py:185-192 without its transposes)."""
         sizes = [int(h) * int(w) for h, w in level_shapes]
         levels = [m.contiguous() for m in memory.split(sizes, 1)]
-        return torch.cat(self.forward_levels(levels, level_shapes), 1)
+        return torch.cat(self.forward_levels(levels, level_shapes, differentiable), 1)
 
     def forward(self, x: "OrderedDict[str, Tensor]"):
         keys = list(x.keys())

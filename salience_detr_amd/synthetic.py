@@ -209,3 +209,26 @@ def sine_position_embedding(mask: torch.Tensor, num_pos_feats: int = 128, temper
         return torch.stack((even, odd), dim=-1).flatten(-2)              # sin, cos interleaved
 
     return torch.cat((axis_features(1), axis_features(2)), dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
+def train_loss_weights(shapes):
+    """Fixed weights of the synthetic whole-transformer training loss ``sum_i (output_i * w_i).sum()``, one tensor per
+    output (name-seeded: the golden generator and the tests build the same ones)."""
+    return [det_randn(f"train.loss.w{i}", tuple(sh)) for i, sh in enumerate(shapes)]
+
+
+def denoising_inputs(B: int, E: int, proposals: int, n_dn: int = 6):
+    """Denoising queries as the detector hands them to the transformer (reference models/detectors/salience_detr.py:
+    the GenerateCDNQueries outputs): label embeddings ``[B,n_dn,E]``, inverse-sigmoid boxes ``[B,n_dn,4]`` and the
+    ``[n_dn+proposals]^2`` attention mask (True = may not attend) that hides the two groups from each other and from the
+    matching queries."""
+    label_q = det_randn("train.dn.label", (B, n_dn, E)) * 0.5
+    box_q = det_randn("train.dn.box", (B, n_dn, 4))
+    n = n_dn + proposals
+    mask = torch.zeros(n, n, dtype=torch.bool)
+    mask[n_dn:, :n_dn] = True
+    half = n_dn // 2
+    mask[:half, half:n_dn] = True
+    mask[half:n_dn, :half] = True
+    return label_q, box_q, mask
+

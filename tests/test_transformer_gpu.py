@@ -222,3 +222,69 @@ def test_fp16_request_runs_config5_shape():
     assert out[0].shape == (6, 2, 900, 91) and out[1].shape == (6, 2, 900, 4)
     assert all(torch.isfinite(t.float()).all() for t in out[:4])
     assert (out[1] >= 0).all() and (out[1] <= 1).all()
+
+
+@pytest.mark.parametrize("tag", ["plain", "neck"])
+def test_whole_transformer_training_step_matches_reference_gradients(gold, tag):
+    """``SalienceTransformer.forward`` under autograd with denoising queries (salience_transformer.py:195-233; train mode:
+    the neck's norms take batch statistics): the five outputs, the loss of fixed random weights on them and the gradients
+    of a spread of parameters -- filtering head, encoder layers, proposal heads, neck, decoder, embeddings -- and of the
+    finest input level against what the imported reference produced (tests/golden/make_golden.py transformer_train)."""
+    t = np.load(os.path.join(G, "transformer_train_small.npz"))
+    neck_fixture = {"sd_keys": t["neck.sd_keys"], "sd_crc": t["neck.sd_crc"]} if tag == "neck" else None
+    tr, sd = build_product_transformer(gold, neck_fixture)
+    assert sorted(sd) == t[f"{tag}.sd_keys"].tolist()
+    tr = tr.cuda().train()
+    E, proposals = int(gold["hyper"][0]), int(gold["hyper"][8])
+    feats, masks, pos = [[x.cuda() for x in part] for part in inputs(gold)]
+    feats[0].requires_grad_(True)
+    label_q, box_q, attn_mask = [x.cuda() for x in syn.denoising_inputs(feats[0].shape[0], E, proposals, int(t["dn"]))]
+    out_cls, out_box, enc_cls, enc_box, sal = tr(feats, masks, pos, label_q, box_q, attn_mask)
+    assert (enc_cls.cpu() - _t(t[f"{tag}.enc_outputs_class"])).abs().max() < 1e-3
+    assert (enc_box.cpu() - _t(t[f"{tag}.enc_outputs_coord"])).abs().max() < 1e-4
+    assert (out_cls.cpu() - _t(t[f"{tag}.outputs_classes"])).abs().max() < 2e-3
+    assert (out_box.cpu() - _t(t[f"{tag}.outputs_coords"])).abs().max() < 2e-4
+    outs = [out_cls, out_box, enc_cls, enc_box] + list(sal)
+    ws = syn.train_loss_weights([o.shape for o in outs])
+    loss = sum((o * w.cuda()).sum() for o, w in zip(outs, ws))
+    loss.backward()
+    want_loss = float(t[f"{tag}.loss"])
+    assert abs(loss.item() - want_loss) < 2e-3 * max(1.0, abs(want_loss)), (loss.item(), want_loss)
+    params = dict(tr.named_parameters(remove_duplicate=False))
+    names = t["grad_names"].tolist() + (t["neck_grad_names"].tolist() if tag == "neck" else [])
+    worst = {}
+    for n in names:
+        g = params[n].grad
+        assert g is not None, n
+        g = g.detach().cpu()
+        if g.numel() > 4096 and g.dim() >= 2:
+            g = g[::4, ::4]
+        ref = _t(t[f"{tag}.grad.{n}"])
+        assert g.shape == ref.shape, n
+        worst[n] = ((g - ref).abs().max() / max(1.0, ref.abs().max().item())).item()
+    gf = feats[0].grad.cpu()[:, ::8]
+    ref = _t(t[f"{tag}.grad.feat0"])
+    worst["feat0"] = ((gf - ref).abs().max() / max(1.0, ref.abs().max().item())).item()
+    bad = {n: e for n, e in worst.items() if not e < 2e-3}
+    assert not bad, bad
+    if tag == "neck":   # the training-mode forward also moved the norms' running statistics, as nn.BatchNorm2d does
+        bn = tr.neck.lateral_convs[0][1]
+        assert (bn.running_mean.cpu() - _t(t["neck.running_mean.lateral0"])).abs().max() < 1e-4
+        assert (bn.running_var.cpu() - _t(t["neck.running_var.lateral0"])).abs().max() < 1e-4
+
+
+def test_whole_transformer_eval_mode_is_differentiable_too(gold):
+    """eval() + grad mode (fine-tuning with frozen norm statistics): the neck takes its torch-op form with running
+    statistics; the forward equals the no-grad kernels' and a gradient reaches the input."""
+    neck = np.load(os.path.join(G, "transformer_small_neck.npz"))
+    tr, _ = build_product_transformer(gold, neck)
+    tr = tr.cuda().eval()
+    feats, masks, pos = [[x.cuda() for x in part] for part in inputs(gold)]
+    with torch.no_grad():
+        want = tr(feats, masks, pos)
+    feats[1].requires_grad_(True)
+    got = tr(feats, masks, pos)
+    assert (got[0] - want[0]).abs().max() < 2e-3 and (got[1] - want[1]).abs().max() < 2e-4
+    (got[0].sum() + got[2].sum()).backward()
+    assert feats[1].grad is not None and torch.isfinite(feats[1].grad).all() and feats[1].grad.abs().max() > 0
+
