@@ -44,11 +44,24 @@ struct GemmArgs {
     int64_t b_plane;       // pre-split B: elements between its three planes
     float *a_row_sum;      // optional [M]: sum_k A(m, k) accumulated with atomics (zero on entry) -- the bias gradient
                            // sum_t dy[t][n] next to dw = dy^T x; reduction-major A only
+    uint32_t a_bytes, b_bytes;   // extents of the operands (second-generation kernel: buffer resources)
 };
+
+// (benchmarks/micro/gemm_x3_ablate.hip compiles this file with SDETR_GX3_ABLATE = 1: no MFMAs, 2: no operand split,
+// 3: no global loads after the first tiles, 4: no LDS tile stores, 5: no barrier, 6: no fragment reads (second-generation
+// kernel) -- where the kernel's time goes.  0 / undefined in the library.)
+#ifndef SDETR_GX3_ABLATE
+#define SDETR_GX3_ABLATE 0
+#endif
 
 __device__ __forceinline__ g_f32x16_t g_mfma(u32x4_t a, u32x4_t b, g_f32x16_t c)
 {
+#if SDETR_GX3_ABLATE == 1
+    c[0] += __uint_as_float(a[0] ^ b[0]);   // keeps the operands alive
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g_bf16x8_t, a), __builtin_bit_cast(g_bf16x8_t, b), c, 0, 0, 0);
+#endif
 }
 
 // Exact three-way split of an MFMA operand fragment (8 fp32 values consecutive along the reduction index) into
@@ -69,6 +82,13 @@ struct Frag3 {
 __device__ __forceinline__ Frag3 g_split(const float4 lo, const float4 hi)
 {
     const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#if SDETR_GX3_ABLATE == 2
+    Frag3 raw;
+    raw.p[0] = u32x4_t{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])};
+    raw.p[1] = u32x4_t{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])};
+    raw.p[2] = raw.p[0];
+    return raw;
+#endif
     float r1[8], r2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -178,8 +198,10 @@ __device__ __forceinline__ void gemm_x3_step(const GemmArgs &p, TileLoad<A_KMAJO
     ta.store(pa, tid);
     tb.store(pb, tid);
     __syncthreads();
+#if SDETR_GX3_ABLATE != 3
     ta.load(p.a, p.lda, m0, p.M, k0 + 2 * kGK, kend, tid);   // (reads as zeros past the end)
     tb.load(p.b, p.ldb, n0, p.N, k0 + 2 * kGK, kend, tid);
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         Frag3 a[2], b[2];
@@ -366,6 +388,279 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_pre_kernel(GemmArgs p)
     }
 }
 
+// ---- second generation (round 3): 256 x 128 x 32 tiles, one 8-wave workgroup per CU ---------------------------------
+// Counters and ablations of the kernels above on the feed-forward's first product (22 726 x 256 -> 2048, 201 us): the
+// matrix pipes are busy 35 % of the time and the vector ALUs 46 %, one after the other -- and WITHOUT the operand split
+// it still takes 177 us where its MFMAs alone are 71 (benchmarks/micro/gemm_x3_ablate.hip).  The hardware does overlap
+// the two pipes, across the wavefronts of a SIMD and inside one (benchmarks/micro/mfma_valu_overlap.hip: 176 VALU + 24
+// MFMA per wavefront, two per SIMD: 940 cycles each where the sum is 1630).  What the first generation loses is the
+// barrier pair around every 32-deep step with ONE tile buffer: the four wavefronts of a workgroup share their SIMDs with
+// another workgroup's in an unrelated phase, so at every barrier three of them wait for the one that found its matrix
+// pipe taken (a 1536-cycle burst).  Here both wavefronts of a SIMD belong to the SAME workgroup (no foreign phase), the
+// tiles are double-buffered in LDS (one barrier per step, between its two k-halves), and a wavefront reads and splits the
+// fragments of the NEXT k-half while the MFMAs of the current one run (same-wavefront overlap; loads through buffer
+// resources, out-of-range pieces by offset select: no branch inside a step, so the scheduler sees one block).
+constexpr int kV2M = 256, kV2N = 128, kV2Threads = 512;
+constexpr int kV2A = kV2M * kGRow;                   // 36 864 bytes: the A tile, fp32 rows of 144 bytes
+constexpr int kV2Bf = kV2N * kGRow;                  // 18 432: B as fp32 rows
+constexpr int kV2Bp = 3 * kV2N * kGPreRow;           // 30 720: B as three bf16 planes (rows of 80 bytes)
+constexpr int kV2PrePlane = kV2N * kGPreRow;         // 10 240
+
+// byte offset or, when the piece is out of range, an offset no buffer contains (the load then returns zeros)
+__device__ __forceinline__ uint32_t v2_off(bool ok, uint32_t off) { return ok ? off : 0xfffffff0u; }
+
+// A tile (256 x 32 fp32): 16 floats per thread; threads 0-255 rows 0-127, threads 256-511 rows 128-255
+template <bool KMAJOR>
+struct V2LoadA {
+    uint4 v0, v1, v2, v3;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, uint32_t ld, int row0, int rows, int k0, int kend, int tid)
+    {
+        const int u = tid & 255, half = tid >> 8;
+        if (KMAJOR) {
+            const int c4 = u & 7, r = row0 + 128 * half + (u >> 3), k = k0 + 4 * c4;
+            const bool kok = k < kend;
+            const uint32_t o = ((uint32_t)r * ld + (uint32_t)k) * 4u, step = 32u * ld * 4u;
+            v0 = buffer_load16(rs, v2_off(kok && r < rows, o));
+            v1 = buffer_load16(rs, v2_off(kok && r + 32 < rows, o + step));
+            v2 = buffer_load16(rs, v2_off(kok && r + 64 < rows, o + 2u * step));
+            v3 = buffer_load16(rs, v2_off(kok && r + 96 < rows, o + 3u * step));
+        } else {
+            const int kb = u >> 5, mb = u & 31, row = row0 + 128 * half + 4 * mb, k = k0 + 4 * kb;
+            const bool rok = row < rows;
+            const uint32_t o = ((uint32_t)k * ld + (uint32_t)row) * 4u, step = ld * 4u;
+            v0 = buffer_load16(rs, v2_off(rok && k < kend, o));
+            v1 = buffer_load16(rs, v2_off(rok && k + 1 < kend, o + step));
+            v2 = buffer_load16(rs, v2_off(rok && k + 2 < kend, o + 2u * step));
+            v3 = buffer_load16(rs, v2_off(rok && k + 3 < kend, o + 3u * step));
+        }
+    }
+    __device__ __forceinline__ void store(char *tile, int tid) const
+    {
+        const int u = tid & 255, half = tid >> 8;
+        if (KMAJOR) {
+            char *d = tile + (128 * half + (u >> 3)) * kGRow + 16 * (u & 7);
+            *reinterpret_cast<uint4 *>(d) = v0;
+            *reinterpret_cast<uint4 *>(d + 32 * kGRow) = v1;
+            *reinterpret_cast<uint4 *>(d + 64 * kGRow) = v2;
+            *reinterpret_cast<uint4 *>(d + 96 * kGRow) = v3;
+        } else {
+            char *d = tile + (128 * half + 4 * (u & 31)) * kGRow + 16 * (u >> 5);   // 4 x 4 block transposed in registers
+            *reinterpret_cast<uint4 *>(d) = make_uint4(v0.x, v1.x, v2.x, v3.x);
+            *reinterpret_cast<uint4 *>(d + kGRow) = make_uint4(v0.y, v1.y, v2.y, v3.y);
+            *reinterpret_cast<uint4 *>(d + 2 * kGRow) = make_uint4(v0.z, v1.z, v2.z, v3.z);
+            *reinterpret_cast<uint4 *>(d + 3 * kGRow) = make_uint4(v0.w, v1.w, v2.w, v3.w);
+        }
+    }
+    __device__ __forceinline__ float4 row_sums() const   // reduction-major form: my 4 rows over my 4 reduction indices
+    {
+        const float4 a = __builtin_bit_cast(float4, v0), b = __builtin_bit_cast(float4, v1), c = __builtin_bit_cast(float4, v2),
+                     d = __builtin_bit_cast(float4, v3);
+        return make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    }
+};
+
+// B tile (128 x 32): BMODE 0 fp32 with the reduction index as the source's row, 1 fp32 k-major, 2 three bf16 planes
+template <int BMODE>
+struct V2LoadB {
+    uint4 q0, q1, q2;
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, uint32_t ld, uint32_t plane_bytes, int row0, int rows, int k0,
+                                         int kend, int tid)
+    {
+        if (BMODE == 1) {
+            const int c4 = tid & 7, r = row0 + (tid >> 3), k = k0 + 4 * c4;
+            const bool kok = k < kend;
+            const uint32_t o = ((uint32_t)r * ld + (uint32_t)k) * 4u;
+            q0 = buffer_load16(rs, v2_off(kok && r < rows, o));
+            q1 = buffer_load16(rs, v2_off(kok && r + 64 < rows, o + 64u * ld * 4u));
+        } else if (BMODE == 0) {
+            const int kb = tid >> 5, mb = tid & 31, row = row0 + 4 * mb, k = k0 + 2 * kb;
+            const bool rok = row < rows;
+            const uint32_t o = ((uint32_t)k * ld + (uint32_t)row) * 4u;
+            q0 = buffer_load16(rs, v2_off(rok && k < kend, o));
+            q1 = buffer_load16(rs, v2_off(rok && k + 1 < kend, o + ld * 4u));
+        } else {
+            const int r = row0 + (tid >> 2), k = k0 + 8 * (tid & 3);
+            const bool ok = r < rows && k < kend;
+            const uint32_t o = ((uint32_t)r * ld + (uint32_t)k) * 2u;
+            q0 = buffer_load16(rs, v2_off(ok, o));
+            q1 = buffer_load16(rs, v2_off(ok, o + plane_bytes));
+            q2 = buffer_load16(rs, v2_off(ok, o + 2u * plane_bytes));
+        }
+    }
+    __device__ __forceinline__ void store(char *tile, int tid) const
+    {
+        if (BMODE == 1) {
+            char *d = tile + (tid >> 3) * kGRow + 16 * (tid & 7);
+            *reinterpret_cast<uint4 *>(d) = q0;
+            *reinterpret_cast<uint4 *>(d + 64 * kGRow) = q1;
+        } else if (BMODE == 0) {
+            char *d = tile + (4 * (tid & 31)) * kGRow + 8 * (tid >> 5);   // rows n .. n + 3, two reduction indices each
+            *reinterpret_cast<uint2 *>(d) = make_uint2(q0.x, q1.x);
+            *reinterpret_cast<uint2 *>(d + kGRow) = make_uint2(q0.y, q1.y);
+            *reinterpret_cast<uint2 *>(d + 2 * kGRow) = make_uint2(q0.z, q1.z);
+            *reinterpret_cast<uint2 *>(d + 3 * kGRow) = make_uint2(q0.w, q1.w);
+        } else {
+            char *d = tile + (tid >> 2) * kGPreRow + 16 * (tid & 3);
+            *reinterpret_cast<uint4 *>(d) = q0;
+            *reinterpret_cast<uint4 *>(d + kV2PrePlane) = q1;
+            *reinterpret_cast<uint4 *>(d + 2 * kV2PrePlane) = q2;
+        }
+    }
+};
+
+// the fragments of one k-half (16 reduction indices): A rows 64 wm + {0, 32} + lane % 32, B rows 64 wn + ...
+template <int BMODE>
+struct V2Frags {
+    Frag3 a[2], b[2];
+    __device__ __forceinline__ void fetch(const char *fa, const char *fb, int kk)
+    {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 *qa = reinterpret_cast<const float4 *>(fa + t * 32 * kGRow + kk * 64);
+            a[t] = g_split(qa[0], qa[1]);
+            if (BMODE == 2) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[t].p[pl] = *reinterpret_cast<const u32x4_t *>(fb + t * 32 * kGPreRow + pl * kV2PrePlane + kk * 32);
+            } else {
+                const float4 *qb = reinterpret_cast<const float4 *>(fb + t * 32 * kGRow + kk * 64);
+                b[t] = g_split(qb[0], qb[1]);
+            }
+        }
+    }
+    __device__ __forceinline__ void mfmas(g_f32x16_t (&acc)[2][2]) const
+    {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                g_f32x16_t c = acc[rt][ct];
+                c = g_mfma(a[rt].p[2], b[ct].p[0], c);   // smallest terms first
+                c = g_mfma(a[rt].p[0], b[ct].p[2], c);
+                c = g_mfma(a[rt].p[1], b[ct].p[1], c);
+                c = g_mfma(a[rt].p[1], b[ct].p[0], c);
+                c = g_mfma(a[rt].p[0], b[ct].p[1], c);
+                c = g_mfma(a[rt].p[0], b[ct].p[0], c);
+                acc[rt][ct] = c;
+            }
+    }
+};
+
+template <bool A_KMAJOR, int BMODE>
+__global__ void __launch_bounds__(kV2Threads, 1) gemm_x3_v2_kernel(GemmArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int kStage = kV2A + (BMODE == 2 ? kV2Bp : kV2Bf);
+    constexpr int kBRow = BMODE == 2 ? kGPreRow : kGRow;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * kV2M, n0 = blockIdx.x * kV2N;
+    const int kbeg = blockIdx.z * p.k_per_split, kend = min(p.K, kbeg + p.k_per_split);
+    const __amdgpu_buffer_rsrc_t ra = make_uniform_rsrc(reinterpret_cast<const char *>(p.a), p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_uniform_rsrc(reinterpret_cast<const char *>(p.b), p.b_bytes);
+    const uint32_t lda = (uint32_t)p.lda, ldb = (uint32_t)p.ldb, plane_bytes = (uint32_t)(p.b_plane * 2);
+
+    g_f32x16_t acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+
+    // Tiles travel TWO steps ahead of the MFMAs that consume them (a step is ~1.5 us of matrix work per SIMD, a trip to
+    // memory under load 1-2.5 us: one step ahead left every step waiting ~2.5 us for its tile): two register sets, the
+    // loop unrolled by two.
+    V2LoadA<A_KMAJOR> ta0, ta1;
+    V2LoadB<BMODE> tb0, tb1;
+    const bool want_row_sum = !A_KMAJOR && p.a_row_sum != nullptr && blockIdx.x == 0;
+    float4 row_sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_row_sum = [&](const V2LoadA<A_KMAJOR> &t) {
+        if (!A_KMAJOR && want_row_sum) {
+            const float4 r = t.row_sums();
+            row_sum.x += r.x; row_sum.y += r.y; row_sum.z += r.z; row_sum.w += r.w;
+        }
+    };
+    // tile 0 into stage 0, tiles 1 and 2 into the registers
+    ta0.load(ra, lda, m0, p.M, kbeg, kend, tid);
+    tb0.load(rb, ldb, plane_bytes, n0, p.N, kbeg, kend, tid);
+    ta1.load(ra, lda, m0, p.M, kbeg + kGK, kend, tid);
+    tb1.load(rb, ldb, plane_bytes, n0, p.N, kbeg + kGK, kend, tid);
+    add_row_sum(ta0);
+    ta0.store(lds, tid);
+    tb0.store(lds + kV2A, tid);
+    ta0.load(ra, lda, m0, p.M, kbeg + 2 * kGK, kend, tid);
+    tb0.load(rb, ldb, plane_bytes, n0, p.N, kbeg + 2 * kGK, kend, tid);
+    __syncthreads();
+    const int fa_off = (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 32;
+    const int fb_off = kV2A + (64 * wn + (lane & 31)) * kBRow + (lane >> 5) * (BMODE == 2 ? 16 : 32);
+    V2Frags<BMODE> f0, f1;
+    f0.fetch(lds + fa_off, lds + fb_off, 0);
+    f1 = f0;   // (defined also when an ablation build skips the fetches)
+    // one step: `cur` holds the step's tile; (ta, tb) hold the NEXT step's tile (stored to `nxt` now) and are reloaded
+    // with the tile three steps on
+    auto step = [&](V2LoadA<A_KMAJOR> &ta, V2LoadB<BMODE> &tb, char *cur, char *nxt, int k0) {
+        add_row_sum(ta);
+#if SDETR_GX3_ABLATE != 4
+        ta.store(nxt, tid);   // (nobody reads `nxt`: its last readers fetched their fragments before the previous barrier)
+        tb.store(nxt + kV2A, tid);
+#endif
+#if SDETR_GX3_ABLATE != 3
+        ta.load(ra, lda, m0, p.M, k0 + 3 * kGK, kend, tid);
+        tb.load(rb, ldb, plane_bytes, n0, p.N, k0 + 3 * kGK, kend, tid);
+#endif
+        // first k-half: its MFMAs run while the second half's fragments are read and split
+#if SDETR_GX3_ABLATE != 6
+        f1.fetch(cur + fa_off, cur + fb_off, 1);
+#endif
+        f0.mfmas(acc);
+#if SDETR_GX3_ABLATE != 5
+        __syncthreads();      // the next tile is complete in `nxt`; everybody holds what it needs from `cur`
+#endif
+#if SDETR_GX3_ABLATE != 6
+        f0.fetch(nxt + fa_off, nxt + fb_off, 0);
+#endif
+        f1.mfmas(acc);
+    };
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * kGK) {
+        step(ta1, tb1, lds, lds + kStage, k0);
+        if (k0 + kGK < kend) step(ta0, tb0, lds + kStage, lds, k0 + kGK);
+    }
+
+    if (want_row_sum) {   // (uniform per workgroup) 8 threads hold pieces of each row's sum: meet in LDS, one atomic per row
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(lds);   // [8][256]
+        const int u = tid & 255, half = tid >> 8, kb = u >> 5, mb = u & 31;
+        *reinterpret_cast<float4 *>(red + kb * 256 + 128 * half + 4 * mb) = row_sum;
+        __syncthreads();
+        if (tid < 256 && m0 + tid < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += red[j * 256 + tid];
+            unsafeAtomicAdd(p.a_row_sum + m0 + tid, t);
+        }
+    }
+    const bool add_bias = p.bias && blockIdx.z == 0;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int n = n0 + 64 * wn + 32 * ct + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = add_bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + 64 * wm + 32 * rt + g_acc_row(i, lane);
+                if (m < p.M) {
+                    float *dst = p.c + (int64_t)m * p.ldc + n;
+                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
+                    else *dst = acc[rt][ct][i] + bias;
+                }
+            }
+    }
+}
+
 // planes[pl][i][j] = plane pl of (transpose ? w[j][i] : w[i][j]); rows_out x cols_out = transpose ? cols x rows : rows x cols
 __global__ void __launch_bounds__(256) gemm_x3_presplit_kernel(const float *w, int64_t ld, int rows, int cols, int transpose,
                                                                uint16_t *out)
@@ -397,6 +692,38 @@ static int launch_gemm_x3(hipStream_t s, const GemmArgs &a, int splits)
     return check_launch("gemm_x3");
 }
 
+// the second-generation kernel (256 x 128 tiles, 8 waves): operands below 2 GB (32-bit buffer offsets)
+template <bool AK, int BMODE>
+static int launch_gemm_x3_v2(hipStream_t s, const GemmArgs &a, int splits)
+{
+    constexpr int lds_bytes = 2 * (kV2A + (BMODE == 2 ? kV2Bp : kV2Bf));
+    static DeviceOnce once;
+    allow_dynamic_lds(gemm_x3_v2_kernel<AK, BMODE>, once, lds_bytes);
+    const dim3 grid((unsigned)((a.N + kV2N - 1) / kV2N), (unsigned)((a.M + kV2M - 1) / kV2M), (unsigned)splits);
+    hipLaunchKernelGGL((gemm_x3_v2_kernel<AK, BMODE>), grid, dim3(kV2Threads), lds_bytes, s, a);
+    return check_launch("gemm_x3");
+}
+
+// Which generation takes a product.  Measured (benchmarks/gemm_x3_bench.py, MI355X): the 256 x 128 tiles win where an
+// output or reduction dimension is long (feed-forward shapes: 154-190 us against 186-217), the 128 x 128 tiles with two
+// workgroups per CU where the output is a few tiles wide (256 / 384 features: 56-66 us against 62-101).
+// SDETR_GEMM_X3_V1=1 / =0: force the first / second generation (A/B runs).
+static bool gemm_x3_use_v2(int M, int N, int K)
+{
+    const char *e = getenv("SDETR_GEMM_X3_V1");   // (read per call: the tests switch it)
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '0';
+    const int longest = N > K ? N : K;
+    return M >= 256 && longest >= 1024;
+}
+
+// extent in bytes of a 2-d operand (rows x width elements of `elem` bytes, rows `ld` elements apart); 0 when it does not
+// fit the 31 bits a buffer resource's offsets are trusted with here
+static uint32_t operand_bytes(int64_t rows, int64_t width, int64_t ld, int elem, int64_t extra = 0)
+{
+    const int64_t b = (rows > 0 ? ((rows - 1) * ld + width) : 0) * elem + extra;
+    return b > 0 && b < ((int64_t)1 << 31) ? (uint32_t)b : 0u;
+}
+
 // C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n]).  a_kmajor: A(m,k) = a[m * lda + k], else a[k * lda + m]; b likewise with n.
 // reduction_splits > 1: the reduction is cut into that many slices whose partial products are accumulated into C with
 // fp32 atomics -- C must be zero on entry.  Alignment: every operand 16-byte aligned, its leading dimension a multiple
@@ -424,8 +751,14 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
         splits = g.k_per_split > 0 ? (K + g.k_per_split - 1) / g.k_per_split : 1;
         if (splits < 1) splits = 1;
         g.atomic = splits > 1;
-        const dim3 grid((unsigned)((N + kGTile - 1) / kGTile), (unsigned)((M + kGTile - 1) / kGTile), (unsigned)splits);
         hipStream_t hs = static_cast<hipStream_t>(stream);
+        g.a_bytes = a_kmajor ? operand_bytes(M, K, lda, 4) : operand_bytes(K, M, lda, 4);
+        g.b_bytes = operand_bytes(N, K, ldb, 2, 2 * g.b_plane * 2);
+        if (gemm_x3_use_v2(M, N, K) && g.a_bytes && g.b_bytes) {
+            if (a_kmajor) return launch_gemm_x3_v2<true, 2>(hs, g, splits);
+            return launch_gemm_x3_v2<false, 2>(hs, g, splits);
+        }
+        const dim3 grid((unsigned)((N + kGTile - 1) / kGTile), (unsigned)((M + kGTile - 1) / kGTile), (unsigned)splits);
         if (a_kmajor) hipLaunchKernelGGL((gemm_x3_pre_kernel<true>), grid, dim3(kGThreads), kGLdsPre, hs, g);
         else hipLaunchKernelGGL((gemm_x3_pre_kernel<false>), grid, dim3(kGThreads), kGLdsPre, hs, g);
         return check_launch("gemm_x3");
@@ -446,6 +779,14 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
     if (splits < 1) splits = 1;
     g.atomic = splits > 1;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    g.a_bytes = a_kmajor ? operand_bytes(M, K, lda, 4) : operand_bytes(K, M, lda, 4);
+    g.b_bytes = b_kmajor ? operand_bytes(N, K, ldb, 4) : operand_bytes(K, N, ldb, 4);
+    if (gemm_x3_use_v2(M, N, K) && g.a_bytes && g.b_bytes) {
+        if (a_kmajor && b_kmajor) return launch_gemm_x3_v2<true, 1>(s, g, splits);
+        if (a_kmajor && !b_kmajor) return launch_gemm_x3_v2<true, 0>(s, g, splits);
+        if (!a_kmajor && b_kmajor) return launch_gemm_x3_v2<false, 1>(s, g, splits);
+        return launch_gemm_x3_v2<false, 0>(s, g, splits);
+    }
     if (a_kmajor && b_kmajor) return launch_gemm_x3<true, true>(s, g, splits);
     if (a_kmajor && !b_kmajor) return launch_gemm_x3<true, false>(s, g, splits);
     if (!a_kmajor && b_kmajor) return launch_gemm_x3<false, true>(s, g, splits);

@@ -100,8 +100,15 @@ def _weight_grad_splits(T: int, N: int, K: int) -> int:
 # tiles the library does not split over the token dimension.  With the weight pre-split once per call (``presplit``,
 # ``gemm_x3_presplit_b``: half the split work) the other two reach 115-128 TFLOP/s: 1.3x the library on two of the four
 # large FFN products, equal on the rest -- not enough to route them by default.
-X3_FORWARD, X3_DX, X3_DW = False, False, True
-X3_MIN_ROWS = 2048      # below this many tokens the library's small-GEMM kernels win
+X3_FORWARD, X3_DX, X3_DW = True, True, True
+X3_WIDE_ROWS, X3_WIDE_FEATURES = 16000, 2048   # (module attributes: the tests lower them to route everything here)
+
+
+def _x3_wide(T: int, N: int, K: int) -> bool:
+    """The forward / input-gradient products that go to the x3 kernel with the weight pre-split (round 3: its 256 x 128
+    tile generation): the feed-forward's 256 <-> 2048 products at >= 16 000 tokens -- 154-200 us against the library's
+    194-272 (benchmarks/gemm_x3_bench.py); narrower products and shorter token lists stay with the library."""
+    return T >= X3_WIDE_ROWS and max(N, K) >= X3_WIDE_FEATURES
 
 
 class _LinearX3(Function):
@@ -117,7 +124,7 @@ class _LinearX3(Function):
         T, N = x2.shape[0], weight.shape[0]
         y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         y2 = y.view(T, N)
-        if X3_FORWARD and K % 8 == 0 and T >= X3_MIN_ROWS:
+        if X3_FORWARD and K % 8 == 0 and _x3_wide(T, N, K):
             gemm_x3_presplit_b(x2, True, presplit(weight), T, N, K, bias=bias, out=y2)   # y = x w^T, w split once
         elif bias is not None:
             torch.addmm(bias, x2, weight.t(), out=y2)
@@ -136,7 +143,7 @@ class _LinearX3(Function):
         g2 = (gy if gy.is_contiguous() else gy.contiguous()).view(T, N)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                                    # dx = dy w
-            if X3_DX and N % 8 == 0 and T >= X3_MIN_ROWS:
+            if X3_DX and N % 8 == 0 and _x3_wide(T, N, K):
                 gx = gemm_x3_presplit_b(g2, True, presplit(weight, transpose=True), T, K, N)   # dx = dy w
             else:
                 gx = g2 @ weight

@@ -14,10 +14,17 @@ def _err(got, want64):
     return ((got.double().cpu() - want64).abs().max() / want64.abs().max()).item()
 
 
+@pytest.fixture(params=["128x128 tiles", "256x128 tiles"])
+def generation(request, monkeypatch):
+    """Every GEMM test runs on both kernel generations (the library picks by shape; SDETR_GEMM_X3_V1 forces one)."""
+    monkeypatch.setenv("SDETR_GEMM_X3_V1", "1" if request.param.startswith("128") else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 260, 256), (22726, 256, 2048), (4545, 384, 256), (4, 4, 4),
-                                   (1000, 2048, 256)])
+                                   (1000, 2048, 256), (516, 132, 36), (256, 128, 96), (260, 4, 100)])
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
-def test_gemm_x3_matches_float64(M, N, K, ak, bk):
+def test_gemm_x3_matches_float64(M, N, K, ak, bk, generation):
     a = syn.det_randn(f"ga{M}{K}", (M, K)) * 1.3
     b = syn.det_randn(f"gb{N}{K}", (N, K)) * 0.7
     want = a.double() @ b.double().t()
@@ -33,7 +40,7 @@ def test_gemm_x3_matches_float64(M, N, K, ak, bk):
         assert _err(got2, want) <= max(2.0 * _err(ref32, want), 2e-6)
 
 
-def test_gemm_x3_row_sums_of_a_reduction_major_operand():
+def test_gemm_x3_row_sums_of_a_reduction_major_operand(generation):
     """dw = dy^T x with db = sum_t dy from the same launch (with and without a split reduction)."""
     T, N, K = 3001 * 4, 260, 256
     dy, x = syn.det_randn("rs_dy", (T, N)).to(DEV), syn.det_randn("rs_x", (T, K)).to(DEV)
@@ -52,7 +59,7 @@ def test_gemm_x3_row_sums_of_a_reduction_major_operand():
 @pytest.mark.parametrize("M,N,K", [(300, 260, 256), (22726, 256, 2048), (4545, 384, 256), (130, 8, 8)])
 @pytest.mark.parametrize("ak", [True, False])
 @pytest.mark.parametrize("transposed", [False, True])
-def test_gemm_x3_with_a_presplit_operand(M, N, K, ak, transposed):
+def test_gemm_x3_with_a_presplit_operand(M, N, K, ak, transposed, generation):
     """B given as three bf16 planes made once per call (from the matrix or from its transpose)."""
     if not ak and M % 4:
         pytest.skip("row counts of a reduction-major operand must be multiples of 4")
@@ -70,7 +77,7 @@ def test_gemm_x3_with_a_presplit_operand(M, N, K, ak, transposed):
     assert _err(got, want) <= max(2.0 * _err(ref32, want), 2e-6)
 
 
-def test_gemm_x3_bias_and_argument_checks():
+def test_gemm_x3_bias_and_argument_checks(generation):
     a, b = syn.det_randn("gba", (70, 64)).to(DEV), syn.det_randn("gbb", (36, 64)).to(DEV)
     bias = syn.det_randn("gbias", (36,)).to(DEV)
     got = X.gemm_x3(a, True, b, True, 70, 36, 64, bias=bias)
@@ -85,10 +92,11 @@ def test_gemm_x3_bias_and_argument_checks():
 
 
 @pytest.mark.parametrize("shape,N", [((2, 1137, 256), 2048), ((3000, 2048), 256), ((2, 300, 256), 384)])
-def test_x3_linear_forward_backward_match_float64(shape, N, monkeypatch):
+def test_x3_linear_forward_backward_match_float64(shape, N, monkeypatch, generation):
     for flag in ("X3_FORWARD", "X3_DX", "X3_DW"):   # all three products through the kernel under test
         monkeypatch.setattr(X, flag, True)
-    monkeypatch.setattr(X, "X3_MIN_ROWS", 1)
+    monkeypatch.setattr(X, "X3_WIDE_ROWS", 1)
+    monkeypatch.setattr(X, "X3_WIDE_FEATURES", 1)
     K = shape[-1]
     lin = torch.nn.Linear(K, N)
     x = syn.det_randn(f"lx{N}", shape)
