@@ -345,6 +345,49 @@ class SalienceTransformerEncoder(nn.Module):
             counts.append(int(t.shape[1]))
         return counts
 
+    def _forward_sorted_autograd(self, value, ori_pos, padding_mask, foreground_score, focus_token_nums, foreground_inds,
+                                 counts, spatial_shapes, level_start_index, valid_ratios, level_shapes, multi_level_masks):
+        """The autograd path when every layer's index set is a prefix of ONE sorted list (what ``salience_filtering``
+        produces): the tokens are gathered ONCE into sorted order, layer k works on the rows ``[:c_k]`` (a view), rows
+        beyond an image's focus count keep their value, and the result goes back to token space once -- the reference's
+        per-layer gather / scatter pair on the whole ``[B,Nv,E]`` tensor (salience_transformer.py:454-485; in the
+        backward: a zero fill, a scatter-add and an add of that size per layer) is left to the general loop."""
+        E = self.embed_dim
+        b = value.shape[0]
+        sorted_index = foreground_inds[0]
+        n0 = counts[0]
+        idx_e = sorted_index.unsqueeze(-1).expand(-1, -1, E)
+        cur = torch.gather(value, 1, idx_e)
+        pos_s = torch.gather(ori_pos, 1, idx_e)
+        with torch.no_grad():   # (the selection score and the sampling centres carry no gradient)
+            fg_s = torch.gather(foreground_score.detach(), 1, sorted_index)
+            ref_s = encoder_reference_points(valid_ratios.float().contiguous(), spatial_shapes, level_start_index, n0,
+                                             index=sorted_index)
+            live = torch.arange(n0, device=value.device)[None] < focus_token_nums.to(torch.int64)[:, None]    # [B,n0]
+        final = []
+        for layer_id, layer in enumerate(self.layers):
+            if self.layer_marker is not None:
+                self.layer_marker(layer_id)
+            c = counts[layer_id]
+            q = cur[:, :c]
+            out = layer(q, pos_s[:, :c], value, ref_s[:, :c], spatial_shapes, level_start_index, padding_mask,
+                        self.enhance_mcsp(q), fg_s[:, :c])
+            out = torch.where(live[:, :c, None], out, q)
+            nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
+            final.append(out[:, nxt:c])        # rows no later layer touches
+            cur = out
+        if self.layer_marker is not None:
+            self.layer_marker(self.num_layers)
+        output = value.scatter(1, idx_e, torch.cat(final[::-1], 1))
+        if multi_level_masks is not None:
+            # learnt embedding for background tokens: neither padding nor in the LAST layer's set (:487-495)
+            bg = self.background_embedding.flat(level_shapes).to(output.dtype)
+            keep = torch.ones(b, value.shape[1], dtype=output.dtype, device=output.device)
+            keep.scatter_(1, sorted_index[:, :counts[-1]], 0.0)
+            keep = keep * (~padding_mask).to(output.dtype)
+            output = torch.addcmul(output, bg.unsqueeze(0), keep.unsqueeze(-1))
+        return output
+
     def project_values(self, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
         """Head-major value maps of ALL layers ``[num_layers,B,heads,Nv,D]`` (no-grad path).  The six layers sample
         the same, never-updated feature map (salience_transformer.py:452), so their ``value_proj`` run as one
@@ -380,9 +423,13 @@ class SalienceTransformerEncoder(nn.Module):
         E = self.embed_dim
         level_shapes = pyramid.level_shapes_of(multi_level_masks) if multi_level_masks is not None \
             else [tuple(s) for s in spatial_shapes.tolist()]
-        counts = self._prefix_counts(foreground_inds) if native else None
+        counts = self._prefix_counts(foreground_inds)
         b, n = query.shape[:2]
         s, p = len(level_shapes), 2
+        if counts is not None and not native:
+            return self._forward_sorted_autograd(query, query_pos, query_key_padding_mask, foreground_score, focus_token_nums,
+                                                 foreground_inds, counts, spatial_shapes, level_start_index, valid_ratios,
+                                                 level_shapes, multi_level_masks)
         if counts is None:
             reference_points = self.get_reference_points(level_shapes, valid_ratios, device=query.device)
             ori_reference_points = reference_points.reshape(b, n, s * p).contiguous()

@@ -219,6 +219,39 @@ def test_sorted_order_loop_equals_token_space_loop(tag):
     assert (general - memory).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("tag", ["single", "mixed"])
+def test_sorted_order_autograd_loop_equals_token_space_autograd_loop(tag):
+    """Under autograd too: prefix views of one sorted list take the sorted-order loop (one gather in, one scatter out),
+    independent index tensors the reference's per-layer gather / scatter loop -- same memory, same gradients."""
+    d, m, feats, masks, pos, layers = _small(tag)
+    with torch.no_grad():
+        _, _, aux = m(feats, masks, pos, return_aux=True)
+    enc = m.encoder
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    w = syn.det_randn("sorted.autograd.w", tuple(aux["feat_flatten"].shape)).to(DEV)
+    results = []
+    for inds in (aux["foreground_inds"], [t.clone() for t in aux["foreground_inds"]]):
+        assert (enc._prefix_counts(inds) is not None) == (inds is aux["foreground_inds"])
+        enc.zero_grad(set_to_none=True)
+        q = aux["feat_flatten"].clone().requires_grad_(True)
+        qp = aux["lvl_pos_embed_flatten"].clone().requires_grad_(True)
+        out = enc(query=q, query_pos=qp, query_key_padding_mask=aux["mask_flatten"], spatial_shapes=aux["spatial_shapes"],
+                  level_start_index=aux["level_start_index"], valid_ratios=aux["valid_ratios"],
+                  foreground_score=aux["foreground_score"], focus_token_nums=aux["focus_token_nums"],
+                  foreground_inds=inds, multi_level_masks=masks)
+        (out * w).sum().backward()
+        grads = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        results.append((out.detach(), q.grad.clone(), qp.grad.clone(), grads))
+    (o1, gq1, gp1, g1), (o2, gq2, gp2, g2) = results
+    assert (o1 - o2).abs().max().item() <= 2e-5
+    assert (gq1 - gq2).abs().max().item() <= 1e-4 * max(1.0, gq2.abs().max().item())
+    assert (gp1 - gp2).abs().max().item() <= 1e-4 * max(1.0, gp2.abs().max().item())
+    assert sorted(g1) == sorted(g2) and len(g1) > 20
+    for n in g1:
+        assert (g1[n] - g2[n]).abs().max().item() <= 1e-4 * max(1.0, g2[n].abs().max().item()), n
+
+
 @pytest.mark.parametrize("image_sizes", [[(480, 640)], [(800, 1333), (608, 911), (333, 500)],
                                          [(800, 1333), (800, 1333), (736, 1100), (800, 1201)]])
 def test_bf16_launch_fusions_do_not_change_the_result(image_sizes):
