@@ -703,6 +703,23 @@ int sdetr_topk_attention_with_projection_bf16(
 /* (internal: the in-projection launch of sdetr_topk_attention_bf16 for csrc/fused_head_value.hip) */
 int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in_args);
 
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm of the TRAINING step, fp32 (models/bricks/salience_transformer.py:347-351, 377-378, 390-391:
+ * norm(query + sublayer(query)); 64 / 128 / 256 / 512 channels, contiguous [rows, channels] operands).
+ *   forward : out = LN(a [+ residual]) * gamma + beta; sum_out = a + residual (required iff residual != NULL: the
+ *             tensor the backward normalises again); mean / rstd [rows] = the row statistics.
+ *   backward: grad_input = d loss / d (a + residual) (the gradient of a and of the residual alike) from grad_out,
+ *             normalized_input (= sum_out, or a without a residual), the saved statistics and gamma;
+ *             grad_gamma / grad_beta [channels] are ACCUMULATED with fp32 atomics: zero (or a running sum) on entry.
+ * --------------------------------------------------------------------------------------------- */
+int sdetr_layer_norm_train_supported(int channels);
+int sdetr_layer_norm_train_forward_f32(sdetr_stream_t stream, const float *a, const float *residual, const float *gamma,
+                                       const float *beta, float eps, int64_t rows, int channels, float *sum_out,
+                                       float *out, float *mean, float *rstd);
+int sdetr_layer_norm_train_backward_f32(sdetr_stream_t stream, const float *grad_out, const float *normalized_input,
+                                        const float *mean, const float *rstd, const float *gamma, int64_t rows,
+                                        int channels, float *grad_input, float *grad_gamma, float *grad_beta);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from .filter_ops import attention_heads, attention_heads_applies, box_refine, decoder_query_sine_embed, fused_ffn, fused_ffn_applies, fused_layer_norm
+from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
 
@@ -115,7 +116,7 @@ class SalienceTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(tgt2))
+        return add_layer_norm(tgt, self.norm3, self.dropout4(tgt2))
 
     def _self_attention(self, qk: Tensor, v: Tensor, attn_mask: Optional[Tensor]) -> Tensor:
         return self.self_attn(query=qk, key=qk, value=v, attn_mask=attn_mask, need_weights=False)[0]
@@ -151,11 +152,11 @@ class SalienceTransformerDecoderLayer(nn.Module):
         else:
             query2 = self._self_attention(self.with_pos_embed(query, query_pos), query, self_attn_mask)
         if not native:
-            query = self.norm2(query + self.dropout2(query2))
+            query = add_layer_norm(query, self.norm2, self.dropout2(query2))
             query2 = self.cross_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
                                      value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                      key_padding_mask=key_padding_mask)
-            query = self.norm1(query + self.dropout1(query2))
+            query = add_layer_norm(query, self.norm1, self.dropout1(query2))
             return self.forward_ffn(query)
         query = fused_layer_norm(query, self.norm2, residual=query2)
         if value_hm is None:

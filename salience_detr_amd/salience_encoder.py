@@ -31,6 +31,7 @@ from .filter_ops import (advance_rows, attention_heads, attention_heads_applies,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_self_attention_,
                          topk_self_attention_applies)
+from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps, plan_batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 
@@ -92,7 +93,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, query):
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(query))))
-        return self.norm2(query + self.dropout3(src2))
+        return add_layer_norm(query, self.norm2, self.dropout3(src2))
 
     def _forward_ffn_native(self, query, advance=None):
         """No-grad FFN: ReLU in the first GEMM's epilogue when the activation is ReLU, residual + LayerNorm in
@@ -259,7 +260,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
         if native:
             select_tgt = fused_layer_norm(select_tgt, self.pre_norm, residual=tgt2)
         else:
-            select_tgt = self.pre_norm(select_tgt + self.pre_dropout(tgt2))
+            select_tgt = add_layer_norm(select_tgt, self.pre_norm, self.pre_dropout(tgt2))
         if native:
             query = scatter_rows_(query, select_tgt_index, select_tgt)  # query is the layer's own gathered copy
         else:
@@ -277,7 +278,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
                                   key_padding_mask=query_key_padding_mask)
         if native:
             return self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2))
-        query = self.norm1(query + self.dropout1(src2))
+        query = add_layer_norm(query, self.norm1, self.dropout1(src2))
         return self.forward_ffn(query)
 
 

@@ -152,3 +152,18 @@ def test_round2_entry_points_reject_bad_arguments(libpath):
     # which top-k shapes go through the prefilter, how many stage-1 blocks a level takes
     assert lib.sdetr_topk_uses_prefilter(11363, 300) == 1 and lib.sdetr_topk_uses_prefilter(1050, 1050) == 0
     assert lib.sdetr_salience_head_blocks(2, 16800) == 525 and lib.sdetr_salience_head_blocks(2, 0) == 0
+
+
+def test_layer_norm_train_rejects_bad_arguments(libpath):
+    from salience_detr_amd import _hip
+    lib = _hip.lib()
+    assert lib.sdetr_layer_norm_train_supported(256) == 1 and lib.sdetr_layer_norm_train_supported(96) == 0
+    f = lib.sdetr_layer_norm_train_forward_f32
+    assert f(None, 8, None, 8, 8, 1e-5, 4, 96, None, 8, 8, 8) == _hip.EINVAL and b"channels" in lib.sdetr_last_error()
+    assert f(None, 8, 8, 8, 8, 1e-5, 4, 256, None, 8, 8, 8) == _hip.EINVAL and b"sum_out" in lib.sdetr_last_error()
+    assert f(None, None, None, 8, 8, 1e-5, 4, 256, None, 8, 8, 8) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
+    assert f(None, 8, None, 8, 8, 1e-5, 0, 256, None, 8, 8, 8) == 0
+    g = lib.sdetr_layer_norm_train_backward_f32
+    assert g(None, 8, 8, 8, 8, 8, -1, 256, 8, 8, 8) == _hip.EINVAL
+    assert g(None, 8, 8, 8, 8, 8, 4, 256, 8, None, 8) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
+
