@@ -99,7 +99,8 @@ def encoder_output_memory(enc_output: nn.Linear, enc_output_norm: nn.LayerNorm, 
         keep.append(ok.expand(n, h, w).reshape(n, h * w))
         cur += h * w
     keep = torch.cat(keep, 1) & ~memory_padding_mask
-    return enc_output_norm(enc_output(memory * keep.unsqueeze(-1).to(memory.dtype)))
+    from .layer_norm_train import add_layer_norm   # (one launch each way for fp32 HIP tensors, nn.LayerNorm otherwise)
+    return add_layer_norm(enc_output(memory * keep.unsqueeze(-1).to(memory.dtype)), enc_output_norm)
 
 
 class PositionEmbeddingLearned(nn.Module):

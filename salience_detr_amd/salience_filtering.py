@@ -20,6 +20,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import pyramid
+from .layer_norm_train import add_layer_norm
 from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, merge_sorted_desc,
                          plan_masked_topk, salience_head)
 
@@ -53,7 +54,9 @@ class MaskPredictor(nn.Module):
         if needs_grad or not x.is_cuda:
             if row_scale is not None:
                 x = x + x * row_scale.unsqueeze(-1) * alpha
-            z = self.layer1(x)
+            z = add_layer_norm(x, self.layer1[0]) if x.is_cuda else self.layer1[0](x)   # (one launch each way on the device)
+            for m in list(self.layer1)[1:]:
+                z = m(z)
             # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
             z = torch.cat([z[..., :half], z[..., half:].mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
             return self.layer2(z)
