@@ -720,6 +720,23 @@ int sdetr_layer_norm_train_backward_f32(sdetr_stream_t stream, const float *grad
                                         const float *mean, const float *rstd, const float *gamma, int64_t rows,
                                         int channels, float *grad_input, float *grad_gamma, float *grad_beta);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sampling locations + attention weights of the deformable attention for the TRAINING step, fp32, 4 levels x 4 points
+ * (models/bricks/ms_deform_attn.py:322-349): offsets [rows, M, L, P, 2] and logits [rows, M, L*P] (the two Linear
+ * outputs, rows = B * Nq), reference_points [rows, L, 2 | 4], spatial_shapes [L, 2] int64 (h, w) on the device ->
+ * sampling_locations [rows, M, L, P, 2], attention_weights [rows, M, L, P] (softmax over L*P).  backward: the gradients
+ * of the two Linear outputs from the op's grad_sampling_locations / grad_attention_weights and the saved weights.
+ * --------------------------------------------------------------------------------------------- */
+int sdetr_sampling_prep_supported(int num_levels, int num_points);
+int sdetr_sampling_prep_f32(sdetr_stream_t stream, const float *offsets, const float *logits, const float *reference_points,
+                            const int64_t *spatial_shapes, int64_t rows, int num_heads, int num_levels, int num_points,
+                            int ref_dim, float *sampling_locations, float *attention_weights);
+int sdetr_sampling_prep_backward_f32(sdetr_stream_t stream, const float *grad_sampling_locations,
+                                     const float *grad_attention_weights, const float *attention_weights,
+                                     const float *reference_points, const int64_t *spatial_shapes, int64_t rows,
+                                     int num_heads, int num_levels, int num_points, int ref_dim, float *grad_offsets,
+                                     float *grad_logits);
+
 #ifdef __cplusplus
 }
 #endif

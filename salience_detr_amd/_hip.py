@@ -62,6 +62,9 @@ SIGNATURES = {
     "sdetr_topk_uses_prefilter": (_i, [_i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
     "sdetr_merge_sorted_desc": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "sdetr_sampling_prep_supported": (_i, [_i, _i]),
+    "sdetr_sampling_prep_f32": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p, _p]),
+    "sdetr_sampling_prep_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p, _p]),
     "sdetr_layer_norm_train_supported": (_i, [_i]),
     "sdetr_layer_norm_train_forward_f32": (_i, [_p, _p, _p, _p, _p, ctypes.c_float, _i64, _i, _p, _p, _p, _p]),
     "sdetr_layer_norm_train_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),

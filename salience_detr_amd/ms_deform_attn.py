@@ -375,6 +375,49 @@ def invalidate_caches(module: nn.Module) -> None:
                 p.__dict__.pop(key, None)
 
 
+class _SamplingPrep(Function):
+    """``(sampling_locations, attention_weights)`` of ms_deform_attn.py:322-349 from the two Linear outputs and the
+    reference points (``csrc/sampling_prep.hip``); the reference points carry no gradient here."""
+
+    @staticmethod
+    def applies(offsets: Tensor, logits: Tensor, reference_points: Tensor, L: int, P: int) -> bool:
+        return (offsets.is_cuda and offsets.dtype == torch.float32 and logits.dtype == torch.float32
+                and reference_points.dtype == torch.float32 and not reference_points.requires_grad
+                and offsets.numel() > 0 and bool(_hip.lib().sdetr_sampling_prep_supported(L, P)))
+
+    @staticmethod
+    def forward(ctx, offsets, logits, reference_points, spatial_shapes, L, P):
+        B, Nq, M = offsets.shape[:3]
+        off, lg = offsets.contiguous(), logits.contiguous()
+        ref = reference_points.contiguous()
+        RD = ref.shape[-1]
+        loc = torch.empty((B, Nq, M, L, P, 2), dtype=torch.float32, device=off.device)
+        w = torch.empty((B, Nq, M, L, P), dtype=torch.float32, device=off.device)
+        with torch.cuda.device(off.device):
+            code = _hip.lib().sdetr_sampling_prep_f32(_hip.stream_ptr(), off.data_ptr(), lg.data_ptr(), ref.data_ptr(),
+                                                      spatial_shapes.data_ptr(), B * Nq, M, L, P, RD, loc.data_ptr(),
+                                                      w.data_ptr())
+        _hip.check(code, "sampling_prep")
+        ctx.save_for_backward(w, ref, spatial_shapes)
+        ctx.dims = (B, Nq, M, L, P, RD)
+        return loc, w
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loc, grad_w):
+        w, ref, spatial_shapes = ctx.saved_tensors
+        B, Nq, M, L, P, RD = ctx.dims
+        gl, gw = grad_loc.contiguous(), grad_w.contiguous()
+        g_off = torch.empty((B, Nq, M, L, P, 2), dtype=torch.float32, device=w.device)
+        g_lg = torch.empty((B, Nq, M, L * P), dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            code = _hip.lib().sdetr_sampling_prep_backward_f32(
+                _hip.stream_ptr(), gl.data_ptr(), gw.data_ptr(), w.data_ptr(), ref.data_ptr(), spatial_shapes.data_ptr(),
+                B * Nq, M, L, P, RD, g_off.data_ptr(), g_lg.data_ptr())
+        _hip.check(code, "sampling_prep_backward")
+        return g_off, g_lg, None, None, None, None
+
+
 class MultiScaleDeformableAttention(nn.Module):
     """Multi-Scale Deformable Attention Module (Deformable-DETR), MI355X-native inside.
 
@@ -547,6 +590,14 @@ class MultiScaleDeformableAttention(nn.Module):
             batch_size, num_query, self.num_heads, self.num_levels, self.num_points, 2)
         attention_weights = self.attention_weights(query).view(
             batch_size, num_query, self.num_heads, self.num_levels * self.num_points)
+        if _SamplingPrep.applies(sampling_offsets, attention_weights, reference_points, self.num_levels, self.num_points):
+            # softmax, offset normalisation and the reference-point add in one launch (and one launch backward)
+            sampling_locations, attention_weights = _SamplingPrep.apply(
+                sampling_offsets, attention_weights, reference_points, spatial_shapes, self.num_levels, self.num_points)
+            output = MultiScaleDeformableAttnFunction.apply(
+                value.to(torch.float32).contiguous(), spatial_shapes, level_start_index, sampling_locations,
+                attention_weights, self.im2col_step)
+            return self.output_proj(output)
         attention_weights = attention_weights.softmax(-1).view(
             batch_size, num_query, self.num_heads, self.num_levels, self.num_points)
         if reference_points.shape[-1] == 2:

@@ -20,8 +20,10 @@ def flatten_multi_level(multi_level_elements: Sequence[Tensor]) -> Tensor:
 
 
 def get_lvl_pos_embed(level_embeds: Tensor, multi_level_pos_embeds: Sequence[Tensor]) -> Tensor:
-    """pos + level embedding, flattened (base_transformer.py:29-33)."""
-    return flatten_multi_level([p + level_embeds[l].view(1, -1, 1, 1) for l, p in enumerate(multi_level_pos_embeds)])
+    """pos + level embedding, flattened (base_transformer.py:29-33).  The level embedding is added in the token-major
+    layout -- the same sums, but its gradient then is a column sum of contiguous ``[B, hw, C]`` rows instead of a reduction
+    over the strided NCHW map (0.15 ms for the finest level alone in the training step)."""
+    return torch.cat([p.flatten(-2).transpose(1, 2) + level_embeds[l] for l, p in enumerate(multi_level_pos_embeds)], 1)
 
 
 def get_valid_ratios(mask: Tensor) -> Tensor:

@@ -167,3 +167,17 @@ def test_layer_norm_train_rejects_bad_arguments(libpath):
     assert g(None, 8, 8, 8, 8, 8, -1, 256, 8, 8, 8) == _hip.EINVAL
     assert g(None, 8, 8, 8, 8, 8, 4, 256, 8, None, 8) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
 
+
+def test_sampling_prep_rejects_bad_arguments(libpath):
+    from salience_detr_amd import _hip
+    lib = _hip.lib()
+    assert lib.sdetr_sampling_prep_supported(4, 4) == 1 and lib.sdetr_sampling_prep_supported(5, 4) == 0
+    f = lib.sdetr_sampling_prep_f32
+    assert f(None, 8, 8, 8, 8, 10, 8, 5, 4, 2, 8, 8) == _hip.EINVAL and b"4 levels" in lib.sdetr_last_error()
+    assert f(None, 8, 8, 8, 8, 10, 8, 4, 4, 3, 8, 8) == _hip.EINVAL and b"2 or 4" in lib.sdetr_last_error()
+    assert f(None, 8, None, 8, 8, 10, 8, 4, 4, 2, 8, 8) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
+    assert f(None, 8, 8, 8, 8, 0, 8, 4, 4, 2, 8, 8) == 0
+    g = lib.sdetr_sampling_prep_backward_f32
+    assert g(None, 8, 8, 8, 8, 8, -1, 8, 4, 4, 2, 8, 8) == _hip.EINVAL
+    assert g(None, 8, 8, 8, 8, 8, 10, 8, 4, 4, 2, None, 8) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
+

@@ -254,3 +254,40 @@ def test_head_major_projection_layout_equals_token_rows():
         o_rows = M_.msda_fused_forward(value_hm, shapes, lsi, ref, rows, L, P, out_dtype=torch.bfloat16)
         o_hm = M_.msda_fused_forward(value_hm, shapes, lsi, ref, slabs, L, P, out_dtype=torch.bfloat16, proj_head_major=True)
     assert torch.equal(o_rows, o_hm)
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("B,Nq", [(2, 300), (1, 11363), (3, 1)])
+def test_sampling_prep_op_matches_the_torch_expressions(B, Nq, ref_dim):
+    """softmax + offset normalisation + reference-point add as one launch each way (csrc/sampling_prep.hip) against the
+    module's torch formulation (ms_deform_attn.py:322-349), values and gradients."""
+    from salience_detr_amd.ms_deform_attn import _SamplingPrep
+    M, L, P = 8, 4, 4
+    shapes = torch.tensor([[100, 168], [50, 84], [25, 42], [13, 21]], device="cuda")
+    off = (syn.det_randn(f"sp.off{Nq}", (B, Nq, M, L, P, 2)) * 3).cuda()
+    lg = (syn.det_randn(f"sp.lg{Nq}", (B, Nq, M, L * P)) * 2).cuda()
+    ref = syn.det_rand(f"sp.ref{Nq}", (B, Nq, L, ref_dim)).cuda()
+    gl = syn.det_randn(f"sp.gl{Nq}", (B, Nq, M, L, P, 2)).cuda()
+    gw = syn.det_randn(f"sp.gw{Nq}", (B, Nq, M, L, P)).cuda()
+
+    def torch_form(o, g):
+        w = g.softmax(-1).view(B, Nq, M, L, P)
+        if ref_dim == 2:
+            norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+            loc = ref[:, :, None, :, None, :] + o / norm[None, None, None, :, None, :]
+        else:
+            loc = ref[:, :, None, :, None, :2] + o / P * ref[:, :, None, :, None, 2:] * 0.5
+        return loc, w
+
+    o1, g1 = off.clone().requires_grad_(True), lg.clone().requires_grad_(True)
+    loc1, w1 = torch_form(o1, g1)
+    ((loc1 * gl).sum() + (w1 * gw).sum()).backward()
+    o2, g2 = off.clone().requires_grad_(True), lg.clone().requires_grad_(True)
+    assert _SamplingPrep.applies(o2, g2, ref, L, P)
+    loc2, w2 = _SamplingPrep.apply(o2, g2, ref, shapes, L, P)
+    ((loc2 * gl).sum() + (w2 * gw).sum()).backward()
+    assert (loc2 - loc1).abs().max() <= 1e-6 * max(1.0, loc1.abs().max().item())
+    assert (w2 - w1).abs().max() <= 5e-7
+    assert (o2.grad - o1.grad).abs().max() <= 1e-6 * max(1.0, o1.grad.abs().max().item())
+    assert (g2.grad - g1.grad).abs().max() <= 2e-6 * max(1.0, g1.grad.abs().max().item())
+
