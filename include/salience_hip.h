@@ -737,6 +737,26 @@ int sdetr_sampling_prep_backward_f32(sdetr_stream_t stream, const float *grad_sa
                                      int num_heads, int num_levels, int num_points, int ref_dim, float *grad_offsets,
                                      float *grad_logits);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense multi-head attention over a few hundred rows for the TRAINING step, fp32, 32-channel heads
+ * (models/bricks/salience_transformer.py:371-376: the encoder layer's self-attention over its top-300 rows, between the
+ * in- and the out-projection of nn.MultiheadAttention).  q / k / v: element (b, n, h, c) at base + b * batch_stride +
+ * n * row_stride + h * 32 + c (floats; strides multiples of 4) -- e.g. the q and k halves of one [B, N, 512] projection.
+ * out [B, N, H * 32] = softmax(q k^T * scale) v with the heads concatenated; lse [B, H, N] = the rows' log-sum-exp
+ * (saved for the backward).  backward: grad_q / grad_k / grad_v in the layouts of q / k / v (every element written).
+ * At most sdetr_attention_train_max_rows() rows.
+ * --------------------------------------------------------------------------------------------- */
+int sdetr_attention_train_max_rows(void);
+int sdetr_attention_train_forward_f32(sdetr_stream_t stream, const float *q, int64_t q_batch_stride, int64_t q_row_stride,
+                                      const float *k, int64_t k_batch_stride, int64_t k_row_stride, const float *v,
+                                      int64_t v_batch_stride, int64_t v_row_stride, int batch_size, int num_heads,
+                                      int num_rows, int head_dim, float scale, float *out, float *lse);
+int sdetr_attention_train_backward_f32(sdetr_stream_t stream, const float *q, int64_t q_batch_stride, int64_t q_row_stride,
+                                       const float *k, int64_t k_batch_stride, int64_t k_row_stride, const float *v,
+                                       int64_t v_batch_stride, int64_t v_row_stride, int batch_size, int num_heads,
+                                       int num_rows, int head_dim, float scale, const float *out, const float *lse,
+                                       const float *grad_out, float *grad_q, float *grad_k, float *grad_v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,11 @@ SIGNATURES = {
     "sdetr_topk_uses_prefilter": (_i, [_i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
     "sdetr_merge_sorted_desc": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "sdetr_attention_train_max_rows": (_i, []),
+    "sdetr_attention_train_forward_f32": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, ctypes.c_float,
+                                                _p, _p]),
+    "sdetr_attention_train_backward_f32": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, ctypes.c_float,
+                                                 _p, _p, _p, _p, _p, _p]),
     "sdetr_sampling_prep_supported": (_i, [_i, _i]),
     "sdetr_sampling_prep_f32": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p, _p]),
     "sdetr_sampling_prep_backward_f32": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p, _p]),

@@ -24,7 +24,7 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
-from . import pyramid
+from . import attention_train, pyramid
 from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, attn_tail_ffn_advance,
                          attn_tail_ffn_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
@@ -121,7 +121,22 @@ class SalienceTransformerEncoderLayer(nn.Module):
         """nn.MultiheadAttention(q=k=qk, value=v) with the module's own parameters
         (salience_transformer.py:371-376).  The 300-token problem is launch-latency bound, so it is arranged as
         few launches: ONE in-projection GEMM over the stacked [qk ; v] rows (q,k are read from the first half,
-        v from the second), one fused scaled-dot-product attention, one out-projection."""
+        v from the second), one fused scaled-dot-product attention, one out-projection.  Under autograd (fp32, 32-channel
+        heads, no attention dropout): the q | k and the v projections as two GEMMs on their own rows and the attention
+        core as one launch forward, two backward (``attention_train.attention_qk_v``) -- no head-split copies."""
+        mha = self.pre_attention
+        E = qk.shape[-1]
+        if (torch.is_grad_enabled() and (qk.requires_grad or v.requires_grad or mha.in_proj_weight.requires_grad)
+                and not (self.training and mha.dropout > 0.0)):
+            w, b = mha.in_proj_weight, mha.in_proj_bias
+            linear = F.linear
+            if self.x3_projections and qk.dtype == torch.float32:
+                from .linear_x3 import x3_linear as linear
+            pqk = linear(qk, w[:2 * E], b[:2 * E])
+            pv = linear(v, w[2 * E:], b[2 * E:])
+            if attention_train.applies(pqk, pv, mha.num_heads):
+                o = attention_train.attention_qk_v(pqk, pv, mha.num_heads)
+                return linear(o, mha.out_proj.weight, mha.out_proj.bias)
         return self._pre_attention_stacked(torch.cat([qk, v], 1), qk.shape[1], qk.requires_grad)
 
     def _pre_attention_stacked(self, stacked: Tensor, N: int, needs_grad: bool = False,

@@ -181,3 +181,18 @@ def test_sampling_prep_rejects_bad_arguments(libpath):
     assert g(None, 8, 8, 8, 8, 8, -1, 8, 4, 4, 2, 8, 8) == _hip.EINVAL
     assert g(None, 8, 8, 8, 8, 8, 10, 8, 4, 4, 2, None, 8) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
 
+
+def test_attention_train_rejects_bad_arguments(libpath):
+    from salience_detr_amd import _hip
+    lib = _hip.lib()
+    assert lib.sdetr_attention_train_max_rows() >= 300
+    f = lib.sdetr_attention_train_forward_f32
+    args = lambda N=300, hd=32, rs=512, q=8: (None, q, 300 * 512, rs, 8, 300 * 512, 512, 8, 300 * 256, 256, 2, 8, N, hd, 0.17, 8, 8)
+    assert f(*args(hd=64)) == _hip.EINVAL and b"32-channel" in lib.sdetr_last_error()
+    assert f(*args(N=100000)) == _hip.EINVAL and b"at most" in lib.sdetr_last_error()
+    assert f(*args(rs=130)) == _hip.EINVAL and b"strides" in lib.sdetr_last_error()
+    assert f(*args(q=None)) == _hip.EINVAL and b"null" in lib.sdetr_last_error()
+    assert f(*args(N=0)) == 0
+    g = lib.sdetr_attention_train_backward_f32
+    assert g(None, 8, 1, 512, 8, 1, 512, 8, 1, 256, 2, 8, 300, 32, 0.17, 8, 8, 8, 8, None, 8) == _hip.EINVAL
+
