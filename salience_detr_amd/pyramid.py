@@ -19,10 +19,31 @@ def flatten_multi_level(multi_level_elements: Sequence[Tensor]) -> Tensor:
     return flat
 
 
+class _LevelPosEmbed(torch.autograd.Function):
+    """``cat_l(flatten(pos_l) + level_embeds[l])`` with the level embeddings' gradient as column sums of the token-major
+    gradient: one sum over the batch, then one per level over its rows -- the broadcast add's own backward reduces each
+    level's ``[B, hw, C]`` slice in up to three kernels (0.34 ms of the training step)."""
+
+    @staticmethod
+    def forward(ctx, level_embeds, *pos):
+        ctx.sizes = [int(p.shape[-2]) * int(p.shape[-1]) for p in pos]
+        return torch.cat([p.flatten(-2).transpose(1, 2) + level_embeds[l] for l, p in enumerate(pos)], 1)
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = grad.sum(0) if grad.shape[0] > 1 else grad[0]          # [S, C]
+        out, cur = [], 0
+        for n in ctx.sizes:
+            out.append(g[cur:cur + n].sum(0))
+            cur += n
+        return (torch.stack(out),) + (None,) * len(ctx.sizes)
+
+
 def get_lvl_pos_embed(level_embeds: Tensor, multi_level_pos_embeds: Sequence[Tensor]) -> Tensor:
     """pos + level embedding, flattened (base_transformer.py:29-33).  The level embedding is added in the token-major
-    layout -- the same sums, but its gradient then is a column sum of contiguous ``[B, hw, C]`` rows instead of a reduction
-    over the strided NCHW map (0.15 ms for the finest level alone in the training step)."""
+    layout (the same sums as the reference's NCHW add)."""
+    if level_embeds.requires_grad and torch.is_grad_enabled() and not any(p.requires_grad for p in multi_level_pos_embeds):
+        return _LevelPosEmbed.apply(level_embeds, *multi_level_pos_embeds)
     return torch.cat([p.flatten(-2).transpose(1, 2) + level_embeds[l] for l, p in enumerate(multi_level_pos_embeds)], 1)
 
 
