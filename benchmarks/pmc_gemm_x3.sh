@@ -7,7 +7,7 @@ for set in \
   "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VMEM" \
   "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_WR" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python benchmarks/gemm_x3_one.py 22726 256 2048 y 5 > /dev/null 2> $O/p$i.err
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o p -- python benchmarks/gemm_x3_one.py ${GX3_ARGS:-22726 256 2048 y 5} > /dev/null 2> $O/p$i.err
 done
 python - <<'PY'
 import csv, glob, collections

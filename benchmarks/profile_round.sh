@@ -43,13 +43,33 @@ rm -rf $O/${R}_mfma_1
 # 5. kernel A/B at batch 2 and at batch 16 (value maps beyond the 256 MiB Infinity Cache)
 python benchmarks/msda_resident_ab.py --out $O/${R}_msda_ab.json > /dev/null 2>&1
 python benchmarks/msda_resident_ab.py --batch 16 --reps 10 --out $O/${R}_msda_ab_b16.json > /dev/null 2>&1
+#    ... and on the reference's 5scale pyramid (level 3 alone resident), one and two images
+python benchmarks/msda_resident_ab.py --levels 5scale --batch 1 --nq 45330,36264,27198,18132,9066 --chunks 0 --out $O/${R}_msda_ab_5scale_b1.json > /dev/null 2>&1
+python benchmarks/msda_resident_ab.py --levels 5scale --batch 2 --nq 45330,9066 --chunks 0 --out $O/${R}_msda_ab_5scale_b2.json > /dev/null 2>&1
+python - <<PY
+import json
+a = json.load(open("$O/${R}_msda_ab_5scale_b1.json")); b = json.load(open("$O/${R}_msda_ab_5scale_b2.json"))
+json.dump({"note": "benchmarks/msda_resident_ab.py --levels 5scale (level 3 alone resident in LDS); batch 1 rows then batch 2 rows",
+           "rows": a + b}, open("$O/${R}_msda_ab_5scale.json", "w"), indent=1)
+PY
+rm -f $O/${R}_msda_ab_5scale_b1.json $O/${R}_msda_ab_5scale_b2.json
 # 6. training step, for the backward kernel
 python bench.py --mode train --steps 5 --warmup 2 > $O/${R}_train.json 2> $O/${R}_train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o p -- python bench.py --mode train --steps 3 --warmup 1 > /dev/null 2> $O/${R}_prof_train.err
 cp $(find $O/${R}_prof_train -name '*kernel_stats.csv' | head -1) $O/${R}_train_kernel_stats.csv
 rm -rf $O/${R}_prof_train
+#    the fp32-accurate GEMM on the step's Linear shapes, both generations against the library
+python benchmarks/gemm_x3_bench.py > $O/${R}_gemm_x3.json 2> /dev/null
+python benchmarks/train_op_profile.py > $O/${R}_train_ops.txt 2> /dev/null
 # 7. standalone micro-benchmarks of this round (built by benchmarks/micro/build.sh)
-for m in l2_prefetch hsort_phases; do
+for m in l2_prefetch hsort_phases mfma_valu_overlap; do
   [ -x benchmarks/micro/$m ] && timeout 60 ./benchmarks/micro/$m > $O/${R}_$m.json 2> /dev/null
 done
+( echo '{"gemm_x3_ablate": ['
+  for v in 0 1 2 3 4 5 6; do
+    [ -x benchmarks/micro/gemm_x3_ablate_$v ] && timeout 60 ./benchmarks/micro/gemm_x3_ablate_$v | sed 's/$/,/'
+  done
+  for K in 64 1024 2048; do timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 22726 $K 2048 | sed 's/$/,/'; done
+  SDETR_GEMM_X3_V1=1 timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 | sed 's/}$/, "generation": "128x128 tiles"}/'
+  echo ']}' ) > $O/${R}_gemm_x3_ablate.json 2> /dev/null
 ls $O | grep "^${R}" | head -40

@@ -402,9 +402,23 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_pre_kernel(GemmArgs p)
 // resources, out-of-range pieces by offset select: no branch inside a step, so the scheduler sees one block).
 constexpr int kV2M = 256, kV2N = 128, kV2Threads = 512;
 constexpr int kV2A = kV2M * kGRow;                   // 36 864 bytes: the A tile, fp32 rows of 144 bytes
-constexpr int kV2Bf = kV2N * kGRow;                  // 18 432: B as fp32 rows
 constexpr int kV2Bp = 3 * kV2N * kGPreRow;           // 30 720: B as three bf16 planes (rows of 80 bytes)
 constexpr int kV2PrePlane = kV2N * kGPreRow;         // 10 240
+
+// exact three-way split of four consecutive values: plane pl gets two words (bf16 pairs, lower index in the low half)
+__device__ __forceinline__ void g_split4(const float4 x, uint2 (&p)[3])
+{
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    float r1[4], r2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r1[i] = v[i] - __uint_as_float(__float_as_uint(v[i]) & 0xffff0000u);
+        r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
+    }
+    p[0] = make_uint2(g_pack_hi(v[0], v[1]), g_pack_hi(v[2], v[3]));
+    p[1] = make_uint2(g_pack_hi(r1[0], r1[1]), g_pack_hi(r1[2], r1[3]));
+    p[2] = make_uint2(g_pack_hi(r2[0], r2[1]), g_pack_hi(r2[2], r2[3]));
+}
 
 // byte offset or, when the piece is out of range, an offset no buffer contains (the load then returns zeros)
 __device__ __forceinline__ uint32_t v2_off(bool ok, uint32_t off) { return ok ? off : 0xfffffff0u; }
@@ -487,18 +501,35 @@ struct V2LoadB {
             q2 = buffer_load16(rs, v2_off(ok, o + 2u * plane_bytes));
         }
     }
+    // The LDS tile is three bf16 planes in every mode: an fp32 B is split HERE, once per element -- a B fragment is read
+    // by the four row-waves of the workgroup, and splitting it in each of them made the vector ALUs as busy as the matrix
+    // pipes (counters at 22 726 x 2048 x 2048: MFMA 56 % of the cycles, VALU 56 %, barely overlapped).
     __device__ __forceinline__ void store(char *tile, int tid) const
     {
-        if (BMODE == 1) {
-            char *d = tile + (tid >> 3) * kGRow + 16 * (tid & 7);
-            *reinterpret_cast<uint4 *>(d) = q0;
-            *reinterpret_cast<uint4 *>(d + 64 * kGRow) = q1;
-        } else if (BMODE == 0) {
-            char *d = tile + (4 * (tid & 31)) * kGRow + 8 * (tid >> 5);   // rows n .. n + 3, two reduction indices each
-            *reinterpret_cast<uint2 *>(d) = make_uint2(q0.x, q1.x);
-            *reinterpret_cast<uint2 *>(d + kGRow) = make_uint2(q0.y, q1.y);
-            *reinterpret_cast<uint2 *>(d + 2 * kGRow) = make_uint2(q0.z, q1.z);
-            *reinterpret_cast<uint2 *>(d + 3 * kGRow) = make_uint2(q0.w, q1.w);
+        if (BMODE == 1) {   // rows r, r + 64; reduction indices 4 c4 .. + 3: 8 bytes per plane and row
+            char *d = tile + (tid >> 3) * kGPreRow + 8 * (tid & 7);
+            const float4 x0 = __builtin_bit_cast(float4, q0), x1 = __builtin_bit_cast(float4, q1);
+            uint2 p0[3], p1[3];
+            g_split4(x0, p0);
+            g_split4(x1, p1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<uint2 *>(d + pl * kV2PrePlane) = p0[pl];
+                *reinterpret_cast<uint2 *>(d + pl * kV2PrePlane + 64 * kGPreRow) = p1[pl];
+            }
+        } else if (BMODE == 0) {   // rows n .. n + 3, reduction indices 2 kb, 2 kb + 1: 4 bytes per plane and row
+            char *d = tile + (4 * (tid & 31)) * kGPreRow + 4 * (tid >> 5);
+            const float4 k0 = __builtin_bit_cast(float4, q0), k1 = __builtin_bit_cast(float4, q1);
+            uint2 pa[3], pb[3];   // (row n, n + 1) and (row n + 2, n + 3), each word = the row's two reduction indices
+            g_split4(make_float4(k0.x, k1.x, k0.y, k1.y), pa);
+            g_split4(make_float4(k0.z, k1.z, k0.w, k1.w), pb);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<uint32_t *>(d + pl * kV2PrePlane) = pa[pl].x;
+                *reinterpret_cast<uint32_t *>(d + pl * kV2PrePlane + kGPreRow) = pa[pl].y;
+                *reinterpret_cast<uint32_t *>(d + pl * kV2PrePlane + 2 * kGPreRow) = pb[pl].x;
+                *reinterpret_cast<uint32_t *>(d + pl * kV2PrePlane + 3 * kGPreRow) = pb[pl].y;
+            }
         } else {
             char *d = tile + (tid >> 2) * kGPreRow + 16 * (tid & 3);
             *reinterpret_cast<uint4 *>(d) = q0;
@@ -518,14 +549,9 @@ struct V2Frags {
         for (int t = 0; t < 2; ++t) {
             const float4 *qa = reinterpret_cast<const float4 *>(fa + t * 32 * kGRow + kk * 64);
             a[t] = g_split(qa[0], qa[1]);
-            if (BMODE == 2) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[t].p[pl] = *reinterpret_cast<const u32x4_t *>(fb + t * 32 * kGPreRow + pl * kV2PrePlane + kk * 32);
-            } else {
-                const float4 *qb = reinterpret_cast<const float4 *>(fb + t * 32 * kGRow + kk * 64);
-                b[t] = g_split(qb[0], qb[1]);
-            }
+            for (int pl = 0; pl < 3; ++pl)
+                b[t].p[pl] = *reinterpret_cast<const u32x4_t *>(fb + t * 32 * kGPreRow + pl * kV2PrePlane + kk * 32);
         }
     }
     __device__ __forceinline__ void mfmas(g_f32x16_t (&acc)[2][2]) const
@@ -550,8 +576,8 @@ template <bool A_KMAJOR, int BMODE>
 __global__ void __launch_bounds__(kV2Threads, 1) gemm_x3_v2_kernel(GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int kStage = kV2A + (BMODE == 2 ? kV2Bp : kV2Bf);
-    constexpr int kBRow = BMODE == 2 ? kGPreRow : kGRow;
+    constexpr int kStage = kV2A + kV2Bp;
+    constexpr int kBRow = kGPreRow;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -594,7 +620,7 @@ __global__ void __launch_bounds__(kV2Threads, 1) gemm_x3_v2_kernel(GemmArgs p)
     tb0.load(rb, ldb, plane_bytes, n0, p.N, kbeg + 2 * kGK, kend, tid);
     __syncthreads();
     const int fa_off = (64 * wm + (lane & 31)) * kGRow + (lane >> 5) * 32;
-    const int fb_off = kV2A + (64 * wn + (lane & 31)) * kBRow + (lane >> 5) * (BMODE == 2 ? 16 : 32);
+    const int fb_off = kV2A + (64 * wn + (lane & 31)) * kBRow + (lane >> 5) * 16;
     V2Frags<BMODE> f0, f1;
     f0.fetch(lds + fa_off, lds + fb_off, 0);
     f1 = f0;   // (defined also when an ablation build skips the fetches)
@@ -696,7 +722,7 @@ static int launch_gemm_x3(hipStream_t s, const GemmArgs &a, int splits)
 template <bool AK, int BMODE>
 static int launch_gemm_x3_v2(hipStream_t s, const GemmArgs &a, int splits)
 {
-    constexpr int lds_bytes = 2 * (kV2A + (BMODE == 2 ? kV2Bp : kV2Bf));
+    constexpr int lds_bytes = 2 * (kV2A + kV2Bp);
     static DeviceOnce once;
     allow_dynamic_lds(gemm_x3_v2_kernel<AK, BMODE>, once, lds_bytes);
     const dim3 grid((unsigned)((a.N + kV2N - 1) / kV2N), (unsigned)((a.M + kV2M - 1) / kV2M), (unsigned)splits);
