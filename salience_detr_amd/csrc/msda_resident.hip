@@ -51,6 +51,8 @@ struct ResidentArgs {
     int B, Nv, M, Nq;
     int H0, W0, H1, W1, H2, W2, H3, W3;   // host copy of the level shapes
     int S1, S2, S3;                       // level start pixels (S0 = 0)
+    int image_serial;                     // G > 0: a workgroup = (image lane g < G, head, chunk) and walks the images g, g + G, ...;
+                                          // 0: a workgroup = (image, head, chunk)
     int res_start;                        // first resident pixel: S2 (levels 2 + 3 resident) or S3 (level 3 only)
     int res_px;                           // Nv - res_start: pixels resident in LDS
     int chunks;                           // workgroups per (image, head)
@@ -121,7 +123,7 @@ __device__ __forceinline__ float quad_xor2(float v)
 // RES = number of resident levels: 2 (levels 2 + 3, the benchmark pyramid: 8 of a row's 16 samples come from LDS) or 1
 // (level 3 only, for pyramids whose two coarse levels together exceed the LDS -- the reference's 5scale configuration,
 // configs/salience_detr/salience_detr_resnet50_5scale_800_1333.py:33-36: 4 of the 16 samples).
-template <typename VT, bool REF4, int RES = 2>
+template <typename VT, bool REF4, int RES = 2, bool SERIAL = false>
 __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p)
 {
     using F = ResFma<VT>;
@@ -135,13 +137,21 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = blockIdx.x % p.M;
     const int rest = blockIdx.x / p.M;
-    const int b = rest / p.chunks;
-    const int chunk = rest - b * p.chunks;
+    // one image per workgroup (the workgroups of all images side by side), or -- large batches, `image_serial` -- every
+    // workgroup walks ALL images for its (head, chunk of the queries): the chip then works on one image at a time and
+    // that image's maps (23 MB) stay in the L2s / the Infinity Cache while they are gathered from; with sixteen images
+    // in flight at once their 366 MB of maps evict each other from the 256 MB Infinity Cache (0.14-0.15 of the roofline)
+    // (SERIAL is a template parameter: the one-image form keeps its register allocation -- exactly 128, no spills)
+    const int b_first = rest / p.chunks;                       // SERIAL: the workgroup's image lane (0 .. image_serial - 1)
+    const int b_end = SERIAL ? p.B : b_first + 1;
+    const int b_step = SERIAL ? p.image_serial : 1;
+    const int chunk = rest - b_first * p.chunks;
     const int rows_per_chunk = (p.Nq + p.chunks - 1) / p.chunks;
     const int q_lo = chunk * rows_per_chunk;
     const int q_hi = min(p.Nq, q_lo + rows_per_chunk);
     if (q_lo >= q_hi) return;  // workgroup-uniform
 
+    for (int b = b_first; b < b_end; b += b_step) {
     const char *base = p.value + ((int64_t)b * p.M + m) * p.Nv * 64;
 
     // ---- stage levels 2 and 3 of this (image, head) with LDS-DMA (global_load_lds_dwordx4: no registers, no LDS store
@@ -216,7 +226,6 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
         // no row group for this wave: its pieces of the maps still have to land before the others read them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        return;
     }
     for (int rg = wave; rg < ngroups; rg += kRWaves) {
         const int slot = q_lo + rg * 16 + g;
@@ -373,6 +382,8 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
         // the next row group rewrites the weight table: this wave's reads of it have all returned (their values
         // were consumed above), and LDS operations of one wave complete in order
     }
+    if (SERIAL && b + b_step < b_end) __syncthreads();   // every wave is done with this image's maps: the next image's take their place
+    }   // images
 }
 
 static int device_cu_count()
@@ -441,33 +452,53 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     a.proj = reinterpret_cast<const bf16_t *>(proj_hm_bf16);
     a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
     a.B = B; a.Nv = Nv; a.M = M; a.Nq = Nq;
+    // Maps beyond what the Infinity Cache holds next to everything else (256 MiB; the benchmark's two images: 46 MB): the
+    // chip works on FOUR images at a time (every workgroup walks the images of its lane), so that the maps being gathered
+    // from stay cached: at batch 16 (366 MB of maps) 299 / 187 / 78 us at 11 363 / 6817 / 2272 queries against 380 / 231 /
+    // 79 with all sixteen in flight and 336 / 249 / 129 one at a time (direct kernel: 350 / 234 / 68).
+    // SDETR_MSDA_IMAGE_SERIAL=0 / G forces the number of lanes for A/B runs.
+    const int cus = device_cu_count();
+    int lanes = 0;
+    if ((int64_t)B * M * Nv * 64 > ((int64_t)160 << 20) && B > 4) lanes = 4;
+    if (const char *e = getenv("SDETR_MSDA_IMAGE_SERIAL")) {
+        const int v = atoi(e);
+        lanes = v <= 0 ? 0 : (v > B ? B : v);
+    }
+    a.image_serial = lanes;
+    const int groups = lanes ? lanes : B;   // (image, head) slots the workgroups are spread over
     if (chunks <= 0) {
         // one workgroup per CU: the (image, head) pairs share the CUs evenly; at least four row groups per workgroup
         // (measured at 900 / 2272 queries: spreading a small layer over all CUs beats filling fewer CUs' waves)
-        chunks = device_cu_count() / (B * M);
+        chunks = cus / (groups * M);
         const int max_chunks = (Nq + 63) / 64;
         if (chunks > max_chunks) chunks = max_chunks;
         if (chunks < 1) chunks = 1;
     }
     a.chunks = chunks;
-    const int64_t blocks = (int64_t)B * M * chunks;
+    const int64_t blocks = (int64_t)groups * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_resident_forward: grid too large");
     const int lds_bytes = 2 * kRPad + a.res_px * 64 + kRWaves * kRWeightBytes;
     // the attribute is per device and the call is cheap: set before every launch (no process-wide flag)
-#define SDETR_RES_LAUNCH(VT, REF4, RES)                                                                    \
-    do {                                                                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4, RES>),     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                    \
-        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4, RES>), dim3((unsigned)blocks), dim3(kRThreads), \
-                           lds_bytes, stream, a);                                                              \
+#define SDETR_RES_LAUNCH(VT, REF4, RES, SER)                                                                    \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_resident_kernel<VT, REF4, RES, SER>),     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                         \
+        hipLaunchKernelGGL((msda_resident_kernel<VT, REF4, RES, SER>), dim3((unsigned)blocks), dim3(kRThreads), \
+                           lds_bytes, stream, a);                                                                   \
+    } while (0)
+#define SDETR_RES_PICK(REF4, RES)                                                                               \
+    do {                                                                                                            \
+        if (a.image_serial) SDETR_RES_LAUNCH(half_t, REF4, RES, true);                                          \
+        else SDETR_RES_LAUNCH(half_t, REF4, RES, false);                                                        \
     } while (0)
     if (res_levels == 2) {
-        if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true, 2);
-        else SDETR_RES_LAUNCH(half_t, false, 2);
+        if (ref_dim == 4) SDETR_RES_PICK(true, 2);
+        else SDETR_RES_PICK(false, 2);
     } else {
-        if (ref_dim == 4) SDETR_RES_LAUNCH(half_t, true, 1);
-        else SDETR_RES_LAUNCH(half_t, false, 1);
+        if (ref_dim == 4) SDETR_RES_PICK(true, 1);
+        else SDETR_RES_PICK(false, 1);
     }
+#undef SDETR_RES_PICK
 #undef SDETR_RES_LAUNCH
     note_forward_kernel(SDETR_KERNEL_MSDA_RESIDENT);
     return check_launch("msda_resident");

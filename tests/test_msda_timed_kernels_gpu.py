@@ -113,6 +113,40 @@ def test_resident_kernel_vs_oracle(B, Nq, levels, chunks, ref_dim):
     assert (out - direct).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("lanes", ["1", "2", "3", "5"])
+@pytest.mark.parametrize("B,Nq,levels", [(5, 300, LEVELS_SMALL), (3, 1000, LEVELS_FULL), (4, 40, LEVELS_L3_ONLY)])
+def test_resident_kernel_image_lanes(B, Nq, levels, lanes, monkeypatch):
+    """Large batches: a workgroup walks the images of its lane (g, g + G, ...) so that only G images' maps are gathered
+    from at a time -- forced here on small batches (also with more lanes than images, with idle waves and with a
+    partial last round); the same numbers as the one-image-per-workgroup form."""
+    value, shapes, lsi, proj, ref = _case(B, Nq, levels, 2, seed=Nq + 7)
+    Nv = value.shape[1]
+    hm = M.value_to_head_major(value.view(B, Nv, HEADS * D).to(DEV), None, HEADS, torch.float16)
+    slab = _head_major_slab(proj).to(DEV)
+    monkeypatch.setenv("SDETR_MSDA_IMAGE_SERIAL", "0")
+    want = M.msda_resident_forward(hm, levels, ref.to(DEV), slab, out_dtype=torch.float32)
+    monkeypatch.setenv("SDETR_MSDA_IMAGE_SERIAL", lanes)
+    for chunks in (0, 1, 5):
+        got = M.msda_resident_forward(hm, levels, ref.to(DEV), slab, out_dtype=torch.float32, chunks=chunks)
+        assert torch.equal(got, want)
+    expect = _expected(value.to(torch.float16).float(), shapes, lsi, ref, proj.float())
+    assert np.abs(want.cpu().numpy() - expect).max() < TOL
+
+
+def test_resident_kernel_batch_16_takes_the_image_lanes():
+    """366 MB of value maps (batch 16 of the benchmark pyramid): the launch picks the image-lane form by itself; checked
+    against the direct kernel (same arithmetic, different data path)."""
+    B, Nq = 16, 1500
+    value, shapes, lsi, proj, ref = _case(B, Nq, LEVELS_FULL, 2, seed=99)
+    Nv = value.shape[1]
+    hm = M.value_to_head_major(value.view(B, Nv, HEADS * D).to(DEV), None, HEADS, torch.float16)
+    slab = _head_major_slab(proj).to(DEV)
+    out = M.msda_resident_forward(hm, LEVELS_FULL, ref.to(DEV), slab, out_dtype=torch.float32)
+    direct = M.msda_fused_forward(hm, shapes.to(DEV), lsi.to(DEV), ref.to(DEV), slab, L, P, out_dtype=torch.float32,
+                                  proj_head_major=True)
+    assert (out - direct).abs().max().item() < 2e-5
+
+
 def test_resident_kernel_borders_and_wild_locations():
     """Samples on / beyond every border of every level, NaN-free zero contributions outside (the reference's
     `h_im > -1 && w_im > -1 && h_im < H && w_im < W` early-out, ms_deform_im2col_cuda.cuh:258-262)."""
