@@ -11,7 +11,7 @@ for f in lds_atomic_rate mfma_rate ffn_two_wave graph_launch_floor valu_rate gat
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $extra -o $f $f.hip 2> /dev/null && echo "built $f"
 done
 # csrc/gemm_x3.hip with one leg removed (see gemm_x3_ablate.hip)
-for v in 0 1 2 3; do
+for v in 0 1 2 3 4 5 6; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DSDETR_GX3_ABLATE=$v -I ../../include \
     -o gemm_x3_ablate_$v gemm_x3_ablate.hip 2> /dev/null && echo "built gemm_x3_ablate_$v"
 done

@@ -19,6 +19,7 @@ char *error_buffer()
 int main(int argc, char **argv)
 {
     const int T = argc > 1 ? atoi(argv[1]) : 22726, K = argc > 2 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 2048;
+    const bool dw = argc > 4 && argv[4][0] == 'd';   // "dw": the weight gradient dy^T x (both operands reduction-major, 16 slices)
     float *x, *w, *y;
     CK(hipMalloc(&x, (size_t)T * K * 4));
     CK(hipMalloc(&w, (size_t)N * K * 4));
@@ -33,15 +34,21 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    // y = x w^T [T, N]   or   dw = dy^T x [N, K] with dy = the [T, N] buffer (reduction over T in 16 slices, atomics)
+    auto call = [&]() {
+        if (dw) return sdetr_gemm_x3_f32(s, y, N, 0, x, K, 0, w, K, N, K, T, nullptr, 16, nullptr);
+        return sdetr_gemm_x3_f32(s, x, K, 1, w, K, 1, y, N, T, N, K, nullptr, 1, nullptr);
+    };
     for (int r = 0; r < 3; ++r)
-        if (sdetr_gemm_x3_f32(s, x, K, 1, w, K, 1, y, N, T, N, K, nullptr, 1, nullptr)) { fprintf(stderr, "%s\n", sdetr::error_buffer()); return 1; }
+        if (call()) { fprintf(stderr, "%s\n", sdetr::error_buffer()); return 1; }
     CK(hipEventRecord(e0, s));
-    for (int r = 0; r < 10; ++r) sdetr_gemm_x3_f32(s, x, K, 1, w, K, 1, y, N, T, N, K, nullptr, 1, nullptr);
+    for (int r = 0; r < 10; ++r) call();
     CK(hipEventRecord(e1, s));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("{\"ablate\": %d, \"T\": %d, \"K\": %d, \"N\": %d, \"us\": %.1f, \"tflops_fp32_equivalent\": %.1f}\n", SDETR_GX3_ABLATE, T, K, N,
+    printf("{\"ablate\": %d, \"product\": \"%s\", \"T\": %d, \"K\": %d, \"N\": %d, \"us\": %.1f, \"tflops_fp32_equivalent\": %.1f}\n", SDETR_GX3_ABLATE,
+           dw ? "dw = dy^T x" : "y = x w^T", T, K, N,
            ms * 100.f, 2.0 * T * K * N / (ms * 1e-4) / 1e12);
     return 0;
 }

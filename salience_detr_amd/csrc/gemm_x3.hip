@@ -123,7 +123,10 @@ struct TileLoad {
             v2 = ld4(q + 64 * ld, kok && r + 64 < rows);
             v3 = ld4(q + 96 * ld, kok && r + 96 < rows);
         } else {
-            const int kb = tid >> 5, mb = tid & 31;
+            // (the reduction index varies fastest over the lanes: the 4 x 4 blocks of 8 neighbouring lanes land on 32
+            // consecutive dwords of an LDS row -- with the row block varying fastest, 32 lanes met on 8 banks: 77 % of the
+            // LDS cycles of the weight-gradient product were bank conflicts)
+            const int kb = tid & 7, mb = tid >> 3;
             const int row = row0 + 4 * mb, k = k0 + 4 * kb;
             const float *q = src + (int64_t)k * ld + row;
             const bool rok = row < rows;
@@ -143,7 +146,7 @@ struct TileLoad {
             *reinterpret_cast<float4 *>(d + 64 * kGRow) = v2;
             *reinterpret_cast<float4 *>(d + 96 * kGRow) = v3;
         } else {
-            const int kb = tid >> 5, mb = tid & 31;   // 4 x 4 block transposed in registers
+            const int kb = tid & 7, mb = tid >> 3;   // 4 x 4 block transposed in registers
             char *d = tile + (4 * mb) * kGRow + 16 * kb;
             *reinterpret_cast<float4 *>(d) = make_float4(v0.x, v1.x, v2.x, v3.x);
             *reinterpret_cast<float4 *>(d + kGRow) = make_float4(v0.y, v1.y, v2.y, v3.y);
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
 
     if (want_row_sum) {   // (uniform per workgroup) 8 threads hold pieces of each row's sum: meet in LDS, one atomic per row
         float *red = reinterpret_cast<float *>(pa);   // [8][128]; the operand tiles are no longer needed
-        const int kb = tid >> 5, mb = tid & 31;
+        const int kb = tid & 7, mb = tid >> 3;
         *reinterpret_cast<float4 *>(red + kb * 128 + 4 * mb) = row_sum;
         __syncthreads();
         if (tid < 128 && m0 + tid < p.M) {
@@ -439,7 +442,7 @@ struct V2LoadA {
             v2 = buffer_load16(rs, v2_off(kok && r + 64 < rows, o + 2u * step));
             v3 = buffer_load16(rs, v2_off(kok && r + 96 < rows, o + 3u * step));
         } else {
-            const int kb = u >> 5, mb = u & 31, row = row0 + 128 * half + 4 * mb, k = k0 + 4 * kb;
+            const int kb = u & 7, mb = u >> 3, row = row0 + 128 * half + 4 * mb, k = k0 + 4 * kb;   // (see TileLoad)
             const bool rok = row < rows;
             const uint32_t o = ((uint32_t)k * ld + (uint32_t)row) * 4u, step = ld * 4u;
             v0 = buffer_load16(rs, v2_off(rok && k < kend, o));
@@ -458,7 +461,7 @@ struct V2LoadA {
             *reinterpret_cast<uint4 *>(d + 64 * kGRow) = v2;
             *reinterpret_cast<uint4 *>(d + 96 * kGRow) = v3;
         } else {
-            char *d = tile + (128 * half + 4 * (u & 31)) * kGRow + 16 * (u >> 5);   // 4 x 4 block transposed in registers
+            char *d = tile + (128 * half + 4 * (u >> 3)) * kGRow + 16 * (u & 7);   // 4 x 4 block transposed in registers
             *reinterpret_cast<uint4 *>(d) = make_uint4(v0.x, v1.x, v2.x, v3.x);
             *reinterpret_cast<uint4 *>(d + kGRow) = make_uint4(v0.y, v1.y, v2.y, v3.y);
             *reinterpret_cast<uint4 *>(d + 2 * kGRow) = make_uint4(v0.z, v1.z, v2.z, v3.z);
@@ -487,7 +490,7 @@ struct V2LoadB {
             q0 = buffer_load16(rs, v2_off(kok && r < rows, o));
             q1 = buffer_load16(rs, v2_off(kok && r + 64 < rows, o + 64u * ld * 4u));
         } else if (BMODE == 0) {
-            const int kb = tid >> 5, mb = tid & 31, row = row0 + 4 * mb, k = k0 + 2 * kb;
+            const int kb = tid & 15, mb = tid >> 4, row = row0 + 4 * mb, k = k0 + 2 * kb;   // (reduction index fastest)
             const bool rok = row < rows;
             const uint32_t o = ((uint32_t)k * ld + (uint32_t)row) * 4u;
             q0 = buffer_load16(rs, v2_off(rok && k < kend, o));
@@ -518,7 +521,7 @@ struct V2LoadB {
                 *reinterpret_cast<uint2 *>(d + pl * kV2PrePlane + 64 * kGPreRow) = p1[pl];
             }
         } else if (BMODE == 0) {   // rows n .. n + 3, reduction indices 2 kb, 2 kb + 1: 4 bytes per plane and row
-            char *d = tile + (4 * (tid & 31)) * kGPreRow + 4 * (tid >> 5);
+            char *d = tile + (4 * (tid >> 4)) * kGPreRow + 4 * (tid & 15);
             const float4 k0 = __builtin_bit_cast(float4, q0), k1 = __builtin_bit_cast(float4, q1);
             uint2 pa[3], pb[3];   // (row n, n + 1) and (row n + 2, n + 3), each word = the row's two reduction indices
             g_split4(make_float4(k0.x, k1.x, k0.y, k1.y), pa);
@@ -657,7 +660,7 @@ __global__ void __launch_bounds__(kV2Threads, 1) gemm_x3_v2_kernel(GemmArgs p)
     if (want_row_sum) {   // (uniform per workgroup) 8 threads hold pieces of each row's sum: meet in LDS, one atomic per row
         __syncthreads();
         float *red = reinterpret_cast<float *>(lds);   // [8][256]
-        const int u = tid & 255, half = tid >> 8, kb = u >> 5, mb = u & 31;
+        const int u = tid & 255, half = tid >> 8, kb = u & 7, mb = u >> 3;
         *reinterpret_cast<float4 *>(red + kb * 256 + 128 * half + 4 * mb) = row_sum;
         __syncthreads();
         if (tid < 256 && m0 + tid < p.M) {
