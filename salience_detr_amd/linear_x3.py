@@ -144,7 +144,7 @@ class _LinearX3(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                                    # dx = dy w
             if X3_DX and N % 8 == 0 and _x3_wide(T, N, K):
-                gx = gemm_x3_presplit_b(g2, True, presplit(weight, transpose=True), T, K, N)   # dx = dy w
+                gx = gemm_x3(g2, True, weight, False, T, K, N)   # dx = dy w (the weight read reduction-major: no transposed split pass)
             else:
                 gx = g2 @ weight
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
