@@ -6,19 +6,23 @@
 // way, softmax and its backward, and ~20 layout copies / zero fills per layer around the head split -- all launch-bound.
 // Here the projected rows are read where the two in-projection GEMMs leave them (q | k of a row side by side, heads along
 // the features) and the heads come out concatenated for the out-projection: no copy, three launches per layer in all.
-//   forward      : workgroup = (64 query rows, head, image), 4 lanes per row; the head's K and V in LDS (rows padded to
-//                  36 floats: the four lanes of a row walk four distant keys on different banks); online softmax per
-//                  lane over its quarter of the keys, the quarters merged by two lane exchanges; saves the row's
+//   forward      : workgroup = (32 query rows, head, image), 8 lanes per row (160 workgroups for 2 x 300 rows: with 4 lanes
+//                  per row the 80 single-wave-per-SIMD workgroups were instruction-bound at 34 us); the head's K and V in LDS
+//                  (rows padded to 36 floats); online softmax per lane over its eighth of the keys, merged by three lane
+//                  exchanges; saves the row's
 //                  log-sum-exp for the backward.
 //   backward dq  : the same decomposition; p = exp(s - lse) recomputed, dS = p (dO.v - D) with D = dO.o.
-//   backward dkv : workgroup = (64 keys, head, image), 4 lanes per key over quarters of the QUERY rows, the head's Q and
+//   backward dkv : workgroup = (32 keys, head, image), 8 lanes per key over eighths of the QUERY rows, the head's Q and
 //                  dO (and lse, D) in LDS.
 // Every output element is written exactly once (no zero fill, no atomics).  N <= 512 rows.
 #include "common.h"
 
 namespace sdetr {
 
-constexpr int kAtD = 32, kAtRow = 36, kAtMaxN = 512, kAtThreads = 256, kAtRowsPerBlock = 64;
+constexpr int kAtD = 32, kAtRow = 36, kAtMaxN = 512, kAtThreads = 256;
+constexpr int kAtLanes = 8;                                // lanes per row: each walks 1 / 8 of the keys (or of the query rows)
+constexpr int kAtRowsPerBlock = kAtThreads / kAtLanes;    // 32
+constexpr int kAtOwn = kAtD / kAtLanes;                    // channels a lane writes: 4
 
 struct AtArgs {
     const float *q, *k, *v;       // element (b, n, h, c) at base + b * bs + n * rs + h * 32 + c
@@ -59,11 +63,22 @@ __device__ __forceinline__ void at_axpy(float (&acc)[kAtD], float a, const float
     }
 }
 // rows [0, N) of a head's matrix (row stride rs floats in global memory) into LDS rows of kAtRow floats
+// (four loads in flight per thread and round: one at a time the copy of a 300 x 32 matrix is ten dependent trips to memory)
 __device__ __forceinline__ void at_stage(const float *src, int64_t rs, int N, float *dst, int tid)
 {
-    for (int t = tid; t < N * (kAtD / 4); t += kAtThreads) {
-        const int n = t >> 3, c4 = t & 7;
-        reinterpret_cast<float4 *>(dst + n * kAtRow)[c4] = reinterpret_cast<const float4 *>(src + (int64_t)n * rs)[c4];
+    const int total = N * (kAtD / 4);
+    for (int t0 = tid; t0 < total; t0 += 4 * kAtThreads) {
+        float4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = min(t0 + u * kAtThreads, total - 1);
+            r[u] = reinterpret_cast<const float4 *>(src + (int64_t)(t >> 3) * rs)[t & 7];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * kAtThreads;
+            if (t < total) reinterpret_cast<float4 *>(dst + (t >> 3) * kAtRow)[t & 7] = r[u];
+        }
     }
 }
 
@@ -75,14 +90,14 @@ __global__ void __launch_bounds__(kAtThreads) attention_train_fwd_kernel(AtArgs 
     at_stage(p.k + (int64_t)b * p.k_bs + h * kAtD, p.k_rs, p.N, ks, tid);
     at_stage(p.v + (int64_t)b * p.v_bs + h * kAtD, p.v_rs, p.N, vs, tid);
     __syncthreads();
-    const int part = tid & 3, i = blockIdx.x * kAtRowsPerBlock + (tid >> 2);
+    const int part = tid & (kAtLanes - 1), i = blockIdx.x * kAtRowsPerBlock + tid / kAtLanes;
     const bool live = i < p.N;
     const int ii = live ? i : p.N - 1;
     float q[kAtD], acc[kAtD];
     at_load_row(p.q + (int64_t)b * p.q_bs + (int64_t)ii * p.q_rs + h * kAtD, q);
 #pragma unroll
     for (int c = 0; c < kAtD; ++c) { q[c] *= p.scale; acc[c] = 0.f; }
-    const int per = (p.N + 3) >> 2, j0 = part * per, j1 = min(p.N, j0 + per);
+    const int per = (p.N + kAtLanes - 1) / kAtLanes, j0 = part * per, j1 = min(p.N, j0 + per);
     float m = -INFINITY, l = 0.f;
     for (int j = j0; j < j1; ++j) {
         const float s = at_dot(q, ks + j * kAtRow);
@@ -97,26 +112,26 @@ __global__ void __launch_bounds__(kAtThreads) attention_train_fwd_kernel(AtArgs 
         l += e;
         at_axpy(acc, e, vs + j * kAtRow);
     }
-    // the four quarters of a row sit in adjacent lanes
-    float m_all = fmaxf(m, __shfl_xor(m, 1, 4));
-    m_all = fmaxf(m_all, __shfl_xor(m_all, 2, 4));
-    const float w = m == -INFINITY ? 0.f : expf(m - m_all);   // (an empty quarter: N < 4)
+    // the parts of a row sit in adjacent lanes
+    float m_all = m;
+#pragma unroll
+    for (int o = 1; o < kAtLanes; o <<= 1) m_all = fmaxf(m_all, __shfl_xor(m_all, o, kAtLanes));
+    const float w = m == -INFINITY ? 0.f : expf(m - m_all);   // (an empty part: fewer keys than lanes)
     l *= w;
-    l += __shfl_xor(l, 1, 4);
-    l += __shfl_xor(l, 2, 4);
+#pragma unroll
+    for (int o = 1; o < kAtLanes; o <<= 1) l += __shfl_xor(l, o, kAtLanes);
     const float inv = 1.0f / l;
-    float mine[8];
+    float mine[kAtOwn];
 #pragma unroll
     for (int c = 0; c < kAtD; ++c) {
         float a = acc[c] * w;
-        a += __shfl_xor(a, 1, 4);
-        a += __shfl_xor(a, 2, 4);
-        if ((c >> 3) == part) mine[c & 7] = a * inv;   // (c is a compile-time index: a select, not an indexed store)
+#pragma unroll
+        for (int o = 1; o < kAtLanes; o <<= 1) a += __shfl_xor(a, o, kAtLanes);
+        if (c / kAtOwn == part) mine[c % kAtOwn] = a * inv;   // (c is a compile-time index: a select, not an indexed store)
     }
     if (live) {
-        float *o = p.o + ((int64_t)b * p.N + i) * (p.H * kAtD) + h * kAtD + 8 * part;
+        float *o = p.o + ((int64_t)b * p.N + i) * (p.H * kAtD) + h * kAtD + kAtOwn * part;
         reinterpret_cast<float4 *>(o)[0] = make_float4(mine[0], mine[1], mine[2], mine[3]);
-        reinterpret_cast<float4 *>(o)[1] = make_float4(mine[4], mine[5], mine[6], mine[7]);
         if (part == 0) p.lse[((int64_t)b * p.H + h) * p.N + i] = m_all + logf(l);
     }
 }
@@ -129,7 +144,7 @@ __global__ void __launch_bounds__(kAtThreads) attention_train_bwd_dq_kernel(AtAr
     at_stage(p.k + (int64_t)b * p.k_bs + h * kAtD, p.k_rs, p.N, ks, tid);
     at_stage(p.v + (int64_t)b * p.v_bs + h * kAtD, p.v_rs, p.N, vs, tid);
     __syncthreads();
-    const int part = tid & 3, i = blockIdx.x * kAtRowsPerBlock + (tid >> 2);
+    const int part = tid & (kAtLanes - 1), i = blockIdx.x * kAtRowsPerBlock + tid / kAtLanes;
     const bool live = i < p.N;
     const int ii = live ? i : p.N - 1;
     float q[kAtD], go[kAtD], dq[kAtD];
@@ -146,24 +161,23 @@ __global__ void __launch_bounds__(kAtThreads) attention_train_bwd_dq_kernel(AtAr
     const float lse = p.lse[((int64_t)b * p.H + h) * p.N + ii];
 #pragma unroll
     for (int c = 0; c < kAtD; ++c) { q[c] *= p.scale; dq[c] = 0.f; }
-    const int per = (p.N + 3) >> 2, j0 = part * per, j1 = min(p.N, j0 + per);
+    const int per = (p.N + kAtLanes - 1) / kAtLanes, j0 = part * per, j1 = min(p.N, j0 + per);
     for (int j = j0; j < j1; ++j) {
         const float pr = expf(at_dot(q, ks + j * kAtRow) - lse);
         const float ds = pr * (at_dot(go, vs + j * kAtRow) - D) * p.scale;
         at_axpy(dq, ds, ks + j * kAtRow);
     }
-    float mine[8];
+    float mine[kAtOwn];
 #pragma unroll
     for (int c = 0; c < kAtD; ++c) {
         float a = dq[c];
-        a += __shfl_xor(a, 1, 4);
-        a += __shfl_xor(a, 2, 4);
-        if ((c >> 3) == part) mine[c & 7] = a;
+#pragma unroll
+        for (int o = 1; o < kAtLanes; o <<= 1) a += __shfl_xor(a, o, kAtLanes);
+        if (c / kAtOwn == part) mine[c % kAtOwn] = a;
     }
     if (live) {
-        float *g = p.gq + (int64_t)b * p.q_bs + (int64_t)i * p.q_rs + h * kAtD + 8 * part;
+        float *g = p.gq + (int64_t)b * p.q_bs + (int64_t)i * p.q_rs + h * kAtD + kAtOwn * part;
         reinterpret_cast<float4 *>(g)[0] = make_float4(mine[0], mine[1], mine[2], mine[3]);
-        reinterpret_cast<float4 *>(g)[1] = make_float4(mine[4], mine[5], mine[6], mine[7]);
     }
 }
 
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(kAtThreads) attention_train_bwd_dkv_kernel(AtA
         lse_s[n] = p.lse[((int64_t)b * p.H + h) * p.N + n];
     }
     __syncthreads();
-    const int part = tid & 3, j = blockIdx.x * kAtRowsPerBlock + (tid >> 2);
+    const int part = tid & (kAtLanes - 1), j = blockIdx.x * kAtRowsPerBlock + tid / kAtLanes;
     const bool live = j < p.N;
     const int jj = live ? j : p.N - 1;
     float k[kAtD], v[kAtD], dk[kAtD], dv[kAtD];
@@ -194,28 +208,26 @@ __global__ void __launch_bounds__(kAtThreads) attention_train_bwd_dkv_kernel(AtA
     at_load_row(p.v + (int64_t)b * p.v_bs + (int64_t)jj * p.v_rs + h * kAtD, v);
 #pragma unroll
     for (int c = 0; c < kAtD; ++c) { k[c] *= p.scale; dk[c] = 0.f; dv[c] = 0.f; }
-    const int per = (p.N + 3) >> 2, i0 = part * per, i1 = min(p.N, i0 + per);
+    const int per = (p.N + kAtLanes - 1) / kAtLanes, i0 = part * per, i1 = min(p.N, i0 + per);
     for (int i = i0; i < i1; ++i) {
         const float pr = expf(at_dot(k, qs + i * kAtRow) - lse_s[i]);
         const float ds = pr * (at_dot(v, gs + i * kAtRow) - d_s[i]) * p.scale;
         at_axpy(dk, ds, qs + i * kAtRow);
         at_axpy(dv, pr, gs + i * kAtRow);
     }
-    float mk[8], mv[8];
+    float mk[kAtOwn], mv[kAtOwn];
 #pragma unroll
     for (int c = 0; c < kAtD; ++c) {
         float a = dk[c], e = dv[c];
-        a += __shfl_xor(a, 1, 4); e += __shfl_xor(e, 1, 4);
-        a += __shfl_xor(a, 2, 4); e += __shfl_xor(e, 2, 4);
-        if ((c >> 3) == part) { mk[c & 7] = a; mv[c & 7] = e; }
+#pragma unroll
+        for (int o = 1; o < kAtLanes; o <<= 1) { a += __shfl_xor(a, o, kAtLanes); e += __shfl_xor(e, o, kAtLanes); }
+        if (c / kAtOwn == part) { mk[c % kAtOwn] = a; mv[c % kAtOwn] = e; }
     }
     if (live) {
-        float *g = p.gk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * kAtD + 8 * part;
+        float *g = p.gk + (int64_t)b * p.k_bs + (int64_t)j * p.k_rs + h * kAtD + kAtOwn * part;
         reinterpret_cast<float4 *>(g)[0] = make_float4(mk[0], mk[1], mk[2], mk[3]);
-        reinterpret_cast<float4 *>(g)[1] = make_float4(mk[4], mk[5], mk[6], mk[7]);
-        float *gv = p.gv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * kAtD + 8 * part;
+        float *gv = p.gv + (int64_t)b * p.v_bs + (int64_t)j * p.v_rs + h * kAtD + kAtOwn * part;
         reinterpret_cast<float4 *>(gv)[0] = make_float4(mv[0], mv[1], mv[2], mv[3]);
-        reinterpret_cast<float4 *>(gv)[1] = make_float4(mv[4], mv[5], mv[6], mv[7]);
     }
 }
 
