@@ -132,8 +132,10 @@ class SalienceTransformerEncoderLayer(nn.Module):
             linear = F.linear
             if self.x3_projections and qk.dtype == torch.float32:
                 from .linear_x3 import x3_linear as linear
-            pqk = linear(qk, w[:2 * E], b[:2 * E])
-            pv = linear(v, w[2 * E:], b[2 * E:])
+            w_qk, w_v = split_prefix(w, 2 * E, 0)
+            b_qk, b_v = split_prefix(b, 2 * E, 0)
+            pqk = linear(qk, w_qk, b_qk)
+            pv = linear(v, w_v, b_v)
             if attention_train.applies(pqk, pv, mha.num_heads):
                 o = attention_train.attention_qk_v(pqk, pv, mha.num_heads)
                 return linear(o, mha.out_proj.weight, mha.out_proj.bias)
@@ -297,6 +299,35 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return self.forward_ffn(query)
 
 
+class _SplitPrefix(torch.autograd.Function):
+    """``x.narrow(dim, 0, n)`` and the rest as views whose backward is ONE concatenation (the two slices' own backward nodes
+    each zero-fill a tensor of x's size, copy their part in, and the results are added: five launches where this is one)."""
+
+    @staticmethod
+    def forward(ctx, x, n, dim):
+        ctx.n, ctx.tail, ctx.dim = n, x.shape[dim] - n, dim
+        return x.narrow(dim, 0, n), x.narrow(dim, n, x.shape[dim] - n)
+
+    @staticmethod
+    def backward(ctx, g_head, g_tail):
+        if g_head is None and g_tail is None:
+            return None, None, None
+        ref = g_head if g_head is not None else g_tail   # (an unused part arrives as None: zeros of its shape)
+        shape = list(ref.shape)
+        if g_head is None:
+            shape[ctx.dim] = ctx.n
+            g_head = ref.new_zeros(shape)
+        if g_tail is None:
+            shape[ctx.dim] = ctx.tail
+            g_tail = ref.new_zeros(shape)
+        return torch.cat([g_head, g_tail], ctx.dim), None, None
+
+
+def split_prefix(x: Tensor, n: int, dim: int = 1):
+    """``(x[..., :n, ...], x[..., n:, ...])`` along ``dim`` (views; see ``_SplitPrefix``)."""
+    return _SplitPrefix.apply(x, n, dim)
+
+
 class SalienceTransformerEncoder(nn.Module):
     """Encoder over salience-filtered queries (salience_transformer.py:399-497)."""
 
@@ -381,17 +412,22 @@ class SalienceTransformerEncoder(nn.Module):
                                              index=sorted_index)
             live = torch.arange(n0, device=value.device)[None] < focus_token_nums.to(torch.int64)[:, None]    # [B,n0]
         final = []
+        q = cur                                 # the rows of the layer about to run (c_0 = all gathered rows)
         for layer_id, layer in enumerate(self.layers):
             if self.layer_marker is not None:
                 self.layer_marker(layer_id)
             c = counts[layer_id]
-            q = cur[:, :c]
             out = layer(q, pos_s[:, :c], value, ref_s[:, :c], spatial_shapes, level_start_index, padding_mask,
                         self.enhance_mcsp(q), fg_s[:, :c])
             out = torch.where(live[:, :c, None], out, q)
             nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
-            final.append(out[:, nxt:c])        # rows no later layer touches
-            cur = out
+            if nxt == 0:
+                final.append(out)
+            elif nxt == c:
+                q = out                         # (equal ratios: the next layer takes all of them, nothing is final yet)
+            else:
+                q, done = split_prefix(out, nxt)   # rows the next layer takes | rows no later layer touches
+                final.append(done)
         if self.layer_marker is not None:
             self.layer_marker(self.num_layers)
         output = value.scatter(1, idx_e, torch.cat(final[::-1], 1))

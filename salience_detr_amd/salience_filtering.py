@@ -21,6 +21,7 @@ from torch.nn import functional as F
 
 from . import pyramid
 from .layer_norm_train import add_layer_norm
+from .salience_encoder import split_prefix
 from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, merge_sorted_desc,
                          plan_masked_topk, salience_head)
 
@@ -58,7 +59,8 @@ class MaskPredictor(nn.Module):
             for m in list(self.layer1)[1:]:
                 z = m(z)
             # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
-            z = torch.cat([z[..., :half], z[..., half:].mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
+            local, glob = split_prefix(z, half, -1) if z.is_cuda else (z[..., :half], z[..., half:])
+            z = torch.cat([local, glob.mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
             return self.layer2(z)
         if self.fused_kernels_apply(x):
             return salience_head(x, self, row_scale=row_scale, alpha=alpha).unsqueeze(-1)
