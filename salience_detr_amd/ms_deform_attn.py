@@ -375,6 +375,23 @@ def invalidate_caches(module: nn.Module) -> None:
                 p.__dict__.pop(key, None)
 
 
+class _ZeroRowsInPlace(Function):
+    """``x.masked_fill_(mask[..., None], 0)`` whose backward masks the incoming gradient in place as well."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        ctx.mark_dirty(x)
+        return x.masked_fill_(mask[..., None], 0.0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        (mask,) = ctx.saved_tensors
+        g = grad if grad.is_contiguous() else grad.contiguous()
+        return g.masked_fill_(mask.view(mask.shape + (1,) * (g.dim() - mask.dim())), 0.0), None
+
+
 class _SamplingPrep(Function):
     """``(sampling_locations, attention_weights)`` of ms_deform_attn.py:322-349 from the two Linear outputs and the
     reference points (``csrc/sampling_prep.hip``); the reference points carry no gradient here."""
@@ -582,9 +599,10 @@ class MultiScaleDeformableAttention(nn.Module):
         # autograd path: reference layout, fp32 op with the HIP forward/backward kernels
         value = self.value_proj(value)
         if key_padding_mask is not None:
-            # in place: the projection's output is a fresh tensor nothing else holds and no backward needs
-            # (the out-of-place form copies the [B, Nv, 256] map first)
-            value = value.masked_fill_(key_padding_mask[..., None], float(0))
+            # in place, both ways: the projection's output is a fresh tensor nothing else holds and no backward needs, and
+            # the gradient that comes back is the op's own fresh grad_value (the framework's masked_fill backward copies
+            # the [B, Nv, 256] gradient before it masks it)
+            value = _ZeroRowsInPlace.apply(value, key_padding_mask)
         value = value.view(batch_size, num_value, self.num_heads, self.embed_dim // self.num_heads)
         sampling_offsets = self.sampling_offsets(query).view(
             batch_size, num_query, self.num_heads, self.num_levels, self.num_points, 2)
