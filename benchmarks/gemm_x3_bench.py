@@ -24,8 +24,10 @@ def time_us(fn, reps=20):
 
 def main():
     rows = []
-    for T, K, N in ((22726, 256, 2048), (22726, 2048, 256), (22726, 256, 384), (22726, 256, 256), (9090, 256, 2048),
-                    (44646, 256, 256)):
+    shapes = ((22726, 256, 2048), (22726, 2048, 256), (22726, 256, 384), (22726, 256, 256), (9090, 256, 2048), (44646, 256, 256))
+    if len(sys.argv) > 1:   # "T,K,N T,K,N ..."
+        shapes = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[1:])
+    for T, K, N in shapes:
         x = torch.randn(T, K, device="cuda")
         w = torch.randn(N, K, device="cuda")
         gy = torch.randn(T, N, device="cuda")

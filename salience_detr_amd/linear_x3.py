@@ -94,21 +94,26 @@ def _weight_grad_splits(T: int, N: int, K: int) -> int:
 
 
 # Which of a Linear layer's three products take the x3 kernel (the others go to the library's fp32 GEMM).  Measured on
-# MI355X (benchmarks/gemm_x3_bench.py, profiles/r02_gemm_x3.json): 100-127 TFLOP/s fp32-equivalent at 22 726 tokens
-# (the split of the operand fragments costs as many vector-ALU cycles as the six MFMAs take) -- within +-15 % of the
-# library for y = x w^T and dx = dy w (87-124), 1.3-2x faster for the weight gradient dw = dy^T x, whose few output
-# tiles the library does not split over the token dimension.  With the weight pre-split once per call (``presplit``,
-# ``gemm_x3_presplit_b``: half the split work) the other two reach 115-128 TFLOP/s: 1.3x the library on two of the four
-# large FFN products, equal on the rest -- not enough to route them by default.
+# MI355X (benchmarks/gemm_x3_bench.py, profiles/r03_gemm_x3.json): the weight gradient dw = dy^T x always (1.3-2x the
+# library, whose few output tiles are not split over the token dimension); y = x w^T and dx = dy w where an output or
+# reduction dimension is long enough for the 256 x 128-tile generation (``_x3_wide``: 146-200 us against the library's
+# 189-275 at 22 726 tokens) -- the weight is read as it lies (k-major for y, reduction-major for dx) and split on its way
+# into LDS; the pre-split form (``presplit`` + ``gemm_x3_presplit_b``) is kept for callers that reuse one weight often.
 X3_FORWARD, X3_DX, X3_DW = True, True, True
-X3_WIDE_ROWS, X3_WIDE_FEATURES = 16000, 2048   # (module attributes: the tests lower them to route everything here)
+# (module attributes: the tests lower them to route everything here)
+X3_WIDE_FEATURES = 2048         # a product counts as wide / long from this many output / reduction features
+X3_WIDE_OUT_ROWS = 9000         # ... and goes to the x3 kernel from this many tokens when its OUTPUT is wide
+X3_LONG_REDUCTION_ROWS = 16000  # ... from this many when its REDUCTION is long (fewer 256-row tiles than CUs below that)
 
 
-def _x3_wide(T: int, N: int, K: int) -> bool:
-    """The forward / input-gradient products that go to the x3 kernel with the weight pre-split (round 3: its 256 x 128
-    tile generation): the feed-forward's 256 <-> 2048 products at >= 16 000 tokens -- 154-200 us against the library's
-    194-272 (benchmarks/gemm_x3_bench.py); narrower products and shorter token lists stay with the library."""
-    return T >= X3_WIDE_ROWS and max(N, K) >= X3_WIDE_FEATURES
+def _x3_wide(T: int, n_out: int, k_red: int) -> bool:
+    """The forward / input-gradient products that go to the x3 kernel (round 3: its 256 x 128 tile generation; measured
+    against the library's fp32 GEMM, benchmarks/gemm_x3_bench.py): a 2048-wide output from 9000 tokens (127 vs 159 us at
+    13 634, 200 vs 275 at 22 726), a 2048-long reduction from 16 000 tokens (137 vs 154 at 18 180; at 13 634 its 108
+    tiles leave half the chip idle and the library wins); narrower products stay with the library."""
+    if n_out >= X3_WIDE_FEATURES and T >= X3_WIDE_OUT_ROWS:
+        return True
+    return k_red >= X3_WIDE_FEATURES and T >= X3_LONG_REDUCTION_ROWS
 
 
 class _LinearX3(Function):
@@ -125,7 +130,7 @@ class _LinearX3(Function):
         y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         y2 = y.view(T, N)
         if X3_FORWARD and K % 8 == 0 and _x3_wide(T, N, K):
-            gemm_x3_presplit_b(x2, True, presplit(weight), T, N, K, bias=bias, out=y2)   # y = x w^T, w split once
+            gemm_x3(x2, True, weight, True, T, N, K, bias=bias, out=y2)   # y = x w^T (the weight is split on its way into LDS)
         elif bias is not None:
             torch.addmm(bias, x2, weight.t(), out=y2)
         else:
@@ -143,7 +148,7 @@ class _LinearX3(Function):
         g2 = (gy if gy.is_contiguous() else gy.contiguous()).view(T, N)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                                    # dx = dy w
-            if X3_DX and N % 8 == 0 and _x3_wide(T, N, K):
+            if X3_DX and N % 8 == 0 and _x3_wide(T, K, N):
                 gx = gemm_x3(g2, True, weight, False, T, K, N)   # dx = dy w (the weight read reduction-major: no transposed split pass)
             else:
                 gx = g2 @ weight

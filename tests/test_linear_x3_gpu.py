@@ -95,7 +95,7 @@ def test_gemm_x3_bias_and_argument_checks(generation):
 def test_x3_linear_forward_backward_match_float64(shape, N, monkeypatch, generation):
     for flag in ("X3_FORWARD", "X3_DX", "X3_DW"):   # all three products through the kernel under test
         monkeypatch.setattr(X, flag, True)
-    monkeypatch.setattr(X, "X3_WIDE_ROWS", 1)
+    monkeypatch.setattr(X, "X3_WIDE_OUT_ROWS", 1)
     monkeypatch.setattr(X, "X3_WIDE_FEATURES", 1)
     K = shape[-1]
     lin = torch.nn.Linear(K, N)
