@@ -103,17 +103,27 @@ X3_FORWARD, X3_DX, X3_DW = True, True, True
 # (module attributes: the tests lower them to route everything here)
 X3_WIDE_FEATURES = 2048         # a product counts as wide / long from this many output / reduction features
 X3_WIDE_OUT_ROWS = 9000         # ... and goes to the x3 kernel from this many tokens when its OUTPUT is wide
-X3_LONG_REDUCTION_ROWS = 16000  # ... from this many when its REDUCTION is long (fewer 256-row tiles than CUs below that)
+X3_LONG_REDUCTION_ROWS = 4000   # ... from this many when its REDUCTION is long (cut into slices until the tiles fill the chip)
 
 
 def _x3_wide(T: int, n_out: int, k_red: int) -> bool:
     """The forward / input-gradient products that go to the x3 kernel (round 3: its 256 x 128 tile generation; measured
     against the library's fp32 GEMM, benchmarks/gemm_x3_bench.py): a 2048-wide output from 9000 tokens (127 vs 159 us at
-    13 634, 200 vs 275 at 22 726), a 2048-long reduction from 16 000 tokens (137 vs 154 at 18 180; at 13 634 its 108
-    tiles leave half the chip idle and the library wins); narrower products stay with the library."""
+    13 634, 200 vs 275 at 22 726), a 2048-long reduction from 4000 tokens (131 vs 151 at 18 180; below that with the
+    reduction cut in slices, ``_reduction_splits``); narrower products stay with the library."""
     if n_out >= X3_WIDE_FEATURES and T >= X3_WIDE_OUT_ROWS:
         return True
     return k_red >= X3_WIDE_FEATURES and T >= X3_LONG_REDUCTION_ROWS
+
+
+def _reduction_splits(T: int, n_out: int, k_red: int) -> int:
+    """Slices of a LONG reduction for y = x w^T / dx = dy w: the 256 x 128 tiles of a narrow output do not fill the chip
+    below ~32 000 tokens (13 634 x 256: 108 tiles on 256 CUs), so the reduction is cut until they do -- 100 vs 130 us at
+    13 634 tokens, 79 vs 132 at 9090 (the library: 128 / 103); the slices add into a zeroed output with fp32 atomics."""
+    if k_red < 1024:
+        return 1
+    tiles = ((T + 255) // 256) * ((n_out + 127) // 128)
+    return max(1, min(256 // max(tiles, 1), k_red // 256))
 
 
 class _LinearX3(Function):
@@ -127,10 +137,12 @@ class _LinearX3(Function):
         K = x.shape[-1]
         x2 = x.view(-1, K)
         T, N = x2.shape[0], weight.shape[0]
-        y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        use_x3 = X3_FORWARD and K % 8 == 0 and _x3_wide(T, N, K)
+        splits = _reduction_splits(T, N, K) if use_x3 else 1
+        y = (torch.zeros if splits > 1 else torch.empty)(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         y2 = y.view(T, N)
-        if X3_FORWARD and K % 8 == 0 and _x3_wide(T, N, K):
-            gemm_x3(x2, True, weight, True, T, N, K, bias=bias, out=y2)   # y = x w^T (the weight is split on its way into LDS)
+        if use_x3:   # y = x w^T (the weight is split on its way into LDS)
+            gemm_x3(x2, True, weight, True, T, N, K, bias=bias, reduction_splits=splits, out=y2)
         elif bias is not None:
             torch.addmm(bias, x2, weight.t(), out=y2)
         else:
@@ -149,7 +161,10 @@ class _LinearX3(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                                                    # dx = dy w
             if X3_DX and N % 8 == 0 and _x3_wide(T, K, N):
-                gx = gemm_x3(g2, True, weight, False, T, K, N)   # dx = dy w (the weight read reduction-major: no transposed split pass)
+                # dx = dy w (the weight read reduction-major: no transposed split pass)
+                sp = _reduction_splits(T, K, N)
+                gx = gemm_x3(g2, True, weight, False, T, K, N, reduction_splits=sp,
+                             out=torch.zeros((T, K), dtype=g2.dtype, device=g2.device) if sp > 1 else None)
             else:
                 gx = g2 @ weight
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
