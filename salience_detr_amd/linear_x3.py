@@ -87,8 +87,12 @@ def x3_linear_applies(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> bool
 
 
 def _weight_grad_splits(T: int, N: int, K: int) -> int:
-    """Slices of the token dimension for ``dw = dy^T x``: its output is only (N/128) x (K/128) tiles, so the
-    reduction over the tokens is what has to fill the chip (512 workgroup slots)."""
+    """Slices of the token dimension for ``dw = dy^T x``: its output is only a few tiles, so the reduction over the
+    tokens is what has to fill the chip (measured: benchmarks/gemm_x3_dw_splits_probe.py -- 256 x 256 at 22 726 tokens:
+    50-52 us at 88-128 slices of the 256 x 128-tile generation, 61-63 on the 128 x 128 tiles, 91 in the library)."""
+    if T >= 1024 and N >= 128:   # the library's 256 x 128-tile generation takes it: one workgroup per CU
+        tiles = ((N + 255) // 256) * ((K + 127) // 128)
+        return max(1, min(T // 256, 256 // tiles))
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     return max(1, min((T + 255) // 256, (512 + tiles - 1) // tiles))
 
