@@ -33,7 +33,7 @@ from salience_detr_amd.hot_path import build_hot_path  # noqa: E402
 DEFAULT_THREADS = torch.get_num_threads()
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MSDA_REPEATS = 8
-CUT_PAIRS, CUT_REPLAYS = 15, 20   # in-step MSDA timing: paired cut-graph measurements
+CUT_PAIRS, CUT_REPLAYS = 30, 20   # in-step MSDA timing: paired cut-graph measurements
 
 
 def parse():
