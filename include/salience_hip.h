@@ -160,6 +160,25 @@ int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *value_hm, int
                                 int spatial_size, int num_heads, int num_query, void *out, int out_dtype, int chunks);
 int sdetr_msda_last_kernel(void);
 
+/* The same kernel on BORDERED head-major maps (round 4, csrc/msda_resident.hip `msda_bordered_kernel`): every level of
+ * the fp16 map [B, M, Np, 32] is stored as (H_l + 2) rows of (W_l + 1) 64-byte records -- row -1 and row H_l are zero
+ * records, record -1 of every row is zero and doubles as record W_l of the row above -- the levels follow each other
+ * and one more zero record closes the map: Np = sdetr_msda_bordered_records(level_hw, 4).  Pixel (y, x) of level l is
+ * record P_l + (y + 1)(W_l + 1) + x + 1.  The producer is sdetr_value_proj_head_major(..., pixel_map, border, ...);
+ * with zero borders the kernel needs none of the corner tests of ms_deform_im2col_cuda.cuh:31-66 (a position is clamped
+ * onto the border, whose records are zero), which removes ~150 of the ~830 vector instructions per 16 rows.
+ *   row_order: optional int32 [B, row_order_batch_stride >= Nq], a permutation of 0..Nq-1 per image: the rows are
+ *              processed in this order (neighbours in the image next to each other keep the fine levels' records in
+ *              the L1); results do not depend on it.  NULL = 0..Nq-1. */
+#define SDETR_KERNEL_MSDA_BORDERED 5 /* msda_bordered_kernel: bordered maps, levels 2+3 resident in LDS */
+int64_t sdetr_msda_bordered_records(const int32_t *level_hw_host, int num_levels);
+int sdetr_msda_bordered_max_resident_records(void);
+int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *value_bordered, int value_dtype,
+                                const int32_t *level_hw_host, const float *ref_points, int ref_dim,
+                                int64_t ref_batch_stride, const void *proj_head_major_bf16, const int32_t *row_order,
+                                int64_t row_order_batch_stride, int batch_size, int bordered_records, int num_heads,
+                                int num_query, void *out, int out_dtype, int chunks);
+
 /* Same gather on a head-major value with explicit sampling locations / weights (the reference
  * op's math on the native layout); loc/aw as in (1), fp32. */
 int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *value_hm, int value_dtype,
@@ -261,6 +280,15 @@ int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *tokens, con
                                   const int64_t *sorted_index, const int64_t *count, const void *background,
                                   const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,
                                   int last_rows, int channels, int dtype, void *out);
+/* Row orders for sdetr_msda_bordered_forward (round 4): for every encoder layer k the rows 0 .. counts[k]-1 of the sorted
+ * list (sorted_index [batch, num_rows] int64: the token of every row, salience_transformer.py:156-163) in TILE-MAJOR
+ * order of their tokens -- tile_pos int32 [spatial_size] is the position of every token in a static order that keeps
+ * neighbours in the image together (tiles of the finest level; tokens of all levels by the tile their centre falls
+ * into).  order int32 [num_layers][batch][order_batch_stride]: order[k][b][0 .. counts[k]) is a permutation of
+ * 0 .. counts[k]-1.  counts_dev: device int32 [num_layers].  One workgroup per image, bit-exact index work. */
+int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sorted_index, int64_t index_batch_stride,
+                           const int32_t *tile_pos, int batch_size, int spatial_size, int num_rows, int num_layers,
+                           const int32_t *counts_dev, int32_t *order, int64_t order_batch_stride);
 int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
                            const int64_t *sorted_index, const int64_t *count, const void *background,
                            const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,
@@ -386,6 +414,13 @@ int sdetr_salience_head_stage1_x3(sdetr_stream_t stream, const float *x, int64_t
  * fill_mode 2 -- or no mask --, no payload; rows short enough that no prefilter is involved):
  * sdetr_stage1_x3_with_jobs = sdetr_salience_head_stage1_x3 + an optional value-projection job (vp_x != NULL) + an
  * optional rank job in one launch. */
+/* destination layout of a value-projection job (see sdetr_value_proj_head_major below) */
+typedef struct {
+    const int32_t *pixel_map;    /* device int32 [spatial_size]: record of every token of an image */
+    const int32_t *border;       /* device int32 [num_border]: the zero records of a map */
+    int num_border;
+    int records;                 /* records per (image, head) */
+} sdetr_bordered_layout;
 typedef struct {
     const float *score;          /* [batch, n] */
     const uint8_t *mask;         /* [batch, n] rows mask_row_stride bytes apart, or NULL */
@@ -414,7 +449,8 @@ int sdetr_stage1_x3_with_jobs(
     float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
     float *z_local, float *partial_sums, const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded,
     const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
-    void *vp_dst, int vp_dst_dtype, const sdetr_rank_job *rank, const sdetr_finalize_job *finalize);
+    void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered, const sdetr_rank_job *rank,
+    const sdetr_finalize_job *finalize);
 int sdetr_stage1_x3_with_value_proj(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
@@ -423,7 +459,7 @@ int sdetr_stage1_x3_with_value_proj(
     float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
     float *z_local, float *partial_sums, const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded,
     const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
-    void *vp_dst, int vp_dst_dtype);
+    void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered);
 /* sdetr_salience_head_const: the per-image constant of stage 2 as a launch of its own; sdetr_stage2_with_value_proj:
  * stage 2 proper (arguments as sdetr_salience_head_stage2; const_workspace already filled) + a value-projection job
  * in one launch (csrc/fused_head_value.hip). */
@@ -435,7 +471,7 @@ int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *z_local, in
                                  float *score_flat, int64_t score_flat_stride, float *score_min, const void *vp_x,
                                  const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
                                  int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
-                                 void *vp_dst, int vp_dst_dtype);
+                                 void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered);
 int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums, int batch_size,
                                int tokens, const float *weight2, const float *bias2,
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,
@@ -501,9 +537,15 @@ int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, const void *x_
                             int rows_per_batch, int tokens, int in_features, const void *packed_weight,
                             const float *bias_padded, int out_features, void *out, int64_t out_row_stride,
                             int group_features);
+/*   Bordered destination (round 4; the layout sdetr_msda_bordered_forward reads): with `bordered` != NULL the maps are
+ *     dst [groups][batch][heads][records][32], token i of an image goes to record pixel_map[i] and the launch also writes
+ *     zeros to the `num_border` records of every map listed in `border` (the level borders and the closing record), so
+ *     dst needs no initialisation.  NULL = the plain layout above. */
+/* (sdetr_bordered_layout is declared with the salience head's jobs above) */
 int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x, const void *packed_weight,
                                 const float *bias_padded, const uint8_t *pad_mask, int batch_size, int spatial_size,
-                                int in_features, int num_heads, int channels, int num_groups, void *dst, int dst_dtype);
+                                int in_features, int num_heads, int channels, int num_groups, void *dst, int dst_dtype,
+                                const sdetr_bordered_layout *bordered);
 int sdetr_class_head_max_times(sdetr_stream_t stream, const void *x, const void *packed_weight,
                                const float *bias_padded, int in_features, int num_classes, const float *scale,
                                int64_t scale_batch_stride, int batch_size, int rows_per_batch, float *out);

@@ -27,6 +27,12 @@ class FinalizeJobStruct(ctypes.Structure):
                 ("batch", ctypes.c_int), ("spatial_size", ctypes.c_int), ("out", ctypes.c_void_p)]
 
 
+class BorderedLayoutStruct(ctypes.Structure):
+    """``sdetr_bordered_layout`` of include/salience_hip.h."""
+    _fields_ = [("pixel_map", ctypes.c_void_p), ("border", ctypes.c_void_p), ("num_border", ctypes.c_int),
+                ("records", ctypes.c_int)]
+
+
 class RankJobStruct(ctypes.Structure):
     """``sdetr_rank_job`` of include/salience_hip.h."""
     _fields_ = [("score", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("mask_row_stride", ctypes.c_int64),
@@ -55,6 +61,10 @@ SIGNATURES = {
     "sdetr_msda_resident_max_pixels": (_i, []),
     "sdetr_msda_resident_forward": (_i, [_p, _p, _i, _p, _p, _i, _i64, _p, _i, _i, _i, _i, _p, _i, _i]),
     "sdetr_msda_last_kernel": (_i, []),
+    "sdetr_msda_bordered_records": (_i64, [_p, _i]),
+    "sdetr_layer_row_orders": (_i, [_p, _p, _i64, _p, _i, _i, _i, _i, _p, _p, _i64]),
+    "sdetr_msda_bordered_max_resident_records": (_i, []),
+    "sdetr_msda_bordered_forward": (_i, [_p, _p, _i, _p, _p, _i, _i64, _p, _p, _i64, _i, _i, _i, _i, _p, _i, _i]),
     "sdetr_topk_attention_workspace_bytes": (_i64, [_i, _i]),
     "sdetr_topk_attention_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i,
                                        _p, _i64]),
@@ -104,13 +114,13 @@ SIGNATURES = {
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p]),
     "sdetr_salience_head_const": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "sdetr_stage2_with_value_proj": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p,
-                                          _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+                                          _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "sdetr_stage1_x3_with_value_proj": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
-                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i]),
+                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "sdetr_stage1_x3_with_jobs": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
-                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
+                                             _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "sdetr_pack_linear_bf16x3": (_i, [_p, _p, _i64, _i, _i, _p]),
     "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "sdetr_ffn_packed_bytes": (_i64, [_i]),
@@ -134,7 +144,7 @@ SIGNATURES = {
     "sdetr_linear_packed_bytes": (_i64, [_i]),
     "sdetr_linear_pack_bf16": (_i, [_p, _p, _i64, _i, _i, _p]),
     "sdetr_token_linear_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _i, _p, _i64, _i]),
-    "sdetr_value_proj_head_major": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i]),
+    "sdetr_value_proj_head_major": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "sdetr_class_head_max_times": (_i, [_p, _p, _p, _p, _i, _i, _p, _i64, _i, _i, _p]),
     "sdetr_token_linear_ln_bf16": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i64]),
     "sdetr_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

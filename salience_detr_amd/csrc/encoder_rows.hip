@@ -250,3 +250,96 @@ extern "C" int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *
                                        batch_size, spatial_size, sorted_rows, last_rows, channels, out, false);
     return fail("encoder_finalize_sorted: bad dtype %d", dtype);
 }
+
+// ---- per-layer row orders for the deformable attention (round 4) ------------------------------------------------------
+// The encoder keeps its rows sorted by salience score (every layer's set is a prefix of that list), so the rows a
+// workgroup of the MSDA kernel works on are scattered over the image and the fine-level records they fetch miss the L1.
+// For every layer k this kernel lists the layer's rows 0 .. counts[k]-1 in TILE-MAJOR order of their tokens
+// (`tile_pos` [S] int32: position of every token in a static order that keeps the tokens of all levels whose centre
+// falls into the same tile of the finest level together): order[k][b][0 .. counts[k]) is a permutation of
+// 0 .. counts[k]-1.  One 1024-thread workgroup per image: the rows are scattered into an LDS array indexed by tile
+// position (a counting sort with one key per slot), every thread counts the rows of each layer in its run of slots, one
+// block scan per layer gives its write offsets.  Pure index work: bit-exact, ~5 us.
+constexpr int kOrderThreads = 1024;
+constexpr int kOrderMaxLayers = 8;
+constexpr int kOrderMaxTokens = 76800;     // 150 KB of 16-bit slots
+
+__global__ void __launch_bounds__(kOrderThreads) layer_row_orders_kernel(const int64_t *sorted_index, int64_t index_batch_stride,
+                                                                        const int32_t *tile_pos, int S, int n0, int nl,
+                                                                        const int *counts_dev, int32_t *order,
+                                                                        int64_t order_layer_stride, int64_t order_batch_stride)
+{
+    extern __shared__ uint16_t slot[];                 // [S] row at every tile position, 0xffff = none
+    __shared__ int wave_tot[kOrderMaxLayers][kOrderThreads / 64];
+    __shared__ int counts[kOrderMaxLayers];
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < nl) counts[tid] = counts_dev[tid];
+    for (int p = tid; p < S; p += kOrderThreads) slot[p] = 0xffffu;
+    __syncthreads();
+    const int64_t *idx = sorted_index + (int64_t)b * index_batch_stride;
+    for (int r = tid; r < n0; r += kOrderThreads) {
+        const int64_t t = idx[r];
+        if (t >= 0 && t < S) slot[tile_pos[t]] = (uint16_t)r;   // (distinct tokens: one row per slot)
+    }
+    __syncthreads();
+    const int per = (S + kOrderThreads - 1) / kOrderThreads;
+    const int p0 = min(S, tid * per), p1 = min(S, p0 + per);
+    int cnt[kOrderMaxLayers];
+#pragma unroll
+    for (int k = 0; k < kOrderMaxLayers; ++k) cnt[k] = 0;
+    for (int p = p0; p < p1; ++p) {
+        const int r = slot[p];
+#pragma unroll
+        for (int k = 0; k < kOrderMaxLayers; ++k)
+            if (k < nl && r < counts[k]) ++cnt[k];
+    }
+    // exclusive block scan of every layer's count: wave-inclusive by shuffles, wave totals through LDS
+    int base[kOrderMaxLayers];
+#pragma unroll
+    for (int k = 0; k < kOrderMaxLayers; ++k) {
+        int v = cnt[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d);
+            if (lane >= d) v += o;
+        }
+        if (lane == 63) wave_tot[k][wave] = v;
+        base[k] = v - cnt[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOrderMaxLayers; ++k) {
+        int add = 0;
+        for (int w = 0; w < wave; ++w) add += wave_tot[k][w];
+        base[k] += add;
+    }
+    for (int p = p0; p < p1; ++p) {
+        const int r = slot[p];
+#pragma unroll
+        for (int k = 0; k < kOrderMaxLayers; ++k)
+            if (k < nl && r < counts[k]) order[k * order_layer_stride + b * order_batch_stride + base[k]++] = r;
+    }
+}
+
+// order [num_layers][batch][order_batch_stride >= n0] int32; counts_host: rows per layer (<= n0 each).  The counts travel
+// as a small device array the caller owns (`counts_dev`, int32 [num_layers]: hipGraph-replayable, no host copy here).
+extern "C" int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sorted_index, int64_t index_batch_stride,
+                                      const int32_t *tile_pos, int batch_size, int spatial_size, int num_rows,
+                                      int num_layers, const int32_t *counts_dev, int32_t *order, int64_t order_batch_stride)
+{
+    if (batch_size <= 0 || spatial_size <= 0 || num_rows <= 0 || num_layers <= 0) return fail("layer_row_orders: bad sizes");
+    if (!sorted_index || !tile_pos || !counts_dev || !order) return fail("layer_row_orders: null pointer");
+    if (num_layers > kOrderMaxLayers) return fail("layer_row_orders: at most %d layers", kOrderMaxLayers);
+    if (spatial_size > kOrderMaxTokens) return fail("layer_row_orders: at most %d tokens per image (got %d)", kOrderMaxTokens, spatial_size);
+    if (num_rows >= 0xffff) return fail("layer_row_orders: at most 65534 rows per image");
+    if (index_batch_stride == 0) index_batch_stride = num_rows;
+    if (order_batch_stride == 0) order_batch_stride = num_rows;
+    if (index_batch_stride < num_rows || order_batch_stride < num_rows) return fail("layer_row_orders: bad strides");
+    static DeviceOnce once;
+    allow_dynamic_lds(layer_row_orders_kernel, once, 160 * 1024 - 1024);
+    const size_t lds = (size_t)spatial_size * 2;
+    hipLaunchKernelGGL(layer_row_orders_kernel, dim3((unsigned)batch_size), dim3(kOrderThreads), lds,
+                       static_cast<hipStream_t>(stream), sorted_index, index_batch_stride, tile_pos, spatial_size, num_rows,
+                       num_layers, counts_dev, order, (int64_t)batch_size * order_batch_stride, order_batch_stride);
+    return check_launch("layer_row_orders");
+}

@@ -128,7 +128,8 @@ extern "C" int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in
 
 static int fill_value_job(TLArgs &t, size_t &lds_tl, int &n2, const void *vp_x, const void *vp_packed_weight,
                           const float *vp_bias_padded, const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size,
-                          int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+                          int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+                          const sdetr_bordered_layout *vp_bordered)
 {
     if (vp_batch_size <= 0 || vp_spatial_size <= 0 || vp_num_heads <= 0 || vp_num_groups <= 0)
         return fail("value-projection job: bad sizes");
@@ -144,7 +145,7 @@ static int fill_value_job(TLArgs &t, size_t &lds_tl, int &n2, const void *vp_x, 
     if ((size_t)t.ntiles * 128 + 2 * kTLStepBytes + 1024 > 160 * 1024) return fail("value-projection job: too many output features");
     lds_tl = 2 * (size_t)kTLStepBytes + (size_t)nsteps * 512;
     n2 = (int)((vp_tokens + kTLTokWave * 8 - 1) / (kTLTokWave * 8));
-    return 0;
+    return tl_set_bordered(t, vp_bordered, vp_spatial_size, n2);
 }
 
 // sdetr_salience_head_stage1_x3 (same arguments) + up to two jobs carried by the same launch: the value projection of
@@ -160,7 +161,7 @@ extern "C" int sdetr_stage1_x3_with_jobs(
     float *z_local, float *partial_sums,
     const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
     int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
-    const sdetr_rank_job *rank, const sdetr_finalize_job *finalize)
+    const sdetr_bordered_layout *vp_bordered, const sdetr_rank_job *rank, const sdetr_finalize_job *finalize)
 {
     if (channels != kC) return fail("stage1_x3_with_jobs: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
     if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_jobs: empty level");
@@ -224,7 +225,7 @@ extern "C" int sdetr_stage1_x3_with_jobs(
     size_t lds_tl = 0;
     int n2 = 0;
     if (int rc = fill_value_job(t, lds_tl, n2, vp_x, vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size,
-                                vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype))
+                                vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, vp_bordered))
         return rc;
     size_t lds = lds_tl > lds_s1 ? lds_tl : lds_s1;
     if (lds_rk > lds) lds = lds_rk;
@@ -243,7 +244,8 @@ extern "C" int sdetr_stage1_x3_with_value_proj(
     float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
     float *z_local, float *partial_sums,
     const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
-    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+    const sdetr_bordered_layout *vp_bordered)
 {
     if (!vp_x) return fail("stage1_x3_with_value_proj: NULL pointer");
     return sdetr_stage1_x3_with_jobs(stream, x, x_batch_stride, x_row_stride, batch_size, tokens, channels, enc_weight_x3,
@@ -251,7 +253,7 @@ extern "C" int sdetr_stage1_x3_with_value_proj(
                                      coarse_h, coarse_w, level_h, level_w, alpha, norm_weight, norm_bias, norm_eps,
                                      weight_x3, bias, memory_out, memory_batch_stride, z_local, partial_sums, vp_x,
                                      vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size, vp_spatial_size,
-                                     vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, nullptr, nullptr);
+                                     vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, vp_bordered, nullptr, nullptr);
 }
 
 // The stage-2 half of sdetr_salience_head_stage2 (the caller has launched the per-image constant already:
@@ -263,7 +265,8 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
                                             int64_t score_flat_stride, float *score_min, const void *vp_x,
                                             const void *vp_packed_weight, const float *vp_bias_padded,
                                             const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size,
-                                            int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype)
+                                            int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+                                            const sdetr_bordered_layout *vp_bordered)
 {
     if (batch_size <= 0 || tokens <= 0) return fail("stage2_with_value_proj: empty level");
     if (!z_local || !weight2_local_packed || !weight3_packed || !bias3 || !weight4 || !bias4 || !const_workspace || !score)
@@ -272,7 +275,7 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
     size_t lds_tl = 0;
     int n2 = 0;
     if (int rc = fill_value_job(t, lds_tl, n2, vp_x, vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size,
-                                vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype))
+                                vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, vp_bordered))
         return rc;
     Stage2Args a;
     a.z_local = z_local; a.cst = const_workspace;

@@ -386,6 +386,449 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
     }   // images
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the same gather on BORDERED maps, with an optional per-launch ROW ORDER.
+//
+// Where the round-3 kernel spends its vector-ALU issue slots (rocprofv3 SQ_INSTS_VALU: 829 wave instructions per
+// 16-row group): 512 v_fma_mix_f32 are the gather itself, ~150 are the per-sample bounds logic -- four corner tests,
+// the selects that zero a weight or shift it over at the left border, three index clamps, two multiply-adds per
+// sample for the row offsets.  None of it is needed when every level of the head-major map carries a BORDER OF ZERO
+// RECORDS: level l is stored as (H_l + 2) rows of (W_l + 1) records -- row -1 and row H_l are zero, record -1 of every
+// row is zero and doubles as record W_l of the row above (one shared column) -- the levels follow each other and one
+// more zero record closes the map (Np = sum (H_l + 2)(W_l + 1) + 1 records per (image, head), +3.7 % at the benchmark
+// pyramid).  A sampling position is clamped to [-1, size) by ONE v_med3_f32 per coordinate (a NaN lands on -1) and
+// then every corner a lane can address exists and outside corners are zeros: floor / fraction / index are
+// v_cvt_u32_f32, v_fract_f32 and one v_mad_u32_u24, the four weights come from the fractions by three multiplies and
+// three subtractions.  (Positions in [size - 2^-17, size) read weight 2^-17 x the border pixel instead of nothing: the
+// reference's own value there differs from zero by more, ms_deform_im2col_cuda.cuh:22-73 is continuous at the border.)
+// The second row of a sample is the first one's address plus the level's row pitch: for the two fine levels that is the
+// SCALAR offset operand of the buffer load -- no vector instruction.  ~680 instructions per group.
+//
+// Row order (PERM): the encoder hands its rows over sorted by salience score, so the 256 rows a workgroup has in flight
+// are scattered over the image and the fine-level records they fetch miss the 32 KB L1 (the L2 -> L1 leg: 64-byte
+// records out of 128-byte lines at ~31 B/clk).  `perm` [B, Nq] lists the rows in an order that
+// keeps neighbours in the image together (tile-major, built once per step next to the merge of the level results): the
+// kernel walks perm instead of 0..Nq-1 -- one extra 4-byte load per row, two row groups ahead -- reads the
+// projection / reference point of row perm[i] and writes its output row; nothing else changes, any permutation gives
+// the same result.
+struct BorderedArgs {
+    const char *value;        // [B, M, Np, 32] fp16, bordered layout
+    const float *ref;         // [B, Nq, 4, ref_dim]
+    int64_t ref_batch_stride; // floats between images
+    int ref_dim;
+    const bf16_t *proj;       // [B, M, Nq, 48] bf16: 32 offsets (x,y per level, point) then 16 logits
+    const int32_t *perm;      // [B, Nq] row order, or NULL
+    int64_t perm_batch_stride;
+    void *out;                // [B, Nq, M*32]
+    int out_bf16;
+    int B, Np, M, Nq;
+    int H0, W0, H1, W1, H2, W2, H3, W3;   // host copy of the level shapes
+    int P1, P2, P3;                       // first record of levels 1..3 (level 0 starts at record 0)
+    int image_serial;
+    int res_start;                        // first resident record: P2 (levels 2 + 3 resident) or P3 (level 3 only)
+    int res_px;                           // Np - res_start: records resident in LDS
+    int chunks;                           // workgroups per (image, head)
+    int stage_rotate;                     // workgroups start their copy of the resident records at different pieces
+    int prefetch_fine;                    // touch this workgroup's share of the fine levels' lines first (L2 warm-up)
+    unsigned long long *stamps;           // benchmarks only (ABL & 32): [workgroup][8] wall-clock stamps (100 MHz)
+};
+
+constexpr int kBMaxResidentPx = (kRLdsBudget - kRWaves * kRWeightBytes) / 64;   // 1536 records
+constexpr int kBPieces = (kBMaxResidentPx * 64 + kRWaves * 1024 - 1) / (kRWaves * 1024);   // copy instructions per wave: 6
+
+__device__ __forceinline__ uint4 buffer_load16_s(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t buffer_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ float sub_f32(float a, float b)
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint4 lds_read16(uint32_t lds_addr)
+{
+    const u32x4_t v = *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t *>(lds_addr);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float max3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max_f32(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_dpp_xor1(float v)
+{
+    float r;
+    asm("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ float max_dpp_xor2(float v)
+{
+    float r;
+    asm("v_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+// (y * pitch_bytes + base) and ((x << 6) + t) as one instruction each (hipcc picks mul + add_lshl + add)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t lshl6_add(uint32_t a, uint32_t c)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 6, %2" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+// the first product of a row's accumulators: acc = f32(half of `packed`) * w (no zero fill in front of the chain)
+__device__ __forceinline__ float mul_f16lo(uint32_t packed, float w)
+{
+    float acc;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(packed), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ float mul_f16hi(uint32_t packed, float w)
+{
+    float acc;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(packed), "v"(w));
+    return acc;
+}
+__device__ __forceinline__ void mul8_f16(float *acc, const uint4 &v, float w)
+{
+    acc[0] = mul_f16lo(v.x, w); acc[1] = mul_f16hi(v.x, w); acc[2] = mul_f16lo(v.y, w); acc[3] = mul_f16hi(v.y, w);
+    acc[4] = mul_f16lo(v.z, w); acc[5] = mul_f16hi(v.z, w); acc[6] = mul_f16lo(v.w, w); acc[7] = mul_f16hi(v.w, w);
+}
+__device__ __forceinline__ void buffer_store16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, const uint4 &v)
+{
+    const u32x4_t d = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, 0);
+}
+
+template <bool REF4, int RES, bool SERIAL, bool PERM, int ABL = 0>
+__global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p)
+{
+    using F = ResFma<half_t>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // [resident records: levels 2, 3 with their borders + the closing zero record][weights: kRWaves x 4 KB]
+    const int slab_bytes = p.res_px * 64;
+    float4 *wts = reinterpret_cast<float4 *>(lds + slab_bytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = blockIdx.x % p.M;
+    const int rest = blockIdx.x / p.M;
+    const int b_first = rest / p.chunks;
+    const int b_end = SERIAL ? p.B : b_first + 1;
+    const int b_step = SERIAL ? p.image_serial : 1;
+    const int chunk = rest - b_first * p.chunks;
+    const int rows_per_chunk = (p.Nq + p.chunks - 1) / p.chunks;
+    const int q_lo = chunk * rows_per_chunk;
+    const int q_hi = min(p.Nq, q_lo + rows_per_chunk);
+    if (q_lo >= q_hi) return;  // workgroup-uniform
+    if ((ABL & 32) && tid == 0) p.stamps[blockIdx.x * 8 + 0] = wall_clock64();
+    if ((ABL & 32) && blockIdx.x == 9 && lane == 0) p.stamps[2048 + wave * 4 + 0] = wall_clock64();
+
+    for (int b = b_first; b < b_end; b += b_step) {
+    const char *base = p.value + ((int64_t)b * p.M + m) * p.Np * 64;
+
+    // ---- rows: a quad per (query, head); lane j of the quad owns level j ----
+    const int g = lane >> 2, j = lane & 3;
+    const int H = j == 0 ? p.H0 : j == 1 ? p.H1 : j == 2 ? p.H2 : p.H3;
+    const int W = j == 0 ? p.W0 : j == 1 ? p.W1 : j == 2 ? p.W2 : p.W3;
+    const int P = j == 0 ? 0 : j == 1 ? p.P1 : j == 2 ? p.P2 : p.P3;
+    const float fH = (float)H, fW = (float)W;
+    // largest float below size + 1 (bordered coordinates: pixel x lives at x + 1)
+    const float xmax = __uint_as_float(__float_as_uint(fW + 1.f) - 1u);
+    const float ymax = __uint_as_float(__float_as_uint(fH + 1.f) - 1u);
+    const uint32_t pitch64 = ((uint32_t)W + 1u) * 64u;   // row pitch in bytes (24-bit operand of the index arithmetic)
+    // byte offset of this lane's level: into the head's global map (fine levels) or into `lds` (resident levels)
+    const uint32_t lvl_base = j < 4 - RES ? (uint32_t)P * 64u : (uint32_t)(uint64_t)lds + (uint32_t)(P - p.res_start) * 64u;
+    const uint32_t lane_off = (uint32_t)(j * 16);
+    // row pitch in bytes of each level, wave-uniform (the buffer loads take it as their scalar offset)
+    const uint32_t pb0 = (uint32_t)(p.W0 + 1) * 64u, pb1 = (uint32_t)(p.W1 + 1) * 64u, pb2 = (uint32_t)(p.W2 + 1) * 64u,
+                   pb3 = (uint32_t)(p.W3 + 1) * 64u;
+    const __amdgpu_buffer_rsrc_t rsrc = make_uniform_rsrc(base, (uint32_t)((int64_t)p.Np * 64));
+    constexpr int RD = REF4 ? 4 : 2;
+    const __amdgpu_buffer_rsrc_t proj_rsrc = make_uniform_rsrc(
+        reinterpret_cast<const char *>(p.proj + ((int64_t)b * p.M + m) * p.Nq * 48), (uint32_t)((int64_t)p.Nq * 96));
+    const __amdgpu_buffer_rsrc_t ref_rsrc = make_uniform_rsrc(
+        reinterpret_cast<const char *>(p.ref + (int64_t)b * p.ref_batch_stride), (uint32_t)((int64_t)p.Nq * 4 * RD * 4));
+    const __amdgpu_buffer_rsrc_t perm_rsrc = make_uniform_rsrc(
+        reinterpret_cast<const char *>(PERM ? p.perm + (int64_t)b * p.perm_batch_stride : nullptr),
+        PERM ? (uint32_t)((int64_t)p.Nq * 4) : 0u);
+    const int64_t out_image_bytes = (int64_t)p.Nq * p.M * 32 * (p.out_bf16 ? 2 : 4);
+    const __amdgpu_buffer_rsrc_t out_rsrc = make_uniform_rsrc(reinterpret_cast<const char *>(p.out) + b * out_image_bytes,
+                                                              (uint32_t)out_image_bytes);
+    float4 *myW = wts + wave * 256;
+
+    struct RowIn {
+        uint4 o;
+        uint2 gg;
+        float r[RD];
+    };
+    const int ngroups = (q_hi - q_lo + 15) >> 4;
+    // the row this quad works on in row group rg: position q_lo + 16 rg + g of the row order
+    auto row_slot = [&](int rg) -> uint32_t {
+        const uint32_t pos = (uint32_t)min(q_lo + min(rg, ngroups - 1) * 16 + g, q_hi - 1);
+        if (PERM) return buffer_load4(perm_rsrc, pos * 4u);
+        return pos;
+    };
+    auto load_row = [&](uint32_t slot) {
+        RowIn in;
+        const uint32_t prow = __umul24(slot, 96u);
+        in.o = buffer_load16(proj_rsrc, prow + (uint32_t)j * 16u);
+        in.gg = buffer_load8(proj_rsrc, prow + 64u + (uint32_t)j * 8u);
+        if (REF4) {
+            const uint4 r = buffer_load16(ref_rsrc, (slot * 4u + (uint32_t)j) * 16u);
+            in.r[0] = __uint_as_float(r.x); in.r[1] = __uint_as_float(r.y);
+            in.r[RD - 2] = __uint_as_float(r.z); in.r[RD - 1] = __uint_as_float(r.w);
+        } else {
+            const uint2 r = buffer_load8(ref_rsrc, (slot * 4u + (uint32_t)j) * 8u);
+            in.r[0] = __uint_as_float(r.x); in.r[1] = __uint_as_float(r.y);
+        }
+        return in;
+    };
+    // ---- prologue.  The resident records reach the LDS through REGISTERS (16-byte loads + ds_write_b128), not by
+    // LDS-DMA: a CU's LDS-DMA fills land at ~25 GB/s whatever the number of waves that issue them (MI355X_MICROARCH.md,
+    // "ldsdma-fill"; measured here: 95 KB usable 6.1 us after the kernel's start, the workgroup idle for 3 of them), the
+    // load path delivers the same bytes in ~1 us.  Vector memory reads return in order, so the request order is: the
+    // first two row groups' indices, the wave's six pieces of the slab (into the registers the sample loads use later),
+    // the first row's inputs; the pieces are written to LDS while those inputs are on their way.
+    RowIn nxt;
+    uint32_t slot_cur = row_slot(wave);
+    uint32_t slot_nxt = row_slot(wave + kRWaves);
+    {
+        const uint32_t src0 = (uint32_t)p.res_start * 64u;
+        const int pieces = (slab_bytes + 1023) >> 10;
+        uint4 stage[kBPieces];
+#pragma unroll
+        for (int k = 0; k < kBPieces; ++k) {
+            // (beyond the slab's last piece: that piece once more; lanes past the slab's end read its last 16 bytes)
+            const int piece = min(wave + k * kRWaves, pieces - 1);
+            const uint32_t off = min((uint32_t)piece * 1024u + (uint32_t)lane * 16u, (uint32_t)slab_bytes - 16u);
+            stage[k] = buffer_load16(rsrc, src0 + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        nxt = load_row(slot_cur);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < kBPieces; ++k) {
+            const int piece = min(wave + k * kRWaves, pieces - 1);
+            const uint32_t off = min((uint32_t)piece * 1024u + (uint32_t)lane * 16u, (uint32_t)slab_bytes - 16u);
+            *reinterpret_cast<uint4 *>(lds + off) = stage[k];
+        }
+    }
+    bool maps_pending = true;
+    uint32_t pf_sink = 0;   // destination of the discarded warm-up loads
+    if (wave >= ngroups) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int rg = wave; rg < ngroups; rg += kRWaves) {
+        const bool active = q_lo + rg * 16 + g < q_hi;
+        const uint32_t q = PERM ? min(slot_cur, (uint32_t)p.Nq - 1u) : slot_cur;   // (a bad order cannot write out of range)
+        const RowIn cur = nxt;
+        nxt = load_row(slot_nxt);
+        slot_cur = slot_nxt;
+        slot_nxt = row_slot(rg + 2 * kRWaves);
+        float ox[4], oy[4], lg[4];
+        ox[0] = bf16_lo(cur.o.x); oy[0] = bf16_hi(cur.o.x); ox[1] = bf16_lo(cur.o.y); oy[1] = bf16_hi(cur.o.y);
+        ox[2] = bf16_lo(cur.o.z); oy[2] = bf16_hi(cur.o.z); ox[3] = bf16_lo(cur.o.w); oy[3] = bf16_hi(cur.o.w);
+        lg[0] = bf16_lo(cur.gg.x); lg[1] = bf16_hi(cur.gg.x); lg[2] = bf16_lo(cur.gg.y); lg[3] = bf16_hi(cur.gg.y);
+        // (plain v_max3 / v_max with a DPP operand: fmaxf() adds a canonicalising v_max x, x per operand)
+        float mx = max3_f32(lg[0], lg[1], lg[2]);
+        mx = max_f32(mx, lg[3]);
+        mx = max_dpp_xor1(mx);
+        mx = max_dpp_xor2(mx);
+        const float mxs = mx * -1.4426950408889634f;
+        float e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = __builtin_amdgcn_exp2f(fmaf(lg[t], 1.4426950408889634f, mxs));   // exp(lg - mx)
+        float sum = (e[0] + e[1]) + (e[2] + e[3]);
+        sum += quad_xor1(sum);
+        sum += quad_xor2(sum);
+        const float inv = active ? __builtin_amdgcn_rcpf(sum) : 0.f;  // inactive rows: all weights zero
+
+        // bordered pixel coordinates of the reference point: w_im + 1 = ref_x * W - 0.5 + 1
+        const float bx = fmaf(cur.r[0], fW, 0.5f), by = fmaf(cur.r[1], fH, 0.5f);
+        float sx = 1.f, sy = 1.f;
+        if (REF4) {   // offset / num_points * box size * 0.5 (num_points = 4), in pixels of this level
+            sx = 0.125f * cur.r[RD - 2] * fW;
+            sy = 0.125f * cur.r[RD - 1] * fH;
+        }
+        uint32_t r0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float wx, wy;
+            if (REF4) {
+                wx = fmaf(ox[t], sx, bx);
+                wy = fmaf(oy[t], sy, by);
+            } else {
+                wx = bx + ox[t];
+                wy = by + oy[t];
+            }
+            wx = __builtin_amdgcn_fmed3f(wx, 0.f, xmax);   // NaN -> 0: the zero border
+            wy = __builtin_amdgcn_fmed3f(wy, 0.f, ymax);
+            const float lx = __builtin_amdgcn_fractf(wx), ly = __builtin_amdgcn_fractf(wy);
+            const uint32_t x0 = (uint32_t)wx, y0 = (uint32_t)wy;      // truncation = floor (wx, wy >= 0)
+            r0[t] = (ABL & 16) ? lvl_base + (uint32_t)((t * 4 + j) * 64) : lshl6_add(x0, mad_u24(y0, pitch64, lvl_base));
+            const float a = e[t] * inv;
+            const float wy1 = mul_f32(ly, a), wy0 = sub_f32(a, wy1);
+            const float w01 = mul_f32(wy0, lx), w11 = mul_f32(wy1, lx);
+            myW[(j * 4 + t) * 16 + g] = make_float4(sub_f32(wy0, w01), w01, sub_f32(wy1, w11), w11);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        float acc[8];
+
+#define SDETR_B_PB(JL) (JL == 0 ? pb0 : JL == 1 ? pb1 : JL == 2 ? pb2 : pb3)
+#define SDETR_B_ISSUE(SLOT, JL, T)                                                                             \
+    {                                                                                                          \
+        const uint32_t o0 = quad_bcast<JL>(r0[T]) + lane_off;                                                  \
+        if (!(ABL & 1)) {                                                                                      \
+        va[SLOT][0] = buffer_load16(rsrc, o0);                                                                 \
+        va[SLOT][1] = buffer_load16(rsrc, o0 + 64u);                                                           \
+        va[SLOT][2] = buffer_load16_s(rsrc, o0, SDETR_B_PB(JL));                                               \
+        va[SLOT][3] = buffer_load16_s(rsrc, o0 + 64u, SDETR_B_PB(JL));                                         \
+        } else { va[SLOT][0] = va[SLOT][1] = va[SLOT][2] = va[SLOT][3] = make_uint4(o0, o0, o0, o0); }        \
+    }
+#define SDETR_B_ACC(SLOT, JL, T)                                                                               \
+    {                                                                                                          \
+        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
+        if (!(ABL & 4)) {                                                                                      \
+        F::fma8(acc, va[SLOT][0], w.x);                                                                        \
+        F::fma8(acc, va[SLOT][1], w.y);                                                                        \
+        F::fma8(acc, va[SLOT][2], w.z);                                                                        \
+        F::fma8(acc, va[SLOT][3], w.w);                                                                        \
+        } else { acc[0] += w.x + __uint_as_float(va[SLOT][0].x ^ va[SLOT][1].y ^ va[SLOT][2].z ^ va[SLOT][3].w); } \
+    }
+#define SDETR_B_LDS(JL, T)                                                                                     \
+    {                                                                                                          \
+        const uint32_t o0 = quad_bcast<JL>(r0[T]) + lane_off, o1 = o0 + SDETR_B_PB(JL);                        \
+        uint4 v0, v1, v2, v3;                                                                                  \
+        if (!(ABL & 2)) {                                                                                      \
+            v0 = lds_read16(o0); v1 = lds_read16(o0 + 64u); v2 = lds_read16(o1); v3 = lds_read16(o1 + 64u);    \
+        } else { v0 = v1 = v2 = v3 = make_uint4(o0, o1, o0, o1); }                                             \
+        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
+        if (!(ABL & 8)) {                                                                                      \
+        F::fma8(acc, v0, w.x);                                                                                 \
+        F::fma8(acc, v1, w.y);                                                                                 \
+        F::fma8(acc, v2, w.z);                                                                                 \
+        F::fma8(acc, v3, w.w);                                                                                 \
+        } else { acc[0] += w.x + __uint_as_float(v0.x ^ v1.y ^ v2.z ^ v3.w); }                                 \
+    }
+    /* the row's first sample: its first product starts the accumulators */                                  \
+#define SDETR_B_LDS_FIRST(JL, T)                                                                               \
+    {                                                                                                          \
+        const uint32_t o0 = quad_bcast<JL>(r0[T]) + lane_off, o1 = o0 + SDETR_B_PB(JL);                        \
+        uint4 v0, v1, v2, v3;                                                                                  \
+        if (!(ABL & 2)) {                                                                                      \
+            v0 = lds_read16(o0); v1 = lds_read16(o0 + 64u); v2 = lds_read16(o1); v3 = lds_read16(o1 + 64u);    \
+        } else { v0 = v1 = v2 = v3 = make_uint4(o0, o1, o0, o1); }                                             \
+        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
+        mul8_f16(acc, v0, w.x);                                                                                \
+        F::fma8(acc, v1, w.y);                                                                                 \
+        F::fma8(acc, v2, w.z);                                                                                 \
+        F::fma8(acc, v3, w.w);                                                                                 \
+    }
+#define SDETR_FENCE __builtin_amdgcn_sched_barrier(0);
+        uint4 va[4][4];
+        SDETR_B_ISSUE(0, 0, 0) SDETR_B_ISSUE(1, 0, 1) SDETR_B_ISSUE(2, 0, 2) SDETR_B_ISSUE(3, 0, 3) SDETR_FENCE
+        if (maps_pending) {
+            if ((ABL & 32) && tid == 0) p.stamps[blockIdx.x * 8 + 1] = wall_clock64();
+            if ((ABL & 32) && blockIdx.x == 9 && lane == 0) p.stamps[2048 + wave * 4 + 1] = wall_clock64();
+            // First row group of this wave: everything it can do without the resident records is under way; its own
+            // pieces of them were written above (the barrier's release covers the LDS stores), the sample loads and the
+            // next row's inputs stay in flight across the barrier (a bare s_barrier behind the LDS wait: __syncthreads()
+            // would drain the vector memory queue too).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if ((ABL & 32) && tid == 0) p.stamps[blockIdx.x * 8 + 2] = wall_clock64();
+            if ((ABL & 32) && blockIdx.x == 9 && lane == 0) p.stamps[2048 + wave * 4 + 2] = wall_clock64();
+            if (p.prefetch_fine) {
+                // L2 warm-up (in the step the maps were written ~0.5 ms earlier and come from HBM / the Infinity Cache):
+                // one dword of every 128-byte line of this workgroup's share of the fine levels -- the head's 1.3 MB reach
+                // the XCD's L2 as one bulk read instead of as the gather's demand misses.  The values are discarded; the
+                // registers they land in are not reused before the loop's own waits have drained the queue.
+                const uint32_t lines = ((uint32_t)p.res_start * 64u + 127u) >> 7;
+                const uint32_t share = (lines + (uint32_t)p.chunks - 1u) / (uint32_t)p.chunks;
+                const uint32_t l0 = (uint32_t)chunk * share, l1 = min(lines, l0 + share);
+                for (uint32_t ln = l0 + (uint32_t)wave * 64u + (uint32_t)lane; ln < l1; ln += kRWaves * 64u) {
+                    const uint32_t off = ln * 128u;
+                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(pf_sink) : "v"(off), "s"(rsrc) : "memory");
+                }
+            }
+            maps_pending = false;
+        }
+        SDETR_FENCE
+        if (RES == 2) {
+            SDETR_B_LDS_FIRST(2, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_B_LDS(2, 1) SDETR_FENCE SDETR_B_ACC(1, 0, 1) SDETR_FENCE SDETR_B_ISSUE(1, 1, 1) SDETR_FENCE
+            SDETR_B_LDS(2, 2) SDETR_FENCE SDETR_B_ACC(2, 0, 2) SDETR_FENCE SDETR_B_ISSUE(2, 1, 2) SDETR_FENCE
+            SDETR_B_LDS(2, 3) SDETR_FENCE SDETR_B_ACC(3, 0, 3) SDETR_FENCE SDETR_B_ISSUE(3, 1, 3) SDETR_FENCE
+            SDETR_B_LDS(3, 0) SDETR_FENCE SDETR_B_ACC(0, 1, 0) SDETR_FENCE
+            SDETR_B_LDS(3, 1) SDETR_FENCE SDETR_B_ACC(1, 1, 1) SDETR_FENCE
+            SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(2, 1, 2) SDETR_FENCE
+            SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(3, 1, 3) SDETR_FENCE
+        } else {
+            SDETR_B_LDS_FIRST(3, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_B_LDS(3, 1) SDETR_FENCE SDETR_B_ACC(1, 0, 1) SDETR_FENCE SDETR_B_ISSUE(1, 1, 1) SDETR_FENCE
+            SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(2, 0, 2) SDETR_FENCE SDETR_B_ISSUE(2, 1, 2) SDETR_FENCE
+            SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(3, 0, 3) SDETR_FENCE SDETR_B_ISSUE(3, 1, 3) SDETR_FENCE
+            SDETR_B_ACC(0, 1, 0) SDETR_FENCE SDETR_B_ISSUE(0, 2, 0) SDETR_FENCE
+            SDETR_B_ACC(1, 1, 1) SDETR_FENCE SDETR_B_ISSUE(1, 2, 1) SDETR_FENCE
+            SDETR_B_ACC(2, 1, 2) SDETR_FENCE SDETR_B_ISSUE(2, 2, 2) SDETR_FENCE
+            SDETR_B_ACC(3, 1, 3) SDETR_FENCE SDETR_B_ISSUE(3, 2, 3) SDETR_FENCE
+            SDETR_B_ACC(0, 2, 0) SDETR_FENCE SDETR_B_ACC(1, 2, 1) SDETR_FENCE
+            SDETR_B_ACC(2, 2, 2) SDETR_FENCE SDETR_B_ACC(3, 2, 3) SDETR_FENCE
+        }
+#undef SDETR_FENCE
+#undef SDETR_B_ISSUE
+#undef SDETR_B_ACC
+#undef SDETR_B_LDS
+#undef SDETR_B_LDS_FIRST
+#undef SDETR_B_PB
+
+        if (active) {
+            // this image's output rows through a buffer resource: (row * M + head) * 32 channels, 32-bit offsets
+            const uint32_t oe = (__umul24(q, (uint32_t)p.M) + (uint32_t)m) * 32u + (uint32_t)j * 8u;
+            if (p.out_bf16) {
+                buffer_store16(out_rsrc, oe * 2u, make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                                             pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])));
+            } else {
+                buffer_store16(out_rsrc, oe * 4u, make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]),
+                                                             __float_as_uint(acc[2]), __float_as_uint(acc[3])));
+                buffer_store16(out_rsrc, oe * 4u + 16u, make_uint4(__float_as_uint(acc[4]), __float_as_uint(acc[5]),
+                                                                   __float_as_uint(acc[6]), __float_as_uint(acc[7])));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // (keeps the warm-up loads' register reserved)
+    if (SERIAL && b + b_step < b_end) __syncthreads();
+    }   // images
+    if (ABL & 32) {
+        __syncthreads();
+        if (tid == 0) p.stamps[blockIdx.x * 8 + 3] = wall_clock64();
+    }
+}
+
 static int device_cu_count()
 {
     static thread_local int cached_dev = -1, cached_cus = 0;
@@ -502,4 +945,161 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
 #undef SDETR_RES_LAUNCH
     note_forward_kernel(SDETR_KERNEL_MSDA_RESIDENT);
     return check_launch("msda_resident");
+}
+
+// ---- bordered maps (round 4) ----------------------------------------------------------------------------------------
+
+// Records per (image, head) of the bordered layout of a pyramid: sum (H_l + 2)(W_l + 1) + 1 (see msda_bordered_kernel).
+extern "C" int64_t sdetr_msda_bordered_records(const int32_t *level_hw_host, int num_levels)
+{
+    if (!level_hw_host || num_levels <= 0) return -1;
+    int64_t n = 1;
+    for (int l = 0; l < num_levels; ++l) {
+        const int64_t h = level_hw_host[2 * l], w = level_hw_host[2 * l + 1];
+        if (h <= 0 || w <= 0) return -1;
+        n += (h + 2) * (w + 1);
+    }
+    return n;
+}
+
+extern "C" int sdetr_msda_bordered_max_resident_records(void) { return kBMaxResidentPx; }
+
+// benchmarks only: device buffer of [workgroups][4] uint64 for the SDETR_MSDA_ABLATE=32 phase stamps
+static unsigned long long *g_stamps = nullptr;
+extern "C" void sdetr_msda_debug_stamps(void *device_buffer) { g_stamps = static_cast<unsigned long long *>(device_buffer); }
+
+extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *value_bordered, int value_dtype,
+                                           const int32_t *level_hw_host, const float *ref, int ref_dim,
+                                           int64_t ref_batch_stride, const void *proj_hm_bf16, const int32_t *row_order,
+                                           int64_t row_order_batch_stride, int B, int Np, int M, int Nq, void *out,
+                                           int out_dtype, int chunks)
+{
+    if (B < 0 || Np <= 0 || M <= 0 || Nq < 0) return fail("msda_bordered_forward: bad dims B=%d Np=%d M=%d Nq=%d", B, Np, M, Nq);
+    if (!value_bordered || !level_hw_host || !ref || !proj_hm_bf16 || !out) return fail("msda_bordered_forward: null pointer");
+    if (ref_dim != 2 && ref_dim != 4)
+        return fail("Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+    if (value_dtype != SDETR_F16)
+        return fail("msda_bordered_forward: fp16 bordered head-major value maps only (dtype %d)", value_dtype);
+    if (out_dtype != SDETR_BF16 && out_dtype != SDETR_F32) return fail("msda_bordered_forward: out must be bf16 or f32");
+    if (ref_batch_stride == 0) ref_batch_stride = (int64_t)Nq * 4 * ref_dim;
+    if (ref_batch_stride < (int64_t)Nq * 4 * ref_dim || (ref_batch_stride % ref_dim))
+        return fail("msda_bordered_forward: bad reference point batch stride");
+    if (row_order && row_order_batch_stride == 0) row_order_batch_stride = Nq;
+    if (row_order && row_order_batch_stride < Nq) return fail("msda_bordered_forward: bad row order batch stride");
+    if ((reinterpret_cast<uintptr_t>(proj_hm_bf16) % 16) || (reinterpret_cast<uintptr_t>(ref) % 16) ||
+        (reinterpret_cast<uintptr_t>(value_bordered) % 16) || (reinterpret_cast<uintptr_t>(out) % 16) ||
+        (reinterpret_cast<uintptr_t>(row_order) % 4))
+        return fail("msda_bordered_forward: operands must be 16-byte aligned");
+    BorderedArgs a{};
+    const int32_t *hw = level_hw_host;
+    if (sdetr_msda_bordered_records(hw, 4) != Np)
+        return fail("msda_bordered_forward: the level shapes give %lld bordered records, the map holds %d",
+                    (long long)sdetr_msda_bordered_records(hw, 4), Np);
+    a.H0 = hw[0]; a.W0 = hw[1]; a.H1 = hw[2]; a.W1 = hw[3]; a.H2 = hw[4]; a.W2 = hw[5]; a.H3 = hw[6]; a.W3 = hw[7];
+    const int64_t p1 = (int64_t)(a.H0 + 2) * (a.W0 + 1), p2 = p1 + (int64_t)(a.H1 + 2) * (a.W1 + 1),
+                  p3 = p2 + (int64_t)(a.H2 + 2) * (a.W2 + 1);
+    if ((int64_t)Np * 64 >= 0xffffffffLL) return fail("msda_bordered_forward: value map too large for 32-bit offsets");
+    if ((int64_t)Nq * M * 32 * 4 >= 0xffffffffLL || Nq >= (1 << 24) || M >= (1 << 24))
+        return fail("msda_bordered_forward: too many rows per image for 32-bit offsets (%d x %d heads)", Nq, M);
+    // 24-bit operands in the record index arithmetic
+    if (a.H0 + 2 >= (1 << 24) || a.W0 + 1 >= (1 << 24)) return fail("msda_bordered_forward: level too large");
+    a.P1 = (int)p1; a.P2 = (int)p2; a.P3 = (int)p3;
+    int res_levels = 2;
+    a.res_start = a.P2;
+    if (Np - a.P2 > kBMaxResidentPx) {
+        res_levels = 1;
+        a.res_start = a.P3;
+    }
+    a.res_px = Np - a.res_start;
+    if (a.res_px > kBMaxResidentPx)
+        return fail("msda_bordered_forward: level 3 alone holds %d records, more than the %d that fit in LDS", a.res_px,
+                    kBMaxResidentPx);
+    if ((int64_t)B * Nq == 0) return 0;
+    a.value = reinterpret_cast<const char *>(value_bordered);
+    a.ref = ref; a.ref_batch_stride = ref_batch_stride; a.ref_dim = ref_dim;
+    a.proj = reinterpret_cast<const bf16_t *>(proj_hm_bf16);
+    a.perm = row_order; a.perm_batch_stride = row_order_batch_stride;
+    a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.B = B; a.Np = Np; a.M = M; a.Nq = Nq;
+    const int cus = device_cu_count();
+    int lanes = 0;
+    if ((int64_t)B * M * Np * 64 > ((int64_t)160 << 20) && B > 4) lanes = 4;
+    if (const char *e = getenv("SDETR_MSDA_IMAGE_SERIAL")) {
+        const int v = atoi(e);
+        lanes = v <= 0 ? 0 : (v > B ? B : v);
+    }
+    a.image_serial = lanes;
+    const int groups = lanes ? lanes : B;
+    if (chunks <= 0) {
+        chunks = cus / (groups * M);
+        const int max_chunks = (Nq + 63) / 64;
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+    }
+    a.chunks = chunks;
+    a.stage_rotate = 1;
+    if (const char *e = getenv("SDETR_MSDA_STAGE_ROTATE")) a.stage_rotate = atoi(e) != 0;
+    a.prefetch_fine = 0;
+    if (const char *e = getenv("SDETR_MSDA_PREFETCH")) a.prefetch_fine = atoi(e) != 0;
+    const int64_t blocks = (int64_t)groups * M * chunks;
+    if (blocks > 0x7fffffffLL) return fail("msda_bordered_forward: grid too large");
+    const int lds_bytes = a.res_px * 64 + kRWaves * kRWeightBytes;
+#define SDETR_B_LAUNCH(REF4, RES, SER, PERM)                                                                        \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bordered_kernel<REF4, RES, SER, PERM>),       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                         \
+        hipLaunchKernelGGL((msda_bordered_kernel<REF4, RES, SER, PERM>), dim3((unsigned)blocks), dim3(kRThreads),   \
+                           lds_bytes, static_cast<hipStream_t>(stream), a);                                         \
+    } while (0)
+#define SDETR_B_PICK2(REF4, RES, SER)                                                                               \
+    do {                                                                                                            \
+        if (a.perm) SDETR_B_LAUNCH(REF4, RES, SER, true);                                                           \
+        else SDETR_B_LAUNCH(REF4, RES, SER, false);                                                                 \
+    } while (0)
+#define SDETR_B_LAUNCH_ABL(ABL)                                                                                     \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bordered_kernel<false, 2, false, true, ABL>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                         \
+        hipLaunchKernelGGL((msda_bordered_kernel<false, 2, false, true, ABL>), dim3((unsigned)blocks),              \
+                           dim3(kRThreads), lds_bytes, static_cast<hipStream_t>(stream), a);                        \
+    } while (0)
+    // Ablations for benchmarks/msda_bordered_ab.py (wrong results by construction): SDETR_MSDA_ABLATE = bit mask of
+    // 1 no fine-level loads, 2 no LDS map reads, 4 no fine-level products, 8 no resident-level products, 16 every row
+    // samples the same records
+    if (const char *e = getenv("SDETR_MSDA_ABLATE")) {
+        const int abl = atoi(e);
+        if (abl && a.perm && res_levels == 2 && ref_dim == 2 && !a.image_serial) {
+            switch (abl) {
+            case 1: SDETR_B_LAUNCH_ABL(1); break;
+            case 2: SDETR_B_LAUNCH_ABL(2); break;
+            case 3: SDETR_B_LAUNCH_ABL(3); break;
+            case 5: SDETR_B_LAUNCH_ABL(5); break;
+            case 10: SDETR_B_LAUNCH_ABL(10); break;
+            case 12: SDETR_B_LAUNCH_ABL(12); break;
+            case 15: SDETR_B_LAUNCH_ABL(15); break;
+            case 16: SDETR_B_LAUNCH_ABL(16); break;
+            case 32: a.stamps = g_stamps; if (!a.stamps) return fail("msda_bordered_forward: no stamp buffer"); SDETR_B_LAUNCH_ABL(32); break;
+            default: return fail("msda_bordered_forward: no such ablation %d", abl);
+            }
+            return check_launch("msda_bordered (ablated)");
+        }
+    }
+#define SDETR_B_PICK(REF4, RES)                                                                                     \
+    do {                                                                                                            \
+        if (a.image_serial) SDETR_B_PICK2(REF4, RES, true);                                                         \
+        else SDETR_B_PICK2(REF4, RES, false);                                                                       \
+    } while (0)
+    if (res_levels == 2) {
+        if (ref_dim == 4) SDETR_B_PICK(true, 2);
+        else SDETR_B_PICK(false, 2);
+    } else {
+        if (ref_dim == 4) SDETR_B_PICK(true, 1);
+        else SDETR_B_PICK(false, 1);
+    }
+#undef SDETR_B_PICK
+#undef SDETR_B_PICK2
+#undef SDETR_B_LAUNCH_ABL
+#undef SDETR_B_LAUNCH
+    note_forward_kernel(SDETR_KERNEL_MSDA_BORDERED);
+    return check_launch("msda_bordered");
 }

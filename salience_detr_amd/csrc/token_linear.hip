@@ -175,8 +175,9 @@ static int tl_launch_one(hipStream_t s, const TLArgs &a)
     static DeviceOnce lds_once;   // (one set of flags per instantiation)
     allow_dynamic_lds(token_linear_kernel<EPI, ADD2, WAVES>, lds_once, 160 * 1024);
     const int tpb = kTLTokWave * WAVES;
-    hipLaunchKernelGGL((token_linear_kernel<EPI, ADD2, WAVES>), dim3((unsigned)((a.T + tpb - 1) / tpb)), dim3(64 * (WAVES + 4)), lds,
-                       s, a);
+    TLArgs b = a;
+    b.hm_blocks = (a.T + tpb - 1) / tpb;
+    hipLaunchKernelGGL((token_linear_kernel<EPI, ADD2, WAVES>), dim3((unsigned)b.hm_blocks), dim3(64 * (WAVES + 4)), lds, s, b);
     return check_launch("token_linear");
 }
 
@@ -251,7 +252,8 @@ extern "C" int sdetr_token_linear_bf16(sdetr_stream_t stream, const void *x, con
 extern "C" int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x, const void *packed_weight,
                                            const float *bias_padded, const uint8_t *pad_mask, int batch_size,
                                            int spatial_size, int in_features, int num_heads, int channels,
-                                           int num_groups, void *dst, int dst_dtype)
+                                           int num_groups, void *dst, int dst_dtype,
+                                           const sdetr_bordered_layout *bordered)
 {
     if (channels != 32) return fail("value_proj_head_major: built for 32 channels per head (got %d)", channels);
     if (batch_size < 0 || spatial_size < 0 || num_heads <= 0 || num_groups <= 0) return fail("value_proj_head_major: bad sizes");
@@ -264,6 +266,7 @@ extern "C" int sdetr_value_proj_head_major(sdetr_stream_t stream, const void *x,
     if (!dst) return fail("value_proj_head_major: null pointer");
     a.rows_per_batch = spatial_size; a.pad = pad_mask; a.hm = dst; a.heads = num_heads; a.batch = batch_size;
     a.hm_f16 = dst_dtype == SDETR_F16;
+    if (int rc = tl_set_bordered(a, bordered, spatial_size, 1)) return rc;   // (the launch sets the block count)
     return tl_launch(static_cast<hipStream_t>(stream), kHeadMajor, false, a);
 }
 

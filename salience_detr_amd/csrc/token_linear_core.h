@@ -35,13 +35,32 @@ struct TLArgs {
     int skip_n;
     // kHeadMajor
     const uint8_t *pad;       // [T] or NULL
-    void *hm;                 // [groups][B][M][rows_per_batch][32]
+    void *hm;                 // [groups][B][M][hm_records][32]
     int heads, batch, hm_f16;
+    // bordered destination (include/salience_hip.h sdetr_bordered_layout): token ri of an image -> record hm_pixel_map[ri]
+    // (NULL: record ri, hm_records = rows_per_batch); the launch's `hm_blocks` token blocks share the zero fill of the
+    // hm_num_border border records of every map
+    const int32_t *hm_pixel_map;
+    const int32_t *hm_border;
+    int hm_num_border, hm_records, hm_blocks;
     // kClassMax
     const float *scale;       // [B, rows_per_batch] with batch stride
     int64_t scale_batch_stride;
     float *cmax;              // [T]
 };
+
+// destination layout of a head-major job: plain (`bordered` == NULL) or bordered; `blocks` = token blocks of the launch
+inline int tl_set_bordered(TLArgs &a, const sdetr_bordered_layout *bordered, int spatial_size, int blocks)
+{
+    a.hm_pixel_map = nullptr; a.hm_border = nullptr; a.hm_num_border = 0; a.hm_records = spatial_size; a.hm_blocks = blocks;
+    if (!bordered) return 0;
+    if (!bordered->pixel_map || !bordered->border || bordered->num_border <= 0 || bordered->records < spatial_size + bordered->num_border)
+        return fail("value projection: bad bordered layout (records %d, border %d, tokens %d)", bordered->records,
+                    bordered->num_border, spatial_size);
+    a.hm_pixel_map = bordered->pixel_map; a.hm_border = bordered->border; a.hm_num_border = bordered->num_border;
+    a.hm_records = bordered->records;
+    return 0;
+}
 
 __device__ __forceinline__ tl_f32x16_t tl_mfma(uint4 a, uint4 b, tl_f32x16_t c)
 {
@@ -164,11 +183,28 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
         return;
     }
 
+    if (EPI == kHeadMajor && p.hm_border) {
+        // this block's share of the border records: 64 bytes of zeros in every (group, head) map of the entry's image
+        // (16-byte stores, fire and forget -- nothing in this launch reads them)
+        const int total = p.batch * p.hm_num_border;
+        const int per = (total + p.hm_blocks - 1) / p.hm_blocks;
+        const int e0 = block * per, e1 = min(total, e0 + per);
+        const int pieces = (e1 - e0) * p.ntiles * 4;
+        for (int i = tid; i < pieces; i += kThreads) {
+            const int q4 = i & 3, rest = i >> 2;
+            const int nt = rest % p.ntiles, e = e0 + rest / p.ntiles;
+            const int bi = e / p.hm_num_border, rec = p.hm_border[e - bi * p.hm_num_border];
+            const int grp = nt / p.heads, hm = nt - grp * p.heads;
+            const int64_t pix = (((int64_t)grp * p.batch + bi) * p.heads + hm) * p.hm_records + rec;
+            *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + q4 * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     const int t = lane & 31, h = lane >> 5;
     const int tok = block * (kTLTokWave * WAVES) + wave * kTLTokWave + t;
     const bool valid = tok < p.T;
     const int tk = valid ? tok : p.T - 1;
     const int img = tk / p.rows_per_batch, ri = tk - img * p.rows_per_batch;
+    const int hm_rec = (EPI == kHeadMajor && p.hm_pixel_map) ? p.hm_pixel_map[ri] : ri;   // record of my token in its map
 
     for (int i = tid; i < nsteps * 128; i += kThreads) bs[i] = p.bias[i];
     uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
@@ -279,7 +315,7 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
                     const int n0 = nt * 32 + 16 * m + 8 * h;
                     if (EPI == kHeadMajor) {
                         const int grp = nt / p.heads, hm = nt - grp * p.heads;
-                        const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + hm) * p.rows_per_batch + ri;
+                        const int64_t pix = (((int64_t)grp * p.batch + img) * p.heads + hm) * p.hm_records + hm_rec;
                         *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.hm) + pix * 32 + 16 * m + 8 * h) = v;
                     } else if (p.group > 0) {
                         // feature-group-major [B][N/group][rows][group]: the group size is a multiple of 4

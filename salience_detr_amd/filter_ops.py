@@ -361,35 +361,53 @@ class ValueProjectionJob:
     been launched yet: ``salience_head(..., value_job=job)`` carries it in its stage-1 launch (the coarse levels leave
     the chip nearly empty), ``job.run()`` launches it on its own.  Either way ``job.done`` is set."""
 
-    def __init__(self, value, packed, bias, pad, heads, groups, dst, first_group):
+    def __init__(self, value, packed, bias, pad, heads, groups, dst, first_group, bordered=None):
         self.value, self.packed, self.bias, self.pad = value, packed, bias, pad
         self.heads, self.groups, self.dst, self.first_group = heads, groups, dst, first_group
+        self.bordered = bordered      # (struct, its device tensors) of a bordered destination, or None
         self.done = False
 
     def pointers(self):
-        """(x, packed weight, padded bias, pad mask, B, Nv, heads, groups, dst, dtype code) of the slice."""
+        """(x, packed weight, padded bias, pad mask, B, Nv, heads, groups, dst, dtype code, bordered layout | None) of
+        the slice."""
         B, Nv, _ = self.value.shape
         tiles = self.first_group * self.heads        # 32-feature tiles in front of the slice (32 channels per head)
         d = self.dst[self.first_group]
         return (self.value.data_ptr(), self.packed.data_ptr() + tiles * 16384, self.bias.data_ptr() + tiles * 32 * 4,
-                _hip.ptr(self.pad), B, Nv, self.heads, self.groups, d.data_ptr(), _hip.dtype_code(self.dst.dtype))
+                _hip.ptr(self.pad), B, Nv, self.heads, self.groups, d.data_ptr(), _hip.dtype_code(self.dst.dtype),
+                None if self.bordered is None else ctypes.byref(self.bordered[0]))
 
     def run(self):
         if self.done:
             return
-        x, pw, b, pad, B, Nv, heads, groups, dst, code_ = self.pointers()
+        x, pw, b, pad, B, Nv, heads, groups, dst, code_, lay = self.pointers()
         with torch.cuda.device(self.value.device):
             code = _hip.lib().sdetr_value_proj_head_major(_hip.stream_ptr(), x, pw, b, pad, B, Nv, 256, heads, 32, groups,
-                                                          dst, code_)
+                                                          dst, code_, lay)
         _hip.check(code, "value_proj_head_major")
         self.done = True
 
 
+def bordered_struct(level_shapes, device):
+    """``(sdetr_bordered_layout, keep-alive tensors)`` of a pyramid's bordered map layout on ``device`` (cached)."""
+    from .ms_deform_attn import bordered_layout
+    lay = bordered_layout(level_shapes)
+    key = "struct:" + str(device)
+    hit = lay._dev.get(key)
+    if hit is None:
+        pix, border = lay.on(device)
+        hit = (_hip.BorderedLayoutStruct(pix.data_ptr(), border.data_ptr(), int(border.numel()), int(lay.records)), pix, border)
+        lay._dev[key] = hit
+    return hit
+
+
 def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],
-                          num_heads: int, num_groups: int, dtype: torch.dtype, parts=2):
+                          num_heads: int, num_groups: int, dtype: torch.dtype, parts=2, bordered_levels=None):
     """``value_proj_head_major`` split into jobs over consecutive layer groups that share one destination
     ``[groups,B,heads,Nv,32]``: returns ``(dst, [ValueProjectionJob, ...])``.  ``parts``: a number of (nearly) equal
-    parts, or a sequence of layer counts per job (they must add up to ``num_groups``)."""
+    parts, or a sequence of layer counts per job (they must add up to ``num_groups``).  ``bordered_levels``: the
+    pyramid's level shapes -> the maps are written in the bordered layout ``[groups,B,heads,Np,32]``
+    (``ms_deform_attn.BorderedLayout``; the jobs zero the borders themselves)."""
     if not token_linear_applies(value, weight) or weight.shape[0] != num_groups * num_heads * 32:
         raise RuntimeError("plan_value_projection: bf16 [B,Nv,256] tokens and 32-channel heads expected")
     _hip.require_device("plan_value_projection", value=value, padding_mask=padding_mask)
@@ -397,7 +415,14 @@ def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor],
     packed, b = _packed_linear_bf16(weight, bias)
     pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
                                              else padding_mask)
-    dst = torch.empty((num_groups, B, num_heads, Nv, 32), dtype=dtype, device=value.device)
+    bordered = None
+    records = Nv
+    if bordered_levels is not None:
+        bordered = bordered_struct(bordered_levels, value.device)
+        records = bordered[0].records
+        if sum(int(h) * int(w) for h, w in bordered_levels) != Nv:
+            raise RuntimeError("plan_value_projection: the level shapes do not add up to the token count")
+    dst = torch.empty((num_groups, B, num_heads, records, 32), dtype=dtype, device=value.device)
     if isinstance(parts, int):
         k = max(1, min(int(parts), num_groups))
         sizes = [(num_groups * (i + 1)) // k - (num_groups * i) // k for i in range(k)]
@@ -408,7 +433,7 @@ def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor],
     jobs, g0 = [], 0
     for n in sizes:
         if n > 0:
-            jobs.append(ValueProjectionJob(value, packed, b, pad, num_heads, n, dst, g0))
+            jobs.append(ValueProjectionJob(value, packed, b, pad, num_heads, n, dst, g0, bordered))
         g0 += n
     return dst, jobs
 
@@ -485,7 +510,7 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
         carry_fin = (x3 and finalize_job is not None and not finalize_job.done and not carry_value
                      and finalize_job.tokens.device == x.device)
         if carry_value or carry_rank or carry_fin:
-            vp = value_job.pointers() if carry_value else (None, None, None, None, 0, 0, 0, 0, None, 0)
+            vp = value_job.pointers() if carry_value else (None, None, None, None, 0, 0, 0, 0, None, 0, None)
             rk = ctypes.byref(rank_job.struct()) if carry_rank else None
             fj = ctypes.byref(finalize_job.struct()) if carry_fin else None
             code = lib.sdetr_stage1_x3_with_jobs(*stage1_args, *vp, rk, fj)
@@ -885,10 +910,40 @@ def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optio
     return out if group_features else out.view(tuple(shape[:-1]) + (N,))
 
 
+def layer_row_orders(sorted_index: Tensor, counts, level_shapes, tile: int = 16):
+    """Per-layer row orders for the bordered MSDA kernel (include/salience_hip.h ``sdetr_layer_row_orders``):
+    ``sorted_index`` int64 ``[B,n0]`` (the token of every row of the sorted list), ``counts`` the layers' row counts
+    (non-increasing, ``counts[0] <= n0``) -> list of int32 ``[B,c_k]`` views (rows ``n0`` apart), each a permutation of
+    ``0..c_k-1`` that walks the layer's rows tile by tile of the finest level.  ``None`` when the pyramid is too large for
+    the one-workgroup kernel (the caller then runs the rows in list order)."""
+    from .ms_deform_attn import tile_major_positions
+    _hip.require_device("layer_row_orders", sorted_index=sorted_index)
+    B, n0 = sorted_index.shape
+    S = sum(int(h) * int(w) for h, w in level_shapes)
+    counts = [int(c) for c in counts]
+    if S > 76800 or n0 >= 0xffff or len(counts) > 8 or sorted_index.dtype != torch.int64 or max(counts) > n0:
+        return None
+    dev = sorted_index.device
+    key = ("row_orders", tuple(map(tuple, level_shapes)), int(tile), tuple(counts), str(dev))
+
+    def build():
+        return (tile_major_positions(level_shapes, tile).to(dev), torch.tensor(counts, dtype=torch.int32).to(dev))
+    from . import pyramid
+    tile_pos, counts_dev = pyramid.static_tensor(key, build)
+    order = torch.empty((len(counts), B, n0), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        code = _hip.lib().sdetr_layer_row_orders(_hip.stream_ptr(), sorted_index.data_ptr(), sorted_index.stride(0),
+                                                 tile_pos.data_ptr(), B, S, n0, len(counts), counts_dev.data_ptr(),
+                                                 order.data_ptr(), n0)
+    _hip.check(code, "layer_row_orders")
+    return [order[k, :, :c] for k, c in enumerate(counts)]
+
+
 def value_proj_head_major(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],
-                          num_heads: int, num_groups: int, dtype: torch.dtype) -> Tensor:
+                          num_heads: int, num_groups: int, dtype: torch.dtype, bordered_levels=None) -> Tensor:
     """``value_proj`` of ``num_groups`` stacked layers + ``masked_fill`` + head-major re-layout in one launch:
-    value ``[B,Nv,256]`` bf16, weight ``[groups*heads*32, 256]`` -> ``[groups,B,heads,Nv,32]`` fp16 | bf16."""
+    value ``[B,Nv,256]`` bf16, weight ``[groups*heads*32, 256]`` -> ``[groups,B,heads,Nv,32]`` fp16 | bf16
+    (``bordered_levels``: ``[groups,B,heads,Np,32]`` in the bordered layout of that pyramid)."""
     if not token_linear_applies(value, weight) or weight.shape[0] != num_groups * num_heads * 32:
         raise RuntimeError("value_proj_head_major: bf16 [B,Nv,256] tokens and 32-channel heads expected")
     _hip.require_device("value_proj_head_major", value=value, padding_mask=padding_mask)
@@ -896,11 +951,13 @@ def value_proj_head_major(value: Tensor, weight: Tensor, bias: Optional[Tensor],
     packed, b = _packed_linear_bf16(weight, bias)
     pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
                                              else padding_mask)
-    dst = torch.empty((num_groups, B, num_heads, Nv, 32), dtype=dtype, device=value.device)
+    bordered = None if bordered_levels is None else bordered_struct(bordered_levels, value.device)
+    records = Nv if bordered is None else bordered[0].records
+    dst = torch.empty((num_groups, B, num_heads, records, 32), dtype=dtype, device=value.device)
     with torch.cuda.device(value.device):
         code = _hip.lib().sdetr_value_proj_head_major(
             _hip.stream_ptr(), value.data_ptr(), packed.data_ptr(), b.data_ptr(), _hip.ptr(pad), B, Nv, 256, num_heads,
-            32, num_groups, dst.data_ptr(), _hip.dtype_code(dtype))
+            32, num_groups, dst.data_ptr(), _hip.dtype_code(dtype), None if bordered is None else ctypes.byref(bordered[0]))
     _hip.check(code, "value_proj_head_major")
     return dst
 

@@ -133,7 +133,8 @@ class SalienceEncoderHotPath(nn.Module):
             # of projection under ~20 us of head), one with each stage 2 (~10 under ~17)
             n_layers = len(self.encoder.layers)
             parts = (2, 1, 2, 1) if n_layers == 6 else min(4, n_layers)
-            plan = self.encoder.plan_values(feat_enc, mask_flatten, parts=parts)
+            plan = self.encoder.plan_values(feat_enc, mask_flatten, parts=parts,
+                                            level_shapes=pyramid.level_shapes_of(multi_level_masks))
             if plan is not None:
                 value_maps, value_jobs = plan
         level_shapes = pyramid.level_shapes_of(multi_level_masks)

@@ -283,12 +283,168 @@ def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tens
     return out
 
 
+# ---- bordered head-major maps (round 4; include/salience_hip.h, csrc/msda_resident.hip msda_bordered_kernel) -------------
+
+class BorderedLayout:
+    """Geometry of the bordered head-major layout of one pyramid: level l is (H_l + 2) rows of (W_l + 1) records (row -1
+    and row H_l zero, record -1 of every row zero = record W_l of the row above), the levels one after the other, one
+    closing zero record.  ``records``: records per (image, head); ``pixel_map`` int32 [Nv]: record of every token (level-
+    major raster order, the reference's flatten order, base_transformer.py:22-33); ``border`` int32 [nb]: the zero
+    records.  Device copies are cached per device."""
+
+    def __init__(self, level_shapes):
+        self.level_shapes = [(int(h), int(w)) for h, w in level_shapes]
+        starts, pix, border, p = [], [], [], 0
+        for h, w in self.level_shapes:
+            starts.append(p)
+            rows = torch.arange(h, dtype=torch.int64).view(h, 1)
+            cols = torch.arange(w, dtype=torch.int64).view(1, w)
+            pix.append((p + (rows + 1) * (w + 1) + cols + 1).reshape(-1))
+            border.append(p + torch.arange(w + 1, dtype=torch.int64))                       # row -1
+            border.append(p + (h + 1) * (w + 1) + torch.arange(w + 1, dtype=torch.int64))   # row H
+            border.append(p + (torch.arange(h, dtype=torch.int64) + 1) * (w + 1))           # record -1 of rows 0..H-1
+            p += (h + 2) * (w + 1)
+        border.append(torch.tensor([p], dtype=torch.int64))                                  # the closing record
+        self.starts = starts
+        self.records = p + 1
+        self.tokens = sum(h * w for h, w in self.level_shapes)
+        self.pixel_map_host = torch.cat(pix).to(torch.int32)
+        self.border_host = torch.cat(border).to(torch.int32)
+        self._dev = {}
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.pixel_map_host.to(device), self.border_host.to(device))
+        return self._dev[key]
+
+
+_BORDERED_LAYOUTS = {}
+
+
+def bordered_layout(level_shapes) -> BorderedLayout:
+    key = tuple((int(h), int(w)) for h, w in level_shapes)
+    if key not in _BORDERED_LAYOUTS:
+        _BORDERED_LAYOUTS[key] = BorderedLayout(key)
+    return _BORDERED_LAYOUTS[key]
+
+
+_BORDERED_MAX = None
+
+
+def bordered_supported(level_shapes, num_levels: int, num_points: int, channels: int = 32) -> bool:
+    """Whether ``msda_bordered_forward`` covers this pyramid: 4 levels x 4 points, 32-channel heads, and a coarsest level
+    whose bordered form fits the LDS next to the weight tables."""
+    global _BORDERED_MAX
+    if level_shapes is None or len(level_shapes) != 4 or num_levels != 4 or num_points != 4 or channels != 32:
+        return False
+    if _BORDERED_MAX is None:
+        _BORDERED_MAX = int(_hip.lib().sdetr_msda_bordered_max_resident_records())
+    h, w = level_shapes[3]
+    return (int(h) + 2) * (int(w) + 1) + 1 <= _BORDERED_MAX
+
+
+def is_bordered(value_hm: Tensor, level_shapes) -> bool:
+    """``value_hm`` ``[..., Np, 32]`` holds the bordered layout of ``level_shapes`` (decided by its record count)."""
+    if level_shapes is None or len(level_shapes) != 4:
+        return False
+    lay = bordered_layout(level_shapes)
+    return value_hm.shape[-2] == lay.records and lay.records != lay.tokens
+
+
+def to_bordered(value_hm: Tensor, level_shapes) -> Tensor:
+    """Plain head-major maps ``[..., Nv, D]`` -> bordered ``[..., Np, D]`` (tests and micro-benchmarks; the product path
+    writes the bordered form straight from the value projection, ``filter_ops.plan_value_projection``)."""
+    lay = bordered_layout(level_shapes)
+    if value_hm.shape[-2] != lay.tokens:
+        raise RuntimeError("to_bordered: the maps do not hold this pyramid's tokens")
+    pix, _ = lay.on(value_hm.device)
+    out = torch.zeros(value_hm.shape[:-2] + (lay.records, value_hm.shape[-1]), dtype=value_hm.dtype, device=value_hm.device)
+    out.index_copy_(value_hm.dim() - 2, pix.long(), value_hm)
+    return out
+
+
+def spatial_row_order(token_index: Tensor, level_shapes, tile: int = 16) -> Tensor:
+    """A row order for ``msda_bordered_forward``: the rows (tokens ``token_index`` [B, Nq], level-major raster indices)
+    sorted tile-major -- tiles of ``tile`` x ``tile`` finest-level pixels, the tokens of all levels whose centre falls
+    into a tile next to each other, raster order inside.  int32 [B, Nq].  (torch reference of the kernel that builds the
+    per-layer orders in the step, ``filter_ops.layer_row_orders``.)"""
+    pos = tile_major_positions(level_shapes, tile).to(token_index.device)
+    return pos[token_index.long()].argsort(dim=1, stable=True).to(torch.int32)
+
+
+_TILE_POS = {}
+
+
+def tile_major_positions(level_shapes, tile: int = 16) -> Tensor:
+    """int32 [Nv]: position of every token in the tile-major order of the pyramid (host tensor, cached)."""
+    key = (tuple((int(h), int(w)) for h, w in level_shapes), int(tile))
+    if key not in _TILE_POS:
+        h0, w0 = key[0][0]
+        ty, tx = max(1, -(-h0 // tile)), max(1, -(-w0 // tile))
+        keys = []
+        for lvl, (h, w) in enumerate(key[0]):
+            cy = ((torch.arange(h, dtype=torch.float64) + 0.5) / h * ty).floor().clamp_(max=ty - 1).long()
+            cx = ((torch.arange(w, dtype=torch.float64) + 0.5) / w * tx).floor().clamp_(max=tx - 1).long()
+            t = cy.view(h, 1) * tx + cx.view(1, w)                                    # tile of the token's centre
+            # inside a tile: level, then raster
+            inner = lvl * (1 << 20) + torch.arange(h * w, dtype=torch.int64).view(h, w)
+            keys.append((t * (1 << 24) + inner).reshape(-1))
+        k = torch.cat(keys)
+        order = k.argsort(stable=True)
+        pos = torch.empty_like(order)
+        pos[order] = torch.arange(order.numel(), dtype=torch.int64)
+        _TILE_POS[key] = pos.to(torch.int32)
+    return _TILE_POS[key]
+
+
+def msda_bordered_forward(value_bordered: Tensor, level_shapes, reference_points: Tensor, proj_hm: Tensor,
+                          row_order: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                          chunks: int = 0) -> Tensor:
+    """``msda_resident_forward`` on bordered maps ``[B,M,Np,32]`` fp16 (``to_bordered`` / the value projection's bordered
+    store); ``row_order`` optional int32 ``[B,Nq]`` permutation of the rows (processing order only)."""
+    import ctypes
+    _hip.require_device("msda_bordered_forward", value_bordered=value_bordered, proj_hm=proj_hm)
+    if reference_points.shape[-1] not in (2, 4):
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+            reference_points.shape[-1]))
+    B, M, Np, D = value_bordered.shape
+    if (not bordered_supported(level_shapes, 4, 4, D) or value_bordered.dtype != torch.float16
+            or not is_bordered(value_bordered, level_shapes)):
+        raise RuntimeError("msda_bordered_forward: fp16 bordered [B,M,Np,32] maps of a 4-level pyramid whose coarsest level "
+                           "fits in LDS expected")
+    if (proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or proj_hm.dtype != torch.bfloat16
+            or proj_hm.shape[0] != B):
+        raise RuntimeError("msda_bordered_forward: proj must be a contiguous bf16 [B, M, Nq, 48] tensor")
+    Nq = proj_hm.shape[2]
+    if row_order is not None and (not row_order.is_cuda or row_order.dtype != torch.int32 or row_order.shape != (B, Nq)
+                                  or (Nq > 1 and row_order.stride(1) != 1)):
+        raise RuntimeError("msda_bordered_forward: row_order must be a device int32 [B, Nq] with contiguous rows")
+    if not reference_points.is_cuda:
+        raise RuntimeError("msda_bordered_forward: reference_points must be a HIP (cuda) tensor; no CPU fallback")
+    if reference_points.dtype != torch.float32:
+        reference_points = reference_points.float()
+    if Nq > 0 and not reference_points[0].is_contiguous():
+        reference_points = reference_points.contiguous()
+    ref_bs = reference_points.stride(0) if (B > 1 and Nq > 0) else 0
+    out_dtype = out_dtype or proj_hm.dtype
+    out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_bordered.device)
+    hw = (ctypes.c_int32 * 8)(*[int(v) for s in level_shapes for v in s])
+    with torch.cuda.device(out.device):
+        code = _hip.lib().sdetr_msda_bordered_forward(
+            _hip.stream_ptr(), value_bordered.data_ptr(), _hip.dtype_code(value_bordered.dtype), hw,
+            reference_points.data_ptr(), reference_points.shape[-1], ref_bs, proj_hm.data_ptr(), _hip.ptr(row_order),
+            (row_order.stride(0) if B > 1 else Nq) if row_order is not None else 0, B, Np, M, Nq, out.data_ptr(), _hip.dtype_code(out_dtype), int(chunks))
+    _hip.check(code, "msda_bordered_forward")
+    return out
+
+
 def last_forward_kernel() -> int:
     """``SDETR_KERNEL_*`` code of the kernel the calling thread's last MSDA forward call dispatched to."""
     return int(_hip.lib().sdetr_msda_last_kernel())
 
 
-KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT = 1, 2, 3, 4
+KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT, KERNEL_BORDERED = 1, 2, 3, 4, 5
 
 def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                             sampling_loc: Tensor, attn_weight: Tensor,
@@ -323,7 +479,18 @@ def _stacked_value_proj(attn_modules):
     return hit[1], hit[2]
 
 
-def plan_batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor], parts=2):
+def _bordered_levels_for(attn_modules, level_shapes, vdt):
+    """The level shapes if these modules' maps can take the bordered layout (fp16 maps, 4 levels x 4 points, 32-channel
+    heads, a coarsest level that fits the LDS), else None."""
+    first = attn_modules[0]
+    if (level_shapes is None or vdt != torch.float16 or first.embed_dim != 32 * first.num_heads
+            or not all(m.num_levels == 4 and m.num_points == 4 for m in attn_modules)
+            or not bordered_supported(level_shapes, 4, 4)):
+        return None
+    return [(int(h), int(w)) for h, w in level_shapes]
+
+
+def plan_batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor], parts=2, level_shapes=None):
     """``batched_value_maps`` as pending jobs: ``(maps [n,B,M,Nv,D], [ValueProjectionJob, ...])`` -- slices of the one
     projection that other launches can carry (``filter_ops.salience_head(value_job=...)``) -- or ``None`` when the
     one-launch kernel does not cover the configuration (call ``batched_value_maps`` then)."""
@@ -335,10 +502,11 @@ def plan_batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[
     if not (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
             and value.is_contiguous() and value.dim() == 3):
         return None
-    return plan_value_projection(value, w_all, b_all, padding_mask, heads, len(attn_modules), vdt, parts=parts)
+    return plan_value_projection(value, w_all, b_all, padding_mask, heads, len(attn_modules), vdt, parts=parts,
+                                 bordered_levels=_bordered_levels_for(attn_modules, level_shapes, vdt))
 
 
-def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tensor], level_shapes=None) -> Tensor:
     """Head-major value maps ``[len(attn_modules), B, M, Nv, D]`` of several ``MultiScaleDeformableAttention``
     modules that sample the SAME ``value`` (the six encoder layers, salience_transformer.py:452; the decoder layers'
     cross-attentions, :575-582): their ``value_proj`` run as one projection.  No-grad path only."""
@@ -351,7 +519,9 @@ def batched_value_maps(attn_modules, value: Tensor, padding_mask: Optional[Tenso
     if (token_linear_applies(value, w_all) and E == 32 * heads and vdt in (torch.float16, torch.bfloat16)
             and value.is_contiguous()):
         # projection, padding mask, 16-bit conversion and head-major layout in one launch
-        return value_proj_head_major(value, w_all, b_all, padding_mask, heads, n, vdt)
+        # (with the pyramid's level shapes: the bordered layout the round-4 MSDA kernel reads, [n,B,M,Np,D])
+        return value_proj_head_major(value, w_all, b_all, padding_mask, heads, n, vdt,
+                                     bordered_levels=_bordered_levels_for(attn_modules, level_shapes, vdt))
     v_all = F.linear(value, w_all, b_all)                      # [B, Nv, n*E]
     out = value_to_head_major(v_all, padding_mask, heads, vdt, num_groups=n)
     return out[None] if n == 1 else out
@@ -534,7 +704,8 @@ class MultiScaleDeformableAttention(nn.Module):
     def forward_native(self, query: Tensor, reference_points: Tensor, value_hm: Tensor, spatial_shapes: Tensor,
                        level_start_index: Tensor, order: Optional[Tensor] = None,
                        query_pos: Optional[Tensor] = None, apply_output_proj: bool = True,
-                       level_shapes=None, head_major_projection: Optional[Tensor] = None) -> Tensor:
+                       level_shapes=None, head_major_projection: Optional[Tensor] = None,
+                       row_order: Optional[Tensor] = None) -> Tensor:
         """``query_pos`` (optional): position embedding still to be added to ``query`` -- folded into the projection
         kernel's prologue on the bf16 path.  ``apply_output_proj=False`` returns the sampled heads ``[B,Nq,E]`` for a
         caller that fuses ``output_proj`` with what follows it.  ``head_major_projection``: the offset | weight
@@ -545,7 +716,11 @@ class MultiScaleDeformableAttention(nn.Module):
         # (the token-resident kernel's run time is flat in the token count, ~17 us; below ~12 000 tokens the library GEMM
         # behind an elementwise add is 2-3 us faster, but only the resident kernel writes the per-head slabs that save
         # the gather kernel as much -- so it is used down to a few thousand tokens)
-        big = query.dim() == 3 and query.shape[0] * query.shape[1] >= 3000
+        bordered = is_bordered(value_hm, level_shapes)   # maps in the bordered layout (the encoder's batched projection)
+        if bordered and not (query.dim() == 3 and token_linear_applies(query, w) and order is None):
+            raise RuntimeError("MultiScaleDeformableAttention.forward_native: bordered value maps need contiguous bf16 "
+                               "[B,Nq,256] queries (the head-major projection path)")
+        big = query.dim() == 3 and (bordered or query.shape[0] * query.shape[1] >= 3000)
         head_major = (big and token_linear_applies(query, w) and order is None and self.num_levels == 4
                       and self.num_points == 4 and value_hm.shape[-1] == 32
                       and value_hm.dtype in (torch.float16, torch.bfloat16)
@@ -556,7 +731,11 @@ class MultiScaleDeformableAttention(nn.Module):
             if proj is None:
                 wh, bh = self._fused_query_projection_head_major()
                 proj = token_linear(query, wh, bh, x_add=query_pos, group_features=3 * self.num_levels * self.num_points)
-            if (self.resident_min_queries is not None and query.shape[1] >= self.resident_min_queries
+            if bordered:
+                # round 4: zero-bordered maps + (optional) spatial row order -- every layer size takes this kernel
+                out = msda_bordered_forward(value_hm, level_shapes, reference_points, proj, row_order=row_order,
+                                            out_dtype=query.dtype)
+            elif (self.resident_min_queries is not None and query.shape[1] >= self.resident_min_queries
                     and resident_supported(value_hm, level_shapes, self.num_levels, self.num_points)):
                 out = msda_resident_forward(value_hm, level_shapes, reference_points, proj, out_dtype=query.dtype)
             else:

@@ -25,7 +25,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import attention_train, pyramid
-from .filter_ops import (advance_rows, attention_heads, attention_heads_applies, attn_tail_ffn_advance,
+from .filter_ops import (advance_rows, layer_row_orders, attention_heads, attention_heads_applies, attn_tail_ffn_advance,
                          attn_tail_ffn_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
@@ -182,7 +182,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
                        class_head, level_shapes=None, selection_hook=None, advance=None, mc_score=None,
-                       want_next_score=False):
+                       want_next_score=False, row_order=None):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
@@ -225,7 +225,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
             sampled = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes,
                                                     level_start_index, query_pos=pos_sorted[:, :c],
                                                     apply_output_proj=False, level_shapes=level_shapes,
-                                                    head_major_projection=proj)
+                                                    head_major_projection=proj, row_order=row_order)
             if (advance is not None and self.fuse_attention_tail and not self.training
                     and attn_tail_ffn_applies(sampled, query, self.self_attn.output_proj, self.norm1, self.linear1,
                                               self.linear2, self.norm2, self.activation)):
@@ -247,12 +247,12 @@ class SalienceTransformerEncoderLayer(nn.Module):
         # pre_norm(select_tgt + tgt2) written straight back to the selected rows of the layer's queries
         fused_layer_norm(stacked[:, N:], self.pre_norm, residual=tgt2, scatter_index=sel, scatter_into=query)
         src2 = self.self_attn.forward_native(query, ref_sorted[:, :c], value_hm, spatial_shapes, level_start_index,
-                                             query_pos=pos_sorted[:, :c], level_shapes=level_shapes)
+                                             query_pos=pos_sorted[:, :c], level_shapes=level_shapes, row_order=row_order)
         out = self._forward_ffn_native(fused_layer_norm(query, self.norm1, residual=src2), advance)
         return (out, None) if want_next_score else out
 
     def forward(self, query, query_pos, value, reference_points, spatial_shapes, level_start_index,
-                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None):
+                query_key_padding_mask=None, score_tgt=None, foreground_pre_layer=None, value_hm=None, level_shapes=None):
         """Reference signature (salience_transformer.py:353-364) plus an optional pre-projected
         head-major ``value_hm`` (``[B,M,Nv,D]``) supplied by the encoder's batched value projection."""
         native = not _needs_grad(self, query, value)
@@ -288,7 +288,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
             if value_hm is None:
                 value_hm = self.self_attn.project_value(value, query_key_padding_mask)
             src2 = self.self_attn.forward_native(self.with_pos_embed(query, query_pos), reference_points, value_hm,
-                                                 spatial_shapes, level_start_index)
+                                                 spatial_shapes, level_start_index, level_shapes=level_shapes)
         else:
             src2 = self.self_attn(query=self.with_pos_embed(query, query_pos), reference_points=reference_points,
                                   value=value, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -440,12 +440,18 @@ class SalienceTransformerEncoder(nn.Module):
             output = torch.addcmul(output, bg.unsqueeze(0), keep.unsqueeze(-1))
         return output
 
-    def project_values(self, value: Tensor, padding_mask: Optional[Tensor]) -> Tensor:
+    # the value maps take the bordered layout (zero records around every level) and the deformable attention walks
+    # its rows in a per-layer spatial order (csrc/msda_resident.hip, msda_bordered_kernel); False = round 3's plain maps
+    bordered_value_maps = True
+    row_order_tile = 16
+
+    def project_values(self, value: Tensor, padding_mask: Optional[Tensor], level_shapes=None) -> Tensor:
         """Head-major value maps of ALL layers ``[num_layers,B,heads,Nv,D]`` (no-grad path).  The six layers sample
         the same, never-updated feature map (salience_transformer.py:452), so their ``value_proj`` run as one
         projection; it only depends on the flattened features, which lets a caller overlap it with the filtering
         stage on a second stream (``SalienceEncoderHotPath`` does)."""
-        return batched_value_maps([l.self_attn for l in self.layers], value, padding_mask)
+        return batched_value_maps([l.self_attn for l in self.layers], value, padding_mask,
+                                  level_shapes=level_shapes if self.bordered_value_maps else None)
 
     def plan_finalize(self, value: Tensor, padding_mask: Optional[Tensor], level_shapes):
         """The token-space pass of the output (``tokens + background`` outside the padding) as a pending
@@ -455,11 +461,12 @@ class SalienceTransformerEncoder(nn.Module):
             return None
         return FinalizeJob(value, self.background_embedding.flat_cached(level_shapes, value.dtype), padding_mask)
 
-    def plan_values(self, value: Tensor, padding_mask: Optional[Tensor], parts=2):
+    def plan_values(self, value: Tensor, padding_mask: Optional[Tensor], parts=2, level_shapes=None):
         """``project_values`` as pending jobs ``(maps, [ValueProjectionJob, ...])`` (``None`` when the one-launch
         projection does not apply): the caller lets other launches carry the jobs (the salience head's stage 1 on the
         coarse levels), runs the rest, and hands ``maps`` to ``forward`` as ``precomputed_value_maps``."""
-        return plan_batched_value_maps([l.self_attn for l in self.layers], value, padding_mask, parts=parts)
+        return plan_batched_value_maps([l.self_attn for l in self.layers], value, padding_mask, parts=parts,
+                                       level_shapes=level_shapes if self.bordered_value_maps else None)
 
     def forward(self, query, spatial_shapes, level_start_index, valid_ratios, query_pos=None,
                 query_key_padding_mask=None, foreground_score=None, focus_token_nums=None, foreground_inds=None,
@@ -492,7 +499,8 @@ class SalienceTransformerEncoder(nn.Module):
 
         value_hm_all = precomputed_value_maps
         if native and value_hm_all is None:
-            value_hm_all = self.project_values(value, query_key_padding_mask)
+            # (bordered maps only for the sorted loop below: the general loop's layers take plain maps)
+            value_hm_all = self.project_values(value, query_key_padding_mask, level_shapes if counts is not None else None)
 
         if counts is not None:
             # every layer's set is a prefix of one sorted list (what salience_filtering produces): keep the tokens
@@ -515,6 +523,11 @@ class SalienceTransformerEncoder(nn.Module):
                 fg_s = torch.gather(foreground_score, 1, sorted_index)
             result = torch.empty_like(q)
             score = None
+            # per-layer row orders for the deformable attention (tile-major walk of each layer's rows)
+            orders = None
+            from .ms_deform_attn import is_bordered
+            if value_hm_all is not None and is_bordered(value_hm_all[0], level_shapes) and self.row_order_tile:
+                orders = layer_row_orders(sorted_index, counts, level_shapes, tile=self.row_order_tile)
             for layer_id, layer in enumerate(self.layers):
                 if self.max_layers is not None and layer_id >= self.max_layers:
                     break
@@ -529,7 +542,8 @@ class SalienceTransformerEncoder(nn.Module):
                 q, score = layer.forward_sorted(q, pos_s, ref_s, fg_s, value_hm_all[layer_id], spatial_shapes,
                                                 level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
                                                 selection_hook=hook, advance=(result, nxt, value, sorted_index, focus64),
-                                                mc_score=score, want_next_score=True)
+                                                mc_score=score, want_next_score=True,
+                                                row_order=None if orders is None else orders[layer_id])
             if self.layer_marker is not None:
                 self.layer_marker(self.num_layers)
             if multi_level_masks is not None:
@@ -559,7 +573,7 @@ class SalienceTransformerEncoder(nn.Module):
                 ref = torch.gather(ori_reference_points, 1, inds.unsqueeze(-1).repeat(1, 1, s * p)).view(b, -1, s, p)
             score_tgt = self.enhance_mcsp(q)
             q = layer(q, q_pos, value, ref, spatial_shapes, level_start_index, query_key_padding_mask, score_tgt, fg,
-                      value_hm=value_hm_all[layer_id] if native else None)
+                      value_hm=value_hm_all[layer_id] if native else None, level_shapes=level_shapes if native else None)
             if native:
                 scatter_rows_(output, inds, q, count=focus64)
             else:

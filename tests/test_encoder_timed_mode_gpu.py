@@ -38,15 +38,24 @@ def timed_case():
     return m, sizes, shapes, feats, masks, pos, ref
 
 
-def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case):
+@pytest.mark.parametrize("layout", ["bordered", "plain"])
+def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case, layout):
+    """``bordered``: what the step runs since round 4 (zero-bordered maps, per-layer row orders, msda_bordered_kernel at
+    every layer size); ``plain``: round 3's maps and kernels, still the path of callers without level shapes."""
     m, sizes, level_shapes, feats, masks, pos, ref = timed_case
     enc = m.encoder
     feat_flat = ref["feat_flatten"].to(DEV).to(torch.bfloat16)
     mask_flat = ref["mask_flatten"].to(DEV)
     shapes_d, lsi_d = ref["spatial_shapes"].to(DEV), ref["level_start_index"].to(DEV)
     with torch.no_grad():
-        value_maps = enc.project_values(feat_flat, mask_flat)          # [6,B,8,Nv,32] fp16
-        assert value_maps.dtype == torch.float16
+        value_maps = enc.project_values(feat_flat, mask_flat, level_shapes if layout == "bordered" else None)
+        assert value_maps.dtype == torch.float16               # [6,B,8,Nv | Np,32]
+        assert M.is_bordered(value_maps[0], level_shapes) == (layout == "bordered")
+        orders = None
+        if layout == "bordered":
+            from salience_detr_amd.filter_ops import layer_row_orders
+            counts = [ref["layer_in"][k]["query"].shape[1] for k in range(len(enc.layers))]
+            orders = layer_row_orders(ref["foreground_inds"][0].to(DEV).contiguous(), counts, level_shapes)
         stats = []
         for k, layer in enumerate(enc.layers):
             lin, sel = ref["layer_in"][k], ref["layer_sel"][k].to(DEV)
@@ -54,9 +63,13 @@ def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case):
             qp = lin["query_pos"].to(DEV).to(torch.bfloat16).contiguous()
             out = layer.forward_sorted(q, qp, lin["ref"].to(DEV).contiguous(), lin["fg"].to(DEV).contiguous(),
                                        value_maps[k], shapes_d, lsi_d, enc.enhance_mcsp, level_shapes=level_shapes,
-                                       selection_hook=lambda s, forced=sel: forced)
+                                       selection_hook=lambda s, forced=sel: forced,
+                                       row_order=None if orders is None else orders[k])
             kernel = M.last_forward_kernel()
-            assert kernel == (M.KERNEL_RESIDENT if q.shape[1] >= layer.self_attn.resident_min_queries else M.KERNEL_L4P4)
+            if layout == "bordered":
+                assert kernel == M.KERNEL_BORDERED
+            else:
+                assert kernel == (M.KERNEL_RESIDENT if q.shape[1] >= layer.self_attn.resident_min_queries else M.KERNEL_L4P4)
             err = (out.float().cpu() - ref["layer_out"][k]).abs()
             stats.append((k, q.shape[1], err.mean().item(), err.flatten().kthvalue(int(err.numel() * 0.999))[0].item(),
                           err.max().item()))
@@ -88,7 +101,7 @@ def test_whole_path_selection_flips_are_the_only_large_errors(timed_case):
     finally:
         m.encoder.selection_hook = None
     gpu_inds = [t.cpu() for t in aux["foreground_inds"]]
-    assert M.last_forward_kernel() == M.KERNEL_RESIDENT           # layer 5: 2272 queries per image
+    assert M.last_forward_kernel() == M.KERNEL_BORDERED           # every layer: bordered maps + row order
     B, S, _ = memory.shape
     flipped = torch.zeros(B, S, dtype=torch.bool)
     for k in range(6):
