@@ -612,6 +612,7 @@ def main():
     launches, launch_nq, kernels_used, msda_us = [], [], [], []
     real_fused = msda_mod.msda_fused_forward
     real_resident = msda_mod.msda_resident_forward
+    real_bordered = msda_mod.msda_bordered_forward
 
     def record(call, value_hm, reference_points, proj, head_major, o, kernel):
         B, M, Nv, D = value_hm.shape
@@ -636,9 +637,20 @@ def main():
         record(call, value_hm, reference_points, proj_hm, True, o, "msda_resident_kernel<half_t>")
         return o
 
+    def timed_bordered(value_hm, level_shapes_, reference_points, proj_hm, row_order=None, out_dtype=None, chunks=0):
+        call = lambda: real_bordered(value_hm, level_shapes_, reference_points, proj_hm, row_order=row_order,
+                                     out_dtype=out_dtype, chunks=chunks)
+        o = call()
+        # (algorithmic bytes count the PIXELS of the maps, not the bordered layout's extra zero records)
+        plain_shape = value_hm[:, :, :sum(h * w for h, w in level_shapes_)]
+        record(call, plain_shape, reference_points, proj_hm, True, o,
+               "msda_bordered_kernel" + ("<row order>" if row_order is not None else ""))
+        return o
+
     sel_log = {}
     msda_mod.msda_fused_forward = timed_fused
     msda_mod.msda_resident_forward = timed_resident
+    msda_mod.msda_bordered_forward = timed_bordered
     model.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.cpu()) or s
     gpu_inds = None
     try:
@@ -653,6 +665,7 @@ def main():
     finally:
         msda_mod.msda_fused_forward = real_fused
         msda_mod.msda_resident_forward = real_resident
+        msda_mod.msda_bordered_forward = real_bordered
         model.encoder.selection_hook = None
 
     bytes_per_layer = launches[:nl]
@@ -689,6 +702,7 @@ def main():
 
         msda_mod.msda_fused_forward = cutting(real_fused)
         msda_mod.msda_resident_forward = cutting(real_resident)
+        msda_mod.msda_bordered_forward = cutting(real_bordered)
         try:
             for k in range(nl):
                 pair = []
@@ -717,6 +731,7 @@ def main():
         finally:
             msda_mod.msda_fused_forward = real_fused
             msda_mod.msda_resident_forward = real_resident
+            msda_mod.msda_bordered_forward = real_bordered
     have_in_step = all(u is not None and u > 0 for u in in_step_us)
     total_us = sum(in_step_us) if have_in_step else warm_total_us
     achieved = total_bytes / total_us / 1e3  # GB/s

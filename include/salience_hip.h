@@ -289,6 +289,23 @@ int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *tokens, con
 int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sorted_index, int64_t index_batch_stride,
                            const int32_t *tile_pos, int batch_size, int spatial_size, int num_rows, int num_layers,
                            const int32_t *counts_dev, int32_t *order, int64_t order_batch_stride);
+/* The same as a job another launch carries: sdetr_masked_topk_desc_with_orders_f32 = sdetr_masked_topk_desc_f32 + the job
+ * (when the selection is the one-workgroup-per-row histogram sort, the jobs' workgroups ride in its launch -- the encoder's
+ * first top-300 selection runs 2 workgroups on an otherwise empty chip; otherwise the job is launched behind it). */
+typedef struct {
+    const int64_t *sorted_index; /* [batch, num_rows] rows index_batch_stride apart (0 = num_rows) */
+    int64_t index_batch_stride;
+    const int32_t *tile_pos;     /* [spatial_size] */
+    int batch, spatial_size, num_rows, num_layers;
+    const int32_t *counts;       /* device int32 [num_layers] */
+    int32_t *order;              /* [num_layers][batch][order_batch_stride] */
+    int64_t order_batch_stride;  /* 0 = num_rows */
+} sdetr_row_orders_job;
+int sdetr_masked_topk_desc_with_orders_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                                           int64_t mask_row_stride, int fill_mode, const float *fill_value,
+                                           const int64_t *payload, int B, int n, int k, int64_t index_offset,
+                                           float *out_score, int64_t *out_index, int64_t out_row_stride,
+                                           void *workspace, size_t workspace_bytes, const sdetr_row_orders_job *job);
 int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens, const void *sorted_result,
                            const int64_t *sorted_index, const int64_t *count, const void *background,
                            const uint8_t *padding_mask, int batch_size, int spatial_size, int sorted_rows,

@@ -33,6 +33,14 @@ class BorderedLayoutStruct(ctypes.Structure):
                 ("records", ctypes.c_int)]
 
 
+class RowOrdersJobStruct(ctypes.Structure):
+    """``sdetr_row_orders_job`` of include/salience_hip.h."""
+    _fields_ = [("sorted_index", ctypes.c_void_p), ("index_batch_stride", ctypes.c_int64), ("tile_pos", ctypes.c_void_p),
+                ("batch", ctypes.c_int), ("spatial_size", ctypes.c_int), ("num_rows", ctypes.c_int),
+                ("num_layers", ctypes.c_int), ("counts", ctypes.c_void_p), ("order", ctypes.c_void_p),
+                ("order_batch_stride", ctypes.c_int64)]
+
+
 class RankJobStruct(ctypes.Structure):
     """``sdetr_rank_job`` of include/salience_hip.h."""
     _fields_ = [("score", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("mask_row_stride", ctypes.c_int64),
@@ -71,6 +79,7 @@ SIGNATURES = {
     "sdetr_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "sdetr_topk_uses_prefilter": (_i, [_i, _i]),
     "sdetr_masked_topk_desc_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
+    "sdetr_masked_topk_desc_with_orders_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz, _p]),
     "sdetr_merge_sorted_desc": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sdetr_attention_train_max_rows": (_i, []),
     "sdetr_attention_train_forward_f32": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, ctypes.c_float,

@@ -16,6 +16,7 @@
 //
 // All HBM-bound byte movers: one 16-byte chunk per thread, indices read once per row.
 #include "common.h"
+#include "row_orders_core.h"
 
 namespace sdetr {
 
@@ -260,65 +261,10 @@ extern "C" int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *
 // 0 .. counts[k]-1.  One 1024-thread workgroup per image: the rows are scattered into an LDS array indexed by tile
 // position (a counting sort with one key per slot), every thread counts the rows of each layer in its run of slots, one
 // block scan per layer gives its write offsets.  Pure index work: bit-exact, ~5 us.
-constexpr int kOrderThreads = 1024;
-constexpr int kOrderMaxLayers = 8;
-constexpr int kOrderMaxTokens = 76800;     // 150 KB of 16-bit slots
-
-__global__ void __launch_bounds__(kOrderThreads) layer_row_orders_kernel(const int64_t *sorted_index, int64_t index_batch_stride,
-                                                                        const int32_t *tile_pos, int S, int n0, int nl,
-                                                                        const int *counts_dev, int32_t *order,
-                                                                        int64_t order_layer_stride, int64_t order_batch_stride)
+__global__ void __launch_bounds__(kOrderThreads) layer_row_orders_kernel(RowOrderArgs a)
 {
-    extern __shared__ uint16_t slot[];                 // [S] row at every tile position, 0xffff = none
-    __shared__ int wave_tot[kOrderMaxLayers][kOrderThreads / 64];
-    __shared__ int counts[kOrderMaxLayers];
-    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < nl) counts[tid] = counts_dev[tid];
-    for (int p = tid; p < S; p += kOrderThreads) slot[p] = 0xffffu;
-    __syncthreads();
-    const int64_t *idx = sorted_index + (int64_t)b * index_batch_stride;
-    for (int r = tid; r < n0; r += kOrderThreads) {
-        const int64_t t = idx[r];
-        if (t >= 0 && t < S) slot[tile_pos[t]] = (uint16_t)r;   // (distinct tokens: one row per slot)
-    }
-    __syncthreads();
-    const int per = (S + kOrderThreads - 1) / kOrderThreads;
-    const int p0 = min(S, tid * per), p1 = min(S, p0 + per);
-    int cnt[kOrderMaxLayers];
-#pragma unroll
-    for (int k = 0; k < kOrderMaxLayers; ++k) cnt[k] = 0;
-    for (int p = p0; p < p1; ++p) {
-        const int r = slot[p];
-#pragma unroll
-        for (int k = 0; k < kOrderMaxLayers; ++k)
-            if (k < nl && r < counts[k]) ++cnt[k];
-    }
-    // exclusive block scan of every layer's count: wave-inclusive by shuffles, wave totals through LDS
-    int base[kOrderMaxLayers];
-#pragma unroll
-    for (int k = 0; k < kOrderMaxLayers; ++k) {
-        int v = cnt[k];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(v, d);
-            if (lane >= d) v += o;
-        }
-        if (lane == 63) wave_tot[k][wave] = v;
-        base[k] = v - cnt[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kOrderMaxLayers; ++k) {
-        int add = 0;
-        for (int w = 0; w < wave; ++w) add += wave_tot[k][w];
-        base[k] += add;
-    }
-    for (int p = p0; p < p1; ++p) {
-        const int r = slot[p];
-#pragma unroll
-        for (int k = 0; k < kOrderMaxLayers; ++k)
-            if (k < nl && r < counts[k]) order[k * order_layer_stride + b * order_batch_stride + base[k]++] = r;
-    }
+    extern __shared__ __attribute__((aligned(16))) uint16_t order_slot[];
+    layer_row_orders_body(a, (int)blockIdx.x, (int)blockIdx.y, order_slot);
 }
 
 // order [num_layers][batch][order_batch_stride >= n0] int32; counts_host: rows per layer (<= n0 each).  The counts travel
@@ -335,11 +281,14 @@ extern "C" int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sort
     if (index_batch_stride == 0) index_batch_stride = num_rows;
     if (order_batch_stride == 0) order_batch_stride = num_rows;
     if (index_batch_stride < num_rows || order_batch_stride < num_rows) return fail("layer_row_orders: bad strides");
+    RowOrderArgs a{};
+    a.sorted_index = sorted_index; a.index_batch_stride = index_batch_stride; a.tile_pos = tile_pos; a.S = spatial_size;
+    a.n0 = num_rows; a.nl = num_layers; a.batch = batch_size; a.counts_dev = counts_dev; a.order = order;
+    a.order_layer_stride = (int64_t)batch_size * order_batch_stride; a.order_batch_stride = order_batch_stride;
     static DeviceOnce once;
     allow_dynamic_lds(layer_row_orders_kernel, once, 160 * 1024 - 1024);
-    const size_t lds = (size_t)spatial_size * 2;
-    hipLaunchKernelGGL(layer_row_orders_kernel, dim3((unsigned)batch_size), dim3(kOrderThreads), lds,
-                       static_cast<hipStream_t>(stream), sorted_index, index_batch_stride, tile_pos, spatial_size, num_rows,
-                       num_layers, counts_dev, order, (int64_t)batch_size * order_batch_stride, order_batch_stride);
+    const size_t lds = (((size_t)spatial_size + 7) & ~(size_t)7) * 2;
+    hipLaunchKernelGGL(layer_row_orders_kernel, dim3((unsigned)batch_size, (unsigned)num_layers), dim3(kOrderThreads), lds,
+                       static_cast<hipStream_t>(stream), a);
     return check_launch("layer_row_orders");
 }

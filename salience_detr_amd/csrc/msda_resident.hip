@@ -442,6 +442,12 @@ __device__ __forceinline__ uint4 buffer_load16_s(__amdgpu_buffer_rsrc_t r, uint3
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <int AUX>
+__device__ __forceinline__ uint4 buffer_load16_aux(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff)
+{
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)soff, AUX);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ uint32_t buffer_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
@@ -522,6 +528,7 @@ template <bool REF4, int RES, bool SERIAL, bool PERM, int ABL = 0>
 __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p)
 {
     using F = ResFma<half_t>;
+    constexpr int kAux = ((ABL & 128) ? 2 : 0) | ((ABL & 256) ? 16 : 0);   // experiments: nt / sc1 on the fine-level loads
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // [resident records: levels 2, 3 with their borders + the closing zero record][weights: kRWaves x 4 KB]
     const int slab_bytes = p.res_px * 64;
@@ -639,10 +646,11 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    for (int rg = wave; rg < ngroups; rg += kRWaves) {
+    // One row group: `cur` = its inputs (loaded one group ahead), `nxt` receives the next group's.  The loop below calls it
+    // twice per iteration with the two input sets swapped: no register copies between iterations.
+    auto row_group = [&](const int rg, const RowIn &cur, RowIn &nxt) {
         const bool active = q_lo + rg * 16 + g < q_hi;
         const uint32_t q = PERM ? min(slot_cur, (uint32_t)p.Nq - 1u) : slot_cur;   // (a bad order cannot write out of range)
-        const RowIn cur = nxt;
         nxt = load_row(slot_nxt);
         slot_cur = slot_nxt;
         slot_nxt = row_slot(rg + 2 * kRWaves);
@@ -687,10 +695,15 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             const float lx = __builtin_amdgcn_fractf(wx), ly = __builtin_amdgcn_fractf(wy);
             const uint32_t x0 = (uint32_t)wx, y0 = (uint32_t)wy;      // truncation = floor (wx, wy >= 0)
             r0[t] = (ABL & 16) ? lvl_base + (uint32_t)((t * 4 + j) * 64) : lshl6_add(x0, mad_u24(y0, pitch64, lvl_base));
+            // (w00, w10 | w01, w11) = (row weights) x (1 - lx | lx): the two row weights as one register pair, so the
+            // column split is one packed multiply and one packed subtract
             const float a = e[t] * inv;
-            const float wy1 = mul_f32(ly, a), wy0 = sub_f32(a, wy1);
-            const float w01 = mul_f32(wy0, lx), w11 = mul_f32(wy1, lx);
-            myW[(j * 4 + t) * 16 + g] = make_float4(sub_f32(wy0, w01), w01, sub_f32(wy1, w11), w11);
+            const float wy1 = mul_f32(ly, a);
+            const f32x2_vec_t rw = {sub_f32(a, wy1), wy1}, fr = {lx, ly};
+            f32x2_vec_t wr, wl;
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(wr) : "v"(rw), "v"(fr));   // both halves x lx (fr's low half)
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(wl) : "v"(rw), "v"(wr));
+            myW[(j * 4 + t) * 16 + g] = make_float4(wl.x, wl.y, wr.x, wr.y);   // (y0,x0), (y1,x0), (y0,x1), (y1,x1)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -702,10 +715,10 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
     {                                                                                                          \
         const uint32_t o0 = quad_bcast<JL>(r0[T]) + lane_off;                                                  \
         if (!(ABL & 1)) {                                                                                      \
-        va[SLOT][0] = buffer_load16(rsrc, o0);                                                                 \
-        va[SLOT][1] = buffer_load16(rsrc, o0 + 64u);                                                           \
-        va[SLOT][2] = buffer_load16_s(rsrc, o0, SDETR_B_PB(JL));                                               \
-        va[SLOT][3] = buffer_load16_s(rsrc, o0 + 64u, SDETR_B_PB(JL));                                         \
+        va[SLOT][0] = buffer_load16_aux<kAux>(rsrc, o0, 0u);                                                   \
+        va[SLOT][1] = buffer_load16_aux<kAux>(rsrc, o0 + 64u, 0u);                                             \
+        va[SLOT][2] = buffer_load16_aux<kAux>(rsrc, o0, SDETR_B_PB(JL));                                       \
+        va[SLOT][3] = buffer_load16_aux<kAux>(rsrc, o0 + 64u, SDETR_B_PB(JL));                                 \
         } else { va[SLOT][0] = va[SLOT][1] = va[SLOT][2] = va[SLOT][3] = make_uint4(o0, o0, o0, o0); }        \
     }
 #define SDETR_B_ACC(SLOT, JL, T)                                                                               \
@@ -713,8 +726,8 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
         if (!(ABL & 4)) {                                                                                      \
         F::fma8(acc, va[SLOT][0], w.x);                                                                        \
-        F::fma8(acc, va[SLOT][1], w.y);                                                                        \
-        F::fma8(acc, va[SLOT][2], w.z);                                                                        \
+        F::fma8(acc, va[SLOT][1], w.z);                                                                        \
+        F::fma8(acc, va[SLOT][2], w.y);                                                                        \
         F::fma8(acc, va[SLOT][3], w.w);                                                                        \
         } else { acc[0] += w.x + __uint_as_float(va[SLOT][0].x ^ va[SLOT][1].y ^ va[SLOT][2].z ^ va[SLOT][3].w); } \
     }
@@ -728,8 +741,8 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
         if (!(ABL & 8)) {                                                                                      \
         F::fma8(acc, v0, w.x);                                                                                 \
-        F::fma8(acc, v1, w.y);                                                                                 \
-        F::fma8(acc, v2, w.z);                                                                                 \
+        F::fma8(acc, v1, w.z);                                                                                 \
+        F::fma8(acc, v2, w.y);                                                                                 \
         F::fma8(acc, v3, w.w);                                                                                 \
         } else { acc[0] += w.x + __uint_as_float(v0.x ^ v1.y ^ v2.z ^ v3.w); }                                 \
     }
@@ -743,13 +756,21 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         } else { v0 = v1 = v2 = v3 = make_uint4(o0, o1, o0, o1); }                                             \
         const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
         mul8_f16(acc, v0, w.x);                                                                                \
-        F::fma8(acc, v1, w.y);                                                                                 \
-        F::fma8(acc, v2, w.z);                                                                                 \
+        F::fma8(acc, v1, w.z);                                                                                 \
+        F::fma8(acc, v2, w.y);                                                                                 \
         F::fma8(acc, v3, w.w);                                                                                 \
     }
 #define SDETR_FENCE __builtin_amdgcn_sched_barrier(0);
+        // Fine-level samples in flight per wave.  Round 3 kept four (16 loads) rolling; measured on the step's own operands
+        // (benchmarks/msda_real_operands.py) one is FASTER: 25.4 vs 26.7 us at layer 0, 16.2 vs 17.5 at layer 2 -- the 16
+        // waves of a CU request 256 KB at a time with four slots, eight times the 32 KB L1 they allocate in, and with the
+        // rows in spatial order the loop is bound by vector-ALU issue, not by the loads' latency (+128 dummy instructions
+        // per group cost +2.7 us, -12 loads in flight nothing).  The level-3-only variant (twelve fine-level samples) keeps two.
         uint4 va[4][4];
-        SDETR_B_ISSUE(0, 0, 0) SDETR_B_ISSUE(1, 0, 1) SDETR_B_ISSUE(2, 0, 2) SDETR_B_ISSUE(3, 0, 3) SDETR_FENCE
+        SDETR_B_ISSUE(0, 0, 0)
+        if ((ABL & (64 | 2048)) || RES != 2) { SDETR_B_ISSUE(1, 0, 1) }
+        if ((ABL & 2048) && RES == 2) { SDETR_B_ISSUE(2, 0, 2) SDETR_B_ISSUE(3, 0, 3) }
+        SDETR_FENCE
         if (maps_pending) {
             if ((ABL & 32) && tid == 0) p.stamps[blockIdx.x * 8 + 1] = wall_clock64();
             if ((ABL & 32) && blockIdx.x == 9 && lane == 0) p.stamps[2048 + wave * 4 + 1] = wall_clock64();
@@ -762,7 +783,17 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             asm volatile("" ::: "memory");
             if ((ABL & 32) && tid == 0) p.stamps[blockIdx.x * 8 + 2] = wall_clock64();
             if ((ABL & 32) && blockIdx.x == 9 && lane == 0) p.stamps[2048 + wave * 4 + 2] = wall_clock64();
-            if (p.prefetch_fine) {
+            if (p.prefetch_fine & 2) {
+                // L2 warm-up of this workgroup's rows of the projection slab (written by the launch in front on other XCDs:
+                // every row group's first action is a round trip to them)
+                for (int pos = q_lo + tid; pos < q_hi; pos += kRThreads) {
+                    uint32_t row = (uint32_t)pos;
+                    if (PERM) row = buffer_load4(perm_rsrc, (uint32_t)pos * 4u);
+                    const uint32_t off = __umul24(row, 96u);
+                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(pf_sink) : "v"(off), "s"(proj_rsrc) : "memory");
+                }
+            }
+            if (p.prefetch_fine & 1) {
                 // L2 warm-up (in the step the maps were written ~0.5 ms earlier and come from HBM / the Infinity Cache):
                 // one dword of every 128-byte line of this workgroup's share of the fine levels -- the head's 1.3 MB reach
                 // the XCD's L2 as one bulk read instead of as the gather's demand misses.  The values are discarded; the
@@ -778,7 +809,27 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             maps_pending = false;
         }
         SDETR_FENCE
-        if (RES == 2) {
+        if (RES == 2 && !(ABL & (64 | 2048))) {
+            // ONE fine-level sample (four loads) in flight per wave: see the note at `va` above
+            SDETR_B_LDS_FIRST(2, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 0, 1) SDETR_FENCE
+            SDETR_B_LDS(2, 1) SDETR_FENCE SDETR_B_ACC(0, 0, 1) SDETR_FENCE SDETR_B_ISSUE(0, 0, 2) SDETR_FENCE
+            SDETR_B_LDS(2, 2) SDETR_FENCE SDETR_B_ACC(0, 0, 2) SDETR_FENCE SDETR_B_ISSUE(0, 0, 3) SDETR_FENCE
+            SDETR_B_LDS(2, 3) SDETR_FENCE SDETR_B_ACC(0, 0, 3) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_B_LDS(3, 0) SDETR_FENCE SDETR_B_ACC(0, 1, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 1) SDETR_FENCE
+            SDETR_B_LDS(3, 1) SDETR_FENCE SDETR_B_ACC(0, 1, 1) SDETR_FENCE SDETR_B_ISSUE(0, 1, 2) SDETR_FENCE
+            SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(0, 1, 2) SDETR_FENCE SDETR_B_ISSUE(0, 1, 3) SDETR_FENCE
+            SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(0, 1, 3) SDETR_FENCE
+        } else if (RES == 2 && (ABL & 64)) {
+            // experiment: two sample slots in flight instead of four
+            SDETR_B_LDS_FIRST(2, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 0, 2) SDETR_FENCE
+            SDETR_B_LDS(2, 1) SDETR_FENCE SDETR_B_ACC(1, 0, 1) SDETR_FENCE SDETR_B_ISSUE(1, 0, 3) SDETR_FENCE
+            SDETR_B_LDS(2, 2) SDETR_FENCE SDETR_B_ACC(0, 0, 2) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_B_LDS(2, 3) SDETR_FENCE SDETR_B_ACC(1, 0, 3) SDETR_FENCE SDETR_B_ISSUE(1, 1, 1) SDETR_FENCE
+            SDETR_B_LDS(3, 0) SDETR_FENCE SDETR_B_ACC(0, 1, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 2) SDETR_FENCE
+            SDETR_B_LDS(3, 1) SDETR_FENCE SDETR_B_ACC(1, 1, 1) SDETR_FENCE SDETR_B_ISSUE(1, 1, 3) SDETR_FENCE
+            SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(0, 1, 2) SDETR_FENCE
+            SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(1, 1, 3) SDETR_FENCE
+        } else if (RES == 2) {
             SDETR_B_LDS_FIRST(2, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
             SDETR_B_LDS(2, 1) SDETR_FENCE SDETR_B_ACC(1, 0, 1) SDETR_FENCE SDETR_B_ISSUE(1, 1, 1) SDETR_FENCE
             SDETR_B_LDS(2, 2) SDETR_FENCE SDETR_B_ACC(2, 0, 2) SDETR_FENCE SDETR_B_ISSUE(2, 1, 2) SDETR_FENCE
@@ -788,16 +839,18 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(2, 1, 2) SDETR_FENCE
             SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(3, 1, 3) SDETR_FENCE
         } else {
-            SDETR_B_LDS_FIRST(3, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
-            SDETR_B_LDS(3, 1) SDETR_FENCE SDETR_B_ACC(1, 0, 1) SDETR_FENCE SDETR_B_ISSUE(1, 1, 1) SDETR_FENCE
-            SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(2, 0, 2) SDETR_FENCE SDETR_B_ISSUE(2, 1, 2) SDETR_FENCE
-            SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(3, 0, 3) SDETR_FENCE SDETR_B_ISSUE(3, 1, 3) SDETR_FENCE
-            SDETR_B_ACC(0, 1, 0) SDETR_FENCE SDETR_B_ISSUE(0, 2, 0) SDETR_FENCE
-            SDETR_B_ACC(1, 1, 1) SDETR_FENCE SDETR_B_ISSUE(1, 2, 1) SDETR_FENCE
-            SDETR_B_ACC(2, 1, 2) SDETR_FENCE SDETR_B_ISSUE(2, 2, 2) SDETR_FENCE
-            SDETR_B_ACC(3, 1, 3) SDETR_FENCE SDETR_B_ISSUE(3, 2, 3) SDETR_FENCE
-            SDETR_B_ACC(0, 2, 0) SDETR_FENCE SDETR_B_ACC(1, 2, 1) SDETR_FENCE
-            SDETR_B_ACC(2, 2, 2) SDETR_FENCE SDETR_B_ACC(3, 2, 3) SDETR_FENCE
+            // level 3 alone resident: twelve fine-level samples through TWO slots (two in flight from the start)
+            SDETR_B_LDS_FIRST(3, 0) SDETR_FENCE SDETR_B_ACC(0, 0, 0) SDETR_FENCE SDETR_B_ISSUE(0, 0, 2) SDETR_FENCE
+            SDETR_B_LDS(3, 1) SDETR_FENCE SDETR_B_ACC(1, 0, 1) SDETR_FENCE SDETR_B_ISSUE(1, 0, 3) SDETR_FENCE
+            SDETR_B_LDS(3, 2) SDETR_FENCE SDETR_B_ACC(0, 0, 2) SDETR_FENCE SDETR_B_ISSUE(0, 1, 0) SDETR_FENCE
+            SDETR_B_LDS(3, 3) SDETR_FENCE SDETR_B_ACC(1, 0, 3) SDETR_FENCE SDETR_B_ISSUE(1, 1, 1) SDETR_FENCE
+            SDETR_B_ACC(0, 1, 0) SDETR_FENCE SDETR_B_ISSUE(0, 1, 2) SDETR_FENCE
+            SDETR_B_ACC(1, 1, 1) SDETR_FENCE SDETR_B_ISSUE(1, 1, 3) SDETR_FENCE
+            SDETR_B_ACC(0, 1, 2) SDETR_FENCE SDETR_B_ISSUE(0, 2, 0) SDETR_FENCE
+            SDETR_B_ACC(1, 1, 3) SDETR_FENCE SDETR_B_ISSUE(1, 2, 1) SDETR_FENCE
+            SDETR_B_ACC(0, 2, 0) SDETR_FENCE SDETR_B_ISSUE(0, 2, 2) SDETR_FENCE
+            SDETR_B_ACC(1, 2, 1) SDETR_FENCE SDETR_B_ISSUE(1, 2, 3) SDETR_FENCE
+            SDETR_B_ACC(0, 2, 2) SDETR_FENCE SDETR_B_ACC(1, 2, 3) SDETR_FENCE
         }
 #undef SDETR_FENCE
 #undef SDETR_B_ISSUE
@@ -806,6 +859,13 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
 #undef SDETR_B_LDS_FIRST
 #undef SDETR_B_PB
 
+        if (ABL & 1024) {
+            // experiment: 128 extra vector instructions per row group (is the loop bound by vector-ALU issue?)
+            float d = acc[0];
+#pragma unroll
+            for (int i = 0; i < 128; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(acc[1]));
+            if (__float_as_uint(d) == 0x7fc12345u) acc[0] = d;
+        }
         if (active) {
             // this image's output rows through a buffer resource: (row * M + head) * 32 channels, 32-bit offsets
             const uint32_t oe = (__umul24(q, (uint32_t)p.M) + (uint32_t)m) * 32u + (uint32_t)j * 8u;
@@ -818,6 +878,13 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
                 buffer_store16(out_rsrc, oe * 4u + 16u, make_uint4(__float_as_uint(acc[4]), __float_as_uint(acc[5]),
                                                                    __float_as_uint(acc[6]), __float_as_uint(acc[7])));
             }
+        }
+    };
+    {
+        RowIn in_b;
+        for (int rg = wave; rg < ngroups; rg += 2 * kRWaves) {
+            row_group(rg, nxt, in_b);
+            if (rg + kRWaves < ngroups) row_group(rg + kRWaves, in_b, nxt);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // (keeps the warm-up loads' register reserved)
@@ -1039,8 +1106,10 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     a.chunks = chunks;
     a.stage_rotate = 1;
     if (const char *e = getenv("SDETR_MSDA_STAGE_ROTATE")) a.stage_rotate = atoi(e) != 0;
-    a.prefetch_fine = 0;
-    if (const char *e = getenv("SDETR_MSDA_PREFETCH")) a.prefetch_fine = atoi(e) != 0;
+    // bit 0: L2 warm-up of the fine levels (on: in the step -132.7 -> 124.3 us over the six launches by rocprofv3; nothing
+    // to gain in a warm replay), bit 1: of the workgroup's projection rows (measured: no gain).  Environment: A/B runs.
+    a.prefetch_fine = 1;
+    if (const char *e = getenv("SDETR_MSDA_PREFETCH")) a.prefetch_fine = atoi(e);
     const int64_t blocks = (int64_t)groups * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_bordered_forward: grid too large");
     const int lds_bytes = a.res_px * 64 + kRWaves * kRWeightBytes;
@@ -1078,6 +1147,14 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
             case 12: SDETR_B_LAUNCH_ABL(12); break;
             case 15: SDETR_B_LAUNCH_ABL(15); break;
             case 16: SDETR_B_LAUNCH_ABL(16); break;
+            case 64: SDETR_B_LAUNCH_ABL(64); break;
+            case 2048: SDETR_B_LAUNCH_ABL(2048); break;
+            case 1024: SDETR_B_LAUNCH_ABL(1024); break;
+            case 3072: SDETR_B_LAUNCH_ABL(3072); break;
+            case 128: SDETR_B_LAUNCH_ABL(128); break;
+            case 256: SDETR_B_LAUNCH_ABL(256); break;
+            case 384: SDETR_B_LAUNCH_ABL(384); break;
+            case 192: SDETR_B_LAUNCH_ABL(192); break;
             case 32: a.stamps = g_stamps; if (!a.stamps) return fail("msda_bordered_forward: no stamp buffer"); SDETR_B_LAUNCH_ABL(32); break;
             default: return fail("msda_bordered_forward: no such ablation %d", abl);
             }

@@ -32,6 +32,7 @@
 #include "common.h"
 
 #include "topk_core.h"
+#include "row_orders_core.h"
 
 namespace sdetr {
 
@@ -254,9 +255,8 @@ struct SelectArgs {
 };
 
 template <int KPT>
-__global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
+__device__ __forceinline__ void topk_hsort_body(const SelectArgs &p, const int b, uint32_t *hs_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hs_lds[];
     // [off: kHsBins + 1 (+3 pad)][cur: kHsBins][list keys: N][list positions (u16): N]
     uint32_t *off = hs_lds;
     uint32_t *cur = hs_lds + kHsBins + 4;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
     __shared__ uint32_t bitmap[kHsMapWords];           // positions of a tie group's members
     __shared__ uint32_t bit_prefix[kHsMapWords];       // members in the words before
     __shared__ uint64_t tmp[kHsTmp];                   // a crowded bin's (key << 16 | position) pairs while they are sorted
-    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *srow = p.score + (int64_t)b * p.N;
     const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
     const float fill = p.fill ? *p.fill : 0.f;
@@ -597,6 +597,29 @@ __global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
 
 using namespace sdetr;
 
+template <int KPT>
+__global__ void __launch_bounds__(kHsThreads) topk_hsort_kernel(SelectArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_dyn[];
+    topk_hsort_body<KPT>(p, (int)blockIdx.x, hs_dyn);
+}
+
+// the same launch carrying the encoder's row-order jobs (row_orders_core.h): workgroups [0, nsel) sort their row, workgroup
+// nsel + k * batch + b builds the order of (image b, layer k).  The selection runs on 2 workgroups of an otherwise empty
+// chip for ~10 us; as a launch of their own the orders cost the step ~17 us.
+template <int KPT>
+__global__ void __launch_bounds__(kHsThreads) topk_hsort_orders_kernel(SelectArgs p, int nsel, RowOrderArgs o)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_dyn[];
+    const int blk = (int)blockIdx.x;
+    if (blk < nsel) {
+        topk_hsort_body<KPT>(p, blk, hs_dyn);
+    } else {
+        const int j = blk - nsel;
+        layer_row_orders_body(o, j % o.batch, j / o.batch, reinterpret_cast<uint16_t *>(hs_dyn));
+    }
+}
+
 static bool use_select(int n, int k)
 {
     // the shapes that used to take prefilter + rank (k well below n) and fit one workgroup: histogram sort in ONE launch
@@ -625,11 +648,61 @@ extern "C" size_t sdetr_topk_workspace_bytes(int B, int n, int k)
     return bytes;
 }
 
+static int fill_order_args(RowOrderArgs &o, const sdetr_row_orders_job *job)
+{
+    if (job->batch <= 0 || job->spatial_size <= 0 || job->num_rows <= 0 || job->num_layers <= 0) return fail("row-orders job: bad sizes");
+    if (!job->sorted_index || !job->tile_pos || !job->counts || !job->order) return fail("row-orders job: null pointer");
+    if (job->num_layers > kOrderMaxLayers || job->spatial_size > kOrderMaxTokens || job->num_rows >= 0xffff)
+        return fail("row-orders job: too many layers / tokens / rows");
+    const int64_t ibs = job->index_batch_stride ? job->index_batch_stride : job->num_rows;
+    const int64_t obs = job->order_batch_stride ? job->order_batch_stride : job->num_rows;
+    if (ibs < job->num_rows || obs < job->num_rows) return fail("row-orders job: bad strides");
+    o = RowOrderArgs{};
+    o.sorted_index = job->sorted_index; o.index_batch_stride = ibs; o.tile_pos = job->tile_pos; o.S = job->spatial_size;
+    o.n0 = job->num_rows; o.nl = job->num_layers; o.batch = job->batch; o.counts_dev = job->counts; o.order = job->order;
+    o.order_layer_stride = (int64_t)job->batch * obs; o.order_batch_stride = obs;
+    return 0;
+}
+
+static int masked_topk_impl(sdetr_stream_t stream, const float *score, const uint8_t *mask, int64_t mask_row_stride,
+                            int fill_mode, const float *fill_value, const int64_t *payload, int B, int n, int k,
+                            int64_t index_offset, float *out_score, int64_t *out_index, int64_t out_row_stride,
+                            void *workspace, size_t workspace_bytes, const sdetr_row_orders_job *job, int *carried);
+
 extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
                                           int64_t mask_row_stride, int fill_mode, const float *fill_value,
                                           const int64_t *payload, int B, int n, int k,
                                           int64_t index_offset, float *out_score, int64_t *out_index,
                                           int64_t out_row_stride, void *workspace, size_t workspace_bytes)
+{
+    return masked_topk_impl(stream, score, mask, mask_row_stride, fill_mode, fill_value, payload, B, n, k, index_offset,
+                            out_score, out_index, out_row_stride, workspace, workspace_bytes, nullptr, nullptr);
+}
+
+// sdetr_masked_topk_desc_f32 + a row-orders job (sdetr_layer_row_orders' arguments) that the selection's launch carries
+// when it is the one-workgroup-per-row histogram sort; otherwise the job runs as a launch of its own behind it.
+extern "C" int sdetr_masked_topk_desc_with_orders_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                                                      int64_t mask_row_stride, int fill_mode, const float *fill_value,
+                                                      const int64_t *payload, int B, int n, int k, int64_t index_offset,
+                                                      float *out_score, int64_t *out_index, int64_t out_row_stride,
+                                                      void *workspace, size_t workspace_bytes,
+                                                      const sdetr_row_orders_job *job)
+{
+    if (!job) return fail("masked_topk_with_orders: no job");
+    int carried = 0;
+    if (int rc = masked_topk_impl(stream, score, mask, mask_row_stride, fill_mode, fill_value, payload, B, n, k, index_offset,
+                                  out_score, out_index, out_row_stride, workspace, workspace_bytes, job, &carried))
+        return rc;
+    if (carried) return 0;
+    return sdetr_layer_row_orders(stream, job->sorted_index, job->index_batch_stride, job->tile_pos, job->batch,
+                                  job->spatial_size, job->num_rows, job->num_layers, job->counts, job->order,
+                                  job->order_batch_stride);
+}
+
+static int masked_topk_impl(sdetr_stream_t stream, const float *score, const uint8_t *mask, int64_t mask_row_stride,
+                            int fill_mode, const float *fill_value, const int64_t *payload, int B, int n, int k,
+                            int64_t index_offset, float *out_score, int64_t *out_index, int64_t out_row_stride,
+                            void *workspace, size_t workspace_bytes, const sdetr_row_orders_job *job, int *carried)
 {
     if (out_row_stride == 0) out_row_stride = k;
     if (out_row_stride < k) return fail("masked_topk: output row stride too small");
@@ -662,12 +735,30 @@ extern "C" int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *sc
         a.k = k; a.index_offset = index_offset; a.out_score = out_score; a.out_index = out_index;
         a.out_stride = out_row_stride;
         const int chunk = (n + kHsThreads - 1) / kHsThreads;
-        const size_t dyn = ((size_t)(2 * kHsBins + 4) + (size_t)n) * 4 + (((size_t)n * 2 + 15) & ~(size_t)15);
+        size_t dyn = ((size_t)(2 * kHsBins + 4) + (size_t)n) * 4 + (((size_t)n * 2 + 15) & ~(size_t)15);
+        RowOrderArgs o{};
+        int order_blocks = 0;
+        if (job) {
+            if (int rc = fill_order_args(o, job)) return rc;
+            const size_t need = (((size_t)o.S + 7) & ~(size_t)7) * 2;
+            if (need <= 136 * 1024) {       // (fits the launch's dynamic LDS limit next to the sort's static arrays)
+                order_blocks = o.batch * o.nl;
+                if (need > dyn) dyn = need;
+                if (carried) *carried = 1;
+            }
+        }
 #define SDETR_HS(KPT)                                                                                               \
     do {                                                                                                            \
-        static DeviceOnce lds_once;                                                                                 \
-        allow_dynamic_lds(topk_hsort_kernel<KPT>, lds_once, 136 * 1024);   /* + ~14 KB of static LDS */                                            \
-        hipLaunchKernelGGL(topk_hsort_kernel<KPT>, dim3((unsigned)B), dim3(kHsThreads), dyn, stream, a);            \
+        if (order_blocks) {                                                                                         \
+            static DeviceOnce lds_once2;                                                                            \
+            allow_dynamic_lds(topk_hsort_orders_kernel<KPT>, lds_once2, 136 * 1024);                                \
+            hipLaunchKernelGGL(topk_hsort_orders_kernel<KPT>, dim3((unsigned)(B + order_blocks)), dim3(kHsThreads), dyn, \
+                               stream, a, B, o);                                                                    \
+        } else {                                                                                                    \
+            static DeviceOnce lds_once;                                                                             \
+            allow_dynamic_lds(topk_hsort_kernel<KPT>, lds_once, 136 * 1024);   /* + ~14 KB of static LDS */         \
+            hipLaunchKernelGGL(topk_hsort_kernel<KPT>, dim3((unsigned)B), dim3(kHsThreads), dyn, stream, a);        \
+        }                                                                                                           \
     } while (0)
         if (chunk <= 3) SDETR_HS(3);
         else if (chunk <= 5) SDETR_HS(5);

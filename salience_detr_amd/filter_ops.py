@@ -12,7 +12,7 @@ from . import _hip
 
 def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_with_global_min: bool = False,
                      payload: Optional[Tensor] = None, index_offset: int = 0, want_scores: bool = True,
-                     fill_value: Optional[Tensor] = None, out=None):
+                     fill_value: Optional[Tensor] = None, out=None, orders_job: Optional["RowOrdersJob"] = None):
     """Sorted-descending top-k per row with ties -> lower index first.
 
     ``score`` [B,N] fp32.  With ``mask`` (bool [B,N], True = masked) and ``fill_with_global_min`` the
@@ -59,12 +59,17 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
     lib = _hip.lib()
     ws_bytes = lib.sdetr_topk_workspace_bytes(B, N, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=score.device) if ws_bytes else None
-    with torch.cuda.device(score.device):
-        code = lib.sdetr_masked_topk_desc_f32(
-            _hip.stream_ptr(), score.data_ptr(), _hip.ptr(mask), mask_stride,
+    args = (_hip.stream_ptr(), score.data_ptr(), _hip.ptr(mask), mask_stride,
             (2 if fill_value is not None else 1) if fill_with_global_min else 0, _hip.ptr(fill_value),
             _hip.ptr(payload), B, N, k, int(index_offset), _hip.ptr(out_score), out_index.data_ptr(), out_stride,
             _hip.ptr(ws), ws_bytes)
+    with torch.cuda.device(score.device):
+        if orders_job is not None and not orders_job.done and orders_job.device == score.device:
+            # the encoder's row orders ride in this launch (or run right behind it when it is not the one-launch sort)
+            code = lib.sdetr_masked_topk_desc_with_orders_f32(*args, ctypes.byref(orders_job.struct))
+            orders_job.done = True
+        else:
+            code = lib.sdetr_masked_topk_desc_f32(*args)
     _hip.check(code, "masked_topk_desc")
     return out_score, out_index
 
@@ -910,12 +915,38 @@ def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optio
     return out if group_features else out.view(tuple(shape[:-1]) + (N,))
 
 
-def layer_row_orders(sorted_index: Tensor, counts, level_shapes, tile: int = 16):
+class RowOrdersJob:
+    """``layer_row_orders`` not launched yet: ``masked_topk_desc(..., orders_job=job)`` lets the layer-0 selection's launch
+    carry it, ``job.run()`` launches it on its own.  ``job.orders``: the per-layer ``[B,c_k]`` int32 views it fills."""
+
+    def __init__(self, sorted_index, tile_pos, counts_dev, counts, S, order):
+        B, n0 = sorted_index.shape
+        self.device = sorted_index.device
+        self._keep = (sorted_index, tile_pos, counts_dev, order)
+        self.struct = _hip.RowOrdersJobStruct(sorted_index.data_ptr(), sorted_index.stride(0), tile_pos.data_ptr(), B, S, n0,
+                                              len(counts), counts_dev.data_ptr(), order.data_ptr(), n0)
+        self.orders = [order[k, :, :c] for k, c in enumerate(counts)]
+        self.done = False
+
+    def run(self):
+        if self.done:
+            return
+        j = self.struct
+        with torch.cuda.device(self.device):
+            code = _hip.lib().sdetr_layer_row_orders(_hip.stream_ptr(), j.sorted_index, j.index_batch_stride, j.tile_pos,
+                                                     j.batch, j.spatial_size, j.num_rows, j.num_layers, j.counts, j.order,
+                                                     j.order_batch_stride)
+        _hip.check(code, "layer_row_orders")
+        self.done = True
+
+
+def layer_row_orders(sorted_index: Tensor, counts, level_shapes, tile: int = 16, as_job: bool = False):
     """Per-layer row orders for the bordered MSDA kernel (include/salience_hip.h ``sdetr_layer_row_orders``):
     ``sorted_index`` int64 ``[B,n0]`` (the token of every row of the sorted list), ``counts`` the layers' row counts
     (non-increasing, ``counts[0] <= n0``) -> list of int32 ``[B,c_k]`` views (rows ``n0`` apart), each a permutation of
     ``0..c_k-1`` that walks the layer's rows tile by tile of the finest level.  ``None`` when the pyramid is too large for
-    the one-workgroup kernel (the caller then runs the rows in list order)."""
+    the one-workgroup kernel (the caller then runs the rows in list order).  ``as_job``: return the pending
+    ``RowOrdersJob`` instead of launching it."""
     from .ms_deform_attn import tile_major_positions
     _hip.require_device("layer_row_orders", sorted_index=sorted_index)
     B, n0 = sorted_index.shape
@@ -931,12 +962,11 @@ def layer_row_orders(sorted_index: Tensor, counts, level_shapes, tile: int = 16)
     from . import pyramid
     tile_pos, counts_dev = pyramid.static_tensor(key, build)
     order = torch.empty((len(counts), B, n0), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        code = _hip.lib().sdetr_layer_row_orders(_hip.stream_ptr(), sorted_index.data_ptr(), sorted_index.stride(0),
-                                                 tile_pos.data_ptr(), B, S, n0, len(counts), counts_dev.data_ptr(),
-                                                 order.data_ptr(), n0)
-    _hip.check(code, "layer_row_orders")
-    return [order[k, :, :c] for k, c in enumerate(counts)]
+    job = RowOrdersJob(sorted_index, tile_pos, counts_dev, counts, S, order)
+    if as_job:
+        return job            # (``as_job``: the pending job; None above still means "no orders for this pyramid")
+    job.run()
+    return job.orders
 
 
 def value_proj_head_major(value: Tensor, weight: Tensor, bias: Optional[Tensor], padding_mask: Optional[Tensor],

@@ -18,6 +18,7 @@ forward/backward op (``MultiScaleDeformableAttnFunction``).
 """
 import copy
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -182,7 +183,7 @@ class SalienceTransformerEncoderLayer(nn.Module):
 
     def forward_sorted(self, query, pos_sorted, ref_sorted, fg_sorted, value_hm, spatial_shapes, level_start_index,
                        class_head, level_shapes=None, selection_hook=None, advance=None, mc_score=None,
-                       want_next_score=False, row_order=None):
+                       want_next_score=False, row_order=None, orders_job=None):
         """No-grad layer body for index sets that are prefixes of one sorted list (the encoder keeps the tokens
         in sorted order, see ``SalienceTransformerEncoder.forward``).  ``query`` [B,c,E] is this layer's own copy
         (updated in place); ``pos_sorted`` [B,n0,E], ``ref_sorted`` [B,n0,L,2], ``fg_sorted`` [B,n0] are the
@@ -198,7 +199,10 @@ class SalienceTransformerEncoderLayer(nn.Module):
             mc_score = class_head_max_times(query, class_head, fg_sorted[:, :c])   # logits never materialised
         else:
             mc_score = class_max_times(class_head(query), fg_sorted[:, :c])
-        sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False)[1]
+        # (``orders_job``: the encoder's pending row orders ride in this selection's launch -- layer 0)
+        sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False, orders_job=orders_job)[1]
+        if orders_job is not None:
+            orders_job.run()             # (no-op when the launch carried it)
         if selection_hook is not None:   # instrumentation: record the layer's top-k set, or force a given one
             sel = selection_hook(sel)
         N = sel.shape[1]
@@ -442,8 +446,8 @@ class SalienceTransformerEncoder(nn.Module):
 
     # the value maps take the bordered layout (zero records around every level) and the deformable attention walks
     # its rows in a per-layer spatial order (csrc/msda_resident.hip, msda_bordered_kernel); False = round 3's plain maps
-    bordered_value_maps = True
-    row_order_tile = 16
+    bordered_value_maps = os.environ.get("SDETR_BORDERED_MAPS", "1") != "0"          # (environment: A/B runs of bench.py)
+    row_order_tile = int(os.environ.get("SDETR_ROW_ORDER_TILE", "16"))
 
     def project_values(self, value: Tensor, padding_mask: Optional[Tensor], level_shapes=None) -> Tensor:
         """Head-major value maps of ALL layers ``[num_layers,B,heads,Nv,D]`` (no-grad path).  The six layers sample
@@ -524,10 +528,12 @@ class SalienceTransformerEncoder(nn.Module):
             result = torch.empty_like(q)
             score = None
             # per-layer row orders for the deformable attention (tile-major walk of each layer's rows)
-            orders = None
+            orders, orders_job = None, None
             from .ms_deform_attn import is_bordered
             if value_hm_all is not None and is_bordered(value_hm_all[0], level_shapes) and self.row_order_tile:
-                orders = layer_row_orders(sorted_index, counts, level_shapes, tile=self.row_order_tile)
+                # pending: the first layer's top-300 selection (2 workgroups on an empty chip) carries the job
+                orders_job = layer_row_orders(sorted_index, counts, level_shapes, tile=self.row_order_tile, as_job=True)
+                orders = None if orders_job is None else orders_job.orders
             for layer_id, layer in enumerate(self.layers):
                 if self.max_layers is not None and layer_id >= self.max_layers:
                     break
@@ -543,7 +549,8 @@ class SalienceTransformerEncoder(nn.Module):
                                                 level_start_index, self.enhance_mcsp, level_shapes=level_shapes,
                                                 selection_hook=hook, advance=(result, nxt, value, sorted_index, focus64),
                                                 mc_score=score, want_next_score=True,
-                                                row_order=None if orders is None else orders[layer_id])
+                                                row_order=None if orders is None else orders[layer_id],
+                                                orders_job=orders_job if layer_id == 0 else None)
             if self.layer_marker is not None:
                 self.layer_marker(self.num_layers)
             if multi_level_masks is not None:
