@@ -123,6 +123,9 @@ class OverlappedGradReducer(FlatGradAllReducer):
     parameter that is already packed): ``finish()`` then waits for whatever was launched and falls back to the
     pack-at-the-end reduction of the base class over the accumulated ``p.grad`` -- correct, just not overlapped.
 
+    Construction is a COLLECTIVE with ``own_group=True`` (``dist.new_group()``: every rank of the default group must build
+    its reducer at the same point; pass ``group=`` / ``own_group=False`` for a reducer on a subset of ranks).
+
     Collective order.  By default the reducer owns a process group of its own (``own_group=True``): other collectives
     issued during backward on the default group -- the neck's SyncBatchNorm statistics, ``_SyncBatchNormTrain.backward``
     -- interleave with the bucket all-reduces differently on ranks that did not use a parameter (they launch that bucket
@@ -198,12 +201,17 @@ class OverlappedGradReducer(FlatGradAllReducer):
     def finish(self, average: bool = True) -> None:
         """After ``backward()``: reduce what is left, wait, average, unpack into ``p.grad``; ready for the next step."""
         world = dist.get_world_size(self.group)
-        if self._repack:
-            # more than one backward reached the hooks.  Ranks may have launched different numbers of buckets by now
-            # (a rank that did not use a parameter launches its bucket late): launch the rest so that every rank has
-            # issued every bucket exactly once, drain them (results discarded), then reduce the accumulated p.grad the
-            # non-overlapped way
-            self._launch_ready(force=True)
+        # Whether ANY rank saw a second hooked backward decides the path for ALL ranks: the fallback issues one more
+        # collective than the normal path, so a per-rank decision (data-dependent unused parameters in the second
+        # backward) would leave the ranks with different collective sequences (ADVICE r3).  One 1-element all-reduce per
+        # step, issued BEHIND the last bucket (ranks have launched different numbers of buckets when they get here: only
+        # after the forced launches is the sequence the same everywhere).
+        self._launch_ready(force=True)   # every rank has now issued every bucket exactly once
+        flag = self.flat[0].new_tensor([1.0 if self._repack else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if float(flag.item()) > 0.0:
+            # more than one backward reached the hooks somewhere: drain the buckets (results discarded), then reduce the
+            # accumulated p.grad the non-overlapped way
             for w in self._works:
                 w.wait()
             self._reset()
@@ -270,10 +278,22 @@ class StaticGradAllReducer:
         return self.flat.numel() * self.flat.element_size()
 
     def pack(self) -> None:
-        """Last call of the captured region (after ``backward()``): gradients -> flat buffer."""
-        self.flat.zero_()
-        dst = [v for v, p in zip(self.views, self.params) if p.grad is not None and p.grad is not v]
-        src = [p.grad for v, p in zip(self.views, self.params) if p.grad is not None and p.grad is not v]
+        """Last call of the captured region (after ``backward()``): gradients -> flat buffer.
+
+        Per parameter: no gradient -> its slice is zeroed; a gradient in its own storage -> copied in; ``p.grad`` IS the
+        slice (what ``all_reduce`` leaves behind, and what a following backward under ``zero_grad(set_to_none=False)`` or
+        gradient accumulation adds into) -> left alone: the freshly accumulated values are already in place.  (Until round
+        4 the whole buffer was zeroed first, which wiped exactly those)"""
+        zero, dst, src = [], [], []
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                zero.append(v)
+            elif p.grad is not v and not (p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape
+                                          and p.grad.stride() == v.stride()):
+                dst.append(v)
+                src.append(p.grad)
+        if zero:
+            torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
 

@@ -558,8 +558,14 @@ class _ZeroRowsInPlace(Function):
     @once_differentiable
     def backward(ctx, grad):
         (mask,) = ctx.saved_tensors
-        g = grad if grad.is_contiguous() else grad.contiguous()
-        return g.masked_fill_(mask.view(mask.shape + (1,) * (g.dim() - mask.dim())), 0.0), None
+        m = mask.reshape(mask.shape + (1,) * (grad.dim() - mask.dim()))   # (reshape: the mask may be a slice / transpose)
+        # In place only for the one producer this Function is used behind: the value operand of
+        # MultiScaleDeformableAttnFunction, whose backward hands over a grad_value it has just allocated (a [B,Nv,M,D]
+        # view of it arrives here: nobody else holds it).  Anything else -- a non-contiguous gradient, a tensor some hook
+        # retained (its version counter or base say so) -- is masked out of place, as autograd requires.
+        fresh = grad.is_contiguous() and not grad.requires_grad and grad._version <= 1 and (
+            grad._base is None or grad._base._version <= 1)
+        return (grad.masked_fill_(m, 0.0) if fresh else grad.masked_fill(m, 0.0)), None
 
 
 class _SamplingPrep(Function):
@@ -568,9 +574,17 @@ class _SamplingPrep(Function):
 
     @staticmethod
     def applies(offsets: Tensor, logits: Tensor, reference_points: Tensor, L: int, P: int) -> bool:
-        return (offsets.is_cuda and offsets.dtype == torch.float32 and logits.dtype == torch.float32
+        # dense operands of exactly the shapes the kernel indexes (a broadcastable [B,Nq,1,2] reference, host tensors or
+        # mismatched logits take the torch formula instead -- ADVICE r3)
+        if not (offsets.is_cuda and logits.is_cuda and reference_points.is_cuda and offsets.dim() == 6 and offsets.numel() > 0):
+            return False
+        B, Nq, M = offsets.shape[:3]
+        return (offsets.dtype == torch.float32 and logits.dtype == torch.float32
                 and reference_points.dtype == torch.float32 and not reference_points.requires_grad
-                and offsets.numel() > 0 and bool(_hip.lib().sdetr_sampling_prep_supported(L, P)))
+                and tuple(offsets.shape) == (B, Nq, M, L, P, 2) and logits.numel() == B * Nq * M * L * P
+                and reference_points.dim() == 4 and tuple(reference_points.shape[:3]) == (B, Nq, L)
+                and reference_points.shape[3] in (2, 4)
+                and bool(_hip.lib().sdetr_sampling_prep_supported(L, P)))
 
     @staticmethod
     def forward(ctx, offsets, logits, reference_points, spatial_shapes, L, P):

@@ -421,8 +421,10 @@ class SalienceTransformerEncoder(nn.Module):
             if self.layer_marker is not None:
                 self.layer_marker(layer_id)
             c = counts[layer_id]
+            with torch.no_grad():   # (the selection score is only used detached: no graph for the class head here)
+                score_tgt = self.enhance_mcsp(q.detach())
             out = layer(q, pos_s[:, :c], value, ref_s[:, :c], spatial_shapes, level_start_index, padding_mask,
-                        self.enhance_mcsp(q), fg_s[:, :c])
+                        score_tgt, fg_s[:, :c])
             out = torch.where(live[:, :c, None], out, q)
             nxt = counts[layer_id + 1] if layer_id + 1 < self.num_layers else 0
             if nxt == 0:

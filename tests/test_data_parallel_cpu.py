@@ -345,3 +345,43 @@ def test_static_grad_all_reducer_two_ranks(tmp_path):
     red.all_reduce()
     for n, p in m.named_parameters():
         assert torch.equal(p.grad, want[n]), n
+
+
+def test_static_grad_all_reducer_accumulates_in_place():
+    """after the first ``all_reduce`` every ``p.grad`` IS its slice of the flat buffer; a following backward
+    under ``zero_grad(set_to_none=False)`` (or gradient accumulation over micro-steps) adds into that slice in place, and
+    ``pack()`` must keep what it finds there instead of zeroing the buffer."""
+    from salience_detr_amd.data_parallel import StaticGradAllReducer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    unused = torch.nn.Parameter(torch.ones(4))                 # never receives a gradient: its slice must stay zero
+    params = list(m.parameters()) + [unused]
+    red = StaticGradAllReducer(params)
+    xs = [torch.randn(7, 6) for _ in range(3)]
+    m(xs[0]).square().sum().backward()
+    red.pack()
+    red.all_reduce()
+    first = [p.grad.clone() for p in m.parameters()]
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red.params, red.views))
+    # (1) zero_grad(set_to_none=False): the views are zeroed in place, the next backward fills them
+    for p in params:
+        if p.grad is not None:
+            p.grad.zero_()
+    m(xs[1]).square().sum().backward()
+    want = [g.clone() for g in (p.grad for p in m.parameters())]
+    red.pack()
+    red.all_reduce()
+    for p, w in zip(m.parameters(), want):
+        assert torch.equal(p.grad, w) and p.grad.abs().sum() > 0
+    assert torch.equal(unused.grad, torch.zeros(4))
+    # (2) accumulation over two micro-steps without zeroing
+    m(xs[2]).square().sum().backward()
+    red.pack()
+    red.all_reduce()
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref.load_state_dict(m.state_dict())
+    ref(xs[1]).square().sum().backward()
+    ref(xs[2]).square().sum().backward()
+    for p, q in zip(m.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-6)
+    assert first[0].abs().sum() > 0

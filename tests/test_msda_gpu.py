@@ -64,6 +64,7 @@ LEVELS_FULL = [(100, 168), (50, 84), (25, 42), (13, 21)]
     (3, 50, LEVELS_SMALL[:2], 2, 64, 5),   # L*P = 10
     (1, 40, LEVELS_SMALL, 2, 8, 9),        # L*P = 36 > one LDS chunk
     (2, 2272, LEVELS_FULL, 8, 32, 4),      # encoder layer 5 at the benchmark shape
+    (2, 11363, LEVELS_FULL, 8, 32, 4),     # encoder layer 0 at the benchmark shape: the largest call of the step
 ])
 def test_forward_backward_vs_c_oracle(B, Nq, levels, M_, D, P):
     value, shapes, lsi, loc, aw = syn.make_msda_inputs(B, Nq, levels, M_, D, P, seed=1, spread_px=6.0)
