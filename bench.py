@@ -54,6 +54,9 @@ def parse():
                          "gradient pack, eager flat all-reduce + optimizer) -- how that path is exercised on a 1-GPU box")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="the default line's `train_step` sub-record: this many timed training steps (0: skip)")
+    ap.add_argument("--config-steps", type=int, default=10,
+                    help="the default line's `configs` sub-records (fp32 path, BASELINE configs[3] and configs[4] at N = 1): "
+                         "timed steps each (0: skip)")
     ap.add_argument("--in-flight", dest="in_flight", type=int, default=1,
                     help="--plain only, informational: this many independent batches (own inputs, own graph, own "
                          "stream) replayed side by side; the official line is 1")
@@ -388,6 +391,136 @@ def time_replays(g, n):
     return e0.elapsed_time(e1) / n
 
 
+STRESS_LEVELS = [(200, 336), (100, 168), (50, 84), (25, 42)]   # the reference's 5scale pyramid (strides 4-32)
+
+
+def _graph_ms(step, steps, warmup=3):
+    """ms per call of `step` under hipGraph replay (eager launches if the capture fails)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    try:
+        g, _ = capture(step, {})
+        time_replays(g, 3)
+        return time_replays(g, steps), True
+    except Exception:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps, False
+
+
+def config_records(args, device, steps=10):
+    """Sub-records of the default line for the other BASELINE.json configurations / arithmetic modes on ONE GPU
+    (VERDICT r3 item 3): each its own model instance and inputs, `steps` timed steps under hipGraph replay.
+
+    * ``fp32``     the parity-bar path: fp32 inference of the hot path, batch 2, 800x1333 -- with the 1e-3 check against
+                   the reference's fp32 fixture (tests/golden/hotpath_full_digest.npz, single-image case) inline;
+    * ``config4``  BASELINE configs[3] at N = 1: bf16, batch 1 per GPU on the large 4-level pyramid of the reference's
+                   5scale configuration (salience_detr_resnet50_5scale_800_1333.py:33-36: 89 250 tokens, 45 330 queries);
+    * ``config5``  BASELINE configs[4] at N = 1: the whole SalienceTransformer (neck, encoder, two-stage proposals + NMS,
+                   6 decoder layers at 900 queries; salience_transformer.py:97-226,552-674) on 800x1333 + 800x1066,
+                   requested as "fp16" (what ``resolve_activation_dtype`` serves that request with is in the record)."""
+    import numpy as np
+    from salience_detr_amd.hot_path import resolve_activation_dtype
+    out = {}
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:   # a sub-record must not take the line down
+            out[name] = {"error": str(e).split("\n")[0][:200]}
+        torch.cuda.empty_cache()
+
+    def fp32():
+        m = build_hot_path()
+        m.load_state_dict(syn.det_state_dict(m.state_dict()))
+        m = m.to(device).eval()
+        sizes, canvas, level_shapes, _, (feats, masks, pos) = make_inputs(args.batch, args.height, args.width, device, seed=0)
+
+        def step():
+            with torch.no_grad():
+                return m(feats, masks, pos, image_sizes=sizes, canvas=canvas)[0]
+        ms, graphed = _graph_ms(step, steps)
+        rec = {"workload": "salience_detr_resnet50_800_1333 fp32 inference, batch=%d: the path that carries the 1e-3 parity "
+                           "claim" % args.batch, "dtype": "fp32", "ms_per_step": round(ms, 4),
+               "images_per_s": round(args.batch * 1e3 / ms, 1), "steps": steps, "hipgraph": graphed}
+        fixture = os.path.join(ROOT, "tests", "golden", "hotpath_full_digest.npz")
+        if os.path.exists(fixture) and (args.height, args.width) == (800, 1333):
+            d = np.load(fixture)
+            s1, c1, _, _, (f1, m1, p1) = make_inputs(1, 800, 1333, device, seed=0)
+            with torch.no_grad():
+                mem = m(f1, m1, p1, image_sizes=s1, canvas=c1)[0]
+            err = float((mem.float().cpu()[:, ::41, ::3] - torch.from_numpy(d["single.memory_sub"])).abs().max())
+            rec["parity"] = {"max_abs_err_vs_reference_fp32": round(err, 6), "bar": 1e-3, "ok": err < 1e-3,
+                             "against": "tests/golden/hotpath_full_digest.npz single.memory_sub (the imported reference's fp32 "
+                                        "run of one 800x1333 image, every 41st token x every 3rd channel)"}
+        return rec
+
+    def config4():
+        m = build_hot_path(max_num_embedding=500)
+        m.load_state_dict(syn.det_state_dict(m.state_dict()))
+        m = m.to(device).eval()
+        m.set_encoder_dtype(torch.bfloat16, torch.float16)
+        sizes = [(800, 1333)]
+        _, masks = syn.make_masks(sizes, STRESS_LEVELS)
+        feats = [f.to(device) for f in syn.make_feats(1, STRESS_LEVELS, 256, seed=0)]
+        pos = [syn.sine_position_embedding(x, 128).to(device) for x in masks]
+        masks = [x.to(device) for x in masks]
+        canvas = syn.pad_to_32(800, 1333)
+        holder = {}
+
+        def step():
+            with torch.no_grad():
+                r = m(feats, masks, pos, image_sizes=sizes, canvas=canvas, return_aux=("nq" not in holder))
+            if "nq" not in holder:
+                holder["nq"] = [int(t.shape[1]) for t in r[2]["foreground_inds"]]
+            return r[0]
+        step()
+        ms, graphed = _graph_ms(step, steps)
+        return {"workload": "BASELINE configs[3] at N=1: bf16 inference, batch=1 per GPU, large 4-level pyramid "
+                            "(200x336 .. 25x42, 89 250 tokens: the reference's 5scale configuration)",
+                "dtype": "bf16", "value_map_storage": "fp16", "ms_per_step": round(ms, 4),
+                "images_per_s": round(1e3 / ms, 1), "steps": steps, "hipgraph": graphed,
+                "levels": [list(x) for x in STRESS_LEVELS], "num_queries_per_layer": holder.get("nq")}
+
+    def config5():
+        from salience_detr_amd.salience_transformer import build_salience_transformer
+        sizes = [(800, 1333), (800, 1066)]
+        tr = build_salience_transformer(with_neck=True)
+        tr.load_state_dict(syn.det_state_dict(tr.state_dict()))
+        tr = tr.eval().to(device)
+        act, vdt = resolve_activation_dtype(torch.float16)
+        tr.set_dtype(torch.float16, None)
+        tr.static_proposals = True
+        img_mask, masks = syn.make_masks(sizes)
+        canvas = tuple(img_mask.shape[-2:])
+        shapes = [tuple(x.shape[-2:]) for x in masks]
+        feats = [f.to(device) for f in syn.make_feats(2, shapes, 256, 0)]
+        pos = [syn.sine_position_embedding(x, 128).to(device) for x in masks]
+        masks = [x.to(device) for x in masks]
+
+        def step():
+            with torch.no_grad():
+                return tr(feats, masks, pos, image_sizes=sizes, canvas=canvas)
+        ms, graphed = _graph_ms(step, steps)
+        return {"workload": "BASELINE configs[4] at N=1: whole SalienceTransformer (RepVGGPluX neck, encoder, two-stage "
+                            "proposals + NMS, 6 decoder layers, 900 queries), batch=2 (800x1333 + 800x1066)",
+                "requested_dtype": "fp16", "served_as": {"activations": str(act).replace("torch.", ""),
+                                                         "value_maps": str(vdt).replace("torch.", "")},
+                "ms_per_step": round(ms, 4), "images_per_s": round(2e3 / ms, 1), "steps": steps, "hipgraph": graphed,
+                "queries": 900}
+
+    guarded("fp32", fp32)
+    guarded("config4", config4)
+    guarded("config5", config5)
+    return out
+
+
 def cpu_baseline(args, model, cpu_inputs_of, out, sel_log, gpu_inds=None):
     """The oracle's CPU port of the same path, timed on the host cores: per stage (F0-F3 filtering,
     each encoder layer, the MSDA core alone).  Default: bounded to ~15-30 s (batch 2; 8 threads 1 warm-up + 3 passes,
@@ -476,6 +609,22 @@ def cpu_baseline(args, model, cpu_inputs_of, out, sel_log, gpu_inds=None):
                   "non_flipped_tokens": {"max_abs": round(float(clean.max()), 5), "mean_abs": round(float(clean.mean()), 6),
                                          "p999_abs": round(float(clean.flatten().kthvalue(max(1, int(clean.numel() * 0.999)))[0]), 5)},
                   "note": "GPU %s output vs fp32 CPU oracle on the same batch" % args.dtype}
+        # the reference's OWN bf16 mode against its fp32 run, from the committed fixture (tests/golden/
+        # hotpath_autocast_digest.npz: torch.autocast("cpu", bfloat16) around the imported reference's encoder, 800x1333 +
+        # 800x1066); tests/test_encoder_timed_mode_gpu.py holds the build's timed mode to it on the same inputs
+        try:
+            import numpy as np
+            ac = np.load(os.path.join(ROOT, "tests", "golden", "hotpath_autocast_digest.npz"))
+            e = ac["mixed.encoder.memory_err_non_flipped"]
+            parity["reference_bf16_autocast_vs_its_fp32"] = {
+                "inputs": "800x1333 + 800x1066 (fixture batch)", "top300_symmetric_difference_per_layer":
+                    [int(v) for v in ac["mixed.encoder.flips_per_layer"]],
+                "non_flipped_elements": {"mean_abs": round(float(e[0]), 6), "p999_abs": round(float(e[1]), 5),
+                                         "max_abs": round(float(e[2]), 5)},
+                "note": "elementwise statistics (the build's `non_flipped_tokens` above are per-token maxima over 256 "
+                        "channels: compare through the test, which computes both sides the same way)"}
+        except (OSError, KeyError, ValueError):
+            pass
     return result, parity
 
 
@@ -741,17 +890,28 @@ def main():
     traffic, traffic_src = None, None
     tag = kernel_source_tag()
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_msda_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_msda_traffic.json")))
         nqs = launch_nq[:nl]
         if (tj.get("kernel_source_tag") == tag and args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same")
                 and args.batch == tj["batch"] and all(str(n) in tj["per_num_query"] for n in nqs)):
             traffic = int(sum(tj["per_num_query"][str(n)]["hbm_bytes"] for n in nqs) / nl)
-            traffic_src = "profiles/r03_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tag
+            traffic_src = "profiles/r04_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tag
         else:
             traffic_src = "null: committed PMC passes were measured on other kernel sources (%s) than these (%s)" % (
                 tj.get("kernel_source_tag"), tag)
     except (OSError, ValueError, KeyError):
         traffic_src = "null: no PMC passes committed for this round"
+    # the same launches by rocprofv3 (kernel-trace average over the timed loop of `bench.py --plain`, committed by
+    # benchmarks/profile_round.sh with the kernel sources' tag): the steadier of the two in-step figures (the cut-graph
+    # medians scatter around it by a few percent), reported next to them; null when the sources have changed since
+    rocprof_us, rocprof_src = None, "null: no rocprofv3 summary committed for these kernel sources"
+    try:
+        rj = json.load(open(os.path.join(ROOT, "profiles", "r04_msda_rocprof.json")))
+        if rj.get("kernel_source_tag") == tag and rj.get("batch") == args.batch:
+            rocprof_us = rj["avg_launch_us"]
+            rocprof_src = "profiles/r04_msda_rocprof.json (%s)" % rj.get("source", "rocprofv3 --kernel-trace --stats")
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {
         "kernel": "sdetr::" + " / ".join(sorted(set(kernels_used[:nl])))
                   + " (fused softmax + sampling locations + bilinear gather)",
@@ -765,6 +925,9 @@ def main():
                            for b, u in zip(bytes_per_layer, in_step_us if have_in_step else msda_us[:nl])],
         "per_layer_algorithmic_MB": [round(b / 1e6, 2) for b in bytes_per_layer],
         "timing": in_step_note if have_in_step else "warm replay only (see frac_warm)",
+        "timing_rocprof_us": rocprof_us,
+        "frac_rocprof": (round(total_bytes / nl / rocprof_us / 1e3 / HBM_PEAK_GBPS, 4) if rocprof_us else None),
+        "timing_rocprof_source": rocprof_src,
         "frac_warm": round(achieved_warm / HBM_PEAK_GBPS, 4), "achieved_warm": round(achieved_warm, 1),
         "avg_launch_us_warm": round(warm_total_us / nl, 2), "per_layer_us_warm": [round(u, 2) for u in msda_us[:nl]],
         "timing_warm": "per launch: %d back-to-back repetitions of the step's own launch captured in a hipGraph, replayed "
@@ -831,6 +994,10 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:
             result["train_step"] = {"error": str(e).split("\n")[0][:200]}
+
+    # ---- the other configurations / arithmetic modes at N = 1 (sub-records; `--config-steps 0` skips them) ----
+    if args.config_steps > 0 and args.dtype == "bf16":
+        result["configs"] = config_records(args, device, steps=args.config_steps)
 
     # ---- CPU baseline: the oracle's port of the same path on the host cores (rank 0, N=1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
