@@ -98,6 +98,23 @@ def algorithmic_bytes(B, Nv, Nq, M, D, L, P, value_bytes, proj_bytes, out_bytes,
                 + Nq * M * D * out_bytes)
 
 
+class _ReplaySafeMean(torch.autograd.Function):
+    """``x.mean()`` of a fp32 ``[B,n,C]`` device tensor through the hot path's own column-mean kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from salience_detr_amd.filter_ops import column_mean
+        ctx.shape = x.shape
+        return column_mean(x.contiguous()).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for d in ctx.shape:
+            n *= d
+        return (g / n).expand(ctx.shape)
+
+
 def train_record(args, model, device, rank, world, dist, steps, warmup, force_dist_path=False):
     """configs[2]: one training step of the hot-path modules per batch of 2 images per GPU -- fp32 forward
     through the autograd path (HIP MSDA forward/backward op), the salience criterion (row N4: targets + focal loss
@@ -116,6 +133,9 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     if args.x3_linear:
         from salience_detr_amd.linear_x3 import use_x3_linear_
         use_x3_linear_(model)   # weight gradients of the Linear layers on the bf16 matrix cores at fp32 accuracy
+        if os.environ.get("SDETR_X3_ALL"):   # A/B: every forward / input-gradient product on the x3 kernel too
+            from salience_detr_amd import linear_x3
+            linear_x3.X3_WIDE_FEATURES, linear_x3.X3_WIDE_OUT_ROWS, linear_x3.X3_LONG_REDUCTION_ROWS = 1, 1, 1
     if dist is not None:
         broadcast_parameters(model)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -143,16 +163,24 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
         nonlocal w
         opt.zero_grad(set_to_none=True)
         memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
-        if w is None:
-            w = torch.randn_like(memory)
-        loss = (memory * w).mean() + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
+        if w is None:   # fixed weights of the synthetic loss on `memory` (name-seeded: the same on every run and rank)
+            w = syn.det_randn("bench.train.memory_weights", tuple(memory.shape)).to(memory.device)
+        # (the mean over `memory` as per-image column means + a 512-element mean: the framework's one-kernel reduction of
+        # 11 M elements clears its semaphores with a hipMemsetAsync that a replayed hipGraph does not reproduce here)
+        loss = _ReplaySafeMean.apply(memory * w) + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
         loss.backward()
         if reducer is not None:
             reducer.pack()
-        return loss
+        # (detached: a loss that keeps its autograd graph alive across iterations keeps the AccumulateGrad nodes of the
+        # first iteration -- created on the default stream -- alive too, and the capture then records the gradient
+        # accumulation on another stream than the kernels that produce the gradients)
+        return loss.detach()
 
     def finish():   # what follows the captured region when there are ranks
         reducer.all_reduce(average=True)
+        opt.step()
+
+    def finish_single():   # one process: the fused AdamW step, eager, behind the replayed forward + backward
         opt.step()
 
     def step():
@@ -160,8 +188,21 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
         if reducer is not None:
             finish()
         else:
-            opt.step()
+            finish_single()
         return loss
+
+    # the timed steps start from the INITIAL parameters and optimizer state whatever the warm-up and the capture did
+    # (the single-process capture runs the optimizer, the N > 1 capture does not): the loss after K steps is then the same
+    # number on every execution path -- tests/test_rccl_path_gpu.py compares them
+    initial = [p.detach().clone() for p in params]
+
+    def reset_training_state():
+        with torch.no_grad():
+            torch._foreach_copy_(params, initial)
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
 
     for _ in range(max(warmup, 2)):
         step()
@@ -178,13 +219,19 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     capture_kw = {"capture_error_mode": "thread_local"} if dist is not None else {}
     if not args.no_graph:
         try:
-            graph, loss_static = capture(step if reducer is None else forward_backward, capture_kw)
+            # The optimizer step stays OUTSIDE the captured region at every world size (round 4).  Captured together with
+            # forward + backward (rounds 2-3, single process) the fused AdamW kernels did not reproduce the eager update on
+            # this stack: same first-step gradients, a different second-step loss (4.58 against 4.39; 5.22 with the library's
+            # Linear products) -- the loss trace of SDETR_BENCH_LOSS_TRACE=1 shows it.  Replayed forward + backward followed
+            # by the eager fused step reproduces the eager trajectory to the last digit (tests/test_rccl_path_gpu.py).
+            graph, loss_static = capture(forward_backward, capture_kw)
             if reducer is not None:
                 finish()      # (capture() replays once: complete that step)
                 graph_note = ("hipGraph replay of forward + backward + gradient pack, then one eager all-reduce of the "
                               "flat gradient buffer and the fused AdamW step")
             else:
-                graph_note = "hipGraph replay of the whole step"
+                finish_single()
+                graph_note = "hipGraph replay of forward + backward, then the eager fused AdamW step"
         except Exception as e:   # a host synchronisation inside the autograd path: report it, time the eager step
             graph = None
             graph_note = "eager (capture failed: %s)" % str(e).split("\n")[0][:120]
@@ -200,19 +247,51 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
             graph.replay()
             if reducer is not None:
                 finish()
+            else:
+                finish_single()
             return loss_static
         return step()
 
+    for _ in range(2):   # (two more steps in their final form before the state is reset and the clock starts)
+        timed_step()
+    reset_training_state()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = timed_step()
     fence()
     elapsed = time.perf_counter() - t0
+    final_loss = float(loss.detach())
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    loss_trace = None
+    if os.environ.get("SDETR_BENCH_LOSS_TRACE"):
+        # debugging / tests: the loss of every one of 4 steps from the initial state (host read-back per step)
+        reset_training_state()
+        loss_trace = []
+        for i in range(4):
+            loss_trace.append(float(timed_step().detach()))
+            if i == 0:   # gradients behind the first update: how many parameter tensors have one, their L1 norms
+                torch.cuda.synchronize()
+                gs = [p.grad for p in params]
+                norms = [0.0 if g_ is None else float(g_.abs().sum()) for g_ in gs]
+                if os.environ.get("SDETR_BENCH_GRAD_DUMP"):
+                    names = [n for n, p in model.named_parameters() if p.requires_grad]
+                    json.dump(dict(zip(names, norms)), open(os.environ["SDETR_BENCH_GRAD_DUMP"], "w"), indent=0)
+                loss_trace.append({"no_grad": sum(g_ is None for g_ in gs), "zero_grad": sum(n == 0.0 for n in norms),
+                                   "l1_total": sum(norms), "l1_first10": [round(n, 4) for n in norms[:10]],
+                                   "param_l1": float(sum(p.detach().abs().sum() for p in params))})
+    if loss_trace is not None and graph is not None:
+        # the same parameters through the replayed graph and through an eager forward: must give the same loss
+        snap = [p.detach().clone() for p in params]
+        replay_loss = float(timed_step().detach())
+        with torch.no_grad():
+            torch._foreach_copy_(params, snap)
+        eager_loss = float(forward_backward().detach())
+        rec = {"same_parameters": {"replayed": replay_loss, "eager": eager_loss}}
+        loss_trace.append(rec)
     # dominant kernel of the training step: the MSDA backward op (grad_value scatter + grad_loc / grad_aw gather;
     # LDS-accumulating kernel from 1200 queries up, direct global-atomic kernel below); timed with stream events
     # around the op (bucketing launches and the zero fill of grad_value included)
@@ -250,13 +329,15 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
                    "parallelism": "data parallel, one all-reduce of the flat gradient buffer over RCCL after the replayed "
                                   "forward + backward" if use_ranks_path else "single GPU",
                    "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params),
-                   "execution": graph_note, "x3_linear": bool(args.x3_linear)},
+                   "execution": graph_note, "x3_linear": bool(args.x3_linear), "world_size": world,
+                   "backend": (dist.get_backend() if dist is not None else "none (single process)")},
         "roofline": {"kernel": "MSDA backward op: sdetr::bt_main_kernel (fixed-point LDS windows) + bucketing, "
                                "sdetr::msda_col2im_chan_kernel below 1200 queries", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "avg_launch_us": round(tot_us / max(1, len(evs)), 1)},
-        "loss": float(loss.detach()),
+        "loss": final_loss,   # of the last timed step, `steps` AdamW updates after the initial state
+        "loss_trace": loss_trace,
     }
 
 
@@ -326,8 +407,13 @@ def capture(step, capture_kw):
         step()
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
+    dump = os.environ.get("SDETR_BENCH_GRAPH_DOT")
+    if dump:
+        g.enable_debug_mode()
     with torch.cuda.graph(g, **capture_kw):
         out = step()
+    if dump:
+        g.debug_dump(dump)
     g.replay()
     torch.cuda.synchronize()
     return g, out

@@ -568,6 +568,12 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
     }
 }
 
+__global__ void __launch_bounds__(256) bt_clear_kernel(uint32_t *words, int n)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) words[i] = 0u;
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
@@ -617,8 +623,16 @@ extern "C" int sdetr_msda_col2im_lds_f32(sdetr_stream_t stream, const float *gra
     ws += bt_align((size_t)L * B * Nq * 4);
     a.tile_id = reinterpret_cast<uint16_t *>(ws);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(workspace, 0, bt_header_bytes(B, M, L), s) != hipSuccess)
-        return fail("msda_col2im_lds_f32: clearing the workspace header failed");
+    // The header (work counter, per-item bounds) is cleared by a KERNEL: the hipMemsetAsync that stood here until round 4 was
+    // not replayed with a captured hipGraph on this stack (ROCm 7.2 / torch 2.10: the training step's replays then ran
+    // bt_main_kernel against an exhausted work counter -- no item was processed and grad_loc / grad_aw kept whatever the
+    // pool memory held; found by comparing the replayed step's gradients with the eager step's, bench.py loss trace).
+    {
+        const int words = (int)(bt_header_bytes(B, M, L) / 4);
+        hipLaunchKernelGGL(bt_clear_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<uint32_t *>(workspace), words);
+        if (int rc = check_launch("msda_col2im_lds clear")) return rc;
+    }
     hipLaunchKernelGGL(bt_tile_id_kernel, dim3((unsigned)(B * ((Nq + 31) / 32))), dim3(256), 0, s, a);
     if (int rc = check_launch("msda_col2im_lds tile ids")) return rc;
     hipLaunchKernelGGL(bt_order_kernel, dim3((unsigned)(L * B)), dim3(1024), 0, s, a);

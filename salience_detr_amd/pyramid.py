@@ -31,8 +31,19 @@ class _LevelPosEmbed(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        g = grad.sum(0) if grad.shape[0] > 1 else grad[0]          # [S, C]
         out, cur = [], 0
+        if grad.is_cuda and grad.dtype == torch.float32 and grad.stride(2) == 1 and grad.shape[2] % 4 == 0:
+            # The device's own column-sum kernel (fixed-order tree, no atomics, no scratch): the framework's multi-block
+            # reduction clears its semaphores with a hipMemsetAsync, which a REPLAYED hipGraph does not reproduce on this
+            # stack (ROCm 7.2 / torch 2.10) -- the training step's replays then summed stale partial results (this
+            # gradient came out 10x too large; found by comparing the replayed step's gradients with the eager step's).
+            from .filter_ops import column_mean
+            for n in ctx.sizes:
+                per_image = column_mean(grad[:, cur:cur + n]) * float(n)      # [B, 1, C]
+                out.append(per_image.sum(0)[0] if grad.shape[0] > 1 else per_image[0, 0])
+                cur += n
+            return (torch.stack(out),) + (None,) * len(ctx.sizes)
+        g = grad.sum(0) if grad.shape[0] > 1 else grad[0]          # [S, C]
         for n in ctx.sizes:
             out.append(g[cur:cur + n].sum(0))
             cur += n

@@ -26,6 +26,57 @@ from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_
                          plan_masked_topk, salience_head)
 
 
+class _Modulate(torch.autograd.Function):
+    """``x + x * row_scale[..., None] * alpha`` (the coarse-to-fine update, salience_transformer.py:143) with ``alpha``'s
+    gradient -- a sum over every element of the level -- taken by the device's own column-sum kernel: the framework's
+    multi-block reduction relies on a hipMemsetAsync that a replayed hipGraph does not reproduce on this stack (see
+    ``pyramid._LevelPosEmbed.backward``; ``alpha``'s gradient came out 3 % off in the replayed training step)."""
+
+    @staticmethod
+    def forward(ctx, x, row_scale, alpha):
+        ctx.save_for_backward(x, row_scale, alpha)
+        return torch.addcmul(x, x, row_scale.unsqueeze(-1) * alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .filter_ops import column_mean
+        x, row_scale, alpha = ctx.saved_tensors
+        gx = g_rs = g_alpha = None
+        dot = (g * x).sum(-1)                                   # [B,N]: per-row reductions over the 256 channels
+        if ctx.needs_input_grad[0]:
+            gx = torch.addcmul(g, g, row_scale.unsqueeze(-1) * alpha)
+        if ctx.needs_input_grad[1]:
+            g_rs = dot * alpha
+        if ctx.needs_input_grad[2]:
+            t = (dot * row_scale).unsqueeze(-1).expand(-1, -1, 4).contiguous()        # [B,N,4]: the kernel's row format
+            g_alpha = (column_mean(t)[:, 0, 0] * float(t.shape[1])).sum().reshape(alpha.shape)
+        return gx, g_rs, g_alpha
+
+
+class _GlobalHalfMean(torch.autograd.Function):
+    """``cat([z[..., :half], z[..., half:].mean(1, keepdim=True).expand_as(...)], -1)`` (salience_transformer.py:43-45) with
+    both column reductions -- the mean over the level's tokens and, backward, the sum of the broadcast half's gradient --
+    on the device's own deterministic column-mean kernel (see ``_Modulate``: the framework's multi-block reductions are
+    not replay-safe under hipGraph on this stack)."""
+
+    @staticmethod
+    def forward(ctx, z, half):
+        from .filter_ops import column_mean
+        ctx.half = half
+        out = z.clone()
+        out[..., half:] = column_mean(z[..., half:])            # [B,1,h/2] broadcast over the tokens
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .filter_ops import column_mean
+        half = ctx.half
+        gz = g.clone()
+        # d mean / d z[b,n,c] = 1/N: every token of the global half receives the MEAN of that half's gradient
+        gz[..., half:] = column_mean(g[..., half:])
+        return gz, None
+
+
 class MaskPredictor(nn.Module):
     """Salience head (salience_transformer.py:16-47); identical parameter names
     (``layer1.0`` LayerNorm, ``layer1.1`` Linear, ``layer2.{0,2,4}`` Linear)."""
@@ -54,13 +105,17 @@ class MaskPredictor(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad or not x.is_cuda:
             if row_scale is not None:
-                x = x + x * row_scale.unsqueeze(-1) * alpha
+                x = _Modulate.apply(x, row_scale, alpha) if x.is_cuda and x.dtype == torch.float32 else \
+                    x + x * row_scale.unsqueeze(-1) * alpha
             z = add_layer_norm(x, self.layer1[0]) if x.is_cuda else self.layer1[0](x)   # (one launch each way on the device)
             for m in list(self.layer1)[1:]:
                 z = m(z)
             # the "global" half is replaced by its mean over ALL tokens of the level, masked ones included
-            local, glob = split_prefix(z, half, -1) if z.is_cuda else (z[..., :half], z[..., half:])
-            z = torch.cat([local, glob.mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
+            if z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and half % 4 == 0:
+                z = _GlobalHalfMean.apply(z, half)
+            else:
+                local, glob = split_prefix(z, half, -1) if z.is_cuda else (z[..., :half], z[..., half:])
+                z = torch.cat([local, glob.mean(dim=1, keepdim=True).expand(-1, z.shape[1], -1)], dim=-1)
             return self.layer2(z)
         if self.fused_kernels_apply(x):
             return salience_head(x, self, row_scale=row_scale, alpha=alpha).unsqueeze(-1)
