@@ -480,14 +480,24 @@ def time_replays(g, n):
 STRESS_LEVELS = [(200, 336), (100, 168), (50, 84), (25, 42)]   # the reference's 5scale pyramid (strides 4-32)
 
 
-def _graph_ms(step, steps, warmup=3):
-    """ms per call of `step` under hipGraph replay (eager launches if the capture fails)."""
+def _first_tensor(o):
+    while isinstance(o, (list, tuple)):
+        o = o[0]
+    return o
+
+
+def _graph_ms(step, steps, warmup=3, check=None):
+    """ms per call of `step` under hipGraph replay (eager launches if the capture fails).  ``check`` (a dict) receives
+    ``replay_vs_eager_max_abs``: the replayed graph's first output against the eager call's on the same inputs."""
     for _ in range(warmup):
-        step()
+        eager_out = step()
     torch.cuda.synchronize()
     try:
-        g, _ = capture(step, {})
+        g, out = capture(step, {})
         time_replays(g, 3)
+        if check is not None:
+            a, b = _first_tensor(out), _first_tensor(eager_out)
+            check["replay_vs_eager_max_abs"] = float((a.float() - b.float()).abs().max())
         return time_replays(g, steps), True
     except Exception:
         torch.cuda.synchronize()
@@ -531,10 +541,11 @@ def config_records(args, device, steps=10):
         def step():
             with torch.no_grad():
                 return m(feats, masks, pos, image_sizes=sizes, canvas=canvas)[0]
-        ms, graphed = _graph_ms(step, steps)
+        chk = {}
+        ms, graphed = _graph_ms(step, steps, check=chk)
         rec = {"workload": "salience_detr_resnet50_800_1333 fp32 inference, batch=%d: the path that carries the 1e-3 parity "
                            "claim" % args.batch, "dtype": "fp32", "ms_per_step": round(ms, 4),
-               "images_per_s": round(args.batch * 1e3 / ms, 1), "steps": steps, "hipgraph": graphed}
+               "images_per_s": round(args.batch * 1e3 / ms, 1), "steps": steps, "hipgraph": graphed, **chk}
         fixture = os.path.join(ROOT, "tests", "golden", "hotpath_full_digest.npz")
         if os.path.exists(fixture) and (args.height, args.width) == (800, 1333):
             d = np.load(fixture)
@@ -567,8 +578,9 @@ def config_records(args, device, steps=10):
                 holder["nq"] = [int(t.shape[1]) for t in r[2]["foreground_inds"]]
             return r[0]
         step()
-        ms, graphed = _graph_ms(step, steps)
-        return {"workload": "BASELINE configs[3] at N=1: bf16 inference, batch=1 per GPU, large 4-level pyramid "
+        chk = {}
+        ms, graphed = _graph_ms(step, steps, check=chk)
+        return {**chk, "workload": "BASELINE configs[3] at N=1: bf16 inference, batch=1 per GPU, large 4-level pyramid "
                             "(200x336 .. 25x42, 89 250 tokens: the reference's 5scale configuration)",
                 "dtype": "bf16", "value_map_storage": "fp16", "ms_per_step": round(ms, 4),
                 "images_per_s": round(1e3 / ms, 1), "steps": steps, "hipgraph": graphed,
@@ -593,8 +605,9 @@ def config_records(args, device, steps=10):
         def step():
             with torch.no_grad():
                 return tr(feats, masks, pos, image_sizes=sizes, canvas=canvas)
-        ms, graphed = _graph_ms(step, steps)
-        return {"workload": "BASELINE configs[4] at N=1: whole SalienceTransformer (RepVGGPluX neck, encoder, two-stage "
+        chk = {}
+        ms, graphed = _graph_ms(step, steps, check=chk)
+        return {**chk, "workload": "BASELINE configs[4] at N=1: whole SalienceTransformer (RepVGGPluX neck, encoder, two-stage "
                             "proposals + NMS, 6 decoder layers, 900 queries), batch=2 (800x1333 + 800x1066)",
                 "requested_dtype": "fp16", "served_as": {"activations": str(act).replace("torch.", ""),
                                                          "value_maps": str(vdt).replace("torch.", "")},
