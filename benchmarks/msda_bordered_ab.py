@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--ablate", default="", help="comma list of SDETR_MSDA_ABLATE masks timed with the tile-16 order "
                     "(1 no fine-level loads, 2 no LDS map reads, 4 / 8 no products of the fine / resident levels, 16 one "
                     "record for everybody); results are wrong by construction")
+    ap.add_argument("--minimal", action="store_true", help="only: round-3 resident kernel, bordered kernel in list order, "
+                    "bordered kernel in the first --tiles order (what the counter passes wrap: one configuration per kernel name)")
     ap.add_argument("--stamps", action="store_true", help="phase stamps of the workgroups (wall clock, one eager launch)")
     ap.add_argument("--out", default="gpurun_out/msda_bordered_ab.json")
     args = ap.parse_args()
@@ -61,14 +63,15 @@ def main():
             sfx = "" if ch == 0 else f"_c{ch}"
             record("bordered" + sfx, lambda: M.msda_bordered_forward(hb, levels, rf, slab, out_dtype=torch.bfloat16, chunks=ch), base)
             raster = tk.argsort(1).to(torch.int32)
-            record("bordered_raster" + sfx, lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=raster,
-                                                                            out_dtype=torch.bfloat16, chunks=ch), base)
-            for tile in [int(t) for t in args.tiles.split(",")]:
+            if not args.minimal:
+                record("bordered_raster" + sfx, lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=raster,
+                                                                                out_dtype=torch.bfloat16, chunks=ch), base)
+            for tile in [int(t) for t in args.tiles.split(",")][:1 if args.minimal else None]:
                 order = M.spatial_row_order(tk, levels, tile)
                 record(f"bordered_tile{tile}" + sfx, lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=order,
                                                                                       out_dtype=torch.bfloat16, chunks=ch), base)
         order16 = M.spatial_row_order(tk, levels, 16)
-        for name, env in (("tile16_norotate", {"SDETR_MSDA_STAGE_ROTATE": "0"}), ("tile16_prefetch", {"SDETR_MSDA_PREFETCH": "1"})):
+        for name, env in (() if args.minimal else (("tile16_no_l2_warmup", {"SDETR_MSDA_PREFETCH": "0"}),)):
             os.environ.update(env)
             record(name, lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=order16, out_dtype=torch.bfloat16), base)
             for k in env:

@@ -9,7 +9,8 @@ B=${3:-2}
 O=$PWD/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
-CMD="python benchmarks/msda_resident_ab.py --batch $B --nq $NQ --reps 5 --out $O/${TAG}_pmc_ab.json"
+# (round 4: the round-3 resident kernel on plain maps and the bordered kernel without / with a row order, same operands)
+CMD="python benchmarks/msda_bordered_ab.py --batch $B --nq $NQ --reps 5 --tiles 16 --minimal --out $O/${TAG}_pmc_ab.json"
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \

@@ -7,12 +7,12 @@
 # (The survey's full CPU-baseline protocol -- minutes of host time -- is `python bench.py --cpu-protocol full`; the
 # committed run of it is profiles/r02_bench_cpu_full.json: the CPU oracle has not changed since.)
 set -u
-R=${1:-r03}
+R=${1:-r04}
 O=$PWD/gpurun_out
 mkdir -p $O profiles
 export TMPDIR=/tmp
-# 1. PMC traffic passes first: the bench line's roofline.traffic is read from profiles/r03_msda_traffic.json
-python bench.py --no-cpu-baseline --train-steps 0 --in-flight-report 0 > $O/${R}_bench_quick.json 2> $O/${R}_bench_quick.err
+# 1. PMC traffic passes first: the bench line's roofline.traffic is read from profiles/r04_msda_traffic.json
+python bench.py --no-cpu-baseline --train-steps 0 --in-flight-report 0 --config-steps 0 > $O/${R}_bench_quick.json 2> $O/${R}_bench_quick.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${R}_pmc_$c -o p -- \
     python bench.py --plain --no-graph --steps 5 --warmup 3 > /dev/null 2> $O/${R}_pmc_$c.err
@@ -20,29 +20,52 @@ done
 F=$(find $O/${R}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find $O/${R}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 python benchmarks/pmc_to_traffic.py $F $W $O/${R}_bench_quick.json $O/${R}_msda_traffic.json && \
-  cp $O/${R}_msda_traffic.json profiles/r03_msda_traffic.json      # (this box's copy: what the bench run below reads)
+  cp $O/${R}_msda_traffic.json profiles/r04_msda_traffic.json      # (this box's copy: what the bench run below reads)
 rm -rf $O/${R}_pmc_FETCH_SIZE $O/${R}_pmc_WRITE_SIZE
-# 2. the official bench line (with the train_step sub-record and the CPU baseline); its kernel summary from the plain
-#    timed loop (six layers in equal proportion)
-python bench.py --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/${R}_bench.err
-tail -c 300 $O/${R}_bench.json
+# 2. the kernel summary of the plain timed loop (six layers in equal proportion) FIRST: the bench line's
+#    roofline.timing_rocprof_us is read from profiles/r04_msda_rocprof.json; then the official bench line (with the
+#    train_step sub-record, the config sub-records and the CPU baseline)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof -o p -- python bench.py --plain --steps 50 > $O/${R}_bench_profiled.json 2> $O/${R}_prof.err
 cp $(find $O/${R}_prof -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv
 python benchmarks/step_timeline.py $(find $O/${R}_prof -name '*kernel_trace.csv' | head -1) > $O/${R}_step_timeline.txt
+python - $(find $O/${R}_prof -name '*kernel_trace.csv' | head -1) $O/${R}_msda_rocprof.json <<'PY'
+import csv, json, sys
+sys.path.insert(0, ".")
+import bench
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "msda_bordered_kernel" in r["Kernel_Name"] or "msda_resident_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+per_layer = [round(sum(us[k::6]) / len(us[k::6]), 2) for k in range(6)] if len(us) % 6 == 0 else None
+json.dump({"source": "rocprofv3 --kernel-trace over `python bench.py --plain --steps 50` (hipGraph replay): every fused-MSDA launch of "
+                     "the timed loop and its warm-up, launch i of the trace = encoder layer i mod 6",
+           "kernel": rows[0]["Kernel_Name"].split("(")[0], "launches": len(us), "avg_launch_us": round(sum(us) / len(us), 2),
+           "per_layer_us": per_layer, "batch": 2, "kernel_source_tag": bench.kernel_source_tag()}, open(sys.argv[2], "w"), indent=1)
+print(open(sys.argv[2]).read())
+PY
+cp $O/${R}_msda_rocprof.json profiles/r04_msda_rocprof.json
 rm -rf $O/${R}_prof
+python bench.py --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/${R}_bench.err
+tail -c 300 $O/${R}_bench.json
 head -8 $O/${R}_bench_kernel_stats.csv | cut -c1-150
-# 3. counters of the two fused MSDA forward kernels (layer 0 size)
+# 3. counters of the fused MSDA forward kernels (layer 0 size: round 3's resident kernel, the bordered kernel without and
+#    with a row order) and of the MSDA backward kernels
 bash benchmarks/pmc_msda.sh ${R} 11363 2 > /dev/null 2>&1
+mv $O/${R}_pmc_summary.md $O/${R}_msda_pmc.md 2> /dev/null
 rm -rf $O/${R}_pmc_[1-5]
+bash benchmarks/pmc_msda_bwd.sh ${R} 11363 2 > /dev/null 2>&1
 # 4. MFMA-busy counters of the dense kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES \
   --kernel-trace --output-format csv -d $O/${R}_mfma_1 -o p -- \
   python bench.py --plain --no-graph --steps 5 --warmup 3 > /dev/null 2> $O/${R}_mfma_1.err
 python benchmarks/mfma_busy_summary.py $O/${R}_mfma_ $O/${R}_mfma_busy.md > /dev/null
 rm -rf $O/${R}_mfma_1
-# 5. kernel A/B at batch 2 and at batch 16 (value maps beyond the 256 MiB Infinity Cache)
-python benchmarks/msda_resident_ab.py --out $O/${R}_msda_ab.json > /dev/null 2>&1
-python benchmarks/msda_resident_ab.py --batch 16 --reps 10 --out $O/${R}_msda_ab_b16.json > /dev/null 2>&1
+# 5. kernel A/B at batch 2 and at batch 16 (value maps beyond the 256 MiB Infinity Cache): round 3's resident kernel, the
+#    bordered kernel in list / raster / tile order; then on the step's own operands with the ablations and phase stamps
+python benchmarks/msda_bordered_ab.py --tiles 8,16,32 --out $O/${R}_msda_ab.json > /dev/null 2>&1
+python benchmarks/msda_bordered_ab.py --batch 16 --reps 10 --tiles 16 --nq 11363,6817,4545 --out $O/${R}_msda_ab_b16.json > /dev/null 2>&1
+python benchmarks/msda_bordered_ab.py --levels 5scale --batch 1 --nq 45330,27198,9066 --tiles 16 --out $O/${R}_msda_ab_5scale_bordered.json > /dev/null 2>&1
+python benchmarks/msda_real_operands.py --ablate 1,2,3,12,15,16,64,2048,128,256,1024 --stamps --tiles 8,32 --out $O/${R}_msda_real_operands.json > /dev/null 2>&1
+python benchmarks/msda_backward_ab.py > $O/${R}_msda_backward_ab.json 2> /dev/null
 #    ... and on the reference's 5scale pyramid (level 3 alone resident), one and two images
 python benchmarks/msda_resident_ab.py --levels 5scale --batch 1 --nq 45330,36264,27198,18132,9066 --chunks 0 --out $O/${R}_msda_ab_5scale_b1.json > /dev/null 2>&1
 python benchmarks/msda_resident_ab.py --levels 5scale --batch 2 --nq 45330,9066 --chunks 0 --out $O/${R}_msda_ab_5scale_b2.json > /dev/null 2>&1

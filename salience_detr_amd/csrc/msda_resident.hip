@@ -403,7 +403,21 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
 // three subtractions.  (Positions in [size - 2^-17, size) read weight 2^-17 x the border pixel instead of nothing: the
 // reference's own value there differs from zero by more, ms_deform_im2col_cuda.cuh:22-73 is continuous at the border.)
 // The second row of a sample is the first one's address plus the level's row pitch: for the two fine levels that is the
-// SCALAR offset operand of the buffer load -- no vector instruction.  ~680 instructions per group.
+// SCALAR offset operand of the buffer load -- no vector instruction.  With the packed-f32 weight split, the loop
+// unrolled over two input sets (no register copies between row groups) and the first product of a row starting the
+// accumulators, the loop holds 651 vector instructions per row group (784 in the round-3 kernel; counted from the
+// device assembly by benchmarks/tools/asm_loop_count.py).
+//
+// What the measurements of this round say about the kernel (benchmarks/msda_real_operands.py on the step's own operands,
+// ablation builds `ABL`, per-workgroup phase stamps):
+//  * with the rows in list (score) order the loop is bound by the fine levels' misses in the 32 KB L1 -- fewer vector
+//    instructions bought nothing there (round 3's packed-fp16 experiment, this kernel in list order: 29.4 vs 29.7 us);
+//  * with the rows in tile order it is bound by vector-ALU ISSUE: +128 dummy instructions per group cost +2.7 us, removing
+//    the fine-level loads only 3.8, the LDS reads 0.7; the 512 v_fma_mix are 12 of the 17.5 us the loop takes at layer 0;
+//  * four fine-level samples (16 loads) in flight per wave were too many: 16 waves x 16 KB = 8 x the L1 -- ONE is faster;
+//  * ~6 us of every launch pass before the first resident-level sample can be read: the four waves of a SIMD run their
+//    first row group's set-up one after the other (vector-ALU bound as well); LDS-DMA staging (25 GB/s per CU whatever
+//    the number of issuing waves) would add to it, so the records travel through registers.
 //
 // Row order (PERM): the encoder hands its rows over sorted by salience score, so the 256 rows a workgroup has in flight
 // are scattered over the image and the fine-level records they fetch miss the 32 KB L1 (the L2 -> L1 leg: 64-byte
@@ -429,7 +443,6 @@ struct BorderedArgs {
     int res_start;                        // first resident record: P2 (levels 2 + 3 resident) or P3 (level 3 only)
     int res_px;                           // Np - res_start: records resident in LDS
     int chunks;                           // workgroups per (image, head)
-    int stage_rotate;                     // workgroups start their copy of the resident records at different pieces
     int prefetch_fine;                    // touch this workgroup's share of the fine levels' lines first (L2 warm-up)
     unsigned long long *stamps;           // benchmarks only (ABL & 32): [workgroup][8] wall-clock stamps (100 MHz)
 };
@@ -1104,8 +1117,6 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
         if (chunks < 1) chunks = 1;
     }
     a.chunks = chunks;
-    a.stage_rotate = 1;
-    if (const char *e = getenv("SDETR_MSDA_STAGE_ROTATE")) a.stage_rotate = atoi(e) != 0;
     // bit 0: L2 warm-up of the fine levels (on: in the step -132.7 -> 124.3 us over the six launches by rocprofv3; nothing
     // to gain in a warm replay), bit 1: of the workgroup's projection rows (measured: no gain).  Environment: A/B runs.
     a.prefetch_fine = 1;
