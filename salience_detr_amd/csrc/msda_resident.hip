@@ -1119,7 +1119,9 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     a.chunks = chunks;
     // bit 0: L2 warm-up of the fine levels (on: in the step -132.7 -> 124.3 us over the six launches by rocprofv3; nothing
     // to gain in a warm replay), bit 1: of the workgroup's projection rows (measured: no gain).  Environment: A/B runs.
-    a.prefetch_fine = 1;
+    // Only while the fine levels of the images an XCD serves at a time fit its 4 MB L2 beside the rest: on the 5scale
+    // pyramid (5.7 MB per head) the warm-up costs 4 us per launch (profiles/r04_msda_ab_5scale_bordered.json).
+    a.prefetch_fine = (int64_t)groups * a.res_start * 64 <= ((int64_t)7 << 19) ? 1 : 0;
     if (const char *e = getenv("SDETR_MSDA_PREFETCH")) a.prefetch_fine = atoi(e);
     const int64_t blocks = (int64_t)groups * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_bordered_forward: grid too large");
