@@ -98,23 +98,6 @@ def algorithmic_bytes(B, Nv, Nq, M, D, L, P, value_bytes, proj_bytes, out_bytes,
                 + Nq * M * D * out_bytes)
 
 
-class _ReplaySafeMean(torch.autograd.Function):
-    """``x.mean()`` of a fp32 ``[B,n,C]`` device tensor through the hot path's own column-mean kernel."""
-
-    @staticmethod
-    def forward(ctx, x):
-        from salience_detr_amd.filter_ops import column_mean
-        ctx.shape = x.shape
-        return column_mean(x.contiguous()).mean()
-
-    @staticmethod
-    def backward(ctx, g):
-        n = 1
-        for d in ctx.shape:
-            n *= d
-        return (g / n).expand(ctx.shape)
-
-
 def train_record(args, model, device, rank, world, dist, steps, warmup, force_dist_path=False):
     """configs[2]: one training step of the hot-path modules per batch of 2 images per GPU -- fp32 forward
     through the autograd path (HIP MSDA forward/backward op), the salience criterion (row N4: targets + focal loss
@@ -127,6 +110,7 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     device-bound, and N = 1 and N > 1 run the same captured kernels)."""
     from salience_detr_amd.data_parallel import StaticGradAllReducer, broadcast_parameters
     from salience_detr_amd.salience_criterion import SalienceCriterion
+    from salience_detr_amd.salience_filtering import replay_safe_mean
     sizes, canvas, level_shapes, _, (feats, masks, pos) = make_inputs(args.batch, args.height, args.width, device,
                                                                       seed=rank)
     model.train()
@@ -167,7 +151,7 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
             w = syn.det_randn("bench.train.memory_weights", tuple(memory.shape)).to(memory.device)
         # (the mean over `memory` as per-image column means + a 512-element mean: the framework's one-kernel reduction of
         # 11 M elements clears its semaphores with a hipMemsetAsync that a replayed hipGraph does not reproduce here)
-        loss = _ReplaySafeMean.apply(memory * w) + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
+        loss = replay_safe_mean(memory * w) + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
         loss.backward()
         if reducer is not None:
             reducer.pack()

@@ -712,6 +712,18 @@ int sdetr_gemm_x3_presplit(sdetr_stream_t stream, const float *w, int64_t ld, in
 int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b, int64_t ldb,
                       int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
                       int reduction_splits, float *a_row_sum);
+/* The same product with an epilogue on C (round 4; unsplit reductions only) -- the feed-forward's ReLU
+ * (models/bricks/salience_transformer.py:347-351: linear2(dropout(relu(linear1(x))))) folded into the products around it:
+ *   SDETR_GEMM_EPI_RELU  C = relu(acc + bias)                         forward of linear1 + activation
+ *   SDETR_GEMM_EPI_GATE  C = gate(m, n) <= 0 ? 0 : acc + bias         dh = (dy w2) * (h > 0): linear2's input gradient
+ *                        followed by ReLU's backward; gate = the ReLU output h, [M, N] rows ldg apart
+ * NaNs behave as in torch (relu(NaN) = NaN; a NaN gate passes the gradient). */
+#define SDETR_GEMM_EPI_NONE 0
+#define SDETR_GEMM_EPI_RELU 1
+#define SDETR_GEMM_EPI_GATE 2
+int sdetr_gemm_x3_epilogue_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b,
+                               int64_t ldb, int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
+                               int reduction_splits, float *a_row_sum, int epilogue, const float *gate, int64_t ldg);
 
 /* The END of an encoder layer in one operator (csrc/ffn.hip, ffn_fused_kernel<true>): the deformable attention's tail
  *     x = norm1(residual + output_proj(sampled))              models/bricks/salience_transformer.py:390-391,

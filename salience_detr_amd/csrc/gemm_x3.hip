@@ -45,7 +45,21 @@ struct GemmArgs {
     float *a_row_sum;      // optional [M]: sum_k A(m, k) accumulated with atomics (zero on entry) -- the bias gradient
                            // sum_t dy[t][n] next to dw = dy^T x; reduction-major A only
     uint32_t a_bytes, b_bytes;   // extents of the operands (second-generation kernel: buffer resources)
+    int epilogue;          // SDETR_GEMM_EPI_*: 0 none; 1 ReLU on (acc + bias); 2 gate: C = gate(m, n) <= 0 ? 0 : acc + bias
+    const float *gate;     // [M, N] rows ldg apart (epilogue 2): the ReLU OUTPUT whose backward this product is
+    int64_t ldg;
 };
+
+// The feed-forward's ReLU lives in the products around it (round 4): forward h = relu(x w1^T + b1) as epilogue 1, backward
+// dh = (dy w2) * (h > 0) as epilogue 2 -- torch's clamp_min_ / threshold_backward passes over the [T, 2048] hidden state
+// (33 + 50 us per layer at 22 726 tokens) disappear.  NaN behaviour as torch's: relu(NaN) = NaN, a NaN gate lets the
+// gradient through.  Unsplit reductions only (an atomic partial sum cannot be clamped).
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs &p, float v, int m, int n)
+{
+    if (p.epilogue == 1) return v < 0.f ? 0.f : v;
+    if (p.epilogue == 2) return p.gate[(int64_t)m * p.ldg + n] <= 0.f ? 0.f : v;
+    return v;
+}
 
 // (benchmarks/micro/gemm_x3_ablate.hip compiles this file with SDETR_GX3_ABLATE = 1: no MFMAs, 2: no operand split,
 // 3: no global loads after the first tiles, 4: no LDS tile stores, 5: no barrier, 6: no fragment reads (second-generation
@@ -296,7 +310,7 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
                 if (m < p.M) {
                     float *dst = p.c + (int64_t)m * p.ldc + n;
                     if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
-                    else *dst = acc[rt][ct][i] + bias;
+                    else *dst = gemm_epilogue(p, acc[rt][ct][i] + bias, m, n);
                 }
             }
     }
@@ -385,7 +399,7 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_pre_kernel(GemmArgs p)
                 if (m < p.M) {
                     float *dst = p.c + (int64_t)m * p.ldc + n;
                     if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
-                    else *dst = acc[rt][ct][i] + bias;
+                    else *dst = gemm_epilogue(p, acc[rt][ct][i] + bias, m, n);
                 }
             }
     }
@@ -684,7 +698,7 @@ __global__ void __launch_bounds__(kV2Threads, 1) gemm_x3_v2_kernel(GemmArgs p)
                 if (m < p.M) {
                     float *dst = p.c + (int64_t)m * p.ldc + n;
                     if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
-                    else *dst = acc[rt][ct][i] + bias;
+                    else *dst = gemm_epilogue(p, acc[rt][ct][i] + bias, m, n);
                 }
             }
     }
@@ -758,13 +772,19 @@ static uint32_t operand_bytes(int64_t rows, int64_t width, int64_t ld, int elem,
 // fp32 atomics -- C must be zero on entry.  Alignment: every operand 16-byte aligned, its leading dimension a multiple
 // of 4; a k-major operand needs K % 4 == 0, the other kind its row count % 4 == 0.  a_row_sum (optional, [M], zero on
 // entry, reduction-major A only): receives sum_k A(m, k) -- the bias gradient that comes with dw = dy^T x.
-extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b,
-                                 int64_t ldb, int b_kmajor, float *c, int64_t ldc, int M, int N, int K,
-                                 const float *bias, int reduction_splits, float *a_row_sum)
+// epilogue (SDETR_GEMM_EPI_NONE / _RELU / _GATE, include/salience_hip.h) with its gate matrix [M, N] (rows ldg apart; _GATE
+// only): unsplit reductions only.
+extern "C" int sdetr_gemm_x3_epilogue_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b,
+                                          int64_t ldb, int b_kmajor, float *c, int64_t ldc, int M, int N, int K,
+                                          const float *bias, int reduction_splits, float *a_row_sum, int epilogue,
+                                          const float *gate, int64_t ldg)
 {
     if (M < 0 || N < 0 || K < 0) return fail("gemm_x3: negative size");
     if (M == 0 || N == 0) return 0;
     if (!a || !b || !c) return fail("gemm_x3: null pointer");
+    if (epilogue < 0 || epilogue > 2) return fail("gemm_x3: unknown epilogue %d", epilogue);
+    if (epilogue && reduction_splits > 1) return fail("gemm_x3: an epilogue needs an unsplit reduction");
+    if (epilogue == 2 && (!gate || ldg < N)) return fail("gemm_x3: the gate epilogue needs a gate matrix with rows of >= N elements");
     if (b_kmajor == 2) {   // pre-split B planes [3][N][K] bf16 (sdetr_gemm_x3_presplit), rows ldb elements apart
         if ((lda & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || (ldb & 7) || (K & 7) || ldb < K)
             return fail("gemm_x3: a pre-split B needs K % 8 == 0, rows of >= K elements, 16-byte aligned operands");
@@ -774,6 +794,7 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
         GemmArgs g{};
         g.a = a; g.b = b; g.c = c; g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
         g.b_plane = (int64_t)N * ldb;
+        g.epilogue = epilogue; g.gate = gate; g.ldg = ldg;
         const int steps = (K + kGK - 1) / kGK;
         int splits = reduction_splits > steps ? (steps > 0 ? steps : 1) : reduction_splits;
         g.k_per_split = ((steps + splits - 1) / splits) * kGK;
@@ -800,6 +821,7 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
     if (a_row_sum && a_kmajor) return fail("gemm_x3: a_row_sum needs a reduction-major A");
     GemmArgs g{};
     g.a_row_sum = a_row_sum;
+    g.epilogue = epilogue; g.gate = gate; g.ldg = ldg;
     g.a = a; g.b = b; g.c = c; g.bias = bias; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     const int steps = (K + kGK - 1) / kGK;
     int splits = reduction_splits > steps ? (steps > 0 ? steps : 1) : reduction_splits;
@@ -820,6 +842,14 @@ extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t 
     if (a_kmajor && !b_kmajor) return launch_gemm_x3<true, false>(s, g, splits);
     if (!a_kmajor && b_kmajor) return launch_gemm_x3<false, true>(s, g, splits);
     return launch_gemm_x3<false, false>(s, g, splits);
+}
+
+extern "C" int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b,
+                                 int64_t ldb, int b_kmajor, float *c, int64_t ldc, int M, int N, int K,
+                                 const float *bias, int reduction_splits, float *a_row_sum)
+{
+    return sdetr_gemm_x3_epilogue_f32(stream, a, lda, a_kmajor, b, ldb, b_kmajor, c, ldc, M, N, K, bias, reduction_splits,
+                                      a_row_sum, 0, nullptr, 0);
 }
 
 // Three bf16 planes of an fp32 matrix (exact split by truncation), optionally transposed: the form in which

@@ -19,13 +19,21 @@ from torch.nn import functional as F
 from . import _hip
 
 
+EPI_NONE, EPI_RELU, EPI_GATE = 0, 1, 2   # SDETR_GEMM_EPI_* (include/salience_hip.h)
+
+
 def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int, K: int,
             bias: Optional[Tensor] = None, reduction_splits: int = 1, out: Optional[Tensor] = None,
-            a_row_sum: Optional[Tensor] = None) -> Tensor:
+            a_row_sum: Optional[Tensor] = None, epilogue: int = EPI_NONE, gate: Optional[Tensor] = None) -> Tensor:
     """``C[M,N] = sum_k A(m,k) B(n,k) (+ bias[n])`` with ``A(m,k) = a[m,k]`` (k-major) or ``a[k,m]``; ``b`` likewise
     (``include/salience_hip.h``).  ``a`` / ``b`` are 2-d fp32 HIP tensors with a contiguous last dimension.
-    ``a_row_sum`` (fp32 [M], zeroed by the caller, reduction-major ``a`` only) receives ``sum_k A(m,k)``."""
-    _hip.require_device("gemm_x3", a=a, b=b, bias=bias)
+    ``a_row_sum`` (fp32 [M], zeroed by the caller, reduction-major ``a`` only) receives ``sum_k A(m,k)``.
+    ``epilogue``: ``EPI_RELU`` clamps ``C`` at zero, ``EPI_GATE`` zeroes it where ``gate`` (fp32 ``[M, N]``) is not
+    positive -- unsplit reductions only."""
+    _hip.require_device("gemm_x3", a=a, b=b, bias=bias, gate=gate)
+    if epilogue == EPI_GATE and (gate is None or gate.dtype != torch.float32 or tuple(gate.shape) != (M, N)
+                                 or gate.stride(1) != 1):
+        raise RuntimeError("gemm_x3: the gate epilogue needs an fp32 [M, N] gate with a contiguous last dimension")
     for t, what in ((a, "a"), (b, "b")):
         if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
             raise RuntimeError(f"gemm_x3: {what} must be a 2-d fp32 tensor with a contiguous last dimension")
@@ -38,9 +46,10 @@ def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int
             raise RuntimeError("gemm_x3: out must be a contiguous fp32 tensor of M * N elements on the operands' device")
         c = out.view(M, N)
     with torch.cuda.device(a.device):
-        code = _hip.lib().sdetr_gemm_x3_f32(_hip.stream_ptr(), a.data_ptr(), a.stride(0), int(a_kmajor), b.data_ptr(),
-                                            b.stride(0), int(b_kmajor), c.data_ptr(), c.stride(0), M, N, K,
-                                            _hip.ptr(bias), int(reduction_splits), _hip.ptr(a_row_sum))
+        code = _hip.lib().sdetr_gemm_x3_epilogue_f32(
+            _hip.stream_ptr(), a.data_ptr(), a.stride(0), int(a_kmajor), b.data_ptr(), b.stride(0), int(b_kmajor),
+            c.data_ptr(), c.stride(0), M, N, K, _hip.ptr(bias), int(reduction_splits), _hip.ptr(a_row_sum),
+            int(epilogue), _hip.ptr(gate) if epilogue == EPI_GATE else None, gate.stride(0) if epilogue == EPI_GATE else 0)
     _hip.check(code, "gemm_x3")
     return c if out is None else out
 
@@ -190,6 +199,98 @@ class _LinearX3(Function):
         if want_gb and gb is None:
             gb = g2.sum(0)
         return (None if gx is None else gx.view(ctx.x_shape)), gw, gb
+
+
+def _weight_and_bias_grad(g2: Tensor, x2: Tensor, want_gb: bool):
+    """``dw = g2^T x2`` (+ ``db = sum_t g2``) through the x3 kernel: one zero fill for both, the bias gradient from the
+    row sums of the tiles the kernel holds anyway."""
+    T, N = g2.shape
+    K = x2.shape[1]
+    splits = _weight_grad_splits(T, N, K)
+    out = gb = None
+    if want_gb:
+        buf = torch.zeros(N * K + N, dtype=torch.float32, device=g2.device)
+        out, gb = buf[:N * K].view(N, K), buf[N * K:]
+    elif splits > 1:
+        out = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
+    gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=splits, out=out, a_row_sum=gb)
+    return (gw if out is None else out), gb
+
+
+class _FfnX3(Function):
+    """``linear2(relu(linear1(x)))`` (``models/bricks/salience_transformer.py:347-351`` without its dropout) as ONE autograd
+    node: the ReLU is the epilogue of the first product forward and of linear2's input-gradient product backward
+    (``EPI_RELU`` / ``EPI_GATE``), so the two elementwise passes over the ``[T, F]`` hidden state and the in-place
+    bookkeeping autograd does for ``nn.ReLU(inplace=True)`` disappear.  Products that the shape routing of ``_LinearX3``
+    leaves with the library keep its GEMM, followed by the elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        K = x.shape[-1]
+        x2 = x.view(-1, K)
+        T, Fh, N = x2.shape[0], w1.shape[0], w2.shape[0]
+        if X3_FORWARD and K % 8 == 0 and _x3_wide(T, Fh, K) and _reduction_splits(T, Fh, K) == 1:
+            h = gemm_x3(x2, True, w1, True, T, Fh, K, bias=b1, epilogue=EPI_RELU)
+        else:
+            h = torch.addmm(b1, x2, w1.t()) if b1 is not None else torch.mm(x2, w1.t())
+            h.clamp_min_(0.0)
+        use_x3 = X3_FORWARD and Fh % 8 == 0 and _x3_wide(T, N, Fh)
+        splits = _reduction_splits(T, N, Fh) if use_x3 else 1
+        y = (torch.zeros if splits > 1 else torch.empty)(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        y2 = y.view(T, N)
+        if use_x3:
+            gemm_x3(h, True, w2, True, T, N, Fh, bias=b2, reduction_splits=splits, out=y2)
+        elif b2 is not None:
+            torch.addmm(b2, h, w2.t(), out=y2)
+        else:
+            torch.mm(h, w2.t(), out=y2)
+        ctx.save_for_backward(x2, h, w1, w2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, h, w1, w2 = ctx.saved_tensors
+        T, K = x2.shape
+        Fh, N = w1.shape[0], w2.shape[0]
+        g2 = (gy if gy.is_contiguous() else gy.contiguous()).view(T, N)
+        need = ctx.needs_input_grad
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        if need[3]:
+            gw2, gb2 = _weight_and_bias_grad(g2, h, ctx.has_bias[1] and need[4])
+        elif ctx.has_bias[1] and need[4]:
+            gb2 = g2.sum(0)
+        if need[0] or need[1] or need[2]:
+            # dh = (dy w2) * (h > 0)
+            if X3_DX and N % 8 == 0 and _x3_wide(T, Fh, N) and _reduction_splits(T, Fh, N) == 1:
+                dh = gemm_x3(g2, True, w2, False, T, Fh, N, epilogue=EPI_GATE, gate=h)
+            else:
+                dh = torch.ops.aten.threshold_backward(g2 @ w2, h, 0.0)
+            if need[1]:
+                gw1, gb1 = _weight_and_bias_grad(dh, x2, ctx.has_bias[0] and need[2])
+            elif ctx.has_bias[0] and need[2]:
+                gb1 = dh.sum(0)
+            if need[0]:
+                if X3_DX and Fh % 8 == 0 and _x3_wide(T, K, Fh):
+                    sp = _reduction_splits(T, K, Fh)
+                    gx = gemm_x3(dh, True, w1, False, T, K, Fh, reduction_splits=sp,
+                                 out=torch.zeros((T, K), dtype=dh.dtype, device=dh.device) if sp > 1 else None)
+                else:
+                    gx = dh @ w1
+                gx = gx.view(ctx.x_shape)
+        return gx, gw1, gb1, gw2, gb2
+
+
+def x3_ffn_applies(x: Tensor, linear1: nn.Linear, linear2: nn.Linear) -> bool:
+    return (X3_DW and x3_linear_applies(x, linear1.weight, linear1.bias) and linear2.weight.is_cuda
+            and x3_linear_applies(x.new_empty((1, linear1.weight.shape[0])), linear2.weight, linear2.bias))
+
+
+def x3_ffn(x: Tensor, linear1: nn.Linear, linear2: nn.Linear) -> Tensor:
+    """``linear2(relu(linear1(x)))`` through ``_FfnX3`` (differentiable; the caller checks ``x3_ffn_applies``)."""
+    return _FfnX3.apply(x if x.is_contiguous() else x.contiguous(), linear1.weight, linear1.bias, linear2.weight,
+                        linear2.bias)
 
 
 def x3_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:

@@ -33,6 +33,7 @@ from .filter_ops import (advance_rows, layer_row_orders, attention_heads, attent
                          select_stack, token_linear_applies, token_linear_ln, topk_self_attention_,
                          topk_self_attention_applies)
 from .layer_norm_train import add_layer_norm
+from .linear_x3 import X3Linear, x3_ffn, x3_ffn_applies
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps, plan_batched_value_maps
 from .pyramid import PositionEmbeddingLearned
 
@@ -93,6 +94,10 @@ class SalienceTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, query):
+        if (isinstance(self.linear1, X3Linear) and isinstance(self.linear2, X3Linear) and isinstance(self.activation, nn.ReLU)
+                and not (self.training and self.dropout2.p > 0.0) and x3_ffn_applies(query, self.linear1, self.linear2)):
+            src2 = x3_ffn(query, self.linear1, self.linear2)   # ReLU inside the products (linear_x3._FfnX3)
+            return add_layer_norm(query, self.norm2, self.dropout3(src2))
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(query))))
         return add_layer_norm(query, self.norm2, self.dropout3(src2))
 

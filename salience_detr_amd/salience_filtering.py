@@ -77,6 +77,30 @@ class _GlobalHalfMean(torch.autograd.Function):
         return gz, None
 
 
+class _ReplaySafeMean(torch.autograd.Function):
+    """``x.mean()`` of a fp32 ``[B, n, C]`` device tensor through the column-mean kernel (per-image column means, then a
+    mean of ``B * C`` numbers): the framework's one-kernel reduction of millions of elements clears its semaphores with a
+    ``hipMemsetAsync`` node that a replayed hipGraph does not reproduce on this stack (see ``_Modulate``)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from .filter_ops import column_mean
+        ctx.shape = x.shape
+        return column_mean(x.contiguous()).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for d in ctx.shape:
+            n *= d
+        return (g / n).expand(ctx.shape)
+
+
+def replay_safe_mean(x: Tensor) -> Tensor:
+    """Differentiable ``x.mean()`` that is safe inside a captured training step (losses over ``memory``)."""
+    return _ReplaySafeMean.apply(x)
+
+
 class MaskPredictor(nn.Module):
     """Salience head (salience_transformer.py:16-47); identical parameter names
     (``layer1.0`` LayerNorm, ``layer1.1`` Linear, ``layer2.{0,2,4}`` Linear)."""

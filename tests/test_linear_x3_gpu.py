@@ -126,3 +126,67 @@ def test_x3_linear_falls_back_where_the_kernel_does_not_apply():
     assert torch.equal(lin(x), torch.nn.functional.linear(x, lin.weight, lin.bias))
     cpu = X.X3Linear(8, 8)
     assert torch.equal(cpu(torch.ones(2, 8)), torch.nn.functional.linear(torch.ones(2, 8), cpu.weight, cpu.bias))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 260, 256), (4545, 2048, 256), (516, 132, 36)])
+def test_gemm_x3_relu_and_gate_epilogues(M, N, K, generation):
+    """C = relu(acc + bias) and C = gate <= 0 ? 0 : acc (the feed-forward's ReLU inside the products around it):
+    bit-identical to the plain product followed by torch's elementwise pass; NaNs as torch's."""
+    a = syn.det_randn(f"ea{M}{K}", (M, K)).to(DEV)
+    b = syn.det_randn(f"eb{N}{K}", (N, K)).to(DEV)
+    bias = syn.det_randn(f"ebias{N}", (N,)).to(DEV)
+    plain = X.gemm_x3(a, True, b, True, M, N, K, bias=bias)
+    assert torch.equal(X.gemm_x3(a, True, b, True, M, N, K, bias=bias, epilogue=X.EPI_RELU), plain.clamp_min(0.0))
+    gate = syn.det_randn(f"eg{M}{N}", (M, N)).to(DEV)
+    gate[1, 2] = float("nan")
+    gate[3, 1] = 0.0
+    gated = X.gemm_x3(a, True, b, True, M, N, K, bias=bias, epilogue=X.EPI_GATE, gate=gate)
+    assert torch.equal(gated, torch.ops.aten.threshold_backward(plain, gate, 0.0))
+    an = a.clone()
+    an[0, 0] = float("nan")
+    r = X.gemm_x3(an, True, b, True, M, N, K, epilogue=X.EPI_RELU)
+    assert torch.isnan(r[0]).all() and not torch.isnan(r[1:]).any()
+    with pytest.raises(RuntimeError):   # an atomic partial sum cannot be clamped
+        X.gemm_x3(a, True, b, True, M, N, K, reduction_splits=2, epilogue=X.EPI_RELU,
+                  out=torch.zeros(M, N, device=DEV))
+    with pytest.raises(RuntimeError):
+        X.gemm_x3(a, True, b, True, M, N, K, epilogue=X.EPI_GATE)
+
+
+@pytest.mark.parametrize("rows,wide", [((2, 1137), True), ((2, 1137), False), ((2, 11363), None)])
+def test_x3_ffn_matches_the_unfused_modules(rows, wide, monkeypatch):
+    """linear2(relu(linear1(x))) as one autograd node (ReLU in the products' epilogues) against the same layers as
+    separate X3Linear modules + nn.ReLU, and both against float64.  wide = True / False forces every product through
+    the x3 kernel / the library's GEMM; None = the shipped shape routing at the benchmark's layer-0 size."""
+    if wide is not None:
+        monkeypatch.setattr(X, "X3_WIDE_OUT_ROWS", 1 if wide else 10 ** 9)
+        monkeypatch.setattr(X, "X3_LONG_REDUCTION_ROWS", 1 if wide else 10 ** 9)
+    l1, l2 = torch.nn.Linear(256, 2048), torch.nn.Linear(2048, 256)
+    x = syn.det_randn("ffn_x", rows + (256,))
+    gy = syn.det_randn("ffn_gy", rows + (256,))
+    x64 = x.double().requires_grad_(True)
+    a64, b64 = torch.nn.Linear(256, 2048).double(), torch.nn.Linear(2048, 256).double()
+    a64.load_state_dict({k: v.double() for k, v in l1.state_dict().items()})
+    b64.load_state_dict({k: v.double() for k, v in l2.state_dict().items()})
+    y64 = b64(torch.relu(a64(x64)))
+    y64.backward(gy.double())
+
+    def run(fused):
+        m1, m2 = torch.nn.Linear(256, 2048).to(DEV), torch.nn.Linear(2048, 256).to(DEV)
+        m1.load_state_dict(l1.state_dict())
+        m2.load_state_dict(l2.state_dict())
+        seq = torch.nn.Sequential(m1, m2)
+        assert X.use_x3_linear_(seq) == 2
+        xd = x.to(DEV).requires_grad_(True)
+        if fused:
+            assert X.x3_ffn_applies(xd, m1, m2)
+            y = X.x3_ffn(xd, m1, m2)
+        else:
+            y = m2(torch.relu(m1(xd)))
+        y.backward(gy.to(DEV))
+        return y.detach(), xd.grad, m1.weight.grad, m1.bias.grad, m2.weight.grad, m2.bias.grad
+
+    fused, plain = run(True), run(False)
+    want = (y64.detach(), x64.grad, a64.weight.grad, a64.bias.grad, b64.weight.grad, b64.bias.grad)
+    for got, ref, w in zip(fused, plain, want):
+        assert _err(got, w) <= max(3.0 * _err(ref, w), 3e-6)

@@ -1,0 +1,118 @@
+"""GPU: the training step `bench.py` times (`train_step`), at the benchmark's full size, against autograd through the
+oracle -- one 800x1333 image, E = 256, six layers, fp32, Linear products on the x3 kernels, forward + backward both eager
+and as a replayed hipGraph (reference: `util/engine.py:44-64` around `SalienceTransformer.forward`,
+`models/bricks/salience_transformer.py:97-183`).
+
+Checks: the loss, and the gradients of a handful of parameters from every stage of the path (position
+embedding, salience head, the coarse-to-fine `alpha`, deformable attention projections, feed-forward, the 300-row
+attention, LayerNorm), within 5e-3 of each gradient's own scale; and that the replayed graph reproduces the eager step's
+gradients (the round-4 finding: memset nodes are not replayed on this stack -- `CHANGELOG.md`)."""
+import pytest
+import torch
+
+from oracle import salience_ref as R
+from salience_detr_amd import synthetic as syn
+from salience_detr_amd.hot_path import build_hot_path
+from salience_detr_amd.linear_x3 import use_x3_linear_
+from salience_detr_amd.salience_filtering import replay_safe_mean
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CHECKED = (
+    "level_embeds",
+    "alpha",
+    "enc_mask_predictor.layer1.1.weight",
+    "enc_mask_predictor.layer2.4.weight",
+    "enc_output.weight",
+    "encoder.layers.0.self_attn.sampling_offsets.weight",
+    "encoder.layers.0.self_attn.attention_weights.bias",
+    "encoder.layers.0.self_attn.value_proj.weight",
+    "encoder.layers.2.self_attn.output_proj.weight",
+    "encoder.layers.0.linear1.weight",
+    "encoder.layers.0.linear1.bias",
+    "encoder.layers.3.linear2.weight",
+    "encoder.layers.5.linear1.weight",
+    "encoder.layers.1.pre_attention.in_proj_weight",
+    "encoder.layers.4.norm2.weight",
+)
+
+
+def _loss(memory, score_maps, w, mean):
+    return mean(memory * w) * 100.0 + sum((s * s).mean() for s in score_maps)
+
+
+def test_full_size_training_step_matches_oracle_autograd():
+    m = build_hot_path(max_num_embedding=200)
+    sd0 = syn.det_state_dict(m.state_dict())
+    m.load_state_dict(sd0)
+    sizes = [(800, 1333)]
+    _, masks = syn.make_masks(sizes)
+    shapes = [tuple(x.shape[-2:]) for x in masks]
+    feats = syn.make_feats(1, shapes, 256, seed=0)
+    pos = [syn.sine_position_embedding(x, 128) for x in masks]
+
+    # ---- oracle: the same loss through the differentiable closed form on the host
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
+    out = R.hot_path(sd, feats, masks, pos, core=R.msda_core_torch)
+    w = syn.det_randn("train_full.w", tuple(out["memory"].shape))
+    rloss = _loss(out["memory"], out["score_maps"], w, lambda t: t.mean())
+    rloss.backward()
+
+    # ---- the product path: train mode, x3 Linear products, as bench.py's train_record sets it up
+    m = m.to(DEV).train()
+    use_x3_linear_(m)
+    params = dict(m.named_parameters())
+    missing = [n for n in CHECKED if n not in params or n not in sd]
+    assert not missing, missing
+    f = [t.to(DEV) for t in feats]
+    k = [t.to(DEV) for t in masks]
+    p = [t.to(DEV) for t in pos]
+    wd = w.to(DEV)
+
+    def forward_backward():
+        m.zero_grad(set_to_none=True)
+        memory, score_maps = m(f, k, p, image_sizes=sizes)
+        loss = _loss(memory, score_maps, wd, replay_safe_mean)
+        loss.backward()
+        return loss.detach()
+
+    loss = forward_backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - rloss.item()) < 2e-3 * max(1.0, abs(rloss.item())), (loss.item(), rloss.item())
+    eager = {n: params[n].grad.detach().clone() for n in CHECKED}
+    worst = {}
+    for n in CHECKED:
+        ref = sd[n].grad
+        scale = ref.abs().max().item()
+        assert scale > 0.0, n
+        err = (eager[n].cpu() - ref).abs().max().item()
+        worst[n] = err / scale
+        assert err < 5e-3 * scale, (n, err, scale)
+
+    # ---- the same step as a replayed hipGraph (the form bench.py times): gradients land in the captured tensors
+    forward_backward()   # (a second eager step: the pool's allocations settle before the capture)
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        forward_backward()
+    torch.cuda.current_stream().wait_stream(stream)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss_static = forward_backward()
+    captured = {n: params[n].grad for n in CHECKED}
+    for _ in range(3):   # replays on freshly poisoned gradient buffers: whatever the graph leaves there is its own work
+        for t in captured.values():
+            t.fill_(float("nan"))
+        g.replay()
+    torch.cuda.synchronize()
+    assert abs(loss_static.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    for n in CHECKED:
+        scale = eager[n].abs().max().item()
+        err = (captured[n] - eager[n]).abs().max().item()
+        assert err <= 2e-4 * scale, (n, err, scale)   # (fp32 atomics in the weight-gradient reductions: order varies)
+    print("full-size training step: worst gradient error / scale per parameter:",
+          {n: round(v, 6) for n, v in worst.items()})
