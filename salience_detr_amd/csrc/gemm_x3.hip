@@ -54,10 +54,10 @@ struct GemmArgs {
 // dh = (dy w2) * (h > 0) as epilogue 2 -- torch's clamp_min_ / threshold_backward passes over the [T, 2048] hidden state
 // (33 + 50 us per layer at 22 726 tokens) disappear.  NaN behaviour as torch's: relu(NaN) = NaN, a NaN gate lets the
 // gradient through.  Unsplit reductions only (an atomic partial sum cannot be clamped).
-__device__ __forceinline__ float gemm_epilogue(const GemmArgs &p, float v, int m, int n)
+__device__ __forceinline__ float gemm_epilogue(int epilogue, float v, float gate)
 {
-    if (p.epilogue == 1) return v < 0.f ? 0.f : v;
-    if (p.epilogue == 2) return p.gate[(int64_t)m * p.ldg + n] <= 0.f ? 0.f : v;
+    if (epilogue == 1) return v < 0.f ? 0.f : v;
+    if (epilogue == 2) return gate <= 0.f ? 0.f : v;
     return v;
 }
 
@@ -246,6 +246,42 @@ __device__ __forceinline__ void gemm_x3_step(const GemmArgs &p, TileLoad<A_KMAJO
     __syncthreads();   // every wave is done with this step's tiles
 }
 
+// C tile of one wave (2 x 2 MFMA accumulators of 32 x 32) to memory, lanes along n.  The gate values of an accumulator
+// (epilogue 2) are requested together before its stores: interleaved, every load waits behind the store in front of it
+// (the compiler must assume C and the gate alias): +77 us on the 22 726 x 2048 product that way.
+__device__ __forceinline__ void gemm_store_c(const GemmArgs &p, const g_f32x16_t (&acc)[2][2], int m_base, int n_base,
+                                             int lane, bool add_bias)
+{
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int n = n_base + 32 * ct + (lane & 31);
+        if (n >= p.N) continue;
+        const float bias = add_bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            float gv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gv[i] = 1.f;
+            if (p.epilogue == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = m_base + 32 * rt + g_acc_row(i, lane);
+                    if (m < p.M) gv[i] = __builtin_nontemporal_load(p.gate + (int64_t)m * p.ldg + n);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m_base + 32 * rt + g_acc_row(i, lane);
+                if (m < p.M) {
+                    float *dst = p.c + (int64_t)m * p.ldc + n;
+                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
+                    else *dst = gemm_epilogue(p.epilogue, acc[rt][ct][i] + bias, gv[i]);
+                }
+            }
+        }
+    }
+}
+
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
 {
@@ -297,23 +333,7 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_kernel(GemmArgs p)
         }
     }
     const bool add_bias = p.bias && blockIdx.z == 0;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int n = n0 + 64 * wn + 32 * ct + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = add_bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + 64 * wm + 32 * rt + g_acc_row(i, lane);
-                if (m < p.M) {
-                    float *dst = p.c + (int64_t)m * p.ldc + n;
-                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
-                    else *dst = gemm_epilogue(p, acc[rt][ct][i] + bias, m, n);
-                }
-            }
-    }
+    gemm_store_c(p, acc, m0 + 64 * wm, n0 + 64 * wn, lane, add_bias);
 }
 
 template <bool A_KMAJOR>
@@ -386,23 +406,7 @@ __global__ void __launch_bounds__(kGThreads, 2) gemm_x3_pre_kernel(GemmArgs p)
         if (k0 + kGK < kend) gemm_x3_pre_step<A_KMAJOR>(p, ta1, tb1, pa, pb, fa, fb, m0, n0, k0 + kGK, kend, tid, acc);
     }
     const bool add_bias = p.bias && blockIdx.z == 0;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int n = n0 + 64 * wn + 32 * ct + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = add_bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + 64 * wm + 32 * rt + g_acc_row(i, lane);
-                if (m < p.M) {
-                    float *dst = p.c + (int64_t)m * p.ldc + n;
-                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
-                    else *dst = gemm_epilogue(p, acc[rt][ct][i] + bias, m, n);
-                }
-            }
-    }
+    gemm_store_c(p, acc, m0 + 64 * wm, n0 + 64 * wn, lane, add_bias);
 }
 
 // ---- second generation (round 3): 256 x 128 x 32 tiles, one 8-wave workgroup per CU ---------------------------------
@@ -685,23 +689,7 @@ __global__ void __launch_bounds__(kV2Threads, 1) gemm_x3_v2_kernel(GemmArgs p)
         }
     }
     const bool add_bias = p.bias && blockIdx.z == 0;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int n = n0 + 64 * wn + 32 * ct + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = add_bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + 64 * wm + 32 * rt + g_acc_row(i, lane);
-                if (m < p.M) {
-                    float *dst = p.c + (int64_t)m * p.ldc + n;
-                    if (p.atomic) unsafeAtomicAdd(dst, acc[rt][ct][i] + bias);
-                    else *dst = gemm_epilogue(p, acc[rt][ct][i] + bias, m, n);
-                }
-            }
-    }
+    gemm_store_c(p, acc, m0 + 64 * wm, n0 + 64 * wn, lane, add_bias);
 }
 
 // planes[pl][i][j] = plane pl of (transpose ? w[j][i] : w[i][j]); rows_out x cols_out = transpose ? cols x rows : rows x cols
