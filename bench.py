@@ -143,19 +143,7 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     # ground-truth boxes staged on the device once (the data loader's side); the target maps are built every step
     staged = criterion.stage_boxes(targets, sizes, device)
 
-    # the ~100 small zero-initialised gradient workspaces of a step (weight / bias gradient pairs of the split-reduction
-    # GEMMs, LayerNorm gamma / beta sums) come out of one buffer cleared by ONE fill at the start of the step
-    from salience_detr_amd.zero_arena import ZeroArena, zero_arena
-    arena = None if os.environ.get("SDETR_NO_ZERO_ARENA") else ZeroArena(device)
-
     def forward_backward():
-        if arena is None:
-            return forward_backward_body()
-        with zero_arena(arena):
-            arena.begin_step()   # (after the optimizer step consumed the previous step's gradients)
-            return forward_backward_body()
-
-    def forward_backward_body():
         nonlocal w
         opt.zero_grad(set_to_none=True)
         memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
