@@ -302,6 +302,23 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
         msda_mod.ms_deform_attn_backward = real_bwd
     tot_us = sum(e0.elapsed_time(e1) for e0, e1 in evs) * 1e3
     achieved = sum(nbytes) / tot_us / 1e3
+    # HBM bytes of the op at the LARGEST layer (11 363 queries, batch 2) from committed counter passes, reported only while
+    # the backward kernels' sources are the ones the passes ran on
+    bwd_traffic, bwd_traffic_at, bwd_traffic_src = None, None, "null: no committed counter passes (profiles/r04_msda_bwd_traffic.json)"
+    try:
+        import hashlib
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_msda_bwd_traffic.json")))
+        h = hashlib.sha256()
+        for f in tj["sources"]:
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        if h.hexdigest()[:16] == tj["source_tag"] and tj["batch"] == args.batch:
+            bwd_traffic = int(tj["hbm_bytes_per_op"])
+            bwd_traffic_at = {"num_query": tj["num_query"], "algorithmic_bytes": max(nbytes) if nbytes else None}
+            bwd_traffic_src = "profiles/r04_msda_bwd_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the op at %d queries, sources %s)" % (tj["num_query"], tj["source_tag"])
+        else:
+            bwd_traffic_src = "null: committed passes were measured on other kernel sources or another batch size"
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "metric": "images/s (whole node) + ms/encoder-layer, ResNet50 800x1333",
         "value": round(world * args.batch * steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
@@ -318,7 +335,7 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
         "roofline": {"kernel": "MSDA backward op: sdetr::bt_main_kernel (fixed-point LDS windows) + bucketing, "
                                "sdetr::msda_col2im_chan_kernel below 1200 queries", "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": bwd_traffic, "traffic_at": bwd_traffic_at, "traffic_source": bwd_traffic_src,
                      "avg_launch_us": round(tot_us / max(1, len(evs)), 1)},
         "loss": final_loss,   # of the last timed step, `steps` AdamW updates after the initial state
         "loss_trace": loss_trace,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes over the MSDA BACKWARD kernels (LDS-accumulating bt_main_kernel + bucketing, and the direct
 # global-atomic kernel) at one layer size (GPU box, via gpurun).
-#   bash benchmarks/pmc_msda_bwd.sh <tag> [NQ] [BATCH]   -> gpurun_out/<tag>_msda_bwd_pmc.md
+#   bash benchmarks/pmc_msda_bwd.sh <tag> [NQ] [BATCH]   -> gpurun_out/<tag>_msda_bwd_pmc.md, <tag>_msda_bwd_traffic.json
 # Counter passes carry --kernel-trace only (no other trace domain), one --pmc set per pass.
 set -u
 TAG=${1:-r04}
@@ -22,5 +22,6 @@ for set in \
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${TAG}_bwdpmc_$i -o p -- $CMD > /dev/null 2> $O/${TAG}_bwdpmc_$i.err
 done
-python benchmarks/pmc_summary.py $O/${TAG}_bwdpmc_ $O/${TAG}_msda_bwd_pmc.md "$NQ" "$B" "bt_main|bt_tile|bt_order|bt_clear|msda_col2im" "MSDA backward kernels (reference layout, fp32)" > /dev/null
+SDETR_TRAFFIC_SOURCES="salience_detr_amd/csrc/msda_backward_tiled.hip salience_detr_amd/csrc/msda_backward.hip" SDETR_TRAFFIC_OP_REGEX="bt_" \
+  python benchmarks/pmc_summary.py $O/${TAG}_bwdpmc_ $O/${TAG}_msda_bwd_pmc.md "$NQ" "$B" "bt_main|bt_tile|bt_order|bt_clear|msda_col2im" "MSDA backward kernels (reference layout, fp32)" $O/${TAG}_msda_bwd_traffic.json > /dev/null
 rm -rf $O/${TAG}_bwdpmc_[1-6]

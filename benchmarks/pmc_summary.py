@@ -1,5 +1,7 @@
 """Mean per-launch value of every counter rocprofv3 collected for the sdetr:: MSDA kernels -> a markdown table.
-usage: pmc_summary.py <dir prefix> <out.md> <nq> <batch> [kernel-name regex, default "msda"] [title]"""
+usage: pmc_summary.py <dir prefix> <out.md> <nq> <batch> [kernel-name regex, default "msda"] [title] [traffic.json]
+traffic.json (optional): HBM bytes per launch of every matched kernel, (2 * FETCH_SIZE + WRITE_SIZE) KiB as
+pmc_to_traffic.py derives them, tagged with the sha256 of the source files named in SDETR_TRAFFIC_SOURCES."""
 import collections
 import csv
 import glob
@@ -33,3 +35,27 @@ with open(out, "w") as fh:
             fh.write(f"| {c} | {sum(v)/len(v):,.0f} |\n")
         fh.write("\n")
 print(open(out).read())
+
+if len(sys.argv) > 7:
+    import hashlib
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    srcs = os.environ.get("SDETR_TRAFFIC_SOURCES", "").split()
+    for f in srcs:
+        h.update(open(os.path.join(root, f), "rb").read())
+    per = {}
+    for k in sorted(agg):
+        if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            f_, w_ = (sum(agg[k][c]) / len(agg[k][c]) for c in ("FETCH_SIZE", "WRITE_SIZE"))
+            ds = sorted(dur[k])
+            per[k] = {"FETCH_SIZE_KiB": round(f_, 1), "WRITE_SIZE_KiB": round(w_, 1), "hbm_bytes": int((2 * f_ + w_) * 1024),
+                      "median_us_under_counters": round(ds[len(ds) // 2], 1)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace; benchmarks/pmc_summary.py",
+               "units": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 note in MI355X_MICROARCH.md",
+               "num_query": int(nq), "batch": int(batch), "sources": srcs, "source_tag": h.hexdigest()[:16],
+               "per_kernel": per, "op_kernels": os.environ.get("SDETR_TRAFFIC_OP_REGEX", ".*"),
+               "hbm_bytes_per_op": sum(v["hbm_bytes"] for k, v in per.items()
+                                       if re.search(os.environ.get("SDETR_TRAFFIC_OP_REGEX", ".*"), k))},
+              open(sys.argv[7], "w"), indent=1)

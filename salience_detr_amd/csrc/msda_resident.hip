@@ -894,6 +894,9 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         }
     };
     {
+        // (one copy of the body with the input set moved between iterations -- 12.5 KB of code instead of 22.6 -- runs the
+        // same time in the step, 121.8 / 122.2 against 122.3 / 121.4 us over the six launches: the cold-launch penalty is not
+        // instruction fetch)
         RowIn in_b;
         for (int rg = wave; rg < ngroups; rg += 2 * kRWaves) {
             row_group(rg, nxt, in_b);
