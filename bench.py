@@ -143,19 +143,7 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     # ground-truth boxes staged on the device once (the data loader's side); the target maps are built every step
     staged = criterion.stage_boxes(targets, sizes, device)
 
-    # the ~100 small zero-initialised gradient workspaces of a step (weight / bias gradient pairs of the split-reduction
-    # GEMMs, LayerNorm gamma / beta sums) come out of one buffer cleared by ONE fill at the start of the step
-    from salience_detr_amd.zero_arena import ZeroArena, zero_arena
-    arena = None if os.environ.get("SDETR_NO_ZERO_ARENA") else ZeroArena(device)
-
     def forward_backward():
-        if arena is None:
-            return forward_backward_body()
-        with zero_arena(arena):
-            arena.begin_step()   # (after the optimizer step consumed the previous step's gradients)
-            return forward_backward_body()
-
-    def forward_backward_body():
         nonlocal w
         opt.zero_grad(set_to_none=True)
         memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
@@ -343,7 +331,6 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
                                   "forward + backward" if use_ranks_path else "single GPU",
                    "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params),
                    "execution": graph_note, "x3_linear": bool(args.x3_linear), "world_size": world,
-                   "zero_arena": None if arena is None else {"bytes_per_step": 4 * arena.high_water, "fallbacks": arena.misses},
                    "backend": (dist.get_backend() if dist is not None else "none (single process)")},
         "roofline": {"kernel": "MSDA backward op: sdetr::bt_main_kernel (fixed-point LDS windows) + bucketing, "
                                "sdetr::msda_col2im_chan_kernel below 1200 queries", "bound": "hbm",

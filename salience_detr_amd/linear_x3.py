@@ -17,7 +17,6 @@ from torch.autograd import Function
 from torch.nn import functional as F
 
 from . import _hip
-from .zero_arena import zeros as _zeros
 
 
 EPI_NONE, EPI_RELU, EPI_GATE = 0, 1, 2   # SDETR_GEMM_EPI_* (include/salience_hip.h)
@@ -188,10 +187,10 @@ class _LinearX3(Function):
                 out = None
                 if want_gb:   # the kernel has dy's tiles in registers anyway: the bias gradient is their row sums
                     # (one zero fill for both gradients: the split reduction adds into dw as the row sums add into db)
-                    buf = _zeros((N * K + N,), g2.device)
+                    buf = torch.zeros(N * K + N, dtype=torch.float32, device=g2.device)
                     out, gb = buf[:N * K].view(N, K), buf[N * K:]
                 elif splits > 1:
-                    out = _zeros((N, K), g2.device)
+                    out = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
                 gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=splits, out=out, a_row_sum=gb)
                 if out is not None:
                     gw = out
@@ -210,10 +209,10 @@ def _weight_and_bias_grad(g2: Tensor, x2: Tensor, want_gb: bool):
     splits = _weight_grad_splits(T, N, K)
     out = gb = None
     if want_gb:
-        buf = _zeros((N * K + N,), g2.device)
+        buf = torch.zeros(N * K + N, dtype=torch.float32, device=g2.device)
         out, gb = buf[:N * K].view(N, K), buf[N * K:]
     elif splits > 1:
-        out = _zeros((N, K), g2.device)
+        out = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
     gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=splits, out=out, a_row_sum=gb)
     return (gw if out is None else out), gb
 

@@ -210,30 +210,3 @@ def test_graph_lanes_input_structure_checks_and_device_requirement():
     with pytest.raises(ValueError):
         GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=0)
 
-
-
-def test_zero_arena_hands_out_zeroed_slices_and_falls_back():
-    """One fill per step for the small zero-initialised workspaces (salience_detr_amd/zero_arena.py): slices are disjoint,
-    16-byte aligned, zero again after begin_step(); requests that do not fit, other dtypes and no active arena fall back
-    to torch.zeros."""
-    import torch
-    from salience_detr_amd.zero_arena import ZeroArena, active, zero_arena, zeros
-    assert active() is None and zeros((3, 5), "cpu").shape == (3, 5)
-    arena = ZeroArena("cpu", capacity_bytes=4096, max_item_bytes=1024)
-    with zero_arena(arena):
-        assert active() is arena
-        arena.begin_step()
-        a, b = zeros((7, 9), "cpu"), zeros((10,), "cpu")
-        assert a.data_ptr() != b.data_ptr() and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
-        assert a.untyped_storage().data_ptr() == arena.buf.untyped_storage().data_ptr()
-        a += 1.0
-        b += 2.0
-        big = zeros((257,), "cpu")            # more than max_item_bytes: not from the arena
-        assert big.untyped_storage().data_ptr() != arena.buf.untyped_storage().data_ptr() and arena.misses == 1
-        assert zeros((4,), "cpu", dtype=torch.float64).dtype == torch.float64
-        while zeros((200,), "cpu").untyped_storage().data_ptr() == arena.buf.untyped_storage().data_ptr():
-            pass                              # until the capacity is exhausted: then torch.zeros
-        arena.begin_step()
-        a2 = zeros((7, 9), "cpu")
-        assert a2.data_ptr() == a.data_ptr() and float(a2.abs().sum()) == 0.0 and float(arena.buf.abs().sum()) == 0.0
-    assert active() is None

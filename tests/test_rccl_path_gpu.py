@@ -61,7 +61,3 @@ def test_training_step_through_a_one_rank_rccl_group_matches_the_single_process_
     # on the benchmark's data), so agreement to 1e-4 is agreement of every gradient that matters
     assert a["loss"] < 4.0
     assert b["config"]["grad_bytes"] == a["config"]["grad_bytes"] > 0
-    # the small zero-initialised gradient workspaces really come out of the step's arena (the requests are made from autograd's
-    # backward thread: a thread-local arena was invisible there) on every execution path, with nothing falling back
-    for r in (a, b, c):
-        assert r["config"]["zero_arena"]["bytes_per_step"] > 1 << 20 and r["config"]["zero_arena"]["fallbacks"] == 0, r["config"]
