@@ -46,6 +46,24 @@ CHECKED = (
 )
 
 
+def _compare(got, ref, name):
+    """(worst error / the gradient's scale, rows left out).  The ReLU's gate is discontinuous: a hidden unit whose
+    pre-activation is within rounding of zero for some token (expected: ~1e-6 of the T x 2048 of them, a handful per layer)
+    is on in one run and off in the other -- GPU against host, or two GPU runs whose split reductions add in another order
+    -- and that token's whole contribution dh[t, j] * x[t] appears in / vanishes from row j of linear1's gradient: a few
+    percent of a row that sums ~1000 active tokens.  Rows of linear1's gradients are therefore compared one by one and the
+    few beyond 1e-2 counted instead of bounded."""
+    scale = ref.abs().max().item()
+    assert scale > 0.0, name
+    err = (got - ref).abs() / scale
+    off = 0
+    if ".linear1." in name:
+        per_row = err.reshape(err.shape[0], -1).max(1)[0]
+        off = int((per_row > 1e-2).sum())
+        err = per_row[per_row <= 1e-2] if off else per_row
+    return err.max().item(), off
+
+
 def _loss(memory, score_maps, w, mean):
     return mean(memory * w) * 100.0 + sum((s * s).mean() for s in score_maps)
 
@@ -122,19 +140,7 @@ def test_full_size_training_step_matches_oracle_autograd():
     eager = {n: params[n].grad.detach().clone() for n in CHECKED}
     worst, off_rows = {}, {}
     for n in CHECKED:
-        ref = sd[n].grad
-        scale = ref.abs().max().item()
-        assert scale > 0.0, n
-        err = (eager[n].cpu() - ref).abs() / scale
-        if ".linear1." in n:
-            # the ReLU's gate is discontinuous: a hidden unit whose pre-activation is within rounding of zero for some token
-            # (expected: ~1e-6 of the T x 2048 of them, a handful per layer) is on for one side and off for the other, and that
-            # token's whole contribution dh[t, j] * x[t] appears in / vanishes from row j -- a few percent of a row that sums
-            # ~1000 active tokens.  Rows of linear1's gradient are therefore compared one by one: all but a few within the bar
-            per_row = err.reshape(err.shape[0], -1).max(1)[0]
-            off_rows[n] = int((per_row > 1e-2).sum())
-            err = per_row[per_row <= 1e-2] if off_rows[n] else per_row
-        worst[n] = err.max().item()
+        worst[n], off_rows[n] = _compare(eager[n].cpu(), sd[n].grad, n)
     print("full-size training step: worst gradient error / scale per parameter:", {n: round(v, 6) for n, v in worst.items()})
     # (fp32 on both sides, but sums over up to 22 323 tokens in different orders, exact-split matrix-core products against
     # the host's fp32 GEMMs, and fixed-point accumulation in the MSDA backward: measured 1e-6 .. 6e-3 of a gradient's scale;
@@ -166,8 +172,7 @@ def test_full_size_training_step_matches_oracle_autograd():
     torch.cuda.synchronize()
     assert abs(loss_static.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
     for n in CHECKED:
-        scale = eager[n].abs().max().item()
-        err = (captured[n] - eager[n]).abs().max().item()
-        # (fp32 atomics in the MSDA backward's flush and in the split weight-gradient reductions: the order of the additions
-        # varies from run to run -- measured up to 3e-4 of a gradient's scale between two runs of the same step)
-        assert err <= 2e-3 * scale, (n, err, scale)
+        # (fp32 atomics in the MSDA backward's flush and in the split reductions of the Linear products: the order of the
+        # additions varies from run to run -- measured up to 3e-4 of a gradient's scale between two runs of the same step)
+        v, off = _compare(captured[n], eager[n], n)
+        assert v <= 2e-3 and off <= 20, (n, v, off)
