@@ -4,8 +4,8 @@
 # training step and the standalone micro-benchmarks.      bash benchmarks/profile_round.sh r03
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 # Counter passes carry --kernel-trace only (no other trace domain), one --pmc set per pass.
-# (The survey's full CPU-baseline protocol -- minutes of host time -- is `python bench.py --cpu-protocol full`; the
-# committed run of it is profiles/r02_bench_cpu_full.json: the CPU oracle has not changed since.)
+# (The survey's full CPU-baseline protocol -- minutes of host time -- runs last when FULL_CPU=1:
+# `python bench.py --cpu-protocol full` -> <tag>_bench_cpu_full.json.)
 set -u
 R=${1:-r04}
 O=$PWD/gpurun_out
@@ -22,6 +22,9 @@ W=$(find $O/${R}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 python benchmarks/pmc_to_traffic.py $F $W $O/${R}_bench_quick.json $O/${R}_msda_traffic.json && \
   cp $O/${R}_msda_traffic.json profiles/r04_msda_traffic.json      # (this box's copy: what the bench run below reads)
 rm -rf $O/${R}_pmc_FETCH_SIZE $O/${R}_pmc_WRITE_SIZE
+#    ... and the backward op's counters (the train_step record reads profiles/r04_msda_bwd_traffic.json)
+bash benchmarks/pmc_msda_bwd.sh ${R} 11363 2 > /dev/null 2>&1
+cp $O/${R}_msda_bwd_traffic.json profiles/r04_msda_bwd_traffic.json 2> /dev/null
 # 2. the kernel summary of the plain timed loop (six layers in equal proportion) FIRST: the bench line's
 #    roofline.timing_rocprof_us is read from profiles/r04_msda_rocprof.json; then the official bench line (with the
 #    train_step sub-record, the config sub-records and the CPU baseline)
@@ -52,7 +55,6 @@ head -8 $O/${R}_bench_kernel_stats.csv | cut -c1-150
 bash benchmarks/pmc_msda.sh ${R} 11363 2 > /dev/null 2>&1
 mv $O/${R}_pmc_summary.md $O/${R}_msda_pmc.md 2> /dev/null
 rm -rf $O/${R}_pmc_[1-5]
-bash benchmarks/pmc_msda_bwd.sh ${R} 11363 2 > /dev/null 2>&1
 # 4. MFMA-busy counters of the dense kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES \
   --kernel-trace --output-format csv -d $O/${R}_mfma_1 -o p -- \
@@ -84,6 +86,7 @@ rm -rf $O/${R}_prof_train
 #    the fp32-accurate GEMM on the step's Linear shapes, both generations against the library
 python benchmarks/gemm_x3_bench.py > $O/${R}_gemm_x3.json 2> /dev/null
 python benchmarks/train_op_profile.py > $O/${R}_train_ops.txt 2> /dev/null
+python benchmarks/gemm_epilogue_probe.py --out $O/${R}_gemm_epilogue.json > /dev/null 2>&1
 # 7. standalone micro-benchmarks of this round (built by benchmarks/micro/build.sh)
 for m in l2_prefetch hsort_phases mfma_valu_overlap; do
   [ -x benchmarks/micro/$m ] && timeout 60 ./benchmarks/micro/$m > $O/${R}_$m.json 2> /dev/null
@@ -95,4 +98,7 @@ done
   for K in 64 1024 2048; do timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 22726 $K 2048 | sed 's/$/,/'; done
   SDETR_GEMM_X3_V1=1 timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 | sed 's/}$/, "generation": "128x128 tiles"}/'
   echo ']}' ) > $O/${R}_gemm_x3_ablate.json 2> /dev/null
+if [ "${FULL_CPU:-0}" = "1" ]; then
+  python bench.py --cpu-protocol full --train-steps 0 --in-flight-report 0 --config-steps 0 > $O/${R}_bench_cpu_full.json 2> $O/${R}_bench_cpu_full.err
+fi
 ls $O | grep "^${R}" | head -40

@@ -172,7 +172,10 @@ def test_full_size_training_step_matches_oracle_autograd():
     torch.cuda.synchronize()
     assert abs(loss_static.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
     for n in CHECKED:
-        # (fp32 atomics in the MSDA backward's flush and in the split reductions of the Linear products: the order of the
-        # additions varies from run to run -- measured up to 3e-4 of a gradient's scale between two runs of the same step)
+        # Two runs of the same step are not bit-identical: fp32 atomics (MSDA backward flush, split reductions of the Linear
+        # products) add in a different order, a pre-activation within that noise of zero flips its ReLU gate, and the ONE
+        # token whose dh[t, j] appears or vanishes moves every gradient upstream of it by up to ~1/T of its scale times that
+        # token's weight -- measured 3e-4 .. 2.1e-3 between runs (T = 2272 rows in the last layer).  What this check is
+        # for -- a replay that drops work (CHANGELOG round 4: memset nodes) -- shows as NaNs or order-one errors.
         v, off = _compare(captured[n], eager[n], n)
-        assert v <= (1e-2 if ".linear1." in n else 2e-3) and off <= 20, (n, v, off)   # (linear1: rows with a gate flip in a weak unit)
+        assert v <= (1e-2 if ".linear1." in n else 5e-3) and off <= 20, (n, v, off)
