@@ -15,7 +15,7 @@ steps = int([r for r in rows if "pyramid_flatten" in r["Name"]][0]["Calls"])
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e3
 pick = {}
 for r in rows:
-    for key in ("msda_bordered", "msda_resident", "row_orders", "fused_attn_proj", "ffn_fused_kernel<true, true>", "topk_hsort"):
+    for key in ("msda_bordered", "msda_resident", "row_orders", "fused_attn_proj", "ffn_fused_kernel<true, true>", "topk_hsort", "encoder_prepare", "pyramid_flatten", "finalize_sorted"):
         if key in r["Name"]:
             pick[key] = pick.get(key, 0) + float(r["TotalDurationNs"]) / steps / 1e3
 try:
