@@ -132,6 +132,20 @@ __global__ void __launch_bounds__(kBlock) finalize_sorted_kernel(const T *tokens
                                                                  int64_t total, int n0, int c_last, int S, int C, T *out)
 {
     const int cpr = C / 8;
+    if (total < ((int64_t)1 << 31)) {
+        // 32-bit index arithmetic (three 64-bit divisions per 16-byte piece were most of this kernel's instructions)
+        const uint32_t ucpr = (uint32_t)cpr, un0 = (uint32_t)n0;
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < (uint32_t)total; t += gridDim.x * blockDim.x) {
+            const uint32_t r = t / ucpr, ch = (t - r * ucpr) * 8u;  // r = b*n0 + i
+            const uint32_t b = r / un0, i = r - b * un0;
+            const int64_t tok = (int64_t)b * S + sorted_index[r];
+            const bool live = !count || (int64_t)i < count[b];
+            const T *base = live ? result + (int64_t)r * C + ch : tokens + tok * C + ch;
+            const bool bg = (int)i >= c_last && !(pad && pad[tok]);
+            add8<T>(base, background + (tok - (int64_t)b * S) * C + ch, bg, out + tok * C + ch);
+        }
+        return;
+    }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(t % cpr) * 8;

@@ -63,7 +63,8 @@ __device__ __forceinline__ void finalize_all_role(const FinalizeJob &j, int role
         const uint4 a = j.tokens[t];
         uint4 o = a;
         if (!(j.pad && j.pad[r])) {
-            const uint4 g = j.background[(r % j.S) * 32 + piece];
+            // (r < 2^31 is checked where the job is built: a 32-bit modulo instead of a 64-bit one per piece)
+            const uint4 g = j.background[(int64_t)((uint32_t)r % (uint32_t)j.S) * 32 + piece];
             o = make_uint4(pack_bf16x2(bf16_lo(a.x) + bf16_lo(g.x), bf16_hi(a.x) + bf16_hi(g.x)),
                            pack_bf16x2(bf16_lo(a.y) + bf16_lo(g.y), bf16_hi(a.y) + bf16_hi(g.y)),
                            pack_bf16x2(bf16_lo(a.z) + bf16_lo(g.z), bf16_hi(a.z) + bf16_hi(g.z)),
@@ -213,6 +214,8 @@ extern "C" int sdetr_stage1_x3_with_jobs(
         fj.tokens = (const uint4 *)finalize->tokens; fj.background = (const uint4 *)finalize->background;
         fj.pad = finalize->padding_mask; fj.out = (uint4 *)finalize->out; fj.S = finalize->spatial_size;
         fj.total = (int64_t)finalize->batch * finalize->spatial_size * 32;
+        if ((int64_t)finalize->batch * finalize->spatial_size >= ((int64_t)1 << 31))
+            return fail("stage1_x3_with_jobs: finalize job too large for 32-bit token arithmetic");
         n4 = 128;   // 65 536 threads in a grid-stride loop over the 16-byte pieces
     }
     if (!vp_x) {
