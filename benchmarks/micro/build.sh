@@ -15,3 +15,5 @@ for v in 0 1 2 3 4 5 6; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DSDETR_GX3_ABLATE=$v -I ../../include \
     -o gemm_x3_ablate_$v gemm_x3_ablate.hip 2> /dev/null && echo "built gemm_x3_ablate_$v"
 done
+# the library's benchmark build (ablated MSDA instantiations + phase stamps) for benchmarks/msda_bordered_ab.py --ablate / --stamps
+python ../../salience_detr_amd/csrc/build.py --ablations > /dev/null && echo "built libsalience_hip_ablate.so"

@@ -11,6 +11,10 @@ import json
 import os
 import sys
 
+# the ablated kernels and the phase stamps live in the benchmark build of the library only
+if any(a.startswith(("--ablate", "--stamps")) for a in sys.argv[1:]):
+    os.environ.setdefault("SDETR_HIP_LIBRARY", "libsalience_hip_ablate.so")
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -12,6 +12,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsalience_hip.so")
+# Benchmarks that time deliberately crippled instantiations of a kernel load the benchmark build instead (same ABI + the
+# ablations; `csrc/build.py --ablations`).  The variable names a FILE INSIDE THIS PACKAGE: nothing outside it is loaded.
+if os.environ.get("SDETR_HIP_LIBRARY"):
+    LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ["SDETR_HIP_LIBRARY"]))
 
 F32, BF16, F16 = 0, 1, 2
 EINVAL = -1

@@ -22,6 +22,33 @@ def _stale(out, deps):
     return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
+# benchmark build: msda_resident.hip with its ablated instantiations and phase stamps (wrong results by construction:
+# never part of the product library), every other object shared with the product build
+ABLATE_LIB = os.path.join(os.path.dirname(HERE), "libsalience_hip_ablate.so")
+ABLATE_SOURCES = {"msda_resident.hip": ["-DSDETR_MSDA_ABLATIONS"]}
+
+
+def build_ablations(force: bool = False, verbose: bool = False) -> str:
+    build(force=force, verbose=verbose)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(ROOT, "include", "salience_hip.h")]
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if src in ABLATE_SOURCES:
+            s = os.path.join(HERE, src)
+            o = os.path.join(OBJ_DIR, src.replace(".hip", ".ablate.o"))
+            if force or _stale(o, [s] + headers):
+                cmd = [hipcc, *FLAGS, *ABLATE_SOURCES[src], "-x", "hip", "-c", s, "-o", o]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                subprocess.run(cmd, check=True)
+        objs.append(o)
+    if force or _stale(ABLATE_LIB, objs):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", ABLATE_LIB], check=True)
+    return ABLATE_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -46,3 +73,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--ablations" in sys.argv:
+        print(build_ablations(force="--force" in sys.argv, verbose=True))

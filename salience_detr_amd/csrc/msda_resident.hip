@@ -1047,9 +1047,15 @@ extern "C" int64_t sdetr_msda_bordered_records(const int32_t *level_hw_host, int
 
 extern "C" int sdetr_msda_bordered_max_resident_records(void) { return kBMaxResidentPx; }
 
-// benchmarks only: device buffer of [workgroups][4] uint64 for the SDETR_MSDA_ABLATE=32 phase stamps
+// The ablated instantiations of the kernel (wrong results by construction) and the phase stamps exist only in the
+// benchmark build of this file (-DSDETR_MSDA_ABLATIONS: `python salience_detr_amd/csrc/build.py --ablations` ->
+// libsalience_hip_ablate.so, loaded by benchmarks/msda_bordered_ab.py / msda_real_operands.py); the product library ignores
+// SDETR_MSDA_ABLATE and does not export sdetr_msda_debug_stamps.
+#ifdef SDETR_MSDA_ABLATIONS
+// device buffer of [workgroups][4] uint64 for the SDETR_MSDA_ABLATE=32 phase stamps
 static unsigned long long *g_stamps = nullptr;
 extern "C" void sdetr_msda_debug_stamps(void *device_buffer) { g_stamps = static_cast<unsigned long long *>(device_buffer); }
+#endif
 
 extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *value_bordered, int value_dtype,
                                            const int32_t *level_hw_host, const float *ref, int ref_dim,
@@ -1141,6 +1147,7 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
         if (a.perm) SDETR_B_LAUNCH(REF4, RES, SER, true);                                                           \
         else SDETR_B_LAUNCH(REF4, RES, SER, false);                                                                 \
     } while (0)
+#ifdef SDETR_MSDA_ABLATIONS
 #define SDETR_B_LAUNCH_ABL(ABL)                                                                                     \
     do {                                                                                                            \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bordered_kernel<false, 2, false, true, ABL>), \
@@ -1177,6 +1184,7 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
             return check_launch("msda_bordered (ablated)");
         }
     }
+#endif   // SDETR_MSDA_ABLATIONS
 #define SDETR_B_PICK(REF4, RES)                                                                                     \
     do {                                                                                                            \
         if (a.image_serial) SDETR_B_PICK2(REF4, RES, true);                                                         \
