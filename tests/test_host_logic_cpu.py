@@ -209,4 +209,3 @@ def test_graph_lanes_input_structure_checks_and_device_requirement():
             GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=1)
     with pytest.raises(ValueError):
         GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=0)
-
