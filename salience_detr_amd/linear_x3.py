@@ -283,8 +283,11 @@ class _FfnX3(Function):
 
 
 def x3_ffn_applies(x: Tensor, linear1: nn.Linear, linear2: nn.Linear) -> bool:
-    return (X3_DW and x3_linear_applies(x, linear1.weight, linear1.bias) and linear2.weight.is_cuda
-            and x3_linear_applies(x.new_empty((1, linear1.weight.shape[0])), linear2.weight, linear2.bias))
+    """Both layers meet ``x3_linear_applies`` (fp32 HIP tensors, feature counts multiples of 4) and chain."""
+    w2, b2 = linear2.weight, linear2.bias
+    return (X3_DW and x3_linear_applies(x, linear1.weight, linear1.bias) and w2.is_cuda and w2.dtype == torch.float32
+            and w2.dim() == 2 and w2.is_contiguous() and w2.shape[1] == linear1.weight.shape[0] and w2.shape[0] % 4 == 0
+            and w2.shape[1] % 4 == 0 and (b2 is None or (b2.dtype == torch.float32 and b2.is_contiguous())))
 
 
 def x3_ffn(x: Tensor, linear1: nn.Linear, linear2: nn.Linear) -> Tensor:
