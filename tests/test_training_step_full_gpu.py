@@ -3,12 +3,18 @@ oracle -- one 800x1333 image, E = 256, six layers, fp32, Linear products on the 
 and as a replayed hipGraph (reference: `util/engine.py:44-64` around `SalienceTransformer.forward`,
 `models/bricks/salience_transformer.py:97-183`).
 
-Checks: the loss, and the gradients of a handful of parameters from every stage of the path (position
+Checks, against the oracle AND against the imported reference's own forward + backward
+(`tests/golden/hotpath_train_full.npz`): the loss, and the gradients of a handful of parameters from every stage of the path (position
 embedding, salience head, the coarse-to-fine `alpha`, deformable attention projections, feed-forward, the 300-row
 attention, LayerNorm), within 1e-2 of each gradient's own scale (8e-2 for a layer whose top-300 set differs from the oracle's by a token); and that the replayed graph reproduces the eager step's
 gradients (the round-4 finding: memset nodes are not replayed on this stack -- `CHANGELOG.md`)."""
+import os
+
+import numpy as np
 import pytest
 import torch
+
+import train_step_compare as C
 
 from oracle import salience_ref as R
 from salience_detr_amd import synthetic as syn
@@ -19,53 +25,9 @@ from salience_detr_amd.salience_filtering import replay_safe_mean
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-CHECKED = (
-    "level_embeds",
-    "alpha",
-    "enc_mask_predictor.layer1.1.weight",
-    "enc_mask_predictor.layer2.4.weight",
-    "enc_output.weight",
-    "encoder.layers.0.self_attn.sampling_offsets.weight",
-    "encoder.layers.0.self_attn.attention_weights.bias",
-    "encoder.layers.0.self_attn.value_proj.weight",
-    "encoder.layers.2.self_attn.output_proj.weight",
-    "encoder.layers.0.linear1.weight",
-    "encoder.layers.0.linear1.bias",
-    "encoder.layers.3.linear2.weight",
-    "encoder.layers.5.linear1.weight",
-    "encoder.layers.5.linear1.bias",
-    "encoder.layers.5.linear2.weight",
-    "encoder.layers.5.norm1.weight",
-    "encoder.layers.5.norm2.weight",
-    "encoder.layers.5.self_attn.output_proj.weight",
-    "encoder.layers.5.self_attn.value_proj.weight",
-    "encoder.layers.4.linear1.weight",
-    "encoder.layers.2.linear1.weight",
-    "encoder.layers.1.pre_attention.in_proj_weight",
-    "encoder.layers.4.norm2.weight",
-)
-
-
-def _compare(got, ref, name):
-    """(worst error / the gradient's scale, rows left out).  The ReLU's gate is discontinuous: a hidden unit whose
-    pre-activation is within rounding of zero for some token (expected: ~1e-6 of the T x 2048 of them, a handful per layer)
-    is on in one run and off in the other -- GPU against host, or two GPU runs whose split reductions add in another order
-    -- and that token's whole contribution dh[t, j] * x[t] appears in / vanishes from row j of linear1's gradient: a few
-    percent of a row that sums ~1000 active tokens.  Rows of linear1's gradients are therefore compared one by one and the
-    few beyond 1e-2 counted instead of bounded."""
-    scale = ref.abs().max().item()
-    assert scale > 0.0, name
-    err = (got - ref).abs() / scale
-    off = 0
-    if ".linear1." in name:
-        per_row = err.reshape(err.shape[0], -1).max(1)[0]
-        off = int((per_row > 1e-2).sum())
-        err = per_row[per_row <= 1e-2] if off else per_row
-    return err.max().item(), off
-
-
-def _loss(memory, score_maps, w, mean):
-    return mean(memory * w) * 100.0 + sum((s * s).mean() for s in score_maps)
+FIXTURE = np.load(os.path.join(os.path.dirname(__file__), "golden", "hotpath_train_full.npz"))
+CHECKED = tuple(FIXTURE["names"].tolist())   # the parameters the reference fixture holds gradients of
+_compare, _loss = C.compare, C.loss_fn
 
 
 def test_full_size_training_step_matches_oracle_autograd():
@@ -145,6 +107,17 @@ def test_full_size_training_step_matches_oracle_autograd():
     # (fp32 on both sides, but sums over up to 22 323 tokens in different orders, exact-split matrix-core products against
     # the host's fp32 GEMMs, and fixed-point accumulation in the MSDA backward: measured 1e-6 .. 6e-3 of a gradient's scale;
     # the parameters of a layer whose top-300 set differs by a token: a few percent)
+    # ---- ... and against the gradients the IMPORTED REFERENCE produced on the same inputs (hotpath_train_full.npz: its
+    # pure-PyTorch MSDA, fp32, sub-sampled as tests/golden/make_golden.py `sub` stores them)
+    assert abs(loss.item() - float(FIXTURE["loss"])) < 2e-3 * max(1.0, abs(float(FIXTURE["loss"])))
+    for kk in range(6):
+        assert set(FIXTURE[f"sel_tokens{kk}"][0].tolist()) == set(lists[0][0][picked[kk][0]].tolist()), kk
+    worst_ref = {}
+    for n in CHECKED:
+        v, off = _compare(C.sub(eager[n].cpu()), torch.from_numpy(FIXTURE["grad." + n]), n, float(FIXTURE["scale." + n]))
+        worst_ref[n] = v
+        assert v < 1e-2 and off <= 20, (n, v, off)
+    print("against the reference's own gradients:", {n: round(v, 6) for n, v in worst_ref.items()})
     print("rows of linear1 gradients off by more than 1e-2 of the gradient's scale (ReLU gate flips):", off_rows)
     for n, v in worst.items():
         layer = int(n.split(".")[2]) if n.startswith("encoder.layers.") else None
