@@ -28,6 +28,20 @@ def test_header_symbols_exported(libpath):
     assert _hip.lib().sdetr_abi_version() == 1
 
 
+def test_product_library_carries_no_benchmark_instantiations(libpath):
+    """The deliberately crippled MSDA instantiations (wrong results by construction) and the phase-stamp hook exist only in
+    the benchmark build (`csrc/build.py --ablations`): the product library does not export the hook, and the only exported
+    `sdetr_*` symbols are the ones the header declares."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "salience_hip.h")).read()
+    declared = set(re.findall(r"\b(sdetr_[a-z0-9_]+)\s*\(", header))
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("sdetr_")}
+    assert "sdetr_msda_debug_stamps" not in exported
+    internal = {"sdetr_topk_inproj_launch"}   # (library-internal launch helper shared between translation units; bound by _hip)
+    assert exported - declared - internal == set(), exported - declared - internal
+
+
 def test_argument_rejection_without_gpu(libpath):
     """Invalid arguments are rejected on the host before any launch (safe without a GPU)."""
     from salience_detr_amd import _hip
