@@ -209,3 +209,71 @@ def test_graph_lanes_input_structure_checks_and_device_requirement():
             GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=1)
     with pytest.raises(ValueError):
         GL.GraphLanes(lambda x: x, (torch.zeros(1),), lanes=0)
+
+
+def test_bordered_layout_and_tile_orders_host_logic():
+    """The bordered value-map layout (`ms_deform_attn.BorderedLayout`, the host side of `sdetr_bordered_layout`) and the
+    tile-major row orders, without a GPU: record count as the library's own host function gives it, pixel records and zero
+    records partition the map, `to_bordered` puts every token where the kernel will look for it with zeros all round,
+    tile positions are a permutation that keeps a tile's tokens together, `spatial_row_order` sorts rows by them."""
+    import ctypes
+    import torch
+    from salience_detr_amd import _hip, ms_deform_attn as M
+    for levels in ([(100, 168), (50, 84), (25, 42), (13, 21)], [(7, 5), (4, 3), (2, 2), (1, 1)],
+                   [(200, 336), (100, 168), (50, 84), (25, 42)]):
+        lay = M.bordered_layout(levels)
+        want = sum((h + 2) * (w + 1) for h, w in levels) + 1
+        hw = (ctypes.c_int32 * 8)(*[v for hw_ in levels for v in hw_])
+        assert lay.records == want == _hip.lib().sdetr_msda_bordered_records(hw, 4)
+        assert lay.tokens == sum(h * w for h, w in levels)
+        pix, border = lay.pixel_map_host.long(), lay.border_host.long()
+        assert pix.numel() == lay.tokens and pix.unique().numel() == pix.numel()
+        both = torch.cat([pix, border])
+        assert both.unique().numel() == both.numel() == lay.records      # a partition of the records
+        # token (level l, y, x) sits at start_l + (y + 1) (W_l + 1) + x + 1: its left neighbour is the token (y, x - 1) or a
+        # zero record, the record above is (y - 1, x) or a zero record -- what lets the kernel read all four corners blindly
+        t0 = 0
+        for (h, w), start in zip(levels, lay.starts):
+            grid = pix[t0:t0 + h * w].view(h, w)
+            assert grid[0, 0].item() == start + (w + 1) + 1
+            if w > 1:
+                assert torch.equal(grid[:, 1:], grid[:, :-1] + 1)
+            if h > 1:
+                assert torch.equal(grid[1:, :], grid[:-1, :] + (w + 1))
+            bset = set(border.tolist())
+            assert all(int(grid[y, 0]) - 1 in bset for y in range(h))                 # record -1 of every row
+            assert all(int(grid[0, x]) - (w + 1) in bset for x in range(w))           # row -1
+            assert all(int(grid[h - 1, x]) + (w + 1) in bset for x in range(w))       # row H
+            assert int(grid[h - 1, w - 1]) + 1 in bset                                # (y, W): the next row's record -1
+            t0 += h * w
+        assert lay.records - 1 in set(border.tolist())                                # the closing record
+        v = torch.arange(1, lay.tokens * 2 + 1, dtype=torch.float32).view(1, lay.tokens, 2)
+        b = M.to_bordered(v, levels)
+        assert b.shape == (1, lay.records, 2) and M.is_bordered(b, levels) and not M.is_bordered(v, levels)
+        assert torch.equal(b[0, pix], v[0]) and float(b[0, border].abs().sum()) == 0.0
+        with pytest.raises(RuntimeError):
+            M.to_bordered(v[:, :-1], levels)
+        for tile in (8, 16):
+            pos = M.tile_major_positions(levels, tile).long()
+            assert pos.numel() == lay.tokens and torch.equal(pos.sort()[0], torch.arange(lay.tokens))
+            # the tokens (of all levels) whose centre falls into one cell of the ceil(H0 / tile) x ceil(W0 / tile) grid occupy
+            # ONE contiguous range of positions
+            h0, w0 = levels[0]
+            ty, tx = max(1, -(-h0 // tile)), max(1, -(-w0 // tile))
+            cells = []
+            for h, w in levels:
+                cy = ((torch.arange(h, dtype=torch.float64) + 0.5) / h * ty).floor().clamp(max=ty - 1).long()
+                cx = ((torch.arange(w, dtype=torch.float64) + 0.5) / w * tx).floor().clamp(max=tx - 1).long()
+                cells.append((cy.view(h, 1) * tx + cx.view(1, w)).reshape(-1))
+            cells = torch.cat(cells)
+            for c in cells.unique().tolist()[:40]:
+                mine = pos[cells == c]
+                assert int(mine.max() - mine.min()) + 1 == mine.numel(), (tile, c)
+        idx = torch.stack([torch.randperm(lay.tokens, generator=torch.Generator().manual_seed(s))[:min(50, lay.tokens)]
+                           for s in (1, 2)])
+        order = M.spatial_row_order(idx, levels, 16)
+        assert order.dtype == torch.int32 and order.shape == idx.shape
+        p16 = M.tile_major_positions(levels, 16).long()
+        for r in range(2):
+            seq = p16[idx[r][order[r].long()]]
+            assert torch.equal(seq, seq.sort()[0]) and torch.equal(order[r].long().sort()[0], torch.arange(idx.shape[1]))
