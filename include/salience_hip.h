@@ -170,7 +170,8 @@ int sdetr_msda_last_kernel(void);
  *   row_order: optional int32 [B, row_order_batch_stride >= Nq], a permutation of 0..Nq-1 per image: the rows are
  *              processed in this order (neighbours in the image next to each other keep the fine levels' records in
  *              the L1); results do not depend on it.  NULL = 0..Nq-1. */
-#define SDETR_KERNEL_MSDA_BORDERED 5 /* msda_bordered_kernel: bordered maps, levels 2+3 resident in LDS */
+#define SDETR_KERNEL_MSDA_BORDERED 5 /* msda_bordered_kernel: bordered maps, levels 2+3 resident in LDS, rows in list order */
+#define SDETR_KERNEL_MSDA_BORDERED_ORDERED 6 /* the same kernel walking the caller's row_order (tile-major in the encoder) */
 int64_t sdetr_msda_bordered_records(const int32_t *level_hw_host, int num_levels);
 int sdetr_msda_bordered_max_resident_records(void);
 int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *value_bordered, int value_dtype,

@@ -301,7 +301,10 @@ extern "C" int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sort
     a.order_layer_stride = (int64_t)batch_size * order_batch_stride; a.order_batch_stride = order_batch_stride;
     static DeviceOnce once;
     allow_dynamic_lds(layer_row_orders_kernel, once, 160 * 1024 - 1024);
-    const size_t lds = (((size_t)spatial_size + 7) & ~(size_t)7) * 2;
+    // one pass while the pyramid's 16-bit slots fit the workgroup's LDS (152 KB of slots), evenly sized passes beyond
+    a.slot_cap = order_slot_cap(spatial_size, 152 * 1024);
+    if (a.slot_cap <= 0) return fail("layer_row_orders: %d tokens per image need more than %d passes", spatial_size, kOrderMaxPasses);
+    const size_t lds = (((size_t)(a.slot_cap < spatial_size ? a.slot_cap : spatial_size) + 7) & ~(size_t)7) * 2;
     hipLaunchKernelGGL(layer_row_orders_kernel, dim3((unsigned)batch_size, (unsigned)num_layers), dim3(kOrderThreads), lds,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("layer_row_orders");

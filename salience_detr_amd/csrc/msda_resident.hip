@@ -1201,6 +1201,6 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
 #undef SDETR_B_PICK2
 #undef SDETR_B_LAUNCH_ABL
 #undef SDETR_B_LAUNCH
-    note_forward_kernel(SDETR_KERNEL_MSDA_BORDERED);
+    note_forward_kernel(a.perm ? SDETR_KERNEL_MSDA_BORDERED_ORDERED : SDETR_KERNEL_MSDA_BORDERED);
     return check_launch("msda_bordered");
 }

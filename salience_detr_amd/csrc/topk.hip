@@ -740,8 +740,10 @@ static int masked_topk_impl(sdetr_stream_t stream, const float *score, const uin
         int order_blocks = 0;
         if (job) {
             if (int rc = fill_order_args(o, job)) return rc;
-            const size_t need = (((size_t)o.S + 7) & ~(size_t)7) * 2;
-            if (need <= 136 * 1024) {       // (fits the launch's dynamic LDS limit next to the sort's static arrays)
+            // (the launch's dynamic LDS limit next to the sort's static arrays; larger pyramids take several passes)
+            o.slot_cap = order_slot_cap(o.S, 136 * 1024);
+            const size_t need = (((size_t)(o.slot_cap < o.S ? o.slot_cap : o.S) + 7) & ~(size_t)7) * 2;
+            if (o.slot_cap > 0 && need <= 136 * 1024) {
                 order_blocks = o.batch * o.nl;
                 if (need > dyn) dyn = need;
                 if (carried) *carried = 1;

@@ -944,15 +944,16 @@ def layer_row_orders(sorted_index: Tensor, counts, level_shapes, tile: int = 16,
     """Per-layer row orders for the bordered MSDA kernel (include/salience_hip.h ``sdetr_layer_row_orders``):
     ``sorted_index`` int64 ``[B,n0]`` (the token of every row of the sorted list), ``counts`` the layers' row counts
     (non-increasing, ``counts[0] <= n0``) -> list of int32 ``[B,c_k]`` views (rows ``n0`` apart), each a permutation of
-    ``0..c_k-1`` that walks the layer's rows tile by tile of the finest level.  ``None`` when the pyramid is too large for
-    the one-workgroup kernel (the caller then runs the rows in list order).  ``as_job``: return the pending
+    ``0..c_k-1`` that walks the layer's rows tile by tile of the finest level.  ``None`` when the list is too long for
+    the kernel's 16-bit row slots (65 534 rows per image; the caller then runs the rows in list order) -- pyramids whose
+    tile positions do not fit one workgroup's LDS take several passes (round 5: the 5scale pyramid's 89 250 in two).  ``as_job``: return the pending
     ``RowOrdersJob`` instead of launching it."""
     from .ms_deform_attn import tile_major_positions
     _hip.require_device("layer_row_orders", sorted_index=sorted_index)
     B, n0 = sorted_index.shape
     S = sum(int(h) * int(w) for h, w in level_shapes)
     counts = [int(c) for c in counts]
-    if S > 76800 or n0 >= 0xffff or len(counts) > 8 or sorted_index.dtype != torch.int64 or max(counts) > n0:
+    if S > (1 << 20) or n0 >= 0xffff or len(counts) > 8 or sorted_index.dtype != torch.int64 or max(counts) > n0:
         return None
     dev = sorted_index.device
     key = ("row_orders", tuple(map(tuple, level_shapes)), int(tile), tuple(counts), str(dev))

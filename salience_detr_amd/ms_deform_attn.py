@@ -444,7 +444,7 @@ def last_forward_kernel() -> int:
     return int(_hip.lib().sdetr_msda_last_kernel())
 
 
-KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT, KERNEL_BORDERED = 1, 2, 3, 4, 5
+KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT, KERNEL_BORDERED, KERNEL_BORDERED_ORDERED = 1, 2, 3, 4, 5, 6
 
 def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_start_index: Tensor,
                             sampling_loc: Tensor, attn_weight: Tensor,

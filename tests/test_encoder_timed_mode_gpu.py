@@ -67,7 +67,7 @@ def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case, layout):
                                        row_order=None if orders is None else orders[k])
             kernel = M.last_forward_kernel()
             if layout == "bordered":
-                assert kernel == M.KERNEL_BORDERED
+                assert kernel == M.KERNEL_BORDERED_ORDERED     # bordered maps, the layer's tile-major row order
             else:
                 assert kernel == (M.KERNEL_RESIDENT if q.shape[1] >= layer.self_attn.resident_min_queries else M.KERNEL_L4P4)
             err = (out.float().cpu() - ref["layer_out"][k]).abs()
@@ -101,7 +101,7 @@ def test_whole_path_selection_flips_are_the_only_large_errors(timed_case):
     finally:
         m.encoder.selection_hook = None
     gpu_inds = [t.cpu() for t in aux["foreground_inds"]]
-    assert M.last_forward_kernel() == M.KERNEL_BORDERED           # every layer: bordered maps + row order
+    assert M.last_forward_kernel() == M.KERNEL_BORDERED_ORDERED   # every layer: bordered maps + row order
     B, S, _ = memory.shape
     flipped = torch.zeros(B, S, dtype=torch.bool)
     for k in range(6):

@@ -151,8 +151,9 @@ def test_hotpath_bf16_encoder_close_to_fp32():
 def test_stress_pyramid_timed_mode_takes_the_level3_resident_kernel():
     """The reference's 5scale pyramid (89 250 tokens, 45 330 first-layer queries) in the timed mode (bf16 rows, fp16
     head-major maps, bordered since round 4): levels 2 + 3 (5250 pixels) do not fit the LDS together, so every layer runs
-    the bordered kernel's level-3-only variant (89 250 tokens are also more than the row-order kernel sorts: list order)
-    -- and the memory stays within bf16 rounding of the fp32 run on the same selection."""
+    the bordered kernel's level-3-only variant -- in the layers' TILE order since round 5 (the row-order kernel takes
+    the 89 250 tile positions in two passes over its LDS slots) -- and the memory stays within bf16 rounding of the fp32
+    run on the same selection."""
     from salience_detr_amd import ms_deform_attn as M
     m, feats, masks, pos = _full_model_and_inputs([(800, 1333)], STRESS_LEVELS, 500)
     m = m.to(DEV).eval()
@@ -161,7 +162,7 @@ def test_stress_pyramid_timed_mode_takes_the_level3_resident_kernel():
         mem32, _, aux32 = m(*args, return_aux=True)
         m.set_encoder_dtype(torch.bfloat16, torch.float16)
         mem16, _, aux16 = m(*args, return_aux=True)
-    assert M.last_forward_kernel() == M.KERNEL_BORDERED
+    assert M.last_forward_kernel() == M.KERNEL_BORDERED_ORDERED    # the tile-order path ran (list order before round 5)
     assert mem16.dtype == torch.bfloat16
     for a, b in zip(aux32["foreground_inds"], aux16["foreground_inds"]):
         assert torch.equal(a, b)

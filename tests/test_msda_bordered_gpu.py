@@ -170,3 +170,46 @@ def test_layer_row_orders_match_the_torch_reference(tile):
         assert torch.equal(order, want)
     small = K.layer_row_orders(sorted_index[:, :40].contiguous(), [40, 7], LEVELS_FULL, tile=tile)
     assert torch.equal(small[1], M.spatial_row_order(sorted_index[:, :7], levels, tile))
+
+
+def test_layer_row_orders_large_pyramid_takes_several_passes():
+    """Round 5: the reference's 5scale pyramid (89 250 tokens: 178 KB of 16-bit slots, more than a workgroup's LDS) is
+    sorted in two passes over the slot array -- BASELINE configs[3]'s first layer has 45 330 rows.  Same torch reference."""
+    from salience_detr_amd import filter_ops as K
+    levels = LEVELS_5SCALE
+    Nv = sum(h * w for h, w in levels)
+    assert Nv == 89250
+    g = torch.Generator().manual_seed(5)
+    counts = [45330, 36264, 27198, 27198, 18132, 9066]
+    sorted_index = torch.stack([torch.randperm(Nv, generator=g)[:counts[0]] for _ in range(2)]).to(DEV)
+    orders = K.layer_row_orders(sorted_index, counts, levels, tile=16)
+    assert orders is not None and len(orders) == 6
+    for c, order in zip(counts, orders):
+        assert torch.equal(order, M.spatial_row_order(sorted_index[:, :c], levels, 16))
+    # the carried form (a job riding in a top-k launch whose LDS limit is lower) gives the same orders
+    job = K.layer_row_orders(sorted_index, counts, levels, tile=16, as_job=True)
+    score = torch.rand(2, 4000, generator=g).to(DEV)
+    K.masked_topk_desc(score, 300, orders_job=job)
+    job.run()
+    for c, order in zip(counts, job.orders):
+        assert torch.equal(order, M.spatial_row_order(sorted_index[:, :c], levels, 16))
+
+
+def test_layer_row_orders_fall_back_to_list_order_on_duplicate_tokens():
+    """ADVICE r4: a caller-supplied list with duplicate / out-of-range tokens cannot be counting-sorted (one row per slot);
+    the order must still be a permutation of the rows (the gather writes exactly the rows it lists): list order."""
+    from salience_detr_amd import filter_ops as K
+    levels = LEVELS_FULL
+    Nv = sum(h * w for h, w in levels)
+    g = torch.Generator().manual_seed(9)
+    good = torch.randperm(Nv, generator=g)[:2000]
+    dup = good.clone()
+    dup[77] = dup[5]                      # one token twice
+    wild = good.clone()
+    wild[1234] = Nv + 3                   # one token outside the pyramid
+    sorted_index = torch.stack([good, dup, wild]).to(DEV)
+    orders = K.layer_row_orders(sorted_index, [2000, 900], levels, tile=16)
+    ident = torch.arange(2000, dtype=torch.int32, device=DEV)
+    assert torch.equal(orders[0][0], M.spatial_row_order(sorted_index[:1], levels, 16)[0])
+    assert torch.equal(orders[0][1], ident) and torch.equal(orders[0][2], ident)
+    assert torch.equal(orders[1][1], M.spatial_row_order(sorted_index[1:2, :900], levels, 16)[0])   # the prefix is clean
