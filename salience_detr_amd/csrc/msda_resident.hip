@@ -448,6 +448,9 @@ struct BorderedArgs {
 };
 
 constexpr int kBMaxResidentPx = (kRLdsBudget - kRWaves * kRWeightBytes) / 64;   // 1536 records
+// corner accumulation of the bordered kernel for 16-bit outputs: 0 exact fp32 products, 1 / 2 packed fp16 (round 5, see
+// the PK helpers in front of the kernel); SDETR_MSDA_PK overrides it for A/B runs
+constexpr int kDefaultPackedAccumulate = 1;
 constexpr int kBPieces = (kBMaxResidentPx * 64 + kRWaves * 1024 - 1) / (kRWaves * 1024);   // copy instructions per wave: 6
 
 __device__ __forceinline__ uint4 buffer_load16_s(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff)
@@ -537,9 +540,128 @@ __device__ __forceinline__ void buffer_store16(__amdgpu_buffer_rsrc_t r, uint32_
     __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, 0);
 }
 
-template <bool REF4, int RES, bool SERIAL, bool PERM, int ABL = 0>
+// ---- round 5: packed-fp16 corner accumulation (template parameter PK of msda_bordered_kernel) ---------------------------
+// The loop is bound by vector-ALU issue (section "What the measurements ... say" above): 512 of its ~650 instructions per
+// 16-row group are one v_fma_mix_f32 per (corner, channel).  v_pk_fma_f16 issues at the same rate and does TWO channels:
+//   PK = 1: the four corners of a sample are combined in packed fp16 with the plain bilinear weights (in [0, 1], rounded to
+//           fp16), 16 instructions for a lane's 8 channels, and the sample enters the fp32 accumulators through 8
+//           v_fma_mix_f32 with the fp32 attention weight: 24 instructions per sample instead of 32.  What is added to the
+//           fp16 rounding the maps carry anyway: four fp16 roundings of a sample's interpolated value (2^-12 relative each).
+//   PK = 2: the attention weight is folded into the fp16 corner weights and the four POINTS of a level are summed in
+//           packed fp16 as well (16 instructions per sample), one conversion-add per level and channel into the fp32
+//           accumulators: 18 instructions per sample.  Sixteen fp16 roundings per level sum.
+// Both are for 16-bit outputs only (the fp32-output form keeps the exact fp32 products: it is the parity path).
+typedef _Float16 f16x2_vec_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi)
+{
+    const f32x2_vec_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_vec_t));   // round to nearest even
+}
+// r = v * (w.lo, w.lo) [+ c]  /  r = v * (w.hi, w.hi) + c: v_pk_mul_f16 / v_pk_fma_f16 with the broadcast in op_sel.  Vector
+// builtins, not inline asm: hipcc pads every inline-asm result that the next inline asm consumes with an s_nop (217 in the
+// loop of the PK = 2 form) and cannot interleave the four channel pairs' chains.
+__device__ __forceinline__ uint32_t pk_mul_f16_blo(uint32_t v, uint32_t w)
+{
+    const f16x2_vec_t hv = __builtin_bit_cast(f16x2_vec_t, v), hw = __builtin_bit_cast(f16x2_vec_t, w);
+    return __builtin_bit_cast(uint32_t, hv * __builtin_shufflevector(hw, hw, 0, 0));
+}
+__device__ __forceinline__ uint32_t pk_fma_f16_blo(uint32_t v, uint32_t w, uint32_t c)
+{
+    const f16x2_vec_t hv = __builtin_bit_cast(f16x2_vec_t, v), hw = __builtin_bit_cast(f16x2_vec_t, w);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(hv, __builtin_shufflevector(hw, hw, 0, 0),
+                                                                  __builtin_bit_cast(f16x2_vec_t, c)));
+}
+__device__ __forceinline__ uint32_t pk_fma_f16_bhi(uint32_t v, uint32_t w, uint32_t c)
+{
+    const f16x2_vec_t hv = __builtin_bit_cast(f16x2_vec_t, v), hw = __builtin_bit_cast(f16x2_vec_t, w);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(hv, __builtin_shufflevector(hw, hw, 1, 1),
+                                                                  __builtin_bit_cast(f16x2_vec_t, c)));
+}
+// f32(half of `packed`) + acc, and the plain conversion (the first level sum starts the accumulators)
+__device__ __forceinline__ float add_f16lo(uint32_t packed, float acc)
+{
+    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed));
+    return acc;
+}
+__device__ __forceinline__ float add_f16hi(uint32_t packed, float acc)
+{
+    asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed));
+    return acc;
+}
+__device__ __forceinline__ float cvt_f16lo(uint32_t packed)
+{
+    float r;
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(r) : "v"(packed));
+    return r;
+}
+__device__ __forceinline__ float cvt_f16hi(uint32_t packed)
+{
+    float r;
+    asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(packed));
+    return r;
+}
+// One sample's bilinear value for a lane's 8 channels (four registers of two): corners (y0,x0), (y0,x1), (y1,x0), (y1,x1) with
+// the packed weights wa = (w(y0,x0), w(y1,x0)), wb = (w(y0,x1), w(y1,x1)).  START: the first product starts the chains, else it
+// adds to h.  Written corner-major over the four registers: four INDEPENDENT chains side by side -- a packed instruction that
+// consumes the result of the one right in front of it costs a wait state on gfx950 (hipcc pads it with an s_nop).
+template <bool START>
+__device__ __forceinline__ void pk_corners4(uint32_t *h, const uint4 &v00, const uint4 &v01, const uint4 &v10, const uint4 &v11,
+                                            uint32_t wa, uint32_t wb)
+{
+    uint32_t t0, t1, t2, t3;
+    if (START) {
+        t0 = pk_mul_f16_blo(v00.x, wa); t1 = pk_mul_f16_blo(v00.y, wa); t2 = pk_mul_f16_blo(v00.z, wa); t3 = pk_mul_f16_blo(v00.w, wa);
+    } else {
+        t0 = pk_fma_f16_blo(v00.x, wa, h[0]); t1 = pk_fma_f16_blo(v00.y, wa, h[1]);
+        t2 = pk_fma_f16_blo(v00.z, wa, h[2]); t3 = pk_fma_f16_blo(v00.w, wa, h[3]);
+    }
+    t0 = pk_fma_f16_blo(v01.x, wb, t0); t1 = pk_fma_f16_blo(v01.y, wb, t1); t2 = pk_fma_f16_blo(v01.z, wb, t2); t3 = pk_fma_f16_blo(v01.w, wb, t3);
+    t0 = pk_fma_f16_bhi(v10.x, wa, t0); t1 = pk_fma_f16_bhi(v10.y, wa, t1); t2 = pk_fma_f16_bhi(v10.z, wa, t2); t3 = pk_fma_f16_bhi(v10.w, wa, t3);
+    h[0] = pk_fma_f16_bhi(v11.x, wb, t0); h[1] = pk_fma_f16_bhi(v11.y, wb, t1);
+    h[2] = pk_fma_f16_bhi(v11.z, wb, t2); h[3] = pk_fma_f16_bhi(v11.w, wb, t3);
+}
+// PK = 1: acc (+)= a * bilinear(sample)
+template <bool FIRST>
+__device__ __forceinline__ void pk1_sample(float *acc, const uint4 &v00, const uint4 &v01, const uint4 &v10, const uint4 &v11,
+                                           uint32_t wa, uint32_t wb, float a)
+{
+    uint32_t t[4];
+    pk_corners4<true>(t, v00, v01, v10, v11, wa, wb);
+    if (FIRST) {
+        acc[0] = mul_f16lo(t[0], a); acc[1] = mul_f16hi(t[0], a); acc[2] = mul_f16lo(t[1], a); acc[3] = mul_f16hi(t[1], a);
+        acc[4] = mul_f16lo(t[2], a); acc[5] = mul_f16hi(t[2], a); acc[6] = mul_f16lo(t[3], a); acc[7] = mul_f16hi(t[3], a);
+    } else {
+        acc[0] = fma_f16lo(t[0], a, acc[0]); acc[1] = fma_f16hi(t[0], a, acc[1]); acc[2] = fma_f16lo(t[1], a, acc[2]);
+        acc[3] = fma_f16hi(t[1], a, acc[3]); acc[4] = fma_f16lo(t[2], a, acc[4]); acc[5] = fma_f16hi(t[2], a, acc[5]);
+        acc[6] = fma_f16lo(t[3], a, acc[6]); acc[7] = fma_f16hi(t[3], a, acc[7]);
+    }
+}
+// PK = 2: h (+)= (a * bilinear weights) . corners, the level's four points into the same packed sums; then acc (+)= h
+template <bool START>
+__device__ __forceinline__ void pk2_sample(uint32_t *h, const uint4 &v00, const uint4 &v01, const uint4 &v10, const uint4 &v11,
+                                           uint32_t wa, uint32_t wb)
+{
+    pk_corners4<START>(h, v00, v01, v10, v11, wa, wb);
+}
+template <bool FIRST>
+__device__ __forceinline__ void pk2_flush(float *acc, const uint32_t *h)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (FIRST) {
+            acc[2 * r] = cvt_f16lo(h[r]);
+            acc[2 * r + 1] = cvt_f16hi(h[r]);
+        } else {
+            acc[2 * r] = add_f16lo(h[r], acc[2 * r]);
+            acc[2 * r + 1] = add_f16hi(h[r], acc[2 * r + 1]);
+        }
+    }
+}
+
+template <bool REF4, int RES, bool SERIAL, bool PERM, int ABL = 0, int PK = 0>
 __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p)
 {
+    static_assert(PK == 0 || (RES == 2 && ABL == 0), "packed-fp16 accumulation: the two-resident-level schedule only");
     using F = ResFma<half_t>;
     constexpr int kAux = ((ABL & 128) ? 2 : 0) | ((ABL & 256) ? 16 : 0);   // experiments: nt / sc1 on the fine-level loads
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -711,12 +833,21 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             // (w00, w10 | w01, w11) = (row weights) x (1 - lx | lx): the two row weights as one register pair, so the
             // column split is one packed multiply and one packed subtract
             const float a = e[t] * inv;
-            const float wy1 = mul_f32(ly, a);
-            const f32x2_vec_t rw = {sub_f32(a, wy1), wy1}, fr = {lx, ly};
+            // (PK = 1: plain bilinear weights, the attention weight stays fp32 beside them)
+            const float wy1 = PK == 1 ? ly : mul_f32(ly, a);
+            const f32x2_vec_t rw = {sub_f32(PK == 1 ? 1.f : a, wy1), wy1}, fr = {lx, ly};
             f32x2_vec_t wr, wl;
             asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(wr) : "v"(rw), "v"(fr));   // both halves x lx (fr's low half)
             asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(wl) : "v"(rw), "v"(wr));
-            myW[(j * 4 + t) * 16 + g] = make_float4(wl.x, wl.y, wr.x, wr.y);   // (y0,x0), (y1,x0), (y0,x1), (y1,x1)
+            // Table layout [point t][row g][level j] (round 5; [level][point][row] before): a wave's store of one point is
+            // 64 consecutive entries -- the four levels of a row used to land 1 KB apart, on the same banks (4-way conflict
+            // on every store) -- and a sample's read (16 rows, 64 bytes apart, a quad sharing an address) stays conflict free.
+            if (PK == 0) myW[(t * 16 + g) * 4 + j] = make_float4(wl.x, wl.y, wr.x, wr.y);   // (y0,x0), (y1,x0), (y0,x1), (y1,x1)
+            else if (PK == 1)
+                myW[(t * 16 + g) * 4 + j] = make_float4(__uint_as_float(cvt_pk_f16(wl.x, wl.y)),
+                                                        __uint_as_float(cvt_pk_f16(wr.x, wr.y)), a, 0.f);
+            else
+                reinterpret_cast<uint2 *>(myW)[(t * 16 + g) * 4 + j] = make_uint2(cvt_pk_f16(wl.x, wl.y), cvt_pk_f16(wr.x, wr.y));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -734,15 +865,34 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         va[SLOT][3] = buffer_load16_aux<kAux>(rsrc, o0 + 64u, SDETR_B_PB(JL));                                 \
         } else { va[SLOT][0] = va[SLOT][1] = va[SLOT][2] = va[SLOT][3] = make_uint4(o0, o0, o0, o0); }        \
     }
+#define SDETR_B_WENTRY(JL, T) ((T * 16 + g) * 4 + JL)
+    /* one sample's four corner records v0 (y0,x0), v1 (y0,x1), v2 (y1,x0), v3 (y1,x1) into the accumulators; KIND: 0 the
+       row's first sample, 1 any other; PK = 2 keeps a packed level sum per memory path (hl: resident levels, hf: fine) */ \
+#define SDETR_B_CONSUME(V0, V1, V2, V3, JL, T, KIND, HS)                                                       \
+    {                                                                                                          \
+        if (PK == 0) {                                                                                         \
+            const float4 w = myW[SDETR_B_WENTRY(JL, T)];                                                       \
+            if (KIND == 0) mul8_f16(acc, V0, w.x); else F::fma8(acc, V0, w.x);                                 \
+            F::fma8(acc, V1, w.z);                                                                             \
+            F::fma8(acc, V2, w.y);                                                                             \
+            F::fma8(acc, V3, w.w);                                                                             \
+        } else if (PK == 1) {                                                                                  \
+            const float4 w = myW[SDETR_B_WENTRY(JL, T)];                                                       \
+            pk1_sample<KIND == 0>(acc, V0, V1, V2, V3, __float_as_uint(w.x), __float_as_uint(w.y), w.z);       \
+        } else {                                                                                               \
+            const uint2 w = reinterpret_cast<const uint2 *>(myW)[SDETR_B_WENTRY(JL, T)];                       \
+            pk2_sample<T == 0>(HS, V0, V1, V2, V3, w.x, w.y);                                                  \
+            if (T == 3) pk2_flush<KIND == 0 || (JL == 2 && RES == 2)>(acc, HS);                                \
+        }                                                                                                      \
+    }
 #define SDETR_B_ACC(SLOT, JL, T)                                                                               \
     {                                                                                                          \
-        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
         if (!(ABL & 4)) {                                                                                      \
-        F::fma8(acc, va[SLOT][0], w.x);                                                                        \
-        F::fma8(acc, va[SLOT][1], w.z);                                                                        \
-        F::fma8(acc, va[SLOT][2], w.y);                                                                        \
-        F::fma8(acc, va[SLOT][3], w.w);                                                                        \
-        } else { acc[0] += w.x + __uint_as_float(va[SLOT][0].x ^ va[SLOT][1].y ^ va[SLOT][2].z ^ va[SLOT][3].w); } \
+            SDETR_B_CONSUME(va[SLOT][0], va[SLOT][1], va[SLOT][2], va[SLOT][3], JL, T, 1, hf)                  \
+        } else {                                                                                               \
+            const float4 w = myW[SDETR_B_WENTRY(JL, T)];                                                       \
+            acc[0] += w.x + __uint_as_float(va[SLOT][0].x ^ va[SLOT][1].y ^ va[SLOT][2].z ^ va[SLOT][3].w);   \
+        }                                                                                                      \
     }
 #define SDETR_B_LDS(JL, T)                                                                                     \
     {                                                                                                          \
@@ -751,13 +901,12 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         if (!(ABL & 2)) {                                                                                      \
             v0 = lds_read16(o0); v1 = lds_read16(o0 + 64u); v2 = lds_read16(o1); v3 = lds_read16(o1 + 64u);    \
         } else { v0 = v1 = v2 = v3 = make_uint4(o0, o1, o0, o1); }                                             \
-        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
         if (!(ABL & 8)) {                                                                                      \
-        F::fma8(acc, v0, w.x);                                                                                 \
-        F::fma8(acc, v1, w.z);                                                                                 \
-        F::fma8(acc, v2, w.y);                                                                                 \
-        F::fma8(acc, v3, w.w);                                                                                 \
-        } else { acc[0] += w.x + __uint_as_float(v0.x ^ v1.y ^ v2.z ^ v3.w); }                                 \
+            SDETR_B_CONSUME(v0, v1, v2, v3, JL, T, 1, hl)                                                      \
+        } else {                                                                                               \
+            const float4 w = myW[SDETR_B_WENTRY(JL, T)];                                                       \
+            acc[0] += w.x + __uint_as_float(v0.x ^ v1.y ^ v2.z ^ v3.w);                                        \
+        }                                                                                                      \
     }
     /* the row's first sample: its first product starts the accumulators */                                  \
 #define SDETR_B_LDS_FIRST(JL, T)                                                                               \
@@ -767,11 +916,7 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         if (!(ABL & 2)) {                                                                                      \
             v0 = lds_read16(o0); v1 = lds_read16(o0 + 64u); v2 = lds_read16(o1); v3 = lds_read16(o1 + 64u);    \
         } else { v0 = v1 = v2 = v3 = make_uint4(o0, o1, o0, o1); }                                             \
-        const float4 w = myW[(JL * 4 + T) * 16 + g];                                                           \
-        mul8_f16(acc, v0, w.x);                                                                                \
-        F::fma8(acc, v1, w.z);                                                                                 \
-        F::fma8(acc, v2, w.y);                                                                                 \
-        F::fma8(acc, v3, w.w);                                                                                 \
+        SDETR_B_CONSUME(v0, v1, v2, v3, JL, T, 0, hl)                                                          \
     }
 #define SDETR_FENCE __builtin_amdgcn_sched_barrier(0);
         // Fine-level samples in flight per wave.  Round 3 kept four (16 loads) rolling; measured on the step's own operands
@@ -780,6 +925,7 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         // rows in spatial order the loop is bound by vector-ALU issue, not by the loads' latency (+128 dummy instructions
         // per group cost +2.7 us, -12 loads in flight nothing).  The level-3-only variant (twelve fine-level samples) keeps two.
         uint4 va[4][4];
+        uint32_t hl[4], hf[4];   // PK = 2: packed fp16 sums of the current resident / fine level's points
         SDETR_B_ISSUE(0, 0, 0)
         if ((ABL & (64 | 2048)) || RES != 2) { SDETR_B_ISSUE(1, 0, 1) }
         if ((ABL & 2048) && RES == 2) { SDETR_B_ISSUE(2, 0, 2) SDETR_B_ISSUE(3, 0, 3) }
@@ -870,6 +1016,8 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
 #undef SDETR_B_ACC
 #undef SDETR_B_LDS
 #undef SDETR_B_LDS_FIRST
+#undef SDETR_B_CONSUME
+#undef SDETR_B_WENTRY
 #undef SDETR_B_PB
 
         if (ABL & 1024) {
@@ -1134,6 +1282,12 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     if (const char *e = getenv("SDETR_MSDA_PREFETCH")) a.prefetch_fine = atoi(e);
     const int64_t blocks = (int64_t)groups * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_bordered_forward: grid too large");
+    // corner accumulation: exact fp32 products for fp32 outputs (the parity path); for 16-bit outputs the packed-fp16 form
+    // `accumulate` asks for (SDETR_MSDA_ACC_*; 0 = the library's default for the output type)
+    int pk = 0;
+    if (a.out_bf16) pk = kDefaultPackedAccumulate;
+    if (const char *e = getenv("SDETR_MSDA_PK")) pk = a.out_bf16 ? atoi(e) : 0;
+    if (pk < 0 || pk > 2) return fail("msda_bordered_forward: SDETR_MSDA_PK must be 0, 1 or 2");
     const int lds_bytes = a.res_px * 64 + kRWaves * kRWeightBytes;
 #define SDETR_B_LAUNCH(REF4, RES, SER, PERM)                                                                        \
     do {                                                                                                            \
@@ -1146,6 +1300,20 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     do {                                                                                                            \
         if (a.perm) SDETR_B_LAUNCH(REF4, RES, SER, true);                                                           \
         else SDETR_B_LAUNCH(REF4, RES, SER, false);                                                                 \
+    } while (0)
+    // packed-fp16 corner accumulation (PK, see the helpers above the kernel): 16-bit outputs, two resident levels, one
+    // image per workgroup
+#define SDETR_B_LAUNCH_PK(REF4, PERM, PKV)                                                                          \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bordered_kernel<REF4, 2, false, PERM, 0, PKV>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRLdsBudget);                         \
+        hipLaunchKernelGGL((msda_bordered_kernel<REF4, 2, false, PERM, 0, PKV>), dim3((unsigned)blocks),            \
+                           dim3(kRThreads), lds_bytes, static_cast<hipStream_t>(stream), a);                        \
+    } while (0)
+#define SDETR_B_PICK_PK(REF4, PKV)                                                                                  \
+    do {                                                                                                            \
+        if (a.perm) SDETR_B_LAUNCH_PK(REF4, true, PKV);                                                             \
+        else SDETR_B_LAUNCH_PK(REF4, false, PKV);                                                                   \
     } while (0)
 #ifdef SDETR_MSDA_ABLATIONS
 #define SDETR_B_LAUNCH_ABL(ABL)                                                                                     \
@@ -1190,7 +1358,15 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
         if (a.image_serial) SDETR_B_PICK2(REF4, RES, true);                                                         \
         else SDETR_B_PICK2(REF4, RES, false);                                                                       \
     } while (0)
-    if (res_levels == 2) {
+    if (pk && res_levels == 2 && !a.image_serial) {
+        if (pk == 1) {
+            if (ref_dim == 4) SDETR_B_PICK_PK(true, 1);
+            else SDETR_B_PICK_PK(false, 1);
+        } else {
+            if (ref_dim == 4) SDETR_B_PICK_PK(true, 2);
+            else SDETR_B_PICK_PK(false, 2);
+        }
+    } else if (res_levels == 2) {
         if (ref_dim == 4) SDETR_B_PICK(true, 2);
         else SDETR_B_PICK(false, 2);
     } else {
@@ -1199,6 +1375,8 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     }
 #undef SDETR_B_PICK
 #undef SDETR_B_PICK2
+#undef SDETR_B_PICK_PK
+#undef SDETR_B_LAUNCH_PK
 #undef SDETR_B_LAUNCH_ABL
 #undef SDETR_B_LAUNCH
     note_forward_kernel(a.perm ? SDETR_KERNEL_MSDA_BORDERED_ORDERED : SDETR_KERNEL_MSDA_BORDERED);

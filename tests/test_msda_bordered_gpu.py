@@ -5,6 +5,8 @@ fp32 output; the maps go through ``to_bordered`` (zero border records around eve
 reference's corner tests (ms_deform_im2col_cuda.cuh:31-66, 258-262) are replaced by clamping the position onto the border:
 positions on / beyond every edge, NaN-free wild offsets and both reference-point forms are covered here.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -45,9 +47,25 @@ def test_bordered_kernel_vs_oracle(B, Nq, levels, chunks, ref_dim):
     order = torch.stack([torch.randperm(Nq, generator=g) for _ in range(B)]).to(torch.int32).to(DEV)
     again = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.float32, chunks=chunks)
     assert torch.equal(again, out)
-    # bf16 output = the fp32 result rounded
-    b16 = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks)
+    # bf16 output with the exact fp32 corner products (SDETR_MSDA_PK=0) = the fp32 result rounded
+    os.environ["SDETR_MSDA_PK"] = "0"
+    try:
+        b16 = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks)
+    finally:
+        del os.environ["SDETR_MSDA_PK"]
     assert torch.equal(b16, out.to(torch.bfloat16))
+    # the library's default for 16-bit outputs since round 5: a sample's four corners combined in packed fp16 (PK = 1;
+    # four fp16 roundings of every interpolated sample on top of the maps' own), PK = 2: a level's four points too
+    for pk, bar_mean, bar_max in ((None, 4e-5, 1.5e-3), ("1", 4e-5, 1.5e-3), ("2", 1.5e-4, 4e-3)):
+        if pk is not None:
+            os.environ["SDETR_MSDA_PK"] = pk
+        try:
+            got = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks)
+        finally:
+            os.environ.pop("SDETR_MSDA_PK", None)
+        # against the fp32 result, beyond the bf16 rounding of the output itself
+        excess = ((got.float() - out).abs() - out.abs() * 2.0 ** -8).clamp_(min=0)
+        assert excess.mean().item() < bar_mean and excess.max().item() < bar_max, (pk, excess.mean().item(), excess.max().item())
 
 
 def test_bordered_spatial_row_order_is_a_permutation_that_groups_tiles():
