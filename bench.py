@@ -521,8 +521,10 @@ def config_records(args, device, steps=10):
                    5scale configuration (salience_detr_resnet50_5scale_800_1333.py:33-36: 89 250 tokens, 45 330 queries);
     * ``config5``  BASELINE configs[4] at N = 1: the whole SalienceTransformer (neck, encoder, two-stage proposals + NMS,
                    6 decoder layers at 900 queries; salience_transformer.py:97-226,552-674) on 800x1333 + 800x1066,
-                   requested as "fp16" (what ``resolve_activation_dtype`` serves that request with is in the record);
-    * ``config5_fp32`` the same whole transformer in fp32 arithmetic (>= the fp16 the configuration names)."""
+                   in fp16: IEEE-half activations since round 5 (libsalience_hip_f16.so, ``resolve_activation_dtype``;
+                   the record states what ran and which library served it);
+    * ``config5_fp32`` the same whole transformer in fp32 arithmetic (the figure rounds 2-4 had to quote for this
+                   configuration, kept for the trend)."""
     import numpy as np
     from salience_detr_amd.hot_path import resolve_activation_dtype
     out = {}
@@ -612,20 +614,24 @@ def config_records(args, device, steps=10):
                 return tr(feats, masks, pos, image_sizes=sizes, canvas=canvas)
         chk = {}
         ms, graphed = _graph_ms(step, steps, check=chk)
+        from salience_detr_amd import _hip
+        ran = str(tr.decoder.layers[0].linear1.weight.dtype).replace("torch.", "")
         return {**chk, "workload": "BASELINE configs[4] at N=1: whole SalienceTransformer (RepVGGPluX neck, encoder, two-stage "
                             "proposals + NMS, 6 decoder layers, 900 queries), batch=2 (800x1333 + 800x1066)",
                 "requested_dtype": "fp16", "served_as": {"activations": str(act).replace("torch.", ""),
-                                                         "value_maps": str(vdt).replace("torch.", "")},
+                                                         "value_maps": str(vdt).replace("torch.", ""),
+                                                         "module_parameters": ran,
+                                                         "library": "libsalience_hip_f16.so" if (ran == "float16" and _hip._lib_f16 is not None)
+                                                                    else "libsalience_hip.so"},
                 "ms_per_step": round(ms, 4), "images_per_s": round(2e3 / ms, 1), "steps": steps, "hipgraph": graphed,
                 "queries": 900}
 
     guarded("fp32", fp32)
     guarded("config4", config4)
     guarded("config5", config5)
-    # The same configuration in fp32 arithmetic: bf16 activations carry 3 fewer mantissa bits than the fp16 the configuration
-    # names, so `config5` above is a number at LOWER precision than named (stated in `served_as`; a true fp16 instantiation
-    # of the activation kernels is not built).  This one is at HIGHER precision than named -- the
-    # configuration's valid N = 1 figure until the fp16 instantiation exists.
+    # The same configuration in fp32 arithmetic.  Rounds 2-4 served the fp16 request with bf16 activations (a precision BELOW
+    # the one named) and this record was the configuration's only valid figure; since round 5 `config5` runs IEEE-half
+    # activations (stated in `served_as`) and this one stays for the trend.
     guarded("config5_fp32", lambda: config5(fp32_arithmetic=True))
     return out
 

@@ -11,9 +11,9 @@ import json
 import os
 import sys
 
-# the ablated kernels and the phase stamps live in the benchmark build of the library only
-if any(a.startswith(("--ablate", "--stamps")) for a in sys.argv[1:]):
-    os.environ.setdefault("SDETR_HIP_LIBRARY", "libsalience_hip_ablate.so")
+# the ablated kernels and the phase stamps live in the benchmark build of the library only (benchmarks/libsalience_hip_ablate.so,
+# `python salience_detr_amd/csrc/build.py --ablations`): bound below, before the first operator call
+USE_ABLATION_BUILD = any(a.startswith(("--ablate", "--stamps")) for a in sys.argv[1:])
 
 import torch
 
@@ -24,6 +24,9 @@ from salience_detr_amd import _hip, ms_deform_attn as M  # noqa: E402
 from salience_detr_amd import synthetic as syn  # noqa: E402
 from salience_detr_amd.hot_path import build_hot_path  # noqa: E402
 from benchmarks.msda_resident_ab import timeit  # noqa: E402
+
+if USE_ABLATION_BUILD:
+    _hip.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsalience_hip_ablate.so")
 
 
 def main():

@@ -12,15 +12,22 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsalience_hip.so")
-# Benchmarks that time deliberately crippled instantiations of a kernel load the benchmark build instead (same ABI + the
-# ablations; `csrc/build.py --ablations`).  The variable names a FILE INSIDE THIS PACKAGE: nothing outside it is loaded.
-if os.environ.get("SDETR_HIP_LIBRARY"):
-    LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ["SDETR_HIP_LIBRARY"]))
+# The fp16-activation flavour (round 5): the same sources built with -DSDETR_ACT_F16, same C ABI, every 16-bit ACTIVATION
+# (token rows, projection slabs, 16-bit outputs, packed weights) IEEE half instead of bfloat16 (csrc/common.h).  An
+# operator picks the library by the dtype of the activations it is handed: ``lib(x.dtype)``.
+F16_LIB_PATH = os.path.join(_HERE, "libsalience_hip_f16.so")
 
 F32, BF16, F16 = 0, 1, 2
 EINVAL = -1
+ACT16 = (torch.bfloat16, torch.float16)      # the two 16-bit activation types (one library each)
 
 _lib = None
+_lib_f16 = None
+_last = None          # the library of the most recent lib() call: where check() reads the error text
+
+
+def is_act16(dt) -> bool:
+    return dt in ACT16
 
 _i = ctypes.c_int
 
@@ -177,28 +184,42 @@ class HipExtensionError(RuntimeError):
     pass
 
 
-def lib() -> ctypes.CDLL:
-    """Load the shared library once; fail loudly if it is not built."""
-    global _lib
+def _load(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise HipExtensionError(
+            f"{path} is missing: build it with `python -m salience_detr_amd.csrc.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
+    cdll = ctypes.CDLL(path)          # RTLD_LOCAL: the two flavours export the same names and do not see each other
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)  # AttributeError -> the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if cdll.sdetr_abi_version() != 1:
+        raise HipExtensionError(f"{os.path.basename(path)} ABI version mismatch")
+    return cdll
+
+
+def lib(act=None) -> ctypes.CDLL:
+    """Load the shared library once; fail loudly if it is not built.  ``act``: the dtype (or a tensor) of the 16-bit
+    activations of the call -- ``torch.float16`` selects the fp16-activation flavour, anything else the bf16 library (which
+    also holds every fp32 / integer operator)."""
+    global _lib, _lib_f16, _last
+    if act is not None and not isinstance(act, torch.dtype):
+        act = act.dtype
+    if act == torch.float16:
+        if _lib_f16 is None:
+            _lib_f16 = _load(F16_LIB_PATH)
+        _last = _lib_f16
+        return _lib_f16
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise HipExtensionError(
-                f"{LIB_PATH} is missing: build it with `python -m salience_detr_amd.csrc.build` "
-                "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
-        cdll = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(cdll, name)  # AttributeError -> the header and the library disagree
-            fn.restype = res
-            fn.argtypes = args
-        if cdll.sdetr_abi_version() != 1:
-            raise HipExtensionError("libsalience_hip.so ABI version mismatch")
-        _lib = cdll
+        _lib = _load(LIB_PATH)
+    _last = _lib
     return _lib
 
 
 def check(code: int, what: str) -> None:
     if code != 0:
-        msg = lib().sdetr_last_error().decode(errors="replace")
+        msg = (_last or lib()).sdetr_last_error().decode(errors="replace")
         if code == EINVAL:
             raise RuntimeError(f"{what}: {msg}")
         raise RuntimeError(f"{what}: HIP launch error {code}: {msg}")
@@ -229,5 +250,5 @@ def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.bfloat16:
         return BF16
     if dt == torch.float16:
-        return F16  # storage type of the head-major value map only
-    raise RuntimeError(f"unsupported dtype {dt} (float32 / bfloat16, float16 value maps only)")
+        return F16  # head-major value maps (either library); activations of the fp16 flavour (lib(torch.float16))
+    raise RuntimeError(f"unsupported dtype {dt} (float32 / bfloat16 / float16)")

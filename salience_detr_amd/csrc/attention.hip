@@ -33,8 +33,7 @@ struct AttArgs {
 
 __device__ __forceinline__ at_f32x16_t at_mfma(uint4 a, uint4 b, at_f32x16_t c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(at_bf16x8_t, a), __builtin_bit_cast(at_bf16x8_t, b),
-                                                   c, 0, 0, 0);
+    return mfma_act_32x32x16(a, b, c);
 }
 __device__ __forceinline__ uint4 at_lds_read16(at_lds_cptr_t p)
 {
@@ -44,8 +43,8 @@ __device__ __forceinline__ uint4 at_lds_read16(at_lds_cptr_t p)
 // registers 8m .. 8m+7 of an accumulator -> one packed bf16 operand fragment
 __device__ __forceinline__ uint4 at_pack_half(const at_f32x16_t &c, int m)
 {
-    return make_uint4(pack_bf16x2(c[8 * m], c[8 * m + 1]), pack_bf16x2(c[8 * m + 2], c[8 * m + 3]),
-                      pack_bf16x2(c[8 * m + 4], c[8 * m + 5]), pack_bf16x2(c[8 * m + 6], c[8 * m + 7]));
+    return make_uint4(pack_act2(c[8 * m], c[8 * m + 1]), pack_act2(c[8 * m + 2], c[8 * m + 3]),
+                      pack_act2(c[8 * m + 4], c[8 * m + 5]), pack_act2(c[8 * m + 6], c[8 * m + 7]));
 }
 // accumulator row of register i for lane half h
 __device__ __forceinline__ int at_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
@@ -158,7 +157,7 @@ __global__ void __launch_bounds__(64 * kAttWaves) attention_heads_kernel(AttArgs
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<uint2 *>(orow + 8 * g) =
-                make_uint2(pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv), pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv));
+                make_uint2(pack_act2(o[4 * g] * inv, o[4 * g + 1] * inv), pack_act2(o[4 * g + 2] * inv, o[4 * g + 3] * inv));
     }
 }
 

@@ -24,7 +24,9 @@ def _stale(out, deps):
 
 # benchmark build: msda_resident.hip with its ablated instantiations and phase stamps (wrong results by construction:
 # never part of the product library), every other object shared with the product build
-ABLATE_LIB = os.path.join(os.path.dirname(HERE), "libsalience_hip_ablate.so")
+# (lives under benchmarks/: the product package ships the two product libraries only; the benchmark scripts that want it
+# point salience_detr_amd._hip.LIB_PATH at it themselves before the first operator call)
+ABLATE_LIB = os.path.join(ROOT, "benchmarks", "libsalience_hip_ablate.so")
 ABLATE_SOURCES = {"msda_resident.hip": ["-DSDETR_MSDA_ABLATIONS"]}
 
 
@@ -49,26 +51,38 @@ def build_ablations(force: bool = False, verbose: bool = False) -> str:
     return ABLATE_LIB
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+# The fp16-activation flavour (round 5): the SAME sources with -DSDETR_ACT_F16 (common.h: every 16-bit activation is IEEE
+# half instead of bfloat16, v_mfma_*_f16 instead of *_bf16) -> libsalience_hip_f16.so, same C ABI.  Loaded next to the
+# bf16 library by _hip.lib(torch.float16); -Bsymbolic keeps each library's internal calls inside it.
+F16_LIB = os.path.join(os.path.dirname(HERE), "libsalience_hip_f16.so")
+F16_OBJ_DIR = os.path.join(HERE, "_obj_f16")
+
+
+def _build_flavour(lib, obj_dir, defines, force, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     headers = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(ROOT, "include", "salience_hip.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)
-        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-x", "hip", "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *defines, "-x", "hip", "-c", s, "-o", o])
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
-    return LIB
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", lib])
+    return lib
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    _build_flavour(F16_LIB, F16_OBJ_DIR, ["-DSDETR_ACT_F16"], force, verbose)
+    return _build_flavour(LIB, OBJ_DIR, [], force, verbose)
 
 
 if __name__ == "__main__":

@@ -83,12 +83,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 struct half_t {
     uint16_t bits;
 };
+typedef _Float16 f16x2_pair_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)
 {
-    // round-to-nearest-even, saturating at +-65504 so a large activation never becomes inf in storage
-    const _Float16 a = (_Float16)fminf(fmaxf(lo, -65504.f), 65504.f);
-    const _Float16 b = (_Float16)fminf(fmaxf(hi, -65504.f), 65504.f);
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    // round-to-nearest-even, saturating at +-65504 so a large activation never becomes inf in storage (a NaN lands on
+    // -65504: v_med3_f32 returns the minimum of the other two).  Three instructions: two v_med3_f32, one v_cvt_pk_f16_f32.
+    const f32x2_vec_t v = {__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_pair_t));
 }
 __device__ __forceinline__ float f16_lo(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed & 0xffffu)); }
 __device__ __forceinline__ float f16_hi(uint32_t packed) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(packed >> 16)); }
@@ -104,6 +105,55 @@ __device__ __forceinline__ float fma_f16hi(uint32_t packed, float w, float acc)
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(packed), "v"(w));
     return acc;
 }
+
+// ---- the library's 16-bit ACTIVATION type (round 5) --------------------------------------------------------------------
+// Token rows, projection slabs, attention / feed-forward operands and 16-bit outputs are "activations".  The product
+// library libsalience_hip.so keeps them in bfloat16; the SAME sources built with -DSDETR_ACT_F16 give
+// libsalience_hip_f16.so, in which every activation is IEEE half (the reference's `--mixed-precision fp16`, main.py:24-56,
+// BASELINE.json configs[4]): v_mfma_f32_*_f16 runs at the bf16 rate, accumulators / LayerNorm / softmax / class scores /
+// sampling locations stay fp32 in both, and stores SATURATE at +-65504 where fp16's range would bite (pack_f16x2).
+// Weight packing permutes 16-bit words and is type-agnostic (the host hands the weights over in the activation type).
+// What is NOT an activation and keeps its explicit type in both flavours: the head-major value maps (`half_t` | `bf16_t`
+// by their own dtype argument) and the bf16 x 3 split of the fp32-accurate products (salience head, gemm_x3).
+typedef float act_f32x16_t __attribute__((ext_vector_type(16)));
+typedef float act_f32x4_t __attribute__((ext_vector_type(4)));
+#ifdef SDETR_ACT_F16
+#define SDETR_ACT_IS_F16 1
+#define SDETR_ACT_MFMA_SUFFIX "f16"
+typedef _Float16 act_x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float act_lo(uint32_t packed) { return f16_lo(packed); }
+__device__ __forceinline__ float act_hi(uint32_t packed) { return f16_hi(packed); }
+__device__ __forceinline__ uint32_t pack_act2(float lo, float hi) { return pack_f16x2(lo, hi); }
+__device__ __forceinline__ uint32_t f32_to_act_bits(float f) { return pack_f16x2(f, 0.f) & 0xffffu; }
+__device__ __forceinline__ act_f32x16_t mfma_act_32x32x16(uint4 a, uint4 b, act_f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(act_x8_t, a), __builtin_bit_cast(act_x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ act_f32x4_t mfma_act_16x16x32(uint4 a, uint4 b, act_f32x4_t c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(act_x8_t, a), __builtin_bit_cast(act_x8_t, b), c, 0, 0, 0);
+}
+#else
+#define SDETR_ACT_IS_F16 0
+#define SDETR_ACT_MFMA_SUFFIX "bf16"
+typedef __bf16 act_x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float act_lo(uint32_t packed) { return bf16_lo(packed); }
+__device__ __forceinline__ float act_hi(uint32_t packed) { return bf16_hi(packed); }
+__device__ __forceinline__ uint32_t pack_act2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+__device__ __forceinline__ uint32_t f32_to_act_bits(float f) { return f32_to_bf16_bits(f); }
+__device__ __forceinline__ act_f32x16_t mfma_act_32x32x16(uint4 a, uint4 b, act_f32x16_t c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(act_x8_t, a), __builtin_bit_cast(act_x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ act_f32x4_t mfma_act_16x16x32(uint4 a, uint4 b, act_f32x4_t c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(act_x8_t, a), __builtin_bit_cast(act_x8_t, b), c, 0, 0, 0);
+}
+#endif
+// storage type of an activation element (a raw 16-bit pattern in both flavours) and the dtype code activation arguments
+// carry: SDETR_BF16 in libsalience_hip.so, SDETR_F16 in libsalience_hip_f16.so
+using act_t = uint16_t;
+constexpr int kActCode = SDETR_ACT_IS_F16 ? SDETR_F16 : SDETR_BF16;
 
 // 16-byte load through a buffer resource: the block-uniform base lives in the (SGPR) descriptor, the lane
 // supplies a 32-bit byte offset -- one v_add_u32 per corner instead of a 64-bit VALU address

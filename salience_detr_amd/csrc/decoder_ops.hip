@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) query_sine_embed_kernel(SineArgs p)
     float s, co;
     sincosf(ang, &s, &co);
     const int64_t o = row * (4 * (int64_t)p.F) + (int64_t)blk * p.F + 2 * pr;
-    if (p.embed_bf16) reinterpret_cast<uint32_t *>(p.embed)[o >> 1] = pack_bf16x2(s, co);
+    if (p.embed_bf16) reinterpret_cast<uint32_t *>(p.embed)[o >> 1] = pack_act2(s, co);
     else reinterpret_cast<float2 *>(p.embed)[o >> 1] = make_float2(s, co);
     if (p.ref_in && rem < p.L) {
         const float4 r = reinterpret_cast<const float4 *>(p.ref)[row];
@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(256) box_refine_kernel(const DT *delta, int64_
     const DT *d = delta + gid * delta_row_stride;
     float v[4];
     if constexpr (sizeof(DT) == 2) {
-        v[0] = __uint_as_float((uint32_t)d[0] << 16); v[1] = __uint_as_float((uint32_t)d[1] << 16);
-        v[2] = __uint_as_float((uint32_t)d[2] << 16); v[3] = __uint_as_float((uint32_t)d[3] << 16);
+        v[0] = act_lo((uint32_t)d[0]); v[1] = act_lo((uint32_t)d[1]);
+        v[2] = act_lo((uint32_t)d[2]); v[3] = act_lo((uint32_t)d[3]);
     } else {
         v[0] = d[0]; v[1] = d[1]; v[2] = d[2]; v[3] = d[3];
     }
@@ -90,12 +90,12 @@ extern "C" int sdetr_decoder_query_sine_embed(sdetr_stream_t stream, const float
     if (batch_size < 0 || num_queries < 0 || num_levels <= 0 || num_pos_feats <= 0 || (num_pos_feats & 1))
         return fail("query_sine_embed: bad sizes (num_pos_feats must be even)");
     if (num_levels > 2 * num_pos_feats) return fail("query_sine_embed: more levels than threads per query");
-    if (embed_dtype != SDETR_F32 && embed_dtype != SDETR_BF16) return fail("query_sine_embed: embed dtype must be f32 or bf16");
+    if (embed_dtype != SDETR_F32 && embed_dtype != kActCode) return fail("query_sine_embed: embed dtype must be f32 or bf16");
     const int64_t rows = (int64_t)batch_size * num_queries;
     if (rows == 0) return 0;
     if (!reference_points || !valid_ratios || !embed) return fail("query_sine_embed: null pointer");
     SineArgs a{reference_points, valid_ratios, num_queries, num_levels, num_pos_feats, temperature, rows, embed,
-               embed_dtype == SDETR_BF16, reference_points_input};
+               embed_dtype == kActCode, reference_points_input};
     const int64_t total = rows * 2 * num_pos_feats;
     hipLaunchKernelGGL(query_sine_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, a);
@@ -106,12 +106,12 @@ extern "C" int sdetr_box_refine(sdetr_stream_t stream, const void *delta, int de
                                 const float *reference_points, int64_t num_boxes, int groups, float eps, float *out)
 {
     if (num_boxes < 0 || groups <= 0 || delta_row_stride < 4) return fail("box_refine: bad sizes");
-    if (delta_dtype != SDETR_F32 && delta_dtype != SDETR_BF16) return fail("box_refine: delta dtype must be f32 or bf16");
+    if (delta_dtype != SDETR_F32 && delta_dtype != kActCode) return fail("box_refine: delta dtype must be f32 or bf16");
     if (num_boxes == 0) return 0;
     if (!delta || !reference_points || !out) return fail("box_refine: null pointer");
     const int64_t total = num_boxes * groups;
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (delta_dtype == SDETR_BF16)
+    if (delta_dtype == kActCode)
         hipLaunchKernelGGL(box_refine_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t *)delta, delta_row_stride, reference_points, num_boxes, groups, eps, out);
     else

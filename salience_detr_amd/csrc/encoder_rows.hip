@@ -76,10 +76,10 @@ __global__ void __launch_bounds__(kBlock) select_stack_kernel(const T *q, int64_
             const uint4 a = *reinterpret_cast<const uint4 *>(qs), pp = *reinterpret_cast<const uint4 *>(ps);
             *reinterpret_cast<uint4 *>(o1) = a;
             *reinterpret_cast<uint4 *>(o0) =
-                make_uint4(pack_bf16x2(bf16_lo(a.x) + bf16_lo(pp.x), bf16_hi(a.x) + bf16_hi(pp.x)),
-                           pack_bf16x2(bf16_lo(a.y) + bf16_lo(pp.y), bf16_hi(a.y) + bf16_hi(pp.y)),
-                           pack_bf16x2(bf16_lo(a.z) + bf16_lo(pp.z), bf16_hi(a.z) + bf16_hi(pp.z)),
-                           pack_bf16x2(bf16_lo(a.w) + bf16_lo(pp.w), bf16_hi(a.w) + bf16_hi(pp.w)));
+                make_uint4(pack_act2(act_lo(a.x) + act_lo(pp.x), act_hi(a.x) + act_hi(pp.x)),
+                           pack_act2(act_lo(a.y) + act_lo(pp.y), act_hi(a.y) + act_hi(pp.y)),
+                           pack_act2(act_lo(a.z) + act_lo(pp.z), act_hi(a.z) + act_hi(pp.z)),
+                           pack_act2(act_lo(a.w) + act_lo(pp.w), act_hi(a.w) + act_hi(pp.w)));
         }
     }
 }
@@ -100,10 +100,10 @@ __device__ __forceinline__ void add8(const T *a, const T *b, bool use_b, T *o)
         uint4 x = *reinterpret_cast<const uint4 *>(a);
         if (use_b) {
             const uint4 y = *reinterpret_cast<const uint4 *>(b);
-            x = make_uint4(pack_bf16x2(bf16_lo(x.x) + bf16_lo(y.x), bf16_hi(x.x) + bf16_hi(y.x)),
-                           pack_bf16x2(bf16_lo(x.y) + bf16_lo(y.y), bf16_hi(x.y) + bf16_hi(y.y)),
-                           pack_bf16x2(bf16_lo(x.z) + bf16_lo(y.z), bf16_hi(x.z) + bf16_hi(y.z)),
-                           pack_bf16x2(bf16_lo(x.w) + bf16_lo(y.w), bf16_hi(x.w) + bf16_hi(y.w)));
+            x = make_uint4(pack_act2(act_lo(x.x) + act_lo(y.x), act_hi(x.x) + act_hi(y.x)),
+                           pack_act2(act_lo(x.y) + act_lo(y.y), act_hi(x.y) + act_hi(y.y)),
+                           pack_act2(act_lo(x.z) + act_lo(y.z), act_hi(x.z) + act_hi(y.z)),
+                           pack_act2(act_lo(x.w) + act_lo(y.w), act_hi(x.w) + act_hi(y.w)));
         }
         *reinterpret_cast<uint4 *>(o) = x;
     }
@@ -197,7 +197,7 @@ extern "C" int sdetr_select_stack(sdetr_stream_t stream, const void *query, int6
         hipLaunchKernelGGL(select_stack_kernel<float>, dim3(rows_grid(total)), dim3(kBlock), 0, s, (const float *)query,
                            query_batch_stride, (const float *)pos, pos_batch_stride, index, total, num_select, channels,
                            (float *)out);
-    else if (dtype == SDETR_BF16)
+    else if (dtype == kActCode)
         hipLaunchKernelGGL(select_stack_kernel<bf16_t>, dim3(rows_grid(total)), dim3(kBlock), 0, s,
                            (const bf16_t *)query, query_batch_stride, (const bf16_t *)pos, pos_batch_stride, index, total,
                            num_select, channels, (bf16_t *)out);
@@ -240,7 +240,7 @@ extern "C" int sdetr_encoder_finalize(sdetr_stream_t stream, const void *tokens,
     if (dtype == SDETR_F32)
         return launch_finalize<float>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
                                       batch_size, spatial_size, sorted_rows, last_rows, channels, out);
-    if (dtype == SDETR_BF16)
+    if (dtype == kActCode)
         return launch_finalize<bf16_t>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
                                        batch_size, spatial_size, sorted_rows, last_rows, channels, out);
     return fail("encoder_finalize: bad dtype %d", dtype);
@@ -260,7 +260,7 @@ extern "C" int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *
     if (dtype == SDETR_F32)
         return launch_finalize<float>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
                                       batch_size, spatial_size, sorted_rows, last_rows, channels, out, false);
-    if (dtype == SDETR_BF16)
+    if (dtype == kActCode)
         return launch_finalize<bf16_t>(s, tokens, sorted_result, sorted_index, count, background, padding_mask,
                                        batch_size, spatial_size, sorted_rows, last_rows, channels, out, false);
     return fail("encoder_finalize_sorted: bad dtype %d", dtype);

@@ -96,8 +96,7 @@ constexpr int kTailChunks = 4;   // Wo [256 x 256] as 128 1-KB A-fragments: chun
 
 __device__ __forceinline__ f32x16_t mfma_bf16(uint4 a, uint4 b, f32x16_t c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
-                                                   0, 0, 0);
+    return mfma_act_32x32x16(a, b, c);
 }
 
 typedef short i16x2_t __attribute__((ext_vector_type(2)));
@@ -109,7 +108,7 @@ typedef __attribute__((address_space(3))) const char *lds_cptr_t;
 __device__ __forceinline__ void mfma_bf16_vgpr(uint4 a, uint4 b, f32x16_t &c)
 {
     const u32x4_t av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w};
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+    asm volatile("v_mfma_f32_32x32x16_" SDETR_ACT_MFMA_SUFFIX " %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
 }
 
 __device__ __forceinline__ uint4 lds_read16(lds_cptr_t p)
@@ -280,7 +279,7 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     auto residual = [&](int et, int g, float (&r)[4]) {   // (after swap_halves)
         const uint4 q = xb[2 * et + (g >> 1)];
         const uint32_t d0 = (g & 1) ? q.z : q.x, d1 = (g & 1) ? q.w : q.y;
-        r[0] = bf16_lo(d0); r[1] = bf16_hi(d0); r[2] = bf16_lo(d1); r[3] = bf16_hi(d1);
+        r[0] = act_lo(d0); r[1] = act_hi(d0); r[2] = act_lo(d1); r[3] = act_hi(d1);
     };
 
     f32x16_t yacc[8];
@@ -355,8 +354,8 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
                 const float x1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
                 const float x2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
                 const float x3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
-                d[2 * gg] = pack_bf16x2(x0, x1);
-                d[2 * gg + 1] = pack_bf16x2(x2, x3);
+                d[2 * gg] = pack_act2(x0, x1);
+                d[2 * gg + 1] = pack_act2(x2, x3);
             }
             xb[ks] = make_uint4(d[0], d[1], d[2], d[3]);   // x (bf16) in the accumulator-quad form
             // (pinned here: the code-sinking pass otherwise moves this arithmetic down to the first reader of x, past
@@ -425,10 +424,10 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
         // the VALU below reads registers an inline-asm MFMA wrote: hipcc cannot see that, so the wait states
         // (XDL write -> VALU read) are spelled out; the accumulator is an operand so that its readers stay below
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hacc));
-        hp[0] = make_uint4(relu_bf16x2(pack_bf16x2(hacc[0], hacc[1])), relu_bf16x2(pack_bf16x2(hacc[2], hacc[3])),
-                           relu_bf16x2(pack_bf16x2(hacc[4], hacc[5])), relu_bf16x2(pack_bf16x2(hacc[6], hacc[7])));
-        hp[1] = make_uint4(relu_bf16x2(pack_bf16x2(hacc[8], hacc[9])), relu_bf16x2(pack_bf16x2(hacc[10], hacc[11])),
-                           relu_bf16x2(pack_bf16x2(hacc[12], hacc[13])), relu_bf16x2(pack_bf16x2(hacc[14], hacc[15])));
+        hp[0] = make_uint4(relu_bf16x2(pack_act2(hacc[0], hacc[1])), relu_bf16x2(pack_act2(hacc[2], hacc[3])),
+                           relu_bf16x2(pack_act2(hacc[4], hacc[5])), relu_bf16x2(pack_act2(hacc[6], hacc[7])));
+        hp[1] = make_uint4(relu_bf16x2(pack_act2(hacc[8], hacc[9])), relu_bf16x2(pack_act2(hacc[10], hacc[11])),
+                           relu_bf16x2(pack_act2(hacc[12], hacc[13])), relu_bf16x2(pack_act2(hacc[14], hacc[15])));
         // pin the conversion HERE: once it has run the accumulator registers are free and the next bias can land in
         // them -- were its live range to reach past load_bias, the allocator would have to move the accumulator
         // between two asm MFMAs, a copy that reads registers the MFMA before it has not written yet
@@ -557,7 +556,7 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
                     const float y1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
                     const float y2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
                     const float y3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
-                    *reinterpret_cast<uint2 *>(orow + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+                    *reinterpret_cast<uint2 *>(orow + e0) = make_uint2(pack_act2(y0, y1), pack_act2(y2, y3));
                 }
                 // one e-tile at a time: hoisting all 64 gamma / beta reads above the arithmetic costs 256 registers
                 __builtin_amdgcn_sched_barrier(0);
@@ -584,8 +583,8 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
             const float y1 = fmaf(fmaf(yacc[et][4 * g + 1] + r[1], rstd, shift), gv.y, be.y);
             const float y2 = fmaf(fmaf(yacc[et][4 * g + 2] + r[2], rstd, shift), gv.z, be.z);
             const float y3 = fmaf(fmaf(yacc[et][4 * g + 3] + r[3], rstd, shift), gv.w, be.w);
-            d[2 * gg] = pack_bf16x2(y0, y1);
-            d[2 * gg + 1] = pack_bf16x2(y2, y3);
+            d[2 * gg] = pack_act2(y0, y1);
+            d[2 * gg + 1] = pack_act2(y2, y3);
         }
         xb[ks] = make_uint4(d[0], d[1], d[2], d[3]);
         asm volatile("" : "+v"(xb[ks].x), "+v"(xb[ks].y), "+v"(xb[ks].z), "+v"(xb[ks].w));
@@ -660,7 +659,7 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_kernel(const float *partial
     if (x) {   // (NULL: piece 0 of the partial products already carries bias + residual -- the TAIL form)
         const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
         const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
-        v0 = bv.x + bf16_lo(r.x); v1 = bv.y + bf16_hi(r.x); v2 = bv.z + bf16_lo(r.y); v3 = bv.w + bf16_hi(r.y);
+        v0 = bv.x + act_lo(r.x); v1 = bv.y + act_hi(r.x); v2 = bv.z + act_lo(r.y); v3 = bv.w + act_hi(r.y);
     }
     for (int s = 0; s < nsplit; ++s) {
         const float4 pv = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
@@ -677,8 +676,8 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_kernel(const float *partial
     const float rstd = rsqrtf(sq * (1.f / kFE) + eps);
     const float4 gv = *reinterpret_cast<const float4 *>(gamma + 4 * lane);
     const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * lane);
-    *reinterpret_cast<uint2 *>(out + o) = make_uint2(pack_bf16x2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
-                                                     pack_bf16x2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
+    *reinterpret_cast<uint2 *>(out + o) = make_uint2(pack_act2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
+                                                     pack_act2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
 }
 
 // The same second pass with the end-of-layer bookkeeping of sdetr_advance_rows in its store (the four hidden-split
@@ -708,7 +707,7 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float 
     if (x) {   // (NULL: piece 0 of the partial products already carries bias + residual -- the TAIL form)
         const uint2 r = *reinterpret_cast<const uint2 *>(x + o);
         const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
-        v0 = bv.x + bf16_lo(r.x); v1 = bv.y + bf16_hi(r.x); v2 = bv.z + bf16_lo(r.y); v3 = bv.w + bf16_hi(r.y);
+        v0 = bv.x + act_lo(r.x); v1 = bv.y + act_hi(r.x); v2 = bv.z + act_lo(r.y); v3 = bv.w + act_hi(r.y);
     }
     for (int s = 0; s < nsplit; ++s) {
         const float4 pv = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
@@ -725,8 +724,8 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float 
     const float rstd = rsqrtf(sq * (1.f / kFE) + eps);
     const float4 gv = *reinterpret_cast<const float4 *>(gamma + 4 * lane);
     const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * lane);
-    const uint2 y = make_uint2(pack_bf16x2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
-                               pack_bf16x2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
+    const uint2 y = make_uint2(pack_act2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
+                               pack_act2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
     *reinterpret_cast<uint2 *>(a.sorted_result + ((int64_t)b * a.sorted_rows + i) * kFE + 4 * lane) = y;
     if (feeds_next) *reinterpret_cast<uint2 *>(a.next_query + ((int64_t)b * a.next_rows + i) * kFE + 4 * lane) = y;
 }

@@ -65,10 +65,10 @@ __device__ __forceinline__ void finalize_all_role(const FinalizeJob &j, int role
         if (!(j.pad && j.pad[r])) {
             // (r < 2^31 is checked where the job is built: a 32-bit modulo instead of a 64-bit one per piece)
             const uint4 g = j.background[(int64_t)((uint32_t)r % (uint32_t)j.S) * 32 + piece];
-            o = make_uint4(pack_bf16x2(bf16_lo(a.x) + bf16_lo(g.x), bf16_hi(a.x) + bf16_hi(g.x)),
-                           pack_bf16x2(bf16_lo(a.y) + bf16_lo(g.y), bf16_hi(a.y) + bf16_hi(g.y)),
-                           pack_bf16x2(bf16_lo(a.z) + bf16_lo(g.z), bf16_hi(a.z) + bf16_hi(g.z)),
-                           pack_bf16x2(bf16_lo(a.w) + bf16_lo(g.w), bf16_hi(a.w) + bf16_hi(g.w)));
+            o = make_uint4(pack_act2(act_lo(a.x) + act_lo(g.x), act_hi(a.x) + act_hi(g.x)),
+                           pack_act2(act_lo(a.y) + act_lo(g.y), act_hi(a.y) + act_hi(g.y)),
+                           pack_act2(act_lo(a.z) + act_lo(g.z), act_hi(a.z) + act_hi(g.z)),
+                           pack_act2(act_lo(a.w) + act_lo(g.w), act_hi(a.w) + act_hi(g.w)));
         }
         j.out[t] = o;
     }

@@ -102,7 +102,7 @@ __device__ __forceinline__ float proj_elem<float>(const void *proj, int64_t idx)
 template <>
 __device__ __forceinline__ float proj_elem<bf16_t>(const void *proj, int64_t idx)
 {
-    return __uint_as_float((uint32_t) reinterpret_cast<const bf16_t *>(proj)[idx] << 16);
+    return act_lo((uint32_t) reinterpret_cast<const bf16_t *>(proj)[idx]);   // (the projection slab is an activation)
 }
 
 // One sample's descriptor: 4 corner byte offsets (relative to the block's value base, lane offset excluded)
@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
                         const int s = min(c0 + j + t * G, LP - 1);
                         const uint32_t xy = *reinterpret_cast<const uint32_t *>(
                             reinterpret_cast<const bf16_t *>(p.proj) + proj_row + ((int64_t)m * LP + s) * 2);
-                        rx[t] = bf16_lo(xy);
-                        ry[t] = bf16_hi(xy);
+                        rx[t] = act_lo(xy);
+                        ry[t] = act_hi(xy);
                         ra[t] = proj_elem<bf16_t>(p.proj, logit0 + s);
                     }
                 } else {
@@ -358,10 +358,10 @@ __global__ void __launch_bounds__(kBlock) msda_gather_kernel(GatherArgs p)
             bf16_t *out = reinterpret_cast<bf16_t *>(p.out) + o;
             if (CPL == 8) {
                 *reinterpret_cast<uint4 *>(out) =
-                    make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
-                               pack_bf16x2(acc[4 % CPL], acc[5 % CPL]), pack_bf16x2(acc[6 % CPL], acc[7 % CPL]));
+                    make_uint4(pack_act2(acc[0], acc[1]), pack_act2(acc[2], acc[3]),
+                               pack_act2(acc[4 % CPL], acc[5 % CPL]), pack_act2(acc[6 % CPL], acc[7 % CPL]));
             } else {
-                *reinterpret_cast<uint2 *>(out) = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+                *reinterpret_cast<uint2 *>(out) = make_uint2(pack_act2(acc[0], acc[1]), pack_act2(acc[2], acc[3]));
             }
         } else {
             float *out = reinterpret_cast<float *>(p.out) + o;
@@ -422,9 +422,9 @@ __global__ void __launch_bounds__(kBlock) msda_gather_l4p4_kernel(GatherArgs p)
             const bf16_t *pp = reinterpret_cast<const bf16_t *>(p.proj);
             const uint4 o = *reinterpret_cast<const uint4 *>(pp + o_idx);
             const uint2 gg = *reinterpret_cast<const uint2 *>(pp + l_idx);
-            ox[0] = bf16_lo(o.x); oy[0] = bf16_hi(o.x); ox[1] = bf16_lo(o.y); oy[1] = bf16_hi(o.y);
-            ox[2] = bf16_lo(o.z); oy[2] = bf16_hi(o.z); ox[3] = bf16_lo(o.w); oy[3] = bf16_hi(o.w);
-            lg[0] = bf16_lo(gg.x); lg[1] = bf16_hi(gg.x); lg[2] = bf16_lo(gg.y); lg[3] = bf16_hi(gg.y);
+            ox[0] = act_lo(o.x); oy[0] = act_hi(o.x); ox[1] = act_lo(o.y); oy[1] = act_hi(o.y);
+            ox[2] = act_lo(o.z); oy[2] = act_hi(o.z); ox[3] = act_lo(o.w); oy[3] = act_hi(o.w);
+            lg[0] = act_lo(gg.x); lg[1] = act_hi(gg.x); lg[2] = act_lo(gg.y); lg[3] = act_hi(gg.y);
         } else {
             const float *pp = reinterpret_cast<const float *>(p.proj);
             const float4 o0 = *reinterpret_cast<const float4 *>(pp + o_idx);
@@ -512,8 +512,8 @@ __global__ void __launch_bounds__(kBlock) msda_gather_l4p4_kernel(GatherArgs p)
         const int64_t o = row * D + j * 8;
         if (p.out_bf16) {
             *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + o) =
-                make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
-                           pack_bf16x2(acc[6], acc[7]));
+                make_uint4(pack_act2(acc[0], acc[1]), pack_act2(acc[2], acc[3]), pack_act2(acc[4], acc[5]),
+                           pack_act2(acc[6], acc[7]));
         } else {
             float *out = reinterpret_cast<float *>(p.out) + o;
             *reinterpret_cast<float4 *>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -669,7 +669,7 @@ extern "C" int sdetr_msda_forward_head_major(sdetr_stream_t stream, const void *
     if ((int64_t)B * Nq == 0) return 0;
     GatherArgs a{};
     a.value = reinterpret_cast<const char *>(value_hm);
-    a.shapes = shapes; a.lsi = lsi; a.loc = loc; a.aw = aw; a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.shapes = shapes; a.lsi = lsi; a.loc = loc; a.aw = aw; a.out = out; a.out_bf16 = (out_dtype == kActCode);
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
     if (value_dtype == SDETR_F32) return dispatch_d<float, true, false>(stream, a, D);
     if (value_dtype == SDETR_BF16) return dispatch_d<bf16_t, true, false>(stream, a, D);
@@ -693,7 +693,7 @@ extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value
     if (L > kMaxLevels) return fail("msda_fused_forward: at most %d levels", kMaxLevels);
     if (!proj_head_major && proj_row_stride < (int64_t)M * L * P * 3)
         return fail("msda_fused_forward: proj row stride too small");
-    if (proj_head_major && !(D == 32 && L == 4 && P == 4 && proj_dtype == SDETR_BF16 &&
+    if (proj_head_major && !(D == 32 && L == 4 && P == 4 && proj_dtype == kActCode &&
                              (value_dtype == SDETR_BF16 || value_dtype == SDETR_F16)))
         return fail("msda_fused_forward: the head-major projection layout is built for D=32, L=P=4, bf16 projections "
                     "and 16-bit value maps");
@@ -701,9 +701,9 @@ extern "C" int sdetr_msda_fused_forward(sdetr_stream_t stream, const void *value
     GatherArgs a{};
     a.value = reinterpret_cast<const char *>(value_hm);
     a.shapes = shapes; a.lsi = lsi; a.ref = ref; a.ref_dim = ref_dim; a.ref_batch_stride = ref_batch_stride;
-    a.proj = proj; a.proj_bf16 = (proj_dtype == SDETR_BF16); a.proj_stride = proj_row_stride; a.order = order;
+    a.proj = proj; a.proj_bf16 = (proj_dtype == kActCode); a.proj_stride = proj_row_stride; a.order = order;
     a.proj_hm = proj_head_major ? 1 : 0;
-    a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.out = out; a.out_bf16 = (out_dtype == kActCode);
     a.B = B; a.Nv = Nv; a.M = M; a.L = L; a.Nq = Nq; a.P = P;
     const bool l4p4 = D == 32 && L == 4 && P == 4 && (proj_head_major || (proj_row_stride % 8) == 0) &&
                       (reinterpret_cast<uintptr_t>(proj) % 16) == 0 && (reinterpret_cast<uintptr_t>(ref) % 16) == 0;

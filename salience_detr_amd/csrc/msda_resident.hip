@@ -234,9 +234,9 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
         const RowIn cur = nxt;
         nxt = load_row(min(rg + kRWaves, ngroups - 1));
         float ox[4], oy[4], lg[4];
-        ox[0] = bf16_lo(cur.o.x); oy[0] = bf16_hi(cur.o.x); ox[1] = bf16_lo(cur.o.y); oy[1] = bf16_hi(cur.o.y);
-        ox[2] = bf16_lo(cur.o.z); oy[2] = bf16_hi(cur.o.z); ox[3] = bf16_lo(cur.o.w); oy[3] = bf16_hi(cur.o.w);
-        lg[0] = bf16_lo(cur.gg.x); lg[1] = bf16_hi(cur.gg.x); lg[2] = bf16_lo(cur.gg.y); lg[3] = bf16_hi(cur.gg.y);
+        ox[0] = act_lo(cur.o.x); oy[0] = act_hi(cur.o.x); ox[1] = act_lo(cur.o.y); oy[1] = act_hi(cur.o.y);
+        ox[2] = act_lo(cur.o.z); oy[2] = act_hi(cur.o.z); ox[3] = act_lo(cur.o.w); oy[3] = act_hi(cur.o.w);
+        lg[0] = act_lo(cur.gg.x); lg[1] = act_hi(cur.gg.x); lg[2] = act_lo(cur.gg.y); lg[3] = act_hi(cur.gg.y);
         // softmax over the quad's 16 logits (quad_perm DPP: lane ^ 1, lane ^ 2 -- no LDS round trip)
         float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
         mx = fmaxf(mx, quad_xor1(mx));
@@ -371,8 +371,8 @@ __global__ void __launch_bounds__(kRThreads) msda_resident_kernel(ResidentArgs p
             const int64_t o = (((int64_t)b * p.Nq + q) * p.M + m) * 32 + j * 8;
             if (p.out_bf16) {
                 *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + o) =
-                    make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
-                               pack_bf16x2(acc[6], acc[7]));
+                    make_uint4(pack_act2(acc[0], acc[1]), pack_act2(acc[2], acc[3]), pack_act2(acc[4], acc[5]),
+                               pack_act2(acc[6], acc[7]));
             } else {
                 float *out = reinterpret_cast<float *>(p.out) + o;
                 *reinterpret_cast<float4 *>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -450,7 +450,9 @@ struct BorderedArgs {
 constexpr int kBMaxResidentPx = (kRLdsBudget - kRWaves * kRWeightBytes) / 64;   // 1536 records
 // corner accumulation of the bordered kernel for 16-bit outputs: 0 exact fp32 products, 1 / 2 packed fp16 (round 5, see
 // the PK helpers in front of the kernel); SDETR_MSDA_PK overrides it for A/B runs
-constexpr int kDefaultPackedAccumulate = 1;
+// (the fp16-activation flavour keeps the exact products: its outputs carry three more mantissa bits than bf16 ones and
+// the packed form's roundings would be the larger part of their error)
+constexpr int kDefaultPackedAccumulate = SDETR_ACT_IS_F16 ? 0 : 1;
 constexpr int kBPieces = (kBMaxResidentPx * 64 + kRWaves * 1024 - 1) / (kRWaves * 1024);   // copy instructions per wave: 6
 
 __device__ __forceinline__ uint4 buffer_load16_s(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff)
@@ -790,9 +792,9 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
         slot_cur = slot_nxt;
         slot_nxt = row_slot(rg + 2 * kRWaves);
         float ox[4], oy[4], lg[4];
-        ox[0] = bf16_lo(cur.o.x); oy[0] = bf16_hi(cur.o.x); ox[1] = bf16_lo(cur.o.y); oy[1] = bf16_hi(cur.o.y);
-        ox[2] = bf16_lo(cur.o.z); oy[2] = bf16_hi(cur.o.z); ox[3] = bf16_lo(cur.o.w); oy[3] = bf16_hi(cur.o.w);
-        lg[0] = bf16_lo(cur.gg.x); lg[1] = bf16_hi(cur.gg.x); lg[2] = bf16_lo(cur.gg.y); lg[3] = bf16_hi(cur.gg.y);
+        ox[0] = act_lo(cur.o.x); oy[0] = act_hi(cur.o.x); ox[1] = act_lo(cur.o.y); oy[1] = act_hi(cur.o.y);
+        ox[2] = act_lo(cur.o.z); oy[2] = act_hi(cur.o.z); ox[3] = act_lo(cur.o.w); oy[3] = act_hi(cur.o.w);
+        lg[0] = act_lo(cur.gg.x); lg[1] = act_hi(cur.gg.x); lg[2] = act_lo(cur.gg.y); lg[3] = act_hi(cur.gg.y);
         // (plain v_max3 / v_max with a DPP operand: fmaxf() adds a canonicalising v_max x, x per operand)
         float mx = max3_f32(lg[0], lg[1], lg[2]);
         mx = max_f32(mx, lg[3]);
@@ -1031,8 +1033,8 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             // this image's output rows through a buffer resource: (row * M + head) * 32 channels, 32-bit offsets
             const uint32_t oe = (__umul24(q, (uint32_t)p.M) + (uint32_t)m) * 32u + (uint32_t)j * 8u;
             if (p.out_bf16) {
-                buffer_store16(out_rsrc, oe * 2u, make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
-                                                             pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])));
+                buffer_store16(out_rsrc, oe * 2u, make_uint4(pack_act2(acc[0], acc[1]), pack_act2(acc[2], acc[3]),
+                                                             pack_act2(acc[4], acc[5]), pack_act2(acc[6], acc[7])));
             } else {
                 buffer_store16(out_rsrc, oe * 4u, make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]),
                                                              __float_as_uint(acc[2]), __float_as_uint(acc[3])));
@@ -1093,7 +1095,7 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     // occupy: it spills at the 128-register budget of a 16-wave workgroup, so bf16 maps stay on the direct kernel)
     if (value_dtype != SDETR_F16)
         return fail("msda_resident_forward: fp16 head-major value maps only (dtype %d)", value_dtype);
-    if (out_dtype != SDETR_BF16 && out_dtype != SDETR_F32) return fail("msda_resident_forward: out must be bf16 or f32");
+    if (out_dtype != kActCode && out_dtype != SDETR_F32) return fail("msda_resident_forward: out must be bf16 or f32");
     if (ref_batch_stride == 0) ref_batch_stride = (int64_t)Nq * 4 * ref_dim;
     if (ref_batch_stride < (int64_t)Nq * 4 * ref_dim || (ref_batch_stride % ref_dim))
         return fail("msda_resident_forward: bad reference point batch stride");
@@ -1124,7 +1126,7 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     a.value = reinterpret_cast<const char *>(value_hm);
     a.ref = ref; a.ref_batch_stride = ref_batch_stride; a.ref_dim = ref_dim;
     a.proj = reinterpret_cast<const bf16_t *>(proj_hm_bf16);
-    a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.out = out; a.out_bf16 = (out_dtype == kActCode);
     a.B = B; a.Nv = Nv; a.M = M; a.Nq = Nq;
     // Maps beyond what the Infinity Cache holds next to everything else (256 MiB; the benchmark's two images: 46 MB): the
     // chip works on FOUR images at a time (every workgroup walks the images of its lane), so that the maps being gathered
@@ -1217,7 +1219,7 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
         return fail("Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
     if (value_dtype != SDETR_F16)
         return fail("msda_bordered_forward: fp16 bordered head-major value maps only (dtype %d)", value_dtype);
-    if (out_dtype != SDETR_BF16 && out_dtype != SDETR_F32) return fail("msda_bordered_forward: out must be bf16 or f32");
+    if (out_dtype != kActCode && out_dtype != SDETR_F32) return fail("msda_bordered_forward: out must be bf16 or f32");
     if (ref_batch_stride == 0) ref_batch_stride = (int64_t)Nq * 4 * ref_dim;
     if (ref_batch_stride < (int64_t)Nq * 4 * ref_dim || (ref_batch_stride % ref_dim))
         return fail("msda_bordered_forward: bad reference point batch stride");
@@ -1256,7 +1258,7 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     a.ref = ref; a.ref_batch_stride = ref_batch_stride; a.ref_dim = ref_dim;
     a.proj = reinterpret_cast<const bf16_t *>(proj_hm_bf16);
     a.perm = row_order; a.perm_batch_stride = row_order_batch_stride;
-    a.out = out; a.out_bf16 = (out_dtype == SDETR_BF16);
+    a.out = out; a.out_bf16 = (out_dtype == kActCode);
     a.B = B; a.Np = Np; a.M = M; a.Nq = Nq;
     const int cus = device_cu_count();
     int lanes = 0;

@@ -28,11 +28,11 @@ struct Store<bf16_t> {
     static __device__ __forceinline__ float4 load4(const bf16_t *p)
     {
         const uint2 u = *reinterpret_cast<const uint2 *>(p);
-        return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+        return make_float4(act_lo(u.x), act_hi(u.x), act_lo(u.y), act_hi(u.y));
     }
     static __device__ __forceinline__ void store4(bf16_t *p, float4 v)
     {
-        *reinterpret_cast<uint2 *>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        *reinterpret_cast<uint2 *>(p) = make_uint2(pack_act2(v.x, v.y), pack_act2(v.z, v.w));
     }
 };
 
@@ -174,8 +174,7 @@ struct ConvMfmaArgs {
 
 __device__ __forceinline__ nk_f32x16_t nk_mfma(uint4 a, uint4 b, nk_f32x16_t c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nk_bf16x8_t, a), __builtin_bit_cast(nk_bf16x8_t, b),
-                                                   c, 0, 0, 0);
+    return mfma_act_32x32x16(a, b, c);
 }
 
 template <bool CHUNK4>  // in_per_group % 64 == 0: k-steps in groups of four
@@ -298,7 +297,7 @@ __global__ void __launch_bounds__(kBlock) conv3x3_pack_kernel(const float *w, in
         const int mt = (int)(f % MT);
         const int g = (int)(f / MT);
         const int ci = c16 * 16 + (lane >> 5) * 8 + j, co = mt * 32 + (lane & 31);
-        out[e] = (bf16_t)f32_to_bf16_bits(w[(((int64_t)g * 9 + tap) * CiG + ci) * CoG + co]);
+        out[e] = (bf16_t)f32_to_act_bits(w[(((int64_t)g * 9 + tap) * CiG + ci) * CoG + co]);
     }
 }
 
@@ -541,7 +540,7 @@ extern "C" int sdetr_neck_conv3x3(sdetr_stream_t stream, const void *x, int dtyp
     if ((in_per_group % 4) || (out_per_group % 4) || (x_row_stride % 4) || x_row_stride < groups * in_per_group)
         return fail("neck_conv3x3: channels per group and the row stride must be multiples of 4");
     if (stride != 1 && stride != 2) return fail("neck_conv3x3: stride %d (1 or 2)", stride);
-    if (dtype != SDETR_F32 && dtype != SDETR_BF16) return fail("neck_conv3x3: bad dtype %d", dtype);
+    if (dtype != SDETR_F32 && dtype != kActCode) return fail("neck_conv3x3: bad dtype %d", dtype);
     if (activation < 0 || activation > 1) return fail("neck_conv3x3: bad activation %d", activation);
     if (batch_size == 0) return 0;
     if (!x || !weight || !out) return fail("neck_conv3x3: null pointer");
@@ -634,7 +633,7 @@ extern "C" int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_ro
         return fail("neck_combine: row strides must be multiples of 4 and >= channels");
     if (up && (up_height <= 0 || up_width <= 0 || (up_row_stride % 4) || up_row_stride < channels))
         return fail("neck_combine: bad up-sampling source");
-    if (dtype != SDETR_F32 && dtype != SDETR_BF16) return fail("neck_combine: bad dtype %d", dtype);
+    if (dtype != SDETR_F32 && dtype != kActCode) return fail("neck_combine: bad dtype %d", dtype);
     if (activation < 0 || activation > 1) return fail("neck_combine: bad activation %d", activation);
     if (batch_size == 0) return 0;
     if (!a || !out) return fail("neck_combine: null pointer");
@@ -666,7 +665,7 @@ extern "C" int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, in
     if (batch_size < 0 || pixels <= 0 || channels <= 0 || (channels % 4) || channels > 256)
         return fail("neck_gate_shortcut: channels must be a multiple of 4, at most 256 (got %d)", channels);
     if (hidden <= 0 || hidden > 64) return fail("neck_gate_shortcut: hidden width %d (1..64)", hidden);
-    if (dtype != SDETR_F32 && dtype != SDETR_BF16) return fail("neck_gate_shortcut: bad dtype %d", dtype);
+    if (dtype != SDETR_F32 && dtype != kActCode) return fail("neck_gate_shortcut: bad dtype %d", dtype);
     if ((shortcut_row_stride % 4) || shortcut_row_stride < channels) return fail("neck_gate_shortcut: bad shortcut stride");
     if (shortcut2 && ((shortcut2_row_stride % 4) || shortcut2_row_stride < channels))
         return fail("neck_gate_shortcut: bad second shortcut stride");

@@ -48,8 +48,8 @@ template <>
 __device__ __forceinline__ void load8<bf16_t>(const bf16_t *p, float *v)
 {
     const uint4 a = *reinterpret_cast<const uint4 *>(p);
-    v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
-    v[4] = bf16_lo(a.z); v[5] = bf16_hi(a.z); v[6] = bf16_lo(a.w); v[7] = bf16_hi(a.w);
+    v[0] = act_lo(a.x); v[1] = act_hi(a.x); v[2] = act_lo(a.y); v[3] = act_hi(a.y);
+    v[4] = act_lo(a.z); v[5] = act_hi(a.z); v[6] = act_lo(a.w); v[7] = act_hi(a.w);
 }
 template <typename T>
 __device__ __forceinline__ void store8(T *p, const float *v);
@@ -62,8 +62,8 @@ __device__ __forceinline__ void store8<float>(float *p, const float *v)
 template <>
 __device__ __forceinline__ void store8<bf16_t>(bf16_t *p, const float *v)
 {
-    *reinterpret_cast<uint4 *>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                              pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    *reinterpret_cast<uint4 *>(p) = make_uint4(pack_act2(v[0], v[1]), pack_act2(v[2], v[3]),
+                                              pack_act2(v[4], v[5]), pack_act2(v[6], v[7]));
 }
 
 // G = lanes per row (C = 8 * G * K with K register rounds; here K = 1: C <= 512)
@@ -207,7 +207,9 @@ extern "C" int sdetr_layernorm(sdetr_stream_t stream, const void *x, const void 
     a.res_batch_stride = res_batch_stride; a.res_row_stride = res_row_stride;
     a.rows = rows; a.n_per_batch = rows_per_batch; a.C = channels; a.eps = eps;
     a.scatter_index = scatter_index; a.out_batch_rows = out_batch_rows; a.gather_x = gather_x ? 1 : 0;
-    const int key = x_dtype * 4 + param_dtype * 2 + out_dtype;
+    // dtype codes -> 0 (fp32) / 1 (the library's 16-bit activation type: SDETR_BF16 here, SDETR_F16 in the fp16 flavour)
+    auto bit = [](int dt) { return dt == SDETR_F32 ? 0 : (dt == kActCode ? 1 : -64); };
+    const int key = bit(x_dtype) * 4 + bit(param_dtype) * 2 + bit(out_dtype);
     switch (key) {
         case 0: return launch_ln<float, float, float>(stream, a);
         case 1: return launch_ln<float, float, bf16_t>(stream, a);

@@ -90,8 +90,8 @@ __device__ __forceinline__ void pyramid_flatten_body(const FlattenArgs &p, int b
             p.sum_out[o] = keep ? f + q : 0.f;
             // bf16 copies: even lanes store channel pairs (4-byte stores; C is even)
             if (!(tx & 1) && c + 1 < p.C) {
-                if (p.feat_bf16) *reinterpret_cast<uint32_t *>(p.feat_bf16 + o) = pack_bf16x2(f, tf[tx + 1][ty + 8 * r]);
-                if (p.pos_bf16) *reinterpret_cast<uint32_t *>(p.pos_bf16 + o) = pack_bf16x2(q, tp[tx + 1][ty + 8 * r]);
+                if (p.feat_bf16) *reinterpret_cast<uint32_t *>(p.feat_bf16 + o) = pack_act2(f, tf[tx + 1][ty + 8 * r]);
+                if (p.pos_bf16) *reinterpret_cast<uint32_t *>(p.pos_bf16 + o) = pack_act2(q, tp[tx + 1][ty + 8 * r]);
             }
             if (c == 0) p.mask_out[(int64_t)b * p.S + p.start + t] = pad ? 1 : 0;
         }
@@ -163,8 +163,8 @@ __device__ __forceinline__ void pyramid_flatten_wide_body(const FlattenArgs &p, 
         if (p.pos_out) *reinterpret_cast<float4 *>(p.pos_out + o) = qv;
         *reinterpret_cast<float4 *>(p.sum_out + o) =
             keep ? make_float4(fv.x + qv.x, fv.y + qv.y, fv.z + qv.z, fv.w + qv.w) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.feat_bf16) *reinterpret_cast<uint2 *>(p.feat_bf16 + o) = make_uint2(pack_bf16x2(fv.x, fv.y), pack_bf16x2(fv.z, fv.w));
-        if (p.pos_bf16) *reinterpret_cast<uint2 *>(p.pos_bf16 + o) = make_uint2(pack_bf16x2(qv.x, qv.y), pack_bf16x2(qv.z, qv.w));
+        if (p.feat_bf16) *reinterpret_cast<uint2 *>(p.feat_bf16 + o) = make_uint2(pack_act2(fv.x, fv.y), pack_act2(fv.z, fv.w));
+        if (p.pos_bf16) *reinterpret_cast<uint2 *>(p.pos_bf16 + o) = make_uint2(pack_act2(qv.x, qv.y), pack_act2(qv.z, qv.w));
         if (c4 == 0 && ch0 == 0) p.mask_out[(int64_t)b * p.S + p.start + t] = pad ? 1 : 0;
     }
 }
@@ -213,7 +213,7 @@ __device__ __forceinline__ float to_f32(T v);
 template <>
 __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <>
-__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return act_lo((uint32_t)v); }   // (a 16-bit activation element)
 
 // 16 lanes per row; rows = B*Nq
 template <typename T>
@@ -505,7 +505,7 @@ extern "C" int sdetr_class_max_times(sdetr_stream_t stream, const void *score, i
     if (score_dtype == SDETR_F32)
         hipLaunchKernelGGL(class_max_times_kernel<float>, grid, block, 0, stream, (const float *)score, scale, rows,
                            num_classes, rows_per_batch, scale_batch_stride, out);
-    else if (score_dtype == SDETR_BF16)
+    else if (score_dtype == kActCode)
         hipLaunchKernelGGL(class_max_times_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t *)score, scale, rows,
                            num_classes, rows_per_batch, scale_batch_stride, out);
     else

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) proposal_refine_kernel(const DT *delta, c
     float v[4];
     if constexpr (sizeof(DT) == 2) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = __uint_as_float((uint32_t)d[k] << 16);
+        for (int k = 0; k < 4; ++k) v[k] = act_lo((uint32_t)d[k]);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = d[k];
@@ -267,13 +267,13 @@ extern "C" int sdetr_proposal_refine(sdetr_stream_t stream, const void *delta, i
                                      int batch_size, int spatial_size, int num_select, float *out)
 {
     if (batch_size < 0 || spatial_size < 0 || num_select < 0) return fail("proposal_refine: bad sizes");
-    if (delta_dtype != SDETR_F32 && delta_dtype != SDETR_BF16) return fail("proposal_refine: delta dtype must be f32 or bf16");
+    if (delta_dtype != SDETR_F32 && delta_dtype != kActCode) return fail("proposal_refine: delta dtype must be f32 or bf16");
     const int64_t total = (int64_t)batch_size * num_select;
     if (total == 0) return 0;
     if (!delta || !proposal_logit || !index || !out) return fail("proposal_refine: null pointer");
     if (index_batch_stride < num_select) return fail("proposal_refine: index batch stride too small");
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (delta_dtype == SDETR_BF16)
+    if (delta_dtype == kActCode)
         hipLaunchKernelGGL(proposal_refine_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const uint16_t *)delta, proposal_logit, index, index_batch_stride, spatial_size, num_select,
                            total, out);

@@ -75,8 +75,8 @@ __global__ void __launch_bounds__(kBlock) head_major_kernel(const ST *src, int64
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
         } else {
             const uint4 a = *reinterpret_cast<const uint4 *>(s);
-            v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
-            v[4] = bf16_lo(a.z); v[5] = bf16_hi(a.z); v[6] = bf16_lo(a.w); v[7] = bf16_hi(a.w);
+            v[0] = act_lo(a.x); v[1] = act_hi(a.x); v[2] = act_lo(a.y); v[3] = act_hi(a.y);
+            v[4] = act_lo(a.z); v[5] = act_hi(a.z); v[6] = act_lo(a.w); v[7] = act_hi(a.w);
         }
         // destination [group][B][M][Nv][D]
         DT *d = dst + ((((int64_t)(m / M) * B + b) * M + (m % M)) * Nv + pix) * D + ch;
@@ -165,10 +165,10 @@ extern "C" int sdetr_value_to_head_major(sdetr_stream_t stream, const void *src,
                        pad_mask, total, B, Nv, M_all, M, D, (DT *)dst)
     if (src_dtype == SDETR_F32 && dst_dtype == SDETR_F32) SDETR_HM(float, float);
     else if (src_dtype == SDETR_F32 && dst_dtype == SDETR_BF16) SDETR_HM(float, bf16_t);
-    else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_BF16) SDETR_HM(bf16_t, bf16_t);
-    else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_F32) SDETR_HM(bf16_t, float);
+    else if (src_dtype == kActCode && dst_dtype == SDETR_BF16) SDETR_HM(bf16_t, bf16_t);
+    else if (src_dtype == kActCode && dst_dtype == SDETR_F32) SDETR_HM(bf16_t, float);
     else if (src_dtype == SDETR_F32 && dst_dtype == SDETR_F16) SDETR_HM(float, half_t);
-    else if (src_dtype == SDETR_BF16 && dst_dtype == SDETR_F16) SDETR_HM(bf16_t, half_t);
+    else if (src_dtype == kActCode && dst_dtype == SDETR_F16) SDETR_HM(bf16_t, half_t);
     else return fail("value_to_head_major: bad dtypes %d -> %d", src_dtype, dst_dtype);
 #undef SDETR_HM
     return check_launch("value_to_head_major");

@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(kBlock, 1) token_linear_ln_kernel(TLNArgs p)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const uint2 r = rbuf[nt * 4 + g];
-            const float v0 = acc[nt][4 * g] + bf16_lo(r.x), v1 = acc[nt][4 * g + 1] + bf16_hi(r.x);
-            const float v2 = acc[nt][4 * g + 2] + bf16_lo(r.y), v3 = acc[nt][4 * g + 3] + bf16_hi(r.y);
+            const float v0 = acc[nt][4 * g] + act_lo(r.x), v1 = acc[nt][4 * g + 1] + act_hi(r.x);
+            const float v2 = acc[nt][4 * g + 2] + act_lo(r.y), v3 = acc[nt][4 * g + 3] + act_hi(r.y);
             sum += (v0 + v1) + (v2 + v3);
             sq = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, sq))));
         }
@@ -145,11 +145,11 @@ __global__ void __launch_bounds__(kBlock, 1) token_linear_ln_kernel(TLNArgs p)
                 const float4 gv = *reinterpret_cast<const float4 *>(par + kTLK + e0);
                 const float4 be = *reinterpret_cast<const float4 *>(par + 2 * kTLK + e0);
                 const uint2 r = rbuf[nt * 4 + g];
-                const float y0 = fmaf(fmaf(acc[nt][4 * g] + bf16_lo(r.x), rstd, shift), gv.x, be.x);
-                const float y1 = fmaf(fmaf(acc[nt][4 * g + 1] + bf16_hi(r.x), rstd, shift), gv.y, be.y);
-                const float y2 = fmaf(fmaf(acc[nt][4 * g + 2] + bf16_lo(r.y), rstd, shift), gv.z, be.z);
-                const float y3 = fmaf(fmaf(acc[nt][4 * g + 3] + bf16_hi(r.y), rstd, shift), gv.w, be.w);
-                *reinterpret_cast<uint2 *>(o + e0) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+                const float y0 = fmaf(fmaf(acc[nt][4 * g] + act_lo(r.x), rstd, shift), gv.x, be.x);
+                const float y1 = fmaf(fmaf(acc[nt][4 * g + 1] + act_hi(r.x), rstd, shift), gv.y, be.y);
+                const float y2 = fmaf(fmaf(acc[nt][4 * g + 2] + act_lo(r.y), rstd, shift), gv.z, be.z);
+                const float y3 = fmaf(fmaf(acc[nt][4 * g + 3] + act_hi(r.y), rstd, shift), gv.w, be.w);
+                *reinterpret_cast<uint2 *>(o + e0) = make_uint2(pack_act2(y0, y1), pack_act2(y2, y3));
             }
             __builtin_amdgcn_sched_barrier(0);   // one tile at a time: all 64 gamma / beta reads up front cost 256 registers
         }

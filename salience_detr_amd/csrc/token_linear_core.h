@@ -64,8 +64,7 @@ inline int tl_set_bordered(TLArgs &a, const sdetr_bordered_layout *bordered, int
 
 __device__ __forceinline__ tl_f32x16_t tl_mfma(uint4 a, uint4 b, tl_f32x16_t c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tl_bf16x8_t, a), __builtin_bit_cast(tl_bf16x8_t, b),
-                                                   c, 0, 0, 0);
+    return mfma_act_32x32x16(a, b, c);
 }
 
 // Weights move in STEPS of four tiles (64 KB): one block barrier and one round of LDS-DMA latency per 64 MFMAs
@@ -101,7 +100,7 @@ __device__ __forceinline__ uint4 tl_lds_read16(tl_lds_cptr_t p)
 
 __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b)
 {
-    return pack_bf16x2(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
+    return pack_act2(act_lo(a) + act_lo(b), act_hi(a) + act_hi(b));
 }
 
 // WAVES = 4: 128 tokens per block (the per-layer projections: <= 256 blocks, one per CU); WAVES = 8: 256 tokens per
@@ -294,9 +293,9 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (EPI == kHeadMajor)
-                        d[i] = masked ? 0u : (p.hm_f16 ? pack_f16x2(acc[2 * i], acc[2 * i + 1]) : pack_bf16x2(acc[2 * i], acc[2 * i + 1]));
+                        d[i] = masked ? 0u : (p.hm_f16 ? pack_f16x2(acc[2 * i], acc[2 * i + 1]) : pack_bf16x2(acc[2 * i], acc[2 * i + 1]));   // (value maps: their own explicit type)
                     else
-                        d[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
+                        d[i] = pack_act2(acc[2 * i], acc[2 * i + 1]);
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)

@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint2 bv = *reinterpret_cast<const uint2 *>(p.bias + ftile * 32 + 8 * g + 4 * h);
-        bias[4 * g] = bf16_lo(bv.x); bias[4 * g + 1] = bf16_hi(bv.x);
-        bias[4 * g + 2] = bf16_lo(bv.y); bias[4 * g + 3] = bf16_hi(bv.y);
+        bias[4 * g] = act_lo(bv.x); bias[4 * g + 1] = act_hi(bv.x);
+        bias[4 * g + 2] = act_lo(bv.y); bias[4 * g + 3] = act_hi(bv.y);
     }
     // rows of the accumulator = features, column = my token; padded tokens are written as zeros (finite keys / values)
     if (qk_tile) {
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
             for (int r = 0; r < 4; ++r) v[r] = valid ? acc[4 * g + r] + bias[4 * g + r] : 0.f;
             bf16_t *out = ftile < 8 ? p.qk + ((int64_t)b * p.Npad + i) * 256 + head * 32 + 8 * g + 4 * h
                                     : kbase + tk_k_index(b, head, i, 8 * g + 4 * h, p.Npad);
-            *reinterpret_cast<uint2 *>(out) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            *reinterpret_cast<uint2 *>(out) = make_uint2(pack_act2(v[0], v[1]), pack_act2(v[2], v[3]));
         }
     } else {
         const tk_f32x16_t acc = inproj_tile<false>(wr, xr, pr);
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
         for (int r = 0; r < 16; ++r) {
             const int ch = tk_row(r, h);
             const float v = valid ? acc[r] + bias[r] : 0.f;
-            p.vt[tk_vt_index(b, head, i, ch, p.Npad)] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+            p.vt[tk_vt_index(b, head, i, ch, p.Npad)] = (bf16_t)(pack_act2(v, 0.f) & 0xffffu);
         }
     }
 }

@@ -11,17 +11,16 @@ typedef float tk_f32x16_t __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ tk_f32x16_t tk_mfma(uint4 a, uint4 b, tk_f32x16_t c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tk_bf16x8_t, a), __builtin_bit_cast(tk_bf16x8_t, b),
-                                                   c, 0, 0, 0);
+    return mfma_act_32x32x16(a, b, c);
 }
 // accumulator row of register i for lane half h (v_mfma_f32_32x32x16: C[row][col = lane & 31])
 __device__ __forceinline__ int tk_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 __device__ __forceinline__ uint4 tk_pack_half(const tk_f32x16_t &c, int m)
 {
-    return make_uint4(pack_bf16x2(c[8 * m], c[8 * m + 1]), pack_bf16x2(c[8 * m + 2], c[8 * m + 3]),
-                      pack_bf16x2(c[8 * m + 4], c[8 * m + 5]), pack_bf16x2(c[8 * m + 6], c[8 * m + 7]));
+    return make_uint4(pack_act2(c[8 * m], c[8 * m + 1]), pack_act2(c[8 * m + 2], c[8 * m + 3]),
+                      pack_act2(c[8 * m + 4], c[8 * m + 5]), pack_act2(c[8 * m + 6], c[8 * m + 7]));
 }
-__device__ __forceinline__ float tk_bf16(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ float tk_bf16(bf16_t v) { return act_lo((uint32_t)v); }   // (one activation element -> f32)
 
 constexpr int kTkE = 256, kTkHeads = 8, kTkHd = 32;
 
@@ -111,8 +110,7 @@ typedef float tk_f32x4_t __attribute__((ext_vector_type(4)));
 // C lane l = column l & 15, rows 4 (l >> 4) + 0..3
 __device__ __forceinline__ tk_f32x4_t tk_mfma16(uint4 a, uint4 b, tk_f32x4_t c)
 {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tk_bf16x8_t, a), __builtin_bit_cast(tk_bf16x8_t, b),
-                                                   c, 0, 0, 0);
+    return mfma_act_16x16x32(a, b, c);
 }
 
 constexpr int kTkQ = 16;            // queries per workgroup
@@ -221,8 +219,8 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     tk_f32x4_t o[2] = {tk_f32x4_t{0.f, 0.f, 0.f, 0.f}, tk_f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int m = 0; m < KT / 2; ++m) {
-        const uint4 pf = make_uint4(pack_bf16x2(s[2 * m][0], s[2 * m][1]), pack_bf16x2(s[2 * m][2], s[2 * m][3]),
-                                    pack_bf16x2(s[2 * m + 1][0], s[2 * m + 1][1]), pack_bf16x2(s[2 * m + 1][2], s[2 * m + 1][3]));
+        const uint4 pf = make_uint4(pack_act2(s[2 * m][0], s[2 * m][1]), pack_act2(s[2 * m][2], s[2 * m][3]),
+                                    pack_act2(s[2 * m + 1][0], s[2 * m + 1][1]), pack_act2(s[2 * m + 1][2], s[2 * m + 1][3]));
         o[0] = tk_mfma16(vfr[m][0], pf, o[0]);
         o[1] = tk_mfma16(vfr[m][1], pf, o[1]);
     }
@@ -243,7 +241,7 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
 #pragma unroll
         for (int c = 0; c < 2; ++c)
             *reinterpret_cast<uint2 *>(orow + 32 * c) =
-                make_uint2(pack_bf16x2(o[c][0] * inv, o[c][1] * inv), pack_bf16x2(o[c][2] * inv, o[c][3] * inv));
+                make_uint2(pack_act2(o[c][0] * inv, o[c][1] * inv), pack_act2(o[c][2] * inv, o[c][3] * inv));
     }
     __syncthreads();
     // ---- out_proj: Z^T[feature][query] = Wo O^T, my 32 features as two 16-feature tiles ----
@@ -258,8 +256,8 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     float tot = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const float rv[4] = {bf16_lo(res_v[c].x), bf16_hi(res_v[c].x), bf16_lo(res_v[c].y), bf16_hi(res_v[c].y)};
-        const float bv[4] = {bf16_lo(bo_v[c].x), bf16_hi(bo_v[c].x), bf16_lo(bo_v[c].y), bf16_hi(bo_v[c].y)};
+        const float rv[4] = {act_lo(res_v[c].x), act_hi(res_v[c].x), act_lo(res_v[c].y), act_hi(res_v[c].y)};
+        const float bv[4] = {act_lo(bo_v[c].x), act_hi(bo_v[c].x), act_lo(bo_v[c].y), act_hi(bo_v[c].y)};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z[c][r] += bv[r] + rv[r];
@@ -292,17 +290,17 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     const float rstd = rsqrtf(var * (1.f / kTkE) + p.eps);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const float gm[4] = {bf16_lo(gamma_v[c].x), bf16_hi(gamma_v[c].x), bf16_lo(gamma_v[c].y), bf16_hi(gamma_v[c].y)};
-        const float bt[4] = {bf16_lo(beta_v[c].x), bf16_hi(beta_v[c].x), bf16_lo(beta_v[c].y), bf16_hi(beta_v[c].y)};
+        const float gm[4] = {act_lo(gamma_v[c].x), act_hi(gamma_v[c].x), act_lo(gamma_v[c].y), act_hi(gamma_v[c].y)};
+        const float bt[4] = {act_lo(beta_v[c].x), act_hi(beta_v[c].x), act_lo(beta_v[c].y), act_hi(beta_v[c].y)};
         float y[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r] = (z[c][r] - mean) * rstd * gm[r] + bt[r];
-        const uint2 yb = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+        const uint2 yb = make_uint2(pack_act2(y[0], y[1]), pack_act2(y[2], y[3]));
         if (valid) *reinterpret_cast<uint2 *>(xrow + 16 * c) = yb;
         if (p.fx_w) {
             // the projection's input row: bf16(updated row + position row), as the token-resident kernel forms it
-            const uint2 xp = make_uint2(pack_bf16x2(bf16_lo(yb.x) + bf16_lo(pos_v[c].x), bf16_hi(yb.x) + bf16_hi(pos_v[c].x)),
-                                        pack_bf16x2(bf16_lo(yb.y) + bf16_lo(pos_v[c].y), bf16_hi(yb.y) + bf16_hi(pos_v[c].y)));
+            const uint2 xp = make_uint2(pack_act2(act_lo(yb.x) + act_lo(pos_v[c].x), act_hi(yb.x) + act_hi(pos_v[c].x)),
+                                        pack_act2(act_lo(yb.y) + act_lo(pos_v[c].y), act_hi(yb.y) + act_hi(pos_v[c].y)));
             *reinterpret_cast<uint2 *>(o_lds + t * kTkORow + (head * kTkHd + 16 * c + 4 * g) * 2) = xp;
         }
     }
@@ -332,7 +330,7 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
         bf16_t *srow = p.fx_slab + (((int64_t)b * kTkHeads + head) * p.fx_rows + (p.fx_by_selection ? qi : row)) * 48 + 4 * g;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<uint2 *>(srow + 16 * c) = make_uint2(pack_bf16x2(pa[c][0], pa[c][1]), pack_bf16x2(pa[c][2], pa[c][3]));
+            *reinterpret_cast<uint2 *>(srow + 16 * c) = make_uint2(pack_act2(pa[c][0], pa[c][1]), pack_act2(pa[c][2], pa[c][3]));
     }
 }
 

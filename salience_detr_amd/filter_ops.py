@@ -201,11 +201,15 @@ def pyramid_flatten(multi_level_feats, multi_level_pos_embeds, multi_level_masks
     pos_out = torch.empty((B, S, C), dtype=torch.float32, device=dev) if want_fp32 else None
     sum_out = torch.empty((B, S, C), dtype=torch.float32, device=dev)
     mask_out = torch.empty((B, S), dtype=torch.bool, device=dev)
-    feat_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
-    pos_bf16 = torch.empty((B, S, C), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    # (``want_bf16``: True = bfloat16 copies; a 16-bit dtype = copies in that activation type, from that library's kernel)
+    act = None if not want_bf16 else (torch.bfloat16 if want_bf16 is True else want_bf16)
+    if act is not None and not _hip.is_act16(act):
+        raise RuntimeError("pyramid_flatten: 16-bit copies are bfloat16 or float16")
+    feat_bf16 = torch.empty((B, S, C), dtype=act, device=dev) if want_bf16 else None
+    pos_bf16 = torch.empty((B, S, C), dtype=act, device=dev) if want_bf16 else None
     le = level_embeds.detach().float().contiguous()
     valid_ratios = torch.empty((B, len(feats), 2), dtype=torch.float32, device=dev)
-    lib = _hip.lib()
+    lib = _hip.lib(act)
     start = 0
     L = len(feats)
     if (flatten_one_launch if one_launch is None else one_launch) and L <= 8:
@@ -244,7 +248,7 @@ def class_max_times(score: Tensor, scale: Tensor) -> Tensor:
         scale = scale.float().contiguous()
     out = torch.empty((B, Nq), dtype=torch.float32, device=score.device)
     with torch.cuda.device(score.device):
-        code = _hip.lib().sdetr_class_max_times(_hip.stream_ptr(), score.data_ptr(), _hip.dtype_code(score.dtype),
+        code = _hip.lib(score.dtype).sdetr_class_max_times(_hip.stream_ptr(), score.data_ptr(), _hip.dtype_code(score.dtype),
                                                 scale.data_ptr(), scale.stride(0) if B > 1 else max(Nq, 1), B, Nq, C,
                                                 out.data_ptr())
     _hip.check(code, "class_max_times")
@@ -302,7 +306,7 @@ def fused_layer_norm(x: Tensor, norm: torch.nn.LayerNorm, residual: Optional[Ten
         out_dtype = out_dtype or x.dtype
         out = torch.empty((B, n, C), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
-        code = _hip.lib().sdetr_layernorm(
+        code = _hip.lib(x.dtype if _hip.is_act16(x.dtype) else out_dtype).sdetr_layernorm(
             _hip.stream_ptr(), xv.data_ptr(), _hip.ptr(rv), _hip.dtype_code(x.dtype), xbs, xrs, rbs, rrs,
             _hip.ptr(row_scale), _hip.ptr(alpha), w.data_ptr(), b.data_ptr(), _hip.dtype_code(w.dtype),
             float(norm.eps), B, n, C, out.data_ptr(), _hip.dtype_code(out_dtype), _hip.ptr(scatter_index), out_rows,
@@ -387,7 +391,7 @@ class ValueProjectionJob:
             return
         x, pw, b, pad, B, Nv, heads, groups, dst, code_, lay = self.pointers()
         with torch.cuda.device(self.value.device):
-            code = _hip.lib().sdetr_value_proj_head_major(_hip.stream_ptr(), x, pw, b, pad, B, Nv, 256, heads, 32, groups,
+            code = _hip.lib(self.value.dtype).sdetr_value_proj_head_major(_hip.stream_ptr(), x, pw, b, pad, B, Nv, 256, heads, 32, groups,
                                                           dst, code_, lay)
         _hip.check(code, "value_proj_head_major")
         self.done = True
@@ -467,7 +471,12 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
         raise RuntimeError("salience_head: fp32 [B,n,C] with a contiguous last dim expected")
     B, n, C = x.shape
-    lib = _hip.lib()
+    # (the head itself is fp32 arithmetic, the same in both libraries; the jobs its launches carry work on 16-bit
+    # activations: they pick the library)
+    job_act = next((j.value.dtype for j in (value_job, value_job2) if j is not None), None)
+    if job_act is None and finalize_job is not None:
+        job_act = finalize_job.tokens.dtype
+    lib = _hip.lib(job_act)
     l1n, l1 = predictor.layer1[0], predictor.layer1[1]
     l2a, l2b, l2c = predictor.layer2[0], predictor.layer2[2], predictor.layer2[4]
     half = predictor.h_dim // 2
@@ -564,7 +573,7 @@ def advance_rows(layer_out: Tensor, sorted_result: Tensor, next_rows: int, token
         raise RuntimeError("advance_rows: count must be int64 [B]")
     nxt = torch.empty((B, next_rows, C), dtype=layer_out.dtype, device=layer_out.device) if next_rows > 0 else None
     with torch.cuda.device(layer_out.device):
-        code = _hip.lib().sdetr_advance_rows(
+        code = _hip.lib(layer_out.dtype).sdetr_advance_rows(
             _hip.stream_ptr(), layer_out.data_ptr(), sorted_result.data_ptr(), _hip.ptr(nxt), tokens.data_ptr(),
             sorted_index.data_ptr(), sorted_index.stride(0), _hip.ptr(count), B, rows, sorted_result.shape[1],
             int(next_rows), tokens.shape[1], C * layer_out.element_size())
@@ -589,7 +598,7 @@ def select_stack(query: Tensor, pos: Tensor, index: Tensor) -> Tensor:
     N = index.shape[1]
     out = torch.empty((B, 2 * N, C), dtype=query.dtype, device=query.device)
     with torch.cuda.device(query.device):
-        code = _hip.lib().sdetr_select_stack(
+        code = _hip.lib(query.dtype).sdetr_select_stack(
             _hip.stream_ptr(), query.data_ptr(), _batch_stride(query, "select_stack"), pos.data_ptr(),
             _batch_stride(pos, "select_stack"), index.data_ptr(), B, N, C, _hip.dtype_code(query.dtype), out.data_ptr())
     _hip.check(code, "select_stack")
@@ -605,9 +614,9 @@ class FinalizeJob:
     def __init__(self, tokens: Tensor, background: Tensor, padding_mask: Optional[Tensor]):
         _hip.require_device("FinalizeJob", tokens=tokens, background=background, padding_mask=padding_mask)
         B, S, C = tokens.shape
-        if (tokens.dtype != torch.bfloat16 or C != 256 or not tokens.is_contiguous() or background.dtype != tokens.dtype
+        if (not _hip.is_act16(tokens.dtype) or C != 256 or not tokens.is_contiguous() or background.dtype != tokens.dtype
                 or tuple(background.shape) != (S, C) or not background.is_contiguous()):
-            raise RuntimeError("FinalizeJob: contiguous bf16 [B,S,256] tokens and [S,256] background expected")
+            raise RuntimeError("FinalizeJob: contiguous 16-bit [B,S,256] tokens and [S,256] background expected")
         self.tokens, self.background = tokens, background
         self.pad = None if padding_mask is None else (padding_mask.view(torch.uint8) if padding_mask.dtype == torch.bool
                                                       else padding_mask).contiguous()
@@ -645,7 +654,7 @@ def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor
     if finalize_job is not None and finalize_job.done and finalize_job.tokens is tokens:
         out = finalize_job.out      # the token-space pass has run (carried by a filtering launch): sorted rows only
         with torch.cuda.device(tokens.device):
-            code = _hip.lib().sdetr_encoder_finalize_sorted(
+            code = _hip.lib(tokens.dtype).sdetr_encoder_finalize_sorted(
                 _hip.stream_ptr(), tokens.data_ptr(), sorted_result.data_ptr(), sorted_index.data_ptr(), _hip.ptr(count),
                 background.data_ptr(), _hip.ptr(pad), B, S, sorted_result.shape[1], int(last_rows), C,
                 _hip.dtype_code(tokens.dtype), out.data_ptr())
@@ -653,7 +662,7 @@ def encoder_finalize(tokens: Tensor, sorted_result: Tensor, sorted_index: Tensor
         return out
     out = torch.empty_like(tokens)
     with torch.cuda.device(tokens.device):
-        code = _hip.lib().sdetr_encoder_finalize(
+        code = _hip.lib(tokens.dtype).sdetr_encoder_finalize(
             _hip.stream_ptr(), tokens.data_ptr(), sorted_result.data_ptr(), sorted_index.data_ptr(), _hip.ptr(count),
             background.data_ptr(), _hip.ptr(pad), B, S, sorted_result.shape[1], int(last_rows), C,
             _hip.dtype_code(tokens.dtype), out.data_ptr())
@@ -667,8 +676,8 @@ def fused_ffn_applies(x: Tensor, linear1, linear2, norm, activation) -> bool:
     token counts are spread over the chip by splitting the hidden dimension (``sdetr_ffn_auto_splits``) -- measured
     against the two library GEMMs + LayerNorm on MI355X: 23 vs 67 us at 1800 tokens, 27 vs 67 at 4544, 36 vs 68 at 9090,
     44 vs 74 at 13 634, 66 vs 116 at 18 180."""
-    return (x.numel() >= 1000 * 256 and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and isinstance(activation, torch.nn.ReLU)
-            and linear1.weight.dtype == torch.bfloat16 and linear2.weight.dtype == torch.bfloat16
+    return (x.numel() >= 1000 * 256 and x.is_cuda and _hip.is_act16(x.dtype) and x.shape[-1] == 256 and isinstance(activation, torch.nn.ReLU)
+            and linear1.weight.dtype == x.dtype and linear2.weight.dtype == x.dtype
             and linear1.in_features == 256 and linear2.out_features == 256
             and linear1.out_features == linear2.in_features and linear1.out_features % 32 == 0
             and linear1.out_features <= 8192 and linear1.bias is not None and linear2.bias is not None)
@@ -680,7 +689,7 @@ def _ffn_operands(x: Tensor, linear1, linear2, norm):
     params = (linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias)
     tag = tuple((t.data_ptr(), t._version) for t in params) + (str(x.device),)
     cache = linear1.weight.__dict__.get("_sdetr_ffn")
-    lib = _hip.lib()
+    lib = _hip.lib(linear1.weight.dtype)
     F = linear1.out_features
     if cache is None or cache[0] != tag:
         with torch.no_grad(), torch.cuda.device(x.device):
@@ -701,7 +710,7 @@ def fused_ffn(x: Tensor, linear1, linear2, norm, hidden_splits: Optional[int] = 
     small token counts still fill it; > 1 adds a reduce + LayerNorm launch)."""
     if not x.is_cuda:
         raise RuntimeError("fused_ffn: HIP device tensors required; there is no CPU fallback")
-    lib = _hip.lib()
+    lib = _hip.lib(x.dtype)
     F = linear1.out_features
     packed, (b1, b2, g, be) = _ffn_operands(x, linear1, linear2, norm)
     x2 = x.reshape(-1, 256)
@@ -737,7 +746,7 @@ def fused_ffn_advance(x: Tensor, linear1, linear2, norm, sorted_result: Tensor, 
         raise RuntimeError("fused_ffn_advance: dtype / layout mismatch")
     if count is not None and (count.dtype != torch.int64 or count.numel() != B):
         raise RuntimeError("fused_ffn_advance: count must be int64 [B]")
-    lib = _hip.lib()
+    lib = _hip.lib(x.dtype)
     F = linear1.out_features
     packed, (b1, b2, g, be) = _ffn_operands(x, linear1, linear2, norm)
     nxt = torch.empty((B, next_rows, C), dtype=x.dtype, device=x.device) if next_rows > 0 else None
@@ -757,9 +766,9 @@ def fused_ffn_advance(x: Tensor, linear1, linear2, norm, sorted_result: Tensor, 
 def attn_tail_ffn_applies(sampled: Tensor, residual: Tensor, output_proj, norm1, linear1, linear2, norm2, activation) -> bool:
     """The layer-end operator (``attn_tail_ffn_advance``) covers the bf16 benchmark configuration."""
     return (sampled.dim() == 3 and sampled.shape == residual.shape and sampled.is_contiguous() and residual.is_contiguous()
-            and residual.dtype == torch.bfloat16 and sampled.dtype == torch.bfloat16
+            and _hip.is_act16(residual.dtype) and sampled.dtype == residual.dtype
             and fused_ffn_applies(residual, linear1, linear2, norm2, activation)
-            and output_proj.weight.dtype == torch.bfloat16 and tuple(output_proj.weight.shape) == (256, 256)
+            and output_proj.weight.dtype == residual.dtype and tuple(output_proj.weight.shape) == (256, 256)
             and output_proj.bias is not None and norm1.weight is not None and norm1.bias is not None
             and norm1.normalized_shape == (256,))
 
@@ -774,7 +783,7 @@ def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2, c
     tag = tuple((t.data_ptr(), t._version) for t in params) + (str(x.device),)
     cache = output_proj.weight.__dict__.get("_sdetr_tail_ffn")
     if cache is None or cache[0] != tag:
-        lib = _hip.lib()
+        lib = _hip.lib(output_proj.weight.dtype)
         F = linear1.out_features
         with torch.no_grad(), torch.cuda.device(x.device):
             tail_bytes, ffn_bytes = lib.sdetr_attn_tail_packed_bytes(), lib.sdetr_ffn_packed_bytes(F)
@@ -815,8 +824,8 @@ def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1,
     _hip.require_device("attn_tail_ffn_advance", sampled=sampled, residual=residual, sorted_result=sorted_result, tokens=tokens,
                         count=count, foreground=foreground)
     if sampled.dim() != 3 or sampled.shape != residual.shape or sampled.shape[2] != 256 or not sampled.is_contiguous() \
-            or not residual.is_contiguous() or sampled.dtype != torch.bfloat16 or residual.dtype != torch.bfloat16:
-        raise RuntimeError("attn_tail_ffn_advance: contiguous bf16 [B, rows, 256] sampled heads and queries expected")
+            or not residual.is_contiguous() or not _hip.is_act16(residual.dtype) or sampled.dtype != residual.dtype:
+        raise RuntimeError("attn_tail_ffn_advance: contiguous 16-bit [B, rows, 256] sampled heads and queries expected")
     B, rows, C = residual.shape
     if (sorted_result.dtype != residual.dtype or tokens.dtype != residual.dtype or sorted_index.dtype != torch.int64
             or sorted_index.dim() != 2 or sorted_index.stride(1) != 1 or not sorted_index.is_cuda
@@ -824,13 +833,13 @@ def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1,
         raise RuntimeError("attn_tail_ffn_advance: dtype / layout mismatch")
     if count is not None and (count.dtype != torch.int64 or count.numel() != B):
         raise RuntimeError("attn_tail_ffn_advance: count must be int64 [B]")
-    lib = _hip.lib()
+    lib = _hip.lib(residual.dtype)
     F = linear1.out_features
     with torch.cuda.device(residual.device):
         splits = int(hidden_splits) if hidden_splits else lib.sdetr_ffn_auto_splits(B * rows, F)
     want_score = next_class_head is not None
     with_score = (want_score and splits == 1 and next_rows > 0 and foreground is not None
-                  and next_class_head.weight.dtype == torch.bfloat16 and next_class_head.weight.shape[0] <= 96
+                  and next_class_head.weight.dtype == residual.dtype and next_class_head.weight.shape[0] <= 96
                   and next_class_head.weight.shape[1] == 256 and next_class_head.bias is not None)
     if with_score and (foreground.dtype != torch.float32 or foreground.dim() != 2 or foreground.shape[0] != B
                        or foreground.shape[1] < next_rows or foreground.stride(1) != 1):
@@ -862,7 +871,7 @@ def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):
     hit = weight.__dict__.get("_sdetr_tl")
     if hit is not None and hit[0] == tag:
         return hit[1], hit[2]
-    lib = _hip.lib()
+    lib = _hip.lib(weight.dtype)
     w = weight.detach()
     N = w.shape[0]
     npad = (N + 127) // 128 * 128
@@ -878,7 +887,7 @@ def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):
 
 
 def token_linear_applies(x: Tensor, weight: Tensor) -> bool:
-    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] == 256
+    return (x.is_cuda and _hip.is_act16(x.dtype) and weight.dtype == x.dtype and x.shape[-1] == 256
             and weight.dim() == 2 and weight.shape[1] == 256 and weight.stride(1) == 1)
 
 
@@ -901,14 +910,14 @@ def token_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], x_add: Optio
     if group_features and (N % group_features or group_features % 4):
         raise RuntimeError("token_linear: group_features must divide out_features and be a multiple of 4")
     out = torch.empty((B, N // group_features, n, group_features) if group_features else (B, n, N),
-                      dtype=torch.bfloat16, device=x.device)
+                      dtype=x.dtype, device=x.device)
     abs_ = 0
     if x_add is not None:
-        if x_add.dtype != torch.bfloat16 or tuple(x_add.shape) != (B, n, 256):
+        if x_add.dtype != x.dtype or tuple(x_add.shape) != (B, n, 256):
             raise RuntimeError("token_linear: x_add must match x")
         abs_ = _batch_stride(x_add, "token_linear")
     with torch.cuda.device(x.device):
-        code = _hip.lib().sdetr_token_linear_bf16(_hip.stream_ptr(), x3.data_ptr(), _hip.ptr(x_add), abs_, n, B * n, 256,
+        code = _hip.lib(x.dtype).sdetr_token_linear_bf16(_hip.stream_ptr(), x3.data_ptr(), _hip.ptr(x_add), abs_, n, B * n, 256,
                                                   packed.data_ptr(), b.data_ptr(), N, out.data_ptr(), N,
                                                   int(group_features))
     _hip.check(code, "token_linear")
@@ -986,7 +995,7 @@ def value_proj_head_major(value: Tensor, weight: Tensor, bias: Optional[Tensor],
     records = Nv if bordered is None else bordered[0].records
     dst = torch.empty((num_groups, B, num_heads, records, 32), dtype=dtype, device=value.device)
     with torch.cuda.device(value.device):
-        code = _hip.lib().sdetr_value_proj_head_major(
+        code = _hip.lib(value.dtype).sdetr_value_proj_head_major(
             _hip.stream_ptr(), value.data_ptr(), packed.data_ptr(), b.data_ptr(), _hip.ptr(pad), B, Nv, 256, num_heads,
             32, num_groups, dst.data_ptr(), _hip.dtype_code(dtype), None if bordered is None else ctypes.byref(bordered[0]))
     _hip.check(code, "value_proj_head_major")
@@ -1005,7 +1014,7 @@ def class_head_max_times(x: Tensor, class_head, scale: Tensor) -> Tensor:
     packed, b = _packed_linear_bf16(class_head.weight, class_head.bias)
     out = torch.empty((B, n), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        code = _hip.lib().sdetr_class_head_max_times(
+        code = _hip.lib(x.dtype).sdetr_class_head_max_times(
             _hip.stream_ptr(), x.data_ptr(), packed.data_ptr(), b.data_ptr(), 256, class_head.out_features,
             scale.data_ptr(), scale.stride(0) if B > 1 else max(n, 1), B, n, out.data_ptr())
     _hip.check(code, "class_head_max_times")
@@ -1109,14 +1118,14 @@ def proposal_refine(delta: Tensor, proposal_logit: Tensor, index: Tensor) -> Ten
     (salience_transformer.py:198-199, 209).  delta ``[B,n,4]`` fp32 | bf16, logits ``[B,S,4]`` fp32, index ``[B,n]``."""
     _hip.require_device("proposal_refine", delta=delta, proposal_logit=proposal_logit, index=index)
     B, n, _ = delta.shape
-    if (delta.dtype not in (torch.float32, torch.bfloat16) or proposal_logit.dtype != torch.float32
+    if (delta.dtype not in (torch.float32,) + _hip.ACT16 or proposal_logit.dtype != torch.float32
             or index.dtype != torch.int64 or tuple(index.shape) != (B, n) or (n > 1 and index.stride(1) != 1)):
         raise RuntimeError("proposal_refine: delta [B,n,4] fp32 | bf16, logits fp32 [B,S,4], index int64 [B,n] expected")
     d = delta.contiguous()
     lg = proposal_logit.contiguous()
     out = torch.empty((B, n, 4), dtype=torch.float32, device=d.device)
     with torch.cuda.device(d.device):
-        code = _hip.lib().sdetr_proposal_refine(_hip.stream_ptr(), d.data_ptr(), _hip.dtype_code(d.dtype), lg.data_ptr(),
+        code = _hip.lib(d.dtype).sdetr_proposal_refine(_hip.stream_ptr(), d.data_ptr(), _hip.dtype_code(d.dtype), lg.data_ptr(),
                                                 index.data_ptr(), index.stride(0) if B > 1 else n, B, lg.shape[1], n,
                                                 out.data_ptr())
     _hip.check(code, "proposal_refine")
@@ -1124,7 +1133,7 @@ def proposal_refine(delta: Tensor, proposal_logit: Tensor, index: Tensor) -> Ten
 
 
 def attention_heads_applies(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> bool:
-    return (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and q.dim() == 3 and q.shape == k.shape == v.shape
+    return (q.is_cuda and q.dtype == k.dtype == v.dtype and _hip.is_act16(q.dtype) and q.dim() == 3 and q.shape == k.shape == v.shape
             and q.shape[-1] == 32 * num_heads and 0 < q.shape[1] <= 1152
             and all(t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 for t in (q, k, v)))
 
@@ -1135,9 +1144,9 @@ def attention_heads(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
     if not attention_heads_applies(q, k, v, num_heads):
         raise RuntimeError("attention_heads: bf16 HIP tensors [B,n,32*heads] with n <= 1152 expected; no CPU fallback")
     B, n, E = q.shape
-    out = torch.empty((B, n, E), dtype=torch.bfloat16, device=q.device)
+    out = torch.empty((B, n, E), dtype=q.dtype, device=q.device)
     with torch.cuda.device(q.device):
-        code = _hip.lib().sdetr_attention_heads_bf16(
+        code = _hip.lib(q.dtype).sdetr_attention_heads_bf16(
             _hip.stream_ptr(), q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(),
             v.stride(0), v.stride(1), B, n, num_heads, 32, 1.0 / math.sqrt(32.0), out.data_ptr())
     _hip.check(code, "attention_heads")
@@ -1149,7 +1158,7 @@ def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num
     """``reference_points_input`` and its sine embedding for one decoder layer (salience_transformer.py:642-643):
     boxes ``[B,Nq,4]`` fp32, ``valid_ratios`` ``[B,L,2]`` -> (``[B,Nq,L,4]`` fp32, ``[B,Nq,4*num_pos_feats]``)."""
     _hip.require_device("decoder_query_sine_embed", reference_points=reference_points, valid_ratios=valid_ratios)
-    if reference_points.dim() != 3 or reference_points.shape[-1] != 4 or dtype not in (torch.float32, torch.bfloat16):
+    if reference_points.dim() != 3 or reference_points.shape[-1] != 4 or dtype not in (torch.float32,) + _hip.ACT16:
         raise RuntimeError("decoder_query_sine_embed: [B,Nq,4] boxes and an fp32 | bf16 embedding expected")
     ref = reference_points.detach().float().contiguous()
     vr = valid_ratios.float().contiguous()
@@ -1158,7 +1167,7 @@ def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num
     embed = torch.empty((B, Nq, 4 * num_pos_feats), dtype=dtype, device=ref.device)
     ref_in = torch.empty((B, Nq, L, 4), dtype=torch.float32, device=ref.device)
     with torch.cuda.device(ref.device):
-        code = _hip.lib().sdetr_decoder_query_sine_embed(
+        code = _hip.lib(dtype).sdetr_decoder_query_sine_embed(
             _hip.stream_ptr(), ref.data_ptr(), vr.data_ptr(), B, Nq, L, int(num_pos_feats), float(temperature),
             embed.data_ptr(), _hip.dtype_code(dtype), ref_in.data_ptr())
     _hip.check(code, "decoder_query_sine_embed")
@@ -1173,12 +1182,12 @@ def box_refine(delta: Tensor, reference_points: Tensor, eps: float = 1e-3) -> Te
     ref = reference_points.detach().float().contiguous()
     n = ref.numel() // 4
     if delta.shape[-1] != 4 or ref.shape[-1] != 4 or n == 0 or delta.numel() % (4 * n) != 0 \
-            or delta.dtype not in (torch.float32, torch.bfloat16):
+            or delta.dtype not in (torch.float32,) + _hip.ACT16:
         raise RuntimeError("box_refine: delta [(G,)B,Nq,4] fp32 | bf16 against boxes [B,Nq,4] expected")
     d = delta.detach().contiguous()
     out = torch.empty(d.shape, dtype=torch.float32, device=d.device)
     with torch.cuda.device(d.device):
-        code = _hip.lib().sdetr_box_refine(_hip.stream_ptr(), d.data_ptr(), _hip.dtype_code(d.dtype), 4, ref.data_ptr(),
+        code = _hip.lib(d.dtype).sdetr_box_refine(_hip.stream_ptr(), d.data_ptr(), _hip.dtype_code(d.dtype), 4, ref.data_ptr(),
                                            n, d.numel() // (4 * n), float(eps), out.data_ptr())
     _hip.check(code, "box_refine")
     return out
@@ -1228,7 +1237,7 @@ def token_linear_ln(x: Tensor, linear, norm, residual: Tensor, scatter_index: Op
     if not x.is_contiguous():
         x = x.contiguous()
     B, n, _ = x.shape
-    if residual.dtype != torch.bfloat16 or tuple(residual.shape) != (B, n, 256):
+    if residual.dtype != x.dtype or tuple(residual.shape) != (B, n, 256):
         raise RuntimeError("token_linear_ln: residual must match x")
     packed, b = _packed_linear_bf16(linear.weight, linear.bias)
     tag = (norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
@@ -1240,13 +1249,13 @@ def token_linear_ln(x: Tensor, linear, norm, residual: Tensor, scatter_index: Op
     if scatter_index is not None:
         _hip.require_device("token_linear_ln", scatter_index=scatter_index, scatter_into=scatter_into)
         if (scatter_index.dtype != torch.int64 or tuple(scatter_index.shape) != (B, n) or scatter_into.dim() != 3
-                or scatter_into.shape[0] != B or scatter_into.shape[2] != 256 or scatter_into.dtype != torch.bfloat16):
-            raise RuntimeError("token_linear_ln: scatter_index [B,n] int64 and scatter_into [B,m,256] bf16 expected")
+                or scatter_into.shape[0] != B or scatter_into.shape[2] != 256 or scatter_into.dtype != x.dtype):
+            raise RuntimeError("token_linear_ln: scatter_index [B,n] int64 and scatter_into [B,m,256] of x's dtype expected")
         out, out_rows = scatter_into, scatter_into.shape[1]
     else:
-        out = torch.empty((B, n, 256), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((B, n, 256), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        code = _hip.lib().sdetr_token_linear_ln_bf16(
+        code = _hip.lib(x.dtype).sdetr_token_linear_ln_bf16(
             _hip.stream_ptr(), x.data_ptr(), residual.data_ptr(), _batch_stride(residual, "token_linear_ln"), n, B * n,
             256, packed.data_ptr(), b.data_ptr(), hit[1].data_ptr(), hit[2].data_ptr(), float(norm.eps), out.data_ptr(),
             _hip.ptr(scatter_index), out_rows)
@@ -1279,22 +1288,23 @@ def _token_map(what: str, name: str, t: Tensor, pixels: int, channels: int) -> i
     returns its row stride in elements."""
     if not t.is_cuda:
         raise RuntimeError(f"{what}: {name} must be a HIP (cuda) tensor; the neck has no CPU fallback")
-    if t.dim() != 3 or t.shape[1] != pixels or t.shape[2] < channels or t.dtype not in (torch.float32, torch.bfloat16):
-        raise RuntimeError(f"{what}: {name} must be [B, {pixels}, >= {channels}] fp32 | bf16, got {tuple(t.shape)} {t.dtype}")
+    if t.dim() != 3 or t.shape[1] != pixels or t.shape[2] < channels or t.dtype not in (torch.float32,) + _hip.ACT16:
+        raise RuntimeError(f"{what}: {name} must be [B, {pixels}, >= {channels}] fp32 | bf16 | fp16, got {tuple(t.shape)} {t.dtype}")
     ld = t.stride(1) if pixels > 1 else max(t.shape[2], t.stride(1))
     if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != pixels * ld) or ld % 4 or t.data_ptr() % (4 * t.element_size()):
         raise RuntimeError(f"{what}: {name} rows must be dense in the channel dim, 4-element aligned, images back to back")
     return ld
 
 
-def neck_pack_conv3x3(weight: Tensor) -> Optional[Tensor]:
-    """bf16 MFMA operand fragments of a ``[G, 3, 3, Ci, Co]`` fp32 kernel (``sdetr_neck_pack_conv3x3_bf16``), or None
-    when the matrix-core kernel does not take the shape (it needs Ci % 16 == 0 and Co % 64 == 0)."""
+def neck_pack_conv3x3(weight: Tensor, act: torch.dtype = torch.bfloat16) -> Optional[Tensor]:
+    """16-bit MFMA operand fragments (in the activation type ``act``) of a ``[G, 3, 3, Ci, Co]`` fp32 kernel
+    (``sdetr_neck_pack_conv3x3_bf16``), or None when the matrix-core kernel does not take the shape (it needs
+    Ci % 16 == 0 and Co % 64 == 0)."""
     _hip.require_device("neck_pack_conv3x3", weight=weight)
     if weight.dim() != 5 or weight.shape[1:3] != (3, 3) or weight.dtype != torch.float32:
         raise RuntimeError("neck_pack_conv3x3: weight must be fp32 [groups, 3, 3, in_per_group, out_per_group]")
     G, _, _, ci, co = weight.shape
-    lib = _hip.lib()
+    lib = _hip.lib(act)
     nbytes = lib.sdetr_neck_conv3x3_packed_bytes(G, ci, co)
     if nbytes == 0:
         return None
@@ -1321,16 +1331,16 @@ def neck_conv3x3(x: Tensor, height: int, width: int, weight: Tensor, bias: Optio
         raise RuntimeError("neck_conv3x3: bias must be fp32 [groups * out_per_group]")
     ho, wo = (height - 1) // stride + 1, (width - 1) // stride + 1
     out = torch.empty((B, ho * wo, G * co), dtype=x.dtype, device=x.device)
-    if packed is not None and x.dtype == torch.bfloat16 and ld % 8 == 0 and x.data_ptr() % 16 == 0:
+    if packed is not None and _hip.is_act16(x.dtype) and ld % 8 == 0 and x.data_ptr() % 16 == 0:
         _hip.require_device("neck_conv3x3", packed=packed)
         with torch.cuda.device(x.device):
-            code = _hip.lib().sdetr_neck_conv3x3_mfma_bf16(_hip.stream_ptr(), x.data_ptr(), B, height, width, ld,
+            code = _hip.lib(x.dtype).sdetr_neck_conv3x3_mfma_bf16(_hip.stream_ptr(), x.data_ptr(), B, height, width, ld,
                                                            packed.data_ptr(), _hip.ptr(bias), G, ci, co, int(stride),
                                                            int(bool(activation)), out.data_ptr())
         _hip.check(code, "neck_conv3x3_mfma")
         return out
     with torch.cuda.device(x.device):
-        code = _hip.lib().sdetr_neck_conv3x3(_hip.stream_ptr(), x.data_ptr(), _hip.dtype_code(x.dtype), B, height, width,
+        code = _hip.lib(x.dtype).sdetr_neck_conv3x3(_hip.stream_ptr(), x.data_ptr(), _hip.dtype_code(x.dtype), B, height, width,
                                              ld, weight.data_ptr(), _hip.ptr(bias), G, ci, co, int(stride),
                                              int(bool(activation)), out.data_ptr())
     _hip.check(code, "neck_conv3x3")
@@ -1355,7 +1365,7 @@ def neck_combine(a: Tensor, height: int, width: int, up: Optional[Tensor] = None
             raise RuntimeError("neck_combine: bias must be fp32 [C]")
     out = torch.empty((B, height * width, C), dtype=a.dtype, device=a.device)
     with torch.cuda.device(a.device):
-        code = _hip.lib().sdetr_neck_combine(_hip.stream_ptr(), a.data_ptr(), lda, _hip.ptr(up), ldu, uh, uw,
+        code = _hip.lib(a.dtype).sdetr_neck_combine(_hip.stream_ptr(), a.data_ptr(), lda, _hip.ptr(up), ldu, uh, uw,
                                              _hip.ptr(bias), _hip.dtype_code(a.dtype), B, height, width, C,
                                              int(bool(activation)), out.data_ptr(), C)
     _hip.check(code, "neck_combine")
@@ -1379,7 +1389,7 @@ def neck_gate_shortcut(y: Tensor, mask_weight: Tensor, squeeze_weight: Tensor, e
     ld2 = _token_map("neck_gate_shortcut", "shortcut2", shortcut2, N, C) if shortcut2 is not None else 0
     if shortcut.dtype != y.dtype or (shortcut2 is not None and shortcut2.dtype != y.dtype):
         raise RuntimeError("neck_gate_shortcut: the shortcuts must have y's dtype")
-    lib = _hip.lib()
+    lib = _hip.lib(y.dtype)
     ws_bytes = lib.sdetr_neck_gate_workspace_bytes(B, N, C)
     ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=y.device)
     gate = torch.empty((B, C), dtype=torch.float32, device=y.device)
@@ -1396,10 +1406,10 @@ def neck_gate_shortcut(y: Tensor, mask_weight: Tensor, squeeze_weight: Tensor, e
 def topk_self_attention_applies(query: Tensor, pos: Tensor, mha, norm, num_selected: int) -> bool:
     """The two-launch top-k self-attention (csrc/topk_attention.hip) covers the released configuration: bf16,
     embed_dim 256, 8 heads, no dropout, batch-first parameters in bf16."""
-    return (query.is_cuda and query.dtype == torch.bfloat16 and pos.dtype == torch.bfloat16 and query.dim() == 3
+    return (query.is_cuda and _hip.is_act16(query.dtype) and pos.dtype == query.dtype and query.dim() == 3
             and query.shape[-1] == 256 and mha.embed_dim == 256 and mha.num_heads == 8 and mha.in_proj_weight is not None
-            and mha.in_proj_weight.dtype == torch.bfloat16 and mha.in_proj_bias is not None
-            and mha.out_proj.bias is not None and norm.weight.dtype == torch.bfloat16 and norm.bias is not None
+            and mha.in_proj_weight.dtype == query.dtype and mha.in_proj_bias is not None
+            and mha.out_proj.bias is not None and norm.weight.dtype == query.dtype and norm.bias is not None
             and 0 < num_selected <= 384 and query.stride(2) == 1 and query.stride(1) == 256
             and pos.stride(2) == 1 and pos.stride(1) == 256)
 
@@ -1419,7 +1429,7 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
     if not topk_self_attention_applies(query, pos, mha, norm, N) or selected.dtype != torch.int64 or selected.shape[0] != B:
         raise RuntimeError("topk_self_attention_: bf16 [B,rows,256] HIP tensors, 8 heads, int64 [B,N] selection expected; "
                            "no CPU fallback")
-    lib = _hip.lib()
+    lib = _hip.lib(query.dtype)
     ws = torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, N), dtype=torch.uint8, device=query.device)
     qbs = query.stride(0) if B > 1 else rows * 256
     pbs = pos.stride(0) if B > 1 else pos.shape[1] * 256
@@ -1430,7 +1440,7 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
         if carried:
             w, b = projection
             packed, b_pad = _packed_linear_bf16(w, b)
-            slab = torch.empty((B, 8, rows, 48), dtype=torch.bfloat16, device=query.device)
+            slab = torch.empty((B, 8, rows, 48), dtype=query.dtype, device=query.device)
             # marks of the selected rows for the projection part of the launch: UNINITIALISED on purpose -- a mark m
             # counts only if selected[b][m - 1] is the row it sits on, which no garbage value can fake, and the
             # in-projection writes the true marks before anything reads them

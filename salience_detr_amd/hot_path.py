@@ -19,20 +19,18 @@ from .salience_filtering import MaskPredictor, level_filtering, salience_filteri
 
 
 def resolve_activation_dtype(dtype: torch.dtype, value_dtype: Optional[torch.dtype] = None):
-    """Map a requested 16-bit mode onto what the MI355X kernels run (BASELINE.json configs[4] asks for "fp16", the
-    reference's ``--mixed-precision fp16``, main.py:24-56).
+    """The activation / value-map types a requested mode runs in.
 
-    ``torch.float16`` is served as **bf16 activations + fp16 value maps + fp32 accumulation / softmax / LayerNorm /
-    sampling locations**: on gfx950 the bf16 and fp16 MFMA rates are identical, so fp16 activations buy no speed, while
-    they would re-introduce what the reference's fp16 mode needs a GradScaler and autocast's fp32 fall-backs for --
-    a 65504 range on LayerNorm inputs, FFN hidden states (ReLU of 2048 pre-activations) and attention logits.  bf16
-    keeps fp32's exponent range there.  Where fp16's three extra mantissa bits matter -- the value maps the deformable
-    attention SAMPLES, each element of which is read ~32 times and weighted by fp32 bilinear x attention weights -- the
-    storage IS fp16 (consumed by v_fma_mix_f32 without an unpack).  The substitution is pinned by
-    tests/test_transformer_gpu.py::test_fp16_request_runs_config5_shape.
+    ``torch.bfloat16`` (BASELINE.json configs[1], the headline): bf16 activations; ``torch.float16`` (configs[4], the
+    reference's ``--mixed-precision fp16``, main.py:24-56): **IEEE half activations** since round 5 -- the token-resident
+    kernels built with ``-DSDETR_ACT_F16`` (``libsalience_hip_f16.so``: ``v_mfma_f32_*_f16`` at the bf16 rate, fp32
+    accumulators / LayerNorm / softmax / class scores / sampling locations, stores saturating at +-65504).  Rounds 2-4
+    served the fp16 request as bf16 activations + fp16 maps (a precision BELOW the one named); that substitution is gone.
+    The head-major value maps of the fp16 mode are fp16 (consumed by ``v_fma_mix_f32`` without an unpack); the bf16 mode's
+    default to bf16 unless the caller asks for fp16 maps (the benchmark does).
     """
     if dtype == torch.float16:
-        return torch.bfloat16, (value_dtype or torch.float16)
+        return dtype, (value_dtype or torch.float16)
     return dtype, value_dtype
 
 
@@ -117,7 +115,7 @@ class SalienceEncoderHotPath(nn.Module):
             from .filter_ops import pyramid_flatten
             feat_flatten, lvl_pos_embed_flatten, enc_in, mask_flatten, feat_enc, pos_enc, valid_ratios_k = pyramid_flatten(
                 multi_level_feats, multi_level_pos_embeds, multi_level_masks, self.level_embeds,
-                want_bf16=(edt == torch.bfloat16), want_fp32=(return_aux or edt != torch.bfloat16))
+                want_bf16=(edt if _hip.is_act16(edt) else False), want_fp32=(return_aux or not _hip.is_act16(edt)))
         else:
             enc_in = valid_ratios_k = None
             feat_flatten = pyramid.flatten_multi_level(multi_level_feats)

@@ -172,7 +172,7 @@ def value_to_head_major(value_proj_out: Tensor, key_padding_mask: Optional[Tenso
         _hip.require_device("value_to_head_major", key_padding_mask=key_padding_mask)
         mask_u8 = key_padding_mask.view(torch.uint8) if key_padding_mask.dtype == torch.bool else key_padding_mask
     with torch.cuda.device(dst.device):
-        code = _hip.lib().sdetr_value_to_head_major(
+        code = _hip.lib(value_proj_out.dtype).sdetr_value_to_head_major(
             _hip.stream_ptr(), value_proj_out.data_ptr(), _hip.dtype_code(value_proj_out.dtype),
             value_proj_out.stride(1), _hip.ptr(mask_u8), B, Nv, num_heads, D, num_groups, dst.data_ptr(),
             _hip.dtype_code(out_dtype))
@@ -216,7 +216,7 @@ def msda_fused_forward(value_hm: Tensor, spatial_shapes: Tensor, level_start_ind
     out_dtype = out_dtype or proj.dtype
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
     with torch.cuda.device(out.device):
-        code = _hip.lib().sdetr_msda_fused_forward(
+        code = _hip.lib(proj.dtype).sdetr_msda_fused_forward(
             _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), reference_points.data_ptr(), reference_points.shape[-1], ref_bs,
             proj.data_ptr(), _hip.dtype_code(proj.dtype), proj_stride, 1 if proj_head_major else 0, _hip.ptr(order),
@@ -258,9 +258,9 @@ def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tens
     if not resident_supported(value_hm, level_shapes, 4, 4):
         raise RuntimeError("msda_resident_forward: fp16 [B,M,Nv,32] maps of a 4-level pyramid whose two coarse levels "
                            "fit in LDS expected")
-    if (proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or proj_hm.dtype != torch.bfloat16
+    if (proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or not _hip.is_act16(proj_hm.dtype)
             or not proj_hm.is_contiguous()):
-        raise RuntimeError("msda_resident_forward: proj must be a contiguous bf16 [B, M, Nq, 48] tensor")
+        raise RuntimeError("msda_resident_forward: proj must be a contiguous bf16 | fp16 [B, M, Nq, 48] tensor")
     if not value_hm.is_contiguous():   # the kernel addresses dense [B,M,Nv,32] maps
         raise RuntimeError("msda_resident_forward: value_hm must be contiguous [B, M, Nv, 32]")
     Nq = proj_hm.shape[2]
@@ -275,7 +275,7 @@ def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tens
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
     hw = (ctypes.c_int32 * 8)(*[int(v) for s in level_shapes for v in s])
     with torch.cuda.device(out.device):
-        code = _hip.lib().sdetr_msda_resident_forward(
+        code = _hip.lib(proj_hm.dtype).sdetr_msda_resident_forward(
             _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), hw, reference_points.data_ptr(),
             reference_points.shape[-1], ref_bs, proj_hm.data_ptr(), B, Nv, M, Nq, out.data_ptr(),
             _hip.dtype_code(out_dtype), int(chunks))
@@ -413,9 +413,9 @@ def msda_bordered_forward(value_bordered: Tensor, level_shapes, reference_points
             or not is_bordered(value_bordered, level_shapes)):
         raise RuntimeError("msda_bordered_forward: fp16 bordered [B,M,Np,32] maps of a 4-level pyramid whose coarsest level "
                            "fits in LDS expected")
-    if (proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or proj_hm.dtype != torch.bfloat16
+    if (proj_hm.dim() != 4 or proj_hm.shape[1] != M or proj_hm.shape[3] != 48 or not _hip.is_act16(proj_hm.dtype)
             or proj_hm.shape[0] != B):
-        raise RuntimeError("msda_bordered_forward: proj must be a contiguous bf16 [B, M, Nq, 48] tensor")
+        raise RuntimeError("msda_bordered_forward: proj must be a contiguous bf16 | fp16 [B, M, Nq, 48] tensor")
     Nq = proj_hm.shape[2]
     if row_order is not None and (not row_order.is_cuda or row_order.dtype != torch.int32 or row_order.shape != (B, Nq)
                                   or (Nq > 1 and row_order.stride(1) != 1)):
@@ -431,7 +431,7 @@ def msda_bordered_forward(value_bordered: Tensor, level_shapes, reference_points
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_bordered.device)
     hw = (ctypes.c_int32 * 8)(*[int(v) for s in level_shapes for v in s])
     with torch.cuda.device(out.device):
-        code = _hip.lib().sdetr_msda_bordered_forward(
+        code = _hip.lib(proj_hm.dtype).sdetr_msda_bordered_forward(
             _hip.stream_ptr(), value_bordered.data_ptr(), _hip.dtype_code(value_bordered.dtype), hw,
             reference_points.data_ptr(), reference_points.shape[-1], ref_bs, proj_hm.data_ptr(), _hip.ptr(row_order),
             (row_order.stride(0) if B > 1 else Nq) if row_order is not None else 0, B, Np, M, Nq, out.data_ptr(), _hip.dtype_code(out_dtype), int(chunks))
@@ -439,9 +439,10 @@ def msda_bordered_forward(value_bordered: Tensor, level_shapes, reference_points
     return out
 
 
-def last_forward_kernel() -> int:
-    """``SDETR_KERNEL_*`` code of the kernel the calling thread's last MSDA forward call dispatched to."""
-    return int(_hip.lib().sdetr_msda_last_kernel())
+def last_forward_kernel(act: Optional[torch.dtype] = None) -> int:
+    """``SDETR_KERNEL_*`` code of the kernel the calling thread's last MSDA forward call dispatched to (``act``:
+    ``torch.float16`` asks the fp16-activation library, which keeps its own record)."""
+    return int(_hip.lib(act).sdetr_msda_last_kernel())
 
 
 KERNEL_GENERIC, KERNEL_GATHER, KERNEL_L4P4, KERNEL_RESIDENT, KERNEL_BORDERED, KERNEL_BORDERED_ORDERED = 1, 2, 3, 4, 5, 6
@@ -456,7 +457,7 @@ def msda_forward_head_major(value_hm: Tensor, spatial_shapes: Tensor, level_star
     _, Nq, _, L, P, _ = sampling_loc.shape
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
     with torch.cuda.device(out.device):
-        code = _hip.lib().sdetr_msda_forward_head_major(
+        code = _hip.lib(out_dtype).sdetr_msda_forward_head_major(
             _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
             B, Nv, M, D, L, Nq, P, out.data_ptr(), _hip.dtype_code(out_dtype))

@@ -466,9 +466,9 @@ class SalienceTransformerEncoder(nn.Module):
 
     def plan_finalize(self, value: Tensor, padding_mask: Optional[Tensor], level_shapes):
         """The token-space pass of the output (``tokens + background`` outside the padding) as a pending
-        ``filter_ops.FinalizeJob`` (bf16 tokens only; ``None`` otherwise)."""
+        ``filter_ops.FinalizeJob`` (16-bit tokens only; ``None`` otherwise)."""
         from .filter_ops import FinalizeJob
-        if value.dtype != torch.bfloat16 or value.dim() != 3 or value.shape[2] != 256 or not value.is_contiguous():
+        if value.dtype not in (torch.bfloat16, torch.float16) or value.dim() != 3 or value.shape[2] != 256 or not value.is_contiguous():
             return None
         return FinalizeJob(value, self.background_embedding.flat_cached(level_shapes, value.dtype), padding_mask)
 

@@ -102,7 +102,7 @@ class RepVggPluXBlock(nn.Module):
         se = self.se_module
         R = se.se_module[0].weight.shape[0]
         return dict(weight=packed, bias=(b3 + alpha * b1).contiguous(),
-                    mfma=FO.neck_pack_conv3x3(packed) if dtype == torch.bfloat16 and packed.is_cuda else None,
+                    mfma=FO.neck_pack_conv3x3(packed, dtype) if dtype in (torch.bfloat16, torch.float16) and packed.is_cuda else None,
                     mask=se.conv_mask.weight.detach().float().reshape(C).contiguous(),
                     squeeze=se.se_module[0].weight.detach().float().reshape(R, C).contiguous(),
                     excite=se.se_module[2].weight.detach().float().reshape(C, R).contiguous())
@@ -194,7 +194,7 @@ class RepVGGPluXNetwork(nn.Module):
             w, b = m.folded()  # dense [out, in, 3, 3] -> [1, 3, 3, in, out]
             wd = w.permute(2, 3, 1, 0).contiguous().unsqueeze(0)
             plan["down"].append((wd, b.contiguous(),
-                                 FO.neck_pack_conv3x3(wd) if dtype == torch.bfloat16 and wd.is_cuda else None))
+                                 FO.neck_pack_conv3x3(wd, dtype) if dtype in (torch.bfloat16, torch.float16) and wd.is_cuda else None))
         for m in self.pan_blocks:
             plan["pan"].append(m.folded(dtype))
         self._plan = (tag, plan)

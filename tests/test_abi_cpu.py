@@ -28,6 +28,27 @@ def test_header_symbols_exported(libpath):
     assert _hip.lib().sdetr_abi_version() == 1
 
 
+def test_fp16_flavour_exports_the_same_abi(libpath):
+    """libsalience_hip_f16.so (round 5: the same sources with -DSDETR_ACT_F16, IEEE-half activations for BASELINE configs[4])
+    is built next to the bf16 library, exports exactly the same `sdetr_*` symbols, loads beside it without the two seeing
+    each other, and `_hip.lib(dtype)` hands out the one that matches the activations."""
+    import subprocess
+    from salience_detr_amd.csrc import build
+    from salience_detr_amd import _hip
+    assert os.path.exists(build.F16_LIB) and os.path.dirname(build.F16_LIB) == os.path.dirname(libpath)
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("sdetr_")}
+    assert exported(build.F16_LIB) == exported(libpath)
+    a, b = _hip.lib(), _hip.lib(torch.float16)
+    assert a is not b and a is _hip.lib(torch.bfloat16) and a is _hip.lib(torch.float32) and a is _hip.lib(None)
+    assert b.sdetr_abi_version() == 1
+    # each library answers with its own state: an error raised in one is not visible in the other
+    assert b.sdetr_msda_bordered_forward(None, None, 2, None, None, 2, 0, None, None, 0, 1, -1, 8, 4, None, 1, 0) != 0
+    assert b"bad dims" in b.sdetr_last_error() and b"bad dims" not in a.sdetr_last_error()
+
+
 def test_product_library_carries_no_benchmark_instantiations(libpath):
     """The deliberately crippled MSDA instantiations (wrong results by construction) and the phase-stamp hook exist only in
     the benchmark build (`csrc/build.py --ablations`): the product library does not export the hook, and the only exported

@@ -196,14 +196,13 @@ def test_decoder_full_size_bf16_close_to_fp32():
             assert d.max() < 0.4 and d.mean() < 0.015, (i, float(d.max()), float(d.mean()))
 
 
-def test_fp16_request_mode_against_fp16_operand_arithmetic():
-    """BASELINE.json configs[4] asks for fp16 (the reference's --mixed-precision fp16, main.py:24-56); this build SERVES
-    such a request as bf16 activations + fp16 value maps + fp32 accumulation (hot_path.resolve_activation_dtype).  The
-    difference that substitution makes is bounded here on the configuration's own stress case -- the 900-query decoder
-    over the 22 000-token memory: every layer, fed the fp32 run's inputs, is compared with the SAME layer evaluated
-    on fp16-rounded parameters and fp16-rounded inputs with fp32 arithmetic (what an fp16-activation path carries between
-    its kernels).  The substituted mode stays within the bf16 rounding bar of that (LayerNorm-scale outputs: mean <= 0.015,
-    max <= 0.4 -- three mantissa bits wider than the fp16-operand run's own distance from fp32, which is printed)."""
+def test_fp16_mode_against_fp16_operand_arithmetic():
+    """BASELINE.json configs[4] asks for fp16 (the reference's --mixed-precision fp16, main.py:24-56).  Since round 5 the
+    build runs that request with IEEE-half activations (libsalience_hip_f16.so).  On the configuration's own stress case --
+    the 900-query decoder over the 22 000-token memory -- every layer, fed the fp32 run's inputs, is compared with the SAME
+    layer evaluated on fp16-rounded parameters and fp16-rounded inputs with fp32 arithmetic (what an fp16-activation path
+    carries between its kernels).  The fp16 mode stays within fp16 rounding of that (LayerNorm-scale outputs: mean <= 2.5e-3,
+    max <= 0.08); the bf16 mode that used to stand in for it (rounds 2-4) is printed beside it: ~8x farther."""
     import copy
     dec, sd, args = _full_size(torch.float32)
     dec = dec.cuda()
@@ -219,8 +218,9 @@ def test_fp16_request_mode_against_fp16_operand_arithmetic():
     with torch.no_grad():
         for p in emu.parameters():
             p.copy_(h16(p))
-    served = copy.deepcopy(dec).bfloat16()
-    for layer in served.layers:
+    served = copy.deepcopy(dec).half()
+    old = copy.deepcopy(dec).bfloat16()
+    for layer in list(served.layers) + list(old.layers):
         layer.cross_attn.value_dtype = torch.float16
     mem = gpu[2]
     with torch.no_grad():
@@ -228,10 +228,16 @@ def test_fp16_request_mode_against_fp16_operand_arithmetic():
             common = dict(reference_points=kw["reference_points"], spatial_shapes=kw["spatial_shapes"],
                           level_start_index=kw["level_start_index"], key_padding_mask=kw["key_padding_mask"])
             e = emu.layers[i](query=h16(kw["query"]), query_pos=h16(kw["query_pos"]), value=h16(mem), **common)
-            s = served.layers[i](query=kw["query"].bfloat16(), query_pos=kw["query_pos"].bfloat16(), value=mem.bfloat16(),
-                                 **common).float()
-            d_sub, d_emu = (s - e).abs(), (e - out32).abs()
-            print("layer", i, "served vs fp16-operand: max %.4f mean %.5f;  fp16-operand vs fp32: max %.4f mean %.6f"
-                  % (float(d_sub.max()), float(d_sub.mean()), float(d_emu.max()), float(d_emu.mean())))
-            assert d_sub.max() < 0.4 and d_sub.mean() < 0.015, (i, float(d_sub.max()), float(d_sub.mean()))
-            assert d_emu.mean() < d_sub.mean()      # (the fp16-operand run is the closer one to fp32, as it should be)
+            s = served.layers[i](query=kw["query"].half(), query_pos=kw["query_pos"].half(), value=mem.half(),
+                                 **common)
+            assert s.dtype == torch.float16
+            s = s.float()
+            o = old.layers[i](query=kw["query"].bfloat16(), query_pos=kw["query_pos"].bfloat16(), value=mem.bfloat16(),
+                              **common).float()
+            d_sub, d_emu, d_old = (s - e).abs(), (e - out32).abs(), (o - e).abs()
+            print("layer", i, "fp16 mode vs fp16-operand: max %.4f mean %.5f;  fp16-operand vs fp32: max %.4f mean %.6f;  "
+                  "bf16 stand-in of rounds 2-4 vs fp16-operand: max %.4f mean %.5f"
+                  % (float(d_sub.max()), float(d_sub.mean()), float(d_emu.max()), float(d_emu.mean()),
+                     float(d_old.max()), float(d_old.mean())))
+            assert d_sub.max() < 0.08 and d_sub.mean() < 2.5e-3, (i, float(d_sub.max()), float(d_sub.mean()))
+            assert d_sub.mean() < 0.5 * d_old.mean()    # (a real gain over the substitution it replaces)

@@ -199,17 +199,33 @@ def test_timed_mode_is_no_farther_from_fp32_than_the_reference_autocast(tag, ima
     assert sum(ours_flips) <= 1.5 * sum(ref_flips) + 10
     assert ours[1] <= 1.25 * ref[1] + 1e-4
     assert ours[2] <= 1.25 * ref[2] + 1e-3
-    # BASELINE configs[4] asks for "fp16" (the reference's --mixed-precision fp16, main.py:24-56); the build serves that
-    # request with this same mode (bf16 activations, fp16 maps: hot_path.resolve_activation_dtype).  How far that is from
-    # the reference's OWN fp16 mode (hotpath_autocast_fp16_digest.npz, generated like the bf16 fixture): fp16 keeps three
-    # more mantissa bits in every Linear operand, so the reference's fp16 run sits ~6x closer to fp32 than either bf16
-    # mode.  The gap is stated and bounded here, not hidden: a true fp16 instantiation of the token-resident kernels is
-    # what would close it.
+    # BASELINE configs[4] asks for "fp16" (the reference's --mixed-precision fp16, main.py:24-56).  Since round 5 the build
+    # runs that request with IEEE-half activations (libsalience_hip_f16.so, hot_path.resolve_activation_dtype); rounds 2-4
+    # served it with the bf16 mode above (~6x farther from fp32 than the reference's own fp16 autocast,
+    # hotpath_autocast_fp16_digest.npz, generated like the bf16 fixture).  The fp16 mode is held to 1.5x of the reference's
+    # fp16-autocast distance on every statistic (the reference keeps LayerNorm outputs and the residual stream in fp32
+    # between its fp16 Linear layers; the build stores fp16 rows between launches).
     f16 = np.load(os.path.join(G, "hotpath_autocast_fp16_digest.npz"))
     f16_flips, f16_flipped = flips_and_mask(lambda k: torch.from_numpy(f16[f"{tag}.encoder.sel{k}"]))
     f16_stats = stats(torch.from_numpy(f16[f"{tag}.encoder.memory_sub"]), f16_flipped)
-    print(f"{tag}: reference fp16 autocast: flips {f16_flips} (sum {sum(f16_flips)}), non-flipped mean {f16_stats[1]:.5f} "
-          f"p99.9 {f16_stats[2]:.4f} -> the build's substitute is {ours[1] / max(f16_stats[1], 1e-9):.1f}x / "
-          f"{ours[2] / max(f16_stats[2], 1e-9):.1f}x farther from fp32")
-    assert ours[1] <= 8.0 * f16_stats[1] and ours[2] <= 3.0 * f16_stats[2]
-    assert sum(ours_flips) <= 4 * sum(f16_flips) + 20
+    m.set_encoder_dtype(torch.float16)
+    sel_log.clear()
+    m.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.clone()) or s
+    try:
+        with torch.no_grad():
+            memory16, _, aux16 = m([f.to(DEV) for f in feats], [x.to(DEV) for x in masks], [p.to(DEV) for p in pos],
+                                   return_aux=True)
+    finally:
+        m.encoder.selection_hook = None
+    assert memory16.dtype == torch.float16
+    from salience_detr_amd import _hip
+    assert _hip._lib_f16 is not None and M.last_forward_kernel(torch.float16) == M.KERNEL_BORDERED_ORDERED
+    h_flips, h_flipped = flips_and_mask(lambda k: torch.gather(aux16["foreground_inds"][k], 1, sel_log[k]).cpu())
+    h = stats(memory16.float().cpu()[:, ::41, ::3], h_flipped)
+    print(f"{tag}: fp16 mode: flips {h_flips} (sum {sum(h_flips)}), non-flipped mean {h[1]:.5f} p99.9 {h[2]:.4f} max {h[3]:.4f};  "
+          f"reference fp16 autocast: flips {f16_flips} (sum {sum(f16_flips)}), non-flipped mean {f16_stats[1]:.5f} "
+          f"p99.9 {f16_stats[2]:.4f} -> {h[1] / max(f16_stats[1], 1e-9):.2f}x / {h[2] / max(f16_stats[2], 1e-9):.2f}x "
+          f"(the bf16 mode that used to serve the request: {ours[1] / max(f16_stats[1], 1e-9):.1f}x / "
+          f"{ours[2] / max(f16_stats[2], 1e-9):.1f}x)")
+    assert h[1] <= 1.5 * f16_stats[1] + 2e-5 and h[2] <= 1.5 * f16_stats[2] + 2e-4
+    assert sum(h_flips) <= 1.5 * sum(f16_flips) + 10

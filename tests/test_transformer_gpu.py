@@ -194,21 +194,21 @@ def test_transformer_full_size_bf16_runs_and_agrees_with_fp32_selection():
 
 
 def test_fp16_request_runs_config5_shape():
-    """BASELINE.json configs[4]: "fp16, 900 queries" (the reference's --mixed-precision fp16, main.py:24-56).  A
-    torch.float16 request is SERVED as bf16 activations + fp16 value maps + fp32 accumulation
-    (hot_path.resolve_activation_dtype says why); this test pins that statement: the dtypes that result and the whole
-    transformer (encoder + proposals + six decoder layers at 900 queries) running in that mode.  The numerical bars
-    of exactly this arithmetic are the teacher-forced per-layer tests: encoder
-    tests/test_encoder_timed_mode_gpu.py::test_teacher_forced_layers_bf16_fp16_vs_oracle, decoder
-    tests/test_decoder_gpu.py::test_decoder_full_size_bf16_close_to_fp32 (bf16 activations, fp16 value maps)."""
+    """BASELINE.json configs[4]: "fp16, 900 queries" (the reference's --mixed-precision fp16, main.py:24-56).  Since
+    round 5 a torch.float16 request runs IEEE-half activations (libsalience_hip_f16.so: the token-resident kernels built
+    with -DSDETR_ACT_F16; fp32 accumulators, LayerNorm, softmax and class scores; saturating stores) + fp16 value maps --
+    rounds 2-4 served it as bf16 activations.  This test pins the dtypes that result, that the fp16 library is the one
+    that ran, and the whole transformer (encoder + proposals + six decoder layers at 900 queries) in that mode; the
+    numerical bars are tests/test_encoder_timed_mode_gpu.py (against the reference's own fp16 autocast) and
+    tests/test_decoder_gpu.py::test_fp16_mode_against_fp16_operand_arithmetic."""
     from salience_detr_amd.salience_transformer import build_salience_transformer
     image_sizes = [(800, 1333), (800, 1066)]
     tr = build_salience_transformer()
     tr.load_state_dict(syn.det_state_dict(tr.state_dict()))
     tr = tr.eval().cuda()
     tr.set_dtype(torch.float16)
-    assert tr.encoder_dtype == torch.bfloat16
-    assert tr.decoder.layers[0].linear1.weight.dtype == torch.bfloat16
+    assert tr.encoder_dtype == torch.float16
+    assert tr.decoder.layers[0].linear1.weight.dtype == torch.float16
     assert all(l.self_attn.value_dtype == torch.float16 for l in tr.encoder.layers)
     assert all(l.cross_attn.value_dtype == torch.float16 for l in tr.decoder.layers)
     assert tr.enc_mask_predictor.layer1[1].weight.dtype == torch.float32      # the filtering stage stays fp32
@@ -217,8 +217,11 @@ def test_fp16_request_runs_config5_shape():
     feats = [f.cuda() for f in syn.make_feats(2, shapes, 256, 0)]
     masks = [m.cuda() for m in masks]
     pos = [syn.sine_position_embedding(m, 128) for m in masks]
+    from salience_detr_amd import _hip, ms_deform_attn as M
     with torch.no_grad():
         out = tr(feats, masks, pos)
+    assert _hip._lib_f16 is not None and M.last_forward_kernel(torch.float16) != 0    # the fp16-activation library ran the MSDA
+    assert out[0].dtype == torch.float16
     assert out[0].shape == (6, 2, 900, 91) and out[1].shape == (6, 2, 900, 4)
     assert all(torch.isfinite(t.float()).all() for t in out[:4])
     assert (out[1] >= 0).all() and (out[1] <= 1).all()
