@@ -452,7 +452,10 @@ constexpr int kBMaxResidentPx = (kRLdsBudget - kRWaves * kRWeightBytes) / 64;   
 // the PK helpers in front of the kernel); SDETR_MSDA_PK overrides it for A/B runs
 // (the fp16-activation flavour keeps the exact products: its outputs carry three more mantissa bits than bf16 ones and
 // the packed form's roundings would be the larger part of their error)
-constexpr int kDefaultPackedAccumulate = SDETR_ACT_IS_F16 ? 0 : 1;
+// bf16 outputs: PK = 2 -- measured in the step (rocprofv3, six launches): 122.2 us exact, 118.5 PK = 1, 116.3 PK = 2, with
+// the end-to-end distance from the reference's fp32 run unchanged (tests/test_encoder_timed_mode_gpu.py: non-flipped
+// mean 0.0084 / 0.0084 / 0.0081 against the reference's own bf16 autocast at 0.0077; profiles/r05_msda_pk_ab.json)
+constexpr int kDefaultPackedAccumulate = SDETR_ACT_IS_F16 ? 0 : 2;
 constexpr int kBPieces = (kBMaxResidentPx * 64 + kRWaves * 1024 - 1) / (kRWaves * 1024);   // copy instructions per wave: 6
 
 __device__ __forceinline__ uint4 buffer_load16_s(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff)

@@ -208,6 +208,10 @@ def test_timed_mode_is_no_farther_from_fp32_than_the_reference_autocast(tag, ima
     f16 = np.load(os.path.join(G, "hotpath_autocast_fp16_digest.npz"))
     f16_flips, f16_flipped = flips_and_mask(lambda k: torch.from_numpy(f16[f"{tag}.encoder.sel{k}"]))
     f16_stats = stats(torch.from_numpy(f16[f"{tag}.encoder.memory_sub"]), f16_flipped)
+    # (a fresh module: .to(bfloat16) above rounded the parameters in place, .to(float16) would only re-encode those)
+    m = build_hot_path()
+    m.load_state_dict(syn.det_state_dict(m.state_dict()))
+    m = m.to(DEV).eval()
     m.set_encoder_dtype(torch.float16)
     sel_log.clear()
     m.encoder.selection_hook = lambda k, s: sel_log.__setitem__(k, s.clone()) or s

@@ -107,3 +107,35 @@ def test_submit_of_temporaries_survives_reallocation():
         lane.launch().synchronize()
         assert torch.equal(lane.outputs, expect)
         del junk
+
+
+def test_capture_guard_flags_memset_nodes():
+    """salience_detr_amd/graph_guard.py: a hipMemsetAsync captured into a graph is not reproduced by replay on this stack
+    (CHANGELOG round 4); the guard finds such nodes at capture time.  ``torch.zeros`` of a fresh block inside a captured
+    region is a memset node, ``tensor.zero_()`` is a kernel."""
+    from salience_detr_amd import graph_guard
+    x = torch.ones(1 << 16, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        x.zero_()
+    torch.cuda.current_stream().wait_stream(side)
+    g = graph_guard.new_graph()
+    with torch.cuda.graph(g):
+        x.zero_()
+        y = x + 1
+    n = graph_guard.assert_replay_safe(g, "kernel fills")
+    if n == 0:
+        pytest.skip("this torch exposes no graph handle")
+    assert n >= 2 and graph_guard.memset_nodes(g) == 0
+    import ctypes
+    rt = graph_guard._runtime()
+    rt.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    g2 = graph_guard.new_graph()
+    with torch.cuda.graph(g2):
+        rt.hipMemsetAsync(ctypes.c_void_p(x.data_ptr()), 0, x.numel() * 4, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        z = x * 2
+    assert graph_guard.memset_nodes(g2) == 1
+    with pytest.raises(RuntimeError, match="memset node"):
+        graph_guard.assert_replay_safe(g2, "raw memset")
+    del y, z

@@ -100,6 +100,7 @@ def test_full_size_training_step_matches_oracle_autograd():
     assert sum(flips) <= 12, flips
     assert abs(loss.item() - rloss.item()) < 2e-3 * max(1.0, abs(rloss.item())), (loss.item(), rloss.item())
     eager = {n: params[n].grad.detach().clone() for n in CHECKED}
+    eager_all = {n: q.grad.detach().clone() for n, q in params.items() if q.grad is not None}   # (for the replay check below)
     worst, off_rows = {}, {}
     for n in CHECKED:
         worst[n], off_rows[n] = _compare(eager[n].cpu(), sd[n].grad, n)
@@ -134,16 +135,37 @@ def test_full_size_training_step_matches_oracle_autograd():
         forward_backward()
     torch.cuda.current_stream().wait_stream(stream)
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
+    from salience_detr_amd import graph_guard
+    g = graph_guard.new_graph()
     with torch.cuda.graph(g):
         loss_static = forward_backward()
+    # capture-time guard: no memset node may sit in the captured step -- replay drops them
+    inspected = graph_guard.assert_replay_safe(g, "training step")
+    print("captured training step:", inspected, "graph nodes inspected, no memset node")
+    assert inspected == 0 or inspected > 500
+    # EVERY parameter that received a gradient is compared (a stale multi-block reduction -- bias / LayerNorm
+    # weight gradients, criterion sums -- would corrupt parameters the CHECKED sample does not cover), and the eager
+    # step's gradients of all of them are the yardstick
+    captured_all = {n: params[n].grad for n in eager_all}
     captured = {n: params[n].grad for n in CHECKED}
     for _ in range(3):   # replays on freshly poisoned gradient buffers: whatever the graph leaves there is its own work
-        for t in captured.values():
+        for t in captured_all.values():
             t.fill_(float("nan"))
+        loss_static.fill_(float("nan"))
         g.replay()
     torch.cuda.synchronize()
     assert abs(loss_static.item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    assert len(eager_all) >= 100, len(eager_all)
+    worst_all = {}
+    for n, ge in eager_all.items():
+        gc = captured_all[n]
+        assert torch.isfinite(gc).all(), n                      # (a gradient the replay did not write stays NaN)
+        scale = max(ge.abs().max().item(), 1e-6)
+        worst_all[n] = ((gc - ge).abs().max() / scale).item()
+    bad = {n: round(v, 5) for n, v in worst_all.items() if v > (3e-2 if ".linear1." in n else 1.5e-2)}
+    print("replay vs eager over all %d parameters: worst %.5f (%s)" % (len(worst_all), max(worst_all.values()),
+                                                                      max(worst_all, key=worst_all.get)))
+    assert not bad, bad
     for n in CHECKED:
         # Two runs of the same step are not bit-identical: fp32 atomics (MSDA backward flush, split reductions of the Linear
         # products) add in a different order, a pre-activation within that noise of zero flips its ReLU gate, and the ONE
