@@ -278,7 +278,9 @@ extern "C" int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *
 __global__ void __launch_bounds__(kOrderThreads) layer_row_orders_kernel(RowOrderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t order_slot[];
-    layer_row_orders_body(a, (int)blockIdx.x, (int)blockIdx.y, order_slot);
+    // block = (part, image, layer)
+    const int j = (int)blockIdx.x;
+    layer_row_orders_body(a, (j / a.parts) % a.batch, j / (a.parts * a.batch), j % a.parts, order_slot);
 }
 
 // order [num_layers][batch][order_batch_stride >= n0] int32; counts_host: rows per layer (<= n0 each).  The counts travel
@@ -301,11 +303,11 @@ extern "C" int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sort
     a.order_layer_stride = (int64_t)batch_size * order_batch_stride; a.order_batch_stride = order_batch_stride;
     static DeviceOnce once;
     allow_dynamic_lds(layer_row_orders_kernel, once, 160 * 1024 - 1024);
-    // one pass while the pyramid's 16-bit slots fit the workgroup's LDS (152 KB of slots), evenly sized passes beyond
     a.slot_cap = order_slot_cap(spatial_size, 152 * 1024);
-    if (a.slot_cap <= 0) return fail("layer_row_orders: %d tokens per image need more than %d passes", spatial_size, kOrderMaxPasses);
+    if (a.slot_cap <= 0) return fail("layer_row_orders: %d tokens per image need more than %d parts", spatial_size, kOrderMaxParts);
+    a.parts = (spatial_size + a.slot_cap - 1) / a.slot_cap;
     const size_t lds = (((size_t)(a.slot_cap < spatial_size ? a.slot_cap : spatial_size) + 7) & ~(size_t)7) * 2;
-    hipLaunchKernelGGL(layer_row_orders_kernel, dim3((unsigned)batch_size, (unsigned)num_layers), dim3(kOrderThreads), lds,
+    hipLaunchKernelGGL(layer_row_orders_kernel, dim3((unsigned)(batch_size * num_layers * a.parts)), dim3(kOrderThreads), lds,
                        static_cast<hipStream_t>(stream), a);
     return check_launch("layer_row_orders");
 }

@@ -615,8 +615,8 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_orders_kernel(SelectArg
     if (blk < nsel) {
         topk_hsort_body<KPT>(p, blk, hs_dyn);
     } else {
-        const int j = blk - nsel;
-        layer_row_orders_body(o, j % o.batch, j / o.batch, reinterpret_cast<uint16_t *>(hs_dyn));
+        const int j = blk - nsel;   // (part, image, layer)
+        layer_row_orders_body(o, (j / o.parts) % o.batch, j / (o.parts * o.batch), j % o.parts, reinterpret_cast<uint16_t *>(hs_dyn));
     }
 }
 
@@ -740,11 +740,12 @@ static int masked_topk_impl(sdetr_stream_t stream, const float *score, const uin
         int order_blocks = 0;
         if (job) {
             if (int rc = fill_order_args(o, job)) return rc;
-            // (the launch's dynamic LDS limit next to the sort's static arrays; larger pyramids take several passes)
+            // (the launch's dynamic LDS limit next to the sort's static arrays)
             o.slot_cap = order_slot_cap(o.S, 136 * 1024);
+            o.parts = o.slot_cap > 0 ? (o.S + o.slot_cap - 1) / o.slot_cap : 0;
             const size_t need = (((size_t)(o.slot_cap < o.S ? o.slot_cap : o.S) + 7) & ~(size_t)7) * 2;
             if (o.slot_cap > 0 && need <= 136 * 1024) {
-                order_blocks = o.batch * o.nl;
+                order_blocks = o.batch * o.nl * o.parts;
                 if (need > dyn) dyn = need;
                 if (carried) *carried = 1;
             }

@@ -34,6 +34,11 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
         raise RuntimeError(f"masked_topk_desc: selected index k out of range (k={k}, row length {N})")
     if mask is not None and not fill_with_global_min:
         raise RuntimeError("masked_topk_desc: a mask requires fill_with_global_min=True")
+    if mask is None and payload is None and out is None and N > _SELECT_MAX_ROW and 0 < k <= 2048 and k * 16 <= N:
+        return _sliced_topk(score, k, int(index_offset), want_scores, orders_job)
+    if (N > _PREFILTER_MAX_ROW and k * 16 > N and payload is None and orders_job is None and score.is_contiguous()
+            and (mask is None or (fill_with_global_min and fill_value is not None))):
+        return _sorted_slices_topk(score, k, mask, fill_value, int(index_offset), want_scores, out)
     mask_stride = 0
     if mask is not None:
         if mask.shape != score.shape or not mask.is_cuda:
@@ -72,6 +77,71 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
             code = lib.sdetr_masked_topk_desc_f32(*args)
     _hip.check(code, "masked_topk_desc")
     return out_score, out_index
+
+
+_SELECT_MAX_ROW = 17408      # longest row of the one-launch histogram sort (csrc/topk.hip kHsMaxN)
+_SLICE = 8192
+
+
+def _sliced_topk(score: Tensor, k: int, index_offset: int, want_scores: bool, orders_job):
+    """Top-k (k small) of rows longer than the one-workgroup histogram sort takes, in two launches of it (round 5):
+    every 8192-key slice of a row keeps its own sorted top-k (a workgroup per slice), then the ``slices x k`` survivors
+    are sorted once more with their row positions as payload.  The rows' global top-k are among their slices' top-k; ties
+    stay in position order (slices are concatenated in row order and each is sorted ties-by-position, so equal scores
+    keep ascending positions in the candidate list -- the second sort's positional rule is the row's).  This is the
+    per-layer top-300 of the reference's 5scale pyramid (salience_transformer.py:366-367 on 45 330 rows, BASELINE
+    configs[3]): the chip-wide rank by counting it replaces is quadratic in the row -- 80-170 us per layer there."""
+    B, N = score.shape
+    S = -(-N // _SLICE)
+    pad = S * _SLICE - N
+    sp = torch.nn.functional.pad(score, (0, pad), value=float("-inf")) if pad else score
+    v1, i1 = masked_topk_desc(sp.reshape(B * S, _SLICE), k)
+    from . import pyramid
+    base = pyramid.static_tensor(("topk_slice_base", S, str(score.device)),
+                                 lambda: (torch.arange(S, dtype=torch.int64) * _SLICE).view(1, S, 1).to(score.device))
+    gidx = (i1.view(B, S, k) + base).view(B, S * k)
+    v2, i2 = masked_topk_desc(v1.view(B, S * k), k, payload=gidx, want_scores=want_scores, orders_job=orders_job)
+    if index_offset:
+        i2 = i2 + index_offset
+    return v2, i2
+
+
+_PREFILTER_MAX_ROW = 24576   # longest row the sampled-threshold prefilter takes (csrc/topk.hip use_prefilter)
+_MERGE_SEGMENTS = 8          # csrc/topk.hip kMaxSegments
+
+
+def _sorted_slices_topk(score: Tensor, k: int, mask: Optional[Tensor], fill_value: Optional[Tensor], index_offset: int,
+                        want_scores: bool, out):
+    """Top-k with k a sizeable fraction of a LONG row (round 5: the finest level of the reference's 5scale pyramid keeps
+    16 700 of 67 200 tokens, salience_transformer.py:146-150 -- beyond every single-workgroup form, so it went to the
+    chip-wide rank by counting: quadratic in the row, ~380 us there).  The row is cut into eight slices, every slice is
+    sorted completely (the same rank kernel, on rows an eighth as long: 1/8 of the comparisons), and the sorted slices are
+    merged (``merge_sorted_desc``: stable in slice order, i.e. ties stay in position order); the first k are the answer.
+    Masked entries compete with ``fill_value`` exactly as in the one-launch forms (the caller supplies the whole array's
+    minimum: a per-slice minimum would be a different number)."""
+    B, N = score.shape
+    c = -(-N // _MERGE_SEGMENTS)
+    c = -(-c // 64) * 64
+    S = -(-N // c)
+    pad = S * c - N
+    sp = torch.nn.functional.pad(score, (0, pad), value=float("-inf")) if pad else score
+    mp = None
+    if mask is not None:
+        mp = torch.nn.functional.pad(mask, (0, pad), value=False) if pad else mask.contiguous()
+        mp = mp.reshape(B * S, c)
+    v1, i1 = masked_topk_desc(sp.reshape(B * S, c), c, mask=mp, fill_with_global_min=mp is not None, fill_value=fill_value)
+    from . import pyramid
+    base = pyramid.static_tensor(("topk_sort_base", S, c, index_offset, str(score.device)),
+                                 lambda: (torch.arange(S, dtype=torch.int64) * c + index_offset).view(1, S, 1).to(score.device))
+    gidx = (i1.view(B, S, c) + base).view(B, S * c)
+    vs, idx = merge_sorted_desc(v1.view(B, S * c), gidx, [i * c for i in range(S)], want_scores=want_scores or out is not None)
+    if out is not None:
+        out_score, out_index = out
+        out_index.copy_(idx[:, :k])
+        if out_score is not None:
+            out_score.copy_(vs[:, :k])
+        return out_score, out_index
+    return (vs[:, :k].contiguous() if want_scores else None), idx[:, :k].contiguous()
 
 
 class RankJob:

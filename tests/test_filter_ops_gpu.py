@@ -29,6 +29,66 @@ def test_topk_exact(B, N, k):
     assert torch.equal(v.cpu(), rv)
 
 
+@pytest.mark.parametrize("B,N,k", [(1, 45330, 300), (2, 36264, 300), (2, 27198, 300), (3, 18132, 300), (1, 17409, 1),
+                                   (2, 65536, 2048), (1, 89250, 900)])
+@pytest.mark.parametrize("kind", ["random", "ties", "constant", "inf_tail"])
+def test_long_rows_small_k_take_the_sliced_selection(B, N, k, kind):
+    """Round 5: rows beyond the one-launch sort's 17 408 keys with k << N (the per-layer top-300 of the reference's 5scale
+    pyramid, salience_transformer.py:366-367 on 45 330 rows): per-slice top-k + one sort of the survivors
+    (filter_ops._sliced_topk) -- bit-exact against the stable descending sort, ties by position, with an index offset."""
+    g = torch.Generator().manual_seed(N + k)
+    score = torch.randn(B, N, generator=g)
+    if kind == "ties":
+        score = (score * 2).round() / 2                     # ~15 distinct values: every slice is full of ties
+    elif kind == "constant":
+        score = torch.full((B, N), 0.25)
+    elif kind == "inf_tail":
+        score[:, N - 5000:] = float("-inf")
+        score[:, 7] = float("inf")
+    called = []
+    real = F._sliced_topk
+    F._sliced_topk = lambda *a, **kw: (called.append(1), real(*a, **kw))[1]
+    try:
+        v, i = F.masked_topk_desc(score.to(DEV), k, index_offset=11)
+        _, i2 = F.masked_topk_desc(score.to(DEV), k, want_scores=False)
+    finally:
+        F._sliced_topk = real
+    assert len(called) == 2
+    rv, ri = R.topk_desc_stable(score, k)
+    assert torch.equal(i.cpu(), ri + 11) and torch.equal(v.cpu(), rv) and torch.equal(i2.cpu(), ri)
+
+
+@pytest.mark.parametrize("B,N,k", [(1, 67200, 16700), (2, 67200, 16800), (2, 40000, 20000), (1, 89250, 89250), (2, 24577, 6000)])
+def test_long_rows_large_k_take_sorted_slices_and_a_merge(B, N, k):
+    """Round 5: the finest level of the reference's 5scale pyramid (top 16 700 of 67 200, mask + whole-array minimum as
+    fill, an index offset, outputs into column slices of wider buffers): eight fully sorted slices + a stable merge
+    (filter_ops._sorted_slices_topk) instead of the quadratic rank over the whole row -- bit-exact against the oracle."""
+    score = syn.det_randn(f"ls{N}", (B, N))
+    score[:, ::7] = score[:, 3::7][:, : score[:, ::7].shape[1]]           # exact duplicates across slices
+    mask = torch.zeros(B, N, dtype=torch.bool)
+    mask[:, N - N // 9:] = True                                             # a padded tail: floods the bottom with the fill value
+    mask[0, ::101] = True
+    called = []
+    real = F._sorted_slices_topk
+    F._sorted_slices_topk = lambda *a, **kw: (called.append(1), real(*a, **kw))[1]
+    try:
+        fill = score.min().reshape(1).to(DEV)
+        v, i = F.masked_topk_desc(score.to(DEV), k, mask=mask.to(DEV), fill_with_global_min=True, fill_value=fill, index_offset=500)
+        wide_s = torch.zeros(B, k + 10, device=DEV)
+        wide_i = torch.zeros(B, k + 10, dtype=torch.int64, device=DEV)
+        F.masked_topk_desc(score.to(DEV), k, mask=mask.to(DEV), fill_with_global_min=True, fill_value=fill, index_offset=500,
+                           out=(wide_s[:, 3:3 + k], wide_i[:, 3:3 + k]))
+        v0, i0 = F.masked_topk_desc(score.to(DEV), k)                       # no mask
+    finally:
+        F._sorted_slices_topk = real
+    assert len(called) == 3
+    rv, ri = _oracle_topk(score, k, mask)
+    assert torch.equal(i.cpu(), ri + 500) and torch.equal(v.cpu(), rv)
+    assert torch.equal(wide_i[:, 3:3 + k].cpu(), ri + 500) and torch.equal(wide_s[:, 3:3 + k].cpu(), rv)
+    rv0, ri0 = R.topk_desc_stable(score, k)
+    assert torch.equal(i0.cpu(), ri0) and torch.equal(v0.cpu(), rv0)
+
+
 @pytest.mark.parametrize("B,N,k", [(2, 273, 273), (2, 4200, 3360), (2, 16800, 6680)])
 def test_masked_topk_with_ties(B, N, k):
     score = syn.det_randn("ms", (B, N))

@@ -211,8 +211,10 @@ def test_bordered_msda_with_half_projection_slab(ref_dim):
         assert np.abs(out.cpu().numpy() - expect).max() < 2e-4
         out16 = M.msda_bordered_forward(hb, LEVELS_FULL, ref.to(DEV), slab, out_dtype=dt)
         assert out16.dtype == dt
-        tol = 2.0 ** (-11 if dt == H else -8)
-        assert (np.abs(out16.float().cpu().numpy() - expect) <= np.abs(expect) * tol + 1.5e-3).all()
+        # (fp16 outputs: exact products + one fp16 rounding; bf16 outputs: the packed-fp16 corner sums of PK = 2, bars of
+        # tests/test_msda_bordered_gpu.py)
+        tol, slack = (2.0 ** -11, 1e-3) if dt == H else (2.0 ** -8, 4e-3)
+        assert (np.abs(out16.float().cpu().numpy() - expect) <= np.abs(expect) * tol + slack).all()
 
 
 def test_value_projection_from_half_tokens():

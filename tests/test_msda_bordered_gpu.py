@@ -213,9 +213,11 @@ def test_layer_row_orders_large_pyramid_takes_several_passes():
         assert torch.equal(order, M.spatial_row_order(sorted_index[:, :c], levels, 16))
 
 
-def test_layer_row_orders_fall_back_to_list_order_on_duplicate_tokens():
-    """ADVICE r4: a caller-supplied list with duplicate / out-of-range tokens cannot be counting-sorted (one row per slot);
-    the order must still be a permutation of the rows (the gather writes exactly the rows it lists): list order."""
+def test_layer_row_orders_stay_permutations_on_duplicate_or_stray_tokens():
+    """a caller-supplied list with a token twice, or tokens outside the pyramid, cannot be counting-sorted (one
+    row per slot) -- but the order must still be a permutation of the rows (the gather writes exactly the rows it lists).
+    A row that loses its slot to a duplicate follows its part's run, rows with stray tokens close the order; every other
+    row keeps its tile-major place."""
     from salience_detr_amd import filter_ops as K
     levels = LEVELS_FULL
     Nv = sum(h * w for h, w in levels)
@@ -225,9 +227,22 @@ def test_layer_row_orders_fall_back_to_list_order_on_duplicate_tokens():
     dup[1500] = dup[5]                    # one token twice (rows 5 and 1500: the 900-row prefix stays clean)
     wild = good.clone()
     wild[1234] = Nv + 3                   # one token outside the pyramid
+    wild[77] = -1
     sorted_index = torch.stack([good, dup, wild]).to(DEV)
     orders = K.layer_row_orders(sorted_index, [2000, 900], levels, tile=16)
-    ident = torch.arange(2000, dtype=torch.int32, device=DEV)
+    ident = torch.arange(2000, dtype=torch.int32)
+    pos = M.tile_major_positions(levels, 16)
     assert torch.equal(orders[0][0], M.spatial_row_order(sorted_index[:1], levels, 16)[0])
-    assert torch.equal(orders[0][1], ident) and torch.equal(orders[0][2], ident)
+    for b in (1, 2):
+        assert torch.equal(orders[0][b].cpu().sort()[0], ident)                      # a permutation
+    # duplicate: without rows 5 and 1500 the order is the clean list's without them
+    o = orders[0][1].cpu()
+    want = M.spatial_row_order(sorted_index[:1], levels, 16)[0].cpu()
+    keep = lambda t: t[(t != 5) & (t != 1500)]
+    assert torch.equal(keep(o), keep(want))
+    # stray tokens: the valid rows in tile order, then the stray rows in row order
+    o = orders[0][2].cpu()
+    rows = torch.tensor([r for r in range(2000) if r not in (77, 1234)])
+    ref = rows[pos[wild[rows]].argsort(stable=True)].to(torch.int32)
+    assert torch.equal(o[:-2], ref) and o[-2:].tolist() == [77, 1234]
     assert torch.equal(orders[1][1], M.spatial_row_order(sorted_index[1:2, :900], levels, 16)[0])   # the prefix is clean
