@@ -954,20 +954,20 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
                     uint32_t row = (uint32_t)pos;
                     if (PERM) row = buffer_load4(perm_rsrc, (uint32_t)pos * 4u);
                     const uint32_t off = __umul24(row, 96u);
-                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(pf_sink) : "v"(off), "s"(proj_rsrc) : "memory");
+                    pf_sink ^= buffer_load4(proj_rsrc, off);
                 }
             }
             if (p.prefetch_fine & 1) {
                 // L2 warm-up (in the step the maps were written ~0.5 ms earlier and come from HBM / the Infinity Cache):
                 // one dword of every 128-byte line of this workgroup's share of the fine levels -- the head's 1.3 MB reach
-                // the XCD's L2 as one bulk read instead of as the gather's demand misses.  The values are discarded; the
-                // registers they land in are not reused before the loop's own waits have drained the queue.
+                // the XCD's L2 as one bulk read instead of as the gather's demand misses.  The values are folded into a
+                // dummy that is consumed after the row loop.
                 const uint32_t lines = ((uint32_t)p.res_start * 64u + 127u) >> 7;
                 const uint32_t share = (lines + (uint32_t)p.chunks - 1u) / (uint32_t)p.chunks;
                 const uint32_t l0 = (uint32_t)chunk * share, l1 = min(lines, l0 + share);
                 for (uint32_t ln = l0 + (uint32_t)wave * 64u + (uint32_t)lane; ln < l1; ln += kRWaves * 64u) {
                     const uint32_t off = ln * 128u;
-                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=&v"(pf_sink) : "v"(off), "s"(rsrc) : "memory");
+                    pf_sink ^= buffer_load4(rsrc, off);     // (compiler-tracked: its wait counters know the load)
                 }
             }
             maps_pending = false;
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(kRThreads) msda_bordered_kernel(BorderedArgs p
             if (rg + kRWaves < ngroups) row_group(rg + kRWaves, in_b, nxt);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // (keeps the warm-up loads' register reserved)
+    asm volatile("" ::"v"(pf_sink));   // (the warm-up loads' values are consumed here, after the loop: nothing waits for them earlier)
     if (SERIAL && b + b_step < b_end) __syncthreads();
     }   // images
     if (ABL & 32) {

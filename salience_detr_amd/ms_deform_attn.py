@@ -21,6 +21,8 @@ import math
 import warnings
 from typing import Optional
 
+import threading
+
 import torch
 from torch import Tensor, nn
 from torch.autograd import Function
@@ -143,6 +145,10 @@ class MultiScaleDeformableAttnFunction(Function):
         value, shapes, lsi, loc, aw = ctx.saved_tensors
         grad_value, grad_loc, grad_aw = ms_deform_attn_backward(
             value, shapes, lsi, loc, aw, grad_output.contiguous(), ctx.im2col_step)
+        # grad_value was allocated by this call and nothing else holds it yet: marked as exclusively owned, so that the
+        # padding mask behind the op (_ZeroRowsInPlace) may zero its rows in place (the consumer used to guess
+        # this from version counters)
+        _mark_exclusive(grad_value)
         return grad_value, None, None, grad_loc, grad_aw, None
 
 
@@ -546,6 +552,29 @@ def invalidate_caches(module: nn.Module) -> None:
                 p.__dict__.pop(key, None)
 
 
+_EXCLUSIVE = threading.local()
+
+
+def _mark_exclusive(t: Tensor) -> None:
+    """Record the storage of a gradient its producer has just allocated (consumed once, by _ZeroRowsInPlace.backward on
+    the autograd thread that produced it)."""
+    s = getattr(_EXCLUSIVE, "ptrs", None)
+    if s is None:
+        s = _EXCLUSIVE.ptrs = set()
+    if len(s) > 64:          # (marks nobody consumed: gradients that went elsewhere)
+        s.clear()
+    s.add(t.untyped_storage().data_ptr())
+
+
+def _take_exclusive(t: Tensor) -> bool:
+    s = getattr(_EXCLUSIVE, "ptrs", None)
+    p = t.untyped_storage().data_ptr()
+    if s is not None and p in s:
+        s.discard(p)
+        return True
+    return False
+
+
 class _ZeroRowsInPlace(Function):
     """``x.masked_fill_(mask[..., None], 0)`` whose backward masks the incoming gradient in place as well."""
 
@@ -564,8 +593,10 @@ class _ZeroRowsInPlace(Function):
         # MultiScaleDeformableAttnFunction, whose backward hands over a grad_value it has just allocated (a [B,Nv,M,D]
         # view of it arrives here: nobody else holds it).  Anything else -- a non-contiguous gradient, a tensor some hook
         # retained (its version counter or base say so) -- is masked out of place, as autograd requires.
-        fresh = grad.is_contiguous() and not grad.requires_grad and grad._version <= 1 and (
-            grad._base is None or grad._base._version <= 1)
+        # Out of place by default; in place only when the producer marked the storage as exclusively owned
+        # (MultiScaleDeformableAttnFunction.backward) AND nothing has written to it since.
+        fresh = (_take_exclusive(grad) and grad.is_contiguous() and not grad.requires_grad and grad._version <= 1
+                 and (grad._base is None or grad._base._version <= 1))
         return (grad.masked_fill_(m, 0.0) if fresh else grad.masked_fill(m, 0.0)), None
 
 
@@ -704,9 +735,11 @@ class MultiScaleDeformableAttention(nn.Module):
         v = F.linear(value, self.value_proj.weight, self.value_proj.bias)
         return value_to_head_major(v, key_padding_mask, self.num_heads, self.value_dtype or v.dtype)
 
-    # queries per image from which the coarse-levels-in-LDS kernel replaces the direct gather when a host copy of
-    # the level shapes is at hand (below it the 85 KB staging per workgroup is not amortised); None disables it
-    resident_min_queries = 1200
+    # Round 5: the round-2/3 coarse-levels-in-LDS kernel on PLAIN maps (msda_resident_kernel) is retired from the module's
+    # dispatch -- every caller with a host copy of the level shapes gets bordered maps and msda_bordered_kernel, plain maps
+    # take the direct gather.  ``msda_resident_forward`` stays as an entry point (sdetr_msda_resident_forward, a test
+    # cross-check of the bordered kernel); an integer here (queries per image) switches the old dispatch back on.
+    resident_min_queries = None
 
     def head_major_projection_applies(self, query: Tensor, value_hm: Tensor) -> bool:
         """``forward_native`` (no ``order``) takes the per-head projection slabs for this input."""

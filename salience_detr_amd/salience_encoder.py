@@ -521,7 +521,10 @@ class SalienceTransformerEncoder(nn.Module):
             if (value.is_contiguous() and ori_pos.is_contiguous() and ori_pos.dtype == value.dtype
                     and foreground_score.dtype == torch.float32 and foreground_score.is_contiguous()
                     and 256 % max(1, value.shape[-1] * value.element_size() // 16) == 0
-                    and (value.shape[-1] * value.element_size()) % 16 == 0):
+                    and (value.shape[-1] * value.element_size()) % 16 == 0
+                    # (the kernel's reference-point lanes: 2 x levels of a row's 16-byte lanes -- narrow rows, e.g. 32 bf16
+                    # channels with 4 levels, take the gather path below instead of the kernel's hard failure)
+                    and value.shape[-1] * value.element_size() // 16 >= 2 * len(level_shapes)):
                 # query / position rows, foreground scores and reference points of the selected tokens: one launch
                 q, pos_s, fg_s, ref_s = encoder_prepare_sorted(value, ori_pos, foreground_score, sorted_index, valid_ratios,
                                                                spatial_shapes, level_start_index)

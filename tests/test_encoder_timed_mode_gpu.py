@@ -41,7 +41,7 @@ def timed_case():
 @pytest.mark.parametrize("layout", ["bordered", "plain"])
 def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case, layout):
     """``bordered``: what the step runs since round 4 (zero-bordered maps, per-layer row orders, msda_bordered_kernel at
-    every layer size); ``plain``: round 3's maps and kernels, still the path of callers without level shapes."""
+    every layer size); ``plain``: plain head-major maps (callers without level shapes): the direct gather since round 5."""
     m, sizes, level_shapes, feats, masks, pos, ref = timed_case
     enc = m.encoder
     feat_flat = ref["feat_flatten"].to(DEV).to(torch.bfloat16)
@@ -69,7 +69,8 @@ def test_teacher_forced_layers_bf16_fp16_vs_oracle(timed_case, layout):
             if layout == "bordered":
                 assert kernel == M.KERNEL_BORDERED_ORDERED     # bordered maps, the layer's tile-major row order
             else:
-                assert kernel == (M.KERNEL_RESIDENT if q.shape[1] >= layer.self_attn.resident_min_queries else M.KERNEL_L4P4)
+                rmq = layer.self_attn.resident_min_queries      # (None since round 5: plain maps take the direct gather)
+                assert kernel == (M.KERNEL_RESIDENT if rmq is not None and q.shape[1] >= rmq else M.KERNEL_L4P4)
             err = (out.float().cpu() - ref["layer_out"][k]).abs()
             stats.append((k, q.shape[1], err.mean().item(), err.flatten().kthvalue(int(err.numel() * 0.999))[0].item(),
                           err.max().item()))
