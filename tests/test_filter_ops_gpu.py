@@ -64,7 +64,8 @@ def test_long_rows_large_k_take_sorted_slices_and_a_merge(B, N, k):
     fill, an index offset, outputs into column slices of wider buffers): eight fully sorted slices + a stable merge
     (filter_ops._sorted_slices_topk) instead of the quadratic rank over the whole row -- bit-exact against the oracle."""
     score = syn.det_randn(f"ls{N}", (B, N))
-    score[:, ::7] = score[:, 3::7][:, : score[:, ::7].shape[1]]           # exact duplicates across slices
+    n7 = score[:, 3::7].shape[1]
+    score[:, ::7][:, :n7] = score[:, 3::7]                                  # exact duplicates across slices
     mask = torch.zeros(B, N, dtype=torch.bool)
     mask[:, N - N // 9:] = True                                             # a padded tail: floods the bottom with the fill value
     mask[0, ::101] = True
