@@ -54,26 +54,27 @@ head -8 $O/${R}_bench_kernel_stats.csv | cut -c1-150
 #    with a row order) and of the MSDA backward kernels
 bash benchmarks/pmc_msda.sh ${R} 11363 2 > /dev/null 2>&1
 mv $O/${R}_pmc_summary.md $O/${R}_msda_pmc.md 2> /dev/null
-#    the shader clock the chip holds under the gather (GRBM_GUI_ACTIVE / launch duration of the same pass): roofline.valu
-python - $O/${R}_pmc_4 $O/${R}_msda_clock.json <<'PY'
+#    the shader clock the chip holds under the gather: SQ_BUSY_CYCLES (summed over the 32 shader engines' sequencers) / 32 /
+#    launch duration of the same pass, for the bordered kernel in tile order (what the step launches) -> roofline.valu
+python - $O/${R}_pmc_1 $O/${R}_msda_clock.json <<'PY'
 import csv, glob, json, sys
 sys.path.insert(0, ".")
 import bench
 d, out = sys.argv[1:3]
-act, dur = {}, {}
+busy, dur = {}, {}
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "msda_bordered_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
-            act.setdefault(r["Dispatch_Id"], 0.0)
-            act[r["Dispatch_Id"]] = max(act[r["Dispatch_Id"]], float(r["Counter_Value"]))
+        if "msda_bordered_kernel<false, 2, false, true" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_BUSY_CYCLES":
+            busy[r["Dispatch_Id"]] = busy.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "msda_bordered_kernel" in r["Kernel_Name"]:
+        if "msda_bordered_kernel<false, 2, false, true" in r["Kernel_Name"]:
             dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-ghz = sorted(act[k] / dur[k] for k in act if k in dur and dur[k] > 0)
+ghz = sorted(busy[k] / 32.0 / dur[k] for k in busy if k in dur and dur[k] > 0)
 if ghz:
     json.dump({"shader_clock_ghz": round(ghz[len(ghz) // 2], 3), "launches": len(ghz), "kernel_source_tag": bench.kernel_source_tag(),
-               "source": "median over the bordered-kernel launches of GRBM_GUI_ACTIVE (busy cycles) / launch duration, rocprofv3 --pmc pass at 11 363 queries"},
+               "source": "median over the tile-order bordered-kernel launches of SQ_BUSY_CYCLES / 32 sequencers / launch duration, "
+                         "rocprofv3 --pmc pass at 11 363 queries (benchmarks/pmc_msda.sh)"},
               open(out, "w"), indent=1)
     print(open(out).read())
 PY

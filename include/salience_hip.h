@@ -34,7 +34,22 @@ typedef struct ihipStream_t *sdetr_stream_t; /* == hipStream_t */
 /* element types for the native (non drop-in) entry points */
 #define SDETR_F32 0
 #define SDETR_BF16 1
-#define SDETR_F16 2 /* IEEE half: accepted as the storage type of the head-major value map only */
+#define SDETR_F16 2 /* IEEE half: the head-major value maps (either library); the activations of the fp16 flavour */
+
+/*
+ * Two builds of this ABI (round 5).  The token-resident kernels keep their ACTIVATIONS -- token rows, projection slabs,
+ * attention / feed-forward operands, 16-bit outputs, the 16-bit weights the *_pack_bf16 entry points permute -- in one
+ * 16-bit type per library:
+ *   libsalience_hip.so      bfloat16 (activation arguments carry SDETR_BF16): the benchmark mode, BASELINE configs[1];
+ *   libsalience_hip_f16.so  IEEE half (activation arguments carry SDETR_F16): the SAME sources built with
+ *                           -DSDETR_ACT_F16 (csrc/common.h) -- v_mfma_f32_*_f16 instead of *_bf16, fp32 accumulators /
+ *                           LayerNorm / softmax / class scores / sampling locations unchanged, stores saturating at
+ *                           +-65504 -- for the reference's `--mixed-precision fp16` (main.py:24-56, BASELINE configs[4]).
+ * Same symbols, same argument lists; the `_bf16` suffix of an entry point reads "the library's 16-bit activation type".
+ * fp32 / fp64 / integer entry points are identical in both.  The value maps keep the explicit type their own dtype
+ * argument names in both.  A host loads the library that matches its activations (the Python layer: _hip.lib(dtype));
+ * both can be loaded side by side (dlopen RTLD_LOCAL; each keeps its own error text and last-kernel record).
+ */
 
 int sdetr_abi_version(void);
 const char *sdetr_last_error(void);
@@ -286,7 +301,10 @@ int sdetr_encoder_finalize_sorted(sdetr_stream_t stream, const void *tokens, con
  * order of their tokens -- tile_pos int32 [spatial_size] is the position of every token in a static order that keeps
  * neighbours in the image together (tiles of the finest level; tokens of all levels by the tile their centre falls
  * into).  order int32 [num_layers][batch][order_batch_stride]: order[k][b][0 .. counts[k]) is a permutation of
- * 0 .. counts[k]-1.  counts_dev: device int32 [num_layers].  One workgroup per image, bit-exact index work. */
+ * 0 .. counts[k]-1.  counts_dev: device int32 [num_layers].  Bit-exact index work; since round 5 one workgroup per
+ * (image, layer, part of the tile positions): any pyramid size (the reference's 5scale configuration, 89 250 tokens, is
+ * six parts), at most 65 534 rows per image.  A list that holds a token twice or tokens outside the pyramid still gets a
+ * permutation: such rows follow their part's run / close the order. */
 int sdetr_layer_row_orders(sdetr_stream_t stream, const int64_t *sorted_index, int64_t index_batch_stride,
                            const int32_t *tile_pos, int batch_size, int spatial_size, int num_rows, int num_layers,
                            const int32_t *counts_dev, int32_t *order, int64_t order_batch_stride);
