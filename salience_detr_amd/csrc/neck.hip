@@ -349,11 +349,21 @@ __global__ void __launch_bounds__(kBlock) neck_combine_kernel(CombineArgs p)
 // (conv_mask's bias is the same for every pixel and drops out of the softmax.)  One workgroup reduces kSePix pixels
 // with a running (max, sum, weighted vector) per wave -- lane l owns channels 4l .. 4l+3 (C <= 256) -- and writes one
 // partial [C + 2] = (vector, max, sum); se_gate_kernel merges the partials of an image and runs the two tiny layers.
-constexpr int kSePix = 128;
+constexpr int kSePix = 128;      // pixels per workgroup at most
+// Pixels per workgroup (a multiple of 16: four waves x four pixels in flight).  Round 5: a wave walks its pixels four at
+// a time, one load round trip per step -- with 128 pixels per workgroup the coarse levels (273 pixels: 3 workgroups per
+// image, 8 dependent round trips each) cost the same 16 us as the finest; fewer pixels per workgroup until ~512
+// workgroups exist cut the chain to 1-2 steps (the gate kernel merges the extra partials in passing).
+static inline int se_pixels_per_block(int batch_size, int pixels)
+{
+    int pix = kSePix;
+    while (pix > 16 && (int64_t)batch_size * ((pixels + pix - 1) / pix) < 512) pix >>= 1;
+    return pix;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) se_context_kernel(const void *y_, const float *w_mask, int N, int C,
-                                                            int nblk, float *partial)
+                                                            int nblk, float *partial, int pix_per_block)
 {
     __shared__ float red[4][256 + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -367,8 +377,8 @@ __global__ void __launch_bounds__(kBlock) se_context_kernel(const void *y_, cons
     float4 V = make_float4(0.f, 0.f, 0.f, 0.f);
     // a wave owns 32 consecutive pixels, four in flight at a time (one pixel per load round trip made every level
     // cost the same 18 us)
-    const int w0 = blk * kSePix + wave * (kSePix / 4);
-    const int w_end = min(N, w0 + kSePix / 4);
+    const int w0 = blk * pix_per_block + wave * (pix_per_block / 4);
+    const int w_end = min(N, w0 + pix_per_block / 4);
     for (int pix = w0; pix < w_end; pix += 4) {
         float4 v[4];
         float m[4];
@@ -476,10 +486,15 @@ __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *part
     __syncthreads();
     if (tid < C) ctx[tid] = (red[tid] + red[tid + 256] + red[tid + 512] + red[tid + 768]) * inv;
     __syncthreads();
-    if (tid < R) {
+    // hidden layer: 16 lanes per row of W1 (round 5; one thread per row walked its 256 columns alone: R = 16 threads busy)
+    for (int r = tid >> 4; r < R; r += kGateThreads >> 4) {
         float h = 0.f;
-        for (int c = 0; c < C; ++c) h = fmaf(w1[(int64_t)tid * C + c], ctx[c], h);
-        hid[tid] = fmaxf(h, 0.f);
+        for (int c = tid & 15; c < C; c += 16) h = fmaf(w1[(int64_t)r * C + c], ctx[c], h);
+        h += __shfl_xor(h, 8, 16);
+        h += __shfl_xor(h, 4, 16);
+        h += __shfl_xor(h, 2, 16);
+        h += __shfl_xor(h, 1, 16);
+        if ((tid & 15) == 0) hid[r] = fmaxf(h, 0.f);
     }
     __syncthreads();
     if (tid < C) {
@@ -652,7 +667,8 @@ extern "C" int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_ro
 extern "C" int64_t sdetr_neck_gate_workspace_bytes(int batch_size, int pixels, int channels)
 {
     if (batch_size <= 0 || pixels <= 0 || channels <= 0) return 0;
-    const int64_t nblk = ((int64_t)pixels + kSePix - 1) / kSePix;
+    const int pix = se_pixels_per_block(batch_size, pixels);
+    const int64_t nblk = ((int64_t)pixels + pix - 1) / pix;
     return (int64_t)batch_size * nblk * ((int64_t)channels + 2) * (int64_t)sizeof(float);
 }
 
@@ -676,15 +692,16 @@ extern "C" int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, in
     const int64_t need = sdetr_neck_gate_workspace_bytes(batch_size, pixels, channels);
     if (!workspace || workspace_bytes < need)
         return fail("neck_gate_shortcut: needs %lld bytes of workspace, got %lld", (long long)need, (long long)workspace_bytes);
-    const int nblk = (pixels + kSePix - 1) / kSePix;
+    const int pix = se_pixels_per_block(batch_size, pixels);
+    const int nblk = (pixels + pix - 1) / pix;
     hipStream_t s = (hipStream_t)stream;
     float *partial = reinterpret_cast<float *>(workspace);
     if (dtype == SDETR_F32)
         hipLaunchKernelGGL((se_context_kernel<float>), dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, y,
-                           mask_weight, pixels, channels, nblk, partial);
+                           mask_weight, pixels, channels, nblk, partial, pix);
     else
         hipLaunchKernelGGL((se_context_kernel<bf16_t>), dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, y,
-                           mask_weight, pixels, channels, nblk, partial);
+                           mask_weight, pixels, channels, nblk, partial, pix);
     int rc = check_launch("neck_gate_shortcut(context)");
     if (rc) return rc;
     hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)batch_size), dim3(kGateThreads), 0, s, partial, nblk, channels, hidden,
