@@ -177,16 +177,23 @@ __device__ __forceinline__ nk_f32x16_t nk_mfma(uint4 a, uint4 b, nk_f32x16_t c)
     return mfma_act_32x32x16(a, b, c);
 }
 
-template <bool CHUNK4>  // in_per_group % 64 == 0: k-steps in groups of four
-__global__ void __launch_bounds__(kBlock) conv3x3_mfma_kernel(ConvMfmaArgs p)
+// SPLIT (round 5): a wave's nine taps are nine dependent load round trips (~2 us each: 18-20 us for a level of any size,
+// 48 us at level 0 with two waves per SIMD) around 0.4 us of MFMA work per tap.  With SPLIT = 3 a workgroup is three
+// waves on ONE 64-pixel tile, each with one kernel row (three taps, fully unrolled: their loads are in flight together);
+// the partial accumulators meet in LDS in the fixed order w0 + w1 + w2 and wave 0 runs the epilogue.
+template <bool CHUNK4, int SPLIT>  // CHUNK4: in_per_group % 64 == 0, k-steps in groups of four
+__global__ void __launch_bounds__(SPLIT == 1 ? kBlock : 64 * SPLIT) __attribute__((amdgpu_waves_per_eu(2, 4)))
+conv3x3_mfma_kernel(ConvMfmaArgs p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = lane & 31, h = lane >> 5;
     const int MT = p.CoG / 32, KC = p.CiG / 16;
     const int cblocks = p.CoG / 64;
     const int g = blockIdx.y / cblocks, mt0 = (blockIdx.y % cblocks) * 2;
-    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
-    if (p0 >= p.P) return;  // whole wave idle (no barriers in this kernel)
+    const int64_t p0 = SPLIT == 1 ? ((int64_t)blockIdx.x * 4 + wave) * 64 : (int64_t)blockIdx.x * 64;
+    if (p0 >= p.P) return;  // SPLIT == 1: whole wave idle (no barriers); otherwise the whole workgroup
+    constexpr int kTaps = 9 / SPLIT;
+    const int tap0 = SPLIT == 1 ? 0 : wave * kTaps;
 
     int oy[2], ox[2];
     int64_t img[2];
@@ -212,7 +219,7 @@ __global__ void __launch_bounds__(kBlock) conv3x3_mfma_kernel(ConvMfmaArgs p)
 
     const char *wbase = p.pw + ((int64_t)(g * MT + mt0) * 9 * KC) * 1024 + lane * 16;
     const int64_t mstride = (int64_t)9 * KC * 1024;  // next 32-row tile of output channels
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = tap0; tap < tap0 + kTaps; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const bf16_t *src[2];
         bool inb[2];
@@ -260,6 +267,38 @@ __global__ void __launch_bounds__(kBlock) conv3x3_mfma_kernel(ConvMfmaArgs p)
         }
     }
 
+    if constexpr (SPLIT > 1) {
+        // slots of 16 float4 x 64 lanes (16 KB): a wave's four accumulators, lane-contiguous (conflict-free both ways)
+        extern __shared__ __align__(16) unsigned char conv_lds[];
+        float4 *slots = reinterpret_cast<float4 *>(conv_lds);
+        auto put = [&](int slot) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        slots[(slot * 16 + (m * 2 + u) * 4 + q) * 64 + lane] =
+                            make_float4(acc[m][u][4 * q], acc[m][u][4 * q + 1], acc[m][u][4 * q + 2], acc[m][u][4 * q + 3]);
+        };
+        auto add = [&](int slot) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = slots[(slot * 16 + (m * 2 + u) * 4 + q) * 64 + lane];
+                        acc[m][u][4 * q] += v.x; acc[m][u][4 * q + 1] += v.y;
+                        acc[m][u][4 * q + 2] += v.z; acc[m][u][4 * q + 3] += v.w;
+                    }
+        };
+        if (wave == 1 || wave == 2) put(wave - 1);
+        __syncthreads();
+        if (wave != 0) return;
+        add(0);
+        add(1);
+    }
     // lane (t, h), register r of tile m: output channel (mt0 + m) * 32 + 8 * (r / 4) + 4 * h + r % 4 of pixel t
     const int cout = p.G * p.CoG;
 #pragma unroll
@@ -432,28 +471,35 @@ constexpr int kGateThreads = 1024;
 __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *partial, int nblk, int C, int R,
                                                                const float *w1, const float *w2, float *gate)
 {
+    // Round 5: one workgroup per image merges up to ~260 partials of 258 floats; the first form walked them with 22
+    // barriers (three LDS tree reductions) and 64-deep single-accumulator column loops and took 10-14 us, 18 times a step.
+    // Now: wave shuffles for the two scalar reductions, the partial matrix read as float2 by 8 row groups x 128 channel
+    // pairs with the whole column walk of a thread in flight at once, and 5 barriers.
+    constexpr int kChunk = 512, kGroups = 8, kWaves = kGateThreads / 64;
     __shared__ float ctx[256];
     __shared__ float hid[64];
-    __shared__ float wf[256];
-    __shared__ float red[kGateThreads];
-    const int tid = threadIdx.x, ch = tid & 255, grp = tid >> 8, b = blockIdx.x;
+    __shared__ float wf[kChunk];
+    __shared__ float red[kGroups][256];
+    __shared__ float wred[kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int pair = tid & 127, grp = tid >> 7;
     const int64_t ld = C + 2;
     const float *part = partial + (int64_t)b * nblk * ld;
     // global max over the partials
     float m = -INFINITY;
     for (int i = tid; i < nblk; i += kGateThreads) m = fmaxf(m, part[i * ld + C]);
-    red[tid] = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) wred[wave] = m;
     __syncthreads();
-    for (int s = kGateThreads / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-        __syncthreads();
-    }
-    const float gM = red[0];
-    __syncthreads();
-    // each partial's factor exp(max_i - max) (256 at a time), the total weight, the weighted channel sums
-    float ssum = 0.f, v = 0.f;
-    for (int base = 0; base < nblk; base += 256) {
-        if (tid < 256) {
+    float gM = wred[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) gM = fmaxf(gM, wred[w]);
+    // each partial's factor exp(max_i - max) (kChunk at a time), the total weight, the weighted channel sums
+    float ssum = 0.f, v0 = 0.f, v1 = 0.f;
+    for (int base = 0; base < nblk; base += kChunk) {
+        __syncthreads();                                   // wf (and, first time, wred) free again
+        if (tid < kChunk) {
             const int i = base + tid;
             float f = 0.f;
             if (i < nblk) {
@@ -466,27 +512,35 @@ __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *part
             wf[tid] = f;
         }
         __syncthreads();
-        const int n = min(256, nblk - base);
-        if (ch < C) {
-            const float *col = part + base * ld + ch;
-#pragma unroll 8
-            for (int k = grp; k < n; k += 4) v = fmaf(col[k * ld], wf[k], v);
+        const int n = min(kChunk, nblk - base);
+        if (2 * pair < C) {
+            const float *col = part + (int64_t)base * ld + 2 * pair;
+#pragma unroll 16
+            for (int k = grp; k < n; k += kGroups) {
+                const float2 c = *reinterpret_cast<const float2 *>(col + k * ld);
+                const float f = wf[k];
+                v0 = fmaf(c.x, f, v0);
+                v1 = fmaf(c.y, f, v1);
+            }
         }
-        __syncthreads();
     }
-    red[tid] = tid < 256 ? ssum : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+    if (lane == 0) wred[wave] = ssum;
+    red[grp][2 * pair] = v0;
+    red[grp][2 * pair + 1] = v1;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
+    if (tid < C) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) tot += wred[w];
+        float c = 0.f;
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) c += red[g][tid];
+        ctx[tid] = c * (1.0f / tot);
     }
-    const float inv = 1.0f / red[0];
     __syncthreads();
-    red[tid] = ch < C ? v : 0.f;
-    __syncthreads();
-    if (tid < C) ctx[tid] = (red[tid] + red[tid + 256] + red[tid + 512] + red[tid + 768]) * inv;
-    __syncthreads();
-    // hidden layer: 16 lanes per row of W1 (round 5; one thread per row walked its 256 columns alone: R = 16 threads busy)
+    // hidden layer: 16 lanes per row of W1
     for (int r = tid >> 4; r < R; r += kGateThreads >> 4) {
         float h = 0.f;
         for (int c = tid & 15; c < C; c += 16) h = fmaf(w1[(int64_t)r * C + c], ctx[c], h);
@@ -499,6 +553,7 @@ __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *part
     __syncthreads();
     if (tid < C) {
         float o = 0.f;
+#pragma unroll 8
         for (int j = 0; j < R; ++j) o = fmaf(w2[(int64_t)tid * R + j], hid[j], o);
         gate[(int64_t)b * C + tid] = 1.0f / (1.0f + __expf(-o));
     }
@@ -601,6 +656,20 @@ extern "C" int sdetr_neck_pack_conv3x3_bf16(sdetr_stream_t stream, const float *
     return check_launch("neck_pack_conv3x3");
 }
 
+// How many waves share a 64-pixel x 64-channel tile of the MFMA convolution (1 or 3; see the kernel's header).
+// SDETR_CONV_SPLIT pins it (benchmarks/conv_split_ab.py).
+static int conv_tap_split(int64_t wave_tiles)
+{
+    static const int pinned = [] {
+        const char *e = getenv("SDETR_CONV_SPLIT");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 3) ? v : 0;
+    }();
+    if (pinned) return pinned;
+    (void)wave_tiles;
+    return 3;
+}
+
 extern "C" int sdetr_neck_conv3x3_mfma_bf16(sdetr_stream_t stream, const void *x, int batch_size, int height, int width,
                                             int x_row_stride, const void *packed_weight, const float *bias, int groups,
                                             int in_per_group, int out_per_group, int stride, int activation, void *out)
@@ -627,13 +696,21 @@ extern "C" int sdetr_neck_conv3x3_mfma_bf16(sdetr_stream_t stream, const void *x
     a.Wo = (width - 1) / stride + 1;
     a.P = (int64_t)batch_size * a.Ho * a.Wo;
     a.ldx = x_row_stride; a.G = groups; a.CiG = in_per_group; a.CoG = out_per_group; a.act = activation;
-    const int64_t gx = (a.P + 255) / 256;
     const int64_t gy = (int64_t)groups * (out_per_group / 64);
+    const int64_t tiles = (a.P + 63) / 64;
+    const int split = conv_tap_split(tiles * gy);
+    const int64_t gx = split == 1 ? (a.P + 255) / 256 : tiles;
     if (gx > 0x7fffffffLL || gy > 65535) return fail("neck_conv3x3_mfma: grid too large");
-    if (in_per_group % 64 == 0)
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    hipStream_t s = (hipStream_t)stream;
+    const bool c4 = in_per_group % 64 == 0;
+    if (split == 3) {
+        if (c4) hipLaunchKernelGGL((conv3x3_mfma_kernel<true, 3>), grid, dim3(192), 2 * 16384, s, a);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<false, 3>), grid, dim3(192), 2 * 16384, s, a);
+    } else {
+        if (c4) hipLaunchKernelGGL((conv3x3_mfma_kernel<true, 1>), grid, dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_mfma_kernel<false, 1>), grid, dim3(kBlock), 0, s, a);
+    }
     return check_launch("neck_conv3x3_mfma");
 }
 

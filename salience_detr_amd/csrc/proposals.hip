@@ -84,12 +84,17 @@ struct NmsArgs {
 constexpr int kNmsThreads = 1024;
 constexpr uint16_t kNoRank = 0xffffu;
 
-// LDS: rank map u16[S] | state u8[K] | scan scratch
+// LDS: rank map u16[S] | state u8[K] | (CACHE) the ranks of a token's higher-priority selected neighbours u16[K][8]
+// CACHE (round 5): the decision rounds used to redo, for every undecided rank and every round, the id load, the level
+// search, the division and eight rank-map lookups; the neighbourhood never changes, so it is resolved once into LDS and a
+// round is one 16-byte read plus the neighbours' states.  Same fixpoint, same output.
+template <bool CACHE>
 __global__ void __launch_bounds__(kNmsThreads) grid_nms_kernel(NmsArgs p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *rank_of = reinterpret_cast<uint16_t *>(smem);
     uint8_t *state = smem + (((size_t)p.S * 2 + 15) & ~(size_t)15);            // 0 undecided, 1 kept, 2 dropped
+    uint16_t *nbr = reinterpret_cast<uint16_t *>(state + (((size_t)p.K + 15) & ~(size_t)15));
     __shared__ int wave_sum[kNmsThreads / 64];
     __shared__ int carry;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -106,29 +111,58 @@ __global__ void __launch_bounds__(kNmsThreads) grid_nms_kernel(NmsArgs p)
     __syncthreads();
 
     const int nnb = p.neighbourhood;   // 0, 4 or 8
+    // the higher-priority selected neighbours of rank r (kNoRank: none in that direction)
+    auto neighbours = [&](int r, uint16_t (&out)[8]) {
+        const int t = (int)idx[r];
+        int lvl = 0;
+        while (lvl + 1 < p.L && t >= p.start[lvl + 1]) ++lvl;
+        const int H = (int)p.shapes[lvl][0], W = (int)p.shapes[lvl][1];
+        const int sp = t - (int)p.start[lvl];
+        const int y = sp / W, x = sp - y * W;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // k: W, E, N, S, NW, NE, SW, SE
+            constexpr int kDx[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
+            constexpr int kDy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+            out[k] = kNoRank;
+            if (k >= nnb) continue;
+            const int xx = x + kDx[k], yy = y + kDy[k];
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const uint16_t rr = rank_of[p.start[lvl] + yy * W + xx];
+            if (rr != kNoRank && (int)rr < r) out[k] = rr;                    // selected and of higher priority
+        }
+    };
+    if constexpr (CACHE) {
+        for (int r = tid; r < p.K; r += kNmsThreads) {
+            uint16_t nb[8];
+            if (state[r] == 0) neighbours(r, nb);
+            else
+                for (int k = 0; k < 8; ++k) nb[k] = kNoRank;
+            uint4 w;
+            w.x = nb[0] | ((uint32_t)nb[1] << 16); w.y = nb[2] | ((uint32_t)nb[3] << 16);
+            w.z = nb[4] | ((uint32_t)nb[5] << 16); w.w = nb[6] | ((uint32_t)nb[7] << 16);
+            reinterpret_cast<uint4 *>(nbr)[r] = w;
+        }
+        __syncthreads();
+    }
     int pending = 1;
     while (pending) {
         int mine = 0;
         for (int r = tid; r < p.K; r += kNmsThreads) {
             if (state[r] != 0) continue;
-            const int t = (int)idx[r];
-            int lvl = 0;
-            while (lvl + 1 < p.L && t >= p.start[lvl + 1]) ++lvl;
-            const int H = (int)p.shapes[lvl][0], W = (int)p.shapes[lvl][1];
-            const int sp = t - (int)p.start[lvl];
-            const int y = sp / W, x = sp - y * W;
+            uint16_t nb[8];
+            if constexpr (CACHE) {
+                const uint4 w = reinterpret_cast<const uint4 *>(nbr)[r];
+                nb[0] = (uint16_t)w.x; nb[1] = (uint16_t)(w.x >> 16); nb[2] = (uint16_t)w.y; nb[3] = (uint16_t)(w.y >> 16);
+                nb[4] = (uint16_t)w.z; nb[5] = (uint16_t)(w.z >> 16); nb[6] = (uint16_t)w.w; nb[7] = (uint16_t)(w.w >> 16);
+            } else {
+                neighbours(r, nb);
+            }
             bool any_kept = false, any_open = false;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                // k: W, E, N, S, NW, NE, SW, SE
-                constexpr int kDx[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
-                constexpr int kDy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
-                if (k >= nnb) continue;
-                const int xx = x + kDx[k], yy = y + kDy[k];
-                if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                const uint16_t rr = rank_of[p.start[lvl] + yy * W + xx];
-                if (rr == kNoRank || (int)rr >= r) continue;                  // not selected, or lower priority
-                const uint8_t s = state[rr];
+                if (nb[k] == kNoRank) continue;
+                const uint8_t s = state[nb[k]];
                 any_kept |= s == 1;
                 any_open |= s == 0;
             }
@@ -247,18 +281,25 @@ extern "C" int sdetr_grid_nms_topk(sdetr_stream_t stream, const int64_t *topk_in
     int64_t total = 0;
     if (copy_levels(level_shapes_host, num_levels, a.shapes, a.start, &total) || total != spatial_size)
         return fail("grid_nms_topk: level shapes do not add up to spatial_size");
-    const size_t lds = (((size_t)spatial_size * 2 + 15) & ~(size_t)15) + (size_t)num_topk;
-    if (lds > 150 * 1024) return fail("grid_nms_topk: pyramid of %d tokens + %d selected does not fit the LDS rank map",
-                                      spatial_size, num_topk);
+    const size_t lds_plain = (((size_t)spatial_size * 2 + 15) & ~(size_t)15) + (((size_t)num_topk + 15) & ~(size_t)15);
+    if (lds_plain > 150 * 1024) return fail("grid_nms_topk: pyramid of %d tokens + %d selected does not fit the LDS rank map",
+                                            spatial_size, num_topk);
+    const size_t lds_cached = lds_plain + (size_t)num_topk * 16;
+    const bool cached = lds_cached <= 150 * 1024;
     if (batch_size == 0) return 0;
     if (!topk_index || !out_index || !out_count) return fail("grid_nms_topk: null pointer");
     if (index_batch_stride < num_topk) return fail("grid_nms_topk: index batch stride too small");
     a.index = topk_index; a.index_batch_stride = index_batch_stride; a.L = num_levels; a.K = num_topk;
     a.S = spatial_size; a.neighbourhood = neighbourhood; a.max_keep = max_keep; a.out_index = out_index;
     a.out_count = out_count;
-    static DeviceOnce lds_once;
-    allow_dynamic_lds(grid_nms_kernel, lds_once, 150 * 1024);
-    hipLaunchKernelGGL(grid_nms_kernel, dim3(batch_size), dim3(kNmsThreads), lds, (hipStream_t)stream, a);
+    static DeviceOnce lds_once, lds_once_cached;
+    if (cached) {
+        allow_dynamic_lds(grid_nms_kernel<true>, lds_once_cached, 150 * 1024);
+        hipLaunchKernelGGL(grid_nms_kernel<true>, dim3(batch_size), dim3(kNmsThreads), lds_cached, (hipStream_t)stream, a);
+    } else {
+        allow_dynamic_lds(grid_nms_kernel<false>, lds_once, 150 * 1024);
+        hipLaunchKernelGGL(grid_nms_kernel<false>, dim3(batch_size), dim3(kNmsThreads), lds_plain, (hipStream_t)stream, a);
+    }
     return check_launch("grid_nms_topk");
 }
 

@@ -135,6 +135,14 @@ class CSPRepPluXLayer(nn.Module):
                     bias=torch.cat([b1, b2]).contiguous(), blocks=[blk.folded(dtype) for blk in self.bottlenecks])
 
 
+def _token_matmul(x: Tensor, weight: Tensor) -> Tensor:
+    """``x @ weight.T`` for token-major ``[B, N, C]`` maps; a row range of a longer buffer (batch stride > N * C) goes
+    through the strided-batched GEMM instead of being copied first."""
+    if x.is_contiguous() or x.dim() != 3 or x.stride(2) != 1 or x.stride(1) != x.shape[2]:
+        return torch.matmul(x, weight.t())
+    return torch.bmm(x, weight.t().expand(x.shape[0], -1, -1))
+
+
 def _is_silu(act) -> bool:
     return act is nn.SiLU or isinstance(act, nn.SiLU)
 
@@ -206,7 +214,7 @@ class RepVGGPluXNetwork(nn.Module):
         """CSPRepPluXLayer on ``cat([first (up-sampled to hw when asked), second], channels)`` (repnet.py:120-123)."""
         h, w = hw
         C = second.shape[2]
-        a_second = torch.matmul(second, p["second"].t())  # [B, N, 2C]: conv1 | conv2 outputs
+        a_second = _token_matmul(second, p["second"])  # [B, N, 2C]: conv1 | conv2 outputs
         if upsample:
             a_first = torch.matmul(first, p["first"].t())  # at the coarse resolution
             both = FO.neck_combine(a_second, h, w, up=a_first, up_hw=first_hw, bias=p["bias"], activation=True)
@@ -241,7 +249,7 @@ class RepVGGPluXNetwork(nn.Module):
         for idx in range(L - 1, 0, -1):  # top-down
             hh, hw_ = shapes[idx]
             wl, bl = plan["lateral"][idx - 1]
-            high = FO.neck_combine(torch.matmul(inner[0], wl.t()), hh, hw_, bias=bl, activation=True)
+            high = FO.neck_combine(_token_matmul(inner[0], wl), hh, hw_, bias=bl, activation=True)
             inner[0] = high
             inner.insert(0, self._csp(plan["layer"][idx - 1], high, shapes[idx], levels[idx - 1], shapes[idx - 1], True))
         outs = [inner[0]]
@@ -304,7 +312,9 @@ class RepVGGPluXNetwork(nn.Module):
         """``memory`` ``[B, sum h*w, C]`` -> the neck's output in the same layout
         (models/bricks/salience_transformer.py:185-192 without its transposes)."""
         sizes = [int(h) * int(w) for h, w in level_shapes]
-        levels = [m.contiguous() for m in memory.split(sizes, 1)]
+        # (row ranges of the memory as they lie: the levels only enter the neck through ``_token_matmul``, which takes
+        #  the batch stride as it is -- four copies of the pyramid less per step)
+        levels = list(memory.split(sizes, 1))
         return torch.cat(self.forward_levels(levels, level_shapes, differentiable), 1)
 
     def forward(self, x: "OrderedDict[str, Tensor]"):

@@ -134,8 +134,11 @@ def test_host_side_size_helpers_need_no_gpu():
     assert lib.sdetr_linear_packed_bytes(91) == 65536 and lib.sdetr_linear_packed_bytes(384) == 3 * 65536
     assert lib.sdetr_focal_loss_workspace_bytes(0) == 0 and lib.sdetr_focal_loss_workspace_bytes(10 ** 9) == 1024 * 8
     assert lib.sdetr_topk_workspace_bytes(2, 20000, 6680) > 2 * 20000 * 8 and lib.sdetr_topk_workspace_bytes(2, 11363, 300) == 16
-    # neck (13): pooling partials = ceil(pixels / 128) x (channels + 2) floats per image; MFMA weight fragments in bf16
-    assert lib.sdetr_neck_gate_workspace_bytes(2, 16800, 256) == 2 * 132 * 258 * 4
+    # neck (13): pooling partials = ceil(pixels / pixels_per_block) x (channels + 2) floats per image, the block halved from
+    # 128 pixels down to 16 until the launch has 512 workgroups (round 5); MFMA weight fragments in bf16
+    assert lib.sdetr_neck_gate_workspace_bytes(2, 16800, 256) == 2 * 263 * 258 * 4         # 64-pixel blocks
+    assert lib.sdetr_neck_gate_workspace_bytes(64, 16800, 256) == 64 * 132 * 258 * 4       # 128-pixel blocks fill the chip
+    assert lib.sdetr_neck_gate_workspace_bytes(2, 273, 256) == 2 * 18 * 258 * 4            # the floor: 16 pixels
     assert lib.sdetr_neck_gate_workspace_bytes(0, 16800, 256) == 0
     assert lib.sdetr_neck_conv3x3_packed_bytes(4, 64, 64) == 4 * 9 * 64 * 64 * 2
     assert lib.sdetr_neck_conv3x3_packed_bytes(1, 256, 256) == 9 * 256 * 256 * 2
