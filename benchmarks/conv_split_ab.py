@@ -1,5 +1,6 @@
-"""A/B of the MFMA 3x3 convolution's tap split (SDETR_CONV_SPLIT = 1: a wave walks its nine taps; 3: three waves per tile,
-one kernel row each) at the benchmark pyramid's four level sizes, plus the neck's gate (context / gate / apply) and the
+"""A/B of the MFMA 3x3 convolution's forms -- SDETR_CONV_SPLIT = 1: a wave walks its nine taps; 3: three waves per tile,
+one kernel row each; SDETR_CONV_LDS = 1 (default): the 64 -> 64 stride-1 blocks with both operands in LDS (the stride-2
+"_down" rows never take that form) -- at the benchmark pyramid's four level sizes, plus the neck's gate (context / gate / apply) and the
 proposal stage's grid NMS at full size.  Each op is captured 40 times into a hipGraph and replayed; us per call.
 
     python benchmarks/conv_split_ab.py [--out gpurun_out/conv_split_ab.json]
@@ -46,7 +47,8 @@ def child():
     from salience_detr_amd import filter_ops as FO
     from salience_detr_amd import synthetic as syn
     dev = "cuda:0"
-    rec = {"split": os.environ.get("SDETR_CONV_SPLIT", "default"), "conv": {}, "gate": {}}
+    rec = {"split": os.environ.get("SDETR_CONV_SPLIT", "default"), "lds_form": os.environ.get("SDETR_CONV_LDS", "default"),
+           "conv": {}, "gate": {}}
     w = (syn.det_randn("ab.w", (4, 3, 3, 64, 64)) / 24.0).to(dev)
     wd = (syn.det_randn("ab.wd", (1, 3, 3, 256, 256)) / 48.0).to(dev)
     bias = (0.1 * syn.det_randn("ab.b", (256,))).to(dev)
@@ -70,6 +72,9 @@ def child():
     score = torch.stack([field, field.flip(0)]) + 1e-4 * torch.rand(2, S, generator=g)
     ti = score.topk(3600, 1)[1].to(dev)
     rec["nms_3600_of_22223"] = graph_us(lambda: FO.grid_nms_topk(ti, LEVELS, S, 0.3, 900))
+    # decoder self-attention core: 2 images x 8 heads x 900 queries
+    qkv = (torch.randn(2, 900, 768, generator=g) * 1.5).to(torch.bfloat16).to(dev)
+    rec["attention_2x900"] = graph_us(lambda: FO.attention_heads(qkv[..., :256], qkv[..., 256:512], qkv[..., 512:], 8))
     print("REC " + json.dumps(rec))
 
 
@@ -81,8 +86,8 @@ def main():
     if args.child:
         return child()
     rows = []
-    for split in ("1", "3"):
-        env = dict(os.environ, SDETR_CONV_SPLIT=split)
+    for split, lds in (("1", "0"), ("3", "0"), ("3", "1")):
+        env = dict(os.environ, SDETR_CONV_SPLIT=split, SDETR_CONV_LDS=lds)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("REC ")]
         if not line:

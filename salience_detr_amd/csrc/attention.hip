@@ -17,7 +17,7 @@ namespace sdetr {
 
 constexpr int kAttHeadDim = 32;
 constexpr int kAttMaxBlocks = 36;        // 36 x 32 = 1152 keys: 144 KB of fragments
-constexpr int kAttWaves = 8;             // 256 queries per workgroup
+constexpr int kAttWaves = 8;             // 4 query groups of 32 x 2 key halves: 128 queries per workgroup
 
 typedef __bf16 at_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float at_f32x16_t __attribute__((ext_vector_type(16)));
@@ -49,6 +49,13 @@ __device__ __forceinline__ uint4 at_pack_half(const at_f32x16_t &c, int m)
 // accumulator row of register i for lane half h
 __device__ __forceinline__ int at_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
+// Round 5: (a) the fragment build requests the rows of ALL of a wave's key blocks before it stores the first one (a block
+// per load round trip had made the build 4-5 round trips long); (b) the eight waves are 4 query groups x 2 key halves: a
+// wave runs the flash loop over half the key blocks, the halves' (max, sum, O) states meet in LDS (exact online-softmax
+// merge, fixed order: low keys then high keys).  2 x 8 x 900 tokens: 28 -> see profiles.
+constexpr int kAttQueryWaves = 4, kAttKeySplits = kAttWaves / kAttQueryWaves;
+constexpr int kAttBuildPerWave = (kAttMaxBlocks + kAttWaves - 1) / kAttWaves;      // 5
+
 __global__ void __launch_bounds__(64 * kAttWaves) attention_heads_kernel(AttArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -57,98 +64,143 @@ __global__ void __launch_bounds__(64 * kAttWaves) attention_heads_kernel(AttArgs
     char *vf = lds + nblk * 2048;        // [nblk][2][1 KB]  V^T fragments (k-blocks 0, 1 of the 32 keys)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = lane & 31, h = lane >> 5;
+    const int qw = wave % kAttQueryWaves, ks = wave / kAttQueryWaves;
     const int chunk = blockIdx.x % p.qchunks, bh = blockIdx.x / p.qchunks;
     const int b = bh / p.heads, head = bh - b * p.heads;
     const bf16_t *kbase = p.k + (int64_t)b * p.k_batch + head * kAttHeadDim;
     const bf16_t *vbase = p.v + (int64_t)b * p.v_batch + head * kAttHeadDim;
 
     // my query rows first (their latency hides behind the fragment build)
-    const int qi = chunk * (32 * kAttWaves) + wave * 32 + t;
-    const bool has_query = chunk * (32 * kAttWaves) + wave * 32 < p.N;      // (wave-uniform)
+    const int q0 = chunk * (32 * kAttQueryWaves) + qw * 32;
+    const int qi = q0 + t;
+    const bool has_query = q0 < p.N;                                        // (wave-uniform)
     uint4 qfrag[2];
     {
         const bf16_t *qr = p.q + (int64_t)b * p.q_batch + (int64_t)min(qi, p.N - 1) * p.q_row + head * kAttHeadDim + 8 * h;
         qfrag[0] = *reinterpret_cast<const uint4 *>(qr);
         qfrag[1] = *reinterpret_cast<const uint4 *>(qr + 16);
     }
-    // ---- K and V^T fragments of every key block, built by all waves ----
-    for (int kb = wave; kb < nblk; kb += kAttWaves) {
-        const int key = min(kb * 32 + t, p.N - 1);                          // (rows past N are masked in the loop)
-        const bf16_t *kr = kbase + (int64_t)key * p.k_row + 8 * h;
-        const uint4 k0 = *reinterpret_cast<const uint4 *>(kr), k1 = *reinterpret_cast<const uint4 *>(kr + 16);
-        // V^T: lane (t = head channel, h) gathers channel t of the 8 keys that slot (m, h) of P^T's operand stands for
-        uint32_t vv[2][4];
+    // ---- K and V^T fragments of every key block, built by all waves: all loads, then all stores ----
+    {
+        uint4 k0[kAttBuildPerWave], k1[kAttBuildPerWave];
+        uint32_t vv[kAttBuildPerWave][2][4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < kAttBuildPerWave; ++i) {
+            const int kb = wave + kAttWaves * i;
+            if (kb < nblk) {                                                    // (wave-uniform)
+                const int key = min(kb * 32 + t, p.N - 1);                      // (rows past N are masked in the loop)
+                const bf16_t *kr = kbase + (int64_t)key * p.k_row + 8 * h;
+                k0[i] = *reinterpret_cast<const uint4 *>(kr);
+                k1[i] = *reinterpret_cast<const uint4 *>(kr + 16);
+                // V^T: lane (t = head channel, h) gathers channel t of the 8 keys that slot (m, h) of P^T's operand stands for
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const int r0 = min(kb * 32 + at_row(8 * m + 2 * s2, h), p.N - 1);
-                const int r1 = min(kb * 32 + at_row(8 * m + 2 * s2 + 1, h), p.N - 1);
-                const uint32_t lo = vbase[(int64_t)r0 * p.v_row + t], hi = vbase[(int64_t)r1 * p.v_row + t];
-                vv[m][s2] = lo | (hi << 16);
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const int r0 = min(kb * 32 + at_row(8 * m + 2 * s2, h), p.N - 1);
+                        const int r1 = min(kb * 32 + at_row(8 * m + 2 * s2 + 1, h), p.N - 1);
+                        const uint32_t lo = vbase[(int64_t)r0 * p.v_row + t], hi = vbase[(int64_t)r1 * p.v_row + t];
+                        vv[i][m][s2] = lo | (hi << 16);
+                    }
             }
-        *reinterpret_cast<uint4 *>(kf + (kb * 2 + 0) * 1024 + lane * 16) = k0;
-        *reinterpret_cast<uint4 *>(kf + (kb * 2 + 1) * 1024 + lane * 16) = k1;
-        *reinterpret_cast<uint4 *>(vf + (kb * 2 + 0) * 1024 + lane * 16) = make_uint4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
-        *reinterpret_cast<uint4 *>(vf + (kb * 2 + 1) * 1024 + lane * 16) = make_uint4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
+        }
+#pragma unroll
+        for (int i = 0; i < kAttBuildPerWave; ++i) {
+            const int kb = wave + kAttWaves * i;
+            if (kb < nblk) {
+                *reinterpret_cast<uint4 *>(kf + (kb * 2 + 0) * 1024 + lane * 16) = k0[i];
+                *reinterpret_cast<uint4 *>(kf + (kb * 2 + 1) * 1024 + lane * 16) = k1[i];
+                *reinterpret_cast<uint4 *>(vf + (kb * 2 + 0) * 1024 + lane * 16) = make_uint4(vv[i][0][0], vv[i][0][1], vv[i][0][2], vv[i][0][3]);
+                *reinterpret_cast<uint4 *>(vf + (kb * 2 + 1) * 1024 + lane * 16) = make_uint4(vv[i][1][0], vv[i][1][1], vv[i][1][2], vv[i][1][3]);
+            }
+        }
     }
     __syncthreads();
-    if (!has_query) return;
 
-    // ---- flash loop: S^T = K Q^T (lane = my query, registers = keys), O^T += V^T P^T, five key blocks per round ----
+    // ---- flash loop over my half of the key blocks: S^T = K Q^T (lane = my query, registers = keys), O^T += V^T P^T,
+    //      five key blocks per round ----
+    const int per_split = (nblk + kAttKeySplits - 1) / kAttKeySplits;
+    const int kb_begin = ks * per_split, kb_end = min(nblk, kb_begin + per_split);
     at_f32x16_t o;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
     float run_max = -INFINITY, run_sum = 0.f;
     constexpr int G = 5;
-    for (int k0 = 0; k0 < nblk; k0 += G) {
-        at_f32x16_t s[G];
-        uint4 kfr[G][2];
+    if (has_query) {
+        for (int k0 = kb_begin; k0 < kb_end; k0 += G) {
+            at_f32x16_t s[G];
+            uint4 kfr[G][2];
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int kb = min(k0 + j, nblk - 1);
-            const at_lds_cptr_t kp = (at_lds_cptr_t)kf + kb * 2048 + lane * 16;
-            kfr[j][0] = at_lds_read16(kp);
-            kfr[j][1] = at_lds_read16(kp + 1024);
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[j][i] = 0.f;
-            s[j] = at_mfma(kfr[j][0], qfrag[0], s[j]);
-            s[j] = at_mfma(kfr[j][1], qfrag[1], s[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = (k0 + j) * 32 + at_row(i, h);
-                s[j][i] = (k0 + j < nblk && key < p.N) ? s[j][i] * p.scale : -INFINITY;
-                mx = fmaxf(mx, s[j][i]);
+            for (int j = 0; j < G; ++j) {
+                const int kb = min(k0 + j, kb_end - 1);
+                const at_lds_cptr_t kp = (at_lds_cptr_t)kf + kb * 2048 + lane * 16;
+                kfr[j][0] = at_lds_read16(kp);
+                kfr[j][1] = at_lds_read16(kp + 1024);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of my query's keys
-        const float new_max = fmaxf(run_max, mx);      // (finite: every round holds at least one real key)
-        const float corr = __expf(run_max - new_max);
-        float sum = 0.f;
+            float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < G; ++j)
+            for (int j = 0; j < G; ++j) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[j][i] = __expf(s[j][i] - new_max);
-                sum += s[j][i];
+                for (int i = 0; i < 16; ++i) s[j][i] = 0.f;
+                s[j] = at_mfma(kfr[j][0], qfrag[0], s[j]);
+                s[j] = at_mfma(kfr[j][1], qfrag[1], s[j]);
             }
-        sum += __shfl_xor(sum, 32);
-        run_sum = run_sum * corr + sum;
-        run_max = new_max;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] *= corr;
+            for (int j = 0; j < G; ++j)
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int kb = min(k0 + j, nblk - 1);        // (a repeated block carries P = 0)
-            const at_lds_cptr_t vp = (at_lds_cptr_t)vf + kb * 2048 + lane * 16;
-            o = at_mfma(at_lds_read16(vp), at_pack_half(s[j], 0), o);
-            o = at_mfma(at_lds_read16(vp + 1024), at_pack_half(s[j], 1), o);
+                for (int i = 0; i < 16; ++i) {
+                    const int key = (k0 + j) * 32 + at_row(i, h);
+                    s[j][i] = (k0 + j < kb_end && key < p.N) ? s[j][i] * p.scale : -INFINITY;
+                    mx = fmaxf(mx, s[j][i]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));            // the other half of my query's keys
+            const float new_max = fmaxf(run_max, mx);      // (finite: every round holds at least one real key)
+            const float corr = __expf(run_max - new_max);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[j][i] = __expf(s[j][i] - new_max);
+                    sum += s[j][i];
+                }
+            sum += __shfl_xor(sum, 32);
+            run_sum = run_sum * corr + sum;
+            run_max = new_max;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] *= corr;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int kb = min(k0 + j, kb_end - 1);        // (a repeated block carries P = 0)
+                const at_lds_cptr_t vp = (at_lds_cptr_t)vf + kb * 2048 + lane * 16;
+                o = at_mfma(at_lds_read16(vp), at_pack_half(s[j], 0), o);
+                o = at_mfma(at_lds_read16(vp + 1024), at_pack_half(s[j], 1), o);
+            }
+        }
+    }
+    // ---- the key halves meet: the high half's state through LDS (over the fragments, which nobody reads any more) ----
+    __syncthreads();
+    float *mg = reinterpret_cast<float *>(lds) + (qw * 64 + lane) * 20;     // 18 floats per lane, 80-byte pitch
+    if (ks == 1 && has_query) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(mg + 4 * g) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+        mg[16] = run_max;
+        mg[17] = run_sum;
+    }
+    __syncthreads();
+    if (ks != 0 || !has_query) return;
+    {
+        const float m1 = mg[16], s1 = mg[17];
+        // (a half without blocks -- N <= 32 * per_split -- left max = -inf, sum = 0: its factor is 0)
+        const float new_max = fmaxf(run_max, m1);
+        const float c0 = __expf(run_max - new_max), c1 = m1 == -INFINITY ? 0.f : __expf(m1 - new_max);
+        run_sum = run_sum * c0 + s1 * c1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(mg + 4 * g);
+            o[4 * g] = o[4 * g] * c0 + v.x * c1; o[4 * g + 1] = o[4 * g + 1] * c0 + v.y * c1;
+            o[4 * g + 2] = o[4 * g + 2] * c0 + v.z * c1; o[4 * g + 3] = o[4 * g + 3] * c0 + v.w * c1;
         }
     }
     if (qi < p.N) {
@@ -181,9 +233,9 @@ extern "C" int sdetr_attention_heads_bf16(sdetr_stream_t stream, const void *q, 
     a.q = (const bf16_t *)q; a.k = (const bf16_t *)k; a.v = (const bf16_t *)v;
     a.q_batch = q_batch_stride; a.q_row = q_row_stride; a.k_batch = k_batch_stride; a.k_row = k_row_stride;
     a.v_batch = v_batch_stride; a.v_row = v_row_stride; a.out = (bf16_t *)out; a.N = num_tokens; a.heads = num_heads;
-    a.qchunks = (num_tokens + 32 * kAttWaves - 1) / (32 * kAttWaves); a.scale = scale;
+    a.qchunks = (num_tokens + 32 * kAttQueryWaves - 1) / (32 * kAttQueryWaves); a.scale = scale;
     const int nblk = (num_tokens + 31) / 32;
-    const size_t lds = (size_t)nblk * 4096;
+    const size_t lds = std::max((size_t)nblk * 4096, (size_t)kAttQueryWaves * 64 * 80);   // fragments, then the merge states
     static DeviceOnce lds_once1;
     allow_dynamic_lds(attention_heads_kernel, lds_once1, kAttMaxBlocks * 4096);
     hipLaunchKernelGGL(attention_heads_kernel, dim3((unsigned)(batch_size * num_heads * a.qchunks)), dim3(64 * kAttWaves), lds,

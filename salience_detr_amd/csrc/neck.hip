@@ -322,6 +322,107 @@ conv3x3_mfma_kernel(ConvMfmaArgs p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The neck's own block shape -- stride 1, groups of 64 -> 64 channels -- with BOTH operands in LDS (round 5).  The kernel
+// above reads a wave's operands fragment by fragment from global memory: nine (three, SPLIT = 3) dependent round trips per
+// 64 pixels and, at level 0, 2100 such wave tiles on 1024 SIMDs -- 43-47 us for 3.9 us of MFMA work, 10-17 us at the small
+// levels.  Here a workgroup of 8 waves owns (group, image, 8 rows x 32 columns of output):
+//   1. one bulk fill: the group's 72 KB of packed fragments (as they lie in the packed buffer: lane-contiguous 16-byte
+//      pieces) and the 10 x 34 pixel input patch x 64 channels, 144 bytes per pixel (128 + 16 of padding: the 16 lanes a
+//      ds_read_b128 serves together are 16 different pixels, 36 words apart -> 16 different 4-bank slots), zero outside
+//      the image -- ONE round trip, everything in flight together;
+//   2. wave w = output row w of the tile: 9 taps x 4 k-steps x 2 channel tiles of v_mfma_f32_32x32x16, the B operand
+//      (pixel t shifted by the tap, 8 channels) and the two A fragments by ds_read_b128, no further global loads;
+//   3. bias + SiLU + 16-bit stores as above.
+constexpr int kLdsConvRows = 8, kLdsConvCols = 32;
+constexpr int kLdsConvPatchCols = kLdsConvCols + 2, kLdsConvPatchRows = kLdsConvRows + 2;
+constexpr int kLdsConvPixelBytes = 144;
+constexpr int kLdsConvWeightBytes = 2 * 9 * 4 * 1024;
+constexpr int kLdsConvBytes = kLdsConvWeightBytes + kLdsConvPatchRows * kLdsConvPatchCols * kLdsConvPixelBytes;
+
+__global__ void __launch_bounds__(64 * kLdsConvRows) conv3x3_lds_kernel(ConvMfmaArgs p, int row_tiles, int col_tiles)
+{
+    extern __shared__ __align__(16) unsigned char conv_lds[];
+    unsigned char *wl = conv_lds, *patch = conv_lds + kLdsConvWeightBytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = lane & 31, h = lane >> 5;
+    const int g = blockIdx.y;
+    int tile = blockIdx.x;
+    const int ct = tile % col_tiles; tile /= col_tiles;
+    const int rt = tile % row_tiles;
+    const int b = tile / row_tiles;
+    const int y0 = rt * kLdsConvRows, x0 = ct * kLdsConvCols;
+
+    // ---- the fill: weights (4608 pieces) and patch (340 pixels x 8 pieces), all loads issued before the first store ----
+    {
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(p.pw + (int64_t)g * kLdsConvWeightBytes);
+        uint4 wv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wv[i] = wsrc[i * 512 + tid];
+        constexpr int kPieces = kLdsConvPatchRows * kLdsConvPatchCols * 8;     // 2720
+        constexpr int kPer = (kPieces + 511) / 512;                             // 6
+        uint4 pv[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = i * 512 + tid;
+            const int pix = e >> 3, piece = e & 7;
+            const int pr = pix / kLdsConvPatchCols, pc = pix - pr * kLdsConvPatchCols;
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            pv[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < kPieces && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                pv[i] = *reinterpret_cast<const uint4 *>(p.x + (((int64_t)b * p.H + iy) * p.W + ix) * p.ldx + g * 64 + piece * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) reinterpret_cast<uint4 *>(wl)[i * 512 + tid] = wv[i];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = i * 512 + tid;
+            if (e < kPieces) *reinterpret_cast<uint4 *>(patch + (e >> 3) * kLdsConvPixelBytes + (e & 7) * 16) = pv[i];
+        }
+    }
+    __syncthreads();
+    const int oy = y0 + wave, ox = x0 + t;
+    if (oy >= p.H) return;                       // (whole wave; no barrier follows)
+
+    nk_f32x16_t acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const unsigned char *wlane = wl + lane * 16;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char *bp = patch + ((wave + ky) * kLdsConvPatchCols + t + kx) * kLdsConvPixelBytes + h * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint4 bv = *reinterpret_cast<const uint4 *>(bp + c * 32);
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(wlane + (tap * 4 + c) * 1024);
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(wlane + ((9 + tap) * 4 + c) * 1024);
+            acc[0] = nk_mfma(a0, bv, acc[0]);
+            acc[1] = nk_mfma(a1, bv, acc[1]);
+        }
+    }
+    if (ox >= p.W) return;
+    // lane (t, h), register r of tile m: output channel m * 32 + 8 * (r / 4) + 4 * h + r % 4 of pixel t
+    const int cout = p.G * 64;
+    bf16_t *orow = p.out + (((int64_t)b * p.H + oy) * p.W + ox) * cout + g * 64;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = m * 32 + 8 * q + 4 * h;
+            float4 v = make_float4(acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]);
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4 *>(p.bias + g * 64 + co);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
+            if (p.act) v = make_float4(silu(v.x), silu(v.y), silu(v.z), silu(v.w));
+            Store<bf16_t>::store4(orow + co, v);
+        }
+    }
+}
+
 // fp32 [G][3][3][CiG][CoG] -> bf16 fragments [G][CoG/32][9][CiG/16][lane][8]:
 // element j of lane (n = lane % 32, h = lane / 32) = W[g][tap][c16 * 16 + h * 8 + j][mt * 32 + n]
 __global__ void __launch_bounds__(kBlock) conv3x3_pack_kernel(const float *w, int G, int CiG, int CoG, bf16_t *out)
@@ -383,6 +484,45 @@ __global__ void __launch_bounds__(kBlock) neck_combine_kernel(CombineArgs p)
     }
 }
 
+// The same for 16-bit maps whose channel count and row strides are multiples of 8 and whose element count fits 32 bits
+// (every call of the real neck): 16-byte accesses and 32-bit index arithmetic.  The generic kernel above moves 8 bytes per
+// thread behind four 64-bit divisions -- 28 us for the 2 x 16700 x 512 map of level 0, 2.7 TB/s.
+__global__ void __launch_bounds__(kBlock) neck_combine8_kernel(CombineArgs p)
+{
+    const unsigned c8n = (unsigned)p.C / 8u;
+    const unsigned n = (unsigned)p.rows * c8n;
+    const float sh = (float)p.Hs / (float)p.H, sw = (float)p.Ws / (float)p.W;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const unsigned row = e / c8n;
+        const int c = (int)(e - row * c8n) * 8;
+        const uint4 av = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(p.a) + (int64_t)row * p.lda + c);
+        float v[8] = {act_lo(av.x), act_hi(av.x), act_lo(av.y), act_hi(av.y), act_lo(av.z), act_hi(av.z), act_lo(av.w), act_hi(av.w)};
+        if (p.up) {
+            const unsigned t = row / (unsigned)p.W;
+            const int xq = (int)(row - t * (unsigned)p.W);
+            const unsigned b = t / (unsigned)p.H;
+            const int yq = (int)(t - b * (unsigned)p.H);
+            const int ys = min((int)floorf((float)yq * sh), p.Hs - 1);
+            const int xs = min((int)floorf((float)xq * sw), p.Ws - 1);
+            const uint4 uv = *reinterpret_cast<const uint4 *>(reinterpret_cast<const bf16_t *>(p.up) +
+                                                             (((int64_t)b * p.Hs + ys) * p.Ws + xs) * p.ldup + c);
+            v[0] += act_lo(uv.x); v[1] += act_hi(uv.x); v[2] += act_lo(uv.y); v[3] += act_hi(uv.y);
+            v[4] += act_lo(uv.z); v[5] += act_hi(uv.z); v[6] += act_lo(uv.w); v[7] += act_hi(uv.w);
+        }
+        if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + c), b1 = *reinterpret_cast<const float4 *>(p.bias + c + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = silu(v[i]);
+        }
+        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(p.out) + (int64_t)row * p.ldo + c) =
+            make_uint4(pack_act2(v[0], v[1]), pack_act2(v[2], v[3]), pack_act2(v[4], v[5]), pack_act2(v[6], v[7]));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention pooling of SqueezeAndExcitation (basic.py:43-54): context[c] = sum_p softmax_p(w_mask . y_p) y_p[c].
 // (conv_mask's bias is the same for every pixel and drops out of the softmax.)  One workgroup reduces kSePix pixels
@@ -398,6 +538,87 @@ static inline int se_pixels_per_block(int batch_size, int pixels)
     int pix = kSePix;
     while (pix > 16 && (int64_t)batch_size * ((pixels + pix - 1) / pix) < 512) pix >>= 1;
     return pix;
+}
+
+// The same for 16-bit maps with 256 channels (the real neck): half a wave per pixel, 8 channels (16 bytes) per lane, up to
+// 16 pixels of a wave in flight at once and 5-step reductions that serve two pixels each.  The form below (a wave per pixel,
+// 8-byte loads, four pixels per round trip, 6-step reductions) ran level 0 at 1.7 TB/s.
+__global__ void __launch_bounds__(kBlock) se_context16_kernel(const bf16_t *y_, const float *w_mask, int N, int nblk,
+                                                              float *partial, int pix_per_block)
+{
+    constexpr int C = 256;
+    __shared__ float red[8][C + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, c = (lane & 31) * 8;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const bf16_t *y = y_ + (int64_t)b * N * C;
+    const float4 wa = *reinterpret_cast<const float4 *>(w_mask + c), wb = *reinterpret_cast<const float4 *>(w_mask + c + 4);
+    float M = -INFINITY, Ssum = 0.f;
+    float V[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) V[j] = 0.f;
+    const int per_wave = pix_per_block / 4;
+    const int w0 = blk * pix_per_block + wave * per_wave;
+    const int w_end = min(N, w0 + per_wave);
+    for (int pix = w0; pix < w_end; pix += 16) {
+        uint4 v[8];
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = pix + 2 * i + half;
+            v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (q < w_end) v[i] = *reinterpret_cast<const uint4 *>(y + (int64_t)q * C + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            m[i] = act_lo(v[i].x) * wa.x + act_hi(v[i].x) * wa.y + act_lo(v[i].y) * wa.z + act_hi(v[i].y) * wa.w +
+                   act_lo(v[i].z) * wb.x + act_hi(v[i].z) * wb.y + act_lo(v[i].w) * wb.z + act_hi(v[i].w) * wb.w;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] += __shfl_xor(m[i], o, 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (pix + 2 * i + half < w_end) {  // uniform over a half wave
+                const float nM = fmaxf(M, m[i]);
+                const float sc = __expf(M - nM), e = __expf(m[i] - nM);  // first pixel: exp(-inf) = 0
+                Ssum = Ssum * sc + e;
+                V[0] = V[0] * sc + e * act_lo(v[i].x); V[1] = V[1] * sc + e * act_hi(v[i].x);
+                V[2] = V[2] * sc + e * act_lo(v[i].y); V[3] = V[3] * sc + e * act_hi(v[i].y);
+                V[4] = V[4] * sc + e * act_lo(v[i].z); V[5] = V[5] * sc + e * act_hi(v[i].z);
+                V[6] = V[6] * sc + e * act_lo(v[i].w); V[7] = V[7] * sc + e * act_hi(v[i].w);
+                M = nM;
+            }
+        }
+    }
+    const int slot = wave * 2 + half;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[slot][c + j] = V[j];
+    if ((lane & 31) == 0) {
+        red[slot][C] = M;
+        red[slot][C + 1] = Ssum;
+    }
+    __syncthreads();
+    float gM = red[0][C];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) gM = fmaxf(gM, red[i][C]);
+    float *dst = partial + ((int64_t)b * nblk + blk) * (C + 2);
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = red[i][C] == -INFINITY ? 0.f : __expf(red[i][C] - gM);
+    {
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o = fmaf(red[i][tid], f[i], o);
+        dst[tid] = o;
+    }
+    if (tid == 0) {
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o = fmaf(red[i][C + 1], f[i], o);
+        dst[C] = gM;
+        dst[C + 1] = o;
+    }
 }
 
 template <typename T>
@@ -471,23 +692,48 @@ constexpr int kGateThreads = 1024;
 __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *partial, int nblk, int C, int R,
                                                                const float *w1, const float *w2, float *gate)
 {
-    // Round 5: one workgroup per image merges up to ~260 partials of 258 floats; the first form walked them with 22
-    // barriers (three LDS tree reductions) and 64-deep single-accumulator column loops and took 10-14 us, 18 times a step.
-    // Now: wave shuffles for the two scalar reductions, the partial matrix read as float2 by 8 row groups x 128 channel
-    // pairs with the whole column walk of a thread in flight at once, and 5 barriers.
-    constexpr int kChunk = 512, kGroups = 8, kWaves = kGateThreads / 64;
+    // One workgroup per image merges up to ~260 partials of 258 floats and runs the two tiny layers.  The work is nothing;
+    // what the first two forms of this kernel paid for (10-14 us, 18 times a step) was a CHAIN of dependent global-memory
+    // phases: partial maxima -> their factors -> the weighted columns -> W1 -> W2, each a round trip to data the context
+    // launch had just written from other XCDs.  Round 5: everything a thread will ever read is requested in the first
+    // instructions -- its W1 slice, its partial's (max, sum) pair, its 34 column pairs of the first 272 partials -- and
+    // only then do the reductions start (wave shuffles + one LDS hop); W2 is requested while the context vector is being
+    // reduced.  Partials beyond 272 (other batch sizes) take further passes of the same loop.
+    constexpr int kGroups = 8, kWaves = kGateThreads / 64, kRowsPerThread = 34, kPass = kGroups * kRowsPerThread;   // 272
     __shared__ float ctx[256];
     __shared__ float hid[64];
-    __shared__ float wf[kChunk];
+    __shared__ float wf[kPass];
     __shared__ float red[kGroups][256];
     __shared__ float wred[kWaves];
+    __shared__ float sred[kWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const int pair = tid & 127, grp = tid >> 7;
+    const int r1 = tid >> 4, c1 = tid & 15;
     const int64_t ld = C + 2;
     const float *part = partial + (int64_t)b * nblk * ld;
-    // global max over the partials
-    float m = -INFINITY;
-    for (int i = tid; i < nblk; i += kGateThreads) m = fmaxf(m, part[i * ld + C]);
+    const bool has_cols = 2 * pair < C;
+
+    // ---- everything this thread reads, requested at once ----
+    float w1v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = c1 + 16 * j;
+        w1v[j] = (r1 < R && c < C) ? w1[(int64_t)r1 * C + c] : 0.f;
+    }
+    float2 ms = make_float2(-INFINITY, 0.f);                                   // (max, sum) of partial `tid`
+    if (tid < nblk) ms = *reinterpret_cast<const float2 *>(part + tid * ld + C);
+    float2 cv[kRowsPerThread];
+    const int n0 = min(kPass, nblk);
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+        const int k = grp + kGroups * j;
+        cv[j] = make_float2(0.f, 0.f);
+        if (has_cols && k < n0) cv[j] = *reinterpret_cast<const float2 *>(part + k * ld + 2 * pair);
+    }
+
+    // ---- global max ----
+    float m = ms.x;
+    for (int i = tid + kGateThreads; i < nblk; i += kGateThreads) m = fmaxf(m, part[i * ld + C]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) wred[wave] = m;
@@ -495,27 +741,40 @@ __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *part
     float gM = wred[0];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) gM = fmaxf(gM, wred[w]);
-    // each partial's factor exp(max_i - max) (kChunk at a time), the total weight, the weighted channel sums
+
+    // ---- factors exp(max_i - max) and weighted channel sums, kPass partials at a time (the first from registers) ----
     float ssum = 0.f, v0 = 0.f, v1 = 0.f;
-    for (int base = 0; base < nblk; base += kChunk) {
-        __syncthreads();                                   // wf (and, first time, wred) free again
-        if (tid < kChunk) {
+    if (tid < kPass) {
+        const float f = (tid < nblk && ms.x != -INFINITY) ? __expf(ms.x - gM) : 0.f;
+        ssum = ms.y * f;
+        wf[tid] = f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kRowsPerThread; ++j) {
+        const float f = wf[grp + kGroups * j];
+        v0 = fmaf(cv[j].x, f, v0);
+        v1 = fmaf(cv[j].y, f, v1);
+    }
+    for (int base = kPass; base < nblk; base += kPass) {
+        __syncthreads();                                                       // wf free again
+        if (tid < kPass) {
             const int i = base + tid;
             float f = 0.f;
             if (i < nblk) {
-                const float pm = part[i * ld + C];
-                if (pm != -INFINITY) {
-                    f = __expf(pm - gM);
-                    ssum = fmaf(part[i * ld + C + 1], f, ssum);
+                const float2 q = *reinterpret_cast<const float2 *>(part + i * ld + C);
+                if (q.x != -INFINITY) {
+                    f = __expf(q.x - gM);
+                    ssum = fmaf(q.y, f, ssum);
                 }
             }
             wf[tid] = f;
         }
         __syncthreads();
-        const int n = min(kChunk, nblk - base);
-        if (2 * pair < C) {
+        const int n = min(kPass, nblk - base);
+        if (has_cols) {
             const float *col = part + (int64_t)base * ld + 2 * pair;
-#pragma unroll 16
+#pragma unroll 8
             for (int k = grp; k < n; k += kGroups) {
                 const float2 c = *reinterpret_cast<const float2 *>(col + k * ld);
                 const float f = wf[k];
@@ -524,37 +783,43 @@ __global__ void __launch_bounds__(kGateThreads) se_gate_kernel(const float *part
             }
         }
     }
+    // W2's first 16 columns of my row, requested now: they arrive while the context vector is reduced
+    float w2v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w2v[j] = (tid < C && j < R) ? w2[(int64_t)tid * R + j] : 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
-    if (lane == 0) wred[wave] = ssum;
+    if (lane == 0) sred[wave] = ssum;
     red[grp][2 * pair] = v0;
     red[grp][2 * pair + 1] = v1;
     __syncthreads();
     if (tid < C) {
         float tot = 0.f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) tot += wred[w];
+        for (int w = 0; w < kWaves; ++w) tot += sred[w];
         float c = 0.f;
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) c += red[g][tid];
         ctx[tid] = c * (1.0f / tot);
     }
     __syncthreads();
-    // hidden layer: 16 lanes per row of W1
-    for (int r = tid >> 4; r < R; r += kGateThreads >> 4) {
+    // hidden layer: 16 lanes per row of W1 (64 rows at once: R <= 64)
+    {
         float h = 0.f;
-        for (int c = tid & 15; c < C; c += 16) h = fmaf(w1[(int64_t)r * C + c], ctx[c], h);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h = fmaf(w1v[j], ctx[c1 + 16 * j], h);
         h += __shfl_xor(h, 8, 16);
         h += __shfl_xor(h, 4, 16);
         h += __shfl_xor(h, 2, 16);
         h += __shfl_xor(h, 1, 16);
-        if ((tid & 15) == 0) hid[r] = fmaxf(h, 0.f);
+        if (c1 == 0 && r1 < R) hid[r1] = fmaxf(h, 0.f);
     }
     __syncthreads();
     if (tid < C) {
         float o = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < R; ++j) o = fmaf(w2[(int64_t)tid * R + j], hid[j], o);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o = fmaf(w2v[j], j < R ? hid[j] : 0.f, o);
+        for (int j = 16; j < R; ++j) o = fmaf(w2[(int64_t)tid * R + j], hid[j], o);
         gate[(int64_t)b * C + tid] = 1.0f / (1.0f + __expf(-o));
     }
 }
@@ -656,6 +921,16 @@ extern "C" int sdetr_neck_pack_conv3x3_bf16(sdetr_stream_t stream, const float *
     return check_launch("neck_pack_conv3x3");
 }
 
+// SDETR_CONV_LDS=0 keeps the neck's 64 -> 64 stride-1 blocks on the fragment-streaming kernel (benchmarks/conv_split_ab.py).
+static bool conv_lds_form()
+{
+    static const bool on = [] {
+        const char *e = getenv("SDETR_CONV_LDS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // How many waves share a 64-pixel x 64-channel tile of the MFMA convolution (1 or 3; see the kernel's header).
 // SDETR_CONV_SPLIT pins it (benchmarks/conv_split_ab.py).
 static int conv_tap_split(int64_t wave_tiles)
@@ -696,6 +971,16 @@ extern "C" int sdetr_neck_conv3x3_mfma_bf16(sdetr_stream_t stream, const void *x
     a.Wo = (width - 1) / stride + 1;
     a.P = (int64_t)batch_size * a.Ho * a.Wo;
     a.ldx = x_row_stride; a.G = groups; a.CiG = in_per_group; a.CoG = out_per_group; a.act = activation;
+    if (stride == 1 && in_per_group == 64 && out_per_group == 64 && conv_lds_form()) {
+        const int row_tiles = (height + kLdsConvRows - 1) / kLdsConvRows, col_tiles = (width + kLdsConvCols - 1) / kLdsConvCols;
+        const int64_t nt = (int64_t)batch_size * row_tiles * col_tiles;
+        if (nt > 0x7fffffffLL || groups > 65535) return fail("neck_conv3x3_mfma: grid too large");
+        static DeviceOnce lds_once;
+        allow_dynamic_lds(conv3x3_lds_kernel, lds_once, kLdsConvBytes);
+        hipLaunchKernelGGL(conv3x3_lds_kernel, dim3((unsigned)nt, (unsigned)groups), dim3(64 * kLdsConvRows), kLdsConvBytes,
+                           (hipStream_t)stream, a, row_tiles, col_tiles);
+        return check_launch("neck_conv3x3_mfma");
+    }
     const int64_t gy = (int64_t)groups * (out_per_group / 64);
     const int64_t tiles = (a.P + 63) / 64;
     const int split = conv_tap_split(tiles * gy);
@@ -734,8 +1019,15 @@ extern "C" int sdetr_neck_combine(sdetr_stream_t stream, const void *a, int a_ro
     p.rows = (int64_t)batch_size * height * width;
     p.H = height; p.W = width; p.Hs = up ? up_height : 1; p.Ws = up ? up_width : 1; p.C = channels;
     p.lda = a_row_stride; p.ldup = up_row_stride; p.ldo = out_row_stride; p.act = activation;
-    const unsigned grid = grid_for(p.rows * (channels / 4));
     hipStream_t s = (hipStream_t)stream;
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (dtype != SDETR_F32 && channels % 8 == 0 && a_row_stride % 8 == 0 && out_row_stride % 8 == 0 &&
+        (!up || up_row_stride % 8 == 0) && al16(a) && al16(out) && (!up || al16(up)) && (!bias || al16(bias)) &&
+        p.rows * (channels / 8) < 0x7fffffffLL) {
+        hipLaunchKernelGGL(neck_combine8_kernel, dim3(grid_for(p.rows * (channels / 8))), dim3(kBlock), 0, s, p);
+        return check_launch("neck_combine");
+    }
+    const unsigned grid = grid_for(p.rows * (channels / 4));
     if (dtype == SDETR_F32) hipLaunchKernelGGL((neck_combine_kernel<float>), dim3(grid), dim3(kBlock), 0, s, p);
     else hipLaunchKernelGGL((neck_combine_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, s, p);
     return check_launch("neck_combine");
@@ -776,6 +1068,9 @@ extern "C" int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, in
     if (dtype == SDETR_F32)
         hipLaunchKernelGGL((se_context_kernel<float>), dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, y,
                            mask_weight, pixels, channels, nblk, partial, pix);
+    else if (channels == 256 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask_weight) & 15) == 0)
+        hipLaunchKernelGGL(se_context16_kernel, dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s,
+                           reinterpret_cast<const bf16_t *>(y), mask_weight, pixels, nblk, partial, pix);
     else
         hipLaunchKernelGGL((se_context_kernel<bf16_t>), dim3((unsigned)nblk, (unsigned)batch_size), dim3(kBlock), 0, s, y,
                            mask_weight, pixels, channels, nblk, partial, pix);

@@ -145,30 +145,41 @@ __global__ void __launch_bounds__(kNmsThreads) grid_nms_kernel(NmsArgs p)
         }
         __syncthreads();
     }
+    // Decision rounds.  A chain of dependent tokens (a score ridge along a row: kept, dropped, kept, ...) resolves one link
+    // per look at the states; a barrier per look made a round ~0.45 us and the benchmark's proposals ~150 rounds.  The
+    // states only ever go 0 -> 1 | 2 and a decision reads decided neighbours only, so looking again WITHOUT a barrier is
+    // safe (whatever another wave has already written is final): kSweeps looks per barrier, same fixpoint.
+    constexpr int kSweeps = 4;
+    volatile uint8_t *vstate = state;
     int pending = 1;
     while (pending) {
         int mine = 0;
-        for (int r = tid; r < p.K; r += kNmsThreads) {
-            if (state[r] != 0) continue;
-            uint16_t nb[8];
-            if constexpr (CACHE) {
-                const uint4 w = reinterpret_cast<const uint4 *>(nbr)[r];
-                nb[0] = (uint16_t)w.x; nb[1] = (uint16_t)(w.x >> 16); nb[2] = (uint16_t)w.y; nb[3] = (uint16_t)(w.y >> 16);
-                nb[4] = (uint16_t)w.z; nb[5] = (uint16_t)(w.z >> 16); nb[6] = (uint16_t)w.w; nb[7] = (uint16_t)(w.w >> 16);
-            } else {
-                neighbours(r, nb);
-            }
-            bool any_kept = false, any_open = false;
+#pragma unroll 1
+        for (int sweep = 0; sweep < kSweeps; ++sweep) {
+            mine = 0;
+            for (int r = tid; r < p.K; r += kNmsThreads) {
+                if (vstate[r] != 0) continue;
+                uint16_t nb[8];
+                if constexpr (CACHE) {
+                    const uint4 w = reinterpret_cast<const uint4 *>(nbr)[r];
+                    nb[0] = (uint16_t)w.x; nb[1] = (uint16_t)(w.x >> 16); nb[2] = (uint16_t)w.y; nb[3] = (uint16_t)(w.y >> 16);
+                    nb[4] = (uint16_t)w.z; nb[5] = (uint16_t)(w.z >> 16); nb[6] = (uint16_t)w.w; nb[7] = (uint16_t)(w.w >> 16);
+                } else {
+                    neighbours(r, nb);
+                }
+                bool any_kept = false, any_open = false;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (nb[k] == kNoRank) continue;
-                const uint8_t s = state[nb[k]];
-                any_kept |= s == 1;
-                any_open |= s == 0;
+                for (int k = 0; k < 8; ++k) {
+                    if (nb[k] == kNoRank) continue;
+                    const uint8_t s = vstate[nb[k]];
+                    any_kept |= s == 1;
+                    any_open |= s == 0;
+                }
+                if (any_kept) vstate[r] = 2;
+                else if (!any_open) vstate[r] = 1;
+                else mine = 1;
             }
-            if (any_kept) state[r] = 2;
-            else if (!any_open) state[r] = 1;
-            else mine = 1;
+            if (!__any(mine)) break;                         // (my wave has nothing left to decide this round)
         }
         pending = __syncthreads_or(mine);
     }

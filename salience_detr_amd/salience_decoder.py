@@ -23,7 +23,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_query_sine_embed, fused_ffn,
-                         fused_ffn_applies, fused_layer_norm, token_linear, token_linear_applies)
+                         fused_ffn_applies, fused_layer_norm)
 from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
@@ -129,17 +129,9 @@ class SalienceTransformerDecoderLayer(nn.Module):
         B, n, E = query.shape
         H = mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
-        if token_linear_applies(query, w) and query.dim() == 3 and query_pos.shape == query.shape:
-            # q | k with the position add in the projection's prologue (one launch instead of add + GEMM); the row slices
-            # are kept as objects so that the packed operands cached on them survive between steps
-            tag = (w.data_ptr(), w._version, b.data_ptr(), b._version)
-            hit = self.__dict__.get("_qk_slices")
-            if hit is None or hit[0] != tag:
-                hit = (tag, w.detach()[:2 * E], b.detach()[:2 * E])
-                self.__dict__["_qk_slices"] = hit
-            qk2 = token_linear(query, hit[1], hit[2], x_add=query_pos.contiguous())
-        else:
-            qk2 = F.linear(query + query_pos, w[:2 * E], b[:2 * E])
+        # (the token-resident projection kernel was tried here in round 5 -- position add in its prologue, one launch for
+        #  add + GEMM: its run time is flat in the row count, 18 us at 2 x 900 rows against 5 + 8 us for these two launches)
+        qk2 = F.linear(query + query_pos, w[:2 * E], b[:2 * E])
         v2 = F.linear(query, w[2 * E:], b[2 * E:])
         if attn_mask is None and attention_heads_applies(qk2[..., :E], qk2[..., E:], v2, H):
             # own flash kernel on the strided projection slices; the heads come out concatenated

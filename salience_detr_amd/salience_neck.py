@@ -219,7 +219,8 @@ class RepVGGPluXNetwork(nn.Module):
             a_first = torch.matmul(first, p["first"].t())  # at the coarse resolution
             both = FO.neck_combine(a_second, h, w, up=a_first, up_hw=first_hw, bias=p["bias"], activation=True)
         else:
-            a_second = torch.baddbmm(a_second, first, p["first"].t().expand(first.shape[0], -1, -1))
+            # (in place: the out-of-place form copies its first operand into the result before the GEMM)
+            a_second = a_second.baddbmm_(first, p["first"].t().expand(first.shape[0], -1, -1))
             both = FO.neck_combine(a_second, h, w, bias=p["bias"], activation=True)
         x, branch = both[:, :, :C], both[:, :, C:]
         last = len(p["blocks"]) - 1
