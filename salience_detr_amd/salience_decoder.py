@@ -199,11 +199,17 @@ class SalienceTransformerDecoder(nn.Module):
             nn.init.constant_(head.layers[-1].weight, 0.0)
             nn.init.constant_(head.layers[-1].bias, 0.0)
 
+    def project_values(self, value, key_padding_mask=None):
+        """The layers' cross-attention value maps ``[num_layers, B, M, Nv, D]`` (one projection: they all sample the same,
+        never-updated memory).  ``forward(..., value_maps=...)`` takes them; a caller can so run the projection beside
+        other work that only needs the memory (the proposal stage, salience_transformer.py)."""
+        return batched_value_maps([l.cross_attn for l in self.layers], value, key_padding_mask)
+
     def forward(self, query, reference_points, value, spatial_shapes, level_start_index, valid_ratios,
-                key_padding_mask=None, attn_mask=None):
+                key_padding_mask=None, attn_mask=None, value_maps=None):
         if query.is_cuda and not _needs_grad(self, query, value, reference_points):
             return self._forward_native(query, reference_points, value, spatial_shapes, level_start_index, valid_ratios,
-                                        key_padding_mask, attn_mask)
+                                        key_padding_mask, attn_mask, value_maps)
         ratio = torch.cat([valid_ratios, valid_ratios], -1)[:, None]          # [B,1,L,4]
         half = self.embed_dim // 2
         classes, coords = [], []
@@ -223,11 +229,12 @@ class SalienceTransformerDecoder(nn.Module):
         return torch.stack(classes), torch.stack(coords)
 
     def _forward_native(self, query, reference_points, value, spatial_shapes, level_start_index, valid_ratios,
-                        key_padding_mask, attn_mask):
+                        key_padding_mask, attn_mask, value_maps=None):
         """No-grad path: one value projection for all layers (they sample the same memory), one launch each for the
         reference scaling + sine embedding and for the two box refinements of a layer (output boxes from the normed
         query, next reference from the raw query: one stacked ``bbox_head`` pass)."""
-        value_maps = batched_value_maps([l.cross_attn for l in self.layers], value, key_padding_mask)
+        if value_maps is None:
+            value_maps = self.project_values(value, key_padding_mask)
         ref = reference_points.float()
         classes, coords = [], []
         for i, layer in enumerate(self.layers):
