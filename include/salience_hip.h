@@ -623,6 +623,20 @@ int sdetr_decoder_query_sine_embed(sdetr_stream_t stream, const float *reference
 int sdetr_box_refine(sdetr_stream_t stream, const void *delta, int delta_dtype, int64_t delta_row_stride,
                      const float *reference_points, int64_t num_boxes, int groups, float eps, float *out);
 
+/* sdetr_mlp_rows_bf16 (round 5): the decoder's small MLPs (models/bricks/basic.py:6-26: Linear + ReLU chains) in one
+ * launch -- ref_point_head 512 -> 256 -> 256 (models/bricks/salience_transformer.py:643-644) with weight3 = NULL and
+ * out_features = 256, bbox_head / encoder_bbox_head 256 -> 256 -> 256 -> out_features <= 32 (:206, :659-668).  Rows
+ * [0, rows_first) are read from x, [rows_first, rows) from x_second (the normed and the raw queries of a decoder layer
+ * share bbox_head: no stacked copy); rows are contiguous, in_features elements each.  Weights as packed by
+ * sdetr_linear_pack_bf16 (section (8): 256 input features per block; a 512-feature first layer is two blocks back to back,
+ * columns 0-255 then 256-511, each sdetr_linear_packed_bytes(256) long), biases fp32 zero-padded to the packed tiles
+ * (256 floats; the last layer's at least 32).  ReLU after every layer but the last; out [rows, out_features] in the
+ * activation type, rows out_row_stride elements apart. */
+int sdetr_mlp_rows_bf16(sdetr_stream_t stream, const void *x, const void *x_second, int64_t rows_first, int64_t rows,
+                        int in_features, const void *packed_weight1, const float *bias1, const void *packed_weight2,
+                        const float *bias2, const void *packed_weight3, const float *bias3, int out_features, void *out,
+                        int64_t out_row_stride);
+
 /* ---- (11) two-stage proposal selection after the encoder (row N1) ---------------------------------------------------
  * models/bricks/salience_transformer.py:194-212, 249-295; models/bricks/base_transformer.py:74-112.
  * level_shapes_host: HOST array [num_levels][2] of (h, w); the levels are laid out back to back in the token dimension.

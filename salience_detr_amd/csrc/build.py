@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["abi.hip", "msda_forward.hip", "msda_backward.hip", "msda_backward_tiled.hip", "msda_resident.hip", "topk.hip", "rows.hip", "plumbing.hip", "norm.hip", "salience_head.hip", "encoder_rows.hip", "ffn.hip", "token_linear.hip", "decoder_ops.hip", "proposals.hip", "salience_criterion.hip", "attention.hip", "topk_attention.hip", "gemm_x3.hip", "fused_head_value.hip", "neck.hip", "layer_norm_train.hip", "sampling_prep.hip", "attention_train.hip"]
+SOURCES = ["abi.hip", "msda_forward.hip", "msda_backward.hip", "msda_backward_tiled.hip", "msda_resident.hip", "topk.hip", "rows.hip", "plumbing.hip", "norm.hip", "salience_head.hip", "encoder_rows.hip", "ffn.hip", "token_linear.hip", "decoder_ops.hip", "proposals.hip", "salience_criterion.hip", "attention.hip", "topk_attention.hip", "gemm_x3.hip", "fused_head_value.hip", "neck.hip", "layer_norm_train.hip", "sampling_prep.hip", "attention_train.hip", "mlp_rows.hip"]
 LIB = os.path.join(os.path.dirname(HERE), "libsalience_hip.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

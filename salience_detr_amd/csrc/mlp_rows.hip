@@ -1,0 +1,199 @@
+// The decoder's small MLPs in one launch each (models/bricks/basic.py:6-26 -- Linear + ReLU chains):
+//   ref_point_head  512 -> 256 -> 256          (models/bricks/salience_transformer.py:643-644, once per decoder layer)
+//   bbox_head[i]    256 -> 256 -> 256 -> 4     (:659-668, on the normed AND the raw queries of a layer: two row sources)
+//   encoder_bbox_head (the same shape, :206)
+// At 2 x 900 queries these are 1 800-3 600 rows: every library GEMM of the chain is a launch of its own whose run time is
+// its latency (6-9 us each, plus a 5 us torch.stack for the two row sources) -- 40 us per decoder layer for 0.8 GFLOP.
+//
+// One workgroup of 8 waves owns 32 rows; wave w owns output features 32 w .. 32 w + 31 of every hidden layer.
+//   * The FIRST instructions request everything the workgroup will ever read from memory: a wave's A-operand fragments
+//     of layer 1 AND layer 2 (AND 3), its biases, and its share of the 32 input rows -> one round trip.  The weights are
+//     the lane-ordered 1 KB fragments of sdetr_linear_pack_bf16 (include/salience_hip.h (8)): a workgroup pulls ALL of
+//     them through its CU's L1 (256-384 KB), and fragment-shaped loads from the row-major matrices -- 32 rows x 32 bytes
+//     per instruction -- made that 12-15 us per launch (first form of this kernel); whole 1 KB pieces are 64 bytes/clk.
+//   * Y^T = W X^T with v_mfma_f32_32x32x16 (lane = row, registers = features); the B operand comes from LDS: the input
+//     rows, then each hidden layer's ReLU output, row-major with a 16-byte pad per row (a ds_read_b128 group = 16 rows,
+//     4 words apart mod 64: conflict-free).
+//   * The last layer of a 3-layer chain (<= 32 outputs) is one wave's work.
+#include "common.h"
+
+namespace sdetr {
+
+typedef float ml_f32x16_t __attribute__((ext_vector_type(16)));
+
+struct MlpArgs {
+    const bf16_t *xa, *xb;     // rows [0, rows_a) from xa, [rows_a, rows) from xb (row-major, K1 elements each)
+    int rows_a, rows;
+    const char *w1;            // packed [K1 / 256][8 tiles][16 k-steps][64 lanes][16 bytes]
+    const char *w2;            // packed [8 tiles][16][64][16]
+    const char *w3;            // packed, tile 0 used (rows past n3 are zero), or NULL (two layers)
+    const float *b1, *b2, *b3; // fp32, zero-padded to the packed tiles
+    int n3;
+    bf16_t *out;               // [rows, 256] (two layers) or [rows, n3]
+    int64_t ldo;
+};
+
+__device__ __forceinline__ int ml_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+constexpr int kMlpRows = 32, kMlpHidden = 256, kMlpHPitch = kMlpHidden * 2 + 16;
+
+template <int K1, int NL>
+__global__ void __launch_bounds__(512) mlp_rows_kernel(MlpArgs p)
+{
+    constexpr int kXPitch = K1 * 2 + 16;
+    extern __shared__ __align__(16) unsigned char mlp_lds[];
+    unsigned char *xs = mlp_lds;                              // [32][kXPitch]   input rows
+    unsigned char *h1 = xs + kMlpRows * kXPitch;              // [32][kMlpHPitch] layer-1 output
+    unsigned char *h2 = h1 + kMlpRows * kMlpHPitch;           // [32][kMlpHPitch] layer-2 output (three layers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * kMlpRows;
+
+    // ---- every global load of the kernel, requested before anything waits ----
+    constexpr int KS1 = K1 / 16;
+    uint4 a1[KS1], a2[16], a3[NL == 3 ? 16 : 1];
+    constexpr int kHalfBytes = 8 * 16 * 1024;                           // one packed 256 x 256 block
+#pragma unroll
+    for (int j = 0; j < KS1; ++j)
+        a1[j] = *reinterpret_cast<const uint4 *>(p.w1 + (j / 16) * kHalfBytes + ((wave * 16 + (j % 16)) * 64 + lane) * 16);
+    constexpr int kPieces = kMlpRows * K1 / 8, kPer = kPieces / 512;      // 16-byte pieces of the input rows: 2 or 4 per thread
+    uint4 xv[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int e = i * 512 + tid;
+        const int r = min(row0 + e / (K1 / 8), p.rows - 1), pc = e % (K1 / 8);
+        const bf16_t *src = r < p.rows_a ? p.xa + (int64_t)r * K1 : p.xb + (int64_t)(r - p.rows_a) * K1;
+        xv[i] = *reinterpret_cast<const uint4 *>(src + pc * 8);
+    }
+    float bias1[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.b1 + wave * 32 + 8 * g + 4 * h);
+        bias1[4 * g] = bv.x; bias1[4 * g + 1] = bv.y; bias1[4 * g + 2] = bv.z; bias1[4 * g + 3] = bv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a2[j] = *reinterpret_cast<const uint4 *>(p.w2 + ((wave * 16 + j) * 64 + lane) * 16);
+    if constexpr (NL == 3) {
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a3[j] = *reinterpret_cast<const uint4 *>(p.w3 + (j * 64 + lane) * 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int e = i * 512 + tid;
+        *reinterpret_cast<uint4 *>(xs + (e / (K1 / 8)) * kXPitch + (e % (K1 / 8)) * 16) = xv[i];
+    }
+    __syncthreads();
+
+    // ---- layer 1 ----
+    ml_f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias1[r];
+    {
+        const unsigned char *bp = xs + t * kXPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < KS1; ++j) acc = mfma_act_32x32x16(a1[j], *reinterpret_cast<const uint4 *>(bp + j * 32), acc);
+    }
+    // second layer's bias: requested now (layer 1's fragments are dead), back by the time the barrier is passed
+    float bias2[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.b2 + wave * 32 + 8 * g + 4 * h);
+        bias2[4 * g] = bv.x; bias2[4 * g + 1] = bv.y; bias2[4 * g + 2] = bv.z; bias2[4 * g + 3] = bv.w;
+    }
+    // lane (t, h), register r: feature 32 w + ml_row(r, h) of row t; four consecutive features per group of registers
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<uint2 *>(h1 + t * kMlpHPitch + (wave * 32 + 8 * g + 4 * h) * 2) =
+            make_uint2(pack_act2(fmaxf(acc[4 * g], 0.f), fmaxf(acc[4 * g + 1], 0.f)),
+                       pack_act2(fmaxf(acc[4 * g + 2], 0.f), fmaxf(acc[4 * g + 3], 0.f)));
+    __syncthreads();
+
+    // ---- layer 2 ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias2[r];
+    {
+        const unsigned char *bp = h1 + t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = mfma_act_32x32x16(a2[j], *reinterpret_cast<const uint4 *>(bp + j * 32), acc);
+    }
+    const int row = row0 + t;
+    if constexpr (NL == 2) {
+        if (row < p.rows) {
+            bf16_t *orow = p.out + (int64_t)row * p.ldo + wave * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2 *>(orow + 8 * g) =
+                    make_uint2(pack_act2(acc[4 * g], acc[4 * g + 1]), pack_act2(acc[4 * g + 2], acc[4 * g + 3]));
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2 *>(h2 + t * kMlpHPitch + (wave * 32 + 8 * g + 4 * h) * 2) =
+                make_uint2(pack_act2(fmaxf(acc[4 * g], 0.f), fmaxf(acc[4 * g + 1], 0.f)),
+                           pack_act2(fmaxf(acc[4 * g + 2], 0.f), fmaxf(acc[4 * g + 3], 0.f)));
+        __syncthreads();
+        if (wave != 0) return;
+        // ---- layer 3: n3 <= 32 outputs, one tile ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char *bp = h2 + t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = mfma_act_32x32x16(a3[j], *reinterpret_cast<const uint4 *>(bp + j * 32), acc);
+        if (row < p.rows) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = ml_row(r, h);
+                if (f < p.n3) {
+                    const float v = acc[r] + p.b3[f];
+                    p.out[(int64_t)row * p.ldo + f] = (bf16_t)(pack_act2(v, 0.f) & 0xffffu);
+                }
+            }
+        }
+    }
+}
+
+template <int K1, int NL>
+static int mlp_launch(hipStream_t s, const MlpArgs &a)
+{
+    const size_t lds = (size_t)kMlpRows * (K1 * 2 + 16) + (size_t)(NL == 3 ? 2 : 1) * kMlpRows * kMlpHPitch;
+    static DeviceOnce once;
+    allow_dynamic_lds(mlp_rows_kernel<K1, NL>, once, 96 * 1024);
+    hipLaunchKernelGGL((mlp_rows_kernel<K1, NL>), dim3((unsigned)((a.rows + kMlpRows - 1) / kMlpRows)), dim3(512), lds, s, a);
+    return check_launch("mlp_rows");
+}
+
+}  // namespace sdetr
+
+using namespace sdetr;
+
+extern "C" int sdetr_mlp_rows_bf16(sdetr_stream_t stream, const void *x, const void *x_second, int64_t rows_first,
+                                   int64_t rows, int in_features, const void *packed_weight1, const float *bias1,
+                                   const void *packed_weight2, const float *bias2, const void *packed_weight3,
+                                   const float *bias3, int out_features, void *out, int64_t out_row_stride)
+{
+    if (rows < 0 || rows_first < 0 || rows_first > rows || rows > 0x7fffffffLL) return fail("mlp_rows: bad row counts");
+    if (in_features != 256 && in_features != 512) return fail("mlp_rows: 256 or 512 input features (got %d)", in_features);
+    const bool three = packed_weight3 != nullptr;
+    if (three ? (out_features < 1 || out_features > 32) : out_features != kMlpHidden)
+        return fail("mlp_rows: a two-layer chain ends in 256 features, a three-layer chain in 1..32 (got %d)", out_features);
+    if (three && in_features != 256) return fail("mlp_rows: the three-layer chain takes 256 input features");
+    if (out_row_stride < out_features || (!three && (out_row_stride % 4))) return fail("mlp_rows: bad output row stride");
+    if (rows == 0) return 0;
+    if (!x || !packed_weight1 || !bias1 || !packed_weight2 || !bias2 || !out || (three && !bias3) ||
+        (rows_first < rows && !x_second))
+        return fail("mlp_rows: null pointer");
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(x) || (x_second && !al16(x_second)) || !al16(packed_weight1) || !al16(packed_weight2) ||
+        (three && !al16(packed_weight3)) || !al16(bias1) || !al16(bias2) || (!three && (reinterpret_cast<uintptr_t>(out) & 7)))
+        return fail("mlp_rows: rows, packed weights and hidden biases must be 16-byte aligned, a 256-wide output 8-byte aligned");
+    MlpArgs a{};
+    a.xa = (const bf16_t *)x; a.xb = (const bf16_t *)x_second; a.rows_a = (int)rows_first; a.rows = (int)rows;
+    a.w1 = (const char *)packed_weight1; a.b1 = bias1; a.w2 = (const char *)packed_weight2; a.b2 = bias2;
+    a.w3 = (const char *)packed_weight3; a.b3 = bias3; a.n3 = out_features; a.out = (bf16_t *)out;
+    a.ldo = out_row_stride;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (three) return mlp_launch<256, 3>(s, a);
+    return in_features == 512 ? mlp_launch<512, 2>(s, a) : mlp_launch<256, 2>(s, a);
+}

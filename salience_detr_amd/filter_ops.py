@@ -1243,6 +1243,73 @@ def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num
     return ref_in, embed
 
 
+def mlp_rows_applies(x: Tensor, layers) -> bool:
+    """``mlp_rows`` takes this Linear + ReLU chain on these rows: 16-bit HIP rows, two layers 256|512 -> 256 -> 256 or
+    three layers 256 -> 256 -> 256 -> n <= 32, parameters in the rows' type."""
+    layers = list(layers)
+    if not (x.is_cuda and _hip.is_act16(x.dtype) and len(layers) in (2, 3) and not torch.is_grad_enabled()):
+        return False
+    dims = [(l.in_features, l.out_features) for l in layers]
+    if x.shape[-1] != dims[0][0] or dims[0][1] != 256 or dims[1] != (256, 256):
+        return False
+    if len(layers) == 2 and dims[0][0] not in (256, 512):
+        return False
+    if len(layers) == 3 and (dims[0][0] != 256 or dims[2][0] != 256 or not 1 <= dims[2][1] <= 32):
+        return False
+    return all(l.bias is not None and l.weight.dtype == x.dtype and l.weight.stride(1) == 1 and l.weight.is_cuda for l in layers)
+
+
+def _packed_linear_512(weight: Tensor, bias: Tensor):
+    """(two packed 256-column blocks back to back, fp32 bias) of a ``[256, 512]`` Linear for ``mlp_rows``; cached on the
+    weight tensor like ``_packed_linear_bf16``."""
+    tag = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, str(weight.device))
+    hit = weight.__dict__.get("_sdetr_tl512")
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    lib = _hip.lib(weight.dtype)
+    w = weight.detach()
+    half = lib.sdetr_linear_packed_bytes(256)
+    with torch.no_grad(), torch.cuda.device(w.device):
+        packed = torch.empty(2 * half, dtype=torch.uint8, device=w.device)
+        for i in range(2):
+            code = lib.sdetr_linear_pack_bf16(_hip.stream_ptr(), w.data_ptr() + i * 256 * w.element_size(), w.stride(0), 256, 256,
+                                              packed.data_ptr() + i * half)
+            _hip.check(code, "linear_pack")
+        b = bias.detach().float().contiguous()
+    weight.__dict__["_sdetr_tl512"] = (tag, packed, b)
+    return packed, b
+
+
+def mlp_rows(x: Tensor, layers, x_second: Optional[Tensor] = None) -> Tensor:
+    """``layers[-1](relu(... relu(layers[0](rows))))`` in one launch (include/salience_hip.h, ``sdetr_mlp_rows_bf16``;
+    models/bricks/basic.py:6-26).  With ``x_second`` (same shape as ``x``) the rows are ``stack((x, x_second))`` and the
+    result has that leading dimension of 2 -- without the stacked copy."""
+    layers = list(layers)
+    if not mlp_rows_applies(x, layers):
+        raise RuntimeError("mlp_rows: 16-bit HIP rows and a 256|512 -> 256 -> 256 (-> n <= 32) Linear chain expected; "
+                           "no CPU fallback")
+    K = x.shape[-1]
+    xa = x if x.is_contiguous() else x.contiguous()
+    rows_a = xa.numel() // K
+    rows, xb = rows_a, None
+    if x_second is not None:
+        if x_second.shape != x.shape or x_second.dtype != x.dtype or x_second.device != x.device:
+            raise RuntimeError("mlp_rows: x_second must match x")
+        xb = x_second if x_second.is_contiguous() else x_second.contiguous()
+        rows = 2 * rows_a
+    n_out = layers[-1].out_features
+    lead = tuple(x.shape[:-1])
+    out = torch.empty(((2,) + lead if xb is not None else lead) + (n_out,), dtype=x.dtype, device=x.device)
+    ops = [(_packed_linear_512 if l.in_features == 512 else _packed_linear_bf16)(l.weight, l.bias) for l in layers]
+    p3, b3 = ops[2] if len(layers) == 3 else (None, None)
+    with torch.cuda.device(x.device):
+        code = _hip.lib(x.dtype).sdetr_mlp_rows_bf16(
+            _hip.stream_ptr(), xa.data_ptr(), _hip.ptr(xb), rows_a, rows, K, ops[0][0].data_ptr(), ops[0][1].data_ptr(),
+            ops[1][0].data_ptr(), ops[1][1].data_ptr(), _hip.ptr(p3), _hip.ptr(b3), n_out, out.data_ptr(), n_out)
+    _hip.check(code, "mlp_rows")
+    return out
+
+
 def box_refine(delta: Tensor, reference_points: Tensor, eps: float = 1e-3) -> Tensor:
     """``sigmoid(delta + inverse_sigmoid(reference_points))`` (salience_transformer.py:659-660, 666-668) in one launch:
     ``delta`` ``[..., 4]`` (fp32 | bf16) whose leading dims are ``reference_points``' ``[B,Nq]`` or ``[G,B,Nq]``

@@ -548,7 +548,7 @@ def invalidate_caches(module: nn.Module) -> None:
                 m.__dict__[attr] = None
         m.__dict__.pop("_batched_value_proj", None)
         for p in m.parameters(recurse=False):
-            for key in ("_sdetr_packed", "_sdetr_ffn", "_sdetr_tl", "_sdetr_f32"):
+            for key in ("_sdetr_packed", "_sdetr_ffn", "_sdetr_tl", "_sdetr_tl512", "_sdetr_f32"):
                 p.__dict__.pop(key, None)
 
 

@@ -23,7 +23,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_query_sine_embed, fused_ffn,
-                         fused_ffn_applies, fused_layer_norm)
+                         fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies)
 from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
@@ -59,7 +59,13 @@ class MLP(nn.Module):
             nn.init.xavier_uniform_(layer.weight)
             nn.init.constant_(layer.bias, 0.0)
 
-    def forward(self, x):
+    def forward(self, x, x_second=None):
+        """``x_second`` (no-grad HIP path only): a second set of rows through the same layers, result stacked in front --
+        ``forward(stack((x, x_second)))`` without the stacked copy."""
+        if mlp_rows_applies(x, self.layers):
+            return mlp_rows(x, self.layers, x_second)          # the whole chain in one launch (csrc/mlp_rows.hip)
+        if x_second is not None:
+            x = torch.stack((x, x_second))
         fused = x.is_cuda and not torch.is_grad_enabled()
         for i, layer in enumerate(self.layers):
             if i + 1 < self.num_layers:
@@ -248,7 +254,7 @@ class SalienceTransformerDecoder(nn.Module):
             if i + 1 == self.num_layers:
                 coords.append(box_refine(self.bbox_head[i](normed), ref))
                 break
-            both = box_refine(self.bbox_head[i](torch.stack((normed, query))), ref)      # [2,B,Nq,4]
+            both = box_refine(self.bbox_head[i](normed, query), ref)                      # [2,B,Nq,4]
             coords.append(both[0])
             ref = both[1]
         return torch.stack(classes), torch.stack(coords)

@@ -1,0 +1,82 @@
+"""GPU: the decoder's small MLPs in one launch (csrc/mlp_rows.hip; models/bricks/basic.py:6-26) against the same chain in
+fp32 on the 16-bit parameters and rows, with the library-GEMM chain in the rows' type as the error scale.
+"""
+import pytest
+import torch
+
+from salience_detr_amd import filter_ops as F
+from salience_detr_amd.salience_decoder import MLP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mlp(in_dim, out_dim, layers, dtype, seed):
+    torch.manual_seed(seed)
+    m = MLP(in_dim, 256, out_dim, layers)
+    with torch.no_grad():
+        for l in m.layers:
+            l.bias.normal_(0, 0.2)
+        m.layers[-1].weight.normal_(0, 0.05)        # (bbox heads are zero-initialised: give the last layer something to do)
+    return m.to(DEV).to(dtype).eval()
+
+
+def _fp32_chain(m, x):
+    y = x.float()
+    for i, l in enumerate(m.layers):
+        y = torch.nn.functional.linear(y, l.weight.float(), l.bias.float())
+        if i + 1 < len(m.layers):
+            y = torch.relu(y).to(x.dtype).float()     # the hidden activations are stored in the rows' type
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("in_dim,out_dim,layers", [(512, 256, 2), (256, 256, 2), (256, 4, 3), (256, 32, 3), (256, 1, 3)])
+@pytest.mark.parametrize("rows", [(1, 1), (1, 31), (3, 11), (2, 900)])
+def test_mlp_rows_matches_the_fp32_chain(dtype, in_dim, out_dim, layers, rows):
+    m = _mlp(in_dim, out_dim, layers, dtype, seed=in_dim + out_dim)
+    g = torch.Generator().manual_seed(rows[1])
+    x = (torch.randn(*rows, in_dim, generator=g) * 1.5).to(dtype).to(DEV)
+    assert F.mlp_rows_applies(x, m.layers) is False             # autograd on: the differentiable chain
+    with torch.no_grad():
+        assert F.mlp_rows_applies(x, m.layers)
+        got = m(x)
+        lib = x
+        for i, l in enumerate(m.layers):
+            lib = l(lib)
+            if i + 1 < len(m.layers):
+                lib = torch.relu(lib)
+    want = _fp32_chain(m, x)
+    assert got.shape == want.shape and got.dtype == dtype
+    err, base = (got.float() - want).abs().max().item(), (lib.float() - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= max(2.0 * base, 2.0 ** -7 * scale), (err, base, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_two_row_sources_equal_the_stacked_rows(dtype):
+    """bbox_head on the normed and the raw queries of a decoder layer: ``forward(x, x_second)`` is bit for bit
+    ``forward(stack((x, x_second)))`` -- also when a 32-row tile holds rows of both sources (2 x 900 = 56 tiles + 8 rows)."""
+    m = _mlp(256, 4, 3, dtype, seed=9)
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(2, 900, 256, generator=g).to(dtype).to(DEV)
+    b = torch.randn(2, 900, 256, generator=g).to(dtype).to(DEV)
+    with torch.no_grad():
+        both = m(a, b)
+        stacked = m(torch.stack((a, b)))
+        alone = m(b)
+    assert both.shape == (2, 2, 900, 4)
+    assert torch.equal(both, stacked) and torch.equal(both[1], alone)
+
+
+def test_mlp_rows_refuses_what_it_does_not_take():
+    m = _mlp(256, 4, 3, torch.bfloat16, seed=1)
+    x = torch.randn(4, 256)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            F.mlp_rows(x.to(torch.bfloat16), m.layers)                       # CPU rows
+        with pytest.raises(RuntimeError):
+            F.mlp_rows(x.to(DEV), m.layers)                                  # fp32 rows
+        wide = _mlp(256, 64, 3, torch.bfloat16, seed=2)
+        assert not F.mlp_rows_applies(x.to(torch.bfloat16).to(DEV), wide.layers)   # 64 outputs: the library chain
+        assert wide(x.to(torch.bfloat16).to(DEV)).shape == (4, 64)
