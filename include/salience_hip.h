@@ -637,6 +637,17 @@ int sdetr_mlp_rows_bf16(sdetr_stream_t stream, const void *x, const void *x_seco
                         const float *bias2, const void *packed_weight3, const float *bias3, int out_features, void *out,
                         int64_t out_row_stride);
 
+/* sdetr_rows_linear_bf16 (round 5): out[r, f] = (x[r] + (f < pos_features ? pos[r] : 0)) . W[f] + b[f] for a few
+ * thousand rows of 256 features in one launch: the decoder layer's self-attention in-projection (nn.MultiheadAttention
+ * with q = k = query + query_pos, v = query, models/bricks/salience_transformer.py:565-570: pos_features = 512 of 768)
+ * and the cross-attention's sampling_offsets | attention_weights projection of query + query_pos
+ * (models/bricks/ms_deform_attn.py:322-349: all 384) -- each an elementwise add and one or two library GEMMs before.
+ * x / pos [rows, 256] contiguous (x + pos is formed in fp32 and rounded once, like the elementwise add); packed_weight /
+ * bias_padded as for sdetr_token_linear_bf16 (section (8)); out_features <= 768, pos_features a multiple of 32. */
+int sdetr_rows_linear_bf16(sdetr_stream_t stream, const void *x, const void *pos, int64_t rows, int pos_features,
+                           const void *packed_weight, const float *bias_padded, int out_features, void *out,
+                           int64_t out_row_stride);
+
 /* ---- (11) two-stage proposal selection after the encoder (row N1) ---------------------------------------------------
  * models/bricks/salience_transformer.py:194-212, 249-295; models/bricks/base_transformer.py:74-112.
  * level_shapes_host: HOST array [num_levels][2] of (h, w); the levels are laid out back to back in the token dimension.

@@ -107,6 +107,7 @@ SIGNATURES = {
     "sdetr_decoder_query_sine_embed": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_float, _p, _i, _p]),
     "sdetr_box_refine": (_i, [_p, _p, _i, _i64, _p, _i64, _i, ctypes.c_float, _p]),
     "sdetr_mlp_rows_bf16": (_i, [_p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i64]),
+    "sdetr_rows_linear_bf16": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _p, _i64]),
     "sdetr_encoder_output_proposals": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "sdetr_grid_nms_topk": (_i, [_p, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sdetr_proposal_refine": (_i, [_p, _p, _i, _p, _p, _i64, _i, _i, _i, _p]),

@@ -154,6 +154,104 @@ __global__ void __launch_bounds__(512) mlp_rows_kernel(MlpArgs p)
     }
 }
 
+// ---- one Linear on rows that may carry a position addend for the first `pos_features` outputs ----------------------
+// out[r, f] = (x[r] + (f < pos_features ? pos[r] : 0)) . W[f] + b[f]:  the decoder layer's self-attention in-projection
+// (q | k from query + query_pos, v from query: nn.MultiheadAttention with q = k = x + pos, v = x,
+// models/bricks/salience_transformer.py:565-570) as ONE launch instead of an elementwise add and two library GEMMs, and the
+// cross-attention's offset | weight projection of query + query_pos (models/bricks/ms_deform_attn.py:322-349) likewise.
+// Same scheme as above: 32 rows per workgroup, 8 waves, wave w owns the feature tiles w, w + 8, w + 16 (<= 768 features),
+// every packed weight fragment requested up front, both B operands (x and x + pos, summed in fp32 and rounded once like
+// the elementwise add) from LDS.
+struct RowsLinearArgs {
+    const bf16_t *x, *pos;     // [rows, 256] each; pos may be NULL
+    int rows, n, pos_features; // n output features, the first pos_features (a multiple of 32) see x + pos
+    const char *w;             // packed tiles [ceil(n / 128) * 4][16][64][16 bytes]
+    const float *b;            // fp32, zero-padded to the packed tiles
+    bf16_t *out;
+    int64_t ldo;
+};
+
+template <int TILES>   // feature tiles per wave: 1, 2 or 3
+__global__ void __launch_bounds__(512) rows_linear_kernel(RowsLinearArgs p)
+{
+    extern __shared__ __align__(16) unsigned char mlp_lds[];
+    unsigned char *xs = mlp_lds;                              // [32][kMlpHPitch]  x
+    unsigned char *xp = xs + kMlpRows * kMlpHPitch;           // [32][kMlpHPitch]  x + pos
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * kMlpRows;
+    const int ntiles = (p.n + 31) / 32;
+
+    uint4 a[TILES][16];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+        const int tile = wave + 8 * i;
+        if (tile < ntiles) {                                  // (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[i][j] = *reinterpret_cast<const uint4 *>(p.w + ((tile * 16 + j) * 64 + lane) * 16);
+        }
+    }
+    // the input rows: 1024 16-byte pieces, two per thread (and the same of pos)
+    uint4 xv[2], pv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = i * 512 + tid;
+        const int r = min(row0 + (e >> 5), p.rows - 1), pc = e & 31;
+        xv[i] = *reinterpret_cast<const uint4 *>(p.x + (int64_t)r * kMlpHidden + pc * 8);
+        pv[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.pos) pv[i] = *reinterpret_cast<const uint4 *>(p.pos + (int64_t)r * kMlpHidden + pc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = i * 512 + tid;
+        const int off = (e >> 5) * kMlpHPitch + (e & 31) * 16;
+        *reinterpret_cast<uint4 *>(xs + off) = xv[i];
+        const uint32_t xw[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, pw[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w};
+        uint32_t sw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sw[q] = pack_act2(act_lo(xw[q]) + act_lo(pw[q]), act_hi(xw[q]) + act_hi(pw[q]));
+        *reinterpret_cast<uint4 *>(xp + off) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+    }
+    __syncthreads();
+
+    const int row = row0 + t;
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+        const int tile = wave + 8 * i;
+        if (tile >= ntiles) break;                            // (wave-uniform)
+        // (the tile's bias is requested here and added behind the products: three tiles' worth held from the start of the
+        //  kernel pushed the three-tile form over the register file)
+        float4 bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const float4 *>(p.b + tile * 32 + 8 * g + 4 * h);
+        ml_f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char *bp = (tile * 32 < p.pos_features ? xp : xs) + t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = mfma_act_32x32x16(a[i][j], *reinterpret_cast<const uint4 *>(bp + j * 32), acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc[4 * g] += bv[g].x; acc[4 * g + 1] += bv[g].y; acc[4 * g + 2] += bv[g].z; acc[4 * g + 3] += bv[g].w;
+        }
+        if (row < p.rows) {
+            bf16_t *orow = p.out + (int64_t)row * p.ldo + tile * 32 + 4 * h;
+            if (tile * 32 + 32 <= p.n && (p.ldo & 3) == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2 *>(orow + 8 * g) =
+                        make_uint2(pack_act2(acc[4 * g], acc[4 * g + 1]), pack_act2(acc[4 * g + 2], acc[4 * g + 3]));
+            } else {                                          // a ragged last tile or an odd row stride: element stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = tile * 32 + ml_row(r, h);
+                    if (f < p.n) p.out[(int64_t)row * p.ldo + f] = (bf16_t)(pack_act2(acc[r], 0.f) & 0xffffu);
+                }
+            }
+        }
+    }
+}
+
 template <int K1, int NL>
 static int mlp_launch(hipStream_t s, const MlpArgs &a)
 {
@@ -196,4 +294,32 @@ extern "C" int sdetr_mlp_rows_bf16(sdetr_stream_t stream, const void *x, const v
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (three) return mlp_launch<256, 3>(s, a);
     return in_features == 512 ? mlp_launch<512, 2>(s, a) : mlp_launch<256, 2>(s, a);
+}
+
+extern "C" int sdetr_rows_linear_bf16(sdetr_stream_t stream, const void *x, const void *pos, int64_t rows,
+                                      int pos_features, const void *packed_weight, const float *bias_padded,
+                                      int out_features, void *out, int64_t out_row_stride)
+{
+    if (rows < 0 || rows > 0x7fffffffLL) return fail("rows_linear: bad row count");
+    if (out_features < 1 || out_features > 768) return fail("rows_linear: 1..768 output features (got %d)", out_features);
+    if (pos_features < 0 || pos_features > out_features + 31 || (pos_features % 32))
+        return fail("rows_linear: pos_features must be a multiple of 32 within the output (got %d)", pos_features);
+    if (out_row_stride < out_features) return fail("rows_linear: bad output row stride");
+    if (rows == 0) return 0;
+    if (!x || !packed_weight || !bias_padded || !out || (pos_features > 0 && !pos)) return fail("rows_linear: null pointer");
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(x) || (pos && !al16(pos)) || !al16(packed_weight) || !al16(bias_padded) || (reinterpret_cast<uintptr_t>(out) & 7))
+        return fail("rows_linear: rows, packed weight and bias must be 16-byte aligned, the output 8-byte aligned");
+    RowsLinearArgs a{};
+    a.x = (const bf16_t *)x; a.pos = pos_features > 0 ? (const bf16_t *)pos : nullptr; a.rows = (int)rows; a.n = out_features;
+    a.pos_features = pos_features; a.w = (const char *)packed_weight; a.b = bias_padded; a.out = (bf16_t *)out;
+    a.ldo = out_row_stride;
+    const int ntiles = (out_features + 31) / 32, per_wave = (ntiles + 7) / 8;
+    const dim3 grid((unsigned)((rows + kMlpRows - 1) / kMlpRows));
+    const size_t lds = 2 * (size_t)kMlpRows * kMlpHPitch;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (per_wave == 1) hipLaunchKernelGGL(rows_linear_kernel<1>, grid, dim3(512), lds, s, a);
+    else if (per_wave == 2) hipLaunchKernelGGL(rows_linear_kernel<2>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(rows_linear_kernel<3>, grid, dim3(512), lds, s, a);
+    return check_launch("rows_linear");
 }

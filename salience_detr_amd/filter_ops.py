@@ -1243,6 +1243,35 @@ def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num
     return ref_in, embed
 
 
+def rows_linear_applies(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> bool:
+    """``rows_linear`` takes this Linear on these rows: 16-bit HIP rows of 256 features, at most 768 outputs, no autograd."""
+    return (x.is_cuda and _hip.is_act16(x.dtype) and x.shape[-1] == 256 and weight.dim() == 2 and weight.shape[1] == 256
+            and weight.dtype == x.dtype and weight.stride(1) == 1 and 1 <= weight.shape[0] <= 768 and bias is not None
+            and not torch.is_grad_enabled())
+
+
+def rows_linear(x: Tensor, weight: Tensor, bias: Tensor, pos: Optional[Tensor] = None, pos_features: int = 0) -> Tensor:
+    """``F.linear(x, weight, bias)`` where the first ``pos_features`` outputs see ``x + pos`` instead of ``x`` -- one launch
+    for a few thousand rows (include/salience_hip.h, ``sdetr_rows_linear_bf16``)."""
+    if not rows_linear_applies(x, weight, bias):
+        raise RuntimeError("rows_linear: 16-bit HIP rows of 256 features and a Linear with at most 768 outputs expected; "
+                           "no CPU fallback")
+    N = weight.shape[0]
+    xa = x if x.is_contiguous() else x.contiguous()
+    pa = None
+    if pos_features:
+        if pos is None or pos.shape != x.shape or pos.dtype != x.dtype or pos.device != x.device:
+            raise RuntimeError("rows_linear: pos must match x")
+        pa = pos if pos.is_contiguous() else pos.contiguous()
+    packed, b = _packed_linear_bf16(weight, bias)
+    out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib(x.dtype).sdetr_rows_linear_bf16(_hip.stream_ptr(), xa.data_ptr(), _hip.ptr(pa), xa.numel() // 256,
+                                                        int(pos_features), packed.data_ptr(), b.data_ptr(), N, out.data_ptr(), N)
+    _hip.check(code, "rows_linear")
+    return out
+
+
 def mlp_rows_applies(x: Tensor, layers) -> bool:
     """``mlp_rows`` takes this Linear + ReLU chain on these rows: 16-bit HIP rows, two layers 256|512 -> 256 -> 256 or
     three layers 256 -> 256 -> 256 -> n <= 32, parameters in the rows' type."""

@@ -759,7 +759,7 @@ class MultiScaleDeformableAttention(nn.Module):
         caller that fuses ``output_proj`` with what follows it.  ``head_major_projection``: the offset | weight
         projection ``[B,M,Nq,48]`` if another launch already produced it (``head_major_projection_applies`` says when
         this method would take that form)."""
-        from .filter_ops import token_linear, token_linear_applies
+        from .filter_ops import rows_linear, rows_linear_applies, token_linear, token_linear_applies
         w, b = self._fused_query_projection()
         # (the token-resident kernel's run time is flat in the token count, ~17 us; below ~12 000 tokens the library GEMM
         # behind an elementwise add is 2-3 us faster, but only the resident kernel writes the per-head slabs that save
@@ -794,6 +794,9 @@ class MultiScaleDeformableAttention(nn.Module):
             return F.linear(out, self.output_proj.weight, self.output_proj.bias)
         if big and token_linear_applies(query, w):
             proj = token_linear(query, w, b, x_add=query_pos)
+        elif query_pos is not None and rows_linear_applies(query, w, b) and query_pos.shape == query.shape:
+            # a few thousand rows (the decoder's 900 queries per image): add + projection in one launch
+            proj = rows_linear(query, w, b, pos=query_pos, pos_features=w.shape[0])
         else:
             proj = F.linear(query if query_pos is None else query + query_pos, w, b)
         out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,

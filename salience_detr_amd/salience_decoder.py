@@ -23,7 +23,8 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_query_sine_embed, fused_ffn,
-                         fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies)
+                         fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies, rows_linear,
+                         rows_linear_applies)
 from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
@@ -135,10 +136,14 @@ class SalienceTransformerDecoderLayer(nn.Module):
         B, n, E = query.shape
         H = mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
-        # (the token-resident projection kernel was tried here in round 5 -- position add in its prologue, one launch for
-        #  add + GEMM: its run time is flat in the row count, 18 us at 2 x 900 rows against 5 + 8 us for these two launches)
-        qk2 = F.linear(query + query_pos, w[:2 * E], b[:2 * E])
-        v2 = F.linear(query, w[2 * E:], b[2 * E:])
+        if rows_linear_applies(query, w, b) and query_pos.shape == query.shape:
+            # q | k | v in one launch: the position add lives in the kernel (csrc/mlp_rows.hip, round 5).  (The
+            # token-resident projection kernel of the encoder was tried first: flat 18 us at 2 x 900 rows.)
+            qkv = rows_linear(query, w, b, pos=query_pos, pos_features=2 * E)
+            qk2, v2 = qkv[..., :2 * E], qkv[..., 2 * E:]
+        else:
+            qk2 = F.linear(query + query_pos, w[:2 * E], b[:2 * E])
+            v2 = F.linear(query, w[2 * E:], b[2 * E:])
         if attn_mask is None and attention_heads_applies(qk2[..., :E], qk2[..., E:], v2, H):
             # own flash kernel on the strided projection slices; the heads come out concatenated
             return F.linear(attention_heads(qk2[..., :E], qk2[..., E:], v2, H), mha.out_proj.weight, mha.out_proj.bias)

@@ -80,3 +80,43 @@ def test_mlp_rows_refuses_what_it_does_not_take():
         wide = _mlp(256, 64, 3, torch.bfloat16, seed=2)
         assert not F.mlp_rows_applies(x.to(torch.bfloat16).to(DEV), wide.layers)   # 64 outputs: the library chain
         assert wide(x.to(torch.bfloat16).to(DEV)).shape == (4, 64)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,pos_features", [(768, 512), (384, 384), (91, 0), (256, 32), (33, 64)])
+@pytest.mark.parametrize("rows", [(1, 1), (1, 33), (2, 900)])
+def test_rows_linear_matches_the_fp32_products(dtype, n, pos_features, rows):
+    """One Linear whose first ``pos_features`` outputs see ``x + pos`` (the decoder's q | k | v in-projection and the
+    cross-attention's offset | weight projection) against fp32 products on the rounded operands -- ``x + pos`` rounded to
+    the rows' type first, as the elementwise add of the reference does."""
+    torch.manual_seed(n + rows[1])
+    lin = torch.nn.Linear(256, n).to(DEV).to(dtype)
+    with torch.no_grad():
+        lin.bias.normal_(0, 0.3)
+    x = (torch.randn(*rows, 256) * 1.5).to(dtype).to(DEV)
+    pos = torch.randn(*rows, 256).to(dtype).to(DEV)
+    assert not F.rows_linear_applies(x, lin.weight, lin.bias)           # autograd on
+    with torch.no_grad():
+        assert F.rows_linear_applies(x, lin.weight, lin.bias)
+        got = F.rows_linear(x, lin.weight, lin.bias, pos=pos if pos_features else None, pos_features=pos_features)
+        lib = torch.cat((lin(x + pos)[..., :pos_features], lin(x)[..., pos_features:]), -1)
+    w, b = lin.weight.float(), lin.bias.float()
+    xs = (x + pos).float()
+    want = torch.cat(((xs @ w.t() + b)[..., :pos_features], (x.float() @ w.t() + b)[..., pos_features:]), -1)
+    assert got.shape == want.shape == tuple(rows) + (n,) and got.dtype == dtype
+    err, base = (got.float() - want).abs().max().item(), (lib.float() - want).abs().max().item()
+    assert err <= max(2.0 * base, 2.0 ** -7 * want.abs().max().item()), (err, base)
+
+
+def test_rows_linear_refuses_what_it_does_not_take():
+    lin = torch.nn.Linear(256, 1024).to(DEV).to(torch.bfloat16)
+    x = torch.randn(4, 256, dtype=torch.bfloat16, device=DEV)
+    with torch.no_grad():
+        assert not F.rows_linear_applies(x, lin.weight, lin.bias)         # 1024 outputs
+        with pytest.raises(RuntimeError):
+            F.rows_linear(x, lin.weight, lin.bias)
+        ok = torch.nn.Linear(256, 64).to(DEV).to(torch.bfloat16)
+        with pytest.raises(RuntimeError):
+            F.rows_linear(x, ok.weight, ok.bias, pos=x[:2], pos_features=64)   # pos of another shape
+        with pytest.raises(RuntimeError):
+            F.rows_linear(x.cpu(), ok.weight, ok.bias)
