@@ -24,13 +24,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--plain", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="decoder value projection on a second stream (A/B; slower)")
+    ap.add_argument("--no-decoder-head", action="store_true", help="A/B: the layer head as norm + GEMM + mlp_rows + box_refine")
     ap.add_argument("--library-linears", action="store_true",
                     help="A/B: the decoder's MLPs and in-projections as library GEMMs (no mlp_rows / rows_linear launches)")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
-    if args.library_linears:
+    if args.no_decoder_head or args.library_linears:
         from salience_detr_amd import filter_ops, salience_decoder
         no = lambda *a, **k: False
+        filter_ops.decoder_head_applies = salience_decoder.decoder_head_applies = no
+    if args.library_linears:
         filter_ops.rows_linear_applies = filter_ops.mlp_rows_applies = no
         salience_decoder.rows_linear_applies = salience_decoder.mlp_rows_applies = no
     sizes = [(800, 1333), (800, 1066)]
@@ -65,7 +68,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.steps
         best = ms if best is None else min(best, ms)
-    print(json.dumps({"workload": "BASELINE configs[4] at N=1", "dtype": args.dtype, "overlap": tr.overlap_value_projection, "library_linears": args.library_linears, "ms_per_step": round(best, 4),
+    print(json.dumps({"workload": "BASELINE configs[4] at N=1", "dtype": args.dtype, "overlap": tr.overlap_value_projection, "library_linears": args.library_linears, "decoder_head": not (args.no_decoder_head or args.library_linears), "ms_per_step": round(best, 4),
                       "images_per_s": round(2e3 / best, 1), "graph_nodes": bench.CAPTURE_INFO.get("graph_nodes")}))
 
 

@@ -648,6 +648,21 @@ int sdetr_rows_linear_bf16(sdetr_stream_t stream, const void *x, const void *pos
                            const void *packed_weight, const float *bias_padded, int out_features, void *out,
                            int64_t out_row_stride);
 
+/* sdetr_decoder_head_bf16 (round 5): a decoder layer's output head, models/bricks/salience_transformer.py:655-668, in
+ * one launch:  normed = LayerNorm(query);  logits = class_head(normed);
+ * boxes[0] = sigmoid(bbox_head(normed) + inverse_sigmoid(reference_points, sigmoid_eps))  (the layer's output boxes) and,
+ * with two_sources, boxes[1] = the same from the raw query rows (the next layer's reference points, :666-668).
+ * query [rows, 256] contiguous; norm_weight / norm_bias fp32 [256]; class head and the three bbox layers as packed by
+ * sdetr_linear_pack_bf16 with fp32 zero-padded biases (num_classes <= 224); reference_points fp32 [rows, 4];
+ * logits [rows, num_classes] in the activation type; boxes fp32 [two_sources ? 2 : 1][rows][4].  The chain's 4 outputs
+ * are rounded to the activation type before the refinement, as the module-by-module path stores them. */
+int sdetr_decoder_head_bf16(sdetr_stream_t stream, const void *query, int64_t rows, const float *norm_weight,
+                            const float *norm_bias, float norm_eps, const void *packed_class_weight,
+                            const float *class_bias_padded, int num_classes, const void *packed_weight1,
+                            const float *bias1, const void *packed_weight2, const float *bias2,
+                            const void *packed_weight3, const float *bias3, const float *reference_points,
+                            float sigmoid_eps, int two_sources, void *logits, int64_t logits_row_stride, float *boxes);
+
 /* ---- (11) two-stage proposal selection after the encoder (row N1) ---------------------------------------------------
  * models/bricks/salience_transformer.py:194-212, 249-295; models/bricks/base_transformer.py:74-112.
  * level_shapes_host: HOST array [num_levels][2] of (h, w); the levels are laid out back to back in the token dimension.

@@ -252,6 +252,208 @@ __global__ void __launch_bounds__(512) rows_linear_kernel(RowsLinearArgs p)
     }
 }
 
+// ---- the decoder layer's output head in one launch ------------------------------------------------------------------
+// models/bricks/salience_transformer.py:655-668 for one layer i:
+//     normed  = decoder.norm(query)
+//     classes = class_head[i](normed)
+//     coords  = sigmoid(bbox_head[i](normed) + inverse_sigmoid(reference_points))
+//     next reference_points = sigmoid(bbox_head[i](query) + inverse_sigmoid(reference_points))      (not for the last layer)
+// = LayerNorm + library GEMM + the three-layer chain on two row sources + the refinement: four launches after the chain
+// became one (mlp_rows above), now one.  32 query rows per workgroup; the LayerNorm is the row-tile fill itself (32 lanes
+// per row, two-pass statistics by shuffles -- the arithmetic of csrc/norm.hip); both bbox chains run side by side (one A
+// fragment feeds two products); wave 0 finishes the boxes, waves 1.. the class tiles on the normed rows.
+struct HeadArgs {
+    const bf16_t *q;
+    int rows;
+    const float *gamma, *beta;
+    float eps;
+    const char *wc;            // packed class head (tiles of 32 classes), fp32 bias padded
+    const float *bc;
+    int ncls;
+    const char *w1, *w2, *w3;  // packed bbox chain (as for mlp_rows)
+    const float *b1, *b2, *b3;
+    const float *ref;          // [rows, 4] boxes to refine (cx, cy, w, h in [0, 1])
+    float sig_eps;
+    bf16_t *logits;            // [rows, ncls], rows ld_logits elements apart
+    int64_t ld_logits;
+    float *boxes;              // [TWO ? 2 : 1][rows][4]: from the normed rows, then from the raw rows
+};
+
+__device__ __forceinline__ float head_inverse_sigmoid(float x, float eps)
+{
+    x = fminf(fmaxf(x, 0.f), 1.f);
+    return logf(fmaxf(x, eps) / fmaxf(1.f - x, eps));
+}
+
+template <bool TWO>
+__global__ void __launch_bounds__(512) decoder_head_kernel(HeadArgs p)
+{
+    extern __shared__ __align__(16) unsigned char mlp_lds[];
+    constexpr int kTile = kMlpRows * kMlpHPitch;
+    unsigned char *xn = mlp_lds, *xq = xn + kTile;            // normed rows, raw rows
+    unsigned char *h1n = xq + kTile, *h1r = h1n + kTile, *h2n = h1r + kTile, *h2r = h2n + kTile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * kMlpRows;
+    const int cls_tiles = (p.ncls + 31) / 32;
+
+    // ---- every global load, requested before anything waits ----
+    uint4 a1[16], a2[16], a3[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a1[j] = *reinterpret_cast<const uint4 *>(p.w1 + ((wave * 16 + j) * 64 + lane) * 16);
+    uint4 xv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = i * 512 + tid;
+        const int r = min(row0 + (e >> 5), p.rows - 1);
+        xv[i] = *reinterpret_cast<const uint4 *>(p.q + (int64_t)r * kMlpHidden + (e & 31) * 8);
+    }
+    float gm[8], bt[8];
+    {
+        const int pc = tid & 31;
+        const float4 g0 = *reinterpret_cast<const float4 *>(p.gamma + pc * 8), g1 = *reinterpret_cast<const float4 *>(p.gamma + pc * 8 + 4);
+        const float4 e0 = *reinterpret_cast<const float4 *>(p.beta + pc * 8), e1 = *reinterpret_cast<const float4 *>(p.beta + pc * 8 + 4);
+        gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+        bt[0] = e0.x; bt[1] = e0.y; bt[2] = e0.z; bt[3] = e0.w; bt[4] = e1.x; bt[5] = e1.y; bt[6] = e1.z; bt[7] = e1.w;
+    }
+    float bias1[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.b1 + wave * 32 + 8 * g + 4 * h);
+        bias1[4 * g] = bv.x; bias1[4 * g + 1] = bv.y; bias1[4 * g + 2] = bv.z; bias1[4 * g + 3] = bv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a2[j] = *reinterpret_cast<const uint4 *>(p.w2 + ((wave * 16 + j) * 64 + lane) * 16);
+    const bool cls_wave = wave >= 1 && wave <= cls_tiles;            // (wave-uniform)
+
+    // ---- the row tiles: raw rows as they are, normed rows through the LayerNorm (32 lanes per row) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = i * 512 + tid;
+        const int off = (e >> 5) * kMlpHPitch + (e & 31) * 16;
+        *reinterpret_cast<uint4 *>(xq + off) = xv[i];
+        float v[8] = {act_lo(xv[i].x), act_hi(xv[i].x), act_lo(xv[i].y), act_hi(xv[i].y),
+                      act_lo(xv[i].z), act_hi(xv[i].z), act_lo(xv[i].w), act_hi(xv[i].w)};
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += v[k];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 32);
+        const float mean = sum / (float)kMlpHidden;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sq += (v[k] - mean) * (v[k] - mean);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 32);
+        const float rstd = rsqrtf(sq / (float)kMlpHidden + p.eps);
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = (v[k] - mean) * rstd * gm[k] + bt[k];
+        *reinterpret_cast<uint4 *>(xn + off) =
+            make_uint4(pack_act2(y[0], y[1]), pack_act2(y[2], y[3]), pack_act2(y[4], y[5]), pack_act2(y[6], y[7]));
+    }
+    __syncthreads();
+
+    // ---- bbox chain, layer 1 (both row sources) ----
+    ml_f32x16_t an, ar;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { an[r] = bias1[r]; ar[r] = bias1[r]; }
+    {
+        const int lo = t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            an = mfma_act_32x32x16(a1[j], *reinterpret_cast<const uint4 *>(xn + lo + j * 32), an);
+            if (TWO) ar = mfma_act_32x32x16(a1[j], *reinterpret_cast<const uint4 *>(xq + lo + j * 32), ar);
+        }
+    }
+    // the last stage's fragments (wave 0: bbox layer 3; waves 1..: a class tile) take layer 1's registers: requested now,
+    // back long before layer 2 is through (all three sets at once spilled 65-80 registers)
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a3[j] = *reinterpret_cast<const uint4 *>(p.w3 + (j * 64 + lane) * 16);
+    } else if (cls_wave) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a3[j] = *reinterpret_cast<const uint4 *>(p.wc + (((wave - 1) * 16 + j) * 64 + lane) * 16);
+    }
+    float bias2[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.b2 + wave * 32 + 8 * g + 4 * h);
+        bias2[4 * g] = bv.x; bias2[4 * g + 1] = bv.y; bias2[4 * g + 2] = bv.z; bias2[4 * g + 3] = bv.w;
+    }
+    auto put_relu = [&](unsigned char *dst, const ml_f32x16_t &acc) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2 *>(dst + t * kMlpHPitch + (wave * 32 + 8 * g + 4 * h) * 2) =
+                make_uint2(pack_act2(fmaxf(acc[4 * g], 0.f), fmaxf(acc[4 * g + 1], 0.f)),
+                           pack_act2(fmaxf(acc[4 * g + 2], 0.f), fmaxf(acc[4 * g + 3], 0.f)));
+    };
+    put_relu(h1n, an);
+    if (TWO) put_relu(h1r, ar);
+    __syncthreads();
+
+    // ---- layer 2 ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { an[r] = bias2[r]; ar[r] = bias2[r]; }
+    {
+        const int lo = t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            an = mfma_act_32x32x16(a2[j], *reinterpret_cast<const uint4 *>(h1n + lo + j * 32), an);
+            if (TWO) ar = mfma_act_32x32x16(a2[j], *reinterpret_cast<const uint4 *>(h1r + lo + j * 32), ar);
+        }
+    }
+    put_relu(h2n, an);
+    if (TWO) put_relu(h2r, ar);
+    __syncthreads();
+
+    const int row = row0 + t;
+    if (wave == 0) {
+        // ---- layer 3 (4 outputs) and the refinement: lane (t, h = 0) holds the four deltas of row t in registers 0..3 ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { an[r] = 0.f; ar[r] = 0.f; }
+        const int lo = t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            an = mfma_act_32x32x16(a3[j], *reinterpret_cast<const uint4 *>(h2n + lo + j * 32), an);
+            if (TWO) ar = mfma_act_32x32x16(a3[j], *reinterpret_cast<const uint4 *>(h2r + lo + j * 32), ar);
+        }
+        if (h == 0 && row < p.rows) {
+            const float4 rf = *reinterpret_cast<const float4 *>(p.ref + (int64_t)row * 4);
+            const float4 b3 = *reinterpret_cast<const float4 *>(p.b3);
+            const float inv[4] = {head_inverse_sigmoid(rf.x, p.sig_eps), head_inverse_sigmoid(rf.y, p.sig_eps),
+                                  head_inverse_sigmoid(rf.z, p.sig_eps), head_inverse_sigmoid(rf.w, p.sig_eps)};
+            const float bb[4] = {b3.x, b3.y, b3.z, b3.w};
+            float o[4];
+            // (the chain's output exists in the activation type in the reference's graph: round it before the refinement)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = 1.f / (1.f + expf(-(act_lo(pack_act2(an[k] + bb[k], 0.f)) + inv[k])));
+            reinterpret_cast<float4 *>(p.boxes)[row] = make_float4(o[0], o[1], o[2], o[3]);
+            if (TWO) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = 1.f / (1.f + expf(-(act_lo(pack_act2(ar[k] + bb[k], 0.f)) + inv[k])));
+                reinterpret_cast<float4 *>(p.boxes)[(int64_t)p.rows + row] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    } else if (cls_wave) {
+        // ---- class logits of the normed rows, tile wave - 1 ----
+        const int tile = wave - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) an[r] = 0.f;
+        const int lo = t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) an = mfma_act_32x32x16(a3[j], *reinterpret_cast<const uint4 *>(xn + lo + j * 32), an);
+        if (row < p.rows) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = tile * 32 + ml_row(r, h);
+                if (f < p.ncls)
+                    p.logits[(int64_t)row * p.ld_logits + f] = (bf16_t)(pack_act2(an[r] + p.bc[f], 0.f) & 0xffffu);
+            }
+        }
+    }
+}
+
 template <int K1, int NL>
 static int mlp_launch(hipStream_t s, const MlpArgs &a)
 {
@@ -322,4 +524,44 @@ extern "C" int sdetr_rows_linear_bf16(sdetr_stream_t stream, const void *x, cons
     else if (per_wave == 2) hipLaunchKernelGGL(rows_linear_kernel<2>, grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL(rows_linear_kernel<3>, grid, dim3(512), lds, s, a);
     return check_launch("rows_linear");
+}
+
+extern "C" int sdetr_decoder_head_bf16(sdetr_stream_t stream, const void *query, int64_t rows, const float *norm_weight,
+                                       const float *norm_bias, float norm_eps, const void *packed_class_weight,
+                                       const float *class_bias_padded, int num_classes, const void *packed_weight1,
+                                       const float *bias1, const void *packed_weight2, const float *bias2,
+                                       const void *packed_weight3, const float *bias3, const float *reference_points,
+                                       float sigmoid_eps, int two_sources, void *logits, int64_t logits_row_stride,
+                                       float *boxes)
+{
+    if (rows < 0 || rows > 0x7fffffffLL) return fail("decoder_head: bad row count");
+    if (num_classes < 1 || num_classes > 224) return fail("decoder_head: 1..224 classes (got %d)", num_classes);
+    if (logits_row_stride < num_classes) return fail("decoder_head: bad logits row stride");
+    if (rows == 0) return 0;
+    if (!query || !norm_weight || !norm_bias || !packed_class_weight || !class_bias_padded || !packed_weight1 || !bias1 ||
+        !packed_weight2 || !bias2 || !packed_weight3 || !bias3 || !reference_points || !logits || !boxes)
+        return fail("decoder_head: null pointer");
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(query) || !al16(norm_weight) || !al16(norm_bias) || !al16(packed_class_weight) || !al16(packed_weight1) ||
+        !al16(packed_weight2) || !al16(packed_weight3) || !al16(bias1) || !al16(bias2) || !al16(bias3) ||
+        !al16(reference_points) || !al16(boxes))
+        return fail("decoder_head: operands must be 16-byte aligned");
+    HeadArgs a{};
+    a.q = (const bf16_t *)query; a.rows = (int)rows; a.gamma = norm_weight; a.beta = norm_bias; a.eps = norm_eps;
+    a.wc = (const char *)packed_class_weight; a.bc = class_bias_padded; a.ncls = num_classes;
+    a.w1 = (const char *)packed_weight1; a.w2 = (const char *)packed_weight2; a.w3 = (const char *)packed_weight3;
+    a.b1 = bias1; a.b2 = bias2; a.b3 = bias3; a.ref = reference_points; a.sig_eps = sigmoid_eps;
+    a.logits = (bf16_t *)logits; a.ld_logits = logits_row_stride; a.boxes = boxes;
+    const dim3 grid((unsigned)((rows + kMlpRows - 1) / kMlpRows));
+    const size_t lds = 6 * (size_t)kMlpRows * kMlpHPitch;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static DeviceOnce once_a, once_b;
+    if (two_sources) {
+        allow_dynamic_lds(decoder_head_kernel<true>, once_a, 128 * 1024);
+        hipLaunchKernelGGL(decoder_head_kernel<true>, grid, dim3(512), lds, s, a);
+    } else {
+        allow_dynamic_lds(decoder_head_kernel<false>, once_b, 128 * 1024);
+        hipLaunchKernelGGL(decoder_head_kernel<false>, grid, dim3(512), lds, s, a);
+    }
+    return check_launch("decoder_head");
 }

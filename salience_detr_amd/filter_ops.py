@@ -1272,6 +1272,63 @@ def rows_linear(x: Tensor, weight: Tensor, bias: Tensor, pos: Optional[Tensor] =
     return out
 
 
+def _norm_f32(norm):
+    """fp32 copies of a LayerNorm's weight and bias, cached on the weight tensor (refreshed when the parameters change)."""
+    tag = (norm.weight.data_ptr(), norm.weight._version, norm.bias.data_ptr(), norm.bias._version)
+    hit = norm.weight.__dict__.get("_sdetr_f32")
+    if hit is None or hit[0] != tag:
+        hit = (tag, norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous())
+        norm.weight.__dict__["_sdetr_f32"] = hit
+    return hit[1], hit[2]
+
+
+def decoder_head_applies(query: Tensor, norm, class_head, bbox_layers) -> bool:
+    """``decoder_head`` takes this layer head: 16-bit HIP queries of 256 features, an affine LayerNorm(256), a Linear class
+    head with at most 224 classes and a 256 -> 256 -> 256 -> 4 bbox chain, parameters in the queries' type, no autograd."""
+    layers = list(bbox_layers)
+    if not (query.is_cuda and _hip.is_act16(query.dtype) and query.shape[-1] == 256 and not torch.is_grad_enabled()):
+        return False
+    if not (isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (256,) and norm.weight is not None
+            and norm.bias is not None):
+        return False
+    if not (class_head.in_features == 256 and 1 <= class_head.out_features <= 224 and class_head.bias is not None
+            and class_head.weight.dtype == query.dtype and class_head.weight.stride(1) == 1):
+        return False
+    return (len(layers) == 3 and [(l.in_features, l.out_features) for l in layers] == [(256, 256), (256, 256), (256, 4)]
+            and all(l.bias is not None and l.weight.dtype == query.dtype and l.weight.stride(1) == 1 for l in layers))
+
+
+def decoder_head(query: Tensor, norm, class_head, bbox_layers, reference_points: Tensor, two_sources: bool,
+                 eps: float = 1e-3):
+    """A decoder layer's output head in one launch (include/salience_hip.h, ``sdetr_decoder_head_bf16``;
+    models/bricks/salience_transformer.py:655-668): ``(logits [.., num_classes], boxes [1 | 2, .., 4] fp32)`` -- boxes[0]
+    refined from the normed queries (the layer's output), boxes[1] from the raw queries (the next reference points)."""
+    layers = list(bbox_layers)
+    if not decoder_head_applies(query, norm, class_head, layers):
+        raise RuntimeError("decoder_head: 16-bit HIP queries, LayerNorm(256), a Linear class head and a 256-256-256-4 bbox "
+                           "chain expected; no CPU fallback")
+    q = query if query.is_contiguous() else query.contiguous()
+    rows = q.numel() // 256
+    ref = reference_points.detach().float().contiguous()
+    if ref.numel() != rows * 4:
+        raise RuntimeError("decoder_head: reference_points must hold one (cx, cy, w, h) box per query row")
+    _hip.require_device("decoder_head", reference_points=ref)
+    g, b = _norm_f32(norm)
+    pc, bc = _packed_linear_bf16(class_head.weight, class_head.bias)
+    ops = [_packed_linear_bf16(l.weight, l.bias) for l in layers]
+    lead = tuple(query.shape[:-1])
+    ncls = class_head.out_features
+    logits = torch.empty(lead + (ncls,), dtype=query.dtype, device=query.device)
+    boxes = torch.empty(((2 if two_sources else 1),) + lead + (4,), dtype=torch.float32, device=query.device)
+    with torch.cuda.device(query.device):
+        code = _hip.lib(query.dtype).sdetr_decoder_head_bf16(
+            _hip.stream_ptr(), q.data_ptr(), rows, g.data_ptr(), b.data_ptr(), float(norm.eps), pc.data_ptr(), bc.data_ptr(),
+            ncls, ops[0][0].data_ptr(), ops[0][1].data_ptr(), ops[1][0].data_ptr(), ops[1][1].data_ptr(), ops[2][0].data_ptr(),
+            ops[2][1].data_ptr(), ref.data_ptr(), float(eps), 1 if two_sources else 0, logits.data_ptr(), ncls, boxes.data_ptr())
+    _hip.check(code, "decoder_head")
+    return logits, boxes
+
+
 def mlp_rows_applies(x: Tensor, layers) -> bool:
     """``mlp_rows`` takes this Linear + ReLU chain on these rows: 16-bit HIP rows, two layers 256|512 -> 256 -> 256 or
     three layers 256 -> 256 -> 256 -> n <= 32, parameters in the rows' type."""

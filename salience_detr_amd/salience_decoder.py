@@ -22,7 +22,8 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
-from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_query_sine_embed, fused_ffn,
+from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_head, decoder_head_applies,
+                         decoder_query_sine_embed, fused_ffn,
                          fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies, rows_linear,
                          rows_linear_applies)
 from .layer_norm_train import add_layer_norm
@@ -254,6 +255,16 @@ class SalienceTransformerDecoder(nn.Module):
             query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                           key_padding_mask=key_padding_mask, self_attn_mask=attn_mask, value_hm=value_maps[i])
+            last = i + 1 == self.num_layers
+            if decoder_head_applies(query, self.norm, self.class_head[i], self.bbox_head[i].layers):
+                # norm + class head + both bbox chains + refinement: one launch (csrc/mlp_rows.hip, round 5)
+                logits, boxes = decoder_head(query, self.norm, self.class_head[i], self.bbox_head[i].layers, ref, not last)
+                classes.append(logits)
+                coords.append(boxes[0])
+                if last:
+                    break
+                ref = boxes[1]
+                continue
             normed = fused_layer_norm(query, self.norm)
             classes.append(self.class_head[i](normed))
             if i + 1 == self.num_layers:

@@ -120,3 +120,43 @@ def test_rows_linear_refuses_what_it_does_not_take():
             F.rows_linear(x, ok.weight, ok.bias, pos=x[:2], pos_features=64)   # pos of another shape
         with pytest.raises(RuntimeError):
             F.rows_linear(x.cpu(), ok.weight, ok.bias)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,ncls", [((2, 900), 91), ((1, 33), 91), ((1, 1), 7), ((2, 50), 224)])
+def test_decoder_head_matches_the_module_by_module_path(dtype, rows, ncls):
+    """LayerNorm + class head + both bbox chains + refinement in one launch against (a) the same stages launched one by
+    one and (b) the stages in fp32 on the 16-bit parameters."""
+    from salience_detr_amd.salience_decoder import inverse_sigmoid
+    torch.manual_seed(ncls + rows[1])
+    norm = torch.nn.LayerNorm(256).to(DEV)
+    cls = torch.nn.Linear(256, ncls).to(DEV)
+    with torch.no_grad():
+        norm.weight.normal_(1.0, 0.2)
+        norm.bias.normal_(0, 0.2)
+        cls.bias.normal_(0, 0.5)
+    norm, cls = norm.to(dtype), cls.to(dtype)
+    bbox = _mlp(256, 4, 3, dtype, seed=5)
+    q = (torch.randn(*rows, 256) * 2.0 + 0.3).to(dtype).to(DEV)
+    ref = torch.rand(*rows, 4).to(DEV)
+    ref[..., 0, 0] = 0.0          # a coordinate on the clamp
+    ref[..., 0, 1] = 1.0
+    with torch.no_grad():
+        assert F.decoder_head_applies(q, norm, cls, bbox.layers)
+        logits, boxes = F.decoder_head(q, norm, cls, bbox.layers, ref, True)
+        only, boxes1 = F.decoder_head(q, norm, cls, bbox.layers, ref, False)
+        normed = F.fused_layer_norm(q, norm)
+        lib_logits = cls(normed)
+        lib_boxes = F.box_refine(bbox(normed, q), ref)
+    assert logits.shape == tuple(rows) + (ncls,) and boxes.shape == (2,) + tuple(rows) + (4,) and boxes1.shape[0] == 1
+    assert torch.equal(only, logits) and torch.equal(boxes1[0], boxes[0])
+    # fp32 on the 16-bit parameters, the normed rows rounded to the rows' type as both paths store them
+    n32 = torch.nn.functional.layer_norm(q.float(), (256,), norm.weight.float(), norm.bias.float(), norm.eps).to(dtype).float()
+    want_logits = n32 @ cls.weight.float().t() + cls.bias.float()
+    want_boxes = torch.stack([(_fp32_chain(bbox, x.to(dtype)).to(dtype).float() + inverse_sigmoid(ref)).sigmoid()
+                              for x in (n32, q.float())])
+    err, base = (logits.float() - want_logits).abs().max().item(), (lib_logits.float() - want_logits).abs().max().item()
+    assert err <= max(2.0 * base, 2.0 ** -6 * want_logits.abs().max().item()), (err, base)
+    berr, bbase = (boxes - want_boxes).abs().max().item(), (lib_boxes - want_boxes).abs().max().item()
+    assert berr <= max(2.0 * bbase, 2e-3), (berr, bbase)
+    assert (boxes - lib_boxes).abs().max().item() <= 4e-3
