@@ -637,6 +637,17 @@ int sdetr_mlp_rows_bf16(sdetr_stream_t stream, const void *x, const void *x_seco
                         const float *bias2, const void *packed_weight3, const float *bias3, int out_features, void *out,
                         int64_t out_row_stride);
 
+/* sdetr_ref_point_head_bf16 (round 5): query_pos = ref_point_head(get_sine_pos_embed(reference_points_input[:, :, 0, :]))
+ * (models/bricks/salience_transformer.py:642-644) in one launch: the sine embedding of sdetr_decoder_query_sine_embed
+ * (128 features per coordinate) is made in the row-tile fill of the 512 -> 256 -> 256 chain instead of going through
+ * memory.  reference_points fp32 [batch, num_queries, 4], valid_ratios fp32 [batch, num_levels, 2]; weights / biases as
+ * for sdetr_mlp_rows_bf16 with in_features = 512; query_pos [batch * num_queries, 256] in the activation type;
+ * reference_points_input fp32 [batch, num_queries, num_levels, 4] (:642) or NULL. */
+int sdetr_ref_point_head_bf16(sdetr_stream_t stream, const float *reference_points, const float *valid_ratios,
+                              int batch_size, int num_queries, int num_levels, float temperature,
+                              const void *packed_weight1, const float *bias1, const void *packed_weight2,
+                              const float *bias2, void *query_pos, float *reference_points_input);
+
 /* sdetr_rows_linear_bf16 (round 5): out[r, f] = (x[r] + (f < pos_features ? pos[r] : 0)) . W[f] + b[f] for a few
  * thousand rows of 256 features in one launch: the decoder layer's self-attention in-projection (nn.MultiheadAttention
  * with q = k = query + query_pos, v = query, models/bricks/salience_transformer.py:565-570: pos_features = 512 of 768)

@@ -31,15 +31,23 @@ struct MlpArgs {
     int n3;
     bf16_t *out;               // [rows, 256] (two layers) or [rows, n3]
     int64_t ldo;
+    // SINE form (ref_point_head): the 512 input features of a row are the sine embedding of its reference box, made in
+    // the tile fill (models/bricks/salience_transformer.py:642-643, models/bricks/position_encoding.py:105-132)
+    const float *ref;          // [rows, 4] boxes (cx, cy, w, h)
+    const float *vr;           // [B, L, 2] valid ratios
+    int Nq, L;
+    float temperature;
+    float *ref_in;             // [rows, L, 4] = box * (rw, rh, rw, rh) per level, or NULL
 };
 
 __device__ __forceinline__ int ml_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 constexpr int kMlpRows = 32, kMlpHidden = 256, kMlpHPitch = kMlpHidden * 2 + 16;
 
-template <int K1, int NL>
+template <int K1, int NL, bool SINE = false>
 __global__ void __launch_bounds__(512) mlp_rows_kernel(MlpArgs p)
 {
+    static_assert(!SINE || (K1 == 512 && NL == 2), "the sine prologue belongs to ref_point_head");
     constexpr int kXPitch = K1 * 2 + 16;
     extern __shared__ __align__(16) unsigned char mlp_lds[];
     unsigned char *xs = mlp_lds;                              // [32][kXPitch]   input rows
@@ -58,12 +66,33 @@ __global__ void __launch_bounds__(512) mlp_rows_kernel(MlpArgs p)
         a1[j] = *reinterpret_cast<const uint4 *>(p.w1 + (j / 16) * kHalfBytes + ((wave * 16 + (j % 16)) * 64 + lane) * 16);
     constexpr int kPieces = kMlpRows * K1 / 8, kPer = kPieces / 512;      // 16-byte pieces of the input rows: 2 or 4 per thread
     uint4 xv[kPer];
+    float coord[kPer];         // (SINE) the box coordinate behind this thread's piece of each of its rows
+    if constexpr (SINE) {
+        // piece pc = tid % 64 of rows tid / 64 + 8 i: features 8 pc .. 8 pc + 7 = pairs 4 (pc % 16) .. + 3 of block pc / 16;
+        // blocks are emitted in (y, x, w, h) order; every coordinate is scaled by the level-0 valid ratio (w, h, w, h)
+        const int blk = (tid & 63) >> 4;
+        const int c = blk == 0 ? 1 : (blk == 1 ? 0 : blk);
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-        const int e = i * 512 + tid;
-        const int r = min(row0 + e / (K1 / 8), p.rows - 1), pc = e % (K1 / 8);
-        const bf16_t *src = r < p.rows_a ? p.xa + (int64_t)r * K1 : p.xb + (int64_t)(r - p.rows_a) * K1;
-        xv[i] = *reinterpret_cast<const uint4 *>(src + pc * 8);
+        for (int i = 0; i < kPer; ++i) {
+            const int r = min(row0 + (tid >> 6) + 8 * i, p.rows - 1);
+            coord[i] = p.ref[(int64_t)r * 4 + c] * p.vr[(int64_t)(r / p.Nq) * p.L * 2 + (c & 1)];
+        }
+        if (p.ref_in && tid < kMlpRows * p.L) {
+            const int r = row0 + tid / p.L, l = tid - (tid / p.L) * p.L;
+            if (r < p.rows) {
+                const float4 b4 = reinterpret_cast<const float4 *>(p.ref)[r];
+                const float rw = p.vr[((int64_t)(r / p.Nq) * p.L + l) * 2], rh = p.vr[((int64_t)(r / p.Nq) * p.L + l) * 2 + 1];
+                reinterpret_cast<float4 *>(p.ref_in)[(int64_t)r * p.L + l] = make_float4(b4.x * rw, b4.y * rh, b4.z * rw, b4.w * rh);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = i * 512 + tid;
+            const int r = min(row0 + e / (K1 / 8), p.rows - 1), pc = e % (K1 / 8);
+            const bf16_t *src = r < p.rows_a ? p.xa + (int64_t)r * K1 : p.xb + (int64_t)(r - p.rows_a) * K1;
+            xv[i] = *reinterpret_cast<const uint4 *>(src + pc * 8);
+        }
     }
     float bias1[16];
 #pragma unroll
@@ -71,13 +100,36 @@ __global__ void __launch_bounds__(512) mlp_rows_kernel(MlpArgs p)
         const float4 bv = *reinterpret_cast<const float4 *>(p.b1 + wave * 32 + 8 * g + 4 * h);
         bias1[4 * g] = bv.x; bias1[4 * g + 1] = bv.y; bias1[4 * g + 2] = bv.z; bias1[4 * g + 3] = bv.w;
     }
+    if constexpr (!SINE) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a2[j] = *reinterpret_cast<const uint4 *>(p.w2 + ((wave * 16 + j) * 64 + lane) * 16);
+        for (int j = 0; j < 16; ++j) a2[j] = *reinterpret_cast<const uint4 *>(p.w2 + ((wave * 16 + j) * 64 + lane) * 16);
+    }
     if constexpr (NL == 3) {
         if (wave == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) a3[j] = *reinterpret_cast<const uint4 *>(p.w3 + (j * 64 + lane) * 16);
         }
+    }
+    if constexpr (SINE) {
+        // (the arithmetic of query_sine_embed_kernel, csrc/decoder_ops.hip: a = c * 2 pi / T^(2p/F), (sin a, cos a))
+        float inv_dim[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            inv_dim[q] = powf(p.temperature, (float)(2 * (4 * (tid & 15) + q)) / (float)(K1 / 4));
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sn, cs;
+                sincosf(coord[i] * 6.283185307179586f / inv_dim[q], &sn, &cs);
+                w[q] = pack_act2(sn, cs);
+            }
+            xv[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        // (layer 2's fragments only now: with them in flight the sine arithmetic spilled 36 registers)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a2[j] = *reinterpret_cast<const uint4 *>(p.w2 + ((wave * 16 + j) * 64 + lane) * 16);
     }
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
@@ -454,14 +506,14 @@ __global__ void __launch_bounds__(512) decoder_head_kernel(HeadArgs p)
     }
 }
 
-template <int K1, int NL>
+template <int K1, int NL, bool SINE = false>
 static int mlp_launch(hipStream_t s, const MlpArgs &a)
 {
     const size_t lds = (size_t)kMlpRows * (K1 * 2 + 16) + (size_t)(NL == 3 ? 2 : 1) * kMlpRows * kMlpHPitch;
     static DeviceOnce once;
-    allow_dynamic_lds(mlp_rows_kernel<K1, NL>, once, 96 * 1024);
-    hipLaunchKernelGGL((mlp_rows_kernel<K1, NL>), dim3((unsigned)((a.rows + kMlpRows - 1) / kMlpRows)), dim3(512), lds, s, a);
-    return check_launch("mlp_rows");
+    allow_dynamic_lds((mlp_rows_kernel<K1, NL, SINE>), once, 96 * 1024);
+    hipLaunchKernelGGL((mlp_rows_kernel<K1, NL, SINE>), dim3((unsigned)((a.rows + kMlpRows - 1) / kMlpRows)), dim3(512), lds, s, a);
+    return check_launch(SINE ? "ref_point_head" : "mlp_rows");
 }
 
 }  // namespace sdetr
@@ -564,4 +616,28 @@ extern "C" int sdetr_decoder_head_bf16(sdetr_stream_t stream, const void *query,
         hipLaunchKernelGGL(decoder_head_kernel<false>, grid, dim3(512), lds, s, a);
     }
     return check_launch("decoder_head");
+}
+
+extern "C" int sdetr_ref_point_head_bf16(sdetr_stream_t stream, const float *reference_points, const float *valid_ratios,
+                                         int batch_size, int num_queries, int num_levels, float temperature,
+                                         const void *packed_weight1, const float *bias1, const void *packed_weight2,
+                                         const float *bias2, void *query_pos, float *reference_points_input)
+{
+    if (batch_size < 0 || num_queries < 0 || num_levels < 1 || num_levels > 8) return fail("ref_point_head: bad sizes");
+    const int64_t rows = (int64_t)batch_size * num_queries;
+    if (rows > 0x7fffffffLL) return fail("ref_point_head: too many rows");
+    if (rows == 0) return 0;
+    if (!reference_points || !valid_ratios || !packed_weight1 || !bias1 || !packed_weight2 || !bias2 || !query_pos)
+        return fail("ref_point_head: null pointer");
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(reference_points) || !al16(packed_weight1) || !al16(packed_weight2) || !al16(bias1) || !al16(bias2) ||
+        (reinterpret_cast<uintptr_t>(query_pos) & 7) || (reference_points_input && !al16(reference_points_input)))
+        return fail("ref_point_head: operands must be 16-byte aligned (query_pos 8-byte)");
+    MlpArgs a{};
+    a.rows = (int)rows; a.rows_a = (int)rows;
+    a.w1 = (const char *)packed_weight1; a.b1 = bias1; a.w2 = (const char *)packed_weight2; a.b2 = bias2;
+    a.n3 = kMlpHidden; a.out = (bf16_t *)query_pos; a.ldo = kMlpHidden;
+    a.ref = reference_points; a.vr = valid_ratios; a.Nq = num_queries; a.L = num_levels; a.temperature = temperature;
+    a.ref_in = reference_points_input;
+    return mlp_launch<512, 2, true>(static_cast<hipStream_t>(stream), a);
 }

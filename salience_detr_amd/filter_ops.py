@@ -1243,6 +1243,41 @@ def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num
     return ref_in, embed
 
 
+def ref_point_head_applies(layers, dtype: torch.dtype, num_pos_feats: int) -> bool:
+    """``ref_point_head`` (sine embedding + 512 -> 256 -> 256 chain in one launch) takes these layers."""
+    layers = list(layers)
+    return (_hip.is_act16(dtype) and num_pos_feats == 128 and len(layers) == 2 and not torch.is_grad_enabled()
+            and [(l.in_features, l.out_features) for l in layers] == [(512, 256), (256, 256)]
+            and all(l.bias is not None and l.weight.is_cuda and l.weight.dtype == dtype and l.weight.stride(1) == 1
+                    for l in layers))
+
+
+def ref_point_head(reference_points: Tensor, valid_ratios: Tensor, layers, dtype: torch.dtype,
+                   temperature: float = 10000.0):
+    """``(reference_points_input [B,Nq,L,4] fp32, query_pos [B,Nq,256])`` of one decoder layer
+    (salience_transformer.py:642-644) in one launch (include/salience_hip.h, ``sdetr_ref_point_head_bf16``)."""
+    layers = list(layers)
+    if not ref_point_head_applies(layers, dtype, 128):
+        raise RuntimeError("ref_point_head: a 512 -> 256 -> 256 chain in a 16-bit type expected; no CPU fallback")
+    _hip.require_device("ref_point_head", reference_points=reference_points, valid_ratios=valid_ratios)
+    if reference_points.dim() != 3 or reference_points.shape[-1] != 4:
+        raise RuntimeError("ref_point_head: [B,Nq,4] boxes expected")
+    ref = reference_points.detach().float().contiguous()
+    vr = valid_ratios.float().contiguous()
+    B, Nq, _ = ref.shape
+    L = vr.shape[1]
+    p1, b1 = _packed_linear_512(layers[0].weight, layers[0].bias)
+    p2, b2 = _packed_linear_bf16(layers[1].weight, layers[1].bias)
+    pos = torch.empty((B, Nq, 256), dtype=dtype, device=ref.device)
+    ref_in = torch.empty((B, Nq, L, 4), dtype=torch.float32, device=ref.device)
+    with torch.cuda.device(ref.device):
+        code = _hip.lib(dtype).sdetr_ref_point_head_bf16(_hip.stream_ptr(), ref.data_ptr(), vr.data_ptr(), B, Nq, L,
+                                                         float(temperature), p1.data_ptr(), b1.data_ptr(), p2.data_ptr(),
+                                                         b2.data_ptr(), pos.data_ptr(), ref_in.data_ptr())
+    _hip.check(code, "ref_point_head")
+    return ref_in, pos
+
+
 def rows_linear_applies(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> bool:
     """``rows_linear`` takes this Linear on these rows: 16-bit HIP rows of 256 features, at most 768 outputs, no autograd."""
     return (x.is_cuda and _hip.is_act16(x.dtype) and x.shape[-1] == 256 and weight.dim() == 2 and weight.shape[1] == 256

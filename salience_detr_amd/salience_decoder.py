@@ -24,8 +24,8 @@ from torch.nn import functional as F
 
 from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_head, decoder_head_applies,
                          decoder_query_sine_embed, fused_ffn,
-                         fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies, rows_linear,
-                         rows_linear_applies)
+                         fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies, ref_point_head,
+                         ref_point_head_applies, rows_linear, rows_linear_applies)
 from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
@@ -250,8 +250,11 @@ class SalienceTransformerDecoder(nn.Module):
         ref = reference_points.float()
         classes, coords = [], []
         for i, layer in enumerate(self.layers):
-            ref_in, sine = decoder_query_sine_embed(ref, valid_ratios, self.embed_dim // 2, query.dtype)
-            query_pos = self.ref_point_head(sine)
+            if ref_point_head_applies(self.ref_point_head.layers, query.dtype, self.embed_dim // 2):
+                ref_in, query_pos = ref_point_head(ref, valid_ratios, self.ref_point_head.layers, query.dtype)   # one launch
+            else:
+                ref_in, sine = decoder_query_sine_embed(ref, valid_ratios, self.embed_dim // 2, query.dtype)
+                query_pos = self.ref_point_head(sine)
             query = layer(query=query, query_pos=query_pos, reference_points=ref_in, value=value,
                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                           key_padding_mask=key_padding_mask, self_attn_mask=attn_mask, value_hm=value_maps[i])

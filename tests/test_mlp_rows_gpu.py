@@ -160,3 +160,21 @@ def test_decoder_head_matches_the_module_by_module_path(dtype, rows, ncls):
     berr, bbase = (boxes - want_boxes).abs().max().item(), (lib_boxes - want_boxes).abs().max().item()
     assert berr <= max(2.0 * bbase, 2e-3), (berr, bbase)
     assert (boxes - lib_boxes).abs().max().item() <= 4e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Nq", [(2, 900), (1, 33), (3, 1)])
+def test_ref_point_head_equals_sine_embed_then_chain(dtype, B, Nq):
+    """Sine embedding made in the chain's tile fill: bit for bit the two launches it replaces (the same arithmetic on the
+    same rounded features), and the scaled reference points with it."""
+    m = _mlp(512, 256, 2, dtype, seed=3)
+    g = torch.Generator().manual_seed(B * 1000 + Nq)
+    ref = torch.rand(B, Nq, 4, generator=g).to(DEV)
+    vr = (torch.rand(B, 4, 2, generator=g) * 0.4 + 0.6).to(DEV)
+    with torch.no_grad():
+        assert F.ref_point_head_applies(m.layers, dtype, 128)
+        ref_in, pos = F.ref_point_head(ref, vr, m.layers, dtype)
+        want_in, sine = F.decoder_query_sine_embed(ref, vr, 128, dtype)
+        want = F.mlp_rows(sine, m.layers)
+    assert torch.equal(ref_in, want_in)
+    assert pos.shape == (B, Nq, 256) and torch.equal(pos, want)
