@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--plain", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="decoder value projection on a second stream (A/B; slower)")
-    ap.add_argument("--no-decoder-head", action="store_true", help="A/B: the layer head as norm + GEMM + mlp_rows + box_refine")
+    ap.add_argument("--no-decoder-head", action="store_true", help="A/B: without the layer head, the GEMM + norm tails and the sine prologue (the state before them)")
     ap.add_argument("--library-linears", action="store_true",
                     help="A/B: the decoder's MLPs and in-projections as library GEMMs (no mlp_rows / rows_linear launches)")
     args = ap.parse_args()
@@ -33,6 +33,8 @@ def main():
         from salience_detr_amd import filter_ops, salience_decoder
         no = lambda *a, **k: False
         filter_ops.decoder_head_applies = salience_decoder.decoder_head_applies = no
+        filter_ops.rows_linear_ln_applies = salience_decoder.rows_linear_ln_applies = no
+        filter_ops.ref_point_head_applies = salience_decoder.ref_point_head_applies = no
     if args.library_linears:
         filter_ops.rows_linear_applies = filter_ops.mlp_rows_applies = no
         salience_decoder.rows_linear_applies = salience_decoder.mlp_rows_applies = no

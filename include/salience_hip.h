@@ -637,6 +637,17 @@ int sdetr_mlp_rows_bf16(sdetr_stream_t stream, const void *x, const void *x_seco
                         const float *bias2, const void *packed_weight3, const float *bias3, int out_features, void *out,
                         int64_t out_row_stride);
 
+/* sdetr_rows_linear_ln_bf16 (round 5): out = LayerNorm(residual + Linear(x)) for a 256 -> 256 Linear on a few thousand
+ * rows -- the tails of the decoder layer's attention blocks (models/bricks/salience_transformer.py:571-572: norm2(query +
+ * out_proj(heads)); :583-585: norm1(query + output_proj(sampled))), a library GEMM and the add + LayerNorm launch each
+ * before.  (sdetr_token_linear_ln_bf16 of section (8) is the same function for tens of thousands of rows.)  x / residual /
+ * out [rows, 256] contiguous in the activation type; packed_weight / bias_padded as in section (8); norm_weight /
+ * norm_bias fp32 [256].  The Linear's output is rounded to the activation type before the add, as the separate launches
+ * store it. */
+int sdetr_rows_linear_ln_bf16(sdetr_stream_t stream, const void *x, const void *residual, int64_t rows,
+                              const void *packed_weight, const float *bias_padded, const float *norm_weight,
+                              const float *norm_bias, float norm_eps, void *out);
+
 /* sdetr_ref_point_head_bf16 (round 5): query_pos = ref_point_head(get_sine_pos_embed(reference_points_input[:, :, 0, :]))
  * (models/bricks/salience_transformer.py:642-644) in one launch: the sine embedding of sdetr_decoder_query_sine_embed
  * (128 features per coordinate) is made in the row-tile fill of the 512 -> 256 -> 256 chain instead of going through

@@ -108,6 +108,7 @@ SIGNATURES = {
     "sdetr_box_refine": (_i, [_p, _p, _i, _i64, _p, _i64, _i, ctypes.c_float, _p]),
     "sdetr_mlp_rows_bf16": (_i, [_p, _p, _p, _i64, _i64, _i, _p, _p, _p, _p, _p, _p, _i, _p, _i64]),
     "sdetr_rows_linear_bf16": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _p, _i64]),
+    "sdetr_rows_linear_ln_bf16": (_i, [_p, _p, _p, _i64, _p, _p, _p, _p, ctypes.c_float, _p]),
     "sdetr_ref_point_head_bf16": (_i, [_p, _p, _p, _i, _i, _i, ctypes.c_float, _p, _p, _p, _p, _p, _p]),
     "sdetr_decoder_head_bf16": (_i, [_p, _p, _i64, _p, _p, ctypes.c_float, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p,
                                      ctypes.c_float, _i, _p, _i64, _p]),

@@ -304,6 +304,107 @@ __global__ void __launch_bounds__(512) rows_linear_kernel(RowsLinearArgs p)
     }
 }
 
+// ---- y = LayerNorm(residual + Linear(x)) for a 256 -> 256 Linear on a few thousand rows ------------------------------
+// The tails of the decoder layer's two attention blocks (models/bricks/salience_transformer.py:571-572, 583-585:
+// norm2(query + dropout(out_proj(heads))), norm1(query + dropout(output_proj(sampled)))) -- a library GEMM and the fused
+// add + LayerNorm launch each.  Wave w owns features 32 w .. 32 w + 31 of the 32 rows; the row statistics (two-pass: mean,
+// then centred variance, as csrc/norm.hip) cross the waves through LDS.  The Linear's output is rounded to the activation
+// type before the residual is added, as the module-by-module path stores it.
+struct RowsLnArgs {
+    const bf16_t *x, *res;     // [rows, 256] each
+    int rows;
+    const char *w;             // packed 8 tiles
+    const float *b, *gamma, *beta;
+    float eps;
+    bf16_t *out;               // [rows, 256]
+};
+
+__global__ void __launch_bounds__(512) rows_linear_ln_kernel(RowsLnArgs p)
+{
+    extern __shared__ __align__(16) unsigned char mlp_lds[];
+    unsigned char *xs = mlp_lds;                                       // [32][kMlpHPitch]
+    float *part = reinterpret_cast<float *>(xs + kMlpRows * kMlpHPitch);   // [2][8 waves][32 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * kMlpRows;
+    const int row = row0 + t, rr = min(row, p.rows - 1);
+
+    uint4 a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = *reinterpret_cast<const uint4 *>(p.w + ((wave * 16 + j) * 64 + lane) * 16);
+    uint4 xv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = i * 512 + tid;
+        xv[i] = *reinterpret_cast<const uint4 *>(p.x + (int64_t)min(row0 + (e >> 5), p.rows - 1) * kMlpHidden + (e & 31) * 8);
+    }
+    // my 16 features of row t: 32 w + 8 g + 4 h + 0..3 -- residual, bias and the norm's parameters
+    uint2 rv[4];
+    float4 bv[4], gv[4], ev[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f = wave * 32 + 8 * g + 4 * h;
+        rv[g] = *reinterpret_cast<const uint2 *>(p.res + (int64_t)rr * kMlpHidden + f);
+        bv[g] = *reinterpret_cast<const float4 *>(p.b + f);
+        gv[g] = *reinterpret_cast<const float4 *>(p.gamma + f);
+        ev[g] = *reinterpret_cast<const float4 *>(p.beta + f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = i * 512 + tid;
+        *reinterpret_cast<uint4 *>(xs + (e >> 5) * kMlpHPitch + (e & 31) * 16) = xv[i];
+    }
+    __syncthreads();
+
+    ml_f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const unsigned char *bp = xs + t * kMlpHPitch + h * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = mfma_act_32x32x16(a[j], *reinterpret_cast<const uint4 *>(bp + j * 32), acc);
+    }
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float bb[4] = {bv[g].x, bv[g].y, bv[g].z, bv[g].w};
+        const float rs[4] = {act_lo(rv[g].x), act_hi(rv[g].x), act_lo(rv[g].y), act_hi(rv[g].y)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 * g + k] = act_lo(pack_act2(acc[4 * g + k] + bb[k], 0.f)) + rs[k];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += v[r];
+    sum += __shfl_xor(sum, 32);
+    if (h == 0) part[wave * 32 + t] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tot += part[w * 32 + t];
+    const float mean = tot / (float)kMlpHidden;
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sq += (v[r] - mean) * (v[r] - mean);
+    sq += __shfl_xor(sq, 32);
+    if (h == 0) part[256 + wave * 32 + t] = sq;
+    __syncthreads();
+    tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tot += part[256 + w * 32 + t];
+    const float rstd = rsqrtf(tot / (float)kMlpHidden + p.eps);
+    if (row < p.rows) {
+        bf16_t *orow = p.out + (int64_t)row * kMlpHidden + wave * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float gg[4] = {gv[g].x, gv[g].y, gv[g].z, gv[g].w}, ee[4] = {ev[g].x, ev[g].y, ev[g].z, ev[g].w};
+            float y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = (v[4 * g + k] - mean) * rstd * gg[k] + ee[k];
+            *reinterpret_cast<uint2 *>(orow + 8 * g) = make_uint2(pack_act2(y[0], y[1]), pack_act2(y[2], y[3]));
+        }
+    }
+}
+
 // ---- the decoder layer's output head in one launch ------------------------------------------------------------------
 // models/bricks/salience_transformer.py:655-668 for one layer i:
 //     normed  = decoder.norm(query)
@@ -640,4 +741,25 @@ extern "C" int sdetr_ref_point_head_bf16(sdetr_stream_t stream, const float *ref
     a.ref = reference_points; a.vr = valid_ratios; a.Nq = num_queries; a.L = num_levels; a.temperature = temperature;
     a.ref_in = reference_points_input;
     return mlp_launch<512, 2, true>(static_cast<hipStream_t>(stream), a);
+}
+
+extern "C" int sdetr_rows_linear_ln_bf16(sdetr_stream_t stream, const void *x, const void *residual, int64_t rows,
+                                         const void *packed_weight, const float *bias_padded, const float *norm_weight,
+                                         const float *norm_bias, float norm_eps, void *out)
+{
+    if (rows < 0 || rows > 0x7fffffffLL) return fail("rows_linear_ln: bad row count");
+    if (rows == 0) return 0;
+    if (!x || !residual || !packed_weight || !bias_padded || !norm_weight || !norm_bias || !out)
+        return fail("rows_linear_ln: null pointer");
+    const auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al16(x) || !al16(packed_weight) || !al16(bias_padded) || !al16(norm_weight) || !al16(norm_bias) ||
+        (reinterpret_cast<uintptr_t>(residual) & 7) || (reinterpret_cast<uintptr_t>(out) & 7))
+        return fail("rows_linear_ln: operands must be 16-byte aligned (residual and out 8-byte)");
+    RowsLnArgs a{};
+    a.x = (const bf16_t *)x; a.res = (const bf16_t *)residual; a.rows = (int)rows; a.w = (const char *)packed_weight;
+    a.b = bias_padded; a.gamma = norm_weight; a.beta = norm_bias; a.eps = norm_eps; a.out = (bf16_t *)out;
+    const size_t lds = (size_t)kMlpRows * kMlpHPitch + 2 * 8 * 32 * sizeof(float);
+    hipLaunchKernelGGL(rows_linear_ln_kernel, dim3((unsigned)((rows + kMlpRows - 1) / kMlpRows)), dim3(512), lds,
+                       static_cast<hipStream_t>(stream), a);
+    return check_launch("rows_linear_ln");
 }

@@ -1243,6 +1243,36 @@ def decoder_query_sine_embed(reference_points: Tensor, valid_ratios: Tensor, num
     return ref_in, embed
 
 
+def rows_linear_ln_applies(x: Tensor, linear, norm) -> bool:
+    """``rows_linear_ln`` takes this tail: 16-bit HIP rows of 256 features, a 256 -> 256 Linear and an affine
+    LayerNorm(256), no autograd."""
+    return (x.is_cuda and _hip.is_act16(x.dtype) and x.shape[-1] == 256 and not torch.is_grad_enabled()
+            and linear.in_features == 256 and linear.out_features == 256 and linear.bias is not None
+            and linear.weight.dtype == x.dtype and linear.weight.stride(1) == 1
+            and isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (256,)
+            and norm.weight is not None and norm.bias is not None)
+
+
+def rows_linear_ln(x: Tensor, linear, norm, residual: Tensor) -> Tensor:
+    """``norm(residual + linear(x))`` in one launch for a few thousand rows (include/salience_hip.h,
+    ``sdetr_rows_linear_ln_bf16``)."""
+    if not rows_linear_ln_applies(x, linear, norm):
+        raise RuntimeError("rows_linear_ln: 16-bit HIP rows, a 256 -> 256 Linear and LayerNorm(256) expected; no CPU fallback")
+    if residual.shape != x.shape or residual.dtype != x.dtype or residual.device != x.device:
+        raise RuntimeError("rows_linear_ln: residual must match x")
+    xa = x if x.is_contiguous() else x.contiguous()
+    ra = residual if residual.is_contiguous() else residual.contiguous()
+    packed, b = _packed_linear_bf16(linear.weight, linear.bias)
+    g, be = _norm_f32(norm)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        code = _hip.lib(x.dtype).sdetr_rows_linear_ln_bf16(_hip.stream_ptr(), xa.data_ptr(), ra.data_ptr(), xa.numel() // 256,
+                                                           packed.data_ptr(), b.data_ptr(), g.data_ptr(), be.data_ptr(),
+                                                           float(norm.eps), out.data_ptr())
+    _hip.check(code, "rows_linear_ln")
+    return out
+
+
 def ref_point_head_applies(layers, dtype: torch.dtype, num_pos_feats: int) -> bool:
     """``ref_point_head`` (sine embedding + 512 -> 256 -> 256 chain in one launch) takes these layers."""
     layers = list(layers)

@@ -25,7 +25,8 @@ from torch.nn import functional as F
 from .filter_ops import (attention_heads, attention_heads_applies, box_refine, decoder_head, decoder_head_applies,
                          decoder_query_sine_embed, fused_ffn,
                          fused_ffn_applies, fused_layer_norm, mlp_rows, mlp_rows_applies, ref_point_head,
-                         ref_point_head_applies, rows_linear, rows_linear_applies)
+                         ref_point_head_applies, rows_linear, rows_linear_applies, rows_linear_ln,
+                         rows_linear_ln_applies)
 from .layer_norm_train import add_layer_norm
 from .ms_deform_attn import MultiScaleDeformableAttention, batched_value_maps
 
@@ -130,9 +131,11 @@ class SalienceTransformerDecoderLayer(nn.Module):
     def _self_attention(self, qk: Tensor, v: Tensor, attn_mask: Optional[Tensor]) -> Tensor:
         return self.self_attn(query=qk, key=qk, value=v, attn_mask=attn_mask, need_weights=False)[0]
 
-    def _self_attention_native(self, query: Tensor, query_pos: Tensor, attn_mask: Optional[Tensor]) -> Tensor:
+    def _self_attention_native(self, query: Tensor, query_pos: Tensor, attn_mask: Optional[Tensor], project: bool = True):
         """nn.MultiheadAttention(q = k = query + pos, v = query) on its parameters without the module's layout copies:
-        two projections (q|k from query + pos, v from query), the flash kernel on strided head views, out_proj."""
+        two projections (q|k from query + pos, v from query), the flash kernel on strided head views, out_proj.
+        ``project=False``: the concatenated heads BEFORE ``out_proj`` when the own attention kernel ran (the caller fuses
+        ``out_proj`` with the residual and the norm).  Returns ``(tensor, out_proj applied)``."""
         mha = self.self_attn
         B, n, E = query.shape
         H = mha.num_heads
@@ -147,7 +150,10 @@ class SalienceTransformerDecoderLayer(nn.Module):
             v2 = F.linear(query, w[2 * E:], b[2 * E:])
         if attn_mask is None and attention_heads_applies(qk2[..., :E], qk2[..., E:], v2, H):
             # own flash kernel on the strided projection slices; the heads come out concatenated
-            return F.linear(attention_heads(qk2[..., :E], qk2[..., E:], v2, H), mha.out_proj.weight, mha.out_proj.bias)
+            heads = attention_heads(qk2[..., :E], qk2[..., E:], v2, H)
+            if not project:
+                return heads, False
+            return F.linear(heads, mha.out_proj.weight, mha.out_proj.bias), True
         qk = qk2.view(B, n, 2, H, E // H)
         v = v2.view(B, n, H, E // H)
         mask = attn_mask
@@ -155,7 +161,7 @@ class SalienceTransformerDecoderLayer(nn.Module):
             mask = torch.zeros_like(mask, dtype=query.dtype).masked_fill_(mask, float("-inf"))   # True = not allowed
         o = F.scaled_dot_product_attention(qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2), v.transpose(1, 2),
                                            attn_mask=mask)
-        return F.linear(o.transpose(1, 2).reshape(B, n, E), mha.out_proj.weight, mha.out_proj.bias)
+        return F.linear(o.transpose(1, 2).reshape(B, n, E), mha.out_proj.weight, mha.out_proj.bias), True
 
     def forward(self, query, query_pos, reference_points, value, spatial_shapes, level_start_index,
                 self_attn_mask=None, key_padding_mask=None, value_hm=None):
@@ -163,7 +169,11 @@ class SalienceTransformerDecoderLayer(nn.Module):
         ``value_hm`` [B,M,Nv,D] the decoder's batched value projection supplies on the no-grad path."""
         native = query.is_cuda and not _needs_grad(self, query, value, reference_points)
         if native and query_pos is not None:
-            query2 = self._self_attention_native(query, query_pos, self_attn_mask)
+            fuse_tail = rows_linear_ln_applies(query, self.self_attn.out_proj, self.norm2)
+            query2, projected = self._self_attention_native(query, query_pos, self_attn_mask, project=not fuse_tail)
+            if not projected:   # out_proj + residual + norm2 in one launch (csrc/mlp_rows.hip, round 5)
+                query = rows_linear_ln(query2, self.self_attn.out_proj, self.norm2, residual=query)
+                query2 = None
         else:
             query2 = self._self_attention(self.with_pos_embed(query, query_pos), query, self_attn_mask)
         if not native:
@@ -173,12 +183,18 @@ class SalienceTransformerDecoderLayer(nn.Module):
                                      key_padding_mask=key_padding_mask)
             query = add_layer_norm(query, self.norm1, self.dropout1(query2))
             return self.forward_ffn(query)
-        query = fused_layer_norm(query, self.norm2, residual=query2)
+        if query2 is not None:
+            query = fused_layer_norm(query, self.norm2, residual=query2)
         if value_hm is None:
             value_hm = self.cross_attn.project_value(value, key_padding_mask)
-        query2 = self.cross_attn.forward_native(query, reference_points.contiguous(), value_hm, spatial_shapes,
-                                                level_start_index, query_pos=query_pos)
-        query = fused_layer_norm(query, self.norm1, residual=query2)
+        if rows_linear_ln_applies(query, self.cross_attn.output_proj, self.norm1):
+            sampled = self.cross_attn.forward_native(query, reference_points.contiguous(), value_hm, spatial_shapes,
+                                                     level_start_index, query_pos=query_pos, apply_output_proj=False)
+            query = rows_linear_ln(sampled, self.cross_attn.output_proj, self.norm1, residual=query)
+        else:
+            query2 = self.cross_attn.forward_native(query, reference_points.contiguous(), value_hm, spatial_shapes,
+                                                    level_start_index, query_pos=query_pos)
+            query = fused_layer_norm(query, self.norm1, residual=query2)
         if fused_ffn_applies(query, self.linear1, self.linear2, self.norm3, self.activation):
             return fused_ffn(query, self.linear1, self.linear2, self.norm3)
         hidden = self.activation(self.linear1(query))

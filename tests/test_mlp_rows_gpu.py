@@ -178,3 +178,33 @@ def test_ref_point_head_equals_sine_embed_then_chain(dtype, B, Nq):
         want = F.mlp_rows(sine, m.layers)
     assert torch.equal(ref_in, want_in)
     assert pos.shape == (B, Nq, 256) and torch.equal(pos, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows", [(1, 1), (1, 33), (2, 900)])
+def test_rows_linear_ln_matches_gemm_then_add_layernorm(dtype, rows):
+    """``norm(residual + linear(x))`` in one launch against the two launches it replaces (library GEMM, fused add +
+    LayerNorm) and against fp32 on the 16-bit parameters with the Linear's output rounded as both paths store it."""
+    torch.manual_seed(rows[1])
+    lin = torch.nn.Linear(256, 256).to(DEV)
+    norm = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        lin.bias.normal_(0, 0.3)
+        norm.weight.normal_(1.0, 0.2)
+        norm.bias.normal_(0, 0.2)
+    lin, norm = lin.to(dtype), norm.to(dtype)
+    x = (torch.randn(*rows, 256) * 1.5).to(dtype).to(DEV)
+    res = (torch.randn(*rows, 256) * 1.5).to(dtype).to(DEV)
+    assert not F.rows_linear_ln_applies(x, lin, norm)                 # autograd on
+    with torch.no_grad():
+        assert F.rows_linear_ln_applies(x, lin, norm)
+        got = F.rows_linear_ln(x, lin, norm, res)
+        lib = F.fused_layer_norm(res, norm, residual=lin(x))
+    y = (x.float() @ lin.weight.float().t() + lin.bias.float()).to(dtype).float() + res.float()
+    want = torch.nn.functional.layer_norm(y, (256,), norm.weight.float(), norm.bias.float(), norm.eps)
+    assert got.shape == x.shape and got.dtype == dtype
+    err, base = (got.float() - want).abs().max().item(), (lib.float() - want).abs().max().item()
+    assert err <= max(2.0 * base, 2.0 ** -6 * want.abs().max().item()), (err, base)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            F.rows_linear_ln(x, lin, norm, res[..., :128])
