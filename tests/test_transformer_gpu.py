@@ -93,6 +93,26 @@ def test_grid_nms_full_size_counts_and_order():
         assert torch.equal(kept[b].cpu(), per_image[b][:900])
 
 
+@pytest.mark.parametrize("kind", ["random", "ramp"])
+def test_grid_nms_pyramid_too_large_for_the_neighbour_cache(kind):
+    """A 49 877-token pyramid: the u16 rank map (100 KB) and the states fit the LDS, the 16-byte neighbour records of the
+    3600 candidates (round 5) no longer do -- the kernel form that re-derives the neighbourhoods every round must give
+    the same answer (``ramp``: the longest suppression chains)."""
+    shapes = [(150, 250), (75, 125), (38, 63), (19, 32)]
+    t_shapes, lsi, S = _levels(shapes)
+    assert 2 * S + 3600 <= 150 * 1024 < 2 * S + 17 * 3600
+    B, K = 2, 3600
+    score = _score_maps(kind, B, S, shapes, 17)
+    if kind == "random":
+        score[:, :37500] += 1.0
+    ts, ti = R.topk_desc_stable(score, K)
+    want = R.nms_on_topk_index(ts, ti, t_shapes, lsi, num_proposals=900, iou_threshold=0.3)
+    kept, count = grid_nms_topk(ti.cuda(), shapes, S, 0.3, 900)
+    n = min(int(count.min()), 900)
+    assert n == want.shape[1]
+    assert torch.equal(kept[:, :n].cpu(), want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_proposal_refine_matches_gather_sigmoid(dtype):
     B, S, n = 2, 500, 77
