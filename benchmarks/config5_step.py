@@ -23,7 +23,6 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--plain", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="decoder value projection on a second stream (A/B; slower)")
     ap.add_argument("--no-decoder-head", action="store_true", help="A/B: without the layer head, the GEMM + norm tails and the sine prologue (the state before them)")
     ap.add_argument("--library-linears", action="store_true",
                     help="A/B: the decoder's MLPs and in-projections as library GEMMs (no mlp_rows / rows_linear launches)")
@@ -45,7 +44,6 @@ def main():
     if args.dtype != "fp32":
         tr.set_dtype(torch.float16 if args.dtype == "fp16" else torch.bfloat16, torch.float16)
     tr.static_proposals = True
-    tr.overlap_value_projection = args.overlap
     img_mask, masks = syn.make_masks(sizes)
     canvas = tuple(img_mask.shape[-2:])
     shapes = [tuple(x.shape[-2:]) for x in masks]
@@ -70,7 +68,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.steps
         best = ms if best is None else min(best, ms)
-    print(json.dumps({"workload": "BASELINE configs[4] at N=1", "dtype": args.dtype, "overlap": tr.overlap_value_projection, "library_linears": args.library_linears, "decoder_head": not (args.no_decoder_head or args.library_linears), "ms_per_step": round(best, 4),
+    print(json.dumps({"workload": "BASELINE configs[4] at N=1", "dtype": args.dtype, "library_linears": args.library_linears, "decoder_head": not (args.no_decoder_head or args.library_linears), "ms_per_step": round(best, 4),
                       "images_per_s": round(2e3 / best, 1), "graph_nodes": bench.CAPTURE_INFO.get("graph_nodes")}))
 
 
