@@ -229,8 +229,9 @@ class SalienceTransformerDecoder(nn.Module):
 
     def project_values(self, value, key_padding_mask=None):
         """The layers' cross-attention value maps ``[num_layers, B, M, Nv, D]`` (one projection: they all sample the same,
-        never-updated memory).  ``forward(..., value_maps=...)`` takes them; a caller can so run the projection beside
-        other work that only needs the memory (the proposal stage, salience_transformer.py)."""
+        never-updated memory).  ``forward(..., value_maps=...)`` takes them, so a caller may place the projection where
+        it likes (beside the proposal stage on a second stream it measured slower under graph replay:
+        benchmarks/experiments/README.md)."""
         return batched_value_maps([l.cross_attn for l in self.layers], value, key_padding_mask)
 
     def forward(self, query, reference_points, value, spatial_shapes, level_start_index, valid_ratios,
