@@ -247,6 +247,49 @@ def test_fp16_request_runs_config5_shape():
     assert (out[1] >= 0).all() and (out[1] <= 1).all()
 
 
+def test_config5_step_is_a_graph_of_at_most_240_launches():
+    """BASELINE configs[4] with the neck under hipGraph capture: 234 nodes since round 5 (313 before the decoder's GEMM
+    chains, in-projections, attention tails and layer heads became row-tile launches: ten per decoder layer), none of
+    them a memset, and the replay reproduces the eager outputs bit for bit.  A silent fall-back of one of those stages to
+    its module-by-module form (a cache key, a dtype or a contiguity rule that no longer holds) adds 6-36 nodes."""
+    from salience_detr_amd import graph_guard
+    from salience_detr_amd.salience_transformer import build_salience_transformer
+    image_sizes = [(800, 1333), (800, 1066)]
+    tr = build_salience_transformer(with_neck=True)
+    tr.load_state_dict(syn.det_state_dict(tr.state_dict()))
+    tr = tr.eval().cuda()
+    tr.set_dtype(torch.float16)
+    tr.static_proposals = True
+    img_mask, masks = syn.make_masks(image_sizes)
+    canvas = tuple(img_mask.shape[-2:])
+    shapes = [tuple(m.shape[-2:]) for m in masks]
+    feats = [f.cuda() for f in syn.make_feats(2, shapes, 256, 0)]
+    masks = [m.cuda() for m in masks]
+    pos = [syn.sine_position_embedding(m, 128).cuda() for m in masks]
+
+    def step():
+        with torch.no_grad():
+            return tr(feats, masks, pos, image_sizes=image_sizes, canvas=canvas)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            eager = [t.clone() for t in step()[:4]]
+    torch.cuda.current_stream().wait_stream(side)
+    g = graph_guard.new_graph()
+    with torch.cuda.graph(g):
+        out = step()
+    types = graph_guard.node_types(g)
+    if not types:
+        pytest.skip("this torch build exposes no graph handle")
+    assert graph_guard.memset_nodes(g) == 0
+    assert len(types) <= 240, len(types)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(out[:4], eager):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tag", ["plain", "neck"])
 def test_whole_transformer_training_step_matches_reference_gradients(gold, tag):
     """``SalienceTransformer.forward`` under autograd with denoising queries (salience_transformer.py:195-233; train mode:
