@@ -888,7 +888,7 @@ def main():
             layer_note = f"truncated-graph timing failed: {e}"
 
     # ---- instrumented eager pass: device time of every fused-MSDA launch (a captured graph of repeats), top-300 sets ----
-    launches, launch_nq, kernels_used, msda_us = [], [], [], []
+    launches, launch_nq, kernels_used, msda_us, msda_us_exact = [], [], [], [], []
     real_fused = msda_mod.msda_fused_forward
     real_resident = msda_mod.msda_resident_forward
     real_bordered = msda_mod.msda_bordered_forward
@@ -910,16 +910,21 @@ def main():
         record(call, value_hm, reference_points, proj, proj_head_major, o, "msda_gather_l4p4_kernel<half_t>")
         return o
 
-    def timed_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=None, chunks=0):
-        call = lambda: real_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=out_dtype, chunks=chunks)
+    def timed_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=None, chunks=0, **kw):
+        call = lambda: real_resident(value_hm, level_shapes_, reference_points, proj_hm, out_dtype=out_dtype, chunks=chunks, **kw)
         o = call()
         record(call, value_hm, reference_points, proj_hm, True, o, "msda_resident_kernel<half_t>")
         return o
 
-    def timed_bordered(value_hm, level_shapes_, reference_points, proj_hm, row_order=None, out_dtype=None, chunks=0):
+    def timed_bordered(value_hm, level_shapes_, reference_points, proj_hm, row_order=None, out_dtype=None, chunks=0, **kw):
         call = lambda: real_bordered(value_hm, level_shapes_, reference_points, proj_hm, row_order=row_order,
-                                     out_dtype=out_dtype, chunks=chunks)
+                                     out_dtype=out_dtype, chunks=chunks, **kw)
         o = call()
+        # the same launch with the reference op's exact fp32 corner sums (ACC_EXACT), warm, for the A/B the line reports
+        kw_exact = dict(kw, accumulate=msda_mod.ACC_EXACT)
+        msda_us_exact.append(graph_time_us(lambda: real_bordered(value_hm, level_shapes_, reference_points, proj_hm,
+                                                                 row_order=row_order, out_dtype=out_dtype, chunks=chunks,
+                                                                 **kw_exact), MSDA_REPEATS))
         # (algorithmic bytes count the PIXELS of the maps, not the bordered layout's extra zero records)
         plain_shape = value_hm[:, :, :sum(h * w for h, w in level_shapes_)]
         record(call, plain_shape, reference_points, proj_hm, True, o,
@@ -1058,7 +1063,8 @@ def main():
             clk_meas, clk_src = cj["shader_clock_ghz"], "profiles/r05_msda_clock.json (%s)" % cj.get("source", "SQ_BUSY_CYCLES / duration")
     except (OSError, ValueError, KeyError):
         pass
-    pk = int(os.environ.get("SDETR_MSDA_PK", "2" if args.dtype == "bf16" else "0"))
+    # (the library's default accumulation form for the activation type: include/salience_hip.h SDETR_MSDA_ACC_DEFAULT)
+    pk = 2 if args.dtype == "bf16" else 0
     fma_per_sample_lane = {0: 32, 1: 24, 2: 18}.get(pk, 32)
     macs = [args.batch * n * 8 * 16 * 4 * 32 for n in launch_nq[:nl]]
     lanes = cus * 4 * 16
@@ -1075,6 +1081,21 @@ def main():
         "instruction_floor_us": round(sum(m / 32.0 * fma_per_sample_lane for m in macs) / nl / (lanes * clk * 1e3), 2),
         "note": "MACs / (CUs x 4 SIMDs x 16 lanes x clock): the vector-ALU roofline of the gather beside the HBM one",
     }
+    # the timed 16-bit form sums corners in packed fp16; the reference's op is fp32.  Both forms of the same
+    # launches, warm (back to back in a graph); `frac_in_step_estimate` scales the in-step figure by the warm ratio.
+    accumulate_ab = None
+    if len(msda_us_exact) >= nl and warm_total_us > 0:
+        ex_total = sum(msda_us_exact[:nl])
+        accumulate_ab = {
+            "timed_form": {0: "exact fp32 (ACC_EXACT)", 1: "packed fp16 per sample (ACC_PACKED_SAMPLE)",
+                           2: "packed fp16 per sample and level (ACC_PACKED_LEVEL)"}[pk],
+            "frac_warm_timed_form": round(total_bytes / warm_total_us / 1e3 / HBM_PEAK_GBPS, 4),
+            "frac_warm_exact_fp32": round(total_bytes / ex_total / 1e3 / HBM_PEAK_GBPS, 4),
+            "avg_launch_us_warm_exact_fp32": round(ex_total / nl, 2),
+            "frac_in_step_exact_fp32_estimate": round(achieved / HBM_PEAK_GBPS * warm_total_us / ex_total, 4),
+            "note": "the same six launches with the reference op's fp32 corner sums (accumulate = SDETR_MSDA_ACC_EXACT), "
+                    "warm; the in-step estimate is roofline.frac x (warm time of the timed form / warm time of the exact form)",
+        }
     roofline = {
         "kernel": "sdetr::" + " / ".join(sorted(set(kernels_used[:nl])))
                   + " (fused softmax + sampling locations + bilinear gather)",
@@ -1096,6 +1117,7 @@ def main():
         "timing_rocprof_us": rocprof_us,
         "frac_rocprof": (round(total_bytes / nl / rocprof_us / 1e3 / HBM_PEAK_GBPS, 4) if rocprof_us else None),
         "timing_rocprof_source": rocprof_src,
+        "accumulate_ab": accumulate_ab,
         "frac_warm": round(achieved_warm / HBM_PEAK_GBPS, 4), "achieved_warm": round(achieved_warm, 1),
         "avg_launch_us_warm": round(warm_total_us / nl, 2), "per_layer_us_warm": [round(u, 2) for u in msda_us[:nl]],
         "timing_warm": "per launch: %d back-to-back repetitions of the step's own launch captured in a hipGraph, replayed "

@@ -1,6 +1,6 @@
 """BASELINE configs[3] at N = 1 (bf16, batch 1, the reference's 5scale pyramid: 89 250 tokens, 45 330 first-layer queries)
 as a program of its own: ms per step under hipGraph replay, for A/B runs and per-kernel profiles
-(`SDETR_ROW_ORDER_TILE=0` = rows in list order, the state before round 5).
+(`--row-order-tile 0` = rows in list order, the state before round 5).
 
     python benchmarks/config4_step.py [--steps 30] [--plain]
     rocprofv3 --kernel-trace --stats ... -- python benchmarks/config4_step.py --plain
@@ -24,9 +24,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--plain", action="store_true", help="no second timing pass: the profile's launches are the step's")
+    ap.add_argument("--row-order-tile", type=int, default=16, help="tile edge of the gather's row order; 0 = list order")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
     m = build_hot_path(max_num_embedding=500)
+    m.encoder.row_order_tile = args.row_order_tile
     m.load_state_dict(syn.det_state_dict(m.state_dict()))
     m = m.to(device).eval()
     m.set_encoder_dtype(torch.bfloat16, torch.float16)
@@ -55,7 +57,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.steps
         best = ms if best is None else min(best, ms)
-    print(json.dumps({"workload": "BASELINE configs[3] at N=1", "row_order_tile": os.environ.get("SDETR_ROW_ORDER_TILE", "16"),
+    print(json.dumps({"workload": "BASELINE configs[3] at N=1", "row_order_tile": args.row_order_tile,
                       "msda_kernel_code": kernel, "tile_order": kernel == M.KERNEL_BORDERED_ORDERED,
                       "ms_per_step": round(best, 4), "images_per_s": round(1e3 / best, 1), "steps": args.steps}))
 

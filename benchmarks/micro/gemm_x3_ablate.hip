@@ -20,6 +20,7 @@ int main(int argc, char **argv)
 {
     const int T = argc > 1 ? atoi(argv[1]) : 22726, K = argc > 2 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 2048;
     const bool dw = argc > 4 && argv[4][0] == 'd';   // "dw": the weight gradient dy^T x (both operands reduction-major, 16 slices)
+    if (argc > 5) sdetr_gemm_x3_generation(atoi(argv[5]));   // 1 = 128 x 128 tiles, 2 = 256 x 128 tiles, default: the shape rule
     float *x, *w, *y;
     CK(hipMalloc(&x, (size_t)T * K * 4));
     CK(hipMalloc(&w, (size_t)N * K * 4));

@@ -79,11 +79,11 @@ def main():
                 record(f"bordered_tile{tile}" + sfx, lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=order,
                                                                                       out_dtype=torch.bfloat16, chunks=ch), base)
         order16 = M.spatial_row_order(tk, levels, 16)
-        for name, env in (() if args.minimal else (("tile16_no_l2_warmup", {"SDETR_MSDA_PREFETCH": "0"}),)):
-            os.environ.update(env)
-            record(name, lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=order16, out_dtype=torch.bfloat16), base)
-            for k in env:
-                os.environ.pop(k)
+        if not args.minimal:
+            record("tile16_no_l2_warmup", lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=order16,
+                                                                          out_dtype=torch.bfloat16, l2_warmup=0), base)
+            record("tile16_exact_fp32_sums", lambda: M.msda_bordered_forward(hb, levels, rf, slab, row_order=order16,
+                                                                             out_dtype=torch.bfloat16, accumulate=M.ACC_EXACT), base)
         if args.ablate:
             order = M.spatial_row_order(tk, levels, 16)
             for abl in args.ablate.split(","):

@@ -121,7 +121,7 @@ done
     [ -x benchmarks/micro/gemm_x3_ablate_$v ] && timeout 60 ./benchmarks/micro/gemm_x3_ablate_$v | sed 's/$/,/'
   done
   for K in 64 1024 2048; do timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 22726 $K 2048 | sed 's/$/,/'; done
-  SDETR_GEMM_X3_V1=1 timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 | sed 's/}$/, "generation": "128x128 tiles"}/'
+  timeout 60 ./benchmarks/micro/gemm_x3_ablate_0 22726 256 2048 fwd 1 | sed 's/}$/, "generation": "128x128 tiles"}/'
   echo ']}' ) > $O/${R}_gemm_x3_ablate.json 2> /dev/null
 if [ "${FULL_CPU:-0}" = "1" ]; then
   python bench.py --cpu-protocol full --train-steps 0 --in-flight-report 0 --config-steps 0 > $O/${R}_bench_cpu_full.json 2> $O/${R}_bench_cpu_full.err

@@ -173,6 +173,12 @@ int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *value_hm, int
                                 const int32_t *level_hw_host, const float *ref_points, int ref_dim,
                                 int64_t ref_batch_stride, const void *proj_head_major_bf16, int batch_size,
                                 int spatial_size, int num_heads, int num_query, void *out, int out_dtype, int chunks);
+/* ..._ex: `image_lanes` >= 0 fixes how many images the chip works on at a time (0 = all), -1 = by the maps' size. */
+int sdetr_msda_resident_forward_ex(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                   const int32_t *level_hw_host, const float *ref_points, int ref_dim,
+                                   int64_t ref_batch_stride, const void *proj_head_major_bf16, int batch_size,
+                                   int spatial_size, int num_heads, int num_query, void *out, int out_dtype, int chunks,
+                                   int image_lanes);
 int sdetr_msda_last_kernel(void);
 
 /* The same kernel on BORDERED head-major maps (round 4, csrc/msda_resident.hip `msda_bordered_kernel`): every level of
@@ -194,6 +200,25 @@ int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *value_bordere
                                 int64_t ref_batch_stride, const void *proj_head_major_bf16, const int32_t *row_order,
                                 int64_t row_order_batch_stride, int batch_size, int bordered_records, int num_heads,
                                 int num_query, void *out, int out_dtype, int chunks);
+/* The same call with its launch choices as explicit arguments (round 6: nothing in the product libraries reads the
+ * environment).  sdetr_msda_bordered_forward == ..._ex(..., SDETR_MSDA_ACC_DEFAULT, -1, -1).
+ *   accumulate:  how a 16-bit output's corner products are summed (fp32 outputs always take the exact form):
+ *                SDETR_MSDA_ACC_EXACT         fp32 products and sums (ms_deform_im2col_cuda.cuh:226-288 rounded once at the end)
+ *                SDETR_MSDA_ACC_PACKED_SAMPLE a sample's four corners summed in packed fp16 (v_pk_fma_f16), fp32 across samples
+ *                SDETR_MSDA_ACC_PACKED_LEVEL  a level's four samples x four corners summed in packed fp16, fp32 across levels
+ *                SDETR_MSDA_ACC_DEFAULT       the library's choice: PACKED_LEVEL for bf16 activations, EXACT for fp16 ones
+ *   image_lanes: >= 0 fixes how many images the chip works on at a time (0 = all); -1 = by the maps' total size
+ *   l2_warmup:   >= 0 fixes the warm-up mask (bit 0 fine levels, bit 1 projection rows); -1 = by the maps' size */
+#define SDETR_MSDA_ACC_DEFAULT (-1)
+#define SDETR_MSDA_ACC_EXACT 0
+#define SDETR_MSDA_ACC_PACKED_SAMPLE 1
+#define SDETR_MSDA_ACC_PACKED_LEVEL 2
+int sdetr_msda_bordered_forward_ex(sdetr_stream_t stream, const void *value_bordered, int value_dtype,
+                                   const int32_t *level_hw_host, const float *ref_points, int ref_dim,
+                                   int64_t ref_batch_stride, const void *proj_head_major_bf16, const int32_t *row_order,
+                                   int64_t row_order_batch_stride, int batch_size, int bordered_records, int num_heads,
+                                   int num_query, void *out, int out_dtype, int chunks, int accumulate, int image_lanes,
+                                   int l2_warmup);
 
 /* Same gather on a head-major value with explicit sampling locations / weights (the reference
  * op's math on the native layout); loc/aw as in (1), fp32. */
@@ -790,6 +815,10 @@ int sdetr_neck_gate_shortcut(sdetr_stream_t stream, const void *y, int dtype, in
  * elements apart, K % 8 == 0): a weight is split once per call instead of in every workgroup that reads it. */
 int sdetr_gemm_x3_presplit(sdetr_stream_t stream, const float *w, int64_t ld, int rows, int cols, int transpose,
                            void *out);
+/* sdetr_gemm_x3_generation: pins the kernel generation the CALLING THREAD's later gemm_x3 calls take -- 1 = 128 x 128
+ * tiles, 2 = 256 x 128 tiles, 0 = the library's shape rule (the default) -- and returns the previous setting.  Both
+ * generations take the same six bf16 products per term; the parity tests run every shape on each. */
+int sdetr_gemm_x3_generation(int generation);
 int sdetr_gemm_x3_f32(sdetr_stream_t stream, const float *a, int64_t lda, int a_kmajor, const float *b, int64_t ldb,
                       int b_kmajor, float *c, int64_t ldc, int M, int N, int K, const float *bias,
                       int reduction_splits, float *a_row_sum);

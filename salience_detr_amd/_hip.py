@@ -6,6 +6,7 @@ of device memory and streams (``tensor.data_ptr()``, ``torch.cuda.current_stream
 """
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -23,7 +24,7 @@ ACT16 = (torch.bfloat16, torch.float16)      # the two 16-bit activation types (
 
 _lib = None
 _lib_f16 = None
-_last = None          # the library of the most recent lib() call: where check() reads the error text
+_tls = threading.local()   # .last = the library of this thread's most recent lib() call: where check() reads the error text
 
 
 def is_act16(dt) -> bool:
@@ -84,6 +85,9 @@ SIGNATURES = {
     "sdetr_layer_row_orders": (_i, [_p, _p, _i64, _p, _i, _i, _i, _i, _p, _p, _i64]),
     "sdetr_msda_bordered_max_resident_records": (_i, []),
     "sdetr_msda_bordered_forward": (_i, [_p, _p, _i, _p, _p, _i, _i64, _p, _p, _i64, _i, _i, _i, _i, _p, _i, _i]),
+    "sdetr_msda_bordered_forward_ex": (_i, [_p, _p, _i, _p, _p, _i, _i64, _p, _p, _i64, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i]),
+    "sdetr_msda_resident_forward_ex": (_i, [_p, _p, _i, _p, _p, _i, _i64, _p, _i, _i, _i, _i, _p, _i, _i, _i]),
+    "sdetr_gemm_x3_generation": (_i, [_i]),
     "sdetr_topk_attention_workspace_bytes": (_i64, [_i, _i]),
     "sdetr_topk_attention_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i,
                                        _p, _i64]),
@@ -209,23 +213,25 @@ def lib(act=None) -> ctypes.CDLL:
     """Load the shared library once; fail loudly if it is not built.  ``act``: the dtype (or a tensor) of the 16-bit
     activations of the call -- ``torch.float16`` selects the fp16-activation flavour, anything else the bf16 library (which
     also holds every fp32 / integer operator)."""
-    global _lib, _lib_f16, _last
+    global _lib, _lib_f16
     if act is not None and not isinstance(act, torch.dtype):
         act = act.dtype
     if act == torch.float16:
         if _lib_f16 is None:
             _lib_f16 = _load(F16_LIB_PATH)
-        _last = _lib_f16
+        _tls.last = _lib_f16
         return _lib_f16
     if _lib is None:
         _lib = _load(LIB_PATH)
-    _last = _lib
+    _tls.last = _lib
     return _lib
 
 
-def check(code: int, what: str) -> None:
+def check(code: int, what: str, library: Optional[ctypes.CDLL] = None) -> None:
+    """Raises on a non-zero status.  The error text is thread-local inside each library; ``library`` names the one the
+    failing call went to (default: the library THIS thread's most recent ``lib()`` call selected -- ADVICE r5)."""
     if code != 0:
-        msg = (_last or lib()).sdetr_last_error().decode(errors="replace")
+        msg = (library or getattr(_tls, "last", None) or lib()).sdetr_last_error().decode(errors="replace")
         if code == EINVAL:
             raise RuntimeError(f"{what}: {msg}")
         raise RuntimeError(f"{what}: HIP launch error {code}: {msg}")

@@ -27,7 +27,9 @@ def _stale(out, deps):
 # (lives under benchmarks/: the product package ships the two product libraries only; the benchmark scripts that want it
 # point salience_detr_amd._hip.LIB_PATH at it themselves before the first operator call)
 ABLATE_LIB = os.path.join(ROOT, "benchmarks", "libsalience_hip_ablate.so")
-ABLATE_SOURCES = {"msda_resident.hip": ["-DSDETR_MSDA_ABLATIONS"]}
+# -DSDETR_AB_SWITCHES (common.h ab_env): the benchmark scripts' environment switches exist in this library only
+ABLATE_SOURCES = {"msda_resident.hip": ["-DSDETR_MSDA_ABLATIONS", "-DSDETR_AB_SWITCHES"], "topk.hip": ["-DSDETR_AB_SWITCHES"],
+                  "neck.hip": ["-DSDETR_AB_SWITCHES"], "salience_head.hip": ["-DSDETR_AB_SWITCHES"]}
 
 
 def build_ablations(force: bool = False, verbose: bool = False) -> str:

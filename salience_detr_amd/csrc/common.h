@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/salience_hip.h"
 
@@ -26,6 +27,20 @@ inline int fail(const char *fmt, ...)
     vsnprintf(error_buffer(), 512, fmt, ap);
     va_end(ap);
     return SDETR_EINVAL;
+}
+
+// A/B switches of the benchmark scripts (kernel forms, tile sizes, warm-ups): read from the environment ONLY in the
+// benchmark build (-DSDETR_AB_SWITCHES, csrc/build.py build_ablations -> benchmarks/libsalience_hip_ablate.so).  In the two
+// product libraries this returns NULL for every name: what they compute never depends on the environment; the choices
+// a test needs (the gather's accumulation form, the GEMM generation) are explicit entry-point arguments.
+inline const char *ab_env(const char *name)
+{
+#ifdef SDETR_AB_SWITCHES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
 }
 
 inline int check_launch(const char *what)

@@ -738,11 +738,18 @@ static int launch_gemm_x3_v2(hipStream_t s, const GemmArgs &a, int splits)
 // Which generation takes a product.  Measured (benchmarks/gemm_x3_bench.py, MI355X): the 256 x 128 tiles win where an
 // output or reduction dimension is long (feed-forward shapes: 154-190 us against 186-217), the 128 x 128 tiles with two
 // workgroups per CU where the output is a few tiles wide (256 / 384 features: 56-66 us against 62-101).
-// SDETR_GEMM_X3_V1=1 / =0: force the first / second generation (A/B runs).
+// sdetr_gemm_x3_generation(1 | 2) pins the first / second generation for the calling thread (0 = this rule): both
+// generations compute the same six-term products, the parity tests run every shape on each.
+static thread_local int t_generation = 0;
+extern "C" int sdetr_gemm_x3_generation(int generation)
+{
+    const int before = t_generation;
+    if (generation >= 0 && generation <= 2) t_generation = generation;
+    return before;
+}
 static bool gemm_x3_use_v2(int M, int N, int K)
 {
-    const char *e = getenv("SDETR_GEMM_X3_V1");   // (read per call: the tests switch it)
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '0';
+    if (t_generation) return t_generation == 2;
     const int longest = N > K ? N : K;
     return M >= 128 && longest >= 1024;   // (a 128-row output still wins on the 256-row tiles when the reduction is long: 40 vs 55 us)
 }

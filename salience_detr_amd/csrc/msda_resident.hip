@@ -1090,6 +1090,15 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
                                            int64_t ref_batch_stride, const void *proj_hm_bf16, int B, int Nv, int M,
                                            int Nq, void *out, int out_dtype, int chunks)
 {
+    return sdetr_msda_resident_forward_ex(stream, value_hm, value_dtype, level_hw_host, ref, ref_dim, ref_batch_stride,
+                                          proj_hm_bf16, B, Nv, M, Nq, out, out_dtype, chunks, -1);
+}
+
+extern "C" int sdetr_msda_resident_forward_ex(sdetr_stream_t stream, const void *value_hm, int value_dtype,
+                                              const int32_t *level_hw_host, const float *ref, int ref_dim,
+                                              int64_t ref_batch_stride, const void *proj_hm_bf16, int B, int Nv, int M,
+                                              int Nq, void *out, int out_dtype, int chunks, int image_lanes)
+{
     if (B < 0 || Nv <= 0 || M <= 0 || Nq < 0) return fail("msda_resident_forward: bad dims B=%d Nv=%d M=%d Nq=%d", B, Nv, M, Nq);
     if (!value_hm || !level_hw_host || !ref || !proj_hm_bf16 || !out) return fail("msda_resident_forward: null pointer");
     if (ref_dim != 2 && ref_dim != 4)
@@ -1135,14 +1144,11 @@ extern "C" int sdetr_msda_resident_forward(sdetr_stream_t stream, const void *va
     // chip works on FOUR images at a time (every workgroup walks the images of its lane), so that the maps being gathered
     // from stay cached: at batch 16 (366 MB of maps) 299 / 187 / 78 us at 11 363 / 6817 / 2272 queries against 380 / 231 /
     // 79 with all sixteen in flight and 336 / 249 / 129 one at a time (direct kernel: 350 / 234 / 68).
-    // SDETR_MSDA_IMAGE_SERIAL=0 / G forces the number of lanes for A/B runs.
+    // `image_lanes` >= 0 fixes the number of lanes (0 = every image in flight); -1 = the rule above.
     const int cus = device_cu_count();
     int lanes = 0;
     if ((int64_t)B * M * Nv * 64 > ((int64_t)160 << 20) && B > 4) lanes = 4;
-    if (const char *e = getenv("SDETR_MSDA_IMAGE_SERIAL")) {
-        const int v = atoi(e);
-        lanes = v <= 0 ? 0 : (v > B ? B : v);
-    }
+    if (image_lanes >= 0) lanes = image_lanes > B ? B : image_lanes;
     a.image_serial = lanes;
     const int groups = lanes ? lanes : B;   // (image, head) slots the workgroups are spread over
     if (chunks <= 0) {
@@ -1216,6 +1222,17 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
                                            int64_t row_order_batch_stride, int B, int Np, int M, int Nq, void *out,
                                            int out_dtype, int chunks)
 {
+    return sdetr_msda_bordered_forward_ex(stream, value_bordered, value_dtype, level_hw_host, ref, ref_dim, ref_batch_stride,
+                                          proj_hm_bf16, row_order, row_order_batch_stride, B, Np, M, Nq, out, out_dtype,
+                                          chunks, SDETR_MSDA_ACC_DEFAULT, -1, -1);
+}
+
+extern "C" int sdetr_msda_bordered_forward_ex(sdetr_stream_t stream, const void *value_bordered, int value_dtype,
+                                              const int32_t *level_hw_host, const float *ref, int ref_dim,
+                                              int64_t ref_batch_stride, const void *proj_hm_bf16, const int32_t *row_order,
+                                              int64_t row_order_batch_stride, int B, int Np, int M, int Nq, void *out,
+                                              int out_dtype, int chunks, int accumulate, int image_lanes, int l2_warmup)
+{
     if (B < 0 || Np <= 0 || M <= 0 || Nq < 0) return fail("msda_bordered_forward: bad dims B=%d Np=%d M=%d Nq=%d", B, Np, M, Nq);
     if (!value_bordered || !level_hw_host || !ref || !proj_hm_bf16 || !out) return fail("msda_bordered_forward: null pointer");
     if (ref_dim != 2 && ref_dim != 4)
@@ -1266,10 +1283,7 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     const int cus = device_cu_count();
     int lanes = 0;
     if ((int64_t)B * M * Np * 64 > ((int64_t)160 << 20) && B > 4) lanes = 4;
-    if (const char *e = getenv("SDETR_MSDA_IMAGE_SERIAL")) {
-        const int v = atoi(e);
-        lanes = v <= 0 ? 0 : (v > B ? B : v);
-    }
+    if (image_lanes >= 0) lanes = image_lanes > B ? B : image_lanes;
     a.image_serial = lanes;
     const int groups = lanes ? lanes : B;
     if (chunks <= 0) {
@@ -1280,19 +1294,19 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     }
     a.chunks = chunks;
     // bit 0: L2 warm-up of the fine levels (on: in the step -132.7 -> 124.3 us over the six launches by rocprofv3; nothing
-    // to gain in a warm replay), bit 1: of the workgroup's projection rows (measured: no gain).  Environment: A/B runs.
+    // to gain in a warm replay), bit 1: of the workgroup's projection rows (measured: no gain).  `l2_warmup` >= 0 fixes it.
     // Only while the fine levels of the images an XCD serves at a time fit its 4 MB L2 beside the rest: on the 5scale
     // pyramid (5.7 MB per head) the warm-up costs 4 us per launch (profiles/r04_msda_ab_5scale_bordered.json).
     a.prefetch_fine = (int64_t)groups * a.res_start * 64 <= ((int64_t)7 << 19) ? 1 : 0;
-    if (const char *e = getenv("SDETR_MSDA_PREFETCH")) a.prefetch_fine = atoi(e);
+    if (l2_warmup >= 0) a.prefetch_fine = l2_warmup & 3;
     const int64_t blocks = (int64_t)groups * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_bordered_forward: grid too large");
     // corner accumulation: exact fp32 products for fp32 outputs (the parity path); for 16-bit outputs the packed-fp16 form
-    // `accumulate` asks for (SDETR_MSDA_ACC_*; 0 = the library's default for the output type)
+    // `accumulate` asks for (SDETR_MSDA_ACC_*; SDETR_MSDA_ACC_DEFAULT = the library's choice for the output type)
+    if (accumulate < SDETR_MSDA_ACC_DEFAULT || accumulate > SDETR_MSDA_ACC_PACKED_LEVEL)
+        return fail("msda_bordered_forward: accumulate must be one of SDETR_MSDA_ACC_* (got %d)", accumulate);
     int pk = 0;
-    if (a.out_bf16) pk = kDefaultPackedAccumulate;
-    if (const char *e = getenv("SDETR_MSDA_PK")) pk = a.out_bf16 ? atoi(e) : 0;
-    if (pk < 0 || pk > 2) return fail("msda_bordered_forward: SDETR_MSDA_PK must be 0, 1 or 2");
+    if (a.out_bf16) pk = accumulate == SDETR_MSDA_ACC_DEFAULT ? kDefaultPackedAccumulate : accumulate;
     const int lds_bytes = a.res_px * 64 + kRWaves * kRWeightBytes;
 #define SDETR_B_LAUNCH(REF4, RES, SER, PERM)                                                                        \
     do {                                                                                                            \
@@ -1331,7 +1345,7 @@ extern "C" int sdetr_msda_bordered_forward(sdetr_stream_t stream, const void *va
     // Ablations for benchmarks/msda_bordered_ab.py (wrong results by construction): SDETR_MSDA_ABLATE = bit mask of
     // 1 no fine-level loads, 2 no LDS map reads, 4 no fine-level products, 8 no resident-level products, 16 every row
     // samples the same records
-    if (const char *e = getenv("SDETR_MSDA_ABLATE")) {
+    if (const char *e = ab_env("SDETR_MSDA_ABLATE")) {
         const int abl = atoi(e);
         if (abl && a.perm && res_levels == 2 && ref_dim == 2 && !a.image_serial) {
             switch (abl) {

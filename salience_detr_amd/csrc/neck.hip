@@ -925,7 +925,7 @@ extern "C" int sdetr_neck_pack_conv3x3_bf16(sdetr_stream_t stream, const float *
 static bool conv_lds_form()
 {
     static const bool on = [] {
-        const char *e = getenv("SDETR_CONV_LDS");
+        const char *e = ab_env("SDETR_CONV_LDS");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -936,7 +936,7 @@ static bool conv_lds_form()
 static int conv_tap_split(int64_t wave_tiles)
 {
     static const int pinned = [] {
-        const char *e = getenv("SDETR_CONV_SPLIT");
+        const char *e = ab_env("SDETR_CONV_SPLIT");
         const int v = e ? atoi(e) : 0;
         return (v == 1 || v == 3) ? v : 0;
     }();

@@ -318,7 +318,7 @@ static int stage1_lds_bytes(int tm) { return (tm * kXS + kParRows * kC + tm + 4)
 
 static int stage1_block_tokens(int batch_size, int tokens)
 {
-    static const int forced = [] { const char *e = getenv("SDETR_HEAD_ROWTILES"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char *e = ab_env("SDETR_HEAD_ROWTILES"); return e ? atoi(e) : 0; }();
     (void)batch_size; (void)tokens;
     return forced == 2 ? 64 : 32;
 }

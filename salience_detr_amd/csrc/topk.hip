@@ -624,7 +624,7 @@ static bool use_select(int n, int k)
 {
     // the shapes that used to take prefilter + rank (k well below n) and fit one workgroup: histogram sort in ONE launch
     // (SDETR_TOPK_SELECT=0: the two-launch path, for A/B runs)
-    static const bool enabled = [] { const char *e = getenv("SDETR_TOPK_SELECT"); return !(e && e[0] == '0'); }();
+    static const bool enabled = [] { const char *e = ab_env("SDETR_TOPK_SELECT"); return !(e && e[0] == '0'); }();
     if (!enabled) return false;
     return n >= 1024 && n <= kHsMaxN && (int64_t)k * 5 <= (int64_t)n * 2;
 }

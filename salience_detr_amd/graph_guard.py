@@ -10,30 +10,43 @@ has to happen inside a captured region must be a kernel (``tensor.zero_()`` / ``
 block, ``hipMemsetAsync`` and the semaphore reset of ATen's split reductions are not).
 """
 import ctypes
+import os
 from typing import List
 
 import torch
 
 _HIP_GRAPH_NODE_TYPE_MEMSET = 2          # hipGraphNodeTypeMemset (hip_runtime_api.h)
+_HIP_GRAPH_NODE_TYPE_GRAPH = 4           # hipGraphNodeTypeGraph: a child graph
 _hip_rt = None
+
+
+def _mapped_runtime_path():
+    """Path of the libamdhip64 ALREADY mapped into this process (the one torch's graphs belong to): handles of one
+    runtime instance must not be handed to a second copy loaded by an unversioned name."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64.so" in os.path.basename(path):
+                    return path
+    except OSError:
+        pass
+    return None
 
 
 def _runtime():
     global _hip_rt
     if _hip_rt is None:
-        # the HIP runtime torch itself is linked against (already mapped into the process)
-        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
-            try:
-                _hip_rt = ctypes.CDLL(name)
-                break
-            except OSError:
-                continue
-        if _hip_rt is None:
-            raise RuntimeError("graph_guard: the HIP runtime (libamdhip64.so) is not loadable")
+        path = _mapped_runtime_path()
+        if path is None:
+            raise RuntimeError("graph_guard: no libamdhip64 is mapped into this process (is torch's HIP runtime initialised?)")
+        _hip_rt = ctypes.CDLL(path)          # same inode as the mapped copy: the loader returns that instance
         _hip_rt.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
         _hip_rt.hipGraphGetNodes.restype = ctypes.c_int
         _hip_rt.hipGraphNodeGetType.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         _hip_rt.hipGraphNodeGetType.restype = ctypes.c_int
+        _hip_rt.hipGraphChildGraphNodeGetGraph.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        _hip_rt.hipGraphChildGraphNodeGetGraph.restype = ctypes.c_int
     return _hip_rt
 
 
@@ -45,8 +58,32 @@ def new_graph() -> "torch.cuda.CUDAGraph":
         return torch.cuda.CUDAGraph()
 
 
+def _graph_node_types(rt, handle, out: List[int], depth: int = 0) -> None:
+    n = ctypes.c_size_t(0)
+    status = rt.hipGraphGetNodes(ctypes.c_void_p(handle), None, ctypes.byref(n))
+    if status != 0:
+        raise RuntimeError(f"graph_guard: hipGraphGetNodes failed with status {status}")
+    if n.value == 0:
+        return
+    nodes = (ctypes.c_void_p * n.value)()
+    status = rt.hipGraphGetNodes(ctypes.c_void_p(handle), nodes, ctypes.byref(n))
+    if status != 0:
+        raise RuntimeError(f"graph_guard: hipGraphGetNodes failed with status {status}")
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        status = rt.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        if status != 0:
+            raise RuntimeError(f"graph_guard: hipGraphNodeGetType failed with status {status}")
+        out.append(t.value)
+        if t.value == _HIP_GRAPH_NODE_TYPE_GRAPH and depth < 8:      # a child graph's memsets count too
+            child = ctypes.c_void_p()
+            if rt.hipGraphChildGraphNodeGetGraph(ctypes.c_void_p(nodes[i]), ctypes.byref(child)) == 0 and child.value:
+                _graph_node_types(rt, child.value, out, depth + 1)
+
+
 def node_types(graph: "torch.cuda.CUDAGraph") -> List[int]:
-    """hipGraphNodeType of every top-level node of a captured graph (``new_graph()``); [] when torch exposes no handle."""
+    """hipGraphNodeType of every node of a captured graph (``new_graph()``), child graphs included; [] when torch exposes
+    no handle.  A failing runtime call raises (an empty list must mean "no handle", never "could not look")."""
     raw = getattr(graph, "raw_cuda_graph", None)
     if raw is None:
         return []
@@ -54,18 +91,8 @@ def node_types(graph: "torch.cuda.CUDAGraph") -> List[int]:
         handle = raw()
     except RuntimeError:     # created without keep_graph
         return []
-    rt = _runtime()
-    n = ctypes.c_size_t(0)
-    if rt.hipGraphGetNodes(ctypes.c_void_p(handle), None, ctypes.byref(n)) != 0 or n.value == 0:
-        return []
-    nodes = (ctypes.c_void_p * n.value)()
-    if rt.hipGraphGetNodes(ctypes.c_void_p(handle), nodes, ctypes.byref(n)) != 0:
-        return []
-    out = []
-    for i in range(n.value):
-        t = ctypes.c_int(-1)
-        rt.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
-        out.append(t.value)
+    out: List[int] = []
+    _graph_node_types(_runtime(), handle, out)
     return out
 
 

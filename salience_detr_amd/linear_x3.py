@@ -9,6 +9,7 @@ bf16 matrix cores divided by six.  ``use_x3_linear_(model)`` switches a model's 
 (same parameters, same ``state_dict`` keys); inputs that do not meet the kernel's alignment rules, CPU tensors and
 non-fp32 dtypes keep going through ``F.linear``.
 """
+import contextlib
 from typing import Optional
 
 import torch
@@ -68,6 +69,17 @@ def presplit(w: Tensor, transpose: bool = False) -> Tensor:
                                                  out.data_ptr())
     _hip.check(code, "presplit")
     return out
+
+
+@contextlib.contextmanager
+def pinned_generation(generation: int):
+    """Pins the kernel generation of this thread's ``gemm_x3`` calls (1 = 128 x 128 tiles, 2 = 256 x 128 tiles;
+    ``sdetr_gemm_x3_generation``) for the duration of the block: the parity tests run every shape on both."""
+    before = _hip.lib().sdetr_gemm_x3_generation(int(generation))
+    try:
+        yield
+    finally:
+        _hip.lib().sdetr_gemm_x3_generation(before)
 
 
 def gemm_x3_presplit_b(a: Tensor, a_kmajor: bool, b_planes: Tensor, M: int, N: int, K: int,

@@ -250,7 +250,8 @@ def resident_supported(value_hm: Tensor, level_shapes, num_levels: int, num_poin
 
 
 def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tensor, proj_hm: Tensor,
-                          out_dtype: Optional[torch.dtype] = None, chunks: int = 0) -> Tensor:
+                          out_dtype: Optional[torch.dtype] = None, chunks: int = 0,
+                          image_lanes: Optional[int] = None) -> Tensor:
     """``msda_fused_forward`` with the coarse levels served from LDS (csrc/msda_resident.hip): ``value_hm``
     ``[B,M,Nv,32]`` fp16, ``level_shapes`` HOST list of the four (h, w), ``reference_points`` ``[B,Nq,4,2|4]`` fp32,
     ``proj_hm`` the head-major bf16 projection slab ``[B,M,Nq,48]``.  ``chunks``: workgroups per (image, head),
@@ -281,10 +282,10 @@ def msda_resident_forward(value_hm: Tensor, level_shapes, reference_points: Tens
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_hm.device)
     hw = (ctypes.c_int32 * 8)(*[int(v) for s in level_shapes for v in s])
     with torch.cuda.device(out.device):
-        code = _hip.lib(proj_hm.dtype).sdetr_msda_resident_forward(
+        code = _hip.lib(proj_hm.dtype).sdetr_msda_resident_forward_ex(
             _hip.stream_ptr(), value_hm.data_ptr(), _hip.dtype_code(value_hm.dtype), hw, reference_points.data_ptr(),
             reference_points.shape[-1], ref_bs, proj_hm.data_ptr(), B, Nv, M, Nq, out.data_ptr(),
-            _hip.dtype_code(out_dtype), int(chunks))
+            _hip.dtype_code(out_dtype), int(chunks), -1 if image_lanes is None else int(image_lanes))
     _hip.check(code, "msda_resident_forward")
     return out
 
@@ -404,11 +405,18 @@ def tile_major_positions(level_shapes, tile: int = 16) -> Tensor:
     return _TILE_POS[key]
 
 
+ACC_DEFAULT, ACC_EXACT, ACC_PACKED_SAMPLE, ACC_PACKED_LEVEL = -1, 0, 1, 2      # SDETR_MSDA_ACC_* (include/salience_hip.h)
+
+
 def msda_bordered_forward(value_bordered: Tensor, level_shapes, reference_points: Tensor, proj_hm: Tensor,
                           row_order: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                          chunks: int = 0) -> Tensor:
+                          chunks: int = 0, accumulate: int = ACC_DEFAULT, image_lanes: Optional[int] = None,
+                          l2_warmup: Optional[int] = None) -> Tensor:
     """``msda_resident_forward`` on bordered maps ``[B,M,Np,32]`` fp16 (``to_bordered`` / the value projection's bordered
-    store); ``row_order`` optional int32 ``[B,Nq]`` permutation of the rows (processing order only)."""
+    store); ``row_order`` optional int32 ``[B,Nq]`` permutation of the rows (processing order only).  ``accumulate``
+    (``ACC_*``): how a 16-bit output's corner products are summed -- ``ACC_EXACT`` = fp32 as the reference's op,
+    ``ACC_DEFAULT`` = the library's choice for the activation type; ``image_lanes`` / ``l2_warmup``: launch choices
+    (``None`` = the library's rule), see ``sdetr_msda_bordered_forward_ex``."""
     import ctypes
     _hip.require_device("msda_bordered_forward", value_bordered=value_bordered, proj_hm=proj_hm)
     if reference_points.shape[-1] not in (2, 4):
@@ -437,10 +445,12 @@ def msda_bordered_forward(value_bordered: Tensor, level_shapes, reference_points
     out = torch.empty((B, Nq, M * D), dtype=out_dtype, device=value_bordered.device)
     hw = (ctypes.c_int32 * 8)(*[int(v) for s in level_shapes for v in s])
     with torch.cuda.device(out.device):
-        code = _hip.lib(proj_hm.dtype).sdetr_msda_bordered_forward(
+        code = _hip.lib(proj_hm.dtype).sdetr_msda_bordered_forward_ex(
             _hip.stream_ptr(), value_bordered.data_ptr(), _hip.dtype_code(value_bordered.dtype), hw,
             reference_points.data_ptr(), reference_points.shape[-1], ref_bs, proj_hm.data_ptr(), _hip.ptr(row_order),
-            (row_order.stride(0) if B > 1 else Nq) if row_order is not None else 0, B, Np, M, Nq, out.data_ptr(), _hip.dtype_code(out_dtype), int(chunks))
+            (row_order.stride(0) if B > 1 else Nq) if row_order is not None else 0, B, Np, M, Nq, out.data_ptr(),
+            _hip.dtype_code(out_dtype), int(chunks), int(accumulate), -1 if image_lanes is None else int(image_lanes),
+            -1 if l2_warmup is None else int(l2_warmup))
     _hip.check(code, "msda_bordered_forward")
     return out
 
@@ -796,7 +806,9 @@ class MultiScaleDeformableAttention(nn.Module):
             proj = token_linear(query, w, b, x_add=query_pos)
         elif query_pos is not None and rows_linear_applies(query, w, b) and query_pos.shape == query.shape:
             # a few thousand rows (the decoder's 900 queries per image): add + projection in one launch
-            proj = rows_linear(query, w, b, pos=query_pos, pos_features=w.shape[0])
+            # (every output sees x + pos; the kernel selects per 32-feature tile and accepts a count rounded up to the
+            # tile, so that output widths that are not multiples of 32 -- levels * points % 4 != 0 -- take it too: ADVICE r5)
+            proj = rows_linear(query, w, b, pos=query_pos, pos_features=(w.shape[0] + 31) // 32 * 32)
         else:
             proj = F.linear(query if query_pos is None else query + query_pos, w, b)
         out = msda_fused_forward(value_hm, spatial_shapes, level_start_index, reference_points, proj,

@@ -18,7 +18,6 @@ forward/backward op (``MultiScaleDeformableAttnFunction``).
 """
 import copy
 import math
-import os
 from typing import List, Optional
 
 import torch
@@ -453,8 +452,9 @@ class SalienceTransformerEncoder(nn.Module):
 
     # the value maps take the bordered layout (zero records around every level) and the deformable attention walks
     # its rows in a per-layer spatial order (csrc/msda_resident.hip, msda_bordered_kernel); False = round 3's plain maps
-    bordered_value_maps = os.environ.get("SDETR_BORDERED_MAPS", "1") != "0"          # (environment: A/B runs of bench.py)
-    row_order_tile = int(os.environ.get("SDETR_ROW_ORDER_TILE", "16"))
+    # (class attributes: an A/B script sets them on the class or an instance; nothing here reads the environment)
+    bordered_value_maps = True
+    row_order_tile = 16
 
     def project_values(self, value: Tensor, padding_mask: Optional[Tensor], level_shapes=None) -> Tensor:
         """Head-major value maps of ALL layers ``[num_layers,B,heads,Nv,D]`` (no-grad path).  The six layers sample

@@ -15,10 +15,10 @@ def _err(got, want64):
 
 
 @pytest.fixture(params=["128x128 tiles", "256x128 tiles"])
-def generation(request, monkeypatch):
-    """Every GEMM test runs on both kernel generations (the library picks by shape; SDETR_GEMM_X3_V1 forces one)."""
-    monkeypatch.setenv("SDETR_GEMM_X3_V1", "1" if request.param.startswith("128") else "0")
-    return request.param
+def generation(request):
+    """Every GEMM test runs on both kernel generations (the library picks by shape; ``pinned_generation`` pins one)."""
+    with X.pinned_generation(1 if request.param.startswith("128") else 2):
+        yield request.param
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 260, 256), (22726, 256, 2048), (4545, 384, 256), (4, 4, 4),

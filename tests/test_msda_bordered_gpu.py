@@ -47,22 +47,16 @@ def test_bordered_kernel_vs_oracle(B, Nq, levels, chunks, ref_dim):
     order = torch.stack([torch.randperm(Nq, generator=g) for _ in range(B)]).to(torch.int32).to(DEV)
     again = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.float32, chunks=chunks)
     assert torch.equal(again, out)
-    # bf16 output with the exact fp32 corner products (SDETR_MSDA_PK=0) = the fp32 result rounded
-    os.environ["SDETR_MSDA_PK"] = "0"
-    try:
-        b16 = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks)
-    finally:
-        del os.environ["SDETR_MSDA_PK"]
+    # bf16 output with the exact fp32 corner products (accumulate = ACC_EXACT) = the fp32 result rounded
+    b16 = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks,
+                                  accumulate=M.ACC_EXACT)
     assert torch.equal(b16, out.to(torch.bfloat16))
     # 16-bit outputs since round 5: a sample's four corners combined in packed fp16 (PK = 1; four fp16 roundings of every
     # interpolated sample on top of the maps' own), PK = 2 (the library's default for bf16 outputs): a level's four points too
-    for pk, bar_mean, bar_max in ((None, 1.5e-4, 4e-3), ("1", 4e-5, 1.5e-3), ("2", 1.5e-4, 4e-3)):
-        if pk is not None:
-            os.environ["SDETR_MSDA_PK"] = pk
-        try:
-            got = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks)
-        finally:
-            os.environ.pop("SDETR_MSDA_PK", None)
+    for pk, bar_mean, bar_max in ((M.ACC_DEFAULT, 1.5e-4, 4e-3), (M.ACC_PACKED_SAMPLE, 4e-5, 1.5e-3),
+                                  (M.ACC_PACKED_LEVEL, 1.5e-4, 4e-3)):
+        got = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, chunks=chunks,
+                                      accumulate=pk)
         # against the fp32 result, beyond the bf16 rounding of the output itself
         excess = ((got.float() - out).abs() - out.abs() * 2.0 ** -8).clamp_(min=0)
         assert excess.mean().item() < bar_mean and excess.max().item() < bar_max, (pk, excess.mean().item(), excess.max().item())
@@ -82,20 +76,19 @@ def test_bordered_spatial_row_order_is_a_permutation_that_groups_tiles():
         assert (walked[:, 1:] > walked[:, :-1]).all()
 
 
-@pytest.mark.parametrize("lanes", ["1", "2", "3", "5"])
+@pytest.mark.parametrize("lanes", [1, 2, 3, 5])
 @pytest.mark.parametrize("B,Nq,levels", [(5, 300, LEVELS_SMALL), (3, 1000, LEVELS_FULL), (4, 40, LEVELS_L3_ONLY)])
-def test_bordered_kernel_image_lanes(B, Nq, levels, lanes, monkeypatch):
+def test_bordered_kernel_image_lanes(B, Nq, levels, lanes):
     value, shapes, lsi, proj, ref = _case(B, Nq, levels, 2, seed=Nq + 7)
     _, hb = _maps(value, levels)
     slab = _head_major_slab(proj).to(DEV)
-    monkeypatch.setenv("SDETR_MSDA_IMAGE_SERIAL", "0")
-    want = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, out_dtype=torch.float32)
-    monkeypatch.setenv("SDETR_MSDA_IMAGE_SERIAL", lanes)
+    want = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, out_dtype=torch.float32, image_lanes=0)
     order = torch.stack([torch.randperm(Nq) for _ in range(B)]).to(torch.int32).to(DEV)
     for chunks in (0, 1, 5):
-        assert torch.equal(M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, out_dtype=torch.float32, chunks=chunks), want)
+        assert torch.equal(M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, out_dtype=torch.float32, chunks=chunks,
+                                                   image_lanes=lanes), want)
         assert torch.equal(M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.float32,
-                                                   chunks=chunks), want)
+                                                   chunks=chunks, image_lanes=lanes), want)
     expect = _expected(value.to(torch.float16).float(), shapes, lsi, ref, proj.float())
     assert np.abs(want.cpu().numpy() - expect).max() < TOL
 

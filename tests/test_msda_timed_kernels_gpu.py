@@ -113,9 +113,9 @@ def test_resident_kernel_vs_oracle(B, Nq, levels, chunks, ref_dim):
     assert (out - direct).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("lanes", ["1", "2", "3", "5"])
+@pytest.mark.parametrize("lanes", [1, 2, 3, 5])
 @pytest.mark.parametrize("B,Nq,levels", [(5, 300, LEVELS_SMALL), (3, 1000, LEVELS_FULL), (4, 40, LEVELS_L3_ONLY)])
-def test_resident_kernel_image_lanes(B, Nq, levels, lanes, monkeypatch):
+def test_resident_kernel_image_lanes(B, Nq, levels, lanes):
     """Large batches: a workgroup walks the images of its lane (g, g + G, ...) so that only G images' maps are gathered
     from at a time -- forced here on small batches (also with more lanes than images, with idle waves and with a
     partial last round); the same numbers as the one-image-per-workgroup form."""
@@ -123,11 +123,9 @@ def test_resident_kernel_image_lanes(B, Nq, levels, lanes, monkeypatch):
     Nv = value.shape[1]
     hm = M.value_to_head_major(value.view(B, Nv, HEADS * D).to(DEV), None, HEADS, torch.float16)
     slab = _head_major_slab(proj).to(DEV)
-    monkeypatch.setenv("SDETR_MSDA_IMAGE_SERIAL", "0")
-    want = M.msda_resident_forward(hm, levels, ref.to(DEV), slab, out_dtype=torch.float32)
-    monkeypatch.setenv("SDETR_MSDA_IMAGE_SERIAL", lanes)
+    want = M.msda_resident_forward(hm, levels, ref.to(DEV), slab, out_dtype=torch.float32, image_lanes=0)
     for chunks in (0, 1, 5):
-        got = M.msda_resident_forward(hm, levels, ref.to(DEV), slab, out_dtype=torch.float32, chunks=chunks)
+        got = M.msda_resident_forward(hm, levels, ref.to(DEV), slab, out_dtype=torch.float32, chunks=chunks, image_lanes=lanes)
         assert torch.equal(got, want)
     expect = _expected(value.to(torch.float16).float(), shapes, lsi, ref, proj.float())
     assert np.abs(want.cpu().numpy() - expect).max() < TOL
