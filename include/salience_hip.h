@@ -272,6 +272,18 @@ int sdetr_masked_topk_desc_f32(sdetr_stream_t stream, const float *score, const 
                                int64_t index_offset, float *out_score, int64_t *out_index,
                                int64_t out_row_stride, void *workspace, size_t workspace_bytes);
 
+/*   sdetr_masked_topk_sliced_f32 (round 6): the same top-k (fill_mode 2 semantics: masked entries compete with
+ *   *fill_value; ties -> lower position first; bit-identical results) for k a sizeable fraction of a long row, as two
+ *   chip-wide launches: the row is cut into `slices` (2..8) slices, every slice is sorted completely by rank counting,
+ *   the sorted slices are merged and the first k written.  Replaces torch.topk at salience_transformer.py:150 for the
+ *   finest level (6680 of 16 800 scores at 800 x 1333; 16 700 of 67 200 on the 5scale pyramid).
+ *   workspace: sdetr_topk_sliced_workspace_bytes(B, n) bytes.  score contiguous [B, n]. */
+size_t sdetr_topk_sliced_workspace_bytes(int batch_size, int n);
+int sdetr_masked_topk_sliced_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask, int64_t mask_row_stride,
+                                 const float *fill_value, int batch_size, int n, int k, int slices, int64_t index_offset,
+                                 float *out_score, int64_t *out_index, int64_t out_row_stride, void *workspace,
+                                 size_t workspace_bytes);
+
 /*   sdetr_merge_sorted_desc: stable descending sort of a [B,n] score array that is the concatenation of
  *   num_segments segments (host array segment_start, first = 0), each already sorted descending with ties in position
  *   order -- exactly what the per-level calls above leave in the column blocks of one buffer -- done as a merge

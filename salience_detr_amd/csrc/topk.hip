@@ -532,8 +532,11 @@ struct MergeArgs {
     const int64_t *payload;   // [B, n]
     int seg_start[kMaxSegments + 1];
     int nseg, n;
-    int64_t *out_index;       // [B, n]
-    float *out_score;         // [B, n] or NULL
+    int64_t *out_index;       // [B, limit], rows out_stride apart
+    float *out_score;         // the same or NULL
+    int limit;                // ranks below it are written (n: the whole merge)
+    int64_t out_stride;
+    int64_t index_offset;     // added to the payload
 };
 
 __global__ void __launch_bounds__(256) merge_sorted_kernel(MergeArgs p)
@@ -557,14 +560,15 @@ __global__ void __launch_bounds__(256) merge_sorted_kernel(MergeArgs p)
         }
         rank += lo - p.seg_start[s];
     }
-    const int64_t o = (int64_t)blockIdx.y * p.n + rank;
-    p.out_index[o] = p.payload[(int64_t)blockIdx.y * p.n + i];
+    if (rank >= p.limit) return;
+    const int64_t o = (int64_t)blockIdx.y * p.out_stride + rank;
+    p.out_index[o] = p.payload[(int64_t)blockIdx.y * p.n + i] + p.index_offset;
     if (p.out_score) p.out_score[o] = row[i];
 }
 
 // The same merge with the row's keys staged in LDS first (rows of up to kMergeLdsKeys keys): the binary searches are
 // chains of ~40 dependent reads per element -- from L2 that was the kernel's whole 13 us; from LDS ~2.
-constexpr int kMergeLdsKeys = 16384;
+constexpr int kMergeLdsKeys = 24576;   // 96 KB of keys (level 0 of the 800 x 1333 pyramid: 16 800)
 __global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
 {
     extern __shared__ uint32_t mkeys[];
@@ -588,8 +592,9 @@ __global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
         }
         rank += lo - p.seg_start[s];
     }
-    const int64_t o = (int64_t)blockIdx.y * p.n + rank;
-    p.out_index[o] = p.payload[(int64_t)blockIdx.y * p.n + i];
+    if (rank >= p.limit) return;
+    const int64_t o = (int64_t)blockIdx.y * p.out_stride + rank;
+    p.out_index[o] = p.payload[(int64_t)blockIdx.y * p.n + i] + p.index_offset;
     if (p.out_score) p.out_score[o] = row[i];
 }
 
@@ -807,6 +812,20 @@ static int masked_topk_impl(sdetr_stream_t stream, const float *score, const uin
     return check_launch("topk_rank");
 }
 
+static int launch_merge(hipStream_t stream, const MergeArgs &a, int B)
+{
+    const int n = a.n;
+    if (n <= kMergeLdsKeys) {
+        static DeviceOnce lds_once;
+        allow_dynamic_lds(merge_sorted_lds_kernel, lds_once, kMergeLdsKeys * 4);
+        hipLaunchKernelGGL(merge_sorted_lds_kernel, dim3((unsigned)((n + 1023) / 1024), (unsigned)B), dim3(1024), (size_t)n * 4,
+                           stream, a);
+        return check_launch("merge_sorted");
+    }
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, stream, a);
+    return check_launch("merge_sorted");
+}
+
 extern "C" int sdetr_merge_sorted_desc(sdetr_stream_t stream, const float *score, const int64_t *payload,
                                        const int *segment_start, int num_segments, int B, int n, int64_t *out_index,
                                        float *out_score)
@@ -816,6 +835,7 @@ extern "C" int sdetr_merge_sorted_desc(sdetr_stream_t stream, const float *score
     if (!score || !payload || !segment_start || !out_index) return fail("merge_sorted: null pointer");
     MergeArgs a{};
     a.score = score; a.payload = payload; a.nseg = num_segments; a.n = n; a.out_index = out_index; a.out_score = out_score;
+    a.limit = n; a.out_stride = n; a.index_offset = 0;
     for (int s = 0; s < num_segments; ++s) {
         a.seg_start[s] = segment_start[s];
         if (segment_start[s] < 0 || segment_start[s] > n || (s > 0 && segment_start[s] < segment_start[s - 1]))
@@ -823,14 +843,51 @@ extern "C" int sdetr_merge_sorted_desc(sdetr_stream_t stream, const float *score
     }
     if (segment_start[0] != 0) return fail("merge_sorted: the first segment starts at 0");
     a.seg_start[num_segments] = n;
-    if (n <= kMergeLdsKeys) {
-        static DeviceOnce lds_once;
-        allow_dynamic_lds(merge_sorted_lds_kernel, lds_once, kMergeLdsKeys * 4);
-        hipLaunchKernelGGL(merge_sorted_lds_kernel, dim3((unsigned)((n + 1023) / 1024), (unsigned)B), dim3(1024), (size_t)n * 4,
-                           static_cast<hipStream_t>(stream), a);
-        return check_launch("merge_sorted");
-    }
-    hipLaunchKernelGGL(merge_sorted_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a);
-    return check_launch("merge_sorted");
+    return launch_merge(static_cast<hipStream_t>(stream), a, B);
+}
+
+// Top-k with k a sizeable fraction of a long row, in two chip-wide launches (round 6; rounds 1-5: one histogram-sort
+// workgroup per row -- 36 us on 2 workgroups for the finest level of the 800 x 1333 pyramid, 6680 of 16 800 --, round 5's
+// python form of this for the 5scale pyramid: six launches).  The row is cut into `slices` <= 8 slices; launch 1 sorts
+// every slice completely by rank counting (the rank kernel on rows 1/slices as long: 1/slices of the comparisons, the
+// position payload and the strided mask handled in the kernel), launch 2 merges the sorted slices (stable in slice order,
+// i.e. ties stay in position order -- the tie rule of the one-launch forms) and writes the first k.  Masked entries
+// compete with *fill_value exactly as in sdetr_masked_topk_desc_f32 with fill_mode 2.
+extern "C" size_t sdetr_topk_sliced_workspace_bytes(int B, int n) { return B > 0 && n > 0 ? (size_t)B * n * 12 + 16 : 0; }
+
+extern "C" int sdetr_masked_topk_sliced_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                                            int64_t mask_row_stride, const float *fill_value, int B, int n, int k,
+                                            int slices, int64_t index_offset, float *out_score, int64_t *out_index,
+                                            int64_t out_row_stride, void *workspace, size_t workspace_bytes)
+{
+    if (B < 0 || n < 0 || k < 0) return fail("masked_topk_sliced: negative size");
+    if (k > n) return fail("masked_topk_sliced: k (%d) out of range for a row of %d scores", k, n);
+    if (slices < 2 || slices > kMaxSegments) return fail("masked_topk_sliced: 2 .. %d slices (got %d)", kMaxSegments, slices);
+    if (out_row_stride == 0) out_row_stride = k;
+    if (out_row_stride < k) return fail("masked_topk_sliced: output row stride too small");
+    if (mask && !fill_value) return fail("masked_topk_sliced: a mask needs the device scalar fill_value");
+    if (mask && mask_row_stride == 0) mask_row_stride = n;
+    if (mask && mask_row_stride < n) return fail("masked_topk_sliced: mask row stride too small");
+    if (B == 0 || k == 0) return 0;
+    if (!score || !out_index) return fail("masked_topk_sliced: null pointer");
+    if (n >= (1 << 30) || (int64_t)B * slices > 65535) return fail("masked_topk_sliced: row too long / too many rows");
+    if (!workspace || workspace_bytes < sdetr_topk_sliced_workspace_bytes(B, n))
+        return fail("masked_topk_sliced: needs %zu bytes of workspace, got %zu", sdetr_topk_sliced_workspace_bytes(B, n),
+                    workspace_bytes);
+    const int c = (n + slices - 1) / slices;
+    const int used = (n + c - 1) / c;   // slices that hold keys
+    int64_t *ws_pos = reinterpret_cast<int64_t *>(workspace);                    // [B, n] column of every sorted key
+    float *ws_score = reinterpret_cast<float *>(ws_pos + (size_t)B * n);         // [B, n] the sorted slices, back to back
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    RankArgs r{};
+    r.score = score; r.mask = mask; r.mask_stride = mask_row_stride; r.fill = mask ? fill_value : nullptr; r.N = n; r.k = c;
+    r.index_offset = 0; r.out_score = ws_score; r.out_index = ws_pos; r.out_stride = n; r.slices = used; r.slice_len = c;
+    hipLaunchKernelGGL(topk_rank_kernel, dim3((unsigned)((c + 63) / 64), (unsigned)(B * used)), dim3(kRankThreads), 0, hs, r);
+    if (int e = check_launch("topk_rank (slices)")) return e;
+    MergeArgs a{};
+    a.score = ws_score; a.payload = ws_pos; a.nseg = used; a.n = n; a.out_index = out_index; a.out_score = out_score;
+    a.limit = k; a.out_stride = out_row_stride; a.index_offset = index_offset;
+    for (int s = 0; s < used; ++s) a.seg_start[s] = s * c;
+    a.seg_start[used] = n;
+    return launch_merge(hs, a, B);
 }

@@ -38,6 +38,10 @@ struct RankArgs {
     float *out_score;
     int64_t *out_index;
     int64_t out_stride;   // elements between output rows (>= k)
+    // SLICED form (round 6, sdetr_masked_topk_sliced_f32): a "row" of the launch is slice s = row % slices of image
+    // row / slices -- keys [s * slice_len, min(N, (s + 1) * slice_len)) of that image's score row, sorted COMPLETELY into
+    // the same columns of the output row (position payload = column in the image row).  0 = off.
+    int slices, slice_len;
 };
 
 constexpr int kRankLdsWords = kRankTile + kRankWaves * 64;   // tile | partial
@@ -50,10 +54,13 @@ __device__ __forceinline__ void topk_rank_body(const RankArgs &p, int bx, int b,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = bx * 64;  // owned keys [base, base+64)
     const bool cand = p.cand_key != nullptr;
-    const int n_keys = cand ? p.cand_count[b] : p.N;  // length of the ranked list
+    const int img = p.slices ? b / p.slices : b;                          // image row the keys come from
+    const int col0 = p.slices ? (b - img * p.slices) * p.slice_len : 0;   // first column of this launch row in it
+    const int n_keys = cand ? p.cand_count[b] : (p.slices ? min(p.slice_len, p.N - col0) : p.N);  // length of the ranked list
     if (base >= n_keys) return;                        // uniform per workgroup
-    const float *srow = p.score + (int64_t)b * p.N;
-    const uint8_t *mrow = p.mask ? p.mask + (int64_t)b * p.mask_stride : nullptr;
+    const int k_row = p.slices ? n_keys : p.k;         // (a slice is sorted completely)
+    const float *srow = p.score + (int64_t)img * p.N + col0;
+    const uint8_t *mrow = p.mask ? p.mask + (int64_t)img * p.mask_stride + col0 : nullptr;
     const uint32_t *ckey = cand ? p.cand_key + (int64_t)b * p.N : nullptr;
     const float fill = p.fill ? *p.fill : 0.f;
     auto key_at = [&](int i) -> uint32_t {  // i < n_keys
@@ -130,10 +137,10 @@ __device__ __forceinline__ void topk_rank_body(const RankArgs &p, int bx, int b,
         uint32_t r = 0;
 #pragma unroll
         for (int w = 0; w < kRankWaves; ++w) r += partial[w * 64 + lane];
-        if (r < (uint32_t)p.k) {
-            const int pos = cand ? (int)p.cand_pos[(int64_t)b * p.N + mypos] : mypos;
-            if (p.out_score) p.out_score[(int64_t)b * p.out_stride + r] = undesc_bits(mine);
-            p.out_index[(int64_t)b * p.out_stride + r] =
+        if (r < (uint32_t)k_row) {
+            const int pos = cand ? (int)p.cand_pos[(int64_t)b * p.N + mypos] : mypos + col0;
+            if (p.out_score) p.out_score[(int64_t)img * p.out_stride + col0 + r] = undesc_bits(mine);
+            p.out_index[(int64_t)img * p.out_stride + col0 + r] =
                 p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
         }
     }

@@ -36,7 +36,8 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
         raise RuntimeError("masked_topk_desc: a mask requires fill_with_global_min=True")
     if mask is None and payload is None and out is None and N > _SELECT_MAX_ROW and 0 < k <= 2048 and k * 16 <= N:
         return _sliced_topk(score, k, int(index_offset), want_scores, orders_job)
-    if (N > _PREFILTER_MAX_ROW and k * 16 > N and payload is None and orders_job is None and score.is_contiguous()
+    if (((N > _PREFILTER_MAX_ROW and k * 16 > N) or (N >= _SLICED_MIN_ROW and k * 5 > N)) and payload is None
+            and orders_job is None and score.is_contiguous()
             and (mask is None or (fill_with_global_min and fill_value is not None))):
         return _sorted_slices_topk(score, k, mask, fill_value, int(index_offset), want_scores, out)
     mask_stride = 0
@@ -107,40 +108,51 @@ def _sliced_topk(score: Tensor, k: int, index_offset: int, want_scores: bool, or
 
 
 _PREFILTER_MAX_ROW = 24576   # longest row the sampled-threshold prefilter takes (csrc/topk.hip use_prefilter)
+_SLICED_MIN_ROW = 8192       # rows from here on with k > N / 5 take the two chip-wide launches of the sliced form
 _MERGE_SEGMENTS = 8          # csrc/topk.hip kMaxSegments
 
 
 def _sorted_slices_topk(score: Tensor, k: int, mask: Optional[Tensor], fill_value: Optional[Tensor], index_offset: int,
                         want_scores: bool, out):
-    """Top-k with k a sizeable fraction of a LONG row (round 5: the finest level of the reference's 5scale pyramid keeps
-    16 700 of 67 200 tokens, salience_transformer.py:146-150 -- beyond every single-workgroup form, so it went to the
-    chip-wide rank by counting: quadratic in the row, ~380 us there).  The row is cut into eight slices, every slice is
-    sorted completely (the same rank kernel, on rows an eighth as long: 1/8 of the comparisons), and the sorted slices are
-    merged (``merge_sorted_desc``: stable in slice order, i.e. ties stay in position order); the first k are the answer.
-    Masked entries compete with ``fill_value`` exactly as in the one-launch forms (the caller supplies the whole array's
-    minimum: a per-slice minimum would be a different number)."""
+    """Top-k with k a sizeable fraction of a LONG row -- the finest level of a pyramid (salience_transformer.py:146-150):
+    6680 of 16 800 scores at 800 x 1333 (rounds 1-5: one histogram-sort workgroup per image, 36 us on two workgroups),
+    16 700 of 67 200 on the reference's 5scale pyramid (beyond every single-workgroup form; the chip-wide rank by
+    counting is quadratic in the row, ~380 us there).  ``sdetr_masked_topk_sliced_f32``: the row is cut into eight slices,
+    every slice is sorted completely by the rank kernel (1/8 of the comparisons, all slices of all images in one
+    launch), and the sorted slices are merged (stable in slice order, i.e. ties stay in position order); the first k are
+    written straight into ``out``.  Masked entries compete with ``fill_value`` exactly as in the one-launch forms (the
+    caller supplies the whole array's minimum: a per-slice minimum would be a different number)."""
     B, N = score.shape
-    c = -(-N // _MERGE_SEGMENTS)        # (67 200 tokens: eight slices of 8400, nothing to pad)
-    S = -(-N // c)
-    pad = S * c - N
-    sp = torch.nn.functional.pad(score, (0, pad), value=float("-inf")) if pad else score
-    mp = None
+    mask_stride = 0
     if mask is not None:
-        mp = torch.nn.functional.pad(mask, (0, pad), value=False) if pad else mask.contiguous()
-        mp = mp.reshape(B * S, c)
-    v1, i1 = masked_topk_desc(sp.reshape(B * S, c), c, mask=mp, fill_with_global_min=mp is not None, fill_value=fill_value)
-    from . import pyramid
-    base = pyramid.static_tensor(("topk_sort_base", S, c, index_offset, str(score.device)),
-                                 lambda: (torch.arange(S, dtype=torch.int64) * c + index_offset).view(1, S, 1).to(score.device))
-    gidx = (i1.view(B, S, c) + base).view(B, S * c)
-    vs, idx = merge_sorted_desc(v1.view(B, S * c), gidx, [i * c for i in range(S)], want_scores=want_scores or out is not None)
+        if mask.shape != score.shape or not mask.is_cuda:
+            raise RuntimeError("masked_topk_desc: mask shape / device mismatch")
+        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        if N > 1 and mask.stride(1) != 1:
+            mask = mask.contiguous()
+        mask_stride = mask.stride(0) if B > 1 else N
     if out is not None:
         out_score, out_index = out
-        out_index.copy_(idx[:, :k])
-        if out_score is not None:
-            out_score.copy_(vs[:, :k])
-        return out_score, out_index
-    return (vs[:, :k].contiguous() if want_scores else None), idx[:, :k].contiguous()
+        if (tuple(out_index.shape) != (B, k) or out_index.dtype != torch.int64 or not out_index.is_cuda
+                or (k > 1 and out_index.stride(1) != 1)
+                or (out_score is not None and (tuple(out_score.shape) != (B, k) or out_score.dtype != torch.float32
+                                               or out_score.stride() != out_index.stride()))):
+            raise RuntimeError("masked_topk_desc: out must be ([B,k] fp32 | None, [B,k] int64) column slices of equal stride")
+        out_stride = out_index.stride(0) if B > 1 else k
+    else:
+        out_score = torch.empty((B, k), dtype=torch.float32, device=score.device) if want_scores else None
+        out_index = torch.empty((B, k), dtype=torch.int64, device=score.device)
+        out_stride = k
+    lib = _hip.lib()
+    ws_bytes = lib.sdetr_topk_sliced_workspace_bytes(B, N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=score.device)
+    with torch.cuda.device(score.device):
+        code = lib.sdetr_masked_topk_sliced_f32(
+            _hip.stream_ptr(), score.data_ptr(), _hip.ptr(mask), mask_stride, _hip.ptr(fill_value) if mask is not None else None,
+            B, N, k, _MERGE_SEGMENTS, int(index_offset), _hip.ptr(out_score), out_index.data_ptr(), out_stride,
+            ws.data_ptr(), ws_bytes)
+    _hip.check(code, "masked_topk_desc (sliced)")
+    return out_score, out_index
 
 
 class RankJob:

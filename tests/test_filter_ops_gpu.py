@@ -58,11 +58,14 @@ def test_long_rows_small_k_take_the_sliced_selection(B, N, k, kind):
     assert torch.equal(i.cpu(), ri + 11) and torch.equal(v.cpu(), rv) and torch.equal(i2.cpu(), ri)
 
 
-@pytest.mark.parametrize("B,N,k", [(1, 67200, 16700), (2, 67200, 16800), (2, 40000, 20000), (1, 89250, 89250), (2, 24577, 6000)])
+@pytest.mark.parametrize("B,N,k", [(1, 67200, 16700), (2, 67200, 16800), (2, 40000, 20000), (1, 89250, 89250), (2, 24577, 6000),
+                                   (2, 16800, 6680), (2, 16801, 6680), (1, 8192, 4000), (3, 8199, 8199), (2, 24576, 5000)])
 def test_long_rows_large_k_take_sorted_slices_and_a_merge(B, N, k):
-    """Round 5: the finest level of the reference's 5scale pyramid (top 16 700 of 67 200, mask + whole-array minimum as
-    fill, an index offset, outputs into column slices of wider buffers): eight fully sorted slices + a stable merge
-    (filter_ops._sorted_slices_topk) instead of the quadratic rank over the whole row -- bit-exact against the oracle."""
+    """The finest level of a pyramid (top 6680 of 16 800 at 800 x 1333 -- since round 6 --, 16 700 of 67 200 on the
+    reference's 5scale pyramid; mask + whole-array minimum as fill, an index offset, outputs into column slices of wider
+    buffers): eight fully sorted slices + a stable merge, two chip-wide launches (filter_ops._sorted_slices_topk ->
+    sdetr_masked_topk_sliced_f32) instead of one workgroup per row / the quadratic rank over the whole row -- bit-exact
+    against the oracle, rows that do not divide into eight equal slices included."""
     score = syn.det_randn(f"ls{N}", (B, N))
     n7 = score[:, 3::7].shape[1]
     score[:, ::7][:, :n7] = score[:, 3::7]                                  # exact duplicates across slices
