@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--x3-linear", dest="x3_linear", action="store_true", default=True,
                     help="train mode: weight gradients of the nn.Linear layers through sdetr_gemm_x3_f32 (default)")
     ap.add_argument("--no-x3-linear", dest="x3_linear", action="store_false")
+    ap.add_argument("--no-zero-arena", dest="zero_arena", action="store_false", default=True,
+                    help="training step: every zero-initialised buffer its own fill launch (the state before round 6), for A/B runs")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="train mode, one process: take the N > 1 execution path anyway (captured forward + backward + "
                          "gradient pack, eager flat all-reduce + optimizer) -- how that path is exercised on a 1-GPU box")
@@ -143,18 +145,26 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     # ground-truth boxes staged on the device once (the data loader's side); the target maps are built every step
     staged = criterion.stage_boxes(targets, sizes, device)
 
+    # every zero-initialised fp32 buffer of the step's autograd nodes (split-reduction outputs, weight / bias gradients,
+    # LayerNorm's dw | db, the MSDA backward's grad_value: ~150 per step) is a slice of ONE buffer cleared by ONE fill
+    # kernel at the start of the step (salience_detr_amd/zero_arena.py); the first warm-up step measures the demand
+    from salience_detr_amd.zero_arena import ZeroArena
+    import contextlib
+    arena = ZeroArena(device) if getattr(args, "zero_arena", True) else None
+
     def forward_backward():
         nonlocal w
         opt.zero_grad(set_to_none=True)
-        memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
-        if w is None:   # fixed weights of the synthetic loss on `memory` (name-seeded: the same on every run and rank)
-            w = syn.det_randn("bench.train.memory_weights", tuple(memory.shape)).to(memory.device)
-        # (the mean over `memory` as per-image column means + a 512-element mean: the framework's one-kernel reduction of
-        # 11 M elements clears its semaphores with a hipMemsetAsync that a replayed hipGraph does not reproduce here)
-        loss = replay_safe_mean(memory * w) + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
-        loss.backward()
-        if reducer is not None:
-            reducer.pack()
+        with (arena.step() if arena is not None else contextlib.nullcontext()):
+            memory, score_maps = model(feats, masks, pos, image_sizes=sizes, canvas=canvas)
+            if w is None:   # fixed weights of the synthetic loss on `memory` (name-seeded: the same on every run and rank)
+                w = syn.det_randn("bench.train.memory_weights", tuple(memory.shape)).to(memory.device)
+            # (the mean over `memory` as per-image column means + a 512-element mean: the framework's one-kernel reduction
+            # of 11 M elements clears its semaphores with a hipMemsetAsync that a replayed hipGraph does not reproduce here)
+            loss = replay_safe_mean(memory * w) + criterion(score_maps, targets, strides, sizes, staged=staged)["loss_salience"]
+            loss.backward()
+            if reducer is not None:
+                reducer.pack()
         # (detached: a loss that keeps its autograd graph alive across iterations keeps the AccumulateGrad nodes of the
         # first iteration -- created on the default stream -- alive too, and the capture then records the gradient
         # accumulation on another stream than the kernels that produce the gradients)
@@ -331,6 +341,10 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
                                   "forward + backward" if use_ranks_path else "single GPU",
                    "grad_bytes": reducer.num_bytes if reducer is not None else sum(p.numel() * 4 for p in params),
                    "execution": graph_note, "x3_linear": bool(args.x3_linear), "world_size": world,
+                   "hipgraph_nodes": CAPTURE_INFO.get("graph_nodes") if graph is not None else None,
+                   "zero_arena": (None if arena is None else
+                                  {"bytes": 0 if arena.buf is None else int(arena.buf.numel() * 4),
+                                   "buffers_served_per_step": int(arena.fills_saved)}),
                    "backend": (dist.get_backend() if dist is not None else "none (single process)")},
         "roofline": {"kernel": "MSDA backward op: sdetr::bt_main_kernel (fixed-point LDS windows) + bucketing, "
                                "sdetr::msda_col2im_chan_kernel below 1200 queries", "bound": "hbm",
@@ -1180,6 +1194,8 @@ def main():
             tr = train_record(args, tmodel, device, rank, world, dist, args.train_steps, 2)
             result["train_step"] = {"ms_per_step": tr["ms_per_step"], "images_per_s": tr["value"], "steps": tr["steps"],
                                     "dtype": tr["dtype"], "execution": tr["config"]["execution"],
+                                    "hipgraph_nodes": tr["config"].get("hipgraph_nodes"),
+                                    "zero_arena": tr["config"].get("zero_arena"),
                                     "grad_bytes": tr["config"]["grad_bytes"], "msda_backward_roofline": tr["roofline"],
                                     "loss": tr["loss"], "workload": tr["config"]["workload"]}
             del tmodel

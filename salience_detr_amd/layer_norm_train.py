@@ -13,7 +13,7 @@ import torch
 from torch import Tensor, nn
 from torch.autograd import Function
 
-from . import _hip
+from . import _hip, zero_arena
 
 
 def applies(x: Tensor, norm: nn.LayerNorm, residual: Optional[Tensor] = None) -> bool:
@@ -51,7 +51,7 @@ class _AddLayerNorm(Function):
         rows, C = z.shape
         g2 = gy.contiguous().view(rows, C)
         dz = torch.empty_like(z)
-        dwb = torch.zeros((2, C), dtype=torch.float32, device=z.device)
+        dwb = zero_arena.zeros((2, C), dtype=torch.float32, device=z.device)
         with torch.cuda.device(z.device):
             code = _hip.lib().sdetr_layer_norm_train_backward_f32(
                 _hip.stream_ptr(), g2.data_ptr(), z.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), w.data_ptr(),

@@ -18,6 +18,7 @@ from torch.autograd import Function
 from torch.nn import functional as F
 
 from . import _hip
+from .zero_arena import zeros as _zeros
 
 
 EPI_NONE, EPI_RELU, EPI_GATE = 0, 1, 2   # SDETR_GEMM_EPI_* (include/salience_hip.h)
@@ -41,7 +42,7 @@ def gemm_x3(a: Tensor, a_kmajor: bool, b: Tensor, b_kmajor: bool, M: int, N: int
     if tuple(a.shape) != ((M, K) if a_kmajor else (K, M)) or tuple(b.shape) != ((N, K) if b_kmajor else (K, N)):
         raise RuntimeError("gemm_x3: operand shapes do not match (M, N, K) and the layouts")
     if out is None:
-        c = (torch.zeros if reduction_splits > 1 else torch.empty)((M, N), dtype=torch.float32, device=a.device)
+        c = (_zeros if reduction_splits > 1 else torch.empty)((M, N), dtype=torch.float32, device=a.device)
     else:   # a contiguous fp32 buffer of M * N elements in any shape (zeroed by the caller for a split reduction)
         if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != M * N or out.device != a.device:
             raise RuntimeError("gemm_x3: out must be a contiguous fp32 tensor of M * N elements on the operands' device")
@@ -164,7 +165,7 @@ class _LinearX3(Function):
         T, N = x2.shape[0], weight.shape[0]
         use_x3 = X3_FORWARD and K % 8 == 0 and _x3_wide(T, N, K)
         splits = _reduction_splits(T, N, K) if use_x3 else 1
-        y = (torch.zeros if splits > 1 else torch.empty)(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        y = (_zeros if splits > 1 else torch.empty)(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         y2 = y.view(T, N)
         if use_x3:   # y = x w^T (the weight is split on its way into LDS)
             gemm_x3(x2, True, weight, True, T, N, K, bias=bias, reduction_splits=splits, out=y2)
@@ -189,7 +190,7 @@ class _LinearX3(Function):
                 # dx = dy w (the weight read reduction-major: no transposed split pass)
                 sp = _reduction_splits(T, K, N)
                 gx = gemm_x3(g2, True, weight, False, T, K, N, reduction_splits=sp,
-                             out=torch.zeros((T, K), dtype=g2.dtype, device=g2.device) if sp > 1 else None)
+                             out=_zeros((T, K), dtype=g2.dtype, device=g2.device) if sp > 1 else None)
             else:
                 gx = g2 @ weight
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
@@ -199,10 +200,10 @@ class _LinearX3(Function):
                 out = None
                 if want_gb:   # the kernel has dy's tiles in registers anyway: the bias gradient is their row sums
                     # (one zero fill for both gradients: the split reduction adds into dw as the row sums add into db)
-                    buf = torch.zeros(N * K + N, dtype=torch.float32, device=g2.device)
+                    buf = _zeros(N * K + N, dtype=torch.float32, device=g2.device)
                     out, gb = buf[:N * K].view(N, K), buf[N * K:]
                 elif splits > 1:
-                    out = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
+                    out = _zeros((N, K), dtype=torch.float32, device=g2.device)
                 gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=splits, out=out, a_row_sum=gb)
                 if out is not None:
                     gw = out
@@ -221,10 +222,10 @@ def _weight_and_bias_grad(g2: Tensor, x2: Tensor, want_gb: bool):
     splits = _weight_grad_splits(T, N, K)
     out = gb = None
     if want_gb:
-        buf = torch.zeros(N * K + N, dtype=torch.float32, device=g2.device)
+        buf = _zeros(N * K + N, dtype=torch.float32, device=g2.device)
         out, gb = buf[:N * K].view(N, K), buf[N * K:]
     elif splits > 1:
-        out = torch.zeros((N, K), dtype=torch.float32, device=g2.device)
+        out = _zeros((N, K), dtype=torch.float32, device=g2.device)
     gw = gemm_x3(g2, False, x2, False, N, K, T, reduction_splits=splits, out=out, a_row_sum=gb)
     return (gw if out is None else out), gb
 
@@ -248,7 +249,7 @@ class _FfnX3(Function):
             h.clamp_min_(0.0)
         use_x3 = X3_FORWARD and Fh % 8 == 0 and _x3_wide(T, N, Fh)
         splits = _reduction_splits(T, N, Fh) if use_x3 else 1
-        y = (torch.zeros if splits > 1 else torch.empty)(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        y = (_zeros if splits > 1 else torch.empty)(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
         y2 = y.view(T, N)
         if use_x3:
             gemm_x3(h, True, w2, True, T, N, Fh, bias=b2, reduction_splits=splits, out=y2)
@@ -287,7 +288,7 @@ class _FfnX3(Function):
                 if X3_DX and Fh % 8 == 0 and _x3_wide(T, K, Fh):
                     sp = _reduction_splits(T, K, Fh)
                     gx = gemm_x3(dh, True, w1, False, T, K, Fh, reduction_splits=sp,
-                                 out=torch.zeros((T, K), dtype=dh.dtype, device=dh.device) if sp > 1 else None)
+                                 out=_zeros((T, K), dtype=dh.dtype, device=dh.device) if sp > 1 else None)
                 else:
                     gx = dh @ w1
                 gx = gx.view(ctx.x_shape)

@@ -105,7 +105,8 @@ def ms_deform_attn_backward(value: Tensor, spatial_shapes: Tensor, level_start_i
     _hip.require_device("ms_deform_attn_backward", grad_output=grad_output)
     if grad_output.dtype != value.dtype or grad_output.numel() != B * Nq * M * D:
         raise RuntimeError("ms_deform_attn_backward: grad_output must be [B, Nq, M*D] of value's dtype")
-    grad_value = torch.zeros_like(value)
+    from . import zero_arena
+    grad_value = zero_arena.zeros_like(value)   # (the op accumulates into it; inside a ZeroArena step: a slice of the step's one fill)
     grad_loc = torch.empty_like(sampling_loc)
     grad_aw = torch.empty_like(attn_weight)
     lib = _hip.lib()
