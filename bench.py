@@ -24,6 +24,7 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+PROFILE_ROUND = "r06"   # profiles/<round>_msda_{traffic,rocprof,clock,bwd_traffic}.json: the source-tagged counter / trace records the line quotes
 sys.path.insert(0, ROOT)
 
 from salience_detr_amd import ms_deform_attn as msda_mod  # noqa: E402
@@ -314,17 +315,17 @@ def train_record(args, model, device, rank, world, dist, steps, warmup, force_di
     achieved = sum(nbytes) / tot_us / 1e3
     # HBM bytes of the op at the LARGEST layer (11 363 queries, batch 2) from committed counter passes, reported only while
     # the backward kernels' sources are the ones the passes ran on
-    bwd_traffic, bwd_traffic_at, bwd_traffic_src = None, None, "null: no committed counter passes (profiles/r05_msda_bwd_traffic.json)"
+    bwd_traffic, bwd_traffic_at, bwd_traffic_src = None, None, "null: no committed counter passes (profiles/%s_msda_bwd_traffic.json)" % PROFILE_ROUND
     try:
         import hashlib
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_msda_bwd_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_msda_bwd_traffic.json")))
         h = hashlib.sha256()
         for f in tj["sources"]:
             h.update(open(os.path.join(ROOT, f), "rb").read())
         if h.hexdigest()[:16] == tj["source_tag"] and tj["batch"] == args.batch:
             bwd_traffic = int(tj["hbm_bytes_per_op"])
             bwd_traffic_at = {"num_query": tj["num_query"], "algorithmic_bytes": max(nbytes) if nbytes else None}
-            bwd_traffic_src = "profiles/r05_msda_bwd_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the op at %d queries, sources %s)" % (tj["num_query"], tj["source_tag"])
+            bwd_traffic_src = "profiles/%s_msda_bwd_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the op at %d queries, sources %s)" % (PROFILE_ROUND, tj["num_query"], tj["source_tag"])
         else:
             bwd_traffic_src = "null: committed passes were measured on other kernel sources or another batch size"
     except (OSError, KeyError, ValueError):
@@ -1039,12 +1040,12 @@ def main():
     traffic, traffic_src = None, None
     tag = kernel_source_tag()
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_msda_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_msda_traffic.json")))
         nqs = launch_nq[:nl]
         if (tj.get("kernel_source_tag") == tag and args.dtype == "bf16" and args.value_dtype == tj.get("value_dtype", "same")
                 and args.batch == tj["batch"] and all(str(n) in tj["per_num_query"] for n in nqs)):
             traffic = int(sum(tj["per_num_query"][str(n)]["hbm_bytes"] for n in nqs) / nl)
-            traffic_src = "profiles/r05_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % tag
+            traffic_src = "profiles/%s_msda_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel sources %s)" % (PROFILE_ROUND, tag)
         else:
             traffic_src = "null: committed PMC passes were measured on other kernel sources (%s) than these (%s)" % (
                 tj.get("kernel_source_tag"), tag)
@@ -1055,10 +1056,10 @@ def main():
     # medians scatter around it by a few percent), reported next to them; null when the sources have changed since
     rocprof_us, rocprof_src = None, "null: no rocprofv3 summary committed for these kernel sources"
     try:
-        rj = json.load(open(os.path.join(ROOT, "profiles", "r05_msda_rocprof.json")))
+        rj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_msda_rocprof.json")))
         if rj.get("kernel_source_tag") == tag and rj.get("batch") == args.batch:
             rocprof_us = rj["avg_launch_us"]
-            rocprof_src = "profiles/r05_msda_rocprof.json (%s)" % rj.get("source", "rocprofv3 --kernel-trace --stats")
+            rocprof_src = "profiles/%s_msda_rocprof.json (%s)" % (PROFILE_ROUND, rj.get("source", "rocprofv3 --kernel-trace --stats"))
     except (OSError, ValueError, KeyError):
         pass
     # The vector-ALU side of the same launches (the counters name vector-ALU issue, not HBM, as the busiest
@@ -1072,9 +1073,9 @@ def main():
     clk_peak = float(getattr(props, "clock_rate", 2400000)) / 1e6       # GHz
     clk_meas, clk_src = None, "null: no counter pass committed for these kernel sources"
     try:
-        cj = json.load(open(os.path.join(ROOT, "profiles", "r05_msda_clock.json")))
+        cj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_msda_clock.json")))
         if cj.get("kernel_source_tag") == tag:
-            clk_meas, clk_src = cj["shader_clock_ghz"], "profiles/r05_msda_clock.json (%s)" % cj.get("source", "SQ_BUSY_CYCLES / duration")
+            clk_meas, clk_src = cj["shader_clock_ghz"], "profiles/%s_msda_clock.json (%s)" % (PROFILE_ROUND, cj.get("source", "SQ_BUSY_CYCLES / duration"))
     except (OSError, ValueError, KeyError):
         pass
     # (the library's default accumulation form for the activation type: include/salience_hip.h SDETR_MSDA_ACC_DEFAULT)
@@ -1118,7 +1119,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
         # `bound` names the roofline `frac` is taken against (the graded figure).  What the COUNTERS show as
         # the limit of this kernel is not HBM (traffic ~1.2x algorithmic at a quarter of the bandwidth): vector-ALU issue,
-        # the L1's 64 B/clk/CU and the LDS each run at 50-85 % (profiles/r05_msda_pmc.md); `valu` is that roofline.
+        # the L1's 64 B/clk/CU and the LDS each run at 50-85 % (profiles/r06_msda_pmc.md); `valu` is that roofline.
         "measured_limiter": "vector-ALU issue + L1 (64 B/clk/CU) + LDS, none saturated alone; not HBM",
         "valu": valu,
         "traffic_source": traffic_src, "kernel_source_tag": tag, "algorithmic_bytes_per_launch": int(total_bytes / nl),

@@ -7,11 +7,11 @@
 # (The survey's full CPU-baseline protocol -- minutes of host time -- runs last when FULL_CPU=1:
 # `python bench.py --cpu-protocol full` -> <tag>_bench_cpu_full.json.)
 set -u
-R=${1:-r05}
+R=${1:-r06}
 O=$PWD/gpurun_out
 mkdir -p $O profiles
 export TMPDIR=/tmp
-# 1. PMC traffic passes first: the bench line's roofline.traffic is read from profiles/r05_msda_traffic.json
+# 1. PMC traffic passes first: the bench line's roofline.traffic is read from profiles/${R}_msda_traffic.json
 python bench.py --no-cpu-baseline --train-steps 0 --in-flight-report 0 --config-steps 0 > $O/${R}_bench_quick.json 2> $O/${R}_bench_quick.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${R}_pmc_$c -o p -- \
@@ -20,13 +20,13 @@ done
 F=$(find $O/${R}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find $O/${R}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 python benchmarks/pmc_to_traffic.py $F $W $O/${R}_bench_quick.json $O/${R}_msda_traffic.json && \
-  cp $O/${R}_msda_traffic.json profiles/r05_msda_traffic.json      # (this box's copy: what the bench run below reads)
+  cp $O/${R}_msda_traffic.json profiles/${R}_msda_traffic.json      # (this box's copy: what the bench run below reads)
 rm -rf $O/${R}_pmc_FETCH_SIZE $O/${R}_pmc_WRITE_SIZE
-#    ... and the backward op's counters (the train_step record reads profiles/r05_msda_bwd_traffic.json)
+#    ... and the backward op's counters (the train_step record reads profiles/${R}_msda_bwd_traffic.json)
 bash benchmarks/pmc_msda_bwd.sh ${R} 11363 2 > /dev/null 2>&1
-cp $O/${R}_msda_bwd_traffic.json profiles/r05_msda_bwd_traffic.json 2> /dev/null
+cp $O/${R}_msda_bwd_traffic.json profiles/${R}_msda_bwd_traffic.json 2> /dev/null
 # 2. the kernel summary of the plain timed loop (six layers in equal proportion) FIRST: the bench line's
-#    roofline.timing_rocprof_us is read from profiles/r05_msda_rocprof.json; then the official bench line (with the
+#    roofline.timing_rocprof_us is read from profiles/${R}_msda_rocprof.json; then the official bench line (with the
 #    train_step sub-record, the config sub-records and the CPU baseline)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof -o p -- python bench.py --plain --steps 50 > $O/${R}_bench_profiled.json 2> $O/${R}_prof.err
 cp $(find $O/${R}_prof -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv
@@ -45,7 +45,7 @@ json.dump({"source": "rocprofv3 --kernel-trace over `python bench.py --plain --s
            "per_layer_us": per_layer, "batch": 2, "kernel_source_tag": bench.kernel_source_tag()}, open(sys.argv[2], "w"), indent=1)
 print(open(sys.argv[2]).read())
 PY
-cp $O/${R}_msda_rocprof.json profiles/r05_msda_rocprof.json
+cp $O/${R}_msda_rocprof.json profiles/${R}_msda_rocprof.json
 rm -rf $O/${R}_prof
 python bench.py --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/${R}_bench.err
 tail -c 300 $O/${R}_bench.json
@@ -78,7 +78,7 @@ if ghz:
               open(out, "w"), indent=1)
     print(open(out).read())
 PY
-cp $O/${R}_msda_clock.json profiles/r05_msda_clock.json 2> /dev/null
+cp $O/${R}_msda_clock.json profiles/${R}_msda_clock.json 2> /dev/null
 rm -rf $O/${R}_pmc_[1-5]
 # 4. MFMA-busy counters of the dense kernels
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES \

@@ -407,12 +407,16 @@ int sdetr_encoder_reference_points(sdetr_stream_t stream, const float *valid_rat
  *     index[b][i] (i < rows; images index_batch_stride apart): query_out / pos_out [batch, rows, row_bytes] = the
  *     tokens' rows of `tokens` / `pos` [batch, S, row_bytes] (the gathers of salience_transformer.py:454-461),
  *     score_out [batch, rows] = score[b][index] (NULL: skipped) and reference_points_out [batch, rows, num_levels, 2]
- *     as sdetr_encoder_reference_points.  row_bytes = 16 * (a divisor of 256). */
+ *     as sdetr_encoder_reference_points.  row_bytes = 16 * (a divisor of 256).
+ *     score_mask / score_mins (round 6, both or neither): `score` is the UNFILLED flattened salience score and the gather
+ *     applies sdetr_masked_fill_min on the fly -- score_out = score_mask[b][index] ? min(score_mins[0..num_mins)) :
+ *     score[b][index] (foreground_score of salience_transformer.py:164-168 restricted to the rows the encoder reads). */
 int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes,
                                  const float *score, const int64_t *index, int64_t index_batch_stride, int batch_size,
                                  int spatial_size, int rows, const float *valid_ratios, const int64_t *shapes,
                                  const int64_t *level_start_index, int num_levels, void *query_out, void *pos_out,
-                                 float *score_out, float *reference_points_out);
+                                 float *score_out, float *reference_points_out, const uint8_t *score_mask,
+                                 const float *score_mins, int num_mins);
 int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
                           int64_t scale_batch_stride, int batch_size, int rows_per_batch, int num_classes, float *out);
 

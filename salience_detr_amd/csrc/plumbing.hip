@@ -284,6 +284,9 @@ struct PrepareArgs {
     uint4 *q_out, *pos_out;          // [B, n, vec_per_row]
     float *score_out;                // [B, n] or NULL
     float *ref_out;                  // [B, n, L, 2]
+    const uint8_t *score_mask;       // [B, S] or NULL: masked tokens take min(score_mins) instead of their score
+    const float *score_mins;         // [num_mins]
+    int num_mins;
 };
 
 // One row per 16-byte-piece group and pass.  Round 4: 32-bit row arithmetic (the 64-bit division per lane was ~150
@@ -303,6 +306,11 @@ __global__ void __launch_bounds__(256) encoder_prepare_kernel(PrepareArgs p)
         geo[2 * kMaxLevels + threadIdx.x] = (int)p.shapes[2 * threadIdx.x];
     }
     __syncthreads();
+    float fill = 0.f;   // masked_fill(mask, score.min()) of salience_transformer.py:168: the minimum of the level minima
+    if (p.score_mask) {
+        fill = p.score_mins[0];
+        for (int l = 1; l < p.num_mins; ++l) fill = fminf(fill, p.score_mins[l]);
+    }
     const uint32_t total = (uint32_t)p.B * (uint32_t)p.n, n = (uint32_t)p.n;
     const uint32_t per_block = 256u / (uint32_t)p.vec_per_row;      // rows per block pass (vec_per_row divides 256)
     const uint32_t sub = threadIdx.x / (uint32_t)p.vec_per_row, c = threadIdx.x - sub * (uint32_t)p.vec_per_row;
@@ -322,12 +330,14 @@ __global__ void __launch_bounds__(256) encoder_prepare_kernel(PrepareArgs p)
         }
         uint4 qv[kPrepRows], pv[kPrepRows];
         float sc[kPrepRows], centre_px[kPrepRows], size[kPrepRows], va[kPrepRows], vb[kPrepRows];
+        uint8_t mk[kPrepRows];
 #pragma unroll
         for (int u = 0; u < kPrepRows; ++u) {
             const uint32_t src = (bi[u] * (uint32_t)p.S + (uint32_t)tok[u]) * (uint32_t)p.vec_per_row + c;
             qv[u] = p.tokens[src];
             pv[u] = p.pos[src];
             sc[u] = (c == 0 && p.score_out) ? p.score[bi[u] * (uint32_t)p.S + (uint32_t)tok[u]] : 0.f;
+            mk[u] = (c == 0 && p.score_out && p.score_mask) ? p.score_mask[bi[u] * (uint32_t)p.S + (uint32_t)tok[u]] : (uint8_t)0;
             centre_px[u] = size[u] = va[u] = vb[u] = 1.f;
             if (ref_lane) {
                 int l = 0;
@@ -348,7 +358,7 @@ __global__ void __launch_bounds__(256) encoder_prepare_kernel(PrepareArgs p)
             if (!ok[u]) continue;
             p.q_out[(int64_t)row[u] * p.vec_per_row + c] = qv[u];
             p.pos_out[(int64_t)row[u] * p.vec_per_row + c] = pv[u];
-            if (c == 0 && p.score_out) p.score_out[row[u]] = sc[u];
+            if (c == 0 && p.score_out) p.score_out[row[u]] = mk[u] ? fill : sc[u];
             if (ref_lane) p.ref_out[(int64_t)row[u] * p.L * 2 + c] = centre_px[u] / (va[u] * size[u]) * vb[u];
         }
     }
@@ -362,7 +372,8 @@ extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *t
                                             const float *score, const int64_t *index, int64_t index_batch_stride,
                                             int batch_size, int spatial_size, int rows, const float *valid_ratios,
                                             const int64_t *shapes, const int64_t *level_start_index, int num_levels,
-                                            void *query_out, void *pos_out, float *score_out, float *reference_points_out)
+                                            void *query_out, void *pos_out, float *score_out, float *reference_points_out,
+                                            const uint8_t *score_mask, const float *score_mins, int num_mins)
 {
     if (batch_size < 0 || spatial_size < 0 || rows < 0 || num_levels <= 0 || num_levels > kMaxLevels)
         return fail("encoder_prepare: bad sizes");
@@ -371,6 +382,8 @@ extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *t
     if (!tokens || !pos || !index || !valid_ratios || !shapes || !level_start_index || !query_out || !pos_out || !reference_points_out)
         return fail("encoder_prepare: null pointer");
     if (score_out && !score) return fail("encoder_prepare: score_out without score");
+    if ((score_mask != nullptr) != (score_mins != nullptr) || (score_mask && (num_mins <= 0 || !score_out)))
+        return fail("encoder_prepare: score_mask and score_mins (num_mins > 0) come together, with a score output");
     if (index_batch_stride < rows) return fail("encoder_prepare: index batch stride too small");
     if (2 * num_levels > row_bytes / 16) return fail("encoder_prepare: rows of at least 32 bytes per level expected");
     if ((int64_t)batch_size * rows >= ((int64_t)1 << 30) || (int64_t)batch_size * spatial_size * (row_bytes / 16) >= ((int64_t)1 << 31))
@@ -380,6 +393,7 @@ extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *t
     a.index_batch_stride = index_batch_stride; a.vr = valid_ratios; a.shapes = shapes; a.lsi = level_start_index;
     a.B = batch_size; a.S = spatial_size; a.n = rows; a.L = num_levels; a.vec_per_row = row_bytes / 16;
     a.q_out = (uint4 *)query_out; a.pos_out = (uint4 *)pos_out; a.score_out = score_out; a.ref_out = reference_points_out;
+    a.score_mask = score_mask; a.score_mins = score_mins; a.num_mins = num_mins;
     const int per_block = 256 / a.vec_per_row;
     int64_t blocks = ((int64_t)batch_size * rows + per_block * kPrepRows - 1) / (per_block * kPrepRows);
     if (blocks > 8192) blocks = 8192;

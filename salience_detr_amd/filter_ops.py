@@ -1492,12 +1492,41 @@ def box_refine(delta: Tensor, reference_points: Tensor, eps: float = 1e-3) -> Te
     return out
 
 
-def encoder_prepare_sorted(tokens: Tensor, pos: Tensor, score: Optional[Tensor], sorted_index: Tensor, valid_ratios: Tensor,
+class LazyForegroundScore:
+    """``foreground_score = masked_fill(flatten(salience maps), mask, min)`` (salience_transformer.py:164-168) NOT yet
+    materialised: the flattened scores, the padding mask and the per-level minima.  The sorted-order encoder loop only
+    reads the score of the rows it gathers, so ``encoder_prepare_sorted`` applies the fill to those rows on the fly (one
+    launch less in the hot path); ``materialize()`` gives the ``[B,S]`` tensor of the reference (``masked_fill_min``)."""
+
+    def __init__(self, score_flat: Tensor, mask: Tensor, level_min: Tensor):
+        self.score_flat, self.mask, self.level_min = score_flat, mask, level_min
+        self.dtype, self.shape, self.device = score_flat.dtype, score_flat.shape, score_flat.device
+        self._full = None
+
+    def is_contiguous(self) -> bool:
+        return True
+
+    def materialize(self) -> Tensor:
+        if self._full is None:
+            self._full = masked_fill_min(self.score_flat, self.mask, self.level_min)
+        return self._full
+
+
+def encoder_prepare_sorted(tokens: Tensor, pos: Tensor, score, sorted_index: Tensor, valid_ratios: Tensor,
                            spatial_shapes: Tensor, level_start_index: Tensor):
     """Entry of the sorted-order encoder loop in one launch: ``(tokens[b, idx], pos[b, idx], score[b, idx],
     reference points of idx)`` for ``idx = sorted_index`` ``[B,n]`` -- the two row gathers of
-    salience_transformer.py:454-461, the score gather and ``get_reference_points`` (:418-432) restricted to them."""
-    _hip.require_device("encoder_prepare_sorted", tokens=tokens, pos=pos, score=score, valid_ratios=valid_ratios)
+    salience_transformer.py:454-461, the score gather and ``get_reference_points`` (:418-432) restricted to them.
+    ``score``: fp32 ``[B,S]``, ``None``, or a ``LazyForegroundScore`` (the masked fill then happens in the gather)."""
+    score_mask = score_mins = None
+    if isinstance(score, LazyForegroundScore):
+        score_mask = score.mask.view(torch.uint8) if score.mask.dtype == torch.bool else score.mask
+        score_mins = score.level_min
+        score = score.score_flat
+        if not (score_mask.is_contiguous() and tuple(score_mask.shape) == tuple(score.shape) and score_mins.dtype == torch.float32):
+            raise RuntimeError("encoder_prepare_sorted: a lazy foreground score needs a contiguous [B,S] mask and fp32 minima")
+    _hip.require_device("encoder_prepare_sorted", tokens=tokens, pos=pos, score=score, valid_ratios=valid_ratios,
+                        score_mask=score_mask, score_mins=score_mins)
     if not sorted_index.is_cuda:
         raise RuntimeError("encoder_prepare_sorted: sorted_index must be a HIP (cuda) tensor; no CPU fallback")
     B, S, C = tokens.shape
@@ -1521,7 +1550,8 @@ def encoder_prepare_sorted(tokens: Tensor, pos: Tensor, score: Optional[Tensor],
         code = _hip.lib().sdetr_encoder_prepare_sorted(
             _hip.stream_ptr(), tokens.data_ptr(), pos.data_ptr(), row_bytes, _hip.ptr(score), sorted_index.data_ptr(),
             sorted_index.stride(0) if B > 1 else n, B, S, n, vr.data_ptr(), spatial_shapes.data_ptr(),
-            level_start_index.data_ptr(), L, q.data_ptr(), ps.data_ptr(), _hip.ptr(fg), ref.data_ptr())
+            level_start_index.data_ptr(), L, q.data_ptr(), ps.data_ptr(), _hip.ptr(fg), ref.data_ptr(),
+            _hip.ptr(score_mask), _hip.ptr(score_mins), 0 if score_mins is None else score_mins.numel())
     _hip.check(code, "encoder_prepare_sorted")
     return q, ps, fg, ref
 

@@ -190,8 +190,10 @@ class SalienceEncoderHotPath(nn.Module):
             salience_score, level_inds, level_score = level_filtering(
                 backbone_output_memory, mask_flatten, level_shapes, starts, level_token_nums, self.enc_mask_predictor,
                 self.alpha)
+        # (the masked fill of foreground_score happens in the encoder's entry gather unless the caller wants the tensor)
         foreground_inds, foreground_score = salience_filtering(salience_score, level_inds, level_score, mask_flatten,
-                                                               layer_ratio, score_flat=score_flat, extras=extras)
+                                                               layer_ratio, score_flat=score_flat, extras=extras,
+                                                               lazy_foreground=native and not return_aux)
         if feat_enc is None:
             feat_enc, pos_enc = feat_flatten.to(edt), lvl_pos_embed_flatten.to(edt)
         for job in value_jobs or ():   # whatever no stage-1 launch carried

@@ -496,6 +496,9 @@ class SalienceTransformerEncoder(nn.Module):
         counts = self._prefix_counts(foreground_inds)
         b, n = query.shape[:2]
         s, p = len(level_shapes), 2
+        from .filter_ops import LazyForegroundScore
+        if isinstance(foreground_score, LazyForegroundScore) and not (native and counts is not None):
+            foreground_score = foreground_score.materialize()   # (only the sorted no-grad loop fills the rows it gathers itself)
         if counts is not None and not native:
             return self._forward_sorted_autograd(query, query_pos, query_key_padding_mask, foreground_score, focus_token_nums,
                                                  foreground_inds, counts, spatial_shapes, level_start_index, valid_ratios,
@@ -529,6 +532,8 @@ class SalienceTransformerEncoder(nn.Module):
                 q, pos_s, fg_s, ref_s = encoder_prepare_sorted(value, ori_pos, foreground_score, sorted_index, valid_ratios,
                                                                spatial_shapes, level_start_index)
             else:
+                if isinstance(foreground_score, LazyForegroundScore):
+                    foreground_score = foreground_score.materialize()
                 q = gather_rows(value, sorted_index)
                 pos_s = gather_rows(ori_pos, sorted_index)
                 # reference points of the selected tokens only, straight from their indices

@@ -275,13 +275,15 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
 
 def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Tensor], level_score: Sequence[Tensor],
                        mask_flatten: Tensor, layer_filter_ratio: Sequence[float], score_flat: Optional[Tensor] = None,
-                       extras: Optional[dict] = None):
+                       extras: Optional[dict] = None, lazy_foreground: bool = False):
     """Global sort, per-layer prefixes and foreground score (salience_transformer.py:156-168).
 
     Returns ``(foreground_inds: list[num_layers] of [B,Nq_k] int64, foreground_score [B,S])`` -- exactly the
     ``foreground_inds`` / ``foreground_score`` keyword arguments of ``SalienceTransformerEncoder.forward``.
     ``score_flat`` [B,S]: the already flattened ``salience_score`` (saves the concatenation); ``extras``: the
-    by-products dict filled by ``level_filtering``.
+    by-products dict filled by ``level_filtering``.  ``lazy_foreground``: return ``foreground_score`` as a
+    ``filter_ops.LazyForegroundScore`` when the by-products allow it (the encoder's entry gather then fills the masked
+    rows itself: one launch less); ``.materialize()`` gives the tensor.
     """
     extras = extras or {}
     if "selected" in extras:
@@ -300,7 +302,11 @@ def salience_filtering(salience_score: Sequence[Tensor], level_inds: Sequence[Te
     foreground_inds = [sorted_inds if c == n else sorted_inds[:, :c] for c in counts]
     fg = score_flat if score_flat is not None else pyramid.flatten_multi_level(salience_score).squeeze(-1)
     if "level_min" in extras and fg.is_cuda and fg.is_contiguous() and mask_flatten.is_contiguous():
-        fg = masked_fill_min(fg, mask_flatten, extras["level_min"])   # fg.min() == min of the level minima
+        if lazy_foreground and fg.dtype == torch.float32:
+            from .filter_ops import LazyForegroundScore
+            fg = LazyForegroundScore(fg, mask_flatten, extras["level_min"])
+        else:
+            fg = masked_fill_min(fg, mask_flatten, extras["level_min"])   # fg.min() == min of the level minima
     else:
         fg = torch.where(mask_flatten, fg.min(), fg)
     return foreground_inds, fg

@@ -658,6 +658,16 @@ def test_encoder_prepare_sorted_equals_its_four_parts(dtype):
     assert torch.equal(ps, F.gather_rows(pos, index.contiguous()))
     assert torch.equal(fg, torch.gather(score, 1, index))
     assert torch.equal(ref, F.encoder_reference_points(vr, t_shapes.to(DEV), lsi.to(DEV), n, index=index))
+    # round 6: the masked fill of foreground_score (salience_transformer.py:164-168) applied in the gather instead of as a
+    # launch of its own over all tokens -- the same numbers on the gathered rows, and materialize() is the old tensor
+    mask = (torch.rand(B, S, generator=g) < 0.3).to(DEV)
+    mins = torch.tensor([0.5, -2.25, 1.0, -0.75], device=DEV)
+    lazy = F.LazyForegroundScore(score, mask, mins)
+    q2, ps2, fg2, ref2 = F.encoder_prepare_sorted(tokens, pos, lazy, index, vr, t_shapes.to(DEV), lsi.to(DEV))
+    full = torch.where(mask, mins.min(), score)
+    assert torch.equal(lazy.materialize(), full)
+    assert torch.equal(fg2, torch.gather(full, 1, index)) and mask.gather(1, index).any()
+    assert torch.equal(q2, q) and torch.equal(ps2, ps) and torch.equal(ref2, ref)
 
 
 @pytest.mark.parametrize("rows,next_rows,splits", [(300, 200, 4), (1200, 1200, 2), (1500, 0, 8), (700, 300, 1)])
