@@ -573,7 +573,16 @@ __global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
 {
     extern __shared__ uint32_t mkeys[];
     const float *row = p.score + (int64_t)blockIdx.y * p.n;
-    for (int i = threadIdx.x; i < p.n; i += 1024) mkeys[i] = desc_bits(row[i]);
+    // eight loads in flight per thread, then their LDS stores (one load -> wait -> store per iteration was a chain of
+    // n / 1024 trips to memory: 16 us at 16 800 keys, most of this kernel)
+    for (int i0 = threadIdx.x; i0 < p.n; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = row[min(i0 + u * 1024, p.n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < p.n) mkeys[i0 + u * 1024] = desc_bits(v[u]);
+    }
     __syncthreads();
     const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i >= p.n) return;

@@ -70,7 +70,10 @@ __device__ __forceinline__ void topk_rank_body(const RankArgs &p, int bx, int b,
         return desc_bits(s);
     };
     const int mypos = base + lane;
-    const uint32_t mine = mypos < n_keys ? key_at(mypos) : 0u;
+    // a list that fits one LDS round: the owned key is read from the staged tile (saves a dependent trip to memory in front
+    // of the staging loads)
+    const bool single = n_keys <= kRankTile;
+    uint32_t mine = (!single && mypos < n_keys) ? key_at(mypos) : 0u;
     uint32_t rank = 0;
 
     for (int t0 = 0; t0 < n_keys; t0 += kRankTile) {
@@ -103,6 +106,7 @@ __device__ __forceinline__ void topk_rank_body(const RankArgs &p, int bx, int b,
             if ((c0 + 12) * kRankThreads >= tn) break;
         }
         __syncthreads();
+        if (single && mypos < n_keys) mine = tile[mypos];
         // groups of 4 keys, round-robin over the wavefronts; the list splits into three ranges relative to
         // the owned block so every loop body is branch-free and the LDS reads pipeline (8 in flight)
         const int ngroups = (tn + 3) / 4;
