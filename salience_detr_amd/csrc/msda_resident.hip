@@ -1297,7 +1297,11 @@ extern "C" int sdetr_msda_bordered_forward_ex(sdetr_stream_t stream, const void 
     // to gain in a warm replay), bit 1: of the workgroup's projection rows (measured: no gain).  `l2_warmup` >= 0 fixes it.
     // Only while the fine levels of the images an XCD serves at a time fit its 4 MB L2 beside the rest: on the 5scale
     // pyramid (5.7 MB per head) the warm-up costs 4 us per launch (profiles/r04_msda_ab_5scale_bordered.json).
-    a.prefetch_fine = (int64_t)groups * a.res_start * 64 <= ((int64_t)7 << 19) ? 1 : 0;
+    // ... and only when a wave walks more than one row group: measured in the step per layer (benchmarks/msda_warmup_ab.sh,
+    // rocprofv3, with / without): 28.5 / 32.3, 23.3 / 27.5, 19.4 / 22.2, 18.5 / 20.1, 15.4 / 17.1 us at 11 363 ... 4545 rows
+    // per image, but 12.4 / 11.6 at 2272 -- there every wave has at most one group and the warm-up's loads queue in
+    // front of its only samples.
+    a.prefetch_fine = ((int64_t)groups * a.res_start * 64 <= ((int64_t)7 << 19) && (int64_t)Nq > (int64_t)chunks * kRWaves * 16) ? 1 : 0;
     if (l2_warmup >= 0) a.prefetch_fine = l2_warmup & 3;
     const int64_t blocks = (int64_t)groups * M * chunks;
     if (blocks > 0x7fffffffLL) return fail("msda_bordered_forward: grid too large");

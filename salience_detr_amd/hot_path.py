@@ -96,6 +96,10 @@ class SalienceEncoderHotPath(nn.Module):
             self._ratio_key = key
         return self._ratio_host
 
+    # layers of the batched value projection per carrier launch, in carrier order: stage 1 / stage 2 of the coarsest level,
+    # of the next one, then stage 2 of the third-coarsest (level_filtering); pieces no launch carried run on their own
+    value_projection_parts = (2, 1, 2, 1)
+
     def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
                 multi_level_pos_embeds: Sequence[Tensor],
                 image_sizes: Optional[Sequence[Tuple[int, int]]] = None,
@@ -130,7 +134,7 @@ class SalienceEncoderHotPath(nn.Module):
             # four carriers (stage 1 and stage 2 of the two coarsest levels): two layers with each stage 1 (~20 us
             # of projection under ~20 us of head), one with each stage 2 (~10 under ~17)
             n_layers = len(self.encoder.layers)
-            parts = (2, 1, 2, 1) if n_layers == 6 else min(4, n_layers)
+            parts = self.value_projection_parts if n_layers == 6 else min(4, n_layers)
             plan = self.encoder.plan_values(feat_enc, mask_flatten, parts=parts,
                                             level_shapes=pyramid.level_shapes_of(multi_level_masks))
             if plan is not None:

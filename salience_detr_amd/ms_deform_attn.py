@@ -751,6 +751,9 @@ class MultiScaleDeformableAttention(nn.Module):
     # take the direct gather.  ``msda_resident_forward`` stays as an entry point (sdetr_msda_resident_forward, a test
     # cross-check of the bordered kernel); an integer here (queries per image) switches the old dispatch back on.
     resident_min_queries = None
+    # launch choices of the bordered gather (sdetr_msda_bordered_forward_ex): ACC_DEFAULT / None = the library's rules
+    bordered_accumulate = ACC_DEFAULT
+    bordered_l2_warmup = None
 
     def head_major_projection_applies(self, query: Tensor, value_hm: Tensor) -> bool:
         """``forward_native`` (no ``order``) takes the per-head projection slabs for this input."""
@@ -793,7 +796,8 @@ class MultiScaleDeformableAttention(nn.Module):
             if bordered:
                 # round 4: zero-bordered maps + (optional) spatial row order -- every layer size takes this kernel
                 out = msda_bordered_forward(value_hm, level_shapes, reference_points, proj, row_order=row_order,
-                                            out_dtype=query.dtype)
+                                            out_dtype=query.dtype, accumulate=self.bordered_accumulate,
+                                            l2_warmup=self.bordered_l2_warmup)
             elif (self.resident_min_queries is not None and query.shape[1] >= self.resident_min_queries
                     and resident_supported(value_hm, level_shapes, self.num_levels, self.num_points)):
                 out = msda_resident_forward(value_hm, level_shapes, reference_points, proj, out_dtype=query.dtype)

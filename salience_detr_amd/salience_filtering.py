@@ -168,8 +168,13 @@ def token_budgets(multi_level_masks: Sequence[Tensor], level_filter_ratio: Tenso
     return focus.sum(-1), focus.max(0)[0], valid
 
 
-def _next_value_jobs(value_jobs) -> dict:
-    """The next two pending value-projection jobs as ``salience_head``'s ``value_job`` / ``value_job2``."""
+def _next_value_jobs(value_jobs, stage2_only=None) -> dict:
+    """The next two pending value-projection jobs as ``salience_head``'s ``value_job`` / ``value_job2``; with
+    ``stage2_only`` (a job list) the next pending one of it for the stage-2 launch alone (a level whose stage-1 launch
+    fills the chip by itself)."""
+    if stage2_only is not None:
+        pending = [j for j in stage2_only if not j.done]
+        return dict(value_job=None, value_job2=pending[0] if pending else None)
     pending = [j for j in (value_jobs or ()) if not j.done]
     return dict(value_job=pending[0] if pending else None, value_job2=pending[1] if len(pending) > 1 else None)
 
@@ -236,7 +241,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
                 score_min=level_min[lvl:lvl + 1],
                 rank_job=pending_rank, finalize_job=finalize_job,
-                **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None))
+                **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None,
+                                   stage2_only=value_jobs if lvl == L - 3 and L > 3 else None))
             if pending_rank is not None:
                 pending_rank.run()          # (no-op when stage 1 carried it)
                 pending_rank = None
