@@ -85,23 +85,32 @@ _SLICE = 8192
 
 
 def _sliced_topk(score: Tensor, k: int, index_offset: int, want_scores: bool, orders_job):
-    """Top-k (k small) of rows longer than the one-workgroup histogram sort takes, in two launches of it (round 5):
-    every 8192-key slice of a row keeps its own sorted top-k (a workgroup per slice), then the ``slices x k`` survivors
-    are sorted once more with their row positions as payload.  The rows' global top-k are among their slices' top-k; ties
-    stay in position order (slices are concatenated in row order and each is sorted ties-by-position, so equal scores
-    keep ascending positions in the candidate list -- the second sort's positional rule is the row's).  This is the
-    per-layer top-300 of the reference's 5scale pyramid (salience_transformer.py:366-367 on 45 330 rows, BASELINE
-    configs[3]): the chip-wide rank by counting it replaces is quadratic in the row -- 80-170 us per layer there."""
-    B, N = score.shape
-    S = -(-N // _SLICE)
-    pad = S * _SLICE - N
-    sp = torch.nn.functional.pad(score, (0, pad), value=float("-inf")) if pad else score
-    v1, i1 = masked_topk_desc(sp.reshape(B * S, _SLICE), k)
+    """Top-k (k small) of rows longer than the one-workgroup histogram sort takes, in launches of it (round 5): every
+    8192-key slice of a row keeps its own sorted top-k (a workgroup per slice), then the ``slices x k`` survivors are
+    sorted once more with their row positions as payload -- and, when the survivors themselves are longer than one
+    workgroup's row (very long rows: ADVICE r5), they are sliced again first.  The rows' global top-k are among their
+    slices' top-k; ties stay in position order (slices are concatenated in row order and each is sorted
+    ties-by-position, so equal scores keep ascending positions in every candidate list -- the last sort's positional rule
+    is the row's).  This is the per-layer top-300 of the reference's 5scale pyramid (salience_transformer.py:366-367 on
+    45 330 rows, BASELINE configs[3]): the chip-wide rank by counting it replaces is quadratic in the row -- 80-170 us
+    per layer there."""
     from . import pyramid
-    base = pyramid.static_tensor(("topk_slice_base", S, str(score.device)),
-                                 lambda: (torch.arange(S, dtype=torch.int64) * _SLICE).view(1, S, 1).to(score.device))
-    gidx = (i1.view(B, S, k) + base).view(B, S * k)
-    v2, i2 = masked_topk_desc(v1.view(B, S * k), k, payload=gidx, want_scores=want_scores, orders_job=orders_job)
+    B = score.shape[0]
+    vals, pos = score, None                     # candidate scores and their positions in the row (None: identity)
+    while vals.shape[1] > _SELECT_MAX_ROW:
+        n = vals.shape[1]
+        S = -(-n // _SLICE)
+        pad = S * _SLICE - n
+        sp = torch.nn.functional.pad(vals, (0, pad), value=float("-inf")) if pad else vals
+        v1, i1 = masked_topk_desc(sp.reshape(B * S, _SLICE), k)
+        base = pyramid.static_tensor(("topk_slice_base", S, str(score.device)),
+                                     lambda: (torch.arange(S, dtype=torch.int64) * _SLICE).view(1, S, 1).to(score.device))
+        at = (i1.view(B, S, k) + base).view(B, S * k)           # positions in `vals` (padding never survives: k <= n)
+        if pad:
+            at = at.clamp_(max=n - 1)                           # (-inf padding tied with real -inf scores)
+        pos = at if pos is None else torch.gather(pos, 1, at)
+        vals = v1.view(B, S * k)
+    v2, i2 = masked_topk_desc(vals, k, payload=pos, want_scores=want_scores, orders_job=orders_job)
     if index_offset:
         i2 = i2 + index_offset
     return v2, i2

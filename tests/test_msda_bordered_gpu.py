@@ -62,6 +62,33 @@ def test_bordered_kernel_vs_oracle(B, Nq, levels, chunks, ref_dim):
         assert excess.mean().item() < bar_mean and excess.max().item() < bar_max, (pk, excess.mean().item(), excess.max().item())
 
 
+@pytest.mark.parametrize("scale", [1.0, 60.0, 2000.0])
+def test_packed_fp16_accumulation_scales_with_the_maps(scale):
+    """The timed 16-bit form sums a level's 16 corner products in packed fp16 (ACC_PACKED_LEVEL; ADVICE r5: bound it against
+    the exact form on large-magnitude maps).  The partial sums are convex combinations of the map's values (bilinear
+    weights sum to 1, attention weights to <= 1), so they cannot overflow half's range while the map itself fits it, and
+    their rounding is relative: the excess over the exact fp32 sums (beyond the bf16 rounding of the output) stays below
+    4e-3 of the map's scale at every magnitude -- including maps close to half's maximum (65 504)."""
+    B, Nq, levels = 2, 2272, LEVELS_FULL
+    value, shapes, lsi, proj, ref = _case(B, Nq, levels, 2, seed=17)
+    value = value * scale                                           # |v| up to ~5 * scale: 10 000 at scale 2000
+    assert value.abs().max() < 60000
+    _, hb = _maps(value, levels)
+    slab = _head_major_slab(proj).to(DEV)
+    order = M.spatial_row_order(torch.stack([torch.randperm(sum(h * w for h, w in levels))[:Nq] for _ in range(B)]).to(DEV),
+                                levels, 16)
+    exact = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.float32)
+    assert torch.isfinite(exact).all()
+    for acc, bar_mean, bar_max in ((M.ACC_PACKED_SAMPLE, 4e-5, 1.5e-3), (M.ACC_PACKED_LEVEL, 1.5e-4, 4e-3)):
+        got = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, accumulate=acc)
+        assert torch.isfinite(got.float()).all()
+        excess = ((got.float() - exact).abs() - exact.abs() * 2.0 ** -8).clamp_(min=0) / scale
+        assert excess.mean().item() < bar_mean and excess.max().item() < bar_max, (scale, acc, excess.mean().item(), excess.max().item())
+    # and the exact form under a 16-bit output is the fp32 result rounded, at every magnitude
+    b16 = M.msda_bordered_forward(hb, levels, ref.to(DEV), slab, row_order=order, out_dtype=torch.bfloat16, accumulate=M.ACC_EXACT)
+    assert torch.equal(b16, exact.to(torch.bfloat16))
+
+
 def test_bordered_spatial_row_order_is_a_permutation_that_groups_tiles():
     levels = LEVELS_FULL
     Nv = sum(h * w for h, w in levels)
