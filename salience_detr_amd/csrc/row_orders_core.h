@@ -10,7 +10,7 @@ constexpr int kOrderMaxLayers = 8;
 constexpr int kOrderSlotQuantum = 4096;     // slots per part are a multiple of 16 waves x 256 (aligned 8-byte slot reads)
 constexpr int kOrderMaxParts = 64;
 constexpr int kOrderMaxTokens = 64 * 65536; // (round 5) any pyramid: the tile positions are cut into parts
-constexpr int kOrderPartSlots = 16384;      // preferred slots per part (32 KB of LDS): 2 parts at the benchmark pyramid, 6 at 5scale
+constexpr int kOrderPartSlots = 4096;       // preferred slots per part (8 KB of LDS): 6 parts at the benchmark pyramid, 22 at 5scale
 constexpr int kOrderBatch = 12;            // rows a thread has in flight (two dependent loads each): the benchmark's 11 363 rows in one batch
 
 // One workgroup per (image, layer, PART of the tile positions).  Round 4 ran one workgroup per (image, layer) over ALL
