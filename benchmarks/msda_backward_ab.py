@@ -10,6 +10,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("LIB"):   # a scratch build (benchmarks/bt_variant.sh)
+    from salience_detr_amd import _hip  # noqa: E402
+    _hip.LIB_PATH = os.path.abspath(os.environ["LIB"])
 from salience_detr_amd import ms_deform_attn as M  # noqa: E402
 from salience_detr_amd import synthetic as syn  # noqa: E402
 
@@ -35,6 +38,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--spread", type=float, default=4.0)
     ap.add_argument("--queries", type=int, nargs="*", default=[11363, 9090, 6817, 4545, 2272, 900])
+    ap.add_argument("--only-lds", action="store_true")
     a = ap.parse_args()
     rows = []
     for nq in a.queries:
@@ -44,14 +48,14 @@ def main():
         nv = value.shape[1]
         alg = a.batch * (2 * nv * 256 * 4 + 2 * nq * 8 * 16 * 3 * 4 + nq * 256 * 4)
         res = {"queries": nq, "algorithmic_bytes": alg}
-        for name, flag in (("lds", True), ("direct", False)):
+        for name, flag in ((("lds", True),) if a.only_lds else (("lds", True), ("direct", False))):
             M.lds_backward, M.lds_backward_min_queries = flag, 1
             # the wrapper's zero-fill of grad_value is part of the op as the reference defines it (it accumulates)
             us = time_us(lambda: M.ms_deform_attn_backward(*dev[:5], dev[5], 64), a.reps)
             res[name + "_us"] = round(us, 1)
             res[name + "_frac_of_8TBs"] = round(alg / (us * 1e-6) / 8e12, 4)
         rows.append(res)
-    print(json.dumps({"batch": a.batch, "spread_px": a.spread, "levels": LEVELS, "layers": rows}))
+    print(json.dumps({"lib": os.path.basename(os.environ.get("LIB", "product")), "batch": a.batch, "spread_px": a.spread, "levels": LEVELS, "layers": rows}))
 
 
 if __name__ == "__main__":

@@ -68,8 +68,12 @@ constexpr int kBtWinBytes = kBtWinPx * kBtD * 4;     // 139 776
 constexpr int kBtMaxTiles = 1024;
 constexpr int kBtMaxL = 8, kBtMaxHeads = 64;
 constexpr int kBtChunkRows = 512, kBtMaxChunks = 16;
-constexpr int kBtThreads = 512, kBtRowsPerPass = kBtThreads / 8;   // 8 waves: 256 VGPRs each (16 corner loads in flight)
-constexpr int kBtLdsBytes = kBtWinBytes + 1024;
+constexpr int kBtThreads = 512, kBtWaves = kBtThreads / 64;   // 8 waves: 256 VGPRs each (16 corner loads in flight)
+constexpr int kBtPassRows = 16;                      // rows of one wave's pass: its 64 lanes set up 16 rows x 4 samples
+constexpr int kBtRecRow = 4 * 64 + 16;               // bytes between the records of two rows (4 samples x 64 B + a bank step)
+constexpr int kBtRecBytes = 8 * kBtRecRow;           // one wave's records: an 8-row half of a pass
+constexpr int kBtLdsBytes = kBtWinBytes + 1024 + kBtWaves * kBtRecBytes;
+constexpr uint32_t kBtNoCorner = 0xffffff00u;        // + 16 * lane stays beyond any value slab (sdetr_msda_col2im_lds_supported)
 enum { kBtTile = 0, kBtResident = 1, kBtDirect = 2 };
 
 struct BtLevel {
@@ -261,7 +265,8 @@ typedef float bt_f32x2_t __attribute__((ext_vector_type(2)));
 // accumulate into an LDS word by byte address (no return value, nothing to wait for until the flush's barrier)
 __device__ __forceinline__ void bt_lds_add(uint32_t byte_addr, int v)
 {
-    asm volatile("ds_add_u32 %0, %1" : : "v"(byte_addr), "v"(v) : "memory");
+    // (no "memory" clobber: the record reads of the next sample may pass the adds; the flush is fenced by its barrier)
+    asm volatile("ds_add_u32 %0, %1" : : "v"(byte_addr), "v"(v));
 }
 __device__ __forceinline__ int bt_clamp(int v, int lo, int hi)
 {
@@ -304,6 +309,57 @@ __device__ __forceinline__ BtSample bt_setup(float lxn, float lyn, float a, int 
     return s;
 }
 
+// sum over the 8 lanes of a row group of twelve values at once, complete in lanes 0-3 of the group.  Written out as
+// three blocks of twelve DPP adds: left to the compiler the 36 steps became ~100 instructions (a v_mov_b32_dpp and the
+// hazard no-ops in front of most adds); inside a block an add reads a register written twelve instructions earlier.
+#define BT_DPP12(ctrl)                                                                                              \
+    asm("s_nop 1\n"                                                                                                 \
+        "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %9, %9, %9 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                               \
+        "v_add_f32_dpp %10, %10, %10 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                            \
+        "v_add_f32_dpp %11, %11, %11 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                            \
+        : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), \
+          "+v"(x[9]), "+v"(x[10]), "+v"(x[11]))
+__device__ __forceinline__ void bt_sum8_x12(float (&x)[12])
+{
+    BT_DPP12("quad_perm:[1,0,3,2]");
+    BT_DPP12("quad_perm:[2,3,0,1]");
+    BT_DPP12("row_shl:4");
+}
+// LDS byte address of a window pixel from its 16-bit index: idx * 128 + base in one instruction
+__device__ __forceinline__ uint32_t bt_pix_lo(uint32_t packed, uint32_t pitch, uint32_t base)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(packed), "s"(pitch), "v"(base));
+    return r;
+}
+__device__ __forceinline__ uint32_t bt_pix_hi(uint32_t packed, uint32_t pitch, uint32_t base)
+{
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(pitch), "v"(base));
+    return r;
+}
+
+// Round 6: the per-sample set-up (pixel, validity, corner weights, window addresses -- ~75 vector instructions) ran in
+// all eight lanes of a row, four times per row: 300 of the 800 vector instructions of an 8-row pass, and the counters
+// say the kernel's time is vector-ALU issue.  Now a wave's pass is 16 rows: its 64 lanes set up the 64 samples ONCE
+// (lane = (row, sample)), the result goes through LDS as a 64-byte record per sample (rows 272 bytes apart: the eight
+// rows of a broadcast read fall on different banks), first for rows 0-7, then -- from the registers of lanes 32-63 -- for
+// rows 8-15; the eight lanes of a row read the record back with four broadcast ds_read_b128.
+//   record: [0] byte offsets of the four corners in the (image, head) value slab, kBtNoCorner where the corner is off
+//               the image (the buffer load returns zeros)
+//           [1] corner weights x attention weight x fixed-point scale (zero: corner off the image / sample outside
+//               the window / row on the floating-point path)
+//           [2] window pixel of each corner (4 x u16) | bit 0 of dword 2: the sample takes the global-atomic path
+//           [3] lx, ly, W * aw, H * aw
 __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -312,8 +368,14 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = bt_uniform(tid >> 6);
-    const int slot = wave * 8 + (lane >> 3), k = lane & 7, rho = (lane >> 3) & 3;
+    // the lane as one of the eight of a row (gather / scatter halves)
+    const int k = lane & 7, r8 = lane >> 3, rho = r8 & 3;
     const uint32_t lane_base = (uint32_t)(uint64_t)win + (uint32_t)(32 * rho + 4 * k);   // LDS byte address of my accumulator in pixel 0
+    // the lane as the set-up of one sample
+    const int su_row = lane >> 2, su_s = lane & 3;
+    char *rec = smem + kBtWinBytes + 1024 + wave * kBtRecBytes;
+    const char *rec_rd = rec + r8 * kBtRecRow;
+    char *rec_wr = rec + (su_row & 7) * kBtRecRow + su_s * 64;
 
     if (tid < p.L) {
         const BtLevel v = bt_level(p.shapes, p.lsi, tid, p.B, p.M, p.Nq);
@@ -335,10 +397,12 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         // the next item's number is fetched now and published before this item's last barrier
         int next_item = 0;
         if (tid == 0) next_item = atomicAdd(p.counter, 1);
-        int l = 0;
+        // items are numbered from the LAST level down: the whole-level items of the coarse levels are the longest
+        // (all rows of a query chunk), the tiles of level 0 the shortest -- long first keeps the tail of the launch short
+        int l = p.L - 1;
         while (r >= sh_i[8 * l + 6]) {
             r -= sh_i[8 * l + 6];
-            ++l;
+            --l;
         }
         l = bt_uniform(l);
         const int H = bt_uniform(sh_i[8 * l]), W = bt_uniform(sh_i[8 * l + 1]), lstart = bt_uniform(sh_i[8 * l + 2]);
@@ -400,165 +464,254 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         float *gv_base = p.grad_value + ((int64_t)b * p.Nv * p.M + m) * kBtD;
         const float fW = (float)W, fH = (float)H;
 
-        // row operands of a pass: loaded one pass ahead (the loads of pass i+1 fly under the arithmetic of pass i)
-        struct RowIn {
-            float4 g, l01, l23, a4;
+        // ---- operands of a pass, loaded one pass ahead (a wave's passes are kBtWaves * 16 rows apart) ----
+        struct SuIn {     // of the lane as a set-up lane: its sample's location and weight, 8 channels of its row's gradient
+            float2 xy;
+            float a;
+            float4 g0, g1;
+        };
+        struct CoIn {     // of the lane as one of the eight of a row
+            float4 g;
             float gs[4];
             int64_t row;
         };
-        auto load_row = [&](int i) {
-            RowIn r;
+        auto row_of = [&](int i) -> int64_t {
             const int ii = min(i, n - 1);
             const int q = ord ? ord[ii] : begin + ii;
-            r.row = ((int64_t)b * p.Nq + q) * p.M + m;
+            return ((int64_t)b * p.Nq + q) * p.M + m;
+        };
+        auto load_su = [&](int base) {
+            SuIn r;
+            const int64_t row = row_of(base + su_row);
+            r.xy = *reinterpret_cast<const float2 *>(p.loc + ((row * p.L + l) * kBtP + su_s) * 2);
+            r.a = p.aw[(row * p.L + l) * kBtP + su_s];
+            const float4 *gp = reinterpret_cast<const float4 *>(p.grad_out + row * kBtD + 8 * su_s);
+            r.g0 = gp[0];
+            r.g1 = gp[1];
+            return r;
+        };
+        auto load_co = [&](int base) {
+            CoIn r;
+            r.row = row_of(base + r8);
             r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) r.gs[j] = p.grad_out[r.row * kBtD + 8 * (rho ^ j) + k];
-            const float4 *lp = reinterpret_cast<const float4 *>(p.loc + (r.row * p.L + l) * (kBtP * 2));
-            r.l01 = lp[0];
-            r.l23 = lp[1];
-            r.a4 = *reinterpret_cast<const float4 *>(p.aw + (r.row * p.L + l) * kBtP);
             return r;
         };
-        RowIn nxt;
-        if (n > 0) nxt = load_row(slot);
-        for (int base = 0; base < n; base += kBtRowsPerPass) {
-            const int i = base + slot;
-            const bool act = i < n;
-            const RowIn cur = nxt;
-            if (base + kBtRowsPerPass < n) nxt = load_row(i + kBtRowsPerPass);
-            const int64_t row = cur.row;
-            float4 g = cur.g;
-            float gs[4] = {cur.gs[0], cur.gs[1], cur.gs[2], cur.gs[3]};
-            const float4 l01 = cur.l01, l23 = cur.l23, a4 = cur.a4;
-            if (!act) {
-                g = make_float4(0.f, 0.f, 0.f, 0.f);
-                gs[0] = gs[1] = gs[2] = gs[3] = 0.f;
-            }
-            const float lx_[4] = {l01.x, l01.z, l23.x, l23.z}, ly_[4] = {l01.y, l01.w, l23.y, l23.w};
-            const float aw_[4] = {a4.x, a4.y, a4.z, a4.w};
-            // this row's own bound (all eight lanes of the row agree on it)
-            const float row_mag = bt_max8_all(fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))), k) *
-                                  ((fabsf(a4.x) + fabsf(a4.y)) + (fabsf(a4.z) + fabsf(a4.w)));
-            const bool row_in_window = use_window && !(row_mag < small_row);   // (a NaN stays with the window's NaN handling)
 
-            // ---- software pipeline over the row's four samples: [set-up + corner loads of s+1] [scatter of s]
-            // [dots of s].  The three stages load three different units (vector memory, LDS atomics, vector ALU); run
-            // as three whole-pass phases the eight waves of the workgroup hit the same unit at the same time and the
-            // other two idle (measured: phase times simply added up)
-            BtSample sm[kBtP];
+        // ---- one 8-row half: corner loads, scatter (under the loads), corner dot products, outputs ----
+        auto half = [&](const CoIn &co, int hbase) {
+            const bool act = hbase + r8 < n;
+            uint4 q0[kBtP], q2[kBtP];
+            float4 q1[kBtP], q3[kBtP];
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) q0[s] = *reinterpret_cast<const uint4 *>(rec_rd + s * 64);
             float4 v[kBtP][4];
-            float wa[kBtP][4];
-            uint32_t ad[kBtP][4];
-            float o_aw[kBtP], o_x[kBtP], o_y[kBtP];
-            uint32_t fallback = 0;
-            const bt_f32x2_t gs01 = {gs[0], gs[1]}, gs23 = {gs[2], gs[3]};
-            auto stage_a = [&](int s) {
-                int x0, y0;
-                sm[s] = bt_setup(lx_[s], ly_[s], aw_[s], H, W, fH, fW, lstart, ox, oy, ww, wh, row_in_window, x0, y0);
-                const uint32_t f = sm[s].flags;
-                const uint32_t o00 = (uint32_t)sm[s].pix * pix_bytes + 16u * k;
-                v[s][0] = as_f4(buffer_load16(vrsrc, (f & 1u) ? o00 : 0xffffffffu));
-                v[s][1] = as_f4(buffer_load16(vrsrc, (f & 2u) ? o00 + pix_bytes : 0xffffffffu));
-                v[s][2] = as_f4(buffer_load16(vrsrc, (f & 4u) ? o00 + (uint32_t)W * pix_bytes : 0xffffffffu));
-                v[s][3] = as_f4(buffer_load16(vrsrc, (f & 8u) ? o00 + (uint32_t)(W + 1) * pix_bytes : 0xffffffffu));
-                // scaled corner weights (zero for corners off the image and for samples that leave the window:
-                // their adds are exact zeros on a clamped address) and the accumulator address of each corner
-                const float hx = 1.f - sm[s].lx, hy = 1.f - sm[s].ly;
-                const float as = (f & 16u) ? sm[s].a * scale : 0.f;
-                wa[s][0] = (f & 1u) ? hy * hx * as : 0.f;
-                wa[s][1] = (f & 2u) ? hy * sm[s].lx * as : 0.f;
-                wa[s][2] = (f & 4u) ? sm[s].ly * hx * as : 0.f;
-                wa[s][3] = (f & 8u) ? sm[s].ly * sm[s].lx * as : 0.f;
-                const int cx0 = bt_clamp(x0 - ox, 0, ww - 1), cx1 = bt_clamp(x0 + 1 - ox, 0, ww - 1);
-                const int cy0 = bt_clamp(y0 - oy, 0, wh - 1), cy1 = bt_clamp(y0 + 1 - oy, 0, wh - 1);
-                ad[s][0] = ((uint32_t)(cy0 * ww + cx0) << 7) + lane_base;
-                ad[s][1] = ((uint32_t)(cy0 * ww + cx1) << 7) + lane_base;
-                ad[s][2] = ((uint32_t)(cy1 * ww + cx0) << 7) + lane_base;
-                ad[s][3] = ((uint32_t)(cy1 * ww + cx1) << 7) + lane_base;
-            };
-            auto stage_b = [&](int s) {
-                if (use_window) {
+#if defined(BT_KO_LOADS) || defined(BT_KO_GATHER)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const bt_f32x2_t w2 = {wa[s][c], wa[s][c]};
-                        const bt_f32x2_t p01 = gs01 * w2, p23 = gs23 * w2;   // v_pk_mul_f32
-                        bt_lds_add(ad[s][c], bt_round(p01.x));
-                        bt_lds_add(ad[s][c] ^ 32u, bt_round(p01.y));
-                        bt_lds_add(ad[s][c] ^ 64u, bt_round(p23.x));
-                        bt_lds_add(ad[s][c] ^ 96u, bt_round(p23.y));
-                    }
-                }
-            };
-            auto stage_c = [&](int s) {
-                float d[4];
+            for (int s = 0; s < kBtP; ++s)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    d[c] = bt_sum8(g.x * v[s][c].x + g.y * v[s][c].y + g.z * v[s][c].z + g.w * v[s][c].w);
-                const float lx = sm[s].lx, ly = sm[s].ly, hx = 1.f - lx, hy = 1.f - ly, a = sm[s].a;
-                o_aw[s] = hy * hx * d[0] + hy * lx * d[1] + ly * hx * d[2] + ly * lx * d[3];
-                o_x[s] = fW * a * (hy * (d[1] - d[0]) + ly * (d[3] - d[2]));
-                o_y[s] = fH * a * (hx * (d[2] - d[0]) + lx * (d[3] - d[1]));
-                fallback |= ((sm[s].flags & 0x30u) == 0x20u) ? (1u << s) : 0u;   // inside the level, not in the window
-            };
-            stage_a(0);
+                for (int c = 0; c < 4; ++c) v[s][c] = make_float4(__uint_as_float(q0[s].x), __uint_as_float(q0[s].y), __uint_as_float(q0[s].z), 1.f);
+#else
 #pragma unroll
             for (int s = 0; s < kBtP; ++s) {
-                if (s + 1 < kBtP) stage_a(s + 1);
-                stage_b(s);
-                stage_c(s);
+                v[s][0] = as_f4(buffer_load16(vrsrc, q0[s].x + 16u * k));
+                v[s][1] = as_f4(buffer_load16(vrsrc, q0[s].y + 16u * k));
+                v[s][2] = as_f4(buffer_load16(vrsrc, q0[s].z + 16u * k));
+                v[s][3] = as_f4(buffer_load16(vrsrc, q0[s].w + 16u * k));
             }
+#endif
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) {
+                q1[s] = *reinterpret_cast<const float4 *>(rec_rd + s * 64 + 16);
+                q2[s] = *reinterpret_cast<const uint4 *>(rec_rd + s * 64 + 32);
+                q3[s] = *reinterpret_cast<const float4 *>(rec_rd + s * 64 + 48);
+            }
+            uint32_t fallback = 0;
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) fallback |= (q2[s].z & 1u) << s;
+#ifndef BT_KO_SCATTER
+            if (use_window) {
+                const bt_f32x2_t gs01 = {co.gs[0], co.gs[1]}, gs23 = {co.gs[2], co.gs[3]};
+#pragma unroll
+                for (int s = 0; s < kBtP; ++s) {
+                    const uint32_t ad[4] = {bt_pix_lo(q2[s].x, 128u, lane_base), bt_pix_hi(q2[s].x, 128u, lane_base),
+                                            bt_pix_lo(q2[s].y, 128u, lane_base), bt_pix_hi(q2[s].y, 128u, lane_base)};
+                    const float wa[4] = {q1[s].x, q1[s].y, q1[s].z, q1[s].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bt_f32x2_t w2 = {wa[c], wa[c]};
+                        const bt_f32x2_t p01 = gs01 * w2, p23 = gs23 * w2;   // v_pk_mul_f32
+                        bt_lds_add(ad[c], bt_round(p01.x));
+                        bt_lds_add(ad[c] ^ 32u, bt_round(p01.y));
+                        bt_lds_add(ad[c] ^ 64u, bt_round(p23.x));
+                        bt_lds_add(ad[c] ^ 96u, bt_round(p23.y));
+                    }
+                }
+            }
+#endif
+            // the three outputs of a sample are linear in its four corner dot products: combined per lane (on the
+            // lane's four channels), THEN summed over the eight lanes -- 12 sums per row instead of 16
+            float o[12];
+            const float4 g = co.g;
+#ifdef BT_KO_GATHER
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) o[3 * s] = o[3 * s + 1] = o[3 * s + 2] = v[s][0].x + q3[s].x;
+            if (o[0] == 12345.f)
+#endif
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) {
+                float d[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[c] = g.x * v[s][c].x + g.y * v[s][c].y + g.z * v[s][c].z + g.w * v[s][c].w;
+                const float lx = q3[s].x, ly = q3[s].y, hx = 1.f - lx, hy = 1.f - ly;
+                o[3 * s] = hy * hx * d[0] + hy * lx * d[1] + ly * hx * d[2] + ly * lx * d[3];
+                o[3 * s + 1] = q3[s].z * (hy * (d[1] - d[0]) + ly * (d[3] - d[2]));
+                o[3 * s + 2] = q3[s].w * (hx * (d[2] - d[0]) + lx * (d[3] - d[1]));
+            }
+#ifndef BT_KO_GATHER
+            bt_sum8_x12(o);
+#endif
             if (act && k == 0) {
-                *reinterpret_cast<float4 *>(p.grad_aw + (row * p.L + l) * kBtP) = make_float4(o_aw[0], o_aw[1], o_aw[2], o_aw[3]);
-                float4 *gl = reinterpret_cast<float4 *>(p.grad_loc + (row * p.L + l) * (kBtP * 2));
-                gl[0] = make_float4(o_x[0], o_y[0], o_x[1], o_y[1]);
-                gl[1] = make_float4(o_x[2], o_y[2], o_x[3], o_y[3]);
+                *reinterpret_cast<float4 *>(p.grad_aw + (co.row * p.L + l) * kBtP) = make_float4(o[0], o[3], o[6], o[9]);
+                float4 *gl = reinterpret_cast<float4 *>(p.grad_loc + (co.row * p.L + l) * (kBtP * 2));
+                gl[0] = make_float4(o[1], o[2], o[4], o[5]);
+                gl[1] = make_float4(o[7], o[8], o[10], o[11]);
             }
-            // ---- samples that left their window (or items without one): fp32 atomics on global memory ----
+            // ---- samples that left their window (or items / rows without one): fp32 atomics on global memory, set up
+            // again from the row's own location (rare) ----
             if (act && fallback) {
 #pragma unroll
                 for (int s = 0; s < kBtP; ++s) {
                     if (!(fallback & (1u << s))) continue;
-                    const float lx = sm[s].lx, ly = sm[s].ly, hx = 1.f - lx, hy = 1.f - ly, a = sm[s].a;
-                    float *gp = gv_base + (int64_t)sm[s].pix * pix_floats + k;
+                    const float2 xy = *reinterpret_cast<const float2 *>(p.loc + ((co.row * p.L + l) * kBtP + s) * 2);
+                    const float a = p.aw[(co.row * p.L + l) * kBtP + s];
+                    int x0, y0;
+                    const BtSample sm = bt_setup(xy.x, xy.y, a, H, W, fH, fW, lstart, 0, 0, 0, 0, false, x0, y0);
+                    const float lx = sm.lx, ly = sm.ly, hx = 1.f - lx, hy = 1.f - ly;
+                    float *gp = gv_base + (int64_t)sm.pix * pix_floats + k;
                     const float wf[4] = {hy * hx * a, hy * lx * a, ly * hx * a, ly * lx * a};
-                    const int64_t co[4] = {0, pix_floats, (int64_t)W * pix_floats, (int64_t)(W + 1) * pix_floats};
+                    const int64_t co_[4] = {0, pix_floats, (int64_t)W * pix_floats, (int64_t)(W + 1) * pix_floats};
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (sm[s].flags & (1u << c)) {
+                        if (sm.flags & (1u << c)) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gp + co[c] + 8 * (rho ^ j), wf[c] * gs[j]);
+                            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gp + co_[c] + 8 * (rho ^ j), wf[c] * co.gs[j]);
                         }
                 }
+            }
+        };
+
+        constexpr int kStride = kBtWaves * kBtPassRows;
+        int base = wave * kBtPassRows;
+        SuIn su_n;
+        CoIn co_n0, co_n1;
+#ifdef BT_KO_PASS
+        base = n;
+#endif
+        if (base < n) {
+            su_n = load_su(base);
+            co_n0 = load_co(base);
+            co_n1 = load_co(base + 8);
+        }
+        for (; base < n; base += kStride) {
+            const SuIn su = su_n;
+            const CoIn co0 = co_n0, co1 = co_n1;
+            if (base + kStride < n) {
+                su_n = load_su(base + kStride);
+                co_n0 = load_co(base + kStride);
+                co_n1 = load_co(base + kStride + 8);
+            }
+            // ---- set-up of the pass's 64 samples, one per lane ----
+            uint4 r0, r2;
+            float4 r1, r3;
+            {
+                const bool act_su = base + su_row < n;
+                // the row's own bound (the four lanes of the row agree on it)
+                float mg = fmaxf(fmaxf(fmaxf(fabsf(su.g0.x), fabsf(su.g0.y)), fmaxf(fabsf(su.g0.z), fabsf(su.g0.w))),
+                                 fmaxf(fmaxf(fabsf(su.g1.x), fabsf(su.g1.y)), fmaxf(fabsf(su.g1.z), fabsf(su.g1.w))));
+                mg = fmaxf(mg, bt_xor1(mg));
+                mg = fmaxf(mg, bt_xor2(mg));
+                float sa = fabsf(su.a);
+                sa += bt_xor1(sa);
+                sa += bt_xor2(sa);
+                const float row_mag = mg * sa;
+                const bool row_in_window = use_window && act_su && !(row_mag < small_row);   // (a NaN stays with the window's NaN handling)
+                int x0, y0;
+                const BtSample sm = bt_setup(su.xy.x, su.xy.y, su.a, H, W, fH, fW, lstart, ox, oy, ww, wh, row_in_window, x0, y0);
+                const uint32_t f = sm.flags;
+                const uint32_t o00 = (uint32_t)sm.pix * pix_bytes;
+                r0 = make_uint4((f & 1u) ? o00 : kBtNoCorner, (f & 2u) ? o00 + pix_bytes : kBtNoCorner,
+                                (f & 4u) ? o00 + (uint32_t)W * pix_bytes : kBtNoCorner,
+                                (f & 8u) ? o00 + (uint32_t)(W + 1) * pix_bytes : kBtNoCorner);
+                // scaled corner weights (zero for corners off the image and for samples that leave the window: their
+                // adds are exact zeros on a clamped address) and the window pixel of each corner
+                const float hx = 1.f - sm.lx, hy = 1.f - sm.ly;
+                const float as = (f & 16u) ? sm.a * scale : 0.f;
+                r1 = make_float4((f & 1u) ? hy * hx * as : 0.f, (f & 2u) ? hy * sm.lx * as : 0.f,
+                                 (f & 4u) ? sm.ly * hx * as : 0.f, (f & 8u) ? sm.ly * sm.lx * as : 0.f);
+                const int cx0 = bt_clamp(x0 - ox, 0, ww - 1), cx1 = bt_clamp(x0 + 1 - ox, 0, ww - 1);
+                const int cy0 = bt_clamp(y0 - oy, 0, wh - 1), cy1 = bt_clamp(y0 + 1 - oy, 0, wh - 1);
+                r2 = make_uint4((uint32_t)(cy0 * ww + cx0) | ((uint32_t)(cy0 * ww + cx1) << 16),
+                                (uint32_t)(cy1 * ww + cx0) | ((uint32_t)(cy1 * ww + cx1) << 16),
+                                (act_su && (f & 0x30u) == 0x20u) ? 1u : 0u,   // inside the level, not in the window
+                                0u);
+                r3 = make_float4(sm.lx, sm.ly, fW * sm.a, fH * sm.a);
+            }
+            if (lane < 32) {
+                *reinterpret_cast<uint4 *>(rec_wr) = r0;
+                *reinterpret_cast<float4 *>(rec_wr + 16) = r1;
+                *reinterpret_cast<uint4 *>(rec_wr + 32) = r2;
+                *reinterpret_cast<float4 *>(rec_wr + 48) = r3;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            half(co0, base);
+            if (base + 8 < n) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane >= 32) {
+                    *reinterpret_cast<uint4 *>(rec_wr) = r0;
+                    *reinterpret_cast<float4 *>(rec_wr + 16) = r1;
+                    *reinterpret_cast<uint4 *>(rec_wr + 32) = r2;
+                    *reinterpret_cast<float4 *>(rec_wr + 48) = r3;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                half(co1, base + 8);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the inline-asm adds are invisible to the compiler's counters
         __syncthreads();
-        // ---- flush: whole 128-byte lines of fp32 atomics, accumulators left at zero for the next item ----
+        // ---- flush: whole 128-byte lines of fp32 atomics, accumulators left at zero for the next item.  A wave takes
+        // window rows wave, wave + 8, ...: the row's image coordinates and base address are scalars, a lane is (pixel
+        // parity, channel) and steps two pixels at a time ----
         if (use_window && scale != 0.f && n > 0) {
-            const int c = tid & 31, npx = ww * wh;
-            constexpr int kStep = kBtThreads / 32, kAhead = 4;
-            int wy = 0, wx = tid >> 5;
-            while (wx >= ww) {
-                wx -= ww;
-                ++wy;
-            }
-            for (int px0 = tid >> 5; px0 < npx; px0 += kAhead * kStep) {
-                int v[kAhead];
+            const int c = lane & 31, h = lane >> 5;
+            constexpr int kAhead = 4;
+            for (int wy = wave; wy < wh; wy += kBtWaves) {
+                const int Y = oy + wy;
+                if (Y < 0 || Y >= H) continue;   // (rows of the halo beyond the image hold zeros: nothing was added there)
+                float *rowp = gv_base + (int64_t)(lstart + Y * W + ox) * pix_floats + c;
+                uint32_t *wrow = win + wy * ww * 32 + c;
+                for (int wx0 = h; wx0 < ww; wx0 += 2 * kAhead) {
+                    int v[kAhead];
 #pragma unroll
-                for (int u = 0; u < kAhead; ++u) v[u] = px0 + u * kStep < npx ? (int)win[(px0 + u * kStep) * 32 + c] : 0;
+                    for (int u = 0; u < kAhead; ++u) v[u] = wx0 + 2 * u < ww ? (int)wrow[(wx0 + 2 * u) * 32] : 0;
 #pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    if (v[u] != 0) {
-                        win[(px0 + u * kStep) * 32 + c] = 0u;
-                        const int X = ox + wx, Y = oy + wy;
-                        if (X >= 0 && X < W && Y >= 0 && Y < H)
-                            unsafeAtomicAdd(gv_base + (int64_t)(lstart + Y * W + X) * pix_floats + c, (float)v[u] * inv_scale);
-                    }
-                    wx += kStep;
-                    while (wx >= ww) {
-                        wx -= ww;
-                        ++wy;
+                    for (int u = 0; u < kAhead; ++u) {
+                        const int wx = wx0 + 2 * u;
+                        if (v[u] != 0) {
+                            wrow[wx * 32] = 0u;
+#ifdef BT_KO_FLUSH
+                            if (wx == -12345)
+#else
+                            if (ox + wx >= 0 && ox + wx < W)
+#endif
+                                unsafeAtomicAdd(rowp + (int64_t)wx * pix_floats, (float)v[u] * inv_scale);
+                        }
                     }
                 }
             }
@@ -591,7 +744,7 @@ extern "C" size_t sdetr_msda_col2im_lds_workspace_bytes(int B, int Nq, int M, in
 extern "C" int sdetr_msda_col2im_lds_supported(int M, int D, int L, int P, int Nv)
 {
     return D == kBtD && P == kBtP && L >= 1 && L <= kBtMaxL && M >= 1 && M <= kBtMaxHeads &&
-           (int64_t)Nv * M * D * 4 < 0xffffffffLL;
+           (int64_t)Nv * M * D * 4 < (int64_t)kBtNoCorner;
 }
 
 extern "C" int sdetr_msda_col2im_lds_f32(sdetr_stream_t stream, const float *grad_col, const float *value,
