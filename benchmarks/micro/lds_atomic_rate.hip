@@ -44,11 +44,11 @@ __global__ void __launch_bounds__(1024, 1) k(int iters, int rows, float *gbuf, f
 // integer / 64-bit / packed-half LDS atomics on the 2 rows x 32 pattern, and the non-atomic read-add-write a wave
 // may use when it knows its lanes' addresses are distinct
 template <int KIND>
-__global__ void __launch_bounds__(1024, 1) k2(int iters, int rows, float *out)
+__global__ void __launch_bounds__(1024, 1) k2(int iters, int rows, float *out)   // (launched with 1024 or 512 threads)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < rows * 32 * (KIND == 1 || KIND == 4 ? 2 : 1); i += 1024) lds[i] = 0.f;
+    for (int i = tid; i < rows * 32 * (KIND == 1 || KIND == 4 ? 2 : 1); i += blockDim.x) lds[i] = 0.f;
     __syncthreads();
     uint32_t s = (blockIdx.x * 16 + wave) * 2654435761u + 12345u;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -66,6 +66,18 @@ __global__ void __launch_bounds__(1024, 1) k2(int iters, int rows, float *out)
                 float4 v = reinterpret_cast<float4 *>(lds)[i4];
                 v.x += 1.f; v.y += 1.f; v.z += 1.f; v.w += 1.f;
                 reinterpret_cast<float4 *>(lds)[i4] = v;
+            } else if (KIND == 5) {   // the backward kernel's scatter: 8 rows x 8 lanes, octet (row & 3) ^ u of a random pixel per row
+                const int row = lane >> 3, kk = lane & 7;
+                const int pix = (r + row * 7919u) & (rows - 1);
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(lds) + pix * 32 + 8 * ((row & 3) ^ (u & 3)) + kk, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (KIND == 6) {   // the same with 64-bit adds: a lane owns two neighbouring channels, half (row & 1) ^ u of the pixel
+                const int row = lane >> 3, kk = lane & 7;
+                const int pix = (r + row * 7919u) & (rows - 1);
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(lds) + pix * 16 + 8 * ((row & 1) ^ (u & 1)) + kk, 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (KIND == 7) {   // 64-bit adds, 4 rows x 16 lanes: a lane owns two neighbouring channels of a whole pixel
+                const int row = lane >> 4, kk = lane & 15;
+                const int pix = (r + row * 7919u) & (rows - 1);
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(lds) + pix * 16 + kk, 3ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (KIND == 4) {                                                                  // b64 read-add-write
                 const int i2 = ((r + (lane >> 4) * 7919u) & (rows - 1)) * 16 + (lane & 15);
                 float2 v = reinterpret_cast<float2 *>(lds)[i2];
@@ -76,12 +88,12 @@ __global__ void __launch_bounds__(1024, 1) k2(int iters, int rows, float *out)
     }
     __syncthreads();
     float t = acc.x;
-    for (int i = tid; i < rows * 32; i += 1024) t += lds[i];
+    for (int i = tid; i < rows * 32; i += blockDim.x) t += lds[i];
     atomicAdd(out, t);
 }
 
 template <int KIND>
-void run2(const char *name, int rows, int per_lane)
+void run2(const char *name, int rows, int per_lane, int threads = 1024)
 {
     float *out;
     hipMalloc(&out, 4); hipMemset(out, 0, 4);
@@ -89,12 +101,12 @@ void run2(const char *name, int rows, int per_lane)
     const int bytes = rows * 32 * 4 * (KIND == 1 ? 2 : 1);
     hipFuncSetAttribute((const void *)k2<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k2<KIND><<<blocks, 1024, bytes>>>(10, rows, out);
+    k2<KIND><<<blocks, threads, bytes>>>(10, rows, out);
     hipEventRecord(e0);
-    k2<KIND><<<blocks, 1024, bytes>>>(iters, rows, out);
+    k2<KIND><<<blocks, threads, bytes>>>(iters, rows, out);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double adds = (double)blocks * 1024 * iters * 8 * per_lane;
+    const double adds = (double)blocks * threads * iters * 8 * per_lane;
     printf("%-58s rows %5d  %8.3f ms  %8.1f G adds/s  (%5.2f adds/clk/CU at 2.1 GHz)\n", name, rows, ms, adds / ms * 1e-6,
            adds / ms * 1e-6 / 256 / 2.1);
     hipFree(out);
@@ -129,6 +141,12 @@ int main()
     run<0, false>("lds  2 rows x 32 floats, 64 rows (conflicts across waves)", 64);
     run2<0>("lds  ds_add_u32, 2 rows x 32", 1024, 1);
     run2<1>("lds  ds_add_u64, 2 rows x 32", 512, 1);
+    run2<5>("lds  ds_add_u32, 8 rows x 8 lanes (rotated octets), 16 waves", 1024, 1);
+    run2<5>("lds  ds_add_u32, 8 rows x 8 lanes (rotated octets), 8 waves", 1024, 1, 512);
+    run2<0>("lds  ds_add_u32, 2 rows x 32, 8 waves", 1024, 1, 512);
+    run2<6>("lds  ds_add_u64, 8 rows x 8 lanes x 2 (rotated halves), 16 w", 1024, 2);
+    run2<6>("lds  ds_add_u64, 8 rows x 8 lanes x 2 (rotated halves), 8 w", 1024, 2, 512);
+    run2<7>("lds  ds_add_u64, 4 rows x 16 lanes x 2, 8 waves", 1024, 2, 512);
     run2<2>("lds  read b32 / add / write b32 (racy between waves)", 1024, 1);
     run2<4>("lds  read b64 / add / write b64", 1024, 2);
     run2<3>("lds  read b128 / add / write b128", 1024, 4);

@@ -73,6 +73,9 @@ constexpr int kBtPassRows = 16;                      // rows of one wave's pass:
 constexpr int kBtRecRow = 4 * 64 + 16;               // bytes between the records of two rows (4 samples x 64 B + a bank step)
 constexpr int kBtRecBytes = 8 * kBtRecRow;           // one wave's records: an 8-row half of a pass
 constexpr int kBtLdsBytes = kBtWinBytes + 1024 + kBtWaves * kBtRecBytes;
+#ifndef BT_STAGGER
+#define BT_STAGGER 1   // the two waves of a SIMD (wave, wave + 4) run the LDS-bound and the ALU-bound part of a half in opposite order
+#endif
 constexpr uint32_t kBtNoCorner = 0xffffff00u;        // + 16 * lane stays beyond any value slab (sdetr_msda_col2im_lds_supported)
 enum { kBtTile = 0, kBtResident = 1, kBtDirect = 2 };
 
@@ -360,11 +363,53 @@ __device__ __forceinline__ uint32_t bt_pix_hi(uint32_t packed, uint32_t pitch, u
 //               the window / row on the floating-point path)
 //           [2] window pixel of each corner (4 x u16) | bit 0 of dword 2: the sample takes the global-atomic path
 //           [3] lx, ly, W * aw, H * aw
+// An item of the work list, as every thread of the workgroup needs it.
+struct BtItem {
+    int l, H, W, lstart, mode, m, b, n, begin, ox, oy, ww, wh;
+    const int32_t *ord;
+    float scale, inv_scale, small_row;
+    bool use_window;
+};
+// item number -> (level, part, head, image).  Items are numbered from the LAST level down: the whole-level items of the
+// coarse levels are the longest (all rows of a query chunk), the tiles of level 0 the shortest -- long first keeps the
+// tail of the launch short.  `sh_i` = the level table in LDS.
+__device__ __forceinline__ void bt_item_place(int r, const int *sh_i, int L, int M, int &l, int &part, int &m, int &b)
+{
+    l = L - 1;
+    while (r >= sh_i[8 * l + 6]) {
+        r -= sh_i[8 * l + 6];
+        --l;
+    }
+    const int parts = sh_i[8 * l + 5];
+    part = r % parts;
+    const int bm = r / parts;
+    m = bm % M;
+    b = bm / M;
+}
+
+// (benchmark builds only: cycle stamps per phase, summed over the waves into the workspace header, words 8...)
+#ifdef BT_STAMPS
+#define BT_STAMP(i)                                      \
+    {                                                    \
+        const long long t_now = clock64();               \
+        st_acc[i] += (unsigned long long)(t_now - st_t); \
+        st_t = t_now;                                    \
+    }
+#else
+#define BT_STAMP(i)
+#endif
 __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
 {
+#ifdef BT_STAMPS
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long st_t = clock64();
+    const long long st_t0 = st_t;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *win = reinterpret_cast<uint32_t *>(smem);
-    int *sh_i = reinterpret_cast<int *>(smem + kBtWinBytes);            // [8 l + f] level table, [64], [65] items
+    // [8 l + f] level table; [64 + 4 s + f], s = parity of the item's turn: item number, first row in the tile order,
+    // rows, bits of the (level, image, head) row bound -- written by thread 0 one item ahead (see below)
+    int *sh_i = reinterpret_cast<int *>(smem + kBtWinBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = bt_uniform(tid >> 6);
@@ -382,7 +427,6 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         int *t = sh_i + 8 * tid;
         t[0] = v.H; t[1] = v.W; t[2] = v.start; t[3] = v.mode; t[4] = v.tx; t[5] = v.parts; t[6] = v.items;
     }
-    if (tid == 0) sh_i[64] = atomicAdd(p.counter, 1);
     for (int i = tid; i < kBtWinBytes / 16; i += kBtThreads) reinterpret_cast<uint4 *>(win)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     int total = 0;
@@ -391,113 +435,163 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
     const int64_t pix_floats = (int64_t)p.M * kBtD;
     const uint32_t pix_bytes = (uint32_t)(p.M * kBtD * 4);
 
-    for (int iter = 0;; ++iter) {
-        int r = bt_uniform(sh_i[64 + (iter & 1)]);
-        if (r >= total) break;
-        // the next item's number is fetched now and published before this item's last barrier
-        int next_item = 0;
-        if (tid == 0) next_item = atomicAdd(p.counter, 1);
-        // items are numbered from the LAST level down: the whole-level items of the coarse levels are the longest
-        // (all rows of a query chunk), the tiles of level 0 the shortest -- long first keeps the tail of the launch short
-        int l = p.L - 1;
-        while (r >= sh_i[8 * l + 6]) {
-            r -= sh_i[8 * l + 6];
-            --l;
-        }
-        l = bt_uniform(l);
-        const int H = bt_uniform(sh_i[8 * l]), W = bt_uniform(sh_i[8 * l + 1]), lstart = bt_uniform(sh_i[8 * l + 2]);
-        const int mode = bt_uniform(sh_i[8 * l + 3]), tiles_x = bt_uniform(sh_i[8 * l + 4]);
-        const int parts = bt_uniform(sh_i[8 * l + 5]);
-        const int part = bt_uniform(r % parts), bm = r / parts;
-        const int m = bt_uniform(bm % p.M), b = bt_uniform(bm / p.M);
-
-        // rows of the item
-        int n, begin = 0;
-        const int32_t *ord = nullptr;
-        if (mode == kBtTile) {
+    // ---- the work list, pipelined one item deep (round 6).  An item used to begin with a chain of dependent trips to
+    // memory during which the whole CU idled: counter -> tile's row range and bound -> row order -> row operands, ~10 us
+    // of the ~40 an item takes.  Now thread 0 draws item numbers TWO turns ahead and fetches the next item's row range
+    // and bound while the current item's rows are processed; after the barrier in front of the flush every thread knows
+    // the next item, requests its first rows' numbers before the flush and their operands after it ----
+    // thread 0: the three scalars of an item that live in memory
+    auto fetch = [&](int r, int &s0, int &n, uint32_t &bound) {
+        s0 = 0;
+        n = 0;
+        bound = 0u;
+        if (r >= total) return;
+        int l, part, m, b;
+        bt_item_place(r, sh_i, p.L, p.M, l, part, m, b);
+        if (sh_i[8 * l + 3] == kBtTile) {
             const int32_t *st = p.start + ((int64_t)l * p.B + b) * (kBtMaxTiles + 1);
-            const int s0 = st[part];
-            n = st[part + 1] - s0;
-            ord = p.order + ((int64_t)l * p.B + b) * p.Nq + s0;
+            s0 = st[part];
+            n = st[part + 1];   // (minus s0: by the caller, after the loads)
+        }
+        bound = p.row_bound[((int64_t)l * p.B + b) * p.M + m];
+    };
+    auto publish = [&](int slot, int r, int s0, int s1, uint32_t bound) {
+        int *t = sh_i + 64 + 4 * slot;
+        t[0] = r;
+        t[1] = s0;
+        t[2] = s1 - s0;
+        t[3] = (int)bound;
+    };
+    // every thread: the item of a published slot
+    auto item_of = [&](int slot) {
+        BtItem it{};
+        const int *t = sh_i + 64 + 4 * slot;
+        const int r = bt_uniform(t[0]);
+        it.n = -1;
+        if (r >= total) return it;
+        int l, part, m, b;
+        bt_item_place(r, sh_i, p.L, p.M, l, part, m, b);
+        it.l = bt_uniform(l);
+        part = bt_uniform(part);
+        it.m = bt_uniform(m);
+        it.b = bt_uniform(b);
+        it.H = bt_uniform(sh_i[8 * it.l]);
+        it.W = bt_uniform(sh_i[8 * it.l + 1]);
+        it.lstart = bt_uniform(sh_i[8 * it.l + 2]);
+        it.mode = bt_uniform(sh_i[8 * it.l + 3]);
+        const int tiles_x = bt_uniform(sh_i[8 * it.l + 4]), parts = bt_uniform(sh_i[8 * it.l + 5]);
+        if (it.mode == kBtTile) {
+            it.n = bt_uniform(t[2]);
+            it.ord = p.order + ((int64_t)it.l * p.B + it.b) * p.Nq + bt_uniform(t[1]);
+            it.ox = kBtTileW * (part % tiles_x) - kBtHalo;
+            it.oy = kBtTileH * (part / tiles_x) - kBtHalo;
+            it.ww = kBtWinW;
+            it.wh = kBtWinH;
         } else {
             const int per = (p.Nq + parts - 1) / parts;
-            begin = part * per;
-            n = min(p.Nq, begin + per) - begin;
+            it.begin = part * per;
+            it.n = min(p.Nq, it.begin + per) - it.begin;
+            if (it.mode == kBtResident) {
+                it.ww = it.W;
+                it.wh = it.H;
+            }
         }
-        n = bt_uniform(n);
+        it.n = max(it.n, 0);
         // window and fixed-point scale: no accumulator of the item can exceed n * (largest row bound of the
         // (level, image, head)), bt_tile_id_kernel's max of max_c|g| * sum_p|aw|.  bound < 2^x -> scale 2^(29 - x).
-        int ox = 0, oy = 0, ww = 0, wh = 0;
-        if (mode == kBtTile) {
-            ox = kBtTileW * (part % tiles_x) - kBtHalo;
-            oy = kBtTileH * (part / tiles_x) - kBtHalo;
-            ww = kBtWinW;
-            wh = kBtWinH;
-        } else if (mode == kBtResident) {
-            ww = W;
-            wh = H;
-        }
-        float scale = 0.f, inv_scale = 0.f;
         // A row whose own bound max_c|g| * sum_p|aw| lies more than 2^-20 below the item's accumulator bound would have
         // its contributions rounded at a quantum (2^-30 of the bound) that is coarse for THEM: one outlier query, or a
         // heavy-tailed loss scale, must not cost the small gradients their bits.  Such rows take the fp32
         // path (direct atomics), like samples outside the window.  Rows above the threshold keep a relative rounding
         // error <= 2^-11 per add before the exact integer accumulation; typical gradients are nowhere near it.
-        float small_row = 0.f;
-        bool use_window = false;
-        if (mode != kBtDirect && n > 0) {
-            const float bound = (float)n * __uint_as_float(p.row_bound[((int64_t)l * p.B + b) * p.M + m]);
-            small_row = bound * 0x1p-20f;
+        if (it.mode != kBtDirect && it.n > 0) {
+            const float bound = (float)it.n * __uint_as_float((uint32_t)bt_uniform(t[3]));
+            it.small_row = bound * 0x1p-20f;
             if (bound > 0x1p-90f && bound < 0x1p+90f) {
                 const int x = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
-                scale = __uint_as_float((uint32_t)(29 - x + 127) << 23);
-                inv_scale = __uint_as_float((uint32_t)(127 - (29 - x)) << 23);
-                use_window = true;
+                it.scale = __uint_as_float((uint32_t)(29 - x + 127) << 23);
+                it.inv_scale = __uint_as_float((uint32_t)(127 - (29 - x)) << 23);
+                it.use_window = true;
             } else if (bound == 0.f) {
-                use_window = true;   // nothing to scatter: every contribution is an exact zero
+                it.use_window = true;   // nothing to scatter: every contribution is an exact zero
             }
         }
+        return it;
+    };
 
-        const __amdgpu_buffer_rsrc_t vrsrc = make_uniform_rsrc(
-            reinterpret_cast<const char *>(p.value + ((int64_t)b * p.Nv * p.M + m) * kBtD),
-            (uint32_t)(((int64_t)p.Nv * p.M - m) * kBtD * 4));
-        float *gv_base = p.grad_value + ((int64_t)b * p.Nv * p.M + m) * kBtD;
-        const float fW = (float)W, fH = (float)H;
-
-        // ---- operands of a pass, loaded one pass ahead (a wave's passes are kBtWaves * 16 rows apart) ----
-        struct SuIn {     // of the lane as a set-up lane: its sample's location and weight, 8 channels of its row's gradient
-            float2 xy;
-            float a;
-            float4 g0, g1;
-        };
-        struct CoIn {     // of the lane as one of the eight of a row
-            float4 g;
-            float gs[4];
-            int64_t row;
-        };
-        auto row_of = [&](int i) -> int64_t {
-            const int ii = min(i, n - 1);
-            const int q = ord ? ord[ii] : begin + ii;
-            return ((int64_t)b * p.Nq + q) * p.M + m;
-        };
-        auto load_su = [&](int base) {
-            SuIn r;
-            const int64_t row = row_of(base + su_row);
-            r.xy = *reinterpret_cast<const float2 *>(p.loc + ((row * p.L + l) * kBtP + su_s) * 2);
-            r.a = p.aw[(row * p.L + l) * kBtP + su_s];
-            const float4 *gp = reinterpret_cast<const float4 *>(p.grad_out + row * kBtD + 8 * su_s);
-            r.g0 = gp[0];
-            r.g1 = gp[1];
-            return r;
-        };
-        auto load_co = [&](int base) {
-            CoIn r;
-            r.row = row_of(base + r8);
-            r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
+    // ---- operands of a pass, loaded one pass ahead (a wave's passes are kBtWaves * 16 rows apart) ----
+    struct SuIn {     // of the lane as a set-up lane: its sample's location and weight, 8 channels of its row's gradient
+        float2 xy;
+        float a;
+        float4 g0, g1;
+    };
+    struct CoIn {     // of the lane as one of the eight of a row
+        float4 g;
+        float gs[4];
+        int64_t row;
+    };
+    auto query_of = [&](const BtItem &it, int i) {
+        const int ii = min(i, it.n - 1);
+        return it.ord ? it.ord[ii] : it.begin + ii;
+    };
+    auto load_su = [&](const BtItem &it, int q) {
+        SuIn r;
+        const int64_t row = ((int64_t)it.b * p.Nq + q) * p.M + it.m;
+        r.xy = *reinterpret_cast<const float2 *>(p.loc + ((row * p.L + it.l) * kBtP + su_s) * 2);
+        r.a = p.aw[(row * p.L + it.l) * kBtP + su_s];
+        const float4 *gp = reinterpret_cast<const float4 *>(p.grad_out + row * kBtD + 8 * su_s);
+        r.g0 = gp[0];
+        r.g1 = gp[1];
+        return r;
+    };
+    auto load_co = [&](const BtItem &it, int q) {
+        CoIn r;
+        r.row = ((int64_t)it.b * p.Nq + q) * p.M + it.m;
+        r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r.gs[j] = p.grad_out[r.row * kBtD + 8 * (rho ^ j) + k];
-            return r;
-        };
+        for (int j = 0; j < 4; ++j) r.gs[j] = p.grad_out[r.row * kBtD + 8 * (rho ^ j) + k];
+        return r;
+    };
+
+    // prologue: the first two item numbers in one draw, the first item fetched and published
+    int r_next = 0;   // (thread 0) the item after the current one
+    if (tid == 0) {
+        const int r0 = atomicAdd(p.counter, 2);
+        int s0, s1;
+        uint32_t bd;
+        fetch(r0, s0, s1, bd);
+        publish(0, r0, s0, s1, bd);
+        r_next = r0 + 1;
+    }
+    __syncthreads();
+    BtItem it = item_of(0);
+    constexpr int kStride = kBtWaves * kBtPassRows;
+    SuIn su_n{};
+    CoIn co_n0{}, co_n1{};
+    if (wave * kBtPassRows < it.n) {
+        su_n = load_su(it, query_of(it, wave * kBtPassRows + su_row));
+        co_n0 = load_co(it, query_of(it, wave * kBtPassRows + r8));
+        co_n1 = load_co(it, query_of(it, wave * kBtPassRows + 8 + r8));
+    }
+
+    BT_STAMP(0);   // prologue
+    for (int iter = 0; it.n >= 0; ++iter) {
+        // thread 0: draw the item after the next, start the next item's three scalars on their way
+        int r_next2 = 0, nx_s0 = 0, nx_s1 = 0;
+        uint32_t nx_bd = 0u;
+        if (tid == 0) {
+            r_next2 = atomicAdd(p.counter, 1);
+            fetch(r_next, nx_s0, nx_s1, nx_bd);
+        }
+        const int l = it.l, H = it.H, W = it.W, lstart = it.lstart, n = it.n;
+        const int ox = it.ox, oy = it.oy, ww = it.ww, wh = it.wh;
+        const float scale = it.scale, inv_scale = it.inv_scale, small_row = it.small_row;
+        const bool use_window = it.use_window;
+        const __amdgpu_buffer_rsrc_t vrsrc = make_uniform_rsrc(
+            reinterpret_cast<const char *>(p.value + ((int64_t)it.b * p.Nv * p.M + it.m) * kBtD),
+            (uint32_t)(((int64_t)p.Nv * p.M - it.m) * kBtD * 4));
+        float *gv_base = p.grad_value + ((int64_t)it.b * p.Nv * p.M + it.m) * kBtD;
+        const float fW = (float)W, fH = (float)H;
 
         // ---- one 8-row half: corner loads, scatter (under the loads), corner dot products, outputs ----
         auto half = [&](const CoIn &co, int hbase) {
@@ -530,6 +624,8 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
             uint32_t fallback = 0;
 #pragma unroll
             for (int s = 0; s < kBtP; ++s) fallback |= (q2[s].z & 1u) << s;
+            BT_STAMP(2);   // records written and read back, corner loads issued
+            auto scatter = [&]() {
 #ifndef BT_KO_SCATTER
             if (use_window) {
                 const bt_f32x2_t gs01 = {co.gs[0], co.gs[1]}, gs23 = {co.gs[2], co.gs[3]};
@@ -550,6 +646,10 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                 }
             }
 #endif
+            };
+            const bool scatter_first = !BT_STAGGER || (wave & 4) == 0;
+            if (scatter_first) scatter();
+            BT_STAMP(3);   // scatter
             // the three outputs of a sample are linear in its four corner dot products: combined per lane (on the
             // lane's four channels), THEN summed over the eight lanes -- 12 sums per row instead of 16
             float o[12];
@@ -572,6 +672,8 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
 #ifndef BT_KO_GATHER
             bt_sum8_x12(o);
 #endif
+            if (!scatter_first) scatter();
+            BT_STAMP(4);   // corner dot products (waits for the corner loads), sums
             if (act && k == 0) {
                 *reinterpret_cast<float4 *>(p.grad_aw + (co.row * p.L + l) * kBtP) = make_float4(o[0], o[3], o[6], o[9]);
                 float4 *gl = reinterpret_cast<float4 *>(p.grad_loc + (co.row * p.L + l) * (kBtP * 2));
@@ -602,25 +704,17 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
             }
         };
 
-        constexpr int kStride = kBtWaves * kBtPassRows;
         int base = wave * kBtPassRows;
-        SuIn su_n;
-        CoIn co_n0, co_n1;
 #ifdef BT_KO_PASS
         base = n;
 #endif
-        if (base < n) {
-            su_n = load_su(base);
-            co_n0 = load_co(base);
-            co_n1 = load_co(base + 8);
-        }
         for (; base < n; base += kStride) {
             const SuIn su = su_n;
             const CoIn co0 = co_n0, co1 = co_n1;
             if (base + kStride < n) {
-                su_n = load_su(base + kStride);
-                co_n0 = load_co(base + kStride);
-                co_n1 = load_co(base + kStride + 8);
+                su_n = load_su(it, query_of(it, base + kStride + su_row));
+                co_n0 = load_co(it, query_of(it, base + kStride + r8));
+                co_n1 = load_co(it, query_of(it, base + kStride + 8 + r8));
             }
             // ---- set-up of the pass's 64 samples, one per lane ----
             uint4 r0, r2;
@@ -658,6 +752,7 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                                 0u);
                 r3 = make_float4(sm.lx, sm.ly, fW * sm.a, fH * sm.a);
             }
+            BT_STAMP(1);   // set-up (+ item head for the first pass)
             if (lane < 32) {
                 *reinterpret_cast<uint4 *>(rec_wr) = r0;
                 *reinterpret_cast<float4 *>(rec_wr + 16) = r1;
@@ -683,8 +778,24 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                 half(co1, base + 8);
             }
         }
+        BT_STAMP(5);   // output stores, global-atomic samples
+        // thread 0: the next item's scalars (on their way since the item began) and the number of the one after it
+        if (tid == 0) {
+            publish((iter + 1) & 1, r_next, nx_s0, nx_s1, nx_bd);
+            r_next = r_next2;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the inline-asm adds are invisible to the compiler's counters
         __syncthreads();
+        BT_STAMP(6);   // waiting for the item's other waves
+        // the next item; the numbers of its first rows are requested before the flush ...
+        const BtItem nx = item_of((iter + 1) & 1);
+        const bool nx_rows = wave * kBtPassRows < nx.n;
+        int nq_su = 0, nq_0 = 0, nq_1 = 0;
+        if (nx_rows) {
+            nq_su = query_of(nx, wave * kBtPassRows + su_row);
+            nq_0 = query_of(nx, wave * kBtPassRows + r8);
+            nq_1 = query_of(nx, wave * kBtPassRows + 8 + r8);
+        }
         // ---- flush: whole 128-byte lines of fp32 atomics, accumulators left at zero for the next item.  A wave takes
         // window rows wave, wave + 8, ...: the row's image coordinates and base address are scalars, a lane is (pixel
         // parity, channel) and steps two pixels at a time ----
@@ -716,9 +827,24 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                 }
             }
         }
-        if (tid == 0) sh_i[64 + ((iter + 1) & 1)] = next_item;
+        // ... and their operands after it
+        if (nx_rows) {
+            su_n = load_su(nx, nq_su);
+            co_n0 = load_co(nx, nq_0);
+            co_n1 = load_co(nx, nq_1);
+        }
+        it = nx;
+        BT_STAMP(7);   // flush, next item's first requests
         __syncthreads();
+        BT_STAMP(8);   // waiting for the flush of the other waves
     }
+#ifdef BT_STAMPS
+    st_acc[9] = (unsigned long long)(clock64() - st_t0);
+    if (lane == 0) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.counter) + 4;
+        for (int i = 0; i < 10; ++i) atomicAdd(dst + i, st_acc[i]);
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(256) bt_clear_kernel(uint32_t *words, int n)
