@@ -26,31 +26,46 @@
 //    global memory for that sample only, so the result never depends on the window; levels with more than 1024
 //    tiles, or an item whose bound is not a normal number, take that path for every sample.
 //
-// Lane mapping: 8 lanes per (query, head) row, 128 rows per pass.  For the gather half of the backward
-// (grad_sampling_loc, grad_attn_weight) lane k holds channels 4k..4k+3 of a corner (one 16-byte buffer load,
-// out-of-image corners read as zero through the buffer's bounds check) and the four corner dot products
-// <grad_out, v_c> are reduced over the 8 lanes with three DPP adds; the gradients are linear combinations of
-// those four numbers.  For the scatter half lane k owns channels {8j + k}: in instruction i row r adds octet
-// j = (r & 3) ^ i, so the 32 lanes the LDS serves per clock (4 rows x 8 lanes) always cover 32 different banks
-// whatever pixels the rows hit -- no bank conflicts by construction, and no two lanes of an instruction ever share
-// an address.
+// Waves and lanes (round 6; until then eight waves did both halves of the backward, every lane of a row repeating the
+// per-sample set-up).  A workgroup is 16 waves of two kinds.  Waves 0-7 (two per SIMD) are the SCATTER waves: they own
+// the window, draw the work list, accumulate grad_value and flush; they synchronise among themselves through an LDS
+// counter (s_barrier would tie the other eight in).  Waves 8-15 are the GATHER waves: grad_sampling_loc and
+// grad_attn_weight of ALL rows of all (level, image, head), 16 rows per turn in the order of the tiles, with no
+// synchronisation at all.  Either kind works on 16 rows at a time: the 64 lanes set up the 64 samples ONCE (lane = (row,
+// sample): pixel, validity, weights, addresses -- these ~75 vector instructions used to run in all eight lanes of a
+// row), the result goes through LDS as a 32-byte record per sample and the eight lanes of a row read it back by
+// broadcast.  Gather: lane k of a row holds channels 4k..4k+3 of a corner (one 16-byte buffer load, out-of-image
+// corners read as zero through the buffer's bounds check); the three outputs of a sample are linear in its four corner
+// dot products <grad_out, v_c>, so they are combined per lane and THEN summed over the 8 lanes (12 fused DPP adds per
+// step instead of 16 sums that compiled to ~100 instructions).  Scatter: lane k owns channels {8j + k}: in instruction
+// i row r adds octet j = (r & 3) ^ i, so the 32 lanes the LDS serves per clock (4 rows x 8 lanes) always cover 32
+// different banks whatever pixels the rows hit -- no bank conflicts by construction, and no two lanes of an
+// instruction ever share an address.
 //
-// Measured (benchmarks/msda_backward_ab.py, B = 2, profiles/r02_msda_backward_ab.json): 334 us at 11 363 queries
-// against 1047 us for the direct kernel (fixed part ~100 us: the flush's ~35 M L2 atomics ~70 us, bucketing
-// ~20 us; below ~1200 queries the direct kernel wins and the host wrapper keeps it).  Where the rest goes, from
-// cycle stamps and knock-out builds: no single unit -- per 64-row pass ~2000 clocks of L1 requests (sixteen
-// 16-byte corner loads per lane: fp32 value is 128 bytes per corner), ~2600 of LDS atomics (64 per wave, ~5 clocks
-// each per CU), ~5000 of vector ALU (8 waves x ~650 instructions, of which ~250 are the per-sample set-up that all
-// eight lanes of a row repeat) and the flush, which runs with the rest of the CU idle (one workgroup per CU: the
-// window takes the LDS).  Tried without gain: two 256-thread workgroups per CU on half-size windows (24x8 tiles) so that one's flush runs
-// under the other's arithmetic (438 us: 1.5x the flush atomics, smaller passes), sixteen waves at 128 VGPRs (spills), whole-pass phases instead of
-// the per-sample pipeline (same time), an exact per-item bound from a pre-pass over the rows (an extra round trip
-// per item for 2-3 bits of scale).  Next: the set-up computed once per sample by one lane of the row and
-// broadcast; `ds_add_u64` on channel pairs (same lane rate, half the instructions).
+// Measured (benchmarks/msda_backward_ab.py, B = 2; profiles/r06_msda_backward_ab.json): 250 us at 11 363 queries (341
+// before round 6; the direct kernel: 1047).  Of these ~46 are the other launches (grad_value's zero fill 12, bucketing
+// 22 + 10, header clear 2); the main launch is ~205.  Knock-outs and cycle stamps (benchmarks/bt_stamps.py,
+// bt_variant.sh): gather waves alone ~113 us, scatter waves alone ~155 (126 without the flush's atomics) -- they overlap
+// only by a quarter; a scatter wave's time is 36 % flush, 19 % LDS adds, 15 % record round trips (behind the queued
+// adds), 17 % waiting for the item's other waves.  No unit is busy more than 40 % (vector ALU 40, LDS 30, L1 20): every
+// wave is a chain of dependent latencies, and 16 waves of 128 registers are what the window leaves room for.  The floor
+// under the flush is the memory side: float atomics are executed behind the L2 (TCC_EA0_ATOMIC = all 1.77 M line
+// requests of a launch), and the chip retires 10 G whole-line fp32 atomics per second when it does nothing else
+// (benchmarks/micro/global_atomic_lines.hip: 1.68 M lines in 165 us; plain stores of the same lines: 31 us) -- the
+// flush's atomics are spread under the other work (knocked out: -31 us), but they are why this design cannot reach
+// 0.15 of the roofline: that needs tiles that own their pixels (no halo, rows bucketed per SAMPLE, plain stores).
+// Tried in round 6 without gain: 64-bit LDS adds on channel pairs (the LDS does retire them at the 32-bit instruction
+// rate -- lds_atomic_rate.hip, 18-20 channel adds per clock and CU against 10 -- but the launch did not move: 251.8
+// against 248.8 us), the two waves of a SIMD running the LDS-bound and the ALU-bound part in opposite order (+3 us),
+// 8 or 21 LDS reads ahead in the flush (0 / +56 us), 8 whole-level items per (level, image, head) instead of 16 (-3 %,
+// but the coarser fixed-point quantum crosses the tests' 1e-4).  Earlier: two 256-thread workgroups per CU on half-size
+// windows (438 us: 1.5x the flush atomics), whole-pass phases instead of the per-sample pipeline (same time), an exact
+// per-item bound from a pre-pass over the rows (an extra round trip per item for 2-3 bits of scale).
 //
 // Everything that depends on the level shapes is decided on the device from the shape tensors (the reference
 // interface hands them over as device tensors; no host copy, no synchronisation): persistent workgroups draw
-// (level, image, head, part) items from a counter.
+// (level, image, head, part) items from a counter, one item ahead of their need (the next item's row range, bound and
+// first rows travel under the current item's rows and flush).
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "common.h"
@@ -67,15 +82,19 @@ constexpr int kBtWinPx = kBtWinW * kBtWinH;          // 1092
 constexpr int kBtWinBytes = kBtWinPx * kBtD * 4;     // 139 776
 constexpr int kBtMaxTiles = 1024;
 constexpr int kBtMaxL = 8, kBtMaxHeads = 64;
-constexpr int kBtChunkRows = 512, kBtMaxChunks = 16;
-constexpr int kBtThreads = 512, kBtWaves = kBtThreads / 64;   // 8 waves: 256 VGPRs each (16 corner loads in flight)
-constexpr int kBtPassRows = 16;                      // rows of one wave's pass: its 64 lanes set up 16 rows x 4 samples
-constexpr int kBtRecRow = 4 * 64 + 16;               // bytes between the records of two rows (4 samples x 64 B + a bank step)
-constexpr int kBtRecBytes = 8 * kBtRecRow;           // one wave's records: an 8-row half of a pass
-constexpr int kBtLdsBytes = kBtWinBytes + 1024 + kBtWaves * kBtRecBytes;
-#ifndef BT_STAGGER
-#define BT_STAGGER 1   // the two waves of a SIMD (wave, wave + 4) run the LDS-bound and the ALU-bound part of a half in opposite order
+#ifndef BT_MAX_CHUNKS
+// whole-level items per (level, image, head).  Every one flushes the whole level, so fewer would flush less (8: -3 % of the
+// launch at 11 363 queries) -- but an item's fixed-point quantum is 2^-29 of (its rows) x (the largest row bound), and
+// at 8 the accumulated rounding of level 2 (1421 rows per item) crosses the 1e-4 the tests hold this kernel to
+#define BT_MAX_CHUNKS 16
 #endif
+constexpr int kBtChunkRows = 512, kBtMaxChunks = BT_MAX_CHUNKS;
+constexpr int kBtScWaves = 8, kBtGaWaves = 8;        // scatter waves (window, work list, flush) | gather waves
+constexpr int kBtThreads = 64 * (kBtScWaves + kBtGaWaves);   // 16 waves, four per SIMD: 128 VGPRs each
+constexpr int kBtPassRows = 16;                      // rows of one wave's pass: its 64 lanes set up 16 rows x 4 samples
+constexpr int kBtRecRow = 4 * 32 + 16;               // bytes between the records of two rows (4 samples x 32 B + a bank step)
+constexpr int kBtRecBytes = 8 * kBtRecRow;           // one wave's records: an 8-row half of a pass
+constexpr int kBtLdsBytes = kBtWinBytes + 1024 + (kBtScWaves + kBtGaWaves) * kBtRecBytes;
 constexpr uint32_t kBtNoCorner = 0xffffff00u;        // + 16 * lane stays beyond any value slab (sdetr_msda_col2im_lds_supported)
 enum { kBtTile = 0, kBtResident = 1, kBtDirect = 2 };
 
@@ -229,35 +248,6 @@ __device__ __forceinline__ float bt_xor2(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
 }
-__device__ __forceinline__ float bt_up4(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0xf, true));  // row_shl:4: lane i <- lane i+4
-}
-// sum over the 8 lanes of a row group; complete in lanes 0-3 of the group
-__device__ __forceinline__ float bt_sum8(float v)
-{
-    v += bt_xor1(v);
-    v += bt_xor2(v);
-    return v + bt_up4(v);
-}
-__device__ __forceinline__ float bt_max8(float v)
-{
-    v = fmaxf(v, bt_xor1(v));
-    v = fmaxf(v, bt_xor2(v));
-    return fmaxf(v, bt_up4(v));
-}
-__device__ __forceinline__ float bt_down4(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));  // row_shr:4: lane i <- lane i-4
-}
-// max over the 8 lanes of a row group of a NON-NEGATIVE value, complete in all eight lanes (k = lane within the group)
-__device__ __forceinline__ float bt_max8_all(float v, int k)
-{
-    v = fmaxf(v, bt_xor1(v));
-    v = fmaxf(v, bt_xor2(v));
-    const float up = bt_up4(v), down = bt_down4(v);
-    return fmaxf(v, k < 4 ? up : down);
-}
 __device__ __forceinline__ int bt_round(float v)   // floor(v + 0.5) in one instruction
 {
     int r;
@@ -351,19 +341,27 @@ __device__ __forceinline__ uint32_t bt_pix_hi(uint32_t packed, uint32_t pitch, u
     return r;
 }
 
-// Round 6: the per-sample set-up (pixel, validity, corner weights, window addresses -- ~75 vector instructions) ran in
-// all eight lanes of a row, four times per row: 300 of the 800 vector instructions of an 8-row pass, and the counters
-// say the kernel's time is vector-ALU issue.  Now a wave's pass is 16 rows: its 64 lanes set up the 64 samples ONCE
-// (lane = (row, sample)), the result goes through LDS as a 64-byte record per sample (rows 272 bytes apart: the eight
-// rows of a broadcast read fall on different banks), first for rows 0-7, then -- from the registers of lanes 32-63 -- for
-// rows 8-15; the eight lanes of a row read the record back with four broadcast ds_read_b128.
-//   record: [0] byte offsets of the four corners in the (image, head) value slab, kBtNoCorner where the corner is off
-//               the image (the buffer load returns zeros)
-//           [1] corner weights x attention weight x fixed-point scale (zero: corner off the image / sample outside
-//               the window / row on the floating-point path)
-//           [2] window pixel of each corner (4 x u16) | bit 0 of dword 2: the sample takes the global-atomic path
-//           [3] lx, ly, W * aw, H * aw
-// An item of the work list, as every thread of the workgroup needs it.
+// Round 6.  (1) The per-sample set-up (pixel, validity, corner weights, window addresses -- ~75 vector instructions) ran
+// in all eight lanes of a row, four times per row: 300 of the 800 vector instructions of an 8-row pass.  Now a wave's
+// pass is 16 rows: its 64 lanes set up the 64 samples ONCE (lane = (row, sample)), the result goes through LDS as a
+// 32-byte record per sample (rows 144 bytes apart: the eight rows of a broadcast read fall on different banks), first
+// for rows 0-7, then -- from the registers of lanes 32-63 -- for rows 8-15; the eight lanes of a row read the record back
+// with two broadcast ds_read_b128.  (2) The two halves of the backward are different machines -- the gather half
+// (grad_sampling_loc, grad_attn_weight) is corner loads + vector arithmetic and needs neither the window nor the work
+// list's barriers, the scatter half is LDS atomics + the flush's global atomics -- and with every wave doing both they
+// ran one after the other (cycle stamps: set-up 23 %, scatter 27 %, flush 23 % of a wave's time, the LDS pipe and the
+// vector ALUs idle in turn).  So the workgroup is 16 waves of two kinds: waves 0-7 (two per SIMD) own the window, the
+// work list and the flush and synchronise among themselves through an LDS counter (s_barrier would tie the other
+// eight in); waves 8-15 walk ALL rows of all (level, image, head) in the tile order, 16 rows at a time, with no
+// synchronisation at all, and leave when they are done.
+//   scatter record: [0] corner weights x attention weight x fixed-point scale (zero: corner off the image / sample
+//                       outside the window / row on the floating-point path)
+//                   [1] window pixel of each corner (4 x u16) | dword 2 bit 0: the sample takes the global-atomic path
+//   gather record:  [0] byte offsets of the four corners in the (image, head) value slab, kBtNoCorner where the corner
+//                       is off the image (the buffer load returns zeros)
+//                   [1] lx, ly, W * aw, H * aw
+
+// An item of the work list, as every scatter wave needs it.
 struct BtItem {
     int l, H, W, lstart, mode, m, b, n, begin, ox, oy, ww, wh;
     const int32_t *ord;
@@ -398,6 +396,192 @@ __device__ __forceinline__ void bt_item_place(int r, const int *sh_i, int L, int
 #else
 #define BT_STAMP(i)
 #endif
+
+// barrier among the scatter waves: an ever-growing LDS counter (the gather waves never meet it)
+__device__ __forceinline__ void bt_scatter_barrier(int *bar, int &epoch, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my LDS adds / stores have landed (the inline-asm adds are invisible to the compiler's counters)
+    epoch += kBtScWaves;
+    if (lane == 0) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+}
+
+struct BtCtx {   // what both kinds of wave know
+    int lane, k, r8, rho, su_row, su_s;
+    char *rec;
+    const char *rec_rd;
+    char *rec_wr;
+    int64_t pix_floats;
+    uint32_t pix_bytes;
+};
+
+// ------------------------------------------------------------------------------------------------
+// gather waves: grad_sampling_loc, grad_attn_weight of every row, 16 rows per turn
+__device__ __forceinline__ void bt_gather_waves(const BtArgs &p, const int *sh_i, const BtCtx &c, int gw, int gws)
+{
+    const int lane = c.lane, k = c.k, r8 = c.r8;
+    const int G = (p.Nq + kBtPassRows - 1) / kBtPassRows;
+    const int64_t units = (int64_t)p.L * p.B * p.M * G;
+    struct Unit {
+        int l, b, m, g;
+    };
+    auto unit_of = [&](int64_t u) {
+        Unit t;
+        t.g = (int)(u % G);
+        const int lbm = (int)(u / G);
+        t.m = bt_uniform(lbm % p.M);
+        const int lb = lbm / p.M;
+        t.b = bt_uniform(lb % p.B);
+        t.l = bt_uniform(lb / p.B);
+        t.g = bt_uniform(t.g);
+        return t;
+    };
+    // the rows of a (level, image) in the order of its tiles where the level has tiles (neighbouring rows sample
+    // neighbouring pixels: the corner loads of a turn stay in a few cache lines), in their own order elsewhere
+    auto query_of = [&](const Unit &t, int i) {
+        const int ii = min(i, p.Nq - 1);
+        return sh_i[8 * t.l + 3] == kBtTile ? p.order[((int64_t)t.l * p.B + t.b) * p.Nq + ii] : ii;
+    };
+    struct SuIn {
+        float2 xy;
+        float a;
+    };
+    struct CoIn {
+        float4 g;
+        int64_t row;
+    };
+    auto load_su = [&](const Unit &t, int q) {
+        SuIn r;
+        const int64_t row = ((int64_t)t.b * p.Nq + q) * p.M + t.m;
+        r.xy = *reinterpret_cast<const float2 *>(p.loc + ((row * p.L + t.l) * kBtP + c.su_s) * 2);
+        r.a = p.aw[(row * p.L + t.l) * kBtP + c.su_s];
+        return r;
+    };
+    auto load_co = [&](const Unit &t, int q) {
+        CoIn r;
+        r.row = ((int64_t)t.b * p.Nq + q) * p.M + t.m;
+        r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
+        return r;
+    };
+
+    int64_t u = gw;
+    if (u >= units) return;
+    // row numbers two turns ahead, operands one turn ahead (a row number is a trip to memory in front of its operands)
+    Unit t0 = unit_of(u), t1 = t0;
+    int q_su = query_of(t0, t0.g * kBtPassRows + c.su_row), q_a = query_of(t0, t0.g * kBtPassRows + r8),
+        q_b = query_of(t0, t0.g * kBtPassRows + 8 + r8);
+    SuIn su_n = load_su(t0, q_su);
+    CoIn co_n0 = load_co(t0, q_a), co_n1 = load_co(t0, q_b);
+    if (u + gws < units) {
+        t1 = unit_of(u + gws);
+        q_su = query_of(t1, t1.g * kBtPassRows + c.su_row);
+        q_a = query_of(t1, t1.g * kBtPassRows + r8);
+        q_b = query_of(t1, t1.g * kBtPassRows + 8 + r8);
+    }
+    for (; u < units; u += gws) {
+        const Unit t = t0;
+        const SuIn su = su_n;
+        const CoIn co0 = co_n0;
+        CoIn co1 = co_n1;
+        // the next turn's operands are requested between this turn's halves, behind an explicit use of everything the
+        // previous request brought: requested at the top of the turn they sat in front of the set-up's first wait, which
+        // (one counter, in order) then waited for THEM -- a trip to memory per turn in plain view
+        auto request_next = [&]() {
+            asm volatile("" : "+v"(co1.g.x), "+v"(co1.g.y), "+v"(co1.g.z), "+v"(co1.g.w), "+v"(q_su), "+v"(q_a), "+v"(q_b));
+            t0 = t1;
+            if (u + gws < units) {
+                su_n = load_su(t0, q_su);
+                co_n0 = load_co(t0, q_a);
+                co_n1 = load_co(t0, q_b);
+                if (u + 2 * gws < units) {
+                    t1 = unit_of(u + 2 * gws);
+                    q_su = query_of(t1, t1.g * kBtPassRows + c.su_row);
+                    q_a = query_of(t1, t1.g * kBtPassRows + r8);
+                    q_b = query_of(t1, t1.g * kBtPassRows + 8 + r8);
+                }
+            }
+        };
+        const int l = t.l, H = bt_uniform(sh_i[8 * l]), W = bt_uniform(sh_i[8 * l + 1]), lstart = bt_uniform(sh_i[8 * l + 2]);
+        const float fW = (float)W, fH = (float)H;
+        const __amdgpu_buffer_rsrc_t vrsrc = make_uniform_rsrc(
+            reinterpret_cast<const char *>(p.value + ((int64_t)t.b * p.Nv * p.M + t.m) * kBtD),
+            (uint32_t)(((int64_t)p.Nv * p.M - t.m) * kBtD * 4));
+        // ---- set-up of the turn's 64 samples, one per lane ----
+        uint4 r0;
+        float4 r1;
+        {
+            int x0, y0;
+            const BtSample sm = bt_setup(su.xy.x, su.xy.y, su.a, H, W, fH, fW, lstart, 0, 0, 0, 0, false, x0, y0);
+            const uint32_t f = sm.flags;
+            const uint32_t o00 = (uint32_t)sm.pix * c.pix_bytes;
+            r0 = make_uint4((f & 1u) ? o00 : kBtNoCorner, (f & 2u) ? o00 + c.pix_bytes : kBtNoCorner,
+                            (f & 4u) ? o00 + (uint32_t)W * c.pix_bytes : kBtNoCorner,
+                            (f & 8u) ? o00 + (uint32_t)(W + 1) * c.pix_bytes : kBtNoCorner);
+            r1 = make_float4(sm.lx, sm.ly, fW * sm.a, fH * sm.a);
+        }
+        auto half = [&](const CoIn &co, int hbase) {
+            const bool act = hbase + r8 < p.Nq;
+            uint4 q0[kBtP];
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) q0[s] = *reinterpret_cast<const uint4 *>(c.rec_rd + s * 32);
+            float4 v[kBtP][4];
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) {
+                v[s][0] = as_f4(buffer_load16(vrsrc, q0[s].x + 16u * k));
+                v[s][1] = as_f4(buffer_load16(vrsrc, q0[s].y + 16u * k));
+                v[s][2] = as_f4(buffer_load16(vrsrc, q0[s].z + 16u * k));
+                v[s][3] = as_f4(buffer_load16(vrsrc, q0[s].w + 16u * k));
+            }
+            // the three outputs of a sample are linear in its four corner dot products: combined per lane (on the
+            // lane's four channels), THEN summed over the eight lanes -- 12 sums per row instead of 16
+            float o[12];
+            const float4 g = co.g;
+#pragma unroll
+            for (int s = 0; s < kBtP; ++s) {
+                const float4 q1 = *reinterpret_cast<const float4 *>(c.rec_rd + s * 32 + 16);
+                float d[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    d[cc] = g.x * v[s][cc].x + g.y * v[s][cc].y + g.z * v[s][cc].z + g.w * v[s][cc].w;
+                const float lx = q1.x, ly = q1.y, hx = 1.f - lx, hy = 1.f - ly;
+                o[3 * s] = hy * hx * d[0] + hy * lx * d[1] + ly * hx * d[2] + ly * lx * d[3];
+                o[3 * s + 1] = q1.z * (hy * (d[1] - d[0]) + ly * (d[3] - d[2]));
+                o[3 * s + 2] = q1.w * (hx * (d[2] - d[0]) + lx * (d[3] - d[1]));
+            }
+            bt_sum8_x12(o);
+            if (act && k == 0) {
+                *reinterpret_cast<float4 *>(p.grad_aw + (co.row * p.L + l) * kBtP) = make_float4(o[0], o[3], o[6], o[9]);
+                float4 *gl = reinterpret_cast<float4 *>(p.grad_loc + (co.row * p.L + l) * (kBtP * 2));
+                gl[0] = make_float4(o[1], o[2], o[4], o[5]);
+                gl[1] = make_float4(o[7], o[8], o[10], o[11]);
+            }
+        };
+        const int base = t.g * kBtPassRows;
+        if (lane < 32) {
+            *reinterpret_cast<uint4 *>(c.rec_wr) = r0;
+            *reinterpret_cast<float4 *>(c.rec_wr + 16) = r1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        half(co0, base);
+        request_next();
+        if (base + 8 < p.Nq) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= 32) {
+                *reinterpret_cast<uint4 *>(c.rec_wr) = r0;
+                *reinterpret_cast<float4 *>(c.rec_wr + 16) = r1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            half(co1, base + 8);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
 {
 #ifdef BT_STAMPS
@@ -408,38 +592,63 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *win = reinterpret_cast<uint32_t *>(smem);
     // [8 l + f] level table; [64 + 4 s + f], s = parity of the item's turn: item number, first row in the tile order,
-    // rows, bits of the (level, image, head) row bound -- written by thread 0 one item ahead (see below)
+    // rows, bits of the (level, image, head) row bound -- written by thread 0 one item ahead (see below); [80] the scatter
+    // waves' barrier counter
     int *sh_i = reinterpret_cast<int *>(smem + kBtWinBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = bt_uniform(tid >> 6);
-    // the lane as one of the eight of a row (gather / scatter halves)
-    const int k = lane & 7, r8 = lane >> 3, rho = r8 & 3;
-    const uint32_t lane_base = (uint32_t)(uint64_t)win + (uint32_t)(32 * rho + 4 * k);   // LDS byte address of my accumulator in pixel 0
+    BtCtx c;
+    c.lane = lane;
+    // the lane as one of the eight of a row
+    c.k = lane & 7;
+    c.r8 = lane >> 3;
+    c.rho = c.r8 & 3;
     // the lane as the set-up of one sample
-    const int su_row = lane >> 2, su_s = lane & 3;
-    char *rec = smem + kBtWinBytes + 1024 + wave * kBtRecBytes;
-    const char *rec_rd = rec + r8 * kBtRecRow;
-    char *rec_wr = rec + (su_row & 7) * kBtRecRow + su_s * 64;
+    c.su_row = lane >> 2;
+    c.su_s = lane & 3;
+    c.rec = smem + kBtWinBytes + 1024 + wave * kBtRecBytes;
+    c.rec_rd = c.rec + c.r8 * kBtRecRow;
+    c.rec_wr = c.rec + (c.su_row & 7) * kBtRecRow + c.su_s * 32;
+    c.pix_floats = (int64_t)p.M * kBtD;
+    c.pix_bytes = (uint32_t)(p.M * kBtD * 4);
+    const int k = c.k, r8 = c.r8, rho = c.rho, su_row = c.su_row, su_s = c.su_s;
+    const int64_t pix_floats = c.pix_floats;
+    // LDS byte address of my accumulator in pixel 0: lane k of a row owns channels {8j + k}; instruction i of a corner
+    // takes octet j = (row & 3) ^ i, so that the 32 lanes the LDS serves per clock (4 rows x 8 lanes) always cover 32
+    // different banks whatever pixels the rows hit, and no two lanes of an instruction ever share an address
+    const uint32_t lane_base = (uint32_t)(uint64_t)win + (uint32_t)(32 * rho + 4 * k);
 
     if (tid < p.L) {
         const BtLevel v = bt_level(p.shapes, p.lsi, tid, p.B, p.M, p.Nq);
         int *t = sh_i + 8 * tid;
         t[0] = v.H; t[1] = v.W; t[2] = v.start; t[3] = v.mode; t[4] = v.tx; t[5] = v.parts; t[6] = v.items;
     }
+    if (tid == 0) sh_i[80] = 0;
     for (int i = tid; i < kBtWinBytes / 16; i += kBtThreads) reinterpret_cast<uint4 *>(win)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    __syncthreads();   // the only s_barrier of the kernel: from here on the two kinds of wave go their own ways
+
+    if (wave >= kBtScWaves) {
+#ifndef BT_KO_GATHER_WAVES
+        bt_gather_waves(p, sh_i, c, (int)blockIdx.x * kBtGaWaves + (wave - kBtScWaves), (int)gridDim.x * kBtGaWaves);
+#endif
+#ifdef BT_STAMPS
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(p.counter) + 4 + 4, (unsigned long long)(clock64() - st_t0));
+#endif
+        return;
+    }
+
+    // ================= scatter waves =================
+    int *bar = sh_i + 80;
+    int epoch = 0;
     int total = 0;
     for (int l = 0; l < p.L; ++l) total += sh_i[8 * l + 6];
 
-    const int64_t pix_floats = (int64_t)p.M * kBtD;
-    const uint32_t pix_bytes = (uint32_t)(p.M * kBtD * 4);
-
-    // ---- the work list, pipelined one item deep (round 6).  An item used to begin with a chain of dependent trips to
-    // memory during which the whole CU idled: counter -> tile's row range and bound -> row order -> row operands, ~10 us
-    // of the ~40 an item takes.  Now thread 0 draws item numbers TWO turns ahead and fetches the next item's row range
-    // and bound while the current item's rows are processed; after the barrier in front of the flush every thread knows
-    // the next item, requests its first rows' numbers before the flush and their operands after it ----
+    // ---- the work list, pipelined one item deep.  An item used to begin with a chain of dependent trips to memory
+    // during which the waves idled: counter -> tile's row range and bound -> row order -> row operands.  Thread 0 draws
+    // item numbers TWO turns ahead and fetches the next item's row range and bound while the current item's rows are
+    // processed; after the barrier in front of the flush every wave knows the next item, requests the numbers of its
+    // first rows before the flush and their operands after it ----
     // thread 0: the three scalars of an item that live in memory
     auto fetch = [&](int r, int &s0, int &n, uint32_t &bound) {
         s0 = 0;
@@ -462,7 +671,7 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         t[2] = s1 - s0;
         t[3] = (int)bound;
     };
-    // every thread: the item of a published slot
+    // every scatter wave: the item of a published slot
     auto item_of = [&](int slot) {
         BtItem it{};
         const int *t = sh_i + 64 + 4 * slot;
@@ -519,19 +728,18 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         return it;
     };
 
-    // ---- operands of a pass, loaded one pass ahead (a wave's passes are kBtWaves * 16 rows apart) ----
+    // ---- operands of a pass, loaded one pass ahead, their row numbers two (a wave's passes are kBtScWaves * 16 rows apart) ----
     struct SuIn {     // of the lane as a set-up lane: its sample's location and weight, 8 channels of its row's gradient
         float2 xy;
         float a;
         float4 g0, g1;
     };
-    struct CoIn {     // of the lane as one of the eight of a row
-        float4 g;
+    struct CoIn {     // of the lane as one of the eight of a row: its four channels of the row's gradient (rotated octets)
         float gs[4];
         int64_t row;
     };
     auto query_of = [&](const BtItem &it, int i) {
-        const int ii = min(i, it.n - 1);
+        const int ii = max(min(i, it.n - 1), 0);
         return it.ord ? it.ord[ii] : it.begin + ii;
     };
     auto load_su = [&](const BtItem &it, int q) {
@@ -547,7 +755,6 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
     auto load_co = [&](const BtItem &it, int q) {
         CoIn r;
         r.row = ((int64_t)it.b * p.Nq + q) * p.M + it.m;
-        r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.gs[j] = p.grad_out[r.row * kBtD + 8 * (rho ^ j) + k];
         return r;
@@ -563,15 +770,22 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         publish(0, r0, s0, s1, bd);
         r_next = r0 + 1;
     }
-    __syncthreads();
+    bt_scatter_barrier(bar, epoch, lane);
     BtItem it = item_of(0);
-    constexpr int kStride = kBtWaves * kBtPassRows;
+    constexpr int kStride = kBtScWaves * kBtPassRows;
     SuIn su_n{};
     CoIn co_n0{}, co_n1{};
-    if (wave * kBtPassRows < it.n) {
-        su_n = load_su(it, query_of(it, wave * kBtPassRows + su_row));
-        co_n0 = load_co(it, query_of(it, wave * kBtPassRows + r8));
-        co_n1 = load_co(it, query_of(it, wave * kBtPassRows + 8 + r8));
+    int q_su = 0, q_a = 0, q_b = 0;   // row numbers of the pass after the loaded one
+    {
+        const int b0 = wave * kBtPassRows;
+        if (b0 < it.n) {
+            su_n = load_su(it, query_of(it, b0 + su_row));
+            co_n0 = load_co(it, query_of(it, b0 + r8));
+            co_n1 = load_co(it, query_of(it, b0 + 8 + r8));
+            q_su = query_of(it, b0 + kStride + su_row);
+            q_a = query_of(it, b0 + kStride + r8);
+            q_b = query_of(it, b0 + kStride + 8 + r8);
+        }
     }
 
     BT_STAMP(0);   // prologue
@@ -587,45 +801,23 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         const int ox = it.ox, oy = it.oy, ww = it.ww, wh = it.wh;
         const float scale = it.scale, inv_scale = it.inv_scale, small_row = it.small_row;
         const bool use_window = it.use_window;
-        const __amdgpu_buffer_rsrc_t vrsrc = make_uniform_rsrc(
-            reinterpret_cast<const char *>(p.value + ((int64_t)it.b * p.Nv * p.M + it.m) * kBtD),
-            (uint32_t)(((int64_t)p.Nv * p.M - it.m) * kBtD * 4));
         float *gv_base = p.grad_value + ((int64_t)it.b * p.Nv * p.M + it.m) * kBtD;
         const float fW = (float)W, fH = (float)H;
 
-        // ---- one 8-row half: corner loads, scatter (under the loads), corner dot products, outputs ----
+        // ---- one 8-row half: the 64 window adds of every lane; samples outside the window by global atomics ----
         auto half = [&](const CoIn &co, int hbase) {
             const bool act = hbase + r8 < n;
-            uint4 q0[kBtP], q2[kBtP];
-            float4 q1[kBtP], q3[kBtP];
-#pragma unroll
-            for (int s = 0; s < kBtP; ++s) q0[s] = *reinterpret_cast<const uint4 *>(rec_rd + s * 64);
-            float4 v[kBtP][4];
-#if defined(BT_KO_LOADS) || defined(BT_KO_GATHER)
-#pragma unroll
-            for (int s = 0; s < kBtP; ++s)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[s][c] = make_float4(__uint_as_float(q0[s].x), __uint_as_float(q0[s].y), __uint_as_float(q0[s].z), 1.f);
-#else
+            float4 q1[kBtP];
+            uint4 q2[kBtP];
 #pragma unroll
             for (int s = 0; s < kBtP; ++s) {
-                v[s][0] = as_f4(buffer_load16(vrsrc, q0[s].x + 16u * k));
-                v[s][1] = as_f4(buffer_load16(vrsrc, q0[s].y + 16u * k));
-                v[s][2] = as_f4(buffer_load16(vrsrc, q0[s].z + 16u * k));
-                v[s][3] = as_f4(buffer_load16(vrsrc, q0[s].w + 16u * k));
-            }
-#endif
-#pragma unroll
-            for (int s = 0; s < kBtP; ++s) {
-                q1[s] = *reinterpret_cast<const float4 *>(rec_rd + s * 64 + 16);
-                q2[s] = *reinterpret_cast<const uint4 *>(rec_rd + s * 64 + 32);
-                q3[s] = *reinterpret_cast<const float4 *>(rec_rd + s * 64 + 48);
+                q1[s] = *reinterpret_cast<const float4 *>(c.rec_rd + s * 32);
+                q2[s] = *reinterpret_cast<const uint4 *>(c.rec_rd + s * 32 + 16);
             }
             uint32_t fallback = 0;
 #pragma unroll
             for (int s = 0; s < kBtP; ++s) fallback |= (q2[s].z & 1u) << s;
-            BT_STAMP(2);   // records written and read back, corner loads issued
-            auto scatter = [&]() {
+            BT_STAMP(2);   // records written and read back
 #ifndef BT_KO_SCATTER
             if (use_window) {
                 const bt_f32x2_t gs01 = {co.gs[0], co.gs[1]}, gs23 = {co.gs[2], co.gs[3]};
@@ -635,51 +827,18 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                                             bt_pix_lo(q2[s].y, 128u, lane_base), bt_pix_hi(q2[s].y, 128u, lane_base)};
                     const float wa[4] = {q1[s].x, q1[s].y, q1[s].z, q1[s].w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const bt_f32x2_t w2 = {wa[c], wa[c]};
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const bt_f32x2_t w2 = {wa[cc], wa[cc]};
                         const bt_f32x2_t p01 = gs01 * w2, p23 = gs23 * w2;   // v_pk_mul_f32
-                        bt_lds_add(ad[c], bt_round(p01.x));
-                        bt_lds_add(ad[c] ^ 32u, bt_round(p01.y));
-                        bt_lds_add(ad[c] ^ 64u, bt_round(p23.x));
-                        bt_lds_add(ad[c] ^ 96u, bt_round(p23.y));
+                        bt_lds_add(ad[cc], bt_round(p01.x));
+                        bt_lds_add(ad[cc] ^ 32u, bt_round(p01.y));
+                        bt_lds_add(ad[cc] ^ 64u, bt_round(p23.x));
+                        bt_lds_add(ad[cc] ^ 96u, bt_round(p23.y));
                     }
                 }
             }
 #endif
-            };
-            const bool scatter_first = !BT_STAGGER || (wave & 4) == 0;
-            if (scatter_first) scatter();
             BT_STAMP(3);   // scatter
-            // the three outputs of a sample are linear in its four corner dot products: combined per lane (on the
-            // lane's four channels), THEN summed over the eight lanes -- 12 sums per row instead of 16
-            float o[12];
-            const float4 g = co.g;
-#ifdef BT_KO_GATHER
-#pragma unroll
-            for (int s = 0; s < kBtP; ++s) o[3 * s] = o[3 * s + 1] = o[3 * s + 2] = v[s][0].x + q3[s].x;
-            if (o[0] == 12345.f)
-#endif
-#pragma unroll
-            for (int s = 0; s < kBtP; ++s) {
-                float d[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[c] = g.x * v[s][c].x + g.y * v[s][c].y + g.z * v[s][c].z + g.w * v[s][c].w;
-                const float lx = q3[s].x, ly = q3[s].y, hx = 1.f - lx, hy = 1.f - ly;
-                o[3 * s] = hy * hx * d[0] + hy * lx * d[1] + ly * hx * d[2] + ly * lx * d[3];
-                o[3 * s + 1] = q3[s].z * (hy * (d[1] - d[0]) + ly * (d[3] - d[2]));
-                o[3 * s + 2] = q3[s].w * (hx * (d[2] - d[0]) + lx * (d[3] - d[1]));
-            }
-#ifndef BT_KO_GATHER
-            bt_sum8_x12(o);
-#endif
-            if (!scatter_first) scatter();
-            BT_STAMP(4);   // corner dot products (waits for the corner loads), sums
-            if (act && k == 0) {
-                *reinterpret_cast<float4 *>(p.grad_aw + (co.row * p.L + l) * kBtP) = make_float4(o[0], o[3], o[6], o[9]);
-                float4 *gl = reinterpret_cast<float4 *>(p.grad_loc + (co.row * p.L + l) * (kBtP * 2));
-                gl[0] = make_float4(o[1], o[2], o[4], o[5]);
-                gl[1] = make_float4(o[7], o[8], o[10], o[11]);
-            }
             // ---- samples that left their window (or items / rows without one): fp32 atomics on global memory, set up
             // again from the row's own location (rare) ----
             if (act && fallback) {
@@ -695,13 +854,14 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                     const float wf[4] = {hy * hx * a, hy * lx * a, ly * hx * a, ly * lx * a};
                     const int64_t co_[4] = {0, pix_floats, (int64_t)W * pix_floats, (int64_t)(W + 1) * pix_floats};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (sm.flags & (1u << c)) {
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (sm.flags & (1u << cc)) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gp + co_[c] + 8 * (rho ^ j), wf[c] * co.gs[j]);
+                            for (int j = 0; j < 4; ++j) unsafeAtomicAdd(gp + co_[cc] + 8 * (rho ^ j), wf[cc] * co.gs[j]);
                         }
                 }
             }
+            BT_STAMP(5);   // global-atomic samples
         };
 
         int base = wave * kBtPassRows;
@@ -710,15 +870,11 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
 #endif
         for (; base < n; base += kStride) {
             const SuIn su = su_n;
-            const CoIn co0 = co_n0, co1 = co_n1;
-            if (base + kStride < n) {
-                su_n = load_su(it, query_of(it, base + kStride + su_row));
-                co_n0 = load_co(it, query_of(it, base + kStride + r8));
-                co_n1 = load_co(it, query_of(it, base + kStride + 8 + r8));
-            }
+            const CoIn co0 = co_n0;
+            CoIn co1 = co_n1;
             // ---- set-up of the pass's 64 samples, one per lane ----
-            uint4 r0, r2;
-            float4 r1, r3;
+            float4 r0;
+            uint4 r1;
             {
                 const bool act_su = base + su_row < n;
                 // the row's own bound (the four lanes of the row agree on it)
@@ -734,43 +890,45 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                 int x0, y0;
                 const BtSample sm = bt_setup(su.xy.x, su.xy.y, su.a, H, W, fH, fW, lstart, ox, oy, ww, wh, row_in_window, x0, y0);
                 const uint32_t f = sm.flags;
-                const uint32_t o00 = (uint32_t)sm.pix * pix_bytes;
-                r0 = make_uint4((f & 1u) ? o00 : kBtNoCorner, (f & 2u) ? o00 + pix_bytes : kBtNoCorner,
-                                (f & 4u) ? o00 + (uint32_t)W * pix_bytes : kBtNoCorner,
-                                (f & 8u) ? o00 + (uint32_t)(W + 1) * pix_bytes : kBtNoCorner);
                 // scaled corner weights (zero for corners off the image and for samples that leave the window: their
                 // adds are exact zeros on a clamped address) and the window pixel of each corner
                 const float hx = 1.f - sm.lx, hy = 1.f - sm.ly;
                 const float as = (f & 16u) ? sm.a * scale : 0.f;
-                r1 = make_float4((f & 1u) ? hy * hx * as : 0.f, (f & 2u) ? hy * sm.lx * as : 0.f,
+                r0 = make_float4((f & 1u) ? hy * hx * as : 0.f, (f & 2u) ? hy * sm.lx * as : 0.f,
                                  (f & 4u) ? sm.ly * hx * as : 0.f, (f & 8u) ? sm.ly * sm.lx * as : 0.f);
                 const int cx0 = bt_clamp(x0 - ox, 0, ww - 1), cx1 = bt_clamp(x0 + 1 - ox, 0, ww - 1);
                 const int cy0 = bt_clamp(y0 - oy, 0, wh - 1), cy1 = bt_clamp(y0 + 1 - oy, 0, wh - 1);
-                r2 = make_uint4((uint32_t)(cy0 * ww + cx0) | ((uint32_t)(cy0 * ww + cx1) << 16),
+                r1 = make_uint4((uint32_t)(cy0 * ww + cx0) | ((uint32_t)(cy0 * ww + cx1) << 16),
                                 (uint32_t)(cy1 * ww + cx0) | ((uint32_t)(cy1 * ww + cx1) << 16),
                                 (act_su && (f & 0x30u) == 0x20u) ? 1u : 0u,   // inside the level, not in the window
                                 0u);
-                r3 = make_float4(sm.lx, sm.ly, fW * sm.a, fH * sm.a);
             }
-            BT_STAMP(1);   // set-up (+ item head for the first pass)
+            BT_STAMP(1);   // set-up (+ the requests of the next pass)
             if (lane < 32) {
-                *reinterpret_cast<uint4 *>(rec_wr) = r0;
-                *reinterpret_cast<float4 *>(rec_wr + 16) = r1;
-                *reinterpret_cast<uint4 *>(rec_wr + 32) = r2;
-                *reinterpret_cast<float4 *>(rec_wr + 48) = r3;
+                *reinterpret_cast<float4 *>(c.rec_wr) = r0;
+                *reinterpret_cast<uint4 *>(c.rec_wr + 16) = r1;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             half(co0, base);
+            // the next pass's operands: requested here, behind an explicit use of everything the previous request brought
+            // (see bt_gather_waves)
+            asm volatile("" : "+v"(co1.gs[0]), "+v"(co1.gs[1]), "+v"(co1.gs[2]), "+v"(co1.gs[3]), "+v"(q_su), "+v"(q_a), "+v"(q_b));
+            if (base + kStride < n) {
+                su_n = load_su(it, q_su);
+                co_n0 = load_co(it, q_a);
+                co_n1 = load_co(it, q_b);
+                q_su = query_of(it, base + 2 * kStride + su_row);
+                q_a = query_of(it, base + 2 * kStride + r8);
+                q_b = query_of(it, base + 2 * kStride + 8 + r8);
+            }
             if (base + 8 < n) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (lane >= 32) {
-                    *reinterpret_cast<uint4 *>(rec_wr) = r0;
-                    *reinterpret_cast<float4 *>(rec_wr + 16) = r1;
-                    *reinterpret_cast<uint4 *>(rec_wr + 32) = r2;
-                    *reinterpret_cast<float4 *>(rec_wr + 48) = r3;
+                    *reinterpret_cast<float4 *>(c.rec_wr) = r0;
+                    *reinterpret_cast<uint4 *>(c.rec_wr + 16) = r1;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -778,35 +936,37 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
                 half(co1, base + 8);
             }
         }
-        BT_STAMP(5);   // output stores, global-atomic samples
         // thread 0: the next item's scalars (on their way since the item began) and the number of the one after it
         if (tid == 0) {
             publish((iter + 1) & 1, r_next, nx_s0, nx_s1, nx_bd);
             r_next = r_next2;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the inline-asm adds are invisible to the compiler's counters
-        __syncthreads();
+        bt_scatter_barrier(bar, epoch, lane);
         BT_STAMP(6);   // waiting for the item's other waves
         // the next item; the numbers of its first rows are requested before the flush ...
         const BtItem nx = item_of((iter + 1) & 1);
-        const bool nx_rows = wave * kBtPassRows < nx.n;
-        int nq_su = 0, nq_0 = 0, nq_1 = 0;
+        const int nb0 = wave * kBtPassRows;
+        const bool nx_rows = nb0 < nx.n;
+        int nq_su = 0, nq_a = 0, nq_b = 0;
         if (nx_rows) {
-            nq_su = query_of(nx, wave * kBtPassRows + su_row);
-            nq_0 = query_of(nx, wave * kBtPassRows + r8);
-            nq_1 = query_of(nx, wave * kBtPassRows + 8 + r8);
+            nq_su = query_of(nx, nb0 + su_row);
+            nq_a = query_of(nx, nb0 + r8);
+            nq_b = query_of(nx, nb0 + 8 + r8);
+            q_su = query_of(nx, nb0 + kStride + su_row);
+            q_a = query_of(nx, nb0 + kStride + r8);
+            q_b = query_of(nx, nb0 + kStride + 8 + r8);
         }
         // ---- flush: whole 128-byte lines of fp32 atomics, accumulators left at zero for the next item.  A wave takes
         // window rows wave, wave + 8, ...: the row's image coordinates and base address are scalars, a lane is (pixel
         // parity, channel) and steps two pixels at a time ----
         if (use_window && scale != 0.f && n > 0) {
-            const int c = lane & 31, h = lane >> 5;
+            const int ch = lane & 31, h = lane >> 5;
             constexpr int kAhead = 4;
-            for (int wy = wave; wy < wh; wy += kBtWaves) {
+            for (int wy = wave; wy < wh; wy += kBtScWaves) {
                 const int Y = oy + wy;
                 if (Y < 0 || Y >= H) continue;   // (rows of the halo beyond the image hold zeros: nothing was added there)
-                float *rowp = gv_base + (int64_t)(lstart + Y * W + ox) * pix_floats + c;
-                uint32_t *wrow = win + wy * ww * 32 + c;
+                float *rowp = gv_base + (int64_t)(lstart + Y * W + ox) * pix_floats + ch;
+                uint32_t *wrow = win + wy * ww * 32 + ch;
                 for (int wx0 = h; wx0 < ww; wx0 += 2 * kAhead) {
                     int v[kAhead];
 #pragma unroll
@@ -830,19 +990,20 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         // ... and their operands after it
         if (nx_rows) {
             su_n = load_su(nx, nq_su);
-            co_n0 = load_co(nx, nq_0);
-            co_n1 = load_co(nx, nq_1);
+            co_n0 = load_co(nx, nq_a);
+            co_n1 = load_co(nx, nq_b);
         }
         it = nx;
         BT_STAMP(7);   // flush, next item's first requests
-        __syncthreads();
+        bt_scatter_barrier(bar, epoch, lane);
         BT_STAMP(8);   // waiting for the flush of the other waves
     }
 #ifdef BT_STAMPS
     st_acc[9] = (unsigned long long)(clock64() - st_t0);
     if (lane == 0) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.counter) + 4;
-        for (int i = 0; i < 10; ++i) atomicAdd(dst + i, st_acc[i]);
+        for (int i = 0; i < 10; ++i)
+            if (i != 4) atomicAdd(dst + i, st_acc[i]);
     }
 #endif
 }
