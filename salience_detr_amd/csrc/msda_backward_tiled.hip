@@ -361,7 +361,7 @@ __device__ __forceinline__ uint32_t bt_pix_hi(uint32_t packed, uint32_t pitch, u
 //                       is off the image (the buffer load returns zeros)
 //                   [1] lx, ly, W * aw, H * aw
 
-// An item of the work list, as every scatter wave needs it.
+// An item of the work list.
 struct BtItem {
     int l, H, W, lstart, mode, m, b, n, begin, ox, oy, ww, wh;
     const int32_t *ord;
@@ -383,6 +383,65 @@ __device__ __forceinline__ void bt_item_place(int r, const int *sh_i, int L, int
     const int bm = r / parts;
     m = bm % M;
     b = bm / M;
+}
+
+// every wave: the item of a published slot (`sh_i` [64 + 4 slot ...]: item number, first row in the tile order, rows, bits of
+// the (level, image, head) row bound); n = -1 beyond the end of the list
+__device__ __forceinline__ BtItem bt_item_of(const BtArgs &p, const int *sh_i, int total, int slot)
+{
+    BtItem it{};
+    const int *t = sh_i + 64 + 4 * slot;
+    const int r = bt_uniform(t[0]);
+    it.n = -1;
+    if (r >= total) return it;
+    int l, part, m, b;
+    bt_item_place(r, sh_i, p.L, p.M, l, part, m, b);
+    it.l = bt_uniform(l);
+    part = bt_uniform(part);
+    it.m = bt_uniform(m);
+    it.b = bt_uniform(b);
+    it.H = bt_uniform(sh_i[8 * it.l]);
+    it.W = bt_uniform(sh_i[8 * it.l + 1]);
+    it.lstart = bt_uniform(sh_i[8 * it.l + 2]);
+    it.mode = bt_uniform(sh_i[8 * it.l + 3]);
+    const int tiles_x = bt_uniform(sh_i[8 * it.l + 4]), parts = bt_uniform(sh_i[8 * it.l + 5]);
+    if (it.mode == kBtTile) {
+        it.n = bt_uniform(t[2]);
+        it.ord = p.order + ((int64_t)it.l * p.B + it.b) * p.Nq + bt_uniform(t[1]);
+        it.ox = kBtTileW * (part % tiles_x) - kBtHalo;
+        it.oy = kBtTileH * (part / tiles_x) - kBtHalo;
+        it.ww = kBtWinW;
+        it.wh = kBtWinH;
+    } else {
+        const int per = (p.Nq + parts - 1) / parts;
+        it.begin = part * per;
+        it.n = min(p.Nq, it.begin + per) - it.begin;
+        if (it.mode == kBtResident) {
+            it.ww = it.W;
+            it.wh = it.H;
+        }
+    }
+    it.n = max(it.n, 0);
+    // window and fixed-point scale: no accumulator of the item can exceed n * (largest row bound of the
+    // (level, image, head)), bt_tile_id_kernel's max of max_c|g| * sum_p|aw|.  bound < 2^x -> scale 2^(29 - x).
+    // A row whose own bound max_c|g| * sum_p|aw| lies more than 2^-20 below the item's accumulator bound would have
+    // its contributions rounded at a quantum (2^-30 of the bound) that is coarse for THEM: one outlier query, or a
+    // heavy-tailed loss scale, must not cost the small gradients their bits.  Such rows take the fp32
+    // path (direct atomics), like samples outside the window.  Rows above the threshold keep a relative rounding
+    // error <= 2^-11 per add before the exact integer accumulation; typical gradients are nowhere near it.
+    if (it.mode != kBtDirect && it.n > 0) {
+        const float bound = (float)it.n * __uint_as_float((uint32_t)bt_uniform(t[3]));
+        it.small_row = bound * 0x1p-20f;
+        if (bound > 0x1p-90f && bound < 0x1p+90f) {
+            const int x = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
+            it.scale = __uint_as_float((uint32_t)(29 - x + 127) << 23);
+            it.inv_scale = __uint_as_float((uint32_t)(127 - (29 - x)) << 23);
+            it.use_window = true;
+        } else if (bound == 0.f) {
+            it.use_window = true;   // nothing to scatter: every contribution is an exact zero
+        }
+    }
+    return it;
 }
 
 // (benchmark builds only: cycle stamps per phase, summed over the waves into the workspace header, words 8...)
@@ -416,32 +475,14 @@ struct BtCtx {   // what both kinds of wave know
 };
 
 // ------------------------------------------------------------------------------------------------
-// gather waves: grad_sampling_loc, grad_attn_weight of every row, 16 rows per turn
-__device__ __forceinline__ void bt_gather_waves(const BtArgs &p, const int *sh_i, const BtCtx &c, int gw, int gws)
+// gather waves: grad_sampling_loc, grad_attn_weight.  They take the SAME items as their workgroup's scatter waves, at
+// the same time (the rows' gradient, locations and weights come from memory once for both kinds -- walking the rows on
+// their own the gather waves doubled the launch's HBM fetches), 16 rows per turn.  One s_barrier per item, where the
+// scatter waves are done with the item's rows and thread 0 has published the next item: then the scatter waves flush and
+// the gather waves go straight on to the next item's rows.
+__device__ __forceinline__ void bt_gather_role(const BtArgs &p, const int *sh_i, const BtCtx &c, int total, int rwave)
 {
     const int lane = c.lane, k = c.k, r8 = c.r8;
-    const int G = (p.Nq + kBtPassRows - 1) / kBtPassRows;
-    const int64_t units = (int64_t)p.L * p.B * p.M * G;
-    struct Unit {
-        int l, b, m, g;
-    };
-    auto unit_of = [&](int64_t u) {
-        Unit t;
-        t.g = (int)(u % G);
-        const int lbm = (int)(u / G);
-        t.m = bt_uniform(lbm % p.M);
-        const int lb = lbm / p.M;
-        t.b = bt_uniform(lb % p.B);
-        t.l = bt_uniform(lb / p.B);
-        t.g = bt_uniform(t.g);
-        return t;
-    };
-    // the rows of a (level, image) in the order of its tiles where the level has tiles (neighbouring rows sample
-    // neighbouring pixels: the corner loads of a turn stay in a few cache lines), in their own order elsewhere
-    auto query_of = [&](const Unit &t, int i) {
-        const int ii = min(i, p.Nq - 1);
-        return sh_i[8 * t.l + 3] == kBtTile ? p.order[((int64_t)t.l * p.B + t.b) * p.Nq + ii] : ii;
-    };
     struct SuIn {
         float2 xy;
         float a;
@@ -450,77 +491,49 @@ __device__ __forceinline__ void bt_gather_waves(const BtArgs &p, const int *sh_i
         float4 g;
         int64_t row;
     };
-    auto load_su = [&](const Unit &t, int q) {
+    auto query_of = [&](const BtItem &it, int i) {
+        const int ii = max(min(i, it.n - 1), 0);
+        return it.ord ? it.ord[ii] : it.begin + ii;
+    };
+    auto load_su = [&](const BtItem &it, int q) {
         SuIn r;
-        const int64_t row = ((int64_t)t.b * p.Nq + q) * p.M + t.m;
-        r.xy = *reinterpret_cast<const float2 *>(p.loc + ((row * p.L + t.l) * kBtP + c.su_s) * 2);
-        r.a = p.aw[(row * p.L + t.l) * kBtP + c.su_s];
+        const int64_t row = ((int64_t)it.b * p.Nq + q) * p.M + it.m;
+        r.xy = *reinterpret_cast<const float2 *>(p.loc + ((row * p.L + it.l) * kBtP + c.su_s) * 2);
+        r.a = p.aw[(row * p.L + it.l) * kBtP + c.su_s];
         return r;
     };
-    auto load_co = [&](const Unit &t, int q) {
+    auto load_co = [&](const BtItem &it, int q) {
         CoIn r;
-        r.row = ((int64_t)t.b * p.Nq + q) * p.M + t.m;
+        r.row = ((int64_t)it.b * p.Nq + q) * p.M + it.m;
         r.g = *reinterpret_cast<const float4 *>(p.grad_out + r.row * kBtD + 4 * k);
         return r;
     };
+    constexpr int kStride = kBtGaWaves * kBtPassRows;
+    const int b0 = rwave * kBtPassRows;
 
-    int64_t u = gw;
-    if (u >= units) return;
+    BtItem it = bt_item_of(p, sh_i, total, 0);
     // row numbers two turns ahead, operands one turn ahead (a row number is a trip to memory in front of its operands)
-    Unit t0 = unit_of(u), t1 = t0;
-    int q_su = query_of(t0, t0.g * kBtPassRows + c.su_row), q_a = query_of(t0, t0.g * kBtPassRows + r8),
-        q_b = query_of(t0, t0.g * kBtPassRows + 8 + r8);
-    SuIn su_n = load_su(t0, q_su);
-    CoIn co_n0 = load_co(t0, q_a), co_n1 = load_co(t0, q_b);
-    if (u + gws < units) {
-        t1 = unit_of(u + gws);
-        q_su = query_of(t1, t1.g * kBtPassRows + c.su_row);
-        q_a = query_of(t1, t1.g * kBtPassRows + r8);
-        q_b = query_of(t1, t1.g * kBtPassRows + 8 + r8);
-    }
-    for (; u < units; u += gws) {
-        const Unit t = t0;
-        const SuIn su = su_n;
-        const CoIn co0 = co_n0;
-        CoIn co1 = co_n1;
-        // the next turn's operands are requested between this turn's halves, behind an explicit use of everything the
-        // previous request brought: requested at the top of the turn they sat in front of the set-up's first wait, which
-        // (one counter, in order) then waited for THEM -- a trip to memory per turn in plain view
-        auto request_next = [&]() {
-            asm volatile("" : "+v"(co1.g.x), "+v"(co1.g.y), "+v"(co1.g.z), "+v"(co1.g.w), "+v"(q_su), "+v"(q_a), "+v"(q_b));
-            t0 = t1;
-            if (u + gws < units) {
-                su_n = load_su(t0, q_su);
-                co_n0 = load_co(t0, q_a);
-                co_n1 = load_co(t0, q_b);
-                if (u + 2 * gws < units) {
-                    t1 = unit_of(u + 2 * gws);
-                    q_su = query_of(t1, t1.g * kBtPassRows + c.su_row);
-                    q_a = query_of(t1, t1.g * kBtPassRows + r8);
-                    q_b = query_of(t1, t1.g * kBtPassRows + 8 + r8);
-                }
-            }
-        };
-        const int l = t.l, H = bt_uniform(sh_i[8 * l]), W = bt_uniform(sh_i[8 * l + 1]), lstart = bt_uniform(sh_i[8 * l + 2]);
+    SuIn su_n{};
+    CoIn co_n0{}, co_n1{};
+    int q_su = 0, q_a = 0, q_b = 0;
+    auto first_requests = [&](const BtItem &t) {
+        if (b0 >= t.n) return;
+        su_n = load_su(t, query_of(t, b0 + c.su_row));
+        co_n0 = load_co(t, query_of(t, b0 + r8));
+        co_n1 = load_co(t, query_of(t, b0 + 8 + r8));
+        q_su = query_of(t, b0 + kStride + c.su_row);
+        q_a = query_of(t, b0 + kStride + r8);
+        q_b = query_of(t, b0 + kStride + 8 + r8);
+    };
+    first_requests(it);
+    for (int iter = 0; it.n >= 0; ++iter) {
+        const int l = it.l, H = it.H, W = it.W, lstart = it.lstart, n = it.n;
         const float fW = (float)W, fH = (float)H;
         const __amdgpu_buffer_rsrc_t vrsrc = make_uniform_rsrc(
-            reinterpret_cast<const char *>(p.value + ((int64_t)t.b * p.Nv * p.M + t.m) * kBtD),
-            (uint32_t)(((int64_t)p.Nv * p.M - t.m) * kBtD * 4));
-        // ---- set-up of the turn's 64 samples, one per lane ----
-        uint4 r0;
-        float4 r1;
-        {
-            int x0, y0;
-            const BtSample sm = bt_setup(su.xy.x, su.xy.y, su.a, H, W, fH, fW, lstart, 0, 0, 0, 0, false, x0, y0);
-            const uint32_t f = sm.flags;
-            const uint32_t o00 = (uint32_t)sm.pix * c.pix_bytes;
-            r0 = make_uint4((f & 1u) ? o00 : kBtNoCorner, (f & 2u) ? o00 + c.pix_bytes : kBtNoCorner,
-                            (f & 4u) ? o00 + (uint32_t)W * c.pix_bytes : kBtNoCorner,
-                            (f & 8u) ? o00 + (uint32_t)(W + 1) * c.pix_bytes : kBtNoCorner);
-            r1 = make_float4(sm.lx, sm.ly, fW * sm.a, fH * sm.a);
-        }
+            reinterpret_cast<const char *>(p.value + ((int64_t)it.b * p.Nv * p.M + it.m) * kBtD),
+            (uint32_t)(((int64_t)p.Nv * p.M - it.m) * kBtD * 4));
         auto half = [&](const CoIn &co, int hbase) {
-            const bool act = hbase + r8 < p.Nq;
+            const bool act = hbase + r8 < n;
             uint4 q0[kBtP];
 #pragma unroll
             for (int s = 0; s < kBtP; ++s) q0[s] = *reinterpret_cast<const uint4 *>(c.rec_rd + s * 32);
@@ -556,28 +569,59 @@ __device__ __forceinline__ void bt_gather_waves(const BtArgs &p, const int *sh_i
                 gl[1] = make_float4(o[7], o[8], o[10], o[11]);
             }
         };
-        const int base = t.g * kBtPassRows;
-        if (lane < 32) {
-            *reinterpret_cast<uint4 *>(c.rec_wr) = r0;
-            *reinterpret_cast<float4 *>(c.rec_wr + 16) = r1;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        half(co0, base);
-        request_next();
-        if (base + 8 < p.Nq) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= 32) {
+        for (int base = b0; base < n; base += kStride) {
+            const SuIn su = su_n;
+            const CoIn co0 = co_n0;
+            CoIn co1 = co_n1;
+            // ---- set-up of the turn's 64 samples, one per lane ----
+            uint4 r0;
+            float4 r1;
+            {
+                int x0, y0;
+                const BtSample sm = bt_setup(su.xy.x, su.xy.y, su.a, H, W, fH, fW, lstart, 0, 0, 0, 0, false, x0, y0);
+                const uint32_t f = sm.flags;
+                const uint32_t o00 = (uint32_t)sm.pix * c.pix_bytes;
+                r0 = make_uint4((f & 1u) ? o00 : kBtNoCorner, (f & 2u) ? o00 + c.pix_bytes : kBtNoCorner,
+                                (f & 4u) ? o00 + (uint32_t)W * c.pix_bytes : kBtNoCorner,
+                                (f & 8u) ? o00 + (uint32_t)(W + 1) * c.pix_bytes : kBtNoCorner);
+                r1 = make_float4(sm.lx, sm.ly, fW * sm.a, fH * sm.a);
+            }
+            if (lane < 32) {
                 *reinterpret_cast<uint4 *>(c.rec_wr) = r0;
                 *reinterpret_cast<float4 *>(c.rec_wr + 16) = r1;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            half(co1, base + 8);
+            half(co0, base);
+            // the next turn's operands are requested between this turn's halves, behind an explicit use of everything the
+            // previous request brought: requested at the top of the turn they sat in front of the set-up's first wait, which
+            // (one counter, in order) then waited for THEM -- a trip to memory per turn in plain view
+            asm volatile("" : "+v"(co1.g.x), "+v"(co1.g.y), "+v"(co1.g.z), "+v"(co1.g.w), "+v"(q_su), "+v"(q_a), "+v"(q_b));
+            if (base + kStride < n) {
+                su_n = load_su(it, q_su);
+                co_n0 = load_co(it, q_a);
+                co_n1 = load_co(it, q_b);
+                q_su = query_of(it, base + 2 * kStride + c.su_row);
+                q_a = query_of(it, base + 2 * kStride + r8);
+                q_b = query_of(it, base + 2 * kStride + 8 + r8);
+            }
+            if (base + 8 < n) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane >= 32) {
+                    *reinterpret_cast<uint4 *>(c.rec_wr) = r0;
+                    *reinterpret_cast<float4 *>(c.rec_wr + 16) = r1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                half(co1, base + 8);
+            }
         }
+        __syncthreads();   // the item's barrier (bt_main_kernel): the next item is published
+        it = bt_item_of(p, sh_i, total, (iter + 1) & 1);
+        first_requests(it);
     }
 }
 
@@ -626,23 +670,13 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
     }
     if (tid == 0) sh_i[80] = 0;
     for (int i = tid; i < kBtWinBytes / 16; i += kBtThreads) reinterpret_cast<uint4 *>(win)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();   // the only s_barrier of the kernel: from here on the two kinds of wave go their own ways
-
-    if (wave >= kBtScWaves) {
-#ifndef BT_KO_GATHER_WAVES
-        bt_gather_waves(p, sh_i, c, (int)blockIdx.x * kBtGaWaves + (wave - kBtScWaves), (int)gridDim.x * kBtGaWaves);
-#endif
-#ifdef BT_STAMPS
-        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(p.counter) + 4 + 4, (unsigned long long)(clock64() - st_t0));
-#endif
-        return;
-    }
-
-    // ================= scatter waves =================
-    int *bar = sh_i + 80;
-    int epoch = 0;
+    __syncthreads();
     int total = 0;
     for (int l = 0; l < p.L; ++l) total += sh_i[8 * l + 6];
+
+    // (thread 0 and its seven fellow scatter waves run the work list; the gather waves branch off below)
+    int *bar = sh_i + 80;
+    int epoch = 0;
 
     // ---- the work list, pipelined one item deep.  An item used to begin with a chain of dependent trips to memory
     // during which the waves idled: counter -> tile's row range and bound -> row order -> row operands.  Thread 0 draws
@@ -671,62 +705,7 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         t[2] = s1 - s0;
         t[3] = (int)bound;
     };
-    // every scatter wave: the item of a published slot
-    auto item_of = [&](int slot) {
-        BtItem it{};
-        const int *t = sh_i + 64 + 4 * slot;
-        const int r = bt_uniform(t[0]);
-        it.n = -1;
-        if (r >= total) return it;
-        int l, part, m, b;
-        bt_item_place(r, sh_i, p.L, p.M, l, part, m, b);
-        it.l = bt_uniform(l);
-        part = bt_uniform(part);
-        it.m = bt_uniform(m);
-        it.b = bt_uniform(b);
-        it.H = bt_uniform(sh_i[8 * it.l]);
-        it.W = bt_uniform(sh_i[8 * it.l + 1]);
-        it.lstart = bt_uniform(sh_i[8 * it.l + 2]);
-        it.mode = bt_uniform(sh_i[8 * it.l + 3]);
-        const int tiles_x = bt_uniform(sh_i[8 * it.l + 4]), parts = bt_uniform(sh_i[8 * it.l + 5]);
-        if (it.mode == kBtTile) {
-            it.n = bt_uniform(t[2]);
-            it.ord = p.order + ((int64_t)it.l * p.B + it.b) * p.Nq + bt_uniform(t[1]);
-            it.ox = kBtTileW * (part % tiles_x) - kBtHalo;
-            it.oy = kBtTileH * (part / tiles_x) - kBtHalo;
-            it.ww = kBtWinW;
-            it.wh = kBtWinH;
-        } else {
-            const int per = (p.Nq + parts - 1) / parts;
-            it.begin = part * per;
-            it.n = min(p.Nq, it.begin + per) - it.begin;
-            if (it.mode == kBtResident) {
-                it.ww = it.W;
-                it.wh = it.H;
-            }
-        }
-        it.n = max(it.n, 0);
-        // window and fixed-point scale: no accumulator of the item can exceed n * (largest row bound of the
-        // (level, image, head)), bt_tile_id_kernel's max of max_c|g| * sum_p|aw|.  bound < 2^x -> scale 2^(29 - x).
-        // A row whose own bound max_c|g| * sum_p|aw| lies more than 2^-20 below the item's accumulator bound would have
-        // its contributions rounded at a quantum (2^-30 of the bound) that is coarse for THEM: one outlier query, or a
-        // heavy-tailed loss scale, must not cost the small gradients their bits.  Such rows take the fp32
-        // path (direct atomics), like samples outside the window.  Rows above the threshold keep a relative rounding
-        // error <= 2^-11 per add before the exact integer accumulation; typical gradients are nowhere near it.
-        if (it.mode != kBtDirect && it.n > 0) {
-            const float bound = (float)it.n * __uint_as_float((uint32_t)bt_uniform(t[3]));
-            it.small_row = bound * 0x1p-20f;
-            if (bound > 0x1p-90f && bound < 0x1p+90f) {
-                const int x = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
-                it.scale = __uint_as_float((uint32_t)(29 - x + 127) << 23);
-                it.inv_scale = __uint_as_float((uint32_t)(127 - (29 - x)) << 23);
-                it.use_window = true;
-            } else if (bound == 0.f) {
-                it.use_window = true;   // nothing to scatter: every contribution is an exact zero
-            }
-        }
-        return it;
-    };
+    auto item_of = [&](int slot) { return bt_item_of(p, sh_i, total, slot); };
 
     // ---- operands of a pass, loaded one pass ahead, their row numbers two (a wave's passes are kBtScWaves * 16 rows apart) ----
     struct SuIn {     // of the lane as a set-up lane: its sample's location and weight, 8 channels of its row's gradient
@@ -770,7 +749,18 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         publish(0, r0, s0, s1, bd);
         r_next = r0 + 1;
     }
-    bt_scatter_barrier(bar, epoch, lane);
+    __syncthreads();   // item 0 is published: from here on the two kinds of wave meet once per item (in front of the flush)
+    if (wave >= kBtScWaves) {
+#ifdef BT_KO_GATHER_WAVES
+        for (int iter = 0; bt_item_of(p, sh_i, total, iter & 1).n >= 0; ++iter) __syncthreads();
+#else
+        bt_gather_role(p, sh_i, c, total, wave - kBtScWaves);
+#endif
+#ifdef BT_STAMPS
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(p.counter) + 4 + 4, (unsigned long long)(clock64() - st_t0));
+#endif
+        return;
+    }
     BtItem it = item_of(0);
     constexpr int kStride = kBtScWaves * kBtPassRows;
     SuIn su_n{};
@@ -941,7 +931,8 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
             publish((iter + 1) & 1, r_next, nx_s0, nx_s1, nx_bd);
             r_next = r_next2;
         }
-        bt_scatter_barrier(bar, epoch, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my window adds have landed (the inline-asm adds are invisible to the compiler's counters)
+        __syncthreads();   // every wave of either kind is done with the item's rows, the next item is published
         BT_STAMP(6);   // waiting for the item's other waves
         // the next item; the numbers of its first rows are requested before the flush ...
         const BtItem nx = item_of((iter + 1) & 1);
@@ -995,6 +986,7 @@ __global__ void __launch_bounds__(kBtThreads) bt_main_kernel(BtArgs p)
         }
         it = nx;
         BT_STAMP(7);   // flush, next item's first requests
+        // the window is clean again: among the scatter waves only -- the gather waves are already in the next item's rows
         bt_scatter_barrier(bar, epoch, lane);
         BT_STAMP(8);   // waiting for the flush of the other waves
     }
