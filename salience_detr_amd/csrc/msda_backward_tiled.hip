@@ -27,40 +27,45 @@
 //    tiles, or an item whose bound is not a normal number, take that path for every sample.
 //
 // Waves and lanes (round 6; until then eight waves did both halves of the backward, every lane of a row repeating the
-// per-sample set-up).  A workgroup is 16 waves of two kinds.  Waves 0-7 (two per SIMD) are the SCATTER waves: they own
-// the window, draw the work list, accumulate grad_value and flush; they synchronise among themselves through an LDS
-// counter (s_barrier would tie the other eight in).  Waves 8-15 are the GATHER waves: grad_sampling_loc and
-// grad_attn_weight of ALL rows of all (level, image, head), 16 rows per turn in the order of the tiles, with no
-// synchronisation at all.  Either kind works on 16 rows at a time: the 64 lanes set up the 64 samples ONCE (lane = (row,
-// sample): pixel, validity, weights, addresses -- these ~75 vector instructions used to run in all eight lanes of a
-// row), the result goes through LDS as a 32-byte record per sample and the eight lanes of a row read it back by
-// broadcast.  Gather: lane k of a row holds channels 4k..4k+3 of a corner (one 16-byte buffer load, out-of-image
-// corners read as zero through the buffer's bounds check); the three outputs of a sample are linear in its four corner
-// dot products <grad_out, v_c>, so they are combined per lane and THEN summed over the 8 lanes (12 fused DPP adds per
-// step instead of 16 sums that compiled to ~100 instructions).  Scatter: lane k owns channels {8j + k}: in instruction
-// i row r adds octet j = (r & 3) ^ i, so the 32 lanes the LDS serves per clock (4 rows x 8 lanes) always cover 32
-// different banks whatever pixels the rows hit -- no bank conflicts by construction, and no two lanes of an
+// per-sample set-up).  A workgroup is 16 waves of two kinds that work on the SAME item at the same time.  Waves 0-7 (two
+// per SIMD) are the SCATTER waves: they own the window, draw the work list, accumulate grad_value and flush.  Waves 8-15
+// are the GATHER waves: grad_sampling_loc and grad_attn_weight of the item's rows.  The two kinds meet at one s_barrier
+// per item -- in front of the flush, where the next item is published -- after which the scatter waves flush (and
+// synchronise among themselves through an LDS counter: the window must be clean before their next add) while the gather
+// waves are already in the next item's rows.  Either kind works on 16 rows at a time: the 64 lanes set up the 64 samples
+// ONCE (lane = (row, sample): pixel, validity, weights, addresses -- these ~75 vector instructions used to run in all
+// eight lanes of a row), the result goes through LDS as a 32-byte record per sample and the eight lanes of a row read it
+// back by broadcast.  Gather: lane k of a row holds channels 4k..4k+3 of a corner (one 16-byte buffer load,
+// out-of-image corners read as zero through the buffer's bounds check); the three outputs of a sample are linear in its
+// four corner dot products <grad_out, v_c>, so they are combined per lane and THEN summed over the 8 lanes (12 fused DPP
+// adds per step instead of 16 sums that compiled to ~100 instructions).  Scatter: lane k owns channels {8j + k}: in
+// instruction i row r adds octet j = (r & 3) ^ i, so the 32 lanes the LDS serves per clock (4 rows x 8 lanes) always
+// cover 32 different banks whatever pixels the rows hit -- no bank conflicts by construction, and no two lanes of an
 // instruction ever share an address.
 //
-// Measured (benchmarks/msda_backward_ab.py, B = 2; profiles/r06_msda_backward_ab.json): 250 us at 11 363 queries (341
-// before round 6; the direct kernel: 1047).  Of these ~46 are the other launches (grad_value's zero fill 12, bucketing
-// 22 + 10, header clear 2); the main launch is ~205.  Knock-outs and cycle stamps (benchmarks/bt_stamps.py,
-// bt_variant.sh): gather waves alone ~113 us, scatter waves alone ~155 (126 without the flush's atomics) -- they overlap
-// only by a quarter; a scatter wave's time is 36 % flush, 19 % LDS adds, 15 % record round trips (behind the queued
-// adds), 17 % waiting for the item's other waves.  No unit is busy more than 40 % (vector ALU 40, LDS 30, L1 20): every
+// Measured (benchmarks/msda_backward_ab.py, B = 2; profiles/r06_msda_backward_ab.json): 241 us at 11 363 queries (341
+// before round 6; the direct kernel: 1050-1070).  Of these ~46 are the other launches (grad_value's zero fill 12,
+// bucketing 22 + 10, header clear 2); the main launch is ~195.  The steps of round 6, same box each: set-up once per
+// sample through LDS records, fused DPP sums, row-wise flush, long items first 341 -> 270; items pipelined one deep
+// (next item's row range, bound and first rows under the flush) 267; two kinds of wave (first walking the rows
+// independently: 250, but twice the HBM fetches -- every row operand came from memory once per kind of wave and level)
+// 241 with the gather waves on their workgroup's items (HBM fetch 483 -> 216 MB per launch).  Cycle stamps
+// (benchmarks/bt_stamps.py on a bt_variant.sh build): a scatter wave's time is 31 % flush, 23 % LDS adds, 16 % record
+// round trips (behind its queued adds), 21 % waiting for other waves; vector ALU 40 % busy, LDS 30 %, L1 20 %: every
 // wave is a chain of dependent latencies, and 16 waves of 128 registers are what the window leaves room for.  The floor
-// under the flush is the memory side: float atomics are executed behind the L2 (TCC_EA0_ATOMIC = all 1.77 M line
-// requests of a launch), and the chip retires 10 G whole-line fp32 atomics per second when it does nothing else
-// (benchmarks/micro/global_atomic_lines.hip: 1.68 M lines in 165 us; plain stores of the same lines: 31 us) -- the
-// flush's atomics are spread under the other work (knocked out: -31 us), but they are why this design cannot reach
-// 0.15 of the roofline: that needs tiles that own their pixels (no halo, rows bucketed per SAMPLE, plain stores).
+// under the flush is the memory side: float atomics are executed behind the L2 (TCC_EA0_ATOMIC = all 1.77 M requests of
+// a launch), and the chip retires 10 G whole-line fp32 atomics per second when it does nothing else
+// (benchmarks/micro/global_atomic_lines.hip: 1.68 M lines in 165 us; plain stores of the same lines: 31 us).  That is
+// why this design stops short of 0.15 of the roofline: it would take tiles that own their pixels (no halo, samples
+// instead of rows in the buckets, plain stores).
 // Tried in round 6 without gain: 64-bit LDS adds on channel pairs (the LDS does retire them at the 32-bit instruction
 // rate -- lds_atomic_rate.hip, 18-20 channel adds per clock and CU against 10 -- but the launch did not move: 251.8
 // against 248.8 us), the two waves of a SIMD running the LDS-bound and the ALU-bound part in opposite order (+3 us),
 // 8 or 21 LDS reads ahead in the flush (0 / +56 us), 8 whole-level items per (level, image, head) instead of 16 (-3 %,
-// but the coarser fixed-point quantum crosses the tests' 1e-4).  Earlier: two 256-thread workgroups per CU on half-size
-// windows (438 us: 1.5x the flush atomics), whole-pass phases instead of the per-sample pipeline (same time), an exact
-// per-item bound from a pre-pass over the rows (an extra round trip per item for 2-3 bits of scale).
+// but the coarser fixed-point quantum crosses the tests' 1e-4), gather waves sweeping contiguous row ranges or all
+// levels of a row in one turn (no change).  Earlier: two 256-thread workgroups per CU on half-size windows (438 us:
+// 1.5x the flush atomics), whole-pass phases instead of the per-sample pipeline (same time), an exact per-item bound
+// from a pre-pass over the rows (an extra round trip per item for 2-3 bits of scale).
 //
 // Everything that depends on the level shapes is decided on the device from the shape tensors (the reference
 // interface hands them over as device tensors; no host copy, no synchronisation): persistent workgroups draw
@@ -341,19 +346,9 @@ __device__ __forceinline__ uint32_t bt_pix_hi(uint32_t packed, uint32_t pitch, u
     return r;
 }
 
-// Round 6.  (1) The per-sample set-up (pixel, validity, corner weights, window addresses -- ~75 vector instructions) ran
-// in all eight lanes of a row, four times per row: 300 of the 800 vector instructions of an 8-row pass.  Now a wave's
-// pass is 16 rows: its 64 lanes set up the 64 samples ONCE (lane = (row, sample)), the result goes through LDS as a
-// 32-byte record per sample (rows 144 bytes apart: the eight rows of a broadcast read fall on different banks), first
-// for rows 0-7, then -- from the registers of lanes 32-63 -- for rows 8-15; the eight lanes of a row read the record back
-// with two broadcast ds_read_b128.  (2) The two halves of the backward are different machines -- the gather half
-// (grad_sampling_loc, grad_attn_weight) is corner loads + vector arithmetic and needs neither the window nor the work
-// list's barriers, the scatter half is LDS atomics + the flush's global atomics -- and with every wave doing both they
-// ran one after the other (cycle stamps: set-up 23 %, scatter 27 %, flush 23 % of a wave's time, the LDS pipe and the
-// vector ALUs idle in turn).  So the workgroup is 16 waves of two kinds: waves 0-7 (two per SIMD) own the window, the
-// work list and the flush and synchronise among themselves through an LDS counter (s_barrier would tie the other
-// eight in); waves 8-15 walk ALL rows of all (level, image, head) in the tile order, 16 rows at a time, with no
-// synchronisation at all, and leave when they are done.
+// The records the set-up lanes leave in LDS for the eight lanes of a row (32 bytes per sample, rows 144 bytes apart: the
+// eight rows of a broadcast read fall on different banks; first rows 0-7 of a pass, then -- from the registers of lanes
+// 32-63 -- rows 8-15):
 //   scatter record: [0] corner weights x attention weight x fixed-point scale (zero: corner off the image / sample
 //                       outside the window / row on the floating-point path)
 //                   [1] window pixel of each corner (4 x u16) | dword 2 bit 0: the sample takes the global-atomic path
