@@ -8,6 +8,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("LIB"):   # a scratch build (benchmarks/lib_variant.sh)
+    from salience_detr_amd import _hip
+    _hip.LIB_PATH = os.path.abspath(os.environ["LIB"])
 from salience_detr_amd import filter_ops as F
 from salience_detr_amd.salience_filtering import MaskPredictor
 

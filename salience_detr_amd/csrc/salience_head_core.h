@@ -290,6 +290,16 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
     const int n0 = wave * 32;
     const bool with_enc = p.w_enc != nullptr;
 
+    // (benchmark builds only, -DSH_STAMPS through benchmarks/lib_variant.sh: cycle stamps per phase, printed by three
+    // workgroups of a launch)
+#ifdef SH_STAMPS
+    long long sh_t[8];
+    int sh_n = 0;
+#define SH_STAMP() sh_t[sh_n++] = clock64()
+#else
+#define SH_STAMP()
+#endif
+    SH_STAMP();
     WeightStreamX3<kX3Depth> ws;
     ws.start(with_enc ? (const void *)p.w_enc : (const void *)p.w1, wave, lane);
 
@@ -345,12 +355,14 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
         }
     }
     __syncthreads();
+    SH_STAMP();   // 1: tile, parameters, row factors in LDS
 
     f32x16 acc;
     if (with_enc) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
+        SH_STAMP();   // 2: first product
         ws.start(p.w1, wave, lane);   // layer1's first steps travel during the LayerNorm phase
         __syncthreads();   // every wave is done reading the planes: the fp32 tile takes their place
         const int c = n0 + (lane & 31);
@@ -358,6 +370,7 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
 #pragma unroll
         for (int i = 0; i < 16; ++i) tile[acc_row(i, lane) * kXS + c] = acc[i] + bias;
         __syncthreads();
+        SH_STAMP();   // 3: product + bias back in LDS as fp32
     }
 
     // ---- enc_output_norm -> modulation -> layer1 LayerNorm; 16 threads per row, each 4 float4; result -> planes ----
@@ -398,11 +411,13 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
         for (int i = 0; i < NV; ++i) store_split(planes, r, CS * i + 4 * q, v[i]);
     }
     __syncthreads();
+    SH_STAMP();   // 4: two LayerNorms + modulation, planes of the second product's operand
 
     // ---- layer1 Linear + GELU ----
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
+    SH_STAMP();   // 5: second product
     {
         const int c = n0 + (lane & 31);
         const float bias = par[kParB1 * kC + c];
@@ -421,6 +436,12 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
             if (lane < 32) p.partial[((int64_t)b * p.nblk + blk) * kHalf + (c - kHalf)] = s;
         }
     }
+#ifdef SH_STAMPS
+    SH_STAMP();   // 6: GELU + stores
+    if (with_enc && tid == 0 && b == 0 && (blk == 0 || blk == p.nblk / 2 || blk == p.nblk - 1))
+        printf("stage1 n=%d blk=%d cycles: tile %lld | gemm1 %lld | to-lds %lld | ln %lld | gemm2 %lld | epilogue %lld | total %lld\n", p.n, blk,
+               sh_t[1] - sh_t[0], sh_t[2] - sh_t[1], sh_t[3] - sh_t[2], sh_t[4] - sh_t[3], sh_t[5] - sh_t[4], sh_t[6] - sh_t[5], sh_t[6] - sh_t[0]);
+#endif
 }
 
 struct Stage2Args {
