@@ -353,6 +353,31 @@ def test_salience_head_is_deterministic_and_rejects_bad_input():
     assert (got.cpu() - ref).abs().max().item() <= 1e-4
 
 
+def test_salience_head_is_bit_reproducible_with_enc_output_and_modulation():
+    """Round 6: a schedule of stage 1 in which the last step of a LayerNorm's 16-lane sum was consumed behind a workgroup
+    barrier gave ~20 wrong rows of 33 400 per launch, different ones every run (csrc/salience_head_core.h).  Twenty launches
+    of the full form (enc_output + enc_output_norm inside, coarse-to-fine modulation) at the finest level's size must agree
+    bit for bit -- scores and the enc_output memory."""
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    torch.manual_seed(0)
+    B, h, w = 2, 100, 167
+    n = h * w
+    pred = MaskPredictor(256, 256).to(DEV)
+    enc, norm = torch.nn.Linear(256, 256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    alpha = torch.tensor([0.2], device=DEV)
+    x = syn.det_randn("hrep", (B, n, 256)).to(DEV)
+    coarse = syn.det_randn("hrep_c", (B, 1, (h + 1) // 2, (w + 1) // 2)).to(DEV)
+    mem = torch.empty(B, n, 256, device=DEV)
+    kw = dict(coarse_score=coarse, level_hw=(h, w), alpha=alpha, enc_output=enc, enc_output_norm=norm, memory_out=mem)
+    with torch.no_grad():
+        first = F.salience_head(x, pred, **kw).clone()
+        first_mem = mem.clone()
+        for _ in range(20):
+            again = F.salience_head(x, pred, **kw)
+            assert torch.equal(again, first)
+            assert torch.equal(mem, first_mem)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_prefix_row_movers_match_gather_scatter_semantics(dtype):
     """advance_rows / select_stack / encoder_finalize against the reference's gather / scatter formulation
