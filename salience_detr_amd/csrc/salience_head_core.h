@@ -133,6 +133,30 @@ struct Stage1Args {
     int n, nblk;
 };
 
+// sum over the TPR (a power of two <= 16... or more) lanes of a row, the xor butterfly s[i] += s[i ^ o], o = 1, 2, 4, ...
+// For TPR == 16 the steps are DPP moves inside the vector ALU (round 6; same partners, same bits as the shuffles: xor 1
+// and 2 are quad permutations, xor 4 = half-row mirror (i ^ 7) then reversed quads (i ^ 3), xor 8 = rotation by 8 in
+// the row of 16) instead of four ds_bpermute -- each a round trip through the LDS queue, behind the fragment reads of the
+// CU's other workgroup: cycle stamps put the LayerNorm phase at 4 900 cycles on an empty chip and 11 000-15 000 in the
+// finest level's launch.
+template <int TPR>
+__device__ __forceinline__ float row_sum(float s)
+{
+#ifndef SH_SHUFFLE_STATS
+    if (TPR == 16) {
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+        const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xf, 0xf, true);          // row_half_mirror
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true));                    // quad_perm [3,2,1,0]
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x128, 0xf, 0xf, true));   // row_ror:8
+        return s;
+    }
+#endif
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, TPR);
+    return s;
+}
+
 // two-pass LayerNorm statistics of a row held as NV float4 per thread by the TPR threads of the row
 template <int NV, int TPR>
 __device__ __forceinline__ void row_stats(const float4 (&v)[NV], float eps, float &mean, float &rstd)
@@ -140,8 +164,7 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[NV], float eps, floa
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, TPR);
+    s = row_sum<TPR>(s);
     mean = s * (1.f / kC);
     float q = 0.f;
 #pragma unroll
@@ -149,8 +172,7 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[NV], float eps, floa
         const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
         q += (a * a + b * b) + (c * c + d * d);
     }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o, TPR);
+    q = row_sum<TPR>(q);
     rstd = rsqrtf(q * (1.f / kC) + eps);
 }
 
