@@ -20,7 +20,33 @@ constexpr int kZS = kHalf + 4;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU (erf form, torch.nn.GELU()'s default).  Round 6: erf(t) = 1 - 2^(-t p(t)), t = |x| / sqrt 2, p of degree 7 fitted to
+// -log2(erfc(t)) / t on [0, 4] (weights = the error of erf per error of p; benchmarks/fit_erf.py): max |error| 8.3e-8 over
+// [0, 6] in fp32 arithmetic -- the rounding of a result next to 1 -- and 0 / 1 beyond (p stays positive).  14 vector
+// instructions + v_exp_f32 where the library's erff is ~60 with both of its branches taken by a mixed wave: cycle
+// stamps put 9 500 of stage 2's 33 700 cycles per workgroup in 32 erff per lane.  |gelu error| <= 0.5 |x| 1e-7.
+__device__ __forceinline__ float erf_pos(float t)   // t >= 0
+{
+    float p = 4.535823973128572e-05f;
+    p = fmaf(p, t, -0.00044550452730618417f);
+    p = fmaf(p, t, 0.0014894308988004923f);
+    p = fmaf(p, t, 0.0007746480405330658f);
+    p = fmaf(p, t, -0.028253698721528053f);
+    p = fmaf(p, t, 0.14848162233829498f);
+    p = fmaf(p, t, 0.9184163808822632f);
+    p = fmaf(p, t, 1.6279085874557495f);
+    return 1.f - __builtin_amdgcn_exp2f(-t * p);
+}
+__device__ __forceinline__ float gelu_erf(float x)
+{
+#ifdef SH_LIB_ERF
+    return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+#else
+    const float e = erf_pos(fabsf(x) * 0.70710678118654752440f);
+    const float h = 0.5f * x;
+    return fmaf(fabsf(h), e, h);   // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
+#endif
+}
 
 __device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 c)
 {
@@ -396,6 +422,10 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
             else *reinterpret_cast<float4 *>(tile + r * kXS + c4 * 4) = val;
         }
     }
+#ifdef SH_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const long long sh_tile_done = clock64();   // (wave 0: its loads are back, its part of the tile is stored)
+#endif
     __syncthreads();
     SH_STAMP();   // 1: tile, parameters, row factors in LDS
 
@@ -490,8 +520,8 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
 #ifdef SH_STAMPS
     SH_STAMP();   // 6: GELU + stores
     if (with_enc && tid == 0 && b == 0 && (blk == 0 || blk == p.nblk / 2 || blk == p.nblk - 1))
-        printf("stage1 n=%d blk=%d cycles: tile %lld | gemm1 %lld | to-lds %lld | ln %lld | gemm2 %lld | epilogue %lld | total %lld\n", p.n, blk,
-               sh_t[1] - sh_t[0], sh_t[2] - sh_t[1], sh_t[3] - sh_t[2], sh_t[4] - sh_t[3], sh_t[5] - sh_t[4], sh_t[6] - sh_t[5], sh_t[6] - sh_t[0]);
+        printf("stage1 n=%d blk=%d cycles: (own part of the tile %lld) tile %lld | gemm1 %lld | to-lds %lld | ln %lld | gemm2 %lld | epilogue %lld | total %lld\n", p.n, blk,
+               sh_tile_done - sh_t[0], sh_t[1] - sh_t[0], sh_t[2] - sh_t[1], sh_t[3] - sh_t[2], sh_t[4] - sh_t[3], sh_t[5] - sh_t[4], sh_t[6] - sh_t[5], sh_t[6] - sh_t[0]);
 #endif
 }
 
@@ -518,6 +548,14 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = blk * kTM;
     const int nvalid = min(kTM, p.n - t0);
+#ifdef SH_STAMPS
+    long long s2_t[8];
+    int s2_n = 0;
+#define S2_STAMP() s2_t[s2_n++] = clock64()
+#else
+#define S2_STAMP()
+#endif
+    S2_STAMP();
     WeightStream<1, 8> ws;
     ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
     const float cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
@@ -540,11 +578,13 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
         }
     }
     __syncthreads();
+    S2_STAMP();   // 1: tile in LDS
     // layer2[0] (local half; the global half is the per-image constant) + GELU: wave w -> columns [32w, 32w+32)
     {
         f32x16 acc[2][1];
         zero_acc(acc);
         block_gemm<kHalf, kZS, 2, 1, 8>(zt, ws, lane, acc);
+        S2_STAMP();   // 2: first product
         ws.start(p.w3, kHalf / 2, kHalf / 8, ct2 * 32, lane);
         __syncthreads();
         const int c = wave * 32 + (lane & 31);
@@ -554,16 +594,32 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
             for (int i = 0; i < 16; ++i) zt[(32 * rt + acc_row(i, lane)) * kZS + c] = gelu_erf(acc[rt][0][i] + cb);
     }
     __syncthreads();
+    S2_STAMP();   // 3: GELU, hidden state in LDS
     // layer2[2] + GELU, layer2[4]: wave -> (row tile, column tile) of the [64 x 64] hidden state
     {
         f32x16 acc[1][1];
         zero_acc(acc);
         block_gemm<kHalf, kZS, 1, 1, 8>(zt + rt2 * 32 * kZS, ws, lane, acc);
+        S2_STAMP();   // 4: second product
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float v = gelu_erf(acc[0][0][i] + bias3) * wo;
+            // sum over the 32 lanes of the column tile: the butterfly v[i] += v[i ^ o], o = 16, 8, 4, 2, 1 -- the first step
+            // through the LDS crossbar, the rest as DPP steps inside the rows of 16 (round 6: same partners in the same
+            // order as five shuffles, a fifth of the LDS instructions; see row_sum)
+            v += __shfl_xor(v, 16, 32);
+#ifdef SH_SHUFFLE_STATS
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+#else
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
+            {
+                const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true);      // row_half_mirror
+                v += __int_as_float(__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true));                // quad_perm [3,2,1,0]
+            }
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+#endif
             if ((lane & 31) == 0) red[ct2 * kTM + 32 * rt2 + acc_row(i, lane)] = v;
         }
     }
@@ -583,6 +639,12 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
             else atomicMax(reinterpret_cast<unsigned int *>(p.score_min), __float_as_uint(s));
         }
     }
+#ifdef SH_STAMPS
+    S2_STAMP();   // 5: GELU, the last layer's dot product over the 64 hidden units, scores
+    if (tid == 0 && b == 0 && (blk == 0 || blk == (p.n / kTM) / 2))
+        printf("stage2 n=%d blk=%d cycles: tile %lld | gemm1 %lld | gelu %lld | gemm2 %lld | last %lld | total %lld\n", p.n, blk,
+               s2_t[1] - s2_t[0], s2_t[2] - s2_t[1], s2_t[3] - s2_t[2], s2_t[4] - s2_t[3], s2_t[5] - s2_t[4], s2_t[5] - s2_t[0]);
+#endif
 }
 
 }  // namespace sdetr
