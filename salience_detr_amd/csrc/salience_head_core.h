@@ -604,23 +604,23 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float v = gelu_erf(acc[0][0][i] + bias3) * wo;
-            // sum over the 32 lanes of the column tile: the butterfly v[i] += v[i ^ o], o = 16, 8, 4, 2, 1 -- the first step
-            // through the LDS crossbar, the rest as DPP steps inside the rows of 16 (round 6: same partners in the same
-            // order as five shuffles, a fifth of the LDS instructions; see row_sum)
-            v += __shfl_xor(v, 16, 32);
-#ifdef SH_SHUFFLE_STATS
+#ifdef SH_BUTTERFLY_LAST
+            // (until round 6: the butterfly v[i] += v[i ^ o], o = 16 ... 1, five trips through the LDS crossbar per element)
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
-#else
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
-            {
-                const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true);      // row_half_mirror
-                v += __int_as_float(__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true));                // quad_perm [3,2,1,0]
-            }
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-#endif
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
             if ((lane & 31) == 0) red[ct2 * kTM + 32 * rt2 + acc_row(i, lane)] = v;
+#else
+            // sum over the 32 lanes of the column tile, INTO lane 31 of the half-wave: shifts inside the rows of 16, then
+            // row 0's total broadcast into row 1 -- DPP steps only, no LDS instruction (round 6; the 16 x 5 shuffles of
+            // the butterfly were 4 400 of the workgroup's 22 000 cycles on an empty chip and 16 000 in the finest
+            // level's launch, behind the other workgroups' fragment reads)
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, true));   // row_bcast:15 -> rows 1, 3
+            if ((lane & 31) == 31) red[ct2 * kTM + 32 * rt2 + acc_row(i, lane)] = v;
+#endif
         }
     }
     __syncthreads();
