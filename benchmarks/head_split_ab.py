@@ -2,6 +2,9 @@
 round-6 hoist experiment needed: benchmarks/experiments/README.md).  Kernel times from the profiler."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
+if os.environ.get("LIB"):
+    from salience_detr_amd import _hip
+    _hip.LIB_PATH = os.path.abspath(os.environ["LIB"])
 from salience_detr_amd import filter_ops as F
 from salience_detr_amd.salience_filtering import MaskPredictor
 DEV = "cuda:0"

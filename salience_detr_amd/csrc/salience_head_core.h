@@ -50,6 +50,10 @@ __device__ __forceinline__ float gelu_erf(float x)
 
 __device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 c)
 {
+#ifdef SH_KO_F32_MFMA   // (benchmark builds: what the f32 products cost a launch)
+    c[0] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    return c;
+#endif
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
