@@ -548,12 +548,17 @@ int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *z_local, in
                                  float *score_flat, int64_t score_flat_stride, float *score_min, const void *vp_x,
                                  const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
                                  int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
-                                 void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered);
+                                 void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered,
+                                 const void *weight2_local_x3);
+/* `weight2_local_x3` (both stage-2 entry points; round 6): sdetr_pack_linear_bf16x3 of W2[:, :128] or NULL.  Given, the
+ * first product of stage 2 runs on the bf16 matrix cores at fp32 accuracy like stage 1's (exact three-way split, six
+ * products) and `weight2_local_packed` is not read: without its f32 MFMAs the launch is a third as long. */
 int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, const float *partial_sums, int batch_size,
                                int tokens, const float *weight2, const float *bias2,
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,
                                const float *weight4, const float *bias4, float *const_workspace, float *score,
-                               float *score_flat, int64_t score_flat_stride, float *score_min);
+                               float *score_flat, int64_t score_flat_stride, float *score_min,
+                               const void *weight2_local_x3);
 
 /* ---- (7) the encoder layer's feed-forward block, fused ----------------------------------------------------------
  * out = LayerNorm(x + W2 relu(W1 x + b1) + b2)   (models/bricks/salience_transformer.py:347-351 forward_ffn with the

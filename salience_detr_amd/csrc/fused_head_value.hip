@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(768, 1) fused_stage2_value_kernel(Stage2Args s
     if (blk < n1) {
         if (threadIdx.x >= kBlock) return;
         float *zt = reinterpret_cast<float *>(fused_lds);
-        stage2_body(s2, blk % s2_blocks, blk / s2_blocks, zt, zt + kTM * kZS);
+        stage2_body(s2, blk % s2_blocks, blk / s2_blocks, zt, zt + kStage2TileFloats);
     } else {
         token_linear_body<kHeadMajor, false, 8>(tl, blk - n1);
     }
@@ -269,10 +269,11 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
                                             const void *vp_packed_weight, const float *vp_bias_padded,
                                             const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size,
                                             int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
-                                            const sdetr_bordered_layout *vp_bordered)
+                                            const sdetr_bordered_layout *vp_bordered, const void *weight2_local_x3)
 {
     if (batch_size <= 0 || tokens <= 0) return fail("stage2_with_value_proj: empty level");
-    if (!z_local || !weight2_local_packed || !weight3_packed || !bias3 || !weight4 || !bias4 || !const_workspace || !score)
+    if (!z_local || (!weight2_local_packed && !weight2_local_x3) || !weight3_packed || !bias3 || !weight4 || !bias4 ||
+        !const_workspace || !score)
         return fail("stage2_with_value_proj: NULL pointer");
     TLArgs t;
     size_t lds_tl = 0;
@@ -283,6 +284,7 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
     Stage2Args a;
     a.z_local = z_local; a.cst = const_workspace;
     a.w2a = reinterpret_cast<const float4 *>(weight2_local_packed);
+    a.w2a_x3 = weight2_local_x3;
     a.w3 = reinterpret_cast<const float4 *>(weight3_packed);
     a.b3 = bias3; a.w4 = weight4; a.b4 = bias4; a.score = score; a.score2 = score_flat;
     a.score2_stride = score_flat_stride; a.n = tokens; a.score_min = score_min;

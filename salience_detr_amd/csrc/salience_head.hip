@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(kHalf * kConstGroups) salience_head_const_kern
 
 __global__ void __launch_bounds__(kBlock, 2) salience_head_stage2_kernel(Stage2Args p)
 {
-    __shared__ __attribute__((aligned(16))) float zt[kTM * kZS];
+    __shared__ __attribute__((aligned(16))) float zt[kStage2TileFloats];
     __shared__ float red[2 * kTM];
     stage2_body(p, (int)blockIdx.x, (int)blockIdx.y, zt, red);
 }
@@ -450,12 +450,12 @@ extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_
                                           const float *weight2_local_packed, const float *weight3_packed,
                                           const float *bias3, const float *weight4, const float *bias4,
                                           float *const_workspace, float *score, float *score_flat,
-                                          int64_t score_flat_stride, float *score_min)
+                                          int64_t score_flat_stride, float *score_min, const void *weight2_local_x3)
 {
     if (batch_size < 0 || tokens < 0) return fail("salience_head_stage2: negative size");
     if (batch_size == 0 || tokens == 0) return 0;
-    if (!z_local || !partial_sums || !weight2 || !bias2 || !weight2_local_packed || !weight3_packed || !bias3 ||
-        !weight4 || !bias4 || !const_workspace || !score)
+    if (!z_local || !partial_sums || !weight2 || !bias2 || (!weight2_local_packed && !weight2_local_x3) || !weight3_packed ||
+        !bias3 || !weight4 || !bias4 || !const_workspace || !score)
         return fail("salience_head_stage2: NULL pointer");
     const int nblk = (tokens + kTM - 1) / kTM;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -467,6 +467,7 @@ extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_
     Stage2Args a;
     a.z_local = z_local; a.cst = const_workspace;
     a.w2a = reinterpret_cast<const float4 *>(weight2_local_packed);
+    a.w2a_x3 = weight2_local_x3;
     a.w3 = reinterpret_cast<const float4 *>(weight3_packed);
     a.b3 = bias3; a.w4 = weight4; a.b4 = bias4; a.score = score; a.score2 = score_flat;
     a.score2_stride = score_flat_stride; a.n = tokens; a.score_min = score_min;

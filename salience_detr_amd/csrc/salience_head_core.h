@@ -339,6 +339,65 @@ __device__ __forceinline__ void block_gemm_x3(const char *planes, WeightStreamX3
     }
 }
 
+// The same for other shapes (round 6: stage 2's first product): NT column tiles of 32 in the packed weight, the operand
+// planes ROWS x KDIM (row stride KDIM * 2 + 16 bytes), RT row tiles of 32 per wave.
+template <int NT, int PD>
+struct WeightStreamX3G {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t lane_off;
+    u32x4_t bq[PD][3];
+    static constexpr uint32_t kStep = NT * 3 * 1024;   // bytes per k-step: NT column tiles x 3 planes x 1 KB
+
+    __device__ __forceinline__ void start(const void *wp, int ksteps, int ctile, int lane)
+    {
+        rs = make_uniform_rsrc(reinterpret_cast<const char *>(wp), kStep * (uint32_t)ksteps);
+        lane_off = (uint32_t)(ctile * 3 * 1024 + lane * 16);
+#pragma unroll
+        for (int u = 0; u < PD; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + pl * 1024), (int)(u * kStep), 0);
+    }
+};
+template <int KDIM, int ROWS, int RT, int NT, int PD>
+__device__ __forceinline__ void block_gemm_x3g(const char *planes, WeightStreamX3G<NT, PD> &ws, int lane, f32x16 (&acc)[RT])
+{
+    constexpr int NS = KDIM / 16, kRow = KDIM * 2 + 16, kPlane = ROWS * kRow;
+    const char *ap = planes + (lane & 31) * kRow + (lane >> 5) * 16;
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+        const int u = S % PD;
+        u32x4_t b[3], a[RT][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = ws.bq[u][pl];
+        if (S + PD < NS) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                ws.bq[u][pl] = __builtin_amdgcn_raw_buffer_load_b128(ws.rs, (int)(ws.lane_off + pl * 1024),
+                                                                     (int)((S + PD) * ws.kStep), 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                a[rt][pl] = *reinterpret_cast<const u32x4_t *>(ap + rt * 32 * kRow + pl * kPlane + S * 32);
+        __builtin_amdgcn_sched_barrier(0);   // this step's prefetch stays in front of its MFMAs (see block_gemm)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[rt] = mfma_bf16(a[rt][2], b[0], acc[rt]);    // smallest terms first
+            acc[rt] = mfma_bf16(a[rt][0], b[2], acc[rt]);
+            acc[rt] = mfma_bf16(a[rt][1], b[1], acc[rt]);
+            acc[rt] = mfma_bf16(a[rt][1], b[0], acc[rt]);
+            acc[rt] = mfma_bf16(a[rt][0], b[1], acc[rt]);
+            acc[rt] = mfma_bf16(a[rt][0], b[0], acc[rt]);
+        }
+    }
+}
+// stage 2's token tile as planes: 64 rows x 128 values
+constexpr int kS2PlaneRow = kHalf * 2 + 16;            // 272 bytes
+constexpr int kS2PlaneBytes = 64 * kS2PlaneRow;        // 17 408
+constexpr int kS2Planes = 3 * kS2PlaneBytes;           // 52 224
+
 // (`blk` / `b` = token block and image: the kernel's own block indices, or the position inside a launch that also
 // carries other work -- fused_head_value.hip.  The first 512 threads of the workgroup take part.)
 __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int b)
@@ -533,6 +592,8 @@ struct Stage2Args {
     const float *z_local;   // [B, n, 128]
     const float *cst;       // [B, 128]
     const float4 *w2a;      // packed W2[:, :128]   (128 x 128)
+    const void *w2a_x3;     // the same as three bf16 planes (sdetr_pack_linear_bf16x3) or NULL: the first product then runs on
+                            // the bf16 matrix cores at fp32 accuracy like stage 1's (round 6; `w2a` is not read)
     const float4 *w3;       // packed W3            (64 x 128)
     const float *b3, *w4, *b4;
     float *score;           // [B, n]
@@ -542,7 +603,8 @@ struct Stage2Args {
     int n;
 };
 
-constexpr int kStage2LdsFloats = kTM * kZS + 2 * kTM;   // zt | red
+constexpr int kStage2TileFloats = kS2Planes / 4 > kTM * kZS ? kS2Planes / 4 : kTM * kZS;   // the planes of the x3 form | the fp32 tile
+constexpr int kStage2LdsFloats = kStage2TileFloats + 2 * kTM;   // zt | red
 
 // (`blk` / `b` = token block and image; `zt` [kTM * kZS] and `red` [2 * kTM] floats of LDS: the kernel's own static
 // arrays, or a piece of the dynamic LDS of a launch that also carries other work -- fused_head_value.hip.  The first
@@ -560,8 +622,11 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
 #define S2_STAMP()
 #endif
     S2_STAMP();
+    const bool x3 = p.w2a_x3 != nullptr;
     WeightStream<1, 8> ws;
-    ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
+    WeightStreamX3G<kHalf / 32, 4> ws3;
+    if (x3) ws3.start(p.w2a_x3, kHalf / 16, wave, lane);
+    else ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
     const float cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
     const int rt2 = wave >> 1, ct2 = wave & 1;
     const float bias3 = p.b3[ct2 * 32 + (lane & 31)], wo = p.w4[ct2 * 32 + (lane & 31)], b4 = p.b4[0];
@@ -578,7 +643,17 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
         for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {
             const int idx = tid + i * kBlock;
             const int r = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<float4 *>(zt + r * kZS + c4 * 4) = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 val = r < nvalid ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x3) {   // three bf16 planes [64][128] (the fp32 tile of the second product takes their place later)
+                uint2 p0, p1, p2;
+                split3<false>(val, p0, p1, p2);
+                char *d = reinterpret_cast<char *>(zt) + r * kS2PlaneRow + c4 * 8;
+                *reinterpret_cast<uint2 *>(d) = p0;
+                *reinterpret_cast<uint2 *>(d + kS2PlaneBytes) = p1;
+                *reinterpret_cast<uint2 *>(d + 2 * kS2PlaneBytes) = p2;
+            } else {
+                *reinterpret_cast<float4 *>(zt + r * kZS + c4 * 4) = val;
+            }
         }
     }
     __syncthreads();
@@ -587,7 +662,14 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
     {
         f32x16 acc[2][1];
         zero_acc(acc);
-        block_gemm<kHalf, kZS, 2, 1, 8>(zt, ws, lane, acc);
+        if (x3) {
+            f32x16 a3[2] = {acc[0][0], acc[1][0]};
+            block_gemm_x3g<kHalf, 64, 2, kHalf / 32, 4>(reinterpret_cast<const char *>(zt), ws3, lane, a3);
+            acc[0][0] = a3[0];
+            acc[1][0] = a3[1];
+        } else {
+            block_gemm<kHalf, kZS, 2, 1, 8>(zt, ws, lane, acc);
+        }
         S2_STAMP();   // 2: first product
         ws.start(p.w3, kHalf / 2, kHalf / 8, ct2 * 32, lane);
         __syncthreads();

@@ -628,7 +628,9 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             stage1 = lib.sdetr_salience_head_stage1_x3 if x3 else lib.sdetr_salience_head_stage1
             code = stage1(*stage1_args)
         _hip.check(code, "salience_head_stage1")
-        w2_local = packed_linear_weight(l2a.weight, cols=(0, half)).data_ptr()
+        # (with the bf16x3 kernels stage 2's first product takes the three-plane packing too: no f32 MFMA in front of GELU)
+        w2_local = None if x3 else packed_linear_weight(l2a.weight, cols=(0, half)).data_ptr()
+        w2_x3 = packed_linear_weight(l2a.weight, cols=(0, half), split3=True).data_ptr() if x3 else None
         w3 = packed_linear_weight(l2b.weight).data_ptr()
         if value_job2 is not None and not value_job2.done and value_job2.value.device == x.device:
             code = lib.sdetr_salience_head_const(s, partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
@@ -637,13 +639,13 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             code = lib.sdetr_stage2_with_value_proj(
                 s, z_local.data_ptr(), B, n, w2_local, w3, l2b.bias.data_ptr(), l2c.weight.data_ptr(),
                 l2c.bias.data_ptr(), cst.data_ptr(), score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min),
-                *value_job2.pointers())
+                *value_job2.pointers(), w2_x3)
             value_job2.done = True
         else:
             code = lib.sdetr_salience_head_stage2(
                 s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
                 w2_local, w3, l2b.bias.data_ptr(), l2c.weight.data_ptr(), l2c.bias.data_ptr(), cst.data_ptr(),
-                score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min))
+                score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min), w2_x3)
         _hip.check(code, "salience_head_stage2")
     return score
 
