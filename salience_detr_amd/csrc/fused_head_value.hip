@@ -117,6 +117,11 @@ template <int KT>
 __global__ void __launch_bounds__(512, 1) fused_attn_proj_kernel(TkOutArgs at, int at_blocks, TLArgs tl)
 {
     const int blk = (int)blockIdx.x;
+#if defined(FH_KO_ATTN)      // (benchmark builds: which of the launch's two bodies sets its length)
+    if (blk < at_blocks) return;
+#elif defined(FH_KO_PROJ)
+    if (blk >= at_blocks) return;
+#endif
     if (blk < at_blocks) topk_attn_out_body<KT>(at, blk);
     else token_linear_body<kStore, true, 4>(tl, blk - at_blocks);
 }

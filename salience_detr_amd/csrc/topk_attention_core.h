@@ -140,6 +140,14 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     __shared__ float part[2][8][kTkQ];
     const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = head
     const int t = lane & 15, g = lane >> 4;
+#ifdef TK_STAMPS   // (benchmark builds: cycle stamps per phase, printed by workgroup 0)
+    long long tk_t[10];
+    int tk_n = 0;
+#define TK_STAMP() tk_t[tk_n++] = clock64()
+#else
+#define TK_STAMP()
+#endif
+    TK_STAMP();
     const int tiles = (p.N + kTkQ - 1) / kTkQ;
     const int tile = block % tiles, b = block / tiles;
     const int qi = tile * kTkQ + t;                 // < Npad (rows past N are zero rows of the slab)
@@ -195,6 +203,7 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
         s[j] = tk_mfma16(kfr[j], qfrag, s[j]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    TK_STAMP();   // 1: operands back, score products issued
 #pragma unroll
     for (int j = 0; j < KT; ++j)
 #pragma unroll
@@ -226,6 +235,7 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     }
     // out_proj fragments of my 32 features (two 16-feature tiles x 8 k-steps of 32): issued once the score and V^T
     // registers are free (together they would not fit in 256), their round trip overlaps the LDS exchange
+    TK_STAMP();   // 2: softmax, P V
     tk_touch_done(sink);   // every load issued before the scores has returned by now (the score MFMAs waited for them)
     uint4 wfrag[2][8];
 #pragma unroll
@@ -252,6 +262,7 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
         z[0] = tk_mfma16(wfrag[0][j], of, z[0]);
         z[1] = tk_mfma16(wfrag[1][j], of, z[1]);
     }
+    TK_STAMP();   // 3: heads exchanged through LDS, out_proj
     // + bias + residual; LayerNorm over the 256 features of a query (8 here, 32 per wave, 8 waves)
     float tot = 0.f;
 #pragma unroll
@@ -304,6 +315,7 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
             *reinterpret_cast<uint2 *>(o_lds + t * kTkORow + (head * kTkHd + 16 * c + 4 * g) * 2) = xp;
         }
     }
+    TK_STAMP();   // 4: residual, LayerNorm, row stores
     if (!p.fx_w) return;
     // ---- sampling_offsets | attention_weights of the 16 updated rows: wave = head, 48 features = three 16-feature
     // tiles, P^T[feature][query] = W (x + pos)^T + b; rows of the head-major slab [B, 8, rows, 48] ----
@@ -332,6 +344,12 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
         for (int c = 0; c < 3; ++c)
             *reinterpret_cast<uint2 *>(srow + 16 * c) = make_uint2(pack_act2(pa[c][0], pa[c][1]), pack_act2(pa[c][2], pa[c][3]));
     }
+#ifdef TK_STAMPS
+    TK_STAMP();   // 5: projection of the updated rows
+    if (threadIdx.x == 0 && (block == 0 || block == 20))
+        printf("attn blk=%d cycles: operands %lld | softmax+PV %lld | exchange+out_proj %lld | LN+stores %lld | projection %lld | total %lld\n", block,
+               tk_t[1] - tk_t[0], tk_t[2] - tk_t[1], tk_t[3] - tk_t[2], tk_t[4] - tk_t[3], tk_t[5] - tk_t[4], tk_t[5] - tk_t[0]);
+#endif
 }
 
 }  // namespace sdetr
