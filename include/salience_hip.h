@@ -901,7 +901,12 @@ int sdetr_topk_attention_with_projection_bf16(
     const int64_t *selected, int batch_size, int num_rows, int num_selected, const void *in_proj_weight,
     const void *in_proj_bias, const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
     const void *norm_bias, float norm_eps, void *workspace, int64_t workspace_bytes, const void *proj_weight,
-    const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride);
+    const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride,
+    const void *out_proj_frag, const void *proj_frag);
+/* `out_proj_frag` / `proj_frag` (optional, round 6): out_proj_weight / proj_weight once more in the fragment order of the
+ * attention workgroups' 16x16x32 products -- element [h][c][j][lane][e] = weight[R h + 16 c + (lane & 15)][32 j + 8 (lane >> 4) + e]
+ * with R = 32, c < 2 (out_proj) or R = 48, c < 3 (projection), j < 8, lane < 64, e < 8: a wave's fragment is then one
+ * contiguous KB.  NULL: the row-major weights are read as before. */
 /* (internal: the in-projection launch of sdetr_topk_attention_bf16 for csrc/fused_head_value.hip) */
 int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in_args);
 

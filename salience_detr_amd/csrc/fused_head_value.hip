@@ -315,7 +315,8 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     const int64_t *selected, int batch_size, int num_rows, int num_selected, const void *in_proj_weight,
     const void *in_proj_bias, const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
     const void *norm_bias, float norm_eps, void *workspace, int64_t workspace_bytes, const void *proj_weight,
-    const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride)
+    const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride,
+    const void *out_proj_frag, const void *proj_frag)
 {
     if (batch_size <= 0 || num_rows <= 0 || num_selected <= 0 || num_selected > num_rows)
         return fail("topk_attention_with_projection: bad sizes (rows %d, selected %d)", num_rows, num_selected);
@@ -347,6 +348,7 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     o.B = batch_size; o.N = num_selected; o.Npad = npad;
     o.fx_w = (const bf16_t *)proj_weight; o.fx_b = proj_bias_padded; o.fx_pos = (const bf16_t *)pos;
     o.fx_p_bs = pos_batch_stride; o.fx_slab = (bf16_t *)slab; o.fx_rows = num_rows; o.fx_by_selection = 0;
+    o.wo_frag = (const bf16_t *)out_proj_frag; o.fx_w_frag = (const bf16_t *)proj_frag;
     TLArgs t{};
     t.x = (const bf16_t *)query; t.pw = (const char *)proj_packed; t.bias = proj_bias_padded;
     t.T = batch_size * num_rows; t.N = 384; t.ntiles = 12; t.rows_per_batch = num_rows;

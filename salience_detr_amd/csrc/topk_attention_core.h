@@ -103,6 +103,12 @@ struct TkOutArgs {
     int fx_rows;
     int fx_by_selection;   // 0: row index = the query's row in the layer (writes the MSDA slab itself); 1: its position
                            // in the selection (a side buffer [B, 8, N, 48])
+    // optional (round 6): `wo` / `fx_w` once more in MFMA-fragment order -- [head][16-feature tile][k-step of 32][lane][8]:
+    // a wave's fragment load is then one contiguous KB (8 cache lines) where the row-major weight gives 16 pieces of 64
+    // bytes from 16 rows per instruction.  Cycle stamps: of a workgroup's 44 000 cycles 14 500 went into the out_proj
+    // phase and 12 300 into the projection of the updated rows -- their 16 + 24 fragment loads per lane.
+    const bf16_t *wo_frag;    // [8][2][8][64][8] or NULL
+    const bf16_t *fx_w_frag;  // [8][3][8][64][8] or NULL
 };
 
 typedef float tk_f32x4_t __attribute__((ext_vector_type(4)));
@@ -161,10 +167,19 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     uint32_t sink = 0;
     // warm the out_proj rows this wave will want after the softmax (their registers are not free until then; untouched
     // they cost a second exposed trip to memory in the middle of the kernel)
+    if (p.wo_frag) {   // the wave's 16 KB of out_proj fragments, 24 KB of projection fragments: a line per lane and touch
+        tk_touch(p.wo_frag + head * 8192 + lane * 64, sink);
+        tk_touch(p.wo_frag + head * 8192 + 4096 + lane * 64, sink);
+        if (p.fx_w_frag) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+            for (int i = 0; i < 3; ++i) tk_touch(p.fx_w_frag + head * 12288 + i * 4096 + lane * 64, sink);
+        }
+    } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tk_touch(p.wo + (int64_t)(head * 32 + 16 * c + t) * kTkE + 32 * j + 8 * g, sink);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tk_touch(p.wo + (int64_t)(head * 32 + 16 * c + t) * kTkE + 32 * j + 8 * g, sink);
+    }
     const uint4 qfrag = *reinterpret_cast<const uint4 *>(p.qk + ((int64_t)b * p.Npad + qi) * 256 + head * kTkHd + 8 * g);
     uint4 kfr[KT];
 #pragma unroll
@@ -242,7 +257,9 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            wfrag[c][j] = *reinterpret_cast<const uint4 *>(p.wo + (int64_t)(head * 32 + 16 * c + t) * kTkE + 32 * j + 8 * g);
+            wfrag[c][j] = p.wo_frag
+                              ? *reinterpret_cast<const uint4 *>(p.wo_frag + ((head * 2 + c) * 8 + j) * 512 + lane * 8)
+                              : *reinterpret_cast<const uint4 *>(p.wo + (int64_t)(head * 32 + 16 * c + t) * kTkE + 32 * j + 8 * g);
     __builtin_amdgcn_sched_barrier(0);
     // ---- the heads meet in LDS: O[query][32 head + channel] bf16 (my channels: 16 c + 4 g + r) ----
     {
@@ -324,7 +341,9 @@ __device__ __forceinline__ void topk_attn_out_body(const TkOutArgs &p, int block
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            pw[c][j] = *reinterpret_cast<const uint4 *>(p.fx_w + (int64_t)(head * 48 + 16 * c + t) * kTkE + 32 * j + 8 * g);
+            pw[c][j] = p.fx_w_frag
+                           ? *reinterpret_cast<const uint4 *>(p.fx_w_frag + ((head * 3 + c) * 8 + j) * 512 + lane * 8)
+                           : *reinterpret_cast<const uint4 *>(p.fx_w + (int64_t)(head * 48 + 16 * c + t) * kTkE + 32 * j + 8 * g);
     tk_f32x4_t pa[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

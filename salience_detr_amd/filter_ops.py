@@ -978,6 +978,23 @@ def _packed_linear_bf16(weight: Tensor, bias: Optional[Tensor]):
     return packed, b
 
 
+def _fragment_order(weight: Tensor, rows_per_head: int) -> Tensor:
+    """``weight`` ([8 * rows_per_head, 256] 16-bit, rows grouped by head) in the fragment order of the top-300 attention's
+    16x16x32 products: ``[head][16-row tile][k-step of 32][lane][8]`` with lane = (row & 15) + 16 * (k / 8 & 3) -- a wave's
+    operand fragment is one contiguous KB (include/salience_hip.h, sdetr_topk_attention_with_projection_bf16).  Cached on
+    the weight object, refreshed when its storage or version changes."""
+    tag = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape))
+    hit = weight.__dict__.get("_sdetr_frag")
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    tiles = rows_per_head // 16
+    with torch.no_grad():
+        # [head, tile c, row t, k-step j, quarter g, element e] -> [head, c, j, g, t, e]
+        frag = weight.detach().view(8, tiles, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+    weight.__dict__["_sdetr_frag"] = (tag, frag)
+    return frag
+
+
 def token_linear_applies(x: Tensor, weight: Tensor) -> bool:
     return (x.is_cuda and _hip.is_act16(x.dtype) and weight.dtype == x.dtype and x.shape[-1] == 256
             and weight.dim() == 2 and weight.shape[1] == 256 and weight.stride(1) == 1)
@@ -1790,7 +1807,9 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
                 mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), mha.out_proj.weight.data_ptr(),
                 mha.out_proj.bias.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
                 ws.data_ptr(), ws.numel(), w.data_ptr(), packed.data_ptr(), b_pad.data_ptr(), slab.data_ptr(),
-                hint.data_ptr(), hint.stride(0))
+                hint.data_ptr(), hint.stride(0),
+                _fragment_order(mha.out_proj.weight, 32).data_ptr() if mha.out_proj.weight.is_contiguous() else None,
+                _fragment_order(w, 48).data_ptr())
             _hip.check(code, "topk_self_attention_")
             return slab
         code = lib.sdetr_topk_attention_bf16(
