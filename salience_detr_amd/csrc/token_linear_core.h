@@ -148,6 +148,14 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
     float *bs = reinterpret_cast<float *>(lds + 2 * kTLStepBytes);      // [nsteps * 128]
     const int nsteps = (p.ntiles + kTLStepTiles - 1) / kTLStepTiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TL_STAMPS   // (benchmark builds: cycle stamps of compute wave 0, printed by two workgroups)
+    long long tl_t[12];
+    int tl_n = 0;
+#define TL_STAMP() tl_t[tl_n++] = clock64()
+#else
+#define TL_STAMP()
+#endif
+    TL_STAMP();
 
     if (wave >= WAVES) {
         // ---- loader wave: a quarter (16 KB) of every 64 KB step.  Step s travels in register set s & 1 and is written
@@ -207,7 +215,12 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
 
     for (int i = tid; i < nsteps * 128; i += kThreads) bs[i] = p.bias[i];
     uint4 xb[16];   // X^T as B operands: k-step ks covers channels 16ks + 8h .. +7 of my token
-    {
+#ifndef TL_ROW_STRIDED_X
+    constexpr bool kLinearX = WAVES == 4;   // (8 compute waves: two rounds through half the staging space were slower, +8 us per launch)
+#else
+    constexpr bool kLinearX = false;
+#endif
+    if (!kLinearX) {
         const bf16_t *xr = p.x + (int64_t)tk * kTLK + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const uint4 *>(xr + 16 * ks);
@@ -220,6 +233,55 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
                                     add_bf16x2(xb[ks].w, o.w));
             }
         }
+    } else {
+        // Round 6.  Read as operands (lane = token, 16 pieces of 16 bytes 32 bytes apart along its row) the wave's 16 KB
+        // of activations were 32 cache lines per load instruction, 1024 line requests through the CU's L1 for 256 lines
+        // of data: cycle stamps put 16 000 of a workgroup's 36 000 cycles here.  The wave's 32 rows are CONTIGUOUS in
+        // memory, so they are loaded as they lie (a KB per instruction: two rows, lane l = row l / 32, piece l % 32),
+        // x2 is added in that layout, and the pieces change lanes through LDS -- the second weight buffer, which the
+        // loaders do not write before the first barrier; piece p of row r sits in slot p ^ r of the row: every LDS
+        // instruction conflict-free.  With 8 compute waves a wave's share of that buffer is 8 KB: two rounds of 16 rows.
+        constexpr int kRows = WAVES == 8 ? 16 : 32;                 // rows per round
+        char *stage = wbuf + kTLStepBytes + wave * (kTLStepBytes / WAVES);
+        const int piece = lane & 31, half = lane >> 5;
+        const int tok0 = block * (kTLTokWave * WAVES) + wave * kTLTokWave;
+        uint4 lin[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int tr = min(tok0 + 2 * i + half, p.T - 1);
+            lin[i] = *reinterpret_cast<const uint4 *>(p.x + (int64_t)tr * kTLK + 8 * piece);
+        }
+        if (ADD2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int tr = min(tok0 + 2 * i + half, p.T - 1);
+                const int im = tr / p.rows_per_batch, rr = tr - im * p.rows_per_batch;
+                const uint4 o = *reinterpret_cast<const uint4 *>(p.x2 + (int64_t)im * p.x2_batch_stride + (int64_t)rr * kTLK + 8 * piece);
+                lin[i] = make_uint4(add_bf16x2(lin[i].x, o.x), add_bf16x2(lin[i].y, o.y), add_bf16x2(lin[i].z, o.z),
+                                    add_bf16x2(lin[i].w, o.w));
+            }
+        }
+#pragma unroll
+        for (int round = 0; round < 32 / kRows; ++round) {
+            if (round > 0) {   // (the first round's reads are done before its slots are written again)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int i = 0; i < kRows / 2; ++i) {
+                const int r = 2 * i + half;            // row of the round
+                *reinterpret_cast<uint4 *>(stage + r * 512 + ((piece ^ r) & 31) * 16) = lin[round * (kRows / 2) + i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int r = t - round * kRows;           // my token's row in this round, if it is in it
+            if (r >= 0 && r < kRows) {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    xb[ks] = *reinterpret_cast<const uint4 *>(stage + r * 512 + (((2 * ks + h) ^ r) & 31) * 16);
+            }
+        }
     }
     // consume the loads here so that hipcc's wait for them is not placed inside the loop (it would drain the LDS
     // copies it cannot see on every iteration)
@@ -228,14 +290,20 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
 
     float run_max = -INFINITY;
     const bool masked = EPI == kHeadMajor && p.pad && p.pad[tk];
+    // (a row the attention kernel of this launch projects itself is skipped: a mark in `skip_hint` that the selection
+    // confirms.  The confirmation is a trip to memory BEHIND the mark's: it is requested after the first barrier and
+    // travels under step 0's products -- in front of the barrier it kept every wave of the workgroup waiting, 6 000 of the
+    // workgroup's 36 000 cycles by the stamps)
     bool skip = false;
-    if (EPI == kStore && p.skip_hint) {
-        const int m = p.skip_hint[(int64_t)img * p.skip_hint_bs + ri];
-        if (m > 0 && m <= p.skip_n) skip = p.skip_sel[(int64_t)img * p.skip_n + m - 1] == ri;
-    }
+    int skip_mark = 0;
+    if (EPI == kStore && p.skip_hint) skip_mark = p.skip_hint[(int64_t)img * p.skip_hint_bs + ri];
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my activations and the staged bias
+    TL_STAMP();   // 1: my activations are back
     __builtin_amdgcn_s_barrier();
+    TL_STAMP();   // 2: step 0 is in LDS
+    if (EPI == kStore && p.skip_hint && skip_mark > 0 && skip_mark <= p.skip_n)
+        skip = p.skip_sel[(int64_t)img * p.skip_n + skip_mark - 1] == ri;
 
     // A fragments come from LDS through a ring of R registers (requested R MFMAs before use, refilled right after the
     // MFMA that consumed the slot): with one wave per SIMD nothing else hides the LDS latency.
@@ -269,6 +337,7 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
             if (f + R < kTLStepTiles * 16) ring[f % R] = tl_lds_read16(cb + frag(f + R));
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (st < 4) TL_STAMP();   // 3 + 2 st: products of step st
         if (EPI == kClassMax) {
 #pragma unroll
             for (int j = 0; j < kTLStepTiles; ++j)
@@ -343,7 +412,14 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
                 }
             }
         }
+        if (st < 4) TL_STAMP();   // 4 + 2 st: stores of step st
     }
+#ifdef TL_STAMPS
+    if (EPI == kStore && tid == 0 && (block == 0 || block == 50) && nsteps == 3)
+        printf("token_linear blk=%d cycles: x %lld | wait step0 %lld | s0 mfma %lld st %lld | s1 wait+mfma %lld st %lld | s2 wait+mfma %lld st %lld | total %lld\n",
+               block, tl_t[1] - tl_t[0], tl_t[2] - tl_t[1], tl_t[3] - tl_t[2], tl_t[4] - tl_t[3], tl_t[5] - tl_t[4], tl_t[6] - tl_t[5],
+               tl_t[7] - tl_t[6], tl_t[8] - tl_t[7], tl_t[8] - tl_t[0]);
+#endif
     if (EPI == kClassMax) {
         run_max = fmaxf(run_max, __shfl_xor(run_max, 32));
         if (valid && h == 0) {
