@@ -415,6 +415,10 @@ __device__ __forceinline__ void token_linear_body(const TLArgs &p, int block)
         if (st < 4) TL_STAMP();   // 4 + 2 st: stores of step st
     }
 #ifdef TL_STAMPS
+    if (EPI == kHeadMajor && tid == 0 && (block == 0 || block == 50) && nsteps == 2)
+        printf("value projection blk=%d cycles: x %lld | wait step0 %lld | s0 mfma %lld st %lld | s1 wait+mfma %lld st %lld | total %lld\n",
+               block, tl_t[1] - tl_t[0], tl_t[2] - tl_t[1], tl_t[3] - tl_t[2], tl_t[4] - tl_t[3], tl_t[5] - tl_t[4], tl_t[6] - tl_t[5],
+               tl_t[6] - tl_t[0]);
     if (EPI == kStore && tid == 0 && (block == 0 || block == 50) && nsteps == 3)
         printf("token_linear blk=%d cycles: x %lld | wait step0 %lld | s0 mfma %lld st %lld | s1 wait+mfma %lld st %lld | s2 wait+mfma %lld st %lld | total %lld\n",
                block, tl_t[1] - tl_t[0], tl_t[2] - tl_t[1], tl_t[3] - tl_t[2], tl_t[4] - tl_t[3], tl_t[5] - tl_t[4], tl_t[6] - tl_t[5],
