@@ -528,6 +528,33 @@ int sdetr_stage1_x3_with_jobs(
     const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
     void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered, const sdetr_rank_job *rank,
     const sdetr_finalize_job *finalize);
+/* The salience head with both 256 x 256 products of stage 1 OUT of the coarse-to-fine chain (round 6; reference
+ * models/bricks/salience_transformer.py:20-24 layer1 = LN -> Linear -> GELU, :131-146 the modulation,
+ * models/bricks/base_transformer.py:104-111 enc_output + norm).  The modulation is a per-token scalar s = 1 + up * alpha,
+ * and LayerNorm of a scaled row is the unscaled row's times a scalar: with mu, sigma the statistics of the row x,
+ *     layer1.Linear(LN(s x)) = k G + c0,   k = s sigma / sqrt(s^2 sigma^2 + eps),
+ *     G = W (gamma (x - mu) / sigma),      c0 = W beta + b,
+ * exactly (the scores agree with the unfactored evaluation to ~5e-7, the index sets of the reference's digests are
+ * unchanged: tests/test_hotpath_gpu.py).  sdetr_salience_head_hoist_x3: ONE launch for all levels' tokens -- enc_output +
+ * enc_output_norm (optional, memory_out optional), the row statistics and G (bf16 x 3 products at fp32 accuracy as in
+ * sdetr_salience_head_stage1_x3); g_out [batch, tokens, 256] and sigma_out [batch, tokens] fp32 with batch strides;
+ * it can carry a value-projection job and / or the finalize pass like sdetr_stage1_x3_with_jobs.
+ * sdetr_salience_head_modulate: what is left per level -- resize of the coarser score (or row_scale) -> s -> k ->
+ * GELU(k G + c0) -> z_local / partial_sums exactly as stage 1 leaves them (sdetr_salience_head_const and stage 2 follow);
+ * g / sigma point at the level's first row; it can carry the rank job of the level before and the finalize pass. */
+int sdetr_salience_head_hoist_x3(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *norm_weight, const void *weight_x3, float *memory_out,
+    int64_t memory_batch_stride, float *g_out, int64_t g_batch_stride, float *sigma_out, int64_t sigma_batch_stride,
+    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+    const sdetr_bordered_layout *vp_bordered, const sdetr_finalize_job *finalize);
+int sdetr_salience_head_modulate(sdetr_stream_t stream, const float *g, int64_t g_batch_stride, const float *sigma,
+                                 int64_t sigma_batch_stride, int batch_size, int tokens, const float *row_scale,
+                                 const float *coarse_score, int coarse_h, int coarse_w, int level_h, int level_w,
+                                 const float *alpha, float norm_eps, const float *c0, float *z_local, float *partial_sums,
+                                 const sdetr_rank_job *rank, const sdetr_finalize_job *finalize);
 int sdetr_stage1_x3_with_value_proj(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,

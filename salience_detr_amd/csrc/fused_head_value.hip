@@ -93,6 +93,37 @@ __global__ void __launch_bounds__(512, 2) fused_stage1_rank_kernel(Stage1Args s1
     }
 }
 
+// What the hoisted head leaves in the coarse-to-fine chain (modulate_body: the first 256 threads) with the jobs stage 1 used
+// to carry: the rank of the level before, the token-space pass of the encoder's output.
+// `rk_tile`: words of LDS in front of the rank body's partial counts -- the whole row of keys when it is shorter than a
+// full tile (the launch's LDS is what every workgroup reserves, the modulation blocks too: with the full 48 KB tile only
+// three of them fit a CU and the finest level's launch took 20 us instead of 9).
+__global__ void __launch_bounds__(512, 2) fused_modulate_rank_kernel(ModulateArgs m, int m_blocks, int m_images, RankArgs rk,
+                                                                     int rk_blocks_x, int rk_blocks, int rk_tile,
+                                                                     FinalizeJob fin, int fin_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) char fused_lds[];
+    // The jobs' workgroups FIRST: each is a longer chain than a modulation block (a rank workgroup scans the whole row of
+    // keys), behind the step's own blocks they would start when those are done -- 22.6 us for the finest level's launch
+    // instead of the longer of the two.
+    const int blk = (int)blockIdx.x;
+    const int n1 = m_blocks * m_images;
+    if (blk < rk_blocks) {
+        uint32_t *lds = reinterpret_cast<uint32_t *>(fused_lds);
+        topk_rank_body(rk, blk % rk_blocks_x, blk / rk_blocks_x, lds, lds + rk_tile);
+    } else if (blk < rk_blocks + fin_blocks) {
+        finalize_all_role(fin, blk - rk_blocks, fin_blocks);
+    } else {
+        // blockDim.x / 256 modulation blocks per workgroup (an odd last one: its waves leave, the hardware barrier counts
+        // the waves that are left)
+        const int per = (int)blockDim.x / kModThreads, half = (int)threadIdx.x / kModThreads;
+        const int e = (blk - rk_blocks - fin_blocks) * per + half;
+        if (e >= n1) return;
+        modulate_body(m, e % m_blocks, e / m_blocks, reinterpret_cast<float *>(fused_lds) + half * kModLdsFloats,
+                      (int)threadIdx.x - half * kModThreads);
+    }
+}
+
 // The same for stage 2 (64-token blocks, first 256 threads; its tile lives behind the projection's LDS buffers).
 __global__ void __launch_bounds__(768, 1) fused_stage2_value_kernel(Stage2Args s2, int s2_blocks, int s2_images, TLArgs tl)
 {
@@ -154,40 +185,13 @@ static int fill_value_job(TLArgs &t, size_t &lds_tl, int &n2, const void *vp_x, 
     return tl_set_bordered(t, vp_bordered, vp_spatial_size, n2);
 }
 
-// sdetr_salience_head_stage1_x3 (same arguments) + up to two jobs carried by the same launch: the value projection of
-// `vp_num_groups` stacked layers (arguments of sdetr_value_proj_head_major; `vp_packed_weight`, `vp_bias_padded` and
-// `vp_dst` already point at the first of those layers; vp_x == NULL: none) and a plain masked top-k by rank counting
-// (`rank`: the arguments of sdetr_masked_topk_desc_f32 with fill_mode 2 and no payload / prefilter; NULL: none).
-extern "C" int sdetr_stage1_x3_with_jobs(
-    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
-    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
-    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
-    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
-    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
-    float *z_local, float *partial_sums,
-    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
-    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
-    const sdetr_bordered_layout *vp_bordered, const sdetr_rank_job *rank, const sdetr_finalize_job *finalize)
+// The launch of a filled-in Stage1Args with the jobs it carries (sdetr_stage1_x3_with_jobs, sdetr_salience_head_hoist_x3).
+static int stage1_launch_with_jobs(sdetr_stream_t stream, Stage1Args &a, int batch_size, const void *vp_x,
+                                   const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+                                   int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst,
+                                   int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered, const sdetr_rank_job *rank,
+                                   const sdetr_finalize_job *finalize)
 {
-    if (channels != kC) return fail("stage1_x3_with_jobs: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
-    if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_jobs: empty level");
-    if (!x || !norm_weight || !norm_bias || !weight_x3 || !bias || !z_local || !partial_sums)
-        return fail("stage1_x3_with_jobs: NULL pointer");
-    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
-        return fail("stage1_x3_with_jobs: enc_output parameters incomplete");
-    if (row_scale && coarse_score) return fail("stage1_x3_with_jobs: give row_scale OR coarse_score");
-    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
-        return fail("stage1_x3_with_jobs: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
-    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("stage1_x3_with_jobs: rows must be 16-byte aligned");
-    Stage1Args a;
-    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
-    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
-    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
-    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
-    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
-    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = bias;
-    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
-    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = (tokens + 31) / 32;
     const int n1 = a.nblk * batch_size;
     const size_t lds_s1 = (size_t)kX3Region + (kParRows * kC + 32 + 4) * sizeof(float);
     // the rank job
@@ -242,6 +246,145 @@ extern "C" int sdetr_stage1_x3_with_jobs(
     hipLaunchKernelGGL(fused_stage1_value_kernel, dim3((unsigned)(n1 + n2 + n3)), dim3(768), lds, hs, a, a.nblk, batch_size, t,
                        n2, r, rk_bx);
     return check_launch("stage1_x3_with_jobs");
+}
+
+// sdetr_salience_head_stage1_x3 (same arguments) + up to two jobs carried by the same launch: the value projection of
+// `vp_num_groups` stacked layers (arguments of sdetr_value_proj_head_major; `vp_packed_weight`, `vp_bias_padded` and
+// `vp_dst` already point at the first of those layers; vp_x == NULL: none) and a plain masked top-k by rank counting
+// (`rank`: the arguments of sdetr_masked_topk_desc_f32 with fill_mode 2 and no payload / prefilter; NULL: none).
+extern "C" int sdetr_stage1_x3_with_jobs(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *row_scale, const float *coarse_score, int coarse_h,
+    int coarse_w, int level_h, int level_w, const float *alpha, const float *norm_weight, const float *norm_bias,
+    float norm_eps, const void *weight_x3, const float *bias, float *memory_out, int64_t memory_batch_stride,
+    float *z_local, float *partial_sums,
+    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+    const sdetr_bordered_layout *vp_bordered, const sdetr_rank_job *rank, const sdetr_finalize_job *finalize)
+{
+    if (channels != kC) return fail("stage1_x3_with_jobs: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
+    if (batch_size <= 0 || tokens <= 0) return fail("stage1_x3_with_jobs: empty level");
+    if (!x || !norm_weight || !norm_bias || !weight_x3 || !bias || !z_local || !partial_sums)
+        return fail("stage1_x3_with_jobs: NULL pointer");
+    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
+        return fail("stage1_x3_with_jobs: enc_output parameters incomplete");
+    if (row_scale && coarse_score) return fail("stage1_x3_with_jobs: give row_scale OR coarse_score");
+    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
+        return fail("stage1_x3_with_jobs: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
+    if ((x_row_stride % 4) || (x_batch_stride % 4)) return fail("stage1_x3_with_jobs: rows must be 16-byte aligned");
+    Stage1Args a;
+    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
+    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
+    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
+    a.row_scale = row_scale; a.coarse = coarse_score; a.ch = coarse_h; a.cw = coarse_w; a.h = level_h; a.w = level_w;
+    a.alpha = alpha; a.g1 = norm_weight; a.beta1 = norm_bias; a.eps1 = norm_eps;
+    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = bias;
+    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
+    a.z_local = z_local; a.partial = partial_sums; a.n = tokens; a.nblk = (tokens + 31) / 32;
+    return stage1_launch_with_jobs(stream, a, batch_size, vp_x, vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size,
+                                   vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, vp_bordered, rank,
+                                   finalize);
+}
+
+// The hoisted stage 1 (Stage1Args, hoisted form) for ALL levels' tokens: x [batch, tokens, 256] -> g_out [batch, tokens, 256]
+// = layer1.Linear's weight times the unit-variance row (no bias) and sigma_out [batch, tokens] = the row's standard
+// deviation, after enc_output + enc_output_norm when their parameters are given (memory_out optional, as in stage 1).
+// Carries a value-projection job and / or the finalize pass like sdetr_stage1_x3_with_jobs (vp_x / finalize NULL: none).
+extern "C" int sdetr_salience_head_hoist_x3(
+    sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
+    int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
+    const float *enc_norm_bias, float enc_norm_eps, const float *norm_weight, const void *weight_x3, float *memory_out,
+    int64_t memory_batch_stride, float *g_out, int64_t g_batch_stride, float *sigma_out, int64_t sigma_batch_stride,
+    const void *vp_x, const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
+    int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
+    const sdetr_bordered_layout *vp_bordered, const sdetr_finalize_job *finalize)
+{
+    if (channels != kC) return fail("salience_head_hoist_x3: built for embed_dim = hidden_dim = %d (got %d)", kC, channels);
+    if (batch_size <= 0 || tokens <= 0) return fail("salience_head_hoist_x3: empty input");
+    if (!x || !norm_weight || !weight_x3 || !g_out || !sigma_out) return fail("salience_head_hoist_x3: NULL pointer");
+    if (enc_weight_x3 && (!enc_bias || !enc_norm_weight || !enc_norm_bias))
+        return fail("salience_head_hoist_x3: enc_output parameters incomplete");
+    if ((x_row_stride % 4) || (x_batch_stride % 4) || (g_batch_stride % 4))
+        return fail("salience_head_hoist_x3: rows must be 16-byte aligned");
+    if (g_batch_stride < (int64_t)tokens * kC || sigma_batch_stride < tokens)
+        return fail("salience_head_hoist_x3: output batch strides too small");
+    Stage1Args a;
+    a.x = x; a.x_batch_stride = x_batch_stride; a.x_row_stride = x_row_stride;
+    a.w_enc = reinterpret_cast<const float4 *>(enc_weight_x3);
+    a.b_enc = enc_bias; a.g_enc = enc_norm_weight; a.beta_enc = enc_norm_bias; a.eps_enc = enc_norm_eps;
+    a.row_scale = nullptr; a.coarse = nullptr; a.ch = a.cw = a.h = a.w = 0;
+    a.alpha = nullptr; a.g1 = norm_weight; a.beta1 = norm_weight; a.eps1 = 0.f;   // (beta1 / b1: staged, not used)
+    a.w1 = reinterpret_cast<const float4 *>(weight_x3); a.b1 = norm_weight;
+    a.memory_out = enc_weight_x3 ? memory_out : nullptr; a.mem_batch_stride = memory_batch_stride;
+    a.z_local = nullptr; a.partial = nullptr; a.n = tokens; a.nblk = (tokens + 31) / 32;
+    a.g_out = g_out; a.g_batch_stride = g_batch_stride; a.sigma_out = sigma_out; a.sigma_batch_stride = sigma_batch_stride;
+    return stage1_launch_with_jobs(stream, a, batch_size, vp_x, vp_packed_weight, vp_bias_padded, vp_pad_mask, vp_batch_size,
+                                   vp_spatial_size, vp_num_heads, vp_num_groups, vp_dst, vp_dst_dtype, vp_bordered, nullptr,
+                                   finalize);
+}
+
+// One level's step of the hoisted head (modulate_body): g / sigma are the level's rows of sdetr_salience_head_hoist_x3's
+// outputs, c0 [256] = layer1.Linear.weight @ layer1.LayerNorm.bias + layer1.Linear.bias; z_local / partial_sums as stage 1
+// leaves them (sdetr_salience_head_const / _stage2 follow).  `rank` / `finalize`: jobs carried as by
+// sdetr_stage1_x3_with_jobs.
+extern "C" int sdetr_salience_head_modulate(sdetr_stream_t stream, const float *g, int64_t g_batch_stride, const float *sigma,
+                                            int64_t sigma_batch_stride, int batch_size, int tokens, const float *row_scale,
+                                            const float *coarse_score, int coarse_h, int coarse_w, int level_h, int level_w,
+                                            const float *alpha, float norm_eps, const float *c0, float *z_local,
+                                            float *partial_sums, const sdetr_rank_job *rank,
+                                            const sdetr_finalize_job *finalize)
+{
+    if (batch_size <= 0 || tokens <= 0) return fail("salience_head_modulate: empty level");
+    if (!g || !sigma || !c0 || !z_local || !partial_sums) return fail("salience_head_modulate: NULL pointer");
+    if (row_scale && coarse_score) return fail("salience_head_modulate: give row_scale OR coarse_score");
+    if (coarse_score && ((int64_t)level_h * level_w != tokens || coarse_h <= 0 || coarse_w <= 0))
+        return fail("salience_head_modulate: level %dx%d does not cover %d tokens", level_h, level_w, tokens);
+    if ((g_batch_stride % 4) || (reinterpret_cast<uintptr_t>(g) & 15)) return fail("salience_head_modulate: rows must be 16-byte aligned");
+    ModulateArgs m;
+    m.g = g; m.g_batch_stride = g_batch_stride; m.sigma = sigma; m.sigma_batch_stride = sigma_batch_stride;
+    m.row_scale = row_scale; m.coarse = coarse_score; m.ch = coarse_h; m.cw = coarse_w; m.h = level_h; m.w = level_w;
+    m.alpha = alpha; m.eps1 = norm_eps; m.c0 = c0; m.z_local = z_local; m.partial = partial_sums; m.n = tokens;
+    m.nblk = (tokens + 31) / 32;
+    const int n1 = m.nblk * batch_size;
+    RankArgs r{};
+    int rk_bx = 1, n3 = 0, rk_tile = kRankTile;
+    size_t lds = 2 * (size_t)kModLdsFloats * sizeof(float);
+    if (rank) {
+        if (rank->batch <= 0 || rank->n <= 0 || rank->k <= 0 || rank->k > rank->n || !rank->score || !rank->out_index)
+            return fail("salience_head_modulate: bad rank job");
+        if (rank->n >= (1 << 30) || rank->batch > 65535) return fail("salience_head_modulate: rank row too long / too many rows");
+        const int64_t ors = rank->out_row_stride ? rank->out_row_stride : rank->k;
+        const int64_t mrs = rank->mask && !rank->mask_row_stride ? rank->n : rank->mask_row_stride;
+        if (ors < rank->k || (rank->mask && mrs < rank->n)) return fail("salience_head_modulate: rank job strides too small");
+        if (rank->mask && !rank->fill_value) return fail("salience_head_modulate: a masked rank job needs its fill value");
+        r.score = rank->score; r.mask = rank->mask; r.mask_stride = mrs; r.fill = rank->fill_value; r.N = rank->n;
+        r.k = rank->k; r.index_offset = rank->index_offset; r.out_score = rank->out_score; r.out_index = rank->out_index;
+        r.out_stride = ors;
+        rk_bx = (rank->n + 63) / 64;
+        n3 = rk_bx * rank->batch;
+        rk_tile = rk_bx * 64 < kRankTile ? rk_bx * 64 : kRankTile;
+        const size_t lds_rk = (size_t)(rk_tile + kRankWaves * 64) * 4;
+        if (lds_rk > lds) lds = lds_rk;
+    }
+    FinalizeJob fj{};
+    int n4 = 0;
+    if (finalize) {
+        if (finalize->batch <= 0 || finalize->spatial_size <= 0 || !finalize->tokens || !finalize->background || !finalize->out)
+            return fail("salience_head_modulate: bad finalize job");
+        fj.tokens = (const uint4 *)finalize->tokens; fj.background = (const uint4 *)finalize->background;
+        fj.pad = finalize->padding_mask; fj.out = (uint4 *)finalize->out; fj.S = finalize->spatial_size;
+        fj.total = (int64_t)finalize->batch * finalize->spatial_size * 32;
+        if ((int64_t)finalize->batch * finalize->spatial_size >= ((int64_t)1 << 31))
+            return fail("salience_head_modulate: finalize job too large for 32-bit token arithmetic");
+        n4 = 512;   // (a short host: the pass's own chain -- pieces per thread -- has to be short as well)
+    }
+    // (the jobs' bodies need 512 threads: two modulation blocks per workgroup then; alone the step runs in 256)
+    const unsigned threads = (n3 || n4) ? 512 : kModThreads;
+    const int per = (int)threads / kModThreads;
+    hipLaunchKernelGGL(fused_modulate_rank_kernel, dim3((unsigned)((n1 + per - 1) / per + n3 + n4)), dim3(threads), lds,
+                       static_cast<hipStream_t>(stream), m, m.nblk, batch_size, r, rk_bx, n3, rk_tile, fj, n4);
+    return check_launch("salience_head_modulate");
 }
 
 extern "C" int sdetr_stage1_x3_with_value_proj(

@@ -161,6 +161,17 @@ struct Stage1Args {
     float *z_local;            // [B, n, 128]
     float *partial;            // [B, nblk, 128]
     int n, nblk;
+    // HOISTED form (g_out != NULL; round 6): everything of stage 1 that does not depend on the coarser level's score, for
+    // ALL levels' tokens in one launch.  The modulation is a per-token scalar s, and LayerNorm of a scaled row is the
+    // unscaled row's times a scalar: with mu, sigma^2 the statistics of the row x,
+    //     LN(s x) = k gamma (x - mu) / sigma + beta,   k = s sigma / sqrt(s^2 sigma^2 + eps)
+    //     layer1.Linear(LN(s x)) = k G + c0,   G = W (gamma (x - mu) / sigma),   c0 = W beta + b.
+    // This launch writes G and sigma; per level only `modulate_body` (resize -> s -> k -> GELU -> halves) is left in the
+    // coarse-to-fine chain.  No row_scale / coarse, no z_local / partial.
+    float *g_out = nullptr;    // [B, n, 256], images g_batch_stride apart
+    int64_t g_batch_stride = 0;
+    float *sigma_out = nullptr;   // [B, n], images sigma_batch_stride apart
+    int64_t sigma_batch_stride = 0;
 };
 
 // sum over the TPR (a power of two <= 16... or more) lanes of a row, the xor butterfly s[i] += s[i ^ o], o = 1, 2, 4, ...
@@ -414,6 +425,7 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
     const int nvalid = min(TM, p.n - t0);
     const int n0 = wave * 32;
     const bool with_enc = p.w_enc != nullptr;
+    const bool hoist = p.g_out != nullptr;
 
     // (benchmark builds only, -DSH_STAMPS through benchmarks/lib_variant.sh: cycle stamps per phase, printed by three
     // workgroups of a launch)
@@ -536,7 +548,13 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
                 v[i] = make_float4(v[i].x + v[i].x * s * a, v[i].y + v[i].y * s * a, v[i].z + v[i].z * s * a,
                                    v[i].w + v[i].w * s * a);
         }
-        row_stats<NV, TPR>(v, p.eps1, mean, rstd);
+        // (hoisted: eps = 0 -- the statistics of the row itself; rstd = 1 / sigma, and a constant row gives G = 0)
+        row_stats<NV, TPR>(v, hoist ? 0.f : p.eps1, mean, rstd);
+        if (hoist) {
+            const bool flat = !(rstd < 3.0e38f);   // sigma == 0 (rsqrt(0) = inf)
+            if (q == 0 && r < nvalid) p.sigma_out[(int64_t)b * p.sigma_batch_stride + t0 + r] = flat ? 0.f : 1.f / rstd;
+            if (flat) rstd = 0.f;
+        }
         // The statistics are COMPLETE in front of the barrier below (round 6).  Left to the scheduler, the last step of the
         // 16-lane sum (a ds_bpermute) was issued in front of the barrier and consumed behind it -- and with the faster
         // split of this round that schedule produced wrong rows in ~20 of 33 400 tokens per launch, always in lanes 48-63
@@ -549,7 +567,8 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             v[i] = ln_apply(v[i], mean, rstd, *reinterpret_cast<const float4 *>(par + kParG1 * kC + CS * i + 4 * q),
-                            *reinterpret_cast<const float4 *>(par + kParBeta1 * kC + CS * i + 4 * q));
+                            hoist ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                  : *reinterpret_cast<const float4 *>(par + kParBeta1 * kC + CS * i + 4 * q));
         __syncthreads();   // every thread holds its part of the tile in registers: the planes may overwrite it
 #pragma unroll
         for (int i = 0; i < NV; ++i) store_split<SH_SITE2_SOFT>(planes, r, CS * i + 4 * q, v[i]);
@@ -562,7 +581,16 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     block_gemm_x3<kX3Depth>(planes, ws, lane, acc);
     SH_STAMP();   // 5: second product
-    {
+    if (hoist) {
+        // G as it leaves the accumulators (no bias, no GELU): lane = column, 16 rows
+        const int c = n0 + (lane & 31);
+        float *g = p.g_out + (int64_t)b * p.g_batch_stride + (int64_t)t0 * kC + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = acc_row(i, lane);
+            if (r < nvalid) g[(int64_t)r * kC] = acc[i];
+        }
+    } else {
         const int c = n0 + (lane & 31);
         const float bias = par[kParB1 * kC + c];
         if (n0 < kHalf) {
@@ -586,6 +614,97 @@ __device__ __forceinline__ void stage1_x3_body(const Stage1Args &p, int blk, int
         printf("stage1 n=%d blk=%d cycles: (own part of the tile %lld) tile %lld | gemm1 %lld | to-lds %lld | ln %lld | gemm2 %lld | epilogue %lld | total %lld\n", p.n, blk,
                sh_tile_done - sh_t[0], sh_t[1] - sh_t[0], sh_t[2] - sh_t[1], sh_t[3] - sh_t[2], sh_t[4] - sh_t[3], sh_t[5] - sh_t[4], sh_t[6] - sh_t[5], sh_t[6] - sh_t[0]);
 #endif
+}
+
+// ---- what is left of stage 1 in the coarse-to-fine chain once G and sigma exist (Stage1Args, hoisted form) ----
+//     s = 1 + resize(coarser score) * alpha          (salience_transformer.py:139-143; x + x * up * alpha = s x)
+//     k = s sigma / sqrt(s^2 sigma^2 + eps)
+//     z = GELU(k G + c0):  z[:128] -> z_local,  sum over the block's tokens of z[128:] -> partial   (as stage 1 leaves them)
+struct ModulateArgs {
+    const float *g;            // [B, n, 256] of this level, images g_batch_stride apart
+    int64_t g_batch_stride;
+    const float *sigma;        // [B, n], images sigma_batch_stride apart
+    int64_t sigma_batch_stride;
+    const float *row_scale;    // [B, n] or NULL
+    const float *coarse;       // [B, ch, cw] coarser score map or NULL
+    int ch, cw, h, w;
+    const float *alpha;        // device scalar (NULL = 1)
+    float eps1;
+    const float *c0;           // [256] W beta + b
+    float *z_local;            // [B, n, 128]
+    float *partial;            // [B, nblk, 128]
+    int n, nblk;
+};
+
+constexpr int kModThreads = 256;
+constexpr int kModLdsFloats = 32 + 4 * kHalf;   // k per token | the waves' column sums
+
+// Block = 32 tokens (stage 1's blocking: `partial` has the same rows) on 256 threads: wave w takes tokens w, w + 4, ...,
+// lane l channels 4l .. 4l + 3 -- a row of G is one coalesced KB, all eight in flight.  `tid` = the thread's index among
+// the 256 of its block, `lds` their kModLdsFloats: a 512-thread workgroup of a launch that carries jobs runs two blocks
+// (were its upper half to exit, the launch would start twice the waves for the same work, and the finest level's 4176
+// waves are what its 9 us consist of -- measured 20 us).
+__device__ __forceinline__ void modulate_body(const ModulateArgs &p, int blk, int b, float *lds, int tid)
+{
+    constexpr int TM = 32;
+    float *kk = lds, *red = lds + 32;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int t0 = blk * TM;
+    const int nvalid = min(TM, p.n - t0);
+    const float *gb = p.g + (int64_t)b * p.g_batch_stride + (int64_t)t0 * kC + 4 * lane;
+    float4 gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const float4 *>(gb + (int64_t)min(wave + 4 * i, nvalid - 1) * kC);
+    const float4 c0 = *reinterpret_cast<const float4 *>(p.c0 + 4 * lane);
+    if (tid < TM) {
+        const int t = min(t0 + tid, p.n - 1);
+        float s = 1.f;
+        if (p.row_scale || p.coarse) {
+            float up;
+            if (p.row_scale) {
+                up = p.row_scale[(int64_t)b * p.n + t];
+            } else {
+                // bilinear, align_corners=True (F.interpolate, salience_transformer.py:139-142) -- as in stage1_x3_body
+                const int y = t / p.w, x = t - y * p.w;
+                const float sh = p.h > 1 ? (float)(p.ch - 1) / (float)(p.h - 1) : 0.f;
+                const float sw = p.w > 1 ? (float)(p.cw - 1) / (float)(p.w - 1) : 0.f;
+                const float fy = sh * (float)y, fx = sw * (float)x;
+                const int y1 = (int)fy, x1 = (int)fx;
+                const int yp = y1 < p.ch - 1 ? 1 : 0, xp = x1 < p.cw - 1 ? 1 : 0;
+                const float ly = fy - (float)y1, lx = fx - (float)x1;
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                const float *cm = p.coarse + (int64_t)b * p.ch * p.cw;
+                up = hy * (hx * cm[y1 * p.cw + x1] + lx * cm[y1 * p.cw + x1 + xp]) +
+                     ly * (hx * cm[(y1 + yp) * p.cw + x1] + lx * cm[(y1 + yp) * p.cw + x1 + xp]);
+            }
+            s = 1.f + up * (p.alpha ? *p.alpha : 1.f);
+        }
+        const float sg = p.sigma[(int64_t)b * p.sigma_batch_stride + t];
+        const float ss = s * sg;
+        kk[tid] = ss * rsqrtf(ss * ss + p.eps1);
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *zl = p.z_local + ((int64_t)b * p.n + t0) * kHalf + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = wave + 4 * i;
+        const float k = kk[r];
+        const float4 z = make_float4(gelu_erf(fmaf(k, gv[i].x, c0.x)), gelu_erf(fmaf(k, gv[i].y, c0.y)),
+                                     gelu_erf(fmaf(k, gv[i].z, c0.z)), gelu_erf(fmaf(k, gv[i].w, c0.w)));
+        if (r < nvalid) {
+            if (lane < 32) {
+                *reinterpret_cast<float4 *>(zl + (int64_t)r * kHalf) = z;
+            } else {
+                acc.x += z.x; acc.y += z.y; acc.z += z.z; acc.w += z.w;
+            }
+        }
+    }
+    if (lane >= 32) *reinterpret_cast<float4 *>(red + wave * kHalf + 4 * (lane - 32)) = acc;
+    __syncthreads();
+    if (tid < kHalf)
+        p.partial[((int64_t)b * p.nblk + blk) * kHalf + tid] =
+            (red[tid] + red[kHalf + tid]) + (red[2 * kHalf + tid] + red[3 * kHalf + tid]);
 }
 
 struct Stage2Args {

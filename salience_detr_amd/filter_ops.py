@@ -537,12 +537,83 @@ def plan_value_projection(value: Tensor, weight: Tensor, bias: Optional[Tensor],
     return dst, jobs
 
 
+class HoistedHead:
+    """``salience_head_hoist``'s result: ``g`` [B,S,256] and ``sigma`` [B,S] of all levels' tokens plus the constant row
+    ``c0`` [256] -- ``salience_head(..., hoisted=h.level(start, n))`` then runs a level without its stage 1."""
+
+    def __init__(self, g: Tensor, sigma: Tensor, c0: Tensor):
+        self.g, self.sigma, self.c0 = g, sigma, c0
+
+    def level(self, start: int, n: int) -> "HoistedHead":
+        return HoistedHead(self.g[:, start:start + n], self.sigma[:, start:start + n], self.c0)
+
+
+def _layer1_constant(predictor) -> Tensor:
+    """``c0 = layer1.Linear.weight @ layer1.LayerNorm.bias + layer1.Linear.bias`` (fp32 [256]), cached on the weight and
+    refreshed when any of the three parameters changes."""
+    l1n, l1 = predictor.layer1[0], predictor.layer1[1]
+    tag = tuple((t.data_ptr(), t._version) for t in (l1.weight, l1.bias, l1n.bias)) + (str(l1.weight.device),)
+    hit = l1.weight.__dict__.get("_sdetr_c0")
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    with torch.no_grad():
+        # (elementwise product + a sum per row: no library GEMV -- its accumulation order varies with the handle's state)
+        c0 = ((l1.weight.detach().double() * l1n.bias.detach().double()).sum(1) + l1.bias.detach().double()).float().contiguous()
+    l1.weight.__dict__["_sdetr_c0"] = (tag, c0)
+    return c0
+
+
+def salience_head_hoist(x: Tensor, predictor, enc_output=None, enc_output_norm=None, memory_out: Optional[Tensor] = None,
+                        value_job: Optional[ValueProjectionJob] = None,
+                        finalize_job: Optional["FinalizeJob"] = None) -> HoistedHead:
+    """Everything of the salience head's stage 1 that does not depend on the coarser level's score, for ALL levels' tokens
+    in one launch (include/salience_hip.h, sdetr_salience_head_hoist_x3): ``x`` [B,S,256] fp32 -> ``HoistedHead``.  With
+    ``enc_output`` / ``enc_output_norm`` they are applied first (``memory_out`` [B,S,256] optionally receives their
+    result).  ``value_job`` / ``finalize_job``: pending jobs the launch carries (the latter only next to no value job)."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1 or x.shape[2] != 256:
+        raise RuntimeError("salience_head_hoist: fp32 [B,S,256] HIP tensor with a contiguous last dim expected; no CPU fallback")
+    B, S, C = x.shape
+    job_act = value_job.value.dtype if value_job is not None else (finalize_job.tokens.dtype if finalize_job is not None else None)
+    lib = _hip.lib(job_act)
+    l1n, l1 = predictor.layer1[0], predictor.layer1[1]
+    w_enc = b_enc = g_enc = be_enc = None
+    eps_enc, mbs = 0.0, 0
+    if enc_output is not None:
+        w_enc = packed_linear_weight(enc_output.weight, split3=True)
+        b_enc, g_enc, be_enc = enc_output.bias.detach(), enc_output_norm.weight.detach(), enc_output_norm.bias.detach()
+        eps_enc = float(enc_output_norm.eps)
+        if memory_out is not None:
+            if memory_out.shape != x.shape or memory_out.stride(2) != 1 or memory_out.stride(1) != C:
+                raise RuntimeError("salience_head_hoist: memory_out must be [B,S,C] with contiguous rows")
+            mbs = memory_out.stride(0)
+    g = torch.empty((B, S, C), dtype=torch.float32, device=x.device)
+    sigma = torch.empty((B, S), dtype=torch.float32, device=x.device)
+    c0 = _layer1_constant(predictor)
+    carry_value = value_job is not None and not value_job.done and value_job.value.device == x.device
+    carry_fin = (finalize_job is not None and not finalize_job.done and not carry_value
+                 and finalize_job.tokens.device == x.device)
+    vp = value_job.pointers() if carry_value else (None, None, None, None, 0, 0, 0, 0, None, 0, None)
+    fj = ctypes.byref(finalize_job.struct()) if carry_fin else None
+    with torch.cuda.device(x.device):
+        code = lib.sdetr_salience_head_hoist_x3(
+            _hip.stream_ptr(), x.data_ptr(), x.stride(0), x.stride(1), B, S, C, _hip.ptr(w_enc), _hip.ptr(b_enc),
+            _hip.ptr(g_enc), _hip.ptr(be_enc), eps_enc, l1n.weight.data_ptr(),
+            packed_linear_weight(l1.weight, split3=True).data_ptr(), _hip.ptr(memory_out), mbs, g.data_ptr(), g.stride(0),
+            sigma.data_ptr(), sigma.stride(0), *vp, fj)
+    _hip.check(code, "salience_head_hoist")
+    if carry_value:
+        value_job.done = True
+    if carry_fin:
+        finalize_job.done = True
+    return HoistedHead(g, sigma, c0)
+
+
 def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coarse_score: Optional[Tensor] = None,
                   level_hw=None, alpha: Optional[Tensor] = None, enc_output=None, enc_output_norm=None,
                   memory_out: Optional[Tensor] = None, score_flat: Optional[Tensor] = None,
                   score_min: Optional[Tensor] = None, value_job: Optional[ValueProjectionJob] = None,
                   value_job2: Optional[ValueProjectionJob] = None, rank_job: Optional["RankJob"] = None,
-                  finalize_job: Optional["FinalizeJob"] = None) -> Tensor:
+                  finalize_job: Optional["FinalizeJob"] = None, hoisted: Optional["HoistedHead"] = None) -> Tensor:
     """The salience head on one level in three launches (include/salience_hip.h (6)).
 
     ``x`` [B,n,256] fp32 (may be one level's slice of ``[B,S,256]``); ``predictor`` a ``MaskPredictor`` with
@@ -555,6 +626,9 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
     that stage 1's launch carries along (bf16x3 kernel only; otherwise it is left pending), ``value_job2`` one for
     stage 2's launch; ``rank_job``: a pending top-k of the next coarser level, ``finalize_job``: the token-space
     pass of the encoder's output -- also for stage 1's launch (the latter only next to no value job).
+    ``hoisted``: the level's rows of ``salience_head_hoist``'s result -- stage 1 then shrinks to the modulation step
+    (``sdetr_salience_head_modulate``: ``x`` is only looked at for its shape, ``enc_output`` / ``memory_out`` have been
+    dealt with by the hoisted launch, a ``value_job`` is left pending).
     Returns ``[B,n]``."""
     if not x.is_cuda:
         raise RuntimeError("salience_head: HIP device tensors required; there is no CPU fallback")
@@ -609,11 +683,26 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps),
             packed_linear_weight(l1.weight, split3=x3).data_ptr(),
             l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
+        if hoisted is not None:
+            if hoisted.g.shape != x.shape or hoisted.g.stride(2) != 1 or hoisted.g.stride(1) != C or hoisted.sigma.stride(1) != 1:
+                raise RuntimeError("salience_head: hoisted rows must be [B,n,256] / [B,n] slices with contiguous rows")
+            value_job = None
         carry_value = x3 and value_job is not None and not value_job.done and value_job.value.device == x.device
         carry_rank = x3 and rank_job is not None and not rank_job.done and rank_job.score.device == x.device
         carry_fin = (x3 and finalize_job is not None and not finalize_job.done and not carry_value
                      and finalize_job.tokens.device == x.device)
-        if carry_value or carry_rank or carry_fin:
+        if hoisted is not None:
+            rk = ctypes.byref(rank_job.struct()) if carry_rank else None
+            fj = ctypes.byref(finalize_job.struct()) if carry_fin else None
+            code = lib.sdetr_salience_head_modulate(
+                s, hoisted.g.data_ptr(), hoisted.g.stride(0), hoisted.sigma.data_ptr(), hoisted.sigma.stride(0), B, n,
+                _hip.ptr(row_scale), _hip.ptr(coarse_score), ch, cw, lh, lw, _hip.ptr(alpha), float(l1n.eps),
+                hoisted.c0.data_ptr(), z_local.data_ptr(), partial.data_ptr(), rk, fj)
+            if carry_rank:
+                rank_job.done = True
+            if carry_fin:
+                finalize_job.done = True
+        elif carry_value or carry_rank or carry_fin:
             vp = value_job.pointers() if carry_value else (None, None, None, None, 0, 0, 0, 0, None, 0, None)
             rk = ctypes.byref(rank_job.struct()) if carry_rank else None
             fj = ctypes.byref(finalize_job.struct()) if carry_fin else None

@@ -18,6 +18,11 @@ from .salience_encoder import SalienceTransformerEncoder, SalienceTransformerEnc
 from .salience_filtering import MaskPredictor, level_filtering, salience_filtering, token_budgets
 
 
+def filter_ops_bf16x3() -> bool:
+    from . import filter_ops
+    return bool(filter_ops.salience_head_bf16x3)
+
+
 def resolve_activation_dtype(dtype: torch.dtype, value_dtype: Optional[torch.dtype] = None):
     """The activation / value-map types a requested mode runs in.
 
@@ -99,6 +104,9 @@ class SalienceEncoderHotPath(nn.Module):
     # layers of the batched value projection per carrier launch, in carrier order: stage 1 / stage 2 of the coarsest level,
     # of the next one, then stage 2 of the third-coarsest (level_filtering); pieces no launch carried run on their own
     value_projection_parts = (2, 1, 2, 1)
+    # with the hoisted head (salience_filtering.HOIST_HEAD): the stage-2 launches of the two coarsest levels (same-box sweep,
+    # benchmarks/hoist_sweep.sh: (3, 3) -26.7 us against the per-level form, (2, 2, 2) -19, (3, 2, 1) -15)
+    value_projection_parts_hoisted = (3, 3)
 
     def forward(self, multi_level_feats: Sequence[Tensor], multi_level_masks: Sequence[Tensor],
                 multi_level_pos_embeds: Sequence[Tensor],
@@ -134,7 +142,10 @@ class SalienceEncoderHotPath(nn.Module):
             # four carriers (stage 1 and stage 2 of the two coarsest levels): two layers with each stage 1 (~20 us
             # of projection under ~20 us of head), one with each stage 2 (~10 under ~17)
             n_layers = len(self.encoder.layers)
-            parts = self.value_projection_parts if n_layers == 6 else min(4, n_layers)
+            from . import salience_filtering as _sf
+            hoisted = _sf.HOIST_HEAD and filter_ops_bf16x3()
+            parts = ((self.value_projection_parts_hoisted if hoisted else self.value_projection_parts) if n_layers == 6
+                     else min(3 if hoisted else 4, n_layers))
             plan = self.encoder.plan_values(feat_enc, mask_flatten, parts=parts,
                                             level_shapes=pyramid.level_shapes_of(multi_level_masks))
             if plan is not None:

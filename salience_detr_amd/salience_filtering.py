@@ -22,8 +22,19 @@ from torch.nn import functional as F
 from . import pyramid
 from .layer_norm_train import add_layer_norm
 from .salience_encoder import split_prefix
+from . import filter_ops
 from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_topk_desc, merge_sorted_desc,
-                         plan_masked_topk, salience_head)
+                         plan_masked_topk, salience_head, salience_head_hoist)
+
+# The fused no-grad path takes both 256 x 256 products of the head's stage 1 out of the coarse-to-fine chain: one launch
+# for all levels' tokens in front of the level loop (filter_ops.salience_head_hoist), per level only the modulation step.
+# False = stage 1 per level (the form up to round 5), kept for same-box comparisons and as the reference of the tests.
+HOIST_HEAD = True
+# Does the hoisted launch carry the first pending value-projection job?
+HOIST_CARRIES_VALUE = False
+# The level whose modulation launch carries the finalize pass (None: the hoisted launch does -- a full chip, where the
+# pass costs what it costs alone)
+FINALIZE_LEVEL = 1
 
 
 class _Modulate(torch.autograd.Function):
@@ -226,12 +237,30 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
         offs = [sum(ks[:i]) for i in range(L)]
         sel_score = torch.empty((B, sum(ks)), dtype=torch.float32, device=dev)
         sel_inds = torch.empty((B, sum(ks)), dtype=torch.int64, device=dev)
+    hoisted = None
+    if fused and HOIST_HEAD and filter_ops.salience_head_bf16x3:
+        pending = [j for j in (value_jobs or ()) if not j.done]
+        hoisted = salience_head_hoist(backbone_output_memory, mask_predictor, enc_output=enc_output,
+                                      enc_output_norm=enc_output_norm, memory_out=memory_out,
+                                      value_job=pending[0] if pending and HOIST_CARRIES_VALUE else None,
+                                      finalize_job=finalize_job if FINALIZE_LEVEL is None else None)
     for lvl in range(L - 1, -1, -1):
         h, w = level_shapes[lvl]
         start = int(level_start_index[lvl])
         level_memory = backbone_output_memory[:, start:start + h * w, :]
         mask = mask_flatten[:, start:start + h * w]
-        if fused:
+        if fused and hoisted is not None:
+            # the level's step of the hoisted head: modulation -> const -> stage 2; every stage-2 launch of the three
+            # coarsest levels carries the next pending value-projection job
+            token_score = salience_head(
+                level_memory, mask_predictor, coarse_score=score, level_hw=(h, w),
+                alpha=alpha[lvl:lvl + 1] if score is not None else None,
+                score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
+                score_min=level_min[lvl:lvl + 1], rank_job=pending_rank,
+                finalize_job=finalize_job if lvl <= (FINALIZE_LEVEL or 0) else None,
+                hoisted=hoisted.level(start, h * w),
+                **_next_value_jobs(None, stage2_only=value_jobs if lvl >= L - 3 and L > 3 and value_jobs else None))
+        elif fused:
             # resize of the coarser score, modulation, both LayerNorms, all five Linear layers: three launches
             token_score = salience_head(
                 level_memory, mask_predictor, coarse_score=score, level_hw=(h, w),
@@ -243,6 +272,7 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 rank_job=pending_rank, finalize_job=finalize_job,
                 **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None,
                                    stage2_only=value_jobs if lvl == L - 3 and L > 3 else None))
+        if fused:
             if pending_rank is not None:
                 pending_rank.run()          # (no-op when stage 1 carried it)
                 pending_rank = None

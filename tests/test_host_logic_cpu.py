@@ -277,3 +277,28 @@ def test_bordered_layout_and_tile_orders_host_logic():
         for r in range(2):
             seq = p16[idx[r][order[r].long()]]
             assert torch.equal(seq, seq.sort()[0]) and torch.equal(order[r].long().sort()[0], torch.arange(idx.shape[1]))
+
+
+def test_cut_tie_canonicalisation_only_touches_ties():
+    """tests/cut_ties.py (used by the full-size GPU digests): a cut neighbourhood that differs from the reference's by an
+    exchange of scores within the tolerance is rewritten in the reference's order; a real difference, a token from outside
+    the window, or a window inside an image's padded tail is left alone."""
+    import cut_ties
+    n, W = 40, 4
+    ref = torch.arange(100, 100 + n).view(1, n).repeat(3, 1)                    # the reference's sorted list, 3 images
+    score = torch.linspace(1.0, 0.0, n).view(1, n).repeat(3, 1).clone()
+    n_k = 20
+    score[:, n_k - 1] = score[:, n_k] + 3e-7                                      # a tie at the cut
+    rec = [(ref[:, n_k - W:n_k + W].numpy(), score[:, n_k - W:n_k + W].numpy(), (n_k - W, n_k))]
+    build = ref.clone()
+    build[0, n_k - 1], build[0, n_k] = ref[0, n_k], ref[0, n_k - 1]              # image 0: the tie changed sides
+    build[1, n_k - 2], build[1, n_k + 1] = ref[1, n_k + 1], ref[1, n_k - 2]      # image 1: a real exchange (scores 0.08 apart)
+    build[2, n_k - 1] = 999                                                       # image 2: a token from elsewhere
+    views = [build, build[:, :n_k]]
+    out, changed = cut_ties.canonical_foreground_inds(views, [n, n, n], rec)
+    assert changed == [(0, 0, [int(ref[0, n_k - 1]), int(ref[0, n_k])])]
+    assert torch.equal(out[0][0], ref[0]) and torch.equal(out[0][1], build[1]) and torch.equal(out[0][2], build[2])
+    assert out[1].data_ptr() == out[0].data_ptr() and out[1].shape == (3, n_k)   # still prefixes of one list
+    # a window that reaches beyond the image's valid count: untouched
+    out2, changed2 = cut_ties.canonical_foreground_inds(views, [n_k + 1, n, n], rec)
+    assert not changed2 and torch.equal(out2[0], build)

@@ -19,6 +19,8 @@ import zlib
 
 import numpy as np
 import pytest
+
+import cut_ties
 import torch
 
 from salience_detr_amd import synthetic as syn
@@ -65,7 +67,14 @@ def _run(gold, dtype, forced):
     cap, sel_log = {}, {}
     enc_forward, neck_forward, nms = tr.encoder.forward, tr.neck.forward_memory, tr.nms_on_topk_index
 
+    records = cut_ties.records_of(gold, "fp32", 6, pattern="{p}.cut{k}")
+
     def enc(*a, **kw):
+        # (ties within 1e-6 at a layer's cut back in the reference's order: tests/cut_ties.py)
+        kw["foreground_inds"], changed = cut_ties.canonical_foreground_inds(
+            kw["foreground_inds"], kw["focus_token_nums"].cpu().tolist(), records)
+        for k, b, moved in changed:
+            print(f"layer {k} image {b}: tokens {moved} tie at the cut: reference order restored")
         cap["foreground_inds"] = kw["foreground_inds"]
         return enc_forward(*a, **kw)
 
