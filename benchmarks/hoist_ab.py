@@ -31,7 +31,10 @@ for pair in range(3):
         if os.environ.get("CARRY_VALUE"):
             SF.HOIST_CARRIES_VALUE = True
         if os.environ.get("FIN_LEVEL"):
-            SF.FINALIZE_LEVEL = None if os.environ["FIN_LEVEL"] == "hoist" else int(os.environ["FIN_LEVEL"])
+            v = os.environ["FIN_LEVEL"]
+            SF.FINALIZE_LEVEL = None if v == "hoist" else (v if v == "merge" else int(v))
+        if os.environ.get("RANK_ON_E0"):
+            SF.RANK_ON_MERGE = False
         if os.environ.get("PARTS"):
             from salience_detr_amd.hot_path import SalienceEncoderHotPath as SalienceHotPath
             SalienceHotPath.value_projection_parts_hoisted = tuple(int(v) for v in os.environ["PARTS"].split(","))

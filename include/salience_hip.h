@@ -518,6 +518,15 @@ typedef struct {
     int batch, spatial_size;
     void *out;                   /* [batch, spatial_size, 256] bf16 */
 } sdetr_finalize_job;
+/* sdetr_masked_topk_sliced_f32 whose merge launch (a few workgroups on an otherwise idle chip) carries a pending rank
+ * job -- the deferred top-k of the next coarser level -- and / or the finalize pass (NULL: none).  *jobs_carried (may be
+ * NULL) = 1 when the launch took them (rows of up to 24 576 keys), else 0 and the caller launches them itself. */
+int sdetr_masked_topk_sliced_with_rank_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                                           int64_t mask_row_stride, const float *fill_value, int batch_size, int n, int k,
+                                           int slices, int64_t index_offset, float *out_score, int64_t *out_index,
+                                           int64_t out_row_stride, void *workspace, size_t workspace_bytes,
+                                           const sdetr_rank_job *rank, const sdetr_finalize_job *finalize,
+                                           int *jobs_carried);
 int sdetr_stage1_x3_with_jobs(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,

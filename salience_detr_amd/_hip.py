@@ -97,6 +97,7 @@ SIGNATURES = {
     "sdetr_masked_topk_desc_with_orders_f32": (_i, [_p, _p, _p, _i64, _i, _p, _p, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz, _p]),
     "sdetr_topk_sliced_workspace_bytes": (_sz, [_i, _i]),
     "sdetr_masked_topk_sliced_f32": (_i, [_p, _p, _p, _i64, _p, _i, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz]),
+    "sdetr_masked_topk_sliced_with_rank_f32": (_i, [_p, _p, _p, _i64, _p, _i, _i, _i, _i, _i64, _p, _p, _i64, _p, _sz, _p, _p, _p]),
     "sdetr_merge_sorted_desc": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sdetr_attention_train_max_rows": (_i, []),
     "sdetr_attention_train_forward_f32": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, ctypes.c_float,

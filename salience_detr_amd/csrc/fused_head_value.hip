@@ -19,6 +19,7 @@
 #include "token_linear_core.h"
 #include "topk_attention_core.h"
 #include "topk_core.h"
+#include "finalize_core.h"
 
 namespace sdetr {
 
@@ -41,36 +42,6 @@ __global__ void __launch_bounds__(768, 1) fused_stage1_value_kernel(Stage1Args s
         const int r = blk - n1 - tl_blocks;
         uint32_t *lds = reinterpret_cast<uint32_t *>(fused_lds);
         topk_rank_body(rk, r % rk_blocks_x, r / rk_blocks_x, lds, lds + kRankTile);
-    }
-}
-
-// out[b, s, :] = tokens[b, s, :] + (pad[b, s] ? 0 : background[s, :]), bf16 rows of 256 -- the token-space pass of the
-// encoder's output (sdetr_encoder_finalize's first launch): it depends on nothing the filtering or the encoder compute,
-// so a filtering launch carries it; the sorted rows are overwritten at the very end as before.
-struct FinalizeJob {
-    const uint4 *tokens;       // [B * S * 32] 16-byte pieces
-    const uint4 *background;   // [S * 32]
-    const uint8_t *pad;        // [B * S] or NULL
-    uint4 *out;
-    int64_t total;             // B * S * 32
-    int S;
-};
-__device__ __forceinline__ void finalize_all_role(const FinalizeJob &j, int role_block, int role_blocks)
-{
-    for (int64_t t = (int64_t)role_block * blockDim.x + threadIdx.x; t < j.total; t += (int64_t)role_blocks * blockDim.x) {
-        const int64_t r = t >> 5;   // b * S + s
-        const int piece = (int)(t & 31);
-        const uint4 a = j.tokens[t];
-        uint4 o = a;
-        if (!(j.pad && j.pad[r])) {
-            // (r < 2^31 is checked where the job is built: a 32-bit modulo instead of a 64-bit one per piece)
-            const uint4 g = j.background[(int64_t)((uint32_t)r % (uint32_t)j.S) * 32 + piece];
-            o = make_uint4(pack_act2(act_lo(a.x) + act_lo(g.x), act_hi(a.x) + act_hi(g.x)),
-                           pack_act2(act_lo(a.y) + act_lo(g.y), act_hi(a.y) + act_hi(g.y)),
-                           pack_act2(act_lo(a.z) + act_lo(g.z), act_hi(a.z) + act_hi(g.z)),
-                           pack_act2(act_lo(a.w) + act_lo(g.w), act_hi(a.w) + act_hi(g.w)));
-        }
-        j.out[t] = o;
     }
 }
 
@@ -218,13 +189,7 @@ static int stage1_launch_with_jobs(sdetr_stream_t stream, Stage1Args &a, int bat
     int n4 = 0;
     if (finalize) {
         if (vp_x) return fail("stage1_x3_with_jobs: the finalize pass rides with launches that carry no value projection");
-        if (finalize->batch <= 0 || finalize->spatial_size <= 0 || !finalize->tokens || !finalize->background || !finalize->out)
-            return fail("stage1_x3_with_jobs: bad finalize job");
-        fj.tokens = (const uint4 *)finalize->tokens; fj.background = (const uint4 *)finalize->background;
-        fj.pad = finalize->padding_mask; fj.out = (uint4 *)finalize->out; fj.S = finalize->spatial_size;
-        fj.total = (int64_t)finalize->batch * finalize->spatial_size * 32;
-        if ((int64_t)finalize->batch * finalize->spatial_size >= ((int64_t)1 << 31))
-            return fail("stage1_x3_with_jobs: finalize job too large for 32-bit token arithmetic");
+        if (int rc = fill_finalize_job(fj, finalize, "stage1_x3_with_jobs")) return rc;
         n4 = 128;   // 65 536 threads in a grid-stride loop over the 16-byte pieces
     }
     if (!vp_x) {
@@ -370,13 +335,7 @@ extern "C" int sdetr_salience_head_modulate(sdetr_stream_t stream, const float *
     FinalizeJob fj{};
     int n4 = 0;
     if (finalize) {
-        if (finalize->batch <= 0 || finalize->spatial_size <= 0 || !finalize->tokens || !finalize->background || !finalize->out)
-            return fail("salience_head_modulate: bad finalize job");
-        fj.tokens = (const uint4 *)finalize->tokens; fj.background = (const uint4 *)finalize->background;
-        fj.pad = finalize->padding_mask; fj.out = (uint4 *)finalize->out; fj.S = finalize->spatial_size;
-        fj.total = (int64_t)finalize->batch * finalize->spatial_size * 32;
-        if ((int64_t)finalize->batch * finalize->spatial_size >= ((int64_t)1 << 31))
-            return fail("salience_head_modulate: finalize job too large for 32-bit token arithmetic");
+        if (int rc = fill_finalize_job(fj, finalize, "salience_head_modulate")) return rc;
         n4 = 512;   // (a short host: the pass's own chain -- pieces per thread -- has to be short as well)
     }
     // (the jobs' bodies need 512 threads: two modulation blocks per workgroup then; alone the step runs in 256)

@@ -642,8 +642,8 @@ constexpr int kModLdsFloats = 32 + 4 * kHalf;   // k per token | the waves' colu
 // Block = 32 tokens (stage 1's blocking: `partial` has the same rows) on 256 threads: wave w takes tokens w, w + 4, ...,
 // lane l channels 4l .. 4l + 3 -- a row of G is one coalesced KB, all eight in flight.  `tid` = the thread's index among
 // the 256 of its block, `lds` their kModLdsFloats: a 512-thread workgroup of a launch that carries jobs runs two blocks
-// (were its upper half to exit, the launch would start twice the waves for the same work, and the finest level's 4176
-// waves are what its 9 us consist of -- measured 20 us).
+// (were its upper half to exit, the launch would start twice the waves for the same work: 20.4 us for the finest level
+// instead of 18.4).
 __device__ __forceinline__ void modulate_body(const ModulateArgs &p, int blk, int b, float *lds, int tid)
 {
     constexpr int TM = 32;
@@ -651,37 +651,55 @@ __device__ __forceinline__ void modulate_body(const ModulateArgs &p, int blk, in
     const int lane = tid & 63, wave = tid >> 6;
     const int t0 = blk * TM;
     const int nvalid = min(TM, p.n - t0);
+    // The k phase's operands are requested FIRST (sigma, the four coarse scores): loads return in order, and behind the
+    // wave's eight rows of G the factor -- hence the barrier, hence every wave's GELUs -- would wait for all of them; the
+    // launch then ran as three chip-wide phases (load 9 us, GELU 5, store 3) instead of one stream.
+    float sg = 0.f, v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f, ly = 0.f, lx = 0.f;
+    const bool modulated = p.row_scale || p.coarse;
+    if (tid < TM) {
+        const int t = min(t0 + tid, p.n - 1);
+        sg = p.sigma[(int64_t)b * p.sigma_batch_stride + t];
+        if (p.row_scale) {
+            v00 = p.row_scale[(int64_t)b * p.n + t];
+        } else if (p.coarse) {
+            // bilinear, align_corners=True (F.interpolate, salience_transformer.py:139-142) -- as in stage1_x3_body
+            const int y = t / p.w, x = t - y * p.w;
+            const float sh = p.h > 1 ? (float)(p.ch - 1) / (float)(p.h - 1) : 0.f;
+            const float sw = p.w > 1 ? (float)(p.cw - 1) / (float)(p.w - 1) : 0.f;
+            const float fy = sh * (float)y, fx = sw * (float)x;
+            const int y1 = (int)fy, x1 = (int)fx;
+            const int yp = y1 < p.ch - 1 ? 1 : 0, xp = x1 < p.cw - 1 ? 1 : 0;
+            ly = fy - (float)y1;
+            lx = fx - (float)x1;
+            const float *cm = p.coarse + (int64_t)b * p.ch * p.cw;
+            v00 = cm[y1 * p.cw + x1]; v01 = cm[y1 * p.cw + x1 + xp];
+            v10 = cm[(y1 + yp) * p.cw + x1]; v11 = cm[(y1 + yp) * p.cw + x1 + xp];
+        }
+    }
     const float *gb = p.g + (int64_t)b * p.g_batch_stride + (int64_t)t0 * kC + 4 * lane;
     float4 gv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) gv[i] = *reinterpret_cast<const float4 *>(gb + (int64_t)min(wave + 4 * i, nvalid - 1) * kC);
     const float4 c0 = *reinterpret_cast<const float4 *>(p.c0 + 4 * lane);
     if (tid < TM) {
-        const int t = min(t0 + tid, p.n - 1);
-        float s = 1.f;
-        if (p.row_scale || p.coarse) {
-            float up;
-            if (p.row_scale) {
-                up = p.row_scale[(int64_t)b * p.n + t];
-            } else {
-                // bilinear, align_corners=True (F.interpolate, salience_transformer.py:139-142) -- as in stage1_x3_body
-                const int y = t / p.w, x = t - y * p.w;
-                const float sh = p.h > 1 ? (float)(p.ch - 1) / (float)(p.h - 1) : 0.f;
-                const float sw = p.w > 1 ? (float)(p.cw - 1) / (float)(p.w - 1) : 0.f;
-                const float fy = sh * (float)y, fx = sw * (float)x;
-                const int y1 = (int)fy, x1 = (int)fx;
-                const int yp = y1 < p.ch - 1 ? 1 : 0, xp = x1 < p.cw - 1 ? 1 : 0;
-                const float ly = fy - (float)y1, lx = fx - (float)x1;
+        // s = 1 + up * alpha as an unevaluated sum s + s_lo (exact product error, TwoSum): where up * alpha comes close to
+        // -1 the rounding of the plain sum (half an ulp of 1) is a RELATIVE error of 1e-5 and more in s, hence in k and in
+        // every channel of the row alike -- the per-level form makes the same rounding per element, where it averages out
+        float s = 1.f, s_lo = 0.f;
+        if (modulated) {
+            float up = v00;
+            if (!p.row_scale) {
                 const float hy = 1.f - ly, hx = 1.f - lx;
-                const float *cm = p.coarse + (int64_t)b * p.ch * p.cw;
-                up = hy * (hx * cm[y1 * p.cw + x1] + lx * cm[y1 * p.cw + x1 + xp]) +
-                     ly * (hx * cm[(y1 + yp) * p.cw + x1] + lx * cm[(y1 + yp) * p.cw + x1 + xp]);
+                up = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
             }
-            s = 1.f + up * (p.alpha ? *p.alpha : 1.f);
+            const float a = p.alpha ? *p.alpha : 1.f;
+            const float pr = up * a, pe = fmaf(up, a, -pr);
+            s = 1.f + pr;
+            const float bb = s - 1.f;
+            s_lo = ((1.f - (s - bb)) + (pr - bb)) + pe;
         }
-        const float sg = p.sigma[(int64_t)b * p.sigma_batch_stride + t];
-        const float ss = s * sg;
-        kk[tid] = ss * rsqrtf(ss * ss + p.eps1);
+        const float ss = fmaf(s_lo, sg, s * sg);
+        kk[tid] = ss * rsqrtf(fmaf(ss, ss, p.eps1));
     }
     __syncthreads();
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);

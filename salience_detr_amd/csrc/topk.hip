@@ -33,6 +33,7 @@
 
 #include "topk_core.h"
 #include "row_orders_core.h"
+#include "finalize_core.h"
 
 namespace sdetr {
 
@@ -569,10 +570,9 @@ __global__ void __launch_bounds__(256) merge_sorted_kernel(MergeArgs p)
 // The same merge with the row's keys staged in LDS first (rows of up to kMergeLdsKeys keys): the binary searches are
 // chains of ~40 dependent reads per element -- from L2 that was the kernel's whole 13 us; from LDS ~2.
 constexpr int kMergeLdsKeys = 24576;   // 96 KB of keys (level 0 of the 800 x 1333 pyramid: 16 800)
-__global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
+__device__ __forceinline__ void merge_sorted_lds_body(const MergeArgs &p, int bx, int by, uint32_t *mkeys)
 {
-    extern __shared__ uint32_t mkeys[];
-    const float *row = p.score + (int64_t)blockIdx.y * p.n;
+    const float *row = p.score + (int64_t)by * p.n;
     // eight loads in flight per thread, then their LDS stores (one load -> wait -> store per iteration was a chain of
     // n / 1024 trips to memory: 16 us at 16 800 keys, most of this kernel)
     for (int i0 = threadIdx.x; i0 < p.n; i0 += 8 * 1024) {
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
             if (i0 + u * 1024 < p.n) mkeys[i0 + u * 1024] = desc_bits(v[u]);
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int i = bx * 1024 + threadIdx.x;
     if (i >= p.n) return;
     const uint32_t key = mkeys[i];
     int seg = 0;
@@ -602,9 +602,37 @@ __global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
         rank += lo - p.seg_start[s];
     }
     if (rank >= p.limit) return;
-    const int64_t o = (int64_t)blockIdx.y * p.out_stride + rank;
-    p.out_index[o] = p.payload[(int64_t)blockIdx.y * p.n + i] + p.index_offset;
+    const int64_t o = (int64_t)by * p.out_stride + rank;
+    p.out_index[o] = p.payload[(int64_t)by * p.n + i] + p.index_offset;
     if (p.out_score) p.out_score[o] = row[i];
+}
+
+__global__ void __launch_bounds__(1024) merge_sorted_lds_kernel(MergeArgs p)
+{
+    extern __shared__ uint32_t mkeys[];
+    merge_sorted_lds_body(p, (int)blockIdx.x, (int)blockIdx.y, mkeys);
+}
+
+// The merge of the sliced top-k (a few workgroups on an otherwise idle chip) carrying a pending rank job -- the deferred
+// top-k of the next coarser level, whose indices nobody needs before the global merge behind this launch (round 6: with
+// the salience head hoisted, the modulation launch that used to carry it is as long as its own traffic, the job 11.6 us)
+// -- and / or the token-space pass of the encoder's output (FinalizeJob: needed at the very end of the encoder).
+// Blocks [0, merge_bx * merge_rows): the merge; then the rank job's workgroups (the first 512 threads); then the pass.
+__global__ void __launch_bounds__(1024) merge_sorted_lds_rank_kernel(MergeArgs p, int merge_bx, int merge_rows, RankArgs rk,
+                                                                     int rk_bx, int rk_blocks, int rk_tile, FinalizeJob fin,
+                                                                     int fin_blocks)
+{
+    extern __shared__ uint32_t mkeys[];
+    const int blk = (int)blockIdx.x, nm = merge_bx * merge_rows;
+    if (blk < nm) {
+        merge_sorted_lds_body(p, blk % merge_bx, blk / merge_bx, mkeys);
+    } else if (blk < nm + rk_blocks) {
+        if (threadIdx.x >= kRankThreads) return;
+        const int r = blk - nm;
+        topk_rank_body(rk, r % rk_bx, r / rk_bx, mkeys, mkeys + rk_tile);
+    } else {
+        finalize_all_role(fin, blk - nm - rk_blocks, fin_blocks);
+    }
 }
 
 }  // namespace sdetr
@@ -821,9 +849,45 @@ static int masked_topk_impl(sdetr_stream_t stream, const float *score, const uin
     return check_launch("topk_rank");
 }
 
-static int launch_merge(hipStream_t stream, const MergeArgs &a, int B)
+static int launch_merge(hipStream_t stream, const MergeArgs &a, int B, const sdetr_rank_job *rank = nullptr,
+                        const sdetr_finalize_job *finalize = nullptr, bool *carried = nullptr)
 {
     const int n = a.n;
+    if (carried) *carried = false;
+    if ((rank || finalize) && n <= kMergeLdsKeys) {
+        RankArgs r{};
+        int rk_bx = 1, rk_blocks = 0, rk_tile = kRankTile;
+        size_t lds = (size_t)n * 4;
+        if (rank) {
+            if (rank->batch <= 0 || rank->n <= 0 || rank->k <= 0 || rank->k > rank->n || !rank->score || !rank->out_index)
+                return fail("merge_sorted: bad rank job");
+            if (rank->n >= (1 << 30) || rank->batch > 65535) return fail("merge_sorted: rank row too long / too many rows");
+            const int64_t ors = rank->out_row_stride ? rank->out_row_stride : rank->k;
+            const int64_t mrs = rank->mask && !rank->mask_row_stride ? rank->n : rank->mask_row_stride;
+            if (ors < rank->k || (rank->mask && mrs < rank->n)) return fail("merge_sorted: rank job strides too small");
+            if (rank->mask && !rank->fill_value) return fail("merge_sorted: a masked rank job needs its fill value");
+            r.score = rank->score; r.mask = rank->mask; r.mask_stride = mrs; r.fill = rank->fill_value; r.N = rank->n;
+            r.k = rank->k; r.index_offset = rank->index_offset; r.out_score = rank->out_score; r.out_index = rank->out_index;
+            r.out_stride = ors;
+            rk_bx = (rank->n + 63) / 64;
+            rk_blocks = rk_bx * rank->batch;
+            rk_tile = rk_bx * 64 < kRankTile ? rk_bx * 64 : kRankTile;
+            if ((size_t)(rk_tile + kRankWaves * 64) * 4 > lds) lds = (size_t)(rk_tile + kRankWaves * 64) * 4;
+        }
+        FinalizeJob fj{};
+        int fin_blocks = 0;
+        if (finalize) {
+            if (int rc = fill_finalize_job(fj, finalize, "merge_sorted")) return rc;
+            fin_blocks = 192;   // x 1024 threads: ~14 pieces per thread
+        }
+        const int mbx = (n + 1023) / 1024;
+        static DeviceOnce lds_once2;
+        allow_dynamic_lds(merge_sorted_lds_rank_kernel, lds_once2, kMergeLdsKeys * 4);
+        hipLaunchKernelGGL(merge_sorted_lds_rank_kernel, dim3((unsigned)(mbx * B + rk_blocks + fin_blocks)), dim3(1024), lds, stream,
+                           a, mbx, B, r, rk_bx, rk_blocks, rk_tile, fj, fin_blocks);
+        if (carried) *carried = true;
+        return check_launch("merge_sorted (+ jobs)");
+    }
     if (n <= kMergeLdsKeys) {
         static DeviceOnce lds_once;
         allow_dynamic_lds(merge_sorted_lds_kernel, lds_once, kMergeLdsKeys * 4);
@@ -864,11 +928,33 @@ extern "C" int sdetr_merge_sorted_desc(sdetr_stream_t stream, const float *score
 // compete with *fill_value exactly as in sdetr_masked_topk_desc_f32 with fill_mode 2.
 extern "C" size_t sdetr_topk_sliced_workspace_bytes(int B, int n) { return B > 0 && n > 0 ? (size_t)B * n * 12 + 16 : 0; }
 
+extern "C" int sdetr_masked_topk_sliced_with_rank_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                                                      int64_t mask_row_stride, const float *fill_value, int B, int n, int k,
+                                                      int slices, int64_t index_offset, float *out_score,
+                                                      int64_t *out_index, int64_t out_row_stride, void *workspace,
+                                                      size_t workspace_bytes, const sdetr_rank_job *rank,
+                                                      const sdetr_finalize_job *finalize, int *jobs_carried);
+
 extern "C" int sdetr_masked_topk_sliced_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
                                             int64_t mask_row_stride, const float *fill_value, int B, int n, int k,
                                             int slices, int64_t index_offset, float *out_score, int64_t *out_index,
                                             int64_t out_row_stride, void *workspace, size_t workspace_bytes)
 {
+    return sdetr_masked_topk_sliced_with_rank_f32(stream, score, mask, mask_row_stride, fill_value, B, n, k, slices,
+                                                  index_offset, out_score, out_index, out_row_stride, workspace,
+                                                  workspace_bytes, nullptr, nullptr, nullptr);
+}
+
+// ... and a pending rank job and / or the finalize pass (NULL: none) in the merge launch; *jobs_carried (may be NULL) = 1
+// when the launch took them (rows of up to 24 576 keys: the LDS form of the merge), else 0 and the caller launches them.
+extern "C" int sdetr_masked_topk_sliced_with_rank_f32(sdetr_stream_t stream, const float *score, const uint8_t *mask,
+                                                      int64_t mask_row_stride, const float *fill_value, int B, int n, int k,
+                                                      int slices, int64_t index_offset, float *out_score,
+                                                      int64_t *out_index, int64_t out_row_stride, void *workspace,
+                                                      size_t workspace_bytes, const sdetr_rank_job *rank,
+                                                      const sdetr_finalize_job *finalize, int *jobs_carried)
+{
+    if (jobs_carried) *jobs_carried = 0;
     if (B < 0 || n < 0 || k < 0) return fail("masked_topk_sliced: negative size");
     if (k > n) return fail("masked_topk_sliced: k (%d) out of range for a row of %d scores", k, n);
     if (slices < 2 || slices > kMaxSegments) return fail("masked_topk_sliced: 2 .. %d slices (got %d)", kMaxSegments, slices);
@@ -898,5 +984,8 @@ extern "C" int sdetr_masked_topk_sliced_f32(sdetr_stream_t stream, const float *
     a.limit = k; a.out_stride = out_row_stride; a.index_offset = index_offset;
     for (int s = 0; s < used; ++s) a.seg_start[s] = s * c;
     a.seg_start[used] = n;
-    return launch_merge(hs, a, B);
+    bool carried = false;
+    const int rc = launch_merge(hs, a, B, rank, finalize, &carried);
+    if (jobs_carried) *jobs_carried = carried ? 1 : 0;
+    return rc;
 }

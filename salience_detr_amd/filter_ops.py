@@ -12,7 +12,8 @@ from . import _hip
 
 def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_with_global_min: bool = False,
                      payload: Optional[Tensor] = None, index_offset: int = 0, want_scores: bool = True,
-                     fill_value: Optional[Tensor] = None, out=None, orders_job: Optional["RowOrdersJob"] = None):
+                     fill_value: Optional[Tensor] = None, out=None, orders_job: Optional["RowOrdersJob"] = None,
+                     carry_rank: Optional["RankJob"] = None, carry_finalize: Optional["FinalizeJob"] = None):
     """Sorted-descending top-k per row with ties -> lower index first.
 
     ``score`` [B,N] fp32.  With ``mask`` (bool [B,N], True = masked) and ``fill_with_global_min`` the
@@ -22,7 +23,9 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
     payload is given (the index gather after the global sort, :156-158), else ``pos + index_offset``.
     ``fill_value`` (one-element fp32 device tensor) supplies ``score.min()`` when the caller already has it;
     ``mask`` may be a column slice of a wider ``[B,S]`` mask.  ``out = (scores, indices)``: column slices
-    ``[B,k]`` of wider buffers to write into (same row stride), instead of fresh tensors.
+    ``[B,k]`` of wider buffers to write into (same row stride), instead of fresh tensors.  ``carry_rank`` /
+    ``carry_finalize``: a pending ``RankJob`` / ``FinalizeJob`` that the call's merge launch takes along when it has one
+    with room (the sliced form); they are marked ``done`` then, and left pending otherwise.
     """
     _hip.require_device("masked_topk_desc", score=score, payload=payload, fill_value=fill_value)
     if score.dtype != torch.float32 or score.dim() != 2:
@@ -39,7 +42,8 @@ def masked_topk_desc(score: Tensor, k: int, mask: Optional[Tensor] = None, fill_
     if (((N > _PREFILTER_MAX_ROW and k * 16 > N) or (N >= _SLICED_MIN_ROW and k * 5 > N)) and payload is None
             and orders_job is None and score.is_contiguous()
             and (mask is None or (fill_with_global_min and fill_value is not None))):
-        return _sorted_slices_topk(score, k, mask, fill_value, int(index_offset), want_scores, out)
+        return _sorted_slices_topk(score, k, mask, fill_value, int(index_offset), want_scores, out, carry_rank,
+                                   carry_finalize)
     mask_stride = 0
     if mask is not None:
         if mask.shape != score.shape or not mask.is_cuda:
@@ -122,7 +126,8 @@ _MERGE_SEGMENTS = 8          # csrc/topk.hip kMaxSegments
 
 
 def _sorted_slices_topk(score: Tensor, k: int, mask: Optional[Tensor], fill_value: Optional[Tensor], index_offset: int,
-                        want_scores: bool, out):
+                        want_scores: bool, out, carry_rank: Optional["RankJob"] = None,
+                        carry_finalize: Optional["FinalizeJob"] = None):
     """Top-k with k a sizeable fraction of a LONG row -- the finest level of a pyramid (salience_transformer.py:146-150):
     6680 of 16 800 scores at 800 x 1333 (rounds 1-5: one histogram-sort workgroup per image, 36 us on two workgroups),
     16 700 of 67 200 on the reference's 5scale pyramid (beyond every single-workgroup form; the chip-wide rank by
@@ -155,12 +160,24 @@ def _sorted_slices_topk(score: Tensor, k: int, mask: Optional[Tensor], fill_valu
     lib = _hip.lib()
     ws_bytes = lib.sdetr_topk_sliced_workspace_bytes(B, N)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=score.device)
+    job = carry_rank if carry_rank is not None and not carry_rank.done and carry_rank.score.device == score.device else None
+    fin = (carry_finalize if carry_finalize is not None and not carry_finalize.done
+           and carry_finalize.tokens.device == score.device else None)
+    if fin is not None:
+        lib = _hip.lib(fin.tokens.dtype)      # (the pass works on 16-bit activations: it picks the library)
+    carried = ctypes.c_int(0)
     with torch.cuda.device(score.device):
-        code = lib.sdetr_masked_topk_sliced_f32(
+        code = lib.sdetr_masked_topk_sliced_with_rank_f32(
             _hip.stream_ptr(), score.data_ptr(), _hip.ptr(mask), mask_stride, _hip.ptr(fill_value) if mask is not None else None,
             B, N, k, _MERGE_SEGMENTS, int(index_offset), _hip.ptr(out_score), out_index.data_ptr(), out_stride,
-            ws.data_ptr(), ws_bytes)
+            ws.data_ptr(), ws_bytes, ctypes.byref(job.struct()) if job is not None else None,
+            ctypes.byref(fin.struct()) if fin is not None else None, ctypes.byref(carried))
     _hip.check(code, "masked_topk_desc (sliced)")
+    if carried.value:
+        if job is not None:
+            job.done = True
+        if fin is not None:
+            fin.done = True
     return out_score, out_index
 
 

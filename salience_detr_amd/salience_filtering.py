@@ -32,9 +32,12 @@ from .filter_ops import (column_mean, fused_layer_norm, masked_fill_min, masked_
 HOIST_HEAD = True
 # Does the hoisted launch carry the first pending value-projection job?
 HOIST_CARRIES_VALUE = False
-# The level whose modulation launch carries the finalize pass (None: the hoisted launch does -- a full chip, where the
-# pass costs what it costs alone)
-FINALIZE_LEVEL = 1
+# Who carries the finalize pass: "merge" = the merge launch of the finest level's sliced top-k (a few workgroups on an
+# idle chip; falls back to that level's modulation launch when the top-k takes another form), a level index = that
+# level's modulation launch, None = the hoisted launch (a full chip, where the pass costs what it costs alone)
+FINALIZE_LEVEL = "merge"
+# The deferred rank of level 1 on the merge launch of the finest level's sliced top-k (else on its modulation launch)
+RANK_ON_MERGE = True
 
 
 class _Modulate(torch.autograd.Function):
@@ -244,6 +247,8 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                                       enc_output_norm=enc_output_norm, memory_out=memory_out,
                                       value_job=pending[0] if pending and HOIST_CARRIES_VALUE else None,
                                       finalize_job=finalize_job if FINALIZE_LEVEL is None else None)
+    # (the modulation launches from this level down may carry the finalize pass: none of them for "merge")
+    fin_level = FINALIZE_LEVEL if isinstance(FINALIZE_LEVEL, int) else (-1 if FINALIZE_LEVEL == "merge" else 0)
     for lvl in range(L - 1, -1, -1):
         h, w = level_shapes[lvl]
         start = int(level_start_index[lvl])
@@ -256,8 +261,11 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 level_memory, mask_predictor, coarse_score=score, level_hw=(h, w),
                 alpha=alpha[lvl:lvl + 1] if score is not None else None,
                 score_flat=None if score_flat is None else score_flat[:, start:start + h * w],
-                score_min=level_min[lvl:lvl + 1], rank_job=pending_rank,
-                finalize_job=finalize_job if lvl <= (FINALIZE_LEVEL or 0) else None,
+                score_min=level_min[lvl:lvl + 1],
+                # (the finest level's modulation launch is as long as its own traffic: the rank of the level before rides on
+                # the merge of this level's sliced top-k instead -- a few workgroups on an idle chip)
+                rank_job=pending_rank if lvl > 0 or not RANK_ON_MERGE else None,
+                finalize_job=finalize_job if lvl <= fin_level else None,
                 hoisted=hoisted.level(start, h * w),
                 **_next_value_jobs(None, stage2_only=value_jobs if lvl >= L - 3 and L > 3 and value_jobs else None))
         elif fused:
@@ -273,8 +281,12 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 **_next_value_jobs(value_jobs if lvl >= L - 2 and L > 2 else None,
                                    stage2_only=value_jobs if lvl == L - 3 and L > 3 else None))
         if fused:
+            late_rank = None
             if pending_rank is not None:
-                pending_rank.run()          # (no-op when stage 1 carried it)
+                if hoisted is not None and lvl == 0 and RANK_ON_MERGE:
+                    late_rank = pending_rank
+                else:
+                    pending_rank.run()          # (no-op when stage 1 carried it)
                 pending_rank = None
             score = token_score.view(B, 1, h, w)
             # the strided mask slice and the minimum stage 2 already took go straight to the kernel.  The level's
@@ -285,7 +297,10 @@ def level_filtering(backbone_output_memory: Tensor, mask_flatten: Tensor, level_
                 pending_rank = plan_masked_topk(token_score, ks[lvl], mask, level_min[lvl:lvl + 1], start, (ls, li))
             else:
                 masked_topk_desc(token_score, ks[lvl], mask=mask, fill_with_global_min=True, index_offset=start,
-                                 fill_value=level_min[lvl:lvl + 1], out=(ls, li))
+                                 fill_value=level_min[lvl:lvl + 1], out=(ls, li), carry_rank=late_rank,
+                                 carry_finalize=finalize_job if hoisted is not None and FINALIZE_LEVEL == "merge" else None)
+            if late_rank is not None:
+                late_rank.run()             # (no-op when the merge carried it)
             salience_score[lvl], level_inds[lvl], level_score[lvl] = score, li, ls
             continue
         mask = mask.contiguous()

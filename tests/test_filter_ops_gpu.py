@@ -915,3 +915,193 @@ def test_salience_head_carrying_the_finalize_pass():
         assert job.done and torch.equal(got_head, want_head)
         got = F.encoder_finalize(tokens, result, idx, count, bg, pad, 400, finalize_job=job)
     assert torch.equal(got, want)
+
+
+def _head_fp64(pred, x, enc, norm, coarse, hw, alpha, row_scale=None):
+    """The head of one level in fp64 (salience_transformer.py:16-47, 139-143; base_transformer.py:104-111)."""
+    B, n, C = x.shape
+    xd = x.double()
+    if enc is not None:
+        xd = torch.nn.functional.layer_norm(torch.nn.functional.linear(xd, enc.weight.double(), enc.bias.double()), (C,),
+                                            norm.weight.double(), norm.bias.double(), norm.eps)
+    if coarse is not None:
+        up = torch.nn.functional.interpolate(coarse.double(), size=hw, mode="bilinear", align_corners=True).view(B, n, 1)
+        xd = xd + xd * up * alpha.double()
+    if row_scale is not None:
+        xd = xd + xd * row_scale.double().unsqueeze(-1) * alpha.double()
+    l1n, l1 = pred.layer1[0], pred.layer1[1]
+    z = torch.nn.functional.gelu(torch.nn.functional.linear(torch.nn.functional.layer_norm(
+        xd, (C,), l1n.weight.double(), l1n.bias.double(), l1n.eps), l1.weight.double(), l1.bias.double()))
+    z = torch.cat([z[..., :128], z[..., 128:].mean(1, keepdim=True).expand(-1, n, -1)], -1)
+    for i, m in enumerate(pred.layer2):
+        z = torch.nn.functional.linear(z, m.weight.double(), m.bias.double()) if i % 2 == 0 else torch.nn.functional.gelu(z)
+    return z.squeeze(-1)
+
+
+def _perturbed_predictor(seed):
+    from salience_detr_amd.salience_filtering import MaskPredictor
+    torch.manual_seed(seed)
+    pred = MaskPredictor(256, 256).to(DEV)
+    with torch.no_grad():   # (the default init has unit LayerNorm weights and zero biases: c0 would be zero)
+        pred.layer1[0].weight.add_((0.2 * syn.det_randn("hh.g", (256,))).to(DEV))
+        pred.layer1[0].bias.add_((0.3 * syn.det_randn("hh.b", (256,))).to(DEV))
+        pred.layer1[1].bias.add_((0.2 * syn.det_randn("hh.lb", (256,))).to(DEV))
+    return pred
+
+
+@pytest.mark.parametrize("hw", [(13, 21), (50, 84), (100, 167)])
+@pytest.mark.parametrize("with_enc", [True, False])
+@pytest.mark.parametrize("mod", ["coarse", "row_scale", "none"])
+def test_hoisted_salience_head_against_the_per_level_form_and_fp64(hw, with_enc, mod):
+    """include/salience_hip.h, sdetr_salience_head_hoist_x3 + sdetr_salience_head_modulate: layer1.Linear(LN(s x)) =
+    k G + c0 with both 256 x 256 products taken before s exists.  The scores are as close to an fp64 evaluation of the
+    reference's expressions as the per-level kernels' are (both ~1e-6 at scores of order 1), the two forms agree to 3e-6,
+    enc_output_norm's output is the same bits, and the hoisted form is bit-reproducible."""
+    h, w = hw
+    n, B, C = h * w, 2, 256
+    pred = _perturbed_predictor(3)
+    enc, norm = (torch.nn.Linear(C, C).to(DEV), torch.nn.LayerNorm(C).to(DEV)) if with_enc else (None, None)
+    x = (syn.det_randn(f"hh.x{n}", (B, n, C)) * 1.3).to(DEV)
+    coarse = syn.det_randn(f"hh.c{n}", (B, 1, (h + 1) // 2, (w + 1) // 2)).to(DEV) if mod == "coarse" else None
+    rs = syn.det_randn(f"hh.r{n}", (B, n)).to(DEV) if mod == "row_scale" else None
+    alpha = torch.tensor([-0.7 if mod == "row_scale" else 0.3], device=DEV)   # (row_scale * alpha reaches s < 0)
+    kw = dict(enc_output=enc, enc_output_norm=norm) if with_enc else {}
+    km = dict(coarse_score=coarse, level_hw=hw, alpha=alpha) if coarse is not None else (
+        dict(row_scale=rs, alpha=alpha) if rs is not None else {})
+    with torch.no_grad():
+        mo_a = torch.zeros_like(x) if with_enc else None
+        mo_b = torch.zeros_like(x) if with_enc else None
+        direct = F.salience_head(x, pred, memory_out=mo_a, **kw, **km)
+        hh = F.salience_head_hoist(x, pred, memory_out=mo_b, **kw)
+        hoisted = F.salience_head(x, pred, hoisted=hh.level(0, n), **km)
+        ref = _head_fp64(pred, x, enc, norm, coarse, hw, alpha, rs)
+        for _ in range(5):
+            hh2 = F.salience_head_hoist(x, pred, **kw)
+            assert torch.equal(hh2.g, hh.g) and torch.equal(hh2.sigma, hh.sigma)
+            assert torch.equal(F.salience_head(x, pred, hoisted=hh2.level(0, n), **km), hoisted)
+    scale = ref.abs().max().item() + 1.0
+    e_direct, e_hoisted = (direct.double() - ref).abs().max().item(), (hoisted.double() - ref).abs().max().item()
+    assert e_hoisted <= 2e-6 * scale, (e_hoisted, scale)
+    assert e_hoisted <= 2.0 * e_direct + 2e-7 * scale, (e_hoisted, e_direct)
+    assert (direct - hoisted).abs().max().item() <= 3e-6 * scale
+    if with_enc:
+        assert torch.equal(mo_a, mo_b)
+
+
+def test_hoisted_salience_head_on_constant_rows_and_zero_scale():
+    """Rows without variance (sigma = 0: G = 0, z = GELU(c0)) and a modulation factor s = 0 (k = 0) are the limits of the
+    factorisation; the per-level form normalises such a row to beta, i.e. to the same c0."""
+    B, n, C = 2, 96, 256
+    pred = _perturbed_predictor(5)
+    x = (syn.det_randn("hz.x", (B, n, C)) * 0.8).to(DEV)
+    x[0, 5] = 0.37
+    x[1, 64:70] = -2.0
+    rs = syn.det_randn("hz.r", (B, n)).to(DEV)
+    rs[0, 9] = -2.0                                  # s = 1 + (-2) * 0.5 = 0
+    alpha = torch.tensor([0.5], device=DEV)
+    with torch.no_grad():
+        hh = F.salience_head_hoist(x, pred)
+        assert hh.sigma[0, 5].item() == 0.0 and (hh.sigma[1, 64:70] == 0).all() and (hh.g[0, 5] == 0).all()
+        assert torch.isfinite(hh.g).all() and torch.isfinite(hh.sigma).all()
+        direct = F.salience_head(x, pred, row_scale=rs, alpha=alpha)
+        hoisted = F.salience_head(x, pred, row_scale=rs, alpha=alpha, hoisted=hh)
+    assert torch.isfinite(hoisted).all()
+    assert (direct - hoisted).abs().max().item() <= 3e-6 * (direct.abs().max().item() + 1.0)
+
+
+@pytest.mark.parametrize("fin_level", [None, 1, "merge"])
+def test_level_filtering_with_the_hoisted_head_carries_the_same_jobs(fin_level):
+    """salience_filtering.level_filtering, HOIST_HEAD: scores within 3e-6 of the per-level form on a four-level pyramid,
+    the same top-k sets except where the per-level scores themselves tie within 1e-5 at a level's cut, and the jobs its
+    launches carry (value projection on the stage-2 launches, the finalize pass on the hoisted or a modulation launch, the
+    deferred ranks) give the bits of their stand-alone launches."""
+    from salience_detr_amd import salience_filtering as SF
+    B, C, heads, groups = 2, 256, 8, 6
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7)]
+    starts = [0]
+    for hh_, ww_ in shapes[:-1]:
+        starts.append(starts[-1] + hh_ * ww_)
+    S = sum(a * b for a, b in shapes)
+    pred = _perturbed_predictor(9)
+    enc, norm = torch.nn.Linear(C, C).to(DEV), torch.nn.LayerNorm(C).to(DEV)
+    alpha = torch.tensor([0.3, 0.2, -0.4, 0.1], device=DEV)
+    x = (syn.det_randn("lf.x", (B, S, C)) * 1.1).to(DEV)
+    mask = (syn.det_rand("lf.m", (B, S)) > 0.93).to(DEV)
+    tokens = syn.det_randn("lf.t", (B, S, C)).to(DEV).to(torch.bfloat16)
+    wv = (syn.det_randn("lf.w", (groups * heads * 32, C)) * 0.05).to(DEV).to(torch.bfloat16)
+    background = syn.det_randn("lf.bg", (S, C)).to(DEV).to(torch.bfloat16)
+    ks = [int(0.4 * shapes[0][0] * shapes[0][1]), int(0.8 * shapes[1][0] * shapes[1][1]), shapes[2][0] * shapes[2][1],
+          shapes[3][0] * shapes[3][1]]
+
+    def run(hoist):
+        maps, jobs = F.plan_value_projection(tokens, wv, None, mask, heads, groups, torch.float16,
+                                             parts=(3, 3) if hoist else (2, 1, 2, 1))
+        fin = F.FinalizeJob(tokens, background, mask)
+        mem = torch.zeros_like(x)
+        flat = torch.zeros(B, S, device=DEV)
+        extras = {}
+        old = SF.HOIST_HEAD, SF.FINALIZE_LEVEL
+        SF.HOIST_HEAD, SF.FINALIZE_LEVEL = hoist, fin_level
+        try:
+            with torch.no_grad():
+                sc, inds, lsc = SF.level_filtering(x, mask, shapes, starts, ks, pred, alpha, enc_output=enc, enc_output_norm=norm,
+                                                   memory_out=mem, score_flat=flat, extras=extras, value_jobs=jobs,
+                                                   finalize_job=fin)
+                for j in jobs:
+                    j.run()
+                fin.run()
+        finally:
+            SF.HOIST_HEAD, SF.FINALIZE_LEVEL = old
+        return flat, inds, mem, maps, fin.out, extras
+
+    flat0, inds0, mem0, maps0, fin0, ex0 = run(False)
+    flat1, inds1, mem1, maps1, fin1, ex1 = run(True)
+    assert (flat0 - flat1).abs().max().item() <= 3e-6 * (flat0.abs().max().item() + 1.0)
+    assert torch.equal(mem0, mem1) and torch.equal(maps0, maps1) and torch.equal(fin0, fin1)
+    with torch.no_grad():
+        want_maps = F.value_proj_head_major(tokens, wv, None, mask, heads, groups, torch.float16)
+    assert torch.equal(maps1, want_maps)
+    assert (ex0["level_min"] - ex1["level_min"]).abs().max().item() <= 3e-6
+    for l in range(4):
+        for b in range(B):
+            a, c = set(inds0[l][b].tolist()), set(inds1[l][b].tolist())
+            for t in a ^ c:   # only scores that tie at the level's cut may change sides
+                lvl_scores = torch.where(mask[b, starts[l]:starts[l] + shapes[l][0] * shapes[l][1]], ex0["level_min"][l],
+                                         flat0[b, starts[l]:starts[l] + shapes[l][0] * shapes[l][1]])
+                cut = torch.sort(lvl_scores, descending=True)[0][ks[l] - 1].item()
+                s_t = ex0["level_min"][l].item() if mask[b, t] else flat0[b, t].item()
+                assert abs(s_t - cut) <= 1e-5, (l, b, t)
+
+
+def test_sliced_topk_merge_carries_a_rank_job_and_the_finalize_pass():
+    """csrc/topk.hip, merge_sorted_lds_rank_kernel: the merge launch of the finest level's sliced top-k takes a pending
+    rank job (the deferred top-k of the level before) and the token-space pass of the encoder's output along -- the bits
+    of the three launches on their own."""
+    torch.manual_seed(21)
+    B, N, k, S, C = 2, 16700, 6680, 3000, 256
+    score = syn.det_randn("mj.s", (B, N)).to(DEV)
+    score[1, 500:560] = score[1, 3]
+    mask = torch.zeros(B, N, dtype=torch.bool, device=DEV)
+    mask[:, 16000:] = True
+    fill = score.min().reshape(1)
+    s1 = syn.det_randn("mj.s1", (B, 4200)).to(DEV)
+    m1 = torch.zeros(B, 4200, dtype=torch.bool, device=DEV)
+    m1[0, 4100:] = True
+    f1 = s1.min().reshape(1)
+    tokens = syn.det_randn("mj.t", (B, S, C)).to(DEV).to(torch.bfloat16)
+    background = syn.det_randn("mj.bg", (S, C)).to(DEV).to(torch.bfloat16)
+    pad = (syn.det_rand("mj.p", (B, S)) > 0.8).to(DEV)
+    want = F.masked_topk_desc(score, k, mask=mask, fill_with_global_min=True, index_offset=7, fill_value=fill)
+    want1 = F.masked_topk_desc(s1, 3360, mask=m1, fill_with_global_min=True, index_offset=16800, fill_value=f1)
+    want_fin = tokens + torch.where(pad[..., None], torch.zeros_like(background[None]), background[None])
+    out1 = (torch.full((B, 3400), -1.0, device=DEV), torch.full((B, 3400), -1, dtype=torch.int64, device=DEV))
+    job = F.plan_masked_topk(s1, 3360, m1, f1, 16800, (out1[0][:, 5:3365], out1[1][:, 5:3365]))
+    fin = F.FinalizeJob(tokens, background, pad)
+    assert job is not None
+    got = F.masked_topk_desc(score, k, mask=mask, fill_with_global_min=True, index_offset=7, fill_value=fill,
+                             carry_rank=job, carry_finalize=fin)
+    assert job.done and fin.done
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert torch.equal(out1[0][:, 5:3365], want1[0]) and torch.equal(out1[1][:, 5:3365], want1[1])
+    assert (out1[1][:, :5] == -1).all() and (out1[1][:, 3365:] == -1).all()
+    assert torch.equal(fin.out, want_fin)
