@@ -35,6 +35,9 @@ for pair in range(3):
             SF.FINALIZE_LEVEL = None if v == "hoist" else (v if v == "merge" else int(v))
         if os.environ.get("RANK_ON_E0"):
             SF.RANK_ON_MERGE = False
+        if os.environ.get("CONST_LAUNCH"):
+            from salience_detr_amd import filter_ops as FO
+            FO.CONST_IN_BLOCK = False
         if os.environ.get("PARTS"):
             from salience_detr_amd.hot_path import SalienceEncoderHotPath as SalienceHotPath
             SalienceHotPath.value_projection_parts_hoisted = tuple(int(v) for v in os.environ["PARTS"].split(","))

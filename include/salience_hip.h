@@ -563,7 +563,12 @@ int sdetr_salience_head_modulate(sdetr_stream_t stream, const float *g, int64_t 
                                  int64_t sigma_batch_stride, int batch_size, int tokens, const float *row_scale,
                                  const float *coarse_score, int coarse_h, int coarse_w, int level_h, int level_w,
                                  const float *alpha, float norm_eps, const float *c0, float *z_local, float *partial_sums,
-                                 const sdetr_rank_job *rank, const sdetr_finalize_job *finalize);
+                                 const sdetr_rank_job *rank, const sdetr_finalize_job *finalize, float *score_min_init);
+/* score_min_init (may be NULL): device scalar set to +inf -- what sdetr_salience_head_const does for stage 2's running
+ * minimum, for a stage 2 that takes the per-image constant in its own blocks (const_in_block != 0 of
+ * sdetr_salience_head_stage2, partial_sums != NULL of sdetr_stage2_with_value_proj: every block sums the level's
+ * partial sums -- up to 160 rows of them, i.e. 5120 tokens; worth it up to ~40 -- and takes the 128 x 128 product itself;
+ * the const launch, 4.6-4.9 us on an idle chip per coarse level, does not exist then). */
 int sdetr_stage1_x3_with_value_proj(
     sdetr_stream_t stream, const float *x, int64_t x_batch_stride, int64_t x_row_stride, int batch_size, int tokens,
     int channels, const void *enc_weight_x3, const float *enc_bias, const float *enc_norm_weight,
@@ -585,7 +590,8 @@ int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *z_local, in
                                  const void *vp_packed_weight, const float *vp_bias_padded, const uint8_t *vp_pad_mask,
                                  int vp_batch_size, int vp_spatial_size, int vp_num_heads, int vp_num_groups,
                                  void *vp_dst, int vp_dst_dtype, const sdetr_bordered_layout *vp_bordered,
-                                 const void *weight2_local_x3);
+                                 const void *weight2_local_x3,
+                                 const float *partial_sums, const float *weight2, const float *bias2);
 /* `weight2_local_x3` (both stage-2 entry points; round 6): sdetr_pack_linear_bf16x3 of W2[:, :128] or NULL.  Given, the
  * first product of stage 2 runs on the bf16 matrix cores at fp32 accuracy like stage 1's (exact three-way split, six
  * products) and `weight2_local_packed` is not read: without its f32 MFMAs the launch is a third as long. */
@@ -594,7 +600,8 @@ int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_local, cons
                                const float *weight2_local_packed, const float *weight3_packed, const float *bias3,
                                const float *weight4, const float *bias4, float *const_workspace, float *score,
                                float *score_flat, int64_t score_flat_stride, float *score_min,
-                               const void *weight2_local_x3);
+                               const void *weight2_local_x3,
+                               int const_in_block);
 
 /* ---- (7) the encoder layer's feed-forward block, fused ----------------------------------------------------------
  * out = LayerNorm(x + W2 relu(W1 x + b1) + b2)   (models/bricks/salience_transformer.py:347-351 forward_ffn with the

@@ -147,19 +147,19 @@ SIGNATURES = {
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p]),
     "sdetr_salience_head_const": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "sdetr_stage2_with_value_proj": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p,
-                                          _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
+                                          _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
     "sdetr_stage1_x3_with_value_proj": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
                                              _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "sdetr_salience_head_hoist_x3": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p,
                                           _i64, _p, _i64, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "sdetr_salience_head_modulate": (_i, [_p, _p, _i64, _p, _i64, _i, _i, _p, _p, _i, _i, _i, _i, _p, ctypes.c_float, _p, _p, _p,
-                                          _p, _p]),
+                                          _p, _p, _p]),
     "sdetr_stage1_x3_with_jobs": (_i, [_p, _p, _i64, _i64, _i, _i, _i, _p, _p, _p, _p, ctypes.c_float, _p, _p, _i, _i,
                                         _i, _i, _p, _p, _p, ctypes.c_float, _p, _p, _p, _i64, _p, _p,
                                              _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p]),
     "sdetr_pack_linear_bf16x3": (_i, [_p, _p, _i64, _i, _i, _p]),
-    "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "sdetr_salience_head_stage2": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i]),
     "sdetr_ffn_packed_bytes": (_i64, [_i]),
     "sdetr_ffn_pack_bf16": (_i, [_p, _p, _p, _i, _i, _p]),
     "sdetr_ffn_auto_splits": (_i, [_i, _i]),

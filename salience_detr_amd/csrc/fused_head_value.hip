@@ -298,7 +298,7 @@ extern "C" int sdetr_salience_head_modulate(sdetr_stream_t stream, const float *
                                             const float *coarse_score, int coarse_h, int coarse_w, int level_h, int level_w,
                                             const float *alpha, float norm_eps, const float *c0, float *z_local,
                                             float *partial_sums, const sdetr_rank_job *rank,
-                                            const sdetr_finalize_job *finalize)
+                                            const sdetr_finalize_job *finalize, float *score_min_init)
 {
     if (batch_size <= 0 || tokens <= 0) return fail("salience_head_modulate: empty level");
     if (!g || !sigma || !c0 || !z_local || !partial_sums) return fail("salience_head_modulate: NULL pointer");
@@ -310,7 +310,7 @@ extern "C" int sdetr_salience_head_modulate(sdetr_stream_t stream, const float *
     m.g = g; m.g_batch_stride = g_batch_stride; m.sigma = sigma; m.sigma_batch_stride = sigma_batch_stride;
     m.row_scale = row_scale; m.coarse = coarse_score; m.ch = coarse_h; m.cw = coarse_w; m.h = level_h; m.w = level_w;
     m.alpha = alpha; m.eps1 = norm_eps; m.c0 = c0; m.z_local = z_local; m.partial = partial_sums; m.n = tokens;
-    m.nblk = (tokens + 31) / 32;
+    m.nblk = (tokens + 31) / 32; m.score_min_init = score_min_init;
     const int n1 = m.nblk * batch_size;
     RankArgs r{};
     int rk_bx = 1, n3 = 0, rk_tile = kRankTile;
@@ -376,12 +376,16 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
                                             const void *vp_packed_weight, const float *vp_bias_padded,
                                             const uint8_t *vp_pad_mask, int vp_batch_size, int vp_spatial_size,
                                             int vp_num_heads, int vp_num_groups, void *vp_dst, int vp_dst_dtype,
-                                            const sdetr_bordered_layout *vp_bordered, const void *weight2_local_x3)
+                                            const sdetr_bordered_layout *vp_bordered, const void *weight2_local_x3,
+                                            const float *partial_sums, const float *weight2, const float *bias2)
 {
     if (batch_size <= 0 || tokens <= 0) return fail("stage2_with_value_proj: empty level");
     if (!z_local || (!weight2_local_packed && !weight2_local_x3) || !weight3_packed || !bias3 || !weight4 || !bias4 ||
-        !const_workspace || !score)
+        (!const_workspace && !partial_sums) || !score)
         return fail("stage2_with_value_proj: NULL pointer");
+    if (partial_sums && (!weight2 || !bias2)) return fail("stage2_with_value_proj: the constant in the block needs layer2[0]");
+    if (partial_sums && (tokens + 31) / 32 > kConstInBlockRows)
+        return fail("stage2_with_value_proj: the constant in the block takes up to %d rows of partial sums", kConstInBlockRows);
     TLArgs t;
     size_t lds_tl = 0;
     int n2 = 0;
@@ -395,6 +399,9 @@ extern "C" int sdetr_stage2_with_value_proj(sdetr_stream_t stream, const float *
     a.w3 = reinterpret_cast<const float4 *>(weight3_packed);
     a.b3 = bias3; a.w4 = weight4; a.b4 = bias4; a.score = score; a.score2 = score_flat;
     a.score2_stride = score_flat_stride; a.n = tokens; a.score_min = score_min;
+    if (partial_sums) {
+        a.partial = partial_sums; a.partial_rows = (tokens + 31) / 32; a.w2 = weight2; a.b2 = bias2;
+    }
     const int nblk = (tokens + kTM - 1) / kTM;
     const size_t lds_s2 = (size_t)kStage2LdsFloats * sizeof(float);
     const size_t lds = lds_tl > lds_s2 ? lds_tl : lds_s2;

@@ -450,21 +450,29 @@ extern "C" int sdetr_salience_head_stage2(sdetr_stream_t stream, const float *z_
                                           const float *weight2_local_packed, const float *weight3_packed,
                                           const float *bias3, const float *weight4, const float *bias4,
                                           float *const_workspace, float *score, float *score_flat,
-                                          int64_t score_flat_stride, float *score_min, const void *weight2_local_x3)
+                                          int64_t score_flat_stride, float *score_min, const void *weight2_local_x3,
+                                          int const_in_block)
 {
     if (batch_size < 0 || tokens < 0) return fail("salience_head_stage2: negative size");
     if (batch_size == 0 || tokens == 0) return 0;
     if (!z_local || !partial_sums || !weight2 || !bias2 || (!weight2_local_packed && !weight2_local_x3) || !weight3_packed ||
-        !bias3 || !weight4 || !bias4 || !const_workspace || !score)
+        !bias3 || !weight4 || !bias4 || (!const_workspace && !const_in_block) || !score)
         return fail("salience_head_stage2: NULL pointer");
     const int nblk = (tokens + kTM - 1) / kTM;
+    const int prow = sdetr_salience_head_blocks(batch_size, tokens);
+    if (const_in_block && prow > kConstInBlockRows)
+        return fail("salience_head_stage2: the constant in the block takes up to %d rows of partial sums (got %d)", kConstInBlockRows, prow);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(salience_head_const_kernel, dim3((unsigned)batch_size), dim3(kHalf * kConstGroups), 0, s,
-                       partial_sums, sdetr_salience_head_blocks(batch_size, tokens), tokens, weight2, bias2,
-                       const_workspace, score_min);
-    int rc = check_launch("salience_head_const");
-    if (rc) return rc;
     Stage2Args a;
+    if (const_in_block) {
+        // (the caller's stage 1 / modulation launch has set *score_min to +inf)
+        a.partial = partial_sums; a.partial_rows = prow; a.w2 = weight2; a.b2 = bias2;
+    } else {
+        hipLaunchKernelGGL(salience_head_const_kernel, dim3((unsigned)batch_size), dim3(kHalf * kConstGroups), 0, s,
+                           partial_sums, prow, tokens, weight2, bias2, const_workspace, score_min);
+        int rc = check_launch("salience_head_const");
+        if (rc) return rc;
+    }
     a.z_local = z_local; a.cst = const_workspace;
     a.w2a = reinterpret_cast<const float4 *>(weight2_local_packed);
     a.w2a_x3 = weight2_local_x3;

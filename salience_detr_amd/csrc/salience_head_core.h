@@ -634,6 +634,8 @@ struct ModulateArgs {
     float *z_local;            // [B, n, 128]
     float *partial;            // [B, nblk, 128]
     int n, nblk;
+    float *score_min_init;     // optional device scalar set to +inf (what the const launch does for stage 2's minimum, when
+                               // stage 2 takes the constant in its own blocks and that launch does not exist)
 };
 
 constexpr int kModThreads = 256;
@@ -651,6 +653,7 @@ __device__ __forceinline__ void modulate_body(const ModulateArgs &p, int blk, in
     const int lane = tid & 63, wave = tid >> 6;
     const int t0 = blk * TM;
     const int nvalid = min(TM, p.n - t0);
+    if (p.score_min_init && blk == 0 && b == 0 && tid == 0) *p.score_min_init = INFINITY;
     // The k phase's operands are requested FIRST (sigma, the four coarse scores): loads return in order, and behind the
     // wave's eight rows of G the factor -- hence the barrier, hence every wave's GELUs -- would wait for all of them; the
     // launch then ran as three chip-wide phases (load 9 us, GELU 5, store 3) instead of one stream.
@@ -738,7 +741,50 @@ struct Stage2Args {
     float *score_min;       // optional device scalar: min over every score of the launch (initialised by const kernel)
     int64_t score2_stride;
     int n;
+    // The per-image constant IN the block (partial != NULL; round 6, levels of up to kConstInBlockRows rows of partial
+    // sums): every block sums the level's partial sums and takes the 128 x 128 product itself -- the same numbers in every
+    // block (one fixed order), and the const launch (4.6-4.9 us on the coarse levels, the chip idle) disappears.
+    const float *partial = nullptr;   // [B, partial_rows, 128]
+    int partial_rows = 0;
+    const float *w2 = nullptr, *b2 = nullptr;   // layer2[0] weight [128, 256] / bias [128]
 };
+
+constexpr int kConstInBlockRows = 160;
+
+// const[j] = b2[j] + sum_c W2[j][128 + c] * mean_c, mean_c = (sum over the rows of partial) / n, by the block's 256 threads
+// in `scratch` (512 floats); the result is scratch[384 + j] (a barrier has been passed).
+__device__ __forceinline__ void stage2_const_in_block(const float *partial, int rows, int n, const float *w2, const float *b2,
+                                                      float *scratch, int tid)
+{
+    const int j = tid & (kHalf - 1), g = tid >> 7;   // two groups take the rows in turns, eight in flight each
+    const float *pp = partial + j;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int i = g; i < rows; i += 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + 2 * u < rows ? pp[(int64_t)(i + 2 * u) * kHalf] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+    scratch[g * kHalf + j] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (tid < kHalf) scratch[2 * kHalf + tid] = (scratch[tid] + scratch[kHalf + tid]) / (float)n;
+    __syncthreads();
+    const int j2 = tid >> 1, q = tid & 1;   // two threads per output row, 64 columns each
+    const float *wr = w2 + (int64_t)j2 * kC + kHalf + q * 64;
+    const float *mean = scratch + 2 * kHalf + q * 64;
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+        const float4 wv = *reinterpret_cast<const float4 *>(wr + c);
+        a += (wv.x * mean[c] + wv.y * mean[c + 1]) + (wv.z * mean[c + 2] + wv.w * mean[c + 3]);
+    }
+    a += __shfl_xor(a, 1);
+    if (q == 0) scratch[3 * kHalf + j2] = b2[j2] + a;
+    __syncthreads();
+}
 
 constexpr int kStage2TileFloats = kS2Planes / 4 > kTM * kZS ? kS2Planes / 4 : kTM * kZS;   // the planes of the x3 form | the fp32 tile
 constexpr int kStage2LdsFloats = kStage2TileFloats + 2 * kTM;   // zt | red
@@ -764,9 +810,9 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
     WeightStreamX3G<kHalf / 32, 4> ws3;
     if (x3) ws3.start(p.w2a_x3, kHalf / 16, wave, lane);
     else ws.start(p.w2a, kHalf, kHalf / 8, wave * 32, lane);
-    const float cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
     const int rt2 = wave >> 1, ct2 = wave & 1;
     const float bias3 = p.b3[ct2 * 32 + (lane & 31)], wo = p.w4[ct2 * 32 + (lane & 31)], b4 = p.b4[0];
+    float cb;
     {
         const float *zb = p.z_local + ((int64_t)b * p.n + t0) * kHalf;
         float4 v[kTM * (kHalf / 4) / kBlock];
@@ -775,6 +821,14 @@ __device__ __forceinline__ void stage2_body(const Stage2Args &p, int blk, int b,
             const int idx = tid + i * kBlock;
             const int r = idx >> 5, c4 = idx & 31;
             v[i] = *reinterpret_cast<const float4 *>(zb + (int64_t)min(r, nvalid - 1) * kHalf + c4 * 4);
+        }
+        if (p.partial) {
+            // (the tile's rows are on their way; the tile's LDS is the scratch until they are stored)
+            stage2_const_in_block(p.partial + (int64_t)b * p.partial_rows * kHalf, p.partial_rows, p.n, p.w2, p.b2, zt, tid);
+            cb = zt[3 * kHalf + wave * 32 + (lane & 31)];
+            __syncthreads();
+        } else {
+            cb = p.cst[(int64_t)b * kHalf + wave * 32 + (lane & 31)];
         }
 #pragma unroll
         for (int i = 0; i < kTM * (kHalf / 4) / kBlock; ++i) {

@@ -440,6 +440,12 @@ def column_mean(x: Tensor) -> Tensor:
 # Stage 1 of the salience head on the bf16 matrix cores at fp32 accuracy (three-way exact split of both operands,
 # six MFMAs per product; csrc/salience_head.hip).  False = the fp32-input MFMA kernel.
 salience_head_bf16x3 = True
+# With the hoisted head, stage 2 of a small level takes its per-image constant in its own blocks (no const launch); False =
+# the const launch everywhere.  Up to 40 rows of partial sums (1280 tokens): same-box timelines of the 800 x 1333 step,
+# per level modulation + const + stage 2 -- 273 tokens 48.4 -> 44.7 us, 1050 tokens 47.9 -> 44.2, 4200 tokens (132 rows, a
+# chain of nine trips to memory in every block) 25.7 -> 27.8: that level keeps the launch.  (The kernel takes up to 160.)
+CONST_IN_BLOCK = True
+CONST_IN_BLOCK_ROWS = 40
 
 
 def packed_linear_weight(weight: Tensor, cols=None, split3: bool = False) -> Tensor:
@@ -700,6 +706,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             l1n.weight.data_ptr(), l1n.bias.data_ptr(), float(l1n.eps),
             packed_linear_weight(l1.weight, split3=x3).data_ptr(),
             l1.bias.data_ptr(), _hip.ptr(memory_out), mbs, z_local.data_ptr(), partial.data_ptr())
+        # a coarse level of the hoisted head takes stage 2's per-image constant in stage 2's own blocks (no const launch)
+        const_in_block = hoisted is not None and x3 and CONST_IN_BLOCK and nblk <= CONST_IN_BLOCK_ROWS
         if hoisted is not None:
             if hoisted.g.shape != x.shape or hoisted.g.stride(2) != 1 or hoisted.g.stride(1) != C or hoisted.sigma.stride(1) != 1:
                 raise RuntimeError("salience_head: hoisted rows must be [B,n,256] / [B,n] slices with contiguous rows")
@@ -714,7 +722,8 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
             code = lib.sdetr_salience_head_modulate(
                 s, hoisted.g.data_ptr(), hoisted.g.stride(0), hoisted.sigma.data_ptr(), hoisted.sigma.stride(0), B, n,
                 _hip.ptr(row_scale), _hip.ptr(coarse_score), ch, cw, lh, lw, _hip.ptr(alpha), float(l1n.eps),
-                hoisted.c0.data_ptr(), z_local.data_ptr(), partial.data_ptr(), rk, fj)
+                hoisted.c0.data_ptr(), z_local.data_ptr(), partial.data_ptr(), rk, fj,
+                _hip.ptr(score_min) if const_in_block else None)
             if carry_rank:
                 rank_job.done = True
             if carry_fin:
@@ -739,19 +748,21 @@ def salience_head(x: Tensor, predictor, row_scale: Optional[Tensor] = None, coar
         w2_x3 = packed_linear_weight(l2a.weight, cols=(0, half), split3=True).data_ptr() if x3 else None
         w3 = packed_linear_weight(l2b.weight).data_ptr()
         if value_job2 is not None and not value_job2.done and value_job2.value.device == x.device:
-            code = lib.sdetr_salience_head_const(s, partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
-                                                 cst.data_ptr(), _hip.ptr(score_min))
-            _hip.check(code, "salience_head_const")
+            if not const_in_block:
+                code = lib.sdetr_salience_head_const(s, partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
+                                                     cst.data_ptr(), _hip.ptr(score_min))
+                _hip.check(code, "salience_head_const")
             code = lib.sdetr_stage2_with_value_proj(
                 s, z_local.data_ptr(), B, n, w2_local, w3, l2b.bias.data_ptr(), l2c.weight.data_ptr(),
                 l2c.bias.data_ptr(), cst.data_ptr(), score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min),
-                *value_job2.pointers(), w2_x3)
+                *value_job2.pointers(), w2_x3, partial.data_ptr() if const_in_block else None,
+                l2a.weight.data_ptr() if const_in_block else None, l2a.bias.data_ptr() if const_in_block else None)
             value_job2.done = True
         else:
             code = lib.sdetr_salience_head_stage2(
                 s, z_local.data_ptr(), partial.data_ptr(), B, n, l2a.weight.data_ptr(), l2a.bias.data_ptr(),
                 w2_local, w3, l2b.bias.data_ptr(), l2c.weight.data_ptr(), l2c.bias.data_ptr(), cst.data_ptr(),
-                score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min), w2_x3)
+                score.data_ptr(), _hip.ptr(score_flat), sfs, _hip.ptr(score_min), w2_x3, 1 if const_in_block else 0)
         _hip.check(code, "salience_head_stage2")
     return score
 

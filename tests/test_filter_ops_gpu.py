@@ -1105,3 +1105,41 @@ def test_sliced_topk_merge_carries_a_rank_job_and_the_finalize_pass():
     assert torch.equal(out1[0][:, 5:3365], want1[0]) and torch.equal(out1[1][:, 5:3365], want1[1])
     assert (out1[1][:, :5] == -1).all() and (out1[1][:, 3365:] == -1).all()
     assert torch.equal(fin.out, want_fin)
+
+
+@pytest.mark.parametrize("n,hw", [(273, (13, 21)), (1050, (25, 42)), (4200, (50, 84))])
+def test_stage2_with_the_constant_in_its_blocks(n, hw):
+    """csrc/salience_head_core.h, stage2_const_in_block: stage 2 of a hoisted level sums the partial sums and takes the
+    128 x 128 product in every block instead of reading the const launch's result -- the same scores to fp32 round-off
+    (another, equally fixed, order of additions), the same minimum bookkeeping, bit-reproducible, with and without a
+    value-projection job in the launch."""
+    B, C = 2, 256
+    pred = _perturbed_predictor(13)
+    x = (syn.det_randn(f"cb.x{n}", (B, n, C)) * 1.2).to(DEV)
+    coarse = syn.det_randn(f"cb.c{n}", (B, 1, (hw[0] + 1) // 2, (hw[1] + 1) // 2)).to(DEV)
+    alpha = torch.tensor([0.25], device=DEV)
+    tokens = syn.det_randn("cb.tok", (B, 900, C)).to(DEV).to(torch.bfloat16)
+    w = (syn.det_randn("cb.w", (2 * 8 * 32, C)) * 0.05).to(DEV).to(torch.bfloat16)
+    old = F.CONST_IN_BLOCK, F.CONST_IN_BLOCK_ROWS
+    try:
+        with torch.no_grad():
+            hh = F.salience_head_hoist(x, pred)
+            kw = dict(coarse_score=coarse, level_hw=hw, alpha=alpha, hoisted=hh)
+            F.CONST_IN_BLOCK = False
+            min_a = torch.zeros(1, device=DEV)
+            want = F.salience_head(x, pred, score_min=min_a, **kw)
+            F.CONST_IN_BLOCK, F.CONST_IN_BLOCK_ROWS = True, 160
+            for with_value in (False, True):
+                min_b = torch.full((1,), -7.0, device=DEV)
+                vjob = None
+                if with_value:
+                    maps, (vjob,) = F.plan_value_projection(tokens, w, None, None, 8, 2, torch.float16, parts=1)
+                got = F.salience_head(x, pred, score_min=min_b, value_job2=vjob, **kw)
+                assert (got - want).abs().max().item() <= 2e-6 * (want.abs().max().item() + 1.0)
+                assert min_b.item() == got.min().item() and abs(min_b.item() - min_a.item()) <= 2e-6 * (abs(min_a.item()) + 1.0)
+                for _ in range(3):
+                    assert torch.equal(F.salience_head(x, pred, **kw), got)
+                if with_value:
+                    assert vjob.done and torch.equal(maps, F.value_proj_head_major(tokens, w, None, None, 8, 2, torch.float16))
+    finally:
+        F.CONST_IN_BLOCK, F.CONST_IN_BLOCK_ROWS = old
