@@ -925,7 +925,8 @@ int sdetr_attn_tail_ffn_advance_bf16(
  * (fp32 accumulators, no logits in memory).  packed_tail_ffn then ends with sdetr_class_head_packed_bytes() bytes of
  * sdetr_class_head_pack_bf16(class head weight [num_classes <= 96, 256] bf16); class_bias_padded fp32 [96] (-inf on the
  * padded classes); foreground fp32 rows of at least next_rows, images foreground_batch_stride apart.  With more hidden
- * pieces the score is NOT written (the caller launches the class head). */
+ * pieces the second pass (partial sums + LayerNorm + row bookkeeping) computes the same score from the rows it has just
+ * finished (ffn_reduce_ln_advance_cls_kernel: 32 rows per block through an LDS tile, one 32-class tile per wave). */
 int64_t sdetr_class_head_packed_bytes(void);
 int sdetr_class_head_pack_bf16(sdetr_stream_t stream, const void *weight, int num_classes, int embed_dim, void *packed);
 

@@ -730,6 +730,138 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float 
     if (feeds_next) *reinterpret_cast<uint2 *>(a.next_query + ((int64_t)b * a.next_rows + i) * kFE + 4 * lane) = y;
 }
 
+// ... and with the NEXT layer's class score of the rows handed on (the NEXT form's epilogue, for a split hidden dimension:
+// the four hidden-split layers of the encoder used to launch the class head on its own, 6.2-6.6 us each on a chip that
+// waits for it).  32 rows per 512-thread block: every wave finishes four rows exactly as the kernel above (same sums in
+// the same order: identical rows), the handed-on rows also go to an LDS tile [32][256] (rows 528 bytes apart: the B-operand
+// reads of a 16-lane group hit 64 distinct banks); then waves 0..2 take one 32-class tile each -- logits^T [32 x 32] =
+// Wc[tile] q^T + bc, sixteen MFMAs on one accumulator in k order (the chain of the NEXT form) from the class head's
+// packed fragments (class_head_pack_kernel; requested first, they arrive under the row sums) -- and the maximum over the
+// three tiles times the foreground score is the row's score.
+constexpr int kRcRows = 32, kRcThreads = 512, kRcRowBytes = 528;
+
+__global__ void __launch_bounds__(kRcThreads) ffn_reduce_ln_advance_cls_kernel(
+    const float *partial, int nsplit, int T, const bf16_t *x, const float *b2, const float *gamma, const float *beta,
+    float eps, FfnAdvance a, const char *cls_pw, const float *cls_bias, const float *fg, int64_t fg_bs, float *cmax)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ytile[kRcRows * kRcRowBytes];
+    __shared__ float red[3][kRcRows];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tok0 = blockIdx.x * kRcRows;
+    uint4 af[16];
+    if (wave < 3) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[ks] = reinterpret_cast<const uint4 *>(cls_pw)[(3 * ks + wave) * 64 + lane];
+    }
+    constexpr int RW = kRcRows / (kRcThreads / 64);   // rows per wave: 4
+    float4 v[RW];
+    int bb[RW], ii[RW];
+    bool live[RW], feeds[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        const int tok = tok0 + wave * RW + k;
+        const bool valid = tok < T;
+        const int tk = valid ? tok : T - 1;
+        bb[k] = tk / a.rows;
+        ii[k] = tk - bb[k] * a.rows;
+        live[k] = valid && (!a.count || ii[k] < a.count[bb[k]]);
+        feeds[k] = valid && a.next_query && ii[k] < a.next_rows;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // the never-updated original tokens of the rows that are handed on without being part of the focus set
+    uint2 orig[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        orig[k] = make_uint2(0u, 0u);
+        if (!live[k] && feeds[k])
+            orig[k] = *reinterpret_cast<const uint2 *>(
+                a.tokens + ((int64_t)bb[k] * a.spatial_size + a.sorted_index[(int64_t)bb[k] * a.index_batch_stride + ii[k]]) * kFE +
+                4 * lane);
+    }
+    if (x) {   // (NULL: piece 0 of the partial products already carries bias + residual -- the TAIL form)
+        const float4 bv = *reinterpret_cast<const float4 *>(b2 + 4 * lane);
+#pragma unroll
+        for (int k = 0; k < RW; ++k)
+            if (live[k]) {
+                const uint2 r = *reinterpret_cast<const uint2 *>(x + (int64_t)(tok0 + wave * RW + k) * kFE + 4 * lane);
+                v[k] = make_float4(bv.x + act_lo(r.x), bv.y + act_hi(r.x), bv.z + act_lo(r.y), bv.w + act_hi(r.y));
+            }
+    }
+    // two pieces of every row in flight (eight 16-byte loads per lane and trip)
+    for (int s = 0; s < nsplit; s += 2) {
+        float4 p0[RW], p1[RW];
+        const bool two = s + 1 < nsplit;
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const int64_t o = (int64_t)(tok0 + wave * RW + k) * kFE + 4 * lane;
+            p0[k] = p1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live[k]) {
+                p0[k] = *reinterpret_cast<const float4 *>(partial + (int64_t)s * T * kFE + o);
+                if (two) p1[k] = *reinterpret_cast<const float4 *>(partial + (int64_t)(s + 1) * T * kFE + o);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            v[k].x += p0[k].x; v[k].y += p0[k].y; v[k].z += p0[k].z; v[k].w += p0[k].w;
+            if (two) { v[k].x += p1[k].x; v[k].y += p1[k].y; v[k].z += p1[k].z; v[k].w += p1[k].w; }
+        }
+    }
+    // (the second half of the fragments takes the registers the pieces have left: 128 registers, two blocks per CU)
+    if (wave < 3) {
+#pragma unroll
+        for (int ks = 8; ks < 16; ++ks) af[ks] = reinterpret_cast<const uint4 *>(cls_pw)[(3 * ks + wave) * 64 + lane];
+    }
+    const float4 gv = *reinterpret_cast<const float4 *>(gamma + 4 * lane);
+    const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * lane);
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        uint2 y = orig[k];
+        if (live[k]) {
+            float sum = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+            const float mean = sum * (1.f / kFE);
+            const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+            float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) sq += __shfl_xor(sq, m);
+            const float rstd = rsqrtf(sq * (1.f / kFE) + eps);
+            y = make_uint2(pack_act2(d0 * rstd * gv.x + be.x, d1 * rstd * gv.y + be.y),
+                           pack_act2(d2 * rstd * gv.z + be.z, d3 * rstd * gv.w + be.w));
+            *reinterpret_cast<uint2 *>(a.sorted_result + ((int64_t)bb[k] * a.sorted_rows + ii[k]) * kFE + 4 * lane) = y;
+        }
+        if (feeds[k]) *reinterpret_cast<uint2 *>(a.next_query + ((int64_t)bb[k] * a.next_rows + ii[k]) * kFE + 4 * lane) = y;
+        // (a column of the class product depends on its own row only: what rows that are not handed on leave here is unused)
+        *reinterpret_cast<uint2 *>(ytile + (wave * RW + k) * kRcRowBytes + 8 * lane) = y;
+    }
+    __syncthreads();
+    const int t = lane & 31, h = lane >> 5;
+    if (wave < 3) {
+        f32x16_t acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4 *>(cls_bias + 32 * wave + 8 * g + 4 * h);
+            acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+        }
+        const unsigned char *qrow = ytile + t * kRcRowBytes + 16 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc = mfma_bf16(af[ks], *reinterpret_cast<const uint4 *>(qrow + 32 * ks), acc);
+        float mx = acc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (h == 0) red[wave][t] = mx;
+    }
+    __syncthreads();
+    if (tid < kRcRows) {
+        const int tok = tok0 + tid;
+        if (tok < T) {
+            const int b = tok / a.rows, i = tok - b * a.rows;
+            if (i < a.next_rows) cmax[(int64_t)b * a.next_rows + i] = fmaxf(fmaxf(red[0][tid], red[1][tid]), red[2][tid]) * fg[(int64_t)b * fg_bs + i];
+        }
+    }
+}
+
 // hidden index inside a 16-wide k-block that MFMA operand slot (h, s) stands for: the accumulator rows a lane of
 // half h holds in registers 0..7 (kb = 0) / 8..15 (kb = 1)
 __device__ __forceinline__ int acc_hidden(int h, int s) { return s < 4 ? 4 * h + s : 8 + 4 * h + (s - 4); }
@@ -976,6 +1108,16 @@ static int ffn_advance_impl(sdetr_stream_t stream, const void *x, const TailArgs
                                   batch_size, rows, sorted_rows, next_rows, spatial_size, kFE * 2);
     }
     // (TAIL: piece 0 of the partial products carries b2 + x, the pass only sums)
+    if (with_tail && tail.next_score && next_rows > 0) {
+        // ... and the next layer's class score of the rows handed on: the class head's fragments close the packed buffer
+        if (!tail.cls_bias || !tail.fg || tail.fg_bs < next_rows) return fail("attn_tail_ffn_advance: bad class-score operands");
+        const char *cls_pw = static_cast<const char *>(packed_weights) + (int64_t)(kTailChunks + hidden / kFChunk) * kFChunkBytes;
+        hipLaunchKernelGGL(ffn_reduce_ln_advance_cls_kernel, dim3((unsigned)((tokens_total + kRcRows - 1) / kRcRows)),
+                           dim3(kRcThreads), 0, s, (const float *)workspace, hidden_splits, tokens_total,
+                           (const bf16_t *)nullptr, bias2, norm_weight, norm_bias, norm_eps, adv, cls_pw, tail.cls_bias, tail.fg,
+                           tail.fg_bs, tail.next_score);
+        return check_launch("attn_tail_ffn_advance_score");
+    }
     hipLaunchKernelGGL(ffn_reduce_ln_advance_kernel, dim3((unsigned)((tokens_total + 3) / 4)), dim3(256), 0, s,
                        (const float *)workspace, hidden_splits, tokens_total, with_tail ? nullptr : (const bf16_t *)x, bias2,
                        norm_weight, norm_bias, norm_eps, adv);

@@ -1017,6 +1017,11 @@ def _tail_ffn_operands(x: Tensor, output_proj, norm1, linear1, linear2, norm2, c
     return cache[1], cache[2]
 
 
+# The second pass of a split hidden dimension computes the next layer's class score (csrc/ffn.hip,
+# ffn_reduce_ln_advance_cls_kernel); False = the caller launches the class head (the form up to round 6, for A/B runs).
+SPLIT_PASS_CLASS_SCORE = True
+
+
 def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1, linear1, linear2, norm2,
                           sorted_result: Tensor, next_rows: int, tokens: Tensor, sorted_index: Tensor,
                           count: Optional[Tensor] = None, hidden_splits: Optional[int] = None, next_class_head=None,
@@ -1028,8 +1033,8 @@ def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1,
 
     ``next_class_head`` + ``foreground`` ([B, >= next_rows] fp32): returns ``(next_query, score)`` where ``score``
     [B, next_rows] is the NEXT layer's selection score ``class_head_max_times(next_query, next_class_head, foreground)`` --
-    computed in the same launch's epilogue when the feed-forward runs in one hidden piece (``next_class_score_applies``),
-    else ``None`` (the caller launches the class head)."""
+    computed in the feed-forward launch's epilogue (one hidden piece) or by the second pass of a split hidden dimension;
+    ``None`` when the class head does not fit the kernels (the caller launches it)."""
     _hip.require_device("attn_tail_ffn_advance", sampled=sampled, residual=residual, sorted_result=sorted_result, tokens=tokens,
                         count=count, foreground=foreground)
     if sampled.dim() != 3 or sampled.shape != residual.shape or sampled.shape[2] != 256 or not sampled.is_contiguous() \
@@ -1047,7 +1052,7 @@ def attn_tail_ffn_advance(sampled: Tensor, residual: Tensor, output_proj, norm1,
     with torch.cuda.device(residual.device):
         splits = int(hidden_splits) if hidden_splits else lib.sdetr_ffn_auto_splits(B * rows, F)
     want_score = next_class_head is not None
-    with_score = (want_score and splits == 1 and next_rows > 0 and foreground is not None
+    with_score = (want_score and (splits == 1 or SPLIT_PASS_CLASS_SCORE) and next_rows > 0 and foreground is not None
                   and next_class_head.weight.dtype == residual.dtype and next_class_head.weight.shape[0] <= 96
                   and next_class_head.weight.shape[1] == 256 and next_class_head.bias is not None)
     if with_score and (foreground.dtype != torch.float32 or foreground.dim() != 2 or foreground.shape[0] != B

@@ -781,8 +781,8 @@ def test_attn_tail_ffn_advance_equals_the_two_launches(rows, next_rows, splits, 
 
 @pytest.mark.parametrize("rows,next_rows,hidden", [(700, 300, 512), (1111, 900, 2048), (640, 640, 512), (1300, 1, 512)])
 def test_layer_end_hands_on_the_next_layers_class_score(rows, next_rows, hidden):
-    """One hidden piece: the layer-end launch also does the row bookkeeping in its epilogue and returns the NEXT layer's
-    selection score of the rows it hands on (salience_transformer.py:462, 366) -- against the separate launches:
+    """The layer-end launch (one hidden piece: its epilogue; more: the second pass) also does the row bookkeeping and returns
+    the NEXT layer's selection score of the rows it hands on (salience_transformer.py:462, 366) -- against the separate launches:
     identical rows, score = class_head_max_times(next rows) up to fp32 accumulation order."""
     B, S, n0, C = 2, 3000, 2400, 256
     torch.manual_seed(rows)
@@ -813,11 +813,24 @@ def test_layer_end_hands_on_the_next_layers_class_score(rows, next_rows, hidden)
         assert (score - ref).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1)
         if want_score is not None:
             assert (score - want_score).abs().max().item() <= 2e-4 * (ref.abs().max().item() + 1)
-        # more hidden pieces: rows as before, no score from this launch
-        res_c = torch.full((B, n0, C), -3.0, dtype=torch.bfloat16, device=DEV)
-        nxt3, none = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_c, next_rows, tokens, idx, count,
-                                             hidden_splits=3, next_class_head=head, foreground=fg_long)
-        assert none is None and nxt3.shape == got_next.shape
+        # more hidden pieces: the second pass (partial sums + LayerNorm + bookkeeping) hands the score on -- the rows are
+        # those of the same split without the class head, bit for bit
+        for splits in (2, 3, 5):
+            res_c = torch.full((B, n0, C), -3.0, dtype=torch.bfloat16, device=DEV)
+            res_d = res_c.clone()
+            want3 = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_c, next_rows, tokens, idx, count,
+                                            hidden_splits=splits)
+            nxt3, score3 = F.attn_tail_ffn_advance(sampled, query, wo, n1, l1, l2, n2, res_d, next_rows, tokens, idx, count,
+                                                   hidden_splits=splits, next_class_head=head, foreground=fg_long)
+            assert score3 is not None and score3.shape == (B, next_rows)
+            assert torch.equal(res_c, res_d) and torch.equal(want3, nxt3)
+            logits3 = torch.nn.functional.linear(nxt3.float(), head.weight.float(), head.bias.float())
+            ref3 = logits3.max(-1)[0] * fg_long[:, :next_rows]
+            assert (score3 - ref3).abs().max().item() <= 2e-4 * (ref3.abs().max().item() + 1)
+            if B * next_rows >= 32:
+                assert torch.equal(score3, F.class_head_max_times(nxt3, head, fg_long[:, :next_rows])) or \
+                    (score3 - F.class_head_max_times(nxt3, head, fg_long[:, :next_rows])).abs().max().item() <= \
+                    2e-4 * (ref3.abs().max().item() + 1)
 
 
 @pytest.mark.parametrize("n,hw,mode", [(273, (13, 21), "enc"), (1050, (25, 42), "enc+coarse")])
