@@ -946,11 +946,28 @@ int sdetr_topk_attention_with_projection_bf16(
     const void *in_proj_bias, const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
     const void *norm_bias, float norm_eps, void *workspace, int64_t workspace_bytes, const void *proj_weight,
     const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride,
-    const void *out_proj_frag, const void *proj_frag);
+    const void *out_proj_frag, const void *proj_frag, int in_projection_done);
+/* in_projection_done != 0: `workspace` and `hint` were filled by sdetr_topk_select_inproj_bf16 (below) for this
+ * `selected`; the in-projection launch is skipped. */
 /* `out_proj_frag` / `proj_frag` (optional, round 6): out_proj_weight / proj_weight once more in the fragment order of the
  * attention workgroups' 16x16x32 products -- element [h][c][j][lane][e] = weight[R h + 16 c + (lane & 15)][32 j + 8 (lane >> 4) + e]
  * with R = 32, c < 2 (out_proj) or R = 48, c < 3 (projection), j < 8, lane < 64, e < 8: a wave's fragment is then one
  * contiguous KB.  NULL: the row-major weights are read as before. */
+/* The encoder layer's top-k selection of its rows by class score (models/bricks/salience_transformer.py:366:
+ * torch.topk(mc_score, topk_sa, dim=1)[1]; ties: lower position first) TOGETHER with the in-projection of the selected
+ * rows (the first launch of sdetr_topk_attention_*: gather + position add + nn.MultiheadAttention's in_proj) in ONE launch
+ * (csrc/topk.hip, topk_hsort_inproj_kernel): every workgroup of an image runs the same one-workgroup histogram sort,
+ * keeps the list in LDS and its sixteen waves take one 32-row x 32-feature in-projection tile each.
+ *   score fp32 [batch, n] contiguous (no mask); out_index int64 [batch, k] (the positions, descending score);
+ *   query / pos [batch, >= n, 256] 16-bit activations, images *_batch_stride elements apart; workspace of
+ *   sdetr_topk_attention_workspace_bytes(batch, k) bytes and hint as sdetr_topk_attention_with_projection_bf16 takes
+ *   them (call it with in_projection_done = 1 next); hint may be NULL.
+ *   Shapes: 1024 <= n <= 17 408, 5 k <= 2 n, k <= 384.  job (may be NULL): as sdetr_masked_topk_desc_with_orders_f32. */
+int sdetr_topk_select_inproj_bf16(sdetr_stream_t stream, const float *score, int batch_size, int n, int k,
+                                  int64_t *out_index, const void *query, int64_t query_batch_stride, const void *pos,
+                                  int64_t pos_batch_stride, const void *in_proj_weight, const void *in_proj_bias,
+                                  void *workspace, int64_t workspace_bytes, int32_t *hint, int64_t hint_batch_stride,
+                                  const sdetr_row_orders_job *job);
 /* (internal: the in-projection launch of sdetr_topk_attention_bf16 for csrc/fused_head_value.hip) */
 int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in_args);
 

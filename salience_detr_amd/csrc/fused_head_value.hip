@@ -425,7 +425,7 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     const void *in_proj_bias, const void *out_proj_weight, const void *out_proj_bias, const void *norm_weight,
     const void *norm_bias, float norm_eps, void *workspace, int64_t workspace_bytes, const void *proj_weight,
     const void *proj_packed, const float *proj_bias_padded, void *slab, int32_t *hint, int64_t hint_batch_stride,
-    const void *out_proj_frag, const void *proj_frag)
+    const void *out_proj_frag, const void *proj_frag, int in_projection_done)
 {
     if (batch_size <= 0 || num_rows <= 0 || num_selected <= 0 || num_selected > num_rows)
         return fail("topk_attention_with_projection: bad sizes (rows %d, selected %d)", num_rows, num_selected);
@@ -448,7 +448,9 @@ extern "C" int sdetr_topk_attention_with_projection_bf16(
     a.sel = selected; a.w = (const bf16_t *)in_proj_weight; a.bias = (const bf16_t *)in_proj_bias;
     a.qk = (bf16_t *)workspace; a.vt = a.qk + (int64_t)batch_size * npad * 512;
     a.B = batch_size; a.N = num_selected; a.Npad = npad; a.hint = hint; a.hint_bs = hint_batch_stride;
-    if (int rc = sdetr_topk_inproj_launch(stream, &a)) return rc;
+    // (in_projection_done: sdetr_topk_select_inproj_bf16 has filled `workspace` and `hint` in the selection's launch)
+    if (!in_projection_done)
+        if (int rc = sdetr_topk_inproj_launch(stream, &a)) return rc;
     TkOutArgs o{};
     o.qk = a.qk; o.vt = a.vt; o.sel = selected; o.query = (bf16_t *)query; o.q_bs = query_batch_stride;
     o.wo = (const bf16_t *)out_proj_weight; o.bo = (const bf16_t *)out_proj_bias;

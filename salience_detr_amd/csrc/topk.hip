@@ -34,6 +34,7 @@
 #include "topk_core.h"
 #include "row_orders_core.h"
 #include "finalize_core.h"
+#include "topk_attention_core.h"
 
 namespace sdetr {
 
@@ -255,8 +256,11 @@ struct SelectArgs {
     int64_t out_stride;
 };
 
+// `sel_lds` (optional, k entries of static LDS): the output indices once more, for a consumer inside the same workgroup
+// (topk_hsort_inproj_kernel); complete behind the body's last barrier + one more.
 template <int KPT>
-__device__ __forceinline__ void topk_hsort_body(const SelectArgs &p, const int b, uint32_t *hs_lds)
+__device__ __forceinline__ void topk_hsort_body(const SelectArgs &p, const int b, uint32_t *hs_lds, int32_t *sel_lds = nullptr,
+                                                const bool to_memory = true)
 {
     // [off: kHsBins + 1 (+3 pad)][cur: kHsBins][list keys: N][list positions (u16): N]
     uint32_t *off = hs_lds;
@@ -292,8 +296,10 @@ __device__ __forceinline__ void topk_hsort_body(const SelectArgs &p, const int b
     if (tid == 0) { misc[0] = 0u; misc[1] = 0u; }
     auto real = [&](int c) { return c * kHsThreads + tid < p.N; };
     auto emit = [&](uint32_t rank, uint32_t key, int pos) {
-        if (p.out_score) p.out_score[(int64_t)b * p.out_stride + rank] = undesc_bits(key);
-        p.out_index[(int64_t)b * p.out_stride + rank] = p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
+        if (p.out_score && to_memory) p.out_score[(int64_t)b * p.out_stride + rank] = undesc_bits(key);
+        const int64_t index = p.payload ? p.payload[(int64_t)b * p.N + pos] : (int64_t)pos + p.index_offset;
+        if (to_memory) p.out_index[(int64_t)b * p.out_stride + rank] = index;
+        if (sel_lds) sel_lds[rank] = (int32_t)index;
     };
     // Ranks of a group of EQUAL keys `tie` (every thread finds its members in its registers): base + number of members at
     // earlier positions, emitted when < limit.  Uniform control flow (barriers inside).
@@ -662,6 +668,40 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_orders_kernel(SelectArg
     }
 }
 
+// The top-300 selection of an encoder layer TOGETHER with the in-projection of the selected rows (topk_attention.hip,
+// launch 1 of the layer's self-attention): the selection is one workgroup's dependent chain (~7 us on an empty chip) and
+// the in-projection behind it was a launch of 8.3-9.1 us that starts with two dependent trips to memory (the selection,
+// then the rows it names).  Here every one of the image's `wgs` workgroups runs the SAME selection (deterministic: the same
+// list in each; the first writes it out) and keeps it in LDS, then its first kHsTileWaves waves take one tile each of the
+// image's (Npad / 32) x 24 in-projection tiles: no launch boundary, no trip for the selection, the rows' loads start the
+// moment the last rank is known.  (Four tile waves per workgroup, as in the stand-alone launch: the operand loads are
+// row-strided -- 32 cache lines per instruction -- and sixteen waves of them on one CU took 12 us in its address unit.)
+// Workgroups >= nsel carry the row-order jobs as in topk_hsort_orders_kernel.
+constexpr int kHsTileWaves = 4;
+
+template <int KPT>
+__global__ void __launch_bounds__(kHsThreads) topk_hsort_inproj_kernel(SelectArgs p, TkInArgs q, int wgs, int nsel, RowOrderArgs o)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_dyn[];
+    __shared__ int32_t sel_lds[kTkMaxSel];
+    const int blk = (int)blockIdx.x;
+    if (blk >= nsel) {
+        const int j = blk - nsel;   // (part, image, layer)
+        layer_row_orders_body(o, (j / o.parts) % o.batch, j / (o.parts * o.batch), j % o.parts, reinterpret_cast<uint16_t *>(hs_dyn));
+        return;
+    }
+    const int b = blk / wgs, part = blk - b * wgs;
+    topk_hsort_body<KPT>(p, b, hs_dyn, sel_lds, part == 0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= kHsTileWaves) return;
+    const int idx = part * kHsTileWaves + wave;      // the wave's tile among the image's (Npad / 32) x 24
+    const int tile = idx / 24, ftile = idx - tile * 24;
+    if (tile >= q.Npad / 32) return;
+    const int i = tile * 32 + (lane & 31);
+    inproj_wave_body<4>(q, b, tile, ftile, lane, (int64_t)sel_lds[min(i, q.N - 1)]);
+}
+
 static bool use_select(int n, int k)
 {
     // the shapes that used to take prefilter + rank (k well below n) and fit one workgroup: histogram sort in ONE launch
@@ -988,4 +1028,69 @@ extern "C" int sdetr_masked_topk_sliced_with_rank_f32(sdetr_stream_t stream, con
     const int rc = launch_merge(hs, a, B, rank, finalize, &carried);
     if (jobs_carried) *jobs_carried = carried ? 1 : 0;
     return rc;
+}
+
+// The layer's top-k selection (no mask, positions as indices) and the in-projection of the selected rows in ONE launch
+// (topk_hsort_inproj_kernel); sdetr_topk_attention_with_projection_bf16(..., in_projection_done = 1) follows.  Rows the
+// one-workgroup histogram sort covers only (1024 <= n <= 17 408, 5 k <= 2 n) with k <= 384; `job` as in
+// sdetr_masked_topk_desc_with_orders_f32 (carried by the launch when its slots fit, launched behind it otherwise).
+extern "C" int sdetr_topk_select_inproj_bf16(sdetr_stream_t stream, const float *score, int batch_size, int n, int k,
+                                             int64_t *out_index, const void *query, int64_t query_batch_stride,
+                                             const void *pos, int64_t pos_batch_stride, const void *in_proj_weight,
+                                             const void *in_proj_bias, void *workspace, int64_t workspace_bytes,
+                                             int32_t *hint, int64_t hint_batch_stride, const sdetr_row_orders_job *job)
+{
+    if (batch_size <= 0 || n <= 0 || k <= 0 || k > n) return fail("topk_select_inproj: bad sizes (n %d, k %d)", n, k);
+    if (!use_select(n, k) || k > kTkMaxSel)
+        return fail("topk_select_inproj: rows of 1024..%d scores with 5 k <= 2 n and k <= %d (got n %d, k %d)", kHsMaxN, kTkMaxSel, n, k);
+    if (!score || !out_index || !query || !pos || !in_proj_weight || !in_proj_bias || !workspace)
+        return fail("topk_select_inproj: null pointer");
+    const int npad = (k + 31) / 32 * 32;
+    if (workspace_bytes < (int64_t)batch_size * npad * (512 + 256) * 2) return fail("topk_select_inproj: workspace too small");
+    if (query_batch_stride < (int64_t)n * kTkE || pos_batch_stride < (int64_t)n * kTkE || (query_batch_stride & 7) || (pos_batch_stride & 7))
+        return fail("topk_select_inproj: bad batch strides");
+    if (hint && hint_batch_stride < n) return fail("topk_select_inproj: hint rows shorter than the layer");
+    SelectArgs a{};
+    a.score = score; a.N = n; a.k = k; a.out_index = out_index; a.out_stride = k;
+    TkInArgs q{};
+    q.query = (const bf16_t *)query; q.q_bs = query_batch_stride; q.pos = (const bf16_t *)pos; q.p_bs = pos_batch_stride;
+    q.sel = out_index; q.w = (const bf16_t *)in_proj_weight; q.bias = (const bf16_t *)in_proj_bias;
+    q.qk = (bf16_t *)workspace; q.vt = q.qk + (int64_t)batch_size * npad * 512;
+    q.B = batch_size; q.N = k; q.Npad = npad; q.hint = hint; q.hint_bs = hint_batch_stride;
+    const int wgs = ((npad / 32) * 24 + kHsTileWaves - 1) / kHsTileWaves;
+    const int chunk = (n + kHsThreads - 1) / kHsThreads;
+    size_t dyn = ((size_t)(2 * kHsBins + 4) + (size_t)n) * 4 + (((size_t)n * 2 + 15) & ~(size_t)15);
+    RowOrderArgs o{};
+    int order_blocks = 0;
+    if (job) {
+        if (int rc = fill_order_args(o, job)) return rc;
+        o.slot_cap = order_slot_cap(o.S, 136 * 1024);
+        o.parts = o.slot_cap > 0 ? (o.S + o.slot_cap - 1) / o.slot_cap : 0;
+        const size_t need = (((size_t)(o.slot_cap < o.S ? o.slot_cap : o.S) + 7) & ~(size_t)7) * 2;
+        if (o.slot_cap > 0 && need <= 136 * 1024) {
+            order_blocks = o.batch * o.nl * o.parts;
+            if (need > dyn) dyn = need;
+        }
+    }
+    const int nsel = batch_size * wgs;
+#define SDETR_HSI(KPT)                                                                                              \
+    do {                                                                                                            \
+        static DeviceOnce lds_once3;                                                                                \
+        allow_dynamic_lds(topk_hsort_inproj_kernel<KPT>, lds_once3, 136 * 1024);                                    \
+        hipLaunchKernelGGL(topk_hsort_inproj_kernel<KPT>, dim3((unsigned)(nsel + order_blocks)), dim3(kHsThreads), dyn, \
+                           static_cast<hipStream_t>(stream), a, q, wgs, nsel, o);                                   \
+    } while (0)
+    if (chunk <= 3) SDETR_HSI(3);
+    else if (chunk <= 5) SDETR_HSI(5);
+    else if (chunk <= 7) SDETR_HSI(7);
+    else if (chunk <= 9) SDETR_HSI(9);
+    else if (chunk <= 12) SDETR_HSI(12);
+    else SDETR_HSI(17);
+#undef SDETR_HSI
+    if (int rc = check_launch("topk_select_inproj")) return rc;
+    if (job && !order_blocks)   // (a pyramid whose orders do not fit the launch: on their own)
+        return sdetr_layer_row_orders(stream, job->sorted_index, job->index_batch_stride, job->tile_pos, job->batch,
+                                      job->spatial_size, job->num_rows, job->num_layers, job->counts, job->order,
+                                      job->order_batch_stride);
+    return 0;
 }

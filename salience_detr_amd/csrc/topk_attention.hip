@@ -23,56 +23,12 @@ namespace sdetr {
 
 __global__ void __launch_bounds__(256) topk_inproj_kernel(TkInArgs p)
 {
-    // the wave number must be PROVABLY uniform: the two tile variants are chosen by a branch on it, and an MFMA under
-    // a branch the compiler takes for divergent is merely exec-masked -- which matrix instructions ignore
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = lane & 31, h = lane >> 5;
     const int tiles = p.Npad / 32;
     const int fgroup = blockIdx.x % 6, rest = blockIdx.x / 6;
     const int tile = rest % tiles, b = rest / tiles;
-    const int ftile = fgroup * 4 + wave;                 // 24 tiles of 32 output features
-    const bool qk_tile = ftile < 16;
-    const int i = tile * 32 + t;                          // my token (as B-operand / accumulator column)
-    const bool valid = i < p.N;
-    const int64_t row = p.sel[(int64_t)b * p.N + min(i, p.N - 1)];
-    if (p.hint && ftile == 0 && h == 0 && valid) p.hint[(int64_t)b * p.hint_bs + row] = i + 1;
-    const bf16_t *xr = p.query + (int64_t)b * p.q_bs + row * kTkE + 8 * h;
-    const bf16_t *pr = p.pos + (int64_t)b * p.p_bs + row * kTkE + 8 * h;
-    const bf16_t *wr = p.w + (int64_t)(ftile * 32 + t) * kTkE + 8 * h;
-
-    // bias of my 16 features (groups of 4 consecutive ones: accumulator rows 8g + 4h + 0..3), loaded up front as four
-    // 8-byte pieces -- per-element loads behind the `valid` test were serialised by the compiler, one round trip each
-    float bias[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint2 bv = *reinterpret_cast<const uint2 *>(p.bias + ftile * 32 + 8 * g + 4 * h);
-        bias[4 * g] = act_lo(bv.x); bias[4 * g + 1] = act_hi(bv.x);
-        bias[4 * g + 2] = act_lo(bv.y); bias[4 * g + 3] = act_hi(bv.y);
-    }
-    // rows of the accumulator = features, column = my token; padded tokens are written as zeros (finite keys / values)
-    if (qk_tile) {
-        const tk_f32x16_t acc = inproj_tile<true>(wr, xr, pr);
-        const int head = ftile & 7;                           // tiles 0-7: q of head 0-7, tiles 8-15: k
-        bf16_t *kbase = p.qk + (int64_t)p.B * p.Npad * 256;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                         // my 4 consecutive channels 8g + 4h + 0..3 of the head
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = valid ? acc[4 * g + r] + bias[4 * g + r] : 0.f;
-            bf16_t *out = ftile < 8 ? p.qk + ((int64_t)b * p.Npad + i) * 256 + head * 32 + 8 * g + 4 * h
-                                    : kbase + tk_k_index(b, head, i, 8 * g + 4 * h, p.Npad);
-            *reinterpret_cast<uint2 *>(out) = make_uint2(pack_act2(v[0], v[1]), pack_act2(v[2], v[3]));
-        }
-    } else {
-        const tk_f32x16_t acc = inproj_tile<false>(wr, xr, pr);
-        const int head = ftile - 16;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = tk_row(r, h);
-            const float v = valid ? acc[r] + bias[r] : 0.f;
-            p.vt[tk_vt_index(b, head, i, ch, p.Npad)] = (bf16_t)(pack_act2(v, 0.f) & 0xffffu);
-        }
-    }
+    const int i = tile * 32 + (lane & 31);
+    inproj_wave_body(p, b, tile, fgroup * 4 + wave, lane, p.sel[(int64_t)b * p.N + min(i, p.N - 1)]);
 }
 
 template <int KT>

@@ -20,6 +20,7 @@ __device__ __forceinline__ uint4 tk_pack_half(const tk_f32x16_t &c, int m)
     return make_uint4(pack_act2(c[8 * m], c[8 * m + 1]), pack_act2(c[8 * m + 2], c[8 * m + 3]),
                       pack_act2(c[8 * m + 4], c[8 * m + 5]), pack_act2(c[8 * m + 6], c[8 * m + 7]));
 }
+constexpr int kTkMaxSel = 384;   // selected rows per image the two-launch attention is built for
 __device__ __forceinline__ float tk_bf16(bf16_t v) { return act_lo((uint32_t)v); }   // (one activation element -> f32)
 
 constexpr int kTkE = 256, kTkHeads = 8, kTkHd = 32;
@@ -56,29 +57,136 @@ __device__ __forceinline__ int64_t tk_vt_index(int b, int head, int key, int ch,
 
 // one 32-feature x 32-token tile; QK = the tile holds q or k features (the position rows are added).  Straight-line
 // code per variant: with a branch inside, hipcc sinks the operand loads into the MFMA sequence (two in flight)
-template <bool QK>
-__device__ __forceinline__ tk_f32x16_t inproj_tile(const bf16_t *wr, const bf16_t *xr, const bf16_t *pr)
+// `bias4` / `bv`: the lane's four 8-byte bias pieces (stride 8 elements) are requested inside the SECOND half's MFMA chain,
+// once two of its k-steps' fragments are dead (they arrive under the remaining twelve MFMAs) -- requested up front they were
+// eight more live registers under 24 fragments, and the 1024-thread selection + in-projection launch (128 registers per
+// wave) spilled.
+// `R` = k-steps (of 16) whose fragments are in flight together: 8 (two rounds of 16 / 24 fragments; the stand-alone launch)
+// or 6 (rounds of 6, 6, 4: 18 fragments -- the 1024-thread selection + in-projection launch has 128 registers per wave, and
+// with 24 fragments it spilled: a kernel that needs scratch memory pays for it at every wave's dispatch).
+template <bool QK, int R = 8>
+__device__ __forceinline__ tk_f32x16_t inproj_tile(const bf16_t *wr, const bf16_t *xr, const bf16_t *pr, const bf16_t *bias4,
+                                                   uint2 (&bv)[4])
 {
-    tk_f32x16_t acc;
+    tk_f32x16_t acc = {};   // (a constant zero: the first MFMA takes it as its inline C operand, no registers until then)
+    if constexpr (R == 4) {
+        // four rounds of four k-steps through TWO register sets: round r + 2 is requested when round r's MFMAs are issued,
+        // so a wave waits for one trip to memory (and what of the second the first round's MFMAs do not cover), with 24
+        // fragments in flight at most -- and only 12 while its MFMAs need the accumulator
+        uint4 a[2][4], bx[2][4], bp[2][4];
+        auto request = [&](int rd, int s) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                a[s][j] = *reinterpret_cast<const uint4 *>(wr + (rd * 4 + j) * 16);
+                bx[s][j] = *reinterpret_cast<const uint4 *>(xr + (rd * 4 + j) * 16);
+                if (QK) bp[s][j] = *reinterpret_cast<const uint4 *>(pr + (rd * 4 + j) * 16);
+            }
+        };
+        request(0, 0);
+        request(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {               // 8 k-steps of 16 at a time: 16 / 24 fragments in flight
-        uint4 a[8], bx[8], bp[8];
+        for (int rd = 0; rd < 4; ++rd) {
+            const int s = rd & 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a[j] = *reinterpret_cast<const uint4 *>(wr + (half * 8 + j) * 16);
-            bx[j] = *reinterpret_cast<const uint4 *>(xr + (half * 8 + j) * 16);
-            if (QK) bp[j] = *reinterpret_cast<const uint4 *>(pr + (half * 8 + j) * 16);
+            for (int j = 0; j < 4; ++j) {
+                acc = tk_mfma(a[s][j], bx[s][j], acc);
+                if (QK) acc = tk_mfma(a[s][j], bp[s][j], acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (rd + 2 < 4) request(rd + 2, s);
+            if (rd == 2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const uint2 *>(bias4 + 8 * g);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);   // every load of the half issued before its first MFMA
+        return acc;
+    }
+    constexpr int ROUNDS = (16 + R - 1) / R;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        uint4 a[R], bx[R], bp[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (rd * R + j >= 16) continue;
+            a[j] = *reinterpret_cast<const uint4 *>(wr + (rd * R + j) * 16);
+            bx[j] = *reinterpret_cast<const uint4 *>(xr + (rd * R + j) * 16);
+            if (QK) bp[j] = *reinterpret_cast<const uint4 *>(pr + (rd * R + j) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // every load of the round issued before its first MFMA
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (rd * R + j >= 16) continue;
             acc = tk_mfma(a[j], bx[j], acc);
             if (QK) acc = tk_mfma(a[j], bp[j], acc);   // W (x + pos) = W x + W pos
+            if (rd == ROUNDS - 1 && j == 1) {          // (two k-steps' fragments are dead: room for the bias pieces)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const uint2 *>(bias4 + 8 * g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     return acc;
+}
+
+// One wave's tile of the in-projection: 32 selected rows (tile `tile` of image b) x 32 output features (`ftile` of 24);
+// `row` = the lane's selected row, sel[b][min(32 tile + (lane & 31), N - 1)] (from memory or from the selection's own LDS
+// list).  `ftile` must be PROVABLY wave-uniform: the two tile variants are chosen by a branch on it, and an MFMA under a
+// branch the compiler takes for divergent is merely exec-masked -- which matrix instructions ignore.
+template <int R = 8>
+__device__ __forceinline__ void inproj_wave_body(const TkInArgs &p, const int b, const int tile, const int ftile, const int lane,
+                                                 const int64_t row)
+{
+    const int t = lane & 31, h = lane >> 5;
+    const bool qk_tile = ftile < 16;
+    const int i = tile * 32 + t;                          // my token (as B-operand / accumulator column)
+    const bool valid = i < p.N;
+    if (p.hint && ftile == 0 && h == 0 && valid) p.hint[(int64_t)b * p.hint_bs + row] = i + 1;
+    // (wave-uniform bases + 32-bit lane offsets: the loads take the scalar-base form, one address register each)
+    const uint32_t ro = (uint32_t)row * (uint32_t)kTkE + 8u * (uint32_t)h;
+    const bf16_t *xr = p.query + (int64_t)b * p.q_bs + ro;
+    const bf16_t *pr = p.pos + (int64_t)b * p.p_bs + ro;
+    const bf16_t *wr = p.w + (int64_t)ftile * 32 * kTkE + (uint32_t)(t * kTkE + 8 * h);
+    // bias of my 16 features (groups of 4 consecutive ones: accumulator rows 8g + 4h + 0..3) as four 8-byte pieces --
+    // per-element loads behind the `valid` test were serialised by the compiler, one round trip each
+    const bf16_t *bias4 = p.bias + ftile * 32 + 4 * h;
+    uint2 bv[4];
+    float bias[16];
+    auto unpack_bias = [&]() {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bias[4 * g] = act_lo(bv[g].x); bias[4 * g + 1] = act_hi(bv[g].x);
+            bias[4 * g + 2] = act_lo(bv[g].y); bias[4 * g + 3] = act_hi(bv[g].y);
+        }
+    };
+    // rows of the accumulator = features, column = my token; padded tokens are written as zeros (finite keys / values)
+    if (qk_tile) {
+        const tk_f32x16_t acc = inproj_tile<true, R>(wr, xr, pr, bias4, bv);
+        unpack_bias();
+        const int head = ftile & 7;                           // tiles 0-7: q of head 0-7, tiles 8-15: k
+        bf16_t *kbase = p.qk + (int64_t)p.B * p.Npad * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                         // my 4 consecutive channels 8g + 4h + 0..3 of the head
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = valid ? acc[4 * g + r] + bias[4 * g + r] : 0.f;
+            bf16_t *out = ftile < 8 ? p.qk + ((int64_t)b * p.Npad + i) * 256 + head * 32 + 8 * g + 4 * h
+                                    : kbase + tk_k_index(b, head, i, 8 * g + 4 * h, p.Npad);
+            *reinterpret_cast<uint2 *>(out) = make_uint2(pack_act2(v[0], v[1]), pack_act2(v[2], v[3]));
+        }
+    } else {
+        const tk_f32x16_t acc = inproj_tile<false, R>(wr, xr, pr, bias4, bv);
+        unpack_bias();
+        const int head = ftile - 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = tk_row(r, h);
+            const float v = valid ? acc[r] + bias[r] : 0.f;
+            p.vt[tk_vt_index(b, head, i, ch, p.Npad)] = (bf16_t)(pack_act2(v, 0.f) & 0xffffu);
+        }
+    }
 }
 
 struct TkOutArgs {

@@ -1893,7 +1893,57 @@ def topk_self_attention_applies(query: Tensor, pos: Tensor, mha, norm, num_selec
             and pos.stride(2) == 1 and pos.stride(1) == 256)
 
 
-def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm, projection=None):
+# The layer's top-k selection and the in-projection of the selected rows in one launch (csrc/topk.hip,
+# topk_hsort_inproj_kernel); False = selection launch + in-projection launch (the form up to round 6, for A/B runs).
+SELECT_WITH_INPROJECTION = True
+
+
+class SelectedInProjection:
+    """``topk_select_inproj``'s result: ``selected`` int64 [B,k] and the in-projection of those rows (``workspace`` /
+    ``hint`` as ``topk_self_attention_`` hands them to the attention launch)."""
+
+    def __init__(self, selected, workspace, hint):
+        self.selected, self.workspace, self.hint = selected, workspace, hint
+
+
+def topk_select_inproj_applies(score: Tensor, k: int, query: Tensor, pos: Tensor, mha, norm) -> bool:
+    """Shapes ``sdetr_topk_select_inproj_bf16`` covers: a contiguous fp32 [B,n] score row per image for the one-workgroup
+    histogram sort (1024 <= n <= 17 408, 5 k <= 2 n), 289 <= k <= 320 (the attention launch that follows), the layer's
+    queries contiguous."""
+    if not SELECT_WITH_INPROJECTION or score.dim() != 2 or score.dtype != torch.float32 or not score.is_contiguous():
+        return False
+    B, n = score.shape
+    return (B > 0 and 1024 <= n <= 17408 and 5 * k <= 2 * n and 289 <= k <= 320 and query.is_contiguous()
+            and tuple(query.shape[:2]) == (B, n) and pos.shape[1] >= n
+            and topk_self_attention_applies(query, pos, mha, norm, k))
+
+
+def topk_select_inproj(score: Tensor, k: int, query: Tensor, pos: Tensor, mha, orders_job=None) -> SelectedInProjection:
+    """``torch.topk(score, k, dim=1)[1]`` (ties: lower position first; salience_transformer.py:366) and the in-projection
+    of the rows it selects -- the first launch of ``topk_self_attention_`` -- in ONE launch; pass the result as
+    ``topk_self_attention_(..., inprojection=result)``.  ``orders_job``: the pending ``RowOrdersJob`` rides along."""
+    _hip.require_device("topk_select_inproj", score=score, query=query, pos=pos)
+    B, n = score.shape
+    lib = _hip.lib(query.dtype)
+    dev = query.device
+    sel = torch.empty((B, k), dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, k), dtype=torch.uint8, device=dev)
+    hint = torch.empty((B, n), dtype=torch.int32, device=dev)   # (uninitialised on purpose, see topk_self_attention_)
+    job = orders_job if orders_job is not None and not orders_job.done and orders_job.device == dev else None
+    with torch.cuda.device(dev):
+        code = lib.sdetr_topk_select_inproj_bf16(
+            _hip.stream_ptr(), score.data_ptr(), B, n, k, sel.data_ptr(), query.data_ptr(),
+            query.stride(0) if B > 1 else n * 256, pos.data_ptr(), pos.stride(0) if B > 1 else pos.shape[1] * 256,
+            mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), ws.data_ptr(), ws.numel(), hint.data_ptr(),
+            hint.stride(0), None if job is None else ctypes.byref(job.struct))
+    _hip.check(code, "topk_select_inproj")
+    if job is not None:
+        job.done = True
+    return SelectedInProjection(sel, ws, hint)
+
+
+def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm, projection=None,
+                         inprojection: Optional[SelectedInProjection] = None):
     """In place on ``query`` [B,rows,256] bf16: rows ``selected[b]`` become
     ``norm(x + mha(q = k = x + pos, v = x))`` (salience_transformer.py:366-379); ``pos`` [B,>=rows,256] holds the position
     rows in the same row order (may be a row prefix of a longer buffer).  Two launches, no library GEMM.
@@ -1901,7 +1951,9 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
     ``projection = (weight [384,256] bf16 head-major rows, bias)``: the deformable attention's offset | weight
     projection of the UPDATED queries (``token_linear(query, weight, bias, x_add=pos, group_features=48)``) rides in the
     attention's launch (``sdetr_topk_attention_with_projection_bf16``) and is returned as ``[B,8,rows,48]``; ``None`` is
-    returned in its place when that launch does not cover the shape (the caller projects afterwards)."""
+    returned in its place when that launch does not cover the shape (the caller projects afterwards).
+    ``inprojection``: ``topk_select_inproj``'s result for this ``selected`` (the carried form only): its launch has done
+    the in-projection."""
     _hip.require_device("topk_self_attention_", selected=selected)
     B, rows, _ = query.shape
     N = selected.shape[1]
@@ -1909,7 +1961,10 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
         raise RuntimeError("topk_self_attention_: bf16 [B,rows,256] HIP tensors, 8 heads, int64 [B,N] selection expected; "
                            "no CPU fallback")
     lib = _hip.lib(query.dtype)
-    ws = torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, N), dtype=torch.uint8, device=query.device)
+    if inprojection is not None and inprojection.selected is not selected:
+        raise RuntimeError("topk_self_attention_: the in-projection belongs to another selection")
+    ws = (inprojection.workspace if inprojection is not None
+          else torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, N), dtype=torch.uint8, device=query.device))
     qbs = query.stride(0) if B > 1 else rows * 256
     pbs = pos.stride(0) if B > 1 else pos.shape[1] * 256
     carried = (projection is not None and 289 <= N <= 320 and query.is_contiguous()
@@ -1923,7 +1978,7 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
             # marks of the selected rows for the projection part of the launch: UNINITIALISED on purpose -- a mark m
             # counts only if selected[b][m - 1] is the row it sits on, which no garbage value can fake, and the
             # in-projection writes the true marks before anything reads them
-            hint = torch.empty((B, rows), dtype=torch.int32, device=query.device)
+            hint = inprojection.hint if inprojection is not None else torch.empty((B, rows), dtype=torch.int32, device=query.device)
             code = lib.sdetr_topk_attention_with_projection_bf16(
                 _hip.stream_ptr(), query.data_ptr(), qbs, pos.data_ptr(), pbs, selected.data_ptr(), B, rows, N,
                 mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), mha.out_proj.weight.data_ptr(),
@@ -1931,9 +1986,11 @@ def topk_self_attention_(query: Tensor, pos: Tensor, selected: Tensor, mha, norm
                 ws.data_ptr(), ws.numel(), w.data_ptr(), packed.data_ptr(), b_pad.data_ptr(), slab.data_ptr(),
                 hint.data_ptr(), hint.stride(0),
                 _fragment_order(mha.out_proj.weight, 32).data_ptr() if mha.out_proj.weight.is_contiguous() else None,
-                _fragment_order(w, 48).data_ptr())
+                _fragment_order(w, 48).data_ptr(), 1 if inprojection is not None else 0)
             _hip.check(code, "topk_self_attention_")
             return slab
+        if inprojection is not None:
+            raise RuntimeError("topk_self_attention_: an in-projection from the selection's launch needs the carried form")
         code = lib.sdetr_topk_attention_bf16(
             _hip.stream_ptr(), query.data_ptr(), qbs, pos.data_ptr(), pbs, selected.data_ptr(), B, rows, N,
             mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), mha.out_proj.weight.data_ptr(),

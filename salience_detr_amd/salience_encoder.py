@@ -29,7 +29,8 @@ from .filter_ops import (advance_rows, layer_row_orders, attention_heads, attent
                          attn_tail_ffn_applies, class_head_max_times,
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
-                         select_stack, token_linear_applies, token_linear_ln, topk_self_attention_,
+                         select_stack, token_linear_applies, token_linear_ln, topk_self_attention_, topk_select_inproj,
+                         topk_select_inproj_applies,
                          topk_self_attention_applies)
 from .layer_norm_train import add_layer_norm
 from .linear_x3 import X3Linear, x3_ffn, x3_ffn_applies
@@ -203,14 +204,23 @@ class SalienceTransformerEncoderLayer(nn.Module):
             mc_score = class_head_max_times(query, class_head, fg_sorted[:, :c])   # logits never materialised
         else:
             mc_score = class_max_times(class_head(query), fg_sorted[:, :c])
-        # (``orders_job``: the encoder's pending row orders ride in this selection's launch -- layer 0)
-        sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False, orders_job=orders_job)[1]
+        fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
+        carried = (fuse_tail and not self.training and self.two_launch_topk_attention and self.carry_sampling_projection
+                   and self.self_attn.head_major_projection_applies(query, value_hm))
+        inproj = None
+        if (carried and selection_hook is None
+                and topk_select_inproj_applies(mc_score, self.topk_sa, query, pos_sorted, self.pre_attention, self.pre_norm)):
+            # the selection's launch also does the in-projection of the rows it selects (csrc/topk.hip)
+            inproj = topk_select_inproj(mc_score, self.topk_sa, query, pos_sorted, self.pre_attention, orders_job=orders_job)
+            sel = inproj.selected
+        else:
+            # (``orders_job``: the encoder's pending row orders ride in this selection's launch -- layer 0)
+            sel = masked_topk_desc(mc_score, self.topk_sa, want_scores=False, orders_job=orders_job)[1]
         if orders_job is not None:
             orders_job.run()             # (no-op when the launch carried it)
         if selection_hook is not None:   # instrumentation: record the layer's top-k set, or force a given one
             sel = selection_hook(sel)
         N = sel.shape[1]
-        fuse_tail = token_linear_applies(query, self.self_attn.output_proj.weight) and self.embed_dim == 256
         if (fuse_tail and not self.training and self.two_launch_topk_attention and sel.is_contiguous()
                 and topk_self_attention_applies(query, pos_sorted, self.pre_attention, self.pre_norm, N)):
             # gather + (x + pos) + in-projection, then attention + out_proj + residual + pre_norm + scatter: two launches,
@@ -218,7 +228,8 @@ class SalienceTransformerEncoderLayer(nn.Module):
             if self.carry_sampling_projection and self.self_attn.head_major_projection_applies(query, value_hm):
                 # the MSDA offset | weight projection of all rows rides in the attention's launch
                 proj = topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm,
-                                            projection=self.self_attn._fused_query_projection_head_major())
+                                            projection=self.self_attn._fused_query_projection_head_major(),
+                                            inprojection=inproj)
             else:
                 topk_self_attention_(query, pos_sorted, sel, self.pre_attention, self.pre_norm)
             stacked = None

@@ -40,3 +40,58 @@ def test_attention_carrying_the_projection_equals_the_two_operators(rows, N):
     scale = want.float().abs().max().item()
     assert d.max().item() <= 2 ** -7 * scale
     assert (d > 0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("rows,N,ties", [(11363, 300, False), (9090, 300, True), (2272, 300, False), (1500, 289, False),
+                                        (4545, 320, True)])
+def test_selection_launch_with_the_in_projection_equals_the_two_launches(rows, N, ties):
+    """csrc/topk.hip topk_hsort_inproj_kernel: the layer's top-k selection and the in-projection of the selected rows in ONE
+    launch (every workgroup of an image repeats the selection) -- the same selection as masked_topk_desc (ties by position
+    included) and, through the attention launch that follows, the same bits in the queries and the projection slab."""
+    B = 2
+    torch.manual_seed(rows + N)
+    mha = torch.nn.MultiheadAttention(256, 8, batch_first=True).to(DEV).to(torch.bfloat16)
+    norm = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)
+    q0 = (syn.det_randn(f"siq{rows}", (B, rows, 256)) * 0.8).to(DEV).to(torch.bfloat16)
+    pos = (syn.det_randn(f"sip{rows}", (B, rows + 50, 256)) * 0.5).to(DEV).to(torch.bfloat16)
+    score = syn.det_randn(f"sis{rows}", (B, rows)).to(DEV)
+    if ties:
+        score = (score * 8).round() / 8          # many exact ties, also across the cut
+        score[1, : rows // 2] = score[1, 0]      # a crowded bin
+    w = (syn.det_randn("siw", (384, 256)) * 0.06).to(DEV).to(torch.bfloat16)
+    b = (syn.det_randn("sibb", (384,)) * 0.2).to(DEV).to(torch.bfloat16)
+    assert F.topk_select_inproj_applies(score, N, q0, pos, mha, norm)
+    with torch.no_grad():
+        qa, qb = q0.clone(), q0.clone()
+        sel = F.masked_topk_desc(score, N, want_scores=False)[1]
+        want = F.topk_self_attention_(qa, pos, sel, mha, norm, projection=(w, b))
+        both = F.topk_select_inproj(score, N, qb, pos, mha)
+        got = F.topk_self_attention_(qb, pos, both.selected, mha, norm, projection=(w, b), inprojection=both)
+    assert torch.equal(both.selected, sel)
+    assert torch.equal(qa, qb) and torch.equal(got, want)
+    # the selection against the framework's (descending scores; equal scores by position)
+    ref = torch.sort(score, dim=1, descending=True, stable=True)[1][:, :N]
+    assert torch.equal(sel, ref)
+
+
+def test_selection_launch_with_the_in_projection_carries_the_row_orders():
+    """... and the encoder's row-order job, as the selection's own launch does at layer 0."""
+    B, rows, N = 2, 11363, 300
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    torch.manual_seed(5)
+    mha = torch.nn.MultiheadAttention(256, 8, batch_first=True).to(DEV).to(torch.bfloat16)
+    norm = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)
+    q0 = (syn.det_randn("soq", (B, rows, 256)) * 0.8).to(DEV).to(torch.bfloat16)
+    pos = (syn.det_randn("sop", (B, rows, 256)) * 0.5).to(DEV).to(torch.bfloat16)
+    score = syn.det_randn("sos", (B, rows)).to(DEV)
+    sorted_index = torch.stack([torch.randperm(S)[:rows] for _ in range(B)]).to(DEV)
+    counts = [rows, 9090, 6817, 6817, 4545, 2272]
+    want_orders = F.layer_row_orders(sorted_index, counts, shapes)
+    job = F.layer_row_orders(sorted_index, counts, shapes, as_job=True)
+    with torch.no_grad():
+        both = F.topk_select_inproj(score, N, q0, pos, mha, orders_job=job)
+    assert job.done
+    for a, c in zip(job.orders, want_orders):
+        assert torch.equal(a, c)
+    assert torch.equal(both.selected, F.masked_topk_desc(score, N, want_scores=False)[1])
