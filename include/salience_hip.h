@@ -417,6 +417,18 @@ int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *tokens, cons
                                  const int64_t *level_start_index, int num_levels, void *query_out, void *pos_out,
                                  float *score_out, float *reference_points_out, const uint8_t *score_mask,
                                  const float *score_mins, int num_mins);
+/*   sdetr_encoder_prepare_sorted_scored: the same launch also writes the FIRST layer's selection score of the gathered rows,
+ *     class_score_out [batch, rows] = max_c(class_head(query_out[b][i])) * score_out-value[b][i]
+ *     (models/bricks/salience_transformer.py:462, 366) -- 512-byte rows of 16-bit activations only; class_packed =
+ *     sdetr_class_head_pack_bf16(class head weight [num_classes <= 96, 256]), class_bias_padded fp32 [96] (-inf on the
+ *     padded classes); `score` is required (score_out may still be NULL). */
+int sdetr_encoder_prepare_sorted_scored(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes,
+                                        const float *score, const int64_t *index, int64_t index_batch_stride,
+                                        int batch_size, int spatial_size, int rows, const float *valid_ratios,
+                                        const int64_t *shapes, const int64_t *level_start_index, int num_levels,
+                                        void *query_out, void *pos_out, float *score_out, float *reference_points_out,
+                                        const uint8_t *score_mask, const float *score_mins, int num_mins,
+                                        const void *class_packed, const float *class_bias_padded, float *class_score_out);
 int sdetr_class_max_times(sdetr_stream_t stream, const void *score, int score_dtype, const float *scale,
                           int64_t scale_batch_stride, int batch_size, int rows_per_batch, int num_classes, float *out);
 

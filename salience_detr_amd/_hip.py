@@ -128,6 +128,8 @@ SIGNATURES = {
     "sdetr_salience_focal_loss_backward": (_i, [_p, _p, _p, _i64, ctypes.c_float, ctypes.c_float, _p, _p, _p]),
     "sdetr_attention_heads_bf16": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i, _i, _i, _i, ctypes.c_float, _p]),
     "sdetr_encoder_prepare_sorted": (_i, [_p, _p, _p, _i, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i]),
+    "sdetr_encoder_prepare_sorted_scored": (_i, [_p, _p, _p, _i, _p, _p, _i64, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i,
+                                                  _p, _p, _p]),
     "sdetr_encoder_reference_points": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "sdetr_pyramid_flatten_level": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i]),
     "sdetr_pyramid_flatten": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),

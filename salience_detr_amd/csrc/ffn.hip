@@ -40,6 +40,7 @@
 // A block keeps a CU for the whole hidden dimension, so small token counts leave most of the chip idle: the hidden
 // dimension can be cut into `nsplit` pieces per token block (fp32 partial products + ffn_reduce_ln_kernel).
 #include "common.h"
+#include "class_head_core.h"
 
 namespace sdetr {
 
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(256) ffn_reduce_ln_advance_kernel(const float 
 // Wc[tile] q^T + bc, sixteen MFMAs on one accumulator in k order (the chain of the NEXT form) from the class head's
 // packed fragments (class_head_pack_kernel; requested first, they arrive under the row sums) -- and the maximum over the
 // three tiles times the foreground score is the row's score.
-constexpr int kRcRows = 32, kRcThreads = 512, kRcRowBytes = 528;
+constexpr int kRcRows = kClsTileRows, kRcThreads = 512, kRcRowBytes = kClsRowBytes;
 
 __global__ void __launch_bounds__(kRcThreads) ffn_reduce_ln_advance_cls_kernel(
     const float *partial, int nsplit, int T, const bf16_t *x, const float *b2, const float *gamma, const float *beta,
@@ -749,10 +750,7 @@ __global__ void __launch_bounds__(kRcThreads) ffn_reduce_ln_advance_cls_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tok0 = blockIdx.x * kRcRows;
     uint4 af[16];
-    if (wave < 3) {
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) af[ks] = reinterpret_cast<const uint4 *>(cls_pw)[(3 * ks + wave) * 64 + lane];
-    }
+    if (wave < 3) class_frag_load<0, 8>(af, cls_pw, wave, lane);
     constexpr int RW = kRcRows / (kRcThreads / 64);   // rows per wave: 4
     float4 v[RW];
     int bb[RW], ii[RW];
@@ -807,10 +805,7 @@ __global__ void __launch_bounds__(kRcThreads) ffn_reduce_ln_advance_cls_kernel(
         }
     }
     // (the second half of the fragments takes the registers the pieces have left: 128 registers, two blocks per CU)
-    if (wave < 3) {
-#pragma unroll
-        for (int ks = 8; ks < 16; ++ks) af[ks] = reinterpret_cast<const uint4 *>(cls_pw)[(3 * ks + wave) * 64 + lane];
-    }
+    if (wave < 3) class_frag_load<8, 16>(af, cls_pw, wave, lane);
     const float4 gv = *reinterpret_cast<const float4 *>(gamma + 4 * lane);
     const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * lane);
 #pragma unroll
@@ -835,22 +830,9 @@ __global__ void __launch_bounds__(kRcThreads) ffn_reduce_ln_advance_cls_kernel(
         *reinterpret_cast<uint2 *>(ytile + (wave * RW + k) * kRcRowBytes + 8 * lane) = y;
     }
     __syncthreads();
-    const int t = lane & 31, h = lane >> 5;
     if (wave < 3) {
-        f32x16_t acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bv = *reinterpret_cast<const float4 *>(cls_bias + 32 * wave + 8 * g + 4 * h);
-            acc[4 * g] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
-        }
-        const unsigned char *qrow = ytile + t * kRcRowBytes + 16 * h;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc = mfma_bf16(af[ks], *reinterpret_cast<const uint4 *>(qrow + 32 * ks), acc);
-        float mx = acc[0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (h == 0) red[wave][t] = mx;
+        const float mx = class_tile_max(af, ytile, cls_bias, wave, lane);
+        if (lane < 32) red[wave][lane] = mx;
     }
     __syncthreads();
     if (tid < kRcRows) {

@@ -13,6 +13,7 @@
 //  * class_max_times_kernel: mc_score = score_tgt.max(-1)[0] * foreground_pre_layer
 //    (models/bricks/salience_transformer.py:366): one pass over the [B*Nq, num_classes] logits.
 #include "common.h"
+#include "class_head_core.h"
 
 namespace sdetr {
 
@@ -364,9 +365,112 @@ __global__ void __launch_bounds__(256) encoder_prepare_kernel(PrepareArgs p)
     }
 }
 
+// The same entry with the FIRST layer's class score of the gathered rows (salience_transformer.py:462, 366:
+// max_c(class_head(q)) * foreground) -- the class head used to be the next launch (8.2 us at 2 x 11 363 rows, most of it
+// the launch's own start-up).  512-byte rows only; 32 rows per 1024-thread block, a row per 32-lane group exactly as
+// above (the launch lives on the number of independent index -> row chains in flight: unchanged), the gathered query rows
+// also go to an LDS tile and three waves take one 32-class tile each (class_head_core.h).
+struct PrepareClsArgs {
+    const char *cls_pw;      // the class head's packed fragments (sdetr_class_head_pack_bf16)
+    const float *cls_bias;   // [96], -inf on the padded classes
+    float *cmax;             // [B, n]
+};
+
+__global__ void __launch_bounds__(1024) encoder_prepare_cls_kernel(PrepareArgs p, PrepareClsArgs k)
+{
+    __shared__ int geo[3 * kMaxLevels];   // level start | W | H
+    __shared__ __attribute__((aligned(16))) unsigned char ytile[kClsTileRows * kClsRowBytes];
+    __shared__ float fgs[kClsTileRows];
+    __shared__ float red[3][kClsTileRows];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4 af[16];
+    if (wave < 3) class_frag_load<0, 16>(af, k.cls_pw, wave, lane);   // (requested first: they arrive under the gather)
+    if (tid < p.L) {
+        geo[tid] = (int)p.lsi[tid];
+        geo[kMaxLevels + tid] = (int)p.shapes[2 * tid + 1];
+        geo[2 * kMaxLevels + tid] = (int)p.shapes[2 * tid];
+    }
+    __syncthreads();
+    float fill = 0.f;
+    if (p.score_mask) {
+        fill = p.score_mins[0];
+        for (int l = 1; l < p.num_mins; ++l) fill = fminf(fill, p.score_mins[l]);
+    }
+    const uint32_t total = (uint32_t)p.B * (uint32_t)p.n, n = (uint32_t)p.n;
+    const uint32_t sub = (uint32_t)tid >> 5, c = (uint32_t)tid & 31u;
+    const uint32_t r = blockIdx.x * (uint32_t)kClsTileRows + sub;
+    const bool ok = r < total;
+    const uint32_t row = ok ? r : total - 1u;
+    const uint32_t bi = row / n;
+    const int tok = (int)p.index[(int64_t)bi * p.index_batch_stride + (row - bi * n)];
+    const uint32_t src = (bi * (uint32_t)p.S + (uint32_t)tok) * 32u + c;
+    const uint4 qv = p.tokens[src];
+    const uint4 pv = p.pos[src];
+    const float sc = c == 0 ? p.score[bi * (uint32_t)p.S + (uint32_t)tok] : 0.f;
+    const uint8_t mk = (c == 0 && p.score_mask) ? p.score_mask[bi * (uint32_t)p.S + (uint32_t)tok] : (uint8_t)0;
+    const bool ref_lane = c < 2u * (uint32_t)p.L;
+    float centre_px = 1.f, size = 1.f, va = 1.f, vb = 1.f;
+    if (ref_lane) {
+        int l = 0;
+        for (int j = 1; j < p.L; ++j) l = tok >= geo[j] ? j : l;
+        const uint32_t W = (uint32_t)geo[kMaxLevels + l], H = (uint32_t)geo[2 * kMaxLevels + l];
+        const uint32_t t = (uint32_t)(tok - geo[l]);
+        const uint32_t y = t / W, x = t - y * W;
+        const bool is_y = c & 1u;
+        centre_px = (float)(is_y ? y : x) + 0.5f;
+        size = (float)(is_y ? H : W);
+        const float *v = p.vr + (int64_t)bi * p.L * 2;
+        va = v[2 * l + (is_y ? 1 : 0)];
+        vb = v[c];
+    }
+    if (ok) {
+        p.q_out[(int64_t)row * 32 + c] = qv;
+        p.pos_out[(int64_t)row * 32 + c] = pv;
+        if (c == 0 && p.score_out) p.score_out[row] = mk ? fill : sc;
+        if (ref_lane) p.ref_out[(int64_t)row * p.L * 2 + c] = centre_px / (va * size) * vb;
+    }
+    *reinterpret_cast<uint4 *>(ytile + sub * kClsRowBytes + 16 * c) = qv;
+    if (c == 0) fgs[sub] = mk ? fill : sc;
+    __syncthreads();
+    if (wave < 3) {
+        const float mx = class_tile_max(af, ytile, k.cls_bias, wave, lane);
+        if (lane < 32) red[wave][lane] = mx;
+    }
+    __syncthreads();
+    if (tid < kClsTileRows) {
+        const uint32_t rr = blockIdx.x * (uint32_t)kClsTileRows + (uint32_t)tid;
+        if (rr < total) k.cmax[rr] = fmaxf(fmaxf(red[0][tid], red[1][tid]), red[2][tid]) * fgs[tid];
+    }
+}
+
 }  // namespace sdetr
 
 using namespace sdetr;
+
+static int encoder_prepare_impl(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes, const float *score,
+                                const int64_t *index, int64_t index_batch_stride, int batch_size, int spatial_size, int rows,
+                                const float *valid_ratios, const int64_t *shapes, const int64_t *level_start_index,
+                                int num_levels, void *query_out, void *pos_out, float *score_out, float *reference_points_out,
+                                const uint8_t *score_mask, const float *score_mins, int num_mins, const void *class_packed,
+                                const float *class_bias_padded, float *class_score_out);
+
+extern "C" int sdetr_encoder_prepare_sorted_scored(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes,
+                                                   const float *score, const int64_t *index, int64_t index_batch_stride,
+                                                   int batch_size, int spatial_size, int rows, const float *valid_ratios,
+                                                   const int64_t *shapes, const int64_t *level_start_index, int num_levels,
+                                                   void *query_out, void *pos_out, float *score_out,
+                                                   float *reference_points_out, const uint8_t *score_mask,
+                                                   const float *score_mins, int num_mins, const void *class_packed,
+                                                   const float *class_bias_padded, float *class_score_out)
+{
+    if (row_bytes != 512) return fail("encoder_prepare_scored: 512-byte rows (256 16-bit channels) only");
+    if (!class_packed || !class_bias_padded || !class_score_out || !score)
+        return fail("encoder_prepare_scored: the class head's fragments, bias, a score output and the foreground score are needed");
+    return encoder_prepare_impl(stream, tokens, pos, row_bytes, score, index, index_batch_stride, batch_size, spatial_size, rows,
+                                valid_ratios, shapes, level_start_index, num_levels, query_out, pos_out, score_out,
+                                reference_points_out, score_mask, score_mins, num_mins, class_packed, class_bias_padded,
+                                class_score_out);
+}
 
 extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes,
                                             const float *score, const int64_t *index, int64_t index_batch_stride,
@@ -374,6 +478,18 @@ extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *t
                                             const int64_t *shapes, const int64_t *level_start_index, int num_levels,
                                             void *query_out, void *pos_out, float *score_out, float *reference_points_out,
                                             const uint8_t *score_mask, const float *score_mins, int num_mins)
+{
+    return encoder_prepare_impl(stream, tokens, pos, row_bytes, score, index, index_batch_stride, batch_size, spatial_size, rows,
+                                valid_ratios, shapes, level_start_index, num_levels, query_out, pos_out, score_out,
+                                reference_points_out, score_mask, score_mins, num_mins, nullptr, nullptr, nullptr);
+}
+
+static int encoder_prepare_impl(sdetr_stream_t stream, const void *tokens, const void *pos, int row_bytes, const float *score,
+                                const int64_t *index, int64_t index_batch_stride, int batch_size, int spatial_size, int rows,
+                                const float *valid_ratios, const int64_t *shapes, const int64_t *level_start_index,
+                                int num_levels, void *query_out, void *pos_out, float *score_out, float *reference_points_out,
+                                const uint8_t *score_mask, const float *score_mins, int num_mins, const void *class_packed,
+                                const float *class_bias_padded, float *class_score_out)
 {
     if (batch_size < 0 || spatial_size < 0 || rows < 0 || num_levels <= 0 || num_levels > kMaxLevels)
         return fail("encoder_prepare: bad sizes");
@@ -394,6 +510,12 @@ extern "C" int sdetr_encoder_prepare_sorted(sdetr_stream_t stream, const void *t
     a.B = batch_size; a.S = spatial_size; a.n = rows; a.L = num_levels; a.vec_per_row = row_bytes / 16;
     a.q_out = (uint4 *)query_out; a.pos_out = (uint4 *)pos_out; a.score_out = score_out; a.ref_out = reference_points_out;
     a.score_mask = score_mask; a.score_mins = score_mins; a.num_mins = num_mins;
+    if (class_score_out) {
+        PrepareClsArgs k{static_cast<const char *>(class_packed), class_bias_padded, class_score_out};
+        const int64_t cblocks = ((int64_t)batch_size * rows + kClsTileRows - 1) / kClsTileRows;
+        hipLaunchKernelGGL(encoder_prepare_cls_kernel, dim3((unsigned)cblocks), dim3(1024), 0, static_cast<hipStream_t>(stream), a, k);
+        return check_launch("encoder_prepare_scored");
+    }
     const int per_block = 256 / a.vec_per_row;
     int64_t blocks = ((int64_t)batch_size * rows + per_block * kPrepRows - 1) / (per_block * kPrepRows);
     if (blocks > 8192) blocks = 8192;

@@ -1662,12 +1662,48 @@ class LazyForegroundScore:
         return self._full
 
 
+# The encoder's entry gather also computes the first layer's class score (csrc/plumbing.hip, encoder_prepare_cls_kernel);
+# False = the class head as a launch of its own (the form up to round 6, for A/B runs).
+PREPARE_WITH_CLASS_SCORE = True
+
+
+def _class_head_fragments(class_head):
+    """``(packed fragments, fp32 bias padded to 96 with -inf)`` of a ``[<= 96, 256]`` 16-bit class head for the kernels that
+    compute ``max_c(class_head(q))`` from an LDS tile (csrc/class_head_core.h); cached on the weight object."""
+    w, b = class_head.weight, class_head.bias
+    tag = (w.data_ptr(), w._version, b.data_ptr(), b._version, str(w.device), tuple(w.shape))
+    hit = w.__dict__.get("_sdetr_cls_frag")
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    lib = _hip.lib(w.dtype)
+    with torch.no_grad(), torch.cuda.device(w.device):
+        packed = torch.empty(lib.sdetr_class_head_packed_bytes(), dtype=torch.uint8, device=w.device)
+        wc = w.detach().contiguous()
+        _hip.check(lib.sdetr_class_head_pack_bf16(_hip.stream_ptr(), wc.data_ptr(), wc.shape[0], 256, packed.data_ptr()),
+                   "class_head_pack")
+        cb = torch.full((96,), float("-inf"), dtype=torch.float32, device=w.device)
+        cb[:wc.shape[0]] = b.detach().float()
+    w.__dict__["_sdetr_cls_frag"] = (tag, packed, cb)
+    return packed, cb
+
+
+def prepare_class_score_applies(tokens: Tensor, score, class_head) -> bool:
+    return (PREPARE_WITH_CLASS_SCORE and class_head is not None and score is not None and _hip.is_act16(tokens.dtype)
+            and tokens.shape[-1] == 256 and class_head.weight.dtype == tokens.dtype and class_head.weight.dim() == 2
+            and class_head.weight.shape[1] == 256 and class_head.weight.shape[0] <= 96 and class_head.bias is not None)
+
+
 def encoder_prepare_sorted(tokens: Tensor, pos: Tensor, score, sorted_index: Tensor, valid_ratios: Tensor,
-                           spatial_shapes: Tensor, level_start_index: Tensor):
+                           spatial_shapes: Tensor, level_start_index: Tensor, class_head=None):
     """Entry of the sorted-order encoder loop in one launch: ``(tokens[b, idx], pos[b, idx], score[b, idx],
     reference points of idx)`` for ``idx = sorted_index`` ``[B,n]`` -- the two row gathers of
     salience_transformer.py:454-461, the score gather and ``get_reference_points`` (:418-432) restricted to them.
-    ``score``: fp32 ``[B,S]``, ``None``, or a ``LazyForegroundScore`` (the masked fill then happens in the gather)."""
+    ``score``: fp32 ``[B,S]``, ``None``, or a ``LazyForegroundScore`` (the masked fill then happens in the gather).
+    ``class_head`` (with ``prepare_class_score_applies``): a fifth result, the first layer's selection score
+    ``class_head(rows).max(-1)[0] * score rows`` (salience_transformer.py:462, 366) out of the same launch."""
+    with_cls = class_head is not None
+    if with_cls and not prepare_class_score_applies(tokens, score, class_head):
+        raise RuntimeError("encoder_prepare_sorted: the class score needs 16-bit [B,S,256] tokens, a score and a [<= 96, 256] head")
     score_mask = score_mins = None
     if isinstance(score, LazyForegroundScore):
         score_mask = score.mask.view(torch.uint8) if score.mask.dtype == torch.bool else score.mask
@@ -1696,12 +1732,20 @@ def encoder_prepare_sorted(tokens: Tensor, pos: Tensor, score, sorted_index: Ten
             raise RuntimeError("encoder_prepare_sorted: fp32 contiguous [B,S] score expected")
         fg = torch.empty((B, n), dtype=torch.float32, device=tokens.device)
     ref = torch.empty((B, n, L, 2), dtype=torch.float32, device=tokens.device)
-    with torch.cuda.device(tokens.device):
-        code = _hip.lib().sdetr_encoder_prepare_sorted(
-            _hip.stream_ptr(), tokens.data_ptr(), pos.data_ptr(), row_bytes, _hip.ptr(score), sorted_index.data_ptr(),
+    args = (tokens.data_ptr(), pos.data_ptr(), row_bytes, _hip.ptr(score), sorted_index.data_ptr(),
             sorted_index.stride(0) if B > 1 else n, B, S, n, vr.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), L, q.data_ptr(), ps.data_ptr(), _hip.ptr(fg), ref.data_ptr(),
             _hip.ptr(score_mask), _hip.ptr(score_mins), 0 if score_mins is None else score_mins.numel())
+    if with_cls:
+        packed, cb = _class_head_fragments(class_head)
+        cls = torch.empty((B, n), dtype=torch.float32, device=tokens.device)
+        with torch.cuda.device(tokens.device):
+            code = _hip.lib(tokens.dtype).sdetr_encoder_prepare_sorted_scored(_hip.stream_ptr(), *args, packed.data_ptr(),
+                                                                              cb.data_ptr(), cls.data_ptr())
+        _hip.check(code, "encoder_prepare_sorted")
+        return q, ps, fg, ref, cls
+    with torch.cuda.device(tokens.device):
+        code = _hip.lib().sdetr_encoder_prepare_sorted(_hip.stream_ptr(), *args)
     _hip.check(code, "encoder_prepare_sorted")
     return q, ps, fg, ref
 

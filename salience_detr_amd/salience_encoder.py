@@ -30,7 +30,7 @@ from .filter_ops import (advance_rows, layer_row_orders, attention_heads, attent
                          class_max_times, encoder_finalize, encoder_prepare_sorted, encoder_reference_points, fused_ffn,
                          fused_ffn_advance, fused_ffn_applies, fused_layer_norm, gather_rows, masked_topk_desc, scatter_rows_,
                          select_stack, token_linear_applies, token_linear_ln, topk_self_attention_, topk_select_inproj,
-                         topk_select_inproj_applies,
+                         topk_select_inproj_applies, prepare_class_score_applies,
                          topk_self_attention_applies)
 from .layer_norm_train import add_layer_norm
 from .linear_x3 import X3Linear, x3_ffn, x3_ffn_applies
@@ -540,9 +540,14 @@ class SalienceTransformerEncoder(nn.Module):
                     # channels with 4 levels, take the gather path below instead of the kernel's hard failure)
                     and value.shape[-1] * value.element_size() // 16 >= 2 * len(level_shapes)):
                 # query / position rows, foreground scores and reference points of the selected tokens: one launch
-                q, pos_s, fg_s, ref_s = encoder_prepare_sorted(value, ori_pos, foreground_score, sorted_index, valid_ratios,
-                                                               spatial_shapes, level_start_index)
+                # (... and the first layer's class score of those rows when the kernel covers the head)
+                head0 = self.enhance_mcsp if prepare_class_score_applies(value, foreground_score, self.enhance_mcsp) else None
+                prepared = encoder_prepare_sorted(value, ori_pos, foreground_score, sorted_index, valid_ratios,
+                                                  spatial_shapes, level_start_index, class_head=head0)
+                q, pos_s, fg_s, ref_s = prepared[:4]
+                score0 = prepared[4] if head0 is not None else None
             else:
+                score0 = None
                 if isinstance(foreground_score, LazyForegroundScore):
                     foreground_score = foreground_score.materialize()
                 q = gather_rows(value, sorted_index)
@@ -552,7 +557,7 @@ class SalienceTransformerEncoder(nn.Module):
                                                  index=sorted_index)
                 fg_s = torch.gather(foreground_score, 1, sorted_index)
             result = torch.empty_like(q)
-            score = None
+            score = score0
             # per-layer row orders for the deformable attention (tile-major walk of each layer's rows)
             orders, orders_job = None, None
             from .ms_deform_attn import is_bordered

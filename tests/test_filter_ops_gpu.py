@@ -696,6 +696,40 @@ def test_encoder_prepare_sorted_equals_its_four_parts(dtype):
     assert torch.equal(q2, q) and torch.equal(ps2, ps) and torch.equal(ref2, ref)
 
 
+@pytest.mark.parametrize("dtype,n", [(torch.bfloat16, 200), (torch.bfloat16, 3001), (torch.float16, 777)])
+def test_encoder_prepare_sorted_hands_on_the_first_layers_class_score(dtype, n):
+    """The entry gather with a class head: the four results bit for bit, plus class_head(rows).max(-1) * foreground rows
+    (salience_transformer.py:462, 366) -- against the fp32 statement and against the class head's own launch."""
+    B, C = 2, 256
+    shapes = [(100, 60), (50, 30), (25, 15), (13, 8)]
+    t_shapes = torch.tensor(shapes, dtype=torch.int64)
+    sizes = t_shapes.prod(1)
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    S = int(sizes.sum())
+    g = torch.Generator().manual_seed(n)
+    tokens = torch.randn(B, S, C, generator=g).to(dtype).to(DEV)
+    pos = torch.randn(B, S, C, generator=g).to(dtype).to(DEV)
+    score = torch.randn(B, S, generator=g).to(DEV)
+    index = torch.stack([torch.randperm(S, generator=g)[:n] for _ in range(B)]).to(DEV)
+    vr = (torch.rand(B, 4, 2, generator=g) * 0.4 + 0.6).to(DEV)
+    head = torch.nn.Linear(C, 91).to(DEV).to(dtype)
+    with torch.no_grad():
+        head.bias.copy_((torch.randn(91, generator=g) - 2.0).to(DEV))
+    mask = (torch.rand(B, S, generator=g) < 0.3).to(DEV)
+    mins = torch.tensor([0.5, -2.25, 1.0, -0.75], device=DEV)
+    for sc in (score, F.LazyForegroundScore(score, mask, mins)):
+        assert F.prepare_class_score_applies(tokens, sc, head)
+        q, ps, fg, ref = F.encoder_prepare_sorted(tokens, pos, sc, index, vr, t_shapes.to(DEV), lsi.to(DEV))
+        q2, ps2, fg2, ref2, cls = F.encoder_prepare_sorted(tokens, pos, sc, index, vr, t_shapes.to(DEV), lsi.to(DEV),
+                                                           class_head=head)
+        assert torch.equal(q, q2) and torch.equal(ps, ps2) and torch.equal(fg, fg2) and torch.equal(ref, ref2)
+        with torch.no_grad():
+            want = torch.nn.functional.linear(q.float(), head.weight.float(), head.bias.float()).max(-1)[0] * fg
+            own = F.class_head_max_times(q, head, fg)
+        bar = 2e-4 * (want.abs().max().item() + 1)
+        assert cls.shape == (B, n) and (cls - want).abs().max().item() <= bar and (cls - own).abs().max().item() <= bar
+
+
 @pytest.mark.parametrize("rows,next_rows,splits", [(300, 200, 4), (1200, 1200, 2), (1500, 0, 8), (700, 300, 1)])
 def test_fused_ffn_advance_equals_ffn_then_advance_rows(rows, next_rows, splits):
     """The end-of-layer operator (FFN + row bookkeeping in the reduce pass) against the two operators it replaces:
