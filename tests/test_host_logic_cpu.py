@@ -302,3 +302,37 @@ def test_cut_tie_canonicalisation_only_touches_ties():
     # a window that reaches beyond the image's valid count: untouched
     out2, changed2 = cut_ties.canonical_foreground_inds(views, [n_k + 1, n, n], rec)
     assert not changed2 and torch.equal(out2[0], build)
+
+
+def test_round6_launch_fusions_are_gated_by_shape_and_fail_loudly_without_a_gpu():
+    """filter_ops.topk_select_inproj / encoder_prepare_sorted(class_head=...) / the second pass's class score: the gates
+    decline shapes the kernels do not cover (the callers then take the separate launches), and the operators themselves
+    raise on CPU tensors -- no fallback."""
+    import pytest
+    from salience_detr_amd import filter_ops as F
+    mha = torch.nn.MultiheadAttention(256, 8, batch_first=True).to(torch.bfloat16)
+    norm = torch.nn.LayerNorm(256).to(torch.bfloat16)
+    head = torch.nn.Linear(256, 91).to(torch.bfloat16)
+    q = torch.zeros(2, 4000, 256, dtype=torch.bfloat16)
+    score = torch.zeros(2, 4000)
+    # CPU tensors: never
+    assert not F.topk_select_inproj_applies(score, 300, q, q, mha, norm)
+    with pytest.raises(RuntimeError):
+        F.topk_select_inproj(score, 300, q, q, mha)
+    with pytest.raises(RuntimeError):
+        F.encoder_prepare_sorted(q, q, score, torch.zeros(2, 10, dtype=torch.int64), torch.ones(2, 4, 2),
+                                 torch.ones(4, 2, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), class_head=head)
+    # the class-score gate of the entry gather looks at dtypes and shapes only
+    assert F.prepare_class_score_applies(q, score, head)
+    assert not F.prepare_class_score_applies(q.float(), score, head)                     # fp32 tokens: the class head's own launch
+    assert not F.prepare_class_score_applies(q, None, head)                              # no foreground score
+    assert not F.prepare_class_score_applies(q, score, torch.nn.Linear(256, 120).to(torch.bfloat16))   # > 96 classes
+    assert not F.prepare_class_score_applies(q, score, torch.nn.Linear(256, 91))         # head in another dtype
+    old = F.PREPARE_WITH_CLASS_SCORE
+    try:
+        F.PREPARE_WITH_CLASS_SCORE = False
+        assert not F.prepare_class_score_applies(q, score, head)
+    finally:
+        F.PREPARE_WITH_CLASS_SCORE = old
+    # the three switches exist and default to the fused forms
+    assert F.SPLIT_PASS_CLASS_SCORE and F.SELECT_WITH_INPROJECTION and F.PREPARE_WITH_CLASS_SCORE
