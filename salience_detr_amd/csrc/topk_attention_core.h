@@ -57,13 +57,14 @@ __device__ __forceinline__ int64_t tk_vt_index(int b, int head, int key, int ch,
 
 // one 32-feature x 32-token tile; QK = the tile holds q or k features (the position rows are added).  Straight-line
 // code per variant: with a branch inside, hipcc sinks the operand loads into the MFMA sequence (two in flight)
-// `bias4` / `bv`: the lane's four 8-byte bias pieces (stride 8 elements) are requested inside the SECOND half's MFMA chain,
-// once two of its k-steps' fragments are dead (they arrive under the remaining twelve MFMAs) -- requested up front they were
-// eight more live registers under 24 fragments, and the 1024-thread selection + in-projection launch (128 registers per
+// `bias4` / `bv`: the lane's four 8-byte bias pieces (stride 8 elements) are requested inside the LAST round's MFMA chain,
+// once some of its fragments are dead (they arrive under the remaining MFMAs) -- requested up front they were eight more
+// live registers under 24 fragments, and the 1024-thread selection + in-projection launch (topk.hip: 128 registers per
 // wave) spilled.
-// `R` = k-steps (of 16) whose fragments are in flight together: 8 (two rounds of 16 / 24 fragments; the stand-alone launch)
-// or 6 (rounds of 6, 6, 4: 18 fragments -- the 1024-thread selection + in-projection launch has 128 registers per wave, and
-// with 24 fragments it spilled: a kernel that needs scratch memory pays for it at every wave's dispatch).
+// `R` = k-steps (of 16) per round of operand requests: 8 = two rounds of 16 / 24 fragments (the stand-alone launch); 4 =
+// four rounds through TWO register sets, round r + 2 requested when round r's MFMAs are issued (the selection +
+// in-projection launch: 125 registers, no spill; one exposed trip to memory instead of two -- measured the same 7-8 us
+// as the two- and three-round forms: the in-projection behind a selection is not bound by how its operands are requested).
 template <bool QK, int R = 8>
 __device__ __forceinline__ tk_f32x16_t inproj_tile(const bf16_t *wr, const bf16_t *xr, const bf16_t *pr, const bf16_t *bias4,
                                                    uint2 (&bv)[4])
