@@ -974,12 +974,18 @@ int sdetr_topk_attention_with_projection_bf16(
  *   query / pos [batch, >= n, 256] 16-bit activations, images *_batch_stride elements apart; workspace of
  *   sdetr_topk_attention_workspace_bytes(batch, k) bytes and hint as sdetr_topk_attention_with_projection_bf16 takes
  *   them (call it with in_projection_done = 1 next); hint may be NULL.
- *   Shapes: 1024 <= n <= 17 408, 5 k <= 2 n, k <= 384.  job (may be NULL): as sdetr_masked_topk_desc_with_orders_f32. */
+ *   Shapes: 1024 <= n <= 17 408, 5 k <= 2 n, k <= 384 (longer rows: below).  job (may be NULL): as
+ *   sdetr_masked_topk_desc_with_orders_f32. */
 int sdetr_topk_select_inproj_bf16(sdetr_stream_t stream, const float *score, int batch_size, int n, int k,
                                   int64_t *out_index, const void *query, int64_t query_batch_stride, const void *pos,
                                   int64_t pos_batch_stride, const void *in_proj_weight, const void *in_proj_bias,
                                   void *workspace, int64_t workspace_bytes, int32_t *hint, int64_t hint_batch_stride,
-                                  const sdetr_row_orders_job *job);
+                                  const sdetr_row_orders_job *job, void *candidate_workspace, int64_t candidate_bytes);
+/* Rows of more than 17 408 scores (the reference's 5scale pyramid: up to 45 330 rows per layer) take one launch more: every
+ * slice of a row (<= 8192 keys, balanced) keeps its sorted top-k with the positions in the row, then the launch above selects
+ * among the slices x k candidates (ties still by position).  candidate_workspace: sdetr_topk_select_candidate_bytes(batch,
+ * n, k) bytes (0 = the row needs none, or the sliced form does not cover it: n / slices >= 1024 and >= 2.5 k per slice). */
+int64_t sdetr_topk_select_candidate_bytes(int batch_size, int n, int k);
 /* (internal: the in-projection launch of sdetr_topk_attention_bf16 for csrc/fused_head_value.hip) */
 int sdetr_topk_inproj_launch(sdetr_stream_t stream, const void *tk_in_args);
 

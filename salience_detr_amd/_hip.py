@@ -179,7 +179,8 @@ SIGNATURES = {
     "sdetr_gemm_x3_epilogue_f32": (_i, [_p, _p, _i64, _i, _p, _i64, _i, _p, _i64, _i, _i, _i, _p, _i, _p, _i, _p, _i64]),
     "sdetr_topk_attention_with_projection_bf16": (_i, [_p, _p, _i64, _p, _i64, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p,
                                                        ctypes.c_float, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _p, _i]),
-    "sdetr_topk_select_inproj_bf16": (_i, [_p, _p, _i, _i, _i, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p]),
+    "sdetr_topk_select_inproj_bf16": (_i, [_p, _p, _i, _i, _i, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _p, _i64, _p, _p, _i64]),
+    "sdetr_topk_select_candidate_bytes": (_i64, [_i, _i, _i]),
     "sdetr_topk_inproj_launch": (_i, [_p, _p]),
     "sdetr_ffn_fused_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float, _i, _i, _i, _p, _i, _p, _i64]),
     "sdetr_linear_packed_bytes": (_i64, [_i]),

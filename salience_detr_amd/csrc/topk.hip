@@ -702,6 +702,30 @@ __global__ void __launch_bounds__(kHsThreads) topk_hsort_inproj_kernel(SelectArg
     inproj_wave_body<4>(q, b, tile, ftile, lane, (int64_t)sel_lds[min(i, q.N - 1)]);
 }
 
+// Rows beyond one workgroup's histogram sort (round 6; the per-layer top-300 of the reference's 5scale pyramid: up to 45 330
+// rows): workgroup (b, s) keeps the sorted top-k of slice s of row b -- candidate scores and their positions IN THE ROW
+// (index_offset = the slice's start) -- and the selection of the slices x k candidates with the positions as payload follows
+// (topk_hsort_inproj_kernel or topk_hsort_kernel).  The row's top-k are among its slices' top-k, and ties stay in position
+// order: the slices are concatenated in row order and each is sorted ties-by-position, so equal scores keep ascending
+// positions in the candidate list, whose sort breaks ties by candidate position.  (filter_ops._sliced_topk is the same in
+// five framework launches around two of these kernels: padding fill + copy, slice sort, offset add, clamp, final sort.)
+template <int KPT>
+__global__ void __launch_bounds__(kHsThreads) topk_hsort_slices_kernel(SelectArgs p, int slices, int slice_len, float *cand_score,
+                                                                       int64_t *cand_pos)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hs_dyn[];
+    const int b = (int)blockIdx.x / slices, sl = (int)blockIdx.x - b * slices;
+    const int start = sl * slice_len;
+    SelectArgs q = p;
+    q.score = p.score + (int64_t)b * p.N + start;
+    q.N = min(slice_len, p.N - start);
+    q.index_offset = start;
+    q.out_score = cand_score + ((int64_t)b * slices + sl) * p.k;
+    q.out_index = cand_pos + ((int64_t)b * slices + sl) * p.k;
+    q.out_stride = p.k;
+    topk_hsort_body<KPT>(q, 0, hs_dyn);
+}
+
 static bool use_select(int n, int k)
 {
     // the shapes that used to take prefilter + rank (k well below n) and fit one workgroup: histogram sort in ONE launch
@@ -1030,28 +1054,86 @@ extern "C" int sdetr_masked_topk_sliced_with_rank_f32(sdetr_stream_t stream, con
     return rc;
 }
 
+// Slices of a long row for topk_hsort_slices_kernel: as few as cover the row with slices one workgroup sorts, but enough
+// candidates (slices x k) for the one-workgroup selection that follows; balanced lengths (every slice holds >= k keys).
+static bool select_slices(int n, int k, int *slices, int *slice_len)
+{
+    int s = (n + 8191) / 8192;
+    while (s * k < 1024) ++s;
+    const int len = (n + s - 1) / s;
+    *slices = s; *slice_len = len;
+    // every slice and the candidate row must be rows the histogram sort takes; the last slice is the shortest
+    const int last = n - (s - 1) * len;
+    return len <= kHsMaxN && last >= 1024 && (int64_t)k * 5 <= (int64_t)last * 2 && s * k <= kHsMaxN && k <= last;
+}
+
+extern "C" int64_t sdetr_topk_select_candidate_bytes(int batch_size, int n, int k)
+{
+    int slices = 0, slice_len = 0;
+    if (n <= kHsMaxN || batch_size <= 0 || k <= 0 || !select_slices(n, k, &slices, &slice_len)) return 0;
+    return (((int64_t)batch_size * slices * k * 4 + 15) & ~(int64_t)15) + (int64_t)batch_size * slices * k * 8;
+}
+
 // The layer's top-k selection (no mask, positions as indices) and the in-projection of the selected rows in ONE launch
 // (topk_hsort_inproj_kernel); sdetr_topk_attention_with_projection_bf16(..., in_projection_done = 1) follows.  Rows the
-// one-workgroup histogram sort covers only (1024 <= n <= 17 408, 5 k <= 2 n) with k <= 384; `job` as in
+// one-workgroup histogram sort covers (1024 <= n <= 17 408, 5 k <= 2 n) with k <= 384 -- and longer rows in TWO launches
+// (their slices' top-k first, topk_hsort_slices_kernel, into `candidate_workspace` of sdetr_topk_select_candidate_bytes
+// bytes; that query returns 0 for a row the one launch takes or the sliced form does not); `job` as in
 // sdetr_masked_topk_desc_with_orders_f32 (carried by the launch when its slots fit, launched behind it otherwise).
 extern "C" int sdetr_topk_select_inproj_bf16(sdetr_stream_t stream, const float *score, int batch_size, int n, int k,
                                              int64_t *out_index, const void *query, int64_t query_batch_stride,
                                              const void *pos, int64_t pos_batch_stride, const void *in_proj_weight,
                                              const void *in_proj_bias, void *workspace, int64_t workspace_bytes,
-                                             int32_t *hint, int64_t hint_batch_stride, const sdetr_row_orders_job *job)
+                                             int32_t *hint, int64_t hint_batch_stride, const sdetr_row_orders_job *job,
+                                             void *candidate_workspace, int64_t candidate_bytes)
 {
     if (batch_size <= 0 || n <= 0 || k <= 0 || k > n) return fail("topk_select_inproj: bad sizes (n %d, k %d)", n, k);
-    if (!use_select(n, k) || k > kTkMaxSel)
-        return fail("topk_select_inproj: rows of 1024..%d scores with 5 k <= 2 n and k <= %d (got n %d, k %d)", kHsMaxN, kTkMaxSel, n, k);
     if (!score || !out_index || !query || !pos || !in_proj_weight || !in_proj_bias || !workspace)
         return fail("topk_select_inproj: null pointer");
+    const int rows = n;                    // the layer's rows (strides, hint); n becomes the keys of the final selection
+    const float *sel_score = score;
+    const int64_t *sel_payload = nullptr;
+    if (n > kHsMaxN) {
+        // a long row: its slices' top-k first (one more launch), the selection below then runs on the candidates
+        int slices = 0, slice_len = 0;
+        if (!select_slices(n, k, &slices, &slice_len))
+            return fail("topk_select_inproj: rows of %d scores with k = %d are beyond the sliced form", n, k);
+        const int64_t need = sdetr_topk_select_candidate_bytes(batch_size, n, k);
+        if (!candidate_workspace || candidate_bytes < need)
+            return fail("topk_select_inproj: %lld bytes of candidate workspace needed", (long long)need);
+        float *cs = static_cast<float *>(candidate_workspace);
+        int64_t *cp = reinterpret_cast<int64_t *>(static_cast<char *>(candidate_workspace) +
+                                                  (((int64_t)batch_size * slices * k * 4 + 15) & ~(int64_t)15));
+        SelectArgs sa{};
+        sa.score = score; sa.N = n; sa.k = k;
+        const int schunk = (slice_len + kHsThreads - 1) / kHsThreads;
+        const size_t sdyn = ((size_t)(2 * kHsBins + 4) + (size_t)slice_len) * 4 + (((size_t)slice_len * 2 + 15) & ~(size_t)15);
+#define SDETR_HSS(KPT)                                                                                              \
+    do {                                                                                                            \
+        static DeviceOnce lds_once4;                                                                                \
+        allow_dynamic_lds(topk_hsort_slices_kernel<KPT>, lds_once4, 136 * 1024);                                    \
+        hipLaunchKernelGGL(topk_hsort_slices_kernel<KPT>, dim3((unsigned)(batch_size * slices)), dim3(kHsThreads), sdyn, \
+                           static_cast<hipStream_t>(stream), sa, slices, slice_len, cs, cp);                        \
+    } while (0)
+        if (schunk <= 3) SDETR_HSS(3);
+        else if (schunk <= 5) SDETR_HSS(5);
+        else if (schunk <= 7) SDETR_HSS(7);
+        else if (schunk <= 9) SDETR_HSS(9);
+        else if (schunk <= 12) SDETR_HSS(12);
+        else SDETR_HSS(17);
+#undef SDETR_HSS
+        if (int rc = check_launch("topk_select_slices")) return rc;
+        sel_score = cs; sel_payload = cp; n = slices * k;
+    }
+    if (!use_select(n, k) || k > kTkMaxSel)
+        return fail("topk_select_inproj: rows of 1024..%d scores with 5 k <= 2 n and k <= %d (got n %d, k %d)", kHsMaxN, kTkMaxSel, n, k);
     const int npad = (k + 31) / 32 * 32;
     if (workspace_bytes < (int64_t)batch_size * npad * (512 + 256) * 2) return fail("topk_select_inproj: workspace too small");
-    if (query_batch_stride < (int64_t)n * kTkE || pos_batch_stride < (int64_t)n * kTkE || (query_batch_stride & 7) || (pos_batch_stride & 7))
+    if (query_batch_stride < (int64_t)rows * kTkE || pos_batch_stride < (int64_t)rows * kTkE || (query_batch_stride & 7) || (pos_batch_stride & 7))
         return fail("topk_select_inproj: bad batch strides");
-    if (hint && hint_batch_stride < n) return fail("topk_select_inproj: hint rows shorter than the layer");
+    if (hint && hint_batch_stride < rows) return fail("topk_select_inproj: hint rows shorter than the layer");
     SelectArgs a{};
-    a.score = score; a.N = n; a.k = k; a.out_index = out_index; a.out_stride = k;
+    a.score = sel_score; a.payload = sel_payload; a.N = n; a.k = k; a.out_index = out_index; a.out_stride = k;
     TkInArgs q{};
     q.query = (const bf16_t *)query; q.q_bs = query_batch_stride; q.pos = (const bf16_t *)pos; q.p_bs = pos_batch_stride;
     q.sel = out_index; q.w = (const bf16_t *)in_proj_weight; q.bias = (const bf16_t *)in_proj_bias;

@@ -1952,14 +1952,18 @@ class SelectedInProjection:
 
 def topk_select_inproj_applies(score: Tensor, k: int, query: Tensor, pos: Tensor, mha, norm) -> bool:
     """Shapes ``sdetr_topk_select_inproj_bf16`` covers: a contiguous fp32 [B,n] score row per image for the one-workgroup
-    histogram sort (1024 <= n <= 17 408, 5 k <= 2 n), 289 <= k <= 320 (the attention launch that follows), the layer's
-    queries contiguous."""
+    histogram sort (1024 <= n <= 17 408, 5 k <= 2 n) or its sliced form (longer rows: one launch more), 289 <= k <= 320
+    (the attention launch that follows), the layer's queries contiguous."""
     if not SELECT_WITH_INPROJECTION or score.dim() != 2 or score.dtype != torch.float32 or not score.is_contiguous():
         return False
     B, n = score.shape
-    return (B > 0 and 1024 <= n <= 17408 and 5 * k <= 2 * n and 289 <= k <= 320 and query.is_contiguous()
-            and tuple(query.shape[:2]) == (B, n) and pos.shape[1] >= n
-            and topk_self_attention_applies(query, pos, mha, norm, k))
+    if not (B > 0 and 289 <= k <= 320 and query.is_contiguous() and tuple(query.shape[:2]) == (B, n) and pos.shape[1] >= n
+            and topk_self_attention_applies(query, pos, mha, norm, k)):
+        return False
+    if 1024 <= n <= 17408:
+        return 5 * k <= 2 * n
+    # longer rows: the sliced form (one launch more), where the library covers the shape
+    return n > 17408 and _hip.lib(query.dtype).sdetr_topk_select_candidate_bytes(B, n, k) > 0
 
 
 def topk_select_inproj(score: Tensor, k: int, query: Tensor, pos: Tensor, mha, orders_job=None) -> SelectedInProjection:
@@ -1974,12 +1978,14 @@ def topk_select_inproj(score: Tensor, k: int, query: Tensor, pos: Tensor, mha, o
     ws = torch.empty(lib.sdetr_topk_attention_workspace_bytes(B, k), dtype=torch.uint8, device=dev)
     hint = torch.empty((B, n), dtype=torch.int32, device=dev)   # (uninitialised on purpose, see topk_self_attention_)
     job = orders_job if orders_job is not None and not orders_job.done and orders_job.device == dev else None
+    cand_bytes = lib.sdetr_topk_select_candidate_bytes(B, n, k)      # (rows beyond one workgroup's sort: their slices' top-k)
+    cand = torch.empty(cand_bytes, dtype=torch.uint8, device=dev) if cand_bytes else None
     with torch.cuda.device(dev):
         code = lib.sdetr_topk_select_inproj_bf16(
             _hip.stream_ptr(), score.data_ptr(), B, n, k, sel.data_ptr(), query.data_ptr(),
             query.stride(0) if B > 1 else n * 256, pos.data_ptr(), pos.stride(0) if B > 1 else pos.shape[1] * 256,
             mha.in_proj_weight.data_ptr(), mha.in_proj_bias.data_ptr(), ws.data_ptr(), ws.numel(), hint.data_ptr(),
-            hint.stride(0), None if job is None else ctypes.byref(job.struct))
+            hint.stride(0), None if job is None else ctypes.byref(job.struct), _hip.ptr(cand), cand_bytes)
     _hip.check(code, "topk_select_inproj")
     if job is not None:
         job.done = True

@@ -43,7 +43,10 @@ def test_attention_carrying_the_projection_equals_the_two_operators(rows, N):
 
 
 @pytest.mark.parametrize("rows,N,ties", [(11363, 300, False), (9090, 300, True), (2272, 300, False), (1500, 289, False),
-                                        (4545, 320, True)])
+                                        (4545, 320, True),
+                                        # rows beyond one workgroup's sort (the 5scale pyramid's layers): slices first
+                                        (45330, 300, False), (36264, 300, True), (27198, 300, False), (18132, 300, True),
+                                        (17409, 320, True)])
 def test_selection_launch_with_the_in_projection_equals_the_two_launches(rows, N, ties):
     """csrc/topk.hip topk_hsort_inproj_kernel: the layer's top-k selection and the in-projection of the selected rows in ONE
     launch (every workgroup of an image repeats the selection) -- the same selection as masked_topk_desc (ties by position
