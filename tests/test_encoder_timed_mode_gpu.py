@@ -237,3 +237,44 @@ def test_timed_mode_is_no_farther_from_fp32_than_the_reference_autocast(tag, ima
     # the two runs): 1.3-1.55x, held to 1.75x; the mean -- every token's own rounding -- to the 1.5x asked for.
     assert h[1] <= 1.5 * f16_stats[1] + 2e-5 and h[2] <= 1.75 * f16_stats[2] + 2e-4
     assert sum(h_flips) <= 1.5 * sum(f16_flips) + 30
+
+
+@pytest.mark.parametrize("levels", ["benchmark", "5scale"])
+def test_selection_with_the_in_projection_leaves_the_step_bit_identical(levels):
+    """Round 6: the layer's top-300 selection + in-projection in one launch (two for the 5scale pyramid's long rows) against
+    the separate launches -- the same selection (ties by position) and the same in-projection arithmetic, so the whole bf16
+    step's output is bit-identical with the switch on and off; and the step does take the fused launches when it is on."""
+    from salience_detr_amd import filter_ops as F
+    stress = levels == "5scale"
+    sizes = [(800, 1333)] if stress else [(800, 1333), (800, 1066)]
+    level_shapes = [(200, 336), (100, 168), (50, 84), (25, 42)] if stress else None
+    m = build_hot_path(max_num_embedding=500 if stress else 200)
+    m.load_state_dict(syn.det_state_dict(m.state_dict()))
+    _, masks = syn.make_masks(sizes, level_shapes)
+    shapes = [tuple(x.shape[-2:]) for x in masks]
+    feats = [f.to(DEV) for f in syn.make_feats(len(sizes), shapes, 256, seed=0)]
+    pos = [syn.sine_position_embedding(x, 128).to(DEV) for x in masks]
+    masks = [x.to(DEV) for x in masks]
+    m = m.to(DEV).eval()
+    m.set_encoder_dtype(torch.bfloat16, torch.float16)
+    calls = {"n": 0}
+    real = F.topk_select_inproj
+
+    def counting(*a, **kw):
+        calls["n"] += 1
+        return real(*a, **kw)
+
+    import salience_detr_amd.salience_encoder as SE
+    old_switch, old_fn = F.SELECT_WITH_INPROJECTION, SE.topk_select_inproj
+    try:
+        SE.topk_select_inproj = counting
+        with torch.no_grad():
+            F.SELECT_WITH_INPROJECTION = True
+            fused, _ = m(feats, masks, pos)
+            taken = calls["n"]
+            F.SELECT_WITH_INPROJECTION = False
+            separate, _ = m(feats, masks, pos)
+    finally:
+        F.SELECT_WITH_INPROJECTION, SE.topk_select_inproj = old_switch, old_fn
+    assert taken == 6 and calls["n"] == 6          # every layer took the fused launch, none with the switch off
+    assert torch.equal(fused, separate)
