@@ -262,7 +262,12 @@ __global__ void __launch_bounds__(kFThreads, 1) ffn_fused_kernel(FfnArgs p)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the staged vectors; the loaders bring chunks 0..2
     __builtin_amdgcn_s_barrier();
 
-    constexpr int R = 4;
+#ifndef SDETR_FFN_RING
+#define SDETR_FFN_RING 4   // (benchmarks/lib_variant.sh ... -DSDETR_FFN_RING=5 | 6: 72-156 bytes of scratch per lane and the
+                           // same launch times, 78.5 / 71.9 / 47.2 -> 78.3 / 71.6 / 47.0 (5) and 80.0 / 72.2 / 47.1 (6) us on
+                           // one box, round 6 -- the ring's depth is not what the loop waits for)
+#endif
+    constexpr int R = SDETR_FFN_RING;
     uint4 ring[R];
     const lds_cptr_t lbase = (lds_cptr_t)wbuf + lane * 16;
     auto chunk_lds = [&](int c) { return lbase + (c & 3) * kFChunkBytes; };   // c = STREAM chunk
