@@ -98,3 +98,31 @@ def test_selection_launch_with_the_in_projection_carries_the_row_orders():
     for a, c in zip(job.orders, want_orders):
         assert torch.equal(a, c)
     assert torch.equal(both.selected, F.masked_topk_desc(score, N, want_scores=False)[1])
+
+
+def test_selection_launch_random_row_lengths_against_a_stable_sort():
+    """Row lengths across both forms (one launch up to 17 408 keys, slices beyond), every admissible k, batch 1-3: wherever
+    the gate accepts the shape the selection equals torch's stable descending sort (ties by position); what it declines is
+    exactly what the library's own query declines."""
+    g = torch.Generator().manual_seed(20260)
+    mha = torch.nn.MultiheadAttention(256, 8, batch_first=True).to(DEV).to(torch.bfloat16)
+    norm = torch.nn.LayerNorm(256).to(DEV).to(torch.bfloat16)
+    took = declined = 0
+    lengths = [1024, 1500, 17408, 17409, 17500, 20000, 24577, 32768, 40001, 65536, 90000] + \
+        [int(v) for v in torch.randint(1024, 70000, (14,), generator=g)]
+    for n in lengths:
+        B = int(torch.randint(1, 4, (1,), generator=g))
+        k = int(torch.randint(289, 321, (1,), generator=g))
+        score = torch.randn(B, n, generator=g)
+        score = ((score * 64).round() / 64).to(DEV)              # plenty of exact ties
+        q = torch.zeros(B, n, 256, dtype=torch.bfloat16, device=DEV)
+        if not F.topk_select_inproj_applies(score, k, q, q, mha, norm):
+            declined += 1
+            assert n < 1024 or 5 * k > 2 * n or (n > 17408 and F._hip.lib().sdetr_topk_select_candidate_bytes(B, n, k) == 0)
+            continue
+        took += 1
+        with torch.no_grad():
+            both = F.topk_select_inproj(score, k, q, q, mha)
+        ref = torch.sort(score, dim=1, descending=True, stable=True)[1][:, :k]
+        assert torch.equal(both.selected, ref), (n, k, B)
+    assert took >= 20
