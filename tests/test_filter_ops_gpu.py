@@ -696,7 +696,8 @@ def test_encoder_prepare_sorted_equals_its_four_parts(dtype):
     assert torch.equal(q2, q) and torch.equal(ps2, ps) and torch.equal(ref2, ref)
 
 
-@pytest.mark.parametrize("dtype,n", [(torch.bfloat16, 200), (torch.bfloat16, 3001), (torch.float16, 777)])
+@pytest.mark.parametrize("dtype,n", [(torch.bfloat16, 200), (torch.bfloat16, 3001), (torch.float16, 777), (torch.bfloat16, 1),
+                                     (torch.bfloat16, 33)])
 def test_encoder_prepare_sorted_hands_on_the_first_layers_class_score(dtype, n):
     """The entry gather with a class head: the four results bit for bit, plus class_head(rows).max(-1) * foreground rows
     (salience_transformer.py:462, 366) -- against the fp32 statement and against the class head's own launch."""
@@ -813,7 +814,8 @@ def test_attn_tail_ffn_advance_equals_the_two_launches(rows, next_rows, splits, 
             assert torch.equal(got_next[b, n_live:], want_next[b, n_live:])     # original tokens, copied
 
 
-@pytest.mark.parametrize("rows,next_rows,hidden", [(700, 300, 512), (1111, 900, 2048), (640, 640, 512), (1300, 1, 512)])
+@pytest.mark.parametrize("rows,next_rows,hidden", [(700, 300, 512), (1111, 900, 2048), (640, 640, 512), (1300, 1, 512),
+                                                   (1025, 33, 512)])
 def test_layer_end_hands_on_the_next_layers_class_score(rows, next_rows, hidden):
     """The layer-end launch (one hidden piece: its epilogue; more: the second pass) also does the row bookkeeping and returns
     the NEXT layer's selection score of the rows it hands on (salience_transformer.py:462, 366) -- against the separate launches:
